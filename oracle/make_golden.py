@@ -1,0 +1,201 @@
+"""TEST INFRASTRUCTURE. Generates tests/golden/*.npz by running the UNMODIFIED reference files
+(/root/reference/sherf/training/volumetric_rendering/renderer.py, ray_marcher.py, ray_sampler.py,
+triplane.py::NeRFDecoder / prepare_sp_input) on CPU in the build container, through the stand-in
+packages in oracle/ref_shims (pytorch3d K-NN, spconv, torchvision, imageio) and three monkeypatches
+(no GPU here; SMPL pickle replaced by the synthetic SMPL of oracle/synth.py).
+
+    python -m oracle.make_golden [tiny tiny_nv cfg1]
+
+Inputs and weights are regenerated from seeds by oracle/fixtures.py, so the files hold OUTPUTS only.
+/root/reference does not exist on the GPU box: nothing at test time imports this module.
+"""
+import os
+import sys
+import time
+import types
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/sherf'
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(HERE, 'ref_shims'))
+    sys.path.insert(0, REF)
+    torch.cuda.current_device = lambda: 0
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from training.volumetric_rendering import renderer as R
+    from oracle import synth
+    orig = R.SMPL_to_tensor
+    R.SMPL_to_tensor = lambda params, device: orig(params, torch.device('cpu'))
+    R.read_pickle = lambda path: synth.make_synth_smpl(0)
+    import training.triplane as T
+    T.SMPL_to_tensor = R.SMPL_to_tensor
+    T.read_pickle = R.read_pickle
+    return R, T
+
+
+def run(cfg_name, R, T, out_dir):
+    from oracle import fixtures
+    fx = fixtures.renderer_inputs(cfg_name)
+    c = fx['cfg']
+    torch.manual_seed(0)
+    rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
+    dec = T.NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.')
+    fixtures.load_seeded_state(dec, 'decoder.')
+    rend.train(); dec.train()        # the reference never calls .eval() before test (training_loop.py:193,321)
+
+    d = fixtures.to_torch(fx['input_data'])
+    planes = torch.from_numpy(fx['planes'])
+    obs_img = d['obs_img_all'][:, 0]
+    obs_feat = torch.from_numpy(fx['obs_feat'])
+    vfeat = torch.from_numpy(fx['vertex_feat'])
+
+    cap = {}
+    # --- a17 glue done with the reference's own functions (triplane.py:129-137) ---
+    smpl_obs_pts = torch.matmul(d['obs_vertices'] - d['obs_params']['Th'], d['obs_params']['R'])
+    obs_can = rend.coarse_deform_target2c(d['obs_params'], d['obs_vertices'], d['t_params'], smpl_obs_pts)
+    sp_input, _ = T.TriPlaneGenerator.prepare_sp_input(types.SimpleNamespace(), d['t_vertices'].clone(), obs_can)
+    import spconv.pytorch as spconv
+    sp = spconv.core.SparseConvTensor(vfeat, sp_input['coord'], sp_input['out_sh'], sp_input['batch_size'])
+    cap['obs_vertex_canonical'] = obs_can[0].numpy()
+    cap['sp_coord'] = sp_input['coord'].numpy()
+    cap['sp_out_sh'] = np.asarray(sp_input['out_sh'])
+    cap['sp_bounds'] = sp_input['bounds'].numpy()
+
+    # --- capture intermediates of the unmodified forward by wrapping bound methods ---
+    knn_calls = []
+    orig_knn = R.knn_points
+
+    def knn_rec(a, b, K=1):
+        out = orig_knn(a, b, K=K)
+        knn_calls.append((out[0].clone(), out[1].clone()))
+        return out
+    R.knn_points = knn_rec
+
+    def wrap(obj, name, key, pick):
+        f = getattr(obj, name)
+
+        def g(*a, **k):
+            out = f(*a, **k)
+            cap.setdefault(key, []).append(pick(out, a, k))
+            return out
+        setattr(obj, name, g)
+
+    wrap(rend, 'coarse_deform_target2c', 't2c', lambda o, a, k: [x.clone() for x in (o if isinstance(o, tuple) else (o,))])
+    wrap(rend, 'coarse_deform_c2source', 'c2s', lambda o, a, k: o[1].clone())
+    wrap(rend, 'projection', 'uv', lambda o, a, k: o.clone())
+    wrap(rend, 'run_model', 'run', lambda o, a, k: dict(rgb=o['rgb'].clone(), sigma=o['sigma'].clone(), f2d=a[1].clone(), f3d=a[2].clone()))
+    wrap(rend, 'get_grid_coords', 'grid', lambda o, a, k: o.clone())
+    enc_fwd = rend.encoder_3d.forward
+
+    def enc_rec(x, g):
+        out = enc_fwd(x, g)
+        cap['f3d_raw'] = out.clone()
+        return out
+    rend.encoder_3d.forward = enc_rec
+    tr_fwd = rend.transformer.forward
+
+    def tr_rec(x):
+        out = tr_fwd(x)
+        cap['tokens_in'] = x.clone(); cap['tokens_out'] = out.clone()
+        return out
+    rend.transformer.forward = tr_rec
+    rm = rend.ray_marcher.run_forward
+
+    def rm_rec(*a):
+        out = rm(*a)
+        cap['weights'] = out[2].clone()
+        return out
+    rend.ray_marcher.run_forward = rm_rec
+
+    t0 = time.time()
+    with torch.no_grad():
+        rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec,
+                               d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0],
+                               d, fx['options'])
+    dt = time.time() - t0
+    R.knn_points = orig_knn
+
+    dist1, idx1 = knn_calls[0]
+    mask = (dist1.view(-1) < 0.05 ** 2)
+    valid = torch.nonzero(mask)[:, 0]
+    out = dict(
+        rgb=rgb[0].numpy(), depth=depth[0].numpy(), acc=acc[0].numpy(),
+        mask_bits=np.packbits(mask.numpy().astype(np.uint8)),
+        n_samples=np.int64(mask.numel()), n_valid=np.int64(valid.numel()),
+        sample_rgb=cap['run'][0]['rgb'][0].numpy(), sample_sigma=cap['run'][0]['sigma'][0, :, 0].numpy(),
+        vert_id=idx1.view(-1)[valid].numpy().astype(np.int32),
+        vert_d2=dist1.view(-1)[valid].numpy(),
+        ref_cpu_seconds=np.float64(dt),
+        sp_coord=cap['sp_coord'], sp_out_sh=cap['sp_out_sh'], sp_bounds=cap['sp_bounds'],
+    )
+    if c['H'] * c['W'] * c['S'] <= 64 * 64 * 32:   # full per-stage intermediates only for the tiny configs
+        out.update(
+            x_c=cap['t2c'][0][0][0].numpy(), v_c=cap['t2c'][0][1][0].numpy(),
+            t_vert_id=knn_calls[2][1].view(-1).numpy().astype(np.int32),
+            x_w=cap['c2s'][0][0].numpy(), uv=cap['uv'][0].reshape(-1, 2).numpy(),
+            f2d=cap['run'][0]['f2d'][0].numpy(), f3d=cap['run'][0]['f3d'][0].numpy(),
+            f3d_raw=cap['f3d_raw'][0].numpy(), grid=cap['grid'][0].reshape(-1, 3).numpy(),
+            tokens_in=cap['tokens_in'].numpy(), tokens_out=cap['tokens_out'].numpy(),
+            weights=cap['weights'][0, :, :, 0].numpy(),
+            obs_vertex_canonical=cap['obs_vertex_canonical'],
+        )
+    path = os.path.join(out_dir, f'renderer_{cfg_name}.npz')
+    np.savez_compressed(path, **out)
+    print(f'{cfg_name}: R={rgb.shape[1]} Nv={valid.numel()}/{mask.numel()} ({valid.numel()/mask.numel():.3%}) '
+          f'ref forward {dt:.2f}s  rgb range [{rgb.min():.3f},{rgb.max():.3f}] acc max {acc.max():.3f} -> {path} '
+          f'({os.path.getsize(path)/1e6:.2f} MB)')
+
+
+def run_small_units(R, T, out_dir):
+    """Golden vectors for the standalone API pieces: RaySampler, MipRayMarcher2, PositionalEncoding, linspace."""
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    from training.volumetric_rendering.ray_marcher import MipRayMarcher2
+    from training.volumetric_rendering import math_utils
+    rs = np.random.RandomState(7)
+    out = {}
+    # RaySampler (ray_sampler.py:24-61)
+    c2w = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+    from scipy.spatial.transform import Rotation
+    c2w[:, :3, :3] = Rotation.from_rotvec(rs.normal(0, 0.5, (2, 3))).as_matrix()
+    c2w[:, :3, 3] = rs.normal(0, 1, (2, 3))
+    intr = np.tile(np.array([[1.2, 0.03, 0.5], [0, 1.1, 0.52], [0, 0, 1]], np.float32), (2, 1, 1))
+    o, dd = RaySampler()(torch.from_numpy(c2w), torch.from_numpy(intr), 8)
+    out.update(rs_c2w=c2w, rs_intr=intr, rs_origins=o.numpy(), rs_dirs=dd.numpy())
+    # MipRayMarcher2 (ray_marcher.py:25-64), incl. sigma=-80 fill, white_back, all-empty ray (NaN depth path)
+    Rr, S = 37, 13
+    colors = rs.uniform(0, 1, (1, Rr, S, 3)).astype(np.float32)
+    dens = (rs.normal(0, 20, (1, Rr, S, 1))).astype(np.float32)
+    dens[0, :5] = -80.0
+    near = rs.uniform(1, 2, (1, Rr, 1, 1)).astype(np.float32); far = near + rs.uniform(0.5, 2, (1, Rr, 1, 1)).astype(np.float32)
+    depths = near + np.linspace(0, 1, S, dtype=np.float32).reshape(1, 1, S, 1) * (far - near)
+    rd = rs.normal(0, 1, (1, Rr, 3)).astype(np.float32)
+    for wb in (False, True):
+        rgb, dep, w = MipRayMarcher2()(torch.from_numpy(colors), torch.from_numpy(dens), torch.from_numpy(depths),
+                                       torch.from_numpy(rd), dict(clamp_mode='relu', white_back=wb))
+        out.update({f'mrm_rgb_{int(wb)}': rgb.numpy(), f'mrm_depth_{int(wb)}': dep.numpy(), f'mrm_w_{int(wb)}': w.numpy()})
+    out.update(mrm_colors=colors, mrm_dens=dens, mrm_depths=depths, mrm_rd=rd)
+    # PositionalEncoding (renderer.py:875-916) and linspace (math_utils.py:101-118)
+    x = rs.normal(0, 1, (11, 3)).astype(np.float32)
+    for F_ in (4, 5, 6):
+        out[f'pe_{F_}'] = R.PositionalEncoding(num_freqs=F_)(torch.from_numpy(x)).numpy()
+    out['pe_x'] = x
+    a = rs.uniform(0, 2, (1, 9, 1)).astype(np.float32); b = a + rs.uniform(0, 3, (1, 9, 1)).astype(np.float32)
+    out['ls_a'] = a; out['ls_b'] = b
+    out['ls_out'] = math_utils.linspace(torch.from_numpy(a), torch.from_numpy(b), 17).numpy()
+    path = os.path.join(out_dir, 'units.npz')
+    np.savez_compressed(path, **out)
+    print('units ->', path)
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or ['tiny', 'tiny_nv', 'cfg1']
+    out_dir = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+    os.makedirs(out_dir, exist_ok=True)
+    R, T = import_reference()
+    run_small_units(R, T, out_dir)
+    for n in names:
+        run(n, R, T, out_dir)

@@ -1,0 +1,142 @@
+"""Pins oracle/sherf_oracle.py (the CPU restatement) against golden vectors produced by running the
+UNMODIFIED reference files (oracle/make_golden.py) on the same seeded inputs. CPU only."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures, sherf_oracle as O
+
+
+def _state(golden_dir):
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    st = {}
+    for name, shp in shapes.items():
+        v = fixtures.seeded_param(name, shp)
+        if v is not None:
+            st[name] = torch.from_numpy(v)
+    return st
+
+
+@pytest.fixture(scope='module')
+def state(golden_dir):
+    return _state(golden_dir)
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a); b = torch.as_tensor(b)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize('cfg', ['tiny', 'tiny_nv'])
+def test_every_stage_matches_reference(cfg, state, golden_dir):
+    g = np.load(os.path.join(golden_dir, f'renderer_{cfg}.npz'))
+    fx = fixtures.renderer_inputs(cfg)
+    r = O.render_from_fixture(fx, state, training=True)
+    # a17 glue: canonicalised obs vertices, voxel coords, out_sh, bounds
+    assert _rel(r['obs_vertex_canonical'], g['obs_vertex_canonical']) < 1e-5
+    assert list(r['sp_input']['out_sh']) == list(g['sp_out_sh'])
+    assert _rel(r['sp_input']['bounds'], g['sp_bounds'][0]) < 1e-6
+    dc = (r['sp_input']['coord'].numpy() != g['sp_coord']).any(1).mean()
+    assert dc < 2e-3, dc                      # round() of a value that differs in the last ulp may flip
+    # mask + nearest vertex: bit exact
+    mask = np.unpackbits(g['mask_bits'])[:int(g['n_samples'])].astype(bool)
+    assert (r['mask'].numpy() == mask).all()
+    assert (r['vert_id'].numpy() == g['vert_id']).all()
+    assert np.array_equal(r['vert_d2'].numpy(), g['vert_d2'])
+    assert (r['t_vert_id'].numpy() == g['t_vert_id']).all()
+    for k, tol in (('x_c', 1e-5), ('v_c', 1e-5), ('x_w', 1e-5), ('uv', 1e-5), ('f2d', 5e-5), ('grid', 1e-5),
+                   ('f3d_raw', 2e-4), ('f3d', 2e-4), ('sample_rgb', 1e-4), ('sample_sigma', 2e-4), ('weights', 1e-4)):
+        assert _rel(r[k], g[k]) < tol, (k, _rel(r[k], g[k]))
+    n = r['tokens_in'].shape[0]
+    assert _rel(r['tokens_in'], g['tokens_in'].reshape(n, 3, 32)) < 1e-4
+    assert _rel(r['tokens_out'], g['tokens_out'].reshape(n, 3, 32)) < 1e-4
+    assert _rel(r['rgb'], g['rgb']) < 1e-4
+    assert _rel(r['acc'], g['acc'][:, 0]) < 1e-4
+    assert torch.allclose(r['depth'], torch.from_numpy(g['depth'][:, 0]), rtol=1e-4, atol=1e-5)
+
+
+def test_cfg1_final_image_matches_reference(state, golden_dir):
+    """BASELINE config 1 (128x128 rays x 32 samples): final outputs + per-sample sigma/rgb + PSNR."""
+    g = np.load(os.path.join(golden_dir, 'renderer_cfg1.npz'))
+    fx = fixtures.renderer_inputs('cfg1')
+    r = O.render_from_fixture(fx, state, training=True, keep=True)
+    mask = np.unpackbits(g['mask_bits'])[:int(g['n_samples'])].astype(bool)
+    assert (r['mask'].numpy() == mask).all()
+    assert (r['vert_id'].numpy() == g['vert_id']).all()
+    assert _rel(r['sample_sigma'], g['sample_sigma']) < 5e-4
+    assert _rel(r['sample_rgb'], g['sample_rgb']) < 2e-4
+    assert _rel(r['rgb'], g['rgb']) < 2e-4
+    assert O.psnr(r['rgb'], torch.from_numpy(g['rgb'])) > 70.0
+
+
+def test_units_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'units.npz'))
+    t = torch.from_numpy
+    o, d = O.ray_sampler(t(g['rs_c2w']), t(g['rs_intr']), 8)
+    assert torch.allclose(o, t(g['rs_origins']), atol=1e-6) and torch.allclose(d, t(g['rs_dirs']), atol=1e-6)
+    for F_ in (4, 5, 6):
+        assert torch.allclose(O.positional_encoding(t(g['pe_x']), F_), t(g[f'pe_{F_}']), atol=1e-6)
+    ls = O.depths(t(g['ls_a'])[0, :, 0], t(g['ls_b'])[0, :, 0], 17)                 # [9,17]
+    assert torch.equal(ls, t(g['ls_out'])[:, 0, :, 0].t())
+    for wb in (0, 1):
+        rgb, dep, w = O.composite(t(g['mrm_colors'])[0], t(g['mrm_dens'])[0, :, :, 0], t(g['mrm_depths'])[0, :, :, 0],
+                                  t(g['mrm_rd'])[0], white_back=bool(wb))
+        assert torch.allclose(rgb, t(g[f'mrm_rgb_{wb}'])[0], atol=1e-6)
+        assert torch.allclose(w, t(g[f'mrm_w_{wb}'])[0, :, :, 0], atol=1e-7)
+        assert torch.allclose(dep, t(g[f'mrm_depth_{wb}'])[0, :, 0], atol=1e-5)
+
+
+def test_sparse_encoder_vs_dense_conv_with_duplicates():
+    """Independent formulation: dense conv3d on a <=32^3 grid, rows sharing a voxel sum (oracle docstring)."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(3)
+    sh = [32, 32, 32]
+    N = 300
+    coord = torch.from_numpy(np.concatenate([np.zeros((N, 1)), rs.randint(8, 24, (N, 3))], 1).astype(np.int32))
+    coord[5] = coord[4]; coord[17] = coord[4]; coord[100] = coord[99]            # duplicates
+    feat = torch.from_numpy(rs.standard_normal((N, 32)).astype(np.float32))
+    shapes = {}
+    for name, cin, cout, n in (('conv0', 32, 32, 2), ('down0', 32, 32, 1), ('conv1', 32, 32, 2), ('down1', 32, 64, 1),
+                               ('conv2', 64, 64, 3), ('down2', 64, 96, 1), ('conv3', 96, 96, 3)):
+        for i in range(n):
+            ci = cin if i == 0 else cout
+            shapes[f'renderer.encoder_3d.{name}.{3 * i}.weight'] = [cout, 3, 3, 3, ci]
+            for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+                shapes[f'renderer.encoder_3d.{name}.{3 * i + 1}.{leaf}'] = [cout]
+    st = {k: torch.from_numpy(fixtures.seeded_param(k, v)) for k, v in shapes.items()}
+    taps = O.sparse_encoder(st, feat, coord, sh, training=False)      # eval-mode BN: row statistics don't enter
+    # dense reference (eval BN). Row semantics: per-voxel value = sum over rows in that voxel.
+    c = coord.long()
+    cnt = torch.zeros(sh); cnt.index_put_((c[:, 1], c[:, 2], c[:, 3]), torch.ones(N), accumulate=True)
+    dense = torch.zeros(*sh, 32); dense.index_put_((c[:, 1], c[:, 2], c[:, 3]), feat, accumulate=True)
+    dense = dense.permute(3, 0, 1, 2)[None].contiguous()
+    act = (cnt > 0).float()[None, None]
+
+    def bn_relu(x, pre):
+        s = lambda k: st[pre + k].view(1, -1, 1, 1, 1)
+        return torch.relu((x - s('.running_mean')) / torch.sqrt(s('.running_var') + 1e-3) * s('.weight') + s('.bias'))
+    x, m, mult = dense, act, cnt[None, None]
+    level_out = []
+    for name, kind, n in (('conv0', 's', 2), ('down0', 'd', 1), ('conv1', 's', 2), ('TAP', 0, 0), ('down1', 'd', 1),
+                          ('conv2', 's', 3), ('TAP', 0, 0), ('down2', 'd', 1), ('conv3', 's', 3), ('TAP', 0, 0)):
+        if name == 'TAP':
+            level_out.append((x, m)); continue
+        for i in range(n):
+            W = st[f'renderer.encoder_3d.{name}.{3 * i}.weight'].permute(0, 4, 1, 2, 3)
+            pre = f'renderer.encoder_3d.{name}.{3 * i + 1}'
+            if kind == 's':
+                raw = F.conv3d(x, W, padding=1) * m
+                v0 = bn_relu(torch.zeros(1, W.shape[0], 1, 1, 1), pre)
+                x = (bn_relu(raw, pre) + (mult - 1).clamp(min=0) * v0) * m
+            else:
+                raw = F.conv3d(x, W, stride=2, padding=1)
+                m = (F.conv3d(m, torch.ones(1, 1, 3, 3, 3), stride=2, padding=1) > 0).float()
+                mult = m.clone()
+                x = bn_relu(raw, pre) * m
+    for (keys, feats, shp), (xd, md) in zip(taps, level_out):
+        D, H, W_ = shp
+        got = torch.zeros(feats.shape[1], D * H * W_); got[:, keys] = feats.t()
+        assert int(md.sum()) == keys.numel()
+        assert torch.allclose(got.view(1, -1, D, H, W_), xd, atol=2e-4, rtol=1e-4)
