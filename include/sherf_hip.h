@@ -1,0 +1,182 @@
+/* sherf_hip.h -- C ABI of libsherf_hip.so: the MI355X (gfx950) implementation of SHERF's volumetric
+ * rendering hot path.
+ *
+ * The reference has no FFI around this path (it is PyTorch eager code + two CUDA libraries); the
+ * drop-in boundary is its Python class API (ImportanceRenderer / MipRayMarcher2 / RaySampler /
+ * TriPlaneGenerator).  `sherf_amd/` mirrors those classes and calls the entry points below through
+ * ctypes, the way the reference's own native ops are reached through
+ * sherf/torch_utils/custom_ops.py:61 (get_plugin) + sherf/torch_utils/ops/bias_act.py:40-88.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`;
+ *   - the callee never allocates persistent memory, never synchronises, launches on `stream`;
+ *   - returns 0 on success, a negative SHERF_E* code on bad arguments / launch failure
+ *     (the Python wrapper raises RuntimeError, like TORCH_CHECK in bias_act.cpp:39-55);
+ *   - fp32 unless stated; B == 1 (the reference forces a per-GPU batch of one, renderer.py:320-321).
+ * Reference citations are relative to /root/reference/sherf/.
+ */
+#ifndef SHERF_HIP_H
+#define SHERF_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sherf_stream_t; /* hipStream_t */
+
+#define SHERF_OK 0
+#define SHERF_EINVAL (-1)
+#define SHERF_ELAUNCH (-2)
+
+#define SHERF_V 6890     /* SMPL vertices (renderer.py:584 hard-codes 6890*3) */
+#define SHERF_NJ 24
+#define SHERF_MAX_CELLS (64 * 64 * 64)
+
+int sherf_version(void);
+const char* sherf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a7: SMPL bone transforms.  Replaces get_transform_params_torch + batch_rodrigues_torch +
+ * get_rigid_transformation_torch (training/volumetric_rendering/renderer.py:129-157, 76-94, 96-126).
+ *   poses[n_sets][72], shapes[n_sets][10]; J_template[24][3] = J_regressor @ v_template,
+ *   J_shapedirs[24][3][10] = J_regressor @ shapedirs (constants of the SMPL asset);
+ *   parents[24] int32.  Out: A[n_sets][24][12] (rows of the 3x4 rigid transform, rest pose removed)
+ *   and posefeat[n_sets][207] = vec(R_1..23 - I) (renderer.py:582-583).
+ */
+int sherf_smpl_bones(const float* poses, const float* shapes, int n_sets, const float* J_template,
+                     const float* J_shapedirs, const int32_t* parents, float* A, float* posefeat,
+                     sherf_stream_t stream);
+
+/* Per-vertex pose/shape blend offsets (renderer.py:578-593, 646-670):
+ *   PO[n_sets][V][3] = posedirs[V*3][207] @ posefeat[set],  SO[n_sets][V][3] = shapedirs[V][3][10] @ shapes[set]. */
+int sherf_smpl_offsets(const float* posedirs, const float* shapedirs, const float* posefeat,
+                       const float* shapes, int n_sets, float* PO, float* SO, sherf_stream_t stream);
+
+/* a8 collapsed: coarse_deform_target2c (renderer.py:558-621) depends on the query point only through its
+ * nearest posed vertex j, so x_c = P[j] x_s + q[j], v_c = P[j] v_s.  T2C[V][12] = (P row-major 9, q 3).
+ *   A_tgt/A_big [24][12]; PO_tgt, SO_tgt, PO_big [V][3]; weights [V][24]. */
+int sherf_smpl_t2c_table(const float* weights, const float* A_tgt, const float* A_big, const float* PO_tgt,
+                         const float* SO_tgt, const float* PO_big, float* T2C, sherf_stream_t stream);
+
+/* a9+a10 collapsed: coarse_deform_c2source (renderer.py:623-684) + projection (:686-704) keyed by the
+ * nearest T-pose vertex k: h = L[k] x_c + l[k] with uv = h.xy / (h.z + 1e-5).  C2S[V][12] = (L 9, l 3).
+ *   R_obs[9], Th_obs[3] = obs_params R/Th; cam_R[9], cam_T[3], cam_K[9] = obs_R_all/obs_T_all/obs_K_all. */
+int sherf_smpl_c2s_table(const float* weights, const float* A_big, const float* A_obs, const float* PO_big,
+                         const float* SO_obs, const float* PO_obs, const float* R_obs, const float* Th_obs,
+                         const float* cam_R, const float* cam_T, const float* cam_K, float* C2S,
+                         sherf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6 support: uniform cell list over n (<= 6890) vertices, replacing the brute-force pytorch3d K-NN of
+ * renderer.py:315,564,627.  verts_s = (verts - Th) @ R when R/Th are non-null (renderer.py:313-314).
+ *   grid_hdr[8] x 32 bit: origin xyz, cell, 1/cell (f32), nx, ny, nz (int32 bit patterns); cell >= cell_size,
+ *   enlarged only if an axis would exceed 64 cells; scratch: int32[5*n].
+ *   cell_start[SHERF_MAX_CELLS+1] int32, cell_pts[n] float4 (x,y,z,bitcast(id)) sorted by cell. */
+int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
+                      float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
+                      sherf_stream_t stream);
+
+/* a4+a5+a6: sample_stratified (renderer.py:458-481, math_utils.py:101-118), sample positions and SMPL-frame
+ * transform (renderer.py:304-310), nearest posed vertex + 5 cm shell mask (renderer.py:315-321) and stream
+ * compaction, fused.  One wave per ray.
+ *   in : ray_o/ray_d [R][3], near/far [R], Rg[9], Th[3] (params R, Th), cell list of the posed vertices.
+ *   out: counters[0] = number of valid samples, counters[1..2] = ordered-int min/max of all depths (for the
+ *        global clamp of ray_marcher.py:57); ray_base[R], ray_cnt[R]; for compact sample c:
+ *        cs_idx[c] = ray*S + k, cs_vid[c] = vertex id, cs_xs[c][4] = (x_s, 0).  Order: ray-major, ascending k
+ *        == the order of the reference's boolean-mask indexing (renderer.py:320), found by a two-pass
+ *        count / scan / write so it is deterministic and needs no global atomics.
+ *   workspace: dense_vid[R*S] int32, ray_mask[R*ceil(S/64)] u64, scan_ws[R + R/1024 + 1] int32.  S <= 256. */
+int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
+                         int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
+                         const int32_t* cell_start, const float* cell_pts, int64_t capacity,
+                         int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
+                         int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
+                         int32_t* scan_ws, sherf_stream_t stream);
+
+/* a8+a9+a10 (geometry part): per compact sample: x_c, v_c via T2C[vid]; nearest T-pose vertex (exact, cell
+ * list of t_vertices, renderer.py:627); uv via C2S.  geom[c][8] = (x_c.xyz, v_c.xyz, u, v); cs_tvid[c]. */
+int sherf_warp_geom(const int32_t* counters, const int32_t* cs_idx, const int32_t* cs_vid, const float* cs_xs,
+                    const float* ray_d, int S, const float* Rg, const float* T2C, const float* C2S,
+                    const float* t_verts, const float* tgrid_hdr, const int32_t* tcell_start,
+                    const float* tcell_pts, int64_t capacity, float* geom, int32_t* cs_tvid,
+                    sherf_stream_t stream);
+
+/* Sparse voxel level descriptor used by the gather (a11). All pointers device. */
+typedef struct {
+    const uint32_t* bitmap;  /* 1 bit per voxel of this level, linear index (z*H + y)*W + x */
+    const int32_t* prefix;   /* exclusive popcount prefix per 32-bit word */
+    const float* rows;       /* folded features [n_rows][96] */
+    int32_t D, H, W;
+} sherf_vox_level;
+
+/* a10+a11+a12 taps: pixel-aligned (renderer.py:330-340), tri-plane (:234-243) and voxel trilinear (:744-797)
+ * gathers, with the linear layers conv1d_projection/conv1d_reprojection (renderer.py:350,423-424) folded into
+ * the tables ahead of time (interpolation is linear).  Writes the transformer input tokens and extras in the
+ * tile-major layout the MLP kernel consumes:
+ *   tokens[tile][3][8][32][4] floats, extras[tile][12][32] floats (x_c, v_c, tapped rgb, pad), 32 samples/tile.
+ *   planes_f [3][P][P][32], feat_f [Hf][Wf][64], img4 [H][W][4], tok_bias[96], bounds[6] (t_world_bounds),
+ *   vox_min[3] (xyz of sp_input bounds min), vox_sh[3] (out_sh as z,y,x). */
+int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
+                        const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
+                        const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
+                        const float* vox_min, const int32_t* vox_sh_host, int64_t capacity, float* tokens,
+                        float* extras, sherf_stream_t stream);
+
+/* a13+a14: rgb positional encoding -> slot-2 token, 3-token transformer (renderer.py:949-993), pos/view
+ * encodings (:875-916) and NeRFDecoder (triplane.py:285-316) as one MFMA kernel; weights arrive as the
+ * pre-packed fragment stream built by sherf_amd/mlp_pack.py.  prec: 0 = bf16, 1 = bf16x3 (hi/lo split,
+ * fp32-grade).  out[c] = (r,g,b,sigma). */
+int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                   const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* layout of the weight stream the kernel expects: number of chunks and K-blocks per chunk. */
+int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int32_t max_chunks);
+
+/* a15+a16: scatter-back + MipRayMarcher2 (renderer.py:364-371, ray_marcher.py:25-64) on the compact samples;
+ * masked-out samples (sigma=-80) contribute exact zeros so they are skipped.  rgb[R][3], depth[R], acc[R]. */
+int sherf_composite_compact(const int32_t* counters, const int32_t* ray_base, const int32_t* ray_cnt,
+                            const int32_t* cs_idx, const float* sample_out, const float* ray_d,
+                            const float* near, const float* far, int R, int S, int white_back, float* rgb,
+                            float* depth, float* acc, sherf_stream_t stream);
+
+/* MipRayMarcher2.forward on dense inputs (ray_marcher.py:67-70): colors[R][S][3], sigma[R][S], depths[R][S],
+ * rays_d[R][3] -> rgb[R][3], depth[R], weights[R][S].  dmin/dmax = global min/max of depths (ray_marcher.py:57). */
+int sherf_composite_dense(const float* colors, const float* sigma, const float* depths, const float* rays_d,
+                          int R, int S, int white_back, float dmin, float dmax, float* rgb, float* depth,
+                          float* weights, sherf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a11: sparse voxel encoder (SparseConvNet, renderer.py:708-871; spconv 2.3.3 semantics restated in
+ * oracle/sherf_oracle.py).  Level bookkeeping is bitmap + popcount-prefix (rank == row id, rows sorted by
+ * linear voxel index). */
+int sherf_svox_mark_rows(const int32_t* coord, int n, int D, int H, int W, uint32_t* bitmap, sherf_stream_t stream);
+int sherf_svox_mark_down(const int32_t* keys, const int32_t* n_rows, int D, int H, int W, uint32_t* bitmap_out,
+                         int max_rows, sherf_stream_t stream);
+int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, sherf_stream_t stream);
+int sherf_svox_keys(const uint32_t* bitmap, const int32_t* prefix, int n_words, int32_t* keys, sherf_stream_t stream);
+int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int C, int D, int H, int W,
+                            const uint32_t* bitmap, const int32_t* prefix, float* g, int32_t* mult,
+                            sherf_stream_t stream);
+/* submanifold (down=0) or stride-2 (down=1) 3x3x3 conv; wt packed [27][Cin][Cout]. in: level (Di,Hi,Wi). */
+int sherf_svox_conv(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
+                    const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in,
+                    int Cin, const float* wt, int Cout, int down, int max_rows, float* out, sherf_stream_t stream);
+/* BatchNorm1d(eps=1e-3)+ReLU over the ROW set (rows = n_total_rows, of which the n_rows voxels are non-zero):
+ * training!=0 -> batch statistics (written to stats[2][C] = mean, biased var), else running stats from stats. */
+int sherf_svox_bn_relu(float* x, const int32_t* n_rows, const int32_t* mult, const int32_t* n_total_rows, int C,
+                       const float* gamma, const float* beta, float* stats, int training, sherf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-61). cam2world[N][16], intr[N][9]. */
+int sherf_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* origins,
+                      float* dirs, sherf_stream_t stream);
+/* a1+a2: get_rays + get_near_far + near/far packing (training/RenderPeople_dataset.py:14-27, 68-101, 129-134)
+ * in fp32 on device. K_inv[9], Rc[9], Tc[3], bounds[6] (world min/max of the posed vertices +-5cm). */
+int sherf_dataset_rays(const float* K_inv, const float* Rc, const float* Tc, const float* bounds, int H, int W,
+                       float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box,
+                       sherf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+"""Ahead-of-time build of libsherf_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m sherf_amd.build            # rebuild if any source is newer than the .so
+
+The .so is built IN-TREE (sherf_amd/libsherf_hip.so) so it travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libsherf_hip.so')
+SOURCES = ['smpl.hip', 'sample.hip', 'gather.hip', 'mlp.hip', 'composite.hip', 'svox.hip', 'rays.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-Wno-unused-value']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'common.h'),
+                                                         os.path.join(HERE, '..', 'include', 'sherf_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
+        objs.append(o)
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{out.decode()}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stdout.decode())
+    if verbose:
+        print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.2f} MB)')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

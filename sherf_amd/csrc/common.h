@@ -1,0 +1,79 @@
+// Shared host/device helpers for libsherf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sherf_hip.h"
+
+extern char g_sherf_err[256];
+
+#define SHERF_CHECK_ARG(cond)                                                                     \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            snprintf(g_sherf_err, sizeof(g_sherf_err), "%s: bad argument: %s", __func__, #cond);  \
+            return SHERF_EINVAL;                                                                  \
+        }                                                                                         \
+    } while (0)
+
+#define SHERF_LAUNCH_CHECK()                                                                      \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) {                                                                   \
+            snprintf(g_sherf_err, sizeof(g_sherf_err), "%s: launch failed: %s", __func__,         \
+                     hipGetErrorString(e_));                                                      \
+            return SHERF_ELAUNCH;                                                                 \
+        }                                                                                         \
+        return SHERF_OK;                                                                          \
+    } while (0)
+
+static inline hipStream_t as_stream(sherf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// grid header layout (8 x 32-bit): origin.xyz (f32), cell (f32), inv_cell (f32), nx, ny, nz (i32)
+struct CellGrid {
+    float ox, oy, oz, cell, inv_cell;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ CellGrid load_grid(const float* hdr) {
+    CellGrid g;
+    g.ox = hdr[0]; g.oy = hdr[1]; g.oz = hdr[2]; g.cell = hdr[3]; g.inv_cell = hdr[4];
+    g.nx = __float_as_int(hdr[5]); g.ny = __float_as_int(hdr[6]); g.nz = __float_as_int(hdr[7]);
+    return g;
+}
+
+// Exact fp32 squared distance, evaluated as ((dx*dx)+(dy*dy))+(dz*dz) with NO fma contraction: the same
+// expression the oracle uses for the role of pytorch3d.knn_points (renderer.py:315).
+__device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// Examine every vertex whose cell overlaps the ball (x, r); keep the lexicographic minimum of (d2, id).
+// All vertices with distance <= r are guaranteed to be examined (cell range widened by a safety margin).
+__device__ __forceinline__ void nn_search(const CellGrid& g, const int32_t* __restrict__ cell_start,
+                                          const float4* __restrict__ pts, float x, float y, float z, float r,
+                                          float& best_d2, int& best_id) {
+    float rr = r + 1e-4f * g.cell;
+    int x0 = (int)floorf((x - rr - g.ox) * g.inv_cell), x1 = (int)floorf((x + rr - g.ox) * g.inv_cell);
+    int y0 = (int)floorf((y - rr - g.oy) * g.inv_cell), y1 = (int)floorf((y + rr - g.oy) * g.inv_cell);
+    int z0 = (int)floorf((z - rr - g.oz) * g.inv_cell), z1 = (int)floorf((z + rr - g.oz) * g.inv_cell);
+    x0 = max(x0, 0); y0 = max(y0, 0); z0 = max(z0, 0);
+    x1 = min(x1, g.nx - 1); y1 = min(y1, g.ny - 1); z1 = min(z1, g.nz - 1);
+    if (x0 > x1 || y0 > y1 || z0 > z1) return;
+    for (int cz = z0; cz <= z1; ++cz)
+        for (int cy = y0; cy <= y1; ++cy) {
+            int row = (cz * g.ny + cy) * g.nx;
+            int s = cell_start[row + x0], e = cell_start[row + x1 + 1];   // cells along x are contiguous
+            for (int i = s; i < e; ++i) {
+                float4 p = pts[i];
+                float d2 = dist2_exact(x, y, z, p.x, p.y, p.z);
+                int id = __float_as_int(p.w);
+                if (d2 < best_d2 || (d2 == best_d2 && id < best_id)) { best_d2 = d2; best_id = id; }
+            }
+        }
+}
+
+// order-preserving float <-> int map for atomicMin/atomicMax on floats of any sign
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }

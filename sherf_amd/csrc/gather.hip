@@ -1,0 +1,174 @@
+// Hierarchical feature gather (gfx950): rows a10 (pixel-aligned), a11 (voxel trilinear) and a12 (tri-plane)
+// of SURVEY.md section 8, fused into one pass that emits the transformer's input tokens.
+//
+// Interpolation is linear, so the 1x1 convolutions the reference applies AFTER sampling
+// (conv1d_projection 192->96, renderer.py:350; conv1d_reprojection 96->32 per slot, renderer.py:423-424) are
+// applied ONCE per frame to the tables instead (sherf_amd/renderer.py: fold_tables): the taps then sum
+// straight into the three 32-d slot tokens.  Only the rgb positional encoding (non-linear) is left for the
+// MLP kernel.  Tables are channel-last fp32 so every tap is one 16-byte load per lane: 8 lanes own the
+// 8 channel quads of a slot, 8 samples per wave, 32 samples (= one MFMA column tile) per workgroup.
+#include "common.h"
+
+namespace {
+
+struct Levels { sherf_vox_level l[3]; };
+
+__device__ __forceinline__ void axpy4(float4& a, float w, const float4 v) {
+    a.x += w * v.x; a.y += w * v.y; a.z += w * v.z; a.w += w * v.w;
+}
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
+                                                            const float4* __restrict__ planes_f, int P,
+                                                            const float4* __restrict__ feat_f, int Hf, int Wf,
+                                                            const float4* __restrict__ img4, int H, int W, Levels lv,
+                                                            const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
+                                                            const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
+                                                            float4* __restrict__ tokens, float* __restrict__ extras) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    const int l = threadIdx.x & 7;                 // channel quad within a slot
+    const int j = threadIdx.x >> 3;                // sample within the tile (0..31)
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t c = tile * 32 + j;
+        float4 acc[3];
+        acc[0] = tok_bias[l]; acc[1] = tok_bias[8 + l]; acc[2] = tok_bias[16 + l];
+        float ex[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            const float* gm = geom + c * 8;
+            const float xc[3] = {gm[0], gm[1], gm[2]};
+            ex[0] = xc[0]; ex[1] = xc[1]; ex[2] = xc[2]; ex[3] = gm[3]; ex[4] = gm[4]; ex[5] = gm[5];
+            // ---- tri-plane: renderer.py:234-243, align_corners=False, zeros padding ----
+            float n[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float ga = p == 2 ? n[2] : n[0];                 // planes (x,y), (x,z), (z,y)
+                const float gb = p == 1 ? n[2] : n[1];
+                float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+                float py = clampf(((gb + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < P && yy >= 0 && yy < P) {
+                            float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            axpy4(acc[p], w, planes_f[((size_t)(p * P + yy) * P + xx) * 8 + l]);
+                        }
+                    }
+            }
+            // ---- pixel-aligned feature + rgb: renderer.py:330-336, align_corners=True ----
+            {
+                float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
+                float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
+                float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
+                            float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            const float4* t = feat_f + ((size_t)yy * Wf + xx) * 16;
+                            axpy4(acc[0], w, t[l]);
+                            axpy4(acc[1], w, t[8 + l]);
+                        }
+                    }
+                px = clampf((gx + 1.f) * 0.5f * (W - 1), -2.f, (float)W + 1.f);
+                py = clampf((gy + 1.f) * 0.5f * (H - 1), -2.f, (float)H + 1.f);
+                x0 = floorf(px); y0 = floorf(py); fx = px - x0; fy = py - y0;
+                xi = (int)x0; yi = (int)y0;
+                float4 rgb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                            float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            axpy4(rgb, w, img4[(size_t)yy * W + xx]);
+                        }
+                    }
+                ex[6] = rgb.x; ex[7] = rgb.y; ex[8] = rgb.z;
+            }
+            // ---- sparse voxel levels: renderer.py:544-556 + 762-782, align_corners=True ----
+            {
+                float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;   // vox_sh = (D,H,W) = (z,y,x)
+                float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
+                float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
+#pragma unroll
+                for (int L = 0; L < 3; ++L) {
+                    const sherf_vox_level& lev = lv.l[L];
+                    float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
+                    float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
+                    float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
+                    float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                    float fx = px - x0, fy = py - y0, fz = pz - z0;
+                    int xi = (int)x0, yi = (int)y0, zi = (int)z0;
+#pragma unroll
+                    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                int xx = xi + dx, yy = yi + dy, zz = zi + dz;
+                                if (xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
+                                    int key = (zz * lev.H + yy) * lev.W + xx;
+                                    uint32_t word = lev.bitmap[key >> 5];
+                                    uint32_t bit = 1u << (key & 31);
+                                    if (word & bit) {
+                                        int row = lev.prefix[key >> 5] + __popc(word & (bit - 1u));
+                                        float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
+                                        const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)row * 24;
+                                        axpy4(acc[0], w, r[l]);
+                                        axpy4(acc[1], w, r[8 + l]);
+                                        axpy4(acc[2], w, r[16 + l]);
+                                    }
+                                }
+                            }
+                }
+            }
+        } else {
+            acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // tokens[tile][slot][quad][j] (float4), extras[tile][12][j]
+#pragma unroll
+        for (int s = 0; s < 3; ++s) tokens[((tile * 3 + s) * 8 + l) * 32 + j] = acc[s];
+        float e0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e0 = (l == i) ? ex[i] : e0;
+        extras[(tile * 12 + l) * 32 + j] = e0;
+        if (l < 4) extras[(tile * 12 + 8 + l) * 32 + j] = (l == 0) ? ex[8] : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
+                                   const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
+                                   const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
+                                   const float* vox_min, const int32_t* vox_sh_host, int64_t capacity, float* tokens,
+                                   float* extras, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && levels_host && tok_bias && bounds && vox_min &&
+                    vox_sh_host && tokens && extras);
+    SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
+    Levels lv;
+    for (int i = 0; i < 3; ++i) {
+        lv.l[i] = levels_host[i];
+        SHERF_CHECK_ARG(lv.l[i].bitmap && lv.l[i].prefix && lv.l[i].rows && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
+    }
+    int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
+    const int64_t tiles = (capacity + 31) / 32;
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
+                       geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
+                       reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
+                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras);
+    SHERF_LAUNCH_CHECK();
+}

@@ -1,0 +1,501 @@
+// Fused per-sample network (gfx950 MFMA): rows a13 + a14 of SURVEY.md section 8.
+//
+//   slot-2 token += W_b . PE5(rgb)[:32]                         (rest of conv1d_reprojection, renderer.py:423-424)
+//   3-token pre-norm transformer, dim 32, 3 heads x 16            (renderer.py:949-993)
+//   PE6(x_c), PE4(v_c)                                            (renderer.py:875-916)
+//   NeRFDecoder 8x128 with skip, sigma / feature / view / rgb     (triplane.py:285-316)
+//
+// Formulation: D^T = W . X^T -- the weight matrix is the MFMA A operand (32 output features per tile) and 32
+// samples are the B operand columns, using v_mfma_f32_32x32x16_bf16.  A wave owns 32 samples for the whole
+// network; a layer's fp32 accumulator tile (lane = sample, 16 regs = 16 of the tile's 32 features) is
+// converted in registers into two B operand K-blocks of the next layer: the K permutation this implies,
+//     k-slot (kb, h, e)  <->  feature 16*kb + (e&3) + 8*(e>>2) + 4*h,
+// is baked into the packed weight stream (sherf_amd/mlp_pack.py), so activations never leave the register
+// file and never cross lanes (except the 3x3 attention dot products and LayerNorm sums: one lane^32 exchange).
+// Weights stream L2 -> LDS one output tile ("chunk") at a time in MFMA fragment order (ds_read_b128,
+// lane-linear, conflict free), double buffered, one barrier per chunk, shared by the 8 waves of a workgroup.
+//
+// prec 0: bf16 operands, fp32 accumulate.   prec 1 ("bf16x3"): operands split hi+lo, three MFMAs per product
+// (lo*hi + hi*lo + hi*hi), ~2^-16 relative error -- the mode that meets the 1e-3 parity tolerance.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NW = 8;               // waves per workgroup (each: one 32-sample column tile)
+constexpr int NT = NW * 64;
+constexpr int N_CHUNKS = 49;
+constexpr int MAX_NKB = 13;
+constexpr int BIAS_LN = N_CHUNKS;   // index of the first LayerNorm table in wbias ([idx][2][16] floats)
+
+// K-blocks (16 inputs each) per chunk; a chunk is one 32-row output tile of one layer.
+__host__ __device__ constexpr int chunk_nkb(int c) {
+    return c == 0 ? 2        // rgb PE -> slot-2 token
+         : c <= 5 ? 2        // to_qkv tiles: [q0|q1] [q2|pad] [k0|k1] [k2|v0] [v1|v2]
+         : c == 6 ? 3        // to_out (48 -> 32)
+         : c <= 8 ? 2        // FF 32->32, 32->32
+         : c <= 12 ? 5       // pts_linears.0 : PE6 (3 kb) + z0 (2 kb)
+         : c <= 28 ? 8       // pts_linears.1-4
+         : c <= 32 ? 13      // pts_linears.5 : PE6 + z0 + h
+         : c <= 40 ? 8       // pts_linears.6-7
+         : c <= 45 ? 8       // feature_linear (4 tiles) + alpha_linear (1 tile, row 0)
+         : c <= 47 ? 12      // views_linear : feature (8) + PE4 (2) + z1 (2)
+         : 4;                // rgb_linear (rows 0..2)
+}
+__host__ __device__ constexpr int chunk_off_kb(int c) {   // stream offset in KiB; every chunk stores hi then lo
+    int o = 0;
+    for (int i = 0; i < c; ++i) o += 2 * chunk_nkb(i);
+    return o;
+}
+
+template <int PREC> struct BFrag;
+template <> struct BFrag<0> { uint4 hi; };
+template <> struct BFrag<1> { uint4 hi, lo; };
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_rt(float a) { return (float)((__bf16)a); }
+
+template <int PREC>
+__device__ __forceinline__ BFrag<PREC> make_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    BFrag<PREC> f;
+    f.hi = make_uint4(pack2(v0, v1), pack2(v2, v3), pack2(v4, v5), pack2(v6, v7));
+    if constexpr (PREC == 1)
+        f.lo = make_uint4(pack2(v0 - bf16_rt(v0), v1 - bf16_rt(v1)), pack2(v2 - bf16_rt(v2), v3 - bf16_rt(v3)),
+                          pack2(v4 - bf16_rt(v4), v5 - bf16_rt(v5)), pack2(v6 - bf16_rt(v6), v7 - bf16_rt(v7)));
+    return f;
+}
+
+// one fp32 accumulator tile -> the two K-blocks it becomes as an input of the next layer
+template <int PREC>
+__device__ __forceinline__ void split_tile(const f32x16& a, BFrag<PREC>& k0, BFrag<PREC>& k1) {
+    k0 = make_frag<PREC>(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+    k1 = make_frag<PREC>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+}
+
+__device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int PREC> struct Ctx {
+    const char* ws;          // packed weight stream (global)
+    const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables
+    char* lds;               // 2 slots
+    uint4 pf[2 * (PREC + 1)];
+    int tid, lane, h;
+    static constexpr int SLOT = MAX_NKB * 1024 * (PREC + 1);
+    __device__ __forceinline__ char* slot(int c) const { return lds + (c & 1) * SLOT; }
+};
+
+template <int PREC>
+__device__ __forceinline__ void pf_load(Ctx<PREC>& cx, int c) {
+    if (c >= N_CHUNKS) return;
+    const int bytes = chunk_nkb(c) * 1024 * (PREC + 1);
+    const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024;
+#pragma unroll
+    for (int i = 0; i < 2 * (PREC + 1); ++i) {
+        int off = (i * NT + cx.tid) * 16;
+        if (off < bytes) cx.pf[i] = *reinterpret_cast<const uint4*>(src + off);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ void pf_store(Ctx<PREC>& cx, int c) {
+    if (c >= N_CHUNKS) return;
+    const int bytes = chunk_nkb(c) * 1024 * (PREC + 1);
+    char* dst = cx.slot(c);
+#pragma unroll
+    for (int i = 0; i < 2 * (PREC + 1); ++i) {
+        int off = (i * NT + cx.tid) * 16;
+        if (off < bytes) *reinterpret_cast<uint4*>(dst + off) = cx.pf[i];
+    }
+}
+// end of chunk c: publish chunk c+1 (already in registers) to the other slot, start fetching chunk c+2
+template <int PREC>
+__device__ __forceinline__ void advance(Ctx<PREC>& cx, int c) {
+    pf_store(cx, c + 1);
+    __syncthreads();
+    pf_load(cx, c + 2);
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 bias_tile(const Ctx<PREC>& cx, int idx) {
+    const float4* p = reinterpret_cast<const float4*>(cx.wbias + (idx * 2 + cx.h) * 16);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    return r;
+}
+
+// acc[t] += W_chunk . B[t]  for NTOK column sets sharing the chunk's A fragments
+template <int PREC, int NKB, int NTOK>
+__device__ __forceinline__ void mma_chunk(const Ctx<PREC>& cx, int c, const BFrag<PREC> (&b)[NTOK][NKB], f32x16 (&acc)[NTOK]) {
+    const char* s = cx.slot(c) + cx.lane * 16;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(s + kb * 1024);
+        if constexpr (PREC == 1) {
+            const uint4 al = *reinterpret_cast<const uint4*>(s + (NKB + kb) * 1024);
+#pragma unroll
+            for (int t = 0; t < NTOK; ++t) {
+                acc[t] = mfma(al, b[t][kb].hi, acc[t]);
+                acc[t] = mfma(ah, b[t][kb].lo, acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTOK; ++t) acc[t] = mfma(ah, b[t][kb].hi, acc[t]);
+    }
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   // partner lane holds the other 16 features
+
+// LayerNorm over the 32 features of a token (16 here, 16 in lane^32), eps 1e-5 (renderer.py:931)
+template <int PREC>
+__device__ __forceinline__ void layer_norm(const Ctx<PREC>& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += x[r];
+    s += xhalf(s);
+    const float mean = s * (1.0f / 32.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { float d = x[r] - mean; q += d * d; }
+    q += xhalf(q);
+    const float inv = 1.0f / sqrtf(q * (1.0f / 32.0f) + 1e-5f);
+    const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
+    f32x16 y;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = (x[r] - mean) * inv * g[r] + bt[r];
+    split_tile<PREC>(y, k0, k1);
+}
+
+// NeRF positional encoding in "natural" K-block order: feature f = 16*kb + 8*h + e of
+// [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]; entries >= 3 + 6*NF are zero.
+template <int PREC, int NF, int NKB, int NTOT, int OFF>
+__device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag<PREC> (&out)[1][NTOT]) {
+    float f[NKB * 16];
+#pragma unroll
+    for (int i = 0; i < NKB * 16; ++i) f[i] = 0.f;
+    f[0] = x; f[1] = y; f[2] = z;
+    float s[3], c[3];
+    sincosf(x, &s[0], &c[0]); sincosf(y, &s[1], &c[1]); sincosf(z, &s[2], &c[2]);
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (3 + 6 * q + a < NKB * 16) f[3 + 6 * q + a] = s[a];
+            if (6 + 6 * q + a < NKB * 16) f[6 + 6 * q + a] = c[a];
+            float s2 = 2.f * s[a] * c[a], c2 = 1.f - 2.f * s[a] * s[a];    // double the angle
+            s[a] = s2; c[a] = c2;
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = h ? f[16 * kb + 8 + e] : f[16 * kb + e];
+        out[0][OFF + kb] = make_frag<PREC>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens,
+                                                         const float* __restrict__ extras, const char* __restrict__ ws,
+                                                         const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * Ctx<PREC>::SLOT];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
+    Ctx<PREC> cx;
+    cx.ws = ws; cx.wbias = wbias; cx.lds = lds;
+    cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
+    const int j = cx.lane & 31, h = cx.h;
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // still takes part in every barrier
+
+    pf_load(cx, 0);
+    pf_store(cx, 0);
+    __syncthreads();
+    pf_load(cx, 1);
+
+    // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
+    f32x16 tok[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+            tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
+        }
+    const float* ex = extras + tile * 12 * 32 + j;
+    const float xc0 = ex[0], xc1 = ex[32], xc2 = ex[64], vc0 = ex[96], vc1 = ex[128], vc2 = ex[160];
+
+    // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
+    {
+        BFrag<PREC> b[1][2];
+        pe_frags<PREC, 5, 2, 2, 0>(h, ex[192], ex[224], ex[256], b);
+        f32x16 acc[1] = {bias_tile(cx, 0)};
+        mma_chunk<PREC, 2, 1>(cx, 0, b, acc);
+        advance(cx, 0);
+        tok[2] += acc[0];
+    }
+
+    // ---- transformer: LN1 + to_qkv (chunks 1..5), attention, to_out (6) ----
+    BFrag<PREC> zb[2][2];                                       // fused tokens z_0, z_1 as K-blocks
+    {
+        BFrag<PREC> ln[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) layer_norm<PREC>(cx, tok[t], 0, ln[t][0], ln[t][1]);
+        float qa[2][16], qb[2][8];
+        {
+            BFrag<PREC> b2[2][2] = {{ln[0][0], ln[0][1]}, {ln[1][0], ln[1][1]}};
+            f32x16 acc[2] = {bias_tile(cx, 1), bias_tile(cx, 1)};
+            mma_chunk<PREC, 2, 2>(cx, 1, b2, acc);              // [q head0 | q head1]
+            advance(cx, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qa[i][r] = acc[i][r];
+            f32x16 acc2[2] = {bias_tile(cx, 2), bias_tile(cx, 2)};
+            mma_chunk<PREC, 2, 2>(cx, 2, b2, acc2);             // [q head2 | pad]
+            advance(cx, 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) qb[i][r] = acc2[i][r];
+        }
+        float dot[2][3][3];                                     // [query token][head][key token]
+        float o[2][3][8];                                       // attention output [query][head][8 of 16 dims]
+        float v0[3][8];
+        {
+            f32x16 acc[3] = {bias_tile(cx, 3), bias_tile(cx, 3), bias_tile(cx, 3)};
+            mma_chunk<PREC, 2, 3>(cx, 3, ln, acc);              // [k head0 | k head1]
+            advance(cx, 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { d0 += qa[i][r] * acc[t][r]; d1 += qa[i][8 + r] * acc[t][8 + r]; }
+                    dot[i][0][t] = d0; dot[i][1][t] = d1;
+                }
+        }
+        {
+            f32x16 acc[3] = {bias_tile(cx, 4), bias_tile(cx, 4), bias_tile(cx, 4)};
+            mma_chunk<PREC, 2, 3>(cx, 4, ln, acc);              // [k head2 | v head0]
+            advance(cx, 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) d2 += qb[i][r] * acc[t][r];
+                    dot[i][2][t] = d2;
+                }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v0[t][r] = acc[t][8 + r];
+        }
+        // softmax over the 3 keys, scale 16^-0.5 (renderer.py:956,971-973)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int hd = 0; hd < 3; ++hd) {
+                float d[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) d[t] = (dot[i][hd][t] + xhalf(dot[i][hd][t])) * 0.25f;
+                float m = fmaxf(d[0], fmaxf(d[1], d[2]));
+                float e0 = expf(d[0] - m), e1 = expf(d[1] - m), e2 = expf(d[2] - m);
+                float inv = 1.0f / (e0 + e1 + e2);
+                dot[i][hd][0] = e0 * inv; dot[i][hd][1] = e1 * inv; dot[i][hd][2] = e2 * inv;
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
+        {
+            f32x16 acc[3] = {bias_tile(cx, 5), bias_tile(cx, 5), bias_tile(cx, 5)};
+            mma_chunk<PREC, 2, 3>(cx, 5, ln, acc);              // [v head1 | v head2]
+            advance(cx, 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    o[i][1][r] = dot[i][1][0] * acc[0][r] + dot[i][1][1] * acc[1][r] + dot[i][1][2] * acc[2][r];
+                    o[i][2][r] = dot[i][2][0] * acc[0][8 + r] + dot[i][2][1] * acc[1][8 + r] + dot[i][2][2] * acc[2][8 + r];
+                }
+        }
+        f32x16 y[2];
+        {
+            BFrag<PREC> ob[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int hd = 0; hd < 3; ++hd)
+                    ob[i][hd] = make_frag<PREC>(o[i][hd][0], o[i][hd][1], o[i][hd][2], o[i][hd][3], o[i][hd][4], o[i][hd][5],
+                                                o[i][hd][6], o[i][hd][7]);
+            f32x16 acc[2] = {bias_tile(cx, 6), bias_tile(cx, 6)};
+            mma_chunk<PREC, 3, 2>(cx, 6, ob, acc);              // to_out + bias
+            advance(cx, 6);
+            y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];     // residual (renderer.py:925)
+        }
+        // ---- FF: LN2 -> Linear -> GELU(erf) -> Linear, residual (chunks 7, 8) ----
+        {
+            BFrag<PREC> l2[2][2];
+            layer_norm<PREC>(cx, y[0], 1, l2[0][0], l2[0][1]);
+            layer_norm<PREC>(cx, y[1], 1, l2[1][0], l2[1][1]);
+            f32x16 acc[2] = {bias_tile(cx, 7), bias_tile(cx, 7)};
+            mma_chunk<PREC, 2, 2>(cx, 7, l2, acc);
+            advance(cx, 7);
+            BFrag<PREC> gb[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { float a = acc[i][r]; acc[i][r] = 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
+                split_tile<PREC>(acc[i], gb[i][0], gb[i][1]);
+            }
+            f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
+            mma_chunk<PREC, 2, 2>(cx, 8, gb, acc2);
+            advance(cx, 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { f32x16 z = acc2[i] + y[i]; split_tile<PREC>(z, zb[i][0], zb[i][1]); }
+        }
+    }
+
+    // ---- NeRF decoder trunk ----
+    BFrag<PREC> ha[1][8], hb[1][8];
+    {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
+        BFrag<PREC> b[1][5];
+        pe_frags<PREC, 6, 3, 5, 0>(h, xc0, xc1, xc2, b);
+        b[0][3] = zb[0][0]; b[0][4] = zb[0][1];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 acc[1] = {bias_tile(cx, 9 + T)};
+            mma_chunk<PREC, 5, 1>(cx, 9 + T, b, acc);
+            advance(cx, 9 + T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
+        }
+    }
+#pragma unroll
+    for (int L = 0; L < 4; ++L) {   // pts_linears.1-4 (ping-pong ha -> hb -> ha ...)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const int c = 13 + 4 * L + T;
+            f32x16 acc[1] = {bias_tile(cx, c)};
+            if (L & 1) mma_chunk<PREC, 8, 1>(cx, c, hb, acc);
+            else mma_chunk<PREC, 8, 1>(cx, c, ha, acc);
+            advance(cx, c);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            if (L & 1) split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
+            else split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
+        }
+    }
+    {   // pts_linears.5 : [PE6 | z_0 | h(128)] ; after 4 layers the activations are back in ha
+        BFrag<PREC> b[1][13];
+        pe_frags<PREC, 6, 3, 13, 0>(h, xc0, xc1, xc2, b);
+        b[0][3] = zb[0][0]; b[0][4] = zb[0][1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[0][5 + k] = ha[0][k];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 acc[1] = {bias_tile(cx, 29 + T)};
+            mma_chunk<PREC, 13, 1>(cx, 29 + T, b, acc);
+            advance(cx, 29 + T);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
+        }
+    }
+#pragma unroll
+    for (int L = 0; L < 2; ++L) {   // pts_linears.6-7 : hb -> ha -> hb
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const int c = 33 + 4 * L + T;
+            f32x16 acc[1] = {bias_tile(cx, c)};
+            if (L == 0) mma_chunk<PREC, 8, 1>(cx, c, hb, acc);
+            else mma_chunk<PREC, 8, 1>(cx, c, ha, acc);
+            advance(cx, c);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            if (L == 0) split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
+            else split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
+        }
+    }
+    // ---- heads: feature_linear (4 tiles, no activation) + alpha_linear (tile 45, row 0), from hb ----
+    float sigma;
+    BFrag<PREC> vb[1][12];
+    {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 acc[1] = {bias_tile(cx, 41 + T)};
+            mma_chunk<PREC, 8, 1>(cx, 41 + T, hb, acc);
+            advance(cx, 41 + T);
+            split_tile<PREC>(acc[0], vb[0][2 * T], vb[0][2 * T + 1]);
+        }
+        f32x16 acc[1] = {bias_tile(cx, 45)};
+        mma_chunk<PREC, 8, 1>(cx, 45, hb, acc);
+        advance(cx, 45);
+        sigma = acc[0][0];                                       // row 0 lives in reg 0 of the h == 0 lanes
+    }
+    // ---- views_linear : [feature (8 kb) | PE4(v_c) (2 kb) | z_1 (2 kb)] -> 64, ReLU ; rgb_linear -> sigmoid ----
+    pe_frags<PREC, 4, 2, 12, 8>(h, vc0, vc1, vc2, vb);
+    vb[0][10] = zb[1][0]; vb[0][11] = zb[1][1];
+    BFrag<PREC> gb[1][4];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        f32x16 acc[1] = {bias_tile(cx, 46 + T)};
+        mma_chunk<PREC, 12, 1>(cx, 46 + T, vb, acc);
+        advance(cx, 46 + T);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+        split_tile<PREC>(acc[0], gb[0][2 * T], gb[0][2 * T + 1]);
+    }
+    {
+        f32x16 acc[1] = {bias_tile(cx, 48)};
+        mma_chunk<PREC, 4, 1>(cx, 48, gb, acc);
+        if (live && h == 0) {
+            const int64_t c = tile * 32 + j;
+            if (c < nv) {
+                float r = 1.0f / (1.0f + expf(-acc[0][0])), g = 1.0f / (1.0f + expf(-acc[0][1])), b = 1.0f / (1.0f + expf(-acc[0][2]));
+                out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma);   // triplane.py:314
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int32_t max_chunks) {
+    SHERF_CHECK_ARG(n_chunks && nkb_host && max_chunks >= N_CHUNKS);
+    *n_chunks = N_CHUNKS;
+    for (int c = 0; c < N_CHUNKS; ++c) nkb_host[c] = chunk_nkb(c);
+    return SHERF_OK;
+}
+
+extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                              const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && capacity > 0);
+    const int64_t tiles = (capacity + 31) / 32;
+    const unsigned grid = (unsigned)((tiles + NW - 1) / NW);
+    if (prec == 0)
+        hipLaunchKernelGGL(nerf_mlp_kernel<0>, dim3(grid), dim3(NT), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(nerf_mlp_kernel<1>, dim3(grid), dim3(NT), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out));
+    SHERF_LAUNCH_CHECK();
+}

@@ -1,0 +1,371 @@
+// Geometry stage (gfx950): cell list build, fused depth sampling + SMPL-frame transform + exact nearest
+// vertex + 5 cm shell mask + deterministic stream compaction, and the per-sample warp.
+// Rows a4, a5, a6, a8, a9, a10(geometry) of SURVEY.md section 8.
+//
+// The reference runs a brute-force K-NN of all R*S samples against 6890 vertices three times
+// (renderer.py:315,564,627: 1.16e11 pair tests at 512x512x64).  Here a uniform cell list with 5 cm cells
+// bounds the exact search to a 3x3x3 neighbourhood; the second K-NN is redundant (same id) and the third
+// is an exact ball query seeded by the same-index T-pose vertex.
+#include "common.h"
+
+namespace {
+
+constexpr float kThresh2 = (float)(0.05 * 0.05);   // renderer.py:318 (python float -> fp32 on comparison)
+
+// (v - Th) @ R, evaluated without contraction in the order ((a0*R0c + a1*R1c) + a2*R2c)
+__device__ __forceinline__ void to_smpl_frame(float x, float y, float z, const float* __restrict__ R,
+                                              const float* __restrict__ Th, float& ox, float& oy, float& oz) {
+    float a0 = __fsub_rn(x, Th[0]), a1 = __fsub_rn(y, Th[1]), a2 = __fsub_rn(z, Th[2]);
+    ox = __fadd_rn(__fadd_rn(__fmul_rn(a0, R[0]), __fmul_rn(a1, R[3])), __fmul_rn(a2, R[6]));
+    oy = __fadd_rn(__fadd_rn(__fmul_rn(a0, R[1]), __fmul_rn(a1, R[4])), __fmul_rn(a2, R[7]));
+    oz = __fadd_rn(__fadd_rn(__fmul_rn(a0, R[2]), __fmul_rn(a1, R[5])), __fmul_rn(a2, R[8]));
+}
+__device__ __forceinline__ void rot_only(float x, float y, float z, const float* __restrict__ R, float& ox,
+                                         float& oy, float& oz) {
+    ox = __fadd_rn(__fadd_rn(__fmul_rn(x, R[0]), __fmul_rn(y, R[3])), __fmul_rn(z, R[6]));
+    oy = __fadd_rn(__fadd_rn(__fmul_rn(x, R[1]), __fmul_rn(y, R[4])), __fmul_rn(z, R[7]));
+    oz = __fadd_rn(__fadd_rn(__fmul_rn(x, R[2]), __fmul_rn(y, R[5])), __fmul_rn(z, R[8]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// cell list: one block of 1024 threads (n <= 6890 points)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restrict__ verts, int n,
+                                                           const float* __restrict__ R, const float* __restrict__ Th,
+                                                           float cell_size, float* __restrict__ hdr,
+                                                           int32_t* __restrict__ cell_start, float4* __restrict__ cell_pts,
+                                                           int32_t* __restrict__ scratch) {
+    __shared__ float red[6][1024 / 64];
+    __shared__ float s_hdr[8];
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pos = reinterpret_cast<float*>(scratch) ;            // [n][3] transformed positions
+    int32_t* cid = scratch + 3 * n;                             // [n]
+    int32_t* rank = scratch + 4 * n;                            // [n]
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = tid; i < n; i += 1024) {
+        float x = verts[i * 3], y = verts[i * 3 + 1], z = verts[i * 3 + 2];
+        if (R) to_smpl_frame(x, y, z, R, Th, x, y, z);
+        pos[i * 3] = x; pos[i * 3 + 1] = y; pos[i * 3 + 2] = z;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+    for (int c = 0; c < 3; ++c) {
+        float a = mn[c], b = mx[c];
+        for (int off = 32; off > 0; off >>= 1) { a = fminf(a, __shfl_xor(a, off)); b = fmaxf(b, __shfl_xor(b, off)); }
+        if (lane == 0) { red[c][wave] = a; red[3 + c][wave] = b; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3], hi[3];
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = red[c][0]; hi[c] = red[3 + c][0];
+            for (int w = 1; w < 16; ++w) { lo[c] = fminf(lo[c], red[c][w]); hi[c] = fmaxf(hi[c], red[3 + c][w]); }
+        }
+        float cell = cell_size;
+        for (int c = 0; c < 3; ++c) cell = fmaxf(cell, (hi[c] - lo[c]) / 60.0f);   // keep every axis <= 64 cells
+        float inv = 1.0f / cell;
+        int dims[3];
+        for (int c = 0; c < 3; ++c) dims[c] = min(64, (int)floorf((hi[c] - lo[c]) * inv) + 3);
+        s_hdr[0] = lo[0] - cell; s_hdr[1] = lo[1] - cell; s_hdr[2] = lo[2] - cell; s_hdr[3] = cell; s_hdr[4] = inv;
+        s_hdr[5] = __int_as_float(dims[0]); s_hdr[6] = __int_as_float(dims[1]); s_hdr[7] = __int_as_float(dims[2]);
+        for (int i = 0; i < 8; ++i) hdr[i] = s_hdr[i];
+    }
+    __syncthreads();
+    const float ox = s_hdr[0], oy = s_hdr[1], oz = s_hdr[2], inv = s_hdr[4];
+    const int nx = __float_as_int(s_hdr[5]), ny = __float_as_int(s_hdr[6]), nz = __float_as_int(s_hdr[7]);
+    const int ncell = nx * ny * nz;
+    for (int i = tid; i <= ncell; i += 1024) cell_start[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        int cx = min(nx - 1, max(0, (int)floorf((pos[i * 3] - ox) * inv)));
+        int cy = min(ny - 1, max(0, (int)floorf((pos[i * 3 + 1] - oy) * inv)));
+        int cz = min(nz - 1, max(0, (int)floorf((pos[i * 3 + 2] - oz) * inv)));
+        int c = (cz * ny + cy) * nx + cx;
+        cid[i] = c;
+        rank[i] = atomicAdd(&cell_start[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cell_start[0..ncell] in place: per-thread segments + block scan of the partials
+    const int seg = (ncell + 1 + 1023) / 1024;
+    const int s0 = tid * seg, s1 = min(ncell + 1, s0 + seg);
+    int sum = 0;
+    // counts were produced by global atomics (performed at L2): read them L1-bypassing
+    for (int i = s0; i < s1; ++i) sum += __hip_atomic_load(&cell_start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = s0; i < s1; ++i) {
+        int c = __hip_atomic_load(&cell_start[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cell_start[i] = run; run += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024)
+        cell_pts[cell_start[cid[i]] + rank[i]] = make_float4(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2], __int_as_float(i));
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 1: one wave per ray: depths, positions, exact NN within 5 cm, validity mask
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float depth_at(float near, float range, int k, int S) {
+    // math_utils.py:101-118: steps = arange(S)/(S-1);  t = near + steps * (far - near)
+    float step = __fdiv_rn((float)k, (float)(S - 1));
+    return __fadd_rn(near, __fmul_rn(step, range));
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                        const float* __restrict__ near, const float* __restrict__ far,
+                                                        int R, int S, const float* __restrict__ Rg,
+                                                        const float* __restrict__ Th, const float* __restrict__ hdr,
+                                                        const int32_t* __restrict__ cell_start,
+                                                        const float4* __restrict__ cell_pts,
+                                                        int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
+                                                        int32_t* __restrict__ dense_vid) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const CellGrid g = load_grid(hdr);
+    const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
+    const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
+    const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+    int total = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int k = ch * 64 + lane;
+        bool valid = false;
+        int best_id = 0x7FFFFFFF;
+        if (k < S) {
+            float t = depth_at(nr, range, k, S);
+            float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
+            float xs, ys, zs;
+            to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+            float best = 3.0e38f;
+            nn_search(g, cell_start, cell_pts, xs, ys, zs, 0.05f, best, best_id);
+            valid = best < kThresh2;
+        }
+        uint64_t m = __ballot(valid);
+        if (valid) dense_vid[(size_t)ray * S + k] = best_id;
+        if (lane == 0) ray_mask[(size_t)ray * NCH + ch] = m;
+        total += __popcll(m);
+    }
+    if (lane == 0) ray_cnt[ray] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of ray_cnt -> ray_base (chunks of 1024 rays), total -> counters[0]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) scan_chunk_kernel(const int32_t* __restrict__ cnt, int R,
+                                                          int32_t* __restrict__ base, int32_t* __restrict__ chunk_sum) {
+    __shared__ int s[1024];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < R ? cnt[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int a = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (i < R) base[i] = s[threadIdx.x] - v;
+    if (threadIdx.x == 1023) chunk_sum[blockIdx.x] = s[1023];
+}
+
+__global__ void __launch_bounds__(1024) scan_top_kernel(int32_t* __restrict__ chunk_sum, int n_chunks,
+                                                        int32_t* __restrict__ counters) {
+    __shared__ int s[1024];
+    int carry = 0;
+    for (int b0 = 0; b0 < n_chunks; b0 += 1024) {
+        int i = b0 + threadIdx.x;
+        int v = i < n_chunks ? chunk_sum[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int a = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < n_chunks) chunk_sum[i] = carry + s[threadIdx.x] - v;
+        int tot = s[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) counters[0] = carry;
+}
+
+// global min / max of all depths (ray_marcher.py:57 clamps with torch.min/max over the whole tensor)
+__global__ void __launch_bounds__(256) depth_minmax_kernel(const float* __restrict__ near, const float* __restrict__ far,
+                                                           int R, int S, int32_t* __restrict__ counters) {
+    __shared__ float smn[4], smx[4];
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        float nr = near[r], range = __fsub_rn(far[r], nr);
+        float t0 = depth_at(nr, range, 0, S), t1 = depth_at(nr, range, S - 1, S);
+        mn = fminf(mn, fminf(t0, t1)); mx = fmaxf(mx, fmaxf(t0, t1));
+    }
+    for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
+        atomicMin(&counters[1], f2ord(fminf(mn, smn[0])));
+        atomicMax(&counters[2], f2ord(fmaxf(mx, smx[0])));
+    }
+}
+
+__global__ void init_counters_kernel(int32_t* counters) {
+    counters[0] = 0; counters[1] = 0x7FFFFFFF; counters[2] = (int32_t)0x80000000; counters[3] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass 2: write the compact records in ray-major / ascending-k order (== the reference's boolean-mask order)
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ void __launch_bounds__(256) compact_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                      const float* __restrict__ near, const float* __restrict__ far,
+                                                      int R, int S, const float* __restrict__ Rg, const float* __restrict__ Th,
+                                                      const int32_t* __restrict__ ray_base_local,
+                                                      const int32_t* __restrict__ chunk_off, const uint64_t* __restrict__ ray_mask,
+                                                      const int32_t* __restrict__ dense_vid, int64_t capacity,
+                                                      int32_t* __restrict__ ray_base, int32_t* __restrict__ cs_idx,
+                                                      int32_t* __restrict__ cs_vid, float4* __restrict__ cs_xs,
+                                                      const float4* __restrict__ cell_pts_unused) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    int base = ray_base_local[ray] + chunk_off[ray >> 10];
+    if (lane == 0) ray_base[ray] = base;
+    const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
+    const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
+    const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const uint64_t m = ray_mask[(size_t)ray * NCH + ch];
+        const int k = ch * 64 + lane;
+        if ((m >> lane) & 1ull) {
+            int rank = __popcll(m & ((1ull << lane) - 1ull));
+            int64_t c = (int64_t)base + rank;
+            if (c < capacity) {
+                float t = depth_at(nr, range, k, S);
+                float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
+                float xs, ys, zs;
+                to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+                int vid = dense_vid[(size_t)ray * S + k];
+                cs_idx[c] = ray * S + k;
+                cs_vid[c] = vid;
+                cs_xs[c] = make_float4(xs, ys, zs, 0.f);
+            }
+        }
+        base += __popcll(m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-sample warp: canonical point/direction, exact nearest T-pose vertex, pixel in the observation view
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restrict__ counters, const int32_t* __restrict__ cs_idx,
+                                                        const int32_t* __restrict__ cs_vid, const float4* __restrict__ cs_xs,
+                                                        const float* __restrict__ ray_d, int S, const float* __restrict__ Rg,
+                                                        const float* __restrict__ T2C, const float* __restrict__ C2S,
+                                                        const float* __restrict__ t_verts, const float* __restrict__ thdr,
+                                                        const int32_t* __restrict__ tcell_start,
+                                                        const float4* __restrict__ tcell_pts, int64_t capacity,
+                                                        float* __restrict__ geom, int32_t* __restrict__ cs_tvid) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const CellGrid g = load_grid(thdr);
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nv; c += (int64_t)gridDim.x * 256) {
+    const int ray = cs_idx[c] / S;
+    const int vid = cs_vid[c];
+    const float4 xs = cs_xs[c];
+    float vx, vy, vz;
+    rot_only(ray_d[ray * 3], ray_d[ray * 3 + 1], ray_d[ray * 3 + 2], Rg, vx, vy, vz);   // renderer.py:310
+    const float* P = T2C + (size_t)vid * 12;
+    float xc = P[0] * xs.x + P[1] * xs.y + P[2] * xs.z + P[9];
+    float yc = P[3] * xs.x + P[4] * xs.y + P[5] * xs.z + P[10];
+    float zc = P[6] * xs.x + P[7] * xs.y + P[8] * xs.z + P[11];
+    float ux = P[0] * vx + P[1] * vy + P[2] * vz;
+    float uy = P[3] * vx + P[4] * vy + P[5] * vz;
+    float uz = P[6] * vx + P[7] * vy + P[8] * vz;
+    // exact nearest T-pose vertex: the same-index vertex bounds the search ball (renderer.py:627)
+    float best = dist2_exact(xc, yc, zc, t_verts[vid * 3], t_verts[vid * 3 + 1], t_verts[vid * 3 + 2]);
+    int bid = vid;
+    float r = sqrtf(best) * 1.00001f + 1e-6f;
+    nn_search(g, tcell_start, tcell_pts, xc, yc, zc, r, best, bid);
+    const float* L = C2S + (size_t)bid * 12;
+    float hx = L[0] * xc + L[1] * yc + L[2] * zc + L[9];
+    float hy = L[3] * xc + L[4] * yc + L[5] * zc + L[10];
+    float hz = L[6] * xc + L[7] * yc + L[8] * zc + L[11];
+    float iz = hz + 1e-5f;                                 // renderer.py:699
+    float* o = geom + c * 8;
+    o[0] = xc; o[1] = yc; o[2] = zc; o[3] = ux; o[4] = uy; o[5] = uz; o[6] = hx / iz; o[7] = hy / iz;
+    cs_tvid[c] = bid;
+    }
+}
+
+}  // namespace
+
+extern "C" int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
+                                 float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
+                                 sherf_stream_t stream) {
+    SHERF_CHECK_ARG(verts && grid_hdr && cell_start && cell_pts && scratch);
+    SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
+    SHERF_CHECK_ARG((R == nullptr) == (Th == nullptr));
+    hipLaunchKernelGGL(build_cells_kernel, dim3(1), dim3(1024), 0, as_stream(stream), verts, n, R, Th, cell_size,
+                       grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
+                                       int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
+                                       const int32_t* cell_start, const float* cell_pts, int64_t capacity,
+                                       int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
+                                       int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
+                                       int32_t* scan_ws, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(ray_o && ray_d && near && far && Rg && Th && grid_hdr && cell_start && cell_pts);
+    SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && cs_vid && cs_xs && dense_vid && ray_mask && scan_ws);
+    SHERF_CHECK_ARG(R > 0 && S >= 2 && S <= 256 && (int64_t)R * S < 2147483647LL && capacity > 0);
+    hipStream_t st = as_stream(stream);
+    const int nch = (S + 63) / 64;
+    const int n_chunks = cdiv(R, 1024);
+    int32_t* base_local = scan_ws;              // [R]
+    int32_t* chunk_sum = scan_ws + R;           // [n_chunks]
+    const float4* cp = reinterpret_cast<const float4*>(cell_pts);
+    hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters);
+    hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
+#define SHERF_SAMPLE_LAUNCH(N)                                                                                        \
+    hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
+                       grid_hdr, cell_start, cp, ray_cnt, ray_mask, dense_vid)
+    if (nch == 1) SHERF_SAMPLE_LAUNCH(1); else if (nch == 2) SHERF_SAMPLE_LAUNCH(2);
+    else if (nch == 3) SHERF_SAMPLE_LAUNCH(3); else SHERF_SAMPLE_LAUNCH(4);
+    hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, ray_cnt, R, base_local, chunk_sum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, chunk_sum, n_chunks, counters);
+#define SHERF_COMPACT_LAUNCH(N)                                                                                        \
+    hipLaunchKernelGGL(compact_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,   \
+                       base_local, chunk_sum, ray_mask, dense_vid, capacity, ray_base, cs_idx, cs_vid,                 \
+                       reinterpret_cast<float4*>(cs_xs), cp)
+    if (nch == 1) SHERF_COMPACT_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_LAUNCH(2);
+    else if (nch == 3) SHERF_COMPACT_LAUNCH(3); else SHERF_COMPACT_LAUNCH(4);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_warp_geom(const int32_t* counters, const int32_t* cs_idx, const int32_t* cs_vid,
+                               const float* cs_xs, const float* ray_d, int S, const float* Rg, const float* T2C,
+                               const float* C2S, const float* t_verts, const float* tgrid_hdr,
+                               const int32_t* tcell_start, const float* tcell_pts, int64_t capacity, float* geom,
+                               int32_t* cs_tvid, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && cs_idx && cs_vid && cs_xs && ray_d && Rg && T2C && C2S && t_verts && tgrid_hdr &&
+                    tcell_start && tcell_pts && geom && cs_tvid);
+    SHERF_CHECK_ARG(S >= 2 && capacity > 0);
+    hipLaunchKernelGGL(warp_geom_kernel, dim3(min(8192, cdiv(capacity, 256))), dim3(256), 0, as_stream(stream), counters, cs_idx,
+                       cs_vid, reinterpret_cast<const float4*>(cs_xs), ray_d, S, Rg, T2C, C2S, t_verts, tgrid_hdr,
+                       tcell_start, reinterpret_cast<const float4*>(tcell_pts), capacity, geom, cs_tvid);
+    SHERF_LAUNCH_CHECK();
+}
