@@ -1,0 +1,159 @@
+"""rays/s of SHERF's volumetric-rendering hot path (ImportanceRenderer.forward) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one 512x512 frame x 64 samples/ray of synthetic input already resident
+in HBM (BASELINE.json config 2: single subject novel view).  With N > 1 every rank renders its own target view
+of the same subject (BASELINE config 4: views sharded across GPUs, weak scaling) and the step ends with the RCCL
+all_gather of the rendered [rays, 5] tiles.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_VALID_SAMPLE = 429248       # 214,624 MAC per valid sample (fusion + transformer + decoder)
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def make_inputs(cfg_name, theta, dev):
+    from oracle import fixtures, synth   # synthetic-input generators only (seeded data), not the oracle renderer
+    c = dict(fixtures.CONFIGS[cfg_name])
+    c['theta_tgt'] = theta
+    fixtures.CONFIGS['_bench'] = c
+    fx = fixtures.renderer_inputs('_bench')
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {k: ({kk: to(vv) for kk, vv in v.items()} if isinstance(v, dict) else to(v)) for k, v in fx['input_data'].items()}
+    return fx, d, to
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(lrank)
+    dev = torch.device('cuda', lrank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder, TriPlaneGenerator
+    from sherf_amd.voxel import SparseConvTensor
+    from sherf_amd import dist as sdist
+    from oracle import fixtures, synth
+
+    smpl = synth.make_synth_smpl(0)
+    fx, d, to = make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)
+    dec = NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
+    rend.to(dev).train(); dec.to(dev).train()
+    # voxelisation glue (triplane.py:129-137) through the product path
+    gen = TriPlaneGenerator.__new__(TriPlaneGenerator)
+    torch.nn.Module.__init__(gen); gen.renderer = rend
+    can = gen.canonical_obs_vertices(d)
+    sp_input, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
+    sp = SparseConvTensor(to(fx['vertex_feat']), sp_input['coord'], sp_input['out_sh'], 1)
+    planes, obs_feat = to(fx['planes']), to(fx['obs_feat'])
+    obs_img = d['obs_img_all'][:, 0]
+    ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
+    opts = dict(fx['options']); opts['mlp_precision'] = a.precision
+    R = ro.shape[1]; S = opts['depth_resolution']
+    rend.profile_mlp = True
+
+    def step():
+        with torch.no_grad():
+            rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)
+            tile = torch.cat([rgb[0], depth[0], acc[0]], 1)
+            if world > 1:
+                out = [torch.empty_like(tile) for _ in range(world)]
+                torch.distributed.all_gather(out, tile)
+        return tile
+
+    for _ in range(a.warmup):
+        step()
+    rend.mlp_events = []
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    nv = int(rend.last['ws']['counters'][0])
+    mlp_ms = float(np.mean([s.elapsed_time(e) for s, e in rend.mlp_events])) if rend.mlp_events else None
+    if rank == 0:
+        res = dict(metric='rendered rays/sec at 512x512x64 samples (ImportanceRenderer.forward)', value=world * R * a.steps / dt,
+                   unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps,
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16x3 MFMA (fp32-grade split bf16), fp32 elsewhere'
+                   if a.precision == 'bf16x3' else 'bf16 MFMA, fp32 elsewhere', data='synthetic',
+                   config=dict(workload=f'{a.config}: 512x512 rays x 64 samples, synthetic SMPL subject, novel view, all feature branches, '
+                                        f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
+                               parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision))
+        if mlp_ms:
+            ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_mlp_bytes_per_launch.json')
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            res['roofline'] = dict(kernel='nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                                   frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, kernel_ms=mlp_ms,
+                                   algorithmic_flop_per_launch=nv * FLOP_PER_VALID_SAMPLE)
+        if not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(a.config)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cfg_name):
+    """The oracle (CPU port of the reference algorithm, brute-force K-NN included) timed on the host cores, on a
+    bounded sample of the same workload: a centred 48x48-ray crop of the 512x512x64 frame."""
+    from oracle import fixtures, sherf_oracle as O
+    import json as _json
+    shapes = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'param_shapes.json')))
+    state = {n: torch.from_numpy(fixtures.seeded_param(n, s)) for n, s in shapes.items() if fixtures.seeded_param(n, s) is not None}
+    fx = fixtures.renderer_inputs(cfg_name)
+    c = fx['cfg']
+    H, W, n = c['H'], c['W'], 48
+    ys, xs = np.meshgrid(np.arange(H // 2 - n // 2, H // 2 + n // 2), np.arange(W // 2 - n // 2, W // 2 + n // 2), indexing='ij')
+    sel = (ys * W + xs).reshape(-1)
+    d = {k: (dict(v) if isinstance(v, dict) else v) for k, v in fx['input_data'].items()}
+    for k in ('ray_o_all', 'ray_d_all', 'near_all', 'far_all'):
+        d[k] = np.ascontiguousarray(d[k][:, :, sel])
+    fx = dict(fx); fx['input_data'] = d
+    torch.set_num_threads(os.cpu_count())
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True, keep=False)
+    dt = time.perf_counter() - t0
+    return dict(value=len(sel) / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'centred {n}x{n}-ray crop of the {H}x{W}x{c["S"]} frame ({len(sel)} rays, {int(r["mask"].sum())} valid samples), '
+                       f'oracle/sherf_oracle.py fp32 torch-CPU, {dt:.1f} s')
+
+
+if __name__ == '__main__':
+    main()

@@ -140,9 +140,10 @@ int sherf_composite_compact(const int32_t* counters, const int32_t* ray_base, co
                             float* depth, float* acc, sherf_stream_t stream);
 
 /* MipRayMarcher2.forward on dense inputs (ray_marcher.py:67-70): colors[R][S][3], sigma[R][S], depths[R][S],
- * rays_d[R][3] -> rgb[R][3], depth[R], weights[R][S].  dmin/dmax = global min/max of depths (ray_marcher.py:57). */
+ * rays_d[R][3] -> rgb[R][3], depth[R], weights[R][S].  dminmax[2] (device) = global min/max of depths
+ * (ray_marcher.py:57). */
 int sherf_composite_dense(const float* colors, const float* sigma, const float* depths, const float* rays_d,
-                          int R, int S, int white_back, float dmin, float dmax, float* rgb, float* depth,
+                          int R, int S, int white_back, const float* dminmax, float* rgb, float* depth,
                           float* weights, sherf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

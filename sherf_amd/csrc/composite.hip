@@ -54,11 +54,12 @@ __global__ void __launch_bounds__(256) composite_compact_kernel(const int32_t* _
 
 __global__ void __launch_bounds__(256) composite_dense_kernel(const float* __restrict__ colors, const float* __restrict__ sigma,
                                                               const float* __restrict__ depths, const float* __restrict__ rays_d,
-                                                              int R, int S, int white_back, float dmin, float dmax,
+                                                              int R, int S, int white_back, const float* __restrict__ dminmax,
                                                               float* __restrict__ rgb, float* __restrict__ depth,
                                                               float* __restrict__ weights) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= R) return;
+    const float dmin = dminmax[0], dmax = dminmax[1];
     const float d0 = rays_d[r * 3], d1 = rays_d[r * 3 + 1], d2 = rays_d[r * 3 + 2];
     const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     const float* c = colors + (size_t)r * S * 3;
@@ -97,11 +98,11 @@ extern "C" int sherf_composite_compact(const int32_t* counters, const int32_t* r
 }
 
 extern "C" int sherf_composite_dense(const float* colors, const float* sigma, const float* depths, const float* rays_d,
-                                     int R, int S, int white_back, float dmin, float dmax, float* rgb, float* depth,
+                                     int R, int S, int white_back, const float* dminmax, float* rgb, float* depth,
                                      float* weights, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(colors && sigma && depths && rays_d && rgb && depth && weights);
+    SHERF_CHECK_ARG(colors && sigma && depths && rays_d && dminmax && rgb && depth && weights);
     SHERF_CHECK_ARG(R > 0 && S >= 1);
     hipLaunchKernelGGL(composite_dense_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), colors, sigma, depths,
-                       rays_d, R, S, white_back, dmin, dmax, rgb, depth, weights);
+                       rays_d, R, S, white_back, dminmax, rgb, depth, weights);
     SHERF_LAUNCH_CHECK();
 }

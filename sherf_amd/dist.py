@@ -1,0 +1,88 @@
+"""Multi-GPU sharding of the render path: one process per GPU, `torch.distributed` over RCCL (backend "nccl" on
+ROCm) / xGMI.  The reference has NO inference parallelism (eval runs on rank 0 only, training_loop.py:311-328);
+rays are independent end to end, so the path shards with no data-path exchange and ONE collective per frame:
+an all_gather of the rendered [rays, 5] (rgb, depth, acc) tiles -- 5.24 MB total at 512x512, latency bound.
+
+Two partitions:
+  * views  : a batch of target views of one subject, view v -> rank v % world  (BASELINE config 4)
+  * rays   : one frame, interleaved tiles of `tile` consecutive rays round-robin over ranks, which balances the
+             body's footprint (contiguous row blocks would not: the subject covers a fraction of the frame).
+Per-frame shared state (planes, feature map, voxel tables, SMPL tables, weights, < 300 MB) is replicated.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_views(n_views, rank=None, world_size=None):
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return list(range(rank, n_views, world_size))
+
+
+def ray_tiles(n_rays, rank=None, world_size=None, tile=1024):
+    """Indices (int64, ascending) of the rays this rank renders under the interleaved-tile partition."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    idx = torch.arange(n_rays)
+    return idx[((idx // tile) % world_size) == rank]
+
+
+def padded_shard_size(n_rays, world_size, tile=1024):
+    return max(int((((torch.arange(n_rays) // tile) % world_size) == r).sum()) for r in range(world_size))
+
+
+def gather_rays(local, n_rays, tile=1024):
+    """local: [n_local, C] results for `ray_tiles(n_rays)` on every rank -> full [n_rays, C] on every rank (one all_gather)."""
+    rank, w = world()
+    if w == 1:
+        return local
+    m = padded_shard_size(n_rays, w, tile)
+    buf = torch.zeros(m, local.shape[1], dtype=local.dtype, device=local.device)
+    buf[:local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(w)]
+    dist.all_gather(out, buf)
+    full = torch.empty(n_rays, local.shape[1], dtype=local.dtype, device=local.device)
+    for r in range(w):
+        idx = ray_tiles(n_rays, r, w, tile).to(local.device)
+        full[idx] = out[r][:idx.numel()]
+    return full
+
+
+def gather_views(local_frames, n_views):
+    """local_frames: {view index: [R, C]} rendered on this rank (view v lives on rank v % world) -> list of all frames."""
+    rank, w = world()
+    if w == 1:
+        return [local_frames[v] for v in range(n_views)]
+    per = (n_views + w - 1) // w
+    any_frame = next(iter(local_frames.values()))
+    buf = torch.zeros(per, *any_frame.shape, dtype=any_frame.dtype, device=any_frame.device)
+    for i, v in enumerate(shard_views(n_views, rank, w)):
+        buf[i] = local_frames[v]
+    out = [torch.empty_like(buf) for _ in range(w)]
+    dist.all_gather(out, buf)
+    return [out[v % w][v // w] for v in range(n_views)]
+
+
+def allreduce_flat_grads(params, world_size=None):
+    """The reference's manual data-parallel gradient exchange (training_loop.py:374-383): flatten every existing
+    grad, one all_reduce(SUM), divide by the number of GPUs, nan_to_num, scatter back."""
+    _, w = world()
+    world_size = w if world_size is None else world_size
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return
+    flat = torch.cat([p.grad.flatten() for p in params])
+    if world_size > 1:
+        dist.all_reduce(flat)
+        flat /= world_size
+    torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+    for p, g in zip(params, flat.split([p.numel() for p in params])):
+        p.grad = g.reshape(p.shape)

@@ -1,0 +1,197 @@
+"""Drop-in counterparts of /root/reference/sherf/training/triplane.py for the hot path:
+
+  * `NeRFDecoder`        (triplane.py:267-316)  -- parameter container; its math runs inside sherf_nerf_mlp.
+  * `TriPlaneGenerator`  (triplane.py:29-236)   -- same constructor / mapping / synthesis / forward signatures and
+    output dict; the per-frame glue of `synthesis` (triplane.py:105-137, 150-172, 174-217: per-vertex features,
+    voxelisation, image reshapes) feeds the MI355X `ImportanceRenderer`.
+
+The feature PRODUCERS (StyleGAN2 backbone, ResNet18 encoders, super-resolution) are outside the hot path
+(SURVEY.md section 8f rank 2): they are taken from the reference package when it is importable, or injected.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .ray_sampler import RaySampler
+from .renderer import ImportanceRenderer, V
+from .voxel import SparseConvTensor
+
+
+class NeRFDecoder(nn.Module):
+    """triplane.py:267-283 (W=128, skip at layer 4, 39-d position encoding + 32-d feature)."""
+
+    def __init__(self, n_features=32):
+        super().__init__()
+        W = 128
+        self.with_viewdirs = True
+        self.skips = [4]
+        cin = n_features + 39
+        self.pts_linears = nn.ModuleList([nn.Linear(cin, W)] + [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + cin, W)
+                                                               for i in range(7)])
+        self.views_linear = nn.Linear(n_features + W + 27, W // 2)
+        self.feature_linear = nn.Linear(W, W)
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+
+    def forward(self, *a, **k):
+        raise RuntimeError('NeRFDecoder is evaluated inside the fused HIP kernel (sherf_nerf_mlp); '
+                           'pass it to ImportanceRenderer.forward as `decoder`')
+
+
+def compute_normal(vertices, faces):
+    """renderer.py:50-63: area-weighted-by-count vertex normals from unit face normals. vertices [B,V,3], faces [F,3]."""
+    tris = vertices[:, faces]
+    n = torch.cross(tris[:, :, 1] - tris[:, :, 0], tris[:, :, 2] - tris[:, :, 0], dim=-1)
+    n = n / torch.sqrt((n ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
+    norm = torch.zeros_like(vertices)
+    for c in range(3):
+        norm.index_add_(1, faces[:, c], n)
+    return norm / torch.sqrt((norm ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
+
+
+class TriPlaneGenerator(nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, use_1d_feature, use_2d_feature, use_3d_feature, use_trans, use_NeRF_decoder,
+                 img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={},
+                 backbone=None, encoder_2d=None, encoder_2d_feature=None, superresolution=None, smpl=None, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.renderer = ImportanceRenderer(use_1d_feature, use_2d_feature, use_3d_feature, use_trans, use_NeRF_decoder, smpl=smpl)
+        self.ray_sampler = RaySampler()
+        self.encoder_2d = encoder_2d
+        self.encoder_2d_feature = encoder_2d_feature
+        self.conv1d_projection = nn.Conv1d(96, 32, 1)
+        self.backbone = backbone
+        self.superresolution = superresolution
+        if self.backbone is None:
+            try:        # the reference's own StyleGAN2 generator, when /root/reference/sherf is on sys.path
+                from training.networks_stylegan2 import Generator as StyleGAN2Backbone
+                self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3,
+                                                  mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+            except ImportError:
+                pass
+        if not use_NeRF_decoder:
+            raise NotImplementedError('OSGDecoder path is unused by SHERF (--use_nerf_decoder True in every script)')
+        self.decoder = NeRFDecoder(32)
+        self.neural_rendering_resolution = 64
+        self.rendering_kwargs = rendering_kwargs
+        self.use_1d_feature, self.use_2d_feature, self.use_3d_feature = use_1d_feature, use_2d_feature, use_3d_feature
+        self._last_planes = None
+
+    def mapping(self, z, c, input_img=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        z = self.encoder_2d(input_img)
+        if self.rendering_kwargs.get('c_gen_conditioning_zero', True):
+            c = torch.zeros_like(c)
+        return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+
+    # ---- triplane.py:111-137 ------------------------------------------------------------------
+    def vertex_features(self, input_data, obs_input_img, obs_input_feature):
+        """Per-vertex 32-d features (zero for back-facing vertices) + the back-face mask."""
+        smpl = self.renderer.SMPL_NEUTRAL
+        verts = input_data['obs_vertices'].float()                                            # [1,V,3]
+        Rc, Tc, K = input_data['obs_R_all'][:, 0].float(), input_data['obs_T_all'][:, 0].float(), input_data['obs_K_all'][:, 0].float()
+        cam = torch.matmul(verts, Rc.transpose(1, 2)) + Tc.transpose(1, 2)                    # [1,V,3]
+        normal = compute_normal(verts, smpl['f'])
+        ncam = torch.matmul(normal, Rc.transpose(1, 2))
+        mask = (ncam * cam).sum(-1) < 0                                                       # renderer.py:693-695
+        h = torch.matmul(cam, K.transpose(1, 2))
+        uv = h[..., :2] / (h[..., 2:] + 1e-5)
+        Himg, Wimg = obs_input_img.shape[-2:]
+        g = 2.0 * uv.unsqueeze(2) / torch.tensor([Wimg, Himg], device=uv.device, dtype=torch.float32) - 1.0
+        vf = F.grid_sample(obs_input_feature, g, align_corners=True)[..., 0].permute(0, 2, 1)
+        vrgb = F.grid_sample(obs_input_img, g, align_corners=True)[..., 0].permute(0, 2, 1)
+        sh = vrgb.shape
+        vrgb = self.renderer.rgb_enc(vrgb.reshape(-1, 3)).reshape(*sh[:2], 33)[..., :32]
+        f3d = self.conv1d_projection(torch.cat((vf, vrgb), -1).permute(0, 2, 1)).permute(0, 2, 1)
+        f3d = f3d * mask.unsqueeze(-1).to(f3d.dtype)                                          # triplane.py:126
+        return f3d, mask
+
+    def canonical_obs_vertices(self, input_data):
+        """coarse_deform_target2c(obs_params, obs_vertices, t_params, smpl_obs_pts) (triplane.py:129-132) through the
+        per-vertex affine table built by the HIP SMPL kernels (each vertex is its own nearest vertex)."""
+        r = self.renderer
+        dev = input_data['obs_vertices'].device
+        smpl = r._smpl(dev)
+        op, tp = input_data['obs_params'], input_data['t_params']
+        f32 = lambda t: t.detach().float().contiguous()
+        poses = torch.stack([f32(op['poses']).view(72), f32(tp['poses']).view(72)])
+        shapes = torch.stack([f32(op['shapes']).view(10), f32(tp['shapes']).view(10)])
+        A = torch.zeros(2, 24, 12, device=dev); pf = torch.zeros(2, 207, device=dev)
+        PO = torch.zeros(2, V, 3, device=dev); SO = torch.zeros(2, V, 3, device=dev); T2C = torch.zeros(V, 12, device=dev)
+        P, st = _lib.ptr, _lib.stream()
+        _lib.call('sherf_smpl_bones', P(poses), P(shapes), 2, P(smpl['J_template']), P(smpl['J_shapedirs']), P(smpl['parents_i32']),
+                  P(A), P(pf), st)
+        _lib.call('sherf_smpl_offsets', P(smpl['posedirs_flat']), P(smpl['shapedirs']), P(pf), P(shapes), 2, P(PO), P(SO), st)
+        _lib.call('sherf_smpl_t2c_table', P(smpl['weights']), P(A[0]), P(A[1]), P(PO[0]), P(SO[0]), P(PO[1]), P(T2C), st)
+        xs = torch.matmul(f32(input_data['obs_vertices']).view(V, 3) - f32(op['Th']).view(1, 3), f32(op['R']).view(3, 3))
+        Pm, q = T2C[:, :9].view(V, 3, 3), T2C[:, 9:]
+        return (torch.einsum('vij,vj->vi', Pm, xs) + q).unsqueeze(0)
+
+    def prepare_sp_input(self, vertex, xyz):
+        """triplane.py:174-217 (big_box=True): 5 mm voxel coords of `xyz` inside the +-5 cm box of `vertex`."""
+        min_xyz = torch.min(vertex, dim=1)[0] - 0.05
+        max_xyz = torch.max(vertex, dim=1)[0] + 0.05
+        bounds = torch.cat([min_xyz.unsqueeze(1), max_xyz.unsqueeze(1)], 1)
+        dhw = xyz[:, :, [2, 1, 0]]
+        min_dhw, max_dhw = min_xyz[:, [2, 1, 0]], max_xyz[:, [2, 1, 0]]
+        vs = torch.tensor([0.005, 0.005, 0.005], device=dhw.device)
+        coord = torch.round((dhw - min_dhw.unsqueeze(1)) / vs).to(torch.int32)
+        out_sh = torch.ceil((max_dhw - min_dhw) / vs).to(torch.int32)
+        out_sh = (out_sh | 31) + 1
+        sh = dhw.shape
+        idx = torch.cat([torch.full([sh[1]], i) for i in range(sh[0])]).to(coord)
+        coord = torch.cat([idx[:, None], coord.view(-1, 3)], 1)
+        out_sh, _ = torch.max(out_sh, dim=0)
+        return {'coord': coord, 'out_sh': out_sh.tolist(), 'batch_size': sh[0], 'bounds': bounds}, None
+
+    def synthesis(self, ws, input_data, c, neural_rendering_resolution=None, use_sr_module=True, update_emas=False,
+                  cache_backbone=False, use_cached_backbone=False, test_flag=False, planes=None, **synthesis_kwargs):
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        ray_origins, ray_directions = input_data['ray_o_all'][:, 0], input_data['ray_d_all'][:, 0]
+        near, far = input_data['near_all'][:, 0], input_data['far_all'][:, 0]
+        N, M, _ = ray_origins.shape
+        if planes is None:
+            if use_cached_backbone and self._last_planes is not None:
+                planes = self._last_planes
+            else:
+                planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+        if cache_backbone:
+            self._last_planes = planes
+        obs_input_img = input_data['obs_img_all'][:, 0]
+        obs_input_feature = self.encoder_2d_feature(obs_input_img, extract_feature=True)
+        f3d, mask = self.vertex_features(input_data, obs_input_img, obs_input_feature)
+        can = self.canonical_obs_vertices(input_data)
+        sp_input, _ = self.prepare_sp_input(input_data['t_vertices'].float(), can)
+        sp = SparseConvTensor(f3d.reshape(-1, f3d.shape[-1]), sp_input['coord'], sp_input['out_sh'], sp_input['batch_size'])
+        planes = planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+        if test_flag:
+            self.rendering_kwargs.update({'density_noise': 0})
+        rgb, depth, acc = self.renderer(planes, obs_input_img, obs_input_feature, sp, mask, sp_input, self.decoder, ray_origins,
+                                        ray_directions, near, far, input_data, self.rendering_kwargs)
+        H, W = input_data['obs_img_all'].shape[-2:]
+        feature_image = rgb.permute(0, 2, 1).reshape(N, rgb.shape[-1], H, W).contiguous()
+        depth_image = depth.permute(0, 2, 1).reshape(N, 1, H, W)
+        weights_image = acc.permute(0, 2, 1).reshape(N, 1, H, W)
+        rgb_image = feature_image[:, :3]
+        if use_sr_module:
+            if self.superresolution is None:
+                raise RuntimeError('no superresolution module attached (every SHERF script passes --use_sr_module False)')
+            sr_image = self.superresolution(rgb_image, feature_image, ws, noise_mode=self.rendering_kwargs['superresolution_noise_mode'],
+                                            **{k: synthesis_kwargs[k] for k in synthesis_kwargs if k != 'noise_mode'})
+        else:
+            sr_image = rgb_image
+        return {'image': sr_image, 'image_raw': rgb_image, 'image_depth': depth_image, 'weights_image': weights_image}
+
+    def forward(self, input_data, z, c, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, use_sr_module=True,
+                update_emas=False, cache_backbone=False, use_cached_backbone=False, test_flag=False, **synthesis_kwargs):
+        input_img = input_data['obs_img_all'][:, 0]
+        ws = self.mapping(z, c, input_img=input_img, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff,
+                          update_emas=update_emas)
+        return self.synthesis(ws, input_data, c, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
+                              use_sr_module=use_sr_module, cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone,
+                              test_flag=test_flag, **synthesis_kwargs)

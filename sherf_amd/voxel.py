@@ -1,0 +1,164 @@
+"""Sparse voxel encoder: drop-in parameter container for the reference's `SparseConvNet`
+(training/volumetric_rendering/renderer.py:708-871) and its HIP execution (sherf_amd/csrc/svox.hip).
+
+The module tree reproduces the reference's state_dict keys (`encoder_3d.conv0.0.weight` ... spconv KRSC weight
+shape [out, 3, 3, 3, in]; `encoder_3d.conv0.1.{weight,bias,running_mean,running_var,num_batches_tracked}`)
+so `copy_params_and_buffers(require_all=True)` (training_loop.py:207-208) keeps working.  conv4 / down3 exist
+but never influence the output with num_layers=4 (renderer.py:778-792) and are not executed.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class SparseConvTensor:
+    """Minimal stand-in for spconv.core.SparseConvTensor as built at triplane.py:137."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size=1):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+
+
+class _SpConv(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = cin, cout, stride
+        self.weight = nn.Parameter(torch.empty(cout, 3, 3, 3, cin))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class SubMConv3d(_SpConv):
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1)
+
+
+class SparseConv3d(_SpConv):
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 2)
+
+
+def _bn(c):
+    return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+
+
+def _multi_conv(cin, cout, n):
+    mods = []
+    for i in range(n):
+        mods += [SubMConv3d(cin if i == 0 else cout, cout), _bn(cout), nn.ReLU()]
+    return nn.Sequential(*mods)
+
+
+def _stride_conv(cin, cout):
+    return nn.Sequential(SparseConv3d(cin, cout), _bn(cout), nn.ReLU())
+
+
+# executed part of the network: (module name, number of convs in it); a tap follows conv1, conv2, conv3
+_PLAN = (('conv0', 2), ('down0', 1), ('conv1', 2), ('down1', 1), ('conv2', 3), ('down2', 1), ('conv3', 3))
+
+
+class SparseConvNet(nn.Module):
+    def __init__(self, num_layers=4):
+        super().__init__()
+        assert num_layers == 4, 'the reference instantiates SparseConvNet(num_layers=4) (renderer.py:270)'
+        self.num_layers = num_layers
+        self.conv0 = _multi_conv(32, 32, 2); self.down0 = _stride_conv(32, 32)
+        self.conv1 = _multi_conv(32, 32, 2); self.down1 = _stride_conv(32, 64)
+        self.conv2 = _multi_conv(64, 64, 3); self.down2 = _stride_conv(64, 96)
+        self.conv3 = _multi_conv(96, 96, 3); self.down3 = _stride_conv(96, 96)
+        self.conv4 = _multi_conv(96, 96, 3)
+        self._packed = None
+
+    # ---- host-side caches -------------------------------------------------------------------
+    def _pack(self, device):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        if self._packed is not None and self._packed['key'] == key:
+            return self._packed
+        layers = []
+        for name, n in _PLAN:
+            seq = getattr(self, name)
+            for i in range(n):
+                conv, bn = seq[3 * i], seq[3 * i + 1]
+                w = conv.weight.detach().to(device=device, dtype=torch.float32)
+                wt = w.permute(1, 2, 3, 4, 0).reshape(27, conv.in_channels, conv.out_channels).contiguous()
+                layers.append(dict(wt=wt, cin=conv.in_channels, cout=conv.out_channels, down=conv.stride == 2, bn=bn,
+                                   gamma=bn.weight.detach().float().contiguous(), beta=bn.bias.detach().float().contiguous(),
+                                   tap=(name in ('conv1', 'conv2', 'conv3') and i == n - 1)))
+        self._packed = dict(key=key, layers=layers)
+        return self._packed
+
+    def encode(self, sp, fold_mats, ws):
+        """Runs the encoder on a SparseConvTensor; returns the three tapped levels as `_lib.VoxLevel`s whose rows
+        are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see ImportanceRenderer._fold_weights."""
+        feat = sp.features.detach().float().contiguous()
+        coord = sp.indices.to(torch.int32).contiguous()
+        dev = feat.device
+        N = feat.shape[0]
+        pk = self._pack(dev)
+        shapes = [tuple(sp.spatial_shape)]
+        for _ in range(3):
+            shapes.append(tuple((d - 1) // 2 + 1 for d in shapes[-1]))
+        L = ws.voxel_levels(shapes, N, dev)
+        st = _lib.stream()
+        P = _lib.ptr
+        training = self.training
+        # level 0: unique voxels, summed features, multiplicities
+        l0 = L[0]
+        l0['bitmap'].zero_(); l0['mult'].zero_(); l0['xa'][:N].zero_()
+        D, H, W = shapes[0]
+        _lib.call('sherf_svox_mark_rows', P(coord), N, D, H, W, P(l0['bitmap']), st)
+        _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), st)
+        _lib.call('sherf_svox_keys', P(l0['bitmap']), P(l0['prefix']), l0['nwords'], P(l0['keys']), st)
+        _lib.call('sherf_svox_scatter_rows', P(coord), P(feat), N, 32, D, H, W, P(l0['bitmap']), P(l0['prefix']),
+                  P(l0['xa']), P(l0['mult']), st)
+        l0['n_total'].fill_(N)
+        cur, lev = 'xa', 0
+        taps = []
+        for li, ly in enumerate(pk['layers']):
+            src = L[lev]
+            if ly['down']:
+                dst = L[lev + 1]
+                dst['bitmap'].zero_()
+                _lib.call('sherf_svox_mark_down', P(src['keys']), P(src['n_rows']), *shapes[lev], P(dst['bitmap']), src['cap'], st)
+                _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), st)
+                _lib.call('sherf_svox_keys', P(dst['bitmap']), P(dst['prefix']), dst['nwords'], P(dst['keys']), st)
+                out_buf = dst['xa']
+                _lib.call('sherf_svox_conv', P(dst['keys']), P(dst['n_rows']), *shapes[lev + 1], P(src['bitmap']), P(src['prefix']),
+                          *shapes[lev], P(src[cur]), ly['cin'], P(ly['wt']), ly['cout'], 1, dst['cap'], P(out_buf), st)
+                lev += 1; cur = 'xa'
+                tgt = L[lev]
+            else:
+                tgt = src
+                nxt = 'xb' if cur == 'xa' else 'xa'
+                _lib.call('sherf_svox_conv', P(src['keys']), P(src['n_rows']), *shapes[lev], P(src['bitmap']), P(src['prefix']),
+                          *shapes[lev], P(src[cur]), ly['cin'], P(ly['wt']), ly['cout'], 0, src['cap'], P(src[nxt]), st)
+                cur = nxt
+            bn = ly['bn']
+            stats = ws.bn_stats(li, ly['cout'], dev)
+            if not training:
+                stats[0].copy_(bn.running_mean); stats[1].copy_(bn.running_var)
+            mult = P(tgt['mult']) if lev == 0 else None
+            n_total = tgt['n_total'] if lev == 0 else tgt['n_rows']
+            _lib.call('sherf_svox_bn_relu', P(tgt[cur]), P(tgt['n_rows']), mult, P(n_total), ly['cout'], P(ly['gamma']),
+                      P(ly['beta']), P(stats), 1 if training else 0, st)
+            if training and torch.is_grad_enabled() and bn.track_running_stats:
+                with torch.no_grad():     # nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance)
+                    n = n_total.float()
+                    bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * stats[0])
+                    bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * stats[1] * n / (n - 1))
+                    bn.num_batches_tracked += 1
+            if ly['tap']:
+                taps.append((lev, cur))
+        levels = (_lib.VoxLevel * 3)()
+        keep = []
+        for i, (lev, cur) in enumerate(taps):
+            rows = torch.matmul(L[lev][cur], fold_mats[i])             # [cap, C] @ [C, 96]: plain library GEMM
+            keep.append(rows)
+            levels[i].bitmap = L[lev]['bitmap'].data_ptr(); levels[i].prefix = L[lev]['prefix'].data_ptr()
+            levels[i].rows = rows.data_ptr()
+            levels[i].D, levels[i].H, levels[i].W = shapes[lev]
+        return levels, keep, dict(levels=L, taps=taps, shapes=shapes)

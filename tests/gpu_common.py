@@ -1,0 +1,96 @@
+"""Shared harness for the `-m gpu` parity tests: same seeded inputs and weights for the oracle (CPU restatement
+pinned to the reference) and for the HIP path behind the drop-in classes. Nothing here reads /root/reference."""
+import functools
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import fixtures, sherf_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+@functools.lru_cache(None)
+def seeded_state():
+    shapes = json.load(open(os.path.join(GOLDEN, 'param_shapes.json')))
+    return {n: torch.from_numpy(fixtures.seeded_param(n, s)) for n, s in shapes.items() if fixtures.seeded_param(n, s) is not None}
+
+
+@functools.lru_cache(None)
+def smpl():
+    from oracle import synth
+    return synth.make_synth_smpl(0)
+
+
+@functools.lru_cache(4)
+def fixture(cfg):
+    return fixtures.renderer_inputs(cfg, smpl())
+
+
+@functools.lru_cache(4)
+def oracle_render(cfg, training=True):
+    return O.render_from_fixture(fixture(cfg), seeded_state(), training=training, keep=True)
+
+
+def to_cuda(x):
+    if isinstance(x, dict):
+        return {k: to_cuda(v) for k, v in x.items()}
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    if isinstance(x, torch.Tensor):
+        return x.cuda()
+    return x
+
+
+@functools.lru_cache(None)
+def hip_modules(precision='bf16x3'):
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl(), mlp_precision=precision)
+    dec = NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.')
+    fixtures.load_seeded_state(dec, 'decoder.')
+    return rend.cuda().train(), dec.cuda().train()
+
+
+def hip_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, options=None):
+    """Runs sherf_amd.ImportanceRenderer.forward on the fixture; the voxel coordinates come from the oracle's
+    prepare_sp_input so this isolates the renderer (the TriPlaneGenerator glue has its own test)."""
+    from sherf_amd.voxel import SparseConvTensor
+    fx = fx or fixture(cfg)
+    rend, dec = hip_modules(precision)
+    rend.train(training)
+    if sp_input is None:
+        sp_input = oracle_render(cfg)['sp_input']
+    d = to_cuda(fx['input_data'])
+    sp = SparseConvTensor(to_cuda(fx['vertex_feat']), sp_input['coord'].cuda(), sp_input['out_sh'], 1)
+    spi = dict(coord=sp_input['coord'].cuda(), out_sh=sp_input['out_sh'], batch_size=1, bounds=sp_input['bounds'].cuda()[None])
+    opts = dict(fx['options'])
+    opts['mlp_precision'] = precision
+    if options:
+        opts.update(options)
+    with torch.no_grad():
+        rgb, depth, acc = rend(to_cuda(fx['planes']), d['obs_img_all'][:, 0], to_cuda(fx['obs_feat']), sp, None, spi, dec,
+                               d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, opts)
+    torch.cuda.synchronize()
+    return dict(rgb=rgb[0].cpu(), depth=depth[0, :, 0].cpu(), acc=acc[0, :, 0].cpu(), last=rend.last, rend=rend)
+
+
+def untile_tokens(tokens, n):
+    """tokens[tile][3][8][32][4] -> [n,3,32]."""
+    tiles = (n + 31) // 32
+    t = tokens[:tiles * 3072].view(tiles, 3, 8, 32, 4).permute(0, 3, 1, 2, 4).reshape(tiles * 32, 3, 32)
+    return t[:n]
+
+
+def untile_extras(extras, n):
+    tiles = (n + 31) // 32
+    return extras[:tiles * 384].view(tiles, 12, 32).permute(0, 2, 1).reshape(tiles * 32, 12)[:n]
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))

@@ -1,0 +1,70 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header declares,
+and the product modules expose exactly the reference's parameter / buffer names and shapes (the checkpoint
+contract of training_loop.py:207-208, dumped from the unmodified reference by oracle/make_golden.py)."""
+import ctypes
+import json
+import os
+import pickle
+
+import pytest
+import torch
+
+from sherf_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 23
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(lib, name), name
+    l = _lib.lib()
+    assert l.sherf_version() >= 100
+
+
+def test_bad_arguments_return_error_codes_not_crashes():
+    l = _lib.lib()
+    assert l.sherf_smpl_bones(None, None, 3, None, None, None, None, None, None) == -1
+    assert b'bad argument' in l.sherf_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.call('sherf_svox_scan', None, 0, None, None, None)
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    with pytest.raises(RuntimeError, match='not on a GPU'):
+        _lib.ptr(torch.zeros(4))
+    from sherf_amd.ray_sampler import RaySampler
+    with pytest.raises(RuntimeError, match='GPU only'):
+        RaySampler()(torch.eye(4)[None], torch.eye(3)[None], 4)
+
+
+def test_parameter_names_match_reference(golden_dir):
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder
+    ref = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl={})
+    dec = NeRFDecoder(32)
+    ours = {'renderer.' + k: list(v.shape) for k, v in rend.state_dict().items()}
+    ours.update({'decoder.' + k: list(v.shape) for k, v in dec.state_dict().items()})
+    assert set(ours) == set(ref), (sorted(set(ref) - set(ours))[:5], sorted(set(ours) - set(ref))[:5])
+    for k in ref:
+        assert ours[k] == ref[k], (k, ours[k], ref[k])
+
+
+def test_renderer_is_picklable_like_reference_snapshots():
+    from sherf_amd.renderer import ImportanceRenderer
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl={})
+    r2 = pickle.loads(pickle.dumps(rend))               # training_loop.py:566-579 pickles the whole generator
+    assert set(r2.state_dict()) == set(rend.state_dict())
+
+
+def test_mlp_stream_layout_matches_packer(golden_dir):
+    from sherf_amd import mlp_pack
+    from oracle import fixtures
+    n = ctypes.c_int32(0)
+    nkb = (ctypes.c_int32 * 64)()
+    assert _lib.lib().sherf_mlp_stream_layout(ctypes.byref(n), nkb, 64) == 0
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    sd = {k: fixtures.seeded_param(k, s) for k, s in shapes.items() if fixtures.seeded_param(k, s) is not None}
+    _, _, nkbs = mlp_pack.pack(sd)
+    assert n.value == len(nkbs) and list(nkb[:n.value]) == nkbs
