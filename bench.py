@@ -138,14 +138,14 @@ def cpu_baseline(cfg_name):
     state = {n: torch.from_numpy(fixtures.seeded_param(n, s)) for n, s in shapes.items() if fixtures.seeded_param(n, s) is not None}
     fx = fixtures.renderer_inputs(cfg_name)
     c = fx['cfg']
-    H, W, n = c['H'], c['W'], 48
+    H, W, n = c['H'], c['W'], 64
     ys, xs = np.meshgrid(np.arange(H // 2 - n // 2, H // 2 + n // 2), np.arange(W // 2 - n // 2, W // 2 + n // 2), indexing='ij')
     sel = (ys * W + xs).reshape(-1)
     d = {k: (dict(v) if isinstance(v, dict) else v) for k, v in fx['input_data'].items()}
     for k in ('ray_o_all', 'ray_d_all', 'near_all', 'far_all'):
         d[k] = np.ascontiguousarray(d[k][:, :, sel])
     fx = dict(fx); fx['input_data'] = d
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(16, os.cpu_count()))     # more threads only add contention at these matrix sizes
     t0 = time.perf_counter()
     with torch.no_grad():
         r = O.render_from_fixture(fx, state, training=True, keep=False)

@@ -75,7 +75,8 @@ int sherf_smpl_c2s_table(const float* weights, const float* A_big, const float* 
  *   cell_start[SHERF_MAX_CELLS+1] int32, cell_pts[n] float4 (x,y,z,bitcast(id)) sorted by cell. */
 int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
                       float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
-                      sherf_stream_t stream);
+                      uint32_t* near_mask, sherf_stream_t stream);
+/* near_mask (nullable): uint32[SHERF_MAX_CELLS/32], bit c set iff a vertex lives in the 3x3x3 neighbourhood of cell c */
 
 /* a4+a5+a6: sample_stratified (renderer.py:458-481, math_utils.py:101-118), sample positions and SMPL-frame
  * transform (renderer.py:304-310), nearest posed vertex + 5 cm shell mask (renderer.py:315-321) and stream
@@ -89,8 +90,8 @@ int sherf_build_cells(const float* verts, int n, const float* R, const float* Th
  *   workspace: dense_vid[R*S] int32, ray_mask[R*ceil(S/64)] u64, scan_ws[R + R/1024 + 1] int32.  S <= 256. */
 int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
                          int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
-                         const int32_t* cell_start, const float* cell_pts, int64_t capacity,
-                         int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
+                         const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask,
+                         int64_t capacity, int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
                          int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
                          int32_t* scan_ws, sherf_stream_t stream);
 
@@ -123,6 +124,16 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
                         const float* vox_min, const int32_t* vox_sh_host, int64_t capacity, float* tokens,
                         float* extras, sherf_stream_t stream);
 
+/* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
+ * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):
+ *   out[g*group_base + pix*pix_stride + o] = sum_c Wt[c][o] * in[(g*32 + c)*HW + pix],  g < groups.
+ * planes [3*32][P*P] -> [3][P*P][32] (pix_stride 32, group_base P*P*32); feature map [2*32][HW] -> [HW][64]
+ * (pix_stride 64, group_base 32). */
+int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int groups, int pix_stride,
+                      int64_t group_base, sherf_stream_t stream);
+/* obs image [3][HW] -> [HW][4] (rgb0) for the rgb tap of renderer.py:336 */
+int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t stream);
+
 /* a13+a14: rgb positional encoding -> slot-2 token, 3-token transformer (renderer.py:949-993), pos/view
  * encodings (:875-916) and NeRFDecoder (triplane.py:285-316) as one MFMA kernel; weights arrive as the
  * pre-packed fragment stream built by sherf_amd/mlp_pack.py.  prec: 0 = bf16, 1 = bf16x3 (hi/lo split,
@@ -153,7 +164,8 @@ int sherf_composite_dense(const float* colors, const float* sigma, const float* 
 int sherf_svox_mark_rows(const int32_t* coord, int n, int D, int H, int W, uint32_t* bitmap, sherf_stream_t stream);
 int sherf_svox_mark_down(const int32_t* keys, const int32_t* n_rows, int D, int H, int W, uint32_t* bitmap_out,
                          int max_rows, sherf_stream_t stream);
-int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, sherf_stream_t stream);
+int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, int32_t* chunk_ws,
+                    sherf_stream_t stream); /* chunk_ws: int32[n_words/1024 + 1] */
 int sherf_svox_keys(const uint32_t* bitmap, const int32_t* prefix, int n_words, int32_t* keys, sherf_stream_t stream);
 int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int C, int D, int H, int W,
                             const uint32_t* bitmap, const int32_t* prefix, float* g, int32_t* mult,
@@ -162,6 +174,19 @@ int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int 
 int sherf_svox_conv(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
                     const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in,
                     int Cin, const float* wt, int Cout, int down, int max_rows, float* out, sherf_stream_t stream);
+/* v2 (tiled, BatchNorm fused): out_raw = conv(act(in_raw)) with act = relu(in_bn scale/shift) (+ (mult-1)*v0) applied
+ * while gathering (in_bn == NULL: raw input).  mode 0 submanifold, 1 stride-2, 2 pointwise (folds the 1x1 projections
+ * into the tapped levels).  partials[grid][2][Cout] fp64 per-block sums of out and out^2 (NULL: none). */
+int sherf_svox_conv2(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
+                     const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in_raw,
+                     int Cin, const float* in_bn, const int32_t* in_mult, const float* wt, int Cout, int mode,
+                     int max_rows, float* out_raw, double* partials, sherf_stream_t stream);
+int sherf_svox_conv2_rows_per_block(int Cout);
+/* statistics over the reference's row set (n_total rows, the non-voxel rows being zeros) -> bnparam[3][C] =
+ * (scale, shift, relu(shift)); training != 0: batch statistics into stats[2][C], else stats holds running stats. */
+int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
+                           int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
+                           float* bnparam, sherf_stream_t stream);
 /* BatchNorm1d(eps=1e-3)+ReLU over the ROW set (rows = n_total_rows, of which the n_rows voxels are non-zero):
  * training!=0 -> batch statistics (written to stats[2][C] = mean, biased var), else running stats from stats. */
 int sherf_svox_bn_relu(float* x, const int32_t* n_rows, const int32_t* mult, const int32_t* n_total_rows, int C,

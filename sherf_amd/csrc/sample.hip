@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restri
                                                            const float* __restrict__ R, const float* __restrict__ Th,
                                                            float cell_size, float* __restrict__ hdr,
                                                            int32_t* __restrict__ cell_start, float4* __restrict__ cell_pts,
-                                                           int32_t* __restrict__ scratch) {
+                                                           int32_t* __restrict__ scratch, uint32_t* __restrict__ near_mask) {
+    __shared__ uint32_t s_near[SHERF_MAX_CELLS / 32];      // 1 bit per cell: some vertex lives in its 3x3x3 neighbourhood
     __shared__ float red[6][1024 / 64];
     __shared__ float s_hdr[8];
     __shared__ int s_part[1024];
@@ -76,6 +77,7 @@ __global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restri
     const int nx = __float_as_int(s_hdr[5]), ny = __float_as_int(s_hdr[6]), nz = __float_as_int(s_hdr[7]);
     const int ncell = nx * ny * nz;
     for (int i = tid; i <= ncell; i += 1024) cell_start[i] = 0;
+    for (int i = tid; i < SHERF_MAX_CELLS / 32; i += 1024) s_near[i] = 0u;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         int cx = min(nx - 1, max(0, (int)floorf((pos[i * 3] - ox) * inv)));
@@ -84,8 +86,17 @@ __global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restri
         int c = (cz * ny + cy) * nx + cx;
         cid[i] = c;
         rank[i] = atomicAdd(&cell_start[c], 1);
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int qx = cx + dx, qy = cy + dy, qz = cz + dz;
+                    if (qx < 0 || qx >= nx || qy < 0 || qy >= ny || qz < 0 || qz >= nz) continue;
+                    int q = (qz * ny + qy) * nx + qx;
+                    atomicOr(&s_near[q >> 5], 1u << (q & 31));
+                }
     }
     __syncthreads();
+    if (near_mask) for (int i = tid; i < SHERF_MAX_CELLS / 32; i += 1024) near_mask[i] = s_near[i];
     // exclusive scan of cell_start[0..ncell] in place: per-thread segments + block scan of the partials
     const int seg = (ncell + 1 + 1023) / 1024;
     const int s0 = tid * seg, s1 = min(ncell + 1, s0 + seg);
@@ -126,6 +137,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         const float* __restrict__ Th, const float* __restrict__ hdr,
                                                         const int32_t* __restrict__ cell_start,
                                                         const float4* __restrict__ cell_pts,
+                                                        const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid) {
     const int lane = threadIdx.x & 63;
@@ -146,9 +158,18 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
             float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
             float xs, ys, zs;
             to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
-            float best = 3.0e38f;
-            nn_search(g, cell_start, cell_pts, xs, ys, zs, 0.05f, best, best_id);
-            valid = best < kThresh2;
+            // quick reject: a sample within 5 cm of a vertex lies in a cell whose 3x3x3 neighbourhood holds that vertex
+            // (cells are >= 5 cm and the grid carries a one-cell margin), so an unset bit means "no vertex in range".
+            const int cx = (int)floorf((xs - g.ox) * g.inv_cell), cy = (int)floorf((ys - g.oy) * g.inv_cell),
+                      cz = (int)floorf((zs - g.oz) * g.inv_cell);
+            if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+                const int q = (cz * g.ny + cy) * g.nx + cx;
+                if ((near_mask[q >> 5] >> (q & 31)) & 1u) {
+                    float best = 3.0e38f;
+                    nn_search(g, cell_start, cell_pts, xs, ys, zs, 0.05f, best, best_id);
+                    valid = best < kThresh2;
+                }
+            }
         }
         uint64_t m = __ballot(valid);
         if (valid) dense_vid[(size_t)ray * S + k] = best_id;
@@ -314,22 +335,22 @@ __global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restric
 
 extern "C" int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
                                  float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
-                                 sherf_stream_t stream) {
+                                 uint32_t* near_mask, sherf_stream_t stream) {
     SHERF_CHECK_ARG(verts && grid_hdr && cell_start && cell_pts && scratch);
     SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
     SHERF_CHECK_ARG((R == nullptr) == (Th == nullptr));
     hipLaunchKernelGGL(build_cells_kernel, dim3(1), dim3(1024), 0, as_stream(stream), verts, n, R, Th, cell_size,
-                       grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch);
+                       grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
     SHERF_LAUNCH_CHECK();
 }
 
 extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
                                        int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
-                                       const int32_t* cell_start, const float* cell_pts, int64_t capacity,
-                                       int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
+                                       const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask, int64_t capacity,
+                                    int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
                                        int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
                                        int32_t* scan_ws, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(ray_o && ray_d && near && far && Rg && Th && grid_hdr && cell_start && cell_pts);
+    SHERF_CHECK_ARG(ray_o && ray_d && near && far && Rg && Th && grid_hdr && cell_start && cell_pts && near_mask);
     SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && cs_vid && cs_xs && dense_vid && ray_mask && scan_ws);
     SHERF_CHECK_ARG(R > 0 && S >= 2 && S <= 256 && (int64_t)R * S < 2147483647LL && capacity > 0);
     hipStream_t st = as_stream(stream);
@@ -342,7 +363,7 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
 #define SHERF_SAMPLE_LAUNCH(N)                                                                                        \
     hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
-                       grid_hdr, cell_start, cp, ray_cnt, ray_mask, dense_vid)
+                       grid_hdr, cell_start, cp, near_mask, ray_cnt, ray_mask, dense_vid)
     if (nch == 1) SHERF_SAMPLE_LAUNCH(1); else if (nch == 2) SHERF_SAMPLE_LAUNCH(2);
     else if (nch == 3) SHERF_SAMPLE_LAUNCH(3); else SHERF_SAMPLE_LAUNCH(4);
     hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, ray_cnt, R, base_local, chunk_sum);

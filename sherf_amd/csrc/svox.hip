@@ -44,25 +44,54 @@ __global__ void __launch_bounds__(256) mark_down_kernel(const int32_t* __restric
     }
 }
 
-__global__ void __launch_bounds__(1024) scan_kernel(const uint32_t* __restrict__ bitmap, int n_words,
-                                                    int32_t* __restrict__ prefix, int32_t* __restrict__ n_rows) {
-    __shared__ int s[1024];
+// exclusive popcount scan, 3 launches: per-1024-word chunk scan, scan of chunk sums, add chunk offsets
+__global__ void __launch_bounds__(256) scan_local_kernel(const uint32_t* __restrict__ bitmap, int n_words,
+                                                        int32_t* __restrict__ prefix, int32_t* __restrict__ chunk_sum) {
+    __shared__ int s[256];
     const int tid = threadIdx.x;
-    const int seg = (n_words + 1023) / 1024;
-    const int s0 = tid * seg, s1 = min(n_words, s0 + seg);
-    int sum = 0;
-    for (int i = s0; i < s1; ++i) sum += __popc(bitmap[i]);
+    const int w0 = blockIdx.x * 1024 + tid * 4;
+    int c[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = (w0 + i < n_words) ? __popc(bitmap[w0 + i]) : 0; sum += c[i]; }
     s[tid] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < 256; off <<= 1) {
         int v = tid >= off ? s[tid - off] : 0;
         __syncthreads();
         s[tid] += v;
         __syncthreads();
     }
     int run = s[tid] - sum;
-    for (int i = s0; i < s1; ++i) { prefix[i] = run; run += __popc(bitmap[i]); }
-    if (tid == 1023) *n_rows = s[1023];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (w0 + i < n_words) prefix[w0 + i] = run; run += c[i]; }
+    if (tid == 255) chunk_sum[blockIdx.x] = s[255];
+}
+
+__global__ void __launch_bounds__(1024) scan_chunks_kernel(int32_t* __restrict__ chunk_sum, int n_chunks, int32_t* __restrict__ n_rows) {
+    __shared__ int s[1024];
+    int carry = 0;
+    for (int b0 = 0; b0 < n_chunks; b0 += 1024) {
+        int i = b0 + threadIdx.x;
+        int v = i < n_chunks ? chunk_sum[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int a = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < n_chunks) chunk_sum[i] = carry + s[threadIdx.x] - v;
+        int tot = s[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *n_rows = carry;
+}
+
+__global__ void __launch_bounds__(256) scan_add_kernel(int32_t* __restrict__ prefix, int n_words, const int32_t* __restrict__ chunk_off) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w < n_words) prefix[w] += chunk_off[w >> 10];
 }
 
 __global__ void __launch_bounds__(256) keys_kernel(const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ prefix,
@@ -195,6 +224,148 @@ __global__ void __launch_bounds__(1024) bn_relu_kernel(float* __restrict__ x, co
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: tiled sparse convolution.  A block owns TM output rows; per kernel tap it stages W_tap [Cin][COUT] and the
+// gathered (BatchNorm+ReLU applied on the fly) input rows in LDS and does a 4x4 register-tiled fp32 product.
+// mode 0 submanifold, 1 stride-2 (k3 p1), 2 pointwise (1 tap, row -> same row; used to fold the 1x1 projections).
+// BatchNorm statistics of the OUTPUT are produced as per-block fp64 partial sums (deterministic two-stage reduce).
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
+                                                     int Do, int Ho, int Wo, const uint32_t* __restrict__ bitmap_in,
+                                                     const int32_t* __restrict__ prefix_in, int Di, int Hi, int Wi,
+                                                     const float* __restrict__ in_raw, int Cin, const float* __restrict__ in_bn,
+                                                     const int32_t* __restrict__ in_mult, const float* __restrict__ wt, int mode,
+                                                     float* __restrict__ out_raw, double* __restrict__ partials) {
+    constexpr int CQ = COUT / 4, RQ = 256 / CQ, TM = RQ * 4, TMP = TM + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_w = reinterpret_cast<float*>(smem);                          // [Cin][COUT]
+    float* s_in = s_w + Cin * COUT;                                       // [Cin][TMP]
+    int* s_nb = reinterpret_cast<int*>(s_in + Cin * TMP);                 // [ntaps][TM]
+    float* s_red = s_in;                                                  // [2][RQ][COUT], reused after the tap loop
+    const int n_rows = *n_rows_out;
+    const int row0 = blockIdx.x * TM;
+    if (row0 >= n_rows) return;
+    const int tid = threadIdx.x;
+    const int ntaps = mode == 2 ? 1 : 27;
+    for (int i = tid; i < ntaps * TM; i += 256) {
+        const int tap = i / TM, r = i % TM, row = row0 + r;
+        int nb = -1;
+        if (row < n_rows) {
+            if (mode == 2) nb = row;
+            else {
+                const int key = keys_out[row];
+                const int z = key / (Ho * Wo), y = (key / Wo) % Ho, x = key % Wo;
+                const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+                const int qz = mode ? 2 * z + kz - 1 : z + kz - 1, qy = mode ? 2 * y + ky - 1 : y + ky - 1,
+                          qx = mode ? 2 * x + kx - 1 : x + kx - 1;
+                if (qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi) {
+                    const int qk = (qz * Hi + qy) * Wi + qx;
+                    const uint32_t word = bitmap_in[qk >> 5], bit = 1u << (qk & 31);
+                    if (word & bit) nb = prefix_in[qk >> 5] + __popc(word & (bit - 1u));
+                }
+            }
+        }
+        s_nb[tap * TM + r] = nb;
+    }
+    __syncthreads();
+    const int cq = tid % CQ, rq = tid / CQ;
+    const bool worker = rq < RQ;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int tap = 0; tap < ntaps; ++tap) {
+        bool any = false;
+        for (int r = tid; r < TM; r += 256) any |= s_nb[tap * TM + r] >= 0;
+        if (!__syncthreads_or(any)) continue;                             // no row of this tile has that neighbour
+        const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)tap * Cin * COUT);
+        for (int i = tid; i < Cin * COUT / 4; i += 256) reinterpret_cast<float4*>(s_w)[i] = wsrc[i];
+        for (int i = tid; i < TM * Cin; i += 256) {
+            const int r = i / Cin, ci = i % Cin;
+            const int nb = s_nb[tap * TM + r];
+            float v = 0.f;
+            if (nb >= 0) {
+                v = in_raw[(size_t)nb * Cin + ci];
+                if (in_bn) {
+                    v = fmaxf(v * in_bn[ci] + in_bn[Cin + ci], 0.f);
+                    if (in_mult) v += (float)(in_mult[nb] - 1) * in_bn[2 * Cin + ci];
+                }
+            }
+            s_in[ci * TMP + r] = v;
+        }
+        __syncthreads();
+        if (worker) {
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float4 a = *reinterpret_cast<const float4*>(s_in + ci * TMP + 4 * rq);
+                const float4 w = *reinterpret_cast<const float4*>(s_w + ci * COUT + 4 * cq);
+                acc[0][0] += a.x * w.x; acc[0][1] += a.x * w.y; acc[0][2] += a.x * w.z; acc[0][3] += a.x * w.w;
+                acc[1][0] += a.y * w.x; acc[1][1] += a.y * w.y; acc[1][2] += a.y * w.z; acc[1][3] += a.y * w.w;
+                acc[2][0] += a.z * w.x; acc[2][1] += a.z * w.y; acc[2][2] += a.z * w.z; acc[2][3] += a.z * w.w;
+                acc[3][0] += a.w * w.x; acc[3][1] += a.w * w.y; acc[3][2] += a.w * w.z; acc[3][3] += a.w * w.w;
+            }
+        }
+        __syncthreads();
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (worker) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + 4 * rq + i;
+            if (row < n_rows) {
+                *reinterpret_cast<float4*>(out_raw + (size_t)row * COUT + 4 * cq) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += acc[i][j]; s2[j] += acc[i][j] * acc[i][j]; }
+            }
+        }
+    }
+    if (partials) {
+        if (worker)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s_red[rq * COUT + 4 * cq + j] = s1[j]; s_red[(RQ + rq) * COUT + 4 * cq + j] = s2[j]; }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, co = tid % COUT;
+            double t = 0.0;
+            for (int q = 0; q < RQ; ++q) t += (double)s_red[(which * RQ + q) * COUT + co];
+            partials[((size_t)blockIdx.x * 2 + which) * COUT + co] = t;
+        }
+    }
+}
+
+// mean/var over the reference's ROW set from the per-block partials -> bnparam[3][C] = (scale, shift, relu(shift)), stats[2][C]
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ partials, const int32_t* __restrict__ n_rows_p,
+                                                          const int32_t* __restrict__ n_total_p, int C, int rows_per_block,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ stats, int training, float* __restrict__ bnparam) {
+    __shared__ double s[2][96];
+    const int tid = threadIdx.x;
+    if (training) {
+        if (tid < 2 * C) {
+            const int which = tid / C, c = tid % C;
+            const int nblk = (*n_rows_p + rows_per_block - 1) / rows_per_block;
+            double t = 0.0;
+            for (int b = 0; b < nblk; ++b) t += partials[((size_t)b * 2 + which) * C + c];
+            s[which][c] = t;
+        }
+        __syncthreads();
+        if (tid < C) {
+            const double n = (double)(*n_total_p);
+            const double mean = s[0][tid] / n, var = fmax(s[1][tid] / n - mean * mean, 0.0);
+            stats[tid] = (float)mean; stats[C + tid] = (float)var;
+        }
+        __syncthreads();
+    }
+    if (tid < C) {
+        const float mean = stats[tid], var = stats[C + tid];
+        const float scale = gamma[tid] / sqrtf(var + 1e-3f);
+        const float shift = beta[tid] - mean * scale;
+        bnparam[tid] = scale; bnparam[C + tid] = shift; bnparam[2 * C + tid] = fmaxf(shift, 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" int sherf_svox_mark_rows(const int32_t* coord, int n, int D, int H, int W, uint32_t* bitmap, sherf_stream_t stream) {
@@ -211,9 +382,13 @@ extern "C" int sherf_svox_mark_down(const int32_t* keys, const int32_t* n_rows, 
     SHERF_LAUNCH_CHECK();
 }
 
-extern "C" int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(bitmap && prefix && n_rows && n_words > 0);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), bitmap, n_words, prefix, n_rows);
+extern "C" int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, int32_t* chunk_ws,
+                               sherf_stream_t stream) {
+    SHERF_CHECK_ARG(bitmap && prefix && n_rows && chunk_ws && n_words > 0);
+    const int n_chunks = cdiv(n_words, 1024);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), bitmap, n_words, prefix, chunk_ws);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(1024), 0, as_stream(stream), chunk_ws, n_chunks, n_rows);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n_words, 256)), dim3(256), 0, as_stream(stream), prefix, n_words, chunk_ws);
     SHERF_LAUNCH_CHECK();
 }
 
@@ -250,5 +425,33 @@ extern "C" int sherf_svox_bn_relu(float* x, const int32_t* n_rows, const int32_t
     SHERF_CHECK_ARG(x && n_rows && n_total_rows && gamma && beta && stats && C > 0 && C <= kMaxCin);
     hipLaunchKernelGGL(bn_relu_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n_rows, mult, n_total_rows, C, gamma, beta,
                        stats, training);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_svox_conv2(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
+                                const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in_raw,
+                                int Cin, const float* in_bn, const int32_t* in_mult, const float* wt, int Cout, int mode,
+                                int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(n_rows_out && in_raw && wt && out_raw && (mode == 2 || (keys_out && bitmap_in && prefix_in)));
+    SHERF_CHECK_ARG(Cin > 0 && Cin <= 96 && Cin % 4 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
+    const int CQ = Cout / 4, RQ = 256 / CQ, TM = RQ * 4, TMP = TM + 4;
+    const size_t smem = (size_t)Cin * Cout * 4 + (size_t)Cin * TMP * 4 + (size_t)27 * TM * 4;
+    SHERF_CHECK_ARG(partials == nullptr || Cin * TMP >= 2 * RQ * Cout);
+    const dim3 grid(cdiv(max_rows, TM)), block(256);
+#define SHERF_CONV2(C)                                                                                                  \
+    hipLaunchKernelGGL(sconv2_kernel<C>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo, bitmap_in,  \
+                       prefix_in, Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, wt, mode, out_raw, partials)
+    if (Cout == 32) SHERF_CONV2(32); else if (Cout == 64) SHERF_CONV2(64); else SHERF_CONV2(96);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_svox_conv2_rows_per_block(int Cout) { return (256 / (Cout / 4)) * 4; }
+
+extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
+                                      int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
+                                      float* bnparam, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(partials && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
+                       rows_per_block, gamma, beta, stats, training, bnparam);
     SHERF_LAUNCH_CHECK();
 }

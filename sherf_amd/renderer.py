@@ -139,6 +139,7 @@ class _Workspace:
             SO=torch.zeros(3, V, 3, **f32), T2C=torch.zeros(V, 12, **f32), C2S=torch.zeros(V, 12, **f32),
             grid_hdr=torch.zeros(2, 8, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
             cell_pts=torch.zeros(2, V, 4, **f32), cell_scratch=torch.zeros(5 * V, **i32),
+            near_mask=torch.zeros(64 * 64 * 64 // 32, **i32),
         )
         self.key, self.t = key, t
         return t
@@ -147,25 +148,49 @@ class _Workspace:
         key = (tuple(shapes), N, str(dev))
         if self.vox is not None and self.vox[0] == key:
             return self.vox[1]
-        chans = (32, 32, 64, 96)
-        L = []
+        i32 = dict(dtype=torch.int32, device=dev)
+        dims = []
         for li, (D, H, W) in enumerate(shapes):
             nvox = D * H * W
-            nwords = (nvox + 31) // 32
-            cap = N if li == 0 else min(nvox, 8 * N)
-            i32 = dict(dtype=torch.int32, device=dev)
-            L.append(dict(bitmap=torch.zeros(nwords, **i32), prefix=torch.zeros(nwords, **i32), keys=torch.zeros(cap, **i32),
-                          n_rows=torch.zeros(1, **i32), n_total=torch.zeros(1, **i32), mult=torch.zeros(cap, **i32),
-                          xa=torch.zeros(cap, chans[li], device=dev), xb=torch.zeros(cap, chans[li], device=dev),
-                          nwords=nwords, cap=cap))
-        self.vox = (key, L)
-        return L
+            dims.append((nvox, (nvox + 31) // 32, N if li == 0 else min(nvox, 8 * N)))
+        # one contiguous region for everything that must be zero at the start of a frame -> a single memset
+        zsize = sum(d[1] for d in dims) + N + N * 32
+        zero_region = torch.zeros(zsize, **i32)
+        L, off = [], 0
+        for li, (nvox, nwords, cap) in enumerate(dims):
+            lv = dict(bitmap=zero_region[off:off + nwords], prefix=torch.zeros(nwords, **i32), keys=torch.zeros(cap, **i32),
+                      n_rows=torch.zeros(1, **i32), chunk_ws=torch.zeros(nwords // 1024 + 2, **i32), nwords=nwords, cap=cap)
+            off += nwords
+            L.append(lv)
+        L[0]['mult'] = zero_region[off:off + N]; off += N
+        L[0]['g0'] = zero_region[off:off + N * 32].view(torch.float32).view(N, 32)
+        L[0]['n_total'] = torch.full((1,), N, **i32)
+        self.vox = (key, (L, zero_region))
+        return self.vox[1]
+
+    def _cached(self, kind, idx, shape, dev, dtype=torch.float32):
+        k = (kind, idx, tuple(shape), str(dev))
+        if k not in self.bn:
+            self.bn[k] = torch.zeros(*shape, device=dev, dtype=dtype)
+        return self.bn[k]
 
     def bn_stats(self, idx, C, dev):
-        k = (idx, C, str(dev))
-        if k not in self.bn:
-            self.bn[k] = torch.zeros(2, C, device=dev)
-        return self.bn[k]
+        return self._cached('stats', idx, (2, C), dev)
+
+    def bn_param(self, idx, C, dev):
+        return self._cached('bnp', idx, (3, C), dev)
+
+    def layer_out(self, idx, cap, C, dev):
+        return self._cached('out', idx, (cap, C), dev)
+
+    def partials(self, idx, nblk, C, dev):
+        return self._cached('part', idx, (nblk, 2, C), dev, torch.float64)
+
+    def fold_out(self, idx, cap, dev):
+        return self._cached('fold', idx, (cap, 96), dev)
+
+    def table(self, kind, shape, dev):
+        return self._cached(kind, 0, shape, dev)
 
 
 class ImportanceRenderer(nn.Module):
@@ -288,9 +313,9 @@ class ImportanceRenderer(nn.Module):
         verts = f32(input_data['vertices']).view(V, 3)
         tverts = f32(input_data['t_vertices']).view(V, 3)
         _lib.call('sherf_build_cells', P(verts), V, P(Rg), P(Th), 0.05, P(ws['grid_hdr'][0]), P(ws['cell_start'][0]),
-                  P(ws['cell_pts'][0]), P(ws['cell_scratch']), st)
+                  P(ws['cell_pts'][0]), P(ws['cell_scratch']), P(ws['near_mask']), st)
         _lib.call('sherf_build_cells', P(tverts), V, None, None, 0.05, P(ws['grid_hdr'][1]), P(ws['cell_start'][1]),
-                  P(ws['cell_pts'][1]), P(ws['cell_scratch']), st)
+                  P(ws['cell_pts'][1]), P(ws['cell_scratch']), None, st)
 
         # ---- a11: sparse voxel encoder -> folded level tables ----
         levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws)
@@ -300,18 +325,21 @@ class ImportanceRenderer(nn.Module):
 
         # ---- per-frame table re-layout (channel-last) with the slot projections folded in ----
         Pres = planes.shape[-1]
-        planes_f = torch.matmul(f32(planes)[0].permute(0, 2, 3, 1), wc['Wa_t']).contiguous()          # [3,P,P,32]
         Hf, Wf = obs_input_feature.shape[-2:]
-        feat_f = torch.matmul(f32(obs_input_feature)[0].view(2, 32, Hf, Wf).permute(2, 3, 0, 1), wc['Wb_t']).contiguous()
         H, W = obs_input_img.shape[-2:]
-        img4 = torch.cat([f32(obs_input_img)[0].permute(1, 2, 0), torch.zeros(H, W, 1, device=dev)], -1).contiguous()
+        planes_f = self._ws.table('planes_f', (3, Pres, Pres, 32), dev)
+        feat_f = self._ws.table('feat_f', (Hf, Wf, 64), dev)
+        img4 = self._ws.table('img4', (H, W, 4), dev)
+        _lib.call('sherf_fold_tables', P(f32(planes)), P(wc['Wa_t']), P(planes_f), Pres * Pres, 3, 32, Pres * Pres * 32, st)
+        _lib.call('sherf_fold_tables', P(f32(obs_input_feature)), P(wc['Wb_t']), P(feat_f), Hf * Wf, 2, 64, 32, st)
+        _lib.call('sherf_img_to_hwc4', P(f32(obs_input_img)), P(img4), H * W, st)
         bounds = f32(input_data['t_world_bounds']).view(6)
 
         # ---- a4-a6: sample, mask, nearest vertex, compaction ----
         ro, rd = f32(ray_origins).view(R, 3), f32(ray_directions).view(R, 3)
         nr, fr = f32(near).view(R), f32(far).view(R)
         _lib.call('sherf_sample_mask_nn', P(ro), P(rd), P(nr), P(fr), R, S, P(Rg), P(Th), P(ws['grid_hdr'][0]),
-                  P(ws['cell_start'][0]), P(ws['cell_pts'][0]), cap, P(ws['counters']), P(ws['ray_base']), P(ws['ray_cnt']),
+                  P(ws['cell_start'][0]), P(ws['cell_pts'][0]), P(ws['near_mask']), cap, P(ws['counters']), P(ws['ray_base']), P(ws['ray_cnt']),
                   P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(ws['dense_vid']), P(ws['ray_mask']), P(ws['scan_ws']), st)
         # ---- a8-a10: warp ----
         _lib.call('sherf_warp_geom', P(ws['counters']), P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(rd), S, P(Rg),

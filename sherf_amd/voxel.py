@@ -93,7 +93,10 @@ class SparseConvNet(nn.Module):
 
     def encode(self, sp, fold_mats, ws):
         """Runs the encoder on a SparseConvTensor; returns the three tapped levels as `_lib.VoxLevel`s whose rows
-        are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see ImportanceRenderer._fold_weights."""
+        are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see ImportanceRenderer._weights.
+
+        Per layer: one tiled conv launch (BatchNorm+ReLU of the INPUT applied while gathering, fp64 partial sums
+        of the OUTPUT) + one tiny finalize launch that turns the partials into scale/shift for the next layer."""
         feat = sp.features.detach().float().contiguous()
         coord = sp.indices.to(torch.int32).contiguous()
         dev = feat.device
@@ -102,61 +105,59 @@ class SparseConvNet(nn.Module):
         shapes = [tuple(sp.spatial_shape)]
         for _ in range(3):
             shapes.append(tuple((d - 1) // 2 + 1 for d in shapes[-1]))
-        L = ws.voxel_levels(shapes, N, dev)
+        L, zero_region = ws.voxel_levels(shapes, N, dev)
         st = _lib.stream()
         P = _lib.ptr
         training = self.training
-        # level 0: unique voxels, summed features, multiplicities
+        zero_region.zero_()                                   # every bitmap, level-0 multiplicities and summed features
         l0 = L[0]
-        l0['bitmap'].zero_(); l0['mult'].zero_(); l0['xa'][:N].zero_()
         D, H, W = shapes[0]
         _lib.call('sherf_svox_mark_rows', P(coord), N, D, H, W, P(l0['bitmap']), st)
-        _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), st)
+        _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), P(l0['chunk_ws']), st)
         _lib.call('sherf_svox_keys', P(l0['bitmap']), P(l0['prefix']), l0['nwords'], P(l0['keys']), st)
         _lib.call('sherf_svox_scatter_rows', P(coord), P(feat), N, 32, D, H, W, P(l0['bitmap']), P(l0['prefix']),
-                  P(l0['xa']), P(l0['mult']), st)
-        l0['n_total'].fill_(N)
-        cur, lev = 'xa', 0
+                  P(l0['g0']), P(l0['mult']), st)
+        lev = 0
+        cur, cur_bn = l0['g0'], None                          # raw features of the current level + their BN params (None: raw)
         taps = []
         for li, ly in enumerate(pk['layers']):
             src = L[lev]
+            dst = L[lev + 1] if ly['down'] else src
             if ly['down']:
-                dst = L[lev + 1]
-                dst['bitmap'].zero_()
                 _lib.call('sherf_svox_mark_down', P(src['keys']), P(src['n_rows']), *shapes[lev], P(dst['bitmap']), src['cap'], st)
-                _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), st)
+                _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), P(dst['chunk_ws']), st)
                 _lib.call('sherf_svox_keys', P(dst['bitmap']), P(dst['prefix']), dst['nwords'], P(dst['keys']), st)
-                out_buf = dst['xa']
-                _lib.call('sherf_svox_conv', P(dst['keys']), P(dst['n_rows']), *shapes[lev + 1], P(src['bitmap']), P(src['prefix']),
-                          *shapes[lev], P(src[cur]), ly['cin'], P(ly['wt']), ly['cout'], 1, dst['cap'], P(out_buf), st)
-                lev += 1; cur = 'xa'
-                tgt = L[lev]
-            else:
-                tgt = src
-                nxt = 'xb' if cur == 'xa' else 'xa'
-                _lib.call('sherf_svox_conv', P(src['keys']), P(src['n_rows']), *shapes[lev], P(src['bitmap']), P(src['prefix']),
-                          *shapes[lev], P(src[cur]), ly['cin'], P(ly['wt']), ly['cout'], 0, src['cap'], P(src[nxt]), st)
-                cur = nxt
+            out = ws.layer_out(li, dst['cap'], ly['cout'], dev)
+            rpb = (256 // (ly['cout'] // 4)) * 4
+            parts = ws.partials(li, (dst['cap'] + rpb - 1) // rpb, ly['cout'], dev)
+            mult = P(src['mult']) if (lev == 0 and cur_bn is not None) else None
+            dlev = lev + 1 if ly['down'] else lev
+            _lib.call('sherf_svox_conv2', P(dst['keys']), P(dst['n_rows']), *shapes[dlev], P(src['bitmap']), P(src['prefix']),
+                      *shapes[lev], P(cur), ly['cin'], P(cur_bn) if cur_bn is not None else None, mult, P(ly['wt']), ly['cout'],
+                      1 if ly['down'] else 0, dst['cap'], P(out), P(parts), st)
             bn = ly['bn']
             stats = ws.bn_stats(li, ly['cout'], dev)
             if not training:
                 stats[0].copy_(bn.running_mean); stats[1].copy_(bn.running_var)
-            mult = P(tgt['mult']) if lev == 0 else None
-            n_total = tgt['n_total'] if lev == 0 else tgt['n_rows']
-            _lib.call('sherf_svox_bn_relu', P(tgt[cur]), P(tgt['n_rows']), mult, P(n_total), ly['cout'], P(ly['gamma']),
-                      P(ly['beta']), P(stats), 1 if training else 0, st)
+            n_total = l0['n_total'] if dlev == 0 else dst['n_rows']
+            bnp = ws.bn_param(li, ly['cout'], dev)
+            _lib.call('sherf_svox_bn_finalize', P(parts), P(dst['n_rows']), P(n_total), ly['cout'], rpb, P(ly['gamma']), P(ly['beta']),
+                      P(stats), 1 if training else 0, P(bnp), st)
             if training and torch.is_grad_enabled() and bn.track_running_stats:
                 with torch.no_grad():     # nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance)
                     n = n_total.float()
                     bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * stats[0])
                     bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * stats[1] * n / (n - 1))
                     bn.num_batches_tracked += 1
+            lev, cur, cur_bn = dlev, out, bnp
             if ly['tap']:
-                taps.append((lev, cur))
+                taps.append((lev, out, bnp, ly['cout']))
         levels = (_lib.VoxLevel * 3)()
         keep = []
-        for i, (lev, cur) in enumerate(taps):
-            rows = torch.matmul(L[lev][cur], fold_mats[i])             # [cap, C] @ [C, 96]: plain library GEMM
+        for i, (lev, raw, bnp, C) in enumerate(taps):
+            rows = ws.fold_out(i, L[lev]['cap'], dev)                   # relu(bn(raw)) @ fold [C, 96] as a pointwise "conv"
+            _lib.call('sherf_svox_conv2', None, P(L[lev]['n_rows']), 1, 1, 1, None, None, 1, 1, 1, P(raw), C, P(bnp), None,
+                      P(fold_mats[i]), 96, 2, L[lev]['cap'], P(rows), None, st)
             keep.append(rows)
             levels[i].bitmap = L[lev]['bitmap'].data_ptr(); levels[i].prefix = L[lev]['prefix'].data_ptr()
             levels[i].rows = rows.data_ptr()
