@@ -76,6 +76,11 @@ int sherf_smpl_c2s_table(const float* weights, const float* A_big, const float* 
 int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
                       float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                       uint32_t* near_mask, sherf_stream_t stream);
+/* Both per-frame lists in one launch: set 0 = verts_a in the SMPL frame (with near_mask), set 1 = verts_b untransformed.
+ * grid_hdr[2][8], cell_start[2][SHERF_MAX_CELLS+1], cell_pts[2][n][4], scratch[2][5n]. */
+int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a, const float* verts_b, int n,
+                       float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
+                       uint32_t* near_mask, sherf_stream_t stream);
 /* near_mask (nullable): uint32[SHERF_MAX_CELLS/32], bit c set iff a vertex lives in the 3x3x3 neighbourhood of cell c */
 
 /* a4+a5+a6: sample_stratified (renderer.py:458-481, math_utils.py:101-118), sample positions and SMPL-frame
@@ -105,8 +110,7 @@ int sherf_warp_geom(const int32_t* counters, const int32_t* cs_idx, const int32_
 
 /* Sparse voxel level descriptor used by the gather (a11). All pointers device. */
 typedef struct {
-    const uint32_t* bitmap;  /* 1 bit per voxel of this level, linear index (z*H + y)*W + x */
-    const int32_t* prefix;   /* exclusive popcount prefix per 32-bit word */
+    const uint32_t* wp;      /* [n_words][2]: (32 occupancy bits, exclusive popcount prefix) per word; voxel index (z*H+y)*W+x */
     const float* rows;       /* folded features [n_rows][96] */
     int32_t D, H, W;
 } sherf_vox_level;
@@ -165,7 +169,7 @@ int sherf_svox_mark_rows(const int32_t* coord, int n, int D, int H, int W, uint3
 int sherf_svox_mark_down(const int32_t* keys, const int32_t* n_rows, int D, int H, int W, uint32_t* bitmap_out,
                          int max_rows, sherf_stream_t stream);
 int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, int32_t* chunk_ws,
-                    sherf_stream_t stream); /* chunk_ws: int32[n_words/1024 + 1] */
+                    uint32_t* wp, sherf_stream_t stream); /* chunk_ws: int32[n_words/1024 + 1]; wp: [n_words][2] */
 int sherf_svox_keys(const uint32_t* bitmap, const int32_t* prefix, int n_words, int32_t* keys, sherf_stream_t stream);
 int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int C, int D, int H, int W,
                             const uint32_t* bitmap, const int32_t* prefix, float* g, int32_t* mult,
@@ -178,7 +182,7 @@ int sherf_svox_conv(const int32_t* keys_out, const int32_t* n_rows_out, int Do, 
  * while gathering (in_bn == NULL: raw input).  mode 0 submanifold, 1 stride-2, 2 pointwise (folds the 1x1 projections
  * into the tapped levels).  partials[grid][2][Cout] fp64 per-block sums of out and out^2 (NULL: none). */
 int sherf_svox_conv2(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
-                     const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in_raw,
+                     const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw,
                      int Cin, const float* in_bn, const int32_t* in_mult, const float* wt, int Cout, int mode,
                      int max_rows, float* out_raw, double* partials, sherf_stream_t stream);
 int sherf_svox_conv2_rows_per_block(int Cout);

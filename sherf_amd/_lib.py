@@ -20,7 +20,7 @@ _protos = None
 
 
 class VoxLevel(ctypes.Structure):
-    _fields_ = [('bitmap', ctypes.c_void_p), ('prefix', ctypes.c_void_p), ('rows', ctypes.c_void_p),
+    _fields_ = [('wp', ctypes.c_void_p), ('rows', ctypes.c_void_p),
                 ('D', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32)]
 
 

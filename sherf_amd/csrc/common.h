@@ -74,6 +74,32 @@ __device__ __forceinline__ void nn_search(const CellGrid& g, const int32_t* __re
         }
 }
 
+// Radius <= cell special case: the ball lies inside the 3x3x3 neighbourhood of the query's own cell (cx,cy,cz), so the
+// nine x-contiguous segments are fetched with 18 INDEPENDENT loads up front (memory-level parallelism) before any
+// point is examined.
+__device__ __forceinline__ void nn_search27(const CellGrid& g, const int32_t* __restrict__ cell_start,
+                                            const float4* __restrict__ pts, float x, float y, float z, int cx, int cy, int cz,
+                                            float& best_d2, int& best_id) {
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    int s[9], e[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
+        const bool ok = qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny;
+        const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
+        s[i] = cell_start[row + x0];
+        e[i] = ok ? cell_start[row + x1 + 1] : s[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        for (int p = s[i]; p < e[i]; ++p) {
+            const float4 q = pts[p];
+            const float d2 = dist2_exact(x, y, z, q.x, q.y, q.z);
+            const int id = __float_as_int(q.w);
+            if (d2 < best_d2 || (d2 == best_d2 && id < best_id)) { best_d2 = d2; best_id = id; }
+        }
+}
+
 // order-preserving float <-> int map for atomicMin/atomicMax on floats of any sign
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }

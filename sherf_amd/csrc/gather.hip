@@ -121,10 +121,10 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                                 int xx = xi + dx, yy = yi + dy, zz = zi + dz;
                                 if (xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
                                     int key = (zz * lev.H + yy) * lev.W + xx;
-                                    uint32_t word = lev.bitmap[key >> 5];
-                                    uint32_t bit = 1u << (key & 31);
-                                    if (word & bit) {
-                                        int row = lev.prefix[key >> 5] + __popc(word & (bit - 1u));
+                                    const uint2 rec = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                                    const uint32_t bit = 1u << (key & 31);
+                                    if (rec.x & bit) {
+                                        int row = (int)rec.y + __popc(rec.x & (bit - 1u));
                                         float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
                                         const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)row * 24;
                                         axpy4(acc[0], w, r[l]);
@@ -162,7 +162,7 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     Levels lv;
     for (int i = 0; i < 3; ++i) {
         lv.l[i] = levels_host[i];
-        SHERF_CHECK_ARG(lv.l[i].bitmap && lv.l[i].prefix && lv.l[i].rows && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
+        SHERF_CHECK_ARG(lv.l[i].wp && lv.l[i].rows && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
     }
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
     const int64_t tiles = (capacity + 31) / 32;

@@ -30,7 +30,7 @@ __device__ __forceinline__ void rot_only(float x, float y, float z, const float*
 // ---------------------------------------------------------------------------------------------
 // cell list: one block of 1024 threads (n <= 6890 points)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restrict__ verts, int n,
+__device__ __forceinline__ void build_cells_body(const float* __restrict__ verts, int n,
                                                            const float* __restrict__ R, const float* __restrict__ Th,
                                                            float cell_size, float* __restrict__ hdr,
                                                            int32_t* __restrict__ cell_start, float4* __restrict__ cell_pts,
@@ -121,6 +121,26 @@ __global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restri
         cell_pts[cell_start[cid[i]] + rank[i]] = make_float4(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2], __int_as_float(i));
 }
 
+__global__ void __launch_bounds__(1024) build_cells_kernel(const float* __restrict__ verts, int n, const float* __restrict__ R,
+                                                           const float* __restrict__ Th, float cell_size, float* __restrict__ hdr,
+                                                           int32_t* __restrict__ cell_start, float4* __restrict__ cell_pts,
+                                                           int32_t* __restrict__ scratch, uint32_t* __restrict__ near_mask) {
+    build_cells_body(verts, n, R, Th, cell_size, hdr, cell_start, cell_pts, scratch, near_mask);
+}
+
+// both per-frame cell lists in one launch: block 0 = posed vertices in the SMPL frame (+ near mask), block 1 = T-pose vertices
+__global__ void __launch_bounds__(1024) build_cells2_kernel(const float* __restrict__ verts_a, const float* __restrict__ R_a,
+                                                            const float* __restrict__ Th_a, const float* __restrict__ verts_b, int n,
+                                                            float cell_size, float* __restrict__ hdr, int32_t* __restrict__ cell_start,
+                                                            float4* __restrict__ cell_pts, int32_t* __restrict__ scratch,
+                                                            uint32_t* __restrict__ near_mask) {
+    if (blockIdx.x == 0)
+        build_cells_body(verts_a, n, R_a, Th_a, cell_size, hdr, cell_start, cell_pts, scratch, near_mask);
+    else
+        build_cells_body(verts_b, n, nullptr, nullptr, cell_size, hdr + 8, cell_start + (SHERF_MAX_CELLS + 1), cell_pts + n,
+                         scratch + 5 * n, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass 1: one wave per ray: depths, positions, exact NN within 5 cm, validity mask
 // ---------------------------------------------------------------------------------------------
@@ -166,7 +186,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                 const int q = (cz * g.ny + cy) * g.nx + cx;
                 if ((near_mask[q >> 5] >> (q & 31)) & 1u) {
                     float best = 3.0e38f;
-                    nn_search(g, cell_start, cell_pts, xs, ys, zs, 0.05f, best, best_id);
+                    nn_search27(g, cell_start, cell_pts, xs, ys, zs, cx, cy, cz, best, best_id);
                     valid = best < kThresh2;
                 }
             }
@@ -340,6 +360,16 @@ extern "C" int sherf_build_cells(const float* verts, int n, const float* R, cons
     SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
     SHERF_CHECK_ARG((R == nullptr) == (Th == nullptr));
     hipLaunchKernelGGL(build_cells_kernel, dim3(1), dim3(1024), 0, as_stream(stream), verts, n, R, Th, cell_size,
+                       grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a, const float* verts_b, int n,
+                                  float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
+                                  uint32_t* near_mask, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(verts_a && R_a && Th_a && verts_b && grid_hdr && cell_start && cell_pts && scratch && near_mask);
+    SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
+    hipLaunchKernelGGL(build_cells2_kernel, dim3(2), dim3(1024), 0, as_stream(stream), verts_a, R_a, Th_a, verts_b, n, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
     SHERF_LAUNCH_CHECK();
 }

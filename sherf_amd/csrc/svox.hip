@@ -89,9 +89,14 @@ __global__ void __launch_bounds__(1024) scan_chunks_kernel(int32_t* __restrict__
     if (threadIdx.x == 0) *n_rows = carry;
 }
 
-__global__ void __launch_bounds__(256) scan_add_kernel(int32_t* __restrict__ prefix, int n_words, const int32_t* __restrict__ chunk_off) {
+__global__ void __launch_bounds__(256) scan_add_kernel(const uint32_t* __restrict__ bitmap, int32_t* __restrict__ prefix, int n_words,
+                                                       const int32_t* __restrict__ chunk_off, uint2* __restrict__ wp) {
     const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w < n_words) prefix[w] += chunk_off[w >> 10];
+    if (w < n_words) {
+        const int pf = prefix[w] + chunk_off[w >> 10];
+        prefix[w] = pf;
+        wp[w] = make_uint2(bitmap[w], (uint32_t)pf);          // one 8-byte record per word: a lookup is a single load
+    }
 }
 
 __global__ void __launch_bounds__(256) keys_kernel(const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ prefix,
@@ -231,14 +236,13 @@ __global__ void __launch_bounds__(1024) bn_relu_kernel(float* __restrict__ x, co
 // mode 0 submanifold, 1 stride-2 (k3 p1), 2 pointwise (1 tap, row -> same row; used to fold the 1x1 projections).
 // BatchNorm statistics of the OUTPUT are produced as per-block fp64 partial sums (deterministic two-stage reduce).
 // ---------------------------------------------------------------------------------------------
-template <int COUT>
-__global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
-                                                     int Do, int Ho, int Wo, const uint32_t* __restrict__ bitmap_in,
-                                                     const int32_t* __restrict__ prefix_in, int Di, int Hi, int Wi,
+template <int COUT, int NTHR>
+__global__ void __launch_bounds__(NTHR) sconv2_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
+                                                     int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, int Cin, const float* __restrict__ in_bn,
                                                      const int32_t* __restrict__ in_mult, const float* __restrict__ wt, int mode,
                                                      float* __restrict__ out_raw, double* __restrict__ partials) {
-    constexpr int CQ = COUT / 4, RQ = 256 / CQ, TM = RQ * 4, TMP = TM + 4;
+    constexpr int CQ = COUT / 4, RQ = NTHR / CQ, TM = RQ * 4, TMP = TM + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_w = reinterpret_cast<float*>(smem);                          // [Cin][COUT]
     float* s_in = s_w + Cin * COUT;                                       // [Cin][TMP]
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__
     if (row0 >= n_rows) return;
     const int tid = threadIdx.x;
     const int ntaps = mode == 2 ? 1 : 27;
-    for (int i = tid; i < ntaps * TM; i += 256) {
+    for (int i = tid; i < ntaps * TM; i += NTHR) {
         const int tap = i / TM, r = i % TM, row = row0 + r;
         int nb = -1;
         if (row < n_rows) {
@@ -262,8 +266,9 @@ __global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__
                           qx = mode ? 2 * x + kx - 1 : x + kx - 1;
                 if (qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi) {
                     const int qk = (qz * Hi + qy) * Wi + qx;
-                    const uint32_t word = bitmap_in[qk >> 5], bit = 1u << (qk & 31);
-                    if (word & bit) nb = prefix_in[qk >> 5] + __popc(word & (bit - 1u));
+                    const uint2 rec = wp_in[qk >> 5];
+                    const uint32_t bit = 1u << (qk & 31);
+                    if (rec.x & bit) nb = (int)rec.y + __popc(rec.x & (bit - 1u));
                 }
             }
         }
@@ -279,11 +284,11 @@ __global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     for (int tap = 0; tap < ntaps; ++tap) {
         bool any = false;
-        for (int r = tid; r < TM; r += 256) any |= s_nb[tap * TM + r] >= 0;
+        for (int r = tid; r < TM; r += NTHR) any |= s_nb[tap * TM + r] >= 0;
         if (!__syncthreads_or(any)) continue;                             // no row of this tile has that neighbour
         const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)tap * Cin * COUT);
-        for (int i = tid; i < Cin * COUT / 4; i += 256) reinterpret_cast<float4*>(s_w)[i] = wsrc[i];
-        for (int i = tid; i < TM * Cin; i += 256) {
+        for (int i = tid; i < Cin * COUT / 4; i += NTHR) reinterpret_cast<float4*>(s_w)[i] = wsrc[i];
+        for (int i = tid; i < TM * Cin; i += NTHR) {
             const int r = i / Cin, ci = i % Cin;
             const int nb = s_nb[tap * TM + r];
             float v = 0.f;
@@ -326,8 +331,8 @@ __global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s_red[rq * COUT + 4 * cq + j] = s1[j]; s_red[(RQ + rq) * COUT + 4 * cq + j] = s2[j]; }
         __syncthreads();
-        if (tid < 2 * COUT) {
-            const int which = tid / COUT, co = tid % COUT;
+        for (int u = tid; u < 2 * COUT; u += NTHR) {
+            const int which = u / COUT, co = u % COUT;
             double t = 0.0;
             for (int q = 0; q < RQ; ++q) t += (double)s_red[(which * RQ + q) * COUT + co];
             partials[((size_t)blockIdx.x * 2 + which) * COUT + co] = t;
@@ -336,24 +341,30 @@ __global__ void __launch_bounds__(256) sconv2_kernel(const int32_t* __restrict__
 }
 
 // mean/var over the reference's ROW set from the per-block partials -> bnparam[3][C] = (scale, shift, relu(shift)), stats[2][C]
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ partials, const int32_t* __restrict__ n_rows_p,
-                                                          const int32_t* __restrict__ n_total_p, int C, int rows_per_block,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ stats, int training, float* __restrict__ bnparam) {
-    __shared__ double s[2][96];
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restrict__ partials, const int32_t* __restrict__ n_rows_p,
+                                                           const int32_t* __restrict__ n_total_p, int C, int rows_per_block,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ stats, int training, float* __restrict__ bnparam) {
+    __shared__ double s[1024];
     const int tid = threadIdx.x;
     if (training) {
-        if (tid < 2 * C) {
-            const int which = tid / C, c = tid % C;
-            const int nblk = (*n_rows_p + rows_per_block - 1) / rows_per_block;
-            double t = 0.0;
-            for (int b = 0; b < nblk; ++b) t += partials[((size_t)b * 2 + which) * C + c];
-            s[which][c] = t;
+        const int series = 2 * C, nparts = 1024 / series;
+        const int sidx = tid % series, part = tid / series;
+        const int nblk = (*n_rows_p + rows_per_block - 1) / rows_per_block;
+        double t = 0.0;
+        if (part < nparts)
+            for (int b = part; b < nblk; b += nparts) t += partials[(size_t)b * series + sidx];    // fixed order: deterministic
+        s[tid] = t;
+        __syncthreads();
+        if (tid < series) {
+            double a = 0.0;
+            for (int q = 0; q < nparts; ++q) a += s[q * series + tid];
+            s[tid] = a;
         }
         __syncthreads();
         if (tid < C) {
             const double n = (double)(*n_total_p);
-            const double mean = s[0][tid] / n, var = fmax(s[1][tid] / n - mean * mean, 0.0);
+            const double mean = s[tid] / n, var = fmax(s[C + tid] / n - mean * mean, 0.0);
             stats[tid] = (float)mean; stats[C + tid] = (float)var;
         }
         __syncthreads();
@@ -383,12 +394,13 @@ extern "C" int sherf_svox_mark_down(const int32_t* keys, const int32_t* n_rows, 
 }
 
 extern "C" int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, int32_t* chunk_ws,
-                               sherf_stream_t stream) {
-    SHERF_CHECK_ARG(bitmap && prefix && n_rows && chunk_ws && n_words > 0);
+                               uint32_t* wp, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(bitmap && prefix && n_rows && chunk_ws && wp && n_words > 0);
     const int n_chunks = cdiv(n_words, 1024);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), bitmap, n_words, prefix, chunk_ws);
     hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(1024), 0, as_stream(stream), chunk_ws, n_chunks, n_rows);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n_words, 256)), dim3(256), 0, as_stream(stream), prefix, n_words, chunk_ws);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n_words, 256)), dim3(256), 0, as_stream(stream), bitmap, prefix, n_words, chunk_ws,
+                       reinterpret_cast<uint2*>(wp));
     SHERF_LAUNCH_CHECK();
 }
 
@@ -429,29 +441,30 @@ extern "C" int sherf_svox_bn_relu(float* x, const int32_t* n_rows, const int32_t
 }
 
 extern "C" int sherf_svox_conv2(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
-                                const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in_raw,
+                                const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw,
                                 int Cin, const float* in_bn, const int32_t* in_mult, const float* wt, int Cout, int mode,
                                 int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(n_rows_out && in_raw && wt && out_raw && (mode == 2 || (keys_out && bitmap_in && prefix_in)));
+    SHERF_CHECK_ARG(n_rows_out && in_raw && wt && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin > 0 && Cin <= 96 && Cin % 4 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
-    const int CQ = Cout / 4, RQ = 256 / CQ, TM = RQ * 4, TMP = TM + 4;
+    constexpr int NTHR = 64;                    // one wave per block: 32 / 16 / 8 rows per block -> hundreds of blocks even at 2.7k rows
+    const int CQ = Cout / 4, RQ = NTHR / CQ, TM = RQ * 4, TMP = TM + 4;
     const size_t smem = (size_t)Cin * Cout * 4 + (size_t)Cin * TMP * 4 + (size_t)27 * TM * 4;
     SHERF_CHECK_ARG(partials == nullptr || Cin * TMP >= 2 * RQ * Cout);
-    const dim3 grid(cdiv(max_rows, TM)), block(256);
-#define SHERF_CONV2(C)                                                                                                  \
-    hipLaunchKernelGGL(sconv2_kernel<C>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo, bitmap_in,  \
-                       prefix_in, Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, wt, mode, out_raw, partials)
+    const dim3 grid(cdiv(max_rows, TM)), block(NTHR);
+#define SHERF_CONV2(C)                                                                                                        \
+    hipLaunchKernelGGL((sconv2_kernel<C, NTHR>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo, \
+                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, wt, mode, out_raw, partials)
     if (Cout == 32) SHERF_CONV2(32); else if (Cout == 64) SHERF_CONV2(64); else SHERF_CONV2(96);
     SHERF_LAUNCH_CHECK();
 }
 
-extern "C" int sherf_svox_conv2_rows_per_block(int Cout) { return (256 / (Cout / 4)) * 4; }
+extern "C" int sherf_svox_conv2_rows_per_block(int Cout) { return (64 / (Cout / 4)) * 4; }
 
 extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
                                       int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
                                       float* bnparam, sherf_stream_t stream) {
     SHERF_CHECK_ARG(partials && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
                        rows_per_block, gamma, beta, stats, training, bnparam);
     SHERF_LAUNCH_CHECK();
 }

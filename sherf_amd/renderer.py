@@ -138,7 +138,7 @@ class _Workspace:
             A=torch.zeros(3, 24, 12, **f32), posefeat=torch.zeros(3, 207, **f32), PO=torch.zeros(3, V, 3, **f32),
             SO=torch.zeros(3, V, 3, **f32), T2C=torch.zeros(V, 12, **f32), C2S=torch.zeros(V, 12, **f32),
             grid_hdr=torch.zeros(2, 8, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
-            cell_pts=torch.zeros(2, V, 4, **f32), cell_scratch=torch.zeros(5 * V, **i32),
+            cell_pts=torch.zeros(2, V, 4, **f32), cell_scratch=torch.zeros(2 * 5 * V, **i32),
             near_mask=torch.zeros(64 * 64 * 64 // 32, **i32),
         )
         self.key, self.t = key, t
@@ -159,7 +159,8 @@ class _Workspace:
         L, off = [], 0
         for li, (nvox, nwords, cap) in enumerate(dims):
             lv = dict(bitmap=zero_region[off:off + nwords], prefix=torch.zeros(nwords, **i32), keys=torch.zeros(cap, **i32),
-                      n_rows=torch.zeros(1, **i32), chunk_ws=torch.zeros(nwords // 1024 + 2, **i32), nwords=nwords, cap=cap)
+                      n_rows=torch.zeros(1, **i32), chunk_ws=torch.zeros(nwords // 1024 + 2, **i32), wp=torch.zeros(nwords, 2, **i32),
+                      nwords=nwords, cap=cap)
             off += nwords
             L.append(lv)
         L[0]['mult'] = zero_region[off:off + N]; off += N
@@ -312,10 +313,8 @@ class ImportanceRenderer(nn.Module):
         # ---- cell lists over the posed (SMPL frame) and canonical vertices ----
         verts = f32(input_data['vertices']).view(V, 3)
         tverts = f32(input_data['t_vertices']).view(V, 3)
-        _lib.call('sherf_build_cells', P(verts), V, P(Rg), P(Th), 0.05, P(ws['grid_hdr'][0]), P(ws['cell_start'][0]),
-                  P(ws['cell_pts'][0]), P(ws['cell_scratch']), P(ws['near_mask']), st)
-        _lib.call('sherf_build_cells', P(tverts), V, None, None, 0.05, P(ws['grid_hdr'][1]), P(ws['cell_start'][1]),
-                  P(ws['cell_pts'][1]), P(ws['cell_scratch']), None, st)
+        _lib.call('sherf_build_cells2', P(verts), P(Rg), P(Th), P(tverts), V, 0.05, P(ws['grid_hdr']), P(ws['cell_start']),
+                  P(ws['cell_pts']), P(ws['cell_scratch']), P(ws['near_mask']), st)
 
         # ---- a11: sparse voxel encoder -> folded level tables ----
         levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws)

@@ -113,7 +113,7 @@ class SparseConvNet(nn.Module):
         l0 = L[0]
         D, H, W = shapes[0]
         _lib.call('sherf_svox_mark_rows', P(coord), N, D, H, W, P(l0['bitmap']), st)
-        _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), P(l0['chunk_ws']), st)
+        _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), P(l0['chunk_ws']), P(l0['wp']), st)
         _lib.call('sherf_svox_keys', P(l0['bitmap']), P(l0['prefix']), l0['nwords'], P(l0['keys']), st)
         _lib.call('sherf_svox_scatter_rows', P(coord), P(feat), N, 32, D, H, W, P(l0['bitmap']), P(l0['prefix']),
                   P(l0['g0']), P(l0['mult']), st)
@@ -125,14 +125,14 @@ class SparseConvNet(nn.Module):
             dst = L[lev + 1] if ly['down'] else src
             if ly['down']:
                 _lib.call('sherf_svox_mark_down', P(src['keys']), P(src['n_rows']), *shapes[lev], P(dst['bitmap']), src['cap'], st)
-                _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), P(dst['chunk_ws']), st)
+                _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), P(dst['chunk_ws']), P(dst['wp']), st)
                 _lib.call('sherf_svox_keys', P(dst['bitmap']), P(dst['prefix']), dst['nwords'], P(dst['keys']), st)
             out = ws.layer_out(li, dst['cap'], ly['cout'], dev)
-            rpb = (256 // (ly['cout'] // 4)) * 4
+            rpb = (64 // (ly['cout'] // 4)) * 4            # rows per block of sconv2_kernel (one wave per block)
             parts = ws.partials(li, (dst['cap'] + rpb - 1) // rpb, ly['cout'], dev)
             mult = P(src['mult']) if (lev == 0 and cur_bn is not None) else None
             dlev = lev + 1 if ly['down'] else lev
-            _lib.call('sherf_svox_conv2', P(dst['keys']), P(dst['n_rows']), *shapes[dlev], P(src['bitmap']), P(src['prefix']),
+            _lib.call('sherf_svox_conv2', P(dst['keys']), P(dst['n_rows']), *shapes[dlev], P(src['wp']),
                       *shapes[lev], P(cur), ly['cin'], P(cur_bn) if cur_bn is not None else None, mult, P(ly['wt']), ly['cout'],
                       1 if ly['down'] else 0, dst['cap'], P(out), P(parts), st)
             bn = ly['bn']
@@ -156,10 +156,10 @@ class SparseConvNet(nn.Module):
         keep = []
         for i, (lev, raw, bnp, C) in enumerate(taps):
             rows = ws.fold_out(i, L[lev]['cap'], dev)                   # relu(bn(raw)) @ fold [C, 96] as a pointwise "conv"
-            _lib.call('sherf_svox_conv2', None, P(L[lev]['n_rows']), 1, 1, 1, None, None, 1, 1, 1, P(raw), C, P(bnp), None,
+            _lib.call('sherf_svox_conv2', None, P(L[lev]['n_rows']), 1, 1, 1, None, 1, 1, 1, P(raw), C, P(bnp), None,
                       P(fold_mats[i]), 96, 2, L[lev]['cap'], P(rows), None, st)
             keep.append(rows)
-            levels[i].bitmap = L[lev]['bitmap'].data_ptr(); levels[i].prefix = L[lev]['prefix'].data_ptr()
+            levels[i].wp = L[lev]['wp'].data_ptr()
             levels[i].rows = rows.data_ptr()
             levels[i].D, levels[i].H, levels[i].W = shapes[lev]
         return levels, keep, dict(levels=L, taps=taps, shapes=shapes)

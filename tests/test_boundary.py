@@ -27,7 +27,7 @@ def test_bad_arguments_return_error_codes_not_crashes():
     assert l.sherf_smpl_bones(None, None, 3, None, None, None, None, None, None) == -1
     assert b'bad argument' in l.sherf_last_error()
     with pytest.raises(RuntimeError):
-        _lib.call('sherf_svox_scan', None, 0, None, None, None)
+        _lib.call('sherf_svox_scan', None, 0, None, None, None, None, None)
 
 
 def test_cpu_tensors_are_rejected_loudly():
