@@ -57,6 +57,9 @@ def main():
     from sherf_amd import dist as sdist
     from oracle import fixtures, synth
 
+    if os.environ.get('SHERF_DEBUG'):
+        from sherf_amd import _lib
+        _lib.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (tools/gpu_ablate.sh)
     smpl = synth.make_synth_smpl(0)
     fx, d, to = make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)

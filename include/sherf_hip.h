@@ -35,6 +35,9 @@ typedef void* sherf_stream_t; /* hipStream_t */
 
 int sherf_version(void);
 const char* sherf_last_error(void);
+/* profiling aid: ablation switches (bit0 sampler skips NN, bit1 sampler skips quick reject, bit2/3/4 gather skips
+ * voxel / tri-plane / pixel taps). Results are WRONG with any bit set; default 0. */
+int sherf_set_debug(int flags);
 
 /* ---------------------------------------------------------------------------------------------
  * a7: SMPL bone transforms.  Replaces get_transform_params_torch + batch_rodrigues_torch +
@@ -171,9 +174,11 @@ int sherf_svox_mark_down(const int32_t* keys, const int32_t* n_rows, int D, int 
 int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* prefix, int32_t* n_rows, int32_t* chunk_ws,
                     uint32_t* wp, sherf_stream_t stream); /* chunk_ws: int32[n_words/1024 + 1]; wp: [n_words][2] */
 int sherf_svox_keys(const uint32_t* bitmap, const int32_t* prefix, int n_words, int32_t* keys, sherf_stream_t stream);
+/* g[row][C] = sum of the input rows in that voxel (acc_fix: zeroed int64[n*C] fixed-point scratch, order independent),
+ * mult[row] = how many (zeroed by the caller). */
 int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int C, int D, int H, int W,
-                            const uint32_t* bitmap, const int32_t* prefix, float* g, int32_t* mult,
-                            sherf_stream_t stream);
+                            const uint32_t* bitmap, const int32_t* prefix, const int32_t* n_rows, int64_t* acc_fix,
+                            float* g, int32_t* mult, sherf_stream_t stream);
 /* submanifold (down=0) or stride-2 (down=1) 3x3x3 conv; wt packed [27][Cin][Cout]. in: level (Di,Hi,Wi). */
 int sherf_svox_conv(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
                     const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in,

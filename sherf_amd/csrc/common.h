@@ -6,6 +6,7 @@
 #include "../../include/sherf_hip.h"
 
 extern char g_sherf_err[256];
+extern int g_sherf_debug;   // ablation switches for profiling (sherf_set_debug); 0 in production
 
 #define SHERF_CHECK_ARG(cond)                                                                     \
     do {                                                                                          \

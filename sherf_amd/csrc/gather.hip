@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                                                             const float4* __restrict__ img4, int H, int W, Levels lv,
                                                             const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
                                                             const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
-                                                            float4* __restrict__ tokens, float* __restrict__ extras) {
+                                                            float4* __restrict__ tokens, float* __restrict__ extras, int dbg) {
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
     const int l = threadIdx.x & 7;                 // channel quad within a slot
@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
             for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
+                if (dbg & 8) break;
                 const float ga = p == 2 ? n[2] : n[0];                 // planes (x,y), (x,z), (z,y)
                 const float gb = p == 1 ? n[2] : n[1];
                 float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                     }
             }
             // ---- pixel-aligned feature + rgb: renderer.py:330-336, align_corners=True ----
-            {
+            if (!(dbg & 16)) {
                 float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
                 float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
                 float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                 ex[6] = rgb.x; ex[7] = rgb.y; ex[8] = rgb.z;
             }
             // ---- sparse voxel levels: renderer.py:544-556 + 762-782, align_corners=True ----
-            {
+            if (!(dbg & 4)) {
                 float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;   // vox_sh = (D,H,W) = (z,y,x)
                 float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
                 float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
@@ -169,6 +170,6 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
                        geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
-                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras);
+                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug);
     SHERF_LAUNCH_CHECK();
 }

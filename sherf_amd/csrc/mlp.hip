@@ -85,7 +85,7 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
 
 template <int PREC> struct Ctx {
     const char* ws;          // packed weight stream (global)
-    const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables
+    const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // 2 slots
     uint4 pf[2 * (PREC + 1)];
     int tid, lane, h;
@@ -206,12 +206,14 @@ template <int PREC>
 __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens,
                                                          const float* __restrict__ extras, const char* __restrict__ ws,
                                                          const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * Ctx<PREC>::SLOT];
+    __shared__ __attribute__((aligned(16))) char lds[2 * Ctx<PREC>::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
     if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
     Ctx<PREC> cx;
-    cx.ws = ws; cx.wbias = wbias; cx.lds = lds;
+    float* lbias = reinterpret_cast<float*>(lds + 2 * Ctx<PREC>::SLOT);
+    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
+    cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
     cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
     const int j = cx.lane & 31, h = cx.h;
     int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);

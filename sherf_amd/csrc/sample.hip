@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         const float4* __restrict__ cell_pts,
                                                         const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
-                                                        int32_t* __restrict__ dense_vid) {
+                                                        int32_t* __restrict__ dense_vid, int dbg) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= R) return;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                       cz = (int)floorf((zs - g.oz) * g.inv_cell);
             if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
                 const int q = (cz * g.ny + cy) * g.nx + cx;
-                if ((near_mask[q >> 5] >> (q & 31)) & 1u) {
+                if (((dbg & 2) || ((near_mask[q >> 5] >> (q & 31)) & 1u)) && !(dbg & 1)) {
                     float best = 3.0e38f;
                     nn_search27(g, cell_start, cell_pts, xs, ys, zs, cx, cy, cz, best, best_id);
                     valid = best < kThresh2;
@@ -393,7 +393,7 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
 #define SHERF_SAMPLE_LAUNCH(N)                                                                                        \
     hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
-                       grid_hdr, cell_start, cp, near_mask, ray_cnt, ray_mask, dense_vid)
+                       grid_hdr, cell_start, cp, near_mask, ray_cnt, ray_mask, dense_vid, g_sherf_debug)
     if (nch == 1) SHERF_SAMPLE_LAUNCH(1); else if (nch == 2) SHERF_SAMPLE_LAUNCH(2);
     else if (nch == 3) SHERF_SAMPLE_LAUNCH(3); else SHERF_SAMPLE_LAUNCH(4);
     hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, ray_cnt, R, base_local, chunk_sum);

@@ -112,9 +112,13 @@ __global__ void __launch_bounds__(256) keys_kernel(const uint32_t* __restrict__ 
     }
 }
 
+// Rows that share a voxel SUM there (spconv indice pairs).  Floating-point atomics would make the sum depend on the
+// arrival order when three or more rows collide, so the sum is taken in 2^-30 fixed point (integer adds commute:
+// bitwise reproducible), then converted once.  |feature| must stay below 2^33.
+constexpr double kFix = 1073741824.0;   // 2^30
 __global__ void __launch_bounds__(256) scatter_rows_kernel(const int32_t* __restrict__ coord, const float* __restrict__ feat,
                                                            int n, int C, int D, int H, int W, const uint32_t* __restrict__ bitmap,
-                                                           const int32_t* __restrict__ prefix, float* __restrict__ g,
+                                                           const int32_t* __restrict__ prefix, unsigned long long* __restrict__ acc,
                                                            int32_t* __restrict__ mult) {
     int idx = blockIdx.x * 256 + threadIdx.x;
     int i = idx / C, c = idx % C;
@@ -124,8 +128,15 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const int32_t* __rest
     int key = (z * H + y) * W + x;
     uint32_t word = bitmap[key >> 5], bit = 1u << (key & 31);
     int row = prefix[key >> 5] + __popc(word & (bit - 1u));
-    atomicAdd(&g[(size_t)row * C + c], feat[(size_t)i * C + c]);
+    long long q = __double2ll_rn((double)feat[(size_t)i * C + c] * kFix);
+    atomicAdd(&acc[(size_t)row * C + c], (unsigned long long)q);
     if (c == 0) atomicAdd(&mult[row], 1);
+}
+
+__global__ void __launch_bounds__(256) fix_to_float_kernel(const long long* __restrict__ acc, const int32_t* __restrict__ n_rows, int C,
+                                                           float* __restrict__ g) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < *n_rows * C) g[idx] = (float)((double)acc[idx] * (1.0 / kFix));
 }
 
 // out[row][co] = sum_{tap, ci} in[nbr(row, tap)][ci] * wt[tap][ci][co]; blockDim = (TPR, RPB)
@@ -411,11 +422,13 @@ extern "C" int sherf_svox_keys(const uint32_t* bitmap, const int32_t* prefix, in
 }
 
 extern "C" int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int C, int D, int H, int W,
-                                       const uint32_t* bitmap, const int32_t* prefix, float* g, int32_t* mult,
-                                       sherf_stream_t stream) {
-    SHERF_CHECK_ARG(coord && feat && bitmap && prefix && g && mult && n > 0 && C > 0);
+                                       const uint32_t* bitmap, const int32_t* prefix, const int32_t* n_rows, int64_t* acc_fix,
+                                       float* g, int32_t* mult, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(coord && feat && bitmap && prefix && n_rows && acc_fix && g && mult && n > 0 && C > 0);
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((int64_t)n * C, 256)), dim3(256), 0, as_stream(stream), coord, feat, n, C,
-                       D, H, W, bitmap, prefix, g, mult);
+                       D, H, W, bitmap, prefix, reinterpret_cast<unsigned long long*>(acc_fix), mult);
+    hipLaunchKernelGGL(fix_to_float_kernel, dim3(cdiv((int64_t)n * C, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const long long*>(acc_fix), n_rows, C, g);
     SHERF_LAUNCH_CHECK();
 }
 

@@ -154,7 +154,7 @@ class _Workspace:
             nvox = D * H * W
             dims.append((nvox, (nvox + 31) // 32, N if li == 0 else min(nvox, 8 * N)))
         # one contiguous region for everything that must be zero at the start of a frame -> a single memset
-        zsize = sum(d[1] for d in dims) + N + N * 32
+        zsize = sum(d[1] for d in dims) + N + N * 32 * 2 + 2
         zero_region = torch.zeros(zsize, **i32)
         L, off = [], 0
         for li, (nvox, nwords, cap) in enumerate(dims):
@@ -164,7 +164,9 @@ class _Workspace:
             off += nwords
             L.append(lv)
         L[0]['mult'] = zero_region[off:off + N]; off += N
-        L[0]['g0'] = zero_region[off:off + N * 32].view(torch.float32).view(N, 32)
+        off += off % 2                                                     # 8-byte alignment of the fixed-point accumulators
+        L[0]['acc_fix'] = zero_region[off:off + N * 64].view(torch.int64)
+        L[0]['g0'] = torch.zeros(N, 32, device=dev)
         L[0]['n_total'] = torch.full((1,), N, **i32)
         self.vox = (key, (L, zero_region))
         return self.vox[1]

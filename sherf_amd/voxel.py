@@ -115,8 +115,8 @@ class SparseConvNet(nn.Module):
         _lib.call('sherf_svox_mark_rows', P(coord), N, D, H, W, P(l0['bitmap']), st)
         _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), P(l0['chunk_ws']), P(l0['wp']), st)
         _lib.call('sherf_svox_keys', P(l0['bitmap']), P(l0['prefix']), l0['nwords'], P(l0['keys']), st)
-        _lib.call('sherf_svox_scatter_rows', P(coord), P(feat), N, 32, D, H, W, P(l0['bitmap']), P(l0['prefix']),
-                  P(l0['g0']), P(l0['mult']), st)
+        _lib.call('sherf_svox_scatter_rows', P(coord), P(feat), N, 32, D, H, W, P(l0['bitmap']), P(l0['prefix']), P(l0['n_rows']),
+                  P(l0['acc_fix']), P(l0['g0']), P(l0['mult']), st)
         lev = 0
         cur, cur_bn = l0['g0'], None                          # raw features of the current level + their BN params (None: raw)
         taps = []

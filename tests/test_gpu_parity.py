@@ -137,6 +137,8 @@ def test_deterministic_and_ray_independent():
     fx['input_data'] = d
     sub = G.hip_render('tiny', fx=fx)
     # depth is clamped with the GLOBAL min/max of the rendered rays' depths (ray_marcher.py:57) -> compare rgb/acc
+    print('ray-independence: max |d rgb|', float((sub['rgb'] - a['rgb'][sel]).abs().max()), 'n diff', int((sub['rgb'] != a['rgb'][sel]).sum()),
+          'max |d acc|', float((sub['acc'] - a['acc'][sel]).abs().max()))
     assert torch.equal(sub['rgb'], a['rgb'][sel]) and torch.equal(sub['acc'], a['acc'][sel])
 
 
