@@ -73,18 +73,19 @@ int sherf_smpl_c2s_table(const float* weights, const float* A_big, const float* 
 /* ---------------------------------------------------------------------------------------------
  * a6 support: uniform cell list over n (<= 6890) vertices, replacing the brute-force pytorch3d K-NN of
  * renderer.py:315,564,627.  verts_s = (verts - Th) @ R when R/Th are non-null (renderer.py:313-314).
- *   grid_hdr[8] x 32 bit: origin xyz, cell, 1/cell (f32), nx, ny, nz (int32 bit patterns); cell >= cell_size,
- *   enlarged only if an axis would exceed 64 cells; scratch: int32[5*n].
+ *   grid_hdr[12] x 32 bit: origin xyz, cell, 1/cell (f32), nx, ny, nz, sub (int32 bit patterns), 3 unused;
+ *   cell >= cell_size, enlarged only if an axis would exceed 64 cells; scratch: int32[5*n].
  *   cell_start[SHERF_MAX_CELLS+1] int32, cell_pts[n] float4 (x,y,z,bitcast(id)) sorted by cell. */
 int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
                       float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                       uint32_t* near_mask, sherf_stream_t stream);
 /* Both per-frame lists in one launch: set 0 = verts_a in the SMPL frame (with near_mask), set 1 = verts_b untransformed.
- * grid_hdr[2][8], cell_start[2][SHERF_MAX_CELLS+1], cell_pts[2][n][4], scratch[2][5n]. */
+ * grid_hdr[2][12], cell_start[2][SHERF_MAX_CELLS+1], cell_pts[2][n][4], scratch[2][5n]. */
 int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a, const float* verts_b, int n,
                        float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                        uint32_t* near_mask, sherf_stream_t stream);
-/* near_mask (nullable): uint32[SHERF_MAX_CELLS/32], bit c set iff a vertex lives in the 3x3x3 neighbourhood of cell c */
+/* near_mask (nullable): uint32[32768]; one bit per sub-cell (edge cell/sub, sub in grid_hdr[8]): set iff the sub-cell's box
+ * comes within cell_size of some vertex -- an unset bit proves "no vertex within the query radius". */
 
 /* a4+a5+a6: sample_stratified (renderer.py:458-481, math_utils.py:101-118), sample positions and SMPL-frame
  * transform (renderer.py:304-310), nearest posed vertex + 5 cm shell mask (renderer.py:315-321) and stream
@@ -179,28 +180,20 @@ int sherf_svox_keys(const uint32_t* bitmap, const int32_t* prefix, int n_words, 
 int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int C, int D, int H, int W,
                             const uint32_t* bitmap, const int32_t* prefix, const int32_t* n_rows, int64_t* acc_fix,
                             float* g, int32_t* mult, sherf_stream_t stream);
-/* submanifold (down=0) or stride-2 (down=1) 3x3x3 conv; wt packed [27][Cin][Cout]. in: level (Di,Hi,Wi). */
-int sherf_svox_conv(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
-                    const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in,
-                    int Cin, const float* wt, int Cout, int down, int max_rows, float* out, sherf_stream_t stream);
-/* v2 (tiled, BatchNorm fused): out_raw = conv(act(in_raw)) with act = relu(in_bn scale/shift) (+ (mult-1)*v0) applied
- * while gathering (in_bn == NULL: raw input).  mode 0 submanifold, 1 stride-2, 2 pointwise (folds the 1x1 projections
- * into the tapped levels).  partials[grid][2][Cout] fp64 per-block sums of out and out^2 (NULL: none). */
-int sherf_svox_conv2(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
-                     const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw,
-                     int Cin, const float* in_bn, const int32_t* in_mult, const float* wt, int Cout, int mode,
+/* Sparse 3x3x3 convolution on MFMA (bf16 operands split hi/lo, fp32 accumulate): out_raw = conv(act(in_raw)) with
+ * act = relu(in_bn scale/shift) (+ (mult-1)*v0) applied while gathering (in_bn == NULL: raw input).
+ * mode 0 submanifold, 1 stride-2 (k3 p1), 2 pointwise (folds the 1x1 projections into the tapped levels).
+ * w_packed: bf16 fragments [ntaps][Cin/16][Cout/32][hi,lo][64 lanes][8] (sherf_amd.voxel.pack_conv_weights).
+ * 32 output rows per workgroup; partials[grid][2][Cout] fp64 per-block sums of out and out^2 (NULL: none). */
+int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
+                     const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw, int Cin,
+                     const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
                      int max_rows, float* out_raw, double* partials, sherf_stream_t stream);
-int sherf_svox_conv2_rows_per_block(int Cout);
 /* statistics over the reference's row set (n_total rows, the non-voxel rows being zeros) -> bnparam[3][C] =
  * (scale, shift, relu(shift)); training != 0: batch statistics into stats[2][C], else stats holds running stats. */
 int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
                            int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
                            float* bnparam, sherf_stream_t stream);
-/* BatchNorm1d(eps=1e-3)+ReLU over the ROW set (rows = n_total_rows, of which the n_rows voxels are non-zero):
- * training!=0 -> batch statistics (written to stats[2][C] = mean, biased var), else running stats from stats. */
-int sherf_svox_bn_relu(float* x, const int32_t* n_rows, const int32_t* mult, const int32_t* n_total_rows, int C,
-                       const float* gamma, const float* beta, float* stats, int training, sherf_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * a3: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-61). cam2world[N][16], intr[N][9]. */
 int sherf_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* origins,

@@ -30,16 +30,19 @@ extern int g_sherf_debug;   // ablation switches for profiling (sherf_set_debug)
 static inline hipStream_t as_stream(sherf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// grid header layout (8 x 32-bit): origin.xyz (f32), cell (f32), inv_cell (f32), nx, ny, nz (i32)
+// grid header layout (12 x 32-bit): origin.xyz (f32), cell (f32), inv_cell (f32), nx, ny, nz (i32), sub (i32: the near
+// mask has sub x sub x sub bits per cell), 3 unused
+constexpr int kGridHdr = 12;
 struct CellGrid {
     float ox, oy, oz, cell, inv_cell;
-    int nx, ny, nz;
+    int nx, ny, nz, sub;
 };
 
 __device__ __forceinline__ CellGrid load_grid(const float* hdr) {
     CellGrid g;
     g.ox = hdr[0]; g.oy = hdr[1]; g.oz = hdr[2]; g.cell = hdr[3]; g.inv_cell = hdr[4];
     g.nx = __float_as_int(hdr[5]); g.ny = __float_as_int(hdr[6]); g.nz = __float_as_int(hdr[7]);
+    g.sub = __float_as_int(hdr[8]);
     return g;
 }
 

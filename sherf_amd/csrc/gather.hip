@@ -113,27 +113,28 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                     float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
                     float fx = px - x0, fy = py - y0, fz = pz - z0;
                     int xi = (int)x0, yi = (int)y0, zi = (int)z0;
+                    // phase 1: the 8 occupancy records, issued back to back (independent loads)
+                    uint2 rec[8];
 #pragma unroll
-                    for (int dz = 0; dz < 2; ++dz)
+                    for (int t = 0; t < 8; ++t) {
+                        const int xx = xi + (t & 1), yy = yi + ((t >> 1) & 1), zz = zi + (t >> 2);
+                        const bool inb = xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
+                        const int key = inb ? (zz * lev.H + yy) * lev.W + xx : 0;
+                        const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                        const uint32_t bit = 1u << (key & 31);
+                        rec[t] = make_uint2((inb && (rr.x & bit)) ? 1u : 0u, rr.y + __popc(rr.x & (bit - 1u)));
+                    }
+                    // phase 2: rows of the occupied corners
 #pragma unroll
-                        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                            for (int dx = 0; dx < 2; ++dx) {
-                                int xx = xi + dx, yy = yi + dy, zz = zi + dz;
-                                if (xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
-                                    int key = (zz * lev.H + yy) * lev.W + xx;
-                                    const uint2 rec = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
-                                    const uint32_t bit = 1u << (key & 31);
-                                    if (rec.x & bit) {
-                                        int row = (int)rec.y + __popc(rec.x & (bit - 1u));
-                                        float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy) * (dz ? fz : 1.f - fz);
-                                        const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)row * 24;
-                                        axpy4(acc[0], w, r[l]);
-                                        axpy4(acc[1], w, r[8 + l]);
-                                        axpy4(acc[2], w, r[16 + l]);
-                                    }
-                                }
-                            }
+                    for (int t = 0; t < 8; ++t) {
+                        if (rec[t].x) {
+                            const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
+                            const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)rec[t].y * 24;
+                            axpy4(acc[0], w, r[l]);
+                            axpy4(acc[1], w, r[8 + l]);
+                            axpy4(acc[2], w, r[16 + l]);
+                        }
+                    }
                 }
             }
         } else {

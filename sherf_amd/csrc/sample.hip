@@ -35,9 +35,11 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
                                                            float cell_size, float* __restrict__ hdr,
                                                            int32_t* __restrict__ cell_start, float4* __restrict__ cell_pts,
                                                            int32_t* __restrict__ scratch, uint32_t* __restrict__ near_mask) {
-    __shared__ uint32_t s_near[SHERF_MAX_CELLS / 32];      // 1 bit per cell: some vertex lives in its 3x3x3 neighbourhood
+    // near mask: 1 bit per sub-cell (cell/sub) whose box comes within the query radius of some vertex. sub = 2 when the
+    // refined grid fits (<= 2^20 bits = 128 KiB of LDS), else 1.
+    __shared__ uint32_t s_near[32768];
     __shared__ float red[6][1024 / 64];
-    __shared__ float s_hdr[8];
+    __shared__ float s_hdr[kGridHdr];
     __shared__ int s_part[1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* pos = reinterpret_cast<float*>(scratch) ;            // [n][3] transformed positions
@@ -70,14 +72,19 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
         for (int c = 0; c < 3; ++c) dims[c] = min(64, (int)floorf((hi[c] - lo[c]) * inv) + 3);
         s_hdr[0] = lo[0] - cell; s_hdr[1] = lo[1] - cell; s_hdr[2] = lo[2] - cell; s_hdr[3] = cell; s_hdr[4] = inv;
         s_hdr[5] = __int_as_float(dims[0]); s_hdr[6] = __int_as_float(dims[1]); s_hdr[7] = __int_as_float(dims[2]);
-        for (int i = 0; i < 8; ++i) hdr[i] = s_hdr[i];
+        const int sub = (8 * dims[0] * dims[1] * dims[2] <= 32768 * 32) ? 2 : 1;
+        s_hdr[8] = __int_as_float(sub); s_hdr[9] = s_hdr[10] = s_hdr[11] = 0.f;
+        for (int i = 0; i < kGridHdr; ++i) hdr[i] = s_hdr[i];
     }
     __syncthreads();
     const float ox = s_hdr[0], oy = s_hdr[1], oz = s_hdr[2], inv = s_hdr[4];
     const int nx = __float_as_int(s_hdr[5]), ny = __float_as_int(s_hdr[6]), nz = __float_as_int(s_hdr[7]);
     const int ncell = nx * ny * nz;
     for (int i = tid; i <= ncell; i += 1024) cell_start[i] = 0;
-    for (int i = tid; i < SHERF_MAX_CELLS / 32; i += 1024) s_near[i] = 0u;
+    const int sub = __float_as_int(s_hdr[8]);
+    const int snx = nx * sub, sny = ny * sub, snz = nz * sub;
+    const int near_words = (snx * sny * snz + 31) / 32;
+    for (int i = tid; i < near_words; i += 1024) s_near[i] = 0u;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         int cx = min(nx - 1, max(0, (int)floorf((pos[i * 3] - ox) * inv)));
@@ -86,17 +93,28 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
         int c = (cz * ny + cy) * nx + cx;
         cid[i] = c;
         rank[i] = atomicAdd(&cell_start[c], 1);
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    int qx = cx + dx, qy = cy + dy, qz = cz + dz;
-                    if (qx < 0 || qx >= nx || qy < 0 || qy >= ny || qz < 0 || qz >= nz) continue;
-                    int q = (qz * ny + qy) * nx + qx;
-                    atomicOr(&s_near[q >> 5], 1u << (q & 31));
-                }
+        if (near_mask) {
+            // mark every sub-cell whose box lies within the query radius (cell_size) of this vertex (conservative margin)
+            const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
+            const float cs = s_hdr[3] / (float)sub, rad = cell_size + 1e-3f * cs, rad2 = rad * rad;
+            const int sx = (int)floorf((px - ox) * inv * sub), sy = (int)floorf((py - oy) * inv * sub), sz = (int)floorf((pz - oz) * inv * sub);
+            for (int dz = -sub; dz <= sub; ++dz)
+                for (int dy = -sub; dy <= sub; ++dy)
+                    for (int dx = -sub; dx <= sub; ++dx) {
+                        const int qx = sx + dx, qy = sy + dy, qz = sz + dz;
+                        if (qx < 0 || qx >= snx || qy < 0 || qy >= sny || qz < 0 || qz >= snz) continue;
+                        const float bx = ox + qx * cs, by = oy + qy * cs, bz = oz + qz * cs;
+                        const float ex = fmaxf(fmaxf(bx - px, px - (bx + cs)), 0.f), ey = fmaxf(fmaxf(by - py, py - (by + cs)), 0.f),
+                                    ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
+                        if (ex * ex + ey * ey + ez * ez < rad2) {
+                            const int q = (qz * sny + qy) * snx + qx;
+                            atomicOr(&s_near[q >> 5], 1u << (q & 31));
+                        }
+                    }
+        }
     }
     __syncthreads();
-    if (near_mask) for (int i = tid; i < SHERF_MAX_CELLS / 32; i += 1024) near_mask[i] = s_near[i];
+    if (near_mask) for (int i = tid; i < near_words; i += 1024) near_mask[i] = s_near[i];
     // exclusive scan of cell_start[0..ncell] in place: per-thread segments + block scan of the partials
     const int seg = (ncell + 1 + 1023) / 1024;
     const int s0 = tid * seg, s1 = min(ncell + 1, s0 + seg);
@@ -137,7 +155,7 @@ __global__ void __launch_bounds__(1024) build_cells2_kernel(const float* __restr
     if (blockIdx.x == 0)
         build_cells_body(verts_a, n, R_a, Th_a, cell_size, hdr, cell_start, cell_pts, scratch, near_mask);
     else
-        build_cells_body(verts_b, n, nullptr, nullptr, cell_size, hdr + 8, cell_start + (SHERF_MAX_CELLS + 1), cell_pts + n,
+        build_cells_body(verts_b, n, nullptr, nullptr, cell_size, hdr + kGridHdr, cell_start + (SHERF_MAX_CELLS + 1), cell_pts + n,
                          scratch + 5 * n, nullptr);
 }
 
@@ -180,10 +198,11 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
             to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
             // quick reject: a sample within 5 cm of a vertex lies in a cell whose 3x3x3 neighbourhood holds that vertex
             // (cells are >= 5 cm and the grid carries a one-cell margin), so an unset bit means "no vertex in range".
-            const int cx = (int)floorf((xs - g.ox) * g.inv_cell), cy = (int)floorf((ys - g.oy) * g.inv_cell),
-                      cz = (int)floorf((zs - g.oz) * g.inv_cell);
-            if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
-                const int q = (cz * g.ny + cy) * g.nx + cx;
+            const float fs = g.inv_cell * (float)g.sub;
+            const int sx = (int)floorf((xs - g.ox) * fs), sy = (int)floorf((ys - g.oy) * fs), sz = (int)floorf((zs - g.oz) * fs);
+            const int cx = g.sub == 2 ? sx >> 1 : sx, cy = g.sub == 2 ? sy >> 1 : sy, cz = g.sub == 2 ? sz >> 1 : sz;
+            if (sx >= 0 && cx < g.nx && sy >= 0 && cy < g.ny && sz >= 0 && cz < g.nz) {
+                const int q = (sz * (g.ny * g.sub) + sy) * (g.nx * g.sub) + sx;
                 if (((dbg & 2) || ((near_mask[q >> 5] >> (q & 31)) & 1u)) && !(dbg & 1)) {
                     float best = 3.0e38f;
                     nn_search27(g, cell_start, cell_pts, xs, ys, zs, cx, cy, cz, best, best_id);

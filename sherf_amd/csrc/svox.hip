@@ -139,133 +139,45 @@ __global__ void __launch_bounds__(256) fix_to_float_kernel(const long long* __re
     if (idx < *n_rows * C) g[idx] = (float)((double)acc[idx] * (1.0 / kFix));
 }
 
-// out[row][co] = sum_{tap, ci} in[nbr(row, tap)][ci] * wt[tap][ci][co]; blockDim = (TPR, RPB)
-constexpr int kMaxCin = 96;
-__global__ void sconv_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out, int Do, int Ho, int Wo,
-                             const uint32_t* __restrict__ bitmap_in, const int32_t* __restrict__ prefix_in, int Di, int Hi, int Wi,
-                             const float* __restrict__ in, int Cin, const float* __restrict__ wt, int Cout, int down,
-                             float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int RPB = blockDim.y, TPR = blockDim.x;
-    int* s_nb = reinterpret_cast<int*>(smem);                                   // [RPB][28]
-    float* s_in = reinterpret_cast<float*>(smem + RPB * 28 * sizeof(int));      // [RPB][27][Cin]
-    const int n_rows = *n_rows_out;
-    const int row = blockIdx.x * RPB + threadIdx.y;
-    if (blockIdx.x * RPB >= n_rows) return;
-    const bool live = row < n_rows;
-    const int cx = threadIdx.x;
-    if (cx < 27) {
-        int nb = -1;
-        if (live) {
-            int key = keys_out[row];
-            int z = key / (Ho * Wo), y = (key / Wo) % Ho, x = key % Wo;
-            int kz = cx / 9, ky = (cx / 3) % 3, kx = cx % 3;
-            int qz = down ? 2 * z + kz - 1 : z + kz - 1, qy = down ? 2 * y + ky - 1 : y + ky - 1,
-                qx = down ? 2 * x + kx - 1 : x + kx - 1;
-            if (qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi) {
-                int qk = (qz * Hi + qy) * Wi + qx;
-                uint32_t word = bitmap_in[qk >> 5], bit = 1u << (qk & 31);
-                if (word & bit) nb = prefix_in[qk >> 5] + __popc(word & (bit - 1u));
-            }
-        }
-        s_nb[threadIdx.y * 28 + cx] = nb;
-    }
-    __syncthreads();
-    for (int tap = 0; tap < 27; ++tap) {
-        int nb = s_nb[threadIdx.y * 28 + tap];
-        if (nb >= 0)
-            for (int ci = cx; ci < Cin; ci += TPR) s_in[(threadIdx.y * 27 + tap) * Cin + ci] = in[(size_t)nb * Cin + ci];
-    }
-    __syncthreads();
-    if (!live || cx >= Cout) return;
-    float acc = 0.f;
-    for (int tap = 0; tap < 27; ++tap) {
-        if (s_nb[threadIdx.y * 28 + tap] < 0) continue;
-        const float* si = s_in + (threadIdx.y * 27 + tap) * Cin;
-        const float* w = wt + (size_t)tap * Cin * Cout + cx;
-        for (int ci = 0; ci < Cin; ++ci) acc += si[ci] * w[(size_t)ci * Cout];
-    }
-    out[(size_t)row * Cout + cx] = acc;
-}
-
-// BatchNorm1d(eps=1e-3) + ReLU over the reference's row set; one block (rows <= ~60k, C <= 96)
-__global__ void __launch_bounds__(1024) bn_relu_kernel(float* __restrict__ x, const int32_t* __restrict__ n_rows_p,
-                                                       const int32_t* __restrict__ mult, const int32_t* __restrict__ n_total_p,
-                                                       int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ stats, int training) {
-    __shared__ float s_red[1024];
-    __shared__ float s_mean[kMaxCin], s_scale[kMaxCin], s_shift[kMaxCin], s_v0[kMaxCin];
-    const int n_rows = *n_rows_p;
-    const float n_total = (float)(*n_total_p);
-    const int G = 1024 / C;
-    const int tid = threadIdx.x;
-    const int grp = tid / C, c = tid % C;
-    const bool act = grp < G;
-    if (training) {
-        float sum = 0.f;
-        if (act) for (int r = grp; r < n_rows; r += G) sum += x[(size_t)r * C + c];
-        s_red[tid] = sum;
-        __syncthreads();
-        if (tid < C) {
-            float t = 0.f;
-            for (int g = 0; g < G; ++g) t += s_red[g * C + tid];
-            s_mean[tid] = t / n_total;
-        }
-        __syncthreads();
-        float m = act ? s_mean[c] : 0.f, sq = 0.f;
-        if (act) for (int r = grp; r < n_rows; r += G) { float d = x[(size_t)r * C + c] - m; sq += d * d; }
-        s_red[tid] = sq;
-        __syncthreads();
-        if (tid < C) {
-            float t = 0.f;
-            for (int g = 0; g < G; ++g) t += s_red[g * C + tid];
-            float mean = s_mean[tid];
-            float var = (t + (n_total - (float)n_rows) * mean * mean) / n_total;      // zero rows of the reference
-            stats[tid] = mean; stats[C + tid] = var;
-        }
-        __syncthreads();
-    }
-    if (tid < C) {
-        float mean = stats[tid], var = stats[C + tid];
-        float inv = 1.0f / sqrtf(var + 1e-3f);
-        s_mean[tid] = mean; s_scale[tid] = inv * gamma[tid]; s_shift[tid] = beta[tid];
-        s_v0[tid] = fmaxf((0.f - mean) * inv * gamma[tid] + beta[tid], 0.f);
-    }
-    __syncthreads();
-    if (act)
-        for (int r = grp; r < n_rows; r += G) {
-            float v = fmaxf((x[(size_t)r * C + c] - s_mean[c]) * s_scale[c] + s_shift[c], 0.f);
-            if (mult) v += (float)(mult[r] - 1) * s_v0[c];
-            x[(size_t)r * C + c] = v;
-        }
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// v2: tiled sparse convolution.  A block owns TM output rows; per kernel tap it stages W_tap [Cin][COUT] and the
-// gathered (BatchNorm+ReLU applied on the fly) input rows in LDS and does a 4x4 register-tiled fp32 product.
-// mode 0 submanifold, 1 stride-2 (k3 p1), 2 pointwise (1 tap, row -> same row; used to fold the 1x1 projections).
-// BatchNorm statistics of the OUTPUT are produced as per-block fp64 partial sums (deterministic two-stage reduce).
+// Sparse 3x3x3 convolution on MFMA (v_mfma_f32_32x32x16_bf16, operands split hi/lo -> fp32-grade "bf16x3").
+//   out[row][co] = sum_tap sum_ci act(in[nbr(row,tap)][ci]) * W[tap][ci][co]
+// A workgroup (4 waves) owns 32 output rows; the taps present in the tile are dealt round-robin to the waves, each
+// wave accumulates its taps into 32 x Cout fp32 tiles, and the four partial tiles are summed in a fixed order
+// through LDS (deterministic).  The A operand (32 rows x 16 input channels) is gathered straight from global memory
+// -- lane (row, half) reads 8 consecutive channels of its neighbour row -- with the producer's BatchNorm+ReLU applied
+// on the fly; the B operand comes pre-packed in fragment order (sherf_amd/voxel.py: pack_conv_weights).
+// mode 0 submanifold, 1 stride-2 (k3 p1), 2 pointwise (1 tap, row -> same row: folds the 1x1 projections).
 // ---------------------------------------------------------------------------------------------
-template <int COUT, int NTHR>
-__global__ void __launch_bounds__(NTHR) sconv2_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+    bf16x2_t v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float rt(float a) { return (float)((__bf16)a); }
+
+template <int NCOT>   // Cout = 32 * NCOT
+__global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, int Cin, const float* __restrict__ in_bn,
-                                                     const int32_t* __restrict__ in_mult, const float* __restrict__ wt, int mode,
+                                                     const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
                                                      float* __restrict__ out_raw, double* __restrict__ partials) {
-    constexpr int CQ = COUT / 4, RQ = NTHR / CQ, TM = RQ * 4, TMP = TM + 4;
+    constexpr int COUT = 32 * NCOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_w = reinterpret_cast<float*>(smem);                          // [Cin][COUT]
-    float* s_in = s_w + Cin * COUT;                                       // [Cin][TMP]
-    int* s_nb = reinterpret_cast<int*>(s_in + Cin * TMP);                 // [ntaps][TM]
-    float* s_red = s_in;                                                  // [2][RQ][COUT], reused after the tap loop
+    int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
+    float* s_bn = reinterpret_cast<float*>(smem + 27 * 32 * 4);                 // [3][Cin]
+    float* s_red = s_bn + 3 * Cin;                                              // [4][32][COUT]
     const int n_rows = *n_rows_out;
-    const int row0 = blockIdx.x * TM;
+    const int row0 = blockIdx.x * 32;
     if (row0 >= n_rows) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntaps = mode == 2 ? 1 : 27;
-    for (int i = tid; i < ntaps * TM; i += NTHR) {
-        const int tap = i / TM, r = i % TM, row = row0 + r;
+    const int NKB = Cin / 16;
+    for (int i = tid; i < ntaps * 32; i += 256) {
+        const int tap = i >> 5, r = i & 31, row = row0 + r;
         int nb = -1;
         if (row < n_rows) {
             if (mode == 2) nb = row;
@@ -283,70 +195,73 @@ __global__ void __launch_bounds__(NTHR) sconv2_kernel(const int32_t* __restrict_
                 }
             }
         }
-        s_nb[tap * TM + r] = nb;
+        s_nb[i] = nb;
     }
+    if (in_bn) for (int i = tid; i < 3 * Cin; i += 256) s_bn[i] = in_bn[i];
     __syncthreads();
-    const int cq = tid % CQ, rq = tid / CQ;
-    const bool worker = rq < RQ;
-    float acc[4][4];
+
+    f32x16_t acc[NCOT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int c = 0; c < NCOT; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int tap = 0; tap < ntaps; ++tap) {
-        bool any = false;
-        for (int r = tid; r < TM; r += NTHR) any |= s_nb[tap * TM + r] >= 0;
-        if (!__syncthreads_or(any)) continue;                             // no row of this tile has that neighbour
-        const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)tap * Cin * COUT);
-        for (int i = tid; i < Cin * COUT / 4; i += NTHR) reinterpret_cast<float4*>(s_w)[i] = wsrc[i];
-        for (int i = tid; i < TM * Cin; i += NTHR) {
-            const int r = i / Cin, ci = i % Cin;
-            const int nb = s_nb[tap * TM + r];
-            float v = 0.f;
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    const int r = lane & 31, h = lane >> 5;
+    for (int tap = wave; tap < ntaps; tap += 4) {
+        const int nb = s_nb[tap * 32 + r];
+        if (__ballot(nb >= 0) == 0ull) continue;                               // nobody in this tile has that neighbour
+        const float mlt = (in_mult && nb >= 0) ? (float)(in_mult[nb] - 1) : 0.f;
+        const float4* src = reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h;
+        for (int kb = 0; kb < NKB; ++kb) {
+            float v[8];
             if (nb >= 0) {
-                v = in_raw[(size_t)nb * Cin + ci];
+                const float4 a = src[4 * kb], b = src[4 * kb + 1];
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
                 if (in_bn) {
-                    v = fmaxf(v * in_bn[ci] + in_bn[Cin + ci], 0.f);
-                    if (in_mult) v += (float)(in_mult[nb] - 1) * in_bn[2 * Cin + ci];
+                    const float* sc = s_bn + kb * 16 + 8 * h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sc[Cin + e], 0.f) + mlt * sc[2 * Cin + e];
                 }
-            }
-            s_in[ci * TMP + r] = v;
-        }
-        __syncthreads();
-        if (worker) {
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float4 a = *reinterpret_cast<const float4*>(s_in + ci * TMP + 4 * rq);
-                const float4 w = *reinterpret_cast<const float4*>(s_w + ci * COUT + 4 * cq);
-                acc[0][0] += a.x * w.x; acc[0][1] += a.x * w.y; acc[0][2] += a.x * w.z; acc[0][3] += a.x * w.w;
-                acc[1][0] += a.y * w.x; acc[1][1] += a.y * w.y; acc[1][2] += a.y * w.z; acc[1][3] += a.y * w.w;
-                acc[2][0] += a.z * w.x; acc[2][1] += a.z * w.y; acc[2][2] += a.z * w.z; acc[2][3] += a.z * w.w;
-                acc[3][0] += a.w * w.x; acc[3][1] += a.w * w.y; acc[3][2] += a.w * w.z; acc[3][3] += a.w * w.w;
-            }
-        }
-        __syncthreads();
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (worker) {
+            } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + 4 * rq + i;
-            if (row < n_rows) {
-                *reinterpret_cast<float4*>(out_raw + (size_t)row * COUT + 4 * cq) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            const uint4 ahi = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+            const uint4 alo = make_uint4(pk2(v[0] - rt(v[0]), v[1] - rt(v[1])), pk2(v[2] - rt(v[2]), v[3] - rt(v[3])),
+                                         pk2(v[4] - rt(v[4]), v[5] - rt(v[5])), pk2(v[6] - rt(v[6]), v[7] - rt(v[7])));
+            const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[j] += acc[i][j]; s2[j] += acc[i][j] * acc[i][j]; }
+            for (int c = 0; c < NCOT; ++c) {
+                const uint4 bhi = wsrc[(c * 2 + 0) * 64], blo = wsrc[(c * 2 + 1) * 64];
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, alo), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, blo), acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
             }
         }
     }
+    // D layout: lane = (col j = lane&31, half h), reg q <-> tile row (q&3) + 8*(q>>2) + 4*h
+#pragma unroll
+    for (int c = 0; c < NCOT; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_red[((wave * 32) + (q & 3) + 8 * (q >> 2) + 4 * h) * COUT + c * 32 + r] = acc[c][q];
+    __syncthreads();
+    constexpr int G = 256 / COUT;                       // row groups: 8 / 4 / 2
+    const int g = tid / COUT, co = tid % COUT;
+    float s1 = 0.f, s2 = 0.f;
+    if (g < G)
+        for (int rr = g; rr < 32; rr += G) {
+            const float val = ((s_red[(0 * 32 + rr) * COUT + co] + s_red[(1 * 32 + rr) * COUT + co]) + s_red[(2 * 32 + rr) * COUT + co]) +
+                              s_red[(3 * 32 + rr) * COUT + co];
+            if (row0 + rr < n_rows) { out_raw[(size_t)(row0 + rr) * COUT + co] = val; s1 += val; s2 += val * val; }
+        }
     if (partials) {
-        if (worker)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s_red[rq * COUT + 4 * cq + j] = s1[j]; s_red[(RQ + rq) * COUT + 4 * cq + j] = s2[j]; }
         __syncthreads();
-        for (int u = tid; u < 2 * COUT; u += NTHR) {
-            const int which = u / COUT, co = u % COUT;
+        if (g < G) { s_red[g * COUT + co] = s1; s_red[(G + g) * COUT + co] = s2; }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, c2 = tid % COUT;
             double t = 0.0;
-            for (int q = 0; q < RQ; ++q) t += (double)s_red[(which * RQ + q) * COUT + co];
-            partials[((size_t)blockIdx.x * 2 + which) * COUT + co] = t;
+            for (int q = 0; q < G; ++q) t += (double)s_red[(which * G + q) * COUT + c2];
+            partials[((size_t)blockIdx.x * 2 + which) * COUT + c2] = t;
         }
     }
 }
@@ -432,46 +347,9 @@ extern "C" int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, 
     SHERF_LAUNCH_CHECK();
 }
 
-extern "C" int sherf_svox_conv(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
-                               const uint32_t* bitmap_in, const int32_t* prefix_in, int Di, int Hi, int Wi, const float* in,
-                               int Cin, const float* wt, int Cout, int down, int max_rows, float* out, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(keys_out && n_rows_out && bitmap_in && prefix_in && in && wt && out);
-    SHERF_CHECK_ARG(Cin > 0 && Cin <= kMaxCin && Cout > 0 && Cout <= 96 && max_rows > 0);
-    const int TPR = ((Cout + 31) / 32) * 32;
-    const int RPB = TPR == 32 ? 8 : (TPR == 64 ? 4 : 2);
-    const size_t smem = (size_t)RPB * 28 * sizeof(int) + (size_t)RPB * 27 * Cin * sizeof(float);
-    hipLaunchKernelGGL(sconv_kernel, dim3(cdiv(max_rows, RPB)), dim3(TPR, RPB), smem, as_stream(stream), keys_out, n_rows_out,
-                       Do, Ho, Wo, bitmap_in, prefix_in, Di, Hi, Wi, in, Cin, wt, Cout, down, out);
-    SHERF_LAUNCH_CHECK();
-}
 
-extern "C" int sherf_svox_bn_relu(float* x, const int32_t* n_rows, const int32_t* mult, const int32_t* n_total_rows, int C,
-                                  const float* gamma, const float* beta, float* stats, int training, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(x && n_rows && n_total_rows && gamma && beta && stats && C > 0 && C <= kMaxCin);
-    hipLaunchKernelGGL(bn_relu_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n_rows, mult, n_total_rows, C, gamma, beta,
-                       stats, training);
-    SHERF_LAUNCH_CHECK();
-}
 
-extern "C" int sherf_svox_conv2(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
-                                const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw,
-                                int Cin, const float* in_bn, const int32_t* in_mult, const float* wt, int Cout, int mode,
-                                int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(n_rows_out && in_raw && wt && out_raw && (mode == 2 || (keys_out && wp_in)));
-    SHERF_CHECK_ARG(Cin > 0 && Cin <= 96 && Cin % 4 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
-    constexpr int NTHR = 64;                    // one wave per block: 32 / 16 / 8 rows per block -> hundreds of blocks even at 2.7k rows
-    const int CQ = Cout / 4, RQ = NTHR / CQ, TM = RQ * 4, TMP = TM + 4;
-    const size_t smem = (size_t)Cin * Cout * 4 + (size_t)Cin * TMP * 4 + (size_t)27 * TM * 4;
-    SHERF_CHECK_ARG(partials == nullptr || Cin * TMP >= 2 * RQ * Cout);
-    const dim3 grid(cdiv(max_rows, TM)), block(NTHR);
-#define SHERF_CONV2(C)                                                                                                        \
-    hipLaunchKernelGGL((sconv2_kernel<C, NTHR>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo, \
-                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, wt, mode, out_raw, partials)
-    if (Cout == 32) SHERF_CONV2(32); else if (Cout == 64) SHERF_CONV2(64); else SHERF_CONV2(96);
-    SHERF_LAUNCH_CHECK();
-}
 
-extern "C" int sherf_svox_conv2_rows_per_block(int Cout) { return (64 / (Cout / 4)) * 4; }
 
 extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
                                       int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
@@ -479,5 +357,21 @@ extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_r
     SHERF_CHECK_ARG(partials && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
                        rows_per_block, gamma, beta, stats, training, bnparam);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
+                                const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw, int Cin,
+                                const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
+                                int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
+    SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
+    const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
+    const dim3 grid(cdiv(max_rows, 32)), block(256);
+#define SHERF_CONV3(N)                                                                                                       \
+    hipLaunchKernelGGL(sconv3_kernel<N>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,                \
+                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult,                          \
+                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials)
+    if (Cout == 32) SHERF_CONV3(1); else if (Cout == 64) SHERF_CONV3(2); else SHERF_CONV3(3);
     SHERF_LAUNCH_CHECK();
 }

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import _lib, mlp_pack
 from .ray_marcher import MipRayMarcher2
-from .voxel import SparseConvNet, SparseConvTensor  # noqa: F401
+from .voxel import SparseConvNet, SparseConvTensor, pack_conv_weights  # noqa: F401
 
 V = 6890
 
@@ -137,9 +137,9 @@ class _Workspace:
             rgb=torch.zeros(R, 3, **f32), depth=torch.zeros(R, **f32), acc=torch.zeros(R, **f32),
             A=torch.zeros(3, 24, 12, **f32), posefeat=torch.zeros(3, 207, **f32), PO=torch.zeros(3, V, 3, **f32),
             SO=torch.zeros(3, V, 3, **f32), T2C=torch.zeros(V, 12, **f32), C2S=torch.zeros(V, 12, **f32),
-            grid_hdr=torch.zeros(2, 8, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
+            grid_hdr=torch.zeros(2, 12, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
             cell_pts=torch.zeros(2, V, 4, **f32), cell_scratch=torch.zeros(2 * 5 * V, **i32),
-            near_mask=torch.zeros(64 * 64 * 64 // 32, **i32),
+            near_mask=torch.zeros(32768, **i32),
         )
         self.key, self.t = key, t
         return t
@@ -264,7 +264,7 @@ class ImportanceRenderer(nn.Module):
         fold = []
         for c0, c1 in cols:             # F_l [96, C_l]: rows 32s.. = W_c @ W_p[32s:32s+32, cols_l]
             F = torch.cat([Wc @ Wp[32 * s:32 * s + 32, c0:c1] for s in range(3)], 0)
-            fold.append(F.t().contiguous().to(device))
+            fold.append(pack_conv_weights(F.t().contiguous()[None]).to(device))   # [C_l, 96] as a 1-tap conv
         tok_bias = torch.cat([br + Wc @ bp[32 * s:32 * s + 32] for s in range(3)]).contiguous().to(device)
         self._wcache = dict(key=key, stream=torch.from_numpy(stream).to(device), wbias=torch.from_numpy(wbias).to(device),
                             Wa_t=Wa.t().contiguous().to(device), Wb_t=Wb.t().contiguous().to(device), fold=fold,

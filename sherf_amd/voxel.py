@@ -57,6 +57,17 @@ def _stride_conv(cin, cout):
     return nn.Sequential(SparseConv3d(cin, cout), _bn(cout), nn.ReLU())
 
 
+def pack_conv_weights(wt):
+    """wt [ntaps, Cin, Cout] fp32 -> bf16 MFMA B-operand fragments [ntaps][Cin/16][Cout/32][hi,lo][64 lanes][8] (int16 bits).
+    Lane l = (column j = l & 31, half h = l >> 5) holds W[tap][16*kb + 8*h + e][32*cot + j], e = 0..7
+    (operand layout of v_mfma_f32_32x32x16_bf16; consumed by sconv3_kernel in csrc/svox.hip)."""
+    T, Cin, Cout = wt.shape
+    w = wt.float().reshape(T, Cin // 16, 2, 8, Cout // 32, 32).permute(0, 1, 4, 2, 5, 3).reshape(T, Cin // 16, Cout // 32, 64, 8)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], 3).contiguous().view(torch.int16)
+
+
 # executed part of the network: (module name, number of convs in it); a tap follows conv1, conv2, conv3
 _PLAN = (('conv0', 2), ('down0', 1), ('conv1', 2), ('down1', 1), ('conv2', 3), ('down2', 1), ('conv3', 3))
 
@@ -85,7 +96,7 @@ class SparseConvNet(nn.Module):
                 conv, bn = seq[3 * i], seq[3 * i + 1]
                 w = conv.weight.detach().to(device=device, dtype=torch.float32)
                 wt = w.permute(1, 2, 3, 4, 0).reshape(27, conv.in_channels, conv.out_channels).contiguous()
-                layers.append(dict(wt=wt, cin=conv.in_channels, cout=conv.out_channels, down=conv.stride == 2, bn=bn,
+                layers.append(dict(wt=pack_conv_weights(wt), cin=conv.in_channels, cout=conv.out_channels, down=conv.stride == 2, bn=bn,
                                    gamma=bn.weight.detach().float().contiguous(), beta=bn.bias.detach().float().contiguous(),
                                    tap=(name in ('conv1', 'conv2', 'conv3') and i == n - 1)))
         self._packed = dict(key=key, layers=layers)
@@ -128,11 +139,11 @@ class SparseConvNet(nn.Module):
                 _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), P(dst['chunk_ws']), P(dst['wp']), st)
                 _lib.call('sherf_svox_keys', P(dst['bitmap']), P(dst['prefix']), dst['nwords'], P(dst['keys']), st)
             out = ws.layer_out(li, dst['cap'], ly['cout'], dev)
-            rpb = (64 // (ly['cout'] // 4)) * 4            # rows per block of sconv2_kernel (one wave per block)
+            rpb = 32                                          # output rows per workgroup of sconv3_kernel
             parts = ws.partials(li, (dst['cap'] + rpb - 1) // rpb, ly['cout'], dev)
             mult = P(src['mult']) if (lev == 0 and cur_bn is not None) else None
             dlev = lev + 1 if ly['down'] else lev
-            _lib.call('sherf_svox_conv2', P(dst['keys']), P(dst['n_rows']), *shapes[dlev], P(src['wp']),
+            _lib.call('sherf_svox_conv3', P(dst['keys']), P(dst['n_rows']), *shapes[dlev], P(src['wp']),
                       *shapes[lev], P(cur), ly['cin'], P(cur_bn) if cur_bn is not None else None, mult, P(ly['wt']), ly['cout'],
                       1 if ly['down'] else 0, dst['cap'], P(out), P(parts), st)
             bn = ly['bn']
@@ -156,7 +167,7 @@ class SparseConvNet(nn.Module):
         keep = []
         for i, (lev, raw, bnp, C) in enumerate(taps):
             rows = ws.fold_out(i, L[lev]['cap'], dev)                   # relu(bn(raw)) @ fold [C, 96] as a pointwise "conv"
-            _lib.call('sherf_svox_conv2', None, P(L[lev]['n_rows']), 1, 1, 1, None, 1, 1, 1, P(raw), C, P(bnp), None,
+            _lib.call('sherf_svox_conv3', None, P(L[lev]['n_rows']), 1, 1, 1, None, 1, 1, 1, P(raw), C, P(bnp), None,
                       P(fold_mats[i]), 96, 2, L[lev]['cap'], P(rows), None, st)
             keep.append(rows)
             levels[i].wp = L[lev]['wp'].data_ptr()

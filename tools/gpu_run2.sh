@@ -11,5 +11,7 @@ rm -rf $OUT/prof; mkdir -p $OUT/prof
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
 echo "prof rc=$?"; grep '"metric"' $OUT/prof_bench.log
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $OUT/prof/trace_results.db 13 45 > $OUT/kernel_stats.txt; rm -rf $OUT/prof
+cut -c1-150 $OUT/kernel_stats.txt | head -32
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench.log
