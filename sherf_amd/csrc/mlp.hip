@@ -88,14 +88,14 @@ template <int PREC> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // 2 slots
     uint4 pf[2 * (PREC + 1)];
-    int tid, lane, h;
+    int tid, lane, h, dbg;
     static constexpr int SLOT = MAX_NKB * 1024 * (PREC + 1);
     __device__ __forceinline__ char* slot(int c) const { return lds + (c & 1) * SLOT; }
 };
 
 template <int PREC>
 __device__ __forceinline__ void pf_load(Ctx<PREC>& cx, int c) {
-    if (c >= N_CHUNKS) return;
+    if (c >= N_CHUNKS || (cx.dbg & 32)) return;
     const int bytes = chunk_nkb(c) * 1024 * (PREC + 1);
     const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024;
 #pragma unroll
@@ -106,7 +106,7 @@ __device__ __forceinline__ void pf_load(Ctx<PREC>& cx, int c) {
 }
 template <int PREC>
 __device__ __forceinline__ void pf_store(Ctx<PREC>& cx, int c) {
-    if (c >= N_CHUNKS) return;
+    if (c >= N_CHUNKS || (cx.dbg & 32)) return;
     const int bytes = chunk_nkb(c) * 1024 * (PREC + 1);
     char* dst = cx.slot(c);
 #pragma unroll
@@ -119,7 +119,7 @@ __device__ __forceinline__ void pf_store(Ctx<PREC>& cx, int c) {
 template <int PREC>
 __device__ __forceinline__ void advance(Ctx<PREC>& cx, int c) {
     pf_store(cx, c + 1);
-    __syncthreads();
+    if (!(cx.dbg & 64)) __syncthreads();
     pf_load(cx, c + 2);
 }
 
@@ -205,7 +205,7 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 template <int PREC>
 __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens,
                                                          const float* __restrict__ extras, const char* __restrict__ ws,
-                                                         const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+                                                         const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
     __shared__ __attribute__((aligned(16))) char lds[2 * Ctx<PREC>::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
     float* lbias = reinterpret_cast<float*>(lds + 2 * Ctx<PREC>::SLOT);
     for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
-    cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
+    cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
     const int j = cx.lane & 31, h = cx.h;
     int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
     const bool live = tile < n_tiles;
@@ -494,10 +494,10 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
     if (prec == 0)
         hipLaunchKernelGGL(nerf_mlp_kernel<0>, dim3(grid), dim3(NT), 0, as_stream(stream), counters,
                            reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out));
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
     else
         hipLaunchKernelGGL(nerf_mlp_kernel<1>, dim3(grid), dim3(NT), 0, as_stream(stream), counters,
                            reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out));
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
     SHERF_LAUNCH_CHECK();
 }

@@ -108,7 +108,8 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
                                     ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
                         if (ex * ex + ey * ey + ez * ez < rad2) {
                             const int q = (qz * sny + qy) * snx + qx;
-                            atomicOr(&s_near[q >> 5], 1u << (q & 31));
+                            const uint32_t bit = 1u << (q & 31);
+                            if (!(s_near[q >> 5] & bit)) atomicOr(&s_near[q >> 5], bit);      // most marks are repeats
                         }
                     }
         }
@@ -168,6 +169,11 @@ __device__ __forceinline__ float depth_at(float near, float range, int k, int S)
     return __fadd_rn(near, __fmul_rn(step, range));
 }
 
+// One wave per ray.  Candidate samples (near-mask hit) are searched COOPERATIVELY: each candidate lane first fetches the
+// nine x-contiguous point segments of its 3x3x3 cell neighbourhood (18 independent loads, all candidates in parallel);
+// then, candidate by candidate, the segment table is broadcast (v_readlane) and the 64 lanes test 64 points at once;
+// the lexicographic minimum of (d^2, vertex id) is taken with one 64-bit LDS atomic min (d^2 >= 0, so the IEEE bit
+// pattern orders like the value).  Only points closer than the 5 cm threshold ever reach the atomic.
 template <int NCH>
 __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                         const float* __restrict__ near, const float* __restrict__ far,
@@ -178,40 +184,83 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid, int dbg) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ unsigned long long s_key[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
     if (ray >= R) return;
     const CellGrid g = load_grid(hdr);
     const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
     const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
     const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+    const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
     int total = 0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int k = ch * 64 + lane;
-        bool valid = false;
-        int best_id = 0x7FFFFFFF;
+        bool cand = false;
+        float xs = 0.f, ys = 0.f, zs = 0.f;
+        int seg_s[9], seg_n[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { seg_s[i] = 0; seg_n[i] = 0; }
         if (k < S) {
             float t = depth_at(nr, range, k, S);
             float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
-            float xs, ys, zs;
             to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
-            // quick reject: a sample within 5 cm of a vertex lies in a cell whose 3x3x3 neighbourhood holds that vertex
-            // (cells are >= 5 cm and the grid carries a one-cell margin), so an unset bit means "no vertex in range".
+            // quick reject: an unset near-mask bit proves that no vertex lies within 5 cm of this sample
             const float fs = g.inv_cell * (float)g.sub;
             const int sx = (int)floorf((xs - g.ox) * fs), sy = (int)floorf((ys - g.oy) * fs), sz = (int)floorf((zs - g.oz) * fs);
             const int cx = g.sub == 2 ? sx >> 1 : sx, cy = g.sub == 2 ? sy >> 1 : sy, cz = g.sub == 2 ? sz >> 1 : sz;
             if (sx >= 0 && cx < g.nx && sy >= 0 && cy < g.ny && sz >= 0 && cz < g.nz) {
                 const int q = (sz * (g.ny * g.sub) + sy) * (g.nx * g.sub) + sx;
-                if (((dbg & 2) || ((near_mask[q >> 5] >> (q & 31)) & 1u)) && !(dbg & 1)) {
-                    float best = 3.0e38f;
-                    nn_search27(g, cell_start, cell_pts, xs, ys, zs, cx, cy, cz, best, best_id);
-                    valid = best < kThresh2;
+                cand = (((dbg & 2) || ((near_mask[q >> 5] >> (q & 31)) & 1u)) && !(dbg & 1));
+                if (cand) {
+                    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
+                        if (qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny) {
+                            const int row = (qz * g.ny + qy) * g.nx;
+                            seg_s[i] = cell_start[row + x0];
+                            seg_n[i] = cell_start[row + x1 + 1] - seg_s[i];
+                        }
+                    }
                 }
             }
         }
-        uint64_t m = __ballot(valid);
-        if (valid) dense_vid[(size_t)ray * S + k] = best_id;
+        unsigned long long cmask = __ballot(cand);
+        unsigned long long my_key = kInit;
+        while (cmask) {
+            const int src = __ffsll((long long)cmask) - 1;
+            cmask &= cmask - 1;
+            const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), src));
+            const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), src));
+            const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), src));
+            int bs[9], cum[10];
+            cum[0] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                bs[i] = __builtin_amdgcn_readlane(seg_s[i], src);
+                cum[i + 1] = cum[i] + __builtin_amdgcn_readlane(seg_n[i], src);
+            }
+            if (lane == 0) __hip_atomic_store(&s_key[wave], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int base = 0; base < cum[9]; base += 64) {
+                const int t = base + lane;
+                if (t < cum[9]) {
+                    int p = bs[0] + t;
+#pragma unroll
+                    for (int i = 1; i < 9; ++i) p = (t >= cum[i]) ? bs[i] + (t - cum[i]) : p;
+                    const float4 v = cell_pts[p];
+                    const float dd = dist2_exact(qx, qy, qz, v.x, v.y, v.z);
+                    if (dd < kThresh2)
+                        atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
+                }
+            }
+            const unsigned long long res = __hip_atomic_load(&s_key[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (lane == src) my_key = res;
+        }
+        const bool valid = (unsigned)(my_key >> 32) < __float_as_uint(kThresh2);
+        const uint64_t m = __ballot(valid);
+        if (valid) dense_vid[(size_t)ray * S + k] = (int)(my_key & 0x7FFFFFFFull);
         if (lane == 0) ray_mask[(size_t)ray * NCH + ch] = m;
         total += __popcll(m);
     }
