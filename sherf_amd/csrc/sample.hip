@@ -35,9 +35,6 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
                                                            float cell_size, float* __restrict__ hdr,
                                                            int32_t* __restrict__ cell_start, float4* __restrict__ cell_pts,
                                                            int32_t* __restrict__ scratch, uint32_t* __restrict__ near_mask) {
-    // near mask: 1 bit per sub-cell (cell/sub) whose box comes within the query radius of some vertex. sub = 2 when the
-    // refined grid fits (<= 2^20 bits = 128 KiB of LDS), else 1.
-    __shared__ uint32_t s_near[32768];
     __shared__ float red[6][1024 / 64];
     __shared__ float s_hdr[kGridHdr];
     __shared__ int s_part[1024];
@@ -81,10 +78,6 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
     const int nx = __float_as_int(s_hdr[5]), ny = __float_as_int(s_hdr[6]), nz = __float_as_int(s_hdr[7]);
     const int ncell = nx * ny * nz;
     for (int i = tid; i <= ncell; i += 1024) cell_start[i] = 0;
-    const int sub = __float_as_int(s_hdr[8]);
-    const int snx = nx * sub, sny = ny * sub, snz = nz * sub;
-    const int near_words = (snx * sny * snz + 31) / 32;
-    for (int i = tid; i < near_words; i += 1024) s_near[i] = 0u;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         int cx = min(nx - 1, max(0, (int)floorf((pos[i * 3] - ox) * inv)));
@@ -93,29 +86,8 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
         int c = (cz * ny + cy) * nx + cx;
         cid[i] = c;
         rank[i] = atomicAdd(&cell_start[c], 1);
-        if (near_mask) {
-            // mark every sub-cell whose box lies within the query radius (cell_size) of this vertex (conservative margin)
-            const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
-            const float cs = s_hdr[3] / (float)sub, rad = cell_size + 1e-3f * cs, rad2 = rad * rad;
-            const int sx = (int)floorf((px - ox) * inv * sub), sy = (int)floorf((py - oy) * inv * sub), sz = (int)floorf((pz - oz) * inv * sub);
-            for (int dz = -sub; dz <= sub; ++dz)
-                for (int dy = -sub; dy <= sub; ++dy)
-                    for (int dx = -sub; dx <= sub; ++dx) {
-                        const int qx = sx + dx, qy = sy + dy, qz = sz + dz;
-                        if (qx < 0 || qx >= snx || qy < 0 || qy >= sny || qz < 0 || qz >= snz) continue;
-                        const float bx = ox + qx * cs, by = oy + qy * cs, bz = oz + qz * cs;
-                        const float ex = fmaxf(fmaxf(bx - px, px - (bx + cs)), 0.f), ey = fmaxf(fmaxf(by - py, py - (by + cs)), 0.f),
-                                    ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
-                        if (ex * ex + ey * ey + ez * ez < rad2) {
-                            const int q = (qz * sny + qy) * snx + qx;
-                            const uint32_t bit = 1u << (q & 31);
-                            if (!(s_near[q >> 5] & bit)) atomicOr(&s_near[q >> 5], bit);      // most marks are repeats
-                        }
-                    }
-        }
     }
     __syncthreads();
-    if (near_mask) for (int i = tid; i < near_words; i += 1024) near_mask[i] = s_near[i];
     // exclusive scan of cell_start[0..ncell] in place: per-thread segments + block scan of the partials
     const int seg = (ncell + 1 + 1023) / 1024;
     const int s0 = tid * seg, s1 = min(ncell + 1, s0 + seg);
@@ -160,6 +132,34 @@ __global__ void __launch_bounds__(1024) build_cells2_kernel(const float* __restr
                          scratch + 5 * n, nullptr);
 }
 
+// near mask: 1 bit per sub-cell (edge cell/sub) whose box comes within the query radius of some vertex; sub = 2 when the
+// refined grid fits the 2^20-bit buffer, else 1.  One thread per vertex, global atomics only for bits not yet set.
+__global__ void __launch_bounds__(256) near_mask_kernel(const float* __restrict__ pos, int n, const float* __restrict__ hdr,
+                                                        float radius, uint32_t* __restrict__ near_mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const CellGrid g = load_grid(hdr);
+    const int sub = g.sub, snx = g.nx * sub, sny = g.ny * sub, snz = g.nz * sub;
+    const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
+    const float cs = g.cell / (float)sub, rad = radius + 1e-3f * cs, rad2 = rad * rad, fs = g.inv_cell * (float)sub;
+    const int sx = (int)floorf((px - g.ox) * fs), sy = (int)floorf((py - g.oy) * fs), sz = (int)floorf((pz - g.oz) * fs);
+    for (int dz = -sub; dz <= sub; ++dz)
+        for (int dy = -sub; dy <= sub; ++dy)
+            for (int dx = -sub; dx <= sub; ++dx) {
+                const int qx = sx + dx, qy = sy + dy, qz = sz + dz;
+                if (qx < 0 || qx >= snx || qy < 0 || qy >= sny || qz < 0 || qz >= snz) continue;
+                const float bx = g.ox + qx * cs, by = g.oy + qy * cs, bz = g.oz + qz * cs;
+                const float ex = fmaxf(fmaxf(bx - px, px - (bx + cs)), 0.f), ey = fmaxf(fmaxf(by - py, py - (by + cs)), 0.f),
+                            ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
+                if (ex * ex + ey * ey + ez * ez < rad2) {
+                    const int q = (qz * sny + qy) * snx + qx;
+                    const uint32_t bit = 1u << (q & 31);
+                    if (!(__hip_atomic_load(&near_mask[q >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+                        atomicOr(&near_mask[q >> 5], bit);
+                }
+            }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pass 1: one wave per ray: depths, positions, exact NN within 5 cm, validity mask
 // ---------------------------------------------------------------------------------------------
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid, int dbg) {
-    __shared__ unsigned long long s_key[4];
+    __shared__ unsigned long long s_key[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= R) return;
@@ -230,33 +230,48 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
         unsigned long long cmask = __ballot(cand);
         unsigned long long my_key = kInit;
         while (cmask) {
-            const int src = __ffsll((long long)cmask) - 1;
-            cmask &= cmask - 1;
-            const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), src));
-            const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), src));
-            const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), src));
-            int bs[9], cum[10];
-            cum[0] = 0;
+            // up to 4 candidates per round: their point loads are issued together (latency overlap)
+            int src[4], bs[4][9], cum[4][10];
+            float qx[4], qy[4], qz[4];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                bs[i] = __builtin_amdgcn_readlane(seg_s[i], src);
-                cum[i + 1] = cum[i] + __builtin_amdgcn_readlane(seg_n[i], src);
-            }
-            if (lane == 0) __hip_atomic_store(&s_key[wave], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            for (int base = 0; base < cum[9]; base += 64) {
-                const int t = base + lane;
-                if (t < cum[9]) {
-                    int p = bs[0] + t;
+            for (int u = 0; u < 4; ++u) {
+                src[u] = cmask ? __ffsll((long long)cmask) - 1 : -1;
+                cmask &= cmask - 1;                                              // (0 & -1) == 0: stays empty
+                const int sl = src[u] < 0 ? 0 : src[u];
+                qx[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), sl));
+                qy[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), sl));
+                qz[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), sl));
+                cum[u][0] = 0;
 #pragma unroll
-                    for (int i = 1; i < 9; ++i) p = (t >= cum[i]) ? bs[i] + (t - cum[i]) : p;
-                    const float4 v = cell_pts[p];
-                    const float dd = dist2_exact(qx, qy, qz, v.x, v.y, v.z);
-                    if (dd < kThresh2)
-                        atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
+                for (int i = 0; i < 9; ++i) {
+                    bs[u][i] = __builtin_amdgcn_readlane(seg_s[i], sl);
+                    cum[u][i + 1] = cum[u][i] + (src[u] < 0 ? 0 : __builtin_amdgcn_readlane(seg_n[i], sl));
                 }
             }
-            const unsigned long long res = __hip_atomic_load(&s_key[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (lane == src) my_key = res;
+            if (lane < 4) __hip_atomic_store(&s_key[wave * 4 + lane], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const int maxn = max(max(cum[0][9], cum[1][9]), max(cum[2][9], cum[3][9]));
+            for (int base = 0; base < maxn; base += 64) {
+                const int t = base + lane;
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int p = bs[u][0] + t;
+#pragma unroll
+                    for (int i = 1; i < 9; ++i) p = (t >= cum[u][i]) ? bs[u][i] + (t - cum[u][i]) : p;
+                    v[u] = t < cum[u][9] ? cell_pts[p] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dd = dist2_exact(qx[u], qy[u], qz[u], v[u].x, v[u].y, v[u].z);
+                    if (dd < kThresh2)
+                        atomicMin(&s_key[wave * 4 + u], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u].w));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long res = __hip_atomic_load(&s_key[wave * 4 + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (lane == src[u]) my_key = res;
+            }
         }
         const bool valid = (unsigned)(my_key >> 32) < __float_as_uint(kThresh2);
         const uint64_t m = __ballot(valid);
@@ -429,6 +444,11 @@ extern "C" int sherf_build_cells(const float* verts, int n, const float* R, cons
     SHERF_CHECK_ARG((R == nullptr) == (Th == nullptr));
     hipLaunchKernelGGL(build_cells_kernel, dim3(1), dim3(1024), 0, as_stream(stream), verts, n, R, Th, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
+    if (near_mask) {
+        (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
+        hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(scratch),
+                           n, grid_hdr, cell_size, near_mask);
+    }
     SHERF_LAUNCH_CHECK();
 }
 
@@ -439,6 +459,9 @@ extern "C" int sherf_build_cells2(const float* verts_a, const float* R_a, const 
     SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
     hipLaunchKernelGGL(build_cells2_kernel, dim3(2), dim3(1024), 0, as_stream(stream), verts_a, R_a, Th_a, verts_b, n, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
+    (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
+    hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(scratch), n,
+                       grid_hdr, cell_size, near_mask);
     SHERF_LAUNCH_CHECK();
 }
 

@@ -4,11 +4,11 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout 600 python tools/gpu_diag.py tiny > $OUT/diag.log 2>&1; echo "diag rc=$?"
-grep -E "nv hip|mismatch|bf16x3|psnr|EXCEPTION|Error" $OUT/diag.log | tail -8
+grep -E "nv hip|mismatch|bf16x3|psnr|EXCEPTION|Error|fp16" $OUT/diag.log | tail -9
 timeout 900 python -m pytest tests -m gpu -q --timeout=600 -x --no-header -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
 tail -4 $OUT/pytest.log
 cd /tmp
-for F in 0 32 96; do
+for F in 0; do
   rm -rf $OUT/abl_$F; mkdir -p $OUT/abl_$F
   SHERF_DEBUG=$F timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/abl_$F -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/abl_$F.log 2>&1
   if [ "$F" = "0" ]; then python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $OUT/abl_0/t_results.db 13 45 > $OUT/kernel_stats.txt; cut -c1-150 $OUT/kernel_stats.txt | head -24; grep '"metric"' $OUT/abl_0.log | cut -c1-200; fi
@@ -23,3 +23,4 @@ PY
 done
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench.log | cut -c1-260
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --voxel-table-dtype fp16 2>&1 | grep '"metric"' | tee $OUT/bench_fp16rows.log | cut -c1-260
