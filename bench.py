@@ -43,7 +43,6 @@ def main():
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--voxel-table-dtype', default='fp32', choices=['fp32', 'fp16'])
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
@@ -58,6 +57,9 @@ def main():
     from sherf_amd import dist as sdist
     from oracle import fixtures, synth
 
+    if os.environ.get('SHERF_DEBUG'):
+        from sherf_amd import _lib
+        _lib.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (tools/gpu_run3.sh)
     smpl = synth.make_synth_smpl(0)
     fx, d, to = make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)
@@ -73,7 +75,7 @@ def main():
     planes, obs_feat = to(fx['planes']), to(fx['obs_feat'])
     obs_img = d['obs_img_all'][:, 0]
     ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
-    opts = dict(fx['options']); opts['mlp_precision'] = a.precision; opts['voxel_table_dtype'] = a.voxel_table_dtype
+    opts = dict(fx['options']); opts['mlp_precision'] = a.precision
     R = ro.shape[1]; S = opts['depth_resolution']
     rend.profile_mlp = True
 

@@ -139,8 +139,6 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
  * (pix_stride 64, group_base 32). */
 int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int groups, int pix_stride,
                       int64_t group_base, sherf_stream_t stream);
-/* rows [n_rows][C] fp32 -> fp16 (optional compact voxel tables; enabled with sherf_set_debug bit 7 = 128) */
-int sherf_rows_to_half(const float* in, const int32_t* n_rows, int C, int max_rows, void* out, sherf_stream_t stream);
 /* obs image [3][HW] -> [HW][4] (rgb0) for the rgb tap of renderer.py:336 */
 int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t stream);
 

@@ -150,6 +150,33 @@ def run(cfg_name, R, T, out_dir):
           f'({os.path.getsize(path)/1e6:.2f} MB)')
 
 
+def run_glue(R, T, out_dir, cfg_name='tiny'):
+    """Golden for the TriPlaneGenerator.synthesis glue (triplane.py:105-126): per-vertex features + back-face mask,
+    produced with the reference's own projection / compute_normal / rgb_enc and a seeded conv1d_projection."""
+    import torch.nn.functional as F
+    from oracle import fixtures
+    fx = fixtures.renderer_inputs(cfg_name)
+    d = fixtures.to_torch(fx['input_data'])
+    rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
+    conv = torch.nn.Conv1d(96, 32, 1)
+    fixtures.load_seeded_state(conv, 'generator.conv1d_projection.')
+    obs_img = d['obs_img_all'][:, 0]
+    obs_feat = torch.from_numpy(fx['obs_feat'])
+    with torch.no_grad():
+        uv, mask = rend.projection(d['obs_vertices'].reshape(1, -1, 3), d['obs_R_all'], d['obs_T_all'], d['obs_K_all'], rend.SMPL_NEUTRAL['f'])
+        uv = uv.view(-1, *uv.shape[2:])
+        uv_ = 2.0 * uv.unsqueeze(2).type(torch.float32) / torch.Tensor([obs_img.shape[-1], obs_img.shape[-2]]) - 1.0
+        vf = F.grid_sample(obs_feat, uv_, align_corners=True)[..., 0].permute(0, 2, 1)
+        vrgb = F.grid_sample(obs_img, uv_, align_corners=True)[..., 0].permute(0, 2, 1)
+        sh = vrgb.shape
+        vrgb = rend.rgb_enc(vrgb.reshape(-1, 3)).reshape(*sh[:2], 33)[..., :32]
+        f3d = conv(torch.cat((vf, vrgb), -1).permute(0, 2, 1)).permute(0, 2, 1)
+        f3d[mask == 0] = 0
+    path = os.path.join(out_dir, f'glue_{cfg_name}.npz')
+    np.savez_compressed(path, vertex_feat=f3d[0].numpy(), front_mask=mask[0].numpy())
+    print('glue ->', path, 'front-facing', float(mask.float().mean()))
+
+
 def run_small_units(R, T, out_dir):
     """Golden vectors for the standalone API pieces: RaySampler, MipRayMarcher2, PositionalEncoding, linspace."""
     from training.volumetric_rendering.ray_sampler import RaySampler
@@ -197,5 +224,6 @@ if __name__ == '__main__':
     os.makedirs(out_dir, exist_ok=True)
     R, T = import_reference()
     run_small_units(R, T, out_dir)
+    run_glue(R, T, out_dir)
     for n in names:
         run(n, R, T, out_dir)

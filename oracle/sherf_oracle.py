@@ -222,6 +222,34 @@ def triplane_features(planes, x_c, bounds):
     return torch.stack([grid_sample_2d(planes[p], n[:, a], n[:, b], False) for p, (a, b) in enumerate(sel)])
 
 
+def compute_normal(vertices, faces):
+    """renderer.py:50-63: normalised face normals accumulated on their three vertices, normalised again. [V,3], [F,3]."""
+    tri = vertices[faces]
+    n = torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=-1)
+    ln = torch.sqrt((n ** 2).sum(-1)).clamp_min(1e-8)
+    n = n / ln[:, None]
+    norm = torch.zeros_like(vertices)
+    for c in range(3):
+        norm.index_add_(0, faces[:, c], n)
+    ln = torch.sqrt((norm ** 2).sum(-1)).clamp_min(1e-8)
+    return norm / ln[:, None]
+
+
+def vertex_features(state, st, obs_vertices, Rc, Tc, K, obs_feat, obs_img, prefix='generator.'):
+    """triplane.py:111-126: per-vertex 32-d features for the sparse voxel encoder. Projects the observation-pose
+    vertices into the observation image, taps feature map + image (align_corners=True), PE5(rgb)[:32], conv1d 96->32,
+    zeroes back-facing vertices (normal . view >= 0, renderer.py:691-695). -> (feat [6890,32], front mask [6890])."""
+    cam = torch.matmul(obs_vertices, Rc.view(3, 3).t()) + Tc.view(1, 3)
+    ncam = torch.matmul(compute_normal(obs_vertices, st['f']), Rc.view(3, 3).t())
+    front = (ncam * cam).sum(-1) < 0
+    h = torch.matmul(cam, K.view(3, 3).t())
+    uv = h[:, :2] / (h[:, 2:] + 1e-5)
+    f2d, _ = pixel_aligned_features(uv, obs_feat, obs_img)
+    W = state[prefix + 'conv1d_projection.weight'][:, :, 0]
+    f = f2d @ W.t() + state[prefix + 'conv1d_projection.bias']
+    return f * front[:, None].float(), front
+
+
 # ----------------------------------------------------------------------------------------------
 # sparse voxel encoder (unique-voxel formulation, see module docstring)
 # ----------------------------------------------------------------------------------------------

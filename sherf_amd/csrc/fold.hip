@@ -3,7 +3,6 @@
 // kernel's taps land directly in token space.  Memory bound: reads NCHW once (coalesced over pixels), writes
 // channel-last once.   out[group_base*g + pix*pix_stride + o] = sum_c W[o][c] * in[(g*32 + c)*HW + pix]
 #include "common.h"
-#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -36,14 +35,6 @@ __global__ void __launch_bounds__(256) img4_kernel(const float* __restrict__ img
     if (p < HW) out[p] = make_float4(img[p], img[HW + p], img[2 * (size_t)HW + p], 0.f);
 }
 
-__global__ void __launch_bounds__(256) to_half_kernel(const float4* __restrict__ in, const int32_t* __restrict__ n_rows, int C4,
-                                                      uint2* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)(*n_rows) * C4) return;
-    const float4 v = in[i];
-    out[i] = make_uint2(__builtin_bit_cast(uint32_t, __floats2half2_rn(v.x, v.y)), __builtin_bit_cast(uint32_t, __floats2half2_rn(v.z, v.w)));
-}
-
 }  // namespace
 
 extern "C" int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int groups, int pix_stride,
@@ -57,13 +48,5 @@ extern "C" int sherf_fold_tables(const float* in, const float* Wt, float* out, i
 extern "C" int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t stream) {
     SHERF_CHECK_ARG(img && out && HW > 0);
     hipLaunchKernelGGL(img4_kernel, dim3(cdiv(HW, 256)), dim3(256), 0, as_stream(stream), img, reinterpret_cast<float4*>(out), HW);
-    SHERF_LAUNCH_CHECK();
-}
-
-/* rows [n_rows][C] fp32 -> fp16 (optional compact voxel tables for the gather). */
-extern "C" int sherf_rows_to_half(const float* in, const int32_t* n_rows, int C, int max_rows, void* out, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(in && n_rows && out && C > 0 && C % 4 == 0 && max_rows > 0);
-    hipLaunchKernelGGL(to_half_kernel, dim3(cdiv((int64_t)max_rows * (C / 4), 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float4*>(in), n_rows, C / 4, reinterpret_cast<uint2*>(out));
     SHERF_LAUNCH_CHECK();
 }

@@ -8,7 +8,6 @@
 // MLP kernel.  Tables are channel-last fp32 so every tap is one 16-byte load per lane: 8 lanes own the
 // 8 channel quads of a slot, 8 samples per wave, 32 samples (= one MFMA column tile) per workgroup.
 #include "common.h"
-#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -20,7 +19,6 @@ __device__ __forceinline__ void axpy4(float4& a, float w, const float4 v) {
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-template <bool VOX_HALF>
 __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                             const float4* __restrict__ planes_f, int P,
                                                             const float4* __restrict__ feat_f, int Hf, int Wf,
@@ -106,8 +104,8 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                 float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;   // vox_sh = (D,H,W) = (z,y,x)
                 float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
                 float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
-#pragma unroll
-                for (int L = 0; L < 3; ++L) {
+#pragma unroll 1
+                for (int L = 0; L < 3; ++L) {      // not unrolled: keeps the register count (occupancy) down
                     const sherf_vox_level& lev = lv.l[L];
                     float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
                     float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
@@ -131,20 +129,10 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                     for (int t = 0; t < 8; ++t) {
                         if (rec[t].x) {
                             const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
-                            if constexpr (VOX_HALF) {          // rows stored as fp16 [n][96]: 8 bytes per lane per slot
-                                const uint2* r = reinterpret_cast<const uint2*>(lev.rows) + (size_t)rec[t].y * 24;
-#pragma unroll
-                                for (int sl = 0; sl < 3; ++sl) {
-                                    const uint2 u = r[sl * 8 + l];
-                                    const float2 a = __half22float2(__builtin_bit_cast(__half2, u.x)), b = __half22float2(__builtin_bit_cast(__half2, u.y));
-                                    axpy4(acc[sl], w, make_float4(a.x, a.y, b.x, b.y));
-                                }
-                            } else {
-                                const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)rec[t].y * 24;
-                                axpy4(acc[0], w, r[l]);
-                                axpy4(acc[1], w, r[8 + l]);
-                                axpy4(acc[2], w, r[16 + l]);
-                            }
+                            const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)rec[t].y * 24;
+                            axpy4(acc[0], w, r[l]);
+                            axpy4(acc[1], w, r[8 + l]);
+                            axpy4(acc[2], w, r[16 + l]);
                         }
                     }
                 }
@@ -180,14 +168,7 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     }
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
     const int64_t tiles = (capacity + 31) / 32;
-    const bool vox_half = (g_sherf_debug & 128) != 0;     // set by sherf_set_options (fp16 voxel rows)
-    if (vox_half)
-        hipLaunchKernelGGL(gather_tokens_kernel<true>, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
-                       geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
-                       reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
-                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug);
-    else
-    hipLaunchKernelGGL(gather_tokens_kernel<false>, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
                        geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug);

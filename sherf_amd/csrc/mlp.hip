@@ -62,14 +62,29 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 }
 __device__ __forceinline__ float bf16_rt(float a) { return (float)((__bf16)a); }
 
+// hi/lo split of a pair for the bf16x3 mode: hi = the top 16 bits (truncation; one v_perm for the pair), lo = x - hi is
+// exact in fp32 and then rounded to bf16, so hi + lo carries ~17 bits whichever way hi was rounded.
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
+    hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);          // [a.hi16 | b.hi16 << 16]
+    lo = pack2(a - __builtin_bit_cast(float, ua & 0xFFFF0000u), b - __builtin_bit_cast(float, ub & 0xFFFF0000u));
+}
+
 template <int PREC>
 __device__ __forceinline__ BFrag<PREC> make_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
     BFrag<PREC> f;
-    f.hi = make_uint4(pack2(v0, v1), pack2(v2, v3), pack2(v4, v5), pack2(v6, v7));
-    if constexpr (PREC == 1)
-        f.lo = make_uint4(pack2(v0 - bf16_rt(v0), v1 - bf16_rt(v1)), pack2(v2 - bf16_rt(v2), v3 - bf16_rt(v3)),
-                          pack2(v4 - bf16_rt(v4), v5 - bf16_rt(v5)), pack2(v6 - bf16_rt(v6), v7 - bf16_rt(v7)));
+    if constexpr (PREC == 1) {
+        split2(v0, v1, f.hi.x, f.lo.x); split2(v2, v3, f.hi.y, f.lo.y);
+        split2(v4, v5, f.hi.z, f.lo.z); split2(v6, v7, f.hi.w, f.lo.w);
+    } else {
+        f.hi = make_uint4(pack2(v0, v1), pack2(v2, v3), pack2(v4, v5), pack2(v6, v7));
+    }
     return f;
+}
+
+// ReLU as an integer max: one instruction, no NaN-canonicalising v_max pair (inputs are finite)
+__device__ __forceinline__ float relu(float x) {
+    return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
 }
 
 // one fp32 accumulator tile -> the two K-blocks it becomes as an input of the next layer
@@ -384,7 +399,7 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
             mma_chunk<PREC, 5, 1>(cx, 9 + T, b, acc);
             advance(cx, 9 + T);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
             split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
         }
     }
@@ -398,7 +413,7 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
             else mma_chunk<PREC, 8, 1>(cx, c, ha, acc);
             advance(cx, c);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
             if (L & 1) split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
             else split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
         }
@@ -415,7 +430,7 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
             mma_chunk<PREC, 13, 1>(cx, 29 + T, b, acc);
             advance(cx, 29 + T);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
             split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
         }
     }
@@ -429,7 +444,7 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
             else mma_chunk<PREC, 8, 1>(cx, c, ha, acc);
             advance(cx, c);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
             if (L == 0) split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
             else split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
         }
@@ -460,7 +475,7 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
         mma_chunk<PREC, 12, 1>(cx, 46 + T, vb, acc);
         advance(cx, 46 + T);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+        for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
         split_tile<PREC>(acc[0], gb[0][2 * T], gb[0][2 * T + 1]);
     }
     {

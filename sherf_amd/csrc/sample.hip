@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(1024) build_cells2_kernel(const float* __restr
 }
 
 // near mask: 1 bit per sub-cell (edge cell/sub) whose box comes within the query radius of some vertex; sub = 2 when the
-// refined grid fits the 2^20-bit buffer, else 1.  One thread per vertex, global atomics only for bits not yet set.
+// refined grid fits the 2^20-bit buffer, else 1.  One thread per vertex, fire-and-forget global atomics.
 __global__ void __launch_bounds__(256) near_mask_kernel(const float* __restrict__ pos, int n, const float* __restrict__ hdr,
                                                         float radius, uint32_t* __restrict__ near_mask) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -153,9 +153,7 @@ __global__ void __launch_bounds__(256) near_mask_kernel(const float* __restrict_
                             ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
                 if (ex * ex + ey * ey + ez * ez < rad2) {
                     const int q = (qz * sny + qy) * snx + qx;
-                    const uint32_t bit = 1u << (q & 31);
-                    if (!(__hip_atomic_load(&near_mask[q >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
-                        atomicOr(&near_mask[q >> 5], bit);
+                    atomicOr(&near_mask[q >> 5], 1u << (q & 31));      // result unused: non-returning atomic, no latency chain
                 }
             }
 }
@@ -184,7 +182,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid, int dbg) {
-    __shared__ unsigned long long s_key[16];
+    __shared__ unsigned long long s_key[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= R) return;
@@ -230,48 +228,33 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
         unsigned long long cmask = __ballot(cand);
         unsigned long long my_key = kInit;
         while (cmask) {
-            // up to 4 candidates per round: their point loads are issued together (latency overlap)
-            int src[4], bs[4][9], cum[4][10];
-            float qx[4], qy[4], qz[4];
+            const int src = __ffsll((long long)cmask) - 1;
+            cmask &= cmask - 1;
+            const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), src));
+            const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), src));
+            const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), src));
+            int bs[9], cum[10];
+            cum[0] = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                src[u] = cmask ? __ffsll((long long)cmask) - 1 : -1;
-                cmask &= cmask - 1;                                              // (0 & -1) == 0: stays empty
-                const int sl = src[u] < 0 ? 0 : src[u];
-                qx[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), sl));
-                qy[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), sl));
-                qz[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), sl));
-                cum[u][0] = 0;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    bs[u][i] = __builtin_amdgcn_readlane(seg_s[i], sl);
-                    cum[u][i + 1] = cum[u][i] + (src[u] < 0 ? 0 : __builtin_amdgcn_readlane(seg_n[i], sl));
-                }
+            for (int i = 0; i < 9; ++i) {
+                bs[i] = __builtin_amdgcn_readlane(seg_s[i], src);
+                cum[i + 1] = cum[i] + __builtin_amdgcn_readlane(seg_n[i], src);
             }
-            if (lane < 4) __hip_atomic_store(&s_key[wave * 4 + lane], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const int maxn = max(max(cum[0][9], cum[1][9]), max(cum[2][9], cum[3][9]));
-            for (int base = 0; base < maxn; base += 64) {
+            if (lane == 0) __hip_atomic_store(&s_key[wave], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int base = 0; base < cum[9]; base += 64) {
                 const int t = base + lane;
-                float4 v[4];
+                if (t < cum[9]) {
+                    int p = bs[0] + t;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int p = bs[u][0] + t;
-#pragma unroll
-                    for (int i = 1; i < 9; ++i) p = (t >= cum[u][i]) ? bs[u][i] + (t - cum[u][i]) : p;
-                    v[u] = t < cum[u][9] ? cell_pts[p] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float dd = dist2_exact(qx[u], qy[u], qz[u], v[u].x, v[u].y, v[u].z);
+                    for (int i = 1; i < 9; ++i) p = (t >= cum[i]) ? bs[i] + (t - cum[i]) : p;
+                    const float4 v = cell_pts[p];
+                    const float dd = dist2_exact(qx, qy, qz, v.x, v.y, v.z);
                     if (dd < kThresh2)
-                        atomicMin(&s_key[wave * 4 + u], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u].w));
+                        atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned long long res = __hip_atomic_load(&s_key[wave * 4 + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (lane == src[u]) my_key = res;
-            }
+            const unsigned long long res = __hip_atomic_load(&s_key[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (lane == src) my_key = res;
         }
         const bool valid = (unsigned)(my_key >> 32) < __float_as_uint(kThresh2);
         const uint64_t m = __ballot(valid);

@@ -319,9 +319,7 @@ class ImportanceRenderer(nn.Module):
                   P(ws['cell_pts']), P(ws['cell_scratch']), P(ws['near_mask']), st)
 
         # ---- a11: sparse voxel encoder -> folded level tables ----
-        vox_half = opts.get('voxel_table_dtype', 'fp32') == 'fp16'
-        _lib.lib().sherf_set_debug((int(os.environ.get('SHERF_DEBUG', '0')) & ~128) | (128 if vox_half else 0))
-        levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws, rows_half=vox_half)
+        levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws)
         vox_min = f32(obs_sp_input['bounds']).view(2, 3)[0].contiguous()
         out_sh = [int(v) for v in obs_sp_input['out_sh']]
         vox_sh = (_ct.c_int32 * 3)(*out_sh)

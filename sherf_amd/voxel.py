@@ -102,7 +102,7 @@ class SparseConvNet(nn.Module):
         self._packed = dict(key=key, layers=layers)
         return self._packed
 
-    def encode(self, sp, fold_mats, ws, rows_half=False):
+    def encode(self, sp, fold_mats, ws):
         """Runs the encoder on a SparseConvTensor; returns the three tapped levels as `_lib.VoxLevel`s whose rows
         are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see ImportanceRenderer._weights.
 
@@ -169,10 +169,6 @@ class SparseConvNet(nn.Module):
             rows = ws.fold_out(i, L[lev]['cap'], dev)                   # relu(bn(raw)) @ fold [C, 96] as a pointwise "conv"
             _lib.call('sherf_svox_conv3', None, P(L[lev]['n_rows']), 1, 1, 1, None, 1, 1, 1, P(raw), C, P(bnp), None,
                       P(fold_mats[i]), 96, 2, L[lev]['cap'], P(rows), None, st)
-            if rows_half:
-                rows16 = ws._cached('fold16', i, (L[lev]['cap'], 96), dev, torch.float16)
-                _lib.call('sherf_rows_to_half', P(rows), P(L[lev]['n_rows']), 96, L[lev]['cap'], P(rows16), st)
-                rows = rows16
             keep.append(rows)
             levels[i].wp = L[lev]['wp'].data_ptr()
             levels[i].rows = rows.data_ptr()

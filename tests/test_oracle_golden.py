@@ -140,3 +140,18 @@ def test_sparse_encoder_vs_dense_conv_with_duplicates():
         got = torch.zeros(feats.shape[1], D * H * W_); got[:, keys] = feats.t()
         assert int(md.sum()) == keys.numel()
         assert torch.allclose(got.view(1, -1, D, H, W_), xd, atol=2e-4, rtol=1e-4)
+
+
+def test_vertex_feature_glue_matches_reference(golden_dir):
+    """triplane.py:105-126 (per-vertex features + back-face mask) against the reference's own functions."""
+    g = np.load(os.path.join(golden_dir, 'glue_tiny.npz'))
+    fx = fixtures.renderer_inputs('tiny')
+    d = fixtures.to_torch(fx['input_data'])
+    st = O.smpl_tensors(fx['smpl'])
+    state = {'generator.conv1d_projection.weight': torch.from_numpy(fixtures.seeded_param('generator.conv1d_projection.weight', (32, 96, 1))),
+             'generator.conv1d_projection.bias': torch.from_numpy(fixtures.seeded_param('generator.conv1d_projection.bias', (32,)))}
+    f, front = O.vertex_features(state, st, d['obs_vertices'][0], d['obs_R_all'], d['obs_T_all'], d['obs_K_all'],
+                                 torch.from_numpy(fx['obs_feat'])[0], d['obs_img_all'][0, 0])
+    assert (front.numpy() != g['front_mask']).mean() < 1e-3
+    same = torch.from_numpy(g['front_mask']) == front
+    assert _rel(f[same], g['vertex_feat'][same.numpy()]) < 1e-4

@@ -69,13 +69,6 @@ def main(cfg='tiny', prec='bf16x3'):
         p('rgb rel', G.rel(h['rgb'], o['rgb']), 'acc rel', G.rel(h['acc'], o['acc']), 'depth max abs', float((h['depth'] - o['depth']).abs().max()), 'psnr', O.psnr(h['rgb'], o['rgb']))
     stage('final', s_final)
 
-    def s_half():
-        hh = G.hip_render(cfg, precision=prec, options=dict(voxel_table_dtype='fp16'))
-        out = hh['last']['ws']['sample_out'][:n].cpu(); sr = torch.relu(o['sample_sigma'][:n])
-        p('fp16 voxel rows: sigma+ rel-to-max', float((torch.relu(out[:, 3]) - sr).abs().max() / sr.max()), 'rgb max abs', float((out[:, :3] - o['sample_rgb'][:n]).abs().max()),
-          'img rgb rel', G.rel(hh['rgb'], o['rgb']))
-    stage('half', s_half)
-
 
 if __name__ == '__main__':
     main(*(sys.argv[1:]))

@@ -23,4 +23,4 @@ PY
 done
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench.log | cut -c1-260
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --voxel-table-dtype fp16 2>&1 | grep '"metric"' | tee $OUT/bench_fp16rows.log | cut -c1-260
+
