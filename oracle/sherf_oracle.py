@@ -223,14 +223,19 @@ def triplane_features(planes, x_c, bounds):
 
 
 def compute_normal(vertices, faces):
-    """renderer.py:50-63: normalised face normals accumulated on their three vertices, normalised again. [V,3], [F,3]."""
+    """renderer.py:50-63. NOTE the reference writes `norm[:, faces[:, c]] += n` with advanced indexing: for a vertex
+    listed by several faces in column c only ONE face's normal lands (index assignment, not accumulation; on CPU the
+    last face wins). That behaviour is restated here (deterministically: highest face index). [V,3], [F,3]."""
     tri = vertices[faces]
     n = torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=-1)
     ln = torch.sqrt((n ** 2).sum(-1)).clamp_min(1e-8)
     n = n / ln[:, None]
     norm = torch.zeros_like(vertices)
+    nf = faces.shape[0]
     for c in range(3):
-        norm.index_add_(0, faces[:, c], n)
+        last = torch.full((vertices.shape[0],), -1, dtype=torch.long).scatter_reduce_(0, faces[:, c], torch.arange(nf), reduce='amax')
+        has = last >= 0
+        norm[has] = norm[has] + n[last[has]]
     ln = torch.sqrt((norm ** 2).sum(-1)).clamp_min(1e-8)
     return norm / ln[:, None]
 

@@ -101,41 +101,60 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
 template <int PREC> struct Ctx {
     const char* ws;          // packed weight stream (global)
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
-    char* lds;               // 2 slots
-    uint4 pf[2 * (PREC + 1)];
-    int tid, lane, h, dbg;
+    char* lds;               // NSLOT ring slots
+    int tid, lane, h, dbg, wave, pending;
     static constexpr int SLOT = MAX_NKB * 1024 * (PREC + 1);
-    __device__ __forceinline__ char* slot(int c) const { return lds + (c & 1) * SLOT; }
+    static constexpr int NSLOT = 3;
+    __device__ __forceinline__ char* slot(int c) const { return lds + (c % NSLOT) * SLOT; }
 };
 
+// Weight stream L2 -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPR round trip), three ring
+// slots, two chunks of prefetch distance.  Completion: a wave waits (counted vmcnt) until only the pieces of the most
+// recently issued chunk are still in flight, then the workgroup barrier makes every wave's pieces visible.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int PREC>
-__device__ __forceinline__ void pf_load(Ctx<PREC>& cx, int c) {
-    if (c >= N_CHUNKS || (cx.dbg & 32)) return;
-    const int bytes = chunk_nkb(c) * 1024 * (PREC + 1);
-    const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024;
-#pragma unroll
-    for (int i = 0; i < 2 * (PREC + 1); ++i) {
-        int off = (i * NT + cx.tid) * 16;
-        if (off < bytes) cx.pf[i] = *reinterpret_cast<const uint4*>(src + off);
-    }
-}
-template <int PREC>
-__device__ __forceinline__ void pf_store(Ctx<PREC>& cx, int c) {
-    if (c >= N_CHUNKS || (cx.dbg & 32)) return;
-    const int bytes = chunk_nkb(c) * 1024 * (PREC + 1);
+__device__ __forceinline__ int dma_issue(Ctx<PREC>& cx, int c) {
+    if (c >= N_CHUNKS || (cx.dbg & 32)) return 0;
+    const int pieces = chunk_nkb(c) * (PREC + 1);
+    const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024 + cx.lane * 16;
     char* dst = cx.slot(c);
+    int n = 0;
 #pragma unroll
-    for (int i = 0; i < 2 * (PREC + 1); ++i) {
-        int off = (i * NT + cx.tid) * 16;
-        if (off < bytes) *reinterpret_cast<uint4*>(dst + off) = cx.pf[i];
+    for (int i = 0; i < (MAX_NKB * (PREC + 1) + NW - 1) / NW; ++i) {
+        const int p = cx.wave + i * NW;                        // wave-uniform
+        if (p < pieces) {
+            // Inline asm on purpose: hipcc drains an LDS-DMA it knows about (vmcnt(0)) before every ds_read that might alias
+            // it, which would serialise the ring.  M0 = LDS byte address of the piece (saved/restored: compiler-reserved).
+            const char* g = src + p * 1024;
+            const uint32_t l = (uint32_t)(size_t)(lptr_t)(dst + p * 1024);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+            ++n;
+        }
+    }
+    return n;
+}
+
+__device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt(n) needs an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     }
 }
-// end of chunk c: publish chunk c+1 (already in registers) to the other slot, start fetching chunk c+2
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// end of chunk c: chunk c+1 must have landed (everything but the newest issue), then chunk c's slot is recycled for c+3
 template <int PREC>
 __device__ __forceinline__ void advance(Ctx<PREC>& cx, int c) {
-    pf_store(cx, c + 1);
-    if (!(cx.dbg & 64)) __syncthreads();
-    pf_load(cx, c + 2);
+    wait_vm(cx.pending);
+    if (!(cx.dbg & 64)) wg_barrier();
+    cx.pending = dma_issue(cx, c + 3);
 }
 
 template <int PREC>
@@ -221,24 +240,26 @@ template <int PREC>
 __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens,
                                                          const float* __restrict__ extras, const char* __restrict__ ws,
                                                          const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * Ctx<PREC>::SLOT + (N_CHUNKS + 4) * 32 * 4];
+    __shared__ __attribute__((aligned(16))) char lds[Ctx<PREC>::NSLOT * Ctx<PREC>::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
     if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
     Ctx<PREC> cx;
-    float* lbias = reinterpret_cast<float*>(lds + 2 * Ctx<PREC>::SLOT);
+    float* lbias = reinterpret_cast<float*>(lds + Ctx<PREC>::NSLOT * Ctx<PREC>::SLOT);
     for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
     cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = cx.lane & 31, h = cx.h;
     int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // still takes part in every barrier
 
-    pf_load(cx, 0);
-    pf_store(cx, 0);
+    dma_issue(cx, 0);
+    const int n1 = dma_issue(cx, 1);
+    wait_vm(n1);                              // chunk 0 (this wave's pieces) landed; also covers the bias table stores
     __syncthreads();
-    pf_load(cx, 1);
+    cx.pending = dma_issue(cx, 2);
 
     // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
     f32x16 tok[3];

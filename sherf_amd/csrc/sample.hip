@@ -69,7 +69,7 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
         for (int c = 0; c < 3; ++c) dims[c] = min(64, (int)floorf((hi[c] - lo[c]) * inv) + 3);
         s_hdr[0] = lo[0] - cell; s_hdr[1] = lo[1] - cell; s_hdr[2] = lo[2] - cell; s_hdr[3] = cell; s_hdr[4] = inv;
         s_hdr[5] = __int_as_float(dims[0]); s_hdr[6] = __int_as_float(dims[1]); s_hdr[7] = __int_as_float(dims[2]);
-        const int sub = (8 * dims[0] * dims[1] * dims[2] <= 32768 * 32) ? 2 : 1;
+        const int sub = (8 * dims[0] * dims[1] * dims[2] <= 16384 * 32) ? 2 : 1;   // refined mask must fit 64 KiB of LDS
         s_hdr[8] = __int_as_float(sub); s_hdr[9] = s_hdr[10] = s_hdr[11] = 0.f;
         for (int i = 0; i < kGridHdr; ++i) hdr[i] = s_hdr[i];
     }
@@ -133,29 +133,40 @@ __global__ void __launch_bounds__(1024) build_cells2_kernel(const float* __restr
 }
 
 // near mask: 1 bit per sub-cell (edge cell/sub) whose box comes within the query radius of some vertex; sub = 2 when the
-// refined grid fits the 2^20-bit buffer, else 1.  One thread per vertex, fire-and-forget global atomics.
+// refined grid fits 2^19 bits (64 KiB of LDS), else 1 (<= 2^18 bits).  Each block marks its 256 vertices in an LDS copy of the mask (fast,
+// heavily contended atomics stay on-chip) and ORs only its non-zero words into the global mask.
 __global__ void __launch_bounds__(256) near_mask_kernel(const float* __restrict__ pos, int n, const float* __restrict__ hdr,
                                                         float radius, uint32_t* __restrict__ near_mask) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    extern __shared__ uint32_t s_mask[];
     const CellGrid g = load_grid(hdr);
     const int sub = g.sub, snx = g.nx * sub, sny = g.ny * sub, snz = g.nz * sub;
-    const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
-    const float cs = g.cell / (float)sub, rad = radius + 1e-3f * cs, rad2 = rad * rad, fs = g.inv_cell * (float)sub;
-    const int sx = (int)floorf((px - g.ox) * fs), sy = (int)floorf((py - g.oy) * fs), sz = (int)floorf((pz - g.oz) * fs);
-    for (int dz = -sub; dz <= sub; ++dz)
-        for (int dy = -sub; dy <= sub; ++dy)
-            for (int dx = -sub; dx <= sub; ++dx) {
-                const int qx = sx + dx, qy = sy + dy, qz = sz + dz;
-                if (qx < 0 || qx >= snx || qy < 0 || qy >= sny || qz < 0 || qz >= snz) continue;
-                const float bx = g.ox + qx * cs, by = g.oy + qy * cs, bz = g.oz + qz * cs;
-                const float ex = fmaxf(fmaxf(bx - px, px - (bx + cs)), 0.f), ey = fmaxf(fmaxf(by - py, py - (by + cs)), 0.f),
-                            ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
-                if (ex * ex + ey * ey + ez * ez < rad2) {
-                    const int q = (qz * sny + qy) * snx + qx;
-                    atomicOr(&near_mask[q >> 5], 1u << (q & 31));      // result unused: non-returning atomic, no latency chain
+    const int words = (snx * sny * snz + 31) / 32;
+    for (int w = threadIdx.x; w < words; w += 256) s_mask[w] = 0u;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
+        const float cs = g.cell / (float)sub, rad = radius + 1e-3f * cs, rad2 = rad * rad, fs = g.inv_cell * (float)sub;
+        const int sx = (int)floorf((px - g.ox) * fs), sy = (int)floorf((py - g.oy) * fs), sz = (int)floorf((pz - g.oz) * fs);
+        for (int dz = -sub; dz <= sub; ++dz)
+            for (int dy = -sub; dy <= sub; ++dy)
+                for (int dx = -sub; dx <= sub; ++dx) {
+                    const int qx = sx + dx, qy = sy + dy, qz = sz + dz;
+                    if (qx < 0 || qx >= snx || qy < 0 || qy >= sny || qz < 0 || qz >= snz) continue;
+                    const float bx = g.ox + qx * cs, by = g.oy + qy * cs, bz = g.oz + qz * cs;
+                    const float ex = fmaxf(fmaxf(bx - px, px - (bx + cs)), 0.f), ey = fmaxf(fmaxf(by - py, py - (by + cs)), 0.f),
+                                ez = fmaxf(fmaxf(bz - pz, pz - (bz + cs)), 0.f);
+                    if (ex * ex + ey * ey + ez * ez < rad2) {
+                        const int q = (qz * sny + qy) * snx + qx;
+                        atomicOr(&s_mask[q >> 5], 1u << (q & 31));
+                    }
                 }
-            }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < words; w += 256) {
+        const uint32_t m = s_mask[w];
+        if (m) atomicOr(&near_mask[w], m);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -429,8 +440,8 @@ extern "C" int sherf_build_cells(const float* verts, int n, const float* R, cons
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
     if (near_mask) {
         (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
-        hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(scratch),
-                           n, grid_hdr, cell_size, near_mask);
+        hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 16384 * sizeof(uint32_t), as_stream(stream),
+                           reinterpret_cast<const float*>(scratch), n, grid_hdr, cell_size, near_mask);
     }
     SHERF_LAUNCH_CHECK();
 }
@@ -443,8 +454,8 @@ extern "C" int sherf_build_cells2(const float* verts_a, const float* R_a, const 
     hipLaunchKernelGGL(build_cells2_kernel, dim3(2), dim3(1024), 0, as_stream(stream), verts_a, R_a, Th_a, verts_b, n, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
     (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
-    hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float*>(scratch), n,
-                       grid_hdr, cell_size, near_mask);
+    hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 16384 * sizeof(uint32_t), as_stream(stream),
+                       reinterpret_cast<const float*>(scratch), n, grid_hdr, cell_size, near_mask);
     SHERF_LAUNCH_CHECK();
 }
 

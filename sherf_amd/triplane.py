@@ -40,13 +40,19 @@ class NeRFDecoder(nn.Module):
 
 
 def compute_normal(vertices, faces):
-    """renderer.py:50-63: area-weighted-by-count vertex normals from unit face normals. vertices [B,V,3], faces [F,3]."""
+    """renderer.py:50-63. The reference's `norm[:, faces[:, c]] += n` is an index ASSIGNMENT: of the faces that list a
+    vertex in column c exactly one contributes (the last on CPU, unspecified on CUDA). We take the highest face index,
+    deterministically. vertices [B,V,3], faces [F,3]."""
     tris = vertices[:, faces]
     n = torch.cross(tris[:, :, 1] - tris[:, :, 0], tris[:, :, 2] - tris[:, :, 0], dim=-1)
     n = n / torch.sqrt((n ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
     norm = torch.zeros_like(vertices)
+    nf = faces.shape[0]
+    ar = torch.arange(nf, device=faces.device)
     for c in range(3):
-        norm.index_add_(1, faces[:, c], n)
+        last = torch.full((vertices.shape[1],), -1, dtype=torch.long, device=faces.device).scatter_reduce_(0, faces[:, c], ar, reduce='amax')
+        has = last >= 0
+        norm[:, has] = norm[:, has] + n[:, last[has]]
     return norm / torch.sqrt((norm ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
 
 

@@ -229,3 +229,72 @@ def test_dataset_rays_on_device():
     both = mm & d['mask_at_box_all'][0, 0]
     assert np.abs(nr.cpu().numpy() - d['near_all'][0, 0, :, 0])[both].max() < 1e-3
     assert np.abs(fr.cpu().numpy() - d['far_all'][0, 0, :, 0])[both].max() < 1e-3
+
+
+def _generator(fx):
+    """sherf_amd.TriPlaneGenerator with the feature producers stubbed: planes and the 2-D feature map come from the
+    fixture (the StyleGAN2 backbone / ResNet18 encoders are outside the hot path)."""
+    from sherf_amd.triplane import TriPlaneGenerator
+
+    class FakeEncoder(torch.nn.Module):
+        def __init__(self, feat):
+            super().__init__()
+            self.feat = feat
+
+        def forward(self, img, extract_feature=False):
+            return self.feat
+
+    rend, dec = G.hip_modules()
+    gen = TriPlaneGenerator(512, 25, 512, True, True, True, True, True, img_resolution=512, img_channels=3,
+                            rendering_kwargs=dict(fx['options']), backbone=torch.nn.Identity(),
+                            encoder_2d_feature=FakeEncoder(G.to_cuda(fx['obs_feat'])), smpl=G.smpl())
+    gen.renderer, gen.decoder = rend, dec
+    fixtures.load_seeded_state(gen.conv1d_projection, 'generator.conv1d_projection.')
+    return gen.cuda()
+
+
+def test_generator_glue_vertex_features_and_voxelisation():
+    """triplane.py:105-137: per-vertex features, canonicalised observation vertices, voxel coordinates."""
+    fx = G.fixture('tiny')
+    o = G.oracle_render('tiny')
+    gen = _generator(fx)
+    d = G.to_cuda(fx['input_data'])
+    with torch.no_grad():
+        f3d, mask = gen.vertex_features(d, d['obs_img_all'][:, 0], G.to_cuda(fx['obs_feat']))
+        can = gen.canonical_obs_vertices(d)
+        sp_input, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
+    st = O.smpl_tensors(fx['smpl'])
+    state = {k: torch.from_numpy(fixtures.seeded_param(k, s)) for k, s in (('generator.conv1d_projection.weight', (32, 96, 1)),
+                                                                          ('generator.conv1d_projection.bias', (32,)))}
+    dd = fixtures.to_torch(fx['input_data'])
+    fo, front = O.vertex_features(state, st, dd['obs_vertices'][0], dd['obs_R_all'], dd['obs_T_all'], dd['obs_K_all'],
+                                  torch.from_numpy(fx['obs_feat'])[0], dd['obs_img_all'][0, 0])
+    same = front == mask[0].cpu()
+    assert float((~same).float().mean()) < 2e-3
+    assert G.rel(f3d[0].cpu()[same], fo[same]) < 1e-4
+    assert (can[0].cpu() - o['obs_vertex_canonical']).abs().max() < 2e-6
+    assert sp_input['out_sh'] == o['sp_input']['out_sh']
+    assert float((sp_input['coord'].cpu() != o['sp_input']['coord']).any(1).float().mean()) < 2e-3
+
+
+def test_generator_synthesis_end_to_end():
+    """TriPlaneGenerator.synthesis (glue + renderer + image reshapes, triplane.py:81-172) vs the oracle fed with the
+    oracle's own vertex features."""
+    fx = dict(G.fixture('tiny'))
+    gen = _generator(fx)
+    d = G.to_cuda(fx['input_data'])
+    planes = G.to_cuda(fx['planes']).view(1, 96, 32, 32)
+    with torch.no_grad():
+        out = gen.synthesis(None, d, None, use_sr_module=False, test_flag=True, planes=planes)
+    assert out['image_raw'].shape == (1, 3, 32, 32) and out['image_depth'].shape == (1, 1, 32, 32)
+    st = O.smpl_tensors(fx['smpl'])
+    state = {k: torch.from_numpy(fixtures.seeded_param(k, s)) for k, s in (('generator.conv1d_projection.weight', (32, 96, 1)),
+                                                                          ('generator.conv1d_projection.bias', (32,)))}
+    dd = fixtures.to_torch(fx['input_data'])
+    fo, _ = O.vertex_features(state, st, dd['obs_vertices'][0], dd['obs_R_all'], dd['obs_T_all'], dd['obs_K_all'],
+                              torch.from_numpy(fx['obs_feat'])[0], dd['obs_img_all'][0, 0])
+    fx['vertex_feat'] = fo.numpy()
+    o = O.render_from_fixture(fx, G.seeded_state(), training=True, keep=False)
+    img = out['image_raw'][0].permute(1, 2, 0).reshape(-1, 3).cpu()
+    assert O.psnr(img, o['rgb']) > 60.0
+    assert G.rel(out['weights_image'].reshape(-1).cpu(), o['acc']) < 2e-3
