@@ -19,7 +19,7 @@ __device__ __forceinline__ void axpy4(float4& a, float w, const float4 v) {
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-__global__ void __launch_bounds__(256, 5) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
+__global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                             const float4* __restrict__ planes_f, int P,
                                                             const float4* __restrict__ feat_f, int Hf, int Wf,
                                                             const float4* __restrict__ img4, int H, int W, Levels lv,
