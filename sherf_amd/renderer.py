@@ -222,10 +222,11 @@ class ImportanceRenderer(nn.Module):
         self._ws = _Workspace()
         self._wcache = None
         self.last = None
+        self._side_stream = None
 
     def __getstate__(self):
         s = self.__dict__.copy()
-        for k in ('_smpl_dev', '_ws', '_wcache', 'last'):
+        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_side_stream'):
             s[k] = None
         s['_ws'] = None
         return s
@@ -233,6 +234,11 @@ class ImportanceRenderer(nn.Module):
     def __setstate__(self, s):
         self.__dict__.update(s)
         self._ws = _Workspace()
+
+    def _side(self, dev):
+        if getattr(self, '_side_stream', None) is None or self._side_stream.device != dev:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        return self._side_stream
 
     # ---- SMPL --------------------------------------------------------------------------------
     @property
@@ -298,31 +304,47 @@ class ImportanceRenderer(nn.Module):
         ws = self._ws.frame(R, S, cap, dev)
         prm, oprm, tprm = input_data['params'], input_data['obs_params'], input_data['t_params']
 
-        # ---- a7-a9: per-frame SMPL tables ----
-        poses = torch.stack([f32(prm['poses']).view(72), f32(tprm['poses']).view(72), f32(oprm['poses']).view(72)])
-        shapes = torch.stack([f32(prm['shapes']).view(10), f32(tprm['shapes']).view(10), f32(oprm['shapes']).view(10)])
-        _lib.call('sherf_smpl_bones', P(poses), P(shapes), 3, P(smpl['J_template']), P(smpl['J_shapedirs']),
-                  P(smpl['parents_i32']), P(ws['A']), P(ws['posefeat']), st)
-        _lib.call('sherf_smpl_offsets', P(smpl['posedirs_flat']), P(smpl['shapedirs']), P(ws['posefeat']), P(shapes), 3,
-                  P(ws['PO']), P(ws['SO']), st)
+        # Two HIP streams: the sparse voxel encoder is a chain of ~45 small launches that cannot fill the chip, and it is
+        # independent of the ray side of the frame until the gather -> it runs (with the SMPL tables) on a side stream,
+        # concurrently with cell lists / sampling / compaction / table folding on the caller's stream.
+        main = torch.cuda.current_stream(dev)
+        side = self._side(dev)
         Rg, Th = f32(prm['R']).view(9), f32(prm['Th']).view(3)
-        A, PO, SO = ws['A'], ws['PO'], ws['SO']
-        _lib.call('sherf_smpl_t2c_table', P(smpl['weights']), P(A[0]), P(A[1]), P(PO[0]), P(SO[0]), P(PO[1]), P(ws['T2C']), st)
-        _lib.call('sherf_smpl_c2s_table', P(smpl['weights']), P(A[1]), P(A[2]), P(PO[1]), P(SO[2]), P(PO[2]),
-                  P(f32(oprm['R']).view(9)), P(f32(oprm['Th']).view(3)), P(f32(input_data['obs_R_all']).view(9)),
-                  P(f32(input_data['obs_T_all']).view(3)), P(f32(input_data['obs_K_all']).view(9)), P(ws['C2S']), st)
-
-        # ---- cell lists over the posed (SMPL frame) and canonical vertices ----
         verts = f32(input_data['vertices']).view(V, 3)
         tverts = f32(input_data['t_vertices']).view(V, 3)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            st2 = _lib.stream()
+            # ---- a7-a9: per-frame SMPL tables ----
+            poses = torch.stack([f32(prm['poses']).view(72), f32(tprm['poses']).view(72), f32(oprm['poses']).view(72)])
+            shapes = torch.stack([f32(prm['shapes']).view(10), f32(tprm['shapes']).view(10), f32(oprm['shapes']).view(10)])
+            _lib.call('sherf_smpl_bones', P(poses), P(shapes), 3, P(smpl['J_template']), P(smpl['J_shapedirs']),
+                      P(smpl['parents_i32']), P(ws['A']), P(ws['posefeat']), st2)
+            _lib.call('sherf_smpl_offsets', P(smpl['posedirs_flat']), P(smpl['shapedirs']), P(ws['posefeat']), P(shapes), 3,
+                      P(ws['PO']), P(ws['SO']), st2)
+            A, PO, SO = ws['A'], ws['PO'], ws['SO']
+            _lib.call('sherf_smpl_t2c_table', P(smpl['weights']), P(A[0]), P(A[1]), P(PO[0]), P(SO[0]), P(PO[1]), P(ws['T2C']), st2)
+            _lib.call('sherf_smpl_c2s_table', P(smpl['weights']), P(A[1]), P(A[2]), P(PO[1]), P(SO[2]), P(PO[2]),
+                      P(f32(oprm['R']).view(9)), P(f32(oprm['Th']).view(3)), P(f32(input_data['obs_R_all']).view(9)),
+                      P(f32(input_data['obs_T_all']).view(3)), P(f32(input_data['obs_K_all']).view(9)), P(ws['C2S']), st2)
+            ev_smpl = torch.cuda.Event()
+            ev_smpl.record(side)
+            # ---- a11: sparse voxel encoder -> folded level tables ----
+            levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws)
+
+        # ---- cell lists over the posed (SMPL frame) and canonical vertices ----
         _lib.call('sherf_build_cells2', P(verts), P(Rg), P(Th), P(tverts), V, 0.05, P(ws['grid_hdr']), P(ws['cell_start']),
                   P(ws['cell_pts']), P(ws['cell_scratch']), P(ws['near_mask']), st)
-
-        # ---- a11: sparse voxel encoder -> folded level tables ----
-        levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws)
         vox_min = f32(obs_sp_input['bounds']).view(2, 3)[0].contiguous()
         out_sh = [int(v) for v in obs_sp_input['out_sh']]
         vox_sh = (_ct.c_int32 * 3)(*out_sh)
+
+        # ---- a4-a6: sample, mask, nearest vertex, compaction ----
+        ro, rd = f32(ray_origins).view(R, 3), f32(ray_directions).view(R, 3)
+        nr, fr = f32(near).view(R), f32(far).view(R)
+        _lib.call('sherf_sample_mask_nn', P(ro), P(rd), P(nr), P(fr), R, S, P(Rg), P(Th), P(ws['grid_hdr'][0]),
+                  P(ws['cell_start'][0]), P(ws['cell_pts'][0]), P(ws['near_mask']), cap, P(ws['counters']), P(ws['ray_base']), P(ws['ray_cnt']),
+                  P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(ws['dense_vid']), P(ws['ray_mask']), P(ws['scan_ws']), st)
 
         # ---- per-frame table re-layout (channel-last) with the slot projections folded in ----
         Pres = planes.shape[-1]
@@ -336,16 +358,12 @@ class ImportanceRenderer(nn.Module):
         _lib.call('sherf_img_to_hwc4', P(f32(obs_input_img)), P(img4), H * W, st)
         bounds = f32(input_data['t_world_bounds']).view(6)
 
-        # ---- a4-a6: sample, mask, nearest vertex, compaction ----
-        ro, rd = f32(ray_origins).view(R, 3), f32(ray_directions).view(R, 3)
-        nr, fr = f32(near).view(R), f32(far).view(R)
-        _lib.call('sherf_sample_mask_nn', P(ro), P(rd), P(nr), P(fr), R, S, P(Rg), P(Th), P(ws['grid_hdr'][0]),
-                  P(ws['cell_start'][0]), P(ws['cell_pts'][0]), P(ws['near_mask']), cap, P(ws['counters']), P(ws['ray_base']), P(ws['ray_cnt']),
-                  P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(ws['dense_vid']), P(ws['ray_mask']), P(ws['scan_ws']), st)
-        # ---- a8-a10: warp ----
+        # ---- a8-a10: warp (needs the SMPL tables of the side stream) ----
+        main.wait_event(ev_smpl)
         _lib.call('sherf_warp_geom', P(ws['counters']), P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(rd), S, P(Rg),
                   P(ws['T2C']), P(ws['C2S']), P(tverts), P(ws['grid_hdr'][1]), P(ws['cell_start'][1]), P(ws['cell_pts'][1]),
                   cap, P(ws['geom']), P(ws['cs_tvid']), st)
+        main.wait_stream(side)                                           # voxel levels ready
         # ---- a10-a12: gather -> tokens ----
         _lib.call('sherf_gather_tokens', P(ws['counters']), P(ws['geom']), P(planes_f), Pres, P(feat_f), Hf, Wf, P(img4), H, W,
                   _ct.c_void_p(_ct.addressof(levels)), P(wc['tok_bias']), P(bounds), P(vox_min),
