@@ -145,9 +145,10 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
 /* a13+a14: rgb positional encoding -> slot-2 token, 3-token transformer (renderer.py:949-993), pos/view
  * encodings (:875-916) and NeRFDecoder (triplane.py:285-316) as one MFMA kernel; weights arrive as the
  * pre-packed fragment stream built by sherf_amd/mlp_pack.py.  prec: 0 = bf16, 1 = bf16x3 (hi/lo split,
- * fp32-grade).  out[c] = (r,g,b,sigma). */
+ * fp32-grade).  shape: 0 = 8 waves x 1 column tile per workgroup (2 waves/SIMD), 1 = 4 waves x 2 tiles (1 wave/SIMD,
+ * 512 registers).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                   const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+                   const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream);
 /* layout of the weight stream the kernel expects: number of chunks and K-blocks per chunk. */
 int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int32_t max_chunks);
 

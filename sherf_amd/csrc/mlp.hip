@@ -25,8 +25,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NW = 8;               // waves per workgroup (each: one 32-sample column tile)
-constexpr int NT = NW * 64;
 constexpr int N_CHUNKS = 49;
 constexpr int MAX_NKB = 13;
 constexpr int BIAS_LN = N_CHUNKS;   // index of the first LayerNorm table in wbias ([idx][2][16] floats)
@@ -98,28 +96,39 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int PREC> struct Ctx {
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel shape: NW waves per workgroup, NTL column tiles (32 samples each) per wave.
+//   <NW=8, NTL=1>: two waves per SIMD (<= 256 VGPRs), each wave one tile.
+//   <NW=4, NTL=2>: one wave per SIMD (<= 512 VGPRs), each wave two tiles: every weight fragment read from LDS feeds two
+//                  MFMA chains, half the barriers and LDS traffic per sample.
+// The weight stream is walked in STEPS: the small transformer chunks 0..8 are replayed once per tile (keeps the
+// attention state of only one tile live), then the decoder chunks 9..48 run once for all tiles of the wave.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NTL> __host__ __device__ constexpr int n_steps() { return 9 * NTL + (N_CHUNKS - 9); }
+template <int NTL> __host__ __device__ constexpr int step_chunk(int s) { return s < 9 * NTL ? s % 9 : s - 9 * (NTL - 1); }
+
+template <int PREC, int NW, int NTL> struct Ctx {
     const char* ws;          // packed weight stream (global)
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // NSLOT ring slots
-    int tid, lane, h, dbg, wave, pending;
+    int lane, h, dbg, wave, pending;
     static constexpr int SLOT = MAX_NKB * 1024 * (PREC + 1);
     static constexpr int NSLOT = 3;
-    __device__ __forceinline__ char* slot(int c) const { return lds + (c % NSLOT) * SLOT; }
+    __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
 };
 
 // Weight stream L2 -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPR round trip), three ring
-// slots, two chunks of prefetch distance.  Completion: a wave waits (counted vmcnt) until only the pieces of the most
-// recently issued chunk are still in flight, then the workgroup barrier makes every wave's pieces visible.
-typedef const __attribute__((address_space(1))) void* gptr_t;
+// slots, two steps of prefetch distance.  Completion: a wave waits (counted vmcnt) until only the pieces of the most
+// recently issued step are still in flight, then the workgroup barrier makes every wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int PREC>
-__device__ __forceinline__ int dma_issue(Ctx<PREC>& cx, int c) {
-    if (c >= N_CHUNKS || (cx.dbg & 32)) return 0;
+template <int PREC, int NW, int NTL>
+__device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL>& cx, int step) {
+    if (step >= n_steps<NTL>() || (cx.dbg & 32)) return 0;
+    const int c = step_chunk<NTL>(step);
     const int pieces = chunk_nkb(c) * (PREC + 1);
     const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024 + cx.lane * 16;
-    char* dst = cx.slot(c);
+    char* dst = cx.lds + (step % Ctx<PREC, NW, NTL>::NSLOT) * Ctx<PREC, NW, NTL>::SLOT;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < (MAX_NKB * (PREC + 1) + NW - 1) / NW; ++i) {
@@ -144,52 +153,54 @@ __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     }
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// end of chunk c: chunk c+1 must have landed (everything but the newest issue), then chunk c's slot is recycled for c+3
-template <int PREC>
-__device__ __forceinline__ void advance(Ctx<PREC>& cx, int c) {
+// end of step s: step s+1 must have landed (everything but the newest issue), then step s's slot is recycled for s+3
+template <int PREC, int NW, int NTL>
+__device__ __forceinline__ void advance(Ctx<PREC, NW, NTL>& cx, int step) {
     wait_vm(cx.pending);
     if (!(cx.dbg & 64)) wg_barrier();
-    cx.pending = dma_issue(cx, c + 3);
+    cx.pending = dma_issue(cx, step + 3);
 }
 
-template <int PREC>
-__device__ __forceinline__ f32x16 bias_tile(const Ctx<PREC>& cx, int idx) {
+template <class C>
+__device__ __forceinline__ f32x16 bias_tile(const C& cx, int idx) {
     const float4* p = reinterpret_cast<const float4*>(cx.wbias + (idx * 2 + cx.h) * 16);
     float4 a = p[0], b = p[1], c = p[2], d = p[3];
     f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
     return r;
 }
 
-// acc[t] += W_chunk . B[t]  for NTOK column sets sharing the chunk's A fragments
-template <int PREC, int NKB, int NTOK>
-__device__ __forceinline__ void mma_chunk(const Ctx<PREC>& cx, int c, const BFrag<PREC> (&b)[NTOK][NKB], f32x16 (&acc)[NTOK]) {
-    const char* s = cx.slot(c) + cx.lane * 16;
+// acc[col] += W_step[kb0 .. kb0+NK) . B[col]: one segment of a chunk's K range, NCOL column sets sharing the A fragments
+template <int PREC, int NK, int NCOL>
+__device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        const uint4 ah = *reinterpret_cast<const uint4*>(s + kb * 1024);
+    for (int kb = 0; kb < NK; ++kb) {
+        const uint4 ah = *reinterpret_cast<const uint4*>(s + (kb0 + kb) * 1024);
         if constexpr (PREC == 1) {
-            const uint4 al = *reinterpret_cast<const uint4*>(s + (NKB + kb) * 1024);
+            const uint4 al = *reinterpret_cast<const uint4*>(s + (nkb_total + kb0 + kb) * 1024);
 #pragma unroll
-            for (int t = 0; t < NTOK; ++t) {
+            for (int t = 0; t < NCOL; ++t) {
                 acc[t] = mfma(al, b[t][kb].hi, acc[t]);
                 acc[t] = mfma(ah, b[t][kb].lo, acc[t]);
             }
         }
 #pragma unroll
-        for (int t = 0; t < NTOK; ++t) acc[t] = mfma(ah, b[t][kb].hi, acc[t]);
+        for (int t = 0; t < NCOL; ++t) acc[t] = mfma(ah, b[t][kb].hi, acc[t]);
     }
 }
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   // partner lane holds the other 16 features
 
 // LayerNorm over the 32 features of a token (16 here, 16 in lane^32), eps 1e-5 (renderer.py:931)
-template <int PREC>
-__device__ __forceinline__ void layer_norm(const Ctx<PREC>& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1) {
+template <int PREC, class C>
+__device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1) {
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += x[r];
@@ -209,8 +220,8 @@ __device__ __forceinline__ void layer_norm(const Ctx<PREC>& cx, const f32x16& x,
 
 // NeRF positional encoding in "natural" K-block order: feature f = 16*kb + 8*h + e of
 // [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]; entries >= 3 + 6*NF are zero.
-template <int PREC, int NF, int NKB, int NTOT, int OFF>
-__device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag<PREC> (&out)[1][NTOT]) {
+template <int PREC, int NF, int NKB>
+__device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag<PREC> (&out)[NKB]) {
     float f[NKB * 16];
 #pragma unroll
     for (int i = 0; i < NKB * 16; ++i) f[i] = 0.f;
@@ -232,60 +243,72 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = h ? f[16 * kb + 8 + e] : f[16 * kb + e];
-        out[0][OFF + kb] = make_frag<PREC>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        out[kb] = make_frag<PREC>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     }
 }
 
-template <int PREC>
-__global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens,
-                                                         const float* __restrict__ extras, const char* __restrict__ ws,
-                                                         const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
-    __shared__ __attribute__((aligned(16))) char lds[Ctx<PREC>::NSLOT * Ctx<PREC>::SLOT + (N_CHUNKS + 4) * 32 * 4];
+
+template <int PREC, int NW, int NTL>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
+nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
+    using CX = Ctx<PREC, NW, NTL>;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
-    Ctx<PREC> cx;
-    float* lbias = reinterpret_cast<float*>(lds + Ctx<PREC>::NSLOT * Ctx<PREC>::SLOT);
+    if ((int64_t)blockIdx.x * NW * NTL >= n_tiles) return;           // whole workgroup beyond the data
+    CX cx;
+    float* lbias = reinterpret_cast<float*>(lds + CX::NSLOT * CX::SLOT);
     for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
-    cx.tid = threadIdx.x; cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = cx.lane & 31, h = cx.h;
-    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
-    const bool live = tile < n_tiles;
-    if (!live) tile = n_tiles - 1;                                   // still takes part in every barrier
+    int64_t tile[NTL];
+    bool live[NTL];
+#pragma unroll
+    for (int u = 0; u < NTL; ++u) {
+        tile[u] = ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * NTL + u;
+        live[u] = tile[u] < n_tiles;
+        if (!live[u]) tile[u] = n_tiles - 1;                         // dead tiles still take part in every barrier
+    }
 
     dma_issue(cx, 0);
     const int n1 = dma_issue(cx, 1);
-    wait_vm(n1);                              // chunk 0 (this wave's pieces) landed; also covers the bias table stores
+    wait_vm(n1);                              // step 0 (this wave's pieces) landed
     __syncthreads();
     cx.pending = dma_issue(cx, 2);
 
-    // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
-    f32x16 tok[3];
+    BFrag<PREC> z0b[NTL][2], z1b[NTL][2];                            // fused tokens z_0, z_1 as K-blocks, per tile
+    float xc[NTL][3], vc[NTL][3];
+    int step = 0;
+
+    // ================= transformer, one tile at a time (steps 9u .. 9u+8 replay chunks 0..8) =================
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int u = 0; u < NTL; ++u) {
+        // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
+        f32x16 tok[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-            tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = tokens[((tile[u] * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+                tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
+            }
+        const float* ex = extras + tile[u] * 12 * 32 + j;
+        xc[u][0] = ex[0]; xc[u][1] = ex[32]; xc[u][2] = ex[64]; vc[u][0] = ex[96]; vc[u][1] = ex[128]; vc[u][2] = ex[160];
+
+        // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
+        {
+            BFrag<PREC> b[1][2];
+            pe_frags<PREC, 5, 2>(h, ex[192], ex[224], ex[256], b[0]);
+            f32x16 acc[1] = {bias_tile(cx, 0)};
+            mma_seg<PREC, 2, 1>(cx.slot(step), 0, 2, b, acc);
+            advance(cx, step); ++step;
+            tok[2] += acc[0];
         }
-    const float* ex = extras + tile * 12 * 32 + j;
-    const float xc0 = ex[0], xc1 = ex[32], xc2 = ex[64], vc0 = ex[96], vc1 = ex[128], vc2 = ex[160];
-
-    // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
-    {
-        BFrag<PREC> b[1][2];
-        pe_frags<PREC, 5, 2, 2, 0>(h, ex[192], ex[224], ex[256], b);
-        f32x16 acc[1] = {bias_tile(cx, 0)};
-        mma_chunk<PREC, 2, 1>(cx, 0, b, acc);
-        advance(cx, 0);
-        tok[2] += acc[0];
-    }
-
-    // ---- transformer: LN1 + to_qkv (chunks 1..5), attention, to_out (6) ----
-    BFrag<PREC> zb[2][2];                                       // fused tokens z_0, z_1 as K-blocks
-    {
+        // ---- LN1 + to_qkv (chunks 1..5), attention, to_out (6) ----
         BFrag<PREC> ln[3][2];
 #pragma unroll
         for (int t = 0; t < 3; ++t) layer_norm<PREC>(cx, tok[t], 0, ln[t][0], ln[t][1]);
@@ -293,15 +316,15 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
         {
             BFrag<PREC> b2[2][2] = {{ln[0][0], ln[0][1]}, {ln[1][0], ln[1][1]}};
             f32x16 acc[2] = {bias_tile(cx, 1), bias_tile(cx, 1)};
-            mma_chunk<PREC, 2, 2>(cx, 1, b2, acc);              // [q head0 | q head1]
-            advance(cx, 1);
+            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, b2, acc);          // [q head0 | q head1]
+            advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qa[i][r] = acc[i][r];
             f32x16 acc2[2] = {bias_tile(cx, 2), bias_tile(cx, 2)};
-            mma_chunk<PREC, 2, 2>(cx, 2, b2, acc2);             // [q head2 | pad]
-            advance(cx, 2);
+            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, b2, acc2);         // [q head2 | pad]
+            advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -312,8 +335,8 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
         float v0[3][8];
         {
             f32x16 acc[3] = {bias_tile(cx, 3), bias_tile(cx, 3), bias_tile(cx, 3)};
-            mma_chunk<PREC, 2, 3>(cx, 3, ln, acc);              // [k head0 | k head1]
-            advance(cx, 3);
+            mma_seg<PREC, 2, 3>(cx.slot(step), 0, 2, ln, acc);          // [k head0 | k head1]
+            advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -326,8 +349,8 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
         }
         {
             f32x16 acc[3] = {bias_tile(cx, 4), bias_tile(cx, 4), bias_tile(cx, 4)};
-            mma_chunk<PREC, 2, 3>(cx, 4, ln, acc);              // [k head2 | v head0]
-            advance(cx, 4);
+            mma_seg<PREC, 2, 3>(cx.slot(step), 0, 2, ln, acc);          // [k head2 | v head0]
+            advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -361,8 +384,8 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
             for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
         {
             f32x16 acc[3] = {bias_tile(cx, 5), bias_tile(cx, 5), bias_tile(cx, 5)};
-            mma_chunk<PREC, 2, 3>(cx, 5, ln, acc);              // [v head1 | v head2]
-            advance(cx, 5);
+            mma_seg<PREC, 2, 3>(cx.slot(step), 0, 2, ln, acc);          // [v head1 | v head2]
+            advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -381,9 +404,9 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
                     ob[i][hd] = make_frag<PREC>(o[i][hd][0], o[i][hd][1], o[i][hd][2], o[i][hd][3], o[i][hd][4], o[i][hd][5],
                                                 o[i][hd][6], o[i][hd][7]);
             f32x16 acc[2] = {bias_tile(cx, 6), bias_tile(cx, 6)};
-            mma_chunk<PREC, 3, 2>(cx, 6, ob, acc);              // to_out + bias
-            advance(cx, 6);
-            y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];     // residual (renderer.py:925)
+            mma_seg<PREC, 3, 2>(cx.slot(step), 0, 3, ob, acc);          // to_out + bias
+            advance(cx, step); ++step;
+            y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];             // residual (renderer.py:925)
         }
         // ---- FF: LN2 -> Linear -> GELU(erf) -> Linear, residual (chunks 7, 8) ----
         {
@@ -391,8 +414,8 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
             layer_norm<PREC>(cx, y[0], 1, l2[0][0], l2[0][1]);
             layer_norm<PREC>(cx, y[1], 1, l2[1][0], l2[1][1]);
             f32x16 acc[2] = {bias_tile(cx, 7), bias_tile(cx, 7)};
-            mma_chunk<PREC, 2, 2>(cx, 7, l2, acc);
-            advance(cx, 7);
+            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, l2, acc);
+            advance(cx, step); ++step;
             BFrag<PREC> gb[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -401,115 +424,108 @@ __global__ void __launch_bounds__(NT, 2) nerf_mlp_kernel(const int32_t* __restri
                 split_tile<PREC>(acc[i], gb[i][0], gb[i][1]);
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
-            mma_chunk<PREC, 2, 2>(cx, 8, gb, acc2);
-            advance(cx, 8);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { f32x16 z = acc2[i] + y[i]; split_tile<PREC>(z, zb[i][0], zb[i][1]); }
+            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, gb, acc2);
+            advance(cx, step); ++step;
+            f32x16 za = acc2[0] + y[0], zb = acc2[1] + y[1];
+            split_tile<PREC>(za, z0b[u][0], z0b[u][1]);
+            split_tile<PREC>(zb, z1b[u][0], z1b[u][1]);
         }
     }
 
-    // ---- NeRF decoder trunk ----
-    BFrag<PREC> ha[1][8], hb[1][8];
-    {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
-        BFrag<PREC> b[1][5];
-        pe_frags<PREC, 6, 3, 5, 0>(h, xc0, xc1, xc2, b);
-        b[0][3] = zb[0][0]; b[0][4] = zb[0][1];
+    // ================= NeRF decoder: all NTL tiles of the wave share every weight fragment =================
+    BFrag<PREC> ha[NTL][8], hb[NTL][8], pe[NTL][3];
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            f32x16 acc[1] = {bias_tile(cx, 9 + T)};
-            mma_chunk<PREC, 5, 1>(cx, 9 + T, b, acc);
-            advance(cx, 9 + T);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
-            split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
-        }
+    for (int u = 0; u < NTL; ++u) pe_frags<PREC, 6, 3>(h, xc[u][0], xc[u][1], xc[u][2], pe[u]);
+    // one output tile of a trunk layer: bias, MFMAs over the listed input segments, ReLU, split into the next layer's K-blocks
+#define SHERF_TRUNK_TILE(CHUNK, OUT, T, ...)                                                          \
+    {                                                                                                 \
+        f32x16 acc[NTL];                                                                              \
+        _Pragma("unroll") for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, CHUNK);                \
+        const char* s_ = cx.slot(step);                                                               \
+        __VA_ARGS__                                                                                   \
+        advance(cx, step); ++step;                                                                    \
+        _Pragma("unroll") for (int u = 0; u < NTL; ++u) {                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[u][r] = relu(acc[u][r]);               \
+            split_tile<PREC>(acc[u], OUT[u][2 * (T)], OUT[u][2 * (T) + 1]);                          \
+        }                                                                                             \
     }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)     // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
+        SHERF_TRUNK_TILE(9 + T, ha, T, mma_seg<PREC, 3, NTL>(s_, 0, 5, pe, acc); mma_seg<PREC, 2, NTL>(s_, 3, 5, z0b, acc);)
 #pragma unroll
     for (int L = 0; L < 4; ++L) {   // pts_linears.1-4 (ping-pong ha -> hb -> ha ...)
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            const int c = 13 + 4 * L + T;
-            f32x16 acc[1] = {bias_tile(cx, c)};
-            if (L & 1) mma_chunk<PREC, 8, 1>(cx, c, hb, acc);
-            else mma_chunk<PREC, 8, 1>(cx, c, ha, acc);
-            advance(cx, c);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
-            if (L & 1) split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
-            else split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
-        }
-    }
-    {   // pts_linears.5 : [PE6 | z_0 | h(128)] ; after 4 layers the activations are back in ha
-        BFrag<PREC> b[1][13];
-        pe_frags<PREC, 6, 3, 13, 0>(h, xc0, xc1, xc2, b);
-        b[0][3] = zb[0][0]; b[0][4] = zb[0][1];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[0][5 + k] = ha[0][k];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            f32x16 acc[1] = {bias_tile(cx, 29 + T)};
-            mma_chunk<PREC, 13, 1>(cx, 29 + T, b, acc);
-            advance(cx, 29 + T);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
-            split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
+            if (L & 1) SHERF_TRUNK_TILE(13 + 4 * L + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)
+            else SHERF_TRUNK_TILE(13 + 4 * L + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)
         }
     }
 #pragma unroll
-    for (int L = 0; L < 2; ++L) {   // pts_linears.6-7 : hb -> ha -> hb
+    for (int T = 0; T < 4; ++T)     // pts_linears.5 : [PE6 | z_0 | h(128)] ; after 4 layers the activations are back in ha
+        SHERF_TRUNK_TILE(29 + T, hb, T, mma_seg<PREC, 3, NTL>(s_, 0, 13, pe, acc); mma_seg<PREC, 2, NTL>(s_, 3, 13, z0b, acc);
+                         mma_seg<PREC, 8, NTL>(s_, 5, 13, ha, acc);)
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            const int c = 33 + 4 * L + T;
-            f32x16 acc[1] = {bias_tile(cx, c)};
-            if (L == 0) mma_chunk<PREC, 8, 1>(cx, c, hb, acc);
-            else mma_chunk<PREC, 8, 1>(cx, c, ha, acc);
-            advance(cx, c);
+    for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(33 + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)   // pts_linears.6
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
-            if (L == 0) split_tile<PREC>(acc[0], ha[0][2 * T], ha[0][2 * T + 1]);
-            else split_tile<PREC>(acc[0], hb[0][2 * T], hb[0][2 * T + 1]);
-        }
+    for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(37 + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)   // pts_linears.7
+    // ---- heads: feature_linear (4 tiles, no activation) into ha, alpha_linear (tile 45, row 0), both from hb ----
+    float sigma[NTL];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        f32x16 acc[NTL];
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 41 + T);
+        mma_seg<PREC, 8, NTL>(cx.slot(step), 0, 8, hb, acc);
+        advance(cx, step); ++step;
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) split_tile<PREC>(acc[u], ha[u][2 * T], ha[u][2 * T + 1]);
     }
-    // ---- heads: feature_linear (4 tiles, no activation) + alpha_linear (tile 45, row 0), from hb ----
-    float sigma;
-    BFrag<PREC> vb[1][12];
     {
+        f32x16 acc[NTL];
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            f32x16 acc[1] = {bias_tile(cx, 41 + T)};
-            mma_chunk<PREC, 8, 1>(cx, 41 + T, hb, acc);
-            advance(cx, 41 + T);
-            split_tile<PREC>(acc[0], vb[0][2 * T], vb[0][2 * T + 1]);
-        }
-        f32x16 acc[1] = {bias_tile(cx, 45)};
-        mma_chunk<PREC, 8, 1>(cx, 45, hb, acc);
-        advance(cx, 45);
-        sigma = acc[0][0];                                       // row 0 lives in reg 0 of the h == 0 lanes
+        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 45);
+        mma_seg<PREC, 8, NTL>(cx.slot(step), 0, 8, hb, acc);
+        advance(cx, step); ++step;
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) sigma[u] = acc[u][0];             // row 0 lives in reg 0 of the h == 0 lanes
     }
     // ---- views_linear : [feature (8 kb) | PE4(v_c) (2 kb) | z_1 (2 kb)] -> 64, ReLU ; rgb_linear -> sigmoid ----
-    pe_frags<PREC, 4, 2, 12, 8>(h, vc0, vc1, vc2, vb);
-    vb[0][10] = zb[1][0]; vb[0][11] = zb[1][1];
-    BFrag<PREC> gb[1][4];
+    BFrag<PREC> pv[NTL][2], gb[NTL][4];
+#pragma unroll
+    for (int u = 0; u < NTL; ++u) pe_frags<PREC, 4, 2>(h, vc[u][0], vc[u][1], vc[u][2], pv[u]);
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
-        f32x16 acc[1] = {bias_tile(cx, 46 + T)};
-        mma_chunk<PREC, 12, 1>(cx, 46 + T, vb, acc);
-        advance(cx, 46 + T);
+        f32x16 acc[NTL];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = relu(acc[0][r]);
-        split_tile<PREC>(acc[0], gb[0][2 * T], gb[0][2 * T + 1]);
-    }
-    {
-        f32x16 acc[1] = {bias_tile(cx, 48)};
-        mma_chunk<PREC, 4, 1>(cx, 48, gb, acc);
-        if (live && h == 0) {
-            const int64_t c = tile * 32 + j;
-            if (c < nv) {
-                float r = 1.0f / (1.0f + expf(-acc[0][0])), g = 1.0f / (1.0f + expf(-acc[0][1])), b = 1.0f / (1.0f + expf(-acc[0][2]));
-                out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma);   // triplane.py:314
-            }
+        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 46 + T);
+        const char* s_ = cx.slot(step);
+        mma_seg<PREC, 8, NTL>(s_, 0, 12, ha, acc);
+        mma_seg<PREC, 2, NTL>(s_, 8, 12, pv, acc);
+        mma_seg<PREC, 2, NTL>(s_, 10, 12, z1b, acc);
+        advance(cx, step); ++step;
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = relu(acc[u][r]);
+            split_tile<PREC>(acc[u], gb[u][2 * T], gb[u][2 * T + 1]);
         }
     }
+    {
+        f32x16 acc[NTL];
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 48);
+        mma_seg<PREC, 4, NTL>(cx.slot(step), 0, 4, gb, acc);
+#pragma unroll
+        for (int u = 0; u < NTL; ++u)
+            if (live[u] && h == 0) {
+                const int64_t c = tile[u] * 32 + j;
+                if (c < nv) {
+                    float r = 1.0f / (1.0f + expf(-acc[u][0])), g = 1.0f / (1.0f + expf(-acc[u][1])), b = 1.0f / (1.0f + expf(-acc[u][2]));
+                    out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma[u]);   // triplane.py:314
+                }
+            }
+    }
+#undef SHERF_TRUNK_TILE
 }
 
 }  // namespace
@@ -522,18 +538,16 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 }
 
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                              const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
+                              const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && (shape == 0 || shape == 1) && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
-    const unsigned grid = (unsigned)((tiles + NW - 1) / NW);
-    if (prec == 0)
-        hipLaunchKernelGGL(nerf_mlp_kernel<0>, dim3(grid), dim3(NT), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-    else
-        hipLaunchKernelGGL(nerf_mlp_kernel<1>, dim3(grid), dim3(NT), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
+    const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
+#define SHERF_MLP(P, W, L)                                                                                                 \
+    hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
+                       as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
+                       reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (prec == 0) { if (wide) SHERF_MLP(0, 4, 2); else SHERF_MLP(0, 8, 1); }
+    else { if (wide) SHERF_MLP(1, 4, 2); else SHERF_MLP(1, 8, 1); }
     SHERF_LAUNCH_CHECK();
 }

@@ -214,6 +214,7 @@ class ImportanceRenderer(nn.Module):
         self.pos_enc = PositionalEncoding(num_freqs=6)
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
+        self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2')
         self._smpl_src = smpl
         self._smpl_path = smpl_path
         # not parameters / buffers (the reference keeps the SMPL dict as a plain attribute too, renderer.py:284);
@@ -237,7 +238,7 @@ class ImportanceRenderer(nn.Module):
 
     def _side(self, dev):
         if getattr(self, '_side_stream', None) is None or self._side_stream.device != dev:
-            self._side_stream = torch.cuda.Stream(device=dev)
+            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # the short serial chain gets dispatch priority
         return self._side_stream
 
     # ---- SMPL --------------------------------------------------------------------------------
@@ -374,8 +375,9 @@ class ImportanceRenderer(nn.Module):
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        shape = {'8x1': 0, '4x2': 1}[opts.get('mlp_shape', self.mlp_shape)]
         _lib.call('sherf_nerf_mlp', P(ws['counters']), P(ws['tokens']), P(ws['extras']), P(wc['stream']), P(wc['wbias']), prec,
-                  cap, P(ws['sample_out']), st)
+                  shape, cap, P(ws['sample_out']), st)
         if prof:
             e1.record()
             self.mlp_events = getattr(self, 'mlp_events', []) + [(e0, e1)]

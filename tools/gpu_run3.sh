@@ -23,4 +23,6 @@ PY
 done
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench.log | cut -c1-260
+SHERF_MLP_SHAPE=4x2 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' | tee $OUT/bench_wide.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('WIDE 4x2: ms/step', d['ms_per_step'], 'mlp ms', d['roofline']['kernel_ms'], 'frac', d['roofline']['frac'])"
+
 
