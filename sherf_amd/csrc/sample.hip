@@ -180,7 +180,7 @@ __device__ __forceinline__ float depth_at(float near, float range, int k, int S)
 
 // One wave per ray.  Candidate samples (near-mask hit) are searched COOPERATIVELY: each candidate lane first fetches the
 // nine x-contiguous point segments of its 3x3x3 cell neighbourhood (18 independent loads, all candidates in parallel);
-// then, candidate by candidate, 7 lanes walk each of the nine segments (segment table via LDS, position via v_readlane);
+// then, candidate by candidate, the segment table is broadcast (v_readlane) and the 64 lanes test 64 points at once;
 // the lexicographic minimum of (d^2, vertex id) is taken with one 64-bit LDS atomic min (d^2 >= 0, so the IEEE bit
 // pattern orders like the value).  Only points closer than the 5 cm threshold ever reach the atomic.
 template <int NCH>
@@ -194,7 +194,6 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid, int dbg) {
     __shared__ unsigned long long s_key[4];
-    __shared__ int2 s_seg[4 * 64 * 9];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= R) return;
@@ -237,27 +236,33 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                 }
             }
         }
-        // the candidate's nine (start, count) pairs go to LDS so that any lane can pick "its" segment without a select chain
-        if (cand) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) s_seg[(wave * 64 + lane) * 9 + i] = make_int2(seg_s[i], seg_n[i]);
-        }
         unsigned long long cmask = __ballot(cand);
         unsigned long long my_key = kInit;
-        const int myseg = lane / 7, myoff = lane % 7;           // 9 segments x 7 lanes (lane 63 idles)
         while (cmask) {
             const int src = __ffsll((long long)cmask) - 1;
             cmask &= cmask - 1;
             const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), src));
             const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), src));
             const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), src));
+            int bs[9], cum[10];
+            cum[0] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                bs[i] = __builtin_amdgcn_readlane(seg_s[i], src);
+                cum[i + 1] = cum[i] + __builtin_amdgcn_readlane(seg_n[i], src);
+            }
             if (lane == 0) __hip_atomic_store(&s_key[wave], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const int2 sn = myseg < 9 ? s_seg[(wave * 64 + src) * 9 + myseg] : make_int2(0, 0);
-            for (int k = myoff; k < sn.y; k += 7) {
-                const float4 v = cell_pts[sn.x + k];
-                const float dd = dist2_exact(qx, qy, qz, v.x, v.y, v.z);
-                if (dd < kThresh2)
-                    atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
+            for (int base = 0; base < cum[9]; base += 64) {
+                const int t = base + lane;
+                if (t < cum[9]) {
+                    int p = bs[0] + t;
+#pragma unroll
+                    for (int i = 1; i < 9; ++i) p = (t >= cum[i]) ? bs[i] + (t - cum[i]) : p;
+                    const float4 v = cell_pts[p];
+                    const float dd = dist2_exact(qx, qy, qz, v.x, v.y, v.z);
+                    if (dd < kThresh2)
+                        atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
+                }
             }
             const unsigned long long res = __hip_atomic_load(&s_key[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (lane == src) my_key = res;
