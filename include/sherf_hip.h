@@ -129,8 +129,10 @@ typedef struct {
 int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
                         const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
                         const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
-                        const float* vox_min, const int32_t* vox_sh_host, int64_t capacity, float* tokens,
+                        const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
                         float* extras, sherf_stream_t stream);
+/* mode 0: all taps; 1: tri-plane + pixel taps only (levels_host may be NULL) -- can run before the voxel encoder has
+ * finished; 2: voxel taps only, ADDED onto the tokens written by a mode-1 pass. */
 
 /* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
  * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):

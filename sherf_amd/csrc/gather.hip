@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                                                             const float4* __restrict__ img4, int H, int W, Levels lv,
                                                             const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
                                                             const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
-                                                            float4* __restrict__ tokens, float* __restrict__ extras, int dbg) {
+                                                            float4* __restrict__ tokens, float* __restrict__ extras, int dbg, int mode) {
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
     const int l = threadIdx.x & 7;                 // channel quad within a slot
@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t c = tile * 32 + j;
         float4 acc[3];
-        acc[0] = tok_bias[l]; acc[1] = tok_bias[8 + l]; acc[2] = tok_bias[16 + l];
+        if (mode == 2) acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);     // voxel pass adds onto the stored tokens
+        else { acc[0] = tok_bias[l]; acc[1] = tok_bias[8 + l]; acc[2] = tok_bias[16 + l]; }
         float ex[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (c < nv) {
             const float* gm = geom + c * 8;
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
             for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                if (dbg & 8) break;
+                if ((dbg & 8) || mode == 2) break;
                 const float ga = p == 2 ? n[2] : n[0];                 // planes (x,y), (x,z), (z,y)
                 const float gb = p == 1 ? n[2] : n[1];
                 float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                     }
             }
             // ---- pixel-aligned feature + rgb: renderer.py:330-336, align_corners=True ----
-            if (!(dbg & 16)) {
+            if (!(dbg & 16) && mode != 2) {
                 float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
                 float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
                 float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                 ex[6] = rgb.x; ex[7] = rgb.y; ex[8] = rgb.z;
             }
             // ---- sparse voxel levels: renderer.py:544-556 + 762-782, align_corners=True ----
-            if (!(dbg & 4)) {
+            if (!(dbg & 4) && mode != 1) {
                 float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;   // vox_sh = (D,H,W) = (z,y,x)
                 float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
                 float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
@@ -141,6 +142,16 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
             acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // tokens[tile][slot][quad][j] (float4), extras[tile][12][j]
+        if (mode == 2) {
+            if (c < nv)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    float4 t = tokens[((tile * 3 + s) * 8 + l) * 32 + j];
+                    t.x += acc[s].x; t.y += acc[s].y; t.z += acc[s].z; t.w += acc[s].w;
+                    tokens[((tile * 3 + s) * 8 + l) * 32 + j] = t;
+                }
+            continue;
+        }
 #pragma unroll
         for (int s = 0; s < 3; ++s) tokens[((tile * 3 + s) * 8 + l) * 32 + j] = acc[s];
         float e0 = 0.f;
@@ -156,13 +167,13 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
 extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
                                    const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
                                    const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
-                                   const float* vox_min, const int32_t* vox_sh_host, int64_t capacity, float* tokens,
+                                   const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
                                    float* extras, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && levels_host && tok_bias && bounds && vox_min &&
-                    vox_sh_host && tokens && extras);
+    SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && tok_bias && bounds && vox_min && vox_sh_host && tokens && extras);
+    SHERF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 1 || levels_host));
     SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
-    Levels lv;
-    for (int i = 0; i < 3; ++i) {
+    Levels lv = {};
+    for (int i = 0; i < 3 && mode != 1; ++i) {
         lv.l[i] = levels_host[i];
         SHERF_CHECK_ARG(lv.l[i].wp && lv.l[i].rows && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
     }
@@ -171,6 +182,6 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
                        geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
-                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug);
+                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode);
     SHERF_LAUNCH_CHECK();
 }

@@ -364,11 +364,15 @@ class ImportanceRenderer(nn.Module):
         _lib.call('sherf_warp_geom', P(ws['counters']), P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(rd), S, P(Rg),
                   P(ws['T2C']), P(ws['C2S']), P(tverts), P(ws['grid_hdr'][1]), P(ws['cell_start'][1]), P(ws['cell_pts'][1]),
                   cap, P(ws['geom']), P(ws['cs_tvid']), st)
+        # ---- a10-a12: gather -> tokens.  Pass 1 (tri-plane + pixel taps) does not need the voxel encoder, so it runs while the
+        # side stream is still busy; pass 2 adds the voxel taps once the levels are ready. ----
+        _lib.call('sherf_gather_tokens', P(ws['counters']), P(ws['geom']), P(planes_f), Pres, P(feat_f), Hf, Wf, P(img4), H, W,
+                  None, P(wc['tok_bias']), P(bounds), P(vox_min), _ct.c_void_p(_ct.addressof(vox_sh)), 1, cap,
+                  P(ws['tokens']), P(ws['extras']), st)
         main.wait_stream(side)                                           # voxel levels ready
-        # ---- a10-a12: gather -> tokens ----
         _lib.call('sherf_gather_tokens', P(ws['counters']), P(ws['geom']), P(planes_f), Pres, P(feat_f), Hf, Wf, P(img4), H, W,
                   _ct.c_void_p(_ct.addressof(levels)), P(wc['tok_bias']), P(bounds), P(vox_min),
-                  _ct.c_void_p(_ct.addressof(vox_sh)), cap, P(ws['tokens']), P(ws['extras']), st)
+                  _ct.c_void_p(_ct.addressof(vox_sh)), 2, cap, P(ws['tokens']), P(ws['extras']), st)
         # ---- a13-a14: fused transformer + NeRF decoder ----
         prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
         prof = getattr(self, 'profile_mlp', False)

@@ -11,7 +11,7 @@ cd /tmp
 for F in 0; do
   rm -rf $OUT/abl_$F; mkdir -p $OUT/abl_$F
   SHERF_DEBUG=$F timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/abl_$F -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/abl_$F.log 2>&1
-  if [ "$F" = "0" ]; then python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $OUT/abl_0/t_results.db 13 45 > $OUT/kernel_stats.txt; cut -c1-150 $OUT/kernel_stats.txt | head -24; grep '"metric"' $OUT/abl_0.log | cut -c1-200; fi
+  if [ "$F" = "0" ]; then python $GRAFT_REPO_ROOT/tools/rocpd_timeline.py $OUT/abl_0/t_results.db > $OUT/timeline.txt; python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $OUT/abl_0/t_results.db 13 45 > $OUT/kernel_stats.txt; cut -c1-150 $OUT/kernel_stats.txt | head -24; grep '"metric"' $OUT/abl_0.log | cut -c1-200; fi
   python - $OUT/abl_$F/t_results.db $F <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
