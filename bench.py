@@ -77,7 +77,8 @@ def main():
     ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
     opts = dict(fx['options']); opts['mlp_precision'] = a.precision
     R = ro.shape[1]; S = opts['depth_resolution']
-    rend.profile_mlp = True
+    from sherf_amd import _lib as _abi
+    import ctypes as _ct
 
     def step():
         with torch.no_grad():
@@ -90,7 +91,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    rend.mlp_events = []
+    _abi.call('sherf_profile_mlp', 1)          # HIP events around sherf_nerf_mlp on its launch stream (csrc/frame.hip)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -106,7 +107,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     nv = int(rend.last['ws']['counters'][0])
-    mlp_ms = float(np.mean([s.elapsed_time(e) for s, e in rend.mlp_events])) if rend.mlp_events else None
+    ms = (_ct.c_float * 256)(); n_ms = _ct.c_int32(0)
+    _abi.call('sherf_profile_mlp_read', ms, 256, _ct.byref(n_ms))
+    _abi.call('sherf_profile_mlp', 0)
+    mlp_ms = float(np.mean(ms[:n_ms.value])) if n_ms.value else None
     if rank == 0:
         res = dict(metric='rendered rays/sec at 512x512x64 samples (ImportanceRenderer.forward)', value=world * R * a.steps / dt,
                    unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps,

@@ -199,6 +199,96 @@ int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const 
                            float* bnparam, sherf_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * a3: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-61). cam2world[N][16], intr[N][9]. */
+/* ---------------------------------------------------------------------------------------------
+ * a11 as ONE native call.  The plan names every persistent buffer of the encoder (caller-owned, sized by the caller,
+ * see sherf_amd/voxel.py: SparseConvNet._plan); sherf_svox_encode enqueues the whole chain -- 1 memset, level-0 build,
+ * per layer [mark_down + scan] + sparse conv with the BatchNorm finalize fused into the last workgroup, and the fold of
+ * each tapped level -- on `stream` without reading anything back.  Replaces SparseConvNet.forward (renderer.py:778-871)
+ * + the three .dense() volumes.  levels_out_host[3] receives the tapped levels for sherf_gather_tokens.
+ */
+#define SHERF_SVOX_MAX_LAYERS 16
+typedef struct {
+    uint32_t* bitmap;        /* [n_words], inside the plan's zero region */
+    int32_t* prefix;         /* [n_words] */
+    int32_t* n_rows;         /* [1] */
+    int32_t* chunk_ws;       /* [n_words/1024 + 2] */
+    uint32_t* wp;            /* [n_words][2] */
+    int32_t* keys;           /* [cap] */
+    int32_t n_words, cap, D, H, W, pad_;
+} sherf_svox_level_ws;
+typedef struct {
+    int32_t cin, cout, down, tap;   /* down: stride-2 SparseConv3d; tap: level is sampled after this layer */
+    const void* wt;          /* packed MFMA fragments (voxel.py: pack_conv_weights) */
+    const float* gamma;
+    const float* beta;
+    float* stats;            /* [2][cout] batch stats out (training) / running stats in (eval) */
+    float* bnparam;          /* [3][cout] */
+    float* out;              /* [cap][cout] raw conv output */
+    double* partials;        /* [ceil(cap/32)][2][cout] */
+    int32_t* done;           /* [1] ticket counter, zero on entry, left zero */
+} sherf_svox_layer;
+typedef struct {
+    sherf_svox_level_ws lev[4];
+    sherf_svox_layer layers[SHERF_SVOX_MAX_LAYERS];
+    int32_t n_layers, pad_;
+    int64_t* acc_fix;        /* [N][32] fixed-point accumulators (inside the zero region) */
+    float* g0;               /* [N][32] summed level-0 features */
+    int32_t* mult;           /* [N] rows per voxel (inside the zero region) */
+    const int32_t* n_total;  /* [1] == N */
+    void* zero_ptr;          /* region cleared at the start of every frame */
+    int64_t zero_bytes;
+    const float* fold_mat[3]; /* packed [C_l -> 96] pointwise weights per tapped level */
+    float* fold_rows[3];      /* [cap_l][96] */
+} sherf_svox_plan;
+int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const float* feat, int n, int training,
+                      sherf_vox_level* levels_out_host, sherf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The whole of ImportanceRenderer.forward (renderer.py:286-398) as ONE native call: every pointer the frame touches is
+ * named in sherf_frame; sherf_render_frame enqueues ~75 kernels on two HIP streams (SMPL tables + voxel encoder on
+ * `stream_side`, rays on `stream_main`), joined with events owned by the library (created once per device; the only
+ * persistent state the library keeps).  Host cost is a few microseconds per launch instead of one interpreter round
+ * trip each.  phase: bit0 = everything up to and including the NeRF MLP, bit1 = compositing (the caller may add
+ * density noise to sample_out[:,3] in between, renderer.py:435-436).
+ */
+typedef struct {
+    /* SMPL (a7-a9) */
+    const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */
+    const float* J_template; const float* J_shapedirs; const int32_t* parents;
+    const float* posedirs; const float* shapedirs; const float* weights;
+    float* A; float* posefeat; float* PO; float* SO; float* T2C; float* C2S;
+    const float* obs_R; const float* obs_Th; const float* cam_R; const float* cam_T; const float* cam_K;
+    /* cell lists + sampling (a4-a6) */
+    const float* verts; const float* Rg; const float* Th; const float* tverts;
+    float* grid_hdr; int32_t* cell_start; float* cell_pts; int32_t* cell_scratch; uint32_t* near_mask;
+    const float* ray_o; const float* ray_d; const float* near; const float* far;
+    int32_t R, S; int64_t capacity;
+    int32_t* counters; int32_t* ray_base; int32_t* ray_cnt; int32_t* cs_idx; int32_t* cs_vid; float* cs_xs;
+    int32_t* dense_vid; uint64_t* ray_mask; int32_t* scan_ws;
+    /* tables (a10, a12) */
+    const float* planes; const float* Wa_t; float* planes_f; int32_t P, pad0_;
+    const float* obs_feat; const float* Wb_t; float* feat_f; int32_t Hf, Wf;
+    const float* obs_img; float* img4; int32_t H, W;
+    /* warp + gather (a8-a12) */
+    float* geom; int32_t* cs_tvid;
+    const float* tok_bias; const float* bounds; const float* vox_min; int32_t vox_sh[3]; int32_t gather_split;
+    float* tokens; float* extras;
+    /* voxel encoder (a11) */
+    const sherf_svox_plan* vox_plan; const int32_t* vox_coord; const float* vox_feat; int32_t vox_n, vox_training;
+    /* MLP + compositing (a13-a16) */
+    const void* wstream; const float* wbias; int32_t mlp_prec, mlp_shape; float* sample_out;
+    int32_t white_back, pad1_; float* rgb; float* depth; float* acc;
+} sherf_frame;
+int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
+                       sherf_stream_t stream_side);
+/* sizeof of {sherf_vox_level, sherf_svox_level_ws, sherf_svox_layer, sherf_svox_plan, sherf_frame} for binding checks */
+int sherf_struct_sizes(int32_t* sizes_host, int32_t n);
+/* HIP-event timing of the sherf_nerf_mlp launches issued by sherf_render_frame (roofline measurement on the launch
+ * stream): enable != 0 starts recording into a ring of 256 event pairs; read synchronises on them and returns the
+ * per-launch milliseconds recorded since enabling (oldest first), n_host = how many. */
+int sherf_profile_mlp(int enable);
+int sherf_profile_mlp_read(float* ms_host, int32_t max_n, int32_t* n_host);
+
 int sherf_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* origins,
                       float* dirs, sherf_stream_t stream);
 /* a1+a2: get_rays + get_near_far + near/far packing (training/RenderPeople_dataset.py:14-27, 68-101, 129-134)

@@ -19,9 +19,60 @@ _lib = None
 _protos = None
 
 
-class VoxLevel(ctypes.Structure):
-    _fields_ = [('wp', ctypes.c_void_p), ('rows', ctypes.c_void_p),
-                ('D', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32)]
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+
+
+class VoxLevel(ctypes.Structure):                     # sherf_vox_level
+    _fields_ = [('wp', _vp), ('rows', _vp), ('D', _i32), ('H', _i32), ('W', _i32)]
+
+
+class SvoxLevelWs(ctypes.Structure):                  # sherf_svox_level_ws
+    _fields_ = [(n, _vp) for n in ('bitmap', 'prefix', 'n_rows', 'chunk_ws', 'wp', 'keys')] + \
+               [(n, _i32) for n in ('n_words', 'cap', 'D', 'H', 'W', 'pad_')]
+
+
+class SvoxLayer(ctypes.Structure):                    # sherf_svox_layer
+    _fields_ = [(n, _i32) for n in ('cin', 'cout', 'down', 'tap')] + \
+               [(n, _vp) for n in ('wt', 'gamma', 'beta', 'stats', 'bnparam', 'out', 'partials', 'done')]
+
+
+SVOX_MAX_LAYERS = 16
+
+
+class SvoxPlan(ctypes.Structure):                     # sherf_svox_plan
+    _fields_ = [('lev', SvoxLevelWs * 4), ('layers', SvoxLayer * SVOX_MAX_LAYERS), ('n_layers', _i32), ('pad_', _i32),
+                ('acc_fix', _vp), ('g0', _vp), ('mult', _vp), ('n_total', _vp), ('zero_ptr', _vp), ('zero_bytes', _i64),
+                ('fold_mat', _vp * 3), ('fold_rows', _vp * 3)]
+
+
+def _frame_fields():
+    f = []
+    P = lambda *names: f.extend((n, _vp) for n in names)
+    I = lambda *names: f.extend((n, _i32) for n in names)
+    P('poses', 'shapes', 'J_template', 'J_shapedirs', 'parents', 'posedirs', 'shapedirs', 'weights',
+      'A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'obs_R', 'obs_Th', 'cam_R', 'cam_T', 'cam_K',
+      'verts', 'Rg', 'Th', 'tverts', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
+      'ray_o', 'ray_d', 'near', 'far')
+    I('R', 'S')
+    f.append(('capacity', _i64))
+    P('counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws')
+    P('planes', 'Wa_t', 'planes_f'); I('P', 'pad0_')
+    P('obs_feat', 'Wb_t', 'feat_f'); I('Hf', 'Wf')
+    P('obs_img', 'img4'); I('H', 'W')
+    P('geom', 'cs_tvid', 'tok_bias', 'bounds', 'vox_min')
+    f.append(('vox_sh', _i32 * 3)); I('gather_split')
+    P('tokens', 'extras', 'vox_plan', 'vox_coord', 'vox_feat'); I('vox_n', 'vox_training')
+    P('wstream', 'wbias'); I('mlp_prec', 'mlp_shape')
+    P('sample_out'); I('white_back', 'pad1_')
+    P('rgb', 'depth', 'acc')
+    return f
+
+
+class Frame(ctypes.Structure):                        # sherf_frame
+    _fields_ = _frame_fields()
+
+
+_STRUCTS = (VoxLevel, SvoxLevelWs, SvoxLayer, SvoxPlan, Frame)
 
 
 _SCALARS = {'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float,
@@ -60,12 +111,22 @@ def _init():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch
         fn.restype = ret
         fn.argtypes = [a[0] for a in args]
+    sizes = (ctypes.c_int32 * len(_STRUCTS))()
+    if lib.sherf_struct_sizes(sizes, len(_STRUCTS)) != 0 or [int(v) for v in sizes] != [ctypes.sizeof(c) for c in _STRUCTS]:
+        raise RuntimeError(f'struct layout mismatch between include/sherf_hip.h and sherf_amd/_lib.py: '
+                           f'{[int(v) for v in sizes]} vs {[ctypes.sizeof(c) for c in _STRUCTS]}')
     _lib = lib
     return lib
 
 
 def lib():
     return _init()
+
+
+def addr(t, dtype=None):
+    """Like `ptr` but returns the integer address (what a c_void_p struct field takes)."""
+    p = ptr(t, dtype)
+    return None if p is None else p.value
 
 
 def ptr(t, dtype=None):

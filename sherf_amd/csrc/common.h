@@ -27,6 +27,17 @@ extern int g_sherf_debug;   // ablation switches for profiling (sherf_set_debug)
         return SHERF_OK;                                                                          \
     } while (0)
 
+#define SHERF_HIP_CHECK(expr)                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            snprintf(g_sherf_err, sizeof(g_sherf_err), "%s: %s: %s", __func__, #expr,             \
+                     hipGetErrorString(e_));                                                      \
+            return SHERF_ELAUNCH;                                                                 \
+        }                                                                                         \
+    } while (0)
+#define SHERF_RUN(x) do { const int rc_ = (x); if (rc_ != SHERF_OK) return rc_; } while (0)
+
 static inline hipStream_t as_stream(sherf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

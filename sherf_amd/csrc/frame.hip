@@ -1,0 +1,156 @@
+// Native frame driver (gfx950): ImportanceRenderer.forward (renderer.py:286-398) enqueued from C++ on two HIP streams.
+//
+// Why native: a frame is ~75 kernel launches of 5-800 us each; issued one by one through the Python binding the host
+// needs about as long to enqueue a frame as the GPU needs to run it, and the ray side of the frame starts only after
+// the whole encoder chain has been queued.  Here the launch order interleaves the two streams so that both start at
+// once: SMPL tables (side) -> cell lists / sampling / table folds (main) -> voxel encoder (side) -> warp, gather, MLP,
+// compositing (main).
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+constexpr int kMaxDev = 16;
+constexpr int kRing = 256;
+
+struct DevState {
+    bool init = false;
+    hipEvent_t ev_start, ev_smpl, ev_enc;
+};
+DevState g_dev[kMaxDev];
+std::mutex g_mu;          // profiling ring + event creation
+std::mutex g_frame_mu;    // one enqueue at a time: the join events are shared per device
+
+bool g_prof_on = false;
+int g_prof_n = 0;
+int g_prof_dev = -1;
+hipEvent_t g_prof_ev[kRing][2];
+bool g_prof_init = false;
+
+}  // namespace
+
+extern "C" int sherf_struct_sizes(int32_t* sizes_host, int32_t n) {
+    SHERF_CHECK_ARG(sizes_host && n >= 5);
+    sizes_host[0] = (int32_t)sizeof(sherf_vox_level);
+    sizes_host[1] = (int32_t)sizeof(sherf_svox_level_ws);
+    sizes_host[2] = (int32_t)sizeof(sherf_svox_layer);
+    sizes_host[3] = (int32_t)sizeof(sherf_svox_plan);
+    sizes_host[4] = (int32_t)sizeof(sherf_frame);
+    return SHERF_OK;
+}
+
+extern "C" int sherf_profile_mlp(int enable) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (enable && !g_prof_init) {
+        for (int i = 0; i < kRing; ++i)
+            for (int j = 0; j < 2; ++j) SHERF_HIP_CHECK(hipEventCreate(&g_prof_ev[i][j]));
+        g_prof_init = true;
+    }
+    g_prof_on = enable != 0;
+    g_prof_n = 0;
+    return SHERF_OK;
+}
+
+extern "C" int sherf_profile_mlp_read(float* ms_host, int32_t max_n, int32_t* n_host) {
+    SHERF_CHECK_ARG(ms_host && n_host && max_n > 0);
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int have = g_prof_n < kRing ? g_prof_n : kRing;
+    const int n = have < max_n ? have : max_n;
+    const int first = g_prof_n - have;
+    for (int i = 0; i < n; ++i) {
+        const int slot = (first + i) % kRing;
+        SHERF_HIP_CHECK(hipEventSynchronize(g_prof_ev[slot][1]));
+        SHERF_HIP_CHECK(hipEventElapsedTime(&ms_host[i], g_prof_ev[slot][0], g_prof_ev[slot][1]));
+    }
+    *n_host = n;
+    return SHERF_OK;
+}
+
+extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
+                                  sherf_stream_t stream_side) {
+    SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main);
+    hipStream_t main = as_stream(stream_main), side = as_stream(stream_side);
+    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    if (phase & 1) {
+        int dev = 0;
+        SHERF_HIP_CHECK(hipGetDevice(&dev));
+        SHERF_CHECK_ARG(dev >= 0 && dev < kMaxDev);
+        DevState& d = g_dev[dev];
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (!d.init) {
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_start, hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_smpl, hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, hipEventDisableTiming));
+                d.init = true;
+            }
+        }
+        SHERF_CHECK_ARG(f->R > 0 && f->S > 0 && f->capacity > 0 && f->vox_plan);
+        const int V = SHERF_V;
+        // inputs were produced on the caller's stream
+        SHERF_HIP_CHECK(hipEventRecord(d.ev_start, main));
+        SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_start, 0));
+        // ---- side: a7-a9 per-frame SMPL tables ----
+        SHERF_RUN(sherf_smpl_bones(f->poses, f->shapes, 3, f->J_template, f->J_shapedirs, f->parents, f->A, f->posefeat, stream_side));
+        SHERF_RUN(sherf_smpl_offsets(f->posedirs, f->shapedirs, f->posefeat, f->shapes, 3, f->PO, f->SO, stream_side));
+        const float *A0 = f->A, *A1 = f->A + 24 * 12, *A2 = f->A + 2 * 24 * 12;
+        const float *PO0 = f->PO, *PO1 = f->PO + V * 3, *PO2 = f->PO + 2 * V * 3;
+        const float *SO0 = f->SO, *SO2 = f->SO + 2 * V * 3;
+        SHERF_RUN(sherf_smpl_t2c_table(f->weights, A0, A1, PO0, SO0, PO1, f->T2C, stream_side));
+        SHERF_RUN(sherf_smpl_c2s_table(f->weights, A1, A2, PO1, SO2, PO2, f->obs_R, f->obs_Th, f->cam_R, f->cam_T, f->cam_K, f->C2S,
+                                       stream_side));
+        SHERF_HIP_CHECK(hipEventRecord(d.ev_smpl, side));
+        // ---- main: cell lists, a4-a6 sampling / mask / nearest vertex / compaction, table re-layout ----
+        SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
+                                     f->cell_scratch, f->near_mask, stream_main));
+        const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
+        SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
+                                       f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
+                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, stream_main));
+        SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, stream_main));
+        SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, stream_main));
+        SHERF_RUN(sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, stream_main));
+        // ---- side: a11 sparse voxel encoder ----
+        SHERF_RUN(sherf_svox_encode(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side));
+        SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
+        // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
+        SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
+        SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
+                                  f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, f->capacity, f->geom,
+                                  f->cs_tvid, stream_main));
+        if (f->gather_split) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
+            SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
+                                          nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1, f->capacity, f->tokens,
+                                          f->extras, stream_main));
+            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
+            SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
+                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 2, f->capacity, f->tokens,
+                                          f->extras, stream_main));
+        } else {
+            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
+            SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
+                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0, f->capacity, f->tokens,
+                                          f->extras, stream_main));
+        }
+        int slot = -1;
+        if (g_prof_on) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            slot = g_prof_n % kRing;
+            SHERF_HIP_CHECK(hipEventRecord(g_prof_ev[slot][0], main));
+        }
+        SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, f->mlp_shape, f->capacity,
+                                 f->sample_out, stream_main));
+        if (slot >= 0) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            SHERF_HIP_CHECK(hipEventRecord(g_prof_ev[slot][1], main));
+            ++g_prof_n;
+        }
+    }
+    if (phase & 2) {
+        // ---- a15-a16 ----
+        SHERF_RUN(sherf_composite_compact(f->counters, f->ray_base, f->ray_cnt, f->cs_idx, f->sample_out, f->ray_d, f->near, f->far,
+                                          f->R, f->S, f->white_back, f->rgb, f->depth, f->acc, stream_main));
+    }
+    return SHERF_OK;
+}

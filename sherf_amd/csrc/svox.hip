@@ -90,12 +90,21 @@ __global__ void __launch_bounds__(1024) scan_chunks_kernel(int32_t* __restrict__
 }
 
 __global__ void __launch_bounds__(256) scan_add_kernel(const uint32_t* __restrict__ bitmap, int32_t* __restrict__ prefix, int n_words,
-                                                       const int32_t* __restrict__ chunk_off, uint2* __restrict__ wp) {
+                                                       const int32_t* __restrict__ chunk_off, uint2* __restrict__ wp,
+                                                       int32_t* __restrict__ keys) {
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w < n_words) {
         const int pf = prefix[w] + chunk_off[w >> 10];
+        uint32_t bits = bitmap[w];
         prefix[w] = pf;
-        wp[w] = make_uint2(bitmap[w], (uint32_t)pf);          // one 8-byte record per word: a lookup is a single load
+        wp[w] = make_uint2(bits, (uint32_t)pf);               // one 8-byte record per word: a lookup is a single load
+        if (keys) {                                           // row id -> linear voxel index (fused keys_kernel)
+            int r = pf;
+            while (bits) {
+                keys[r++] = w * 32 + __ffs(bits) - 1;
+                bits &= bits - 1;
+            }
+        }
     }
 }
 
@@ -159,12 +168,24 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 }
 __device__ __forceinline__ float rt(float a) { return (float)((__bf16)a); }
 
+// BatchNorm statistics of a conv's OUTPUT, finalised by the last workgroup to finish (ticket in `done`, reset by that
+// workgroup): removes the separate single-block launch per layer.  done == nullptr: no fused finalize.
+struct BnFuse {
+    const int32_t* n_total;     // number of rows of the reference's row set (level 0: N incl. duplicates)
+    const float* gamma;
+    const float* beta;
+    float* stats;               // [2][C]: batch mean/var (training: written) or running stats (eval: read)
+    float* bnparam;             // [3][C]: scale, shift, relu(shift)
+    int32_t* done;
+    int training;
+};
+
 template <int NCOT>   // Cout = 32 * NCOT
 __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, int Cin, const float* __restrict__ in_bn,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
-                                                     float* __restrict__ out_raw, double* __restrict__ partials) {
+                                                     float* __restrict__ out_raw, double* partials, BnFuse bn) {
     constexpr int COUT = 32 * NCOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
@@ -264,23 +285,58 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             partials[((size_t)blockIdx.x * 2 + which) * COUT + c2] = t;
         }
     }
+    if (bn.done == nullptr) return;
+    __shared__ int s_last;
+    __threadfence();                                    // this workgroup's partials visible device-wide (all XCDs)
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(bn.done, 1) == ((n_rows + 31) >> 5) - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) *bn.done = 0;
+    double* sd = reinterpret_cast<double*>(s_red);
+    if (bn.training) {
+        constexpr int series = 2 * COUT, nparts = 256 / series;          // 4 / 2 / 1 slices of the block list
+        const int sidx = tid % series, part = tid / series;
+        const int nblk = (n_rows + 31) >> 5;
+        double t = 0.0;
+        if (part < nparts) {
+#pragma unroll 4
+            for (int b = part; b < nblk; b += nparts) t += partials[(size_t)b * series + sidx];   // fixed order: deterministic
+            sd[part * series + sidx] = t;
+        }
+        __syncthreads();
+        if (tid < COUT) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int q = 0; q < nparts; ++q) { a1 += sd[q * series + tid]; a2 += sd[q * series + COUT + tid]; }
+            const double n = (double)(*bn.n_total);
+            const double mean = a1 / n, var = fmax(a2 / n - mean * mean, 0.0);
+            bn.stats[tid] = (float)mean; bn.stats[COUT + tid] = (float)var;
+        }
+    }
+    if (tid < COUT) {                                   // same thread wrote stats[tid] above
+        const float mean = bn.stats[tid], var = bn.stats[COUT + tid];
+        const float scale = bn.gamma[tid] / sqrtf(var + 1e-3f);
+        const float shift = bn.beta[tid] - mean * scale;
+        bn.bnparam[tid] = scale; bn.bnparam[COUT + tid] = shift; bn.bnparam[2 * COUT + tid] = fmaxf(shift, 0.f);
+    }
 }
 
 // mean/var over the reference's ROW set from the per-block partials -> bnparam[3][C] = (scale, shift, relu(shift)), stats[2][C]
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(const double* __restrict__ partials, const int32_t* __restrict__ n_rows_p,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ partials, const int32_t* __restrict__ n_rows_p,
                                                            const int32_t* __restrict__ n_total_p, int C, int rows_per_block,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ stats, int training, float* __restrict__ bnparam) {
-    __shared__ double s[1024];
+    __shared__ double s[256];
     const int tid = threadIdx.x;
     if (training) {
-        const int series = 2 * C, nparts = 1024 / series;
+        const int series = 2 * C, nparts = 256 / series;
         const int sidx = tid % series, part = tid / series;
         const int nblk = (*n_rows_p + rows_per_block - 1) / rows_per_block;
         double t = 0.0;
         if (part < nparts)
             for (int b = part; b < nblk; b += nparts) t += partials[(size_t)b * series + sidx];    // fixed order: deterministic
-        s[tid] = t;
+        s[tid] = t;      // same slicing as the fused finalize in sconv3_kernel -> bitwise identical statistics
         __syncthreads();
         if (tid < series) {
             double a = 0.0;
@@ -326,7 +382,7 @@ extern "C" int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* pre
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), bitmap, n_words, prefix, chunk_ws);
     hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(1024), 0, as_stream(stream), chunk_ws, n_chunks, n_rows);
     hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n_words, 256)), dim3(256), 0, as_stream(stream), bitmap, prefix, n_words, chunk_ws,
-                       reinterpret_cast<uint2*>(wp));
+                       reinterpret_cast<uint2*>(wp), (int32_t*)nullptr);
     SHERF_LAUNCH_CHECK();
 }
 
@@ -355,8 +411,25 @@ extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_r
                                       int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
                                       float* bnparam, sherf_stream_t stream) {
     SHERF_CHECK_ARG(partials && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
                        rows_per_block, gamma, beta, stats, training, bnparam);
+    SHERF_LAUNCH_CHECK();
+}
+
+static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo, const uint32_t* wp_in, int Di,
+                        int Hi, int Wi, const float* in_raw, int Cin, const float* in_bn, const int32_t* in_mult,
+                        const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, double* partials, BnFuse bn,
+                        sherf_stream_t stream) {
+    SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
+    SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
+    SHERF_CHECK_ARG(bn.done == nullptr || (partials && bn.n_total && bn.gamma && bn.beta && bn.stats && bn.bnparam));
+    const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
+    const dim3 grid(cdiv(max_rows, 32)), block(256);
+#define SHERF_CONV3(N)                                                                                                       \
+    hipLaunchKernelGGL(sconv3_kernel<N>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,                \
+                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult,                          \
+                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials, bn)
+    if (Cout == 32) SHERF_CONV3(1); else if (Cout == 64) SHERF_CONV3(2); else SHERF_CONV3(3);
     SHERF_LAUNCH_CHECK();
 }
 
@@ -364,14 +437,65 @@ extern "C" int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_o
                                 const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw, int Cin,
                                 const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
                                 int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
-    SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
-    const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
-    const dim3 grid(cdiv(max_rows, 32)), block(256);
-#define SHERF_CONV3(N)                                                                                                       \
-    hipLaunchKernelGGL(sconv3_kernel<N>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,                \
-                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult,                          \
-                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials)
-    if (Cout == 32) SHERF_CONV3(1); else if (Cout == 64) SHERF_CONV3(2); else SHERF_CONV3(3);
+    return launch_conv3(keys_out, n_rows_out, Do, Ho, Wo, wp_in, Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, w_packed, Cout, mode,
+                        max_rows, out_raw, partials, BnFuse{}, stream);
+}
+
+static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
+    const int n_chunks = cdiv(l.n_words, 1024);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), l.bitmap, l.n_words, l.prefix, l.chunk_ws);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(1024), 0, as_stream(stream), l.chunk_ws, n_chunks, l.n_rows);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(l.n_words, 256)), dim3(256), 0, as_stream(stream), l.bitmap, l.prefix, l.n_words,
+                       l.chunk_ws, reinterpret_cast<uint2*>(l.wp), l.keys);
     SHERF_LAUNCH_CHECK();
+}
+
+// The whole encoder as one native call: 1 memset + 6 launches for level 0, 4 per down-sampling, 1 per conv (BatchNorm
+// finalize fused), 1 per tapped level for the fold.  Everything is enqueued on `stream`; nothing is read back.
+extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
+                                 sherf_vox_level* levels_out_host, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(p && coord && feat && n > 0 && levels_out_host && p->n_layers > 0 && p->n_layers <= SHERF_SVOX_MAX_LAYERS);
+    SHERF_CHECK_ARG(p->zero_ptr && p->zero_bytes > 0 && p->acc_fix && p->g0 && p->mult && p->n_total);
+    for (int i = 0; i < 4; ++i) {
+        const sherf_svox_level_ws& l = p->lev[i];
+        SHERF_CHECK_ARG(l.bitmap && l.prefix && l.n_rows && l.chunk_ws && l.wp && l.keys && l.n_words > 0 && l.cap > 0 && l.D > 0 && l.H > 0 && l.W > 0);
+    }
+    SHERF_HIP_CHECK(hipMemsetAsync(p->zero_ptr, 0, (size_t)p->zero_bytes, as_stream(stream)));
+    const sherf_svox_level_ws& l0 = p->lev[0];
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coord, n, l0.D, l0.H, l0.W, l0.bitmap);
+    SHERF_RUN(scan_level(l0, stream));
+    SHERF_RUN(sherf_svox_scatter_rows(coord, feat, n, 32, l0.D, l0.H, l0.W, l0.bitmap, l0.prefix, l0.n_rows, p->acc_fix, p->g0,
+                                      p->mult, stream));
+    int lev = 0, ntap = 0;
+    const float* cur = p->g0;
+    const float* cur_bn = nullptr;
+    for (int li = 0; li < p->n_layers; ++li) {
+        const sherf_svox_layer& ly = p->layers[li];
+        SHERF_CHECK_ARG(ly.wt && ly.gamma && ly.beta && ly.stats && ly.bnparam && ly.out && ly.partials && ly.done);
+        SHERF_CHECK_ARG(lev + (ly.down ? 1 : 0) < 4);
+        const sherf_svox_level_ws& src = p->lev[lev];
+        const sherf_svox_level_ws& dst = p->lev[lev + (ly.down ? 1 : 0)];
+        if (ly.down) {
+            hipLaunchKernelGGL(mark_down_kernel, dim3(cdiv(src.cap, 256)), dim3(256), 0, as_stream(stream), src.keys, src.n_rows,
+                               src.D, src.H, src.W, dst.bitmap);
+            SHERF_RUN(scan_level(dst, stream));
+        }
+        const int dlev = lev + (ly.down ? 1 : 0);
+        BnFuse bn{dlev == 0 ? p->n_total : dst.n_rows, ly.gamma, ly.beta, ly.stats, ly.bnparam, ly.done, training};
+        SHERF_RUN(launch_conv3(dst.keys, dst.n_rows, dst.D, dst.H, dst.W, src.wp, src.D, src.H, src.W, cur, ly.cin, cur_bn,
+                               (lev == 0 && cur_bn) ? p->mult : nullptr, ly.wt, ly.cout, ly.down ? 1 : 0, dst.cap, ly.out,
+                               ly.partials, bn, stream));
+        lev = dlev; cur = ly.out; cur_bn = ly.bnparam;
+        if (ly.tap) {
+            SHERF_CHECK_ARG(ntap < 3 && p->fold_mat[ntap] && p->fold_rows[ntap]);
+            SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, ly.bnparam, nullptr,
+                                   p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, BnFuse{}, stream));
+            levels_out_host[ntap].wp = dst.wp;
+            levels_out_host[ntap].rows = p->fold_rows[ntap];
+            levels_out_host[ntap].D = dst.D; levels_out_host[ntap].H = dst.H; levels_out_host[ntap].W = dst.W;
+            ++ntap;
+        }
+    }
+    SHERF_CHECK_ARG(ntap == 3);
+    return SHERF_OK;
 }

@@ -215,6 +215,7 @@ class ImportanceRenderer(nn.Module):
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
         self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2')
+        self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         self._smpl_src = smpl
         self._smpl_path = smpl_path
         # not parameters / buffers (the reference keeps the SMPL dict as a plain attribute too, renderer.py:284);
@@ -305,93 +306,77 @@ class ImportanceRenderer(nn.Module):
         ws = self._ws.frame(R, S, cap, dev)
         prm, oprm, tprm = input_data['params'], input_data['obs_params'], input_data['t_params']
 
-        # Two HIP streams: the sparse voxel encoder is a chain of ~45 small launches that cannot fill the chip, and it is
-        # independent of the ray side of the frame until the gather -> it runs (with the SMPL tables) on a side stream,
-        # concurrently with cell lists / sampling / compaction / table folding on the caller's stream.
+        # One native call enqueues the whole frame on two HIP streams (csrc/frame.hip): the sparse voxel encoder is a chain
+        # of ~35 small launches that cannot fill the chip and is independent of the ray side of the frame until the
+        # gather -> it runs (with the SMPL tables) on a side stream, concurrently with cell lists / sampling / compaction /
+        # table folding on the caller's stream.  Everything below only collects pointers.
         main = torch.cuda.current_stream(dev)
         side = self._side(dev)
-        Rg, Th = f32(prm['R']).view(9), f32(prm['Th']).view(3)
-        verts = f32(input_data['vertices']).view(V, 3)
-        tverts = f32(input_data['t_vertices']).view(V, 3)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            st2 = _lib.stream()
-            # ---- a7-a9: per-frame SMPL tables ----
-            poses = torch.stack([f32(prm['poses']).view(72), f32(tprm['poses']).view(72), f32(oprm['poses']).view(72)])
-            shapes = torch.stack([f32(prm['shapes']).view(10), f32(tprm['shapes']).view(10), f32(oprm['shapes']).view(10)])
-            _lib.call('sherf_smpl_bones', P(poses), P(shapes), 3, P(smpl['J_template']), P(smpl['J_shapedirs']),
-                      P(smpl['parents_i32']), P(ws['A']), P(ws['posefeat']), st2)
-            _lib.call('sherf_smpl_offsets', P(smpl['posedirs_flat']), P(smpl['shapedirs']), P(ws['posefeat']), P(shapes), 3,
-                      P(ws['PO']), P(ws['SO']), st2)
-            A, PO, SO = ws['A'], ws['PO'], ws['SO']
-            _lib.call('sherf_smpl_t2c_table', P(smpl['weights']), P(A[0]), P(A[1]), P(PO[0]), P(SO[0]), P(PO[1]), P(ws['T2C']), st2)
-            _lib.call('sherf_smpl_c2s_table', P(smpl['weights']), P(A[1]), P(A[2]), P(PO[1]), P(SO[2]), P(PO[2]),
-                      P(f32(oprm['R']).view(9)), P(f32(oprm['Th']).view(3)), P(f32(input_data['obs_R_all']).view(9)),
-                      P(f32(input_data['obs_T_all']).view(3)), P(f32(input_data['obs_K_all']).view(9)), P(ws['C2S']), st2)
-            ev_smpl = torch.cuda.Event()
-            ev_smpl.record(side)
-            # ---- a11: sparse voxel encoder -> folded level tables ----
-            levels, keep, vdbg = self.encoder_3d.encode(canonical_sp_conv_volume, wc['fold'], self._ws)
+        A = _lib.addr
+        fr = _lib.Frame()
+        keep = []                                                        # conversions that must outlive the enqueue
 
-        # ---- cell lists over the posed (SMPL frame) and canonical vertices ----
-        _lib.call('sherf_build_cells2', P(verts), P(Rg), P(Th), P(tverts), V, 0.05, P(ws['grid_hdr']), P(ws['cell_start']),
-                  P(ws['cell_pts']), P(ws['cell_scratch']), P(ws['near_mask']), st)
-        vox_min = f32(obs_sp_input['bounds']).view(2, 3)[0].contiguous()
-        out_sh = [int(v) for v in obs_sp_input['out_sh']]
-        vox_sh = (_ct.c_int32 * 3)(*out_sh)
+        def a32(t, *shape):
+            t = f32(t).view(*shape)
+            keep.append(t)
+            return A(t)
 
-        # ---- a4-a6: sample, mask, nearest vertex, compaction ----
-        ro, rd = f32(ray_origins).view(R, 3), f32(ray_directions).view(R, 3)
-        nr, fr = f32(near).view(R), f32(far).view(R)
-        _lib.call('sherf_sample_mask_nn', P(ro), P(rd), P(nr), P(fr), R, S, P(Rg), P(Th), P(ws['grid_hdr'][0]),
-                  P(ws['cell_start'][0]), P(ws['cell_pts'][0]), P(ws['near_mask']), cap, P(ws['counters']), P(ws['ray_base']), P(ws['ray_cnt']),
-                  P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(ws['dense_vid']), P(ws['ray_mask']), P(ws['scan_ws']), st)
-
-        # ---- per-frame table re-layout (channel-last) with the slot projections folded in ----
+        poses = torch.stack([f32(prm['poses']).view(72), f32(tprm['poses']).view(72), f32(oprm['poses']).view(72)])
+        shapes = torch.stack([f32(prm['shapes']).view(10), f32(tprm['shapes']).view(10), f32(oprm['shapes']).view(10)])
+        keep += [poses, shapes]
+        fr.poses, fr.shapes = A(poses), A(shapes)
+        fr.J_template, fr.J_shapedirs, fr.parents = A(smpl['J_template']), A(smpl['J_shapedirs']), A(smpl['parents_i32'])
+        fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
+        for k in ('A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
+                  'counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws', 'geom',
+                  'cs_tvid', 'tokens', 'extras', 'sample_out', 'rgb', 'depth', 'acc'):
+            setattr(fr, k, A(ws[k]))
+        fr.obs_R, fr.obs_Th = a32(oprm['R'], 9), a32(oprm['Th'], 3)
+        fr.cam_R, fr.cam_T, fr.cam_K = a32(input_data['obs_R_all'], 9), a32(input_data['obs_T_all'], 3), a32(input_data['obs_K_all'], 9)
+        fr.verts, fr.tverts = a32(input_data['vertices'], V, 3), a32(input_data['t_vertices'], V, 3)
+        fr.Rg, fr.Th = a32(prm['R'], 9), a32(prm['Th'], 3)
+        fr.ray_o, fr.ray_d = a32(ray_origins, R, 3), a32(ray_directions, R, 3)
+        fr.near, fr.far = a32(near, R), a32(far, R)
+        fr.R, fr.S, fr.capacity = R, S, cap
+        # per-frame table re-layout (channel-last) with the slot projections folded in
         Pres = planes.shape[-1]
         Hf, Wf = obs_input_feature.shape[-2:]
         H, W = obs_input_img.shape[-2:]
         planes_f = self._ws.table('planes_f', (3, Pres, Pres, 32), dev)
         feat_f = self._ws.table('feat_f', (Hf, Wf, 64), dev)
         img4 = self._ws.table('img4', (H, W, 4), dev)
-        _lib.call('sherf_fold_tables', P(f32(planes)), P(wc['Wa_t']), P(planes_f), Pres * Pres, 3, 32, Pres * Pres * 32, st)
-        _lib.call('sherf_fold_tables', P(f32(obs_input_feature)), P(wc['Wb_t']), P(feat_f), Hf * Wf, 2, 64, 32, st)
-        _lib.call('sherf_img_to_hwc4', P(f32(obs_input_img)), P(img4), H * W, st)
-        bounds = f32(input_data['t_world_bounds']).view(6)
-
-        # ---- a8-a10: warp (needs the SMPL tables of the side stream) ----
-        main.wait_event(ev_smpl)
-        _lib.call('sherf_warp_geom', P(ws['counters']), P(ws['cs_idx']), P(ws['cs_vid']), P(ws['cs_xs']), P(rd), S, P(Rg),
-                  P(ws['T2C']), P(ws['C2S']), P(tverts), P(ws['grid_hdr'][1]), P(ws['cell_start'][1]), P(ws['cell_pts'][1]),
-                  cap, P(ws['geom']), P(ws['cs_tvid']), st)
-        # ---- a10-a12: gather -> tokens.  Pass 1 (tri-plane + pixel taps) does not need the voxel encoder, so it runs while the
-        # side stream is still busy; pass 2 adds the voxel taps once the levels are ready. ----
-        _lib.call('sherf_gather_tokens', P(ws['counters']), P(ws['geom']), P(planes_f), Pres, P(feat_f), Hf, Wf, P(img4), H, W,
-                  None, P(wc['tok_bias']), P(bounds), P(vox_min), _ct.c_void_p(_ct.addressof(vox_sh)), 1, cap,
-                  P(ws['tokens']), P(ws['extras']), st)
-        main.wait_stream(side)                                           # voxel levels ready
-        _lib.call('sherf_gather_tokens', P(ws['counters']), P(ws['geom']), P(planes_f), Pres, P(feat_f), Hf, Wf, P(img4), H, W,
-                  _ct.c_void_p(_ct.addressof(levels)), P(wc['tok_bias']), P(bounds), P(vox_min),
-                  _ct.c_void_p(_ct.addressof(vox_sh)), 2, cap, P(ws['tokens']), P(ws['extras']), st)
-        # ---- a13-a14: fused transformer + NeRF decoder ----
-        prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
-        prof = getattr(self, 'profile_mlp', False)
-        if prof:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        shape = {'8x1': 0, '4x2': 1}[opts.get('mlp_shape', self.mlp_shape)]
-        _lib.call('sherf_nerf_mlp', P(ws['counters']), P(ws['tokens']), P(ws['extras']), P(wc['stream']), P(wc['wbias']), prec,
-                  shape, cap, P(ws['sample_out']), st)
-        if prof:
-            e1.record()
-            self.mlp_events = getattr(self, 'mlp_events', []) + [(e0, e1)]
+        fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, -1), A(wc['Wa_t']), A(planes_f), Pres
+        fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, -1), A(wc['Wb_t']), A(feat_f), Hf, Wf
+        fr.obs_img, fr.img4, fr.H, fr.W = a32(obs_input_img, -1), A(img4), H, W
+        fr.tok_bias, fr.bounds = A(wc['tok_bias']), a32(input_data['t_world_bounds'], 6)
+        vox_min = f32(obs_sp_input['bounds']).view(2, 3)[0].contiguous()
+        keep.append(vox_min)
+        fr.vox_min = A(vox_min)
+        for i, v in enumerate(obs_sp_input['out_sh']):
+            fr.vox_sh[i] = int(v)
+        fr.gather_split = 1 if opts.get('gather_split', self.gather_split) else 0
+        # a11: sparse voxel encoder plan (persistent buffers) + this frame's voxels
+        pl, vfeat, vcoord = self.encoder_3d.prepare(canonical_sp_conv_volume, wc['fold'], self._ws)
+        keep += [vfeat, vcoord]
+        fr.vox_plan = _ct.addressof(pl['plan'])
+        fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
+        # a13-a14: fused transformer + NeRF decoder
+        fr.wstream, fr.wbias = A(wc['stream']), A(wc['wbias'])
+        fr.mlp_prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
+        fr.mlp_shape = {'8x1': 0, '4x2': 1}[opts.get('mlp_shape', self.mlp_shape)]
+        fr.white_back = 1 if opts.get('white_back', False) else 0
+        levels = (_lib.VoxLevel * 3)()
+        s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
         noise = float(opts.get('density_noise', 0) or 0)
         if noise > 0:                                                    # renderer.py:435-436 (training only)
+            _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side)
             ws['sample_out'][:, 3] += torch.randn(cap, device=dev) * noise
-        # ---- a15-a16: composite ----
-        _lib.call('sherf_composite_compact', P(ws['counters']), P(ws['ray_base']), P(ws['ray_cnt']), P(ws['cs_idx']),
-                  P(ws['sample_out']), P(rd), P(nr), P(fr), R, S, 1 if opts.get('white_back', False) else 0, P(ws['rgb']),
-                  P(ws['depth']), P(ws['acc']), st)
-        self.last = dict(ws=ws, vox=vdbg, keep=(keep, planes_f, feat_f, img4), R=R, S=S, cap=cap)
+            _lib.call('sherf_render_frame', _ct.byref(fr), 2, levels, s_main, s_side)
+        else:
+            _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side)
+        self.encoder_3d.finish(pl)
+        vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
+        keep = (pl['rows'], planes_f, feat_f, img4)
+        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap)
         return ws['rgb'].view(1, R, 3).clone(), ws['depth'].view(1, R, 1).clone(), ws['acc'].view(1, R, 1).clone()
 

@@ -102,75 +102,91 @@ class SparseConvNet(nn.Module):
         self._packed = dict(key=key, layers=layers)
         return self._packed
 
-    def encode(self, sp, fold_mats, ws):
-        """Runs the encoder on a SparseConvTensor; returns the three tapped levels as `_lib.VoxLevel`s whose rows
-        are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see ImportanceRenderer._weights.
-
-        Per layer: one tiled conv launch (BatchNorm+ReLU of the INPUT applied while gathering, fp64 partial sums
-        of the OUTPUT) + one tiny finalize launch that turns the partials into scale/shift for the next layer."""
-        feat = sp.features.detach().float().contiguous()
-        coord = sp.indices.to(torch.int32).contiguous()
-        dev = feat.device
-        N = feat.shape[0]
+    def plan(self, spatial_shape, N, fold_mats, ws, dev):
+        """The native encoder's plan (`sherf_svox_plan`): every persistent buffer of the chain, allocated once per
+        (shape, N, weights version) in the workspace `ws` and reused by every frame."""
         pk = self._pack(dev)
-        shapes = [tuple(sp.spatial_shape)]
+        shapes = [tuple(int(v) for v in spatial_shape)]
         for _ in range(3):
             shapes.append(tuple((d - 1) // 2 + 1 for d in shapes[-1]))
+        key = (pk['key'], tuple(shapes), N, str(dev), tuple(m.data_ptr() for m in fold_mats))
+        cached = getattr(ws, 'vox_plan', None)
+        if cached is not None and cached['key'] == key:
+            return cached
         L, zero_region = ws.voxel_levels(shapes, N, dev)
-        st = _lib.stream()
-        P = _lib.ptr
-        training = self.training
-        zero_region.zero_()                                   # every bitmap, level-0 multiplicities and summed features
-        l0 = L[0]
-        D, H, W = shapes[0]
-        _lib.call('sherf_svox_mark_rows', P(coord), N, D, H, W, P(l0['bitmap']), st)
-        _lib.call('sherf_svox_scan', P(l0['bitmap']), l0['nwords'], P(l0['prefix']), P(l0['n_rows']), P(l0['chunk_ws']), P(l0['wp']), st)
-        _lib.call('sherf_svox_keys', P(l0['bitmap']), P(l0['prefix']), l0['nwords'], P(l0['keys']), st)
-        _lib.call('sherf_svox_scatter_rows', P(coord), P(feat), N, 32, D, H, W, P(l0['bitmap']), P(l0['prefix']), P(l0['n_rows']),
-                  P(l0['acc_fix']), P(l0['g0']), P(l0['mult']), st)
-        lev = 0
-        cur, cur_bn = l0['g0'], None                          # raw features of the current level + their BN params (None: raw)
-        taps = []
+        A = _lib.addr
+        plan = _lib.SvoxPlan()
+        for i, (lv, sh) in enumerate(zip(L, shapes)):
+            c = plan.lev[i]
+            c.bitmap, c.prefix, c.n_rows, c.chunk_ws = A(lv['bitmap']), A(lv['prefix']), A(lv['n_rows']), A(lv['chunk_ws'])
+            c.wp, c.keys, c.n_words, c.cap = A(lv['wp']), A(lv['keys']), lv['nwords'], lv['cap']
+            c.D, c.H, c.W = sh
+        ctot = sum(ly['cout'] for ly in pk['layers'])
+        stats_flat = torch.zeros(2 * ctot, device=dev)                     # all layers' [2][C] stats, one buffer
+        done = torch.zeros(len(pk['layers']), dtype=torch.int32, device=dev)
+        lev, off, meta, taps = 0, 0, [], []
         for li, ly in enumerate(pk['layers']):
-            src = L[lev]
-            dst = L[lev + 1] if ly['down'] else src
-            if ly['down']:
-                _lib.call('sherf_svox_mark_down', P(src['keys']), P(src['n_rows']), *shapes[lev], P(dst['bitmap']), src['cap'], st)
-                _lib.call('sherf_svox_scan', P(dst['bitmap']), dst['nwords'], P(dst['prefix']), P(dst['n_rows']), P(dst['chunk_ws']), P(dst['wp']), st)
-                _lib.call('sherf_svox_keys', P(dst['bitmap']), P(dst['prefix']), dst['nwords'], P(dst['keys']), st)
-            out = ws.layer_out(li, dst['cap'], ly['cout'], dev)
-            rpb = 32                                          # output rows per workgroup of sconv3_kernel
-            parts = ws.partials(li, (dst['cap'] + rpb - 1) // rpb, ly['cout'], dev)
-            mult = P(src['mult']) if (lev == 0 and cur_bn is not None) else None
             dlev = lev + 1 if ly['down'] else lev
-            _lib.call('sherf_svox_conv3', P(dst['keys']), P(dst['n_rows']), *shapes[dlev], P(src['wp']),
-                      *shapes[lev], P(cur), ly['cin'], P(cur_bn) if cur_bn is not None else None, mult, P(ly['wt']), ly['cout'],
-                      1 if ly['down'] else 0, dst['cap'], P(out), P(parts), st)
-            bn = ly['bn']
-            stats = ws.bn_stats(li, ly['cout'], dev)
-            if not training:
-                stats[0].copy_(bn.running_mean); stats[1].copy_(bn.running_var)
-            n_total = l0['n_total'] if dlev == 0 else dst['n_rows']
-            bnp = ws.bn_param(li, ly['cout'], dev)
-            _lib.call('sherf_svox_bn_finalize', P(parts), P(dst['n_rows']), P(n_total), ly['cout'], rpb, P(ly['gamma']), P(ly['beta']),
-                      P(stats), 1 if training else 0, P(bnp), st)
-            if training and torch.is_grad_enabled() and bn.track_running_stats:
-                with torch.no_grad():     # nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance)
-                    n = n_total.float()
-                    bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * stats[0])
-                    bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * stats[1] * n / (n - 1))
-                    bn.num_batches_tracked += 1
-            lev, cur, cur_bn = dlev, out, bnp
+            cap, C = L[dlev]['cap'], ly['cout']
+            out = ws.layer_out(li, cap, C, dev)
+            parts = ws.partials(li, (cap + 31) // 32, C, dev)
+            stats = stats_flat[off:off + 2 * C].view(2, C); off += 2 * C
+            bnp = ws.bn_param(li, C, dev)
+            c = plan.layers[li]
+            c.cin, c.cout, c.down, c.tap = ly['cin'], C, int(ly['down']), int(ly['tap'])
+            c.wt, c.gamma, c.beta = A(ly['wt']), A(ly['gamma']), A(ly['beta'])
+            c.stats, c.bnparam, c.out, c.partials, c.done = A(stats), A(bnp), A(out), A(parts), A(done[li:li + 1])
+            meta.append(dict(bn=ly['bn'], stats=stats, bnp=bnp, out=out, lev=dlev, cout=C))
             if ly['tap']:
-                taps.append((lev, out, bnp, ly['cout']))
+                taps.append((dlev, out, bnp, C))
+            lev = dlev
+        plan.n_layers = len(pk['layers'])
+        l0 = L[0]
+        plan.acc_fix, plan.g0, plan.mult, plan.n_total = A(l0['acc_fix']), A(l0['g0']), A(l0['mult']), A(l0['n_total'])
+        plan.zero_ptr, plan.zero_bytes = A(zero_region), zero_region.numel() * 4
+        rows = []
+        for i, (tl, _, _, _) in enumerate(taps):
+            r = ws.fold_out(i, L[tl]['cap'], dev)
+            plan.fold_mat[i], plan.fold_rows[i] = A(fold_mats[i]), A(r)
+            rows.append(r)
+        ws.vox_plan = dict(key=key, plan=plan, L=L, shapes=shapes, meta=meta, taps=taps, rows=rows, stats_flat=stats_flat,
+                           keep=(done, zero_region, tuple(fold_mats), pk))
+        return ws.vox_plan
+
+    def prepare(self, sp, fold_mats, ws):
+        """Host-side part of a frame: plan lookup + (eval mode) running statistics into the plan's stats buffer.
+        Returns (plan dict, features fp32, coordinates int32)."""
+        feat = sp.features.detach().float().contiguous()
+        coord = sp.indices.to(torch.int32).contiguous()
+        pl = self.plan(sp.spatial_shape, feat.shape[0], fold_mats, ws, feat.device)
+        if not self.training:
+            with torch.no_grad():
+                pl['stats_flat'].copy_(torch.cat([t.reshape(-1) for m in pl['meta'] for t in (m['bn'].running_mean, m['bn'].running_var)]).float())
+        return pl, feat, coord
+
+    def finish(self, pl):
+        """nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance); call after the encoder was enqueued."""
+        if not (self.training and torch.is_grad_enabled()):
+            return
+        with torch.no_grad():
+            for m in pl['meta']:
+                bn = m['bn']
+                if not bn.track_running_stats:
+                    continue
+                n = (pl['L'][0]['n_total'] if m['lev'] == 0 else pl['L'][m['lev']]['n_rows']).float()
+                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * m['stats'][0])
+                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * m['stats'][1] * n / (n - 1))
+                bn.num_batches_tracked += 1
+
+    def encode(self, sp, fold_mats, ws):
+        """Runs the encoder on a SparseConvTensor (one native call, csrc/svox.hip: sherf_svox_encode); returns the three
+        tapped levels as `_lib.VoxLevel`s whose rows are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see
+        ImportanceRenderer._weights.  Per layer: one tiled conv launch (BatchNorm+ReLU of the INPUT applied while
+        gathering, fp64 partial sums of the OUTPUT turned into scale/shift for the next layer by the last workgroup)."""
+        import ctypes
+        pl, feat, coord = self.prepare(sp, fold_mats, ws)
         levels = (_lib.VoxLevel * 3)()
-        keep = []
-        for i, (lev, raw, bnp, C) in enumerate(taps):
-            rows = ws.fold_out(i, L[lev]['cap'], dev)                   # relu(bn(raw)) @ fold [C, 96] as a pointwise "conv"
-            _lib.call('sherf_svox_conv3', None, P(L[lev]['n_rows']), 1, 1, 1, None, 1, 1, 1, P(raw), C, P(bnp), None,
-                      P(fold_mats[i]), 96, 2, L[lev]['cap'], P(rows), None, st)
-            keep.append(rows)
-            levels[i].wp = L[lev]['wp'].data_ptr()
-            levels[i].rows = rows.data_ptr()
-            levels[i].D, levels[i].H, levels[i].W = shapes[lev]
-        return levels, keep, dict(levels=L, taps=taps, shapes=shapes)
+        _lib.call('sherf_svox_encode', ctypes.byref(pl['plan']), _lib.ptr(coord), _lib.ptr(feat), feat.shape[0],
+                  1 if self.training else 0, levels, _lib.stream())
+        self.finish(pl)
+        return levels, pl['rows'], dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])

@@ -68,3 +68,25 @@ def test_mlp_stream_layout_matches_packer(golden_dir):
     sd = {k: fixtures.seeded_param(k, s) for k, s in shapes.items() if fixtures.seeded_param(k, s) is not None}
     _, _, nkbs = mlp_pack.pack(sd)
     assert n.value == len(nkbs) and list(nkb[:n.value]) == nkbs
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """Every field of the ctypes mirrors in sherf_amd/_lib.py sits at the offset the C header gives it."""
+    import ctypes
+    import subprocess
+    from sherf_amd import _lib
+    names = {'VoxLevel': 'sherf_vox_level', 'SvoxLevelWs': 'sherf_svox_level_ws', 'SvoxLayer': 'sherf_svox_layer',
+             'SvoxPlan': 'sherf_svox_plan', 'Frame': 'sherf_frame'}
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){\n' % os.path.abspath(_lib.HEADER)
+    want = []
+    for c in _lib._STRUCTS:
+        for f in c._fields_:
+            src += 'printf("%%zu\\n", offsetof(%s, %s));\n' % (names[c.__name__], f[0])
+            want.append((c.__name__, f[0], getattr(c, f[0]).offset))
+        src += 'printf("%%zu\\n", sizeof(%s));\n' % names[c.__name__]
+        want.append((c.__name__, 'sizeof', ctypes.sizeof(c)))
+    src += 'return 0;}\n'
+    (tmp_path / 't.c').write_text(src)
+    subprocess.check_call(['gcc', str(tmp_path / 't.c'), '-o', str(tmp_path / 't')])
+    got = [int(v) for v in subprocess.check_output([str(tmp_path / 't')]).decode().split()]
+    assert [w[2] for w in want] == got, [(w, g) for w, g in zip(want, got) if w[2] != g]
