@@ -202,7 +202,7 @@ int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const 
 /* ---------------------------------------------------------------------------------------------
  * a11 as ONE native call.  The plan names every persistent buffer of the encoder (caller-owned, sized by the caller,
  * see sherf_amd/voxel.py: SparseConvNet._plan); sherf_svox_encode enqueues the whole chain -- 1 memset, level-0 build,
- * per layer [mark_down + scan] + sparse conv with the BatchNorm finalize fused into the last workgroup, and the fold of
+ * per layer [mark_down + scan] + sparse conv + BatchNorm finalize, and the fold of
  * each tapped level -- on `stream` without reading anything back.  Replaces SparseConvNet.forward (renderer.py:778-871)
  * + the three .dense() volumes.  levels_out_host[3] receives the tapped levels for sherf_gather_tokens.
  */
@@ -225,7 +225,6 @@ typedef struct {
     float* bnparam;          /* [3][cout] */
     float* out;              /* [cap][cout] raw conv output */
     double* partials;        /* [ceil(cap/32)][2][cout] */
-    int32_t* done;           /* [1] ticket counter, zero on entry, left zero */
 } sherf_svox_layer;
 typedef struct {
     sherf_svox_level_ws lev[4];
@@ -277,7 +276,10 @@ typedef struct {
     const sherf_svox_plan* vox_plan; const int32_t* vox_coord; const float* vox_feat; int32_t vox_n, vox_training;
     /* MLP + compositing (a13-a16) */
     const void* wstream; const float* wbias; int32_t mlp_prec, mlp_shape; float* sample_out;
-    int32_t white_back, pad1_; float* rgb; float* depth; float* acc;
+    int32_t white_back;
+    int32_t main_after_layer;   /* scheduling: -1 = both streams start at once; k >= 0 = the ray side starts once encoder
+                                 * layer k is done (the encoder's small launches are slowed 3-5x by a co-running sampler) */
+    float* rgb; float* depth; float* acc;
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side);

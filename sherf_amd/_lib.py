@@ -33,7 +33,7 @@ class SvoxLevelWs(ctypes.Structure):                  # sherf_svox_level_ws
 
 class SvoxLayer(ctypes.Structure):                    # sherf_svox_layer
     _fields_ = [(n, _i32) for n in ('cin', 'cout', 'down', 'tap')] + \
-               [(n, _vp) for n in ('wt', 'gamma', 'beta', 'stats', 'bnparam', 'out', 'partials', 'done')]
+               [(n, _vp) for n in ('wt', 'gamma', 'beta', 'stats', 'bnparam', 'out', 'partials')]
 
 
 SVOX_MAX_LAYERS = 16
@@ -63,7 +63,7 @@ def _frame_fields():
     f.append(('vox_sh', _i32 * 3)); I('gather_split')
     P('tokens', 'extras', 'vox_plan', 'vox_coord', 'vox_feat'); I('vox_n', 'vox_training')
     P('wstream', 'wbias'); I('mlp_prec', 'mlp_shape')
-    P('sample_out'); I('white_back', 'pad1_')
+    P('sample_out'); I('white_back', 'main_after_layer')
     P('rgb', 'depth', 'acc')
     return f
 

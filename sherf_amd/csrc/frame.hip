@@ -9,6 +9,9 @@
 
 #include <mutex>
 
+int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
+                           sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer);   // svox.hip
+
 namespace {
 
 constexpr int kMaxDev = 16;
@@ -16,7 +19,7 @@ constexpr int kRing = 256;
 
 struct DevState {
     bool init = false;
-    hipEvent_t ev_start, ev_smpl, ev_enc;
+    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid;
 };
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
@@ -83,6 +86,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_start, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_smpl, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, hipEventDisableTiming));
                 d.init = true;
             }
         }
@@ -101,9 +105,15 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_smpl_c2s_table(f->weights, A1, A2, PO1, SO2, PO2, f->obs_R, f->obs_Th, f->cam_R, f->cam_T, f->cam_K, f->C2S,
                                        stream_side));
         SHERF_HIP_CHECK(hipEventRecord(d.ev_smpl, side));
+        // ---- side: a11 sparse voxel encoder ----
+        const int stagger = f->main_after_layer;
+        SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
+                                         stagger >= 0 ? d.ev_mid : nullptr, stagger));
+        SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
         // ---- main: cell lists, a4-a6 sampling / mask / nearest vertex / compaction, table re-layout ----
         SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
                                      f->cell_scratch, f->near_mask, stream_main));
+        if (stagger >= 0) SHERF_HIP_CHECK(hipStreamWaitEvent(main, stagger < f->vox_plan->n_layers ? d.ev_mid : d.ev_enc, 0));
         const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
         SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
@@ -111,9 +121,6 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, stream_main));
         SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, stream_main));
         SHERF_RUN(sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, stream_main));
-        // ---- side: a11 sparse voxel encoder ----
-        SHERF_RUN(sherf_svox_encode(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side));
-        SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
         SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,

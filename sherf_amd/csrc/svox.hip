@@ -168,25 +168,15 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 }
 __device__ __forceinline__ float rt(float a) { return (float)((__bf16)a); }
 
-// BatchNorm statistics of a conv's OUTPUT, finalised by the last workgroup to finish (ticket in `done`, reset by that
-// workgroup): removes the separate single-block launch per layer.  done == nullptr: no fused finalize.
-struct BnFuse {
-    const int32_t* n_total;     // number of rows of the reference's row set (level 0: N incl. duplicates)
-    const float* gamma;
-    const float* beta;
-    float* stats;               // [2][C]: batch mean/var (training: written) or running stats (eval: read)
-    float* bnparam;             // [3][C]: scale, shift, relu(shift)
-    int32_t* done;
-    int training;
-};
-
 template <int NCOT>   // Cout = 32 * NCOT
 __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, int Cin, const float* __restrict__ in_bn,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
-                                                     float* __restrict__ out_raw, double* partials, BnFuse bn) {
+                                                     float* __restrict__ out_raw, double* __restrict__ partials) {
     constexpr int COUT = 32 * NCOT;
+    if (mode & 256) __builtin_amdgcn_s_setprio(3);      // experiment (sherf_set_debug bit 7): issue priority over co-resident waves
+    mode &= 255;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
     float* s_bn = reinterpret_cast<float*>(smem + 27 * 32 * 4);                 // [3][Cin]
@@ -284,41 +274,6 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             for (int q = 0; q < G; ++q) t += (double)s_red[(which * G + q) * COUT + c2];
             partials[((size_t)blockIdx.x * 2 + which) * COUT + c2] = t;
         }
-    }
-    if (bn.done == nullptr) return;
-    __shared__ int s_last;
-    __threadfence();                                    // this workgroup's partials visible device-wide (all XCDs)
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(bn.done, 1) == ((n_rows + 31) >> 5) - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (tid == 0) *bn.done = 0;
-    double* sd = reinterpret_cast<double*>(s_red);
-    if (bn.training) {
-        constexpr int series = 2 * COUT, nparts = 256 / series;          // 4 / 2 / 1 slices of the block list
-        const int sidx = tid % series, part = tid / series;
-        const int nblk = (n_rows + 31) >> 5;
-        double t = 0.0;
-        if (part < nparts) {
-#pragma unroll 4
-            for (int b = part; b < nblk; b += nparts) t += partials[(size_t)b * series + sidx];   // fixed order: deterministic
-            sd[part * series + sidx] = t;
-        }
-        __syncthreads();
-        if (tid < COUT) {
-            double a1 = 0.0, a2 = 0.0;
-            for (int q = 0; q < nparts; ++q) { a1 += sd[q * series + tid]; a2 += sd[q * series + COUT + tid]; }
-            const double n = (double)(*bn.n_total);
-            const double mean = a1 / n, var = fmax(a2 / n - mean * mean, 0.0);
-            bn.stats[tid] = (float)mean; bn.stats[COUT + tid] = (float)var;
-        }
-    }
-    if (tid < COUT) {                                   // same thread wrote stats[tid] above
-        const float mean = bn.stats[tid], var = bn.stats[COUT + tid];
-        const float scale = bn.gamma[tid] / sqrtf(var + 1e-3f);
-        const float shift = bn.beta[tid] - mean * scale;
-        bn.bnparam[tid] = scale; bn.bnparam[COUT + tid] = shift; bn.bnparam[2 * COUT + tid] = fmaxf(shift, 0.f);
     }
 }
 
@@ -418,17 +373,17 @@ extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_r
 
 static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo, const uint32_t* wp_in, int Di,
                         int Hi, int Wi, const float* in_raw, int Cin, const float* in_bn, const int32_t* in_mult,
-                        const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, double* partials, BnFuse bn,
+                        const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, double* partials,
                         sherf_stream_t stream) {
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
-    SHERF_CHECK_ARG(bn.done == nullptr || (partials && bn.n_total && bn.gamma && bn.beta && bn.stats && bn.bnparam));
     const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
     const dim3 grid(cdiv(max_rows, 32)), block(256);
+    if (g_sherf_debug & 128) mode |= 256;
 #define SHERF_CONV3(N)                                                                                                       \
     hipLaunchKernelGGL(sconv3_kernel<N>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,                \
                        reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult,                          \
-                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials, bn)
+                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials)
     if (Cout == 32) SHERF_CONV3(1); else if (Cout == 64) SHERF_CONV3(2); else SHERF_CONV3(3);
     SHERF_LAUNCH_CHECK();
 }
@@ -438,7 +393,7 @@ extern "C" int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_o
                                 const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
                                 int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
     return launch_conv3(keys_out, n_rows_out, Do, Ho, Wo, wp_in, Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, w_packed, Cout, mode,
-                        max_rows, out_raw, partials, BnFuse{}, stream);
+                        max_rows, out_raw, partials, stream);
 }
 
 static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
@@ -450,10 +405,13 @@ static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
     SHERF_LAUNCH_CHECK();
 }
 
-// The whole encoder as one native call: 1 memset + 6 launches for level 0, 4 per down-sampling, 1 per conv (BatchNorm
-// finalize fused), 1 per tapped level for the fold.  Everything is enqueued on `stream`; nothing is read back.
-extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
-                                 sherf_vox_level* levels_out_host, sherf_stream_t stream) {
+// The whole encoder as one native call: 1 memset + 6 launches for level 0, 4 per down-sampling, 2 per conv (conv +
+// BatchNorm finalize), 1 per tapped level for the fold.  Everything is enqueued on `stream`; nothing is read back.
+// (A finalize fused into the conv's last workgroup was measured and rejected: the device-scope fence every workgroup
+// needs writes back / invalidates its XCD's L2, which slowed the conv 2x and every kernel running next to it.)
+// `ev` (optional) is recorded after layer `ev_layer`: lets the frame driver start other work mid-chain.
+int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
+                           sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer) {
     SHERF_CHECK_ARG(p && coord && feat && n > 0 && levels_out_host && p->n_layers > 0 && p->n_layers <= SHERF_SVOX_MAX_LAYERS);
     SHERF_CHECK_ARG(p->zero_ptr && p->zero_bytes > 0 && p->acc_fix && p->g0 && p->mult && p->n_total);
     for (int i = 0; i < 4; ++i) {
@@ -471,7 +429,7 @@ extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord,
     const float* cur_bn = nullptr;
     for (int li = 0; li < p->n_layers; ++li) {
         const sherf_svox_layer& ly = p->layers[li];
-        SHERF_CHECK_ARG(ly.wt && ly.gamma && ly.beta && ly.stats && ly.bnparam && ly.out && ly.partials && ly.done);
+        SHERF_CHECK_ARG(ly.wt && ly.gamma && ly.beta && ly.stats && ly.bnparam && ly.out && ly.partials);
         SHERF_CHECK_ARG(lev + (ly.down ? 1 : 0) < 4);
         const sherf_svox_level_ws& src = p->lev[lev];
         const sherf_svox_level_ws& dst = p->lev[lev + (ly.down ? 1 : 0)];
@@ -481,15 +439,17 @@ extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord,
             SHERF_RUN(scan_level(dst, stream));
         }
         const int dlev = lev + (ly.down ? 1 : 0);
-        BnFuse bn{dlev == 0 ? p->n_total : dst.n_rows, ly.gamma, ly.beta, ly.stats, ly.bnparam, ly.done, training};
         SHERF_RUN(launch_conv3(dst.keys, dst.n_rows, dst.D, dst.H, dst.W, src.wp, src.D, src.H, src.W, cur, ly.cin, cur_bn,
                                (lev == 0 && cur_bn) ? p->mult : nullptr, ly.wt, ly.cout, ly.down ? 1 : 0, dst.cap, ly.out,
-                               ly.partials, bn, stream));
+                               ly.partials, stream));
+        SHERF_RUN(sherf_svox_bn_finalize(ly.partials, dst.n_rows, dlev == 0 ? p->n_total : dst.n_rows, ly.cout, 32, ly.gamma,
+                                         ly.beta, ly.stats, training, ly.bnparam, stream));
+        if (ev && li == ev_layer) SHERF_HIP_CHECK(hipEventRecord(ev, as_stream(stream)));
         lev = dlev; cur = ly.out; cur_bn = ly.bnparam;
         if (ly.tap) {
             SHERF_CHECK_ARG(ntap < 3 && p->fold_mat[ntap] && p->fold_rows[ntap]);
             SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, ly.bnparam, nullptr,
-                                   p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, BnFuse{}, stream));
+                                   p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, stream));
             levels_out_host[ntap].wp = dst.wp;
             levels_out_host[ntap].rows = p->fold_rows[ntap];
             levels_out_host[ntap].D = dst.D; levels_out_host[ntap].H = dst.H; levels_out_host[ntap].W = dst.W;
@@ -498,4 +458,9 @@ extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord,
     }
     SHERF_CHECK_ARG(ntap == 3);
     return SHERF_OK;
+}
+
+extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
+                                 sherf_vox_level* levels_out_host, sherf_stream_t stream) {
+    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1);
 }

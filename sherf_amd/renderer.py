@@ -216,6 +216,7 @@ class ImportanceRenderer(nn.Module):
         self.mlp_precision = mlp_precision
         self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
+        self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self._smpl_src = smpl
         self._smpl_path = smpl_path
         # not parameters / buffers (the reference keeps the SMPL dict as a plain attribute too, renderer.py:284);
@@ -365,6 +366,7 @@ class ImportanceRenderer(nn.Module):
         fr.mlp_prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
         fr.mlp_shape = {'8x1': 0, '4x2': 1}[opts.get('mlp_shape', self.mlp_shape)]
         fr.white_back = 1 if opts.get('white_back', False) else 0
+        fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()
         s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
         noise = float(opts.get('density_noise', 0) or 0)

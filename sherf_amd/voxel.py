@@ -123,7 +123,6 @@ class SparseConvNet(nn.Module):
             c.D, c.H, c.W = sh
         ctot = sum(ly['cout'] for ly in pk['layers'])
         stats_flat = torch.zeros(2 * ctot, device=dev)                     # all layers' [2][C] stats, one buffer
-        done = torch.zeros(len(pk['layers']), dtype=torch.int32, device=dev)
         lev, off, meta, taps = 0, 0, [], []
         for li, ly in enumerate(pk['layers']):
             dlev = lev + 1 if ly['down'] else lev
@@ -135,7 +134,7 @@ class SparseConvNet(nn.Module):
             c = plan.layers[li]
             c.cin, c.cout, c.down, c.tap = ly['cin'], C, int(ly['down']), int(ly['tap'])
             c.wt, c.gamma, c.beta = A(ly['wt']), A(ly['gamma']), A(ly['beta'])
-            c.stats, c.bnparam, c.out, c.partials, c.done = A(stats), A(bnp), A(out), A(parts), A(done[li:li + 1])
+            c.stats, c.bnparam, c.out, c.partials = A(stats), A(bnp), A(out), A(parts)
             meta.append(dict(bn=ly['bn'], stats=stats, bnp=bnp, out=out, lev=dlev, cout=C))
             if ly['tap']:
                 taps.append((dlev, out, bnp, C))
@@ -150,7 +149,7 @@ class SparseConvNet(nn.Module):
             plan.fold_mat[i], plan.fold_rows[i] = A(fold_mats[i]), A(r)
             rows.append(r)
         ws.vox_plan = dict(key=key, plan=plan, L=L, shapes=shapes, meta=meta, taps=taps, rows=rows, stats_flat=stats_flat,
-                           keep=(done, zero_region, tuple(fold_mats), pk))
+                           keep=(zero_region, tuple(fold_mats), pk))
         return ws.vox_plan
 
     def prepare(self, sp, fold_mats, ws):
@@ -182,7 +181,7 @@ class SparseConvNet(nn.Module):
         """Runs the encoder on a SparseConvTensor (one native call, csrc/svox.hip: sherf_svox_encode); returns the three
         tapped levels as `_lib.VoxLevel`s whose rows are already multiplied by `fold_mats[l]` ([C_l, 96]) -- see
         ImportanceRenderer._weights.  Per layer: one tiled conv launch (BatchNorm+ReLU of the INPUT applied while
-        gathering, fp64 partial sums of the OUTPUT turned into scale/shift for the next layer by the last workgroup)."""
+        gathering, fp64 partial sums of the OUTPUT) + one tiny finalize launch (scale/shift for the next layer)."""
         import ctypes
         pl, feat, coord = self.prepare(sp, fold_mats, ws)
         levels = (_lib.VoxLevel * 3)()
