@@ -91,13 +91,14 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    _abi.call('sherf_profile_mlp', 1)          # HIP events around sherf_nerf_mlp on its launch stream (csrc/frame.hip)
+    _abi.call('sherf_profile_frames', 1)       # HIP events around sherf_nerf_mlp etc. on their launch streams (csrc/frame.hip)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    host_dt = time.perf_counter() - t0             # enqueue time of the K steps (the host runs ahead of the GPU)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -107,10 +108,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     nv = int(rend.last['ws']['counters'][0])
-    ms = (_ct.c_float * 256)(); n_ms = _ct.c_int32(0)
-    _abi.call('sherf_profile_mlp_read', ms, 256, _ct.byref(n_ms))
-    _abi.call('sherf_profile_mlp', 0)
-    mlp_ms = float(np.mean(ms[:n_ms.value])) if n_ms.value else None
+    ms = (_ct.c_float * (64 * 8))(); n_ms = _ct.c_int32(0)
+    _abi.call('sherf_profile_frames_read', ms, 64, _ct.byref(n_ms))
+    _abi.call('sherf_profile_frames', 0)
+    prof = np.array(ms[:n_ms.value * 8], dtype=np.float64).reshape(-1, 8)
+    mlp_ms = float(prof[:, 7].mean()) if len(prof) else None
     if rank == 0:
         res = dict(metric='rendered rays/sec at 512x512x64 samples (ImportanceRenderer.forward)', value=world * R * a.steps / dt,
                    unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps,
@@ -128,6 +130,10 @@ def main():
             res['roofline'] = dict(kernel='nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
                                    frac=ach / PEAK_BF16_TFLOPS, traffic=traffic, kernel_ms=mlp_ms,
                                    algorithmic_flop_per_launch=nv * FLOP_PER_VALID_SAMPLE)
+        if len(prof):
+            names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done')
+            res['frame_timeline_ms'] = {k: round(float(v), 4) for k, v in zip(names, prof[:, :7].mean(0))}
+            res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_dt / a.steps, 4)
         if not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.config)
         print(json.dumps(res))

@@ -285,11 +285,15 @@ int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* lev
                        sherf_stream_t stream_side);
 /* sizeof of {sherf_vox_level, sherf_svox_level_ws, sherf_svox_layer, sherf_svox_plan, sherf_frame} for binding checks */
 int sherf_struct_sizes(int32_t* sizes_host, int32_t n);
-/* HIP-event timing of the sherf_nerf_mlp launches issued by sherf_render_frame (roofline measurement on the launch
- * stream): enable != 0 starts recording into a ring of 256 event pairs; read synchronises on them and returns the
- * per-launch milliseconds recorded since enabling (oldest first), n_host = how many. */
-int sherf_profile_mlp(int enable);
-int sherf_profile_mlp_read(float* ms_host, int32_t max_n, int32_t* n_host);
+/* HIP-event timeline of the frames issued by sherf_render_frame (roofline measurement on the launch streams, without a
+ * profiler's launch overhead): enable != 0 starts recording into a ring of 64 frames; read synchronises and returns, per
+ * frame (oldest first), SHERF_PROF_FIELDS floats in milliseconds:
+ *   [0] host time of the enqueue call; then GPU times since the frame's first event: [1] SMPL tables done (side),
+ *   [2] encoder done (side), [3] ray side reaches the encoder join, [4] gather done, [5] MLP done, [6] compositing done;
+ *   [7] = [5] - [4] = duration of the sherf_nerf_mlp launch. */
+#define SHERF_PROF_FIELDS 8
+int sherf_profile_frames(int enable);
+int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t* n_host);
 
 int sherf_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* origins,
                       float* dirs, sherf_stream_t stream);

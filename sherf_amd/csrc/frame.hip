@@ -7,6 +7,7 @@
 // compositing (main).
 #include "common.h"
 
+#include <chrono>
 #include <mutex>
 
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
@@ -15,7 +16,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
 namespace {
 
 constexpr int kMaxDev = 16;
-constexpr int kRing = 256;
+constexpr int kRing = 64;
 
 struct DevState {
     bool init = false;
@@ -25,10 +26,13 @@ DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
 std::mutex g_frame_mu;    // one enqueue at a time: the join events are shared per device
 
+// frame profiling ring: kEv timing events per frame + the host time of the enqueue
+constexpr int kEv = 7;     // 0 start (main) 1 SMPL tables done (side) 2 encoder done (side) 3 main reaches the encoder join
+                           // 4 gather done 5 MLP done 6 compositing done
 bool g_prof_on = false;
 int g_prof_n = 0;
-int g_prof_dev = -1;
-hipEvent_t g_prof_ev[kRing][2];
+hipEvent_t g_prof_ev[kRing][kEv];
+float g_prof_host_ms[kRing];
 bool g_prof_init = false;
 
 }  // namespace
@@ -43,11 +47,11 @@ extern "C" int sherf_struct_sizes(int32_t* sizes_host, int32_t n) {
     return SHERF_OK;
 }
 
-extern "C" int sherf_profile_mlp(int enable) {
+extern "C" int sherf_profile_frames(int enable) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (enable && !g_prof_init) {
         for (int i = 0; i < kRing; ++i)
-            for (int j = 0; j < 2; ++j) SHERF_HIP_CHECK(hipEventCreate(&g_prof_ev[i][j]));
+            for (int j = 0; j < kEv; ++j) SHERF_HIP_CHECK(hipEventCreate(&g_prof_ev[i][j]));
         g_prof_init = true;
     }
     g_prof_on = enable != 0;
@@ -55,7 +59,7 @@ extern "C" int sherf_profile_mlp(int enable) {
     return SHERF_OK;
 }
 
-extern "C" int sherf_profile_mlp_read(float* ms_host, int32_t max_n, int32_t* n_host) {
+extern "C" int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t* n_host) {
     SHERF_CHECK_ARG(ms_host && n_host && max_n > 0);
     std::lock_guard<std::mutex> lk(g_mu);
     const int have = g_prof_n < kRing ? g_prof_n : kRing;
@@ -63,8 +67,11 @@ extern "C" int sherf_profile_mlp_read(float* ms_host, int32_t max_n, int32_t* n_
     const int first = g_prof_n - have;
     for (int i = 0; i < n; ++i) {
         const int slot = (first + i) % kRing;
-        SHERF_HIP_CHECK(hipEventSynchronize(g_prof_ev[slot][1]));
-        SHERF_HIP_CHECK(hipEventElapsedTime(&ms_host[i], g_prof_ev[slot][0], g_prof_ev[slot][1]));
+        float* o = ms_host + (size_t)i * SHERF_PROF_FIELDS;
+        SHERF_HIP_CHECK(hipEventSynchronize(g_prof_ev[slot][kEv - 1]));
+        o[0] = g_prof_host_ms[slot];
+        for (int j = 1; j < kEv; ++j) SHERF_HIP_CHECK(hipEventElapsedTime(&o[j], g_prof_ev[slot][0], g_prof_ev[slot][j]));
+        o[7] = o[5] - o[4];
     }
     *n_host = n;
     return SHERF_OK;
@@ -75,6 +82,9 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
     SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main);
     hipStream_t main = as_stream(stream_main), side = as_stream(stream_side);
     std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    const auto host_t0 = std::chrono::steady_clock::now();
+    static int cur_slot = -1;          // guarded by g_frame_mu; phase 2 of a split call reuses phase 1's slot
+#define SHERF_PROF(j, strm) do { if (cur_slot >= 0) SHERF_HIP_CHECK(hipEventRecord(g_prof_ev[cur_slot][j], strm)); } while (0)
     if (phase & 1) {
         int dev = 0;
         SHERF_HIP_CHECK(hipGetDevice(&dev));
@@ -92,7 +102,12 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         }
         SHERF_CHECK_ARG(f->R > 0 && f->S > 0 && f->capacity > 0 && f->vox_plan);
         const int V = SHERF_V;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            cur_slot = g_prof_on ? g_prof_n % kRing : -1;
+        }
         // inputs were produced on the caller's stream
+        SHERF_PROF(0, main);
         SHERF_HIP_CHECK(hipEventRecord(d.ev_start, main));
         SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_start, 0));
         // ---- side: a7-a9 per-frame SMPL tables ----
@@ -105,19 +120,27 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_smpl_c2s_table(f->weights, A1, A2, PO1, SO2, PO2, f->obs_R, f->obs_Th, f->cam_R, f->cam_T, f->cam_K, f->C2S,
                                        stream_side));
         SHERF_HIP_CHECK(hipEventRecord(d.ev_smpl, side));
-        // ---- side: a11 sparse voxel encoder ----
+        SHERF_PROF(1, side);
         const int stagger = f->main_after_layer;
-        SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
-                                         stagger >= 0 ? d.ev_mid : nullptr, stagger));
-        SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
+        const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
+        auto enqueue_encoder = [&]() -> int {        // ---- side: a11 sparse voxel encoder ----
+            SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
+                                             stagger >= 0 ? d.ev_mid : nullptr, stagger));
+            SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
+            SHERF_PROF(2, side);
+            return SHERF_OK;
+        };
+        // Launch order == start order (a launch costs the host ~5 us): staggered -> encoder first, the ray side waits for
+        // layer `stagger`; concurrent -> the ray side's big kernels first, the encoder's ~50 small ones behind them.
+        if (stagger >= 0) SHERF_RUN(enqueue_encoder());
         // ---- main: cell lists, a4-a6 sampling / mask / nearest vertex / compaction, table re-layout ----
         SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
                                      f->cell_scratch, f->near_mask, stream_main));
         if (stagger >= 0) SHERF_HIP_CHECK(hipStreamWaitEvent(main, stagger < f->vox_plan->n_layers ? d.ev_mid : d.ev_enc, 0));
-        const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
         SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
                                        f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, stream_main));
+        if (stagger < 0) SHERF_RUN(enqueue_encoder());
         SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, stream_main));
         SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, stream_main));
         SHERF_RUN(sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, stream_main));
@@ -130,34 +153,35 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1, f->capacity, f->tokens,
                                           f->extras, stream_main));
+            SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 2, f->capacity, f->tokens,
                                           f->extras, stream_main));
         } else {
+            SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0, f->capacity, f->tokens,
                                           f->extras, stream_main));
         }
-        int slot = -1;
-        if (g_prof_on) {
-            std::lock_guard<std::mutex> lk(g_mu);
-            slot = g_prof_n % kRing;
-            SHERF_HIP_CHECK(hipEventRecord(g_prof_ev[slot][0], main));
-        }
+        SHERF_PROF(4, main);
         SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, f->mlp_shape, f->capacity,
                                  f->sample_out, stream_main));
-        if (slot >= 0) {
-            std::lock_guard<std::mutex> lk(g_mu);
-            SHERF_HIP_CHECK(hipEventRecord(g_prof_ev[slot][1], main));
-            ++g_prof_n;
-        }
+        SHERF_PROF(5, main);
     }
     if (phase & 2) {
         // ---- a15-a16 ----
         SHERF_RUN(sherf_composite_compact(f->counters, f->ray_base, f->ray_cnt, f->cs_idx, f->sample_out, f->ray_d, f->near, f->far,
                                           f->R, f->S, f->white_back, f->rgb, f->depth, f->acc, stream_main));
+        SHERF_PROF(6, main);
+        if (cur_slot >= 0) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_prof_host_ms[cur_slot] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+            ++g_prof_n;
+            cur_slot = -1;
+        }
     }
+#undef SHERF_PROF
     return SHERF_OK;
 }

@@ -38,7 +38,11 @@ __global__ void __launch_bounds__(256) mark_down_kernel(const int32_t* __restric
                 int nx = x + 1 - kx;
                 if (nx < 0 || (nx & 1) || (nx >> 1) >= Wo) continue;
                 int ok = ((nz >> 1) * Ho + (ny >> 1)) * Wo + (nx >> 1);
-                atomicOr(&bitmap_out[ok >> 5], 1u << (ok & 31));
+                // an output voxel is hit by up to 27 rows and a word by hundreds: same-address atomics serialise, so look
+                // first (a stale 0 only costs a redundant, idempotent atomicOr)
+                const uint32_t bit = 1u << (ok & 31);
+                if (!(__hip_atomic_load(&bitmap_out[ok >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+                    atomicOr(&bitmap_out[ok >> 5], bit);
             }
         }
     }
@@ -289,9 +293,23 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restri
         const int sidx = tid % series, part = tid / series;
         const int nblk = (*n_rows_p + rows_per_block - 1) / rows_per_block;
         double t = 0.0;
-        if (part < nparts)
-            for (int b = part; b < nblk; b += nparts) t += partials[(size_t)b * series + sidx];    // fixed order: deterministic
-        s[tid] = t;      // same slicing as the fused finalize in sconv3_kernel -> bitwise identical statistics
+        if (part < nparts) {
+            // the partials were written by other XCDs: every load misses to memory (~1-2 us), so keep 8 in flight; the
+            // summation order is fixed (8 interleaved sub-series, combined in order) -> deterministic
+            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int b = part;
+            for (; b + 7 * nparts < nblk; b += 8 * nparts) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * nparts) * series + sidx];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += v[u];
+            }
+            double tail = 0.0;
+            for (; b < nblk; b += nparts) tail += partials[(size_t)b * series + sidx];
+            t = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + tail;
+        }
+        s[tid] = t;
         __syncthreads();
         if (tid < series) {
             double a = 0.0;
