@@ -43,6 +43,9 @@ def main():
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bn-mode', default='eval', choices=['eval', 'train'],
+                    help='BatchNorm of the voxel encoder: eval = running statistics, how the reference renders (G_ema.eval(), '
+                         'training_loop.py:196, metrics/metric_utils.py:256); train = batch statistics (training forward)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
@@ -65,7 +68,7 @@ def main():
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)
     dec = NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
-    rend.to(dev).train(); dec.to(dev).train()
+    rend.to(dev).train(a.bn_mode == 'train'); dec.to(dev).train(a.bn_mode == 'train')
     # voxelisation glue (triplane.py:129-137) through the product path
     gen = TriPlaneGenerator.__new__(TriPlaneGenerator)
     torch.nn.Module.__init__(gen); gen.renderer = rend
@@ -120,7 +123,8 @@ def main():
                    if a.precision == 'bf16x3' else 'bf16 MFMA, fp32 elsewhere', data='synthetic',
                    config=dict(workload=f'{a.config}: 512x512 rays x 64 samples, synthetic SMPL subject, novel view, all feature branches, '
                                         f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
-                               parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision))
+                               parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision,
+                               batchnorm=a.bn_mode))
         if mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
             traffic = None

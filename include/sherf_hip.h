@@ -244,7 +244,7 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
 
 /* ---------------------------------------------------------------------------------------------
  * The whole of ImportanceRenderer.forward (renderer.py:286-398) as ONE native call: every pointer the frame touches is
- * named in sherf_frame; sherf_render_frame enqueues ~75 kernels on two HIP streams (SMPL tables + voxel encoder on
+ * named in sherf_frame; sherf_render_frame enqueues ~60-75 kernels on two (three) HIP streams (SMPL tables + voxel encoder on
  * `stream_side`, rays on `stream_main`), joined with events owned by the library (created once per device; the only
  * persistent state the library keeps).  Host cost is a few microseconds per launch instead of one interpreter round
  * trip each.  phase: bit0 = everything up to and including the NeRF MLP, bit1 = compositing (the caller may add
@@ -282,7 +282,9 @@ typedef struct {
     float* rgb; float* depth; float* acc;
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
-                       sherf_stream_t stream_side);
+                       sherf_stream_t stream_side, sherf_stream_t stream_aux);
+/* stream_aux (may be NULL): a third stream on which the occupancy structure of voxel levels 1-3 is built while the
+ * level-0 convolutions run on stream_side. */
 /* sizeof of {sherf_vox_level, sherf_svox_level_ws, sherf_svox_layer, sherf_svox_plan, sherf_frame} for binding checks */
 int sherf_struct_sizes(int32_t* sizes_host, int32_t n);
 /* HIP-event timeline of the frames issued by sherf_render_frame (roofline measurement on the launch streams, without a

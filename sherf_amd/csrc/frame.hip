@@ -11,7 +11,8 @@
 #include <mutex>
 
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
-                           sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer);   // svox.hip
+                           sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
+                           sherf_stream_t aux, hipEvent_t* lev_ev);   // svox.hip
 
 namespace {
 
@@ -20,7 +21,7 @@ constexpr int kRing = 64;
 
 struct DevState {
     bool init = false;
-    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid;
+    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_lev[4];
 };
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
@@ -78,8 +79,8 @@ extern "C" int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t*
 }
 
 extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
-                                  sherf_stream_t stream_side) {
-    SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main);
+                                  sherf_stream_t stream_side, sherf_stream_t stream_aux) {
+    SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main && stream_aux != stream_main);
     hipStream_t main = as_stream(stream_main), side = as_stream(stream_side);
     std::lock_guard<std::mutex> frame_lock(g_frame_mu);
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -97,6 +98,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_smpl, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, hipEventDisableTiming));
+                for (int k = 0; k < 4; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
                 d.init = true;
             }
         }
@@ -125,7 +127,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
         auto enqueue_encoder = [&]() -> int {        // ---- side: a11 sparse voxel encoder ----
             SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
-                                             stagger >= 0 ? d.ev_mid : nullptr, stagger));
+                                             stagger >= 0 ? d.ev_mid : nullptr, stagger, stream_aux, d.ev_lev));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
             SHERF_PROF(2, side);
             return SHERF_OK;

@@ -383,7 +383,7 @@ extern "C" int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, 
 extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
                                       int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
                                       float* bnparam, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(partials && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
+    SHERF_CHECK_ARG((partials || !training) && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
                        rows_per_block, gamma, beta, stats, training, bnparam);
     SHERF_LAUNCH_CHECK();
@@ -428,10 +428,14 @@ static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
 // (A finalize fused into the conv's last workgroup was measured and rejected: the device-scope fence every workgroup
 // needs writes back / invalidates its XCD's L2, which slowed the conv 2x and every kernel running next to it.)
 // `ev` (optional) is recorded after layer `ev_layer`: lets the frame driver start other work mid-chain.
+// `aux` + `lev_ev[4]` (optional): the occupancy structure of levels 1-3 depends only on the voxel coordinates, not on any
+// feature, so it is built on a second stream while the level-0 convolutions run (12 launches off the dependent chain).
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
-                           sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer) {
+                           sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
+                           sherf_stream_t aux, hipEvent_t* lev_ev) {
     SHERF_CHECK_ARG(p && coord && feat && n > 0 && levels_out_host && p->n_layers > 0 && p->n_layers <= SHERF_SVOX_MAX_LAYERS);
     SHERF_CHECK_ARG(p->zero_ptr && p->zero_bytes > 0 && p->acc_fix && p->g0 && p->mult && p->n_total);
+    SHERF_CHECK_ARG(aux == nullptr || (lev_ev != nullptr && aux != stream));
     for (int i = 0; i < 4; ++i) {
         const sherf_svox_level_ws& l = p->lev[i];
         SHERF_CHECK_ARG(l.bitmap && l.prefix && l.n_rows && l.chunk_ws && l.wp && l.keys && l.n_words > 0 && l.cap > 0 && l.D > 0 && l.H > 0 && l.W > 0);
@@ -440,6 +444,20 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
     const sherf_svox_level_ws& l0 = p->lev[0];
     hipLaunchKernelGGL(mark_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coord, n, l0.D, l0.H, l0.W, l0.bitmap);
     SHERF_RUN(scan_level(l0, stream));
+    auto build_level = [&](int k, sherf_stream_t st) -> int {       // level k from level k-1 (SparseConv3d k3 s2 p1 output sites)
+        const sherf_svox_level_ws& src = p->lev[k - 1];
+        hipLaunchKernelGGL(mark_down_kernel, dim3(cdiv(src.cap, 256)), dim3(256), 0, as_stream(st), src.keys, src.n_rows, src.D,
+                           src.H, src.W, p->lev[k].bitmap);
+        return scan_level(p->lev[k], st);
+    };
+    if (aux) {
+        SHERF_HIP_CHECK(hipEventRecord(lev_ev[0], as_stream(stream)));
+        SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(aux), lev_ev[0], 0));
+        for (int k = 1; k < 4; ++k) {
+            SHERF_RUN(build_level(k, aux));
+            SHERF_HIP_CHECK(hipEventRecord(lev_ev[k], as_stream(aux)));
+        }
+    }
     SHERF_RUN(sherf_svox_scatter_rows(coord, feat, n, 32, l0.D, l0.H, l0.W, l0.bitmap, l0.prefix, l0.n_rows, p->acc_fix, p->g0,
                                       p->mult, stream));
     int lev = 0, ntap = 0;
@@ -449,19 +467,21 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         const sherf_svox_layer& ly = p->layers[li];
         SHERF_CHECK_ARG(ly.wt && ly.gamma && ly.beta && ly.stats && ly.bnparam && ly.out && ly.partials);
         SHERF_CHECK_ARG(lev + (ly.down ? 1 : 0) < 4);
-        const sherf_svox_level_ws& src = p->lev[lev];
-        const sherf_svox_level_ws& dst = p->lev[lev + (ly.down ? 1 : 0)];
-        if (ly.down) {
-            hipLaunchKernelGGL(mark_down_kernel, dim3(cdiv(src.cap, 256)), dim3(256), 0, as_stream(stream), src.keys, src.n_rows,
-                               src.D, src.H, src.W, dst.bitmap);
-            SHERF_RUN(scan_level(dst, stream));
-        }
         const int dlev = lev + (ly.down ? 1 : 0);
+        const sherf_svox_level_ws& src = p->lev[lev];
+        const sherf_svox_level_ws& dst = p->lev[dlev];
+        if (ly.down) {
+            if (aux) SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), lev_ev[dlev], 0));
+            else SHERF_RUN(build_level(dlev, stream));
+        }
+        // training: batch statistics -> per-block fp64 partials + a finalize launch.  eval: bnparam comes from the running
+        // statistics and was prepared by the caller (sherf_svox_bn_finalize with training = 0) when they last changed.
         SHERF_RUN(launch_conv3(dst.keys, dst.n_rows, dst.D, dst.H, dst.W, src.wp, src.D, src.H, src.W, cur, ly.cin, cur_bn,
                                (lev == 0 && cur_bn) ? p->mult : nullptr, ly.wt, ly.cout, ly.down ? 1 : 0, dst.cap, ly.out,
-                               ly.partials, stream));
-        SHERF_RUN(sherf_svox_bn_finalize(ly.partials, dst.n_rows, dlev == 0 ? p->n_total : dst.n_rows, ly.cout, 32, ly.gamma,
-                                         ly.beta, ly.stats, training, ly.bnparam, stream));
+                               training ? ly.partials : nullptr, stream));
+        if (training)
+            SHERF_RUN(sherf_svox_bn_finalize(ly.partials, dst.n_rows, dlev == 0 ? p->n_total : dst.n_rows, ly.cout, 32, ly.gamma,
+                                             ly.beta, ly.stats, 1, ly.bnparam, stream));
         if (ev && li == ev_layer) SHERF_HIP_CHECK(hipEventRecord(ev, as_stream(stream)));
         lev = dlev; cur = ly.out; cur_bn = ly.bnparam;
         if (ly.tap) {
@@ -480,5 +500,5 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
 
 extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                                  sherf_vox_level* levels_out_host, sherf_stream_t stream) {
-    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1);
+    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1, nullptr, nullptr);
 }

@@ -217,6 +217,7 @@ class ImportanceRenderer(nn.Module):
         self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
+        self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
         self._smpl_src = smpl
         self._smpl_path = smpl_path
         # not parameters / buffers (the reference keeps the SMPL dict as a plain attribute too, renderer.py:284);
@@ -225,11 +226,11 @@ class ImportanceRenderer(nn.Module):
         self._ws = _Workspace()
         self._wcache = None
         self.last = None
-        self._side_stream = None
+        self._side_streams = None
 
     def __getstate__(self):
         s = self.__dict__.copy()
-        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_side_stream'):
+        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_side_streams'):
             s[k] = None
         s['_ws'] = None
         return s
@@ -238,10 +239,12 @@ class ImportanceRenderer(nn.Module):
         self.__dict__.update(s)
         self._ws = _Workspace()
 
-    def _side(self, dev):
-        if getattr(self, '_side_stream', None) is None or self._side_stream.device != dev:
-            self._side_stream = torch.cuda.Stream(device=dev, priority=-1)   # the short serial chain gets dispatch priority
-        return self._side_stream
+    def _side(self, dev, idx=0):
+        cur = getattr(self, '_side_streams', None)
+        if cur is None or cur[0].device != dev:
+            # the short serial chains get dispatch priority over the ray side's big kernels
+            self._side_streams = cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+        return cur[idx]
 
     # ---- SMPL --------------------------------------------------------------------------------
     @property
@@ -369,13 +372,14 @@ class ImportanceRenderer(nn.Module):
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()
         s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
+        s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if self.aux_stream else None
         noise = float(opts.get('density_noise', 0) or 0)
         if noise > 0:                                                    # renderer.py:435-436 (training only)
-            _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side)
+            _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
             ws['sample_out'][:, 3] += torch.randn(cap, device=dev) * noise
-            _lib.call('sherf_render_frame', _ct.byref(fr), 2, levels, s_main, s_side)
+            _lib.call('sherf_render_frame', _ct.byref(fr), 2, levels, s_main, s_side, s_aux)
         else:
-            _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side)
+            _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side, s_aux)
         self.encoder_3d.finish(pl)
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)

@@ -159,8 +159,19 @@ class SparseConvNet(nn.Module):
         coord = sp.indices.to(torch.int32).contiguous()
         pl = self.plan(sp.spatial_shape, feat.shape[0], fold_mats, ws, feat.device)
         if not self.training:
-            with torch.no_grad():
-                pl['stats_flat'].copy_(torch.cat([t.reshape(-1) for m in pl['meta'] for t in (m['bn'].running_mean, m['bn'].running_var)]).float())
+            # eval (the reference's inference path: G_ema.eval(), training_loop.py:196): BatchNorm uses the running
+            # statistics, so scale/shift are per-weights constants -- recomputed only when a buffer changes.
+            key = tuple((t.data_ptr(), t._version) for m in pl['meta'] for t in (m['bn'].running_mean, m['bn'].running_var,
+                                                                                  m['bn'].weight, m['bn'].bias))
+            if pl.get('eval_key') != key:
+                P = _lib.ptr
+                with torch.no_grad():
+                    pl['stats_flat'].copy_(torch.cat([t.reshape(-1) for m in pl['meta']
+                                                      for t in (m['bn'].running_mean, m['bn'].running_var)]).float())
+                for m, ly in zip(pl['meta'], self._pack(feat.device)['layers']):
+                    _lib.call('sherf_svox_bn_finalize', None, P(pl['L'][0]['n_total']), P(pl['L'][0]['n_total']), m['cout'], 32,
+                              P(ly['gamma']), P(ly['beta']), P(m['stats']), 0, P(m['bnp']), _lib.stream())
+                pl['eval_key'] = key
         return pl, feat, coord
 
     def finish(self, pl):
