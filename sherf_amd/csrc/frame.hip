@@ -21,7 +21,7 @@ constexpr int kRing = 64;
 
 struct DevState {
     bool init = false;
-    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_lev[4];
+    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[4];
 };
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
@@ -80,7 +80,7 @@ extern "C" int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t*
 
 extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
                                   sherf_stream_t stream_side, sherf_stream_t stream_aux) {
-    SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main && stream_aux != stream_main);
+    SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main && (!stream_aux || (stream_aux != stream_main && stream_aux != stream_side)));
     hipStream_t main = as_stream(stream_main), side = as_stream(stream_side);
     std::lock_guard<std::mutex> frame_lock(g_frame_mu);
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -98,6 +98,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_smpl, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_fold, hipEventDisableTiming));
                 for (int k = 0; k < 4; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
                 d.init = true;
             }
@@ -124,6 +125,16 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_HIP_CHECK(hipEventRecord(d.ev_smpl, side));
         SHERF_PROF(1, side);
         const int stagger = f->main_after_layer;
+        auto fold_tables = [&](sherf_stream_t st) -> int {      // per-frame table re-layout (channel-last, projections folded in)
+            SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, st));
+            SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, st));
+            return sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, st);
+        };
+        if (stream_aux) {       // independent of rays and voxels: off the ray side's chain, ahead of the level builds
+            SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream_aux), d.ev_start, 0));
+            SHERF_RUN(fold_tables(stream_aux));
+            SHERF_HIP_CHECK(hipEventRecord(d.ev_fold, as_stream(stream_aux)));
+        }
         const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
         auto enqueue_encoder = [&]() -> int {        // ---- side: a11 sparse voxel encoder ----
             SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
@@ -143,11 +154,10 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
                                        f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, stream_main));
         if (stagger < 0) SHERF_RUN(enqueue_encoder());
-        SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, stream_main));
-        SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, stream_main));
-        SHERF_RUN(sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, stream_main));
+        if (!stream_aux) SHERF_RUN(fold_tables(stream_main));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
         SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
+        if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
                                   f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, f->capacity, f->geom,
                                   f->cs_tvid, stream_main));

@@ -172,13 +172,13 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 }
 __device__ __forceinline__ float rt(float a) { return (float)((__bf16)a); }
 
-template <int NCOT>   // Cout = 32 * NCOT
+template <int NCOT, int NKB>   // Cout = 32 * NCOT, Cin = 16 * NKB
 __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
-                                                     const float* __restrict__ in_raw, int Cin, const float* __restrict__ in_bn,
+                                                     const float* __restrict__ in_raw, const float* __restrict__ in_bn,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
                                                      float* __restrict__ out_raw, double* __restrict__ partials) {
-    constexpr int COUT = 32 * NCOT;
+    constexpr int COUT = 32 * NCOT, Cin = 16 * NKB;
     if (mode & 256) __builtin_amdgcn_s_setprio(3);      // experiment (sherf_set_debug bit 7): issue priority over co-resident waves
     mode &= 255;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,7 +190,6 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     if (row0 >= n_rows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntaps = mode == 2 ? 1 : 27;
-    const int NKB = Cin / 16;
     for (int i = tid; i < ntaps * 32; i += 256) {
         const int tap = i >> 5, r = i & 31, row = row0 + r;
         int nb = -1;
@@ -219,39 +218,83 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
 #pragma unroll
     for (int c = 0; c < NCOT; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
     const int r = lane & 31, h = lane >> 5;
-    for (int tap = wave; tap < ntaps; tap += 4) {
+    // taps of this wave (tap = wave, wave+4, ...) that have at least one neighbour in the tile
+    uint32_t tapmask = 0;
+    for (int tap = wave; tap < ntaps; tap += 4)
+        if (__ballot(s_nb[tap * 32 + r] >= 0) != 0ull) tapmask |= 1u << tap;
+    tapmask = __builtin_amdgcn_readfirstlane(tapmask);
+
+    // The tile is a chain of dependent gathers (neighbour row -> MFMA); with ~2 waves per SIMD nothing hides their latency
+    // unless the loads are issued ahead: a whole neighbour row (all k-blocks) is fetched one tap ahead, the weight
+    // fragments one k-block ahead.  Lanes without that neighbour read row 0 and are zeroed after the BatchNorm transform
+    // (no divergent control flow in the pipeline).
+    struct Row { float4 v[2 * NKB]; int nb; float mlt; };
+    auto load_row = [&](int tap, Row& R) {
         const int nb = s_nb[tap * 32 + r];
-        if (__ballot(nb >= 0) == 0ull) continue;                               // nobody in this tile has that neighbour
-        const float mlt = (in_mult && nb >= 0) ? (float)(in_mult[nb] - 1) : 0.f;
+        R.nb = nb;
+        R.mlt = (in_mult && nb >= 0) ? (float)(in_mult[nb] - 1) : 0.f;
         const float4* src = reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h;
-        for (int kb = 0; kb < NKB; ++kb) {
-            float v[8];
-            if (nb >= 0) {
-                const float4 a = src[4 * kb], b = src[4 * kb + 1];
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-                if (in_bn) {
-                    const float* sc = s_bn + kb * 16 + 8 * h;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sc[Cin + e], 0.f) + mlt * sc[2 * Cin + e];
-                }
-            } else {
+        for (int kb = 0; kb < NKB; ++kb) { R.v[2 * kb] = src[4 * kb]; R.v[2 * kb + 1] = src[4 * kb + 1]; }
+    };
+    auto load_w = [&](int tap, int kb, uint4 (&w)[2 * NCOT]) {
+        const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 2 * NCOT; ++c) w[c] = wsrc[c * 64];
+    };
+    auto compute = [&](int tap, const Row& R) {
+        uint4 w[2 * NCOT];
+        load_w(tap, 0, w);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            uint4 wn[2 * NCOT];
+            if (kb + 1 < NKB) load_w(tap, kb + 1, wn);
+            const float4 a = R.v[2 * kb], b = R.v[2 * kb + 1];
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            if (in_bn) {
+                const float* sc = s_bn + kb * 16 + 8 * h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sc[Cin + e], 0.f) + R.mlt * sc[2 * Cin + e];
+            }
+            if (R.nb < 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
             const uint4 ahi = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
             const uint4 alo = make_uint4(pk2(v[0] - rt(v[0]), v[1] - rt(v[1])), pk2(v[2] - rt(v[2]), v[3] - rt(v[3])),
                                          pk2(v[4] - rt(v[4]), v[5] - rt(v[5])), pk2(v[6] - rt(v[6]), v[7] - rt(v[7])));
-            const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
 #pragma unroll
             for (int c = 0; c < NCOT; ++c) {
-                const uint4 bhi = wsrc[(c * 2 + 0) * 64], blo = wsrc[(c * 2 + 1) * 64];
+                const uint4 bhi = w[2 * c], blo = w[2 * c + 1];
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, alo), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, blo), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
             }
+            if (kb + 1 < NKB) {
+#pragma unroll
+                for (int c = 0; c < 2 * NCOT; ++c) w[c] = wn[c];
+            }
         }
+    };
+    auto next_tap = [&](int tap) -> int {           // next set bit above `tap`, -1 if none (uniform)
+        const uint32_t rest = tap >= 31 ? 0u : (tapmask & ~((2u << tap) - 1u));
+        return rest ? __ffs(rest) - 1 : -1;
+    };
+    int tap = tapmask ? __ffs(tapmask) - 1 : -1;
+    Row ra, rb;
+    if (tap >= 0) load_row(tap, ra);
+    while (tap >= 0) {                              // ping-pong between the two row buffers
+        int nt = next_tap(tap);
+        if (nt >= 0) load_row(nt, rb);
+        compute(tap, ra);
+        tap = nt;
+        if (tap < 0) break;
+        nt = next_tap(tap);
+        if (nt >= 0) load_row(nt, ra);
+        compute(tap, rb);
+        tap = nt;
     }
     // D layout: lane = (col j = lane&31, half h), reg q <-> tile row (q&3) + 8*(q>>2) + 4*h
 #pragma unroll
@@ -398,11 +441,22 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
     const dim3 grid(cdiv(max_rows, 32)), block(256);
     if (g_sherf_debug & 128) mode |= 256;
-#define SHERF_CONV3(N)                                                                                                       \
-    hipLaunchKernelGGL(sconv3_kernel<N>, grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,                \
-                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult,                          \
+#define SHERF_CONV3(N, K)                                                                                                    \
+    hipLaunchKernelGGL((sconv3_kernel<N, K>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,           \
+                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, in_bn, in_mult,                               \
                        reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials)
-    if (Cout == 32) SHERF_CONV3(1); else if (Cout == 64) SHERF_CONV3(2); else SHERF_CONV3(3);
+    const int sel = (Cout / 32) * 10 + Cin / 16;
+    switch (sel) {
+        case 12: SHERF_CONV3(1, 2); break;     // 32 -> 32
+        case 22: SHERF_CONV3(2, 2); break;     // 32 -> 64
+        case 24: SHERF_CONV3(2, 4); break;     // 64 -> 64
+        case 34: SHERF_CONV3(3, 4); break;     // 64 -> 96
+        case 36: SHERF_CONV3(3, 6); break;     // 96 -> 96
+        case 32: SHERF_CONV3(3, 2); break;     // 32 -> 96 (fold)
+        default:
+            snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_svox_conv3: unsupported channel pair %d -> %d", Cin, Cout);
+            return SHERF_EINVAL;
+    }
     SHERF_LAUNCH_CHECK();
 }
 

@@ -10,12 +10,9 @@ run() { # label, bn mode, env...
   env "$@" timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --bn-mode $bn 2>&1 | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['frame_timeline_ms']; print('%-18s' % '$label', 'ms/step %.3f' % d['ms_per_step'], 'mlp %.3f' % d['roofline']['kernel_ms'], ' '.join('%s=%.3f' % (k[:12], v) for k, v in t.items()))"
 }
 run eval_conc eval X=1
-run eval_conc_noaux eval SHERF_AUX_STREAM=0
-run eval_conc_split eval SHERF_GATHER_SPLIT=1
 run eval_conc_prio eval SHERF_DEBUG=128
-run eval_after1 eval SHERF_MAIN_AFTER_LAYER=1
+run eval_noaux eval SHERF_AUX_STREAM=0
 run eval_serial eval SHERF_MAIN_AFTER_LAYER=13
 run train_conc train X=1
-run train_conc_noaux train SHERF_AUX_STREAM=0
 timeout 900 python -m pytest tests -m gpu -q --timeout=600 -x --no-header -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
 tail -5 $OUT/pytest.log
