@@ -30,6 +30,8 @@ __device__ __forceinline__ void rot_only(float x, float y, float z, const float*
 // ---------------------------------------------------------------------------------------------
 // cell list: one block of 1024 threads (n <= 6890 points)
 // ---------------------------------------------------------------------------------------------
+constexpr int kLdsCells = 24576;      // cell counters that fit the LDS fast path of build_cells_body (96 KiB)
+
 __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts, int n,
                                                            const float* __restrict__ R, const float* __restrict__ Th,
                                                            float cell_size, float* __restrict__ hdr,
@@ -77,6 +79,50 @@ __device__ __forceinline__ void build_cells_body(const float* __restrict__ verts
     const float ox = s_hdr[0], oy = s_hdr[1], oz = s_hdr[2], inv = s_hdr[4];
     const int nx = __float_as_int(s_hdr[5]), ny = __float_as_int(s_hdr[6]), nz = __float_as_int(s_hdr[7]);
     const int ncell = nx * ny * nz;
+    if (ncell + 1 <= kLdsCells && n <= 8 * 1024) {
+        // Usual case (a body is ~10-16 K cells of 5 cm): counts, ranks and the scan stay in LDS and the points in registers
+        // -- the global-memory version below is a chain of ~10 dependent round trips on a single workgroup.
+        __shared__ int s_cnt[kLdsCells];
+        for (int i = tid; i <= ncell; i += 1024) s_cnt[i] = 0;
+        __syncthreads();
+        constexpr int kPer = 8;                                  // points per thread (n <= 8192)
+        float px[kPer], py[kPer], pz[kPer];
+        int pc[kPer], pr[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = tid + k * 1024;
+            pc[k] = -1;
+            if (i < n) {
+                px[k] = pos[i * 3]; py[k] = pos[i * 3 + 1]; pz[k] = pos[i * 3 + 2];       // written by this same thread above
+                const int cx = min(nx - 1, max(0, (int)floorf((px[k] - ox) * inv)));
+                const int cy = min(ny - 1, max(0, (int)floorf((py[k] - oy) * inv)));
+                const int cz = min(nz - 1, max(0, (int)floorf((pz[k] - oz) * inv)));
+                pc[k] = (cz * ny + cy) * nx + cx;
+                pr[k] = atomicAdd(&s_cnt[pc[k]], 1);
+            }
+        }
+        __syncthreads();
+        const int seg = (ncell + 1 + 1023) / 1024;
+        const int s0 = tid * seg, s1 = min(ncell + 1, s0 + seg);
+        int sum = 0;
+        for (int i = s0; i < s1; ++i) sum += s_cnt[i];
+        s_part[tid] = sum;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int v = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        int run = s_part[tid] - sum;
+        for (int i = s0; i < s1; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; run += c; }
+        __syncthreads();
+        for (int i = tid; i <= ncell; i += 1024) cell_start[i] = s_cnt[i];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k)
+            if (pc[k] >= 0) cell_pts[s_cnt[pc[k]] + pr[k]] = make_float4(px[k], py[k], pz[k], __int_as_float(tid + k * 1024));
+        return;
+    }
     for (int i = tid; i <= ncell; i += 1024) cell_start[i] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
