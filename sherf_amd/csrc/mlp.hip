@@ -107,14 +107,13 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
 template <int NTL> __host__ __device__ constexpr int n_steps() { return 9 * NTL + (N_CHUNKS - 9); }
 template <int NTL> __host__ __device__ constexpr int step_chunk(int s) { return s < 9 * NTL ? s % 9 : s - 9 * (NTL - 1); }
 
-template <int PREC, int NW, int NTL, int NS> struct Ctx {
+template <int PREC, int NW, int NTL> struct Ctx {
     const char* ws;          // packed weight stream (global)
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // NSLOT ring slots
-    int lane, h, dbg, wave;
-    int pend[NS - 2];        // pieces this wave issued for the NS-2 newest steps in flight (oldest first)
+    int lane, h, dbg, wave, pending;
     static constexpr int SLOT = MAX_NKB * 1024 * (PREC + 1);
-    static constexpr int NSLOT = NS;
+    static constexpr int NSLOT = 3;
     __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
 };
 
@@ -123,13 +122,13 @@ template <int PREC, int NW, int NTL, int NS> struct Ctx {
 // recently issued step are still in flight, then the workgroup barrier makes every wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int PREC, int NW, int NTL, int NS>
-__device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL, NS>& cx, int step) {
+template <int PREC, int NW, int NTL>
+__device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL>& cx, int step) {
     if (step >= n_steps<NTL>() || (cx.dbg & 32)) return 0;
     const int c = step_chunk<NTL>(step);
     const int pieces = chunk_nkb(c) * (PREC + 1);
     const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024 + cx.lane * 16;
-    char* dst = cx.lds + (step % NS) * Ctx<PREC, NW, NTL, NS>::SLOT;
+    char* dst = cx.lds + (step % Ctx<PREC, NW, NTL>::NSLOT) * Ctx<PREC, NW, NTL>::SLOT;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < (MAX_NKB * (PREC + 1) + NW - 1) / NW; ++i) {
@@ -157,32 +156,17 @@ __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     }
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// end of step s: step s+1 must have landed (everything but the NS-2 newest issues), then step s's slot is recycled for
-// step s+NS.  The LDS-DMAs of a wave complete in issue order, so a counted vmcnt is exact.
-template <int PREC, int NW, int NTL, int NS>
-__device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, NS>& cx, int step) {
-    int outstanding = 0;
-#pragma unroll
-    for (int i = 0; i < NS - 2; ++i) outstanding += cx.pend[i];
-    wait_vm(outstanding);
+// end of step s: step s+1 must have landed (everything but the newest issue), then step s's slot is recycled for s+3
+template <int PREC, int NW, int NTL>
+__device__ __forceinline__ void advance(Ctx<PREC, NW, NTL>& cx, int step) {
+    wait_vm(cx.pending);
     if (!(cx.dbg & 64)) wg_barrier();
-#pragma unroll
-    for (int i = 0; i + 1 < NS - 2; ++i) cx.pend[i] = cx.pend[i + 1];
-    cx.pend[NS - 3] = dma_issue(cx, step + NS);
+    cx.pending = dma_issue(cx, step + 3);
 }
 
 template <class C>
@@ -264,11 +248,11 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 }
 
 
-template <int PREC, int NW, int NTL, int NS>
+template <int PREC, int NW, int NTL>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
-    using CX = Ctx<PREC, NW, NTL, NS>;
+    using CX = Ctx<PREC, NW, NTL>;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
@@ -290,16 +274,11 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         if (!live[u]) tile[u] = n_tiles - 1;                         // dead tiles still take part in every barrier
     }
 
-    // prologue: steps 0 .. NS-2 in flight, wait for step 0, then fill the last slot
     dma_issue(cx, 0);
-    {
-        int later = 0;
-#pragma unroll
-        for (int s = 1; s <= NS - 2; ++s) { const int n = dma_issue(cx, s); later += n; if (s >= 2) cx.pend[s - 2] = n; }
-        wait_vm(later);                       // step 0 (this wave's pieces) landed
-    }
+    const int n1 = dma_issue(cx, 1);
+    wait_vm(n1);                              // step 0 (this wave's pieces) landed
     __syncthreads();
-    cx.pend[NS - 3] = dma_issue(cx, NS - 1);
+    cx.pending = dma_issue(cx, 2);
 
     BFrag<PREC> z0b[NTL][2], z1b[NTL][2];                            // fused tokens z_0, z_1 as K-blocks, per tile
     float xc[NTL][3], vc[NTL][3];
@@ -561,18 +540,14 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 3 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && (shape == 0 || shape == 1) && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
-#define SHERF_MLP(P, W, L, S)                                                                                                \
-    hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L, S>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
+#define SHERF_MLP(P, W, L)                                                                                                 \
+    hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
-    // shape 0: 8 waves x 1 tile, 3 ring slots; 1: 4 x 2; 2 / 3: 8 x 1 with a 4- / 5-slot ring (deeper weight prefetch)
-    if (prec == 0) { if (wide) SHERF_MLP(0, 4, 2, 3); else SHERF_MLP(0, 8, 1, 3); }
-    else if (wide) SHERF_MLP(1, 4, 2, 3);
-    else if (shape == 2) SHERF_MLP(1, 8, 1, 4);
-    else if (shape == 3) SHERF_MLP(1, 8, 1, 5);
-    else SHERF_MLP(1, 8, 1, 3);
+    if (prec == 0) { if (wide) SHERF_MLP(0, 4, 2); else SHERF_MLP(0, 8, 1); }
+    else { if (wide) SHERF_MLP(1, 4, 2); else SHERF_MLP(1, 8, 1); }
     SHERF_LAUNCH_CHECK();
 }

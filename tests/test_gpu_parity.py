@@ -116,10 +116,9 @@ def test_end_to_end_vs_oracle_and_reference_golden(cfg):
     assert abs(O.psnr(h['rgb'], target) - O.psnr(ref_rgb, target)) <= 0.05
 
 
-@pytest.mark.parametrize('shape', ['4x2', '8x1s4', '8x1s5'])
+@pytest.mark.parametrize('shape', ['4x2'])
 def test_mlp_other_shapes_match(shape):
-    """sherf_nerf_mlp shape 1 (4 waves x 2 column tiles, one wave per SIMD) and the deeper weight rings (4 / 5 LDS slots)
-    against the oracle and the default shape."""
+    """sherf_nerf_mlp shape 1 (4 waves x 2 column tiles, one wave per SIMD) against the oracle and the default shape."""
     for cfg in CFGS:
         o = G.oracle_render(cfg)
         a = G.hip_render(cfg)
@@ -130,8 +129,6 @@ def test_mlp_other_shapes_match(shape):
         assert float((torch.relu(out[:, 3]) - sig_ref).abs().max() / sig_ref.max()) < 1e-3
         assert float((out[:, :3] - o['sample_rgb']).abs().max()) < 1e-3
         assert G.rel(b['rgb'], a['rgb']) < 1e-4
-        if shape != '4x2':
-            assert torch.equal(b['rgb'], a['rgb'])               # same arithmetic, only the prefetch depth differs
 
 
 def test_eval_mode_batchnorm_uses_running_stats():
