@@ -113,17 +113,22 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_PROF(0, main);
         SHERF_HIP_CHECK(hipEventRecord(d.ev_start, main));
         SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_start, 0));
-        // ---- side: a7-a9 per-frame SMPL tables ----
-        SHERF_RUN(sherf_smpl_bones(f->poses, f->shapes, 3, f->J_template, f->J_shapedirs, f->parents, f->A, f->posefeat, stream_side));
-        SHERF_RUN(sherf_smpl_offsets(f->posedirs, f->shapedirs, f->posefeat, f->shapes, 3, f->PO, f->SO, stream_side));
-        const float *A0 = f->A, *A1 = f->A + 24 * 12, *A2 = f->A + 2 * 24 * 12;
-        const float *PO0 = f->PO, *PO1 = f->PO + V * 3, *PO2 = f->PO + 2 * V * 3;
-        const float *SO0 = f->SO, *SO2 = f->SO + 2 * V * 3;
-        SHERF_RUN(sherf_smpl_t2c_table(f->weights, A0, A1, PO0, SO0, PO1, f->T2C, stream_side));
-        SHERF_RUN(sherf_smpl_c2s_table(f->weights, A1, A2, PO1, SO2, PO2, f->obs_R, f->obs_Th, f->cam_R, f->cam_T, f->cam_K, f->C2S,
-                                       stream_side));
-        SHERF_HIP_CHECK(hipEventRecord(d.ev_smpl, side));
-        SHERF_PROF(1, side);
+        // ---- a7-a9 per-frame SMPL tables: first needed by the warp (after sampling), so with an aux stream they queue there
+        // behind the table folds and level builds and the encoder chain starts at once on the side stream ----
+        auto smpl_tables = [&](sherf_stream_t st) -> int {
+            SHERF_RUN(sherf_smpl_bones(f->poses, f->shapes, 3, f->J_template, f->J_shapedirs, f->parents, f->A, f->posefeat, st));
+            SHERF_RUN(sherf_smpl_offsets(f->posedirs, f->shapedirs, f->posefeat, f->shapes, 3, f->PO, f->SO, st));
+            const float *A0 = f->A, *A1 = f->A + 24 * 12, *A2 = f->A + 2 * 24 * 12;
+            const float *PO0 = f->PO, *PO1 = f->PO + V * 3, *PO2 = f->PO + 2 * V * 3;
+            const float *SO0 = f->SO, *SO2 = f->SO + 2 * V * 3;
+            SHERF_RUN(sherf_smpl_t2c_table(f->weights, A0, A1, PO0, SO0, PO1, f->T2C, st));
+            SHERF_RUN(sherf_smpl_c2s_table(f->weights, A1, A2, PO1, SO2, PO2, f->obs_R, f->obs_Th, f->cam_R, f->cam_T, f->cam_K,
+                                           f->C2S, st));
+            SHERF_HIP_CHECK(hipEventRecord(d.ev_smpl, as_stream(st)));
+            SHERF_PROF(1, as_stream(st));
+            return SHERF_OK;
+        };
+        if (!stream_aux) SHERF_RUN(smpl_tables(stream_side));
         const int stagger = f->main_after_layer;
         auto fold_tables = [&](sherf_stream_t st) -> int {      // per-frame table re-layout (channel-last, projections folded in)
             SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, st));
@@ -141,6 +146,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                              stagger >= 0 ? d.ev_mid : nullptr, stagger, stream_aux, d.ev_lev));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
             SHERF_PROF(2, side);
+            if (stream_aux) SHERF_RUN(smpl_tables(stream_aux));
             return SHERF_OK;
         };
         // Launch order == start order (a launch costs the host ~5 us): staggered -> encoder first, the ray side waits for

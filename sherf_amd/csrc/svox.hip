@@ -179,7 +179,9 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
                                                      float* __restrict__ out_raw, double* __restrict__ partials) {
     constexpr int COUT = 32 * NCOT, Cin = 16 * NKB;
-    if (mode & 256) __builtin_amdgcn_s_setprio(3);      // experiment (sherf_set_debug bit 7): issue priority over co-resident waves
+    // the encoder is a short serial chain of small launches running next to the ray side's chip-filling kernels: its
+    // waves take issue priority over co-resident waves (measured -20..30 us per frame; sherf_set_debug bit 7 turns it off)
+    if (!(mode & 256)) __builtin_amdgcn_s_setprio(3);
     mode &= 255;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
