@@ -43,9 +43,10 @@ def main():
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--bn-mode', default='eval', choices=['eval', 'train'],
-                    help='BatchNorm of the voxel encoder: eval = running statistics, how the reference renders (G_ema.eval(), '
-                         'training_loop.py:196, metrics/metric_utils.py:256); train = batch statistics (training forward)')
+    ap.add_argument('--bn-mode', default='train', choices=['train', 'eval'],
+                    help='BatchNorm of the voxel encoder. train (default) = batch statistics: the mode the reference renders in, '
+                         'also at test time (eval_*.sh -> train.py --test_flag -> test(G, ...) with G built .train(), '
+                         'training_loop.py:193,311-330); eval = running statistics (G_ema.eval(), training_loop.py:196)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))

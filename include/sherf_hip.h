@@ -191,18 +191,19 @@ int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, int n, int 
 int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
                      const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw, int Cin,
                      const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
-                     int max_rows, float* out_raw, double* partials, sherf_stream_t stream);
+                     int max_rows, float* out_raw, int64_t* out_acc, sherf_stream_t stream);
+/* out_acc (optional): [8][2][Cout] int64, zeroed by the caller; the conv adds 2^24-scaled sums of its output rows and of
+ * their squares (8 interleaved sub-accumulators) -- the batch statistics of the BatchNorm that follows it. */
 /* statistics over the reference's row set (n_total rows, the non-voxel rows being zeros) -> bnparam[3][C] =
  * (scale, shift, relu(shift)); training != 0: batch statistics into stats[2][C], else stats holds running stats. */
-int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
-                           int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
-                           float* bnparam, sherf_stream_t stream);
+int sherf_svox_bn_finalize(const int64_t* acc, const int32_t* n_total_rows, int C, const float* gamma, const float* beta,
+                           float* stats, int training, float* bnparam, sherf_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * a3: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-61). cam2world[N][16], intr[N][9]. */
 /* ---------------------------------------------------------------------------------------------
  * a11 as ONE native call.  The plan names every persistent buffer of the encoder (caller-owned, sized by the caller,
  * see sherf_amd/voxel.py: SparseConvNet._plan); sherf_svox_encode enqueues the whole chain -- 1 memset, level-0 build,
- * per layer [mark_down + scan] + sparse conv + BatchNorm finalize, and the fold of
+ * per layer [mark_down + scan] + sparse conv (BatchNorm statistics resolved in the consumer's prologue), and the fold of
  * each tapped level -- on `stream` without reading anything back.  Replaces SparseConvNet.forward (renderer.py:778-871)
  * + the three .dense() volumes.  levels_out_host[3] receives the tapped levels for sherf_gather_tokens.
  */
@@ -224,7 +225,7 @@ typedef struct {
     float* stats;            /* [2][cout] batch stats out (training) / running stats in (eval) */
     float* bnparam;          /* [3][cout] */
     float* out;              /* [cap][cout] raw conv output */
-    double* partials;        /* [ceil(cap/32)][2][cout] */
+    int64_t* acc;            /* [8][2][cout] fixed-point (2^-24) sums of the output and its squares; inside the zero region */
 } sherf_svox_layer;
 typedef struct {
     sherf_svox_level_ws lev[4];

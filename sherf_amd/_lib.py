@@ -33,7 +33,7 @@ class SvoxLevelWs(ctypes.Structure):                  # sherf_svox_level_ws
 
 class SvoxLayer(ctypes.Structure):                    # sherf_svox_layer
     _fields_ = [(n, _i32) for n in ('cin', 'cout', 'down', 'tap')] + \
-               [(n, _vp) for n in ('wt', 'gamma', 'beta', 'stats', 'bnparam', 'out', 'partials')]
+               [(n, _vp) for n in ('wt', 'gamma', 'beta', 'stats', 'bnparam', 'out', 'acc')]
 
 
 SVOX_MAX_LAYERS = 16

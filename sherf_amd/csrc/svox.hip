@@ -172,12 +172,29 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 }
 __device__ __forceinline__ float rt(float a) { return (float)((__bf16)a); }
 
+// BatchNorm of a conv's INPUT.  Training: the producer conv left fixed-point (2^-24) sums of its output and of its
+// squares in `acc` (integer atomics: order independent, bitwise reproducible; 8 interleaved sub-accumulators spread the
+// same-address traffic); every consumer workgroup turns them into scale/shift in its prologue -- no finalize launch and
+// no cross-workgroup hand-shake inside a kernel -- and workgroup 0 also publishes stats / bnparam.  Eval: bnparam holds
+// the constants derived from the running statistics.  bnparam == nullptr: raw input (first layer).
+// |sum of squares| must stay below 2^39 (activations of rms < ~5000 over 20 K rows).
+constexpr double kAccFix = 16777216.0;    // 2^24
+constexpr int kAccSub = 8;
+struct BnIn {
+    const long long* acc;       // [kAccSub][2][Cin] or nullptr
+    const int32_t* n_total;     // rows of the reference's row set
+    const float* gamma;
+    const float* beta;
+    float* stats;               // [2][Cin] batch mean / biased variance (written by workgroup 0 when acc != nullptr)
+    float* bnparam;             // [3][Cin] scale, shift, relu(shift)
+};
+
 template <int NCOT, int NKB>   // Cout = 32 * NCOT, Cin = 16 * NKB
 __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
-                                                     const float* __restrict__ in_raw, const float* __restrict__ in_bn,
+                                                     const float* __restrict__ in_raw, BnIn bin,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
-                                                     float* __restrict__ out_raw, double* __restrict__ partials) {
+                                                     float* __restrict__ out_raw, long long* __restrict__ out_acc) {
     constexpr int COUT = 32 * NCOT, Cin = 16 * NKB;
     // the encoder is a short serial chain of small launches running next to the ray side's chip-filling kernels: its
     // waves take issue priority over co-resident waves (measured -20..30 us per frame; sherf_set_debug bit 7 turns it off)
@@ -213,7 +230,28 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
         }
         s_nb[i] = nb;
     }
-    if (in_bn) for (int i = tid; i < 3 * Cin; i += 256) s_bn[i] = in_bn[i];
+    const bool in_bn = bin.bnparam != nullptr;
+    if (in_bn) {
+        if (bin.acc) {
+            if (tid < Cin) {
+                long long a1 = 0, a2 = 0;
+#pragma unroll
+                for (int q = 0; q < kAccSub; ++q) { a1 += bin.acc[(q * 2 + 0) * Cin + tid]; a2 += bin.acc[(q * 2 + 1) * Cin + tid]; }
+                const double n = (double)(*bin.n_total);
+                const double mean = (double)a1 * (1.0 / kAccFix) / n, var = fmax((double)a2 * (1.0 / kAccFix) / n - mean * mean, 0.0);
+                const float meanf = (float)mean, varf = (float)var;
+                const float scale = bin.gamma[tid] / sqrtf(varf + 1e-3f);
+                const float shift = bin.beta[tid] - meanf * scale;
+                s_bn[tid] = scale; s_bn[Cin + tid] = shift; s_bn[2 * Cin + tid] = fmaxf(shift, 0.f);
+                if (blockIdx.x == 0) {
+                    bin.stats[tid] = meanf; bin.stats[Cin + tid] = varf;
+                    bin.bnparam[tid] = scale; bin.bnparam[Cin + tid] = shift; bin.bnparam[2 * Cin + tid] = fmaxf(shift, 0.f);
+                }
+            }
+        } else {
+            for (int i = tid; i < 3 * Cin; i += 256) s_bn[i] = bin.bnparam[i];
+        }
+    }
     __syncthreads();
 
     f32x16_t acc[NCOT];
@@ -313,7 +351,7 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
                               s_red[(3 * 32 + rr) * COUT + co];
             if (row0 + rr < n_rows) { out_raw[(size_t)(row0 + rr) * COUT + co] = val; s1 += val; s2 += val * val; }
         }
-    if (partials) {
+    if (out_acc) {
         __syncthreads();
         if (g < G) { s_red[g * COUT + co] = s1; s_red[(G + g) * COUT + co] = s2; }
         __syncthreads();
@@ -321,60 +359,29 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             const int which = tid / COUT, c2 = tid % COUT;
             double t = 0.0;
             for (int q = 0; q < G; ++q) t += (double)s_red[(which * G + q) * COUT + c2];
-            partials[((size_t)blockIdx.x * 2 + which) * COUT + c2] = t;
+            atomicAdd(reinterpret_cast<unsigned long long*>(out_acc) + ((blockIdx.x % kAccSub) * 2 + which) * COUT + c2,
+                      (unsigned long long)__double2ll_rn(t * kAccFix));
         }
     }
 }
 
-// mean/var over the reference's ROW set from the per-block partials -> bnparam[3][C] = (scale, shift, relu(shift)), stats[2][C]
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ partials, const int32_t* __restrict__ n_rows_p,
-                                                           const int32_t* __restrict__ n_total_p, int C, int rows_per_block,
+// standalone form of the consumer prologue: acc (training) or running stats (eval) -> stats[2][C], bnparam[3][C]
+__global__ void __launch_bounds__(128) bn_finalize_kernel(const long long* __restrict__ acc, const int32_t* __restrict__ n_total_p, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ stats, int training, float* __restrict__ bnparam) {
-    __shared__ double s[256];
     const int tid = threadIdx.x;
+    if (tid >= C) return;
     if (training) {
-        const int series = 2 * C, nparts = 256 / series;
-        const int sidx = tid % series, part = tid / series;
-        const int nblk = (*n_rows_p + rows_per_block - 1) / rows_per_block;
-        double t = 0.0;
-        if (part < nparts) {
-            // the partials were written by other XCDs: every load misses to memory (~1-2 us), so keep 8 in flight; the
-            // summation order is fixed (8 interleaved sub-series, combined in order) -> deterministic
-            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int b = part;
-            for (; b + 7 * nparts < nblk; b += 8 * nparts) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u * nparts) * series + sidx];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += v[u];
-            }
-            double tail = 0.0;
-            for (; b < nblk; b += nparts) tail += partials[(size_t)b * series + sidx];
-            t = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + tail;
-        }
-        s[tid] = t;
-        __syncthreads();
-        if (tid < series) {
-            double a = 0.0;
-            for (int q = 0; q < nparts; ++q) a += s[q * series + tid];
-            s[tid] = a;
-        }
-        __syncthreads();
-        if (tid < C) {
-            const double n = (double)(*n_total_p);
-            const double mean = s[tid] / n, var = fmax(s[C + tid] / n - mean * mean, 0.0);
-            stats[tid] = (float)mean; stats[C + tid] = (float)var;
-        }
-        __syncthreads();
+        long long a1 = 0, a2 = 0;
+        for (int q = 0; q < kAccSub; ++q) { a1 += acc[(q * 2 + 0) * C + tid]; a2 += acc[(q * 2 + 1) * C + tid]; }
+        const double n = (double)(*n_total_p);
+        const double mean = (double)a1 * (1.0 / kAccFix) / n, var = fmax((double)a2 * (1.0 / kAccFix) / n - mean * mean, 0.0);
+        stats[tid] = (float)mean; stats[C + tid] = (float)var;
     }
-    if (tid < C) {
-        const float mean = stats[tid], var = stats[C + tid];
-        const float scale = gamma[tid] / sqrtf(var + 1e-3f);
-        const float shift = beta[tid] - mean * scale;
-        bnparam[tid] = scale; bnparam[C + tid] = shift; bnparam[2 * C + tid] = fmaxf(shift, 0.f);
-    }
+    const float mean = stats[tid], var = stats[C + tid];
+    const float scale = gamma[tid] / sqrtf(var + 1e-3f);
+    const float shift = beta[tid] - mean * scale;
+    bnparam[tid] = scale; bnparam[C + tid] = shift; bnparam[2 * C + tid] = fmaxf(shift, 0.f);
 }
 
 }  // namespace
@@ -425,28 +432,28 @@ extern "C" int sherf_svox_scatter_rows(const int32_t* coord, const float* feat, 
 
 
 
-extern "C" int sherf_svox_bn_finalize(const double* partials, const int32_t* n_rows, const int32_t* n_total_rows, int C,
-                                      int rows_per_block, const float* gamma, const float* beta, float* stats, int training,
-                                      float* bnparam, sherf_stream_t stream) {
-    SHERF_CHECK_ARG((partials || !training) && n_rows && n_total_rows && gamma && beta && stats && bnparam && C > 0 && C <= 96 && rows_per_block > 0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, n_rows, n_total_rows, C,
-                       rows_per_block, gamma, beta, stats, training, bnparam);
+extern "C" int sherf_svox_bn_finalize(const int64_t* acc, const int32_t* n_total_rows, int C, const float* gamma, const float* beta,
+                                      float* stats, int training, float* bnparam, sherf_stream_t stream) {
+    SHERF_CHECK_ARG((!training || (acc && n_total_rows)) && gamma && beta && stats && bnparam && C > 0 && C <= 96);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, as_stream(stream), reinterpret_cast<const long long*>(acc),
+                       n_total_rows, C, gamma, beta, stats, training, bnparam);
     SHERF_LAUNCH_CHECK();
 }
 
 static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo, const uint32_t* wp_in, int Di,
-                        int Hi, int Wi, const float* in_raw, int Cin, const float* in_bn, const int32_t* in_mult,
-                        const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, double* partials,
+                        int Hi, int Wi, const float* in_raw, int Cin, BnIn bin, const int32_t* in_mult,
+                        const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, int64_t* out_acc,
                         sherf_stream_t stream) {
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
+    SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
     const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
     const dim3 grid(cdiv(max_rows, 32)), block(256);
     if (g_sherf_debug & 128) mode |= 256;
 #define SHERF_CONV3(N, K)                                                                                                    \
     hipLaunchKernelGGL((sconv3_kernel<N, K>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,           \
-                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, in_bn, in_mult,                               \
-                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, partials)
+                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                                 \
+                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, reinterpret_cast<long long*>(out_acc))
     const int sel = (Cout / 32) * 10 + Cin / 16;
     switch (sel) {
         case 12: SHERF_CONV3(1, 2); break;     // 32 -> 32
@@ -465,9 +472,10 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
 extern "C" int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo,
                                 const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw, int Cin,
                                 const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
-                                int max_rows, float* out_raw, double* partials, sherf_stream_t stream) {
-    return launch_conv3(keys_out, n_rows_out, Do, Ho, Wo, wp_in, Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, w_packed, Cout, mode,
-                        max_rows, out_raw, partials, stream);
+                                int max_rows, float* out_raw, int64_t* out_acc, sherf_stream_t stream) {
+    BnIn bin{nullptr, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(in_bn)};
+    return launch_conv3(keys_out, n_rows_out, Do, Ho, Wo, wp_in, Di, Hi, Wi, in_raw, Cin, bin, in_mult, w_packed, Cout, mode,
+                        max_rows, out_raw, out_acc, stream);
 }
 
 static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
@@ -479,8 +487,8 @@ static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
     SHERF_LAUNCH_CHECK();
 }
 
-// The whole encoder as one native call: 1 memset + 6 launches for level 0, 4 per down-sampling, 2 per conv (conv +
-// BatchNorm finalize), 1 per tapped level for the fold.  Everything is enqueued on `stream`; nothing is read back.
+// The whole encoder as one native call: 1 memset + 6 launches for level 0, 4 per down-sampling, 1 per conv, 1 per tapped
+// level for the fold (no BatchNorm finalize launches: see BnIn).  Everything is enqueued on `stream`; nothing is read back.
 // (A finalize fused into the conv's last workgroup was measured and rejected: the device-scope fence every workgroup
 // needs writes back / invalidates its XCD's L2, which slowed the conv 2x and every kernel running next to it.)
 // `ev` (optional) is recorded after layer `ev_layer`: lets the frame driver start other work mid-chain.
@@ -518,10 +526,14 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
                                       p->mult, stream));
     int lev = 0, ntap = 0;
     const float* cur = p->g0;
-    const float* cur_bn = nullptr;
+    BnIn cur_bn{};                                      // BatchNorm of `cur` (none for the raw level-0 features)
+    auto bn_of = [&](const sherf_svox_layer& ly, int dlev) {
+        return BnIn{training ? reinterpret_cast<const long long*>(ly.acc) : nullptr, dlev == 0 ? p->n_total : p->lev[dlev].n_rows,
+                    ly.gamma, ly.beta, ly.stats, ly.bnparam};
+    };
     for (int li = 0; li < p->n_layers; ++li) {
         const sherf_svox_layer& ly = p->layers[li];
-        SHERF_CHECK_ARG(ly.wt && ly.gamma && ly.beta && ly.stats && ly.bnparam && ly.out && ly.partials);
+        SHERF_CHECK_ARG(ly.wt && ly.gamma && ly.beta && ly.stats && ly.bnparam && ly.out && ly.acc);
         SHERF_CHECK_ARG(lev + (ly.down ? 1 : 0) < 4);
         const int dlev = lev + (ly.down ? 1 : 0);
         const sherf_svox_level_ws& src = p->lev[lev];
@@ -530,19 +542,17 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
             if (aux) SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), lev_ev[dlev], 0));
             else SHERF_RUN(build_level(dlev, stream));
         }
-        // training: batch statistics -> per-block fp64 partials + a finalize launch.  eval: bnparam comes from the running
-        // statistics and was prepared by the caller (sherf_svox_bn_finalize with training = 0) when they last changed.
+        // training: the conv leaves fixed-point sums of its output in ly.acc, resolved by its consumers' prologues.
+        // eval: bnparam comes from the running statistics and was prepared by the caller (sherf_svox_bn_finalize with
+        // training = 0) when they last changed.
         SHERF_RUN(launch_conv3(dst.keys, dst.n_rows, dst.D, dst.H, dst.W, src.wp, src.D, src.H, src.W, cur, ly.cin, cur_bn,
-                               (lev == 0 && cur_bn) ? p->mult : nullptr, ly.wt, ly.cout, ly.down ? 1 : 0, dst.cap, ly.out,
-                               training ? ly.partials : nullptr, stream));
-        if (training)
-            SHERF_RUN(sherf_svox_bn_finalize(ly.partials, dst.n_rows, dlev == 0 ? p->n_total : dst.n_rows, ly.cout, 32, ly.gamma,
-                                             ly.beta, ly.stats, 1, ly.bnparam, stream));
+                               (lev == 0 && cur_bn.bnparam) ? p->mult : nullptr, ly.wt, ly.cout, ly.down ? 1 : 0, dst.cap, ly.out,
+                               training ? ly.acc : nullptr, stream));
         if (ev && li == ev_layer) SHERF_HIP_CHECK(hipEventRecord(ev, as_stream(stream)));
-        lev = dlev; cur = ly.out; cur_bn = ly.bnparam;
+        lev = dlev; cur = ly.out; cur_bn = bn_of(ly, dlev);
         if (ly.tap) {
             SHERF_CHECK_ARG(ntap < 3 && p->fold_mat[ntap] && p->fold_rows[ntap]);
-            SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, ly.bnparam, nullptr,
+            SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, cur_bn, nullptr,
                                    p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, stream));
             levels_out_host[ntap].wp = dst.wp;
             levels_out_host[ntap].rows = p->fold_rows[ntap];

@@ -154,7 +154,8 @@ class _Workspace:
             nvox = D * H * W
             dims.append((nvox, (nvox + 31) // 32, N if li == 0 else min(nvox, 8 * N)))
         # one contiguous region for everything that must be zero at the start of a frame -> a single memset
-        zsize = sum(d[1] for d in dims) + N + N * 32 * 2 + 2
+        n_acc = 16 * 8 * 2 * 96 * 2                                         # BatchNorm accumulators: 16 layers x [8][2][96] int64
+        zsize = sum(d[1] for d in dims) + N + N * 32 * 2 + 2 + n_acc + 2
         zero_region = torch.zeros(zsize, **i32)
         L, off = [], 0
         for li, (nvox, nwords, cap) in enumerate(dims):
@@ -166,6 +167,8 @@ class _Workspace:
         L[0]['mult'] = zero_region[off:off + N]; off += N
         off += off % 2                                                     # 8-byte alignment of the fixed-point accumulators
         L[0]['acc_fix'] = zero_region[off:off + N * 64].view(torch.int64)
+        off += N * 64
+        L[0]['bn_acc'] = zero_region[off:off + n_acc].view(torch.int64)
         L[0]['g0'] = torch.zeros(N, 32, device=dev)
         L[0]['n_total'] = torch.full((1,), N, **i32)
         self.vox = (key, (L, zero_region))
@@ -185,9 +188,6 @@ class _Workspace:
 
     def layer_out(self, idx, cap, C, dev):
         return self._cached('out', idx, (cap, C), dev)
-
-    def partials(self, idx, nblk, C, dev):
-        return self._cached('part', idx, (nblk, 2, C), dev, torch.float64)
 
     def fold_out(self, idx, cap, dev):
         return self._cached('fold', idx, (cap, 96), dev)

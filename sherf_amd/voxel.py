@@ -128,13 +128,13 @@ class SparseConvNet(nn.Module):
             dlev = lev + 1 if ly['down'] else lev
             cap, C = L[dlev]['cap'], ly['cout']
             out = ws.layer_out(li, cap, C, dev)
-            parts = ws.partials(li, (cap + 31) // 32, C, dev)
             stats = stats_flat[off:off + 2 * C].view(2, C); off += 2 * C
             bnp = ws.bn_param(li, C, dev)
             c = plan.layers[li]
             c.cin, c.cout, c.down, c.tap = ly['cin'], C, int(ly['down']), int(ly['tap'])
             c.wt, c.gamma, c.beta = A(ly['wt']), A(ly['gamma']), A(ly['beta'])
-            c.stats, c.bnparam, c.out, c.partials = A(stats), A(bnp), A(out), A(parts)
+            c.stats, c.bnparam, c.out = A(stats), A(bnp), A(out)
+            c.acc = L[0]['bn_acc'].data_ptr() + li * 8 * 2 * 96 * 8                 # [8][2][C] int64 inside the zero region
             meta.append(dict(bn=ly['bn'], stats=stats, bnp=bnp, out=out, lev=dlev, cout=C))
             if ly['tap']:
                 taps.append((dlev, out, bnp, C))
@@ -169,8 +169,8 @@ class SparseConvNet(nn.Module):
                     pl['stats_flat'].copy_(torch.cat([t.reshape(-1) for m in pl['meta']
                                                       for t in (m['bn'].running_mean, m['bn'].running_var)]).float())
                 for m, ly in zip(pl['meta'], self._pack(feat.device)['layers']):
-                    _lib.call('sherf_svox_bn_finalize', None, P(pl['L'][0]['n_total']), P(pl['L'][0]['n_total']), m['cout'], 32,
-                              P(ly['gamma']), P(ly['beta']), P(m['stats']), 0, P(m['bnp']), _lib.stream())
+                    _lib.call('sherf_svox_bn_finalize', None, None, m['cout'], P(ly['gamma']), P(ly['beta']), P(m['stats']), 0,
+                              P(m['bnp']), _lib.stream())
                 pl['eval_key'] = key
         return pl, feat, coord
 

@@ -8,7 +8,8 @@ run() { # label, bn mode, env...
   local label=$1; local bn=$2; shift; shift
   env "$@" timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --bn-mode $bn 2>&1 | grep '"metric"\|rror' | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['frame_timeline_ms']; print('%-18s' % '$label', 'ms/step %.3f' % d['ms_per_step'], 'mlp %.3f' % d['roofline']['kernel_ms'], ' '.join('%s=%.3f' % (k[:12], v) for k, v in t.items()))"
 }
-run eval eval X=1
-run eval_split eval SHERF_GATHER_SPLIT=1
-run eval_noprio eval SHERF_DEBUG=128
 run train train X=1
+run train_split train SHERF_GATHER_SPLIT=1
+run eval eval X=1
+timeout 900 python -m pytest tests -m gpu -q --timeout=600 -x --no-header -p no:cacheprovider > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
+tail -5 $OUT/pytest.log
