@@ -36,7 +36,8 @@ typedef void* sherf_stream_t; /* hipStream_t */
 int sherf_version(void);
 const char* sherf_last_error(void);
 /* profiling aid: ablation switches (bit0 sampler skips NN, bit1 sampler skips quick reject, bit2/3/4 gather skips
- * voxel / tri-plane / pixel taps). Results are WRONG with any bit set; default 0. */
+ * voxel / tri-plane / pixel taps, bit5 MLP without weight traffic, bit6 MLP without barriers). Results are WRONG with any
+ * of bits 0-6 set.  bit7 only turns off the issue priority of the encoder's waves (results unchanged).  Default 0. */
 int sherf_set_debug(int flags);
 
 /* ---------------------------------------------------------------------------------------------

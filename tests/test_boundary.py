@@ -14,7 +14,7 @@ from sherf_amd import _lib
 
 def test_library_exports_every_declared_symbol():
     protos = _lib.parse_header()
-    assert len(protos) >= 23
+    assert len(protos) >= 32
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), name
@@ -28,6 +28,15 @@ def test_bad_arguments_return_error_codes_not_crashes():
     assert b'bad argument' in l.sherf_last_error()
     with pytest.raises(RuntimeError):
         _lib.call('sherf_svox_scan', None, 0, None, None, None, None, None)
+    # the native drivers validate before touching the device
+    assert l.sherf_render_frame(None, 3, None, None, None, None) == -1
+    assert l.sherf_svox_encode(None, None, None, 0, 1, None, None) == -1
+    fr = _lib.Frame()
+    lv = (_lib.VoxLevel * 3)()
+    assert l.sherf_render_frame(ctypes.byref(fr), 0, lv, None, ctypes.c_void_p(8), None) == -1      # phase 0
+    assert l.sherf_render_frame(ctypes.byref(fr), 3, lv, None, None, None) == -1                    # side == main stream
+    n = ctypes.c_int32(0)
+    assert l.sherf_profile_frames_read(None, 4, ctypes.byref(n)) == -1
 
 
 def test_cpu_tensors_are_rejected_loudly():
