@@ -71,22 +71,24 @@ __global__ void __launch_bounds__(256) scan_local_kernel(const uint32_t* __restr
     if (tid == 255) chunk_sum[blockIdx.x] = s[255];
 }
 
-__global__ void __launch_bounds__(1024) scan_chunks_kernel(int32_t* __restrict__ chunk_sum, int n_chunks, int32_t* __restrict__ n_rows) {
-    __shared__ int s[1024];
+// one SMALL workgroup: a 1024-thread block needs 16 free wave slots on one CU at once and starved for up to 240 us next to
+// the chip-filling sampler (rocprofv3 timeline); 256 threads slot in anywhere
+__global__ void __launch_bounds__(256) scan_chunks_kernel(int32_t* __restrict__ chunk_sum, int n_chunks, int32_t* __restrict__ n_rows) {
+    __shared__ int s[256];
     int carry = 0;
-    for (int b0 = 0; b0 < n_chunks; b0 += 1024) {
+    for (int b0 = 0; b0 < n_chunks; b0 += 256) {
         int i = b0 + threadIdx.x;
         int v = i < n_chunks ? chunk_sum[i] : 0;
         s[threadIdx.x] = v;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
+        for (int off = 1; off < 256; off <<= 1) {
             int a = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
             __syncthreads();
             s[threadIdx.x] += a;
             __syncthreads();
         }
         if (i < n_chunks) chunk_sum[i] = carry + s[threadIdx.x] - v;
-        int tot = s[1023];
+        int tot = s[255];
         __syncthreads();
         carry += tot;
     }
@@ -264,6 +266,9 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     uint32_t tapmask = 0;
     for (int tap = wave; tap < ntaps; tap += 4)
         if (__ballot(s_nb[tap * 32 + r] >= 0) != 0ull) tapmask |= 1u << tap;
+    // pointwise fold (one tap): the waves split the output-channel tiles instead of the taps
+    const int csel = mode == 2 ? wave : -1;
+    if (mode == 2) tapmask = wave < NCOT ? 1u : 0u;
     tapmask = __builtin_amdgcn_readfirstlane(tapmask);
 
     // The tile is a chain of dependent gathers (neighbour row -> MFMA); with ~2 waves per SIMD nothing hides their latency
@@ -282,7 +287,8 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     auto load_w = [&](int tap, int kb, uint4 (&w)[2 * NCOT]) {
         const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < 2 * NCOT; ++c) w[c] = wsrc[c * 64];
+        for (int c = 0; c < 2 * NCOT; ++c)
+            if (csel < 0 || (c >> 1) == csel) w[c] = wsrc[c * 64];
     };
     auto compute = [&](int tap, const Row& R) {
         uint4 w[2 * NCOT];
@@ -307,6 +313,7 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
                                          pk2(v[4] - rt(v[4]), v[5] - rt(v[5])), pk2(v[6] - rt(v[6]), v[7] - rt(v[7])));
 #pragma unroll
             for (int c = 0; c < NCOT; ++c) {
+                if (csel >= 0 && c != csel) continue;
                 const uint4 bhi = w[2 * c], blo = w[2 * c + 1];
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, alo), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, blo), acc[c], 0, 0, 0);
@@ -405,7 +412,7 @@ extern "C" int sherf_svox_scan(const uint32_t* bitmap, int n_words, int32_t* pre
     SHERF_CHECK_ARG(bitmap && prefix && n_rows && chunk_ws && wp && n_words > 0);
     const int n_chunks = cdiv(n_words, 1024);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), bitmap, n_words, prefix, chunk_ws);
-    hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(1024), 0, as_stream(stream), chunk_ws, n_chunks, n_rows);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(256), 0, as_stream(stream), chunk_ws, n_chunks, n_rows);
     hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n_words, 256)), dim3(256), 0, as_stream(stream), bitmap, prefix, n_words, chunk_ws,
                        reinterpret_cast<uint2*>(wp), (int32_t*)nullptr);
     SHERF_LAUNCH_CHECK();
@@ -481,7 +488,7 @@ extern "C" int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_o
 static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
     const int n_chunks = cdiv(l.n_words, 1024);
     hipLaunchKernelGGL(scan_local_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), l.bitmap, l.n_words, l.prefix, l.chunk_ws);
-    hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(1024), 0, as_stream(stream), l.chunk_ws, n_chunks, l.n_rows);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(1), dim3(256), 0, as_stream(stream), l.chunk_ws, n_chunks, l.n_rows);
     hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(l.n_words, 256)), dim3(256), 0, as_stream(stream), l.bitmap, l.prefix, l.n_words,
                        l.chunk_ws, reinterpret_cast<uint2*>(l.wp), l.keys);
     SHERF_LAUNCH_CHECK();

@@ -27,6 +27,6 @@ for k, c, n, v in rows:
         continue
     out.setdefault(k, {})[c] = (n, v)
 for k, d in out.items():
-    print(k.split('(')[0][-60:])
+    print(k.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:60])
     for c, (n, v) in sorted(d.items()):
         print(f'    {c:34s} n={n:4d} avg={v:.4g}')
