@@ -8,11 +8,12 @@
 #include "common.h"
 
 #include <chrono>
+#include <functional>
 #include <mutex>
 
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                            sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
-                           sherf_stream_t aux, hipEvent_t* lev_ev);   // svox.hip
+                           sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels);   // svox.hip
 
 namespace {
 
@@ -21,7 +22,7 @@ constexpr int kRing = 64;
 
 struct DevState {
     bool init = false;
-    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[4];
+    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8];
 };
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
@@ -99,7 +100,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_fold, hipEventDisableTiming));
-                for (int k = 0; k < 4; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
+                for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
                 d.init = true;
             }
         }
@@ -142,11 +143,12 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         }
         const size_t ncell1 = (size_t)SHERF_MAX_CELLS + 1;
         auto enqueue_encoder = [&]() -> int {        // ---- side: a11 sparse voxel encoder ----
+            const std::function<int()> smpl_on_aux = [&]() -> int { return smpl_tables(stream_aux); };
             SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
-                                             stagger >= 0 ? d.ev_mid : nullptr, stagger, stream_aux, d.ev_lev));
+                                             stagger >= 0 ? d.ev_mid : nullptr, stagger, stream_aux, d.ev_lev,
+                                             stream_aux ? &smpl_on_aux : nullptr));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
             SHERF_PROF(2, side);
-            if (stream_aux) SHERF_RUN(smpl_tables(stream_aux));
             return SHERF_OK;
         };
         // Launch order == start order (a launch costs the host ~5 us): staggered -> encoder first, the ray side waits for

@@ -8,6 +8,8 @@
 // multiplicity so BatchNorm statistics are taken over the reference's ROW set).
 #include "common.h"
 
+#include <functional>
+
 namespace {
 
 __global__ void __launch_bounds__(256) mark_rows_kernel(const int32_t* __restrict__ coord, int n, int D, int H, int W,
@@ -501,9 +503,13 @@ static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
 // `ev` (optional) is recorded after layer `ev_layer`: lets the frame driver start other work mid-chain.
 // `aux` + `lev_ev[4]` (optional): the occupancy structure of levels 1-3 depends only on the voxel coordinates, not on any
 // feature, so it is built on a second stream while the level-0 convolutions run (12 launches off the dependent chain).
+// With `aux` the three pointwise folds also leave the chain: their output is first read by the gather, so they run on `aux`
+// behind an event per tapped layer (lev_ev[4..6]; lev_ev[7] joins aux back into `stream` at the end).  `after_levels`
+// (optional) is called once the level builds are queued on aux, before the folds: lets the caller slot in aux work that
+// must not wait behind them.
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                            sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
-                           sherf_stream_t aux, hipEvent_t* lev_ev) {
+                           sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels) {
     SHERF_CHECK_ARG(p && coord && feat && n > 0 && levels_out_host && p->n_layers > 0 && p->n_layers <= SHERF_SVOX_MAX_LAYERS);
     SHERF_CHECK_ARG(p->zero_ptr && p->zero_bytes > 0 && p->acc_fix && p->g0 && p->mult && p->n_total);
     SHERF_CHECK_ARG(aux == nullptr || (lev_ev != nullptr && aux != stream));
@@ -529,6 +535,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
             SHERF_HIP_CHECK(hipEventRecord(lev_ev[k], as_stream(aux)));
         }
     }
+    if (after_levels) SHERF_RUN((*after_levels)());
     SHERF_RUN(sherf_svox_scatter_rows(coord, feat, n, 32, l0.D, l0.H, l0.W, l0.bitmap, l0.prefix, l0.n_rows, p->acc_fix, p->g0,
                                       p->mult, stream));
     int lev = 0, ntap = 0;
@@ -559,8 +566,14 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         lev = dlev; cur = ly.out; cur_bn = bn_of(ly, dlev);
         if (ly.tap) {
             SHERF_CHECK_ARG(ntap < 3 && p->fold_mat[ntap] && p->fold_rows[ntap]);
+            sherf_stream_t fst = stream;
+            if (aux) {
+                SHERF_HIP_CHECK(hipEventRecord(lev_ev[4 + ntap], as_stream(stream)));
+                SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(aux), lev_ev[4 + ntap], 0));
+                fst = aux;
+            }
             SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, cur_bn, nullptr,
-                                   p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, stream));
+                                   p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, fst));
             levels_out_host[ntap].wp = dst.wp;
             levels_out_host[ntap].rows = p->fold_rows[ntap];
             levels_out_host[ntap].D = dst.D; levels_out_host[ntap].H = dst.H; levels_out_host[ntap].W = dst.W;
@@ -568,10 +581,14 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         }
     }
     SHERF_CHECK_ARG(ntap == 3);
+    if (aux) {                                          // the caller's "encoder done" event on `stream` covers aux too
+        SHERF_HIP_CHECK(hipEventRecord(lev_ev[7], as_stream(aux)));
+        SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), lev_ev[7], 0));
+    }
     return SHERF_OK;
 }
 
 extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                                  sherf_vox_level* levels_out_host, sherf_stream_t stream) {
-    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1, nullptr, nullptr);
+    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1, nullptr, nullptr, nullptr);
 }
