@@ -63,7 +63,7 @@ def main():
 
     if os.environ.get('SHERF_DEBUG'):
         from sherf_amd import _lib
-        _lib.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (tools/gpu_run3.sh)
+        _lib.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (tools/gpu_ablate.sh, tools/gpu_sweep.sh)
     smpl = synth.make_synth_smpl(0)
     fx, d, to = make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)
