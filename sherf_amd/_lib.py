@@ -13,7 +13,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_HERE, '..', 'include', 'sherf_hip.h')
-LIB_PATH = os.path.join(_HERE, 'libsherf_hip.so')
+# SHERF_HIP_LIB: alternative build of the same ABI (kernel-variant experiments, tools/gpu_variants.sh); default = in-tree build
+LIB_PATH = os.environ.get('SHERF_HIP_LIB') or os.path.join(_HERE, 'libsherf_hip.so')
 
 _lib = None
 _protos = None
