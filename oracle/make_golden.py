@@ -150,6 +150,70 @@ def run(cfg_name, R, T, out_dir):
           f'({os.path.getsize(path)/1e6:.2f} MB)')
 
 
+GRAD_SAMPLE = 64      # entries kept per gradient tensor (strided), next to its sum / abs-sum / L2 norm
+
+
+def grad_fingerprint(g):
+    """Compact golden for one gradient tensor: [sum, sum|.|, L2] in float64 + GRAD_SAMPLE strided entries."""
+    g = g.detach().reshape(-1).double()
+    n = g.numel()
+    idx = torch.linspace(0, n - 1, min(GRAD_SAMPLE, n)).round().long()
+    return np.concatenate([np.array([float(g.sum()), float(g.abs().sum()), float(g.norm())]), g[idx].numpy()])
+
+
+def loss_targets(shape_rgb, shape_acc):
+    """Seeded targets of the stub training loss of BASELINE config 5: L = MSE(rgb, T_rgb) + MSE(acc, T_acc)."""
+    rs = np.random.RandomState(11)
+    return (torch.from_numpy(rs.uniform(-1, 1, tuple(shape_rgb)).astype(np.float32)),
+            torch.from_numpy(rs.uniform(0, 1, tuple(shape_acc)).astype(np.float32)))
+
+
+def run_grad(cfg_name, R, T, out_dir):
+    """Golden GRADIENTS: forward + backward of the unmodified reference (training mode, density_noise 0) under the stub
+    loss, w.r.t. every renderer / decoder parameter and the three feature inputs (tri-planes, 2-D feature map, per-vertex
+    voxel features).  Stored as fingerprints (grad_fingerprint) -- the full set would be 10 MB."""
+    from oracle import fixtures
+    fx = fixtures.renderer_inputs(cfg_name)
+    torch.manual_seed(0)
+    rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
+    dec = T.NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.')
+    fixtures.load_seeded_state(dec, 'decoder.')
+    rend.train(); dec.train()
+    d = fixtures.to_torch(fx['input_data'])
+    planes = torch.from_numpy(fx['planes']).requires_grad_(True)
+    obs_img = d['obs_img_all'][:, 0]
+    obs_feat = torch.from_numpy(fx['obs_feat']).requires_grad_(True)
+    vfeat = torch.from_numpy(fx['vertex_feat']).requires_grad_(True)
+    with torch.no_grad():
+        smpl_obs_pts = torch.matmul(d['obs_vertices'] - d['obs_params']['Th'], d['obs_params']['R'])
+        obs_can = rend.coarse_deform_target2c(d['obs_params'], d['obs_vertices'], d['t_params'], smpl_obs_pts)
+    sp_input, _ = T.TriPlaneGenerator.prepare_sp_input(types.SimpleNamespace(), d['t_vertices'].clone(), obs_can)
+    import spconv.pytorch as spconv
+    sp = spconv.core.SparseConvTensor(vfeat, sp_input['coord'], sp_input['out_sh'], sp_input['batch_size'])
+    t0 = time.time()
+    rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, d['ray_o_all'][:, 0], d['ray_d_all'][:, 0],
+                           d['near_all'][:, 0], d['far_all'][:, 0], d, fx['options'])
+    t_rgb, t_acc = loss_targets(rgb.shape, acc.shape)
+    loss = ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
+    loss.backward()
+    dt = time.time() - t0
+    out = {'loss': np.float64(loss.item()), 'ref_cpu_seconds': np.float64(dt)}
+    for name, t in (('input.planes', planes), ('input.obs_feat', obs_feat), ('input.vertex_feat', vfeat)):
+        out[name] = grad_fingerprint(t.grad)
+    n_none = 0
+    for prefix, mod in (('renderer.', rend), ('decoder.', dec)):
+        for name, p_ in mod.named_parameters():
+            if p_.grad is None:
+                n_none += 1
+                continue
+            out[prefix + name] = grad_fingerprint(p_.grad)
+    path = os.path.join(out_dir, f'grad_{cfg_name}.npz')
+    np.savez_compressed(path, **out)
+    print(f'grad {cfg_name}: loss {loss.item():.6f}, {len(out) - 2} gradient fingerprints ({n_none} parameters without grad), '
+          f'ref fwd+bwd {dt:.2f}s -> {path} ({os.path.getsize(path)/1e3:.0f} KB)')
+
+
 def run_glue(R, T, out_dir, cfg_name='tiny'):
     """Golden for the TriPlaneGenerator.synthesis glue (triplane.py:105-126): per-vertex features + back-face mask,
     produced with the reference's own projection / compute_normal / rgb_enc and a seeded conv1d_projection."""
@@ -227,3 +291,6 @@ if __name__ == '__main__':
     run_glue(R, T, out_dir)
     for n in names:
         run(n, R, T, out_dir)
+    for n in names:
+        if n in ('tiny', 'tiny_nv'):
+            run_grad(n, R, T, out_dir)

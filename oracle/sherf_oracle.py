@@ -526,6 +526,55 @@ def render_from_fixture(fx, state, training=True, keep=True):
     return res
 
 
+GRAD_SAMPLE = 64
+
+
+def grad_fingerprint(g):
+    """[sum, sum|.|, L2] (float64) + GRAD_SAMPLE strided entries of a gradient tensor -- the compact form the golden
+    gradients are stored in (oracle/make_golden.py: grad_fingerprint)."""
+    g = g.detach().reshape(-1).double()
+    n = g.numel()
+    idx = torch.linspace(0, n - 1, min(GRAD_SAMPLE, n)).round().long()
+    return np.concatenate([np.array([float(g.sum()), float(g.abs().sum()), float(g.norm())]), g[idx].numpy()])
+
+
+def stub_loss(rgb, acc):
+    """BASELINE config 5's stub training loss: MSE(rgb, T_rgb) + MSE(acc, T_acc) with seeded targets
+    (RandomState(11): rgb target first, then acc, as in make_golden.loss_targets).  rgb [R,3], acc [R]."""
+    rs = np.random.RandomState(11)
+    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1,) + tuple(rgb.shape)).astype(np.float32))[0]
+    t_acc = torch.from_numpy(rs.uniform(0, 1, (1,) + tuple(acc.shape) + (1,)).astype(np.float32))[0, :, 0]
+    return ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
+
+
+def gradients_from_fixture(fx, state):
+    """Backward of the path by autograd through this restatement (training-mode BatchNorm): returns (loss, {name: grad})
+    for every renderer / decoder parameter that receives one and for the three feature inputs
+    ('input.planes', 'input.obs_feat', 'input.vertex_feat').  The oracle for the HIP backward kernels (BASELINE config 5)."""
+    st = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
+    fx = dict(fx)
+    leaves = {}
+    for key, name in (('planes', 'input.planes'), ('obs_feat', 'input.obs_feat'), ('vertex_feat', 'input.vertex_feat')):
+        leaves[name] = torch.from_numpy(np.ascontiguousarray(fx[key])).requires_grad_(True)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    d = {k: ({kk: to(vv) for kk, vv in v.items()} if isinstance(v, dict) else to(v)) for k, v in fx['input_data'].items()}
+    smpl = smpl_tensors(fx['smpl'])
+    OP = d['obs_params']
+    with torch.no_grad():
+        obs_s = torch.matmul(d['obs_vertices'].view(-1, 3) - OP['Th'].view(1, 3), OP['R'].view(3, 3))
+        _, ovid = nearest_vertex(obs_s, obs_s)
+        obs_can, _ = target_to_canonical(smpl, OP, d['t_params'], obs_s, obs_s, None, ovid)
+    sp_input = prepare_sp_input(d['t_vertices'].view(-1, 3), obs_can)
+    res = render(st, smpl, leaves['input.planes'][0], d['obs_img_all'][0, 0], leaves['input.obs_feat'][0], leaves['input.vertex_feat'],
+                 sp_input, d['ray_o_all'][0, 0], d['ray_d_all'][0, 0], d['near_all'][0, 0, :, 0], d['far_all'][0, 0, :, 0], d,
+                 fx['options'], training=True, keep=False)
+    loss = stub_loss(res['rgb'], res['acc'])
+    loss.backward()
+    grads = {n: t.grad for n, t in leaves.items()}
+    grads.update({n: t.grad for n, t in st.items() if t.is_floating_point() and t.grad is not None})
+    return float(loss.detach()), grads
+
+
 def psnr(a, b):
     """test_loop.py:36-37 on images mapped to [0,1]."""
     mse = torch.mean(((a / 2 + 0.5) - (b / 2 + 0.5)) ** 2)
