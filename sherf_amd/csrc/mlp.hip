@@ -177,6 +177,26 @@ __device__ __forceinline__ f32x16 bias_tile(const C& cx, int idx) {
     return r;
 }
 
+// SHERF_MLP_FASTMATH: hardware transcendentals (v_sin/v_cos/v_exp/v_rsq/v_rcp, ~1e-6 absolute) instead of the
+// correctly rounded libm sequences in the VALU-bound transformer / positional-encoding prologue (sincosf alone is ~130
+// instructions + branches, six times per tile).
+#ifndef SHERF_MLP_FASTMATH
+#define SHERF_MLP_FASTMATH 1
+#endif
+#if SHERF_MLP_FASTMATH
+__device__ __forceinline__ void sincos_(float x, float* s, float* c) { *s = __sinf(x); *c = __cosf(x); }
+__device__ __forceinline__ float exp_(float x) { return __expf(x); }
+__device__ __forceinline__ float rcp_(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float rsqrt_(float x) { return __frsqrt_rn(x); }
+#else
+__device__ __forceinline__ void sincos_(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ float exp_(float x) { return expf(x); }
+__device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
+__device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
+#endif
+#ifndef SHERF_MLP_INTERLEAVE
+#define SHERF_MLP_INTERLEAVE 0
+#endif
 // acc[col] += W_step[kb0 .. kb0+NK) . B[col]: one segment of a chunk's K range, NCOL column sets sharing the A fragments
 template <int PREC, int NK, int NCOL>
 __device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
@@ -193,6 +213,16 @@ __device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, c
         }
 #pragma unroll
         for (int t = 0; t < NCOL; ++t) acc[t] = mfma(ah, b[t][kb].hi, acc[t]);
+#if SHERF_MLP_INTERLEAVE
+        // Software pipeline across chunks: the previous chunk's epilogue (ReLU + bf16 hi/lo split, ~60 VALU) is independent
+        // of this chunk's MFMAs; left alone the compiler sinks all four epilogues of a layer in front of the next layer's
+        // first MFMA (240 VALU during which this wave's MFMA pipe idles).  Ask for a few of them after every K-block.
+        if constexpr (PREC == 1 && NK >= 4) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NCOL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, SHERF_MLP_INTERLEAVE, 0);
+        }
+#endif
     }
 }
 
@@ -210,7 +240,7 @@ __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_
 #pragma unroll
     for (int r = 0; r < 16; ++r) { float d = x[r] - mean; q += d * d; }
     q += xhalf(q);
-    const float inv = 1.0f / sqrtf(q * (1.0f / 32.0f) + 1e-5f);
+    const float inv = rsqrt_(q * (1.0f / 32.0f) + 1e-5f);
     const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
     f32x16 y;
 #pragma unroll
@@ -227,7 +257,7 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
     for (int i = 0; i < NKB * 16; ++i) f[i] = 0.f;
     f[0] = x; f[1] = y; f[2] = z;
     float s[3], c[3];
-    sincosf(x, &s[0], &c[0]); sincosf(y, &s[1], &c[1]); sincosf(z, &s[2], &c[2]);
+    sincos_(x, &s[0], &c[0]); sincos_(y, &s[1], &c[1]); sincos_(z, &s[2], &c[2]);
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
 #pragma unroll
@@ -374,8 +404,8 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 #pragma unroll
                 for (int t = 0; t < 3; ++t) d[t] = (dot[i][hd][t] + xhalf(dot[i][hd][t])) * 0.25f;
                 float m = fmaxf(d[0], fmaxf(d[1], d[2]));
-                float e0 = expf(d[0] - m), e1 = expf(d[1] - m), e2 = expf(d[2] - m);
-                float inv = 1.0f / (e0 + e1 + e2);
+                float e0 = exp_(d[0] - m), e1 = exp_(d[1] - m), e2 = exp_(d[2] - m);
+                float inv = rcp_(e0 + e1 + e2);
                 dot[i][hd][0] = e0 * inv; dot[i][hd][1] = e1 * inv; dot[i][hd][2] = e2 * inv;
             }
 #pragma unroll
@@ -520,7 +550,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             if (live[u] && h == 0) {
                 const int64_t c = tile[u] * 32 + j;
                 if (c < nv) {
-                    float r = 1.0f / (1.0f + expf(-acc[u][0])), g = 1.0f / (1.0f + expf(-acc[u][1])), b = 1.0f / (1.0f + expf(-acc[u][2]));
+                    float r = rcp_(1.0f + exp_(-acc[u][0])), g = rcp_(1.0f + exp_(-acc[u][1])), b = rcp_(1.0f + exp_(-acc[u][2]));
                     out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma[u]);   // triplane.py:314
                 }
             }
