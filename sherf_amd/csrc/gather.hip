@@ -35,11 +35,14 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
         float4 acc[3];
         if (mode == 2) acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);     // voxel pass adds onto the stored tokens
         else { acc[0] = tok_bias[l]; acc[1] = tok_bias[8 + l]; acc[2] = tok_bias[16 + l]; }
-        float ex[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // extras[tile][12][j]: rows 0-5 = x_c, v_c (copied straight from geom by lanes 0-5), 6-8 = tapped rgb, 9-11 = 0.
+        // They are stored as soon as they are known: carried to the end of the tile they cost 9 VGPRs and the kernel
+        // one wave of occupancy (100 -> <= 96 VGPRs: 4 -> 5 waves/SIMD).
+        float4 rgb = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nv) {
             const float* gm = geom + c * 8;
             const float xc[3] = {gm[0], gm[1], gm[2]};
-            ex[0] = xc[0]; ex[1] = xc[1]; ex[2] = xc[2]; ex[3] = gm[3]; ex[4] = gm[4]; ex[5] = gm[5];
+            if (mode != 2 && l < 6) extras[(tile * 12 + l) * 32 + j] = gm[l];
             // ---- tri-plane: renderer.py:234-243, align_corners=False, zeros padding ----
             float n[3];
 #pragma unroll
@@ -87,7 +90,6 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                 py = clampf((gy + 1.f) * 0.5f * (H - 1), -2.f, (float)H + 1.f);
                 x0 = floorf(px); y0 = floorf(py); fx = px - x0; fy = py - y0;
                 xi = (int)x0; yi = (int)y0;
-                float4 rgb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -98,7 +100,11 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                             axpy4(rgb, w, img4[(size_t)yy * W + xx]);
                         }
                     }
-                ex[6] = rgb.x; ex[7] = rgb.y; ex[8] = rgb.z;
+            }
+            if (mode != 2) {
+                if (l == 6) extras[(tile * 12 + 6) * 32 + j] = rgb.x;
+                if (l == 7) extras[(tile * 12 + 7) * 32 + j] = rgb.y;
+                if (l < 4) extras[(tile * 12 + 8 + l) * 32 + j] = (l == 0) ? rgb.z : 0.f;
             }
             // ---- sparse voxel levels: renderer.py:544-556 + 762-782, align_corners=True ----
             if (!(dbg & 4) && mode != 1) {
@@ -140,6 +146,10 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
             }
         } else {
             acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mode != 2) {                               // padding columns of the last tile
+                extras[(tile * 12 + l) * 32 + j] = 0.f;
+                if (l < 4) extras[(tile * 12 + 8 + l) * 32 + j] = 0.f;
+            }
         }
         // tokens[tile][slot][quad][j] (float4), extras[tile][12][j]
         if (mode == 2) {
@@ -154,11 +164,6 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) tokens[((tile * 3 + s) * 8 + l) * 32 + j] = acc[s];
-        float e0 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e0 = (l == i) ? ex[i] : e0;
-        extras[(tile * 12 + l) * 32 + j] = e0;
-        if (l < 4) extras[(tile * 12 + 8 + l) * 32 + j] = (l == 0) ? ex[8] : 0.f;
     }
 }
 
