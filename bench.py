@@ -139,7 +139,7 @@ def main():
             names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done')
             res['frame_timeline_ms'] = {k: round(float(v), 4) for k, v in zip(names, prof[:, :7].mean(0))}
             res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_dt / a.steps, 4)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:            # reported at N = 1 only (rank 0's host cores)
             res['cpu_baseline'] = cpu_baseline(a.config)
         print(json.dumps(res))
     if world > 1:

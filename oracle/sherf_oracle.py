@@ -502,7 +502,8 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
         if keep:
             out.update(vert_id=vid, vert_d2=d2[valid], x_s=xs, v_s=vs, x_c=x_c, v_c=v_c, x_w=x_w, t_vert_id=tvid, uv=uv,
                        f2d=f2d, tap_rgb=tap_rgb, grid=g, f3d_raw=f3d_raw, f3d=f3d, tokens_in=torch.cat(toks_in),
-                       tokens_out=torch.cat(toks_out), sample_rgb=rgb_s, sample_sigma=sig_s, taps=taps)
+                       tokens_out=torch.cat(toks_out), sample_rgb=rgb_s, sample_sigma=sig_s, taps=taps,
+                       _tok_chunks=toks_in, _z_chunks=toks_out)
     rgb, depth, w = composite(col_full.view(R_, S, 3), sig_full.view(R_, S), t, ray_d, bool(options.get('white_back', False)))
     out.update(rgb=rgb, depth=depth, acc=w.sum(1), weights=w)
     return out
@@ -547,10 +548,18 @@ def stub_loss(rgb, acc):
     return ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
 
 
-def gradients_from_fixture(fx, state):
+STAGE_KEYS = ('sample_rgb', 'sample_sigma', 'tokens_out', 'tokens_in', 'f2d', 'f3d', 'f3d_raw')
+
+
+def gradients_from_fixture(fx, state, stages=False):
     """Backward of the path by autograd through this restatement (training-mode BatchNorm): returns (loss, {name: grad})
     for every renderer / decoder parameter that receives one and for the three feature inputs
-    ('input.planes', 'input.obs_feat', 'input.vertex_feat').  The oracle for the HIP backward kernels (BASELINE config 5)."""
+    ('input.planes', 'input.obs_feat', 'input.vertex_feat').  The oracle for the HIP backward kernels (BASELINE config 5).
+
+    stages=True additionally returns the gradient AT EVERY STAGE BOUNDARY of the forward ('stage.<key>' for STAGE_KEYS:
+    per-sample rgb / sigma = what the compositing backward emits, transformer output / input tokens = what the MLP backward
+    emits, f2d / f3d / f3d_raw = what the gather backward scatters; 'stage.level<i>' = gradient of the i-th tapped voxel
+    level's activations), so each backward kernel can be checked on its own."""
     st = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
     fx = dict(fx)
     leaves = {}
@@ -567,11 +576,26 @@ def gradients_from_fixture(fx, state):
     sp_input = prepare_sp_input(d['t_vertices'].view(-1, 3), obs_can)
     res = render(st, smpl, leaves['input.planes'][0], d['obs_img_all'][0, 0], leaves['input.obs_feat'][0], leaves['input.vertex_feat'],
                  sp_input, d['ray_o_all'][0, 0], d['ray_d_all'][0, 0], d['near_all'][0, 0, :, 0], d['far_all'][0, 0, :, 0], d,
-                 fx['options'], training=True, keep=False)
+                 fx['options'], training=True, keep=stages)
+    watched = {}
+    if stages:
+        for k in STAGE_KEYS:
+            if k in res and res[k].requires_grad:
+                res[k].retain_grad(); watched['stage.' + k] = res[k]
+        for i, (_, feats, _) in enumerate(res.get('taps', [])):
+            if feats.requires_grad:
+                feats.retain_grad(); watched[f'stage.level{i}'] = feats
+        chunked = {'stage.tokens_in': res.get('_tok_chunks', []), 'stage.tokens_out': res.get('_z_chunks', [])}
+        for ts in chunked.values():                      # the graph runs through the per-chunk tensors, not their concatenation
+            for t in ts:
+                t.retain_grad()
     loss = stub_loss(res['rgb'], res['acc'])
     loss.backward()
     grads = {n: t.grad for n, t in leaves.items()}
     grads.update({n: t.grad for n, t in st.items() if t.is_floating_point() and t.grad is not None})
+    grads.update({n: t.grad for n, t in watched.items() if t.grad is not None})
+    if stages:
+        grads.update({n: torch.cat([t.grad for t in ts]) for n, ts in chunked.items() if ts})
     return float(loss.detach()), grads
 
 

@@ -185,3 +185,26 @@ def test_oracle_gradients_match_reference_backward(cfg, state, golden_dir):
     assert extra == [], extra
     k = max(worst, key=lambda n: worst[n][1])
     print(f'{cfg}: worst norm rel err {max(v[0] for v in worst.values()):.2e}, worst sampled entry {worst[k][1]:.2e} ({k})')
+
+
+def test_stage_gradients_are_consistent(state):
+    """The stage-boundary gradients the backward kernels will be checked against (gradients_from_fixture(stages=True)) obey
+    the chain rule across the linear stages: d f3d_raw = d f3d @ W_projection, and the per-sample rgb gradient is the
+    compositing weight times the image gradient."""
+    fx = fixtures.renderer_inputs('tiny_nv')
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    for k in ('sample_rgb', 'sample_sigma', 'tokens_out', 'tokens_in', 'f2d', 'f3d', 'f3d_raw', 'level0', 'level1', 'level2'):
+        assert 'stage.' + k in g, k
+    Wp = state['renderer.conv1d_projection.weight'][:, :, 0]
+    assert _rel(g['stage.f3d'] @ Wp, g['stage.f3d_raw']) < 1e-5
+    r = O.render_from_fixture(fx, state, training=True)
+    rs = np.random.RandomState(11)
+    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1,) + tuple(r['rgb'].shape)).astype(np.float32))[0]
+    d_img = 2.0 * (r['rgb'] - t_rgb) / r['rgb'].numel()                 # d loss / d rgb_final
+    S = r['t'].shape[1]
+    w = r['weights'].reshape(-1)[r['valid']]                              # compositing weight of every valid sample
+    ray = r['valid'] // S
+    assert _rel(g['stage.sample_rgb'], 2.0 * w[:, None] * d_img[ray]) < 1e-4       # rgb_final = 2 * sum(w c) - 1
+    n = g['stage.tokens_in'].shape[0]
+    assert g['stage.tokens_in'].shape == (n, 3, 32) and g['stage.tokens_out'].shape == (n, 3, 32)
+    assert float(g['stage.tokens_out'][:, 2].abs().max()) == 0.0         # the decoder never reads slot 2 (triplane.py:285-316)
