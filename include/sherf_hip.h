@@ -165,6 +165,15 @@ int sherf_composite_compact(const int32_t* counters, const int32_t* ray_base, co
 /* MipRayMarcher2.forward on dense inputs (ray_marcher.py:67-70): colors[R][S][3], sigma[R][S], depths[R][S],
  * rays_d[R][3] -> rgb[R][3], depth[R], weights[R][S].  dminmax[2] (device) = global min/max of depths
  * (ray_marcher.py:57). */
+/* Backward of sherf_composite_compact for a loss that reads rgb and acc (BASELINE config 5; the reference's losses do not
+ * read the depth map, loss.py:103-176): d_rgb[R][3], d_acc[R] -> d_sample_out[capacity][4] = d/d(rgb, sigma) of every
+ * compact sample (autograd of MipRayMarcher2.run_forward, ray_marcher.py:25-64, restricted to the valid samples).
+ * EXPERIMENTAL: written after round 1's GPU budget was spent; not yet exercised on hardware. */
+int sherf_composite_compact_bwd(const int32_t* ray_base, const int32_t* ray_cnt, const int32_t* cs_idx,
+                                const float* sample_out, const float* ray_d, const float* near, const float* far,
+                                int R, int S, int white_back, const float* d_rgb, const float* d_acc,
+                                float* d_sample_out, sherf_stream_t stream);
+
 int sherf_composite_dense(const float* colors, const float* sigma, const float* depths, const float* rays_d,
                           int R, int S, int white_back, const float* dminmax, float* rgb, float* depth,
                           float* weights, sherf_stream_t stream);

@@ -83,6 +83,56 @@ __global__ void __launch_bounds__(256) composite_dense_kernel(const float* __res
     depth[r] = dep;
 }
 
+// Backward of composite_compact_kernel w.r.t. the per-sample (rgb, sigma), for a loss that reads rgb_final and acc
+// (the reference's losses never read the depth map: loss.py:103-176).  With g_c = 2 dL/drgb_final and
+//   g_w[k] = g_c . c_k + dL/dacc - white_back * sum(g_c):
+//   dL/dc_k     = g_c w_k
+//   dL/dalpha_k = g_w[k] T_k - (sum_{m>k} g_w[m] w_m) / (1 - alpha_k + 1e-10)        (T_m carries the factor of sample k)
+//   dL/dsigma_k = dL/dalpha_k * delta_k * exp(-sigma_k delta_k) * [sigma_k > 0]
+// Two forward sweeps over the ray's compact samples: the first takes the total of g_w w, the second rebuilds T, alpha, w
+// and turns the running prefix into the suffix sum.  Same thread-per-ray shape and traffic class as the forward.
+__global__ void __launch_bounds__(256) composite_compact_bwd_kernel(const int32_t* __restrict__ ray_base, const int32_t* __restrict__ ray_cnt,
+                                                                    const int32_t* __restrict__ cs_idx, const float4* __restrict__ sample_out,
+                                                                    const float* __restrict__ ray_d, const float* __restrict__ near,
+                                                                    const float* __restrict__ far, int R, int S, int white_back,
+                                                                    const float* __restrict__ d_rgb, const float* __restrict__ d_acc,
+                                                                    float4* __restrict__ d_sample_out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float d0 = ray_d[r * 3], d1 = ray_d[r * 3 + 1], d2 = ray_d[r * 3 + 2];
+    const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float nr = near[r], range = __fsub_rn(far[r], nr);
+    const int base = ray_base[r], cnt = ray_cnt[r];
+    const float gx = 2.f * d_rgb[r * 3], gy = 2.f * d_rgb[r * 3 + 1], gz = 2.f * d_rgb[r * 3 + 2];
+    const float gconst = d_acc[r] - (white_back ? gx + gy + gz : 0.f);
+    float T = 1.f, total = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+        const int k = cs_idx[base + i] - r * S;
+        const float4 o = sample_out[base + i];
+        const float t = depth_at(nr, range, k, S);
+        const float delta = (k == S - 1 ? 1e10f : depth_at(nr, range, k + 1, S) - t) * dn;
+        const float alpha = 1.f - expf(-(fmaxf(o.w, 0.f) * delta));
+        total += (gx * o.x + gy * o.y + gz * o.z + gconst) * (alpha * T);
+        T = T * (1.f - alpha + 1e-10f);
+    }
+    T = 1.f;
+    float prefix = 0.f;
+    for (int i = 0; i < cnt; ++i) {
+        const int k = cs_idx[base + i] - r * S;
+        const float4 o = sample_out[base + i];
+        const float t = depth_at(nr, range, k, S);
+        const float delta = (k == S - 1 ? 1e10f : depth_at(nr, range, k + 1, S) - t) * dn;
+        const float e = expf(-(fmaxf(o.w, 0.f) * delta));
+        const float alpha = 1.f - e, w = alpha * T;
+        const float gw = gx * o.x + gy * o.y + gz * o.z + gconst;
+        prefix += gw * w;
+        const float dalpha = gw * T - (total - prefix) / (1.f - alpha + 1e-10f);
+        const float dsigma = o.w > 0.f ? dalpha * delta * e : 0.f;
+        d_sample_out[base + i] = make_float4(gx * w, gy * w, gz * w, dsigma);
+        T = T * (1.f - alpha + 1e-10f);
+    }
+}
+
 }  // namespace
 
 extern "C" int sherf_composite_compact(const int32_t* counters, const int32_t* ray_base, const int32_t* ray_cnt,
@@ -104,5 +154,17 @@ extern "C" int sherf_composite_dense(const float* colors, const float* sigma, co
     SHERF_CHECK_ARG(R > 0 && S >= 1);
     hipLaunchKernelGGL(composite_dense_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), colors, sigma, depths,
                        rays_d, R, S, white_back, dminmax, rgb, depth, weights);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_composite_compact_bwd(const int32_t* ray_base, const int32_t* ray_cnt, const int32_t* cs_idx,
+                                           const float* sample_out, const float* ray_d, const float* near, const float* far,
+                                           int R, int S, int white_back, const float* d_rgb, const float* d_acc,
+                                           float* d_sample_out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(ray_base && ray_cnt && cs_idx && sample_out && ray_d && near && far && d_rgb && d_acc && d_sample_out);
+    SHERF_CHECK_ARG(R > 0 && S >= 2);
+    hipLaunchKernelGGL(composite_compact_bwd_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), ray_base, ray_cnt, cs_idx,
+                       reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back, d_rgb, d_acc,
+                       reinterpret_cast<float4*>(d_sample_out));
     SHERF_LAUNCH_CHECK();
 }
