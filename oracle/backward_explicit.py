@@ -1,0 +1,239 @@
+"""TEST INFRASTRUCTURE. Explicit (hand-derived, no autograd) backward of the rendering hot path, stage by stage.
+
+`oracle.sherf_oracle.gradients_from_fixture` gets the gradients by autograd through the forward restatement and is pinned
+to the unmodified reference's backward (tests/golden/grad_*.npz).  This module restates the SAME gradients as explicit
+formulas -- the arithmetic a backward kernel has to implement, loop for loop -- and tests/test_backward_math.py checks it
+against autograd.  Nothing in the product imports it.
+
+Stages, in backward order (names follow SURVEY.md section 8 rows):
+  composite_bwd     a16  (d rgb_final, d acc)            -> d (rgb, sigma) per valid sample
+  decoder_bwd       a14  d (rgb, sigma)                  -> d z (fused tokens 0/1) + decoder parameter gradients
+  transformer_bwd   a13  d z                             -> d tokens_in + transformer parameter gradients
+  fuse_bwd          a13  d tokens_in                     -> d tri-plane taps, d f2d, d f3d + conv1d_reprojection gradients
+  taps_bwd      a10-a12  d taps                          -> d planes, d obs_feat, d voxel-level activations + conv1d_projection
+  encoder_bwd       a11  d voxel-level activations       -> d vertex_feat + sparse conv / BatchNorm parameter gradients
+"""
+import math
+
+import torch
+
+from . import sherf_oracle as O
+
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------------------------
+# a16 compositing
+# ----------------------------------------------------------------------------------------------
+def composite_bwd(colors, sigma, t, rays_d, d_rgb, d_acc, white_back=False):
+    """colors [R,S,3], sigma [R,S] (raw, -80 where masked), t [R,S], rays_d [R,3]; d_rgb [R,3], d_acc [R].
+    -> d_colors [R,S,3], d_sigma [R,S].  (ray_marcher.py:25-64; the depth output carries no gradient.)"""
+    delta = torch.cat([t[:, 1:] - t[:, :-1], torch.full_like(t[:, :1], 1e10)], 1) * torch.norm(rays_d, dim=-1)[:, None]
+    sp = torch.relu(sigma)
+    e = torch.exp(-(sp * delta))
+    alpha = 1 - e
+    fac = 1 - alpha + 1e-10
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), fac], 1), 1)[:, :-1]
+    w = alpha * T
+    g = 2.0 * d_rgb                                                   # rgb_final = 2 * (sum w c [+ 1 - acc]) - 1
+    gw = (colors * g[:, None, :]).sum(-1) + d_acc[:, None] - (g.sum(-1)[:, None] if white_back else 0.0)
+    gww = gw * w
+    suffix = gww.flip(1).cumsum(1).flip(1) - gww                      # sum_{m>k} g_w[m] w_m
+    d_alpha = gw * T - suffix / fac
+    d_sigma = d_alpha * delta * e * (sigma > 0).to(F32)
+    return g[:, None, :] * w[..., None], d_sigma
+
+
+# ----------------------------------------------------------------------------------------------
+# a14 NeRF decoder
+# ----------------------------------------------------------------------------------------------
+def decoder_bwd(state, pe_x, z, pe_v, d_rgb, d_sigma, prefix='decoder.'):
+    """Recomputes the forward (triplane.py:285-316), then backpropagates.  Returns (d_z [n,3,32], {param: grad})."""
+    W = lambda k: state[prefix + k + '.weight']
+    B = lambda k: state[prefix + k + '.bias']
+    x0 = torch.cat([pe_x, z[:, 0]], -1)
+    ins, hs = [], []
+    h = x0
+    for i in range(8):
+        ins.append(h)
+        h = torch.relu(h @ W(f'pts_linears.{i}').t() + B(f'pts_linears.{i}'))
+        hs.append(h)
+        if i == 4:
+            h = torch.cat([x0, h], -1)
+    h7 = h
+    f = h7 @ W('feature_linear').t() + B('feature_linear')
+    vin = torch.cat([f, pe_v, z[:, 1]], -1)
+    gpre = vin @ W('views_linear').t() + B('views_linear')
+    g = torch.relu(gpre)
+    s = torch.sigmoid(g @ W('rgb_linear').t() + B('rgb_linear'))
+    grads = {}
+
+    def lin_bwd(name, d_out, inp):
+        grads[prefix + name + '.weight'] = d_out.t() @ inp
+        grads[prefix + name + '.bias'] = d_out.sum(0)
+        return d_out @ W(name)
+
+    d_lin = d_rgb * (1 + 2 * 0.001) * s * (1 - s)
+    d_g = lin_bwd('rgb_linear', d_lin, g)
+    d_vin = lin_bwd('views_linear', d_g * (gpre > 0).to(F32), vin)
+    d_z = torch.zeros_like(z)
+    d_z[:, 1] = d_vin[:, 128 + 27:]
+    d_h = lin_bwd('feature_linear', d_vin[:, :128], h7) + lin_bwd('alpha_linear', d_sigma[:, None], h7)
+    d_x0 = torch.zeros_like(x0)
+    for i in range(7, -1, -1):
+        d_in = lin_bwd(f'pts_linears.{i}', d_h * (hs[i] > 0).to(F32), ins[i])
+        if i == 5:                                                    # its input was cat([x0, h4])
+            d_x0 += d_in[:, :x0.shape[1]]
+            d_h = d_in[:, x0.shape[1]:]
+        elif i == 0:
+            d_x0 += d_in
+        else:
+            d_h = d_in
+    d_z[:, 0] = d_x0[:, pe_x.shape[1]:]
+    return d_z, grads
+
+
+# ----------------------------------------------------------------------------------------------
+# a13 transformer (one pre-norm layer: attention 3 heads x 16 over the 3 slot tokens, GELU feed-forward)
+# ----------------------------------------------------------------------------------------------
+def _ln_fwd(x, w, b):
+    mu = x.mean(-1, keepdim=True)
+    xc = x - mu
+    inv = 1.0 / torch.sqrt((xc ** 2).mean(-1, keepdim=True) + 1e-5)
+    xh = xc * inv
+    return xh * w + b, (xh, inv)
+
+
+def _ln_bwd(d_y, w, cache):
+    """LayerNorm backward: d_x = inv * (d_xh - mean(d_xh) - xh * mean(d_xh * xh)); -> (d_x, d_w, d_b)."""
+    xh, inv = cache
+    d_xh = d_y * w
+    d_x = inv * (d_xh - d_xh.mean(-1, keepdim=True) - xh * (d_xh * xh).mean(-1, keepdim=True))
+    red = tuple(range(d_y.dim() - 1))
+    return d_x, (d_y * xh).sum(red), d_y.sum(red)
+
+
+def transformer_bwd(state, tok, d_out, prefix='renderer.transformer.layers.0.'):
+    """renderer.py:949-993.  tok [n,3,32] (input tokens), d_out [n,3,32] -> (d_tok, {param: grad})."""
+    p = prefix
+    n = tok.shape[0]
+    Wqkv, Wo, bo = state[p + '0.fn.fn.to_qkv.weight'], state[p + '0.fn.fn.to_out.0.weight'], state[p + '0.fn.fn.to_out.0.bias']
+    W1, b1 = state[p + '1.fn.fn.net.0.weight'], state[p + '1.fn.fn.net.0.bias']
+    W2, b2 = state[p + '1.fn.fn.net.3.weight'], state[p + '1.fn.fn.net.3.bias']
+    # ---- forward with caches ----
+    h0, c0 = _ln_fwd(tok, state[p + '0.fn.norm.weight'], state[p + '0.fn.norm.bias'])
+    qkv = h0 @ Wqkv.t()
+    q, k, v = [t_.view(n, 3, 3, 16).permute(0, 2, 1, 3) for t_ in qkv.chunk(3, -1)]          # [n,head,tok,16]
+    att = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * (16 ** -0.5), -1)              # [n,head,tok,tok]
+    o = torch.matmul(att, v).permute(0, 2, 1, 3).reshape(n, 3, 48)
+    y = o @ Wo.t() + bo + tok
+    h1, c1 = _ln_fwd(y, state[p + '1.fn.norm.weight'], state[p + '1.fn.norm.bias'])
+    u = h1 @ W1.t() + b1
+    cdf = 0.5 * (1 + torch.erf(u / math.sqrt(2.0)))
+    ge = u * cdf
+    grads = {}
+    # ---- feed-forward block: out = ge @ W2^T + b2 + y ----
+    grads[p + '1.fn.fn.net.3.weight'] = torch.einsum('nto,nti->oi', d_out, ge)
+    grads[p + '1.fn.fn.net.3.bias'] = d_out.sum((0, 1))
+    d_ge = d_out @ W2
+    d_u = d_ge * (cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi))             # d/du [u Phi(u)]
+    grads[p + '1.fn.fn.net.0.weight'] = torch.einsum('nto,nti->oi', d_u, h1)
+    grads[p + '1.fn.fn.net.0.bias'] = d_u.sum((0, 1))
+    d_h1 = d_u @ W1
+    d_y, grads[p + '1.fn.norm.weight'], grads[p + '1.fn.norm.bias'] = _ln_bwd(d_h1, state[p + '1.fn.norm.weight'], c1)
+    d_y = d_y + d_out                                                                       # residual
+    # ---- attention block: y = o @ Wo^T + bo + tok ----
+    grads[p + '0.fn.fn.to_out.0.weight'] = torch.einsum('nto,nti->oi', d_y, o)
+    grads[p + '0.fn.fn.to_out.0.bias'] = d_y.sum((0, 1))
+    d_o = (d_y @ Wo).view(n, 3, 3, 16).permute(0, 2, 1, 3)                                  # [n,head,tok,16]
+    d_att = torch.matmul(d_o, v.transpose(-1, -2))
+    d_v = torch.matmul(att.transpose(-1, -2), d_o)
+    d_s = att * (d_att - (d_att * att).sum(-1, keepdim=True)) * (16 ** -0.5)               # softmax backward, then the scale
+    d_q = torch.matmul(d_s, k)
+    d_k = torch.matmul(d_s.transpose(-1, -2), q)
+    d_qkv = torch.cat([t_.permute(0, 2, 1, 3).reshape(n, 3, 48) for t_ in (d_q, d_k, d_v)], -1)
+    grads[p + '0.fn.fn.to_qkv.weight'] = torch.einsum('nto,nti->oi', d_qkv, h0)
+    d_h0 = d_qkv @ Wqkv
+    d_tok, grads[p + '0.fn.norm.weight'], grads[p + '0.fn.norm.bias'] = _ln_bwd(d_h0, state[p + '0.fn.norm.weight'], c0)
+    return d_tok + d_y, grads
+
+
+# ----------------------------------------------------------------------------------------------
+# a13 slot fusion (conv1d_reprojection 96 -> 32 per slot)
+# ----------------------------------------------------------------------------------------------
+def fuse_bwd(state, tri, f2d, f3d, d_tok, prefix='renderer.'):
+    """-> (d_tri [3,n,32], d_f2d [n,96], d_f3d [n,96], {param: grad})  (renderer.py:423-424)."""
+    W = state[prefix + 'conv1d_reprojection.weight'][:, :, 0]
+    n = f2d.shape[0]
+    comb = torch.cat([tri.permute(1, 0, 2), f2d.view(n, 3, 32), f3d.view(n, 3, 32)], -1)       # [n,3,96]
+    grads = {prefix + 'conv1d_reprojection.weight': torch.einsum('nso,nsi->oi', d_tok, comb)[:, :, None],
+             prefix + 'conv1d_reprojection.bias': d_tok.sum((0, 1))}
+    d_comb = d_tok @ W
+    return d_comb[..., :32].permute(1, 0, 2).contiguous(), d_comb[..., 32:64].reshape(n, 96), d_comb[..., 64:].reshape(n, 96), grads
+
+
+# ----------------------------------------------------------------------------------------------
+# a10-a12 feature taps: every tap is linear in the table, so its backward is the same stencil as a scatter-add
+# ----------------------------------------------------------------------------------------------
+def _bilinear_bwd(shape, px, py, d_out):
+    """Transpose of sherf_oracle._bilinear: d_out [n,C] at pixel coords (px,py) -> d_img [C,H,W] (zeros padding)."""
+    C, H, W = shape
+    x0 = torch.floor(px); y0 = torch.floor(py)
+    fx = px - x0; fy = py - y0
+    d_img = torch.zeros(C, H * W)
+    for dy, wy in ((0, 1 - fy), (1, fy)):
+        for dx, wx in ((0, 1 - fx), (1, fx)):
+            xi = (x0 + dx).long(); yi = (y0 + dy).long()
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            lin = yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)
+            d_img.index_add_(1, lin, ((wx * wy * ok.to(F32))[:, None] * d_out).t())
+    return d_img.view(C, H, W)
+
+
+def _grid_sample_2d_bwd(shape, gx, gy, align_corners, d_out):
+    C, H, W = shape
+    if align_corners:
+        px = (gx + 1) / 2 * (W - 1); py = (gy + 1) / 2 * (H - 1)
+    else:
+        px = ((gx + 1) * W - 1) / 2; py = ((gy + 1) * H - 1) / 2
+    return _bilinear_bwd(shape, px, py, d_out)
+
+
+def triplane_bwd(plane_shape, x_c, bounds, d_tri):
+    """d_tri [3,n,32] -> d_planes [3,32,P,P]  (renderer.py:234-243)."""
+    nrm = 2 * (x_c - bounds[0:1]) / (bounds[1:2] - bounds[0:1]) - 1
+    sel = ((0, 1), (0, 2), (2, 1))
+    return torch.stack([_grid_sample_2d_bwd(plane_shape[1:], nrm[:, a], nrm[:, b], False, d_tri[p]) for p, (a, b) in enumerate(sel)])
+
+
+def pixel_aligned_bwd(feat_shape, img_hw, uv, d_f2d):
+    """d_f2d [n,96] -> d_obs_feat [64,Hf,Wf]; the PE(rgb) third of f2d only reaches the (input) image: no gradient kept."""
+    H, W = img_hw
+    g = 2.0 * uv / torch.tensor([W, H], dtype=F32) - 1.0
+    return _grid_sample_2d_bwd(feat_shape, g[:, 0], g[:, 1], True, d_f2d[:, :64])
+
+
+def trilinear_sparse_bwd(keys, n_rows, shape, g, d_out):
+    """Transpose of sherf_oracle.trilinear_sparse: d_out [n,C] -> d_feats [n_rows,C]."""
+    D, H, W = shape
+    px = (g[:, 0] + 1) / 2 * (W - 1); py = (g[:, 1] + 1) / 2 * (H - 1); pz = (g[:, 2] + 1) / 2 * (D - 1)
+    x0, y0, z0 = torch.floor(px), torch.floor(py), torch.floor(pz)
+    fx, fy, fz = px - x0, py - y0, pz - z0
+    d_feats = torch.zeros(n_rows, d_out.shape[1])
+    for dz, wz in ((0, 1 - fz), (1, fz)):
+        for dy, wy in ((0, 1 - fy), (1, fy)):
+            for dx, wx in ((0, 1 - fx), (1, fx)):
+                xi, yi, zi = (x0 + dx).long(), (y0 + dy).long(), (z0 + dz).long()
+                ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H) & (zi >= 0) & (zi < D)
+                k = O._lin(zi, yi, xi, shape)
+                pos = torch.searchsorted(keys, k).clamp(max=keys.numel() - 1)
+                ok &= keys[pos] == k
+                d_feats.index_add_(0, pos, (wx * wy * wz * ok.to(F32))[:, None] * d_out)
+    return d_feats
+
+
+def projection_bwd(state, f3d_raw, d_f3d, prefix='renderer.'):
+    """conv1d_projection 192 -> 96 (renderer.py:350): -> (d_f3d_raw [n,192], {param: grad})."""
+    Wp = state[prefix + 'conv1d_projection.weight'][:, :, 0]
+    return d_f3d @ Wp, {prefix + 'conv1d_projection.weight': (d_f3d.t() @ f3d_raw)[:, :, None],
+                        prefix + 'conv1d_projection.bias': d_f3d.sum(0)}

@@ -66,3 +66,77 @@ def test_composite_backward_formula(cfg, state):
     ref_rgb, ref_sig = g['stage.sample_rgb'].numpy(), g['stage.sample_sigma'].numpy()
     assert np.abs(ours[:, :3] - ref_rgb).max() < 1e-5 * np.abs(ref_rgb).max() + 1e-12
     assert np.abs(ours[:, 3] - ref_sig).max() < 2e-4 * np.abs(ref_sig).max() + 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# explicit (hand-derived) backward, stage by stage, against autograd through the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module', params=['tiny_nv', 'tiny'])
+def case(request, state):
+    fx = fixtures.renderer_inputs(request.param)
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+    return fx, r, g
+
+
+def _close(a, b, tol=1e-4):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    return float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-14
+
+
+def _image_grads(r):
+    R = r['rgb'].shape[0]
+    rs = np.random.RandomState(11)
+    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1, R, 3)).astype(np.float32))[0]
+    t_acc = torch.from_numpy(rs.uniform(0, 1, (1, R, 1)).astype(np.float32))[0, :, 0]
+    return 2.0 * (r['rgb'] - t_rgb) / (R * 3), 2.0 * (r['acc'] - t_acc) / R
+
+
+def test_explicit_composite(case):
+    from oracle import backward_explicit as BX
+    fx, r, g = case
+    R, S = r['t'].shape
+    col = torch.zeros(R * S, 3); sig = torch.full((R * S,), -80.0)
+    col[r['valid']] = r['sample_rgb']; sig[r['valid']] = r['sample_sigma']
+    d_rgb, d_acc = _image_grads(r)
+    ray_d = torch.from_numpy(fx['input_data']['ray_d_all'][0, 0])
+    d_col, d_sig = BX.composite_bwd(col.view(R, S, 3), sig.view(R, S), r['t'], ray_d, d_rgb, d_acc)
+    assert _close(d_col.reshape(-1, 3)[r['valid']], g['stage.sample_rgb'])
+    assert _close(d_sig.reshape(-1)[r['valid']], g['stage.sample_sigma'], 2e-4)
+
+
+def test_explicit_decoder_transformer_fuse(case, state):
+    from oracle import backward_explicit as BX
+    fx, r, g = case
+    pe_x, pe_v = O.positional_encoding(r['x_c'], 6), O.positional_encoding(r['v_c'], 4)
+    d_z, gd = BX.decoder_bwd(state, pe_x, r['tokens_out'], pe_v, g['stage.sample_rgb'], g['stage.sample_sigma'])
+    assert _close(d_z, g['stage.tokens_out'])
+    for k, v in gd.items():
+        assert _close(v, g[k], 2e-4), k
+    d_tok, gt = BX.transformer_bwd(state, r['tokens_in'], g['stage.tokens_out'])
+    assert _close(d_tok, g['stage.tokens_in'], 2e-4)
+    for k, v in gt.items():
+        assert _close(v, g[k], 5e-4), k
+    bounds = torch.from_numpy(fx['input_data']['t_world_bounds']).view(2, 3)
+    tri = O.triplane_features(torch.from_numpy(fx['planes'])[0], r['x_c'], bounds)
+    d_tri, d_f2d, d_f3d, gf = BX.fuse_bwd(state, tri, r['f2d'], r['f3d'], g['stage.tokens_in'])
+    assert _close(d_f2d, g['stage.f2d']) and _close(d_f3d, g['stage.f3d'])
+    for k, v in gf.items():
+        assert _close(v, g[k], 2e-4), k
+    # taps: tri-plane scatter, pixel-aligned scatter, conv1d_projection, voxel trilinear scatter
+    d_planes = BX.triplane_bwd(fx['planes'].shape[1:], r['x_c'], bounds, d_tri)
+    assert _close(d_planes, g['input.planes'][0], 2e-4)
+    H, W = fx['input_data']['obs_img_all'].shape[-2:]
+    d_feat = BX.pixel_aligned_bwd(fx['obs_feat'].shape[1:], (H, W), r['uv'], g['stage.f2d'])
+    assert _close(d_feat, g['input.obs_feat'][0], 2e-4)
+    d_raw, gp = BX.projection_bwd(state, r['f3d_raw'], g['stage.f3d'])
+    assert _close(d_raw, g['stage.f3d_raw'])
+    for k, v in gp.items():
+        assert _close(v, g[k], 2e-4), k
+    off = 0
+    for i, (keys, feats, shape) in enumerate(r['taps']):
+        C = feats.shape[1]
+        d_lv = BX.trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], g['stage.f3d_raw'][:, off:off + C])
+        assert _close(d_lv, g[f'stage.level{i}'], 2e-4), i
+        off += C
