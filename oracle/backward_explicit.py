@@ -237,3 +237,173 @@ def projection_bwd(state, f3d_raw, d_f3d, prefix='renderer.'):
     Wp = state[prefix + 'conv1d_projection.weight'][:, :, 0]
     return d_f3d @ Wp, {prefix + 'conv1d_projection.weight': (d_f3d.t() @ f3d_raw)[:, :, None],
                         prefix + 'conv1d_projection.bias': d_f3d.sum(0)}
+
+
+# ----------------------------------------------------------------------------------------------
+# a11 sparse voxel encoder: forward with caches (same arithmetic as sherf_oracle.sparse_encoder), then backward
+# ----------------------------------------------------------------------------------------------
+def _bn_relu_fwd(raw, mult, n_rows, gamma, beta):
+    """Training-mode BatchNorm1d(eps 1e-3) + ReLU over the reference's ROW set: `raw` holds the U rows that carry a conv
+    result, the other n_rows - U rows are zeros (losing duplicates).  -> per-voxel output, cache."""
+    mean = raw.sum(0) / n_rows
+    var = (((raw - mean) ** 2).sum(0) + (n_rows - raw.shape[0]) * mean ** 2) / n_rows
+    inv = 1.0 / torch.sqrt(var + 1e-3)
+    xh = (raw - mean) * inv
+    y = xh * gamma + beta
+    xh0 = -mean * inv                                    # the zero rows
+    y0 = xh0 * gamma + beta
+    out = torch.relu(y) + (mult - 1).to(F32)[:, None] * torch.relu(y0)[None]
+    return out, (xh, inv, y, xh0, y0, mult, n_rows)
+
+
+def _bn_relu_bwd(d_out, gamma, cache):
+    """-> (d_raw [U,C], d_gamma, d_beta).  Standard BatchNorm backward over all n_rows rows, where the n_rows - U zero rows
+    share one value: only the SUM of their upstream gradients matters (d_y0)."""
+    xh, inv, y, xh0, y0, mult, n_rows = cache
+    d_y = d_out * (y > 0).to(F32)
+    d_y0 = ((mult - 1).to(F32)[:, None] * d_out).sum(0) * (y0 > 0).to(F32)
+    s1 = d_y.sum(0) + d_y0                               # sum over the row set of dL/dy
+    s2 = (d_y * xh).sum(0) + d_y0 * xh0                  # sum of dL/dy * xhat
+    d_raw = (gamma * inv / n_rows) * (n_rows * d_y - s1 - xh * s2)
+    return d_raw, s2, s1
+
+
+def encoder_forward_cached(state, feat, coord, out_sh, prefix='renderer.encoder_3d.'):
+    """sherf_oracle.sparse_encoder (training mode) keeping what the backward needs.  -> (taps, cache list)."""
+    sh = [int(v) for v in out_sh]
+    c = coord.long()
+    keys = O._lin(c[:, 1], c[:, 2], c[:, 3], sh)
+    uk, inv = torch.unique(keys, sorted=True, return_inverse=True)
+    mult = torch.bincount(inv, minlength=uk.numel())
+    g = torch.zeros(uk.numel(), feat.shape[1]).index_add_(0, inv, feat)
+    n_rows = feat.shape[0]
+    taps, cache = [], [('input', inv)]
+    for name, kind, nconv in O._ENC_LAYERS:
+        if name == 'TAP':
+            taps.append((uk.clone(), g.clone(), list(sh)))
+            cache.append(('tap',))
+            continue
+        z = uk // (sh[1] * sh[2]); y = (uk // sh[2]) % sh[1]; x = uk % sh[2]
+        if kind == 'subm':
+            for ci in range(nconv):
+                wname, bname = f'{prefix}{name}.{3 * ci}', f'{prefix}{name}.{3 * ci + 1}'
+                W = state[wname + '.weight']                                   # [out,3,3,3,in]
+                raw = torch.zeros(uk.numel(), W.shape[0])
+                pairs = []                                                     # (tap, output rows, input rows)
+                for kk in range(27):
+                    kz, ky, kx = kk // 9, (kk // 3) % 3, kk % 3
+                    qz, qy, qx = z + kz - 1, y + ky - 1, x + kx - 1
+                    ok = (qz >= 0) & (qz < sh[0]) & (qy >= 0) & (qy < sh[1]) & (qx >= 0) & (qx < sh[2])
+                    qk = O._lin(qz, qy, qx, sh)
+                    pos = torch.searchsorted(uk, qk).clamp(max=uk.numel() - 1)
+                    ok &= uk[pos] == qk
+                    o = torch.nonzero(ok)[:, 0]
+                    if o.numel():
+                        raw[o] += g[pos[o]] @ W[:, kz, ky, kx, :].t()
+                        pairs.append((kk, o, pos[o]))
+                g_in = g
+                g, bnc = _bn_relu_fwd(raw, mult, n_rows, state[bname + '.weight'], state[bname + '.bias'])
+                cache.append(('conv', wname, bname, pairs, g_in, bnc))
+        else:
+            wname, bname = f'{prefix}{name}.0', f'{prefix}{name}.1'
+            W = state[wname + '.weight']
+            osh = [(d - 1) // 2 + 1 for d in sh]
+            key_all, src_all, k_all = [], [], []
+            for kk in range(27):
+                kz, ky, kx = kk // 9, (kk // 3) % 3, kk % 3
+                nz, ny, nx = z + 1 - kz, y + 1 - ky, x + 1 - kx
+                ok = (nz % 2 == 0) & (ny % 2 == 0) & (nx % 2 == 0)
+                oz, oy, ox = nz // 2, ny // 2, nx // 2
+                ok &= (oz >= 0) & (oz < osh[0]) & (oy >= 0) & (oy < osh[1]) & (ox >= 0) & (ox < osh[2])
+                o = torch.nonzero(ok)[:, 0]
+                key_all.append(O._lin(oz, oy, ox, osh)[o]); src_all.append(o); k_all.append(torch.full_like(o, kk))
+            key_all = torch.cat(key_all); src_all = torch.cat(src_all); k_all = torch.cat(k_all)
+            nuk, ninv = torch.unique(key_all, sorted=True, return_inverse=True)
+            raw = torch.zeros(nuk.numel(), W.shape[0])
+            Wf = W.reshape(W.shape[0], 27, W.shape[4])
+            pairs = []
+            for kk in range(27):
+                m = k_all == kk
+                if m.any():
+                    raw.index_add_(0, ninv[m], g[src_all[m]] @ Wf[:, kk, :].t())
+                    pairs.append((kk, ninv[m], src_all[m]))
+            g_in = g
+            uk, sh = nuk, osh
+            mult = torch.ones(uk.numel(), dtype=torch.long)
+            n_rows = uk.numel()
+            g, bnc = _bn_relu_fwd(raw, mult, n_rows, state[bname + '.weight'], state[bname + '.bias'])
+            cache.append(('conv', wname, bname, pairs, g_in, bnc))
+    return taps, cache
+
+
+def encoder_bwd(state, cache, d_taps):
+    """d_taps: gradients of the three tapped levels' activations (in tap order).  -> (d_vertex_feat [N,32], {param: grad}).
+    Per conv layer: BatchNorm+ReLU backward over the row set, then for every tap's (output row, input row) pairs
+    d_in[input] += d_raw[output] @ W_tap and dW_tap += d_raw[output]^T in[input]."""
+    grads = {}
+    d_g = None
+    tap_i = len(d_taps) - 1
+    for entry in reversed(cache):
+        if entry[0] == 'tap':
+            d_g = d_taps[tap_i] if d_g is None else d_g + d_taps[tap_i]
+            tap_i -= 1
+        elif entry[0] == 'conv':
+            _, wname, bname, pairs, g_in, bnc = entry
+            W = state[wname + '.weight']                                       # [out,3,3,3,in]
+            d_raw, grads[bname + '.weight'], grads[bname + '.bias'] = _bn_relu_bwd(d_g, state[bname + '.weight'], bnc)
+            dW = torch.zeros_like(W).reshape(W.shape[0], 27, W.shape[4])
+            d_in = torch.zeros_like(g_in)
+            Wf = W.reshape(W.shape[0], 27, W.shape[4])
+            for kk, o, src in pairs:
+                d_in.index_add_(0, src, d_raw[o] @ Wf[:, kk, :])
+                dW[:, kk, :] = d_raw[o].t() @ g_in[src]
+            grads[wname + '.weight'] = dW.reshape(W.shape)
+            d_g = d_in
+        else:                                                                   # level-0 aggregation of duplicate rows
+            return d_g[entry[1]], grads
+    raise AssertionError('cache without input entry')
+
+
+# ----------------------------------------------------------------------------------------------
+# the whole chain
+# ----------------------------------------------------------------------------------------------
+def backward_from_fixture(fx, state):
+    """Forward by the restatement (training mode), then every stage's explicit backward in order, under the stub loss of
+    BASELINE config 5 (sherf_oracle.stub_loss).  -> (loss, {name: grad}) with the same keys as
+    sherf_oracle.gradients_from_fixture: every renderer / decoder parameter + 'input.planes|obs_feat|vertex_feat'."""
+    import numpy as np
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+        R, S = r['t'].shape
+        loss = O.stub_loss(r['rgb'], r['acc'])
+        rs = np.random.RandomState(11)
+        t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1, R, 3)).astype(np.float32))[0]
+        t_acc = torch.from_numpy(rs.uniform(0, 1, (1, R, 1)).astype(np.float32))[0, :, 0]
+        d_rgb_img, d_acc = 2.0 * (r['rgb'] - t_rgb) / (R * 3), 2.0 * (r['acc'] - t_acc) / R
+        valid = r['valid']
+        col = torch.zeros(R * S, 3); sig = torch.full((R * S,), -80.0)
+        col[valid] = r['sample_rgb']; sig[valid] = r['sample_sigma']
+        ray_d = torch.from_numpy(np.ascontiguousarray(fx['input_data']['ray_d_all'][0, 0]))
+        d_col, d_sig = composite_bwd(col.view(R, S, 3), sig.view(R, S), r['t'], ray_d, d_rgb_img, d_acc,
+                                     bool(fx['options'].get('white_back', False)))
+        grads = {}
+        pe_x, pe_v = O.positional_encoding(r['x_c'], 6), O.positional_encoding(r['v_c'], 4)
+        d_z, g = decoder_bwd(state, pe_x, r['tokens_out'], pe_v, d_col.reshape(-1, 3)[valid], d_sig.reshape(-1)[valid]); grads.update(g)
+        d_tok, g = transformer_bwd(state, r['tokens_in'], d_z); grads.update(g)
+        bounds = torch.from_numpy(np.ascontiguousarray(fx['input_data']['t_world_bounds'])).view(2, 3)
+        planes = torch.from_numpy(np.ascontiguousarray(fx['planes']))[0]
+        tri = O.triplane_features(planes, r['x_c'], bounds)
+        d_tri, d_f2d, d_f3d, g = fuse_bwd(state, tri, r['f2d'], r['f3d'], d_tok); grads.update(g)
+        grads['input.planes'] = triplane_bwd(planes.shape, r['x_c'], bounds, d_tri)[None]
+        H, W = fx['input_data']['obs_img_all'].shape[-2:]
+        grads['input.obs_feat'] = pixel_aligned_bwd(fx['obs_feat'].shape[1:], (H, W), r['uv'], d_f2d)[None]
+        d_raw, g = projection_bwd(state, r['f3d_raw'], d_f3d); grads.update(g)
+        sp = r['sp_input']
+        taps, cache = encoder_forward_cached(state, torch.from_numpy(np.ascontiguousarray(fx['vertex_feat'])), sp['coord'], sp['out_sh'])
+        d_taps, off = [], 0
+        for keys, feats, shape in taps:
+            C = feats.shape[1]
+            d_taps.append(trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], d_raw[:, off:off + C]))
+            off += C
+        grads['input.vertex_feat'], g = encoder_bwd(state, cache, d_taps); grads.update(g)
+    return float(loss), grads

@@ -140,3 +140,35 @@ def test_explicit_decoder_transformer_fuse(case, state):
         d_lv = BX.trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], g['stage.f3d_raw'][:, off:off + C])
         assert _close(d_lv, g[f'stage.level{i}'], 2e-4), i
         off += C
+
+
+def test_explicit_sparse_encoder(case, state):
+    """BatchNorm (batch statistics over the reference's row set, duplicate voxels included) + sparse conv backward."""
+    from oracle import backward_explicit as BX
+    fx, r, g = case
+    sp = r['sp_input']
+    with torch.no_grad():
+        taps, cache = BX.encoder_forward_cached(state, torch.from_numpy(fx['vertex_feat']), sp['coord'], sp['out_sh'])
+        for (k1, f1, s1), (k2, f2, s2) in zip(taps, r['taps']):
+            assert torch.equal(k1, k2) and _close(f1, f2, 1e-6)
+        d_vf, ge = BX.encoder_bwd(state, cache, [g[f'stage.level{i}'] for i in range(3)])
+    assert _close(d_vf, g['input.vertex_feat'], 5e-4)
+    names = [k for k in g if k.startswith('renderer.encoder_3d.')]
+    assert len(names) == 39 and set(names) == set(ge)
+    for k in names:
+        assert _close(ge[k], g[k], 2e-3), (k, float((ge[k] - g[k]).abs().max()), float(g[k].abs().max()))
+
+
+@pytest.mark.parametrize('cfg', ['tiny_nv', 'tiny'])
+def test_explicit_chain_matches_reference_gradients(cfg, state, golden_dir):
+    """The whole explicit chain against the fingerprints of the UNMODIFIED reference's gradients (make_golden.run_grad)."""
+    from oracle import backward_explicit as BX
+    ref = np.load(os.path.join(golden_dir, f'grad_{cfg}.npz'))
+    loss, grads = BX.backward_from_fixture(fixtures.renderer_inputs(cfg), state)
+    assert abs(loss - float(ref['loss'])) < 1e-5 * abs(float(ref['loss']))
+    names = [k for k in ref.files if k not in ('loss', 'ref_cpu_seconds')]
+    assert set(names) == set(grads), (set(names) ^ set(grads))
+    for k in names:
+        ours, r = O.grad_fingerprint(grads[k]), ref[k]
+        assert abs(ours[2] - r[2]) < 5e-3 * r[2] + 1e-30, (k, ours[2], r[2])                           # L2 norm
+        assert np.linalg.norm(ours[3:] - r[3:]) < 2e-2 * np.linalg.norm(r[3:]) + 1e-30, k            # 64 sampled entries
