@@ -407,3 +407,57 @@ def backward_from_fixture(fx, state):
             off += C
         grads['input.vertex_feat'], g = encoder_bwd(state, cache, d_taps); grads.update(g)
     return float(loss), grads
+
+
+# ----------------------------------------------------------------------------------------------
+# the same tap / fusion backward in the FOLDED formulation the HIP path uses (sherf_amd/renderer.py: _weights):
+# forward  tokens[n][s] = tok_bias_s + taps(planes_f[s]) + taps(feat_f[:, 32s:32s+32]) (s < 2) + taps(rows_fold_l[:, 32s:32s+32])
+#          planes_f[p][texel] = Wa planes[p][:, texel],  feat_f[texel][32s:] = Wb obs_feat[32s:32s+32, texel],
+#          rows_fold_l[row][32s:] = (Wc Wp[32s:32s+32, cols_l]) act_l[row],  tok_bias_s = br + Wc bp[32s:32s+32]
+#          (+ slot 2 gets Wb PE(rgb)[:32] inside the MLP kernel)
+# backward = (i) ONE scatter of d_tokens with the forward's tap weights into d_planes_f / d_feat_f / d_rows_fold_l,
+#            (ii) small dense "unfold" products per texel / row.
+# ----------------------------------------------------------------------------------------------
+def folded_taps_bwd(state, fx_planes, fx_obs_feat, img_hw, r, d_tok, prefix='renderer.'):
+    """r: forward intermediates of sherf_oracle.render (x_c, uv, grid, taps, tap_rgb); d_tok [n,3,32].
+    -> dict(d_planes, d_obs_feat, d_levels[3], grads{conv1d_reprojection.*, conv1d_projection.*})."""
+    Wr = state[prefix + 'conv1d_reprojection.weight'][:, :, 0]
+    Wp = state[prefix + 'conv1d_projection.weight'][:, :, 0]
+    bp = state[prefix + 'conv1d_projection.bias']
+    Wa, Wb, Wc = Wr[:, 0:32], Wr[:, 32:64], Wr[:, 64:96]
+    n = d_tok.shape[0]
+    # ---- (i) scatter with the forward's stencils ----
+    d_planes_f = triplane_bwd((3, 32) + tuple(fx_planes.shape[-2:]), r['x_c'], r['_bounds'], d_tok.permute(1, 0, 2))   # [3,32,P,P]
+    H, W = img_hw
+    g = 2.0 * r['uv'] / torch.tensor([W, H], dtype=F32) - 1.0
+    d_feat_f = _grid_sample_2d_bwd((64,) + tuple(fx_obs_feat.shape[-2:]), g[:, 0], g[:, 1], True, d_tok[:, :2].reshape(n, 64))
+    d_rows = [trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], d_tok.reshape(n, 96)) for keys, feats, shape in r['taps']]
+    d_bias = d_tok.sum(0)                                                                    # [3,32]
+    # ---- (ii) unfold ----
+    out, dWa, dWb, dWc = {}, torch.zeros(32, 32), torch.zeros(32, 32), torch.zeros(32, 32)
+    out['d_planes'] = torch.einsum('oi,pohw->pihw', Wa, d_planes_f)
+    dWa = torch.einsum('pohw,pihw->oi', d_planes_f, fx_planes)
+    df = d_feat_f.view(2, 32, *d_feat_f.shape[-2:])
+    out['d_obs_feat'] = torch.einsum('oi,sohw->sihw', Wb, df).reshape(64, *d_feat_f.shape[-2:])
+    dWb = torch.einsum('sohw,sihw->oi', df, fx_obs_feat.view(2, 32, *fx_obs_feat.shape[-2:]))
+    dWb = dWb + d_tok[:, 2].t() @ O.positional_encoding(r['tap_rgb'], 5)[:, :32]           # slot 2: PE(rgb) @ Wb^T
+    dWp = torch.zeros_like(Wp)
+    cols = ((0, 32), (32, 96), (96, 192))
+    out['d_levels'] = []
+    for (c0, c1), d_row, (keys, act, shape) in zip(cols, d_rows, r['taps']):
+        d_act = torch.zeros_like(act)
+        for s in range(3):
+            F_ls = Wc @ Wp[32 * s:32 * s + 32, c0:c1]                                        # [32, C_l]
+            d_blk = d_row[:, 32 * s:32 * s + 32]                                             # [rows, 32]
+            d_act += d_blk @ F_ls
+            G = d_blk.t() @ act                                                              # dF_ls [32, C_l]
+            dWc += G @ Wp[32 * s:32 * s + 32, c0:c1].t()
+            dWp[32 * s:32 * s + 32, c0:c1] += Wc.t() @ G
+        out['d_levels'].append(d_act)
+    d_bp = torch.cat([Wc.t() @ d_bias[s] for s in range(3)])
+    for s in range(3):
+        dWc += torch.outer(d_bias[s], bp[32 * s:32 * s + 32])
+    out['grads'] = {prefix + 'conv1d_reprojection.weight': torch.cat([dWa, dWb, dWc], 1)[:, :, None],
+                    prefix + 'conv1d_reprojection.bias': d_bias.sum(0),
+                    prefix + 'conv1d_projection.weight': dWp[:, :, None], prefix + 'conv1d_projection.bias': d_bp}
+    return out

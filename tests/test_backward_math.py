@@ -172,3 +172,20 @@ def test_explicit_chain_matches_reference_gradients(cfg, state, golden_dir):
         ours, r = O.grad_fingerprint(grads[k]), ref[k]
         assert abs(ours[2] - r[2]) < 5e-3 * r[2] + 1e-30, (k, ours[2], r[2])                           # L2 norm
         assert np.linalg.norm(ours[3:] - r[3:]) < 2e-2 * np.linalg.norm(r[3:]) + 1e-30, k            # 64 sampled entries
+
+
+def test_folded_formulation_of_the_tap_backward(case, state):
+    """The HIP path applies conv1d_projection / conv1d_reprojection to the TABLES (linearity of interpolation); its backward
+    is one scatter of d_tokens into the folded tables' gradients plus per-texel / per-row unfold products."""
+    from oracle import backward_explicit as BX
+    fx, r, g = case
+    r = dict(r)
+    r['_bounds'] = torch.from_numpy(fx['input_data']['t_world_bounds']).view(2, 3)
+    H, W = fx['input_data']['obs_img_all'].shape[-2:]
+    out = BX.folded_taps_bwd(state, torch.from_numpy(fx['planes'])[0], torch.from_numpy(fx['obs_feat'])[0], (H, W), r, g['stage.tokens_in'])
+    assert _close(out['d_planes'], g['input.planes'][0], 2e-4)
+    assert _close(out['d_obs_feat'], g['input.obs_feat'][0], 2e-4)
+    for i in range(3):
+        assert _close(out['d_levels'][i], g[f'stage.level{i}'], 5e-4), i
+    for k, v in out['grads'].items():
+        assert _close(v, g[k], 5e-4), k
