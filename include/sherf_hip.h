@@ -140,6 +140,15 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
  *   out[g*group_base + pix*pix_stride + o] = sum_c Wt[c][o] * in[(g*32 + c)*HW + pix],  g < groups.
  * planes [3*32][P*P] -> [3][P*P][32] (pix_stride 32, group_base P*P*32); feature map [2*32][HW] -> [HW][64]
  * (pix_stride 64, group_base 32). */
+/* Backward of sherf_gather_tokens (BASELINE config 5): d_tokens (tile-major, like tokens) is scattered with the forward's
+ * tap weights into the gradients of the folded tables -- d_planes_f [3][P][P][32], d_feat_f [Hf][Wf][64], d_rows{0,1,2}
+ * [n_rows_l][96] of the three voxel levels -- and summed into d_tok_bias[3][32].  All outputs must be zeroed by the caller.
+ * fp32 hardware atomics (order dependent in the last ulp).  EXPERIMENTAL: not yet exercised on hardware. */
+int sherf_gather_tokens_bwd(const int32_t* counters, const float* geom, const float* d_tokens, int P, int Hf, int Wf,
+                            int H, int W, const sherf_vox_level* levels_host, const float* bounds, const float* vox_min,
+                            const int32_t* vox_sh_host, int64_t capacity, float* d_planes_f, float* d_feat_f,
+                            float* d_rows0, float* d_rows1, float* d_rows2, float* d_tok_bias, sherf_stream_t stream);
+
 int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int groups, int pix_stride,
                       int64_t group_base, sherf_stream_t stream);
 /* obs image [3][HW] -> [HW][4] (rgb0) for the rgb tap of renderer.py:336 */

@@ -167,6 +167,128 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the gather (BASELINE config 5; oracle/backward_explicit.py: folded_taps_bwd, step (i)): every tap is linear
+// in its table, so d_tokens is scattered with the forward's tap weights into the gradients of the FOLDED tables
+// (d_planes_f, d_feat_f, d_rows of the three voxel levels; zeroed by the caller) -- same stencils, same lane mapping
+// (8 lanes x float4 per sample), loads replaced by hardware fp32 atomic adds (sums are order dependent in the last ulp,
+// like the reference's grid_sample backward).  d_tok_bias[3][32] = sum over samples, reduced per workgroup first.
+// EXPERIMENTAL: not yet exercised on hardware.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scatter4(float4* dst, float w, const float4 d) {
+    float* p = reinterpret_cast<float*>(dst);
+    unsafeAtomicAdd(p + 0, w * d.x); unsafeAtomicAdd(p + 1, w * d.y); unsafeAtomicAdd(p + 2, w * d.z); unsafeAtomicAdd(p + 3, w * d.w);
+}
+
+struct LevelsBwd { sherf_vox_level l[3]; float* d_rows[3]; };
+
+__global__ void __launch_bounds__(256) gather_tokens_bwd_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
+                                                                const float4* __restrict__ d_tokens, int P, int Hf, int Wf, int H, int W,
+                                                                LevelsBwd lv, const float* __restrict__ bounds,
+                                                                const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
+                                                                float4* __restrict__ d_planes_f, float4* __restrict__ d_feat_f,
+                                                                float* __restrict__ d_tok_bias) {
+    __shared__ float s_bias[3][32];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    const int l = threadIdx.x & 7, j = threadIdx.x >> 3;
+    float4 bsum[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t c = tile * 32 + j;
+        if (c >= nv) continue;
+        float4 d[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            d[s] = d_tokens[((tile * 3 + s) * 8 + l) * 32 + j];
+            bsum[s].x += d[s].x; bsum[s].y += d[s].y; bsum[s].z += d[s].z; bsum[s].w += d[s].w;
+        }
+        const float* gm = geom + c * 8;
+        const float xc[3] = {gm[0], gm[1], gm[2]};
+        // ---- tri-plane (align_corners=False, zeros padding): slot p <- plane p ----
+        float n[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float ga = p == 2 ? n[2] : n[0];
+            const float gb = p == 1 ? n[2] : n[1];
+            float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+            float py = clampf(((gb + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+            float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+            int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    int xx = xi + dx, yy = yi + dy;
+                    if (xx >= 0 && xx < P && yy >= 0 && yy < P)
+                        scatter4(d_planes_f + ((size_t)(p * P + yy) * P + xx) * 8 + l, (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy), d[p]);
+                }
+        }
+        // ---- pixel-aligned feature map (align_corners=True): slots 0, 1 ----
+        {
+            float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
+            float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
+            float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
+            float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+            int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    int xx = xi + dx, yy = yi + dy;
+                    if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
+                        const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                        float4* t = d_feat_f + ((size_t)yy * Wf + xx) * 16;
+                        scatter4(t + l, w, d[0]);
+                        scatter4(t + 8 + l, w, d[1]);
+                    }
+                }
+        }
+        // ---- sparse voxel levels (align_corners=True): all three slots ----
+        {
+            float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;
+            float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
+            float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
+#pragma unroll 1
+            for (int L = 0; L < 3; ++L) {
+                const sherf_vox_level& lev = lv.l[L];
+                float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
+                float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
+                float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                float fx = px - x0, fy = py - y0, fz = pz - z0;
+                int xi = (int)x0, yi = (int)y0, zi = (int)z0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int xx = xi + (t & 1), yy = yi + ((t >> 1) & 1), zz = zi + (t >> 2);
+                    if (!(xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D)) continue;
+                    const int key = (zz * lev.H + yy) * lev.W + xx;
+                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                    const uint32_t bit = 1u << (key & 31);
+                    if (!(rr.x & bit)) continue;
+                    const size_t row = rr.y + __popc(rr.x & (bit - 1u));
+                    const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
+                    float4* rp = reinterpret_cast<float4*>(lv.d_rows[L]) + row * 24;
+                    scatter4(rp + l, w, d[0]);
+                    scatter4(rp + 8 + l, w, d[1]);
+                    scatter4(rp + 16 + l, w, d[2]);
+                }
+            }
+        }
+    }
+    // d_tok_bias: sum this thread's samples over the block's 32 sample lanes, then 96 atomics per workgroup
+    for (int i = threadIdx.x; i < 96; i += 256) (&s_bias[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        atomicAdd(&s_bias[s][4 * l + 0], bsum[s].x); atomicAdd(&s_bias[s][4 * l + 1], bsum[s].y);
+        atomicAdd(&s_bias[s][4 * l + 2], bsum[s].z); atomicAdd(&s_bias[s][4 * l + 3], bsum[s].w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 96; i += 256) unsafeAtomicAdd(d_tok_bias + i, (&s_bias[0][0])[i]);
+}
+
 }  // namespace
 
 extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
@@ -188,5 +310,26 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
                        geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_gather_tokens_bwd(const int32_t* counters, const float* geom, const float* d_tokens, int P, int Hf, int Wf,
+                                       int H, int W, const sherf_vox_level* levels_host, const float* bounds, const float* vox_min,
+                                       const int32_t* vox_sh_host, int64_t capacity, float* d_planes_f, float* d_feat_f,
+                                       float* d_rows0, float* d_rows1, float* d_rows2, float* d_tok_bias, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && geom && d_tokens && levels_host && bounds && vox_min && vox_sh_host && d_planes_f && d_feat_f &&
+                    d_rows0 && d_rows1 && d_rows2 && d_tok_bias);
+    SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
+    LevelsBwd lv = {};
+    for (int i = 0; i < 3; ++i) {
+        lv.l[i] = levels_host[i];
+        SHERF_CHECK_ARG(lv.l[i].wp && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
+    }
+    lv.d_rows[0] = d_rows0; lv.d_rows[1] = d_rows1; lv.d_rows[2] = d_rows2;
+    int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
+    const int64_t tiles = (capacity + 31) / 32;
+    hipLaunchKernelGGL(gather_tokens_bwd_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
+                       geom, reinterpret_cast<const float4*>(d_tokens), P, Hf, Wf, H, W, lv, bounds, vox_min, sh, capacity,
+                       reinterpret_cast<float4*>(d_planes_f), reinterpret_cast<float4*>(d_feat_f), d_tok_bias);
     SHERF_LAUNCH_CHECK();
 }
