@@ -1,0 +1,73 @@
+/* sherf_hip_bwd.h -- C ABI of libsherf_hip_bwd.so: building blocks of the BACKWARD of SHERF's rendering hot path
+ * (BASELINE config 5: forward render + backward through HIP kernels).
+ *
+ * EXPERIMENTAL. Written after round 1's GPU budget was spent: every entry point compiles for gfx950 and mirrors, loop for
+ * loop, a function of oracle/backward_explicit.py that is verified on the CPU against autograd and against the unmodified
+ * reference's gradients -- but none of it has run on hardware yet.  Kept in its own library (it links rocBLAS for the
+ * plain GEMMs of the dense layers) so the forward library libsherf_hip.so is untouched.
+ *
+ * Conventions: as sherf_hip.h (device pointers, caller-owned, launch on `stream`, 0 / negative error code).  Matrices are
+ * row-major fp32 with an explicit leading dimension (`ld*`, in elements).  Correctness first: fp32 everywhere.
+ */
+#ifndef SHERF_HIP_BWD_H
+#define SHERF_HIP_BWD_H
+#include <stdint.h>
+
+#include "sherf_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sherf_bwd_last_error(void);
+
+/* C[M][N] = op(A)[M][K] . op(B)[K][N] + beta * C   (row-major; op = transpose when trans* != 0).  rocBLAS sgemm on
+ * `stream` (handle created once per device by the library).  Replaces every `x @ W.t()` / `d.t() @ x` of
+ * oracle/backward_explicit.py (decoder_bwd.lin_bwd, transformer_bwd). */
+int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, float beta, sherf_stream_t stream);
+
+/* tokens / extras of the forward (tile-major, sherf_gather_tokens) -> row-major tok[n][96], ext[n][12]; and the inverse
+ * for d_tokens (rows beyond n are zero filled up to the tile boundary). */
+int sherf_bwd_untile(const float* tokens_tiled, const float* extras_tiled, int64_t n, float* tok, float* ext,
+                     sherf_stream_t stream);
+int sherf_bwd_tile_tokens(const float* d_tok, int64_t n, float* d_tokens_tiled, sherf_stream_t stream);
+
+/* y[r][c] = act(y[r][c] + bias[c]) in place, act 0 = none, 1 = ReLU (bias may be NULL). */
+int sherf_bwd_bias_act(float* y, int ldy, const float* bias, int64_t n, int C, int act, sherf_stream_t stream);
+/* d[r][c] = h[r][c] > 0 ? d[r][c] : 0  (ReLU backward through the stored post-activation). */
+int sherf_bwd_relu_mask(float* d, int ldd, const float* h, int ldh, int64_t n, int C, sherf_stream_t stream);
+/* out[c] += sum_r d[r][c]   (bias gradients; out must be zeroed by the caller). */
+int sherf_bwd_colsum(const float* d, int ldd, int64_t n, int C, float* out, sherf_stream_t stream);
+/* dst[r][0..C) (+)= src[r][0..C): strided column-block copy (add != 0: accumulate). */
+int sherf_bwd_copy2d(float* dst, int ldd, const float* src, int lds, int64_t n, int C, int add, sherf_stream_t stream);
+
+/* NeRF positional encoding (renderer.py:875-916): out[r] = [x, sin(f0 x), cos(f0 x), sin(f1 x), ...], x = in[r][0..3),
+ * 3 + 6*NF columns. */
+int sherf_bwd_pe(const float* in, int ldi, int64_t n, int NF, float* out, int ldo, sherf_stream_t stream);
+
+/* LayerNorm over 32 features (eps 1e-5), rows = n * tokens.  fwd keeps xh[rows][32], inv[rows]; bwd returns dx and
+ * accumulates dw[32], db[32] (zeroed by the caller).  (transformer_bwd._ln_fwd / _ln_bwd) */
+int sherf_bwd_ln_fwd(const float* x, const float* w, const float* b, int64_t rows, float* y, float* xh, float* inv,
+                     sherf_stream_t stream);
+int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh, const float* inv, int64_t rows, float* dx,
+                     float* dw, float* db, sherf_stream_t stream);
+
+/* 3-token, 3-head x 16 attention core on qkv[n][3 tok][144] (q | k | v, each 3 heads x 16; renderer.py:949-977):
+ * fwd: att[n][3 head][3][3] = softmax(q k^T / 4), o[n][3 tok][48]; bwd: d_o -> d_qkv. */
+int sherf_bwd_attn_fwd(const float* qkv, int64_t n, float* att, float* o, sherf_stream_t stream);
+int sherf_bwd_attn_bwd(const float* qkv, const float* att, const float* d_o, int64_t n, float* d_qkv, sherf_stream_t stream);
+
+/* exact GELU: fwd ge = u Phi(u); bwd d_u = d_ge (Phi(u) + u phi(u)), in place on d. */
+int sherf_bwd_gelu_fwd(const float* u, int64_t count, float* ge, sherf_stream_t stream);
+int sherf_bwd_gelu_bwd(float* d, const float* u, int64_t count, sherf_stream_t stream);
+
+/* rgb head (triplane.py:314): fwd rgb = sigmoid(lin) * 1.002 - 0.001 in place; bwd d_lin = d_rgb * 1.002 s (1 - s)
+ * from the stored rgb. */
+int sherf_bwd_rgb_fwd(float* lin, int64_t count, sherf_stream_t stream);
+int sherf_bwd_rgb_bwd(float* d, const float* rgb, int64_t count, sherf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

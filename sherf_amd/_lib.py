@@ -154,3 +154,30 @@ def call(name, *args):
     rc = getattr(l, name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {l.sherf_last_error().decode()}')
+
+
+# ---- the (experimental) backward library: include/sherf_hip_bwd.h -> libsherf_hip_bwd.so ----------------------------
+HEADER_BWD = os.path.join(_HERE, '..', 'include', 'sherf_hip_bwd.h')
+LIB_BWD_PATH = os.path.join(_HERE, 'libsherf_hip_bwd.so')
+_lib_bwd = None
+
+
+def lib_bwd():
+    global _lib_bwd
+    if _lib_bwd is None:
+        if not os.path.exists(LIB_BWD_PATH):
+            raise RuntimeError(f'{LIB_BWD_PATH} not found: build it with `python -m sherf_amd.build`')
+        l = ctypes.CDLL(LIB_BWD_PATH)
+        for name, (ret, args) in parse_header(HEADER_BWD).items():
+            fn = getattr(l, name)
+            fn.restype = ret
+            fn.argtypes = [a[0] for a in args]
+        _lib_bwd = l
+    return _lib_bwd
+
+
+def call_bwd(name, *args):
+    l = lib_bwd()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {l.sherf_bwd_last_error().decode()}')

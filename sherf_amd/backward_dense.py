@@ -1,0 +1,243 @@
+"""Backward of the per-sample dense stage (a13 + a14: slot-2 rgb encoding, transformer, NeRF decoder) -- EXPERIMENTAL.
+
+Correctness-first formulation: the forward of the valid samples is recomputed in fp32, row-major [n, C], as a sequence of
+plain GEMMs (rocBLAS through `sherf_bwd_gemm`) and small element-wise HIP kernels, every activation kept in HBM (~6 KB per
+valid sample; 288 GB of HBM make that a non-issue), then back-propagated layer by layer.  It mirrors
+oracle/backward_explicit.py (decoder_bwd, transformer_bwd) line for line; the orchestration below is itself checked on the
+CPU by running it against a torch emulation of the C entry points (tests/bwd_emulator.py, tests/test_backward_dense.py),
+so what remains unverified until the next GPU session are the ~15 small kernels of csrc/bwd_dense.hip.
+
+The fused MFMA forward kernel stays the forward of record; a fused backward replaces this once it is correct.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Mat:
+    """Row-major fp32 matrix view [rows, cols] with leading dimension `ld` inside a flat buffer (element offset `off`)."""
+
+    def __init__(self, buf, rows, cols, ld=None, off=0):
+        self.buf, self.rows, self.cols, self.ld, self.off = buf, int(rows), int(cols), int(ld if ld is not None else cols), int(off)
+        assert self.ld >= self.cols and self.off + (self.rows - 1) * self.ld + self.cols <= buf.numel(), 'Mat out of bounds'
+
+    @staticmethod
+    def zeros(rows, cols, device):
+        return Mat(torch.zeros(int(rows) * int(cols), dtype=torch.float32, device=device), rows, cols)
+
+    @staticmethod
+    def of(t):
+        """A contiguous 2-D (or 1-D -> one row) parameter tensor as a Mat (no copy when already fp32 contiguous)."""
+        t = t.detach().to(torch.float32).contiguous()
+        if t.dim() == 1:
+            return Mat(t.view(-1), 1, t.numel())
+        return Mat(t.view(-1), t.shape[0], t.numel() // t.shape[0])
+
+    def colslice(self, c0, c1):
+        return Mat(self.buf, self.rows, c1 - c0, self.ld, self.off + c0)
+
+    def as_rows(self, rows, cols):
+        assert self.ld == self.cols and rows * cols == self.rows * self.cols, 'as_rows needs a dense matrix'
+        return Mat(self.buf, rows, cols, cols, self.off)
+
+    def tensor(self):
+        return torch.as_strided(self.buf, (self.rows, self.cols), (self.ld, 1), self.off)
+
+
+class HipOps:
+    """The C entry points of include/sherf_hip_bwd.h on Mats."""
+
+    def __init__(self):
+        self.st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _p(m):
+        if not m.buf.is_cuda:
+            raise RuntimeError('sherf_amd: tensor is not on a GPU; the HIP path has no CPU fallback')
+        return ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)
+
+    def gemm(self, tA, tB, A, B, C, beta=0.0):
+        M, K = (A.cols, A.rows) if tA else (A.rows, A.cols)
+        K2, N = (B.cols, B.rows) if tB else (B.rows, B.cols)
+        assert K == K2 and C.rows == M and C.cols == N, ('gemm shapes', tA, tB, A.rows, A.cols, B.rows, B.cols, C.rows, C.cols)
+        _lib.call_bwd('sherf_bwd_gemm', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta), self.st)
+
+    def bias_act(self, Y, bias, act):
+        _lib.call_bwd('sherf_bwd_bias_act', self._p(Y), Y.ld, None if bias is None else self._p(bias), Y.rows, Y.cols, act, self.st)
+
+    def relu_mask(self, D, H):
+        _lib.call_bwd('sherf_bwd_relu_mask', self._p(D), D.ld, self._p(H), H.ld, D.rows, D.cols, self.st)
+
+    def colsum(self, D, out):
+        _lib.call_bwd('sherf_bwd_colsum', self._p(D), D.ld, D.rows, D.cols, self._p(out), self.st)
+
+    def copy2d(self, dst, src, add=False):
+        _lib.call_bwd('sherf_bwd_copy2d', self._p(dst), dst.ld, self._p(src), src.ld, src.rows, src.cols, int(add), self.st)
+
+    def pe(self, inp, NF, out):
+        _lib.call_bwd('sherf_bwd_pe', self._p(inp), inp.ld, inp.rows, NF, self._p(out), out.ld, self.st)
+
+    def ln_fwd(self, x, w, b, y, xh, inv):
+        _lib.call_bwd('sherf_bwd_ln_fwd', self._p(x), self._p(w), self._p(b), x.rows, self._p(y), self._p(xh), self._p(inv), self.st)
+
+    def ln_bwd(self, dy, w, xh, inv, dx, dw, db):
+        _lib.call_bwd('sherf_bwd_ln_bwd', self._p(dy), self._p(w), self._p(xh), self._p(inv), dy.rows, self._p(dx), self._p(dw), self._p(db), self.st)
+
+    def attn_fwd(self, qkv, att, o):
+        _lib.call_bwd('sherf_bwd_attn_fwd', self._p(qkv), qkv.rows, self._p(att), self._p(o), self.st)
+
+    def attn_bwd(self, qkv, att, d_o, d_qkv):
+        _lib.call_bwd('sherf_bwd_attn_bwd', self._p(qkv), self._p(att), self._p(d_o), qkv.rows, self._p(d_qkv), self.st)
+
+    def gelu_fwd(self, u, ge):
+        _lib.call_bwd('sherf_bwd_gelu_fwd', self._p(u), u.rows * u.cols, self._p(ge), self.st)
+
+    def gelu_bwd(self, d, u):
+        _lib.call_bwd('sherf_bwd_gelu_bwd', self._p(d), self._p(u), u.rows * u.cols, self.st)
+
+    def rgb_fwd(self, lin):
+        _lib.call_bwd('sherf_bwd_rgb_fwd', self._p(lin), lin.rows * lin.cols, self.st)
+
+    def rgb_bwd(self, d, rgb):
+        _lib.call_bwd('sherf_bwd_rgb_bwd', self._p(d), self._p(rgb), rgb.rows * rgb.cols, self.st)
+
+    def untile(self, tokens_tiled, extras_tiled, n, tok, ext):
+        _lib.call_bwd('sherf_bwd_untile', _lib.ptr(tokens_tiled), _lib.ptr(extras_tiled), n, self._p(tok), self._p(ext), self.st)
+
+    def tile_tokens(self, d_tok, n, out):
+        _lib.call_bwd('sherf_bwd_tile_tokens', self._p(d_tok), n, _lib.ptr(out), self.st)
+
+
+def dense_backward(ops, state, tok, ext, d_sample):
+    """tok [n,96] (gather output, row-major: slot tokens incl. bias, WITHOUT the slot-2 rgb encoding), ext [n,12]
+    (x_c 0:3, v_c 3:6, tapped rgb 6:9), d_sample [n,4] = dL/d(rgb, sigma) per valid sample (compositing backward).
+    `state`: {reference parameter name: tensor} of the renderer (prefix 'renderer.') and decoder ('decoder.').
+
+    Returns (d_tokens_in Mat [n,96], grads {name: tensor}, dWb_pe [32,32]) where dWb_pe is the contribution of the slot-2
+    rgb encoding to conv1d_reprojection.weight[:, 32:64] (the rest of that weight's gradient comes from the tap backward)."""
+    n, dev = tok.rows, tok.buf.device
+    Z = lambda r, c: Mat.zeros(r, c, dev)
+    P = lambda name: Mat.of(state[name])
+    grads = {}
+
+    def lin_fwd(x, wname, act, out=None):
+        W = P(wname + '.weight')                                   # [out, in]
+        y = out if out is not None else Z(x.rows, W.rows)
+        ops.gemm(0, 1, x, W, y)
+        ops.bias_act(y, P(wname + '.bias') if (wname + '.bias') in state else None, act)
+        return y
+
+    def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True):
+        """grads of y = x W^T + b; returns d_x (accumulated into d_in with beta)."""
+        W = P(wname + '.weight')
+        dW = Z(W.rows, W.cols)
+        ops.gemm(1, 0, d_out, x, dW)
+        grads[wname + '.weight'] = dW.tensor().view(state[wname + '.weight'].shape).clone()
+        if bias and (wname + '.bias') in state:
+            db = Z(1, W.rows)
+            ops.colsum(d_out, db)
+            grads[wname + '.bias'] = db.tensor().view(-1).clone()
+        dx = d_in if d_in is not None else Z(d_out.rows, W.cols)
+        ops.gemm(0, 0, d_out, W, dx, beta)
+        return dx
+
+    # ================= forward recompute =================
+    Wr = state['renderer.conv1d_reprojection.weight'].detach().float()[:, :, 0]
+    Wb = Mat.of(Wr[:, 32:64].contiguous())                          # [32 out, 32 in]
+    pe_rgb = Z(n, 33)
+    ops.pe(ext.colslice(6, 9), 5, pe_rgb)
+    tin = Z(n, 96)                                                  # tokens_in = tok (+ slot 2: PE(rgb)[:32] Wb^T)
+    ops.copy2d(tin, tok)
+    ops.gemm(0, 1, pe_rgb.colslice(0, 32), Wb, tin.colslice(64, 96), 1.0)
+    t = 'renderer.transformer.layers.0.'
+    tin3 = tin.as_rows(3 * n, 32)
+    h0, xh0, inv0 = Z(3 * n, 32), Z(3 * n, 32), Z(3 * n, 1)
+    ops.ln_fwd(tin3, P(t + '0.fn.norm.weight'), P(t + '0.fn.norm.bias'), h0, xh0, inv0)
+    qkv = Z(3 * n, 144)
+    ops.gemm(0, 1, h0, P(t + '0.fn.fn.to_qkv.weight'), qkv)
+    att, o = Z(n, 27), Z(3 * n, 48)
+    ops.attn_fwd(qkv.as_rows(n, 432), att, o.as_rows(n, 144))
+    y = lin_fwd(o, t + '0.fn.fn.to_out.0', 0)
+    ops.copy2d(y, tin3, add=True)                                   # residual
+    h1, xh1, inv1 = Z(3 * n, 32), Z(3 * n, 32), Z(3 * n, 1)
+    ops.ln_fwd(y, P(t + '1.fn.norm.weight'), P(t + '1.fn.norm.bias'), h1, xh1, inv1)
+    u = lin_fwd(h1, t + '1.fn.fn.net.0', 0)
+    ge = Z(3 * n, 32)
+    ops.gelu_fwd(u, ge)
+    z = lin_fwd(ge, t + '1.fn.fn.net.3', 0)
+    ops.copy2d(z, y, add=True)
+    z96 = z.as_rows(n, 96)                                          # [n, slot 0 | slot 1 | slot 2]
+    # ---- decoder ----
+    d = 'decoder.'
+    x0 = Z(n, 71)
+    ops.pe(ext.colslice(0, 3), 6, x0.colslice(0, 39))
+    ops.copy2d(x0.colslice(39, 71), z96.colslice(0, 32))
+    ins, hs = [], []
+    h = x0
+    cat5 = Z(n, 199)
+    for i in range(8):
+        ins.append(h)
+        out = cat5.colslice(71, 199) if i == 4 else None            # layer 4 writes straight into cat([x0, h4])
+        hi = lin_fwd(h, d + f'pts_linears.{i}', 1, out)
+        hs.append(hi)
+        h = hi
+        if i == 4:
+            ops.copy2d(cat5.colslice(0, 71), x0)
+            h = cat5
+    h7 = hs[7]
+    vin = Z(n, 187)
+    lin_fwd(h7, d + 'feature_linear', 0, vin.colslice(0, 128))
+    ops.pe(ext.colslice(3, 6), 4, vin.colslice(128, 155))
+    ops.copy2d(vin.colslice(155, 187), z96.colslice(32, 64))
+    g = lin_fwd(vin, d + 'views_linear', 1)
+    rgb = lin_fwd(g, d + 'rgb_linear', 0)
+    ops.rgb_fwd(rgb)
+
+    # ================= backward =================
+    d_lin = Z(n, 3)
+    ops.copy2d(d_lin, d_sample.colslice(0, 3))
+    ops.rgb_bwd(d_lin, rgb)
+    d_g = lin_bwd(d_lin, g, d + 'rgb_linear')
+    ops.relu_mask(d_g, g)
+    d_vin = lin_bwd(d_g, vin, d + 'views_linear')
+    d_sigma = d_sample.colslice(3, 4)
+    d_h = lin_bwd(d_vin.colslice(0, 128), h7, d + 'feature_linear')
+    lin_bwd(d_sigma, h7, d + 'alpha_linear', d_in=d_h, beta=1.0)
+    d_x0 = Z(n, 71)
+    for i in range(7, -1, -1):
+        ops.relu_mask(d_h, hs[i])
+        d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}')
+        if i == 5:
+            ops.copy2d(d_x0, d_in.colslice(0, 71), add=True)
+            d_h = d_in.colslice(71, 199)
+        elif i == 0:
+            ops.copy2d(d_x0, d_in, add=True)
+        else:
+            d_h = d_in
+    d_z = Z(n, 96)                                                  # slot 2 of the transformer output is never read
+    ops.copy2d(d_z.colslice(0, 32), d_x0.colslice(39, 71))
+    ops.copy2d(d_z.colslice(32, 64), d_vin.colslice(155, 187))
+    d_out = d_z.as_rows(3 * n, 32)
+    # ---- transformer: out = ge W2^T + b2 + y ----
+    d_ge = lin_bwd(d_out, ge, t + '1.fn.fn.net.3')
+    ops.gelu_bwd(d_ge, u)
+    d_h1 = lin_bwd(d_ge, h1, t + '1.fn.fn.net.0')
+    d_y, dw, db = Z(3 * n, 32), Z(1, 32), Z(1, 32)
+    ops.ln_bwd(d_h1, P(t + '1.fn.norm.weight'), xh1, inv1, d_y, dw, db)
+    grads[t + '1.fn.norm.weight'], grads[t + '1.fn.norm.bias'] = dw.tensor().view(-1).clone(), db.tensor().view(-1).clone()
+    ops.copy2d(d_y, d_out, add=True)
+    # ---- y = o Wo^T + bo + tokens_in ----
+    d_o = lin_bwd(d_y, o, t + '0.fn.fn.to_out.0')
+    d_qkv = Z(3 * n, 144)
+    ops.attn_bwd(qkv.as_rows(n, 432), att, d_o.as_rows(n, 144), d_qkv.as_rows(n, 432))
+    d_h0 = lin_bwd(d_qkv, h0, t + '0.fn.fn.to_qkv', bias=False)
+    d_tin, dw0, db0 = Z(3 * n, 32), Z(1, 32), Z(1, 32)
+    ops.ln_bwd(d_h0, P(t + '0.fn.norm.weight'), xh0, inv0, d_tin, dw0, db0)
+    grads[t + '0.fn.norm.weight'], grads[t + '0.fn.norm.bias'] = dw0.tensor().view(-1).clone(), db0.tensor().view(-1).clone()
+    ops.copy2d(d_tin, d_y, add=True)
+    d_tin96 = d_tin.as_rows(n, 96)
+    dWb_pe = Z(32, 32)
+    ops.gemm(1, 0, d_tin96.colslice(64, 96), pe_rgb.colslice(0, 32), dWb_pe)
+    return d_tin96, grads, dWb_pe.tensor().clone()

@@ -50,5 +50,35 @@ def build(force=False, verbose=True):
     return LIB
 
 
+LIB_BWD = os.path.join(HERE, 'libsherf_hip_bwd.so')
+SOURCES_BWD = ['bwd_dense.hip']
+
+
+def build_bwd(force=False, verbose=True):
+    """libsherf_hip_bwd.so: the (experimental) backward building blocks, include/sherf_hip_bwd.h.  Separate from the forward
+    library because it links rocBLAS (plain GEMMs of the dense layers); at run time the loader reuses the librocblas that
+    `import torch` already mapped."""
+    deps = [os.path.join(CSRC, s) for s in SOURCES_BWD] + [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'sherf_hip_bwd.h')]
+    if not force and os.path.exists(LIB_BWD) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_BWD) for d in deps):
+        return LIB_BWD
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    objs = []
+    for s in SOURCES_BWD:
+        o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
+        objs.append(o)
+        r = subprocess.run([hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{r.stdout.decode()}')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-L/opt/rocm/lib', '-lrocblas', '-o', LIB_BWD],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stdout.decode())
+    if verbose:
+        print(f'built {LIB_BWD} ({os.path.getsize(LIB_BWD) / 1e6:.2f} MB)')
+    return LIB_BWD
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    build_bwd(force='--force' in sys.argv)

@@ -1,0 +1,370 @@
+// Dense building blocks of the backward path (gfx950) -- see include/sherf_hip_bwd.h.  EXPERIMENTAL: compiles, mirrors
+// oracle/backward_explicit.py (CPU-verified), has not run on hardware yet.  fp32 VALU kernels + rocBLAS for the plain GEMMs.
+#include "common.h"
+
+#include <mutex>
+
+#include <rocblas/rocblas.h>
+
+#include "../../include/sherf_hip_bwd.h"
+
+char g_sherf_err[256] = "";        // this library's own error buffer (common.h macros)
+int g_sherf_debug = 0;
+
+namespace {
+
+std::mutex g_mu;
+rocblas_handle g_handle[16] = {};
+
+#define SHERF_GRID(count) dim3((unsigned)((count + 255) / 256)), dim3(256)
+
+__global__ void untile_kernel(const float4* __restrict__ tokens, const float* __restrict__ extras, int64_t n, float* __restrict__ tok,
+                              float* __restrict__ ext) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one thread per (sample, slot, quad) = n * 24
+    if (i >= n * 24) return;
+    const int64_t c = i / 24;
+    const int q = (int)(i % 24), s = q / 8, l = q % 8;
+    const int64_t tile = c >> 5;
+    const int j = (int)(c & 31);
+    const float4 v = tokens[((tile * 3 + s) * 8 + l) * 32 + j];
+    *reinterpret_cast<float4*>(tok + c * 96 + 32 * s + 4 * l) = v;
+    if (q < 12) ext[c * 12 + q] = extras[(tile * 12 + q) * 32 + j];
+}
+
+__global__ void tile_kernel(const float* __restrict__ d_tok, int64_t n, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // over padded samples * 24
+    const int64_t npad = ((n + 31) / 32) * 32;
+    if (i >= npad * 24) return;
+    const int64_t c = i / 24;
+    const int q = (int)(i % 24), s = q / 8, l = q % 8;
+    const float4 v = c < n ? *reinterpret_cast<const float4*>(d_tok + c * 96 + 32 * s + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+    out[(((c >> 5) * 3 + s) * 8 + l) * 32 + (c & 31)] = v;
+}
+
+__global__ void bias_act_kernel(float* __restrict__ y, int ldy, const float* __restrict__ bias, int64_t n, int C, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    float v = y[r * ldy + c] + (bias ? bias[c] : 0.f);
+    y[r * ldy + c] = act == 1 ? fmaxf(v, 0.f) : v;
+}
+
+__global__ void relu_mask_kernel(float* __restrict__ d, int ldd, const float* __restrict__ h, int ldh, int64_t n, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    if (!(h[r * ldh + c] > 0.f)) d[r * ldd + c] = 0.f;
+}
+
+// each block sums 512 rows; thread t owns columns t, t+256, ...
+__global__ void colsum_kernel(const float* __restrict__ d, int ldd, int64_t n, int C, float* __restrict__ out) {
+    const int64_t r0 = (int64_t)blockIdx.x * 512, r1 = r0 + 512 < n ? r0 + 512 : n;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int64_t r = r0; r < r1; ++r) a += d[r * ldd + c];
+        unsafeAtomicAdd(out + c, a);
+    }
+}
+
+__global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int64_t n, int C, int add) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    const float v = src[r * lds + c];
+    if (add) dst[r * ldd + c] += v; else dst[r * ldd + c] = v;
+}
+
+// out[r] = [x(3), sin(2^0 x)(3), sin(2^0 x + pi/2)(3), sin(2^1 x)(3), ...]  (renderer.py:875-916)
+__global__ void pe_kernel(const float* __restrict__ in, int ldi, int64_t n, int NF, float* __restrict__ out, int ldo) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    float x[3] = {in[r * ldi], in[r * ldi + 1], in[r * ldi + 2]};
+    float* o = out + r * ldo;
+    o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+    float f = 1.f;
+    for (int q = 0; q < NF; ++q, f *= 2.f)
+        for (int a = 0; a < 3; ++a) {
+            o[3 + 6 * q + a] = sinf(f * x[a]);
+            o[6 + 6 * q + a] = sinf(f * x[a] + 1.57079632679489662f);
+        }
+}
+
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, int64_t rows,
+                              float* __restrict__ y, float* __restrict__ xh, float* __restrict__ inv) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float v[32], mu = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { v[c] = x[r * 32 + c]; mu += v[c]; }
+    mu *= (1.f / 32.f);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { v[c] -= mu; q += v[c] * v[c]; }
+    const float iv = 1.f / sqrtf(q * (1.f / 32.f) + 1e-5f);
+    inv[r] = iv;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float h = v[c] * iv;
+        xh[r * 32 + c] = h;
+        y[r * 32 + c] = h * w[c] + b[c];
+    }
+}
+
+// d_x = inv * (d_xh - mean(d_xh) - xh * mean(d_xh * xh)),  d_xh = d_y * w;  dw += d_y * xh, db += d_y
+__global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ xh,
+                              const float* __restrict__ inv, int64_t rows, float* __restrict__ dx, float* __restrict__ dw,
+                              float* __restrict__ db) {
+    __shared__ float s_w[32], s_b[32];
+    if (threadIdx.x < 32) { s_w[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) {
+        float g[32], h[32], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const float d = dy[r * 32 + c];
+            h[c] = xh[r * 32 + c];
+            atomicAdd(&s_w[c], d * h[c]);
+            atomicAdd(&s_b[c], d);
+            g[c] = d * w[c];
+            m1 += g[c]; m2 += g[c] * h[c];
+        }
+        m1 *= (1.f / 32.f); m2 *= (1.f / 32.f);
+        const float iv = inv[r];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dx[r * 32 + c] = iv * (g[c] - m1 - h[c] * m2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) { unsafeAtomicAdd(dw + threadIdx.x, s_w[threadIdx.x]); unsafeAtomicAdd(db + threadIdx.x, s_b[threadIdx.x]); }
+}
+
+// one thread per (sample, head): q_i = qkv[n][i][16h..], k_j = qkv[n][j][48 + 16h..], v_j = qkv[n][j][96 + 16h..]
+__global__ void attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float* __restrict__ att, float* __restrict__ o) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 3) return;
+    const int64_t s = i / 3;
+    const int h = (int)(i % 3);
+    const float* base = qkv + s * 432 + 16 * h;
+    float q[3][16], k[3][16], v[3][16];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { q[t][d] = base[t * 144 + d]; k[t][d] = base[t * 144 + 48 + d]; v[t][d] = base[t * 144 + 96 + d]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float sc[3], m = -3.0e38f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d += q[a][e] * k[b][e];
+            sc[b] = d * 0.25f;
+            m = fmaxf(m, sc[b]);
+        }
+        float e0 = expf(sc[0] - m), e1 = expf(sc[1] - m), e2 = expf(sc[2] - m);
+        const float iv = 1.f / (e0 + e1 + e2);
+        e0 *= iv; e1 *= iv; e2 *= iv;
+        float* ap = att + ((s * 3 + h) * 3 + a) * 3;
+        ap[0] = e0; ap[1] = e1; ap[2] = e2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[(s * 3 + a) * 48 + 16 * h + e] = e0 * v[0][e] + e1 * v[1][e] + e2 * v[2][e];
+    }
+}
+
+__global__ void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ att, const float* __restrict__ d_o, int64_t n,
+                                float* __restrict__ d_qkv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 3) return;
+    const int64_t s = i / 3;
+    const int h = (int)(i % 3);
+    const float* base = qkv + s * 432 + 16 * h;
+    float q[3][16], k[3][16], v[3][16], go[3][16], A[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            q[t][d] = base[t * 144 + d]; k[t][d] = base[t * 144 + 48 + d]; v[t][d] = base[t * 144 + 96 + d];
+            go[t][d] = d_o[(s * 3 + t) * 48 + 16 * h + d];
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) A[t][b] = att[((s * 3 + h) * 3 + t) * 3 + b];
+    }
+    float dS[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float dA[3], dot = 0.f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d += go[a][e] * v[b][e];
+            dA[b] = d;
+            dot += d * A[a][b];
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) dS[a][b] = A[a][b] * (dA[b] - dot) * 0.25f;
+    }
+    float* ob = d_qkv + s * 432 + 16 * h;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            ob[t * 144 + e] = dS[t][0] * k[0][e] + dS[t][1] * k[1][e] + dS[t][2] * k[2][e];                    // d_q[t]
+            ob[t * 144 + 48 + e] = dS[0][t] * q[0][e] + dS[1][t] * q[1][e] + dS[2][t] * q[2][e];               // d_k[t]
+            ob[t * 144 + 96 + e] = A[0][t] * go[0][e] + A[1][t] * go[1][e] + A[2][t] * go[2][e];               // d_v[t]
+        }
+}
+
+__global__ void gelu_fwd_kernel(const float* __restrict__ u, int64_t count, float* __restrict__ ge) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) ge[i] = 0.5f * u[i] * (1.f + erff(u[i] * 0.70710678118654752f));
+}
+
+__global__ void gelu_bwd_kernel(float* __restrict__ d, const float* __restrict__ u, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float x = u[i];
+    d[i] *= 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.39894228040143268f;
+}
+
+__global__ void rgb_fwd_kernel(float* __restrict__ lin, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) lin[i] = (1.f / (1.f + expf(-lin[i]))) * 1.002f - 0.001f;
+}
+
+__global__ void rgb_bwd_kernel(float* __restrict__ d, const float* __restrict__ rgb, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float s = (rgb[i] + 0.001f) * (1.f / 1.002f);
+    d[i] *= 1.002f * s * (1.f - s);
+}
+
+}  // namespace
+
+extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                              float* C, int ldc, float beta, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
+    int dev = 0;
+    SHERF_HIP_CHECK(hipGetDevice(&dev));
+    SHERF_CHECK_ARG(dev >= 0 && dev < 16);
+    rocblas_handle h;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_handle[dev] && rocblas_create_handle(&g_handle[dev]) != rocblas_status_success) {
+            snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_bwd_gemm: rocblas_create_handle failed");
+            return SHERF_ELAUNCH;
+        }
+        h = g_handle[dev];
+    }
+    const float alpha = 1.f;
+    // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T: swap the operands and M <-> N
+    rocblas_status st = rocblas_set_stream(h, as_stream(stream));
+    if (st == rocblas_status_success)
+        st = rocblas_sgemm(h, transB ? rocblas_operation_transpose : rocblas_operation_none,
+                           transA ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
+    if (st != rocblas_status_success) {
+        snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_bwd_gemm: rocblas status %d", (int)st);
+        return SHERF_ELAUNCH;
+    }
+    return SHERF_OK;
+}
+
+extern "C" int sherf_bwd_untile(const float* tokens_tiled, const float* extras_tiled, int64_t n, float* tok, float* ext,
+                                sherf_stream_t stream) {
+    SHERF_CHECK_ARG(tokens_tiled && extras_tiled && tok && ext && n > 0);
+    hipLaunchKernelGGL(untile_kernel, SHERF_GRID(n * 24), 0, as_stream(stream), reinterpret_cast<const float4*>(tokens_tiled), extras_tiled, n,
+                       tok, ext);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_tile_tokens(const float* d_tok, int64_t n, float* d_tokens_tiled, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d_tok && d_tokens_tiled && n > 0);
+    const int64_t npad = ((n + 31) / 32) * 32;
+    hipLaunchKernelGGL(tile_kernel, SHERF_GRID(npad * 24), 0, as_stream(stream), d_tok, n, reinterpret_cast<float4*>(d_tokens_tiled));
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_bias_act(float* y, int ldy, const float* bias, int64_t n, int C, int act, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(y && n > 0 && C > 0 && ldy >= C && (act == 0 || act == 1));
+    hipLaunchKernelGGL(bias_act_kernel, SHERF_GRID(n * C), 0, as_stream(stream), y, ldy, bias, n, C, act);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_relu_mask(float* d, int ldd, const float* h, int ldh, int64_t n, int C, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d && h && n > 0 && C > 0 && ldd >= C && ldh >= C);
+    hipLaunchKernelGGL(relu_mask_kernel, SHERF_GRID(n * C), 0, as_stream(stream), d, ldd, h, ldh, n, C);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_colsum(const float* d, int ldd, int64_t n, int C, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d && out && n > 0 && C > 0 && ldd >= C);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, as_stream(stream), d, ldd, n, C, out);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_copy2d(float* dst, int ldd, const float* src, int lds, int64_t n, int C, int add, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(dst && src && n > 0 && C > 0 && ldd >= C && lds >= C);
+    hipLaunchKernelGGL(copy2d_kernel, SHERF_GRID(n * C), 0, as_stream(stream), dst, ldd, src, lds, n, C, add);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_pe(const float* in, int ldi, int64_t n, int NF, float* out, int ldo, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(in && out && n > 0 && NF > 0 && NF <= 10 && ldi >= 3 && ldo >= 3 + 6 * NF);
+    hipLaunchKernelGGL(pe_kernel, SHERF_GRID(n), 0, as_stream(stream), in, ldi, n, NF, out, ldo);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_ln_fwd(const float* x, const float* w, const float* b, int64_t rows, float* y, float* xh, float* inv,
+                                sherf_stream_t stream) {
+    SHERF_CHECK_ARG(x && w && b && y && xh && inv && rows > 0);
+    hipLaunchKernelGGL(ln_fwd_kernel, SHERF_GRID(rows), 0, as_stream(stream), x, w, b, rows, y, xh, inv);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh, const float* inv, int64_t rows, float* dx,
+                                float* dw, float* db, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(dy && w && xh && inv && dx && dw && db && rows > 0);
+    hipLaunchKernelGGL(ln_bwd_kernel, SHERF_GRID(rows), 0, as_stream(stream), dy, w, xh, inv, rows, dx, dw, db);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_attn_fwd(const float* qkv, int64_t n, float* att, float* o, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(qkv && att && o && n > 0);
+    hipLaunchKernelGGL(attn_fwd_kernel, SHERF_GRID(n * 3), 0, as_stream(stream), qkv, n, att, o);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_attn_bwd(const float* qkv, const float* att, const float* d_o, int64_t n, float* d_qkv, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(qkv && att && d_o && d_qkv && n > 0);
+    hipLaunchKernelGGL(attn_bwd_kernel, SHERF_GRID(n * 3), 0, as_stream(stream), qkv, att, d_o, n, d_qkv);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_gelu_fwd(const float* u, int64_t count, float* ge, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(u && ge && count > 0);
+    hipLaunchKernelGGL(gelu_fwd_kernel, SHERF_GRID(count), 0, as_stream(stream), u, count, ge);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_gelu_bwd(float* d, const float* u, int64_t count, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d && u && count > 0);
+    hipLaunchKernelGGL(gelu_bwd_kernel, SHERF_GRID(count), 0, as_stream(stream), d, u, count);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_rgb_fwd(float* lin, int64_t count, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(lin && count > 0);
+    hipLaunchKernelGGL(rgb_fwd_kernel, SHERF_GRID(count), 0, as_stream(stream), lin, count);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_rgb_bwd(float* d, const float* rgb, int64_t count, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d && rgb && count > 0);
+    hipLaunchKernelGGL(rgb_bwd_kernel, SHERF_GRID(count), 0, as_stream(stream), d, rgb, count);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" const char* sherf_bwd_last_error(void) { return g_sherf_err; }

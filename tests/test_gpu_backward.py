@@ -27,3 +27,108 @@ def test_composite_backward_kernel(cfg):
     out = composite_backward(h['rend'], d_rgb, d_acc, d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]).cpu()
     assert G.rel(out[:, :3], g['stage.sample_rgb']) < 1e-3
     assert G.rel(out[:, 3], g['stage.sample_sigma']) < 1e-3
+
+
+# ---- every entry point of include/sherf_hip_bwd.h against its torch emulation (tests/bwd_emulator.py) on random data ----
+def _pair(rows, cols, ld=None, seed=0):
+    """The same random matrix as a CPU Mat and a GPU Mat (with padding columns when ld > cols)."""
+    from sherf_amd.backward_dense import Mat
+    ld = ld or cols
+    g = torch.Generator().manual_seed(seed)
+    buf = torch.randn(rows * ld + 7, generator=g)
+    return Mat(buf.clone(), rows, cols, ld, 3), Mat(buf.cuda(), rows, cols, ld, 3)
+
+
+def _same(a, b, tol=1e-5):
+    assert G.rel(b.tensor().cpu(), a.tensor()) < tol
+
+
+def test_bwd_gemm_all_transpositions():
+    from sherf_amd.backward_dense import HipOps
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    M, N, K = 37, 29, 53
+    for tA in (0, 1):
+        for tB in (0, 1):
+            a_c, a_g = _pair(*((K, M) if tA else (M, K)), ld=61, seed=1)
+            b_c, b_g = _pair(*((N, K) if tB else (K, N)), ld=67, seed=2)
+            c_c, c_g = _pair(M, N, ld=31, seed=3)
+            e.gemm(tA, tB, a_c, b_c, c_c, 0.5); h.gemm(tA, tB, a_g, b_g, c_g, 0.5)
+            torch.cuda.synchronize()
+            _same(c_c, c_g, 1e-4)
+
+
+def test_bwd_elementwise_kernels():
+    from sherf_amd.backward_dense import HipOps, Mat
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    n = 301
+    # bias_act / relu_mask / colsum / copy2d on strided views
+    y_c, y_g = _pair(n, 40, 45, 4); b_c, b_g = _pair(1, 40, seed=5)
+    for act in (0, 1):
+        e.bias_act(y_c, b_c, act); h.bias_act(y_g, b_g, act); _same(y_c, y_g)
+    d_c, d_g = _pair(n, 40, 41, 6)
+    e.relu_mask(d_c, y_c); h.relu_mask(d_g, y_g); _same(d_c, d_g)
+    s_c, s_g = Mat(torch.zeros(40), 1, 40), Mat(torch.zeros(40).cuda(), 1, 40)
+    e.colsum(d_c, s_c); h.colsum(d_g, s_g); _same(s_c, s_g, 1e-4)
+    e.copy2d(y_c.colslice(3, 20), d_c.colslice(0, 17), add=True); h.copy2d(y_g.colslice(3, 20), d_g.colslice(0, 17), add=True); _same(y_c, y_g)
+    # positional encoding
+    x_c, x_g = _pair(n, 3, 12, 7)
+    for NF in (4, 5, 6):
+        o_c, o_g = _pair(n, 3 + 6 * NF, 45, 8)
+        e.pe(x_c, NF, o_c); h.pe(x_g, NF, o_g); _same(o_c, o_g, 2e-5)
+    # LayerNorm forward / backward
+    rows = 3 * n
+    x_c, x_g = _pair(rows, 32, seed=9); w_c, w_g = _pair(1, 32, seed=10); bb_c, bb_g = _pair(1, 32, seed=11)
+    outs_c = [Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(rows), rows, 1)]
+    outs_g = [Mat(torch.zeros(rows * 32).cuda(), rows, 32), Mat(torch.zeros(rows * 32).cuda(), rows, 32), Mat(torch.zeros(rows).cuda(), rows, 1)]
+    e.ln_fwd(x_c, w_c, bb_c, *outs_c); h.ln_fwd(x_g, w_g, bb_g, *outs_g)
+    for a, b in zip(outs_c, outs_g):
+        _same(a, b, 1e-5)
+    dy_c, dy_g = _pair(rows, 32, seed=12)
+    res_c = [Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(32), 1, 32), Mat(torch.zeros(32), 1, 32)]
+    res_g = [Mat(torch.zeros(rows * 32).cuda(), rows, 32), Mat(torch.zeros(32).cuda(), 1, 32), Mat(torch.zeros(32).cuda(), 1, 32)]
+    e.ln_bwd(dy_c, w_c, outs_c[1], outs_c[2], *res_c); h.ln_bwd(dy_g, w_g, outs_g[1], outs_g[2], *res_g)
+    for a, b in zip(res_c, res_g):
+        _same(a, b, 1e-4)
+    # attention core forward / backward
+    q_c, q_g = _pair(n, 432, seed=13)
+    a_c, a_g = Mat(torch.zeros(n * 27), n, 27), Mat(torch.zeros(n * 27).cuda(), n, 27)
+    o_c, o_g = Mat(torch.zeros(n * 144), n, 144), Mat(torch.zeros(n * 144).cuda(), n, 144)
+    e.attn_fwd(q_c, a_c, o_c); h.attn_fwd(q_g, a_g, o_g); _same(a_c, a_g); _same(o_c, o_g)
+    go_c, go_g = _pair(n, 144, seed=14)
+    dq_c, dq_g = Mat(torch.zeros(n * 432), n, 432), Mat(torch.zeros(n * 432).cuda(), n, 432)
+    e.attn_bwd(q_c, a_c, go_c, dq_c); h.attn_bwd(q_g, a_g, go_g, dq_g); _same(dq_c, dq_g, 1e-4)
+    # GELU / rgb head
+    u_c, u_g = _pair(n, 32, seed=15)
+    g_c, g_g = Mat(torch.zeros(n * 32), n, 32), Mat(torch.zeros(n * 32).cuda(), n, 32)
+    e.gelu_fwd(u_c, g_c); h.gelu_fwd(u_g, g_g); _same(g_c, g_g)
+    d_c, d_g = _pair(n, 32, seed=16)
+    e.gelu_bwd(d_c, u_c); h.gelu_bwd(d_g, u_g); _same(d_c, d_g)
+    l_c, l_g = _pair(n, 3, seed=17)
+    e.rgb_fwd(l_c); h.rgb_fwd(l_g); _same(l_c, l_g)
+    d_c, d_g = _pair(n, 3, seed=18)
+    e.rgb_bwd(d_c, l_c); h.rgb_bwd(d_g, l_g); _same(d_c, d_g)
+    torch.cuda.synchronize()
+
+
+def test_dense_backward_on_the_gpu():
+    """The whole dense-stage backward through the HIP entry points against autograd through the oracle."""
+    from sherf_amd.backward_dense import HipOps, Mat, dense_backward
+    cfg = 'tiny_nv'
+    fx = G.fixture(cfg)
+    state = G.seeded_state()
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    h = G.hip_render(cfg)
+    ws = h['last']['ws']
+    n = int(ws['counters'][0])
+    ops = HipOps()
+    tok, ext = Mat.zeros(n, 96, 'cuda'), Mat.zeros(n, 12, 'cuda')
+    ops.untile(ws['tokens'], ws['extras'], n, tok, ext)
+    d_sample = torch.cat([g['stage.sample_rgb'], g['stage.sample_sigma'][:, None]], 1).contiguous().cuda()
+    st = {k: v.cuda() for k, v in state.items()}
+    d_tin, grads, dWb_pe = dense_backward(ops, st, tok, ext, Mat(d_sample.view(-1), n, 4))
+    torch.cuda.synchronize()
+    assert G.rel(d_tin.tensor().cpu().view(n, 3, 32), g['stage.tokens_in']) < 2e-3
+    for k, v in grads.items():
+        assert G.rel(v.cpu(), g[k]) < 5e-3, k
