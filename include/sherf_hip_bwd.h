@@ -67,6 +67,18 @@ int sherf_bwd_gelu_bwd(float* d, const float* u, int64_t count, sherf_stream_t s
 int sherf_bwd_rgb_fwd(float* lin, int64_t count, sherf_stream_t stream);
 int sherf_bwd_rgb_bwd(float* d, const float* rgb, int64_t count, sherf_stream_t stream);
 
+/* Transpose of sherf_fold_tables (csrc/fold.hip): the gradient d_f of a folded, channel-last table
+ * (element [g][pix][o] at g*group_base + pix*pix_stride + o) goes back to the NCHW source: d_in[g*32+c][pix] =
+ * sum_o W[o][c] d_f[g][pix][o], and dW[32 o][32 c] += sum d_f (x) in  (dW zeroed by the caller).
+ * (oracle/backward_explicit.py: folded_taps_bwd step (ii), tri-planes and 2-D feature map) */
+int sherf_bwd_unfold32(const float* d_f, const float* W, const float* in, int HW, int groups, int pix_stride,
+                       int64_t group_base, float* d_in, float* dW, sherf_stream_t stream);
+
+/* act[r][c] = relu(raw[r][c] * scale[c] + shift[c]) for r < *n_rows, zero up to `cap` rows: the activations of a voxel level
+ * as the forward's consumers see them (BatchNorm+ReLU applied on the fly from bnparam[3][C]). */
+int sherf_bwd_bn_relu_apply(const float* raw, const float* bnparam, const int32_t* n_rows, int64_t cap, int C, float* act,
+                            sherf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

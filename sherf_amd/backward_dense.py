@@ -109,6 +109,13 @@ class HipOps:
     def tile_tokens(self, d_tok, n, out):
         _lib.call_bwd('sherf_bwd_tile_tokens', self._p(d_tok), n, _lib.ptr(out), self.st)
 
+    def unfold32(self, d_f, W, inp, HW, groups, pix_stride, group_base, d_in, dW):
+        _lib.call_bwd('sherf_bwd_unfold32', self._p(d_f), self._p(W), self._p(inp), HW, groups, pix_stride, group_base, self._p(d_in),
+                      self._p(dW), self.st)
+
+    def bn_relu_apply(self, raw, bnparam, n_rows, act):
+        _lib.call_bwd('sherf_bwd_bn_relu_apply', self._p(raw), self._p(bnparam), _lib.ptr(n_rows), raw.rows, raw.cols, self._p(act), self.st)
+
 
 def dense_backward(ops, state, tok, ext, d_sample):
     """tok [n,96] (gather output, row-major: slot tokens incl. bias, WITHOUT the slot-2 rgb encoding), ext [n,12]

@@ -242,6 +242,66 @@ __global__ void rgb_bwd_kernel(float* __restrict__ d, const float* __restrict__ 
     d[i] *= 1.002f * s * (1.f - s);
 }
 
+// transpose of fold32_kernel (csrc/fold.hip): d_in[g*32 + c][pix] = sum_o W[o][c] d_f[g][pix][o];
+// dW[o][c] += sum_{g,pix} d_f[g][pix][o] * in[g*32 + c][pix]  (per-block LDS accumulation, then 1024 atomics per block)
+__global__ void __launch_bounds__(256) unfold32_kernel(const float* __restrict__ d_f, const float* __restrict__ W, const float* __restrict__ in,
+                                                       int HW, int pix_stride, int64_t group_base, float* __restrict__ d_in,
+                                                       float* __restrict__ dW) {
+    __shared__ float s_w[32 * 32];          // [o][c]
+    __shared__ float s_d[64][33], s_x[64][33];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_w[i] = W[i];
+    __syncthreads();
+    const int g = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    float d[32], x[32];
+    const bool live = pix < HW;
+    if (live) {
+        const float4* dp = reinterpret_cast<const float4*>(d_f + (size_t)g * group_base + (size_t)pix * pix_stride);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float4 v = dp[q]; d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            x[c] = in[((size_t)g * 32 + c) * HW + pix];
+            float a = 0.f;
+#pragma unroll
+            for (int o = 0; o < 32; ++o) a += s_w[o * 32 + c] * d[o];
+            d_in[((size_t)g * 32 + c) * HW + pix] = a;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { d[c] = 0.f; x[c] = 0.f; }
+    }
+    // dW: thread t owns entries (o = t / 8, c = 4 * (t % 8) .. +4); pixels staged 64 at a time
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int o_ = threadIdx.x >> 3, c0 = 4 * (threadIdx.x & 7);
+    for (int part = 0; part < 4; ++part) {
+        __syncthreads();
+        if ((threadIdx.x >> 6) == part) {
+            const int r = threadIdx.x & 63;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { s_d[r][c] = d[c]; s_x[r][c] = x[c]; }
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r) {
+            const float dv = s_d[r][o_];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += dv * s_x[r][c0 + e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dW + o_ * 32 + c0 + e, acc[e]);
+}
+
+// act[r][c] = relu(raw[r][c] * scale[c] + shift[c]) for r < *n_rows, 0 beyond (bnparam = [scale | shift | relu(shift)])
+__global__ void bn_relu_apply_kernel(const float* __restrict__ raw, const float* __restrict__ bnparam, const int32_t* __restrict__ n_rows,
+                                     int64_t cap, int C, float* __restrict__ act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    act[i] = r < *n_rows ? fmaxf(raw[i] * bnparam[c] + bnparam[C + c], 0.f) : 0.f;
+}
+
 }  // namespace
 
 extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -364,6 +424,21 @@ extern "C" int sherf_bwd_rgb_fwd(float* lin, int64_t count, sherf_stream_t strea
 extern "C" int sherf_bwd_rgb_bwd(float* d, const float* rgb, int64_t count, sherf_stream_t stream) {
     SHERF_CHECK_ARG(d && rgb && count > 0);
     hipLaunchKernelGGL(rgb_bwd_kernel, SHERF_GRID(count), 0, as_stream(stream), d, rgb, count);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_unfold32(const float* d_f, const float* W, const float* in, int HW, int groups, int pix_stride,
+                                  int64_t group_base, float* d_in, float* dW, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d_f && W && in && d_in && dW && HW > 0 && groups > 0 && pix_stride >= 32 && pix_stride % 4 == 0);
+    hipLaunchKernelGGL(unfold32_kernel, dim3((HW + 255) / 256, groups), dim3(256), 0, as_stream(stream), d_f, W, in, HW, pix_stride,
+                       group_base, d_in, dW);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_bn_relu_apply(const float* raw, const float* bnparam, const int32_t* n_rows, int64_t cap, int C, float* act,
+                                       sherf_stream_t stream) {
+    SHERF_CHECK_ARG(raw && bnparam && n_rows && act && cap > 0 && C > 0);
+    hipLaunchKernelGGL(bn_relu_apply_kernel, SHERF_GRID(cap * C), 0, as_stream(stream), raw, bnparam, n_rows, cap, C, act);
     SHERF_LAUNCH_CHECK();
 }
 

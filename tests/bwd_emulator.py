@@ -82,3 +82,25 @@ class EmuOps:
     def rgb_bwd(self, d, rgb):                                       # sherf_bwd_rgb_bwd
         s = (rgb.tensor() + 0.001) / 1.002
         d.tensor().mul_(1.002 * s * (1 - s))
+
+    def tile_tokens(self, d_tok, n, out):                            # sherf_bwd_tile_tokens: [n,96] -> [tile][3][8][32] float4
+        tiles = (n + 31) // 32
+        pad = torch.zeros(tiles * 32, 96)
+        pad[:n] = d_tok.tensor()
+        out.copy_(pad.view(tiles, 32, 3, 8, 4).permute(0, 2, 3, 1, 4).reshape(-1))
+
+    def unfold32(self, d_f, W, inp, HW, groups, pix_stride, group_base, d_in, dW):     # sherf_bwd_unfold32
+        Wm = W.tensor()                                              # [o, c]
+        flat = d_f.buf[d_f.off:]
+        for g in range(groups):
+            D = torch.as_strided(flat, (HW, 32), (pix_stride, 1), g * group_base)      # [pix, o]
+            X = inp.tensor()[32 * g:32 * g + 32]                                       # [c, pix]
+            d_in.tensor()[32 * g:32 * g + 32].copy_(Wm.t() @ D.t())
+            dW.tensor().add_(D.t() @ X.t())
+
+    def bn_relu_apply(self, raw, bnparam, n_rows, act):              # sherf_bwd_bn_relu_apply
+        C = raw.cols
+        bn = bnparam.tensor().view(3, C)
+        a = torch.relu(raw.tensor() * bn[0] + bn[1])
+        a[int(n_rows):] = 0
+        act.tensor().copy_(a)

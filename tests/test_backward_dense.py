@@ -46,3 +46,62 @@ def test_dense_backward_orchestration(cfg, state):
         assert grads[k].shape == g[k].shape, k
         assert _close(grads[k], g[k], 1e-3), (k, float((grads[k] - g[k]).abs().max()), float(g[k].abs().max()))
     assert _close(dWb_pe, g['stage.tokens_in'][:, 2].t() @ O.positional_encoding(r['tap_rgb'], 5)[:, :32], 1e-4)
+
+
+@pytest.mark.parametrize('cfg', ['tiny_nv', 'tiny'])
+def test_taps_backward_orchestration(cfg, state):
+    """sherf_amd/backward_taps.py on the emulated entry points; the scatter kernel (sherf_gather_tokens_bwd) is stood in for
+    by the oracle's stencils writing the kernel's folded, channel-last layouts."""
+    from oracle import backward_explicit as BX
+    from sherf_amd.backward_taps import taps_backward
+    fx = fixtures.renderer_inputs(cfg)
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+        n = r['x_c'].shape[0]
+        planes = torch.from_numpy(fx['planes'])[0]; obs_feat = torch.from_numpy(fx['obs_feat'])[0]
+        P, (Hf, Wf) = planes.shape[-1], obs_feat.shape[-2:]
+        H, W = fx['input_data']['obs_img_all'].shape[-2:]
+        bounds = torch.from_numpy(fx['input_data']['t_world_bounds']).view(2, 3)
+        taps, cache = BX.encoder_forward_cached(state, torch.from_numpy(fx['vertex_feat']), r['sp_input']['coord'], r['sp_input']['out_sh'])
+        conv_entries = [e for e in cache if e[0] == 'conv']
+        tap_layers = [conv_entries[i] for i in (4, 8, 12)]                 # conv1[1], conv2[2], conv3[2]: the tapped layers
+        levels = []
+        for (keys, feats, shape), ent in zip(taps, tap_layers):
+            xh, inv, y, xh0, y0, mult, n_rows = ent[5]
+            gamma, beta = state[ent[2] + '.weight'], state[ent[2] + '.bias']
+            rows, C = feats.shape
+            cap = rows + 5                                                  # padded capacity, like the product's buffers
+            # raw and the (scale, shift) the forward's consumers use: y = raw * scale + shift
+            scale = gamma * inv
+            raw = (xh / inv + (-(xh0 / inv)))                               # raw = xh / inv + mean, mean = -xh0 / inv
+            shift = beta - (-(xh0 / inv)) * scale
+            rawp = torch.zeros(cap, C); rawp[:rows] = raw
+            levels.append(dict(raw=Mat(rawp.reshape(-1), cap, C), bnparam=Mat(torch.cat([scale, shift, torch.relu(shift)]).clone(), 1, 3 * C),
+                               n_rows=torch.tensor(rows), cap=cap, C=C, keys=keys, shape=shape))
+            assert _close(torch.relu(raw * scale + shift), feats, 1e-5)     # mult == 1 above level 0: feats are the activations
+
+        def scatter(d_tiled, d_planes_f, d_feat_f, d_rows, d_bias):         # stands in for sherf_gather_tokens_bwd
+            tiles = (n + 31) // 32
+            d_tok = d_tiled.view(tiles, 3, 8, 32, 4).permute(0, 3, 1, 2, 4).reshape(tiles * 32, 3, 32)[:n]
+            dpf = BX.triplane_bwd((3, 32, P, P), r['x_c'], bounds, d_tok.permute(1, 0, 2))              # [3,32,P,P]
+            d_planes_f.tensor().copy_(dpf.permute(0, 2, 3, 1).reshape(3 * P * P, 32))
+            gg = 2.0 * r['uv'] / torch.tensor([W, H], dtype=torch.float32) - 1.0
+            dff = BX._grid_sample_2d_bwd((64, Hf, Wf), gg[:, 0], gg[:, 1], True, d_tok[:, :2].reshape(n, 64))
+            d_feat_f.tensor().copy_(dff.permute(1, 2, 0).reshape(Hf * Wf, 64))
+            for lv, dr in zip(levels, d_rows):
+                rows = int(lv['n_rows'])
+                dr.tensor()[:rows].copy_(BX.trilinear_sparse_bwd(lv['keys'], rows, lv['shape'], r['grid'], d_tok.reshape(n, 96)))
+            d_bias.tensor().copy_(d_tok.sum(0).reshape(1, 96))
+
+        ctx = dict(n=n, P=P, Hf=Hf, Wf=Wf, planes=Mat(planes.reshape(-1).clone(), 96, P * P), obs_feat=Mat(obs_feat.reshape(-1).clone(), 64, Hf * Wf),
+                   levels=levels, scatter=scatter)
+        d_tin = Mat(g['stage.tokens_in'].reshape(-1).clone(), n, 96)
+        dWb_pe = g['stage.tokens_in'][:, 2].t() @ O.positional_encoding(r['tap_rgb'], 5)[:, :32]
+        out = taps_backward(EmuOps(), state, ctx, d_tin, dWb_pe)
+    assert _close(out['d_planes'].tensor().view(3, 32, P, P), g['input.planes'][0], 2e-4)
+    assert _close(out['d_obs_feat'].tensor().view(64, Hf, Wf), g['input.obs_feat'][0], 2e-4)
+    for i, lv in enumerate(levels):
+        assert _close(out['d_levels'][i].tensor()[:int(lv['n_rows'])], g[f'stage.level{i}'], 5e-4), i
+    for k, v in out['grads'].items():
+        assert v.shape == g[k].shape and _close(v, g[k], 5e-4), k
