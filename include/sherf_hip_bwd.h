@@ -79,6 +79,30 @@ int sherf_bwd_unfold32(const float* d_f, const float* W, const float* in, int HW
 int sherf_bwd_bn_relu_apply(const float* raw, const float* bnparam, const int32_t* n_rows, int64_t cap, int C, float* act,
                             sherf_stream_t stream);
 
+/* ---- sparse voxel encoder backward (oracle/backward_explicit.py: _bn_relu_bwd, encoder_bwd) ----------------------------
+ * BatchNorm (batch statistics over the reference's row set) + ReLU backward of one layer: d_out = gradient w.r.t. the
+ * per-voxel activation relu(bn(raw)) + (mult - 1) relu(shift); raw [cap][C] the conv output, bnparam [3][C] / stats [2][C]
+ * as left by the forward, mult (level 0 only, else NULL), n_total = rows of the reference row set, n_rows = voxels.
+ * -> d_raw [cap][C] (zero beyond n_rows), dgamma[C], dbeta[C]; sums[3][C] is scratch. */
+int sherf_bwd_bn_relu(const float* d_out, const float* raw, const float* bnparam, const float* stats, const float* gamma,
+                      const int32_t* mult, const int32_t* n_total, const int32_t* n_rows, int64_t cap, int C, float* sums,
+                      float* d_raw, float* dgamma, float* dbeta, sherf_stream_t stream);
+/* Sparse conv backward w.r.t. its input: for the rows (keys_i, dims Di..) of the INPUT level,
+ * d_in[i][ci] = sum_k sum_co d_raw[o(i,k)][co] W[co][k][ci], W = the reference weight [Cout][27][Cin]; the rows o live in the
+ * level described by wp_o (dims Do..): mode 0 submanifold (same level), mode 1 stride-2 (o in the coarser level). */
+int sherf_bwd_conv_dgrad(const int32_t* keys_i, const int32_t* n_rows_i, int Di, int Hi, int Wi, const uint32_t* wp_o, int Do,
+                         int Ho, int Wo, const float* d_raw, int Cout, const float* W, int Cin, int mode, int max_rows,
+                         float* d_in, sherf_stream_t stream);
+/* Sparse conv backward w.r.t. its weight: dW[Cout][27][Cin] += sum_o d_raw[o] (x) act(in[nb(o,k)]) with the forward's
+ * neighbour rule (mode 0 submanifold, 1 stride-2) and the producer's BatchNorm+ReLU applied on the fly (in_bn / in_mult as
+ * in sherf_svox_conv3; NULL = raw input).  dW zeroed by the caller. */
+int sherf_bwd_conv_wgrad(const int32_t* keys_o, const int32_t* n_rows_o, int Do, int Ho, int Wo, const uint32_t* wp_i, int Di,
+                         int Hi, int Wi, const float* in_raw, int Cin, const float* in_bn, const int32_t* in_mult,
+                         const float* d_raw, int Cout, int mode, int max_rows, float* dW, sherf_stream_t stream);
+/* Level-0 aggregation backward: d_feat[i][:] = d_g[row of voxel coord[i]][:] (rows that shared a voxel share its gradient). */
+int sherf_bwd_gather_rows(const int32_t* coord, int n, int D, int H, int W, const uint32_t* wp, const float* d_g, int C,
+                          float* d_feat, sherf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,7 +277,7 @@ def encoder_forward_cached(state, feat, coord, out_sh, prefix='renderer.encoder_
     mult = torch.bincount(inv, minlength=uk.numel())
     g = torch.zeros(uk.numel(), feat.shape[1]).index_add_(0, inv, feat)
     n_rows = feat.shape[0]
-    taps, cache = [], [('input', inv)]
+    taps, cache = [], [('input', inv, uk, list(sh), g)]
     for name, kind, nconv in O._ENC_LAYERS:
         if name == 'TAP':
             taps.append((uk.clone(), g.clone(), list(sh)))
@@ -303,7 +303,8 @@ def encoder_forward_cached(state, feat, coord, out_sh, prefix='renderer.encoder_
                         pairs.append((kk, o, pos[o]))
                 g_in = g
                 g, bnc = _bn_relu_fwd(raw, mult, n_rows, state[bname + '.weight'], state[bname + '.bias'])
-                cache.append(('conv', wname, bname, pairs, g_in, bnc))
+                cache.append(('conv', wname, bname, pairs, g_in, bnc,
+                              dict(keys_in=uk, sh_in=list(sh), keys_out=uk, sh_out=list(sh), down=False, raw=raw)))
         else:
             wname, bname = f'{prefix}{name}.0', f'{prefix}{name}.1'
             W = state[wname + '.weight']
@@ -328,11 +329,12 @@ def encoder_forward_cached(state, feat, coord, out_sh, prefix='renderer.encoder_
                     raw.index_add_(0, ninv[m], g[src_all[m]] @ Wf[:, kk, :].t())
                     pairs.append((kk, ninv[m], src_all[m]))
             g_in = g
+            meta = dict(keys_in=uk, sh_in=list(sh), keys_out=nuk, sh_out=list(osh), down=True, raw=raw)
             uk, sh = nuk, osh
             mult = torch.ones(uk.numel(), dtype=torch.long)
             n_rows = uk.numel()
             g, bnc = _bn_relu_fwd(raw, mult, n_rows, state[bname + '.weight'], state[bname + '.bias'])
-            cache.append(('conv', wname, bname, pairs, g_in, bnc))
+            cache.append(('conv', wname, bname, pairs, g_in, bnc, meta))
     return taps, cache
 
 
@@ -348,7 +350,7 @@ def encoder_bwd(state, cache, d_taps):
             d_g = d_taps[tap_i] if d_g is None else d_g + d_taps[tap_i]
             tap_i -= 1
         elif entry[0] == 'conv':
-            _, wname, bname, pairs, g_in, bnc = entry
+            _, wname, bname, pairs, g_in, bnc = entry[:6]
             W = state[wname + '.weight']                                       # [out,3,3,3,in]
             d_raw, grads[bname + '.weight'], grads[bname + '.bias'] = _bn_relu_bwd(d_g, state[bname + '.weight'], bnc)
             dW = torch.zeros_like(W).reshape(W.shape[0], 27, W.shape[4])

@@ -113,6 +113,25 @@ class HipOps:
         _lib.call_bwd('sherf_bwd_unfold32', self._p(d_f), self._p(W), self._p(inp), HW, groups, pix_stride, group_base, self._p(d_in),
                       self._p(dW), self.st)
 
+    # ---- sparse encoder backward (levels are dicts: keys / wp / n_rows int32 tensors, dims (D,H,W), cap) ----
+    def bn_relu_bwd(self, d_out, raw, bnparam, stats, gamma, mult, n_total, n_rows, d_raw, dgamma, dbeta):
+        sums = Mat.zeros(3, raw.cols, raw.buf.device)
+        _lib.call_bwd('sherf_bwd_bn_relu', self._p(d_out), self._p(raw), self._p(bnparam), self._p(stats), self._p(gamma),
+                      None if mult is None else _lib.ptr(mult), _lib.ptr(n_total), _lib.ptr(n_rows), raw.rows, raw.cols, self._p(sums),
+                      self._p(d_raw), self._p(dgamma), self._p(dbeta), self.st)
+
+    def conv_wgrad(self, lev_out, lev_in, in_raw, Cin, in_bn, in_mult, d_raw, Cout, mode, dW):
+        _lib.call_bwd('sherf_bwd_conv_wgrad', _lib.ptr(lev_out['keys']), _lib.ptr(lev_out['n_rows']), *lev_out['dims'], _lib.ptr(lev_in['wp']),
+                      *lev_in['dims'], self._p(in_raw), Cin, None if in_bn is None else self._p(in_bn),
+                      None if in_mult is None else _lib.ptr(in_mult), self._p(d_raw), Cout, mode, lev_out['cap'], self._p(dW), self.st)
+
+    def conv_dgrad(self, lev_in, lev_out, d_raw, Cout, W, Cin, mode, d_in):
+        _lib.call_bwd('sherf_bwd_conv_dgrad', _lib.ptr(lev_in['keys']), _lib.ptr(lev_in['n_rows']), *lev_in['dims'], _lib.ptr(lev_out['wp']),
+                      *lev_out['dims'], self._p(d_raw), Cout, self._p(W), Cin, mode, lev_in['cap'], self._p(d_in), self.st)
+
+    def gather_rows(self, coord, N, lev0, d_g, C, d_feat):
+        _lib.call_bwd('sherf_bwd_gather_rows', _lib.ptr(coord), N, *lev0['dims'], _lib.ptr(lev0['wp']), self._p(d_g), C, self._p(d_feat), self.st)
+
     def bn_relu_apply(self, raw, bnparam, n_rows, act):
         _lib.call_bwd('sherf_bwd_bn_relu_apply', self._p(raw), self._p(bnparam), _lib.ptr(n_rows), raw.rows, raw.cols, self._p(act), self.st)
 

@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
 
 
 LIB_BWD = os.path.join(HERE, 'libsherf_hip_bwd.so')
-SOURCES_BWD = ['bwd_dense.hip']
+SOURCES_BWD = ['bwd_dense.hip', 'bwd_encoder.hip']
 
 
 def build_bwd(force=False, verbose=True):

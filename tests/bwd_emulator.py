@@ -104,3 +104,79 @@ class EmuOps:
         a = torch.relu(raw.tensor() * bn[0] + bn[1])
         a[int(n_rows):] = 0
         act.tensor().copy_(a)
+
+    # ---- sparse encoder backward: levels are dicts(keys sorted int64, n_rows, dims (D,H,W), cap) ----
+    @staticmethod
+    def _rows_of(lev, z, y, x):
+        """row ids of voxels (z,y,x) in a level, -1 where absent / out of range."""
+        D, H, W = lev['dims']
+        ok = (z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W)
+        k = (z * H + y) * W + x
+        keys = lev['keys'][:int(lev['n_rows'])].long()
+        pos = torch.searchsorted(keys, k.clamp(min=0)).clamp(max=keys.numel() - 1)
+        ok &= keys[pos] == k
+        return torch.where(ok, pos, torch.full_like(pos, -1))
+
+    @staticmethod
+    def _zyx(lev):
+        D, H, W = lev['dims']
+        k = lev['keys'][:int(lev['n_rows'])].long()
+        return k // (H * W), (k // W) % H, k % W
+
+    def bn_relu_bwd(self, d_out, raw, bnparam, stats, gamma, mult, n_total, n_rows, d_raw, dgamma, dbeta):     # sherf_bwd_bn_relu
+        C, n, N = raw.cols, int(n_rows), float(int(n_total))
+        bn, st = bnparam.tensor().view(3, C), stats.tensor().view(2, C)
+        scale, shift, mean, inv = bn[0], bn[1], st[0], 1.0 / torch.sqrt(st[1] + 1e-3)
+        x, d = raw.tensor()[:n], d_out.tensor()[:n]
+        dy = d * ((x * scale + shift) > 0).float()
+        xh = (x - mean) * inv
+        s3 = ((mult[:n].float() - 1)[:, None] * d).sum(0) if mult is not None else torch.zeros(C)
+        dy0 = s3 * (shift > 0).float()
+        s1, s2 = dy.sum(0) + dy0, (dy * xh).sum(0) + dy0 * (-mean * inv)
+        d_raw.tensor().zero_()
+        d_raw.tensor()[:n].copy_((gamma.tensor().view(-1) * inv / N) * (N * dy - s1 - xh * s2))
+        dgamma.tensor().copy_(s2[None]); dbeta.tensor().copy_(s1[None])
+
+    def _act(self, in_raw, in_bn, in_mult, rows):
+        x = in_raw.tensor()[rows]
+        if in_bn is None:
+            return x
+        C = in_raw.cols
+        bn = in_bn.tensor().view(3, C)
+        a = torch.relu(x * bn[0] + bn[1])
+        if in_mult is not None:
+            a = a + (in_mult[rows].float() - 1)[:, None] * bn[2]
+        return a
+
+    def conv_wgrad(self, lev_out, lev_in, in_raw, Cin, in_bn, in_mult, d_raw, Cout, mode, dW):                # sherf_bwd_conv_wgrad
+        z, y, x = self._zyx(lev_out)
+        out = dW.tensor().view(Cout, 27, Cin)
+        for k in range(27):
+            kz, ky, kx = k // 9, (k // 3) % 3, k % 3
+            nb = self._rows_of(lev_in, 2 * z + kz - 1, 2 * y + ky - 1, 2 * x + kx - 1) if mode else self._rows_of(lev_in, z + kz - 1, y + ky - 1, x + kx - 1)
+            o = torch.nonzero(nb >= 0)[:, 0]
+            if o.numel():
+                out[:, k, :] += d_raw.tensor()[o].t() @ self._act(in_raw, in_bn, in_mult, nb[o])
+
+    def conv_dgrad(self, lev_in, lev_out, d_raw, Cout, W, Cin, mode, d_in):                                    # sherf_bwd_conv_dgrad
+        z, y, x = self._zyx(lev_in)
+        Wm = W.tensor().view(Cout, 27, Cin)
+        res = torch.zeros(int(lev_in['n_rows']), Cin)
+        for k in range(27):
+            kz, ky, kx = k // 9, (k // 3) % 3, k % 3
+            nz, ny, nx = z + 1 - kz, y + 1 - ky, x + 1 - kx
+            if mode:
+                even = (nz >= 0) & (ny >= 0) & (nx >= 0) & (nz % 2 == 0) & (ny % 2 == 0) & (nx % 2 == 0)
+                nb = self._rows_of(lev_out, nz // 2, ny // 2, nx // 2)
+                nb = torch.where(even, nb, torch.full_like(nb, -1))
+            else:
+                nb = self._rows_of(lev_out, nz, ny, nx)
+            i = torch.nonzero(nb >= 0)[:, 0]
+            if i.numel():
+                res[i] += d_raw.tensor()[nb[i]] @ Wm[:, k, :]
+        d_in.tensor()[:res.shape[0]].copy_(res)
+
+    def gather_rows(self, coord, N, lev0, d_g, C, d_feat):                                                      # sherf_bwd_gather_rows
+        c = coord.long()
+        rows = self._rows_of(lev0, c[:, 1], c[:, 2], c[:, 3])
+        d_feat.tensor().copy_(torch.where((rows >= 0)[:, None], d_g.tensor()[rows.clamp(min=0)], torch.zeros(N, C)))

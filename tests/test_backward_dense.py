@@ -105,3 +105,58 @@ def test_taps_backward_orchestration(cfg, state):
         assert _close(out['d_levels'][i].tensor()[:int(lv['n_rows'])], g[f'stage.level{i}'], 5e-4), i
     for k, v in out['grads'].items():
         assert v.shape == g[k].shape and _close(v, g[k], 5e-4), k
+
+
+@pytest.mark.parametrize('cfg', ['tiny_nv', 'tiny'])
+def test_encoder_backward_orchestration(cfg, state):
+    """sherf_amd/backward_encoder.py on the emulated entry points: every sparse-conv / BatchNorm parameter gradient and the
+    per-vertex feature gradient against autograd through the oracle."""
+    from oracle import backward_explicit as BX
+    from sherf_amd.backward_encoder import encoder_backward
+    fx = fixtures.renderer_inputs(cfg)
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+        coord = r['sp_input']['coord']
+        N = coord.shape[0]
+        taps, cache = BX.encoder_forward_cached(state, torch.from_numpy(fx['vertex_feat']), coord, r['sp_input']['out_sh'])
+        _, inv0, uk0, sh0, g0 = cache[0]
+        convs = [e for e in cache if e[0] == 'conv']
+        # levels: 0 = input voxels, then one per strided conv
+        lev_keys, lev_dims = [uk0], [tuple(sh0)]
+        for e in convs:
+            if e[6]['down']:
+                lev_keys.append(e[6]['keys_out']); lev_dims.append(tuple(e[6]['sh_out']))
+        pad = 3
+        levels = [dict(keys=torch.cat([k, torch.zeros(pad, dtype=k.dtype)]), n_rows=torch.tensor(k.numel()), dims=d, cap=k.numel() + pad)
+                  for k, d in zip(lev_keys, lev_dims)]
+        mult = torch.cat([torch.bincount(inv0, minlength=uk0.numel()), torch.ones(pad, dtype=torch.long)])
+        layers, lev = [], 0
+        tap_after = {4, 8, 12}
+        for i, e in enumerate(convs):
+            _, wname, bname, pairs, g_in, bnc, meta = e
+            xh, inv, y, xh0, y0, m_, n_rows = bnc
+            lev_out = lev + 1 if meta['down'] else lev
+            gamma, beta = state[bname + '.weight'], state[bname + '.bias']
+            mean, C = -(xh0 / inv), xh.shape[1]
+            scale = gamma * inv
+            shift = beta - mean * scale
+            cap = levels[lev_out]['cap']
+            rawp = torch.zeros(cap, C); rawp[:meta['raw'].shape[0]] = meta['raw']
+            layers.append(dict(wname=wname, bname=bname, cin=g_in.shape[1], cout=C, down=meta['down'], tap=i in tap_after, lev_in=lev, lev_out=lev_out,
+                               raw=Mat(rawp.reshape(-1), cap, C), bnparam=Mat(torch.cat([scale, shift, torch.relu(shift)]).clone(), 1, 3 * C),
+                               stats=Mat(torch.cat([mean, 1.0 / inv ** 2 - 1e-3]).clone(), 1, 2 * C)))
+            lev = lev_out
+        g0p = torch.zeros(levels[0]['cap'], 32); g0p[:g0.shape[0]] = g0
+        ctx = dict(levels=levels, mult=mult, n_total=torch.tensor(N), coord=coord, N=N, g0=Mat(g0p.reshape(-1), levels[0]['cap'], 32), layers=layers)
+        d_levels = []
+        for i, (keys, feats, shape) in enumerate(taps):
+            cap = levels[i + 1]['cap']
+            d = torch.zeros(cap, feats.shape[1]); d[:feats.shape[0]] = g[f'stage.level{i}']
+            d_levels.append(Mat(d.reshape(-1), cap, feats.shape[1]))
+        d_feat, grads = encoder_backward(EmuOps(), state, ctx, d_levels)
+    assert _close(d_feat.tensor(), g['input.vertex_feat'], 1e-3)
+    want = [k for k in g if k.startswith('renderer.encoder_3d.')]
+    assert set(want) == set(grads)
+    for k in want:
+        assert grads[k].shape == g[k].shape and _close(grads[k], g[k], 3e-3), (k, float((grads[k] - g[k]).abs().max()), float(g[k].abs().max()))
