@@ -286,6 +286,20 @@ class ImportanceRenderer(nn.Module):
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
                 decoder, ray_origins, ray_directions, near, far, input_data, rendering_options):
+        if getattr(self, 'enable_autograd', False) and torch.is_grad_enabled() and not getattr(self, '_in_autograd', False):
+            # opt-in training path (BASELINE config 5): the same forward, recorded as one autograd node whose backward runs
+            # the HIP backward pipeline (sherf_amd/backward.py; experimental until verified on hardware)
+            from .backward import RenderFunction, _named_params
+
+            def call():
+                self._in_autograd = True
+                try:
+                    return self.forward(planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask,
+                                        obs_sp_input, decoder, ray_origins, ray_directions, near, far, input_data, rendering_options)
+                finally:
+                    self._in_autograd = False
+            return RenderFunction.apply(self, decoder, call, planes, obs_input_feature, canonical_sp_conv_volume.features,
+                                        *[p for _, p in _named_params(self, decoder)])
         if not (self.use_1d_feature and self.use_2d_feature and self.use_3d_feature and self.use_trans and self.use_NeRF_decoder):
             raise NotImplementedError('sherf_amd implements the shipped SHERF configuration: use_1d/2d/3d_feature, use_trans '
                                       'and use_NeRF_decoder all True (train_*.sh)')
@@ -383,6 +397,10 @@ class ImportanceRenderer(nn.Module):
         self.encoder_3d.finish(pl)
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap)
+        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels,
+                         # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
+                         bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
+                                  bounds=input_data['t_world_bounds'], vox_min=vox_min, vox_sh=[int(v) for v in obs_sp_input['out_sh']],
+                                  coord=vcoord, H=H, W=W, white_back=bool(opts.get('white_back', False))))
         return ws['rgb'].view(1, R, 3).clone(), ws['depth'].view(1, R, 1).clone(), ws['acc'].view(1, R, 1).clone()
 

@@ -98,7 +98,7 @@ class SparseConvNet(nn.Module):
                 wt = w.permute(1, 2, 3, 4, 0).reshape(27, conv.in_channels, conv.out_channels).contiguous()
                 layers.append(dict(wt=pack_conv_weights(wt), cin=conv.in_channels, cout=conv.out_channels, down=conv.stride == 2, bn=bn,
                                    gamma=bn.weight.detach().float().contiguous(), beta=bn.bias.detach().float().contiguous(),
-                                   tap=(name in ('conv1', 'conv2', 'conv3') and i == n - 1)))
+                                   tap=(name in ('conv1', 'conv2', 'conv3') and i == n - 1), wname=f'{name}.{3 * i}', bname=f'{name}.{3 * i + 1}'))
         self._packed = dict(key=key, layers=layers)
         return self._packed
 
@@ -135,7 +135,8 @@ class SparseConvNet(nn.Module):
             c.wt, c.gamma, c.beta = A(ly['wt']), A(ly['gamma']), A(ly['beta'])
             c.stats, c.bnparam, c.out = A(stats), A(bnp), A(out)
             c.acc = L[0]['bn_acc'].data_ptr() + li * 8 * 2 * 96 * 8                 # [8][2][C] int64 inside the zero region
-            meta.append(dict(bn=ly['bn'], stats=stats, bnp=bnp, out=out, lev=dlev, cout=C))
+            meta.append(dict(bn=ly['bn'], stats=stats, bnp=bnp, out=out, lev=dlev, lev_in=lev, cout=C, cin=ly['cin'], down=bool(ly['down']),
+                             tap=bool(ly['tap']), wname=ly['wname'], bname=ly['bname'], stats_off=off - 2 * C))
             if ly['tap']:
                 taps.append((dlev, out, bnp, C))
             lev = dlev

@@ -132,3 +132,31 @@ def test_dense_backward_on_the_gpu():
     assert G.rel(d_tin.tensor().cpu().view(n, 3, 32), g['stage.tokens_in']) < 2e-3
     for k, v in grads.items():
         assert G.rel(v.cpu(), g[k]) < 5e-3, k
+
+
+def test_full_backward_against_reference_gradients():
+    """forward + backward through the HIP pipeline under the stub loss of BASELINE config 5, against the fingerprints of the
+    UNMODIFIED reference's gradients (tests/golden/grad_tiny_nv.npz) and the oracle's input gradients."""
+    import os
+    from sherf_amd.backward import render_backward
+    cfg = 'tiny_nv'
+    fx = G.fixture(cfg)
+    ref = np.load(os.path.join(G.GOLDEN, f'grad_{cfg}.npz'))
+    h = G.hip_render(cfg)                                   # training-mode forward (batch statistics)
+    rend, dec = G.hip_modules()
+    R = h['rgb'].shape[0]
+    rs = np.random.RandomState(11)
+    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1, R, 3)).astype(np.float32))[0]
+    t_acc = torch.from_numpy(rs.uniform(0, 1, (1, R, 1)).astype(np.float32))[0, :, 0]
+    d_rgb = (2.0 * (h['rgb'] - t_rgb) / (R * 3)).cuda()
+    d_acc = (2.0 * (h['acc'] - t_acc) / R).cuda()
+    out = render_backward(rend, dec, d_rgb, d_acc)
+    torch.cuda.synchronize()
+    grads = dict(out['params'])
+    grads.update({'input.planes': out['planes'], 'input.obs_feat': out['obs_feat'], 'input.vertex_feat': out['vertex_feat']})
+    names = [k for k in ref.files if k not in ('loss', 'ref_cpu_seconds')]
+    assert set(names) == set(grads), set(names) ^ set(grads)
+    for k in names:
+        ours, r = O.grad_fingerprint(grads[k].float().cpu()), ref[k]
+        assert abs(ours[2] - r[2]) < 1e-2 * r[2] + 1e-30, (k, ours[2], r[2])
+        assert np.linalg.norm(ours[3:] - r[3:]) < 5e-2 * np.linalg.norm(r[3:]) + 1e-30, k
