@@ -99,3 +99,16 @@ def test_struct_layouts_match_header(tmp_path):
     subprocess.check_call(['gcc', str(tmp_path / 't.c'), '-o', str(tmp_path / 't')])
     got = [int(v) for v in subprocess.check_output([str(tmp_path / 't')]).decode().split()]
     assert [w[2] for w in want] == got, [(w, g) for w, g in zip(want, got) if w[2] != g]
+
+
+def test_backward_library_exports_every_declared_symbol():
+    """libsherf_hip_bwd.so (include/sherf_hip_bwd.h, experimental backward building blocks) loads next to torch's rocBLAS and
+    validates its arguments before touching a device."""
+    protos = _lib.parse_header(_lib.HEADER_BWD)
+    assert len(protos) >= 23
+    l = _lib.lib_bwd()
+    for name in protos:
+        assert hasattr(l, name), name
+    assert l.sherf_bwd_gemm(0, 0, 0, 0, 0, None, 0, None, 0, None, 0, ctypes.c_float(0.0), None) == -1
+    assert b'bad argument' in l.sherf_bwd_last_error()
+    assert l.sherf_bwd_conv_dgrad(None, None, 1, 1, 1, None, 1, 1, 1, None, 32, None, 32, 0, 1, None, None) == -1
