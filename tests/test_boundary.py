@@ -112,3 +112,27 @@ def test_backward_library_exports_every_declared_symbol():
     assert l.sherf_bwd_gemm(0, 0, 0, 0, 0, None, 0, None, 0, None, 0, ctypes.c_float(0.0), None) == -1
     assert b'bad argument' in l.sherf_bwd_last_error()
     assert l.sherf_bwd_conv_dgrad(None, None, 1, 1, 1, None, 1, 1, 1, None, 32, None, 32, 0, 1, None, None) == -1
+
+
+def test_sparse_encoder_plan_host_logic(monkeypatch):
+    """SparseConvNet.plan (the descriptor of the native encoder driver) built on CPU tensors: layer table, level capacities,
+    accumulator placement -- the host logic of sherf_svox_encode, no device involved."""
+    from sherf_amd import voxel
+    from sherf_amd.renderer import _Workspace
+    monkeypatch.setattr(_lib, 'addr', lambda t, dtype=None: None if t is None else t.data_ptr())
+    net = voxel.SparseConvNet()
+    pl = net.plan([96, 320, 384], 6890, [torch.zeros(4) for _ in range(3)], _Workspace(), torch.device('cpu'))
+    p = pl['plan']
+    assert p.n_layers == 13
+    lay = [(p.layers[i].cin, p.layers[i].cout, p.layers[i].down, p.layers[i].tap) for i in range(13)]
+    assert lay == [(32, 32, 0, 0), (32, 32, 0, 0), (32, 32, 1, 0), (32, 32, 0, 0), (32, 32, 0, 1), (32, 64, 1, 0), (64, 64, 0, 0), (64, 64, 0, 0),
+                   (64, 64, 0, 1), (64, 96, 1, 0), (96, 96, 0, 0), (96, 96, 0, 0), (96, 96, 0, 1)]
+    assert [(p.lev[i].D, p.lev[i].H, p.lev[i].W) for i in range(4)] == [(96, 320, 384), (48, 160, 192), (24, 80, 96), (12, 40, 48)]
+    assert [p.lev[i].cap for i in range(4)] == [6890, 55120, 55120, 23040]
+    z0, z1 = p.zero_ptr, p.zero_ptr + p.zero_bytes                       # everything that must be zero at frame start is inside
+    for i in range(4):
+        assert z0 <= p.lev[i].bitmap < z1
+    for i in range(13):
+        assert z0 <= p.layers[i].acc and p.layers[i].acc + 8 * 2 * p.layers[i].cout * 8 <= z1 and p.layers[i].acc % 8 == 0
+    assert z0 <= p.acc_fix < z1 and z0 <= p.mult < z1
+    assert [m['wname'] for m in pl['meta']][:3] == ['conv0.0', 'conv0.3', 'down0.0'] and [t[0] for t in pl['taps']] == [1, 2, 3]
