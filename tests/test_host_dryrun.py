@@ -1,0 +1,85 @@
+"""Host-side dry run of ImportanceRenderer.forward on CPU tensors with the native calls stubbed: exercises every line of the
+Python that fills the frame descriptor (sherf_frame / sherf_svox_plan), in training, eval and density-noise mode, without a
+GPU.  The kernels are not involved; this guards the host logic between GPU sessions."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures, sherf_oracle as O
+from sherf_amd import _lib
+from tests import gpu_common as G
+
+
+class _FakeCuda(torch.Tensor):
+    is_cuda = True
+
+
+@pytest.fixture()
+def stubbed(monkeypatch):
+    calls, frames = [], []
+    monkeypatch.setattr(_lib, 'call', lambda name, *a: calls.append((name, a)))
+    monkeypatch.setattr(_lib, 'addr', lambda t, dtype=None: None if t is None else t.data_ptr())
+    monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: type('S', (), {'cuda_stream': 0})())
+    orig = _lib.Frame
+
+    def make():
+        frames.append(orig())
+        return frames[-1]
+    monkeypatch.setattr(_lib, 'Frame', make)
+    return calls, frames
+
+
+def _run(training, options=None):
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder
+    from sherf_amd.voxel import SparseConvTensor
+    fx = G.fixture('tiny')
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=G.smpl())
+    dec = NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
+    rend.train(training); dec.train(training)
+    rend._side = lambda dev, idx=0: type('X', (), {'cuda_stream': 8 + 8 * idx})()
+    d = fixtures.to_torch(fx['input_data'])
+    spi = O.render_from_fixture(fx, G.seeded_state(), keep=False)['sp_input']
+    sp = SparseConvTensor(torch.from_numpy(fx['vertex_feat']), spi['coord'], spi['out_sh'], 1)
+    spd = dict(coord=spi['coord'], out_sh=spi['out_sh'], batch_size=1, bounds=spi['bounds'][None])
+    opts = dict(fx['options'])
+    opts.update(options or {})
+    with torch.no_grad():
+        out = rend(torch.from_numpy(fx['planes']), d['obs_img_all'][:, 0], torch.from_numpy(fx['obs_feat']), sp, None, spd, dec,
+                   d['ray_o_all'][:, 0].as_subclass(_FakeCuda), d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, opts)
+    return rend, out
+
+
+def test_training_frame_descriptor_is_complete(stubbed):
+    calls, frames = stubbed
+    rend, (rgb, depth, acc) = _run(True)
+    assert [c[0] for c in calls] == ['sherf_render_frame']
+    assert rgb.shape == (1, 1024, 3) and depth.shape == (1, 1024, 1) and acc.shape == (1, 1024, 1)
+    fr = frames[-1]
+    for name, ctype in fr._fields_:
+        if ctype is ctypes.c_void_p:
+            assert getattr(fr, name), f'frame.{name} is NULL'
+    assert (fr.R, fr.S, fr.capacity) == (1024, 16, 1024 * 16) and fr.vox_n == 6890 and fr.vox_training == 1
+    assert (fr.P, fr.Hf, fr.Wf, fr.H, fr.W) == (32, 16, 16, 32, 32) and list(fr.vox_sh) == [int(v) for v in rend.last['bwd']['vox_sh']]
+    assert fr.mlp_prec == 1 and fr.mlp_shape == 0 and fr.main_after_layer == -1
+    assert {'plan', 'levels_struct', 'bwd', 'ws'} <= set(rend.last)
+
+
+def test_eval_mode_prepares_batchnorm_constants_once(stubbed):
+    calls, frames = stubbed
+    rend, _ = _run(False)
+    names = [c[0] for c in calls]
+    assert names.count('sherf_svox_bn_finalize') == 13 and names[-1] == 'sherf_render_frame'     # running statistics -> bnparam
+    assert frames[-1].vox_training == 0
+
+
+def test_density_noise_splits_the_frame_in_two_phases(stubbed, monkeypatch):
+    calls, frames = stubbed
+    monkeypatch.setattr(torch, 'randn', lambda n, device=None: torch.zeros(n))
+    _run(True, dict(density_noise=0.5))
+    phases = [c[1][1] for c in calls if c[0] == 'sherf_render_frame']
+    assert phases == [1, 2]
