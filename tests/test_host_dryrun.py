@@ -83,3 +83,28 @@ def test_density_noise_splits_the_frame_in_two_phases(stubbed, monkeypatch):
     _run(True, dict(density_noise=0.5))
     phases = [c[1][1] for c in calls if c[0] == 'sherf_render_frame']
     assert phases == [1, 2]
+
+
+def test_backward_glue_dry_run(stubbed, monkeypatch):
+    """render_backward's glue (contexts built from the forward's workspace and plan, ~120 staged calls) with every native call
+    stubbed: buffer shapes / strides are checked by Mat's bounds assertions, names by the returned gradient keys."""
+    from sherf_amd import backward, backward_dense
+    calls, frames = stubbed
+    bwd_calls = []
+    monkeypatch.setattr(_lib, 'call_bwd', lambda name, *a: bwd_calls.append(name))
+    monkeypatch.setattr(backward_dense.HipOps, '_p', staticmethod(lambda m: ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)))
+    rend, (rgb, depth, acc) = _run(True)
+    rend.last['ws']['counters'][0] = 77                                  # pretend the sampler found 77 valid samples
+    from sherf_amd.triplane import NeRFDecoder
+    dec = NeRFDecoder(32)
+    out = backward.render_backward(rend, dec, torch.zeros_like(rgb), torch.zeros_like(acc))
+    names = {'renderer.' + k for k, _ in rend.named_parameters() if not k.startswith('encoder_3d.conv4') and not k.startswith('encoder_3d.down3')}
+    names |= {'decoder.' + k for k, _ in dec.named_parameters()}
+    assert set(out['params']) == names, set(out['params']) ^ names
+    for k, p in list(rend.named_parameters()) + list(dec.named_parameters()):
+        full = ('renderer.' if p is not None and k in dict(rend.named_parameters()) else 'decoder.') + k
+        if full in out['params']:
+            assert out['params'][full].shape == p.shape, full
+    assert out['planes'].shape == (1, 3, 32, 32, 32) and out['obs_feat'].shape == (1, 64, 16, 16) and out['vertex_feat'].shape == (6890, 32)
+    assert bwd_calls.count('sherf_bwd_gemm') >= 50 and 'sherf_bwd_conv_wgrad' in bwd_calls and 'sherf_bwd_unfold32' in bwd_calls
+    assert [c[0] for c in calls].count('sherf_gather_tokens_bwd') == 1 and [c[0] for c in calls].count('sherf_composite_compact_bwd') == 1
