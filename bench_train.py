@@ -1,0 +1,100 @@
+"""Training-step timing for BASELINE config 5 (forward render + backward through the HIP kernels + the reference's flat-grad
+all-reduce, training_loop.py:374-383 + Adam step) -- EXPERIMENTAL companion of bench.py, same launch contract:
+
+    python bench_train.py --gpus N --steps K --warmup W          (torchrun for N > 1, one rank per GPU)
+
+The backward pipeline (sherf_amd/backward.py) is verified on the CPU only so far; until its kernels have
+passed `pytest -m gpu_experimental` on an MI355X the number this prints is not a claim.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='cfg2')
+    a = ap.parse_args()
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(lrank)
+    dev = torch.device('cuda', lrank)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    import bench
+    from oracle import fixtures, synth                       # synthetic-input generators only
+    from sherf_amd import dist as sdist
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder, TriPlaneGenerator
+    from sherf_amd.voxel import SparseConvTensor
+    smpl = synth.make_synth_smpl(0)
+    fx, d, to = bench.make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl)
+    dec = NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
+    rend.to(dev).train(); dec.to(dev).train()
+    rend.enable_autograd = True
+    gen = TriPlaneGenerator.__new__(TriPlaneGenerator)
+    torch.nn.Module.__init__(gen); gen.renderer = rend
+    sp_input, _ = gen.prepare_sp_input(d['t_vertices'].float(), gen.canonical_obs_vertices(d))
+    planes = to(fx['planes']).requires_grad_(True)
+    obs_feat = to(fx['obs_feat']).requires_grad_(True)
+    vfeat = to(fx['vertex_feat']).requires_grad_(True)
+    obs_img = d['obs_img_all'][:, 0]
+    ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
+    opts = dict(fx['options'])
+    R = ro.shape[1]
+    params = [p for p in list(rend.parameters()) + list(dec.parameters())]
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.99), eps=1e-8)          # train.py: G_opt_kwargs
+    g = torch.Generator(device='cpu').manual_seed(11 + rank)
+    t_rgb = (torch.rand(1, R, 3, generator=g) * 2 - 1).to(dev); t_acc = torch.rand(1, R, 1, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        sp = SparseConvTensor(vfeat, sp_input['coord'], sp_input['out_sh'], 1)
+        rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)
+        loss = ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
+        loss.backward()
+        sdist.allreduce_flat_grads(params)
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
+                              unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
+                              scaling='weak', vs_baseline=None, dtype='fp32 backward (rocBLAS sgemm + fp32 kernels), bf16x3 MFMA forward',
+                              data='synthetic', status='EXPERIMENTAL: backward kernels not yet verified on hardware', final_loss=float(loss),
+                              config=dict(workload=f'{a.config}: one view per GPU, stub loss MSE(rgb)+MSE(acc)', rays=R))))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
