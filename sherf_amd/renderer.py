@@ -293,11 +293,13 @@ class ImportanceRenderer(nn.Module):
 
             def call():
                 self._in_autograd = True
+                self.encoder_3d._force_stats_update = True      # a training forward updates the BatchNorm running statistics
                 try:
                     return self.forward(planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask,
                                         obs_sp_input, decoder, ray_origins, ray_directions, near, far, input_data, rendering_options)
                 finally:
                     self._in_autograd = False
+                    self.encoder_3d._force_stats_update = False
             return RenderFunction.apply(self, decoder, call, planes, obs_input_feature, canonical_sp_conv_volume.features,
                                         *[p for _, p in _named_params(self, decoder)])
         if not (self.use_1d_feature and self.use_2d_feature and self.use_3d_feature and self.use_trans and self.use_NeRF_decoder):

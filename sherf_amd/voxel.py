@@ -177,7 +177,7 @@ class SparseConvNet(nn.Module):
 
     def finish(self, pl):
         """nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance); call after the encoder was enqueued."""
-        if not (self.training and torch.is_grad_enabled()):
+        if not (self.training and (torch.is_grad_enabled() or getattr(self, '_force_stats_update', False))):
             return
         with torch.no_grad():
             for m in pl['meta']:
