@@ -108,3 +108,38 @@ def test_backward_glue_dry_run(stubbed, monkeypatch):
     assert out['planes'].shape == (1, 3, 32, 32, 32) and out['obs_feat'].shape == (1, 64, 16, 16) and out['vertex_feat'].shape == (6890, 32)
     assert bwd_calls.count('sherf_bwd_gemm') >= 50 and 'sherf_bwd_conv_wgrad' in bwd_calls and 'sherf_bwd_unfold32' in bwd_calls
     assert [c[0] for c in calls].count('sherf_gather_tokens_bwd') == 1 and [c[0] for c in calls].count('sherf_composite_compact_bwd') == 1
+
+
+def test_autograd_node_wiring(stubbed, monkeypatch):
+    """enable_autograd: forward recorded as one node, loss.backward() routes through render_backward and lands a gradient of
+    the right shape on every input and parameter the reference trains (native calls stubbed: values are zeros)."""
+    from sherf_amd import backward_dense
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder
+    from sherf_amd.voxel import SparseConvTensor
+    monkeypatch.setattr(_lib, 'call_bwd', lambda name, *a: None)
+    monkeypatch.setattr(backward_dense.HipOps, '_p', staticmethod(lambda m: ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)))
+    fx = G.fixture('tiny')
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=G.smpl())
+    dec = NeRFDecoder(32)
+    rend.train(); dec.train()
+    rend.enable_autograd = True
+    rend._side = lambda dev, idx=0: type('X', (), {'cuda_stream': 8 + 8 * idx})()
+    d = fixtures.to_torch(fx['input_data'])
+    spi = O.render_from_fixture(fx, G.seeded_state(), keep=False)['sp_input']
+    planes = torch.from_numpy(fx['planes']).requires_grad_(True)
+    obs_feat = torch.from_numpy(fx['obs_feat']).requires_grad_(True)
+    vfeat = torch.from_numpy(fx['vertex_feat']).requires_grad_(True)
+    sp = SparseConvTensor(vfeat, spi['coord'], spi['out_sh'], 1)
+    spd = dict(coord=spi['coord'], out_sh=spi['out_sh'], batch_size=1, bounds=spi['bounds'][None])
+    mean_before = rend.encoder_3d.conv0[1].num_batches_tracked.item()
+    rgb, depth, acc = rend(planes, d['obs_img_all'][:, 0], torch.from_numpy(fx['obs_feat']) * 0 + obs_feat, sp, None, spd, dec,
+                           d['ray_o_all'][:, 0].as_subclass(_FakeCuda), d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d,
+                           dict(fx['options']))
+    assert rgb.requires_grad and acc.requires_grad and not depth.requires_grad
+    assert rend.encoder_3d.conv0[1].num_batches_tracked.item() == mean_before + 1      # running statistics advanced
+    rend.last['ws']['counters'][0] = 50
+    (rgb.sum() + acc.sum()).backward()
+    assert planes.grad.shape == planes.shape and obs_feat.grad.shape == obs_feat.shape and vfeat.grad.shape == vfeat.shape
+    trained = [n for n, p in list(rend.named_parameters()) + list(dec.named_parameters()) if p.grad is not None]
+    assert len(trained) == 78                     # + the 3 inputs above = the 81 gradient tensors of the reference
