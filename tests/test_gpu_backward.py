@@ -160,3 +160,104 @@ def test_full_backward_against_reference_gradients():
         ours, r = O.grad_fingerprint(grads[k].float().cpu()), ref[k]
         assert abs(ours[2] - r[2]) < 1e-2 * r[2] + 1e-30, (k, ours[2], r[2])
         assert np.linalg.norm(ours[3:] - r[3:]) < 5e-2 * np.linalg.norm(r[3:]) + 1e-30, k
+
+
+def _random_level(dims, n, seed):
+    """A random sparse level: sorted unique keys + the (bits, prefix) records the kernels use, as CPU and GPU dicts."""
+    D, H, W = dims
+    g = torch.Generator().manual_seed(seed)
+    keys = torch.unique(torch.randint(0, D * H * W, (n,), generator=g))
+    nwords = (D * H * W + 31) // 32
+    bits = torch.zeros(nwords, dtype=torch.int64)
+    bits.index_put_((keys // 32,), (1 << (keys % 32)), accumulate=True)
+    pop = torch.tensor([bin(int(b)).count('1') for b in bits.tolist()], dtype=torch.int64)
+    prefix = torch.cumsum(pop, 0) - pop
+    wp = torch.stack([bits, prefix], 1)
+    wp32 = wp.to(torch.int64).view(-1)
+    wp32 = torch.where(wp32 >= 2 ** 31, wp32 - 2 ** 32, wp32).to(torch.int32).view(nwords, 2)
+    cap = keys.numel() + 5
+    kp = torch.cat([keys, torch.zeros(5, dtype=keys.dtype)])
+    cpu = dict(keys=kp, n_rows=torch.tensor(keys.numel()), dims=dims, cap=cap)
+    gpu = dict(keys=kp.to(torch.int32).cuda(), wp=wp32.cuda(), n_rows=torch.tensor([keys.numel()], dtype=torch.int32).cuda(), dims=dims, cap=cap)
+    return cpu, gpu
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_sparse_conv_gradient_kernels(mode):
+    """sherf_bwd_conv_wgrad / sherf_bwd_conv_dgrad against their emulation on a random sparse level pair."""
+    from sherf_amd.backward_dense import HipOps, Mat
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    fine_c, fine_g = _random_level((12, 16, 20), 900, 1)
+    if mode == 0:
+        out_c, out_g = fine_c, fine_g
+    else:
+        out_c, out_g = _random_level((6, 8, 10), 300, 2)
+    Cin, Cout = 32, 64
+    gen = torch.Generator().manual_seed(3)
+    in_raw = torch.randn(fine_c['cap'] * Cin, generator=gen); d_raw = torch.randn(out_c['cap'] * Cout, generator=gen)
+    bn = torch.randn(3 * Cin, generator=gen); mult = torch.randint(1, 3, (fine_c['cap'],), generator=gen)
+    W = torch.randn(Cout * 27 * Cin, generator=gen)
+    for use_bn in (False, True):
+        dW_c, dW_g = Mat(torch.zeros(Cout * 27 * Cin), Cout, 27 * Cin), Mat(torch.zeros(Cout * 27 * Cin).cuda(), Cout, 27 * Cin)
+        e.conv_wgrad(out_c, fine_c, Mat(in_raw.clone(), fine_c['cap'], Cin), Cin, Mat(bn.clone(), 1, 3 * Cin) if use_bn else None,
+                     mult if use_bn else None, Mat(d_raw.clone(), out_c['cap'], Cout), Cout, mode, dW_c)
+        h.conv_wgrad(out_g, fine_g, Mat(in_raw.cuda(), fine_c['cap'], Cin), Cin, Mat(bn.cuda(), 1, 3 * Cin) if use_bn else None,
+                     mult.to(torch.int32).cuda() if use_bn else None, Mat(d_raw.cuda(), out_c['cap'], Cout), Cout, mode, dW_g)
+        torch.cuda.synchronize()
+        assert G.rel(dW_g.tensor().cpu(), dW_c.tensor()) < 1e-4
+    di_c, di_g = Mat(torch.zeros(fine_c['cap'] * Cin), fine_c['cap'], Cin), Mat(torch.zeros(fine_c['cap'] * Cin).cuda(), fine_c['cap'], Cin)
+    e.conv_dgrad(fine_c, out_c, Mat(d_raw.clone(), out_c['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_c)
+    h.conv_dgrad(fine_g, out_g, Mat(d_raw.cuda(), out_c['cap'], Cout), Cout, Mat(W.cuda(), Cout, 27 * Cin), Cin, mode, di_g)
+    torch.cuda.synchronize()
+    assert G.rel(di_g.tensor().cpu(), di_c.tensor()) < 1e-4
+
+
+def test_batchnorm_backward_and_small_encoder_kernels():
+    from sherf_amd.backward_dense import HipOps, Mat
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    lev_c, lev_g = _random_level((8, 8, 8), 200, 5)
+    n, cap, C = int(lev_c['n_rows']), lev_c['cap'], 64
+    gen = torch.Generator().manual_seed(6)
+    raw = torch.randn(cap * C, generator=gen); d_out = torch.randn(cap * C, generator=gen)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    mult = torch.randint(1, 4, (cap,), generator=gen)
+    N = int(mult[:n].sum())
+    x = raw.view(cap, C)[:n]
+    mean = x.sum(0) / N
+    var = (((x - mean) ** 2).sum(0) + (N - n) * mean ** 2) / N
+    inv = 1 / torch.sqrt(var + 1e-3)
+    scale, shift = gamma * inv, beta - mean * gamma * inv
+    bn, st = torch.cat([scale, shift, torch.relu(shift)]), torch.cat([mean, var])
+    outs_c = [Mat(torch.zeros(cap * C), cap, C), Mat(torch.zeros(C), 1, C), Mat(torch.zeros(C), 1, C)]
+    outs_g = [Mat(torch.zeros(cap * C).cuda(), cap, C), Mat(torch.zeros(C).cuda(), 1, C), Mat(torch.zeros(C).cuda(), 1, C)]
+    e.bn_relu_bwd(Mat(d_out.clone(), cap, C), Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), Mat(st.clone(), 1, 2 * C), Mat(gamma.clone(), 1, C),
+                  mult, torch.tensor(N), torch.tensor(n), *outs_c)
+    h.bn_relu_bwd(Mat(d_out.cuda(), cap, C), Mat(raw.cuda(), cap, C), Mat(bn.cuda(), 1, 3 * C), Mat(st.cuda(), 1, 2 * C), Mat(gamma.cuda(), 1, C),
+                  mult.to(torch.int32).cuda(), torch.tensor([N], dtype=torch.int32).cuda(), lev_g['n_rows'], *outs_g)
+    torch.cuda.synchronize()
+    for a, b in zip(outs_c, outs_g):
+        assert G.rel(b.tensor().cpu(), a.tensor()) < 1e-4
+    # bn_relu_apply, gather_rows, unfold32
+    a_c, a_g = Mat(torch.zeros(cap * C), cap, C), Mat(torch.zeros(cap * C).cuda(), cap, C)
+    e.bn_relu_apply(Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), torch.tensor(n), a_c)
+    h.bn_relu_apply(Mat(raw.cuda(), cap, C), Mat(bn.cuda(), 1, 3 * C), lev_g['n_rows'], a_g)
+    assert G.rel(a_g.tensor().cpu(), a_c.tensor()) < 1e-6
+    D, H, W = lev_c['dims']
+    k = lev_c['keys'][:n]
+    coord = torch.stack([torch.zeros_like(k), k // (H * W), (k // W) % H, k % W], 1)
+    coord = torch.cat([coord, coord[:7]])                                  # duplicate rows share a voxel
+    f_c, f_g = Mat(torch.zeros(coord.shape[0] * 32), coord.shape[0], 32), Mat(torch.zeros(coord.shape[0] * 32).cuda(), coord.shape[0], 32)
+    dg = torch.randn(cap * 32, generator=gen)
+    e.gather_rows(coord, coord.shape[0], lev_c, Mat(dg.clone(), cap, 32), 32, f_c)
+    h.gather_rows(coord.to(torch.int32).cuda(), coord.shape[0], lev_g, Mat(dg.cuda(), cap, 32), 32, f_g)
+    assert G.rel(f_g.tensor().cpu(), f_c.tensor()) < 1e-6
+    HW, groups = 300, 3
+    d_f = torch.randn(groups * HW * 32, generator=gen); Wm = torch.randn(32 * 32, generator=gen); inp = torch.randn(groups * 32 * HW, generator=gen)
+    di_c, dw_c = Mat(torch.zeros(groups * 32 * HW), groups * 32, HW), Mat(torch.zeros(1024), 32, 32)
+    di_g, dw_g = Mat(torch.zeros(groups * 32 * HW).cuda(), groups * 32, HW), Mat(torch.zeros(1024).cuda(), 32, 32)
+    e.unfold32(Mat(d_f.clone(), groups * HW, 32), Mat(Wm.clone(), 32, 32), Mat(inp.clone(), groups * 32, HW), HW, groups, 32, HW * 32, di_c, dw_c)
+    h.unfold32(Mat(d_f.cuda(), groups * HW, 32), Mat(Wm.cuda(), 32, 32), Mat(inp.cuda(), groups * 32, HW), HW, groups, 32, HW * 32, di_g, dw_g)
+    torch.cuda.synchronize()
+    assert G.rel(di_g.tensor().cpu(), di_c.tensor()) < 1e-4 and G.rel(dw_g.tensor().cpu(), dw_c.tensor()) < 1e-4
