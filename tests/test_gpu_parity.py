@@ -313,3 +313,37 @@ def test_generator_synthesis_end_to_end():
     img = out['image_raw'][0].permute(1, 2, 0).reshape(-1, 3).cpu()
     assert O.psnr(img, o['rgb']) > 60.0
     assert G.rel(out['weights_image'].reshape(-1).cpu(), o['acc']) < 2e-3
+
+
+def _full_size_properties(cfg, stride):
+    """At BASELINE.json's full frame size the oracle cannot run the whole frame in seconds; size-independent properties are
+    checked instead: bitwise repeatability, ray independence (a strided subset of the rays renders to the same bits), the
+    white-background identity, value ranges -- and the subset (which the oracle does finish in seconds) against the oracle."""
+    fx = dict(G.fixture(cfg))
+    d = {k: (dict(v) if isinstance(v, dict) else v) for k, v in fx['input_data'].items()}
+    R = d['ray_o_all'].shape[2]
+    sel = np.arange(stride // 2, R, stride)
+    for k in ('ray_o_all', 'ray_d_all', 'near_all', 'far_all'):
+        d[k] = np.ascontiguousarray(d[k][:, :, sel])
+    fx_sub = dict(fx); fx_sub['input_data'] = d
+    o = O.render_from_fixture(fx_sub, G.seeded_state(), training=True, keep=False)      # oracle on the subset only
+    spi = o['sp_input']                                                                 # depends on the vertices, not on the rays
+    a = G.hip_render(cfg, sp_input=spi)
+    b = G.hip_render(cfg, sp_input=spi)
+    assert a['rgb'].shape == (R, 3) and torch.isfinite(a['rgb']).all() and torch.isfinite(a['acc']).all()
+    assert float(a['acc'].min()) >= 0.0 and float(a['acc'].max()) <= 1.0 + 1e-5 and float(a['rgb'].abs().max()) <= 1.01
+    assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['depth'], b['depth']) and torch.equal(a['acc'], b['acc'])
+    sub = G.hip_render(cfg, fx=fx_sub, sp_input=spi)
+    assert torch.equal(sub['rgb'], a['rgb'][sel]) and torch.equal(sub['acc'], a['acc'][sel])
+    assert int(sub['last']['ws']['counters'][0]) == o['valid'].numel()
+    assert G.rel(sub['rgb'], o['rgb']) < 1e-3 and G.rel(sub['acc'], o['acc']) < 1e-3
+    w = G.hip_render(cfg, sp_input=spi, options=dict(white_back=True))
+    assert torch.allclose(w['rgb'], a['rgb'] + 2 * (1 - a['acc'])[:, None], atol=1e-5)
+    print(f"{cfg}: {R} rays, subset of {sel.size} vs oracle: rgb rel err {G.rel(sub['rgb'], o['rgb']):.2e}, "
+          f"valid samples in the subset {o['valid'].numel()}")
+
+
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3'])
+def test_full_size_frame_properties(cfg):
+    """BASELINE configs 2 and 3: 512 x 512 rays x 64 samples (novel view / novel pose)."""
+    _full_size_properties(cfg, 257)

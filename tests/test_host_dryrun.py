@@ -143,3 +143,19 @@ def test_autograd_node_wiring(stubbed, monkeypatch):
     assert planes.grad.shape == planes.shape and obs_feat.grad.shape == obs_feat.shape and vfeat.grad.shape == vfeat.shape
     trained = [n for n, p in list(rend.named_parameters()) + list(dec.named_parameters()) if p.grad is not None]
     assert len(trained) == 78                     # + the 3 inputs above = the 81 gradient tensors of the reference
+
+
+def test_full_size_property_test_plumbing(monkeypatch):
+    """The full-size GPU test (tests/test_gpu_parity.py: _full_size_properties) executed on the CPU with the HIP render replaced
+    by the oracle, on a small configuration: checks the test's own plumbing (subset selection, shapes, comparisons)."""
+    from tests import test_gpu_parity as T
+
+    def fake_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, options=None):
+        f = dict(fx or G.fixture(cfg))
+        opts = dict(f['options']); opts.update(options or {})
+        f['options'] = opts
+        r = O.render_from_fixture(f, G.seeded_state(), training=training, keep=False)
+        ws = dict(counters=torch.tensor([r['valid'].numel(), 0, 0, 0]))
+        return dict(rgb=r['rgb'], depth=r['depth'], acc=r['acc'], last=dict(ws=ws), rend=None)
+    monkeypatch.setattr(T.G, 'hip_render', fake_render)
+    T._full_size_properties('tiny', 7)
