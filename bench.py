@@ -25,7 +25,7 @@ PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.
 
 
 def make_inputs(cfg_name, theta, dev):
-    from oracle import fixtures, synth   # synthetic-input generators only (seeded data), not the oracle renderer
+    from synthdata import fixtures     # seeded synthetic inputs; nothing from oracle/ on the timed path
     c = dict(fixtures.CONFIGS[cfg_name])
     c['theta_tgt'] = theta
     fixtures.CONFIGS['_bench'] = c
@@ -59,7 +59,7 @@ def main():
     from sherf_amd.triplane import NeRFDecoder, TriPlaneGenerator
     from sherf_amd.voxel import SparseConvTensor
     from sherf_amd import dist as sdist
-    from oracle import fixtures, synth
+    from synthdata import fixtures, synth
 
     if os.environ.get('SHERF_DEBUG'):
         from sherf_amd import _lib

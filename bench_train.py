@@ -32,7 +32,7 @@ def main():
     if world > 1:
         torch.distributed.init_process_group('nccl', device_id=dev)
     import bench
-    from oracle import fixtures, synth                       # synthetic-input generators only
+    from synthdata import fixtures, synth                    # seeded synthetic inputs (not the oracle)
     from sherf_amd import dist as sdist
     from sherf_amd.renderer import ImportanceRenderer
     from sherf_amd.triplane import NeRFDecoder, TriPlaneGenerator
