@@ -194,6 +194,22 @@ __device__ __forceinline__ float exp_(float x) { return expf(x); }
 __device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
 __device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 #endif
+// SHERF_MLP_FAST_ERF (off; to be measured and parity-checked on hardware): Abramowitz-Stegun 7.1.26 for the exact-GELU erf,
+// |error| <= 1.5e-7, ~14 VALU instead of libm's ~38 -- the 32 erf evaluations per lane are the largest VALU block left
+// in the prologue (~1.2 K of 5.3 K instructions per tile).  tests/test_mlp_pack.py checks the formula in float32.
+#ifndef SHERF_MLP_FAST_ERF
+#define SHERF_MLP_FAST_ERF 0
+#endif
+__device__ __forceinline__ float erf_(float x) {
+#if SHERF_MLP_FAST_ERF
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    return copysignf(1.0f - poly * __expf(-ax * ax), x);
+#else
+    return erff(x);
+#endif
+}
 #ifndef SHERF_MLP_INTERLEAVE
 #define SHERF_MLP_INTERLEAVE 0
 #endif
@@ -450,7 +466,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { float a = acc[i][r]; acc[i][r] = 0.5f * a * (1.0f + erff(a * 0.70710678118654752f)); }
+                for (int r = 0; r < 16; ++r) { float a = acc[i][r]; acc[i][r] = 0.5f * a * (1.0f + erf_(a * 0.70710678118654752f)); }
                 split_tile<PREC>(acc[i], gb[i][0], gb[i][1]);
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};

@@ -157,3 +157,18 @@ def test_stream_reproduces_oracle_network(packed):
     # hi-only stream == plain bf16 weights: larger but bounded error
     rgb0, sigma0 = Emu(stream, wbias, nkbs, use_lo=False).run(tok, r['tap_rgb'].numpy(), r['x_c'].numpy(), r['v_c'].numpy())
     assert np.abs(sigma0 - ref_sig).max() / np.abs(ref_sig).max() < 3e-2
+
+
+def test_fast_erf_formula_accuracy():
+    """The optional erf of the MLP kernel's GELU (csrc/mlp.hip: SHERF_MLP_FAST_ERF, Abramowitz-Stegun 7.1.26) evaluated in
+    float32 exactly as the kernel writes it: |error| stays below 6e-7 over the whole range, odd symmetry, saturation."""
+    import math
+    f = np.float32
+    x = np.concatenate([np.linspace(-6, 6, 20001), [0.0, -0.0, 1e-8, -1e-8, 30.0, -30.0]]).astype(f)
+    ax = np.abs(x)
+    t = f(1.0) / (f(0.3275911) * ax + f(1.0))
+    poly = t * (t * (t * (t * (t * f(1.061405429) + f(-1.453152027)) + f(1.421413741)) + f(-0.284496736)) + f(0.254829592))
+    y = np.copysign(f(1.0) - poly * np.exp(-ax * ax, dtype=f), x)
+    ref = np.array([math.erf(float(v)) for v in x])
+    assert np.abs(y.astype(np.float64) - ref).max() < 6e-7        # 1.5e-7 (formula) + float32 rounding
+    assert y[-2] == 1.0 and y[-1] == -1.0
