@@ -261,3 +261,46 @@ def test_batchnorm_backward_and_small_encoder_kernels():
     h.unfold32(Mat(d_f.cuda(), groups * HW, 32), Mat(Wm.cuda(), 32, 32), Mat(inp.cuda(), groups * 32, HW), HW, groups, 32, HW * 32, di_g, dw_g)
     torch.cuda.synchronize()
     assert G.rel(di_g.tensor().cpu(), di_c.tensor()) < 1e-4 and G.rel(dw_g.tensor().cpu(), dw_c.tensor()) < 1e-4
+
+
+def test_gather_backward_kernel():
+    """sherf_gather_tokens_bwd against the oracle's tap stencils, in the kernel's folded channel-last layouts."""
+    import ctypes
+    from oracle import backward_explicit as BX
+    from sherf_amd import _lib
+    from sherf_amd.backward_dense import HipOps, Mat
+    cfg = 'tiny_nv'
+    fx = G.fixture(cfg)
+    loss, g = O.gradients_from_fixture(fx, G.seeded_state(), stages=True)
+    r = G.oracle_render(cfg)
+    h = G.hip_render(cfg)
+    last, ws = h['last'], h['last']['ws']
+    n = int(ws['counters'][0])
+    b = last['bwd']
+    P, (Hf, Wf) = fx['planes'].shape[-1], fx['obs_feat'].shape[-2:]
+    ops = HipOps()
+    d_tok = Mat(g['stage.tokens_in'].reshape(-1).contiguous().cuda(), n, 96)
+    tiles = (n + 31) // 32
+    d_tiled = torch.zeros(tiles * 3072, device='cuda')
+    ops.tile_tokens(d_tok, n, d_tiled)
+    L, taps = last['plan']['L'], last['plan']['taps']
+    d_planes_f, d_feat_f, d_bias = Mat.zeros(3 * P * P, 32, 'cuda'), Mat.zeros(Hf * Wf, 64, 'cuda'), Mat.zeros(1, 96, 'cuda')
+    d_rows = [Mat.zeros(L[t[0]]['cap'], 96, 'cuda') for t in taps]
+    f32 = lambda t: t.detach().float().contiguous()
+    bounds, vox_min = f32(b['bounds']).view(6), f32(b['vox_min']).view(3)
+    _lib.call('sherf_gather_tokens_bwd', _lib.ptr(ws['counters']), _lib.ptr(ws['geom']), _lib.ptr(d_tiled), P, Hf, Wf, b['H'], b['W'],
+              last['levels_struct'], _lib.ptr(bounds), _lib.ptr(vox_min), (ctypes.c_int32 * 3)(*b['vox_sh']), last['cap'], ops._p(d_planes_f),
+              ops._p(d_feat_f), ops._p(d_rows[0]), ops._p(d_rows[1]), ops._p(d_rows[2]), ops._p(d_bias), _lib.stream())
+    torch.cuda.synchronize()
+    dt = g['stage.tokens_in']
+    bnd = torch.from_numpy(fx['input_data']['t_world_bounds']).view(2, 3)
+    ref_pf = BX.triplane_bwd((3, 32, P, P), r['x_c'], bnd, dt.permute(1, 0, 2)).permute(0, 2, 3, 1).reshape(3 * P * P, 32)
+    assert G.rel(d_planes_f.tensor().cpu(), ref_pf) < 1e-4
+    H, W = fx['input_data']['obs_img_all'].shape[-2:]
+    gg = 2.0 * r['uv'] / torch.tensor([W, H], dtype=torch.float32) - 1.0
+    ref_ff = BX._grid_sample_2d_bwd((64, Hf, Wf), gg[:, 0], gg[:, 1], True, dt[:, :2].reshape(n, 64)).permute(1, 2, 0).reshape(Hf * Wf, 64)
+    assert G.rel(d_feat_f.tensor().cpu(), ref_ff) < 1e-4
+    for (keys, feats, shape), dr in zip(r['taps'], d_rows):
+        ref = BX.trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], dt.reshape(n, 96))
+        assert G.rel(dr.tensor().cpu()[:feats.shape[0]], ref) < 1e-4
+    assert G.rel(d_bias.tensor().cpu().view(3, 32), dt.sum(0)) < 1e-4
