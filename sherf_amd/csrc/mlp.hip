@@ -104,15 +104,23 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
 // The weight stream is walked in STEPS: the small transformer chunks 0..8 are replayed once per tile (keeps the
 // attention state of only one tile live), then the decoder chunks 9..48 run once for all tiles of the wave.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NTL> __host__ __device__ constexpr int n_steps() { return 9 * NTL + (N_CHUNKS - 9); }
-template <int NTL> __host__ __device__ constexpr int step_chunk(int s) { return s < 9 * NTL ? s % 9 : s - 9 * (NTL - 1); }
+// PHASE 0: the fused kernel (transformer + decoder).  PHASE 1 / 2 (shape '8x1split', experimental): the VALU-bound
+// transformer prologue and the MFMA-bound decoder as two launches -- 1 streams only chunks 0..8 (tiny ring slots => several
+// workgroups per CU, its waves no longer phase-locked to MFMA-bound ones) and leaves z_0, z_1 as ready-made bf16 hi/lo
+// B-fragments in the first 8 KiB of the tile's `tokens` block; 2 streams chunks 9..48 and starts from those fragments.
+template <int NTL, int PHASE> __host__ __device__ constexpr int n_steps() {
+    return PHASE == 1 ? 9 * NTL : PHASE == 2 ? N_CHUNKS - 9 : 9 * NTL + (N_CHUNKS - 9);
+}
+template <int NTL, int PHASE> __host__ __device__ constexpr int step_chunk(int s) {
+    return PHASE == 2 ? s + 9 : s < 9 * NTL ? s % 9 : s - 9 * (NTL - 1);
+}
 
-template <int PREC, int NW, int NTL> struct Ctx {
+template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
     const char* ws;          // packed weight stream (global)
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // NSLOT ring slots
     int lane, h, dbg, wave, pending;
-    static constexpr int SLOT = MAX_NKB * 1024 * (PREC + 1);
+    static constexpr int SLOT = (PHASE == 1 ? 3 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8 have <= 3 K-blocks
     static constexpr int NSLOT = 3;
     __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
 };
@@ -122,13 +130,13 @@ template <int PREC, int NW, int NTL> struct Ctx {
 // recently issued step are still in flight, then the workgroup barrier makes every wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int PREC, int NW, int NTL>
-__device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL>& cx, int step) {
-    if (step >= n_steps<NTL>() || (cx.dbg & 32)) return 0;
-    const int c = step_chunk<NTL>(step);
+template <int PREC, int NW, int NTL, int PHASE>
+__device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
+    if (step >= n_steps<NTL, PHASE>() || (cx.dbg & 32)) return 0;
+    const int c = step_chunk<NTL, PHASE>(step);
     const int pieces = chunk_nkb(c) * (PREC + 1);
     const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024 + cx.lane * 16;
-    char* dst = cx.lds + (step % Ctx<PREC, NW, NTL>::NSLOT) * Ctx<PREC, NW, NTL>::SLOT;
+    char* dst = cx.lds + (step % Ctx<PREC, NW, NTL, PHASE>::NSLOT) * Ctx<PREC, NW, NTL, PHASE>::SLOT;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < (MAX_NKB * (PREC + 1) + NW - 1) / NW; ++i) {
@@ -137,7 +145,9 @@ __device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL>& cx, int step) {
             // Inline asm on purpose: hipcc drains an LDS-DMA it knows about (vmcnt(0)) before every ds_read that might alias
             // it, which would serialise the ring.  M0 = LDS byte address of the piece (saved/restored: compiler-reserved).
             const char* g = src + p * 1024;
-            const uint32_t l = (uint32_t)(size_t)(lptr_t)(dst + p * 1024);
+            uint32_t l = (uint32_t)(size_t)(lptr_t)(dst + p * 1024);
+            if constexpr (PHASE != 0) l = __builtin_amdgcn_readfirstlane(l);   // wave-uniform by construction; the split kernels' control
+                                                                               // flow hides that from the compiler ("s" constraint)
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(l) : "memory");
@@ -162,8 +172,8 @@ __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // end of step s: step s+1 must have landed (everything but the newest issue), then step s's slot is recycled for s+3
-template <int PREC, int NW, int NTL>
-__device__ __forceinline__ void advance(Ctx<PREC, NW, NTL>& cx, int step) {
+template <int PREC, int NW, int NTL, int PHASE>
+__device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
     wait_vm(cx.pending);
     if (!(cx.dbg & 64)) wg_barrier();
     cx.pending = dma_issue(cx, step + 3);
@@ -210,6 +220,9 @@ __device__ __forceinline__ float erf_(float x) {
     return erff(x);
 #endif
 }
+#ifndef SHERF_MLP_P1_WAVES
+#define SHERF_MLP_P1_WAVES 2     // waves per SIMD the transformer-only launch is compiled for (VGPR cap 512 / this)
+#endif
 #ifndef SHERF_MLP_INTERLEAVE
 #define SHERF_MLP_INTERLEAVE 0
 #endif
@@ -294,11 +307,11 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 }
 
 
-template <int PREC, int NW, int NTL>
-__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
+template <int PREC, int NW, int NTL, int PHASE = 0>
+__global__ void __launch_bounds__(NW * 64, PHASE == 1 ? SHERF_MLP_P1_WAVES : NW == 8 ? 2 : 1)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
-    using CX = Ctx<PREC, NW, NTL>;
+    using CX = Ctx<PREC, NW, NTL, PHASE>;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
@@ -330,9 +343,27 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     float xc[NTL][3], vc[NTL][3];
     int step = 0;
 
+    // z_0 / z_1 hand-over between the two launches of the split shape: 8 uint4 per lane per tile, lane-major, written over the
+    // first 8 KiB of the tile's own `tokens` block (the wave has read its tokens into registers long before): fragment
+    // q = 4 * (0: z_0, 1: z_1) + 2 * kb + (0: hi, 1: lo).
+    uint4* const zfrag = reinterpret_cast<uint4*>(const_cast<float4*>(tokens));
+    if constexpr (PHASE == 2) {
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+            const float* ex = extras + tile[u] * 12 * 32 + j;
+            xc[u][0] = ex[0]; xc[u][1] = ex[32]; xc[u][2] = ex[64]; vc[u][0] = ex[96]; vc[u][1] = ex[128]; vc[u][2] = ex[160];
+            const uint4* zp = zfrag + tile[u] * 768 + cx.lane;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                z0b[u][kb].hi = zp[(2 * kb) * 64];
+                z1b[u][kb].hi = zp[(4 + 2 * kb) * 64];
+                if constexpr (PREC == 1) { z0b[u][kb].lo = zp[(2 * kb + 1) * 64]; z1b[u][kb].lo = zp[(4 + 2 * kb + 1) * 64]; }
+            }
+        }
+    }
     // ================= transformer, one tile at a time (steps 9u .. 9u+8 replay chunks 0..8) =================
 #pragma unroll
-    for (int u = 0; u < NTL; ++u) {
+    for (int u = 0; u < (PHASE == 2 ? 0 : NTL); ++u) {
         // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
         f32x16 tok[3];
 #pragma unroll
@@ -477,6 +508,20 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             split_tile<PREC>(zb, z1b[u][0], z1b[u][1]);
         }
     }
+    if constexpr (PHASE == 1) {                                      // hand z_0, z_1 to the decoder launch and stop
+#pragma unroll
+        for (int u = 0; u < NTL; ++u) {
+            if (!live[u]) continue;
+            uint4* zp = zfrag + tile[u] * 768 + cx.lane;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                zp[(2 * kb) * 64] = z0b[u][kb].hi;
+                zp[(4 + 2 * kb) * 64] = z1b[u][kb].hi;
+                if constexpr (PREC == 1) { zp[(2 * kb + 1) * 64] = z0b[u][kb].lo; zp[(4 + 2 * kb + 1) * 64] = z1b[u][kb].lo; }
+            }
+        }
+        return;
+    }
 
     // ================= NeRF decoder: all NTL tiles of the wave share every weight fragment =================
     BFrag<PREC> ha[NTL][8], hb[NTL][8], pe[NTL][3];
@@ -586,13 +631,23 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && (shape == 0 || shape == 1) && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 2 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (shape == 2) {                         // experimental: transformer prologue and decoder as two launches (see PHASE)
+        SHERF_CHECK_ARG(prec == 1);
+        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 1>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
+        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 2>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
+        SHERF_LAUNCH_CHECK();
+    }
     if (prec == 0) { if (wide) SHERF_MLP(0, 4, 2); else SHERF_MLP(0, 8, 1); }
     else { if (wide) SHERF_MLP(1, 4, 2); else SHERF_MLP(1, 8, 1); }
     SHERF_LAUNCH_CHECK();

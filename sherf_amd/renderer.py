@@ -383,7 +383,7 @@ class ImportanceRenderer(nn.Module):
         # a13-a14: fused transformer + NeRF decoder
         fr.wstream, fr.wbias = A(wc['stream']), A(wc['wbias'])
         fr.mlp_prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
-        fr.mlp_shape = {'8x1': 0, '4x2': 1}[opts.get('mlp_shape', self.mlp_shape)]
+        fr.mlp_shape = {'8x1': 0, '4x2': 1, '8x1split': 2}[opts.get('mlp_shape', self.mlp_shape)]   # split: experimental, overwrites ws['tokens']
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()

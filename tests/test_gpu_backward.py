@@ -304,3 +304,12 @@ def test_gather_backward_kernel():
         ref = BX.trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], dt.reshape(n, 96))
         assert G.rel(dr.tensor().cpu()[:feats.shape[0]], ref) < 1e-4
     assert G.rel(d_bias.tensor().cpu().view(3, 32), dt.sum(0)) < 1e-4
+
+
+def test_mlp_split_shape_matches_fused():
+    """sherf_nerf_mlp shape 2 (transformer prologue and decoder as two launches, z_0/z_1 handed over as ready-made bf16 hi/lo
+    fragments): same arithmetic as the fused kernel -> identical images.  Staged with the experimental tests until it has run."""
+    for cfg in ('tiny', 'tiny_nv'):
+        a = G.hip_render(cfg)
+        b = G.hip_render(cfg, options=dict(mlp_shape='8x1split'))
+        assert torch.equal(b['rgb'], a['rgb']) and torch.equal(b['acc'], a['acc'])
