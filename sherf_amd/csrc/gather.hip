@@ -9,6 +9,10 @@
 // 8 channel quads of a slot, 8 samples per wave, 32 samples (= one MFMA column tile) per workgroup.
 #include "common.h"
 
+#ifndef SHERF_GATHER_BRANCHLESS
+#define SHERF_GATHER_BRANCHLESS 0
+#endif
+
 namespace {
 
 struct Levels { sherf_vox_level l[3]; };
@@ -132,6 +136,19 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                         rec[t] = make_uint2((inb && (rr.x & bit)) ? 1u : 0u, rr.y + __popc(rr.x & (bit - 1u)));
                     }
                     // phase 2: rows of the occupied corners
+#if SHERF_GATHER_BRANCHLESS
+                    // variant to be measured: every corner's three row loads issued unconditionally (absent corners read row 0
+                    // with weight 0) so that all 24 loads of a level are in flight together instead of one divergent branch at
+                    // a time -- trades cached redundant loads for memory-level parallelism in a kernel that is 74 % wait
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float w = rec[t].x ? ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz) : 0.f;
+                        const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)(rec[t].x ? rec[t].y : 0u) * 24;
+                        axpy4(acc[0], w, r[l]);
+                        axpy4(acc[1], w, r[8 + l]);
+                        axpy4(acc[2], w, r[16 + l]);
+                    }
+#else
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         if (rec[t].x) {
@@ -142,6 +159,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                             axpy4(acc[2], w, r[16 + l]);
                         }
                     }
+#endif
                 }
             }
         } else {
