@@ -318,8 +318,6 @@ class ImportanceRenderer(nn.Module):
         S = int(opts['depth_resolution'])
         R = ray_origins.shape[1]
         cap = int(opts.get('sample_capacity', R * S))
-        st = _lib.stream()
-        P = _lib.ptr
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         smpl = self._smpl(dev)
         wc = self._weights(decoder, dev)
