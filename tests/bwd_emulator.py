@@ -180,3 +180,21 @@ class EmuOps:
         c = coord.long()
         rows = self._rows_of(lev0, c[:, 1], c[:, 2], c[:, 3])
         d_feat.tensor().copy_(torch.where((rows >= 0)[:, None], d_g.tensor()[rows.clamp(min=0)], torch.zeros(N, C)))
+
+
+def make_level(keys, dims, pad=5):
+    """A sparse level from sorted unique voxel keys: (emulator dict, kernel dict with int32 keys + (bits, prefix) records)."""
+    D, H, W = dims
+    keys = keys.long()
+    nwords = (D * H * W + 31) // 32
+    bits = torch.zeros(nwords, dtype=torch.int64)
+    bits.index_put_((keys // 32,), (torch.ones_like(keys) << (keys % 32)), accumulate=True)
+    pop = torch.tensor([bin(int(b)).count('1') for b in bits.tolist()], dtype=torch.int64)
+    prefix = torch.cumsum(pop, 0) - pop
+    wp = torch.stack([bits, prefix], 1).view(-1)
+    wp = torch.where(wp >= 2 ** 31, wp - 2 ** 32, wp).to(torch.int32).view(nwords, 2).contiguous()
+    cap = keys.numel() + pad
+    kp = torch.cat([keys, torch.zeros(pad, dtype=keys.dtype)])
+    emu = dict(keys=kp, n_rows=torch.tensor(keys.numel()), dims=tuple(dims), cap=cap)
+    ker = dict(keys=kp.to(torch.int32).contiguous(), wp=wp, n_rows=torch.tensor([keys.numel()], dtype=torch.int32), dims=tuple(dims), cap=cap)
+    return emu, ker

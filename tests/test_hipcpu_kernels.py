@@ -1,0 +1,353 @@
+"""The backward kernels' REAL source executed on the CPU (tests/hipcpu: HIP-on-CPU shim, one std::thread per GPU thread)
+against the torch emulation that specifies them (tests/bwd_emulator.py), op by op and through the whole dense-stage
+orchestration.  This is what verifies csrc/bwd_dense.hip and csrc/bwd_encoder.hip between GPU sessions."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sherf_oracle as O
+from synthdata import fixtures
+from sherf_amd import _lib
+from sherf_amd.backward_dense import HipOps, Mat, dense_backward
+from tests.bwd_emulator import EmuOps
+from tests.hipcpu import build_cpu
+
+
+@pytest.fixture(scope='module')
+def cpu_lib(tmp_path_factory):
+    path = build_cpu.build('sherf_hipcpu_bwd', ['bwd_dense.hip', 'bwd_encoder.hip'], str(tmp_path_factory.mktemp('hipcpu')))
+    lib = ctypes.CDLL(path)
+    for name, (ret, args) in _lib.parse_header(_lib.HEADER_BWD).items():
+        fn = getattr(lib, name)
+        fn.restype = ret
+        fn.argtypes = [a[0] for a in args]
+    return lib
+
+
+class CpuKernelOps(HipOps):
+    """HipOps whose entry points are the CPU build of the same kernel sources (CPU tensors, synchronous)."""
+
+    def __init__(self, lib, monkeypatch):
+        self.st = None
+        self.lib = lib
+
+        def call(name, *a):
+            rc = getattr(lib, name)(*a)
+            assert rc == 0, (name, lib.sherf_bwd_last_error())
+        monkeypatch.setattr(_lib, 'call_bwd', call)
+        monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
+
+    @staticmethod
+    def _p(m):
+        return ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)
+
+
+def _pair(rows, cols, ld=None, seed=0):
+    ld = ld or cols
+    buf = torch.randn(rows * ld + 7, generator=torch.Generator().manual_seed(seed))
+    return Mat(buf.clone(), rows, cols, ld, 3), Mat(buf.clone(), rows, cols, ld, 3)
+
+
+def _same(a, b, tol=1e-5):
+    d = float((a.tensor().double() - b.tensor().double()).abs().max())
+    assert d <= tol * float(a.tensor().abs().max()) + 1e-12, d
+
+
+def test_dense_entry_points_match_their_specification(cpu_lib, monkeypatch):
+    e, h = EmuOps(), CpuKernelOps(cpu_lib, monkeypatch)
+    n = 70
+    for tA in (0, 1):
+        for tB in (0, 1):
+            a_c, a_g = _pair(*((19, 13) if tA else (13, 19)), ld=23, seed=1)
+            b_c, b_g = _pair(*((11, 19) if tB else (19, 11)), ld=25, seed=2)
+            c_c, c_g = _pair(13, 11, ld=17, seed=3)
+            e.gemm(tA, tB, a_c, b_c, c_c, 0.5); h.gemm(tA, tB, a_g, b_g, c_g, 0.5); _same(c_c, c_g)
+    y_c, y_g = _pair(n, 40, 45, 4); b_c, b_g = _pair(1, 40, seed=5)
+    for act in (0, 1):
+        e.bias_act(y_c, b_c, act); h.bias_act(y_g, b_g, act); _same(y_c, y_g)
+    d_c, d_g = _pair(n, 40, 41, 6)
+    e.relu_mask(d_c, y_c); h.relu_mask(d_g, y_g); _same(d_c, d_g)
+    s_c, s_g = Mat(torch.zeros(40), 1, 40), Mat(torch.zeros(40), 1, 40)
+    e.colsum(d_c, s_c); h.colsum(d_g, s_g); _same(s_c, s_g)
+    e.copy2d(y_c.colslice(3, 20), d_c.colslice(0, 17), add=True); h.copy2d(y_g.colslice(3, 20), d_g.colslice(0, 17), add=True); _same(y_c, y_g)
+    x_c, x_g = _pair(n, 3, 12, 7)
+    for NF in (4, 5, 6):
+        o_c, o_g = _pair(n, 3 + 6 * NF, 45, 8)
+        e.pe(x_c, NF, o_c); h.pe(x_g, NF, o_g); _same(o_c, o_g, 2e-5)
+    rows = 3 * n
+    x_c, x_g = _pair(rows, 32, seed=9); w_c, w_g = _pair(1, 32, seed=10); bb_c, bb_g = _pair(1, 32, seed=11)
+    mk = lambda: [Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(rows), rows, 1)]
+    oc, og = mk(), mk()
+    e.ln_fwd(x_c, w_c, bb_c, *oc); h.ln_fwd(x_g, w_g, bb_g, *og)
+    for a, b in zip(oc, og):
+        _same(a, b)
+    dy_c, dy_g = _pair(rows, 32, seed=12)
+    mk2 = lambda: [Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(32), 1, 32), Mat(torch.zeros(32), 1, 32)]
+    rc, rg = mk2(), mk2()
+    e.ln_bwd(dy_c, w_c, oc[1], oc[2], *rc); h.ln_bwd(dy_g, w_g, og[1], og[2], *rg)
+    for a, b in zip(rc, rg):
+        _same(a, b, 1e-4)
+    q_c, q_g = _pair(n, 432, seed=13)
+    a_c, a_g = Mat(torch.zeros(n * 27), n, 27), Mat(torch.zeros(n * 27), n, 27)
+    o_c, o_g = Mat(torch.zeros(n * 144), n, 144), Mat(torch.zeros(n * 144), n, 144)
+    e.attn_fwd(q_c, a_c, o_c); h.attn_fwd(q_g, a_g, o_g); _same(a_c, a_g); _same(o_c, o_g)
+    go_c, go_g = _pair(n, 144, seed=14)
+    dq_c, dq_g = Mat(torch.zeros(n * 432), n, 432), Mat(torch.zeros(n * 432), n, 432)
+    e.attn_bwd(q_c, a_c, go_c, dq_c); h.attn_bwd(q_g, a_g, go_g, dq_g); _same(dq_c, dq_g, 1e-4)
+    u_c, u_g = _pair(n, 32, seed=15)
+    g_c, g_g = Mat(torch.zeros(n * 32), n, 32), Mat(torch.zeros(n * 32), n, 32)
+    e.gelu_fwd(u_c, g_c); h.gelu_fwd(u_g, g_g); _same(g_c, g_g)
+    d_c, d_g = _pair(n, 32, seed=16)
+    e.gelu_bwd(d_c, u_c); h.gelu_bwd(d_g, u_g); _same(d_c, d_g)
+    l_c, l_g = _pair(n, 3, seed=17)
+    e.rgb_fwd(l_c); h.rgb_fwd(l_g); _same(l_c, l_g)
+    d_c, d_g = _pair(n, 3, seed=18)
+    e.rgb_bwd(d_c, l_c); h.rgb_bwd(d_g, l_g); _same(d_c, d_g)
+    # tile / untile round trip and layout
+    tok = torch.randn(n, 96, generator=torch.Generator().manual_seed(19))
+    tiles = (n + 31) // 32
+    t_c, t_g = torch.zeros(tiles * 3072), torch.zeros(tiles * 3072)
+    e.tile_tokens(Mat(tok.reshape(-1).clone(), n, 96), n, t_c); h.tile_tokens(Mat(tok.reshape(-1).clone(), n, 96), n, t_g)
+    assert torch.equal(t_c, t_g)
+    back, ext = Mat(torch.zeros(n * 96), n, 96), Mat(torch.zeros(n * 12), n, 12)
+    h.untile(t_g, torch.arange(tiles * 384, dtype=torch.float32), n, back, ext)
+    assert torch.equal(back.tensor(), tok)
+    assert torch.equal(ext.tensor(), torch.arange(tiles * 384, dtype=torch.float32).view(tiles, 12, 32).permute(0, 2, 1).reshape(tiles * 32, 12)[:n])
+    # unfold32 / bn_relu_apply
+    HW, groups = 70, 3
+    gen = torch.Generator().manual_seed(20)
+    d_f = torch.randn(groups * HW * 32, generator=gen); Wm = torch.randn(1024, generator=gen); inp = torch.randn(groups * 32 * HW, generator=gen)
+    mk3 = lambda: (Mat(torch.zeros(groups * 32 * HW), groups * 32, HW), Mat(torch.zeros(1024), 32, 32))
+    (di_c, dw_c), (di_g, dw_g) = mk3(), mk3()
+    e.unfold32(Mat(d_f.clone(), groups * HW, 32), Mat(Wm.clone(), 32, 32), Mat(inp.clone(), groups * 32, HW), HW, groups, 32, HW * 32, di_c, dw_c)
+    h.unfold32(Mat(d_f.clone(), groups * HW, 32), Mat(Wm.clone(), 32, 32), Mat(inp.clone(), groups * 32, HW), HW, groups, 32, HW * 32, di_g, dw_g)
+    _same(di_c, di_g, 1e-5); _same(dw_c, dw_g, 1e-4)
+
+
+def test_dense_backward_through_the_real_kernels(cpu_lib, monkeypatch, golden_dir):
+    """sherf_amd/backward_dense.py: dense_backward with every entry point served by the CPU build of csrc/bwd_dense.hip, on a
+    48-sample slice of `tiny_nv`, against autograd through the oracle."""
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    state = {k: torch.from_numpy(fixtures.seeded_param(k, s)) for k, s in shapes.items() if fixtures.seeded_param(k, s) is not None}
+    fx = fixtures.renderer_inputs('tiny_nv')
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+    n = 48
+    pe_x, pe_v = O.positional_encoding(r['x_c'][:n], 6), O.positional_encoding(r['v_c'][:n], 4)
+    tin = r['tokens_in'][:n].clone().requires_grad_(True)
+    st = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
+    z = O.transformer(st, tin)
+    rgb, sig = O.nerf_decoder(st, pe_x, z, pe_v)
+    gen = torch.Generator().manual_seed(1)
+    d_rgb, d_sig = torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen)
+    ((rgb * d_rgb).sum() + (sig * d_sig).sum()).backward()
+    Wb = state['renderer.conv1d_reprojection.weight'][:, 32:64, 0]
+    tok = r['tokens_in'][:n].clone()
+    tok[:, 2] -= O.positional_encoding(r['tap_rgb'][:n], 5)[:, :32] @ Wb.t()
+    ext = torch.zeros(n, 12)
+    ext[:, 0:3], ext[:, 3:6], ext[:, 6:9] = r['x_c'][:n], r['v_c'][:n], r['tap_rgb'][:n]
+    d_sample = torch.cat([d_rgb, d_sig[:, None]], 1).contiguous()
+    ops = CpuKernelOps(cpu_lib, monkeypatch)
+    d_tin, grads, dWb_pe = dense_backward(ops, state, Mat(tok.reshape(-1).clone(), n, 96), Mat(ext.reshape(-1).clone(), n, 12),
+                                          Mat(d_sample.reshape(-1).clone(), n, 4))
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    assert rel(d_tin.tensor().view(n, 3, 32), tin.grad) < 1e-3
+    for k, v in grads.items():
+        assert st[k].grad is not None and rel(v, st[k].grad) < 2e-3, (k, rel(v, st[k].grad))
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_sparse_conv_gradient_kernels_on_cpu(cpu_lib, monkeypatch, mode):
+    from tests.bwd_emulator import make_level
+    e, h = EmuOps(), CpuKernelOps(cpu_lib, monkeypatch)
+    g = torch.Generator().manual_seed(1)
+    fine_e, fine_k = make_level(torch.unique(torch.randint(0, 8 * 10 * 12, (260,), generator=g)), (8, 10, 12))
+    if mode == 0:
+        out_e, out_k = fine_e, fine_k
+    else:
+        out_e, out_k = make_level(torch.unique(torch.randint(0, 4 * 5 * 6, (70,), generator=g)), (4, 5, 6))
+    Cin, Cout = 32, 64
+    in_raw = torch.randn(fine_e['cap'] * Cin, generator=g); d_raw = torch.randn(out_e['cap'] * Cout, generator=g)
+    bn = torch.randn(3 * Cin, generator=g); mult = torch.randint(1, 3, (fine_e['cap'],), generator=g)
+    W = torch.randn(Cout * 27 * Cin, generator=g)
+    for use_bn in (False, True):
+        dW_c, dW_g = Mat(torch.zeros(Cout * 27 * Cin), Cout, 27 * Cin), Mat(torch.zeros(Cout * 27 * Cin), Cout, 27 * Cin)
+        e.conv_wgrad(out_e, fine_e, Mat(in_raw.clone(), fine_e['cap'], Cin), Cin, Mat(bn.clone(), 1, 3 * Cin) if use_bn else None,
+                     mult if use_bn else None, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, mode, dW_c)
+        h.conv_wgrad(out_k, fine_k, Mat(in_raw.clone(), fine_e['cap'], Cin), Cin, Mat(bn.clone(), 1, 3 * Cin) if use_bn else None,
+                     mult.to(torch.int32) if use_bn else None, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, mode, dW_g)
+        _same(dW_c, dW_g, 1e-4)
+    di_c, di_g = Mat(torch.zeros(fine_e['cap'] * Cin), fine_e['cap'], Cin), Mat(torch.zeros(fine_e['cap'] * Cin), fine_e['cap'], Cin)
+    e.conv_dgrad(fine_e, out_e, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_c)
+    h.conv_dgrad(fine_k, out_k, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_g)
+    _same(di_c, di_g, 1e-4)
+
+
+def test_batchnorm_backward_and_row_kernels_on_cpu(cpu_lib, monkeypatch):
+    from tests.bwd_emulator import make_level
+    e, h = EmuOps(), CpuKernelOps(cpu_lib, monkeypatch)
+    gen = torch.Generator().manual_seed(6)
+    lev_e, lev_k = make_level(torch.unique(torch.randint(0, 512, (150,), generator=gen)), (8, 8, 8))
+    n, cap, C = int(lev_e['n_rows']), lev_e['cap'], 64
+    raw = torch.randn(cap * C, generator=gen); d_out = torch.randn(cap * C, generator=gen)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    mult = torch.randint(1, 4, (cap,), generator=gen)
+    N = int(mult[:n].sum())
+    x = raw.view(cap, C)[:n]
+    mean = x.sum(0) / N
+    var = (((x - mean) ** 2).sum(0) + (N - n) * mean ** 2) / N
+    inv = 1 / torch.sqrt(var + 1e-3)
+    scale, shift = gamma * inv, beta - mean * gamma * inv
+    bn, st = torch.cat([scale, shift, torch.relu(shift)]), torch.cat([mean, var])
+    mk = lambda: [Mat(torch.zeros(cap * C), cap, C), Mat(torch.zeros(C), 1, C), Mat(torch.zeros(C), 1, C)]
+    oc, og = mk(), mk()
+    for use_mult in (True, False):
+        e.bn_relu_bwd(Mat(d_out.clone(), cap, C), Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), Mat(st.clone(), 1, 2 * C), Mat(gamma.clone(), 1, C),
+                      mult if use_mult else None, torch.tensor(N), torch.tensor(n), *oc)
+        h.bn_relu_bwd(Mat(d_out.clone(), cap, C), Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), Mat(st.clone(), 1, 2 * C), Mat(gamma.clone(), 1, C),
+                      mult.to(torch.int32) if use_mult else None, torch.tensor([N], dtype=torch.int32), lev_k['n_rows'], *og)
+        for a, b in zip(oc, og):
+            _same(a, b, 1e-4)
+    a_c, a_g = Mat(torch.zeros(cap * C), cap, C), Mat(torch.zeros(cap * C), cap, C)
+    e.bn_relu_apply(Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), torch.tensor(n), a_c)
+    h.bn_relu_apply(Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), lev_k['n_rows'], a_g)
+    _same(a_c, a_g, 1e-6)
+    D, H, W = lev_e['dims']
+    k = lev_e['keys'][:n]
+    coord = torch.stack([torch.zeros_like(k), k // (H * W), (k // W) % H, k % W], 1)
+    coord = torch.cat([coord, coord[:7]])
+    f_c, f_g = Mat(torch.zeros(coord.shape[0] * 32), coord.shape[0], 32), Mat(torch.zeros(coord.shape[0] * 32), coord.shape[0], 32)
+    dg = torch.randn(cap * 32, generator=gen)
+    e.gather_rows(coord, coord.shape[0], lev_e, Mat(dg.clone(), cap, 32), 32, f_c)
+    h.gather_rows(coord.to(torch.int32).contiguous(), coord.shape[0], lev_k, Mat(dg.clone(), cap, 32), 32, f_g)
+    _same(f_c, f_g, 1e-6)
+
+
+# ---- kernels of the FORWARD library that need no gfx950 intrinsic: compositing (fwd + bwd), gather (fwd + bwd), table folds ----
+@pytest.fixture(scope='module')
+def fwd_lib(tmp_path_factory):
+    path = build_cpu.build('sherf_hipcpu_fwd', ['composite.hip', 'gather.hip', 'fold.hip'], str(tmp_path_factory.mktemp('hipcpu_fwd')),
+                           extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n')
+    lib = ctypes.CDLL(path)
+    protos = _lib.parse_header()
+    for name in ('sherf_composite_compact', 'sherf_composite_compact_bwd', 'sherf_gather_tokens', 'sherf_gather_tokens_bwd', 'sherf_fold_tables',
+                 'sherf_img_to_hwc4'):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = protos[name][0], [a[0] for a in protos[name][1]]
+    return lib
+
+
+@pytest.fixture(scope='module')
+def frame(golden_dir):
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    state = {k: torch.from_numpy(fixtures.seeded_param(k, s)) for k, s in shapes.items() if fixtures.seeded_param(k, s) is not None}
+    fx = fixtures.renderer_inputs('tiny_nv')
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+    return fx, state, r, g
+
+
+def _P(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f2ord(x):                                              # csrc/common.h: f2ord (order-preserving float -> int)
+    i = np.float32(x).view(np.int32)
+    return int(i if i >= 0 else i ^ 0x7FFFFFFF)
+
+
+def test_compositing_kernels_on_cpu(fwd_lib, frame):
+    fx, state, r, g = frame
+    R, S = r['t'].shape
+    valid = r['valid']
+    nv = valid.numel()
+    ray = valid // S
+    cnt = torch.bincount(ray, minlength=R).to(torch.int32)
+    base = (torch.cumsum(cnt, 0) - cnt).to(torch.int32)
+    cs_idx = valid.to(torch.int32).contiguous()
+    sample_out = torch.cat([r['sample_rgb'], r['sample_sigma'][:, None]], 1).contiguous()
+    d = fixtures.to_torch(fx['input_data'])
+    rd, nr, fr = d['ray_d_all'][0, 0].contiguous(), d['near_all'][0, 0, :, 0].contiguous(), d['far_all'][0, 0, :, 0].contiguous()
+    counters = torch.tensor([nv, _f2ord(float(r['t'].min())), _f2ord(float(r['t'].max())), 0], dtype=torch.int32)
+    rgb, dep, acc = torch.zeros(R, 3), torch.zeros(R), torch.zeros(R)
+    assert fwd_lib.sherf_composite_compact(_P(counters), _P(base), _P(cnt), _P(cs_idx), _P(sample_out), _P(rd), _P(nr), _P(fr), R, S, 0, _P(rgb),
+                                           _P(dep), _P(acc), None) == 0
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    assert rel(rgb, r['rgb']) < 1e-5 and rel(acc, r['acc']) < 1e-5 and torch.allclose(dep, r['depth'], rtol=1e-5, atol=1e-6)
+    rs = np.random.RandomState(11)
+    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1, R, 3)).astype(np.float32))[0]
+    t_acc = torch.from_numpy(rs.uniform(0, 1, (1, R, 1)).astype(np.float32))[0, :, 0]
+    d_rgb = (2.0 * (r['rgb'] - t_rgb) / (R * 3)).contiguous(); d_acc = (2.0 * (r['acc'] - t_acc) / R).contiguous()
+    d_out = torch.zeros(nv, 4)
+    assert fwd_lib.sherf_composite_compact_bwd(_P(base), _P(cnt), _P(cs_idx), _P(sample_out), _P(rd), _P(nr), _P(fr), R, S, 0, _P(d_rgb), _P(d_acc),
+                                               _P(d_out), None) == 0
+    assert rel(d_out[:, :3], g['stage.sample_rgb']) < 1e-5 and rel(d_out[:, 3], g['stage.sample_sigma']) < 2e-4
+
+
+def test_gather_kernels_on_cpu(fwd_lib, frame):
+    """sherf_fold_tables + sherf_gather_tokens (forward) against the oracle's tokens, and sherf_gather_tokens_bwd against the
+    oracle's tap stencils -- the kernels' real source on folded tables built the way sherf_amd/renderer.py builds them."""
+    from oracle import backward_explicit as BX
+    from tests.bwd_emulator import make_level
+    fx, state, r, g = frame
+    n = r['x_c'].shape[0]
+    planes = torch.from_numpy(fx['planes'])[0].contiguous(); obs_feat = torch.from_numpy(fx['obs_feat'])[0].contiguous()
+    obs_img = torch.from_numpy(fx['input_data']['obs_img_all'])[0, 0].contiguous()
+    P, (Hf, Wf), (H, W) = planes.shape[-1], obs_feat.shape[-2:], obs_img.shape[-2:]
+    Wr = state['renderer.conv1d_reprojection.weight'][:, :, 0]; br = state['renderer.conv1d_reprojection.bias']
+    Wp = state['renderer.conv1d_projection.weight'][:, :, 0]; bp = state['renderer.conv1d_projection.bias']
+    Wa, Wb, Wc = Wr[:, 0:32], Wr[:, 32:64], Wr[:, 64:96]
+    planes_f, feat_f, img4 = torch.zeros(3, P, P, 32), torch.zeros(Hf, Wf, 64), torch.zeros(H, W, 4)
+    assert fwd_lib.sherf_fold_tables(_P(planes), _P(Wa.t().contiguous()), _P(planes_f), P * P, 3, 32, P * P * 32, None) == 0
+    assert fwd_lib.sherf_fold_tables(_P(obs_feat), _P(Wb.t().contiguous()), _P(feat_f), Hf * Wf, 2, 64, 32, None) == 0
+    assert fwd_lib.sherf_img_to_hwc4(_P(obs_img), _P(img4), H * W, None) == 0
+    assert torch.allclose(planes_f, torch.einsum('oi,pihw->phwo', Wa, planes), atol=1e-5)
+    # voxel levels: (bits, prefix) records + folded rows  F_l = cat_s Wc Wp[32s:32s+32, cols_l]
+    levels = (_lib.VoxLevel * 3)()
+    keep, kers = [], []
+    for i, ((keys, act, shape), (c0, c1)) in enumerate(zip(r['taps'], ((0, 32), (32, 96), (96, 192)))):
+        emu, ker = make_level(keys, shape)
+        Fcat = torch.cat([Wc @ Wp[32 * s:32 * s + 32, c0:c1] for s in range(3)], 0)          # [96, C]
+        rows = torch.zeros(ker['cap'], 96); rows[:act.shape[0]] = act @ Fcat.t()
+        keep += [ker['wp'], rows]; kers.append(ker)
+        levels[i].wp, levels[i].rows = ker['wp'].data_ptr(), rows.data_ptr()
+        levels[i].D, levels[i].H, levels[i].W = shape
+    tok_bias = torch.cat([br + Wc @ bp[32 * s:32 * s + 32] for s in range(3)]).contiguous()
+    geom = torch.zeros(n, 8); geom[:, 0:3], geom[:, 3:6], geom[:, 6:8] = r['x_c'], r['v_c'], r['uv']
+    tiles = (n + 31) // 32
+    tokens, extras = torch.zeros(tiles * 3072), torch.zeros(tiles * 384)
+    counters = torch.tensor([n, 0, 0, 0], dtype=torch.int32)
+    bounds = torch.from_numpy(fx['input_data']['t_world_bounds']).reshape(6).contiguous()
+    vox_min = r['sp_input']['bounds'][0].contiguous()
+    vox_sh = (ctypes.c_int32 * 3)(*[int(v) for v in r['sp_input']['out_sh']])
+    assert fwd_lib.sherf_gather_tokens(_P(counters), _P(geom), _P(planes_f), P, _P(feat_f), Hf, Wf, _P(img4), H, W, levels, _P(tok_bias), _P(bounds),
+                                       _P(vox_min), vox_sh, 0, n, _P(tokens), _P(extras), None) == 0
+    tok = tokens.view(tiles, 3, 8, 32, 4).permute(0, 3, 1, 2, 4).reshape(tiles * 32, 3, 32)[:n]
+    ref = r['tokens_in'].clone()
+    ref[:, 2] -= O.positional_encoding(r['tap_rgb'], 5)[:, :32] @ Wb.t()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    assert rel(tok, ref) < 1e-4
+    ex = extras.view(tiles, 12, 32).permute(0, 2, 1).reshape(tiles * 32, 12)[:n]
+    assert rel(ex[:, 0:3], r['x_c']) < 1e-6 and rel(ex[:, 6:9], r['tap_rgb']) < 1e-5
+    # ---- backward: scatter of d_tokens ----
+    dt = g['stage.tokens_in']
+    pad = torch.zeros(tiles * 32, 96); pad[:n] = dt.reshape(n, 96)
+    d_tiled = pad.view(tiles, 32, 3, 8, 4).permute(0, 2, 3, 1, 4).reshape(-1).contiguous()
+    d_planes_f, d_feat_f, d_bias = torch.zeros(3 * P * P, 32), torch.zeros(Hf * Wf, 64), torch.zeros(96)
+    d_rows = [torch.zeros(k['cap'], 96) for k in kers]
+    assert fwd_lib.sherf_gather_tokens_bwd(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
+                                           _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), None) == 0
+    bnd = bounds.view(2, 3)
+    ref_pf = BX.triplane_bwd((3, 32, P, P), r['x_c'], bnd, dt.permute(1, 0, 2)).permute(0, 2, 3, 1).reshape(3 * P * P, 32)
+    assert rel(d_planes_f, ref_pf) < 1e-4
+    gg = 2.0 * r['uv'] / torch.tensor([W, H], dtype=torch.float32) - 1.0
+    ref_ff = BX._grid_sample_2d_bwd((64, Hf, Wf), gg[:, 0], gg[:, 1], True, dt[:, :2].reshape(n, 64)).permute(1, 2, 0).reshape(Hf * Wf, 64)
+    assert rel(d_feat_f, ref_ff) < 1e-4
+    for (keys, act, shape), dr in zip(r['taps'], d_rows):
+        assert rel(dr[:act.shape[0]], BX.trilinear_sparse_bwd(keys, act.shape[0], shape, r['grid'], dt.reshape(n, 96))) < 1e-4
+    assert rel(d_bias.view(3, 32), dt.sum(0)) < 1e-4
