@@ -351,3 +351,58 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     for (keys, act, shape), dr in zip(r['taps'], d_rows):
         assert rel(dr[:act.shape[0]], BX.trilinear_sparse_bwd(keys, act.shape[0], shape, r['grid'], dt.reshape(n, 96))) < 1e-4
     assert rel(d_bias.view(3, 32), dt.sum(0)) < 1e-4
+
+
+@pytest.mark.skipif(not os.environ.get('SHERF_SLOW'), reason='minutes on a CPU (millions of emulated GPU threads): SHERF_SLOW=1 to run')
+def test_encoder_backward_through_the_real_kernels(cpu_lib, monkeypatch, golden_dir):
+    """sherf_amd/backward_encoder.py: encoder_backward with every entry point served by the CPU build of csrc/bwd_encoder.hip on the
+    full 13-layer encoder of `tiny_nv`, against autograd through the oracle.  (Per-kernel checks + the emulated orchestration run
+    in the default suite; this is their conjunction.)"""
+    from oracle import backward_explicit as BX
+    from sherf_amd.backward_encoder import encoder_backward
+    from tests.bwd_emulator import make_level
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    state = {k: torch.from_numpy(fixtures.seeded_param(k, s)) for k, s in shapes.items() if fixtures.seeded_param(k, s) is not None}
+    fx = fixtures.renderer_inputs('tiny_nv')
+    loss, g = O.gradients_from_fixture(fx, state, stages=True)
+    with torch.no_grad():
+        r = O.render_from_fixture(fx, state, training=True)
+        coord = r['sp_input']['coord']
+        N = coord.shape[0]
+        taps, cache = BX.encoder_forward_cached(state, torch.from_numpy(fx['vertex_feat']), coord, r['sp_input']['out_sh'])
+    _, inv0, uk0, sh0, g0 = cache[0]
+    convs = [e for e in cache if e[0] == 'conv']
+    lev_keys, lev_dims = [uk0], [tuple(sh0)]
+    for e in convs:
+        if e[6]['down']:
+            lev_keys.append(e[6]['keys_out']); lev_dims.append(tuple(e[6]['sh_out']))
+    levels = [make_level(k, d, pad=3)[1] for k, d in zip(lev_keys, lev_dims)]
+    mult = torch.cat([torch.bincount(inv0, minlength=uk0.numel()), torch.ones(3, dtype=torch.long)]).to(torch.int32)
+    layers, lev = [], 0
+    for i, e in enumerate(convs):
+        _, wname, bname, pairs, g_in, bnc, meta = e
+        xh, inv, y, xh0, y0, m_, n_rows = bnc
+        lev_out = lev + 1 if meta['down'] else lev
+        gamma, beta = state[bname + '.weight'], state[bname + '.bias']
+        mean, C = -(xh0 / inv), xh.shape[1]
+        scale = gamma * inv
+        shift = beta - mean * scale
+        cap = levels[lev_out]['cap']
+        rawp = torch.zeros(cap, C); rawp[:meta['raw'].shape[0]] = meta['raw']
+        layers.append(dict(wname=wname, bname=bname, cin=g_in.shape[1], cout=C, down=meta['down'], tap=i in (4, 8, 12), lev_in=lev, lev_out=lev_out,
+                           raw=Mat(rawp.reshape(-1), cap, C), bnparam=Mat(torch.cat([scale, shift, torch.relu(shift)]).clone(), 1, 3 * C),
+                           stats=Mat(torch.cat([mean, 1.0 / inv ** 2 - 1e-3]).clone(), 1, 2 * C)))
+        lev = lev_out
+    g0p = torch.zeros(levels[0]['cap'], 32); g0p[:g0.shape[0]] = g0
+    ctx = dict(levels=levels, mult=mult, n_total=torch.tensor([N], dtype=torch.int32), coord=coord.to(torch.int32).contiguous(), N=N,
+               g0=Mat(g0p.reshape(-1), levels[0]['cap'], 32), layers=layers)
+    d_levels = []
+    for i, (keys, feats, shape) in enumerate(taps):
+        cap = levels[i + 1]['cap']
+        d = torch.zeros(cap, feats.shape[1]); d[:feats.shape[0]] = g[f'stage.level{i}']
+        d_levels.append(Mat(d.reshape(-1), cap, feats.shape[1]))
+    d_feat, grads = encoder_backward(CpuKernelOps(cpu_lib, monkeypatch), state, ctx, d_levels)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    assert rel(d_feat.tensor(), g['input.vertex_feat']) < 2e-3
+    for k, v in grads.items():
+        assert rel(v, g[k]) < 5e-3, (k, rel(v, g[k]))
