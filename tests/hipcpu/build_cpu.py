@@ -10,7 +10,22 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'sherf_amd', 'csrc')
 
 
-def build(name, sources, out_dir, extra_src=None):
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'     # host compile of the sources that use __bf16 / ext_vector_type (MFMA kernels)
+
+
+def _cpu_mlp(src):
+    """mlp.hip for the host: the three inline-asm sites (LDS-DMA, vmcnt wait, barrier) become their functional equivalents."""
+    a = src.index('            uint32_t l = (uint32_t)(size_t)(lptr_t)(dst + p * 1024);')
+    b = src.index('            ++n;', a)
+    src = src[:a] + '            memcpy(dst + p * 1024 + cx.lane * 16, g, 16);              // what global_load_lds_dwordx4 does for this lane\n' + src[b:]
+    a = src.index('__device__ __forceinline__ void wait_vm(int n) {')
+    b = src.index('__device__ __forceinline__ void wg_barrier()', a)
+    src = src[:a] + '__device__ __forceinline__ void wait_vm(int) {}\n' + src[b:]
+    src = re.sub(r'__device__ __forceinline__ void wg_barrier\(\) \{[^\n]*\}', '__device__ __forceinline__ void wg_barrier() { __syncthreads(); }', src)
+    return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
+
+
+def build(name, sources, out_dir, extra_src=None, compiler='g++'):
     os.makedirs(out_dir, exist_ok=True)
     cpps = [os.path.join(HERE, 'runtime.cpp')]
     if extra_src:
@@ -20,13 +35,15 @@ def build(name, sources, out_dir, extra_src=None):
     for s in sources:
         src = open(os.path.join(CSRC, s)).read()
         src = re.sub(r'extern __shared__ (?:__attribute__\(\(aligned\(16\)\)\) )?(\w+) (\w+)\[\];', r'\1* \2 = reinterpret_cast<\1*>(hipcpu_dyn);', src)
+        if s == 'mlp.hip':
+            src = _cpu_mlp(src)
         src = src.replace('#include "common.h"', f'#include "{os.path.join(CSRC, "common.h")}"')
         src = src.replace('#include "../../include/', f'#include "{os.path.join(ROOT, "include")}/')
         p = os.path.join(out_dir, s.replace('.hip', '.cpp'))
         open(p, 'w').write(src)
         cpps.append(p)
     lib = os.path.join(out_dir, f'lib{name}.so')
-    cmd = ['g++', '-std=c++20', '-O1', '-pthread', '-shared', '-fPIC', '-w', f'-I{HERE}', f'-I{os.path.join(ROOT, "include")}', *cpps, '-o', lib]
+    cmd = [compiler, '-std=c++20', '-O1', '-pthread', '-shared', '-fPIC', '-w', f'-I{HERE}', f'-I{os.path.join(ROOT, "include")}', *cpps, '-o', lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError('hipcpu build failed:\n' + r.stdout.decode()[-4000:])

@@ -406,3 +406,44 @@ def test_encoder_backward_through_the_real_kernels(cpu_lib, monkeypatch, golden_
     assert rel(d_feat.tensor(), g['input.vertex_feat']) < 2e-3
     for k, v in grads.items():
         assert rel(v, g[k]) < 5e-3, (k, rel(v, g[k]))
+
+
+# ---- the MFMA kernels: real source, host build with clang (bf16 / ext_vector_type), wave64 collectives and v_mfma emulated by
+# the shim; the LDS-DMA / waitcnt / barrier inline asm replaced by their functional equivalents (tests/hipcpu/build_cpu.py) ----
+@pytest.fixture(scope='module')
+def mlp_lib(tmp_path_factory):
+    if not os.path.exists(build_cpu.CLANG):
+        pytest.skip('needs the ROCm clang for the host build of the bf16 kernels')
+    path = build_cpu.build('sherf_hipcpu_mlp', ['mlp.hip'], str(tmp_path_factory.mktemp('hipcpu_mlp')),
+                           extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
+    lib = ctypes.CDLL(path)
+    protos = _lib.parse_header()
+    lib.sherf_nerf_mlp.restype, lib.sherf_nerf_mlp.argtypes = protos['sherf_nerf_mlp'][0], [a[0] for a in protos['sherf_nerf_mlp'][1]]
+    return lib
+
+
+@pytest.mark.parametrize('prec,shape,tol', [(1, 0, 1e-3), (1, 1, 1e-3), (1, 2, 1e-3), (0, 0, 5e-2)])
+def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, shape, tol):
+    """sherf_nerf_mlp: the fused transformer + decoder MFMA kernel (default 8x1, 4x2, and the experimental two-launch split
+    shape) executed from its real source on the CPU, against the oracle's per-sample rgb / sigma."""
+    from sherf_amd import mlp_pack
+    fx, state, r, g = frame
+    n = r['x_c'].shape[0]
+    stream, wbias, _ = mlp_pack.pack({k: v.numpy() for k, v in state.items() if not k.startswith('renderer.encoder_3d.')})
+    stream_t, wbias_t = torch.from_numpy(stream), torch.from_numpy(wbias)
+    Wb = state['renderer.conv1d_reprojection.weight'][:, 32:64, 0]
+    tok = r['tokens_in'].clone()
+    tok[:, 2] -= O.positional_encoding(r['tap_rgb'], 5)[:, :32] @ Wb.t()
+    tiles = (n + 31) // 32
+    pad = torch.zeros(tiles * 32, 96); pad[:n] = tok.reshape(n, 96)
+    tokens = pad.view(tiles, 32, 3, 8, 4).permute(0, 2, 3, 1, 4).reshape(-1).contiguous()
+    ext = torch.zeros(tiles * 32, 12)
+    ext[:n, 0:3], ext[:n, 3:6], ext[:n, 6:9] = r['x_c'], r['v_c'], r['tap_rgb']
+    extras = ext.view(tiles, 32, 12).permute(0, 2, 1).reshape(-1).contiguous()
+    counters = torch.tensor([n, 0, 0, 0], dtype=torch.int32)
+    out = torch.zeros(tiles * 32, 4)
+    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, shape, n, _P(out), None) == 0
+    sig_ref = torch.relu(r['sample_sigma'])
+    e_sig = float((torch.relu(out[:n, 3]) - sig_ref).abs().max() / sig_ref.max())
+    e_rgb = float((out[:n, :3] - r['sample_rgb']).abs().max())
+    assert e_sig < tol and e_rgb < tol, (e_sig, e_rgb)
