@@ -108,11 +108,19 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
 // transformer prologue and the MFMA-bound decoder as two launches -- 1 streams only chunks 0..8 (tiny ring slots => several
 // workgroups per CU, its waves no longer phase-locked to MFMA-bound ones) and leaves z_0, z_1 as ready-made bf16 hi/lo
 // B-fragments in the first 8 KiB of the tile's `tokens` block; 2 streams chunks 9..48 and starts from those fragments.
+// PHASE 3 = PHASE 2 with the 128-input layers walked TWO output tiles per step (one DMA of both chunks into a 32 KiB slot, two
+// independent accumulator chains, half the workgroup barriers of the trunk): 26 steps instead of 40.
 template <int NTL, int PHASE> __host__ __device__ constexpr int n_steps() {
-    return PHASE == 1 ? 9 * NTL : PHASE == 2 ? N_CHUNKS - 9 : 9 * NTL + (N_CHUNKS - 9);
+    return PHASE == 1 ? 9 * NTL : PHASE == 2 ? N_CHUNKS - 9 : PHASE == 3 ? 26 : 9 * NTL + (N_CHUNKS - 9);
 }
-template <int NTL, int PHASE> __host__ __device__ constexpr int step_chunk(int s) {
+template <int NTL, int PHASE> __host__ __device__ constexpr int step_chunk(int s) {       // first chunk of a step
+    if (PHASE == 3)
+        return s < 4 ? 9 + s : s < 12 ? 13 + 2 * (s - 4) : s < 16 ? 29 + (s - 12) : s < 20 ? 33 + 2 * (s - 16) : s < 22 ? 41 + 2 * (s - 20)
+             : s == 22 ? 45 : s < 25 ? 46 + (s - 23) : 48;
     return PHASE == 2 ? s + 9 : s < 9 * NTL ? s % 9 : s - 9 * (NTL - 1);
+}
+template <int PHASE> __host__ __device__ constexpr int step_count(int s) {                // chunks streamed in that step
+    return PHASE == 3 && ((s >= 4 && s < 12) || (s >= 16 && s < 22)) ? 2 : 1;
 }
 
 template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
@@ -120,7 +128,7 @@ template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // NSLOT ring slots
     int lane, h, dbg, wave, pending;
-    static constexpr int SLOT = (PHASE == 1 ? 3 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8 have <= 3 K-blocks
+    static constexpr int SLOT = (PHASE == 1 ? 3 : PHASE == 3 ? 16 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8: <= 3 K-blocks; pairs: 2 x 8
     static constexpr int NSLOT = 3;
     __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
 };
@@ -134,12 +142,13 @@ template <int PREC, int NW, int NTL, int PHASE>
 __device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
     if (step >= n_steps<NTL, PHASE>() || (cx.dbg & 32)) return 0;
     const int c = step_chunk<NTL, PHASE>(step);
-    const int pieces = chunk_nkb(c) * (PREC + 1);
+    const int pieces = chunk_nkb(c) * (PREC + 1) * step_count<PHASE>(step);       // a paired step streams two equal, adjacent chunks
     const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024 + cx.lane * 16;
     char* dst = cx.lds + (step % Ctx<PREC, NW, NTL, PHASE>::NSLOT) * Ctx<PREC, NW, NTL, PHASE>::SLOT;
     int n = 0;
+    constexpr int kMaxPieces = (PHASE == 3 ? 16 : MAX_NKB) * (PREC + 1);
 #pragma unroll
-    for (int i = 0; i < (MAX_NKB * (PREC + 1) + NW - 1) / NW; ++i) {
+    for (int i = 0; i < (kMaxPieces + NW - 1) / NW; ++i) {
         const int p = cx.wave + i * NW;                        // wave-uniform
         if (p < pieces) {
             // Inline asm on purpose: hipcc drains an LDS-DMA it knows about (vmcnt(0)) before every ds_read that might alias
@@ -347,7 +356,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     // first 8 KiB of the tile's own `tokens` block (the wave has read its tokens into registers long before): fragment
     // q = 4 * (0: z_0, 1: z_1) + 2 * kb + (0: hi, 1: lo).
     uint4* const zfrag = reinterpret_cast<uint4*>(const_cast<float4*>(tokens));
-    if constexpr (PHASE == 2) {
+    if constexpr (PHASE >= 2) {
 #pragma unroll
         for (int u = 0; u < NTL; ++u) {
             const float* ex = extras + tile[u] * 12 * 32 + j;
@@ -363,7 +372,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     }
     // ================= transformer, one tile at a time (steps 9u .. 9u+8 replay chunks 0..8) =================
 #pragma unroll
-    for (int u = 0; u < (PHASE == 2 ? 0 : NTL); ++u) {
+    for (int u = 0; u < (PHASE >= 2 ? 0 : NTL); ++u) {
         // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
         f32x16 tok[3];
 #pragma unroll
@@ -540,36 +549,72 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             split_tile<PREC>(acc[u], OUT[u][2 * (T)], OUT[u][2 * (T) + 1]);                          \
         }                                                                                             \
     }
+    // two output tiles of a 128-input layer in ONE step (PHASE 3): the slot holds chunk CHUNK (hi, lo) then chunk CHUNK + 1
+#define SHERF_TRUNK_PAIR(CHUNK, OUT, T, IN, RELU)                                                     \
+    {                                                                                                 \
+        static_assert(PREC == 1, "paired steps rely on the hi+lo chunk layout being contiguous");     \
+        f32x16 acc0[NTL], acc1[NTL];                                                                  \
+        _Pragma("unroll") for (int u = 0; u < NTL; ++u) { acc0[u] = bias_tile(cx, CHUNK); acc1[u] = bias_tile(cx, (CHUNK) + 1); } \
+        const char* s_ = cx.slot(step);                                                               \
+        mma_seg<PREC, 8, NTL>(s_, 0, 8, IN, acc0);                                                    \
+        mma_seg<PREC, 8, NTL>(s_ + 2 * 8 * 1024, 0, 8, IN, acc1);                                     \
+        advance(cx, step); ++step;                                                                    \
+        _Pragma("unroll") for (int u = 0; u < NTL; ++u) {                                             \
+            if (RELU) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[u][r] = relu(acc0[u][r]); acc1[u][r] = relu(acc1[u][r]); } } \
+            split_tile<PREC>(acc0[u], OUT[u][2 * (T)], OUT[u][2 * (T) + 1]);                          \
+            split_tile<PREC>(acc1[u], OUT[u][2 * (T) + 2], OUT[u][2 * (T) + 3]);                      \
+        }                                                                                             \
+    }
 #pragma unroll
     for (int T = 0; T < 4; ++T)     // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
         SHERF_TRUNK_TILE(9 + T, ha, T, mma_seg<PREC, 3, NTL>(s_, 0, 5, pe, acc); mma_seg<PREC, 2, NTL>(s_, 3, 5, z0b, acc);)
 #pragma unroll
     for (int L = 0; L < 4; ++L) {   // pts_linears.1-4 (ping-pong ha -> hb -> ha ...)
+        if constexpr (PHASE == 3) {
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            if (L & 1) SHERF_TRUNK_TILE(13 + 4 * L + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)
-            else SHERF_TRUNK_TILE(13 + 4 * L + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)
+            for (int T = 0; T < 4; T += 2) {
+                if (L & 1) SHERF_TRUNK_PAIR(13 + 4 * L + T, ha, T, hb, true)
+                else SHERF_TRUNK_PAIR(13 + 4 * L + T, hb, T, ha, true)
+            }
+        } else {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                if (L & 1) SHERF_TRUNK_TILE(13 + 4 * L + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)
+                else SHERF_TRUNK_TILE(13 + 4 * L + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)
+            }
         }
     }
 #pragma unroll
     for (int T = 0; T < 4; ++T)     // pts_linears.5 : [PE6 | z_0 | h(128)] ; after 4 layers the activations are back in ha
         SHERF_TRUNK_TILE(29 + T, hb, T, mma_seg<PREC, 3, NTL>(s_, 0, 13, pe, acc); mma_seg<PREC, 2, NTL>(s_, 3, 13, z0b, acc);
                          mma_seg<PREC, 8, NTL>(s_, 5, 13, ha, acc);)
+    if constexpr (PHASE == 3) {
 #pragma unroll
-    for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(33 + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)   // pts_linears.6
+        for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(33 + T, ha, T, hb, true)                              // pts_linears.6
 #pragma unroll
-    for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(37 + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)   // pts_linears.7
+        for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(37 + T, hb, T, ha, true)                              // pts_linears.7
+    } else {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(33 + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)   // pts_linears.6
+#pragma unroll
+        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(37 + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)   // pts_linears.7
+    }
     // ---- heads: feature_linear (4 tiles, no activation) into ha, alpha_linear (tile 45, row 0), both from hb ----
     float sigma[NTL];
+    if constexpr (PHASE == 3) {
 #pragma unroll
-    for (int T = 0; T < 4; ++T) {
-        f32x16 acc[NTL];
+        for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(41 + T, ha, T, hb, false)
+    } else {
 #pragma unroll
-        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 41 + T);
-        mma_seg<PREC, 8, NTL>(cx.slot(step), 0, 8, hb, acc);
-        advance(cx, step); ++step;
+        for (int T = 0; T < 4; ++T) {
+            f32x16 acc[NTL];
 #pragma unroll
-        for (int u = 0; u < NTL; ++u) split_tile<PREC>(acc[u], ha[u][2 * T], ha[u][2 * T + 1]);
+            for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 41 + T);
+            mma_seg<PREC, 8, NTL>(cx.slot(step), 0, 8, hb, acc);
+            advance(cx, step); ++step;
+#pragma unroll
+            for (int u = 0; u < NTL; ++u) split_tile<PREC>(acc[u], ha[u][2 * T], ha[u][2 * T + 1]);
+        }
     }
     {
         f32x16 acc[NTL];
@@ -617,6 +662,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             }
     }
 #undef SHERF_TRUNK_TILE
+#undef SHERF_TRUNK_PAIR
 }
 
 }  // namespace
@@ -631,13 +677,23 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 2 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 3 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (shape == 3) {                         // experimental: shape 2 with the decoder walking two output tiles per step (PHASE 3)
+        SHERF_CHECK_ARG(prec == 1);
+        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 1>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
+        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 3>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
+        SHERF_LAUNCH_CHECK();
+    }
     if (shape == 2) {                         // experimental: transformer prologue and decoder as two launches (see PHASE)
         SHERF_CHECK_ARG(prec == 1);
         hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 1>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,

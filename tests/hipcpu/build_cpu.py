@@ -25,7 +25,7 @@ def _cpu_mlp(src):
     return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
 
 
-def build(name, sources, out_dir, extra_src=None, compiler='g++'):
+def build(name, sources, out_dir, extra_src=None, compiler='g++', defines=()):
     os.makedirs(out_dir, exist_ok=True)
     cpps = [os.path.join(HERE, 'runtime.cpp')]
     if extra_src:
@@ -43,7 +43,7 @@ def build(name, sources, out_dir, extra_src=None, compiler='g++'):
         open(p, 'w').write(src)
         cpps.append(p)
     lib = os.path.join(out_dir, f'lib{name}.so')
-    cmd = [compiler, '-std=c++20', '-O1', '-pthread', '-shared', '-fPIC', '-w', f'-I{HERE}', f'-I{os.path.join(ROOT, "include")}', *cpps, '-o', lib]
+    cmd = [compiler, *[f'-D{d}' for d in defines], '-std=c++20', '-O1', '-pthread', '-shared', '-fPIC', '-w', f'-I{HERE}', f'-I{os.path.join(ROOT, "include")}', *cpps, '-o', lib]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError('hipcpu build failed:\n' + r.stdout.decode()[-4000:])

@@ -114,8 +114,7 @@ inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) { 
     for (int i = 0; i < 4; ++i) r |= (unsigned)((src >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
     return r;
 }
-inline int __builtin_amdgcn_readfirstlane(int v) { return v; }                             // callers pass wave-uniform values
-inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
+template <class T> inline T __builtin_amdgcn_readfirstlane(T v) { return v; }                 // callers pass wave-uniform values
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
