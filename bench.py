@@ -43,6 +43,9 @@ def main():
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--torch-gpu-baseline', action='store_true',
+                    help='also time the oracle (the reference algorithm as stock ATen ops, brute-force K-NN) ON THE GPU over the whole '
+                         'frame: SURVEY.md section 8(d) asks for this denominator beside the CPU one (N = 1 only, adds ~1 min)')
     ap.add_argument('--bn-mode', default='train', choices=['train', 'eval'],
                     help='BatchNorm of the voxel encoder. train (default) = batch statistics: the mode the reference renders in, '
                          'also at test time (eval_*.sh -> train.py --test_flag -> test(G, ...) with G built .train(), '
@@ -141,6 +144,8 @@ def main():
             res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_dt / a.steps, 4)
         if not a.no_cpu_baseline and world == 1:            # reported at N = 1 only (rank 0's host cores)
             res['cpu_baseline'] = cpu_baseline(a.config)
+        if a.torch_gpu_baseline and world == 1:
+            res['torch_gpu_baseline'] = torch_gpu_baseline(a.config, dev, a.bn_mode == 'train')
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
@@ -171,6 +176,32 @@ def cpu_baseline(cfg_name):
     return dict(value=len(sel) / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'centred {n}x{n}-ray crop of the {H}x{W}x{c["S"]} frame ({len(sel)} rays, {int(r["mask"].sum())} valid samples), '
                        f'oracle/sherf_oracle.py fp32 torch-CPU, {dt:.1f} s')
+
+
+def torch_gpu_baseline(cfg_name, dev, training, iters=2):
+    """The same oracle as cpu_baseline, run through PyTorch-ROCm's stock kernels on the GPU over the WHOLE frame (checker code
+    timed as a baseline, never on the product path).  Its K-NN is the blocked brute force of oracle.nearest_vertex."""
+    try:
+        from oracle import fixtures, sherf_oracle as O
+        import json as _json
+        shapes = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'param_shapes.json')))
+        state = {n: torch.from_numpy(fixtures.seeded_param(n, s)).to(dev) for n, s in shapes.items() if fixtures.seeded_param(n, s) is not None}
+        fx = fixtures.renderer_inputs(cfg_name)
+        c = fx['cfg']
+        O.NN_CHUNK = 32768                      # 32768 x 6890 distance blocks: large launches, < 4 GB of temporaries
+        times = []
+        with torch.no_grad():
+            for it in range(iters + 1):         # first pass = warm-up (allocator, kernel load)
+                torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                r = O.render_from_fixture(fx, state, training=training, keep=False, device=dev)
+                torch.cuda.synchronize(dev); times.append(time.perf_counter() - t0)
+        dt = min(times[1:])
+        R = c['H'] * c['W']
+        return dict(value=R / dt, unit='rays/s', kind='port', seconds_per_frame=dt,
+                    sample=f'whole {c["H"]}x{c["W"]}x{c["S"]} frame ({int(r["mask"].sum())} valid samples), oracle/sherf_oracle.py as stock '
+                           f'PyTorch-ROCm fp32 ops on the GPU, best of {iters} after 1 warm-up')
+    except Exception as e:                      # a baseline must never take the bench line down with it
+        return dict(error=f'{type(e).__name__}: {e}'[:300])
 
 
 if __name__ == '__main__':

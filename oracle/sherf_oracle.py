@@ -108,10 +108,14 @@ def shape_offsets(st, shapes):
     return torch.matmul(st['shapedirs'], shapes.view(10, 1)).squeeze(-1)
 
 
-def nearest_vertex(x, verts, chunk=2048):
+NN_CHUNK = 2048     # query rows per distance block (bench.py's GPU baseline raises it)
+
+
+def nearest_vertex(x, verts, chunk=None):
     """Exact K=1 nearest neighbour (the role of pytorch3d.ops.knn_points at renderer.py:315,564,627).
     d^2 = ((dx*dx)+(dy*dy))+(dz*dz) in fp32, ties -> lowest index. Returns (d2 [n], idx [n] int64)."""
     n = x.shape[0]
+    chunk = chunk or NN_CHUNK
     d2 = torch.empty(n, dtype=F32); idx = torch.empty(n, dtype=torch.long)
     for s in range(0, n, chunk):
         q = x[s:s + chunk]
@@ -509,9 +513,21 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
     return out
 
 
-def render_from_fixture(fx, state, training=True, keep=True):
-    """Convenience: run `render` on a dict produced by oracle.fixtures.renderer_inputs (numpy) + a state dict."""
-    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+def render_from_fixture(fx, state, training=True, keep=True, device=None):
+    """Convenience: run `render` on a dict produced by oracle.fixtures.renderer_inputs (numpy) + a state dict.
+    device: None = CPU (the oracle proper).  bench.py --torch-gpu-baseline passes the GPU: the same stock ATen ops then run there
+    (`state` must already live on it) -- the "reference through stock PyTorch-ROCm" denominator of SURVEY.md section 8(d)."""
+    if device is not None:
+        with torch.device(device):          # factory calls below (torch.zeros, torch.tensor, ...) then allocate on `device`
+            return _render_from_fixture(fx, state, training, keep, torch.device(device))
+    return _render_from_fixture(fx, state, training, keep, None)
+
+
+def _render_from_fixture(fx, state, training, keep, device):
+    def to(a):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        return a.to(device) if device is not None and torch.is_tensor(a) else a
     d = {k: ({kk: to(vv) for kk, vv in v.items()} if isinstance(v, dict) else to(v)) for k, v in fx['input_data'].items()}
     st = smpl_tensors(fx['smpl'])
     OP = d['obs_params']
