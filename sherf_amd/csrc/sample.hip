@@ -297,7 +297,9 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                 bs[i] = __builtin_amdgcn_readlane(seg_s[i], src);
                 cum[i + 1] = cum[i] + __builtin_amdgcn_readlane(seg_n[i], src);
             }
+            __builtin_amdgcn_wave_barrier();          // (no instruction: the wave runs in lockstep; marks the ordering the LDS slot relies on)
             if (lane == 0) __hip_atomic_store(&s_key[wave], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
             for (int base = 0; base < cum[9]; base += 64) {
                 const int t = base + lane;
                 if (t < cum[9]) {
@@ -310,6 +312,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                         atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
                 }
             }
+            __builtin_amdgcn_wave_barrier();
             const unsigned long long res = __hip_atomic_load(&s_key[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             if (lane == src) my_key = res;
         }

@@ -1,13 +1,14 @@
 // TEST INFRASTRUCTURE: a minimal "HIP on the CPU" shim.  The kernel sources of sherf_amd/csrc that use no gfx950 intrinsics
 // (bwd_dense.hip, bwd_encoder.hip, composite.hip, gather.hip, fold.hip) are compiled UNCHANGED with g++ against this header
-// and executed on the host: one std::thread per GPU thread of a workgroup, workgroups one after the other, __syncthreads() a
-// std::barrier, atomics std::atomic_ref.  Slow (tiny inputs only) but it runs the real kernel code -- indexing, strides,
+// and executed on the host: every GPU thread of a workgroup is a cooperative fiber on one OS thread (runtime.cpp), workgroups
+// spread over the host cores, __syncthreads() / wave collectives are yields, atomics std::atomic_ref.  Slow (small inputs
+// only) but it runs the real kernel code -- indexing, strides,
 // reductions -- so the backward kernels, written without GPU time, are checked against their specification before they ever
 // reach hardware (tests/test_hipcpu_kernels.py).  Nothing in the product uses this.
 #pragma once
 #include <algorithm>
 #include <atomic>
-#include <barrier>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -22,22 +23,22 @@
 #define __forceinline__ inline
 #define __restrict__
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local          // one copy per worker OS thread = per workgroup in flight
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct hipcpu_idx { unsigned x, y, z; };
 extern thread_local hipcpu_idx threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
-extern std::barrier<>* hipcpu_barrier;
-extern unsigned char hipcpu_dyn[];                       // dynamic shared memory of the current workgroup
-inline void __syncthreads() { hipcpu_barrier->arrive_and_wait(); }
+extern thread_local unsigned char hipcpu_dyn[];          // dynamic shared memory of the current workgroup
+void hipcpu_syncthreads();
+void hipcpu_wave_sync();
+void hipcpu_run_grid(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+inline void __syncthreads() { hipcpu_syncthreads(); }
 // ---- wave64 collectives (for the kernels that use them: the 64 threads of a wave meet at a per-wave barrier and exchange
 // through a per-wave scratch line).  Every lane of the wave must reach the call, as on the hardware. ----
-extern std::barrier<>* hipcpu_wave_barrier[16];
-extern unsigned char hipcpu_wave_scratch[16][64 * 64];
+extern thread_local unsigned char hipcpu_wave_scratch[16][64 * 64];
 inline int hipcpu_lane() { return (int)(threadIdx.x & 63); }
 inline int hipcpu_wave() { return (int)(threadIdx.x >> 6); }
-inline void hipcpu_wave_sync() { hipcpu_wave_barrier[hipcpu_wave()]->arrive_and_wait(); }
 template <class T> inline T hipcpu_exchange(T v, int src_lane) {
     T* sc = reinterpret_cast<T*>(hipcpu_wave_scratch[hipcpu_wave()]);
     sc[hipcpu_lane()] = v;
@@ -48,6 +49,28 @@ template <class T> inline T hipcpu_exchange(T v, int src_lane) {
 }
 inline float __shfl_xor(float v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 inline int __shfl_xor(int v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
+template <class T> inline T __shfl_down(T v, int d) { const int l = hipcpu_lane() + d; return hipcpu_exchange(v, l < 64 ? l : hipcpu_lane()); }
+template <class T> inline T __shfl(T v, int src) { return hipcpu_exchange(v, src & 63); }
+inline unsigned long long __ballot(int pred) {           // every lane of the wave must call it (no divergence), as the shim's other collectives
+    unsigned char* sc = hipcpu_wave_scratch[hipcpu_wave()];
+    sc[hipcpu_lane()] = pred != 0;
+    hipcpu_wave_sync();
+    unsigned long long m = 0;
+    const int live = (int)std::min<unsigned>(64u, blockDim.x * blockDim.y * blockDim.z - 64u * hipcpu_wave());
+    for (int l = 0; l < live; ++l) m |= (unsigned long long)sc[l] << l;
+    hipcpu_wave_sync();
+    return m;
+}
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hipcpu_exchange(v, lane); }
+inline void __builtin_amdgcn_wave_barrier() { hipcpu_wave_sync(); }       // lockstep ordering points the kernels mark explicitly
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) std::atomic_ref<std::remove_cv_t<std::remove_pointer_t<decltype(p)>>>(*const_cast<std::remove_cv_t<std::remove_pointer_t<decltype(p)>>*>(p)).load()
+#define __hip_atomic_store(p, v, order, scope) std::atomic_ref<std::remove_cv_t<std::remove_pointer_t<decltype(p)>>>(*(p)).store(v)
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 struct float4 { float x, y, z, w; };
 struct uint2 { uint32_t x, y; };
@@ -61,6 +84,15 @@ inline int3 make_int3(int a, int b, int c) { return {a, b, c}; }
 typedef void* hipStream_t;
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
+// streams / events: every launch is synchronous, so ordering calls are no-ops and elapsed times are zero
+typedef void* hipEvent_t;
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipcpu"; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
@@ -69,6 +101,9 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 inline float unsafeAtomicAdd(float* p, float v) { return std::atomic_ref<float>(*p).fetch_add(v); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_or(v); }
+template <class T> inline T atomicMin(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v < o && !a.compare_exchange_weak(o, v)) {} return o; }
+template <class T> inline T atomicMax(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v > o && !a.compare_exchange_weak(o, v)) {} return o; }
+inline long long __double2ll_rn(double x) { return llrint(x); }
 inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
@@ -126,27 +161,7 @@ inline float __frsqrt_rn(float x) { return 1.0f / sqrtf(x); }
 
 template <class K, class... A>
 void hipcpu_launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t, A... args) {
-    gridDim = grid; blockDim = block;
-    const unsigned nt = block.x * block.y * block.z;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                std::barrier<> bar(nt);
-                hipcpu_barrier = &bar;
-                std::vector<std::unique_ptr<std::barrier<>>> wbars;
-                if (nt % 64 == 0 && nt / 64 <= 16)
-                    for (unsigned w = 0; w < nt / 64; ++w) { wbars.emplace_back(new std::barrier<>(64)); hipcpu_wave_barrier[w] = wbars.back().get(); }
-                if (smem) memset(hipcpu_dyn, 0, smem);
-                std::vector<std::thread> th;
-                th.reserve(nt);
-                for (unsigned t = 0; t < nt; ++t)
-                    th.emplace_back([=, &bar]() {
-                        threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-                        blockIdx = {bx, by, bz};
-                        kernel(args...);
-                        bar.arrive_and_drop();              // a thread that returned no longer takes part in later barriers
-                    });
-                for (auto& x : th) x.join();
-            }
+    const std::function<void()> body = [=]() { kernel(args...); };
+    hipcpu_run_grid(grid, block, smem, body);
 }
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) hipcpu_launch(kernel, grid, block, smem, stream, __VA_ARGS__)

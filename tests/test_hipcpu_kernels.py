@@ -1,4 +1,4 @@
-"""The backward kernels' REAL source executed on the CPU (tests/hipcpu: HIP-on-CPU shim, one std::thread per GPU thread)
+"""The backward kernels' REAL source executed on the CPU (tests/hipcpu: HIP-on-CPU shim, every GPU thread a cooperative fiber)
 against the torch emulation that specifies them (tests/bwd_emulator.py), op by op and through the whole dense-stage
 orchestration.  This is what verifies csrc/bwd_dense.hip and csrc/bwd_encoder.hip between GPU sessions."""
 import ctypes
@@ -353,7 +353,7 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     assert rel(d_bias.view(3, 32), dt.sum(0)) < 1e-4
 
 
-@pytest.mark.skipif(not os.environ.get('SHERF_SLOW'), reason='minutes on a CPU (millions of emulated GPU threads): SHERF_SLOW=1 to run')
+@pytest.mark.skipif(not os.environ.get('SHERF_SLOW'), reason='~20 s and covered end to end by tests/test_hipcpu_frame.py: SHERF_SLOW=1 to run the stage in isolation')
 def test_encoder_backward_through_the_real_kernels(cpu_lib, monkeypatch, golden_dir):
     """sherf_amd/backward_encoder.py: encoder_backward with every entry point served by the CPU build of csrc/bwd_encoder.hip on the
     full 13-layer encoder of `tiny_nv`, against autograd through the oracle.  (Per-kernel checks + the emulated orchestration run
