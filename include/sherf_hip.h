@@ -160,7 +160,8 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * fp32-grade).  shape: 0 = 8 waves x 1 column tile per workgroup (2 waves/SIMD), 1 = 4 waves x 2 tiles (1 wave/SIMD,
  * 512 registers), 2 = EXPERIMENTAL split (prec 1 only): the VALU-bound transformer prologue and the MFMA-bound decoder as two
  * launches; `tokens` is then used as scratch (z_0 / z_1 fragments overwrite the first 8 KiB of every tile); 3 = shape 2 with the
- * decoder walking two output tiles of every 128-input layer per ring step (26 steps instead of 40).  out[c] = (r,g,b,sigma). */
+ * decoder walking two output tiles of every 128-input layer per ring step (26 steps instead of 40); 4 = EXPERIMENTAL shape 0 as
+ * persistent workgroups (one per CU, weight ring kept streaming across tile groups).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream);
 /* layout of the weight stream the kernel expects: number of chunks and K-blocks per chunk. */

@@ -110,6 +110,10 @@ __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32
 // B-fragments in the first 8 KiB of the tile's `tokens` block; 2 streams chunks 9..48 and starts from those fragments.
 // PHASE 3 = PHASE 2 with the 128-input layers walked TWO output tiles per step (one DMA of both chunks into a 32 KiB slot, two
 // independent accumulator chains, half the workgroup barriers of the trunk): 26 steps instead of 40.
+// PHASE -1 (shape '8x1persist', experimental) = the fused kernel as PERSISTENT workgroups: one per CU, each walking tile groups
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the bias tables stay in LDS and the weight ring never drains -- the last three steps
+// of a group already stream steps 0..2 of the next one into the slots they free (slot(s) = s % 3 holds for every group) -- so
+// a group pays neither the launch gap nor the exposed first-chunk latency of a fresh workgroup.
 template <int NTL, int PHASE> __host__ __device__ constexpr int n_steps() {
     return PHASE == 1 ? 9 * NTL : PHASE == 2 ? N_CHUNKS - 9 : PHASE == 3 ? 26 : 9 * NTL + (N_CHUNKS - 9);
 }
@@ -128,6 +132,7 @@ template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // NSLOT ring slots
     int lane, h, dbg, wave, pending;
+    bool more;               // PHASE -1: this workgroup has another tile group after the current one (uniform)
     static constexpr int SLOT = (PHASE == 1 ? 3 : PHASE == 3 ? 16 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8: <= 3 K-blocks; pairs: 2 x 8
     static constexpr int NSLOT = 3;
     __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
@@ -185,6 +190,9 @@ template <int PREC, int NW, int NTL, int PHASE>
 __device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
     wait_vm(cx.pending);
     if (!(cx.dbg & 64)) wg_barrier();
+    if constexpr (PHASE == -1) {             // past the end of this group: the freed slot takes step (step + 3) % 3 of the next group
+        if (step + 3 >= n_steps<NTL, PHASE>()) { cx.pending = cx.more ? dma_issue(cx, (step + 3) % Ctx<PREC, NW, NTL, PHASE>::NSLOT) : 0; return; }
+    }
     cx.pending = dma_issue(cx, step + 3);
 }
 
@@ -332,12 +340,13 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
     cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = cx.lane & 31, h = cx.h;
+    int j = cx.lane & 31, h = cx.h;                                  // (not const: PHASE -1 launders them per group)
     int64_t tile[NTL];
     bool live[NTL];
 #pragma unroll
     for (int u = 0; u < NTL; ++u) {
-        tile[u] = ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * NTL + u;
+        if constexpr (PHASE == -1) tile[u] = ((int64_t)blockIdx.x * NW + cx.wave) * NTL + u;      // scalar: lives across the group loop
+        else tile[u] = ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * NTL + u;
         live[u] = tile[u] < n_tiles;
         if (!live[u]) tile[u] = n_tiles - 1;                         // dead tiles still take part in every barrier
     }
@@ -348,6 +357,16 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     __syncthreads();
     cx.pending = dma_issue(cx, 2);
 
+    [[maybe_unused]] int64_t grp = blockIdx.x;                       // PHASE -1: tile group of this pass
+    bool again = false;
+    do {                                                             // one pass unless PHASE == -1 (persistent workgroups)
+    if constexpr (PHASE == -1) {
+        cx.more = grp + gridDim.x < (n_tiles + NW * NTL - 1) / (NW * NTL);
+        // keep the per-chunk source addresses from being hoisted out of the group loop (dozens of live 64-bit VGPR pairs)
+        asm volatile("" : "+s"(cx.ws));
+        asm volatile("" : "+v"(cx.lane));         // same for everything derived from the lane id: one live VGPR, re-derived per group
+        j = cx.lane & 31; h = cx.lane >> 5; cx.h = h;
+    }
     BFrag<PREC> z0b[NTL][2], z1b[NTL][2];                            // fused tokens z_0, z_1 as K-blocks, per tile
     float xc[NTL][3], vc[NTL][3];
     int step = 0;
@@ -389,6 +408,13 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         {
             BFrag<PREC> b[1][2];
             pe_frags<PREC, 5, 2>(h, ex[192], ex[224], ex[256], b[0]);
+            if constexpr (PHASE == -1) {
+                if (u == 0 && grp != (int64_t)blockIdx.x) {          // steps 0..2 were streamed by the previous group's last steps
+                    wait_vm(0);
+                    __syncthreads();
+                    cx.pending = 0;
+                }
+            }
             f32x16 acc[1] = {bias_tile(cx, 0)};
             mma_seg<PREC, 2, 1>(cx.slot(step), 0, 2, b, acc);
             advance(cx, step); ++step;
@@ -651,6 +677,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 #pragma unroll
         for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 48);
         mma_seg<PREC, 4, NTL>(cx.slot(step), 0, 4, gb, acc);
+        if constexpr (PHASE == -1) { if (cx.more) advance(cx, step); }       // frees slot (n_steps - 1) % 3 for the next group
 #pragma unroll
         for (int u = 0; u < NTL; ++u)
             if (live[u] && h == 0) {
@@ -661,6 +688,19 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 }
             }
     }
+    if constexpr (PHASE == -1) {
+        again = cx.more;
+        if (again) {
+            grp += gridDim.x;
+#pragma unroll
+            for (int u = 0; u < NTL; ++u) {
+                tile[u] = (grp * NW + cx.wave) * NTL + u;
+                live[u] = tile[u] < n_tiles;
+                if (!live[u]) tile[u] = n_tiles - 1;
+            }
+        }
+    }
+    } while (again);   // tile groups
 #undef SHERF_TRUNK_TILE
 #undef SHERF_TRUNK_PAIR
 }
@@ -677,13 +717,28 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 3 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 4 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (shape == 4) {                         // experimental: persistent workgroups, one per CU (PHASE -1)
+        SHERF_CHECK_ARG(prec == 1);
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, v = 0;
+            SHERF_HIP_CHECK(hipGetDevice(&dev));
+            SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+            n_cu = v > 0 ? v : 256;
+        }
+        const int64_t groups = (tiles + 7) / 8;
+        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, -1>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(512), 0, as_stream(stream),
+                           counters, reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
+        SHERF_LAUNCH_CHECK();
+    }
     if (shape == 3) {                         // experimental: shape 2 with the decoder walking two output tiles per step (PHASE 3)
         SHERF_CHECK_ARG(prec == 1);
         hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 1>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,

@@ -214,7 +214,7 @@ class ImportanceRenderer(nn.Module):
         self.pos_enc = PositionalEncoding(num_freqs=6)
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
-        self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2' | experimental '8x1split', '8x1split2')
+        self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2' | experimental '8x1split', '8x1split2', '8x1persist')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
@@ -381,7 +381,7 @@ class ImportanceRenderer(nn.Module):
         # a13-a14: fused transformer + NeRF decoder
         fr.wstream, fr.wbias = A(wc['stream']), A(wc['wbias'])
         fr.mlp_prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
-        fr.mlp_shape = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3}[opts.get('mlp_shape', self.mlp_shape)]   # split: experimental, overwrites ws['tokens']
+        fr.mlp_shape = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4}[opts.get('mlp_shape', self.mlp_shape)]   # split: experimental, overwrites ws['tokens']
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()

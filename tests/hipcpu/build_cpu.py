@@ -22,6 +22,7 @@ def _cpu_mlp(src):
     b = src.index('__device__ __forceinline__ void wg_barrier()', a)
     src = src[:a] + '__device__ __forceinline__ void wait_vm(int) {}\n' + src[b:]
     src = re.sub(r'__device__ __forceinline__ void wg_barrier\(\) \{[^\n]*\}', '__device__ __forceinline__ void wg_barrier() { __syncthreads(); }', src)
+    src = re.sub(r'asm volatile\("" : "\+[sv]"\([^;]*;', ';', src)            # register-class launders (optimisation barriers only)
     return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
 
 

@@ -96,6 +96,8 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipcpu"; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+constexpr int hipDeviceAttributeMultiprocessorCount = 63;
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 2; return hipSuccess; }      // two 'CUs': persistent kernels loop
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }

@@ -107,7 +107,7 @@ def test_frame_matches_oracle_and_reference_golden(cpu_product, cfg):
     assert O.psnr(h['rgb'], ref_rgb) > 60.0
 
 
-@pytest.mark.parametrize('shape', ['4x2', '8x1split', '8x1split2'])
+@pytest.mark.parametrize('shape', ['4x2', '8x1split', '8x1split2', '8x1persist'])
 def test_mlp_shapes_agree_inside_the_frame(cpu_product, shape):
     a = cpu_render('tiny')
     b = cpu_render('tiny', options=dict(mlp_shape=shape))

@@ -20,3 +20,4 @@ python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"met
 SHERF_MLP_SHAPE=8x1split python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('8x1split  ', d['ms_per_step'], d['roofline']['kernel_ms'], '(kernel_ms covers both launches)')"
 SHERF_MLP_SHAPE=8x1split2 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('8x1split2 ', d['ms_per_step'], d['roofline']['kernel_ms'], '(decoder walks two output tiles per step)')"
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --torch-gpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stock-ops oracle on the GPU:', d.get('torch_gpu_baseline'))"
+SHERF_MLP_SHAPE=8x1persist python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('8x1persist', d['ms_per_step'], d['roofline']['kernel_ms'], '(persistent workgroups, ring streams across tile groups)')"
