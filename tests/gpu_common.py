@@ -35,13 +35,38 @@ def oracle_render(cfg, training=True):
     return O.render_from_fixture(fixture(cfg), seeded_state(), training=training, keep=True)
 
 
+# tests/test_hipcpu_frame.py sets this: the same parity tests then run with CPU tensors against the libraries built for the
+# host from the unchanged kernel sources (tests/hipcpu).  Tensors are tagged so the product's "must be on a GPU" checks pass.
+CPU_SHIM = False
+
+
+class _HostTensor(torch.Tensor):
+    is_cuda = True
+
+
+def dev_tensor(t):
+    """`.cuda()` of the GPU tests; in CPU-shim mode the tensor stays on the host (floating point ones tagged as device tensors)."""
+    if not CPU_SHIM:
+        return t.cuda()
+    return t.as_subclass(_HostTensor) if t.is_floating_point() else t
+
+
+def dev_module(m):
+    return m if CPU_SHIM else m.cuda()
+
+
+def plain(t):
+    """`.cpu()` of the GPU tests (drops the shim's tag)."""
+    return t.detach().as_subclass(torch.Tensor).cpu() if isinstance(t, torch.Tensor) else t
+
+
 def to_cuda(x):
     if isinstance(x, dict):
         return {k: to_cuda(v) for k, v in x.items()}
     if isinstance(x, np.ndarray):
-        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        return dev_tensor(torch.from_numpy(np.ascontiguousarray(x)))
     if isinstance(x, torch.Tensor):
-        return x.cuda()
+        return dev_tensor(x)
     return x
 
 
@@ -53,7 +78,9 @@ def hip_modules(precision='bf16x3'):
     dec = NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.')
     fixtures.load_seeded_state(dec, 'decoder.')
-    return rend.cuda().train(), dec.cuda().train()
+    if CPU_SHIM:
+        rend._side = lambda dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})()
+    return dev_module(rend).train(), dev_module(dec).train()
 
 
 def hip_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, options=None):
@@ -66,8 +93,8 @@ def hip_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, o
     if sp_input is None:
         sp_input = oracle_render(cfg)['sp_input']
     d = to_cuda(fx['input_data'])
-    sp = SparseConvTensor(to_cuda(fx['vertex_feat']), sp_input['coord'].cuda(), sp_input['out_sh'], 1)
-    spi = dict(coord=sp_input['coord'].cuda(), out_sh=sp_input['out_sh'], batch_size=1, bounds=sp_input['bounds'].cuda()[None])
+    sp = SparseConvTensor(to_cuda(fx['vertex_feat']), dev_tensor(sp_input['coord']), sp_input['out_sh'], 1)
+    spi = dict(coord=dev_tensor(sp_input['coord']), out_sh=sp_input['out_sh'], batch_size=1, bounds=dev_tensor(sp_input['bounds'])[None])
     opts = dict(fx['options'])
     opts['mlp_precision'] = precision
     if options:
@@ -75,8 +102,9 @@ def hip_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, o
     with torch.no_grad():
         rgb, depth, acc = rend(to_cuda(fx['planes']), d['obs_img_all'][:, 0], to_cuda(fx['obs_feat']), sp, None, spi, dec,
                                d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, opts)
-    torch.cuda.synchronize()
-    return dict(rgb=rgb[0].cpu(), depth=depth[0, :, 0].cpu(), acc=acc[0, :, 0].cpu(), last=rend.last, rend=rend)
+    if not CPU_SHIM:
+        torch.cuda.synchronize()
+    return dict(rgb=plain(rgb[0]), depth=plain(depth[0, :, 0]), acc=plain(acc[0, :, 0]), last=rend.last, rend=rend, dec=dec)
 
 
 def untile_tokens(tokens, n):

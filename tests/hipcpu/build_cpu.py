@@ -4,6 +4,7 @@ shim's buffer); everything else is the source as shipped."""
 import os
 import re
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -44,8 +45,18 @@ def build(name, sources, out_dir, extra_src=None, compiler='g++', defines=()):
         open(p, 'w').write(src)
         cpps.append(p)
     lib = os.path.join(out_dir, f'lib{name}.so')
-    cmd = [compiler, *[f'-D{d}' for d in defines], '-std=c++20', '-O1', '-pthread', '-shared', '-fPIC', '-w', f'-I{HERE}', f'-I{os.path.join(ROOT, "include")}', *cpps, '-o', lib]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    flags = [*[f'-D{d}' for d in defines], '-std=c++20', os.environ.get('HIPCPU_OPT', '-O2'), '-pthread', '-fPIC', '-w', f'-I{HERE}',
+             f'-I{os.path.join(ROOT, "include")}']
+
+    def compile_one(cpp):
+        obj = os.path.join(out_dir, os.path.basename(cpp) + '.o')
+        r = subprocess.run([compiler, *flags, '-c', cpp, '-o', obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError('hipcpu build failed:\n' + r.stdout.decode()[-4000:])
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(cpps), os.cpu_count() or 1)) as ex:      # one compiler process per translation unit
+        objs = list(ex.map(compile_one, cpps))
+    r = subprocess.run([compiler, '-shared', '-pthread', *objs, '-o', lib], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
-        raise RuntimeError('hipcpu build failed:\n' + r.stdout.decode()[-4000:])
+        raise RuntimeError('hipcpu link failed:\n' + r.stdout.decode()[-4000:])
     return lib

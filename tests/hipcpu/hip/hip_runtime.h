@@ -36,29 +36,36 @@ void hipcpu_run_grid(dim3 grid, dim3 block, size_t smem, const std::function<voi
 inline void __syncthreads() { hipcpu_syncthreads(); }
 // ---- wave64 collectives (for the kernels that use them: the 64 threads of a wave meet at a per-wave barrier and exchange
 // through a per-wave scratch line).  Every lane of the wave must reach the call, as on the hardware. ----
-extern thread_local unsigned char hipcpu_wave_scratch[16][64 * 64];
+extern thread_local unsigned char hipcpu_wave_scratch[16][2][64 * 64];     // double-buffered: ONE wave sync per collective
+extern thread_local unsigned char hipcpu_wave_flip[1024];                   // per GPU thread: which buffer its next collective uses
+unsigned hipcpu_linear_tid();
 inline int hipcpu_lane() { return (int)(threadIdx.x & 63); }
 inline int hipcpu_wave() { return (int)(threadIdx.x >> 6); }
+// A collective = every lane publishes into the wave's current buffer, ONE wave sync, every lane reads.  The next collective
+// uses the other buffer: a lane can be at most one collective ahead of the slowest lane of its wave (it has to pass the sync
+// in between), so a buffer is never overwritten while someone still reads it.
+inline unsigned char* hipcpu_collective_buffer() {
+    unsigned char& f = hipcpu_wave_flip[hipcpu_linear_tid()];
+    f ^= 1;
+    return hipcpu_wave_scratch[hipcpu_wave()][f];
+}
 template <class T> inline T hipcpu_exchange(T v, int src_lane) {
-    T* sc = reinterpret_cast<T*>(hipcpu_wave_scratch[hipcpu_wave()]);
+    T* sc = reinterpret_cast<T*>(hipcpu_collective_buffer());
     sc[hipcpu_lane()] = v;
     hipcpu_wave_sync();
-    const T r = sc[src_lane];
-    hipcpu_wave_sync();
-    return r;
+    return sc[src_lane];
 }
 inline float __shfl_xor(float v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 inline int __shfl_xor(int v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 template <class T> inline T __shfl_down(T v, int d) { const int l = hipcpu_lane() + d; return hipcpu_exchange(v, l < 64 ? l : hipcpu_lane()); }
 template <class T> inline T __shfl(T v, int src) { return hipcpu_exchange(v, src & 63); }
 inline unsigned long long __ballot(int pred) {           // every lane of the wave must call it (no divergence), as the shim's other collectives
-    unsigned char* sc = hipcpu_wave_scratch[hipcpu_wave()];
+    unsigned char* sc = hipcpu_collective_buffer();
     sc[hipcpu_lane()] = pred != 0;
     hipcpu_wave_sync();
     unsigned long long m = 0;
     const int live = (int)std::min<unsigned>(64u, blockDim.x * blockDim.y * blockDim.z - 64u * hipcpu_wave());
     for (int l = 0; l < live; ++l) m |= (unsigned long long)sc[l] << l;
-    hipcpu_wave_sync();
     return m;
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipcpu_exchange(v, lane); }
@@ -129,7 +136,7 @@ typedef float hipcpu_f32x16 __attribute__((ext_vector_type(16)));
 // B operand holds B[8h..8h+8)[i], C/D register r holds element [row (r & 3) + 8 (r >> 2) + 4h][column i].
 inline hipcpu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipcpu_bf16x8 a, hipcpu_bf16x8 b, hipcpu_f32x16 c, int, int, int) {
     struct Line { float a[8], b[8]; };
-    Line* sc = reinterpret_cast<Line*>(hipcpu_wave_scratch[hipcpu_wave()]);
+    Line* sc = reinterpret_cast<Line*>(hipcpu_collective_buffer());
     const int l = hipcpu_lane(), col = l & 31, h = l >> 5;
     for (int e = 0; e < 8; ++e) { sc[l].a[e] = (float)a[e]; sc[l].b[e] = (float)b[e]; }
     hipcpu_wave_sync();
@@ -141,7 +148,6 @@ inline hipcpu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipcpu_bf16x8 a, hi
             for (int e = 0; e < 8; ++e) acc += sc[row + 32 * hh].a[e] * sc[col + 32 * hh].b[e];
         d[r] += acc;
     }
-    hipcpu_wave_sync();
     return d;
 }
 #endif

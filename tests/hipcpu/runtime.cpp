@@ -1,18 +1,20 @@
 // TEST INFRASTRUCTURE: scheduler of the "HIP on the CPU" shim (see hip/hip_runtime.h).
-// A workgroup runs on ONE OS thread as a set of cooperative fibers (ucontext), one per GPU thread: __syncthreads() and the
+// A workgroup runs on ONE OS thread as a set of cooperative fibers (hand-written x86-64 switch), one per GPU thread: __syncthreads() and the
 // wave64 collectives are yields, so a barrier costs a context switch instead of a kernel futex and a kernel without barriers
 // runs its threads back to back.  Workgroups are distributed over a few OS worker threads (atomics are std::atomic_ref, so
 // concurrent workgroups are safe); `__shared__` variables are thread_local statics, i.e. one copy per worker = per workgroup.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
 thread_local hipcpu_idx threadIdx, blockIdx;
 dim3 blockDim, gridDim;
 alignas(16) thread_local unsigned char hipcpu_dyn[160 * 1024];
-alignas(64) thread_local unsigned char hipcpu_wave_scratch[16][64 * 64];
+alignas(64) thread_local unsigned char hipcpu_wave_scratch[16][2][64 * 64];
+thread_local unsigned char hipcpu_wave_flip[1024];
 
 #if !defined(__x86_64__)
 #error "tests/hipcpu/runtime.cpp: the fiber switch below is written for x86-64 (System V ABI)"
@@ -65,6 +67,7 @@ struct Worker {
     unsigned wave_alive[16] = {}, wave_arrived[16] = {}, wave_gen[16] = {};
     std::vector<void*> sp;               // parked stack pointer of every fiber
     std::vector<unsigned char> done;
+    std::vector<unsigned> wait_on, wait_gen;      // blocked fibers: 0 = runnable, 1 = workgroup barrier, 2 + w = wave w's barrier
     std::vector<hipcpu_idx> tid;
     void* main_sp = nullptr;
     char* stacks = nullptr;
@@ -100,7 +103,7 @@ void run_block(Worker& w, dim3 block, unsigned bx, unsigned by, unsigned bz, siz
     if (smem) memset(hipcpu_dyn, 0, smem);
     blockIdx = {bx, by, bz};
     for (unsigned t = 0; t < nt; ++t) {
-        w.done[t] = 0;
+        w.done[t] = 0; w.wait_on[t] = 0; hipcpu_wave_flip[t] = 0;
         void** top = reinterpret_cast<void**>(w.stacks + (size_t)(t + 1) * kStack);      // 16-byte aligned
         *--top = nullptr;                                    // fake return address of fiber_entry (keeps rsp = 8 mod 16 at entry)
         *--top = reinterpret_cast<void*>(&fiber_entry);      // hipcpu_switch's `ret` lands here
@@ -112,6 +115,10 @@ void run_block(Worker& w, dim3 block, unsigned bx, unsigned by, unsigned bz, siz
     while (w.alive) {
         for (unsigned t = 0; t < nt; ++t) {
             if (w.done[t]) continue;
+            if (const unsigned k = w.wait_on[t]) {                   // still parked at a barrier nobody released: do not even switch
+                if ((k == 1 ? w.gen : w.wave_gen[k - 2]) == w.wait_gen[t]) continue;
+                w.wait_on[t] = 0;
+            }
             w.cur = t; threadIdx = w.tid[t];
             hipcpu_switch(&w.main_sp, w.sp[t]);
         }
@@ -122,12 +129,14 @@ void run_block(Worker& w, dim3 block, unsigned bx, unsigned by, unsigned bz, siz
 }
 }  // namespace
 
+unsigned hipcpu_linear_tid() { return g_w->cur; }
+
 void hipcpu_syncthreads() {
     Worker& w = *g_w;
     const unsigned my = w.gen;
     ++w.arrived;
     release_checks(w, 99);
-    while (w.gen == my) yield_now();
+    if (w.gen == my) { w.wait_on[w.cur] = 1; w.wait_gen[w.cur] = my; yield_now(); }
 }
 
 void hipcpu_wave_sync() {
@@ -137,7 +146,7 @@ void hipcpu_wave_sync() {
     const unsigned my = w.wave_gen[wave];
     ++w.wave_arrived[wave];
     release_checks(w, wave);
-    while (w.wave_gen[wave] == my) yield_now();
+    if (w.wave_gen[wave] == my) { w.wait_on[w.cur] = 2 + wave; w.wait_gen[w.cur] = my; yield_now(); }
 }
 
 void hipcpu_run_grid(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
@@ -154,7 +163,7 @@ void hipcpu_run_grid(dim3 grid, dim3 block, size_t smem, const std::function<voi
     auto work = [&]() {
         Worker w;
         w.body = &body; w.nt = nt;
-        w.sp.resize(nt); w.done.resize(nt); w.tid.resize(nt);
+        w.sp.resize(nt); w.done.resize(nt); w.tid.resize(nt); w.wait_on.assign(nt, 0); w.wait_gen.assign(nt, 0);
         for (unsigned t = 0; t < nt; ++t) w.tid[t] = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
         w.stacks = pool_get();
         g_w = &w;
@@ -163,8 +172,14 @@ void hipcpu_run_grid(dim3 grid, dim3 block, size_t smem, const std::function<voi
         g_w = nullptr;
         pool_put(w.stacks);
     };
-    if (nworkers == 1) { std::thread t(work); t.join(); return; }     // always a fresh thread: fibers must not run on a tiny caller stack
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nworkers; ++i) th.emplace_back(work);
-    for (auto& t : th) t.join();
+    static const bool trace = getenv("HIPCPU_TRACE") != nullptr;     // per-launch wall time on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    if (nworkers == 1) { std::thread t(work); t.join(); }            // always a fresh thread: fibers must not run on a tiny caller stack
+    else {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nworkers; ++i) th.emplace_back(work);
+        for (auto& t : th) t.join();
+    }
+    if (trace)
+        fprintf(stderr, "hipcpu: grid %lu x block %u: %.1f ms\n", nblocks, nt, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }

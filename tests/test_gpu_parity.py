@@ -216,7 +216,7 @@ def test_units_ray_sampler_and_dense_marcher():
     from sherf_amd.ray_marcher import MipRayMarcher2
     from sherf_amd.ray_sampler import RaySampler
     g = np.load(os.path.join(G.GOLDEN, 'units.npz'))
-    t = lambda k: torch.from_numpy(g[k]).cuda()
+    t = lambda k: G.dev_tensor(torch.from_numpy(g[k]))
     o, d = RaySampler()(t('rs_c2w'), t('rs_intr'), 8)
     assert torch.allclose(o.cpu(), torch.from_numpy(g['rs_origins']), atol=1e-6)
     assert torch.allclose(d.cpu(), torch.from_numpy(g['rs_dirs']), atol=1e-6)
@@ -235,8 +235,8 @@ def test_dataset_rays_on_device():
     verts = d['vertices'][0]
     wb = np.stack([verts.min(0) - 0.05, verts.max(0) + 0.05])
     K, R, T = synth.orbit_camera(0.4, verts.mean(0).astype(np.float64), 3.0, 32, 32)
-    o, dd, nr, fr, m = dataset_rays(torch.from_numpy(K).cuda(), torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda(),
-                                    torch.from_numpy(wb).cuda(), 32, 32)
+    o, dd, nr, fr, m = dataset_rays(G.dev_tensor(torch.from_numpy(K)), G.dev_tensor(torch.from_numpy(R)), G.dev_tensor(torch.from_numpy(T)),
+                                    G.dev_tensor(torch.from_numpy(wb)), 32, 32)
     assert np.abs(o.cpu().numpy() - d['ray_o_all'][0, 0]).max() < 1e-5
     assert np.abs(dd.cpu().numpy() - d['ray_d_all'][0, 0]).max() < 1e-5
     mm = m.cpu().numpy()
@@ -265,7 +265,7 @@ def _generator(fx):
                             encoder_2d_feature=FakeEncoder(G.to_cuda(fx['obs_feat'])), smpl=G.smpl())
     gen.renderer, gen.decoder = rend, dec
     fixtures.load_seeded_state(gen.conv1d_projection, 'generator.conv1d_projection.')
-    return gen.cuda()
+    return G.dev_module(gen)
 
 
 def test_generator_glue_vertex_features_and_voxelisation():

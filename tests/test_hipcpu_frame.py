@@ -1,9 +1,9 @@
 """The WHOLE product path on the CPU: sherf_amd's Python host code + the native frame driver (csrc/frame.hip) + every kernel
 source of libsherf_hip.so / libsherf_hip_bwd.so, compiled unchanged for the host against the HIP-on-CPU shim (tests/hipcpu) and
-driven through the same ctypes binding as on the MI355X.  ImportanceRenderer.forward renders the `tiny` fixtures on CPU
-tensors and is compared with the oracle and with the unmodified reference's golden outputs; render_backward is compared with
-the reference's gradient fingerprints.  These are the `-m gpu` parity tests' counterparts for the sessions without a GPU: they
-check the kernels' arithmetic and indexing, not their timing or anything gfx950-specific (LDS-DMA, wave scheduling)."""
+driven through the same ctypes binding as on the MI355X.  The tests are the `-m gpu` parity tests themselves
+(tests/test_gpu_parity.py, switched to CPU tensors by tests.gpu_common.CPU_SHIM) plus the BASELINE config-5 training step through
+the autograd node.  They check the kernels' arithmetic and indexing between GPU sessions -- not their timing, and nothing
+gfx950-specific (LDS-DMA, wave scheduling, code generation)."""
 import ctypes
 import os
 
@@ -15,18 +15,15 @@ from oracle import sherf_oracle as O
 from synthdata import fixtures
 from sherf_amd import _lib
 from tests import gpu_common as G
+from tests import test_gpu_parity as P
 from tests.hipcpu import build_cpu
 
 FWD_SOURCES = ['smpl.hip', 'sample.hip', 'gather.hip', 'mlp.hip', 'composite.hip', 'svox.hip', 'rays.hip', 'fold.hip', 'frame.hip']
 
 
-class _FakeCuda(torch.Tensor):
-    is_cuda = True
-
-
 @pytest.fixture(scope='module')
 def cpu_product(tmp_path_factory):
-    """sherf_amd._lib pointed at host builds of both libraries; pointer helpers accept CPU tensors; streams are dummies."""
+    """sherf_amd._lib pointed at host builds of both libraries; tests.gpu_common switched to CPU tensors (G.CPU_SHIM)."""
     if not os.path.exists(build_cpu.CLANG):
         pytest.skip('needs the ROCm clang for the host build of the bf16 kernels')
     fwd = build_cpu.build('sherf_hipcpu_full', FWD_SOURCES, str(tmp_path_factory.mktemp('hipcpu_full')), compiler=build_cpu.CLANG)
@@ -41,86 +38,75 @@ def cpu_product(tmp_path_factory):
     mp.setattr(torch.cuda, 'current_stream', lambda dev=None: type('S', (), {'cuda_stream': 0})())
     mp.setattr(torch.cuda, 'synchronize', lambda dev=None: None)
     mp.setattr(backward_dense.HipOps, '_p', staticmethod(lambda m: ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)))
+    from sherf_amd.renderer import ImportanceRenderer
+    mp.setattr(ImportanceRenderer, 'SMPL_NEUTRAL', property(lambda self: self._smpl(torch.device('cpu'))))
+    mp.setattr(G, 'CPU_SHIM', True)
+    G.hip_modules.cache_clear()
     yield
-    _CACHE.clear()
+    G.hip_modules.cache_clear()
     mp.undo()
 
 
-def _modules(precision='bf16x3', training=True):
-    from sherf_amd.renderer import ImportanceRenderer
-    from sherf_amd.triplane import NeRFDecoder
-    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=G.smpl(), mlp_precision=precision)
-    dec = NeRFDecoder(32)
-    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
-    rend.train(training); dec.train(training)
-    rend._side = lambda dev, idx=0: type('X', (), {'cuda_stream': 8 + 8 * idx})()
-    return rend, dec
+# ---- the `-m gpu` parity tests themselves (tests/test_gpu_parity.py), run against the host build ----------------------------
+@pytest.fixture(scope='module', params=P.CFGS)
+def run(request, cpu_product):
+    cfg = request.param
+    return cfg, G.oracle_render(cfg), G.hip_render(cfg)
 
 
-_CACHE = {}
-
-
-def cpu_render(cfg, precision='bf16x3', training=True, options=None, fx=None):
-    """tests.gpu_common.hip_render with CPU tensors (the libraries behind sherf_amd._lib are the host builds)."""
-    key = (cfg, precision, training, tuple(sorted((options or {}).items())))
-    if fx is None and key in _CACHE:
-        return _CACHE[key]
-    r = _cpu_render(cfg, precision, training, options, fx)
-    if fx is None:
-        _CACHE[key] = r
-    return r
-
-
-def _cpu_render(cfg, precision, training, options, fx):
-    from sherf_amd.voxel import SparseConvTensor
-    fx = fx or G.fixture(cfg)
-    rend, dec = _modules(precision, training)
-    d = fixtures.to_torch(fx['input_data'])
-    spi = G.oracle_render(cfg)['sp_input'] if cfg else O.render_from_fixture(fx, G.seeded_state(), keep=False)['sp_input']
-    sp = SparseConvTensor(torch.from_numpy(fx['vertex_feat']), spi['coord'], spi['out_sh'], 1)
-    spd = dict(coord=spi['coord'], out_sh=spi['out_sh'], batch_size=1, bounds=spi['bounds'][None])
-    opts = dict(fx['options']); opts['mlp_precision'] = precision
-    opts.update(options or {})
-    with torch.no_grad():
-        rgb, depth, acc = rend(torch.from_numpy(fx['planes']), d['obs_img_all'][:, 0], torch.from_numpy(fx['obs_feat']), sp, None, spd, dec,
-                               d['ray_o_all'][:, 0].as_subclass(_FakeCuda), d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, opts)
-    return dict(rgb=rgb[0], depth=depth[0, :, 0], acc=acc[0, :, 0], last=rend.last, rend=rend, dec=dec)
-
-
-@pytest.mark.parametrize('cfg', ['tiny', 'tiny_nv'])
-def test_frame_matches_oracle_and_reference_golden(cpu_product, cfg):
-    o = G.oracle_render(cfg)
-    h = cpu_render(cfg)
-    ws = h['last']['ws']
+def test_stage_by_stage_parity(run):
+    """shell mask / vertex ids / compact order bit exact, warp, voxel levels, gathered tokens -- and the frame against the oracle
+    and the unmodified reference's golden image."""
+    P.test_mask_and_nearest_vertex_bit_exact(run)
+    P.test_warp_matches_literal_lbs_chain(run)
+    P.test_sparse_voxel_encoder_levels(run)
+    P.test_gathered_tokens(run)
+    cfg, o, h = run
     nv = o['valid'].numel()
-    assert int(ws['counters'][0]) == nv                                            # shell mask: same sample set
-    out = ws['sample_out'][:nv]
+    out = h['last']['ws']['sample_out'][:nv]
     sig_ref = torch.relu(o['sample_sigma'])
     assert float((torch.relu(out[:, 3]) - sig_ref).abs().max() / sig_ref.max()) < 1e-3
     assert float((out[:, :3] - o['sample_rgb']).abs().max()) < 1e-3
+    g = np.load(os.path.join(G.GOLDEN, f'renderer_{cfg}.npz'))                     # outputs of the UNMODIFIED reference
     assert G.rel(h['rgb'], o['rgb']) < 1e-3 and G.rel(h['acc'], o['acc']) < 1e-3
     assert torch.allclose(h['depth'], o['depth'], rtol=1e-3, atol=1e-4)
-    g = np.load(os.path.join(G.GOLDEN, f'renderer_{cfg}.npz'))                     # outputs of the UNMODIFIED reference
-    ref_rgb = torch.from_numpy(g['rgb'])
-    assert G.rel(h['rgb'], ref_rgb) < 1e-3
-    assert G.rel(h['acc'], torch.from_numpy(g['acc'][:, 0])) < 1e-3
-    assert O.psnr(h['rgb'], ref_rgb) > 60.0
+    assert G.rel(h['rgb'], torch.from_numpy(g['rgb'])) < 1e-3 and G.rel(h['acc'], torch.from_numpy(g['acc'][:, 0])) < 1e-3
+    assert O.psnr(h['rgb'], torch.from_numpy(g['rgb'])) > 60.0
 
 
-@pytest.mark.parametrize('shape', ['4x2', '8x1split', '8x1split2', '8x1persist'])
-def test_mlp_shapes_agree_inside_the_frame(cpu_product, shape):
-    a = cpu_render('tiny')
-    b = cpu_render('tiny', options=dict(mlp_shape=shape))
-    assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4
+def test_mlp_shapes_agree_inside_the_frame(cpu_product):
+    a = G.hip_render('tiny_nv')
+    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist'):
+        b = G.hip_render('tiny_nv', options=dict(mlp_shape=shape))
+        assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4, shape
 
 
-def test_eval_mode_and_bf16_precision(cpu_product):
-    o = G.oracle_render('tiny', training=False)
-    h = cpu_render('tiny', training=False)
-    assert G.rel(h['rgb'], o['rgb']) < 1e-3 and G.rel(h['acc'], o['acc']) < 1e-3
-    o = G.oracle_render('tiny')
-    h = cpu_render('tiny', precision='bf16')
-    assert G.rel(h['rgb'], o['rgb']) < 1e-1                  # sanity only: plain bf16 is outside the parity bar by design
+def test_eval_mode_batchnorm_and_edge_cases(cpu_product):
+    P.test_eval_mode_batchnorm_uses_running_stats()
+    P.test_no_valid_samples_returns_background()
+    P.test_white_back_identity()
+    P.test_ragged_shapes(17, 23, 33)
+    P.test_units_ray_sampler_and_dense_marcher()
+    P.test_dataset_rays_on_device()
+
+
+def test_generator_glue(cpu_product):
+    P.test_generator_glue_vertex_features_and_voxelisation()
+    P.test_generator_synthesis_end_to_end()
+
+
+def test_size_independent_properties_and_rotation(cpu_product):
+    P.test_deterministic_and_ray_independent()
+    P.test_ragged_shapes(9, 31, 128)
+    P.test_ragged_shapes(5, 7, 2)
+    P.test_global_rotation_flip_rate()
+
+
+@pytest.mark.skipif(not os.environ.get('SHERF_SLOW'), reason='BASELINE config 1 (128x128x32) and the per-sample precision sweep on the CPU (~1 min): SHERF_SLOW=1')
+def test_config1_and_per_sample_precision(cpu_product):
+    P.test_per_sample_sigma_rgb('bf16x3', 1e-3, 1e-3)
+    P.test_per_sample_sigma_rgb('bf16', 5e-2, 5e-2)
+    P.test_end_to_end_vs_oracle_and_reference_golden('cfg1')
 
 
 def test_training_step_through_autograd_matches_reference_gradients(cpu_product, monkeypatch):
@@ -133,7 +119,7 @@ def test_training_step_through_autograd_matches_reference_gradients(cpu_product,
     cfg = 'tiny_nv'
     fx = G.fixture(cfg)
     ref = np.load(os.path.join(G.GOLDEN, f'grad_{cfg}.npz'))
-    rend, dec = _modules()
+    rend, dec = G.hip_modules.__wrapped__()                # fresh modules: this test updates running statistics and .grad
     rend.enable_autograd = True
     d = fixtures.to_torch(fx['input_data'])
     spi = G.oracle_render(cfg)['sp_input']
@@ -143,7 +129,7 @@ def test_training_step_through_autograd_matches_reference_gradients(cpu_product,
     sp = SparseConvTensor(vfeat, spi['coord'], spi['out_sh'], 1)
     spd = dict(coord=spi['coord'], out_sh=spi['out_sh'], batch_size=1, bounds=spi['bounds'][None])
     mean0 = rend.encoder_3d.conv0[1].running_mean.clone()
-    rgb, depth, acc = rend(planes, d['obs_img_all'][:, 0], obs_feat, sp, None, spd, dec, d['ray_o_all'][:, 0].as_subclass(_FakeCuda),
+    rgb, depth, acc = rend(planes, d['obs_img_all'][:, 0], obs_feat, sp, None, spd, dec, G.dev_tensor(d['ray_o_all'][:, 0]),
                            d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, dict(fx['options']))
     assert rgb.requires_grad and acc.requires_grad and not depth.requires_grad
     assert not torch.equal(rend.encoder_3d.conv0[1].running_mean, mean0)           # a training forward updates the running statistics
