@@ -243,6 +243,12 @@ __device__ __forceinline__ float erf_(float x) {
 #ifndef SHERF_MLP_INTERLEAVE
 #define SHERF_MLP_INTERLEAVE 0
 #endif
+// SHERF_MLP_WAVE_PRIO (off; to be measured): the two waves a SIMD hosts leave every workgroup barrier together, interleave their
+// MFMA chains and then run their VALU epilogues at the same time with the MFMA pipe idle.  Giving the first half of the waves
+// (one per SIMD) issue priority lets that wave finish its chain first and do its epilogue under the other wave's MFMAs.
+#ifndef SHERF_MLP_WAVE_PRIO
+#define SHERF_MLP_WAVE_PRIO 0
+#endif
 // acc[col] += W_step[kb0 .. kb0+NK) . B[col]: one segment of a chunk's K range, NCOL column sets sharing the A fragments
 template <int PREC, int NK, int NCOL>
 __device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
@@ -340,6 +346,9 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
     cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if SHERF_MLP_WAVE_PRIO
+    if (cx.wave < NW / 2) __builtin_amdgcn_s_setprio(SHERF_MLP_WAVE_PRIO);
+#endif
     int j = cx.lane & 31, h = cx.h;                                  // (not const: PHASE -1 launders them per group)
     int64_t tile[NTL];
     bool live[NTL];
