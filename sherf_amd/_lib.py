@@ -181,3 +181,30 @@ def call_bwd(name, *args):
     rc = getattr(l, name)(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed ({rc}): {l.sherf_bwd_last_error().decode()}')
+
+
+# ---- the producers' element-wise / FIR operators: include/sherf_hip_ops.h -> libsherf_hip_ops.so -----------------------------
+HEADER_OPS = os.path.join(_HERE, '..', 'include', 'sherf_hip_ops.h')
+LIB_OPS_PATH = os.path.join(_HERE, 'libsherf_hip_ops.so')
+_lib_ops = None
+
+
+def lib_ops():
+    global _lib_ops
+    if _lib_ops is None:
+        if not os.path.exists(LIB_OPS_PATH):
+            raise RuntimeError(f'{LIB_OPS_PATH} not found: build it with `python -m sherf_amd.build`. There is no CPU fallback.')
+        l = ctypes.CDLL(LIB_OPS_PATH)
+        for name, (ret, args) in parse_header(HEADER_OPS).items():
+            fn = getattr(l, name)
+            fn.restype = ret
+            fn.argtypes = [a[0] for a in args]
+        _lib_ops = l
+    return _lib_ops
+
+
+def call_ops(name, *args):
+    l = lib_ops()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {l.sherf_ops_last_error().decode()}')

@@ -79,6 +79,33 @@ def build_bwd(force=False, verbose=True):
     return LIB_BWD
 
 
+LIB_OPS = os.path.join(HERE, 'libsherf_hip_ops.so')
+SOURCES_OPS = ['ops_lib.hip', 'ops_bias_act.hip', 'ops_upfirdn2d.hip']
+
+
+def build_ops(force=False, verbose=True):
+    """libsherf_hip_ops.so: bias_act / upfirdn2d for the tri-plane producers (experimental), include/sherf_hip_ops.h."""
+    deps = [os.path.join(CSRC, s) for s in SOURCES_OPS] + [os.path.join(CSRC, 'ops_common.h'), os.path.join(HERE, '..', 'include', 'sherf_hip_ops.h')]
+    if not force and os.path.exists(LIB_OPS) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_OPS) for d in deps):
+        return LIB_OPS
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    objs = []
+    for s in SOURCES_OPS:
+        o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
+        objs.append(o)
+        r = subprocess.run([hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {s}:\n{r.stdout.decode()}')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB_OPS], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stdout.decode())
+    if verbose:
+        print(f'built {LIB_OPS} ({os.path.getsize(LIB_OPS) / 1e6:.2f} MB)')
+    return LIB_OPS
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
     build_bwd(force='--force' in sys.argv)
+    build_ops(force='--force' in sys.argv)

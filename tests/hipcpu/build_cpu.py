@@ -40,6 +40,7 @@ def build(name, sources, out_dir, extra_src=None, compiler='g++', defines=()):
         if s == 'mlp.hip':
             src = _cpu_mlp(src)
         src = src.replace('#include "common.h"', f'#include "{os.path.join(CSRC, "common.h")}"')
+        src = src.replace('#include "ops_common.h"', f'#include "{os.path.join(CSRC, "ops_common.h")}"')
         src = src.replace('#include "../../include/', f'#include "{os.path.join(ROOT, "include")}/')
         p = os.path.join(out_dir, s.replace('.hip', '.cpp'))
         open(p, 'w').write(src)

@@ -114,6 +114,18 @@ def test_backward_library_exports_every_declared_symbol():
     assert l.sherf_bwd_conv_dgrad(None, None, 1, 1, 1, None, 1, 1, 1, None, 32, None, 32, 0, 1, None, None) == -1
 
 
+def test_ops_library_exports_every_declared_symbol():
+    """libsherf_hip_ops.so (include/sherf_hip_ops.h: bias_act, upfirdn2d) loads and validates its arguments before touching a device."""
+    protos = _lib.parse_header(_lib.HEADER_OPS)
+    assert set(protos) == {'sherf_ops_last_error', 'sherf_bias_act', 'sherf_upfirdn2d'}
+    l = _lib.lib_ops()
+    for name in protos:
+        assert hasattr(l, name), name
+    assert l.sherf_bias_act(None, None, None, None, None, None, 4, 1, 1, 0, 3, ctypes.c_float(0.2), ctypes.c_float(1.0), ctypes.c_float(-1.0), 0, None) == -1
+    assert b'bad argument' in l.sherf_ops_last_error()
+    assert l.sherf_upfirdn2d(None, None, None, 1, 1, 4, 4, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, ctypes.c_float(1.0), 0, None) == -1
+
+
 def test_sparse_encoder_plan_host_logic(monkeypatch):
     """SparseConvNet.plan (the descriptor of the native encoder driver) built on CPU tensors: layer table, level capacities,
     accumulator placement -- the host logic of sherf_svox_encode, no device involved."""

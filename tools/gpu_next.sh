@@ -14,6 +14,7 @@ for T in $(python -m pytest tests/test_gpu_backward.py -m gpu_experimental --col
   if [ $rc -ne 0 ]; then grep -E "Error|error|assert|rel\(|failed" $OUT/one.log | head -12 >> $OUT/pytest_experimental.log; fi
 done
 V=""
+timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu_experimental -q -s --no-header -p no:cacheprovider 2>&1 | tail -6 | tee -a $OUT/pytest_experimental.log
 for t in il8 erf erf_il8 gbl prio prio_il8; do [ -f sherf_amd/libsherf_hip_$t.so ] && V="$V $t"; done
 bash tools/gpu_variants.sh $V 2>&1 | tee $OUT/variants.log
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default   ', d['ms_per_step'], d['roofline']['kernel_ms'])"
