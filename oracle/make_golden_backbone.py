@@ -1,0 +1,66 @@
+"""TEST INFRASTRUCTURE. Golden outputs of the UNMODIFIED reference's StyleGAN2 generator (training/networks_stylegan2.py:538,
+`StyleGAN2Backbone` of triplane.py:58) for tests/test_backbone.py, on CPU in the build container (the reference's custom ops fall
+back to their `_ref` implementations there):
+
+  * a SMALL generator (64 x 64 x 96 channels, channel_base 1024, channel_max 48, 2 mapping layers) with every parameter / buffer filled
+    by synthdata.fixtures.seeded_param under its own name -> ws and the synthesised planes in training mode (un-fused modulation) and
+    eval mode (fused), noise_mode const / none, truncation;
+  * the name -> shape table of the FULL generator SHERF instantiates (256 x 256 x 96, cbase 32768, cmax 512, map_depth 2): the
+    checkpoint contract, checked without running it.
+
+    python -m oracle.make_golden_backbone"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/sherf'
+SMALL = dict(z_dim=64, c_dim=0, w_dim=48, img_resolution=64, img_channels=96, mapping_kwargs=dict(num_layers=2), channel_base=1024, channel_max=48,
+             num_fp16_res=0, conv_clamp=None, fused_modconv_default='inference_only')
+FULL = dict(z_dim=512, c_dim=0, w_dim=512, img_resolution=256, img_channels=96, mapping_kwargs=dict(num_layers=2), channel_base=32768, channel_max=512,
+            num_fp16_res=0, conv_clamp=None, fused_modconv_default='inference_only')
+
+
+def seed_module(m, prefix):
+    from synthdata import fixtures
+    with torch.no_grad():
+        for name, t in list(m.named_parameters()) + list(m.named_buffers()):
+            if name.endswith('resample_filter'):
+                continue
+            t.copy_(torch.from_numpy(np.asarray(fixtures.seeded_param(prefix + name, t.shape), np.float32).reshape(tuple(t.shape))).to(t.dtype))
+
+
+def main():
+    sys.path.insert(0, REF)
+    from training import networks_stylegan2 as N                     # the reference's file, untouched
+    out = {}
+    g = N.Generator(**SMALL)
+    seed_module(g, 'backbone.')
+    z = torch.from_numpy(np.random.RandomState(3).standard_normal((2, SMALL['z_dim'])).astype(np.float32))
+    with torch.no_grad():
+        g.train()
+        ws = g.mapping(z, None)
+        out['ws'] = ws.numpy()
+        out['ws_trunc'] = g.mapping(z, None, truncation_psi=0.7, truncation_cutoff=5).numpy()
+        out['img_train_const'] = g.synthesis(ws, noise_mode='const').numpy()
+        out['img_train_none'] = g.synthesis(ws, noise_mode='none').numpy()
+        g.eval()
+        out['img_eval_const'] = g.synthesis(ws, noise_mode='const').numpy()
+        out['img_eval_fwd'] = g(z, None, noise_mode='const').numpy()
+    for k in [k for k in out if k.startswith('img_')]:                 # keep the fixture small: a strided subset + whole-tensor moments
+        v = out.pop(k)
+        out[k + '.sub'] = v[:, ::7, ::3, ::3].copy()
+        out[k + '.moments'] = np.array([v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64), np.square(v, dtype=np.float64).sum()])
+    np.savez_compressed(os.path.join(HERE, '..', 'tests', 'golden', 'backbone_small.npz'), **out)
+    full = N.Generator(**FULL)
+    table = {n: list(t.shape) for n, t in list(full.named_parameters()) + list(full.named_buffers())}
+    small = {n: list(t.shape) for n, t in list(g.named_parameters()) + list(g.named_buffers())}
+    json.dump(dict(full=table, small=small, num_ws_full=full.num_ws, num_ws_small=g.num_ws), open(os.path.join(HERE, '..', 'tests', 'golden', 'backbone_shapes.json'), 'w'), indent=0)
+    print('wrote backbone_small.npz', {k: v.shape for k, v in out.items()}, len(table), 'full entries')
+
+
+if __name__ == '__main__':
+    main()

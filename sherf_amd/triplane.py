@@ -70,13 +70,18 @@ class TriPlaneGenerator(nn.Module):
         self.conv1d_projection = nn.Conv1d(96, 32, 1)
         self.backbone = backbone
         self.superresolution = superresolution
+        # the per-frame producers (experimental): ResNet-18 encoders and the StyleGAN2 tri-plane generator, built
+        # as in triplane.py:55-58 unless the caller injects its own modules
+        if self.encoder_2d is None:
+            from .resnet import ResNet18Classifier
+            self.encoder_2d = ResNet18Classifier()
+        if self.encoder_2d_feature is None:
+            from .resnet import ResNet18Classifier
+            self.encoder_2d_feature = ResNet18Classifier()
         if self.backbone is None:
-            try:        # the reference's own StyleGAN2 generator, when /root/reference/sherf is on sys.path
-                from training.networks_stylegan2 import Generator as StyleGAN2Backbone
-                self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3,
-                                                  mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
-            except ImportError:
-                pass
+            from .stylegan2 import Generator as StyleGAN2Backbone
+            self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3, mapping_kwargs=mapping_kwargs,
+                                              **synthesis_kwargs)
         if not use_NeRF_decoder:
             raise NotImplementedError('OSGDecoder path is unused by SHERF (--use_nerf_decoder True in every script)')
         self.decoder = NeRFDecoder(32)

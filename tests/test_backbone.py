@@ -1,0 +1,149 @@
+"""sherf_amd.stylegan2 (the tri-plane producer) against the UNMODIFIED reference's StyleGAN2 generator:
+checkpoint contract (every parameter / buffer name and shape of the generator SHERF instantiates) and numerics on a small seeded
+generator (tests/golden/backbone_small.npz, oracle/make_golden_backbone.py) -- through the operators' explicit `impl='ref'` path and
+through the HIP kernels' source executed on the CPU (tests/hipcpu)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.make_golden_backbone import FULL, SMALL
+from synthdata import fixtures
+from sherf_amd import _lib, stylegan2 as S
+from tests import gpu_common as G
+from tests.hipcpu import build_cpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+SHAPES = json.load(open(os.path.join(GOLDEN, 'backbone_shapes.json')))
+GOLD = np.load(os.path.join(GOLDEN, 'backbone_small.npz'))
+
+
+def _table(m):
+    return {n: list(t.shape) for n, t in list(m.named_parameters()) + list(m.named_buffers())}
+
+
+def _seed(m, prefix='backbone.'):
+    with torch.no_grad():
+        for name, t in list(m.named_parameters()) + list(m.named_buffers()):
+            if not name.endswith('resample_filter'):
+                t.copy_(torch.from_numpy(np.asarray(fixtures.seeded_param(prefix + name, t.shape), np.float32).reshape(tuple(t.shape))))
+    return m
+
+
+def test_checkpoint_contract_of_the_generator_sherf_instantiates():
+    """name -> shape of the 256 x 256 x 96 generator (cbase 32768, cmax 512, map_depth 2) equals the reference's, as
+    copy_params_and_buffers(require_all=True) demands (training_loop.py:207-208)."""
+    g = S.Generator(**FULL)
+    assert _table(g) == SHAPES['full'] and g.num_ws == SHAPES['num_ws_full']
+    assert _table(S.Generator(**SMALL)) == SHAPES['small']
+
+
+def _check(g, z, dev=lambda t: t, tol=2e-4):
+    def close(a, key):
+        a = G.plain(a).numpy()
+        ref = GOLD[key + '.sub']
+        assert np.abs(a[:, ::7, ::3, ::3] - ref).max() <= tol * np.abs(ref).max(), (key, np.abs(a[:, ::7, ::3, ::3] - ref).max())
+        m = GOLD[key + '.moments']
+        got = np.array([a.sum(dtype=np.float64), np.abs(a).sum(dtype=np.float64), np.square(a, dtype=np.float64).sum()])
+        assert np.all(np.abs(got[1:] - m[1:]) <= 1e-3 * np.abs(m[1:])), (key, got, m)
+    with torch.no_grad():
+        g.train()
+        ws = g.mapping(dev(z), None)
+        assert np.abs(G.plain(ws).numpy() - GOLD['ws']).max() < 1e-5
+        assert np.abs(G.plain(g.mapping(dev(z), None, truncation_psi=0.7, truncation_cutoff=5)).numpy() - GOLD['ws_trunc']).max() < 1e-5
+        close(g.synthesis(ws, noise_mode='const'), 'img_train_const')            # training: un-fused modulation
+        close(g.synthesis(ws, noise_mode='none'), 'img_train_none')
+        g.eval()
+        close(g.synthesis(ws, noise_mode='const'), 'img_eval_const')             # inference: fused (grouped convolution)
+        close(g(dev(z), None, noise_mode='const'), 'img_eval_fwd')
+
+
+def test_small_generator_matches_reference_ref_ops(monkeypatch):
+    monkeypatch.setattr(S, 'OPS_IMPL', 'ref')                                    # explicit choice of the operators' stock-PyTorch path
+    g = _seed(S.Generator(**SMALL))
+    z = torch.from_numpy(np.random.RandomState(3).standard_normal((2, SMALL['z_dim'])).astype(np.float32))
+    _check(g, z)
+
+
+def test_small_generator_matches_reference_through_the_hip_kernels_on_cpu(tmp_path_factory, monkeypatch):
+    if not os.path.exists(build_cpu.CLANG):
+        pytest.skip('needs the ROCm clang for the host build')
+    path = build_cpu.build('sherf_hipcpu_ops', ['ops_lib.hip', 'ops_bias_act.hip', 'ops_upfirdn2d.hip'], str(tmp_path_factory.mktemp('hipcpu_ops_bb')),
+                           compiler=build_cpu.CLANG)
+    monkeypatch.setattr(_lib, 'LIB_OPS_PATH', path); monkeypatch.setattr(_lib, '_lib_ops', None)
+    monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    monkeypatch.setattr(_lib, 'stream', lambda: ctypes.c_void_p(0))
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))       # every host tensor is a "device" tensor of the shim
+    g = _seed(S.Generator(**SMALL))
+    z = torch.from_numpy(np.random.RandomState(3).standard_normal((2, SMALL['z_dim'])).astype(np.float32))
+    _check(g, z)
+
+
+def test_gradients_flow_through_the_operators(monkeypatch):
+    """training-mode backward through bias_act / upfirdn2d autograd nodes: finite gradients for every parameter that is used."""
+    monkeypatch.setattr(S, 'OPS_IMPL', 'ref')
+    g = _seed(S.Generator(**SMALL)).train()
+    z = torch.from_numpy(np.random.RandomState(4).standard_normal((1, SMALL['z_dim'])).astype(np.float32))
+    g(z, None, noise_mode='const').square().mean().backward()
+    missing = [n for n, p in g.named_parameters() if p.grad is None]
+    assert missing == [], missing
+    assert all(torch.isfinite(p.grad).all() for p in g.parameters())
+
+
+def _torchvision_resnet18_table():
+    """name -> shape of torchvision.models.resnet18().state_dict() (the layout a SHERF checkpoint stores under
+    `encoder_2d.backbone.` / `encoder_2d_feature.backbone.`), written out from the architecture's definition."""
+    t = {'conv1.weight': [64, 3, 7, 7]}
+
+    def bn(prefix, c):
+        t.update({f'{prefix}.weight': [c], f'{prefix}.bias': [c], f'{prefix}.running_mean': [c], f'{prefix}.running_var': [c],
+                  f'{prefix}.num_batches_tracked': []})
+    bn('bn1', 64)
+    inp = 64
+    for li, planes in enumerate((64, 128, 256, 512), 1):
+        for bi in range(2):
+            p = f'layer{li}.{bi}'
+            t[f'{p}.conv1.weight'] = [planes, inp if bi == 0 else planes, 3, 3]
+            bn(f'{p}.bn1', planes)
+            t[f'{p}.conv2.weight'] = [planes, planes, 3, 3]
+            bn(f'{p}.bn2', planes)
+            if bi == 0 and li > 1:
+                t[f'{p}.downsample.0.weight'] = [planes, inp, 1, 1]
+                bn(f'{p}.downsample.1', planes)
+        inp = planes
+    t.update({'fc.weight': [1000, 512], 'fc.bias': [1000]})
+    return t
+
+
+def test_resnet18_encoders_contract_and_paths():
+    from sherf_amd.resnet import ResNet18Classifier
+    enc = ResNet18Classifier().eval()
+    got = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    want = {'backbone.' + k: v for k, v in _torchvision_resnet18_table().items()}
+    assert got == want and len(got) == 122
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((2, 3, 64, 48)).astype(np.float32))
+    with torch.no_grad():
+        code, feat = enc(x), enc(x, extract_feature=True)
+        b = enc.backbone
+        manual = b.layer1(torch.relu(b.bn1(b.conv1(x))))                          # triplane.py:327-334: max-pool skipped
+    assert code.shape == (2, 512) and feat.shape == (2, 64, 32, 24)
+    assert torch.equal(feat, manual)
+    assert sum(p.numel() for p in enc.parameters()) == 11689512                    # ResNet-18
+
+
+def test_generator_builds_its_producers_by_default():
+    """TriPlaneGenerator() without injected modules owns the reference's sub-module names (checkpoint contract of
+    triplane.py:53-65, minus the super-resolution module no SHERF script uses)."""
+    from sherf_amd.triplane import TriPlaneGenerator
+    g = TriPlaneGenerator(512, 0, 512, True, True, True, True, True, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                          rendering_kwargs={}, smpl=G.smpl(), channel_base=1024, channel_max=32, num_fp16_res=0, conv_clamp=None,
+                          fused_modconv_default='inference_only')
+    kids = dict(g.named_children())
+    assert {'renderer', 'ray_sampler', 'encoder_2d', 'encoder_2d_feature', 'conv1d_projection', 'backbone', 'decoder'} <= set(kids)
+    assert type(kids['backbone']).__name__ == 'Generator' and kids['backbone'].img_resolution == 256 and kids['backbone'].img_channels == 96
+    names = {n for n, _ in g.named_parameters()}
+    assert 'backbone.synthesis.b256.torgb.weight' in names and 'encoder_2d_feature.backbone.layer1.1.conv2.weight' in names
+    assert 'backbone.mapping.fc1.weight' in names and 'decoder.pts_linears.7.weight' in names

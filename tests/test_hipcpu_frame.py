@@ -28,10 +28,13 @@ def cpu_product(tmp_path_factory):
         pytest.skip('needs the ROCm clang for the host build of the bf16 kernels')
     fwd = build_cpu.build('sherf_hipcpu_full', FWD_SOURCES, str(tmp_path_factory.mktemp('hipcpu_full')), compiler=build_cpu.CLANG)
     bwd = build_cpu.build('sherf_hipcpu_bwd', ['bwd_dense.hip', 'bwd_encoder.hip'], str(tmp_path_factory.mktemp('hipcpu_bwd')))
+    ops = build_cpu.build('sherf_hipcpu_ops', ['ops_lib.hip', 'ops_bias_act.hip', 'ops_upfirdn2d.hip'], str(tmp_path_factory.mktemp('hipcpu_ops')),
+                          compiler=build_cpu.CLANG)
     from sherf_amd import backward_dense
     mp = pytest.MonkeyPatch()
     mp.setattr(_lib, 'LIB_PATH', fwd); mp.setattr(_lib, '_lib', None)
     mp.setattr(_lib, 'LIB_BWD_PATH', bwd); mp.setattr(_lib, '_lib_bwd', None)
+    mp.setattr(_lib, 'LIB_OPS_PATH', ops); mp.setattr(_lib, '_lib_ops', None)
     mp.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
     mp.setattr(_lib, 'addr', lambda t, dtype=None: None if t is None else t.data_ptr())
     mp.setattr(_lib, 'stream', lambda: ctypes.c_void_p(0))
@@ -93,6 +96,47 @@ def test_eval_mode_batchnorm_and_edge_cases(cpu_product):
 def test_generator_glue(cpu_product):
     P.test_generator_glue_vertex_features_and_voxelisation()
     P.test_generator_synthesis_end_to_end()
+
+
+def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
+    """TriPlaneGenerator.forward(input_data, z, c) as the reference calls it (test_loop.py:189-190): ResNet-18 code -> mapping ->
+    StyleGAN2 tri-planes (bias_act / upfirdn2d kernels), ResNet-18 feature map, glue, renderer -- all three libraries built for the
+    host -- against the oracle renderer fed with the planes / feature map the same producers output."""
+    from sherf_amd.triplane import TriPlaneGenerator
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))       # module parameters are "device" tensors too
+    fx = dict(G.fixture('tiny'))
+    rend, dec = G.hip_modules.__wrapped__()
+    gen = TriPlaneGenerator(512, 0, 48, True, True, True, True, True, img_resolution=32, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                            rendering_kwargs=dict(fx['options']), smpl=G.smpl(), channel_base=512, channel_max=16, num_fp16_res=0,
+                            conv_clamp=None, fused_modconv_default='inference_only')
+    gen.renderer, gen.decoder = rend, dec
+    fixtures.load_seeded_state(gen.conv1d_projection, 'generator.conv1d_projection.')
+    for name, mod in (('backbone', gen.backbone), ('encoder_2d', gen.encoder_2d), ('encoder_2d_feature', gen.encoder_2d_feature)):
+        with torch.no_grad():
+            for n, t in list(mod.named_parameters()) + list(mod.named_buffers()):
+                v = None if n.endswith('resample_filter') else fixtures.seeded_param(f'{name}.{n}', t.shape)
+                if v is not None:
+                    t.copy_(torch.from_numpy(np.asarray(v, np.float32).reshape(tuple(t.shape))).to(t.dtype))
+    gen.eval(); rend.train(); dec.train()
+    d = G.to_cuda(fx['input_data'])
+    with torch.no_grad():
+        out = gen(d, None, torch.zeros(1, 25), use_sr_module=False, test_flag=True, noise_mode='const')
+        ws = gen.mapping(None, torch.zeros(1, 25), input_img=d['obs_img_all'][:, 0])
+        planes = gen.backbone.synthesis(ws, noise_mode='const')
+        feat = gen.encoder_2d_feature(d['obs_img_all'][:, 0], extract_feature=True)
+    assert out['image_raw'].shape == (1, 3, 32, 32) and planes.shape == (1, 96, 256, 256) and feat.shape == (1, 64, 16, 16)
+    st = O.smpl_tensors(fx['smpl'])
+    state = {k: torch.from_numpy(fixtures.seeded_param(k, s)) for k, s in (('generator.conv1d_projection.weight', (32, 96, 1)),
+                                                                          ('generator.conv1d_projection.bias', (32,)))}
+    dd = fixtures.to_torch(fx['input_data'])
+    fo, _ = O.vertex_features(state, st, dd['obs_vertices'][0], dd['obs_R_all'], dd['obs_T_all'], dd['obs_K_all'], G.plain(feat)[0], dd['obs_img_all'][0, 0])
+    fx['vertex_feat'] = fo.numpy()
+    fx['planes'] = G.plain(planes).view(1, 3, 32, 256, 256).numpy()
+    fx['obs_feat'] = G.plain(feat).numpy()
+    o = O.render_from_fixture(fx, G.seeded_state(), training=True, keep=False)
+    img = G.plain(out['image_raw'])[0].permute(1, 2, 0).reshape(-1, 3)
+    assert O.psnr(img, o['rgb']) > 55.0
+    assert G.rel(G.plain(out['weights_image']).reshape(-1), o['acc']) < 2e-3
 
 
 def test_size_independent_properties_and_rotation(cpu_product):
