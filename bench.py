@@ -35,6 +35,72 @@ def make_inputs(cfg_name, theta, dev):
     return fx, d, to
 
 
+def _device(lrank):
+    torch.cuda.set_device(lrank)
+    return torch.device('cuda', lrank)
+
+
+def make_workload(a, theta, dev):
+    """The bench frame: seeded synthetic subject / tables / weights on `dev`, the renderer and decoder in the requested modes."""
+    from sherf_amd.renderer import ImportanceRenderer
+    from sherf_amd.triplane import NeRFDecoder, TriPlaneGenerator
+    from sherf_amd.voxel import SparseConvTensor
+    from synthdata import fixtures, synth
+    smpl = synth.make_synth_smpl(0)
+    fx, d, to = make_inputs(a.config, theta, dev)
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)
+    dec = NeRFDecoder(32)
+    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
+    rend.to(dev).train(a.bn_mode == 'train'); dec.to(dev).train(a.bn_mode == 'train')
+    # voxelisation glue (triplane.py:129-137) through the product path
+    gen = TriPlaneGenerator.__new__(TriPlaneGenerator)
+    torch.nn.Module.__init__(gen); gen.renderer = rend
+    can = gen.canonical_obs_vertices(d)
+    sp_input, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
+    sp = SparseConvTensor(to(fx['vertex_feat']), sp_input['coord'], sp_input['out_sh'], 1)
+    opts = dict(fx['options']); opts['mlp_precision'] = a.precision
+    return dict(rend=rend, dec=dec, d=d, sp=sp, sp_input=sp_input, planes=to(fx['planes']), obs_feat=to(fx['obs_feat']),
+                obs_img=d['obs_img_all'][:, 0], opts=opts)
+
+
+def tune_child(a, lrank):
+    """`bench.py --tune-child`: renders the bench frame once on this rank's GPU, times every launch shape of the MLP kernel on it
+    (sherf_amd.tune: each verified bit for bit against the default shape on the device) and prints the report as one line."""
+    dev = _device(lrank)
+    from sherf_amd import tune
+    w = make_workload(a, 0.4, dev)
+    d = w['d']
+    with torch.no_grad():
+        for _ in range(2):
+            w['rend'](w['planes'], w['obs_img'], w['obs_feat'], w['sp'], None, w['sp_input'], w['dec'], d['ray_o_all'][:, 0],
+                      d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, w['opts'])
+    torch.cuda.synchronize()
+    rep = tune.tune_mlp(w['rend'], w['dec'])
+    rep['gather'] = tune.tune_gather(w['rend'], w['dec'])
+    print('TUNE_JSON ' + json.dumps(rep), flush=True)
+
+
+def pick_mlp_shape(a, lrank, timeout=300):
+    """-> (shape name, report | {'error': ...}).  The MLP kernel has several launch shapes with identical results (sherf_amd/tune.py);
+    which is fastest is a property of the device, so it is measured -- in a CHILD process, so that a shape that misbehaves on this
+    hardware (every one of them is verified against the default on the device before it is eligible) cannot take the benchmark
+    down; any failure of the child means the default shape.  Every rank tunes its own GPU; the choice never changes the output."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE',
+                                                            'GROUP_RANK', 'ROLE_RANK', 'TORCHELASTIC_RUN_ID')}
+    env['LOCAL_RANK'] = str(lrank)
+    cmd = [sys.executable, os.path.abspath(__file__), '--tune-child', '--config', a.config, '--precision', a.precision, '--bn-mode', a.bn_mode]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith('TUNE_JSON ')]
+        if r.returncode != 0 or not line:
+            return '8x1', dict(error=f'tune child rc={r.returncode}: {r.stderr.strip()[-300:]}')
+        rep = json.loads(line[-1][len('TUNE_JSON '):])
+        return rep['best'], rep
+    except Exception as ex:                                   # timeout, unparsable output: keep the default
+        return '8x1', dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -50,39 +116,33 @@ def main():
                     help='BatchNorm of the voxel encoder. train (default) = batch statistics: the mode the reference renders in, '
                          'also at test time (eval_*.sh -> train.py --test_flag -> test(G, ...) with G built .train(), '
                          'training_loop.py:193,311-330); eval = running statistics (G_ema.eval(), training_loop.py:196)')
+    ap.add_argument('--mlp-shape', default=os.environ.get('SHERF_MLP_SHAPE', 'auto'),
+                    help="launch shape of sherf_nerf_mlp (sherf_amd.renderer.MLP_SHAPES); 'auto' (default) = time every shape on this "
+                         'GPU in a child process before the run and use the fastest one whose output is bit-identical to the default')
+    ap.add_argument('--tune-child', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(lrank)
-    dev = torch.device('cuda', lrank)
+    if a.tune_child:
+        return tune_child(a, lrank)
+    tune_report = None
+    if a.mlp_shape == 'auto':              # before this process touches the GPU: see pick_mlp_shape
+        a.mlp_shape, tune_report = pick_mlp_shape(a, lrank)
+    dev = _device(lrank)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
-    from sherf_amd.renderer import ImportanceRenderer
-    from sherf_amd.triplane import NeRFDecoder, TriPlaneGenerator
-    from sherf_amd.voxel import SparseConvTensor
-    from sherf_amd import dist as sdist
-    from synthdata import fixtures, synth
+    from sherf_amd import dist as sdist  # noqa: F401
 
     if os.environ.get('SHERF_DEBUG'):
         from sherf_amd import _lib
         _lib.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (tools/gpu_ablate.sh, tools/gpu_sweep.sh)
-    smpl = synth.make_synth_smpl(0)
-    fx, d, to = make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
-    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl, mlp_precision=a.precision)
-    dec = NeRFDecoder(32)
-    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
-    rend.to(dev).train(a.bn_mode == 'train'); dec.to(dev).train(a.bn_mode == 'train')
-    # voxelisation glue (triplane.py:129-137) through the product path
-    gen = TriPlaneGenerator.__new__(TriPlaneGenerator)
-    torch.nn.Module.__init__(gen); gen.renderer = rend
-    can = gen.canonical_obs_vertices(d)
-    sp_input, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
-    sp = SparseConvTensor(to(fx['vertex_feat']), sp_input['coord'], sp_input['out_sh'], 1)
-    planes, obs_feat = to(fx['planes']), to(fx['obs_feat'])
-    obs_img = d['obs_img_all'][:, 0]
+    w = make_workload(a, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
+    rend, dec, d, sp, sp_input, planes, obs_feat, obs_img, opts = (w[k] for k in ('rend', 'dec', 'd', 'sp', 'sp_input', 'planes', 'obs_feat',
+                                                                                  'obs_img', 'opts'))
+    rend.mlp_shape = a.mlp_shape
+    rend.gather_branchless = bool(tune_report and tune_report.get('gather', {}).get('best') == 'branchless') or rend.gather_branchless
     ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
-    opts = dict(fx['options']); opts['mlp_precision'] = a.precision
     R = ro.shape[1]; S = opts['depth_resolution']
     from sherf_amd import _lib as _abi
     import ctypes as _ct
@@ -128,7 +188,10 @@ def main():
                    config=dict(workload=f'{a.config}: 512x512 rays x 64 samples, synthetic SMPL subject, novel view, all feature branches, '
                                         f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
                                parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision,
-                               batchnorm=a.bn_mode))
+                               batchnorm=a.bn_mode, mlp_shape=a.mlp_shape,
+                               gather='branchless' if rend.gather_branchless else 'branch'))
+        if tune_report is not None:
+            res['mlp_tune'] = tune_report
         if mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
             traffic = None

@@ -133,7 +133,9 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
                         const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
                         float* extras, sherf_stream_t stream);
 /* mode 0: all taps; 1: tri-plane + pixel taps only (levels_host may be NULL) -- can run before the voxel encoder has
- * finished; 2: voxel taps only, ADDED onto the tokens written by a mode-1 pass. */
+ * finished; 2: voxel taps only, ADDED onto the tokens written by a mode-1 pass.  `mode | 4`: the voxel-row loads of the 8 corners are
+ * issued unconditionally (absent corners read row 0 with weight 0) instead of under one branch per corner -- same sums, a schedule
+ * variant timed per device by sherf_amd.tune. */
 
 /* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
  * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):
@@ -161,7 +163,9 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * 512 registers), 2 = EXPERIMENTAL split (prec 1 only): the VALU-bound transformer prologue and the MFMA-bound decoder as two
  * launches; `tokens` is then used as scratch (z_0 / z_1 fragments overwrite the first 8 KiB of every tile); 3 = shape 2 with the
  * decoder walking two output tiles of every 128-input layer per ring step (26 steps instead of 40); 4 = EXPERIMENTAL shape 0 as
- * persistent workgroups (one per CU, weight ring kept streaming across tile groups).  out[c] = (r,g,b,sigma). */
+ * persistent workgroups (one per CU, weight ring kept streaming across tile groups); 5 / 6 / 7 = shape 0 with a different instruction
+ * schedule only (5: previous chunk's epilogue interleaved into the MFMA stream, 6: one wave per SIMD at raised issue priority,
+ * 7: both) -- bit-identical results, picked per device by sherf_amd.tune.  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream);
 /* layout of the weight stream the kernel expects: number of chunks and K-blocks per chunk. */
@@ -293,7 +297,7 @@ typedef struct {
     const float* obs_img; float* img4; int32_t H, W;
     /* warp + gather (a8-a12) */
     float* geom; int32_t* cs_tvid;
-    const float* tok_bias; const float* bounds; const float* vox_min; int32_t vox_sh[3]; int32_t gather_split;
+    const float* tok_bias; const float* bounds; const float* vox_min; int32_t vox_sh[3]; int32_t gather_split; /* bit 0: split passes, bit 1: branchless variant */
     float* tokens; float* extras;
     /* voxel encoder (a11) */
     const sherf_svox_plan* vox_plan; const int32_t* vox_coord; const float* vox_feat; int32_t vox_n, vox_training;

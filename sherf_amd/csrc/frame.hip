@@ -169,20 +169,21 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
                                   f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, f->capacity, f->geom,
                                   f->cs_tvid, stream_main));
-        if (f->gather_split) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
+        const int gv = (f->gather_split & 2) ? 4 : 0;      // bit 1: branchless voxel-row loads (mode | 4)
+        if (f->gather_split & 1) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
-                                          nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1, f->capacity, f->tokens,
+                                          nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1 | gv, f->capacity, f->tokens,
                                           f->extras, stream_main));
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
-                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 2, f->capacity, f->tokens,
+                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 2 | gv, f->capacity, f->tokens,
                                           f->extras, stream_main));
         } else {
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
-                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0, f->capacity, f->tokens,
+                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv, f->capacity, f->tokens,
                                           f->extras, stream_main));
         }
         SHERF_PROF(4, main);

@@ -23,6 +23,9 @@ __device__ __forceinline__ void axpy4(float4& a, float w, const float4 v) {
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
+// BL: voxel-row loads issued unconditionally (see phase 2 below); same taps, same sums -- a launch-time variant
+// (`mode | 4` of sherf_gather_tokens) so that it can be timed against the branching form on the device.
+template <bool BL>
 __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                             const float4* __restrict__ planes_f, int P,
                                                             const float4* __restrict__ feat_f, int Hf, int Wf,
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                         rec[t] = make_uint2((inb && (rr.x & bit)) ? 1u : 0u, rr.y + __popc(rr.x & (bit - 1u)));
                     }
                     // phase 2: rows of the occupied corners
-#if SHERF_GATHER_BRANCHLESS
+                    if constexpr (BL) {
                     // variant to be measured: every corner's three row loads issued unconditionally (absent corners read row 0
                     // with weight 0) so that all 24 loads of a level are in flight together instead of one divergent branch at
                     // a time -- trades cached redundant loads for memory-level parallelism in a kernel that is 74 % wait
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                         axpy4(acc[1], w, r[8 + l]);
                         axpy4(acc[2], w, r[16 + l]);
                     }
-#else
+                    } else {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         if (rec[t].x) {
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __res
                             axpy4(acc[2], w, r[16 + l]);
                         }
                     }
-#endif
+                    }
                 }
             }
         } else {
@@ -315,6 +318,8 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
                                    const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
                                    float* extras, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && tok_bias && bounds && vox_min && vox_sh_host && tokens && extras);
+    const bool branchless = (mode & 4) != 0 || SHERF_GATHER_BRANCHLESS;
+    mode &= 3;
     SHERF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 1 || levels_host));
     SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
     Levels lv = {};
@@ -324,10 +329,13 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     }
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
     const int64_t tiles = (capacity + 31) / 32;
-    hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
-                       geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf,
-                       reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,
-                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode);
+#define SHERF_GATHER(BL)                                                                                                     \
+    hipLaunchKernelGGL(gather_tokens_kernel<BL>, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), \
+                       counters, geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf, \
+                       reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
+                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode)
+    if (branchless) SHERF_GATHER(true); else SHERF_GATHER(false);
+#undef SHERF_GATHER
     SHERF_LAUNCH_CHECK();
 }
 

@@ -250,7 +250,7 @@ __device__ __forceinline__ float erf_(float x) {
 #define SHERF_MLP_WAVE_PRIO 0
 #endif
 // acc[col] += W_step[kb0 .. kb0+NK) . B[col]: one segment of a chunk's K range, NCOL column sets sharing the A fragments
-template <int PREC, int NK, int NCOL>
+template <int PREC, int NK, int NCOL, int IL>
 __device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
 #pragma unroll
     for (int kb = 0; kb < NK; ++kb) {
@@ -265,16 +265,14 @@ __device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, c
         }
 #pragma unroll
         for (int t = 0; t < NCOL; ++t) acc[t] = mfma(ah, b[t][kb].hi, acc[t]);
-#if SHERF_MLP_INTERLEAVE
         // Software pipeline across chunks: the previous chunk's epilogue (ReLU + bf16 hi/lo split, ~60 VALU) is independent
         // of this chunk's MFMAs; left alone the compiler sinks all four epilogues of a layer in front of the next layer's
         // first MFMA (240 VALU during which this wave's MFMA pipe idles).  Ask for a few of them after every K-block.
-        if constexpr (PREC == 1 && NK >= 4) {
+        if constexpr (IL > 0 && PREC == 1 && NK >= 4) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * NCOL, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, SHERF_MLP_INTERLEAVE, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, IL, 0);
         }
-#endif
     }
 }
 
@@ -330,12 +328,16 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 }
 
 
-template <int PREC, int NW, int NTL, int PHASE = 0>
+// VAR: scheduling variant of the same arithmetic (results bit-identical): low byte = SHERF_MLP_INTERLEAVE count, next byte =
+// SHERF_MLP_WAVE_PRIO level.  Runtime-selectable through `shape` 5-7 of sherf_nerf_mlp so that sherf_amd.tune can time them on
+// the hardware it runs on; the -D macros only move the default.
+template <int PREC, int NW, int NTL, int PHASE = 0, int VAR = (SHERF_MLP_INTERLEAVE | (SHERF_MLP_WAVE_PRIO << 8))>
 __global__ void __launch_bounds__(NW * 64, PHASE == 1 ? SHERF_MLP_P1_WAVES : NW == 8 ? 2 : 1)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
     using CX = Ctx<PREC, NW, NTL, PHASE>;
     constexpr int NT = NW * 64;
+    constexpr int IL = VAR & 0xff, PRIO = (VAR >> 8) & 0xff;
     __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
@@ -346,9 +348,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
     cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#if SHERF_MLP_WAVE_PRIO
-    if (cx.wave < NW / 2) __builtin_amdgcn_s_setprio(SHERF_MLP_WAVE_PRIO);
-#endif
+    if constexpr (PRIO > 0) { if (cx.wave < NW / 2) __builtin_amdgcn_s_setprio(PRIO); }
     int j = cx.lane & 31, h = cx.h;                                  // (not const: PHASE -1 launders them per group)
     int64_t tile[NTL];
     bool live[NTL];
@@ -425,7 +425,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 }
             }
             f32x16 acc[1] = {bias_tile(cx, 0)};
-            mma_seg<PREC, 2, 1>(cx.slot(step), 0, 2, b, acc);
+            mma_seg<PREC, 2, 1, IL>(cx.slot(step), 0, 2, b, acc);
             advance(cx, step); ++step;
             tok[2] += acc[0];
         }
@@ -437,14 +437,14 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         {
             BFrag<PREC> b2[2][2] = {{ln[0][0], ln[0][1]}, {ln[1][0], ln[1][1]}};
             f32x16 acc[2] = {bias_tile(cx, 1), bias_tile(cx, 1)};
-            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, b2, acc);          // [q head0 | q head1]
+            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, b2, acc);          // [q head0 | q head1]
             advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qa[i][r] = acc[i][r];
             f32x16 acc2[2] = {bias_tile(cx, 2), bias_tile(cx, 2)};
-            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, b2, acc2);         // [q head2 | pad]
+            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, b2, acc2);         // [q head2 | pad]
             advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -456,7 +456,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         float v0[3][8];
         {
             f32x16 acc[3] = {bias_tile(cx, 3), bias_tile(cx, 3), bias_tile(cx, 3)};
-            mma_seg<PREC, 2, 3>(cx.slot(step), 0, 2, ln, acc);          // [k head0 | k head1]
+            mma_seg<PREC, 2, 3, IL>(cx.slot(step), 0, 2, ln, acc);          // [k head0 | k head1]
             advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -470,7 +470,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         }
         {
             f32x16 acc[3] = {bias_tile(cx, 4), bias_tile(cx, 4), bias_tile(cx, 4)};
-            mma_seg<PREC, 2, 3>(cx.slot(step), 0, 2, ln, acc);          // [k head2 | v head0]
+            mma_seg<PREC, 2, 3, IL>(cx.slot(step), 0, 2, ln, acc);          // [k head2 | v head0]
             advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -505,7 +505,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
         {
             f32x16 acc[3] = {bias_tile(cx, 5), bias_tile(cx, 5), bias_tile(cx, 5)};
-            mma_seg<PREC, 2, 3>(cx.slot(step), 0, 2, ln, acc);          // [v head1 | v head2]
+            mma_seg<PREC, 2, 3, IL>(cx.slot(step), 0, 2, ln, acc);          // [v head1 | v head2]
             advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -525,7 +525,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                     ob[i][hd] = make_frag<PREC>(o[i][hd][0], o[i][hd][1], o[i][hd][2], o[i][hd][3], o[i][hd][4], o[i][hd][5],
                                                 o[i][hd][6], o[i][hd][7]);
             f32x16 acc[2] = {bias_tile(cx, 6), bias_tile(cx, 6)};
-            mma_seg<PREC, 3, 2>(cx.slot(step), 0, 3, ob, acc);          // to_out + bias
+            mma_seg<PREC, 3, 2, IL>(cx.slot(step), 0, 3, ob, acc);          // to_out + bias
             advance(cx, step); ++step;
             y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];             // residual (renderer.py:925)
         }
@@ -535,7 +535,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             layer_norm<PREC>(cx, y[0], 1, l2[0][0], l2[0][1]);
             layer_norm<PREC>(cx, y[1], 1, l2[1][0], l2[1][1]);
             f32x16 acc[2] = {bias_tile(cx, 7), bias_tile(cx, 7)};
-            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, l2, acc);
+            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, l2, acc);
             advance(cx, step); ++step;
             BFrag<PREC> gb[2][2];
 #pragma unroll
@@ -545,7 +545,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 split_tile<PREC>(acc[i], gb[i][0], gb[i][1]);
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
-            mma_seg<PREC, 2, 2>(cx.slot(step), 0, 2, gb, acc2);
+            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, gb, acc2);
             advance(cx, step); ++step;
             f32x16 za = acc2[0] + y[0], zb = acc2[1] + y[1];
             split_tile<PREC>(za, z0b[u][0], z0b[u][1]);
@@ -591,8 +591,8 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         f32x16 acc0[NTL], acc1[NTL];                                                                  \
         _Pragma("unroll") for (int u = 0; u < NTL; ++u) { acc0[u] = bias_tile(cx, CHUNK); acc1[u] = bias_tile(cx, (CHUNK) + 1); } \
         const char* s_ = cx.slot(step);                                                               \
-        mma_seg<PREC, 8, NTL>(s_, 0, 8, IN, acc0);                                                    \
-        mma_seg<PREC, 8, NTL>(s_ + 2 * 8 * 1024, 0, 8, IN, acc1);                                     \
+        mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, IN, acc0);                                                    \
+        mma_seg<PREC, 8, NTL, IL>(s_ + 2 * 8 * 1024, 0, 8, IN, acc1);                                     \
         advance(cx, step); ++step;                                                                    \
         _Pragma("unroll") for (int u = 0; u < NTL; ++u) {                                             \
             if (RELU) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[u][r] = relu(acc0[u][r]); acc1[u][r] = relu(acc1[u][r]); } } \
@@ -602,7 +602,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     }
 #pragma unroll
     for (int T = 0; T < 4; ++T)     // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
-        SHERF_TRUNK_TILE(9 + T, ha, T, mma_seg<PREC, 3, NTL>(s_, 0, 5, pe, acc); mma_seg<PREC, 2, NTL>(s_, 3, 5, z0b, acc);)
+        SHERF_TRUNK_TILE(9 + T, ha, T, mma_seg<PREC, 3, NTL, IL>(s_, 0, 5, pe, acc); mma_seg<PREC, 2, NTL, IL>(s_, 3, 5, z0b, acc);)
 #pragma unroll
     for (int L = 0; L < 4; ++L) {   // pts_linears.1-4 (ping-pong ha -> hb -> ha ...)
         if constexpr (PHASE == 3) {
@@ -614,15 +614,15 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         } else {
 #pragma unroll
             for (int T = 0; T < 4; ++T) {
-                if (L & 1) SHERF_TRUNK_TILE(13 + 4 * L + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)
-                else SHERF_TRUNK_TILE(13 + 4 * L + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)
+                if (L & 1) SHERF_TRUNK_TILE(13 + 4 * L + T, ha, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, hb, acc);)
+                else SHERF_TRUNK_TILE(13 + 4 * L + T, hb, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, ha, acc);)
             }
         }
     }
 #pragma unroll
     for (int T = 0; T < 4; ++T)     // pts_linears.5 : [PE6 | z_0 | h(128)] ; after 4 layers the activations are back in ha
-        SHERF_TRUNK_TILE(29 + T, hb, T, mma_seg<PREC, 3, NTL>(s_, 0, 13, pe, acc); mma_seg<PREC, 2, NTL>(s_, 3, 13, z0b, acc);
-                         mma_seg<PREC, 8, NTL>(s_, 5, 13, ha, acc);)
+        SHERF_TRUNK_TILE(29 + T, hb, T, mma_seg<PREC, 3, NTL, IL>(s_, 0, 13, pe, acc); mma_seg<PREC, 2, NTL, IL>(s_, 3, 13, z0b, acc);
+                         mma_seg<PREC, 8, NTL, IL>(s_, 5, 13, ha, acc);)
     if constexpr (PHASE == 3) {
 #pragma unroll
         for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(33 + T, ha, T, hb, true)                              // pts_linears.6
@@ -630,9 +630,9 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(37 + T, hb, T, ha, true)                              // pts_linears.7
     } else {
 #pragma unroll
-        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(33 + T, ha, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, hb, acc);)   // pts_linears.6
+        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(33 + T, ha, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, hb, acc);)   // pts_linears.6
 #pragma unroll
-        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(37 + T, hb, T, mma_seg<PREC, 8, NTL>(s_, 0, 8, ha, acc);)   // pts_linears.7
+        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(37 + T, hb, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, ha, acc);)   // pts_linears.7
     }
     // ---- heads: feature_linear (4 tiles, no activation) into ha, alpha_linear (tile 45, row 0), both from hb ----
     float sigma[NTL];
@@ -645,7 +645,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             f32x16 acc[NTL];
 #pragma unroll
             for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 41 + T);
-            mma_seg<PREC, 8, NTL>(cx.slot(step), 0, 8, hb, acc);
+            mma_seg<PREC, 8, NTL, IL>(cx.slot(step), 0, 8, hb, acc);
             advance(cx, step); ++step;
 #pragma unroll
             for (int u = 0; u < NTL; ++u) split_tile<PREC>(acc[u], ha[u][2 * T], ha[u][2 * T + 1]);
@@ -655,7 +655,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         f32x16 acc[NTL];
 #pragma unroll
         for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 45);
-        mma_seg<PREC, 8, NTL>(cx.slot(step), 0, 8, hb, acc);
+        mma_seg<PREC, 8, NTL, IL>(cx.slot(step), 0, 8, hb, acc);
         advance(cx, step); ++step;
 #pragma unroll
         for (int u = 0; u < NTL; ++u) sigma[u] = acc[u][0];             // row 0 lives in reg 0 of the h == 0 lanes
@@ -670,9 +670,9 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 #pragma unroll
         for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 46 + T);
         const char* s_ = cx.slot(step);
-        mma_seg<PREC, 8, NTL>(s_, 0, 12, ha, acc);
-        mma_seg<PREC, 2, NTL>(s_, 8, 12, pv, acc);
-        mma_seg<PREC, 2, NTL>(s_, 10, 12, z1b, acc);
+        mma_seg<PREC, 8, NTL, IL>(s_, 0, 12, ha, acc);
+        mma_seg<PREC, 2, NTL, IL>(s_, 8, 12, pv, acc);
+        mma_seg<PREC, 2, NTL, IL>(s_, 10, 12, z1b, acc);
         advance(cx, step); ++step;
 #pragma unroll
         for (int u = 0; u < NTL; ++u) {
@@ -685,7 +685,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         f32x16 acc[NTL];
 #pragma unroll
         for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 48);
-        mma_seg<PREC, 4, NTL>(cx.slot(step), 0, 4, gb, acc);
+        mma_seg<PREC, 4, NTL, IL>(cx.slot(step), 0, 4, gb, acc);
         if constexpr (PHASE == -1) { if (cx.more) advance(cx, step); }       // frees slot (n_steps - 1) % 3 for the next group
 #pragma unroll
         for (int u = 0; u < NTL; ++u)
@@ -726,13 +726,23 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 4 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 7 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (shape >= 5) {                         // scheduling variants of the default kernel (same arithmetic, bit-identical results):
+        SHERF_CHECK_ARG(prec == 1);           // 5 = MFMA/VALU interleave 8, 6 = wave priority 2, 7 = both; chosen by sherf_amd.tune
+#define SHERF_MLP_VAR(V)                                                                                                     \
+    hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 0, V>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters, \
+                       reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,  \
+                       reinterpret_cast<float4*>(out), g_sherf_debug)
+        if (shape == 5) SHERF_MLP_VAR(8); else if (shape == 6) SHERF_MLP_VAR(2 << 8); else SHERF_MLP_VAR(8 | (2 << 8));
+#undef SHERF_MLP_VAR
+        SHERF_LAUNCH_CHECK();
+    }
     if (shape == 4) {                         // experimental: persistent workgroups, one per CU (PHASE -1)
         SHERF_CHECK_ARG(prec == 1);
         static int n_cu = 0;

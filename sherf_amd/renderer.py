@@ -19,6 +19,10 @@ from . import _lib, mlp_pack
 from .ray_marcher import MipRayMarcher2
 from .voxel import SparseConvNet, SparseConvTensor, pack_conv_weights  # noqa: F401
 
+# `shape` argument of sherf_nerf_mlp (include/sherf_hip.h).  '8x1il8' / '8x1prio' / '8x1prio_il8' differ from '8x1' in the
+# instruction schedule only (bit-identical results); sherf_amd.tune times them on the device and reports the fastest.
+MLP_SHAPES = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4, '8x1il8': 5, '8x1prio': 6, '8x1prio_il8': 7}
+
 V = 6890
 
 
@@ -216,6 +220,7 @@ class ImportanceRenderer(nn.Module):
         self.mlp_precision = mlp_precision
         self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2' | experimental '8x1split', '8x1split2', '8x1persist')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
+        self.gather_branchless = os.environ.get('SHERF_GATHER_BRANCHLESS', '0') == '1'   # schedule variant of the voxel taps (sherf_hip.h)
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
         self._smpl_src = smpl
@@ -372,7 +377,7 @@ class ImportanceRenderer(nn.Module):
         fr.vox_min = A(vox_min)
         for i, v in enumerate(obs_sp_input['out_sh']):
             fr.vox_sh[i] = int(v)
-        fr.gather_split = 1 if opts.get('gather_split', self.gather_split) else 0
+        fr.gather_split = (1 if opts.get('gather_split', self.gather_split) else 0) | (2 if opts.get('gather_branchless', self.gather_branchless) else 0)
         # a11: sparse voxel encoder plan (persistent buffers) + this frame's voxels
         pl, vfeat, vcoord = self.encoder_3d.prepare(canonical_sp_conv_volume, wc['fold'], self._ws)
         keep += [vfeat, vcoord]
@@ -381,7 +386,7 @@ class ImportanceRenderer(nn.Module):
         # a13-a14: fused transformer + NeRF decoder
         fr.wstream, fr.wbias = A(wc['stream']), A(wc['wbias'])
         fr.mlp_prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
-        fr.mlp_shape = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4}[opts.get('mlp_shape', self.mlp_shape)]   # split: experimental, overwrites ws['tokens']
+        fr.mlp_shape = MLP_SHAPES[opts.get('mlp_shape', self.mlp_shape)]   # split: experimental, overwrites ws['tokens']
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()

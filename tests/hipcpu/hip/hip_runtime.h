@@ -8,6 +8,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <cmath>
 #include <cstdint>
@@ -91,15 +92,19 @@ inline int3 make_int3(int a, int b, int c) { return {a, b, c}; }
 typedef void* hipStream_t;
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
-// streams / events: every launch is synchronous, so ordering calls are no-ops and elapsed times are zero
-typedef void* hipEvent_t;
+// streams / events: every launch is synchronous, so ordering calls are no-ops; an event remembers the host clock at its record
+// (the library's event sets live for the process: never freed here)
+typedef double* hipEvent_t;
 constexpr unsigned hipEventDisableTiming = 2;
-inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0.0); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new double(0.0); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    *e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return hipSuccess;
+}
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*b - *a); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipcpu"; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }

@@ -79,9 +79,79 @@ def test_stage_by_stage_parity(run):
 
 def test_mlp_shapes_agree_inside_the_frame(cpu_product):
     a = G.hip_render('tiny_nv')
-    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist'):
+    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist', '8x1il8', '8x1prio', '8x1prio_il8'):
         b = G.hip_render('tiny_nv', options=dict(mlp_shape=shape))
         assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4, shape
+
+
+def test_tune_mlp_checks_every_shape_against_the_default(cpu_product, monkeypatch):
+    """sherf_amd.tune on the host build: every launch shape reproduces the default's (r, g, b, sigma) bit for bit on the frame's own
+    samples, the workspace is left as found, and a shape whose output differs is never chosen."""
+    import time
+    from sherf_amd import tune
+
+    def host_timer(fn, iters, dev):
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return 1e3 * (time.perf_counter() - t0) / iters
+    monkeypatch.setattr(tune, '_time_launches', host_timer)
+    h = G.hip_render('tiny_nv')
+    ws = h['last']['ws']
+    tok, out, ext = ws['tokens'].clone(), ws['sample_out'].clone(), ws['extras'].clone()
+    rep = tune.tune_mlp(h['rend'], h['dec'], iters=1, warmup=0)
+    assert set(rep['shapes']) == set(tune.MLP_SHAPES) and rep['valid_samples'] == int(ws['counters'][0])
+    for name, e in rep['shapes'].items():
+        assert e['ok'] and e['max_abs_diff'] == 0.0 and e['ms'] > 0, (name, e)
+    assert rep['best'] in tune.MLP_SHAPES
+    assert torch.equal(ws['tokens'], tok) and torch.equal(ws['sample_out'], out)
+    g = tune.tune_gather(h['rend'], h['dec'], iters=1, warmup=0)
+    assert g['variants']['branch']['ok'] and g['variants']['branchless']['ok'] and g['variants']['branchless']['max_abs_diff'] == 0.0
+    assert torch.equal(ws['tokens'], tok) and torch.equal(ws['extras'], ext)
+    bl = G.hip_render('tiny_nv', options=dict(gather_branchless=True))               # and inside the frame
+    assert torch.equal(bl['rgb'], h['rgb']) and torch.equal(bl['acc'], h['acc'])
+    # the guard: corrupt one candidate's result -> it must be reported not ok and not be chosen
+    real_call = _lib.call
+
+    def bad_call(name, *args):
+        real_call(name, *args)
+        if name == 'sherf_nerf_mlp' and args[6] == tune.MLP_SHAPES['8x1il8']:
+            ctypes.cast(ctypes.c_void_p(args[8]), ctypes.POINTER(ctypes.c_float))[0] += 1.0
+    monkeypatch.setattr(_lib, 'call', bad_call)
+    times = iter([1.0, 0.1])                                  # the corrupted candidate would win on time
+    monkeypatch.setattr(tune, '_time_launches', lambda fn, iters, dev: next(times))
+    rep = tune.tune_mlp(h['rend'], h['dec'], candidates=['8x1', '8x1il8'], iters=1, warmup=0)
+    assert not rep['shapes']['8x1il8']['ok'] and rep['best'] == '8x1'
+
+
+def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
+    """bench.py's own plumbing (workload construction, the timed loop, the JSON line with the roofline object, the tune child) executed
+    on the host build -- the numbers mean nothing here, the point is that the script the driver runs on the MI355X has been run."""
+    import json
+    import sys
+    import time
+    import bench
+    from sherf_amd import tune
+    from sherf_amd.renderer import ImportanceRenderer
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    monkeypatch.setattr(bench, '_device', lambda lrank: torch.device('cpu'))
+    monkeypatch.setattr(ImportanceRenderer, '_side', lambda self, dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})())
+
+    def host_timer(fn, iters, dev):
+        t0 = time.perf_counter()
+        fn()
+        return 1e3 * (time.perf_counter() - t0)
+    monkeypatch.setattr(tune, '_time_launches', host_timer)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--tune-child'])
+    bench.main()
+    rep = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('TUNE_JSON ')][-1][len('TUNE_JSON '):])
+    assert rep['best'] in tune.MLP_SHAPES and all(e['ok'] for e in rep['shapes'].values()) and rep['gather']['variants']['branchless']['ok']
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--mlp-shape', '8x1prio_il8'])
+    bench.main()
+    res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert res['n_gpus'] == 1 and res['steps'] == 2 and res['unit'] == 'rays/s' and res['value'] > 0
+    assert res['config']['mlp_shape'] == '8x1prio_il8' and res['config']['valid_samples'] > 0
+    assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and 'frame_timeline_ms' in res
 
 
 def test_eval_mode_batchnorm_and_edge_cases(cpu_product):

@@ -2,6 +2,7 @@
 Python that fills the frame descriptor (sherf_frame / sherf_svox_plan), in training, eval and density-noise mode, without a
 GPU.  The kernels are not involved; this guards the host logic between GPU sessions."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -159,3 +160,33 @@ def test_full_size_property_test_plumbing(monkeypatch):
         return dict(rgb=r['rgb'], depth=r['depth'], acc=r['acc'], last=dict(ws=ws), rend=None)
     monkeypatch.setattr(T.G, 'hip_render', fake_render)
     T._full_size_properties('tiny', 7)
+
+
+# ---- bench.py: MLP launch-shape selection through a child process ---------------------------------------------------------------
+def test_bench_pick_mlp_shape_falls_back_and_parses(monkeypatch):
+    """No GPU here: the tune child fails -> the default shape with the error recorded; a well-formed child report -> its choice."""
+    import argparse
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    a = argparse.Namespace(config='cfg2', precision='bf16x3', bn_mode='train')
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return subprocess.CompletedProcess(cmd, 1, stdout='', stderr='RuntimeError: no HIP device')
+    monkeypatch.setenv('RANK', '3'); monkeypatch.setenv('WORLD_SIZE', '8')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    shape, rep = bench.pick_mlp_shape(a, 3)
+    assert shape == '8x1' and 'no HIP device' in rep['error']
+    assert '--tune-child' in seen['cmd'] and seen['env']['LOCAL_RANK'] == '3' and 'RANK' not in seen['env'] and 'WORLD_SIZE' not in seen['env']
+    good = dict(best='8x1prio', shapes={'8x1': dict(ms=0.75, ok=True), '8x1prio': dict(ms=0.70, ok=True)})
+    monkeypatch.setattr(subprocess, 'run', lambda cmd, **kw: subprocess.CompletedProcess(cmd, 0, stdout='noise\nTUNE_JSON ' + json.dumps(good) + '\n', stderr=''))
+    assert bench.pick_mlp_shape(a, 0) == ('8x1prio', good)
+
+    def boom(cmd, **kw):
+        raise subprocess.TimeoutExpired(cmd, 1)
+    monkeypatch.setattr(subprocess, 'run', boom)
+    assert bench.pick_mlp_shape(a, 0)[0] == '8x1'
