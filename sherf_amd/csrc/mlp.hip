@@ -134,7 +134,9 @@ template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
     int lane, h, dbg, wave, pending;
     bool more;               // PHASE -1: this workgroup has another tile group after the current one (uniform)
     static constexpr int SLOT = (PHASE == 1 ? 3 : PHASE == 3 ? 16 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8: <= 3 K-blocks; pairs: 2 x 8
-    static constexpr int NSLOT = 3;
+    // <NW=4, NTL=1> (shape '4x1'): half-size workgroups, TWO co-resident per CU (one wave of each per SIMD) that are not coupled by
+    // each other's barriers; their rings must fit the 160 KiB LDS together -> two slots, one step of prefetch distance.
+    static constexpr int NSLOT = (NW == 4 && NTL == 1) ? 2 : 3;
     __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
 };
 
@@ -188,12 +190,13 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // end of step s: step s+1 must have landed (everything but the newest issue), then step s's slot is recycled for s+3
 template <int PREC, int NW, int NTL, int PHASE>
 __device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
-    wait_vm(cx.pending);
+    constexpr int NSLOT = Ctx<PREC, NW, NTL, PHASE>::NSLOT;
+    wait_vm(NSLOT == 2 ? 0 : cx.pending);    // two slots: the newest issue IS step s+1
     if (!(cx.dbg & 64)) wg_barrier();
     if constexpr (PHASE == -1) {             // past the end of this group: the freed slot takes step (step + 3) % 3 of the next group
         if (step + 3 >= n_steps<NTL, PHASE>()) { cx.pending = cx.more ? dma_issue(cx, (step + 3) % Ctx<PREC, NW, NTL, PHASE>::NSLOT) : 0; return; }
     }
-    cx.pending = dma_issue(cx, step + 3);
+    cx.pending = dma_issue(cx, step + NSLOT);
 }
 
 template <class C>
@@ -332,7 +335,7 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 // SHERF_MLP_WAVE_PRIO level.  Runtime-selectable through `shape` 5-7 of sherf_nerf_mlp so that sherf_amd.tune can time them on
 // the hardware it runs on; the -D macros only move the default.
 template <int PREC, int NW, int NTL, int PHASE = 0, int VAR = (SHERF_MLP_INTERLEAVE | (SHERF_MLP_WAVE_PRIO << 8))>
-__global__ void __launch_bounds__(NW * 64, PHASE == 1 ? SHERF_MLP_P1_WAVES : NW == 8 ? 2 : 1)
+__global__ void __launch_bounds__(NW * 64, PHASE == 1 ? SHERF_MLP_P1_WAVES : NTL == 1 ? 2 : 1)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
     using CX = Ctx<PREC, NW, NTL, PHASE>;
@@ -364,7 +367,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     const int n1 = dma_issue(cx, 1);
     wait_vm(n1);                              // step 0 (this wave's pieces) landed
     __syncthreads();
-    cx.pending = dma_issue(cx, 2);
+    cx.pending = CX::NSLOT == 2 ? n1 : dma_issue(cx, 2);
 
     [[maybe_unused]] int64_t grp = blockIdx.x;                       // PHASE -1: tile group of this pass
     bool again = false;
@@ -726,13 +729,18 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 7 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 8 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (shape == 8) {                         // 4 waves x 1 tile: two independent workgroups per CU (two-slot weight rings)
+        SHERF_CHECK_ARG(prec == 1);
+        SHERF_MLP(1, 4, 1);
+        SHERF_LAUNCH_CHECK();
+    }
     if (shape >= 5) {                         // scheduling variants of the default kernel (same arithmetic, bit-identical results):
         SHERF_CHECK_ARG(prec == 1);           // 5 = MFMA/VALU interleave 8, 6 = wave priority 2, 7 = both; chosen by sherf_amd.tune
 #define SHERF_MLP_VAR(V)                                                                                                     \

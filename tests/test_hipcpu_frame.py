@@ -79,7 +79,7 @@ def test_stage_by_stage_parity(run):
 
 def test_mlp_shapes_agree_inside_the_frame(cpu_product):
     a = G.hip_render('tiny_nv')
-    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist', '8x1il8', '8x1prio', '8x1prio_il8'):
+    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist', '8x1il8', '8x1prio', '8x1prio_il8', '4x1'):
         b = G.hip_render('tiny_nv', options=dict(mlp_shape=shape))
         assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4, shape
 
