@@ -1,5 +1,6 @@
 #!/bin/bash
 # ablation timing of the sampler / gather (SHERF_DEBUG bits) + one PMC pass; profiling only
+export SHERF_MLP_SHAPE=${SHERF_MLP_SHAPE:-8x1}   # A/B runs pin the MLP shape (bench.py would otherwise autotune it)
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

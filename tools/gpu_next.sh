@@ -17,7 +17,8 @@ V=""
 timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu_experimental -q -s --no-header -p no:cacheprovider 2>&1 | tail -6 | tee -a $OUT/pytest_experimental.log
 for t in il8 erf erf_il8 gbl prio prio_il8; do [ -f sherf_amd/libsherf_hip_$t.so ] && V="$V $t"; done
 bash tools/gpu_variants.sh $V 2>&1 | tee $OUT/variants.log
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default   ', d['ms_per_step'], d['roofline']['kernel_ms'])"
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | tee $OUT/bench_auto.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('auto      ', d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['mlp_shape'], d['config']['gather']); [print('   ', k, v) for k, v in d.get('mlp_tune', {}).get('shapes', {}).items()]; print('    gather', d.get('mlp_tune', {}).get('gather'))"
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline --mlp-shape 8x1 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default   ', d['ms_per_step'], d['roofline']['kernel_ms'])"
 SHERF_MLP_SHAPE=8x1split python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('8x1split  ', d['ms_per_step'], d['roofline']['kernel_ms'], '(kernel_ms covers both launches)')"
 SHERF_MLP_SHAPE=8x1split2 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('8x1split2 ', d['ms_per_step'], d['roofline']['kernel_ms'], '(decoder walks two output tiles per step)')"
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --torch-gpu-baseline 2>/dev/null | grep '"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stock-ops oracle on the GPU:', d.get('torch_gpu_baseline'))"

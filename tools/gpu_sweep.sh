@@ -1,5 +1,6 @@
 #!/bin/bash
 # scheduling sweep for the frame driver (HIP-event timelines from bench.py, no profiler)
+export SHERF_MLP_SHAPE=${SHERF_MLP_SHAPE:-8x1}   # A/B runs pin the MLP shape (bench.py would otherwise autotune it)
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

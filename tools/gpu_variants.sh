@@ -1,6 +1,7 @@
 #!/bin/bash
 # kernel-variant comparison: alternative builds of the library (same ABI) selected with SHERF_HIP_LIB.
 #   usage: bash tools/gpu_variants.sh [tag ...]      (tags of sherf_amd/libsherf_hip_<tag>.so; "" = the default build)
+export SHERF_MLP_SHAPE=${SHERF_MLP_SHAPE:-8x1}   # A/B runs pin the MLP shape (bench.py would otherwise autotune it)
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
