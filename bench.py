@@ -109,9 +109,12 @@ def main():
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--precision', default='bf16x3', choices=['bf16x3', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--torch-gpu-baseline', action='store_true',
-                    help='also time the oracle (the reference algorithm as stock ATen ops, brute-force K-NN) ON THE GPU over the whole '
-                         'frame: SURVEY.md section 8(d) asks for this denominator beside the CPU one (N = 1 only, adds ~1 min)')
+    ap.add_argument('--torch-gpu-baseline', action='store_true', help=argparse.SUPPRESS)      # (now the default at N = 1)
+    ap.add_argument('--no-torch-gpu-baseline', action='store_true',
+                    help='skip timing the oracle (the reference algorithm as stock ATen ops, brute-force K-NN) ON THE GPU over the whole '
+                         'frame: the "reference single-GPU render()" denominator SURVEY.md section 8(d) asks for beside the CPU one '
+                         '(N = 1 only; runs in a child process after the measurement, bounded to 4 minutes)')
+    ap.add_argument('--torch-gpu-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--bn-mode', default='train', choices=['train', 'eval'],
                     help='BatchNorm of the voxel encoder. train (default) = batch statistics: the mode the reference renders in, '
                          'also at test time (eval_*.sh -> train.py --test_flag -> test(G, ...) with G built .train(), '
@@ -125,6 +128,9 @@ def main():
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
     if a.tune_child:
         return tune_child(a, lrank)
+    if a.torch_gpu_child:
+        print('TORCH_GPU_JSON ' + json.dumps(torch_gpu_baseline(a.config, _device(lrank), a.bn_mode == 'train')), flush=True)
+        return
     tune_report = None
     if a.mlp_shape == 'auto':              # before this process touches the GPU: see pick_mlp_shape
         a.mlp_shape, tune_report = pick_mlp_shape(a, lrank)
@@ -207,8 +213,10 @@ def main():
             res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_dt / a.steps, 4)
         if not a.no_cpu_baseline and world == 1:            # reported at N = 1 only (rank 0's host cores)
             res['cpu_baseline'] = cpu_baseline(a.config)
-        if a.torch_gpu_baseline and world == 1:
-            res['torch_gpu_baseline'] = torch_gpu_baseline(a.config, dev, a.bn_mode == 'train')
+        if not a.no_torch_gpu_baseline and world == 1:
+            res['torch_gpu_baseline'] = torch_gpu_baseline_child(a, lrank)
+            if res['torch_gpu_baseline'].get('value'):
+                res['torch_gpu_baseline']['speedup_vs_it'] = res['value'] / res['torch_gpu_baseline']['value']
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
@@ -241,7 +249,24 @@ def cpu_baseline(cfg_name):
                        f'oracle/sherf_oracle.py fp32 torch-CPU, {dt:.1f} s')
 
 
-def torch_gpu_baseline(cfg_name, dev, training, iters=2):
+def torch_gpu_baseline_child(a, lrank, timeout=240):
+    """torch_gpu_baseline in a child process: checker code on stock kernels must not be able to take the bench line down (out of
+    memory, a hang) nor to leave its allocator pool in this process."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['LOCAL_RANK'] = str(lrank)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--torch-gpu-child', '--config', a.config, '--bn-mode', a.bn_mode],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith('TORCH_GPU_JSON ')]
+        if not line:
+            return dict(error=f'child rc={r.returncode}: {r.stderr.strip()[-300:]}')
+        return json.loads(line[-1][len('TORCH_GPU_JSON '):])
+    except Exception as ex:
+        return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
+
+
+def torch_gpu_baseline(cfg_name, dev, training, iters=1):
     """The same oracle as cpu_baseline, run through PyTorch-ROCm's stock kernels on the GPU over the WHOLE frame (checker code
     timed as a baseline, never on the product path).  Its K-NN is the blocked brute force of oracle.nearest_vertex."""
     try:

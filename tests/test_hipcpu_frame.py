@@ -146,12 +146,17 @@ def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
     bench.main()
     rep = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('TUNE_JSON ')][-1][len('TUNE_JSON '):])
     assert rep['best'] in tune.MLP_SHAPES and all(e['ok'] for e in rep['shapes'].values()) and rep['gather']['variants']['branchless']['ok']
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--mlp-shape', '8x1prio_il8'])
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-torch-gpu-baseline',
+                                      '--mlp-shape', '8x1prio_il8'])
     bench.main()
     res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert res['n_gpus'] == 1 and res['steps'] == 2 and res['unit'] == 'rays/s' and res['value'] > 0
     assert res['config']['mlp_shape'] == '8x1prio_il8' and res['config']['valid_samples'] > 0
     assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and 'frame_timeline_ms' in res
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--torch-gpu-child'])       # the stock-ops baseline's child entry
+    bench.main()
+    tg = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('TORCH_GPU_JSON ')][-1][len('TORCH_GPU_JSON '):])
+    assert tg.get('value', 0) > 0, tg
 
 
 def test_eval_mode_batchnorm_and_edge_cases(cpu_product):
