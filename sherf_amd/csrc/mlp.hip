@@ -729,16 +729,20 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 8 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 9 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
-    if (shape == 8) {                         // 4 waves x 1 tile: two independent workgroups per CU (two-slot weight rings)
+    if (shape == 8 || shape == 9) {           // 4 waves x 1 tile: two independent workgroups per CU (two-slot weight rings); 9 = + interleave 8
         SHERF_CHECK_ARG(prec == 1);
-        SHERF_MLP(1, 4, 1);
+        if (shape == 8) SHERF_MLP(1, 4, 1);
+        else
+            hipLaunchKernelGGL((nerf_mlp_kernel<1, 4, 1, 0, 8>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, as_stream(stream), counters,
+                               reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                               reinterpret_cast<float4*>(out), g_sherf_debug);
         SHERF_LAUNCH_CHECK();
     }
     if (shape >= 5) {                         // scheduling variants of the default kernel (same arithmetic, bit-identical results):

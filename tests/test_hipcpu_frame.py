@@ -79,7 +79,9 @@ def test_stage_by_stage_parity(run):
 
 def test_mlp_shapes_agree_inside_the_frame(cpu_product):
     a = G.hip_render('tiny_nv')
-    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist', '8x1il8', '8x1prio', '8x1prio_il8', '4x1'):
+    # (every shape is compared bit for bit on the frame's samples by the tuner test below; here the ones whose launch structure
+    #  interacts with the frame driver: two launches, `tokens` used as scratch, persistent grid, half-size workgroups)
+    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist', '4x1il8'):
         b = G.hip_render('tiny_nv', options=dict(mlp_shape=shape))
         assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4, shape
 
@@ -146,11 +148,11 @@ def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
     bench.main()
     rep = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('TUNE_JSON ')][-1][len('TUNE_JSON '):])
     assert rep['best'] in tune.MLP_SHAPES and all(e['ok'] for e in rep['shapes'].values()) and rep['gather']['variants']['branchless']['ok']
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-torch-gpu-baseline',
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-torch-gpu-baseline',
                                       '--mlp-shape', '8x1prio_il8'])
     bench.main()
     res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert res['n_gpus'] == 1 and res['steps'] == 2 and res['unit'] == 'rays/s' and res['value'] > 0
+    assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
     assert res['config']['mlp_shape'] == '8x1prio_il8' and res['config']['valid_samples'] > 0
     assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and 'frame_timeline_ms' in res
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--torch-gpu-child'])       # the stock-ops baseline's child entry
