@@ -15,6 +15,7 @@ for T in $(python -m pytest tests/test_gpu_backward.py -m gpu_experimental --col
 done
 V=""
 timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu_experimental -q -s --no-header -p no:cacheprovider 2>&1 | tail -6 | tee -a $OUT/pytest_experimental.log
+timeout 300 python -m pytest tests/test_gpu_tune.py -m gpu_experimental -q -s --no-header -p no:cacheprovider 2>&1 | tail -40 | tee -a $OUT/pytest_experimental.log
 for t in il8 erf erf_il8 gbl prio prio_il8; do [ -f sherf_amd/libsherf_hip_$t.so ] && V="$V $t"; done
 bash tools/gpu_variants.sh $V 2>&1 | tee $OUT/variants.log
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '"metric"' | tee $OUT/bench_auto.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('auto      ', d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['mlp_shape'], d['config']['gather']); [print('   ', k, v) for k, v in d.get('mlp_tune', {}).get('shapes', {}).items()]; print('    gather', d.get('mlp_tune', {}).get('gather'))"
