@@ -75,8 +75,24 @@ def tune_child(a, lrank):
             w['rend'](w['planes'], w['obs_img'], w['obs_feat'], w['sp'], None, w['sp_input'], w['dec'], d['ray_o_all'][:, 0],
                       d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, w['opts'])
     torch.cuda.synchronize()
-    rep = tune.tune_mlp(w['rend'], w['dec'])
-    rep['gather'] = tune.tune_gather(w['rend'], w['dec'])
+    rend = w['rend']
+    rep = tune.tune_mlp(rend, w['dec'])
+    rep['gather'] = tune.tune_gather(rend, w['dec'])
+    exact = tune.tune_mlp(rend, w['dec'], exact_capacity=True)          # the same shapes without their grids of empty workgroups
+    rep['shapes_exact_grid'], rep['best_exact_grid'] = exact['shapes'], exact['best']
+    bl = rep['gather']['best'] == 'branchless'
+
+    def render():
+        with torch.no_grad():
+            return rend(w['planes'], w['obs_img'], w['obs_feat'], w['sp'], None, w['sp_input'], w['dec'], d['ray_o_all'][:, 0],
+                        d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, w['opts'])
+    # whole frames: the defaults, the tuned kernels, and both again with launches sized by the frame's own sample count
+    cands = [dict(mlp_shape='8x1', gather_branchless=False, exact_grids=False),
+             dict(mlp_shape=rep['best'], gather_branchless=bl, exact_grids=False),
+             dict(mlp_shape='8x1', gather_branchless=False, exact_grids=True),
+             dict(mlp_shape=rep['best_exact_grid'], gather_branchless=bl, exact_grids=True)]
+    rep['frame'] = tune.tune_frame(render, rend, cands, iters=a.tune_iters, warmup=min(2, a.tune_iters - 1))
+    rep['choice'] = cands[rep['frame']['best']]
     print('TUNE_JSON ' + json.dumps(rep), flush=True)
 
 
@@ -96,7 +112,7 @@ def pick_mlp_shape(a, lrank, timeout=300):
         if r.returncode != 0 or not line:
             return '8x1', dict(error=f'tune child rc={r.returncode}: {r.stderr.strip()[-300:]}')
         rep = json.loads(line[-1][len('TUNE_JSON '):])
-        return rep['best'], rep
+        return rep.get('choice', dict(mlp_shape=rep['best']))['mlp_shape'], rep
     except Exception as ex:                                   # timeout, unparsable output: keep the default
         return '8x1', dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
 
@@ -123,6 +139,7 @@ def main():
                     help="launch shape of sherf_nerf_mlp (sherf_amd.renderer.MLP_SHAPES); 'auto' (default) = time every shape on this "
                          'GPU in a child process before the run and use the fastest one whose output is bit-identical to the default')
     ap.add_argument('--tune-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--tune-iters', type=int, default=10, help=argparse.SUPPRESS)       # frames per candidate in the tune child
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
@@ -147,7 +164,9 @@ def main():
     rend, dec, d, sp, sp_input, planes, obs_feat, obs_img, opts = (w[k] for k in ('rend', 'dec', 'd', 'sp', 'sp_input', 'planes', 'obs_feat',
                                                                                   'obs_img', 'opts'))
     rend.mlp_shape = a.mlp_shape
-    rend.gather_branchless = bool(tune_report and tune_report.get('gather', {}).get('best') == 'branchless') or rend.gather_branchless
+    choice = (tune_report or {}).get('choice', {})
+    rend.gather_branchless = bool(choice.get('gather_branchless')) or rend.gather_branchless
+    rend.exact_grids = bool(choice.get('exact_grids')) or rend.exact_grids
     ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
     R = ro.shape[1]; S = opts['depth_resolution']
     from sherf_amd import _lib as _abi
@@ -195,7 +214,8 @@ def main():
                                         f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
                                parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision,
                                batchnorm=a.bn_mode, mlp_shape=a.mlp_shape,
-                               gather='branchless' if rend.gather_branchless else 'branch'))
+                               gather='branchless' if rend.gather_branchless else 'branch',
+                               exact_grids=bool(rend.exact_grids)))
         if tune_report is not None:
             res['mlp_tune'] = tune_report
         if mlp_ms:

@@ -277,7 +277,12 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
  * persistent state the library keeps).  Host cost is a few microseconds per launch instead of one interpreter round
  * trip each.  phase: bit0 = everything up to and including the NeRF MLP, bit1 = compositing (the caller may add
  * density noise to sample_out[:,3] in between, renderer.py:435-436).
+ * frame->flags & SHERF_FRAME_EXACT_GRIDS (opt-in): the kernels after the compaction (warp, gather, MLP) are launched for the frame's
+ * actual number of valid samples instead of `capacity`: the count is copied to pinned host memory after the compaction and the
+ * call WAITS for it (one hipEventSynchronize, with the encoder chain already enqueued) before it enqueues the rest -- the
+ * reference synchronises at the same point (boolean-mask indexing, renderer.py:320-321).  Results are identical.
  */
+#define SHERF_FRAME_EXACT_GRIDS 1
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */
@@ -293,7 +298,7 @@ typedef struct {
     int32_t* counters; int32_t* ray_base; int32_t* ray_cnt; int32_t* cs_idx; int32_t* cs_vid; float* cs_xs;
     int32_t* dense_vid; uint64_t* ray_mask; int32_t* scan_ws;
     /* tables (a10, a12) */
-    const float* planes; const float* Wa_t; float* planes_f; int32_t P, pad0_;
+    const float* planes; const float* Wa_t; float* planes_f; int32_t P, flags; /* SHERF_FRAME_* */
     const float* obs_feat; const float* Wb_t; float* feat_f; int32_t Hf, Wf;
     const float* obs_img; float* img4; int32_t H, W;
     /* warp + gather (a8-a12) */

@@ -57,7 +57,7 @@ def _frame_fields():
     I('R', 'S')
     f.append(('capacity', _i64))
     P('counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws')
-    P('planes', 'Wa_t', 'planes_f'); I('P', 'pad0_')
+    P('planes', 'Wa_t', 'planes_f'); I('P', 'flags')
     P('obs_feat', 'Wb_t', 'feat_f'); I('Hf', 'Wf')
     P('obs_img', 'img4'); I('H', 'W')
     P('geom', 'cs_tvid', 'tok_bias', 'bounds', 'vox_min')

@@ -22,7 +22,8 @@ constexpr int kRing = 64;
 
 struct DevState {
     bool init = false;
-    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8];
+    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8], ev_cnt;
+    int32_t* host_nv = nullptr;      // pinned: the frame's valid-sample count for SHERF_FRAME_EXACT_GRIDS
 };
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
@@ -101,6 +102,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_fold, hipEventDisableTiming));
                 for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_cnt, hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d.host_nv), 64, 0));
                 d.init = true;
             }
         }
@@ -161,33 +164,50 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
                                        f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, stream_main));
+        // SHERF_FRAME_EXACT_GRIDS: the kernels after the compaction are launched for the frame's ACTUAL number of valid samples instead
+        // of the buffers' capacity (R*S, of which a body fills a few percent: the MLP's grid is then ~96 % workgroups that allocate
+        // 8 waves x 250 VGPRs + 85 KiB LDS only to read the count and exit, one at a time per CU, behind the real ones).  The count is
+        // copied to pinned memory here and awaited just before the warp is enqueued -- the one host synchronisation of this mode (the
+        // reference synchronises at the same point: its boolean-mask indexing, renderer.py:320-321); the encoder chain and the table
+        // folds are enqueued in between and keep the GPU busy meanwhile.  Same results: every kernel clamps to min(count, capacity).
+        const bool exact = (f->flags & SHERF_FRAME_EXACT_GRIDS) != 0;
+        if (exact) {
+            SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));
+            SHERF_HIP_CHECK(hipEventRecord(d.ev_cnt, main));
+        }
         if (stagger < 0) SHERF_RUN(enqueue_encoder());
         if (!stream_aux) SHERF_RUN(fold_tables(stream_main));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
         SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
         if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
+        int64_t cap = f->capacity;
+        if (exact) {
+            SHERF_HIP_CHECK(hipEventSynchronize(d.ev_cnt));
+            int64_t c = *d.host_nv > 0 ? ((int64_t)*d.host_nv + 255) / 256 * 256 : 256;      // whole MLP tile groups
+            if (c < cap) cap = c;
+        }
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
-                                  f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, f->capacity, f->geom,
+                                  f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, cap, f->geom,
                                   f->cs_tvid, stream_main));
         const int gv = (f->gather_split & 2) ? 4 : 0;      // bit 1: branchless voxel-row loads (mode | 4)
         if (f->gather_split & 1) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
-                                          nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1 | gv, f->capacity, f->tokens,
+                                          nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1 | gv, cap, f->tokens,
                                           f->extras, stream_main));
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
-                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 2 | gv, f->capacity, f->tokens,
+                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 2 | gv, cap, f->tokens,
                                           f->extras, stream_main));
         } else {
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
-                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv, f->capacity, f->tokens,
+                                          levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv, cap, f->tokens,
                                           f->extras, stream_main));
         }
         SHERF_PROF(4, main);
-        SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, f->mlp_shape, f->capacity,
+        SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, f->mlp_shape, cap,
                                  f->sample_out, stream_main));
         SHERF_PROF(5, main);
     }

@@ -221,6 +221,9 @@ class ImportanceRenderer(nn.Module):
         self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2' | experimental '8x1split', '8x1split2', '8x1persist')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         self.gather_branchless = os.environ.get('SHERF_GATHER_BRANCHLESS', '0') == '1'   # schedule variant of the voxel taps (sherf_hip.h)
+        # SHERF_FRAME_EXACT_GRIDS (sherf_hip.h): launch warp / gather / MLP for the frame's actual valid-sample count (one host wait per
+        # frame, where the reference has its own) instead of the R*S capacity; same results, chosen per device by sherf_amd.tune
+        self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
         self._smpl_src = smpl
@@ -369,6 +372,7 @@ class ImportanceRenderer(nn.Module):
         feat_f = self._ws.table('feat_f', (Hf, Wf, 64), dev)
         img4 = self._ws.table('img4', (H, W, 4), dev)
         fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, -1), A(wc['Wa_t']), A(planes_f), Pres
+        fr.flags = 1 if opts.get('exact_grids', self.exact_grids) else 0
         fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, -1), A(wc['Wb_t']), A(feat_f), Hf, Wf
         fr.obs_img, fr.img4, fr.H, fr.W = a32(obs_input_img, -1), A(img4), H, W
         fr.tok_bias, fr.bounds = A(wc['tok_bias']), a32(input_data['t_world_bounds'], 6)

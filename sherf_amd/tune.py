@@ -41,9 +41,11 @@ def _time_launches(fn, iters, dev):
     return e0.elapsed_time(e1) / iters
 
 
-def tune_mlp(renderer, decoder, candidates=None, iters=20, warmup=3, tol=0.0):
+def tune_mlp(renderer, decoder, candidates=None, iters=20, warmup=3, tol=0.0, exact_capacity=False):
     """Times `sherf_nerf_mlp` in every candidate shape on the renderer's last frame.  Returns a report dict; never changes the
-    renderer (the caller assigns `renderer.mlp_shape`).  Requires a preceding forward on the GPU with the bf16x3 MLP."""
+    renderer (the caller assigns `renderer.mlp_shape`).  Requires a preceding forward on the GPU with the bf16x3 MLP.
+    exact_capacity: launch for the frame's own sample count (what SHERF_FRAME_EXACT_GRIDS does) instead of the buffers' capacity --
+    the difference between the two timings of a shape is what its grid of empty workgroups costs."""
     last = getattr(renderer, 'last', None)
     if not last:
         raise RuntimeError('tune_mlp needs a rendered frame: call the renderer once first')
@@ -58,6 +60,8 @@ def tune_mlp(renderer, decoder, candidates=None, iters=20, warmup=3, tol=0.0):
         names.insert(0, DEFAULT)
     names.sort(key=lambda n: n != DEFAULT)                              # the reference output first
     nv = min(int(ws['counters'][0]), cap)
+    if exact_capacity:
+        cap = min(cap, max((nv + 255) // 256 * 256, 256))
     tiles = (nv + 31) // 32
     tok_floats = tiles * 3 * 8 * 32 * 4
     tokens0 = ws['tokens'][:tok_floats].clone()
@@ -150,3 +154,53 @@ def tune_gather(renderer, decoder, iters=20, warmup=3):
     if report['branchless']['ok'] and report['branch']['ok'] and report['branchless']['ms'] < 0.98 * report['branch']['ms']:
         best = 'branchless'
     return dict(best=best, valid_samples=nv, iters=iters, variants=report)
+
+
+def _wall_ms(fn, iters, dev):
+    """Wall-clock ms per call of `fn` over `iters` calls bracketed by device synchronisations (what bench.py measures)."""
+    import time
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize(dev)
+    return 1e3 * (time.perf_counter() - t0) / iters
+
+
+FRAME_KEYS = ('mlp_shape', 'gather_branchless', 'exact_grids')
+
+
+def tune_frame(render, renderer, candidates, iters=10, warmup=2):
+    """Times WHOLE frames under each candidate setting of the renderer's launch switches (dicts over FRAME_KEYS; the first one is
+    the baseline) and verifies every candidate's (rgb, depth, acc) against the baseline's bit for bit.  `render()` renders one frame
+    through `renderer` and returns its three outputs.  The renderer's switches are restored; -> {'best': index, 'frames': [...]}."""
+    dev = next(renderer.parameters()).device
+    saved = {k: getattr(renderer, k) for k in FRAME_KEYS}
+    report, ref = [], None
+    try:
+        for cand in candidates:
+            for k in FRAME_KEYS:
+                setattr(renderer, k, cand.get(k, saved[k]))
+            entry = {k: getattr(renderer, k) for k in FRAME_KEYS}
+            try:
+                got = [t.clone() for t in render()]
+                torch.cuda.synchronize(dev)
+                if ref is None:
+                    ref = got
+                    entry['ok'] = bool(all(torch.isfinite(t).all() for t in got[:1] + got[2:]))      # (depth may be inf by definition)
+                else:
+                    entry['ok'] = bool(all(torch.equal(a, b) for a, b in zip(got, ref)))
+                for _ in range(warmup):
+                    render()
+                entry['ms'] = _wall_ms(render, iters, dev)
+            except RuntimeError as ex:
+                entry.update(ok=False, error=str(ex)[:200])
+            report.append(entry)
+    finally:
+        for k, v in saved.items():
+            setattr(renderer, k, v)
+    ok = [i for i, e in enumerate(report) if e.get('ok') and 'ms' in e]
+    best = min(ok, key=lambda i: report[i]['ms']) if ok else 0
+    if best != 0 and (0 not in ok or report[best]['ms'] > 0.99 * report[0]['ms']):      # must beat the baseline by more than the noise
+        best = 0
+    return dict(best=best, iters=iters, frames=report)

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -111,6 +112,9 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 constexpr int hipDeviceAttributeMultiprocessorCount = 63;
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 2; return hipSuccess; }      // two 'CUs': persistent kernels loop
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+constexpr int hipMemcpyDeviceToHost = 2;
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return hipSuccess; }
 
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 inline float unsafeAtomicAdd(float* p, float v) { return std::atomic_ref<float>(*p).fetch_add(v); }

@@ -110,6 +110,9 @@ def test_tune_mlp_checks_every_shape_against_the_default(cpu_product, monkeypatc
     g = tune.tune_gather(h['rend'], h['dec'], iters=1, warmup=0)
     assert g['variants']['branch']['ok'] and g['variants']['branchless']['ok'] and g['variants']['branchless']['max_abs_diff'] == 0.0
     assert torch.equal(ws['tokens'], tok) and torch.equal(ws['extras'], ext)
+    ex = G.hip_render('tiny_nv', options=dict(exact_grids=True))                     # launches sized by the frame's own count
+    assert torch.equal(ex['rgb'], h['rgb']) and torch.equal(ex['acc'], h['acc']) and torch.equal(ex['depth'], h['depth'])
+    assert torch.equal(ex['last']['ws']['sample_out'][:rep['valid_samples']], out[:rep['valid_samples']])
     bl = G.hip_render('tiny_nv', options=dict(gather_branchless=True))               # and inside the frame
     assert torch.equal(bl['rgb'], h['rgb']) and torch.equal(bl['acc'], h['acc'])
     # the guard: corrupt one candidate's result -> it must be reported not ok and not be chosen
@@ -144,10 +147,12 @@ def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
         fn()
         return 1e3 * (time.perf_counter() - t0)
     monkeypatch.setattr(tune, '_time_launches', host_timer)
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--tune-child'])
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--tune-child', '--tune-iters', '1'])
     bench.main()
     rep = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('TUNE_JSON ')][-1][len('TUNE_JSON '):])
     assert rep['best'] in tune.MLP_SHAPES and all(e['ok'] for e in rep['shapes'].values()) and rep['gather']['variants']['branchless']['ok']
+    assert all(e['ok'] for e in rep['shapes_exact_grid'].values()) and len(rep['frame']['frames']) == 4
+    assert all(f['ok'] and f['ms'] > 0 for f in rep['frame']['frames']) and rep['choice'] in [dict((k, f[k]) for k in tune.FRAME_KEYS) for f in rep['frame']['frames']]
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-torch-gpu-baseline',
                                       '--mlp-shape', '8x1prio_il8'])
     bench.main()
