@@ -1,0 +1,71 @@
+"""`sherf_amd.install()`: put the MI355X path under an UNMODIFIED checkout of the reference (second recipe).
+
+    import sys; sys.path.insert(0, '<SHERF>/sherf')
+    import sherf_amd.install; sherf_amd.install.install()
+    # ... then the reference's own entry points: train.py / test loops construct `training.triplane.TriPlaneGenerator`
+    # (train.py:310 -> training_loop.py:193), whose renderer / decoder / sparse tensor are now the classes of this package.
+
+What is rebound (names in the reference's modules; none of its files is edited, none of its objects mutated):
+
+    training.volumetric_rendering.renderer.ImportanceRenderer, training.triplane.ImportanceRenderer -> sherf_amd.renderer.ImportanceRenderer
+    training.triplane.NeRFDecoder                                                                 -> sherf_amd.triplane.NeRFDecoder
+    training.triplane.RaySampler                                                                  -> sherf_amd.ray_sampler.RaySampler
+    training.triplane.spconv (only the attribute path `spconv.core.SparseConvTensor`, triplane.py:137) -> sherf_amd.voxel.SparseConvTensor
+
+The reference's `TriPlaneGenerator` class itself keeps running: its `synthesis` (triplane.py:81-172) calls `renderer.projection`,
+`renderer.coarse_deform_target2c`, `renderer.rgb_enc`, `renderer.SMPL_NEUTRAL['f']` and `renderer(...)`, all of which
+`sherf_amd.renderer.ImportanceRenderer` provides.  With `stub_missing=True` (default) the two CUDA-only third-party packages the
+reference imports at module level -- pytorch3d (K-NN) and spconv -- are replaced by import stubs when they are not installed: every
+use of them sits inside the classes rebound above, so on a ROCm machine the reference then imports without them (calling a stub
+raises).  tests/test_reference_dropin.py runs the reference's generator this way, end to end, against its own unpatched output.
+"""
+import importlib
+import sys
+import types
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__sherf_amd_stub__ = True
+    sys.modules[name] = m
+    return m
+
+
+def _missing(*a, **k):
+    raise RuntimeError('this third-party CUDA package is not installed; sherf_amd replaces the reference code that used it')
+
+
+def stub_missing_packages():
+    """Import stubs for pytorch3d.ops.knn and spconv.pytorch / spconv.core when the real packages are absent."""
+    made = []
+    try:
+        importlib.import_module('pytorch3d.ops.knn')
+    except Exception:
+        p3d, ops = _stub('pytorch3d'), _stub('pytorch3d.ops')
+        knn = _stub('pytorch3d.ops.knn', knn_points=_missing, knn_gather=_missing)
+        p3d.ops, ops.knn = ops, knn
+        made.append('pytorch3d')
+    try:
+        importlib.import_module('spconv.pytorch')
+    except Exception:
+        from . import voxel
+        core = _stub('spconv.core', SparseConvTensor=voxel.SparseConvTensor)
+        pt = _stub('spconv.pytorch', core=core, SparseConvTensor=voxel.SparseConvTensor, SparseSequential=_missing, SubMConv3d=_missing,
+                   SparseConv3d=_missing, SparseInverseConv3d=_missing)
+        sp = _stub('spconv', pytorch=pt, core=core)
+        made.append('spconv')
+    return made
+
+
+def install(stub_missing=True):
+    """Rebinds the reference's names to this package's classes (see the module docstring). Idempotent. -> dict of what was done."""
+    from . import ray_sampler, renderer, triplane, voxel
+    stubs = stub_missing_packages() if stub_missing else []
+    R = importlib.import_module('training.volumetric_rendering.renderer')
+    T = importlib.import_module('training.triplane')
+    R.ImportanceRenderer = T.ImportanceRenderer = renderer.ImportanceRenderer
+    T.NeRFDecoder = triplane.NeRFDecoder
+    T.RaySampler = ray_sampler.RaySampler
+    T.spconv = types.SimpleNamespace(core=types.SimpleNamespace(SparseConvTensor=voxel.SparseConvTensor))
+    return dict(stubs=stubs, modules=(R.__name__, T.__name__))

@@ -26,6 +26,23 @@ MLP_SHAPES = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4
 V = 6890
 
 
+def compute_normal(vertices, faces):
+    """renderer.py:50-63. The reference's `norm[:, faces[:, c]] += n` is an index ASSIGNMENT: of the faces that list a
+    vertex in column c exactly one contributes (the last on CPU, unspecified on CUDA). We take the highest face index,
+    deterministically. vertices [B,V,3], faces [F,3]."""
+    tris = vertices[:, faces]
+    n = torch.cross(tris[:, :, 1] - tris[:, :, 0], tris[:, :, 2] - tris[:, :, 0], dim=-1)
+    n = n / torch.sqrt((n ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
+    norm = torch.zeros_like(vertices)
+    nf = faces.shape[0]
+    ar = torch.arange(nf, device=faces.device)
+    for c in range(3):
+        last = torch.full((vertices.shape[1],), -1, dtype=torch.long, device=faces.device).scatter_reduce_(0, faces[:, c], ar, reduce='amax')
+        has = last >= 0
+        norm[:, has] = norm[:, has] + n[:, last[has]]
+    return norm / torch.sqrt((norm ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
+
+
 # ---------------------------------------------------------------------------------------------------
 # parameter containers with the reference's module tree (renderer.py:875-993)
 # ---------------------------------------------------------------------------------------------------
@@ -264,6 +281,60 @@ class ImportanceRenderer(nn.Module):
             src = self._smpl_src if self._smpl_src is not None else read_pickle(self._smpl_path)
             self._smpl_dev = SMPL_to_tensor(src, device)
         return self._smpl_dev
+
+    # ---- the two helpers the reference's TriPlaneGenerator.synthesis calls on its renderer (triplane.py:113,132) ------------
+    def projection(self, query_pts, R, T, K, face=None):
+        """renderer.py:686-704: pixel coordinates of `query_pts` [bs,N,3] in every view of R [bs,views,3,3], T [bs,views,3,1],
+        K [bs,views,3,3] -> xy [bs,views,N,2]; with `face` also the mask of vertices whose normal faces the (first) camera.
+        Per-frame glue over the 6890 vertices (not the hot path): plain device tensor ops."""
+        R, T, K, q = R.float(), T.float(), K.float(), query_pts.float()
+        xyz = torch.einsum('bvij,bnj->bvni', R, q) + T[:, :, None, :, 0]                       # [bs,views,N,3]
+        mask = None
+        if face is not None:
+            normal = compute_normal(q, face)                                                   # [bs,N,3]
+            ncam = torch.einsum('bvij,bnj->bvni', R, normal)
+            mask = ((ncam * xyz).sum(-1) < 0).squeeze(1)                                       # renderer.py:693-695
+        h = torch.einsum('bvij,bvnj->bvni', K, xyz)
+        xy = h[..., :2] / (h[..., 2:] + 1e-5)
+        return (xy, mask) if face is not None else xy
+
+    def t2c_table(self, params, t_params):
+        """Per-vertex affine of coarse_deform_target2c (renderer.py:558-621; SURVEY appendix A.5: x_c = P[j] x_s + q[j]) for the
+        pose / shape in `params` against the canonical `t_params`, built by the HIP SMPL kernels -> T2C [V,12] = (P row-major | q)."""
+        dev = params['poses'].device
+        smpl = self._smpl(dev)
+        f32 = lambda t: t.detach().float().contiguous()
+        poses = torch.stack([f32(params['poses']).view(72), f32(t_params['poses']).view(72)])
+        shapes = torch.stack([f32(params['shapes']).view(10), f32(t_params['shapes']).view(10)])
+        A = torch.zeros(2, 24, 12, device=dev); pf = torch.zeros(2, 207, device=dev)
+        PO = torch.zeros(2, V, 3, device=dev); SO = torch.zeros(2, V, 3, device=dev); T2C = torch.zeros(V, 12, device=dev)
+        P, st = _lib.ptr, _lib.stream()
+        _lib.call('sherf_smpl_bones', P(poses), P(shapes), 2, P(smpl['J_template']), P(smpl['J_shapedirs']), P(smpl['parents_i32']),
+                  P(A), P(pf), st)
+        _lib.call('sherf_smpl_offsets', P(smpl['posedirs_flat']), P(smpl['shapedirs']), P(pf), P(shapes), 2, P(PO), P(SO), st)
+        _lib.call('sherf_smpl_t2c_table', P(smpl['weights']), P(A[0]), P(A[1]), P(PO[0]), P(SO[0]), P(PO[1]), P(T2C), st)
+        return T2C
+
+    def coarse_deform_target2c(self, params, vertices, t_params, query_pts, query_viewdirs=None):
+        """renderer.py:558-621 for callers outside the frame (triplane.py:132 passes the posed vertices themselves): nearest posed
+        vertex of every query point (exact, lowest index on ties), then that vertex's target->canonical affine from the HIP SMPL
+        kernels.  Inside `forward` the same table is applied by the fused warp kernel; this method is per-frame glue."""
+        if query_pts.shape[0] != 1:
+            raise RuntimeError('per-GPU batch must be 1, as in the reference (renderer.py:567)')
+        f32 = lambda t: t.detach().float().contiguous()
+        T2C = self.t2c_table(params, t_params)
+        xs = torch.matmul(f32(vertices).view(V, 3) - f32(params['Th']).view(1, 3), f32(params['R']).view(3, 3))
+        q = f32(query_pts).view(-1, 3)
+        if q.shape[0] == V and torch.equal(q, xs):
+            vid = torch.arange(V, device=q.device)                        # every vertex is its own nearest vertex
+        else:
+            vid = torch.cat([(((c[:, None, 0] - xs[None, :, 0]) ** 2 + (c[:, None, 1] - xs[None, :, 1]) ** 2)
+                              + (c[:, None, 2] - xs[None, :, 2]) ** 2).argmin(1) for c in q.split(8192)])
+        Pm, t = T2C[vid, :9].view(-1, 3, 3), T2C[vid, 9:]
+        can = (torch.einsum('nij,nj->ni', Pm, q) + t).view(1, -1, 3)
+        if query_viewdirs is not None:
+            return can, torch.einsum('nij,nj->ni', Pm, f32(query_viewdirs).view(-1, 3)).view(1, -1, 3)
+        return can
 
     # ---- weights -----------------------------------------------------------------------------
     def _weights(self, decoder, device):

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .ray_sampler import RaySampler
-from .renderer import ImportanceRenderer, V
+from .renderer import ImportanceRenderer, V, compute_normal  # noqa: F401  (compute_normal: re-exported for the tests / oracle pins)
 from .voxel import SparseConvTensor
 
 
@@ -37,23 +37,6 @@ class NeRFDecoder(nn.Module):
     def forward(self, *a, **k):
         raise RuntimeError('NeRFDecoder is evaluated inside the fused HIP kernel (sherf_nerf_mlp); '
                            'pass it to ImportanceRenderer.forward as `decoder`')
-
-
-def compute_normal(vertices, faces):
-    """renderer.py:50-63. The reference's `norm[:, faces[:, c]] += n` is an index ASSIGNMENT: of the faces that list a
-    vertex in column c exactly one contributes (the last on CPU, unspecified on CUDA). We take the highest face index,
-    deterministically. vertices [B,V,3], faces [F,3]."""
-    tris = vertices[:, faces]
-    n = torch.cross(tris[:, :, 1] - tris[:, :, 0], tris[:, :, 2] - tris[:, :, 0], dim=-1)
-    n = n / torch.sqrt((n ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
-    norm = torch.zeros_like(vertices)
-    nf = faces.shape[0]
-    ar = torch.arange(nf, device=faces.device)
-    for c in range(3):
-        last = torch.full((vertices.shape[1],), -1, dtype=torch.long, device=faces.device).scatter_reduce_(0, faces[:, c], ar, reduce='amax')
-        has = last >= 0
-        norm[:, has] = norm[:, has] + n[:, last[has]]
-    return norm / torch.sqrt((norm ** 2).sum(-1, keepdim=True)).clamp_min(1e-8)
 
 
 class TriPlaneGenerator(nn.Module):
@@ -122,23 +105,10 @@ class TriPlaneGenerator(nn.Module):
     def canonical_obs_vertices(self, input_data):
         """coarse_deform_target2c(obs_params, obs_vertices, t_params, smpl_obs_pts) (triplane.py:129-132) through the
         per-vertex affine table built by the HIP SMPL kernels (each vertex is its own nearest vertex)."""
-        r = self.renderer
-        dev = input_data['obs_vertices'].device
-        smpl = r._smpl(dev)
-        op, tp = input_data['obs_params'], input_data['t_params']
-        f32 = lambda t: t.detach().float().contiguous()
-        poses = torch.stack([f32(op['poses']).view(72), f32(tp['poses']).view(72)])
-        shapes = torch.stack([f32(op['shapes']).view(10), f32(tp['shapes']).view(10)])
-        A = torch.zeros(2, 24, 12, device=dev); pf = torch.zeros(2, 207, device=dev)
-        PO = torch.zeros(2, V, 3, device=dev); SO = torch.zeros(2, V, 3, device=dev); T2C = torch.zeros(V, 12, device=dev)
-        P, st = _lib.ptr, _lib.stream()
-        _lib.call('sherf_smpl_bones', P(poses), P(shapes), 2, P(smpl['J_template']), P(smpl['J_shapedirs']), P(smpl['parents_i32']),
-                  P(A), P(pf), st)
-        _lib.call('sherf_smpl_offsets', P(smpl['posedirs_flat']), P(smpl['shapedirs']), P(pf), P(shapes), 2, P(PO), P(SO), st)
-        _lib.call('sherf_smpl_t2c_table', P(smpl['weights']), P(A[0]), P(A[1]), P(PO[0]), P(SO[0]), P(PO[1]), P(T2C), st)
-        xs = torch.matmul(f32(input_data['obs_vertices']).view(V, 3) - f32(op['Th']).view(1, 3), f32(op['R']).view(3, 3))
-        Pm, q = T2C[:, :9].view(V, 3, 3), T2C[:, 9:]
-        return (torch.einsum('vij,vj->vi', Pm, xs) + q).unsqueeze(0)
+        op = input_data['obs_params']
+        verts = input_data['obs_vertices'].float()
+        smpl_obs_pts = torch.matmul(verts.reshape(1, -1, 3) - op['Th'].float().view(1, 1, 3), op['R'].float().view(1, 3, 3))
+        return self.renderer.coarse_deform_target2c(op, verts, input_data['t_params'], smpl_obs_pts)
 
     def prepare_sp_input(self, vertex, xyz):
         """triplane.py:174-217 (big_box=True): 5 mm voxel coords of `xyz` inside the +-5 cm box of `vertex`."""
