@@ -107,7 +107,9 @@ class TriPlaneGenerator(nn.Module):
         per-vertex affine table built by the HIP SMPL kernels (each vertex is its own nearest vertex)."""
         op = input_data['obs_params']
         verts = input_data['obs_vertices'].float()
-        smpl_obs_pts = torch.matmul(verts.reshape(1, -1, 3) - op['Th'].float().view(1, 1, 3), op['R'].float().view(1, 3, 3))
+        # (the same expression the renderer uses for the posed vertices: bit-equal, so every vertex is recognised as its own nearest one)
+        smpl_obs_pts = torch.matmul(verts.detach().contiguous().view(V, 3) - op['Th'].detach().float().contiguous().view(1, 3),
+                                    op['R'].detach().float().contiguous().view(3, 3)).view(1, V, 3)
         return self.renderer.coarse_deform_target2c(op, verts, input_data['t_params'], smpl_obs_pts)
 
     def prepare_sp_input(self, vertex, xyz):

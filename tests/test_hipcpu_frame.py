@@ -180,6 +180,37 @@ def test_generator_glue(cpu_product):
     P.test_generator_synthesis_end_to_end()
 
 
+def test_renderer_helpers_the_reference_generator_calls(cpu_product):
+    """ImportanceRenderer.projection / coarse_deform_target2c (the two renderer methods the reference's TriPlaneGenerator.synthesis
+    calls, triplane.py:113,132) against the oracle's literal chains -- for arbitrary query points with view directions, not only the
+    vertices themselves."""
+    fx = G.fixture('tiny_nv')
+    rend, _ = G.hip_modules()
+    d = G.to_cuda(fx['input_data'])
+    dd = fixtures.to_torch(fx['input_data'])
+    st = O.smpl_tensors(fx['smpl'])
+    op, tp = dd['obs_params'], dd['t_params']
+    verts = dd['obs_vertices'][0]
+    xs = torch.matmul(verts - op['Th'].view(1, 3), op['R'].view(3, 3))
+    g = torch.Generator().manual_seed(3)
+    pick = torch.randint(0, xs.shape[0], (777,), generator=g)
+    q = xs[pick] + 0.02 * torch.randn(777, 3, generator=g)
+    dirs = torch.nn.functional.normalize(torch.randn(777, 3, generator=g), dim=-1)
+    _, vid = O.nearest_vertex(q, xs)
+    ref_c, ref_v = O.target_to_canonical(st, op, tp, None, q, dirs, vid)
+    can, vdir = rend.coarse_deform_target2c(d['obs_params'], d['obs_vertices'], d['t_params'], G.dev_tensor(q[None].clone()), G.dev_tensor(dirs[None].clone()))
+    assert float((G.plain(can)[0] - ref_c).abs().max()) < 5e-6 and float((G.plain(vdir)[0] - ref_v).abs().max()) < 5e-6
+    own = rend.coarse_deform_target2c(d['obs_params'], d['obs_vertices'], d['t_params'], G.dev_tensor(xs[None].clone()))   # triplane.py:132
+    ref_own, _ = O.target_to_canonical(st, op, tp, None, xs, None, torch.arange(xs.shape[0]))
+    assert float((G.plain(own)[0] - ref_own).abs().max()) < 5e-6
+    xy, mask = rend.projection(d['obs_vertices'].reshape(1, -1, 3), d['obs_R_all'], d['obs_T_all'], d['obs_K_all'], rend.SMPL_NEUTRAL['f'])
+    ref_uv = O.project_uv(verts, dd['obs_R_all'][0, 0], dd['obs_T_all'][0, 0], dd['obs_K_all'][0, 0])
+    assert tuple(xy.shape) == (1, 1, xs.shape[0], 2) and tuple(mask.shape) == (1, xs.shape[0]) and mask.dtype == torch.bool
+    assert float((G.plain(xy)[0, 0] - ref_uv).abs().max()) < 1e-3                       # pixels
+    only_xy = rend.projection(d['obs_vertices'].reshape(1, -1, 3), d['obs_R_all'], d['obs_T_all'], d['obs_K_all'])
+    assert torch.equal(G.plain(only_xy), G.plain(xy)) and 0.2 < float(G.plain(mask).float().mean()) < 0.8
+
+
 def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
     """TriPlaneGenerator.forward(input_data, z, c) as the reference calls it (test_loop.py:189-190): ResNet-18 code -> mapping ->
     StyleGAN2 tri-planes (bias_act / upfirdn2d kernels), ResNet-18 feature map, glue, renderer -- all three libraries built for the
