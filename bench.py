@@ -154,7 +154,8 @@ def main():
     dev = _device(lrank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('SHERF_DIST_BACKEND', 'nccl')          # 'nccl' = RCCL; 'gloo' only for the CPU dry-run in tests/
+        dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
     from sherf_amd import dist as sdist  # noqa: F401
 
     if os.environ.get('SHERF_DEBUG'):

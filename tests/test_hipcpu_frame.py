@@ -166,6 +166,31 @@ def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
     assert tg.get('value', 0) > 0, tg
 
 
+def test_bench_two_ranks_dry_run(cpu_product):
+    """bench.py as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), two ranks over gloo
+    on the host build: every rank renders its own view, the step ends with the all_gather of the tiles, rank 0 prints the one line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   SHERF_DIST_BACKEND='gloo', SHERF_HIPCPU_LIB=_lib.LIB_PATH, OMP_NUM_THREADS='2')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(G.ROOT, 'tests', 'bench_dist_child.py')], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-600:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]          # rank 0 prints ONE line
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['parallelism'] == 'views x2'
+    assert res['value'] > 0 and abs(res['value'] - 2 * res['config']['rays'] * res['steps'] / (res['ms_per_step'] * 1e-3 * res['steps'])) < 1e-6 * res['value']
+
+
 def test_eval_mode_batchnorm_and_edge_cases(cpu_product):
     P.test_eval_mode_batchnorm_uses_running_stats()
     P.test_no_valid_samples_returns_background()
