@@ -6,7 +6,8 @@
 A step = one pass of the hot path over one 512x512 frame x 64 samples/ray of synthetic input already resident
 in HBM (BASELINE.json config 2: single subject novel view).  With N > 1 every rank renders its own target view
 of the same subject (BASELINE config 4: views sharded across GPUs, weak scaling) and the step ends with the RCCL
-all_gather of the rendered [rays, 5] tiles.  Rank 0 prints ONE JSON line.
+all_gather of the rendered [rays, 5] tiles (asynchronous, awaited one step later; the last one inside the timed region).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -178,12 +179,23 @@ def main():
             rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)
             tile = torch.cat([rgb[0], depth[0], acc[0]], 1)
             if world > 1:
+                # the gather of this frame's tiles runs on RCCL's own stream (async_op) and is awaited one step later, so that it
+                # overlaps the next frame's sampling instead of stalling the render stream for a latency-bound 5 MB exchange
                 out = [torch.empty_like(tile) for _ in range(world)]
-                torch.distributed.all_gather(out, tile)
+                inflight.append((torch.distributed.all_gather(out, tile, async_op=True), out, tile))
+                while len(inflight) > 1:
+                    inflight.pop(0)[0].wait()
         return tile
+
+    inflight = []
+
+    def drain():                      # every gather issued so far is complete (on the render stream's timeline) after this
+        while inflight:
+            inflight.pop(0)[0].wait()
 
     for _ in range(a.warmup):
         step()
+    drain()
     _abi.call('sherf_profile_frames', 1)       # HIP events around sherf_nerf_mlp etc. on their launch streams (csrc/frame.hip)
     if world > 1:
         torch.distributed.barrier()
@@ -191,6 +203,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()                                        # the last frame's gather belongs to the timed region
     host_dt = time.perf_counter() - t0             # enqueue time of the K steps (the host runs ahead of the GPU)
     torch.cuda.synchronize()
     if world > 1:
