@@ -277,6 +277,59 @@ def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
     assert G.rel(G.plain(out['weights_image']).reshape(-1), o['acc']) < 2e-3
 
 
+def test_full_training_step_with_the_reconstruction_loss(cpu_product, monkeypatch):
+    """BASELINE config 5, the whole step as training_loop.py:354-386 runs it, on the host build: TriPlaneGenerator with its own producers
+    -> renderer recorded as one autograd node -> reconstruction loss of loss.py:103-176 (sherf_amd/loss.py) -> backward through the HIP
+    backward pipeline and on into the StyleGAN2 / ResNet producers -> flat-gradient sanitising -> optimiser step."""
+    from sherf_amd import loss as L
+    from sherf_amd.triplane import TriPlaneGenerator
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    fx = dict(G.fixture('tiny_nv'))
+    rend, dec = G.hip_modules.__wrapped__()
+    rend.enable_autograd = True
+    opts = dict(fx['options']); opts['density_noise'] = 0
+    gen = TriPlaneGenerator(512, 0, 48, True, True, True, True, True, img_resolution=32, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                            rendering_kwargs=opts, smpl=G.smpl(), channel_base=512, channel_max=16, num_fp16_res=0,
+                            conv_clamp=None, fused_modconv_default='inference_only')
+    gen.renderer, gen.decoder = rend, dec
+    fixtures.load_seeded_state(gen.conv1d_projection, 'generator.conv1d_projection.')
+    for name, mod in (('backbone', gen.backbone), ('encoder_2d', gen.encoder_2d), ('encoder_2d_feature', gen.encoder_2d_feature)):
+        with torch.no_grad():
+            for n, t in list(mod.named_parameters()) + list(mod.named_buffers()):
+                v = None if n.endswith('resample_filter') else fixtures.seeded_param(f'{name}.{n}', t.shape)
+                if v is not None:
+                    t.copy_(torch.from_numpy(np.asarray(v, np.float32).reshape(tuple(t.shape))).to(t.dtype))
+    gen.eval(); rend.train(); dec.train()
+    d = G.to_cuda(fx['input_data'])
+    H, W = d['obs_img_all'].shape[-2:]
+    g = torch.Generator().manual_seed(4)
+    d['img_all'] = torch.rand(1, 1, 3, H, W, generator=g)
+    d['bkgd_msk_all'] = (torch.rand(1, 1, H * W, generator=g) > 0.5).to(torch.uint8)
+    d['mask_at_box_all'] = G.plain(d['mask_at_box_all']).bool()
+    assert int(d['mask_at_box_all'].sum()) > 100
+    watch = {'decoder.pts_linears.0.weight': dec.pts_linears[0].weight, 'renderer.conv1d_reprojection.weight': rend.conv1d_reprojection.weight,
+             'renderer.encoder_3d.conv0.0.weight': rend.encoder_3d.conv0[0].weight, 'conv1d_projection.weight': gen.conv1d_projection.weight,
+             'backbone.synthesis.b256.torgb.weight': gen.backbone.synthesis.b256.torgb.weight,
+             'encoder_2d_feature.conv1.weight': gen.encoder_2d_feature.feature_extractor.conv1.weight if hasattr(gen.encoder_2d_feature, 'feature_extractor')
+             else next(gen.encoder_2d_feature.parameters())}
+    before = {k: G.plain(v).clone() for k, v in watch.items()}
+    loss = L.ReconstructionLoss(torch.device('cpu'), gen, neural_rendering_resolution_initial=32)
+    opt = torch.optim.SGD([p for p in gen.parameters()], lr=1e-3)
+    out = L.training_step(gen, opt, loss, d, torch.zeros(1, 512), torch.zeros(1, 25), gain=1, num_gpus=1, use_sr_module=False)
+    total, img_l, acc_l, ssim_s, lp, _ = [t.detach() for t in out]
+    assert all(bool(torch.isfinite(G.plain(t)).all()) for t in (total, img_l, acc_l, ssim_s)) and float(lp) == 0.0
+    assert abs(float(total) - (100 * float(img_l) + 10 * float(acc_l) + 1 - float(ssim_s))) < 1e-3 * abs(float(total))
+    for k, v in watch.items():
+        assert v.grad is not None and bool(torch.isfinite(G.plain(v.grad)).all()) and float(G.plain(v.grad).abs().max()) > 0, k
+        assert not torch.equal(G.plain(v), before[k]), k                       # the step moved it
+    # a second forward with the updated weights lowers the loss it was stepped on (small step along -grad)
+    with torch.no_grad():
+        rend.enable_autograd = False
+        gen_img, _ = loss.run_G(d, torch.zeros(1, 512), torch.zeros(1, 25), 32, use_sr_module=False)
+        after = loss.terms(gen_img, d)[0]
+    assert float(after) < float(total)
+
+
 def test_size_independent_properties_and_rotation(cpu_product):
     P.test_deterministic_and_ray_independent()
     P.test_ragged_shapes(9, 31, 128)
