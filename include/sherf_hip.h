@@ -330,6 +330,21 @@ int sherf_struct_sizes(int32_t* sizes_host, int32_t n);
 int sherf_profile_frames(int enable);
 int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t* n_host);
 
+/* a17 / SURVEY 8(f) rank 1 -- the per-frame glue in front of the renderer call (triplane.py:105-137, 174-217), inference time:
+ * sherf_vertex_features: per-vertex 32-d features of the observation view.  verts [V][3] observation-pose vertices; tri [F][3] faces
+ *   and last_face [3][V] = highest face index listing the vertex in column c, or -1 (the deterministic reading of the reference's
+ *   index-assignment normals, renderer.py:50-63; a constant of the SMPL asset); cam_R [9], cam_T [3], cam_K [9] of the observation
+ *   camera; feat [64][Hf][Wf] and img [3][H][W] (NCHW as the encoders emit them; taps bilinear, zeros padding, align_corners=True, grid
+ *   normalised by the image size); Wp [32][96], bp [32] = conv1d_projection.  -> f3d [V][32] (back-facing rows zero), front [V] (0/1).
+ * sherf_voxelize: t_verts [V][3] canonical vertices, can [V][3] canonicalised observation vertices -> bounds [2][3] (min - 5 cm,
+ *   max + 5 cm), coord [V][4] = (0, z, y, x) 5 mm voxel indices (round half to even), out_sh [3] = (ceil(extent / 0.005) | 31) + 1
+ *   in (z, y, x) order (device memory: the caller reads the three integers back to size the sparse tensor). */
+int sherf_vertex_features(const float* verts, const int32_t* tri, const int32_t* last_face, int V, const float* cam_R,
+                          const float* cam_T, const float* cam_K, const float* feat, int Hf, int Wf, const float* img, int H, int W,
+                          const float* Wp, const float* bp, float* f3d, uint8_t* front, sherf_stream_t stream);
+int sherf_voxelize(const float* t_verts, const float* can, int V, float* bounds, int32_t* coord, int32_t* out_sh,
+                   sherf_stream_t stream);
+
 int sherf_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* origins,
                       float* dirs, sherf_stream_t stream);
 /* a1+a2: get_rays + get_near_far + near/far packing (training/RenderPeople_dataset.py:14-27, 68-101, 129-134)

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsherf_hip.so')
-SOURCES = ['smpl.hip', 'sample.hip', 'gather.hip', 'mlp.hip', 'composite.hip', 'svox.hip', 'rays.hip', 'fold.hip', 'frame.hip']
+SOURCES = ['smpl.hip', 'sample.hip', 'gather.hip', 'mlp.hip', 'composite.hip', 'svox.hip', 'rays.hip', 'fold.hip', 'glue.hip', 'frame.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=on', '-Wno-unused-value',
          '-mcode-object-version=5']   # v5 loads on every ROCm >= 5 runtime (torch bundles its own libamdhip64)
 

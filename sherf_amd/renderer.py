@@ -127,6 +127,13 @@ def SMPL_to_tensor(params, device):
     out['posedirs_flat'] = out['posedirs'].reshape(V * 3, 207).contiguous()
     out['weights'] = out['weights'].contiguous()
     out['shapedirs'] = out['shapedirs'].contiguous()
+    # for sherf_vertex_features (csrc/glue.hip): faces as int32 and, per face column, the highest face index listing each vertex
+    f = np.asarray(params['f']).astype(np.int64)
+    last = np.full((3, out['v_template'].shape[0]), -1, np.int32)
+    for c in range(3):
+        np.maximum.at(last[c], f[:, c], np.arange(f.shape[0], dtype=np.int32))
+    out['f_i32'] = torch.tensor(f.astype(np.int32), dtype=torch.int32, device=device).contiguous()
+    out['last_face_i32'] = torch.tensor(last, dtype=torch.int32, device=device).contiguous()
     return out
 
 

@@ -8,6 +8,8 @@
 The feature PRODUCERS (StyleGAN2 backbone, ResNet18 encoders, super-resolution) are outside the hot path
 (SURVEY.md section 8f rank 2): they are taken from the reference package when it is importable, or injected.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -72,6 +74,9 @@ class TriPlaneGenerator(nn.Module):
         self.rendering_kwargs = rendering_kwargs
         self.use_1d_feature, self.use_2d_feature, self.use_3d_feature = use_1d_feature, use_2d_feature, use_3d_feature
         self._last_planes = None
+        # vertex features + voxelisation as two HIP launches (csrc/glue.hip) instead of ~40 tensor ops, when no
+        # gradient is being recorded (training keeps the tensor-op glue so that autograd reaches the image encoders)
+        self.fused_glue = os.environ.get('SHERF_FUSED_GLUE', '0') == '1'
 
     def mapping(self, z, c, input_img=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         z = self.encoder_2d(input_img)
@@ -101,6 +106,34 @@ class TriPlaneGenerator(nn.Module):
         f3d = self.conv1d_projection(torch.cat((vf, vrgb), -1).permute(0, 2, 1)).permute(0, 2, 1)
         f3d = f3d * mask.unsqueeze(-1).to(f3d.dtype)                                          # triplane.py:126
         return f3d, mask
+
+    def fused_vertex_features(self, input_data, obs_input_img, obs_input_feature):
+        """`vertex_features` as ONE launch (sherf_vertex_features): -> (f3d [1,V,32], front mask [1,V] bool)."""
+        dev = obs_input_img.device
+        smpl = self.renderer._smpl(dev)
+        f32 = lambda t: t.detach().float().contiguous()
+        verts = f32(input_data['obs_vertices']).view(V, 3)
+        Rc, Tc, K = f32(input_data['obs_R_all']).view(9), f32(input_data['obs_T_all']).view(3), f32(input_data['obs_K_all']).view(9)
+        feat, img = f32(obs_input_feature), f32(obs_input_img)
+        Wp, bp = f32(self.conv1d_projection.weight).view(32, 96), f32(self.conv1d_projection.bias)
+        f3d = torch.empty(V, 32, device=dev, dtype=torch.float32)
+        front = torch.empty(V, device=dev, dtype=torch.uint8)
+        P = _lib.ptr
+        _lib.call('sherf_vertex_features', P(verts), P(smpl['f_i32']), P(smpl['last_face_i32']), V, P(Rc), P(Tc), P(K), P(feat), feat.shape[-2],
+                  feat.shape[-1], P(img), img.shape[-2], img.shape[-1], P(Wp), P(bp), P(f3d), P(front), _lib.stream())
+        return f3d.unsqueeze(0), front.bool().unsqueeze(0)
+
+    def fused_prepare_sp_input(self, vertex, xyz):
+        """`prepare_sp_input` as ONE launch (sherf_voxelize) + the read-back of the three shape integers."""
+        dev = xyz.device
+        f32 = lambda t: t.detach().float().contiguous()
+        tv, can = f32(vertex).view(V, 3), f32(xyz).view(V, 3)
+        bounds = torch.empty(2, 3, device=dev, dtype=torch.float32)
+        coord = torch.empty(V, 4, device=dev, dtype=torch.int32)
+        out_sh = torch.empty(3, device=dev, dtype=torch.int32)
+        P = _lib.ptr
+        _lib.call('sherf_voxelize', P(tv), P(can), V, P(bounds), P(coord), P(out_sh), _lib.stream())
+        return {'coord': coord, 'out_sh': out_sh.tolist(), 'batch_size': 1, 'bounds': bounds.unsqueeze(0)}, None
 
     def canonical_obs_vertices(self, input_data):
         """coarse_deform_target2c(obs_params, obs_vertices, t_params, smpl_obs_pts) (triplane.py:129-132) through the
@@ -147,9 +180,10 @@ class TriPlaneGenerator(nn.Module):
             self._last_planes = planes
         obs_input_img = input_data['obs_img_all'][:, 0]
         obs_input_feature = self.encoder_2d_feature(obs_input_img, extract_feature=True)
-        f3d, mask = self.vertex_features(input_data, obs_input_img, obs_input_feature)
+        fused = self.fused_glue and not torch.is_grad_enabled() and obs_input_img.shape[0] == 1
+        f3d, mask = (self.fused_vertex_features if fused else self.vertex_features)(input_data, obs_input_img, obs_input_feature)
         can = self.canonical_obs_vertices(input_data)
-        sp_input, _ = self.prepare_sp_input(input_data['t_vertices'].float(), can)
+        sp_input, _ = (self.fused_prepare_sp_input if fused else self.prepare_sp_input)(input_data['t_vertices'].float(), can)
         sp = SparseConvTensor(f3d.reshape(-1, f3d.shape[-1]), sp_input['coord'], sp_input['out_sh'], sp_input['batch_size'])
         planes = planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
         if test_flag:

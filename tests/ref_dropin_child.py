@@ -25,8 +25,8 @@ def main():
     from sherf_amd import _lib
     import sherf_amd.renderer as AR
     tmp = tempfile.mkdtemp(prefix='sherf_dropin_')
-    fwd = build_cpu.build('sherf_hipcpu_full', ['smpl.hip', 'sample.hip', 'gather.hip', 'mlp.hip', 'composite.hip', 'svox.hip', 'rays.hip',
-                                                'fold.hip', 'frame.hip'], tmp, compiler=build_cpu.CLANG)
+    from sherf_amd.build import SOURCES
+    fwd = build_cpu.build('sherf_hipcpu_full', SOURCES, tmp, compiler=build_cpu.CLANG)
     # the product on host tensors (what the cpu_product fixture of tests/test_hipcpu_frame.py does)
     _lib.LIB_PATH, _lib._lib = fwd, None
     _lib.ptr = lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -23,3 +23,9 @@ def test_tuner_shapes_bit_identical_on_device(cfg):
     assert not bad, bad
     again = G.hip_render(cfg)                                   # the tuner leaves the renderer and its workspace as found
     assert torch.equal(again['rgb'], h['rgb']) and torch.equal(again['acc'], h['acc'])
+
+
+def test_fused_glue_kernels_on_device():
+    """csrc/glue.hip on hardware: the same comparison the CPU suite runs on the host build (tests/test_hipcpu_frame.py)."""
+    from tests.test_hipcpu_frame import check_fused_glue
+    print('fraction of vertices whose back-face bit differs from the tensor-op glue:', check_fused_glue())

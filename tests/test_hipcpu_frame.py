@@ -18,7 +18,7 @@ from tests import gpu_common as G
 from tests import test_gpu_parity as P
 from tests.hipcpu import build_cpu
 
-FWD_SOURCES = ['smpl.hip', 'sample.hip', 'gather.hip', 'mlp.hip', 'composite.hip', 'svox.hip', 'rays.hip', 'fold.hip', 'frame.hip']
+from sherf_amd.build import SOURCES as FWD_SOURCES   # every source of libsherf_hip.so
 
 
 @pytest.fixture(scope='module')
@@ -203,6 +203,43 @@ def test_eval_mode_batchnorm_and_edge_cases(cpu_product):
 def test_generator_glue(cpu_product):
     P.test_generator_glue_vertex_features_and_voxelisation()
     P.test_generator_synthesis_end_to_end()
+
+
+def check_fused_glue():
+    """csrc/glue.hip (sherf_vertex_features, sherf_voxelize: SURVEY 8f rank 1) against the tensor-op glue it replaces at inference time and,
+    through it, the oracle: same culled vertices, features to 1e-5, identical voxel coordinates / shape / bounds, identical image."""
+    fx = dict(G.fixture('tiny'))
+    gen = P._generator(fx)
+    d = G.to_cuda(fx['input_data'])
+    feat = G.to_cuda(fx['obs_feat'])
+    with torch.no_grad():
+        f_ref, m_ref = gen.vertex_features(d, d['obs_img_all'][:, 0], feat)
+        f_hip, m_hip = gen.fused_vertex_features(d, d['obs_img_all'][:, 0], feat)
+        can = gen.canonical_obs_vertices(d)
+        s_ref, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
+        s_hip, _ = gen.fused_prepare_sp_input(d['t_vertices'].float(), can)
+    m_ref, m_hip = G.plain(m_ref), G.plain(m_hip)
+    same = m_ref == m_hip
+    assert tuple(m_hip.shape) == (1, 6890) and m_hip.dtype == torch.bool and float((~same).float().mean()) < 5e-4      # (dot products ~ 0)
+    assert float((G.plain(f_hip) - G.plain(f_ref))[same].abs().max()) < 1e-5 * max(1.0, float(G.plain(f_ref).abs().max()))
+    assert s_hip['out_sh'] == s_ref['out_sh'] and torch.equal(G.plain(s_hip['bounds']), G.plain(s_ref['bounds']))
+    assert s_hip['coord'].dtype == torch.int32 and torch.equal(G.plain(s_hip['coord']), G.plain(s_ref['coord']))
+    planes = G.to_cuda(fx['planes']).view(1, 96, 32, 32)
+    with torch.no_grad():
+        a = gen.synthesis(None, d, None, use_sr_module=False, test_flag=True, planes=planes)
+        gen.fused_glue = True
+        try:
+            b = gen.synthesis(None, d, None, use_sr_module=False, test_flag=True, planes=planes)
+        finally:
+            gen.fused_glue = False
+    if bool(same.all()):
+        # (1e-5 on the vertex features passes through 13 sparse convolutions with batch statistics and the decoder)
+        assert G.rel(G.plain(b['image_raw']), G.plain(a['image_raw'])) < 5e-4 and G.rel(G.plain(b['weights_image']), G.plain(a['weights_image'])) < 5e-4
+    return float((~same).float().mean())
+
+
+def test_fused_glue_kernels(cpu_product):
+    check_fused_glue()
 
 
 def test_renderer_helpers_the_reference_generator_calls(cpu_product):
