@@ -72,14 +72,15 @@ def tune_child(a, lrank):
     w = make_workload(a, 0.4, dev)
     d = w['d']
     with torch.no_grad():
-        for _ in range(2):
+        for _ in range(min(2, a.tune_iters)):
             w['rend'](w['planes'], w['obs_img'], w['obs_feat'], w['sp'], None, w['sp_input'], w['dec'], d['ray_o_all'][:, 0],
                       d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, w['opts'])
     torch.cuda.synchronize()
     rend = w['rend']
-    rep = tune.tune_mlp(rend, w['dec'])
-    rep['gather'] = tune.tune_gather(rend, w['dec'])
-    exact = tune.tune_mlp(rend, w['dec'], exact_capacity=True)          # the same shapes without their grids of empty workgroups
+    kw = dict(iters=2 * a.tune_iters, warmup=min(3, a.tune_iters - 1))
+    rep = tune.tune_mlp(rend, w['dec'], **kw)
+    rep['gather'] = tune.tune_gather(rend, w['dec'], **kw)
+    exact = tune.tune_mlp(rend, w['dec'], exact_capacity=True, **kw)          # the same shapes without their grids of empty workgroups
     rep['shapes_exact_grid'], rep['best_exact_grid'] = exact['shapes'], exact['best']
     bl = rep['gather']['best'] == 'branchless'
 

@@ -1,8 +1,10 @@
 """TEST INFRASTRUCTURE: compiles kernel sources of sherf_amd/csrc for the HOST against tests/hipcpu/hip/hip_runtime.h.
 The only textual change is the declaration of dynamic shared memory (`extern __shared__ T name[];` -> a pointer to the
 shim's buffer); everything else is the source as shipped."""
+import hashlib
 import os
 import re
+import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
@@ -27,7 +29,37 @@ def _cpu_mlp(src):
     return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
 
 
+CACHE = os.environ.get('HIPCPU_CACHE', os.path.join(HERE, '_cache'))      # content-addressed builds, shared by every test module,
+                                                                            # xdist worker and child process (git-ignored)
+
+
+def _cache_key(name, sources, extra_src, compiler, defines):
+    h = hashlib.sha1(repr((name, tuple(sources), compiler, tuple(defines), os.environ.get('HIPCPU_OPT', '-O2'))).encode())
+    deps = [os.path.join(HERE, 'runtime.cpp'), os.path.join(HERE, 'build_cpu.py')]
+    for d in (os.path.join(HERE, 'hip'), os.path.join(HERE, 'rocblas'), os.path.join(ROOT, 'include')):
+        deps += [os.path.join(d, f) for f in sorted(os.listdir(d))]
+    deps += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + [os.path.join(CSRC, s) for s in sources]
+    for p in deps:
+        h.update(open(p, 'rb').read())
+    h.update((extra_src or '').encode())
+    return h.hexdigest()[:20]
+
+
 def build(name, sources, out_dir, extra_src=None, compiler='g++', defines=()):
+    """-> path of lib<name>.so.  Identical inputs (sources, headers, shim, flags) are built once: the result is kept under CACHE."""
+    key = _cache_key(name, sources, extra_src, compiler, defines)
+    cached = os.path.join(CACHE, key, f'lib{name}.so')
+    if os.path.exists(cached):
+        return cached
+    lib = _build(name, sources, out_dir, extra_src, compiler, defines)
+    os.makedirs(os.path.join(CACHE, key), exist_ok=True)
+    tmp = cached + f'.{os.getpid()}.tmp'
+    shutil.copyfile(lib, tmp)
+    os.replace(tmp, cached)              # atomic: concurrent builders of the same key write the same bytes
+    return cached
+
+
+def _build(name, sources, out_dir, extra_src, compiler, defines):
     os.makedirs(out_dir, exist_ok=True)
     cpps = [os.path.join(HERE, 'runtime.cpp')]
     if extra_src:

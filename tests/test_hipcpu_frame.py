@@ -81,7 +81,7 @@ def test_mlp_shapes_agree_inside_the_frame(cpu_product):
     a = G.hip_render('tiny_nv')
     # (every shape is compared bit for bit on the frame's samples by the tuner test below; here the ones whose launch structure
     #  interacts with the frame driver: two launches, `tokens` used as scratch, persistent grid, half-size workgroups)
-    for shape in ('4x2', '8x1split', '8x1split2', '8x1persist', '4x1il8'):
+    for shape in ('8x1split2', '8x1persist', '4x1il8'):
         b = G.hip_render('tiny_nv', options=dict(mlp_shape=shape))
         assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4, shape
 
@@ -369,8 +369,7 @@ def test_full_training_step_with_the_reconstruction_loss(cpu_product, monkeypatc
 
 def test_size_independent_properties_and_rotation(cpu_product):
     P.test_deterministic_and_ray_independent()
-    P.test_ragged_shapes(9, 31, 128)
-    P.test_ragged_shapes(5, 7, 2)
+    P.test_ragged_shapes(9, 31, 128)            # (S = 2 and the other ragged shapes: tests/test_gpu_parity.py on the device)
     P.test_global_rotation_flip_rate()
 
 
