@@ -133,6 +133,7 @@ def main():
                          'frame: the "reference single-GPU render()" denominator SURVEY.md section 8(d) asks for beside the CPU one '
                          '(N = 1 only; runs in a child process after the measurement, bounded to 4 minutes)')
     ap.add_argument('--torch-gpu-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--save-oracle', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--bn-mode', default='train', choices=['train', 'eval'],
                     help='BatchNorm of the voxel encoder. train (default) = batch statistics: the mode the reference renders in, '
                          'also at test time (eval_*.sh -> train.py --test_flag -> test(G, ...) with G built .train(), '
@@ -148,7 +149,7 @@ def main():
     if a.tune_child:
         return tune_child(a, lrank)
     if a.torch_gpu_child:
-        print('TORCH_GPU_JSON ' + json.dumps(torch_gpu_baseline(a.config, _device(lrank), a.bn_mode == 'train')), flush=True)
+        print('TORCH_GPU_JSON ' + json.dumps(torch_gpu_baseline(a.config, _device(lrank), a.bn_mode == 'train', save=a.save_oracle)), flush=True)
         return
     tune_report = None
     if a.mlp_shape == 'auto':              # before this process touches the GPU: see pick_mlp_shape
@@ -249,9 +250,13 @@ def main():
         if not a.no_cpu_baseline and world == 1:            # reported at N = 1 only (rank 0's host cores)
             res['cpu_baseline'] = cpu_baseline(a.config)
         if not a.no_torch_gpu_baseline and world == 1:
-            res['torch_gpu_baseline'] = torch_gpu_baseline_child(a, lrank)
+            import tempfile
+            path = os.path.join(tempfile.mkdtemp(prefix='sherf_bench_'), 'oracle_frame.npz')
+            res['torch_gpu_baseline'] = torch_gpu_baseline_child(a, lrank, save=path)
             if res['torch_gpu_baseline'].get('value'):
                 res['torch_gpu_baseline']['speedup_vs_it'] = res['value'] / res['torch_gpu_baseline']['value']
+            if os.path.exists(path):             # BASELINE's "PSNR vs ref": the timed frame against the oracle's image of the same frame
+                res['parity'] = frame_parity(step().detach().float().cpu().numpy(), np.load(path))
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()
@@ -284,14 +289,27 @@ def cpu_baseline(cfg_name):
                        f'oracle/sherf_oracle.py fp32 torch-CPU, {dt:.1f} s')
 
 
-def torch_gpu_baseline_child(a, lrank, timeout=240):
+def frame_parity(tile, ref):
+    """tile [R,5] = (rgb, depth, acc) of the bench frame, ref = the oracle's rgb [R,3] / acc [R] of the same frame (whole 512x512x64
+    frame, stock ATen ops on the GPU) -> PSNR on images mapped to [0,1] (test_loop.py:36-37) and the max errors relative to the range."""
+    rgb, acc = tile[:, :3].astype(np.float64), tile[:, 4].astype(np.float64)
+    r_rgb, r_acc = ref['rgb'].reshape(-1, 3).astype(np.float64), ref['acc'].reshape(-1).astype(np.float64)
+    mse = float(np.mean(((rgb / 2 + 0.5) - (r_rgb / 2 + 0.5)) ** 2))
+    return dict(psnr_vs_oracle_db=(-10.0 * np.log10(mse)) if mse > 0 else float('inf'),
+                rgb_rel_err=float(np.abs(rgb - r_rgb).max() / (np.abs(r_rgb).max() + 1e-12)),
+                acc_rel_err=float(np.abs(acc - r_acc).max() / (np.abs(r_acc).max() + 1e-12)), tolerance=1e-3,
+                oracle='oracle/sherf_oracle.py (pinned to the unmodified reference) as stock ATen fp32 ops on the GPU, whole frame')
+
+
+def torch_gpu_baseline_child(a, lrank, timeout=240, save=None):
     """torch_gpu_baseline in a child process: checker code on stock kernels must not be able to take the bench line down (out of
     memory, a hang) nor to leave its allocator pool in this process."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['LOCAL_RANK'] = str(lrank)
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--torch-gpu-child', '--config', a.config, '--bn-mode', a.bn_mode],
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--torch-gpu-child', '--config', a.config, '--bn-mode', a.bn_mode]
+                           + (['--save-oracle', save] if save else []),
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('TORCH_GPU_JSON ')]
         if not line:
@@ -301,7 +319,7 @@ def torch_gpu_baseline_child(a, lrank, timeout=240):
         return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
 
 
-def torch_gpu_baseline(cfg_name, dev, training, iters=1):
+def torch_gpu_baseline(cfg_name, dev, training, iters=1, save=None):
     """The same oracle as cpu_baseline, run through PyTorch-ROCm's stock kernels on the GPU over the WHOLE frame (checker code
     timed as a baseline, never on the product path).  Its K-NN is the blocked brute force of oracle.nearest_vertex."""
     try:
@@ -309,7 +327,9 @@ def torch_gpu_baseline(cfg_name, dev, training, iters=1):
         import json as _json
         shapes = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'param_shapes.json')))
         state = {n: torch.from_numpy(fixtures.seeded_param(n, s)).to(dev) for n, s in shapes.items() if fixtures.seeded_param(n, s) is not None}
-        fx = fixtures.renderer_inputs(cfg_name)
+        bench_cfg = dict(fixtures.CONFIGS[cfg_name]); bench_cfg['theta_tgt'] = 0.4          # rank 0's frame of the measurement (make_inputs)
+        fixtures.CONFIGS['_bench'] = bench_cfg
+        fx = fixtures.renderer_inputs('_bench')
         c = fx['cfg']
         O.NN_CHUNK = 32768                      # 32768 x 6890 distance blocks: large launches, < 4 GB of temporaries
         times = []
@@ -320,6 +340,8 @@ def torch_gpu_baseline(cfg_name, dev, training, iters=1):
                 torch.cuda.synchronize(dev); times.append(time.perf_counter() - t0)
         dt = min(times[1:])
         R = c['H'] * c['W']
+        if save:                                # the oracle's image of the bench frame: what the parent's `parity` entry compares with
+            np.savez(save, rgb=r['rgb'].detach().float().cpu().numpy(), acc=r['acc'].detach().float().cpu().numpy())
         return dict(value=R / dt, unit='rays/s', kind='port', seconds_per_frame=dt,
                     sample=f'whole {c["H"]}x{c["W"]}x{c["S"]} frame ({int(r["mask"].sum())} valid samples), oracle/sherf_oracle.py as stock '
                            f'PyTorch-ROCm fp32 ops on the GPU, best of {iters} after 1 warm-up')

@@ -153,17 +153,18 @@ def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
     assert rep['best'] in tune.MLP_SHAPES and all(e['ok'] for e in rep['shapes'].values()) and rep['gather']['variants']['branchless']['ok']
     assert all(e['ok'] for e in rep['shapes_exact_grid'].values()) and len(rep['frame']['frames']) == 4
     assert all(f['ok'] and f['ms'] > 0 for f in rep['frame']['frames']) and rep['choice'] in [dict((k, f[k]) for k in tune.FRAME_KEYS) for f in rep['frame']['frames']]
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-torch-gpu-baseline',
-                                      '--mlp-shape', '8x1prio_il8'])
+    # the stock-ops baseline's child is run in-process here (no GPU for a real child): its timing entry and the oracle image it saves
+    # feed the `parity` entry -- BASELINE's "PSNR vs ref" for the very frame that was timed
+    monkeypatch.setattr(bench, 'torch_gpu_baseline_child',
+                        lambda a, lrank, timeout=240, save=None: bench.torch_gpu_baseline(a.config, torch.device('cpu'), a.bn_mode == 'train', save=save))
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--mlp-shape', '8x1prio_il8'])
     bench.main()
     res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
     assert res['config']['mlp_shape'] == '8x1prio_il8' and res['config']['valid_samples'] > 0
     assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and 'frame_timeline_ms' in res
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--torch-gpu-child'])       # the stock-ops baseline's child entry
-    bench.main()
-    tg = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('TORCH_GPU_JSON ')][-1][len('TORCH_GPU_JSON '):])
-    assert tg.get('value', 0) > 0, tg
+    assert res['torch_gpu_baseline']['value'] > 0 and res['torch_gpu_baseline']['speedup_vs_it'] > 0
+    assert res['parity']['psnr_vs_oracle_db'] > 60.0 and res['parity']['rgb_rel_err'] < 1e-3 and res['parity']['acc_rel_err'] < 1e-3
 
 
 def test_bench_two_ranks_dry_run(cpu_product):
