@@ -295,8 +295,12 @@ def frame_parity(tile, ref):
     rgb, acc = tile[:, :3].astype(np.float64), tile[:, 4].astype(np.float64)
     r_rgb, r_acc = ref['rgb'].reshape(-1, 3).astype(np.float64), ref['acc'].reshape(-1).astype(np.float64)
     mse = float(np.mean(((rgb / 2 + 0.5) - (r_rgb / 2 + 0.5)) ** 2))
-    return dict(psnr_vs_oracle_db=(-10.0 * np.log10(mse)) if mse > 0 else float('inf'),
-                rgb_rel_err=float(np.abs(rgb - r_rgb).max() / (np.abs(r_rgb).max() + 1e-12)),
+    # per-ray error relative to the range; a sample whose nearest-vertex distance sits within an ulp of the 5 cm shell threshold can fall
+    # on either side in two fp32 implementations (the oracle's GEMMs here are rocBLAS's), which moves one ray visibly: the count of rays
+    # over the tolerance is reported beside the maximum
+    err = np.abs(rgb - r_rgb).max(1) / (np.abs(r_rgb).max() + 1e-12)
+    return dict(psnr_vs_oracle_db=float(-10.0 * np.log10(mse)) if mse > 0 else float('inf'), rgb_rel_err=float(err.max()),
+                rgb_rel_err_p9999=float(np.quantile(err, 0.9999)), rays_over_tolerance=int((err > 1e-3).sum()), rays=int(err.size),
                 acc_rel_err=float(np.abs(acc - r_acc).max() / (np.abs(r_acc).max() + 1e-12)), tolerance=1e-3,
                 oracle='oracle/sherf_oracle.py (pinned to the unmodified reference) as stock ATen fp32 ops on the GPU, whole frame')
 
