@@ -82,7 +82,7 @@ def tune_child(a, lrank):
     rep['gather'] = tune.tune_gather(rend, w['dec'], **kw)
     exact = tune.tune_mlp(rend, w['dec'], exact_capacity=True, **kw)          # the same shapes without their grids of empty workgroups
     rep['shapes_exact_grid'], rep['best_exact_grid'] = exact['shapes'], exact['best']
-    bl = rep['gather']['best'] == 'branchless'
+    bl = {'branch': False, 'branchless': True, 'branchless128': '128'}[rep['gather']['best']]
 
     def render():
         with torch.no_grad():
@@ -169,7 +169,7 @@ def main():
                                                                                   'obs_img', 'opts'))
     rend.mlp_shape = a.mlp_shape
     choice = (tune_report or {}).get('choice', {})
-    rend.gather_branchless = bool(choice.get('gather_branchless')) or rend.gather_branchless
+    rend.gather_branchless = choice.get('gather_branchless') or rend.gather_branchless
     rend.exact_grids = bool(choice.get('exact_grids')) or rend.exact_grids
     ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
     R = ro.shape[1]; S = opts['depth_resolution']
@@ -230,7 +230,7 @@ def main():
                                         f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
                                parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision,
                                batchnorm=a.bn_mode, mlp_shape=a.mlp_shape,
-                               gather='branchless' if rend.gather_branchless else 'branch',
+                               gather={False: 'branch', True: 'branchless', '128': 'branchless128'}[rend.gather_branchless],
                                exact_grids=bool(rend.exact_grids)))
         if tune_report is not None:
             res['mlp_tune'] = tune_report

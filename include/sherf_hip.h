@@ -135,7 +135,7 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
 /* mode 0: all taps; 1: tri-plane + pixel taps only (levels_host may be NULL) -- can run before the voxel encoder has
  * finished; 2: voxel taps only, ADDED onto the tokens written by a mode-1 pass.  `mode | 4`: the voxel-row loads of the 8 corners are
  * issued unconditionally (absent corners read row 0 with weight 0) instead of under one branch per corner -- same sums, a schedule
- * variant timed per device by sherf_amd.tune. */
+ * variant timed per device by sherf_amd.tune; `mode | 12`: the same compiled for 4 waves / SIMD (128 VGPRs instead of 160). */
 
 /* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
  * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):
@@ -303,7 +303,7 @@ typedef struct {
     const float* obs_img; float* img4; int32_t H, W;
     /* warp + gather (a8-a12) */
     float* geom; int32_t* cs_tvid;
-    const float* tok_bias; const float* bounds; const float* vox_min; int32_t vox_sh[3]; int32_t gather_split; /* bit 0: split passes, bit 1: branchless variant */
+    const float* tok_bias; const float* bounds; const float* vox_min; int32_t vox_sh[3]; int32_t gather_split; /* bit 0: split passes, bit 1: branchless variant, bit 2: branchless in 128 VGPRs */
     float* tokens; float* extras;
     /* voxel encoder (a11) */
     const sherf_svox_plan* vox_plan; const int32_t* vox_coord; const float* vox_feat; int32_t vox_n, vox_training;

@@ -25,8 +25,10 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 
 // BL: voxel-row loads issued unconditionally (see phase 2 below); same taps, same sums -- a launch-time variant
 // (`mode | 4` of sherf_gather_tokens) so that it can be timed against the branching form on the device.
-template <bool BL>
-__global__ void __launch_bounds__(256) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
+// MINW: waves per SIMD the kernel is compiled for (register cap 512 / MINW): the unconditional form wants 160 VGPRs (3 waves / SIMD);
+// `mode | 12` asks for it squeezed into 128 (4 waves / SIMD) -- more loads per wave AND more waves, if the compiler finds the registers.
+template <bool BL, int MINW>
+__global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                             const float4* __restrict__ planes_f, int P,
                                                             const float4* __restrict__ feat_f, int Hf, int Wf,
                                                             const float4* __restrict__ img4, int H, int W, Levels lv,
@@ -319,6 +321,7 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
                                    float* extras, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && tok_bias && bounds && vox_min && vox_sh_host && tokens && extras);
     const bool branchless = (mode & 4) != 0 || SHERF_GATHER_BRANCHLESS;
+    const bool squeezed = branchless && (mode & 8) != 0;
     mode &= 3;
     SHERF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 1 || levels_host));
     SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
@@ -329,12 +332,12 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     }
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
     const int64_t tiles = (capacity + 31) / 32;
-#define SHERF_GATHER(BL)                                                                                                     \
-    hipLaunchKernelGGL(gather_tokens_kernel<BL>, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), \
+#define SHERF_GATHER(BL, MW)                                                                                                   \
+    hipLaunchKernelGGL((gather_tokens_kernel<BL, MW>), dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), \
                        counters, geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf, \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode)
-    if (branchless) SHERF_GATHER(true); else SHERF_GATHER(false);
+    if (squeezed) SHERF_GATHER(true, 4); else if (branchless) SHERF_GATHER(true, 1); else SHERF_GATHER(false, 1);
 #undef SHERF_GATHER
     SHERF_LAUNCH_CHECK();
 }

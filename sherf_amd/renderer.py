@@ -244,7 +244,9 @@ class ImportanceRenderer(nn.Module):
         self.mlp_precision = mlp_precision
         self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2' | experimental '8x1split', '8x1split2', '8x1persist')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
-        self.gather_branchless = os.environ.get('SHERF_GATHER_BRANCHLESS', '0') == '1'   # schedule variant of the voxel taps (sherf_hip.h)
+        # schedule variant of the voxel taps (sherf_hip.h): False = one branch per corner, True = unconditional loads (160 VGPRs),
+        # '128' = unconditional loads compiled for 4 waves / SIMD
+        self.gather_branchless = {'0': False, '1': True, '128': '128'}[os.environ.get('SHERF_GATHER_BRANCHLESS', '0')]
         # SHERF_FRAME_EXACT_GRIDS (sherf_hip.h): launch warp / gather / MLP for the frame's actual valid-sample count (one host wait per
         # frame, where the reference has its own) instead of the R*S capacity; same results, chosen per device by sherf_amd.tune
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
@@ -459,7 +461,8 @@ class ImportanceRenderer(nn.Module):
         fr.vox_min = A(vox_min)
         for i, v in enumerate(obs_sp_input['out_sh']):
             fr.vox_sh[i] = int(v)
-        fr.gather_split = (1 if opts.get('gather_split', self.gather_split) else 0) | (2 if opts.get('gather_branchless', self.gather_branchless) else 0)
+        gb = opts.get('gather_branchless', self.gather_branchless)
+        fr.gather_split = (1 if opts.get('gather_split', self.gather_split) else 0) | (4 if gb == '128' else 2 if gb else 0)
         # a11: sparse voxel encoder plan (persistent buffers) + this frame's voxels
         pl, vfeat, vcoord = self.encoder_3d.prepare(canonical_sp_conv_volume, wc['fold'], self._ws)
         keep += [vfeat, vcoord]

@@ -110,7 +110,8 @@ def tune_mlp(renderer, decoder, candidates=None, iters=20, warmup=3, tol=0.0, ex
 def tune_gather(renderer, decoder, iters=20, warmup=3):
     """Times `sherf_gather_tokens` with the voxel-row loads under one branch per corner (default) and issued unconditionally
     (`mode | 4`, include/sherf_hip.h) on the renderer's last frame; the variant is eligible only if tokens and extras equal the
-    default's.  -> {'best': 'branch' | 'branchless', 'variants': {...}}; the caller sets `renderer.gather_branchless`."""
+    default's.  -> {'best': 'branch' | 'branchless' | 'branchless128', 'variants': {...}}; the caller sets `renderer.gather_branchless`
+    (False / True / '128')."""
     last = getattr(renderer, 'last', None)
     if not last:
         raise RuntimeError('tune_gather needs a rendered frame: call the renderer once first')
@@ -134,7 +135,7 @@ def tune_gather(renderer, decoder, iters=20, warmup=3):
                   stream)
 
     report, ref = {}, None
-    for name, mode in (('branch', 0), ('branchless', 4)):
+    for name, mode in (('branch', 0), ('branchless', 4), ('branchless128', 12)):
         ws['tokens'][:nt].fill_(float('nan')); ws['extras'][:ne].fill_(float('nan'))
         launch(mode)
         torch.cuda.synchronize(dev)
@@ -150,9 +151,10 @@ def tune_gather(renderer, decoder, iters=20, warmup=3):
         entry['ms'] = _time_launches(lambda: launch(mode), iters, dev)
         report[name] = entry
     ws['tokens'][:nt].copy_(tokens0); ws['extras'][:ne].copy_(extras0)
-    best = 'branch'
-    if report['branchless']['ok'] and report['branch']['ok'] and report['branchless']['ms'] < 0.98 * report['branch']['ms']:
-        best = 'branchless'
+    ok = [n for n in report if report[n]['ok']]
+    best = min(ok, key=lambda n: report[n]['ms']) if ok else 'branch'
+    if best != 'branch' and ('branch' not in ok or report[best]['ms'] > 0.98 * report['branch']['ms']):
+        best = 'branch'
     return dict(best=best, valid_samples=nv, iters=iters, variants=report)
 
 

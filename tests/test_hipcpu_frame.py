@@ -108,13 +108,14 @@ def test_tune_mlp_checks_every_shape_against_the_default(cpu_product, monkeypatc
     assert rep['best'] in tune.MLP_SHAPES
     assert torch.equal(ws['tokens'], tok) and torch.equal(ws['sample_out'], out)
     g = tune.tune_gather(h['rend'], h['dec'], iters=1, warmup=0)
-    assert g['variants']['branch']['ok'] and g['variants']['branchless']['ok'] and g['variants']['branchless']['max_abs_diff'] == 0.0
+    assert set(g['variants']) == {'branch', 'branchless', 'branchless128'} and all(e['ok'] and e['max_abs_diff'] == 0.0 for e in g['variants'].values())
     assert torch.equal(ws['tokens'], tok) and torch.equal(ws['extras'], ext)
     ex = G.hip_render('tiny_nv', options=dict(exact_grids=True))                     # launches sized by the frame's own count
     assert torch.equal(ex['rgb'], h['rgb']) and torch.equal(ex['acc'], h['acc']) and torch.equal(ex['depth'], h['depth'])
     assert torch.equal(ex['last']['ws']['sample_out'][:rep['valid_samples']], out[:rep['valid_samples']])
-    bl = G.hip_render('tiny_nv', options=dict(gather_branchless=True))               # and inside the frame
-    assert torch.equal(bl['rgb'], h['rgb']) and torch.equal(bl['acc'], h['acc'])
+    for gb in (True, '128'):                                                         # and inside the frame
+        bl = G.hip_render('tiny_nv', options=dict(gather_branchless=gb))
+        assert torch.equal(bl['rgb'], h['rgb']) and torch.equal(bl['acc'], h['acc'])
     # the guard: corrupt one candidate's result -> it must be reported not ok and not be chosen
     real_call = _lib.call
 
