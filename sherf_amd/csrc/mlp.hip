@@ -334,13 +334,13 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 // VAR: scheduling variant of the same arithmetic (results bit-identical): low byte = SHERF_MLP_INTERLEAVE count, next byte =
 // SHERF_MLP_WAVE_PRIO level.  Runtime-selectable through `shape` 5-7 of sherf_nerf_mlp so that sherf_amd.tune can time them on
 // the hardware it runs on; the -D macros only move the default.
-template <int PREC, int NW, int NTL, int PHASE = 0, int VAR = (SHERF_MLP_INTERLEAVE | (SHERF_MLP_WAVE_PRIO << 8))>
+template <int PREC, int NW, int NTL, int PHASE = 0, int VAR = (SHERF_MLP_INTERLEAVE | (SHERF_MLP_WAVE_PRIO << 8))>      // (bits 16+: PHASE_PRIO)
 __global__ void __launch_bounds__(NW * 64, PHASE == 1 ? SHERF_MLP_P1_WAVES : NTL == 1 ? 2 : 1)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
     using CX = Ctx<PREC, NW, NTL, PHASE>;
     constexpr int NT = NW * 64;
-    constexpr int IL = VAR & 0xff, PRIO = (VAR >> 8) & 0xff;
+    constexpr int IL = VAR & 0xff, PRIO = (VAR >> 8) & 0xff, PHASE_PRIO = (VAR >> 16) & 0xff;
     __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
@@ -571,6 +571,9 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     }
 
     // ================= NeRF decoder: all NTL tiles of the wave share every weight fragment =================
+    // PHASE_PRIO (shape '4x1phase'): from here on the wave is MFMA-bound -- it gets issue priority over the co-resident workgroup's wave on
+    // this SIMD whenever that one is still in its VALU-bound transformer / encoding prologue (a new wave starts at priority 0)
+    if constexpr (PHASE_PRIO > 0) __builtin_amdgcn_s_setprio(PHASE_PRIO);
     BFrag<PREC> ha[NTL][8], hb[NTL][8], pe[NTL][3];
 #pragma unroll
     for (int u = 0; u < NTL; ++u) pe_frags<PREC, 6, 3>(h, xc[u][0], xc[u][1], xc[u][2], pe[u]);
@@ -729,13 +732,20 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 9 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 10 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
     hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
                        as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
                        reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
+    if (shape == 10) {                        // 4x1 with the decoder phase at raised issue priority
+        SHERF_CHECK_ARG(prec == 1);
+        hipLaunchKernelGGL((nerf_mlp_kernel<1, 4, 1, 0, (2 << 16)>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, as_stream(stream), counters,
+                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
+                           reinterpret_cast<float4*>(out), g_sherf_debug);
+        SHERF_LAUNCH_CHECK();
+    }
     if (shape == 8 || shape == 9) {           // 4 waves x 1 tile: two independent workgroups per CU (two-slot weight rings); 9 = + interleave 8
         SHERF_CHECK_ARG(prec == 1);
         if (shape == 8) SHERF_MLP(1, 4, 1);
