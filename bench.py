@@ -176,6 +176,23 @@ def main():
     from sherf_amd import _lib as _abi
     import ctypes as _ct
 
+    if tune_report is not None and 'choice' in tune_report:
+        # second guard (the child already verified every candidate on its GPU): this rank's own frame under the tuned switches must
+        # equal the frame under the defaults bit for bit, or the defaults are kept
+        tuned = dict(mlp_shape=rend.mlp_shape, gather_branchless=rend.gather_branchless, exact_grids=rend.exact_grids)
+        if tuned != dict(mlp_shape='8x1', gather_branchless=False, exact_grids=False):
+            def frame():
+                with torch.no_grad():
+                    return [t.clone() for t in rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)]
+            got = frame()
+            rend.mlp_shape, rend.gather_branchless, rend.exact_grids = '8x1', False, False
+            ref = frame()
+            if all(torch.equal(x, y) for x, y in zip(got, ref)):
+                rend.mlp_shape, rend.gather_branchless, rend.exact_grids = tuned['mlp_shape'], tuned['gather_branchless'], tuned['exact_grids']
+            else:
+                tune_report['reverted_to_defaults'] = True
+                a.mlp_shape = '8x1'
+
     def step():
         with torch.no_grad():
             rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)
@@ -229,7 +246,7 @@ def main():
                    config=dict(workload=f'{a.config}: 512x512 rays x 64 samples, synthetic SMPL subject, novel view, all feature branches, '
                                         f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
                                parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=a.precision,
-                               batchnorm=a.bn_mode, mlp_shape=a.mlp_shape,
+                               batchnorm=a.bn_mode, mlp_shape=rend.mlp_shape,
                                gather={False: 'branch', True: 'branchless', '128': 'branchless128'}[rend.gather_branchless],
                                exact_grids=bool(rend.exact_grids)))
         if tune_report is not None:

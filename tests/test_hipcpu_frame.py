@@ -158,11 +158,15 @@ def test_bench_main_and_tune_child_dry_run(cpu_product, monkeypatch, capsys):
     # feed the `parity` entry -- BASELINE's "PSNR vs ref" for the very frame that was timed
     monkeypatch.setattr(bench, 'torch_gpu_baseline_child',
                         lambda a, lrank, timeout=240, save=None: bench.torch_gpu_baseline(a.config, torch.device('cpu'), a.bn_mode == 'train', save=save))
-    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--mlp-shape', '8x1prio_il8'])
+    # `--mlp-shape auto` with the child's report standing in: the tuned switches are adopted after this process's own bit-identity check
+    choice = dict(mlp_shape='4x1phase', gather_branchless='128', exact_grids=True)
+    monkeypatch.setattr(bench, 'pick_mlp_shape', lambda a, lrank, timeout=300: (choice['mlp_shape'], dict(rep, choice=choice)))
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--mlp-shape', 'auto'])
     bench.main()
     res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
-    assert res['config']['mlp_shape'] == '8x1prio_il8' and res['config']['valid_samples'] > 0
+    assert res['config']['mlp_shape'] == '4x1phase' and res['config']['gather'] == 'branchless128' and res['config']['exact_grids'] is True
+    assert 'reverted_to_defaults' not in res['mlp_tune'] and res['config']['valid_samples'] > 0
     assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and 'frame_timeline_ms' in res
     assert res['torch_gpu_baseline']['value'] > 0 and res['torch_gpu_baseline']['speedup_vs_it'] > 0
     assert res['parity']['psnr_vs_oracle_db'] > 60.0 and res['parity']['rgb_rel_err'] < 1e-3 and res['parity']['acc_rel_err'] < 1e-3
