@@ -166,7 +166,8 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * persistent workgroups (one per CU, weight ring kept streaming across tile groups); 5 / 6 / 7 = shape 0 with a different instruction
  * schedule only (5: previous chunk's epilogue interleaved into the MFMA stream, 6: one wave per SIMD at raised issue priority,
  * 7: both); 8 = 4 waves x 1 tile: half-size workgroups, two co-resident per CU with two-slot weight rings, not coupled by each
- * other's barriers (9 = 8 with the schedule of 5; 10 = 8 with the MFMA-bound decoder phase at raised issue priority) -- all bit-identical results, picked per device by sherf_amd.tune.  out[c] = (r,g,b,sigma). */
+ * other's barriers (9 = 8 with the schedule of 5; 10 = 8 with the MFMA-bound decoder phase at raised issue priority;
+ * 11 = 8 as persistent workgroups like 4, two per CU: no empty workgroups, no launch gaps, no host synchronisation) -- all bit-identical results, picked per device by sherf_amd.tune.  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream);
 /* layout of the weight stream the kernel expects: number of chunks and K-blocks per chunk. */

@@ -194,7 +194,7 @@ __device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, PHASE>& cx, int step)
     wait_vm(NSLOT == 2 ? 0 : cx.pending);    // two slots: the newest issue IS step s+1
     if (!(cx.dbg & 64)) wg_barrier();
     if constexpr (PHASE == -1) {             // past the end of this group: the freed slot takes step (step + 3) % 3 of the next group
-        if (step + 3 >= n_steps<NTL, PHASE>()) { cx.pending = cx.more ? dma_issue(cx, (step + 3) % Ctx<PREC, NW, NTL, PHASE>::NSLOT) : 0; return; }
+        if (step + NSLOT >= n_steps<NTL, PHASE>()) { cx.pending = cx.more ? dma_issue(cx, (step + NSLOT) % NSLOT) : 0; return; }
     }
     cx.pending = dma_issue(cx, step + NSLOT);
 }
@@ -732,7 +732,7 @@ extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 10 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 11 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
 #define SHERF_MLP(P, W, L)                                                                                                 \
@@ -765,7 +765,7 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
 #undef SHERF_MLP_VAR
         SHERF_LAUNCH_CHECK();
     }
-    if (shape == 4) {                         // experimental: persistent workgroups, one per CU (PHASE -1)
+    if (shape == 4 || shape == 11) {          // experimental: persistent workgroups (PHASE -1): 4 = 8 waves, one per CU; 11 = 4 waves, two per CU
         SHERF_CHECK_ARG(prec == 1);
         static int n_cu = 0;
         if (!n_cu) {
@@ -773,6 +773,13 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
             SHERF_HIP_CHECK(hipGetDevice(&dev));
             SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
             n_cu = v > 0 ? v : 256;
+        }
+        if (shape == 11) {
+            const int64_t groups4 = (tiles + 3) / 4;
+            hipLaunchKernelGGL((nerf_mlp_kernel<1, 4, 1, -1>), dim3((unsigned)(groups4 < 2 * n_cu ? groups4 : 2 * n_cu)), dim3(256), 0,
+                               as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                               reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug);
+            SHERF_LAUNCH_CHECK();
         }
         const int64_t groups = (tiles + 7) / 8;
         hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, -1>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(512), 0, as_stream(stream),

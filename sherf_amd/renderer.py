@@ -21,7 +21,7 @@ from .voxel import SparseConvNet, SparseConvTensor, pack_conv_weights  # noqa: F
 
 # `shape` argument of sherf_nerf_mlp (include/sherf_hip.h).  '8x1il8' / '8x1prio' / '8x1prio_il8' differ from '8x1' in the
 # instruction schedule only (bit-identical results); sherf_amd.tune times them on the device and reports the fastest.
-MLP_SHAPES = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4, '8x1il8': 5, '8x1prio': 6, '8x1prio_il8': 7, '4x1': 8, '4x1il8': 9, '4x1phase': 10}
+MLP_SHAPES = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4, '8x1il8': 5, '8x1prio': 6, '8x1prio_il8': 7, '4x1': 8, '4x1il8': 9, '4x1phase': 10, '4x1persist': 11}
 
 V = 6890
 

@@ -81,7 +81,7 @@ def test_mlp_shapes_agree_inside_the_frame(cpu_product):
     a = G.hip_render('tiny_nv')
     # (every shape is compared bit for bit on the frame's samples by the tuner test below; here the ones whose launch structure
     #  interacts with the frame driver: two launches, `tokens` used as scratch, persistent grid, half-size workgroups)
-    for shape in ('8x1split2', '8x1persist', '4x1il8', '4x1phase'):
+    for shape in ('8x1split2', '8x1persist', '4x1il8', '4x1phase', '4x1persist'):
         b = G.hip_render('tiny_nv', options=dict(mlp_shape=shape))
         assert G.rel(b['rgb'], a['rgb']) < 1e-4 and G.rel(b['acc'], a['acc']) < 1e-4, shape
 

@@ -422,7 +422,7 @@ def mlp_lib(tmp_path_factory):
     return lib
 
 
-@pytest.mark.parametrize('prec,shape,tol', [(1, 0, 1e-3), (1, 1, 1e-3), (1, 2, 1e-3), (1, 3, 1e-3), (1, 4, 1e-3), (0, 0, 5e-2)])
+@pytest.mark.parametrize('prec,shape,tol', [(1, 0, 1e-3), (1, 1, 1e-3), (1, 2, 1e-3), (1, 3, 1e-3), (1, 4, 1e-3), (1, 8, 1e-3), (1, 11, 1e-3), (0, 0, 5e-2)])
 def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, shape, tol):
     """sherf_nerf_mlp: the fused transformer + decoder MFMA kernel (default 8x1, 4x2, and the experimental two-launch split
     shape) executed from its real source on the CPU, against the oracle's per-sample rgb / sigma."""
