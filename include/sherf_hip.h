@@ -348,9 +348,11 @@ int sherf_voxelize(const float* t_verts, const float* can, int V, float* bounds,
 
 int sherf_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* origins,
                       float* dirs, sherf_stream_t stream);
-/* a1+a2: get_rays + get_near_far + near/far packing (training/RenderPeople_dataset.py:14-27, 68-101, 129-134)
- * in fp32 on device. K_inv[9], Rc[9], Tc[3], bounds[6] (world min/max of the posed vertices +-5cm). */
-int sherf_dataset_rays(const float* K_inv, const float* Rc, const float* Tc, const float* bounds, int H, int W,
+/* a1+a2: get_rays + get_near_far + near/far packing (training/RenderPeople_dataset.py:14-27, 68-101, 121-134) on device, on the
+ * reference's own precision ladder: float64 camera algebra -> float32 rays -> float64 slab test -> float32 near / far.
+ * K_inv[9], Rc[9], Tc[3], bounds[6] (world min/max of the posed vertices +-5cm) are float64 like the dataset's numpy arrays;
+ * a zero direction component comes back as 1e-8 (the reference patches the array it returns, :71). */
+int sherf_dataset_rays(const double* K_inv, const double* Rc, const double* Tc, const double* bounds, int H, int W,
                        float* ray_o, float* ray_d, float* near, float* far, uint8_t* mask_at_box,
                        sherf_stream_t stream);
 

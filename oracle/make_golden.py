@@ -282,11 +282,73 @@ def run_small_units(R, T, out_dir):
     print('units ->', path)
 
 
+def reference_ray_functions():
+    """`get_rays` and `get_near_far` EXACTLY as the reference defines them (training/RenderPeople_dataset.py:14-27, 68-101):
+    the module itself cannot be imported here (cv2 / imageio / the SMPL assets are absent), but the two functions need numpy
+    only, so their source text is cut out of the unmodified file with `ast` and executed."""
+    import ast
+    path = os.path.join(REF, 'training', 'RenderPeople_dataset.py')
+    src = open(path).read()
+    ns = {'np': np}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ('get_rays', 'get_near_far'):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, 'exec'), ns)
+    return ns['get_rays'], ns['get_near_far']
+
+
+def run_rays(out_dir):
+    """Golden vectors for SURVEY rows a1 / a2: the reference's get_rays + get_near_far + the casts and (0, 1) packing of
+    sample_ray_RenderPeople_batch (RenderPeople_dataset.py:121-134, restated here line for line because that function also
+    needs cv2) on five seeded cameras: the `tiny` fixture's own camera, a wide one whose frame overshoots the box (misses),
+    a non-square frame, an axis-aligned camera (exact zeros in ray_d -> the reference's in-place 1e-8 patch) and cfg1's."""
+    from oracle import synth, fixtures
+    get_rays, get_near_far = reference_ray_functions()
+    smpl = synth.make_synth_smpl(0)
+    out = {}
+    cases = []
+    for cfg in ('tiny', 'cfg1'):
+        d = fixtures.renderer_inputs(cfg, smpl)['input_data']
+        verts = d['vertices'][0]
+        H = int(round(np.sqrt(d['ray_o_all'].shape[2])))
+        wb = np.stack([verts.min(0) - 0.05, verts.max(0) + 0.05]).astype(np.float32)
+        K, R, T = synth.orbit_camera(0.4, verts.mean(0).astype(np.float64), 3.0, H, H)
+        cases.append((cfg, H, H, K, R, T, wb))
+    d = fixtures.renderer_inputs('tiny', smpl)['input_data']
+    verts = d['vertices'][0]
+    wb = np.stack([verts.min(0) - 0.05, verts.max(0) + 0.05]).astype(np.float32)
+    c = verts.mean(0).astype(np.float64)
+    K, R, T = synth.orbit_camera(1.1, c, 3.0, 48, 48, fill=4.5)
+    cases.append(('wide', 48, 48, K, R, T, wb))
+    K, R, T = synth.orbit_camera(-2.0, c, 2.5, 40, 56, fill=2.0)
+    cases.append(('rect', 40, 56, K, R, T, wb))
+    K = np.array([[64.0, 0, 16.0], [0, 64.0, 16.0], [0, 0, 1.0]]); R = np.eye(3); T = np.array([[0.0], [0.0], [3.0]]) - c.reshape(3, 1) * np.array([[1.0], [1.0], [1.0]])
+    cases.append(('axis', 32, 32, K, R, T, wb))
+    for name, H, W, K, R, T, wb in cases:
+        ro, rd = get_rays(H, W, K, R, T)
+        ray_o = ro.reshape(-1, 3).astype(np.float32)                     # RenderPeople_dataset.py:121-134
+        ray_d = rd.reshape(-1, 3).astype(np.float32)
+        near, far, mask_at_box = get_near_far(wb, ray_o, ray_d)
+        near = near.astype(np.float32); far = far.astype(np.float32)
+        near_all = np.zeros_like(ray_o[:, 0]); far_all = np.ones_like(ray_o[:, 0])
+        near_all[mask_at_box] = near; far_all[mask_at_box] = far
+        out.update({f'{name}_H': H, f'{name}_W': W, f'{name}_K': K, f'{name}_R': R, f'{name}_T': T, f'{name}_bounds': wb,
+                    f'{name}_ray_o': ray_o, f'{name}_ray_d': ray_d, f'{name}_near': near_all, f'{name}_far': far_all,
+                    f'{name}_mask_at_box': mask_at_box})
+        print(f'rays {name}: {H}x{W}, at box {int(mask_at_box.sum())}/{H * W}, zero-patched {int((ray_d == np.float32(1e-8)).sum())}')
+    out['cases'] = np.array([c[0] for c in cases])
+    path = os.path.join(out_dir, 'rays.npz')
+    np.savez_compressed(path, **out)
+    print('rays ->', path)
+
+
 if __name__ == '__main__':
     names = sys.argv[1:] or ['tiny', 'tiny_nv', 'cfg1']
     out_dir = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
     os.makedirs(out_dir, exist_ok=True)
+    if names == ['rays']:
+        run_rays(out_dir); sys.exit(0)
     R, T = import_reference()
+    run_rays(out_dir)
     run_small_units(R, T, out_dir)
     run_glue(R, T, out_dir)
     for n in names:

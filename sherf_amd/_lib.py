@@ -130,15 +130,16 @@ def addr(t, dtype=None):
     return None if p is None else p.value
 
 
-def ptr(t, dtype=None):
-    """Device pointer of a dense CUDA tensor (argument checks in the spirit of bias_act.cpp:39-55)."""
+def ptr(t, dtype=None, channels_last_ok=False):
+    """Device pointer of a dense CUDA tensor (argument checks in the spirit of bias_act.cpp:39-55).  `channels_last_ok`: a
+    4-D tensor dense in the channels_last format is accepted too (the operators that index by stride, bias_act.cpp:57)."""
     if t is None:
         return None
     if not isinstance(t, torch.Tensor):
         raise RuntimeError(f'expected a tensor, got {type(t)}')
     if not t.is_cuda:
         raise RuntimeError('sherf_amd: tensor is not on a GPU; the HIP path has no CPU fallback')
-    if not t.is_contiguous():
+    if not t.is_contiguous() and not (channels_last_ok and t.ndim == 4 and t.is_contiguous(memory_format=torch.channels_last)):
         raise RuntimeError('sherf_amd: tensor must be contiguous')
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError(f'sherf_amd: expected dtype {dtype}, got {t.dtype}')

@@ -85,7 +85,7 @@ def _launch(x, b, xref, yref, dy, grad, dim, spec, alpha, gain, clamp):
     xref, yref, dy = same(xref), same(yref), same(dy)
     bb = None if b is None else b.to(x.dtype).contiguous()
     y = torch.empty_like(x, memory_format=fmt)
-    P = _lib.ptr
+    P = lambda t: _lib.ptr(t, channels_last_ok=cl)
     _lib.call_ops('sherf_bias_act', P(x), P(bb), P(xref), P(yref), P(dy), P(y), x.numel(), step, 1 if b is None else b.shape[0], grad,
                   spec['idx'], alpha, gain, clamp, _DTYPES[x.dtype], _lib.stream())
     return y

@@ -132,6 +132,9 @@ template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     char* lds;               // NSLOT ring slots
     int lane, h, dbg, wave, pending;
+#if SHERF_MLP_TRACE
+    uint32_t* trace;         // this wave's [64][4] stamps in LDS
+#endif
     bool more;               // PHASE -1: this workgroup has another tile group after the current one (uniform)
     static constexpr int SLOT = (PHASE == 1 ? 3 : PHASE == 3 ? 16 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8: <= 3 K-blocks; pairs: 2 x 8
     // <NW=4, NTL=1> (shape '4x1'): half-size workgroups, TWO co-resident per CU (one wave of each per SIMD) that are not coupled by
@@ -188,11 +191,27 @@ __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // end of step s: step s+1 must have landed (everything but the newest issue), then step s's slot is recycled for s+3
+// SHERF_MLP_TRACE (profiling builds only, tools/mlp_trace.py): every wave stamps s_memtime at the end of its MFMA stream, after the
+// weight-DMA wait and after the workgroup barrier of every step into LDS; selected workgroups copy the stamps out at the end.
+#ifndef SHERF_MLP_TRACE
+#define SHERF_MLP_TRACE 0
+#endif
+#if SHERF_MLP_TRACE
+__device__ uint32_t* g_mlp_trace = nullptr;           // [slot][wave 0..7][64 steps][4] u32
+__device__ int g_mlp_trace_every = 0;
+#define SHERF_TRACE_STAMP(cx, step, k) do { if ((cx).lane == 0) (cx).trace[(step) * 4 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
+#endif
+
 template <int PREC, int NW, int NTL, int PHASE>
 __device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
     constexpr int NSLOT = Ctx<PREC, NW, NTL, PHASE>::NSLOT;
+    SHERF_TRACE_STAMP(cx, step, 0);
     wait_vm(NSLOT == 2 ? 0 : cx.pending);    // two slots: the newest issue IS step s+1
+    SHERF_TRACE_STAMP(cx, step, 1);
     if (!(cx.dbg & 64)) wg_barrier();
+    SHERF_TRACE_STAMP(cx, step, 2);
     if constexpr (PHASE == -1) {             // past the end of this group: the freed slot takes step (step + 3) % 3 of the next group
         if (step + NSLOT >= n_steps<NTL, PHASE>()) { cx.pending = cx.more ? dma_issue(cx, (step + NSLOT) % NSLOT) : 0; return; }
     }
@@ -253,8 +272,33 @@ __device__ __forceinline__ float erf_(float x) {
 #define SHERF_MLP_WAVE_PRIO 0
 #endif
 // acc[col] += W_step[kb0 .. kb0+NK) . B[col]: one segment of a chunk's K range, NCOL column sets sharing the A fragments
+// SHERF_MLP_SPLITK (experiment): the 8-K-block segments accumulate even / odd K-blocks in two independent chains (summed at the
+// end), so that a wave's MFMA stream is not one 24-deep dependent chain.
+#ifndef SHERF_MLP_SPLITK
+#define SHERF_MLP_SPLITK 0
+#endif
 template <int PREC, int NK, int NCOL, int IL>
 __device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
+#if SHERF_MLP_SPLITK
+    if constexpr (PREC == 1 && NK == 8 && NCOL == 1) {
+        f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NK; kb += 2) {
+            const uint4 ah0 = *reinterpret_cast<const uint4*>(s + (kb0 + kb) * 1024);
+            const uint4 al0 = *reinterpret_cast<const uint4*>(s + (nkb_total + kb0 + kb) * 1024);
+            const uint4 ah1 = *reinterpret_cast<const uint4*>(s + (kb0 + kb + 1) * 1024);
+            const uint4 al1 = *reinterpret_cast<const uint4*>(s + (nkb_total + kb0 + kb + 1) * 1024);
+            acc[0] = mfma(al0, b[0][kb].hi, acc[0]);
+            acc2 = mfma(al1, b[0][kb + 1].hi, acc2);
+            acc[0] = mfma(ah0, b[0][kb].lo, acc[0]);
+            acc2 = mfma(ah1, b[0][kb + 1].lo, acc2);
+            acc[0] = mfma(ah0, b[0][kb].hi, acc[0]);
+            acc2 = mfma(ah1, b[0][kb + 1].hi, acc2);
+        }
+        acc[0] += acc2;
+        return;
+    }
+#endif
 #pragma unroll
     for (int kb = 0; kb < NK; ++kb) {
         const uint4 ah = *reinterpret_cast<const uint4*>(s + (kb0 + kb) * 1024);
@@ -341,7 +385,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     using CX = Ctx<PREC, NW, NTL, PHASE>;
     constexpr int NT = NW * 64;
     constexpr int IL = VAR & 0xff, PRIO = (VAR >> 8) & 0xff, PHASE_PRIO = (VAR >> 16) & 0xff;
-    __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4];
+    __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
     if ((int64_t)blockIdx.x * NW * NTL >= n_tiles) return;           // whole workgroup beyond the data
@@ -351,6 +395,10 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
     cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if SHERF_MLP_TRACE
+    cx.trace = reinterpret_cast<uint32_t*>(lds + CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
+    if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
+#endif
     if constexpr (PRIO > 0) { if (cx.wave < NW / 2) __builtin_amdgcn_s_setprio(PRIO); }
     int j = cx.lane & 31, h = cx.h;                                  // (not const: PHASE -1 launders them per group)
     int64_t tile[NTL];
@@ -703,6 +751,14 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 }
             }
     }
+#if SHERF_MLP_TRACE
+    if (g_mlp_trace && g_mlp_trace_every > 0 && blockIdx.x % g_mlp_trace_every == 0 && cx.lane < 64) {
+        if (cx.lane == 0) cx.trace[63 * 4 + 2] = (uint32_t)__builtin_amdgcn_s_memtime();
+        const size_t slot = blockIdx.x / g_mlp_trace_every;
+        uint32_t* dst = g_mlp_trace + (slot * 8 + cx.wave) * 256;
+        for (int i = cx.lane; i < 256; i += 64) dst[i] = cx.trace[i];
+    }
+#endif
     if constexpr (PHASE == -1) {
         again = cx.more;
         if (again) {
@@ -721,6 +777,14 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 }
 
 }  // namespace
+
+#if SHERF_MLP_TRACE
+extern "C" int sherf_mlp_set_trace(void* buf, int every) {
+    SHERF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_trace), &buf, sizeof(buf)));
+    SHERF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_trace_every), &every, sizeof(every)));
+    return SHERF_OK;
+}
+#endif
 
 extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int32_t max_chunks) {
     SHERF_CHECK_ARG(n_chunks && nkb_host && max_chunks >= N_CHUNKS);

@@ -25,13 +25,15 @@ class RaySampler(nn.Module):
 
 
 def dataset_rays(K, R, T, bounds, H, W):
-    """(ray_o [H*W,3], ray_d [H*W,3], near [H*W], far [H*W], mask_at_box [H*W] bool) for one camera, fp32 on device.
-    K [3,3], R [3,3], T [3] or [3,1], bounds [2,3] = posed-vertex world bounds +-5 cm (RenderPeople_dataset.py:216-219)."""
+    """(ray_o [H*W,3], ray_d [H*W,3], near [H*W], far [H*W], mask_at_box [H*W] bool) for one camera, fp32 on device, computed on
+    the reference's precision ladder (float64 camera algebra, float32 rays, float64 slab test: csrc/rays.hip).
+    K [3,3], R [3,3], T [3] or [3,1] (float64 like the dataset's arrays; float32 inputs are widened), bounds [2,3] =
+    posed-vertex world bounds +-5 cm (RenderPeople_dataset.py:216-219)."""
     if not K.is_cuda:
         raise RuntimeError('sherf_amd.dataset_rays runs on the GPU only (no CPU fallback)')
     dev = K.device
-    Kinv = torch.linalg.inv(K.double()).float().contiguous()
-    Rc, Tc, b = R.float().contiguous(), T.float().reshape(3).contiguous(), bounds.float().contiguous().view(6)
+    Kinv = torch.linalg.inv(K.double()).contiguous()
+    Rc, Tc, b = R.double().contiguous(), T.double().reshape(3).contiguous(), bounds.double().contiguous().view(6)
     n = H * W
     o = torch.empty(n, 3, device=dev); d = torch.empty(n, 3, device=dev)
     nr = torch.empty(n, device=dev); fr = torch.empty(n, device=dev)

@@ -209,9 +209,9 @@ def get_rays(H, W, K, R, T):
 
 
 def get_near_far(bounds, ray_o, ray_d):
-    """RenderPeople_dataset.py:68-101 (slab test; rays with exactly two face hits are 'at box')."""
+    """RenderPeople_dataset.py:68-101 (slab test; rays with exactly two face hits are 'at box').  Like the reference, patches
+    zero components of the caller's `ray_d` IN PLACE (:71) -- the array the dataset then returns (:121-134)."""
     bounds = bounds + np.array([-0.01, 0.01])[:, None]
-    ray_d = ray_d.copy()
     ray_d[ray_d == 0.0] = 1e-8
     nom = bounds[None] - ray_o[:, None]
     d_int = (nom / ray_d[:, None]).reshape(-1, 6)

@@ -228,22 +228,26 @@ def test_units_ray_sampler_and_dense_marcher():
 
 
 def test_dataset_rays_on_device():
-    from oracle import synth
+    """Rows a1 / a2 against tests/golden/rays.npz = the outputs of the reference's OWN get_rays / get_near_far source
+    (oracle/make_golden.py::run_rays executes it).  The kernel follows the reference's float64 -> float32 -> float64 ladder, so
+    the comparison is exact: every ray origin / direction / near / far bit for bit and every mask_at_box bit.  Documented margin:
+    a float64 last-bit difference (numpy's BLAS dot vs the kernel's explicit sums) can flip a float32 rounding with
+    probability ~1e-9 per value -- at most 2 of the values of a case may differ, by one float32 ulp, and no mask bit."""
     from sherf_amd.ray_sampler import dataset_rays
-    fx = G.fixture('tiny')
-    d = fx['input_data']
-    verts = d['vertices'][0]
-    wb = np.stack([verts.min(0) - 0.05, verts.max(0) + 0.05])
-    K, R, T = synth.orbit_camera(0.4, verts.mean(0).astype(np.float64), 3.0, 32, 32)
-    o, dd, nr, fr, m = dataset_rays(G.dev_tensor(torch.from_numpy(K)), G.dev_tensor(torch.from_numpy(R)), G.dev_tensor(torch.from_numpy(T)),
-                                    G.dev_tensor(torch.from_numpy(wb)), 32, 32)
-    assert np.abs(o.cpu().numpy() - d['ray_o_all'][0, 0]).max() < 1e-5
-    assert np.abs(dd.cpu().numpy() - d['ray_d_all'][0, 0]).max() < 1e-5
-    mm = m.cpu().numpy()
-    assert (mm != d['mask_at_box_all'][0, 0]).mean() < 0.01
-    both = mm & d['mask_at_box_all'][0, 0]
-    assert np.abs(nr.cpu().numpy() - d['near_all'][0, 0, :, 0])[both].max() < 1e-3
-    assert np.abs(fr.cpu().numpy() - d['far_all'][0, 0, :, 0])[both].max() < 1e-3
+    g = np.load(os.path.join(G.GOLDEN, 'rays.npz'))
+    for name in [str(c) for c in g['cases']]:
+        H, W = int(g[f'{name}_H']), int(g[f'{name}_W'])
+        t = lambda k: G.dev_tensor(torch.from_numpy(g[f'{name}_{k}']))
+        o, dd, nr, fr, m = dataset_rays(t('K'), t('R'), t('T'), t('bounds'), H, W)
+        mm = G.plain(m).numpy()
+        assert (mm == g[f'{name}_mask_at_box']).all(), (name, int((mm != g[f'{name}_mask_at_box']).sum()))
+        for got, key in ((o, 'ray_o'), (dd, 'ray_d'), (nr, 'near'), (fr, 'far')):
+            a, b = G.plain(got).numpy(), g[f'{name}_{key}']
+            bad = a != b
+            assert bad.sum() <= 2, (name, key, int(bad.sum()))
+            if bad.any():
+                assert np.abs(a[bad] - b[bad]).max() <= np.spacing(np.abs(b[bad])).max(), (name, key)
+        assert int((G.plain(dd).numpy() == np.float32(1e-8)).sum()) == int((g[f'{name}_ray_d'] == np.float32(1e-8)).sum())
 
 
 def _generator(fx):

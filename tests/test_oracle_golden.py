@@ -208,3 +208,18 @@ def test_stage_gradients_are_consistent(state):
     n = g['stage.tokens_in'].shape[0]
     assert g['stage.tokens_in'].shape == (n, 3, 32) and g['stage.tokens_out'].shape == (n, 3, 32)
     assert float(g['stage.tokens_out'][:, 2].abs().max()) == 0.0         # the decoder never reads slot 2 (triplane.py:285-316)
+
+
+def test_dataset_ray_restatement_matches_reference_source(golden_dir):
+    """synthdata/synth.py's get_rays / get_near_far / packing (what every fixture's rays come from) against the outputs of the
+    reference's OWN function source (tests/golden/rays.npz, oracle/make_golden.py::run_rays): bit for bit, including the
+    in-place 1e-8 patch of zero direction components."""
+    from oracle import synth
+    g = np.load(os.path.join(golden_dir, 'rays.npz'))
+    for name in [str(c) for c in g['cases']]:
+        H, W = int(g[f'{name}_H']), int(g[f'{name}_W'])
+        ro, rd = synth.get_rays(H, W, g[f'{name}_K'], g[f'{name}_R'], g[f'{name}_T'])
+        ray_o, ray_d, near, far, at_box = synth.pack_near_far(g[f'{name}_bounds'], ro, rd)
+        for got, key in ((ray_o, 'ray_o'), (ray_d, 'ray_d'), (near, 'near'), (far, 'far'), (at_box, 'mask_at_box')):
+            assert np.array_equal(got, g[f'{name}_{key}']), (name, key)
+        assert (ray_d == np.float32(1e-8)).sum() > 0          # every case has exact zeros for the reference to patch
