@@ -88,7 +88,7 @@ def main():
     if rank == 0:
         print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
                               unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
-                              scaling='weak', vs_baseline=None, dtype='fp32 backward (rocBLAS sgemm + fp32 kernels), bf16x3 MFMA forward',
+                              scaling='weak', vs_baseline=None, dtype='fp32 backward (rocBLAS sgemm + fp32 kernels), f16x3 MFMA forward',
                               data='synthetic', status='EXPERIMENTAL: backward kernels not yet verified on hardware', final_loss=float(loss),
                               config=dict(workload=f'{a.config}: one view per GPU, stub loss MSE(rgb)+MSE(acc)', rays=R))))
     if world > 1:

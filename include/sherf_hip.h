@@ -157,21 +157,18 @@ int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int 
 int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t stream);
 
 /* a13+a14: rgb positional encoding -> slot-2 token, 3-token transformer (renderer.py:949-993), pos/view
- * encodings (:875-916) and NeRFDecoder (triplane.py:285-316) as one MFMA kernel; weights arrive as the
- * pre-packed fragment stream built by sherf_amd/mlp_pack.py.  prec: 0 = bf16, 1 = bf16x3 (hi/lo split,
- * fp32-grade).  shape: 0 = 8 waves x 1 column tile per workgroup (2 waves/SIMD), 1 = 4 waves x 2 tiles (1 wave/SIMD,
- * 512 registers), 2 = EXPERIMENTAL split (prec 1 only): the VALU-bound transformer prologue and the MFMA-bound decoder as two
- * launches; `tokens` is then used as scratch (z_0 / z_1 fragments overwrite the first 8 KiB of every tile); 3 = shape 2 with the
- * decoder walking two output tiles of every 128-input layer per ring step (26 steps instead of 40); 4 = EXPERIMENTAL shape 0 as
- * persistent workgroups (one per CU, weight ring kept streaming across tile groups); 5 / 6 / 7 = shape 0 with a different instruction
- * schedule only (5: previous chunk's epilogue interleaved into the MFMA stream, 6: one wave per SIMD at raised issue priority,
- * 7: both); 8 = 4 waves x 1 tile: half-size workgroups, two co-resident per CU with two-slot weight rings, not coupled by each
- * other's barriers (9 = 8 with the schedule of 5; 10 = 8 with the MFMA-bound decoder phase at raised issue priority;
- * 11 = 8 as persistent workgroups like 4, two per CU: no empty workgroups, no launch gaps, no host synchronisation) -- all bit-identical results, picked per device by sherf_amd.tune.  out[c] = (r,g,b,sigma). */
+ * encodings (:875-916) and NeRFDecoder (triplane.py:285-316) as one MFMA kernel (csrc/mlp.hip: 4-wave workgroups, two per CU,
+ * 3-slot LDS ring of <= 20 KiB weight steps, two independent accumulator chains per step); weights arrive as the pre-packed
+ * fragment stream built by sherf_amd/mlp_pack.py FOR THE SAME `prec`.  prec: 1 = f16x3 (operands split hi + lo in fp16, three
+ * MFMAs per product, fp32 accumulate: fp32-grade, the default), 0 = bf16 (one product; north_star's nominal precision, misses the
+ * 1e-3 tolerance).  shape: must be 0 (round 1's alternative launch shapes were measured and removed).
+ * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream);
-/* layout of the weight stream the kernel expects: number of chunks and K-blocks per chunk. */
-int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int32_t max_chunks);
+/* layout of the weight stream the kernel expects for `prec`: *n_steps steps; step_pieces_host[s] = its size in 1 KiB pieces (hi [, lo]
+ * fragments, zero-padded to a multiple of 4); units[s * 10 + u] = chunk * 16 + K-block of the u-th (chunk, K-block) unit the kernel
+ * consumes in step s (-1 = none / padding).  sherf_amd/mlp_pack.py restates it; tests/test_boundary.py compares the two. */
+int sherf_mlp_stream_layout(int prec, int32_t* n_steps, int32_t* step_pieces_host, int32_t* units, int32_t max_steps);
 
 /* a15+a16: scatter-back + MipRayMarcher2 (renderer.py:364-371, ray_marcher.py:25-64) on the compact samples;
  * masked-out samples (sigma=-80) contribute exact zeros so they are skipped.  rgb[R][3], depth[R], acc[R]. */
@@ -226,6 +223,13 @@ int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do,
  * (scale, shift, relu(shift)); training != 0: batch statistics into stats[2][C], else stats holds running stats. */
 int sherf_svox_bn_finalize(const int64_t* acc, const int32_t* n_total_rows, int C, const float* gamma, const float* beta,
                            float* stats, int training, float* bnparam, sherf_stream_t stream);
+/* nn.BatchNorm1d's train-mode side effect (renderer.py:812-871: BatchNorm1d(eps 1e-3, momentum 0.01) behind every conv) for all
+ * layers of the encoder in one launch: running_mean / running_var <- (1 - momentum) old + momentum batch (variance unbiased by
+ * n / (n - 1)), num_batches_tracked += 1.  The arguments are HOST arrays of n_layers (<= SHERF_SVOX_MAX_LAYERS) device pointers /
+ * values: stats[l] = [2][C_l] batch mean, biased variance (written by the frame); n_rows[l] = the row count they were taken over. */
+int sherf_svox_bn_running_update(int n_layers, const float* const* stats, float* const* running_mean, float* const* running_var,
+                                 int64_t* const* num_batches_tracked, const int32_t* const* n_rows, const int32_t* channels,
+                                 const float* momentum, sherf_stream_t stream);
 /* ---------------------------------------------------------------------------------------------
  * a3: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-61). cam2world[N][16], intr[N][9]. */
 /* ---------------------------------------------------------------------------------------------

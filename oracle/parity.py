@@ -1,0 +1,86 @@
+"""TEST INFRASTRUCTURE (checker only: imported by tests/, bench.py's parity leg and __graft_entry__.smoke()).
+
+The margin protocol of SURVEY.md section 7, hard part 1.  The path contains three DISCONTINUOUS selectors --
+the 5 cm shell threshold d^2 < 0.0025 (renderer.py:315-319), the nearest posed vertex (:315, :564) and the nearest T-pose
+vertex (:627) -- so two correct fp32 implementations legitimately disagree on samples whose decision margin is within the
+rounding error of the quantities compared (|x| ~ 1 m -> 1e-7 on a coordinate -> ~1e-8 on d^2 at d = 5 cm).  Parity is therefore
+stated as:
+
+  * flips     every sample on which the two implementations take a different branch is listed with the ORACLE's margin;
+              all margins must be below `eps` (default 1e-6 on d^2, two orders above the rounding error) -- a flip with a
+              larger margin is a bug, not rounding;
+  * clean set samples valid in both, same vertex ids, all three oracle margins > eps: compared per sample with a TRUE relative
+              metric  |ours - ref| / max(|ref|, floor)   (floors: sigma+ 1.0 [1/m], rgb 0.1 of the [0,1] range);
+  * rays      a ray may exceed the image tolerance only if it contains a flipped / in-margin sample ("explained").
+"""
+import numpy as np
+import torch
+
+THRESH2 = 0.05 ** 2
+EPS = 1e-6
+FLOOR_SIGMA = 1.0
+FLOOR_RGB = 0.1
+
+
+def sample_protocol(o, cs_idx, cs_vid, cs_tvid, sample_out, S, eps=EPS):
+    """o: oracle dict with mask [N], d2_all [N], valid [nv], vert_id, t_vert_id, vert_gap, t_vert_gap, sample_rgb, sample_sigma.
+    cs_idx / cs_vid / cs_tvid [n] int, sample_out [n,4] = (rgb, sigma raw): the implementation's compact samples (any order).
+    -> report dict (python scalars) + per-ray bool array `ray_touched` (ray contains a flipped or in-margin sample)."""
+    t = lambda x: torch.as_tensor(x).detach().cpu()
+    mask_o = t(o['mask']).bool()
+    N = mask_o.numel()
+    d2 = t(o['d2_all']).double()
+    cs_idx = t(cs_idx).long(); cs_vid = t(cs_vid).long(); cs_tvid = t(cs_tvid).long(); sample_out = t(sample_out).double()
+    mask_h = torch.zeros(N, dtype=torch.bool); mask_h[cs_idx] = True
+    thr_margin = (d2 - THRESH2).abs()
+    flip = mask_h != mask_o
+    rep = dict(samples=int(N), valid_oracle=int(mask_o.sum()), valid_ours=int(mask_h.sum()), eps=eps,
+               mask_flips=int(flip.sum()), mask_flip_max_margin=float(thr_margin[flip].max()) if flip.any() else 0.0)
+    # samples valid in both, aligned through the dense index
+    pos_o = torch.full((N,), -1, dtype=torch.long); pos_o[t(o['valid']).long()] = torch.arange(int(mask_o.sum()))
+    both = mask_o[cs_idx]
+    io = pos_o[cs_idx[both]]                                   # oracle row of each of our common samples
+    vid_o, tvid_o = t(o['vert_id']).long()[io], t(o['t_vert_id']).long()[io]
+    gap_v, gap_t = t(o['vert_gap']).double()[io], t(o['t_vert_gap']).double()[io]
+    vflip = cs_vid[both] != vid_o
+    tflip = (cs_tvid[both] != tvid_o) & ~vflip                 # (a different posed vertex moves x_c: its T-vertex may differ legitimately)
+    rep.update(common=int(both.sum()), vertex_flips=int(vflip.sum()), vertex_flip_max_gap=float(gap_v[vflip].max()) if vflip.any() else 0.0,
+               t_vertex_flips=int(tflip.sum()), t_vertex_flip_max_gap=float(gap_t[tflip].max()) if tflip.any() else 0.0)
+    clean = ~vflip & ~tflip & (gap_v > eps) & (gap_t > eps) & (thr_margin[cs_idx[both]] > eps)
+    so = sample_out[both]
+    sig_h, sig_o = so[:, 3].clamp(min=0), t(o['sample_sigma']).double().view(-1)[io].clamp(min=0)
+    rgb_h, rgb_o = so[:, :3], t(o['sample_rgb']).double()[io]
+    e_sig = (sig_h - sig_o).abs() / sig_o.clamp(min=FLOOR_SIGMA)
+    e_rgb = ((rgb_h - rgb_o).abs() / rgb_o.abs().clamp(min=FLOOR_RGB)).max(1)[0]
+    c = clean
+    rep.update(clean=int(c.sum()), in_margin=int((~c).sum()),
+               sigma_rel_max=float(e_sig[c].max()) if c.any() else 0.0, sigma_rel_mean=float(e_sig[c].mean()) if c.any() else 0.0,
+               rgb_rel_max=float(e_rgb[c].max()) if c.any() else 0.0, rgb_rel_mean=float(e_rgb[c].mean()) if c.any() else 0.0,
+               floors=dict(sigma=FLOOR_SIGMA, rgb=FLOOR_RGB),
+               sigma_rel_to_max=float((sig_h - sig_o).abs()[c].max() / sig_o.max()) if c.any() else 0.0,
+               rgb_abs_max=float((rgb_h - rgb_o).abs()[c].max()) if c.any() else 0.0)
+    R = N // S
+    touched = torch.zeros(R, dtype=torch.bool)
+    touched[torch.nonzero(flip)[:, 0] // S] = True
+    touched[cs_idx[both][~c] // S] = True
+    return rep, touched.numpy()
+
+
+def image_protocol(rgb, acc, o_rgb, o_acc, ray_touched, tol=1e-3, target_seed=5):
+    """Images [R,3] in [-1,1] / [R]: PSNR on [0,1] (test_loop.py:36-37), |dPSNR| against a fixed synthetic target, per-ray error
+    relative to the range, and the split of the rays over tolerance into explained (contain a flipped / in-margin sample) and not."""
+    a = lambda x: np.asarray(torch.as_tensor(x).detach().cpu(), dtype=np.float64)
+    rgb, acc, o_rgb, o_acc = a(rgb), a(acc).reshape(-1), a(o_rgb), a(o_acc).reshape(-1)
+    mse = float(np.mean(((rgb - o_rgb) / 2) ** 2))
+    psnr = lambda x, y: float(-10.0 * np.log10(max(np.mean(((x - y) / 2) ** 2), 1e-300)))
+    target = np.random.RandomState(target_seed).uniform(-1, 1, o_rgb.shape)
+    err = np.abs(rgb - o_rgb).max(1) / 2.0                        # relative to the [-1, 1] range
+    err_acc = np.abs(acc - o_acc)
+    over = (err > tol) | (err_acc > tol)
+    clean = ~ray_touched
+    return dict(psnr_vs_oracle_db=float(-10.0 * np.log10(mse)) if mse > 0 else float('inf'),
+                dpsnr_vs_target_db=abs(psnr(rgb, target) - psnr(o_rgb, target)),
+                rays=int(err.size), rays_touched_by_margin=int(ray_touched.sum()),
+                rays_over_tolerance=int(over.sum()), rays_over_tolerance_unexplained=int((over & clean).sum()),
+                rgb_err_max_clean=float(err[clean].max()) if clean.any() else 0.0, acc_err_max_clean=float(err_acc[clean].max()) if clean.any() else 0.0,
+                rgb_err_max_all=float(err.max()), acc_err_max_all=float(err_acc.max()), tolerance=tol)

@@ -126,6 +126,22 @@ def nearest_vertex(x, verts, chunk=None):
     return d2, idx
 
 
+def second_nearest_gap(x, verts, idx, chunk=None):
+    """d^2 of the SECOND nearest vertex minus d^2 of the nearest one (`idx`, as returned by nearest_vertex) [n]: the margin by
+    which the discontinuous selector `idx` is decided -- SURVEY.md section 7 hard part 1 (parity is only defined off the ties)."""
+    n = x.shape[0]
+    chunk = chunk or NN_CHUNK
+    gap = torch.empty(n, dtype=F32)
+    for s in range(0, n, chunk):
+        q = x[s:s + chunk]
+        dx = q[:, None, 0] - verts[None, :, 0]; dy = q[:, None, 1] - verts[None, :, 1]; dz = q[:, None, 2] - verts[None, :, 2]
+        dd = (dx * dx + dy * dy) + dz * dz
+        first = dd.gather(1, idx[s:s + chunk, None])
+        dd.scatter_(1, idx[s:s + chunk, None], float('inf'))
+        gap[s:s + chunk] = dd.min(1)[0] - first[:, 0]
+    return gap
+
+
 def target_to_canonical(st, params, t_params, verts_smpl_unused, x_s, v_s, vid):
     """renderer.py:558-621, the literal per-point chain. x_s, v_s [n,3] in the SMPL frame; vid [n] nearest posed vertex."""
     A = bone_transforms(st, params['poses'].view(-1), params['shapes'].view(-1))
@@ -503,6 +519,13 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
             rgbs.append(rgb); sigs.append(sig); toks_in.append(tok); toks_out.append(z)
         rgb_s, sig_s = torch.cat(rgbs), torch.cat(sigs)
         col_full[valid] = rgb_s; sig_full[valid] = sig_s
+        if keep or options.get('margins'):
+            # decision margins of the three discontinuous selectors on the path (shell threshold, nearest posed vertex, nearest
+            # T-pose vertex): what tests / bench use to tell an implementation's legitimate boundary flips from errors
+            out.update(d2_all=d2, vert_gap=second_nearest_gap(xs, verts_s, vid),
+                       t_vert_gap=second_nearest_gap(x_c, input_data['t_vertices'].view(-1, 3), tvid))
+            if not keep:
+                out.update(vert_id=vid, t_vert_id=tvid, sample_rgb=rgb_s, sample_sigma=sig_s)
         if keep:
             out.update(vert_id=vid, vert_d2=d2[valid], x_s=xs, v_s=vs, x_c=x_c, v_c=v_c, x_w=x_w, t_vert_id=tvid, uv=uv,
                        f2d=f2d, tap_rgb=tap_rgb, grid=g, f3d_raw=f3d_raw, f3d=f3d, tokens_in=torch.cat(toks_in),

@@ -5,77 +5,107 @@
 //   PE6(x_c), PE4(v_c)                                            (renderer.py:875-916)
 //   NeRFDecoder 8x128 with skip, sigma / feature / view / rgb     (triplane.py:285-316)
 //
-// Formulation: D^T = W . X^T -- the weight matrix is the MFMA A operand (32 output features per tile) and 32
-// samples are the B operand columns, using v_mfma_f32_32x32x16_bf16.  A wave owns 32 samples for the whole
-// network; a layer's fp32 accumulator tile (lane = sample, 16 regs = 16 of the tile's 32 features) is
-// converted in registers into two B operand K-blocks of the next layer: the K permutation this implies,
+// Formulation: D^T = W . X^T -- the weight matrix is the MFMA A operand (32 output features per tile, a "chunk") and 32
+// samples are the B operand columns of v_mfma_f32_32x32x16_{f16,bf16}.  A wave owns 32 samples for the whole network; a
+// layer's fp32 accumulator tile (lane = sample, 16 regs = 16 of the tile's 32 features) is converted in registers into two B
+// operand K-blocks of the next layer: the K permutation this implies,
 //     k-slot (kb, h, e)  <->  feature 16*kb + (e&3) + 8*(e>>2) + 4*h,
-// is baked into the packed weight stream (sherf_amd/mlp_pack.py), so activations never leave the register
-// file and never cross lanes (except the 3x3 attention dot products and LayerNorm sums: one lane^32 exchange).
-// Weights stream L2 -> LDS one output tile ("chunk") at a time in MFMA fragment order (ds_read_b128,
-// lane-linear, conflict free), double buffered, one barrier per chunk, shared by the 8 waves of a workgroup.
+// is baked into the packed weight stream (sherf_amd/mlp_pack.py), so activations never leave the register file and never cross
+// lanes (except the 3x3 attention dot products and LayerNorm sums: one lane^32 exchange).
 //
-// prec 0: bf16 operands, fp32 accumulate.   prec 1 ("bf16x3"): operands split hi+lo, three MFMAs per product
-// (lo*hi + hi*lo + hi*hi), ~2^-16 relative error -- the mode that meets the 1e-3 parity tolerance.
+// Schedule (round 2; measured with the in-kernel timeline of tools/mlp_trace.py, profiles/r02_mlp_trace_v1.txt): the round-1
+// kernel walked one chunk per step as ONE dependent chain of 24 MFMAs; any instruction between two MFMAs on the same
+// accumulator (the next fragment's ds_read, its s_waitcnt) forfeits the back-to-back forwarding, so every MFMA took ~81 cycles
+// of its wave's time and a SIMD's two waves together kept the matrix pipe < 60 % busy (waits on the weight DMA and the
+// workgroup barrier were only 12 %).  Here every step feeds TWO independent accumulator chains -- a pair of output chunks
+// sharing the B operands (or the even / odd K-blocks of a single chunk) -- issued alternately, and the weight stream is cut
+// into uniform steps of <= 20 KiB (a pair of chunks x 4-5 K-blocks x hi,lo) so that a 3-slot ring (two steps of prefetch
+// distance) fits twice into a CU's LDS: two 4-wave workgroups per CU, one wave of each per SIMD, never phase-locked by each
+// other's barriers -- one runs its VALU-bound transformer prologue under the other's MFMA-bound decoder.
+//
+// prec 1 ("f16x3", default): operands split hi + lo in fp16 (11 + 11 significant bits), three MFMAs per product
+//   (lo*hi + hi*lo + hi*hi, fp32 accumulate): ~2^-21 relative, the mode that meets the 1e-3 per-sample tolerance.
+// prec 0 ("bf16"): one bf16 product (north_star's nominal precision; misses the tolerance by ~10x, reported for reference).
 #include "common.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // a 16-byte MFMA operand fragment (native vector: usable as an asm "v" operand)
 
 constexpr int N_CHUNKS = 49;
-constexpr int MAX_NKB = 13;
+constexpr int N_STEPS = 43;
+constexpr int NW = 4;               // waves per workgroup
+constexpr int NSLOT = 3;            // ring slots: two steps of prefetch distance
 constexpr int BIAS_LN = N_CHUNKS;   // index of the first LayerNorm table in wbias ([idx][2][16] floats)
 
-// K-blocks (16 inputs each) per chunk; a chunk is one 32-row output tile of one layer.
-__host__ __device__ constexpr int chunk_nkb(int c) {
-    return c == 0 ? 2        // rgb PE -> slot-2 token
-         : c <= 5 ? 2        // to_qkv tiles: [q0|q1] [q2|pad] [k0|k1] [k2|v0] [v1|v2]
-         : c == 6 ? 3        // to_out (48 -> 32)
-         : c <= 8 ? 2        // FF 32->32, 32->32
-         : c <= 12 ? 5       // pts_linears.0 : PE6 (3 kb) + z0 (2 kb)
-         : c <= 28 ? 8       // pts_linears.1-4
-         : c <= 32 ? 13      // pts_linears.5 : PE6 + z0 + h
-         : c <= 40 ? 8       // pts_linears.6-7
-         : c <= 45 ? 8       // feature_linear (4 tiles) + alpha_linear (1 tile, row 0)
-         : c <= 47 ? 12      // views_linear : feature (8) + PE4 (2) + z1 (2)
-         : 4;                // rgb_linear (rows 0..2)
+// ---- the weight stream: N_STEPS steps of `step_units` units; a unit = the A fragments (hi [, lo]: 1 KiB each) of one
+//      (chunk, K-block); a chunk = one 32-row output tile of one layer (49 of them, sherf_amd/mlp_pack.py).  Steps: 0-1
+//      transformer (chunks 0-4 | 5-8 + one padding unit), 2-3 pts_linears.0 (a pair of chunks x 5 kb each), 4-19
+//      pts_linears.1-4 (pair x K-half), 20-25 pts_linears.5 (pair x {5, 4, 4} kb), 26-33 pts_linears.6-7, 34-37
+//      feature_linear, 38 alpha_linear (8 kb), 39-41 views_linear (pair x 4 kb), 42 rgb_linear (4 kb). ----
+__host__ __device__ constexpr int step_units(int s) {
+    return s < 4 ? 10 : s < 20 ? 8 : s < 26 ? ((s - 20) % 3 == 0 ? 10 : 8) : s < 42 ? 8 : 4;
 }
-__host__ __device__ constexpr int chunk_off_kb(int c) {   // stream offset in KiB; every chunk stores hi then lo
+// unit u of step s -> chunk * 16 + kb  (-1 = padding); the order in which the kernel consumes them
+__host__ __device__ constexpr int step_unit(int s, int u) {
+    int c = -1, kb = 0;
+    if (s == 0) { if (u < 2) { c = 0; kb = u; } else { c = 1 + (u - 2) / 2; kb = (u - 2) % 2; } }
+    else if (s == 1) {
+        if (u < 2) { c = 5; kb = u; } else if (u < 5) { c = 6; kb = u - 2; } else if (u < 7) { c = 7; kb = u - 5; } else if (u < 9) { c = 8; kb = u - 7; }
+    }
+    else if (s < 4) { c = 9 + 2 * (s - 2) + (u & 1); kb = u / 2; }
+    else if (s < 20) { const int q = s - 4; c = 13 + 4 * (q / 4) + 2 * ((q % 4) / 2) + (u & 1); kb = 4 * (q % 2) + u / 2; }
+    else if (s < 26) { const int q = s - 20, seg = q % 3; c = 29 + 2 * (q / 3) + (u & 1); kb = (seg == 0 ? 0 : seg == 1 ? 5 : 9) + u / 2; }
+    else if (s < 34) { const int q = s - 26; c = 33 + 4 * (q / 4) + 2 * ((q % 4) / 2) + (u & 1); kb = 4 * (q % 2) + u / 2; }
+    else if (s < 38) { const int q = s - 34; c = 41 + 2 * (q / 2) + (u & 1); kb = 4 * (q % 2) + u / 2; }
+    else if (s == 38) { c = 45; kb = u; }
+    else if (s < 42) { c = 46 + (u & 1); kb = 4 * (s - 39) + u / 2; }
+    else { c = 48; kb = u; }
+    return c < 0 ? -1 : c * 16 + kb;
+}
+template <int PREC> __host__ __device__ constexpr int step_pieces(int s) {      // 1 KiB pieces, padded to one DMA round of the 4 waves
+    return s < 0 || s >= N_STEPS ? 0 : (step_units(s) * (PREC + 1) + NW - 1) / NW * NW;
+}
+template <int PREC> __host__ __device__ constexpr int step_off_kib(int s) {
     int o = 0;
-    for (int i = 0; i < c; ++i) o += 2 * chunk_nkb(i);
+    for (int i = 0; i < s; ++i) o += step_pieces<PREC>(i);
     return o;
 }
 
 template <int PREC> struct BFrag;
-template <> struct BFrag<0> { uint4 hi; };
-template <> struct BFrag<1> { uint4 hi, lo; };
+template <> struct BFrag<0> { u32x4 hi; };
+template <> struct BFrag<1> { u32x4 hi, lo; };
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
     bf16x2 v;
     v[0] = (__bf16)a; v[1] = (__bf16)b;
     return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ float bf16_rt(float a) { return (float)((__bf16)a); }
-
-// hi/lo split of a pair for the bf16x3 mode: hi = the top 16 bits (truncation; one v_perm for the pair), lo = x - hi is
-// exact in fp32 and then rounded to bf16, so hi + lo carries ~17 bits whichever way hi was rounded.
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
-    hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);          // [a.hi16 | b.hi16 << 16]
-    lo = pack2(a - __builtin_bit_cast(float, ua & 0xFFFF0000u), b - __builtin_bit_cast(float, ub & 0xFFFF0000u));
+// f16 hi/lo split of a pair: hi = the pair rounded toward zero (one v_cvt_pkrtz), lo = x - hi exactly in fp32 (hi keeps x's
+// leading 11 bits) and then rounded to fp16: hi + lo carries 22 significant bits.  |x| must stay below 65504 (fp16 range): the
+// activations of an 8 x 128 ReLU network fed with encodings in [-1, 1] and O(1) tokens sit 3-4 orders of magnitude below that.
+__device__ __forceinline__ void split2_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    const float ra = __builtin_fmaf((float)h[0], -1.0f, a), rb = __builtin_fmaf((float)h[1], -1.0f, b);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
 template <int PREC>
 __device__ __forceinline__ BFrag<PREC> make_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
     BFrag<PREC> f;
     if constexpr (PREC == 1) {
-        split2(v0, v1, f.hi.x, f.lo.x); split2(v2, v3, f.hi.y, f.lo.y);
-        split2(v4, v5, f.hi.z, f.lo.z); split2(v6, v7, f.hi.w, f.lo.w);
+        uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+        split2_f16(v0, v1, h0, l0); split2_f16(v2, v3, h1, l1);
+        split2_f16(v4, v5, h2, l2); split2_f16(v6, v7, h3, l3);
+        f.hi = u32x4{h0, h1, h2, h3}; f.lo = u32x4{l0, l1, l2, l3};
     } else {
-        f.hi = make_uint4(pack2(v0, v1), pack2(v2, v3), pack2(v4, v5), pack2(v6, v7));
+        f.hi = u32x4{pack2_bf16(v0, v1), pack2_bf16(v2, v3), pack2_bf16(v4, v5), pack2_bf16(v6, v7)};
     }
     return f;
 }
@@ -92,88 +122,68 @@ __device__ __forceinline__ void split_tile(const f32x16& a, BFrag<PREC>& k0, BFr
     k1 = make_frag<PREC>(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
 }
 
-__device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (PREC == 1)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Kernel shape: NW waves per workgroup, NTL column tiles (32 samples each) per wave.
-//   <NW=8, NTL=1>: two waves per SIMD (<= 256 VGPRs), each wave one tile.
-//   <NW=4, NTL=2>: one wave per SIMD (<= 512 VGPRs), each wave two tiles: every weight fragment read from LDS feeds two
-//                  MFMA chains, half the barriers and LDS traffic per sample.
-// The weight stream is walked in STEPS: the small transformer chunks 0..8 are replayed once per tile (keeps the
-// attention state of only one tile live), then the decoder chunks 9..48 run once for all tiles of the wave.
-// ---------------------------------------------------------------------------------------------------------------
-// PHASE 0: the fused kernel (transformer + decoder).  PHASE 1 / 2 (shape '8x1split', experimental): the VALU-bound
-// transformer prologue and the MFMA-bound decoder as two launches -- 1 streams only chunks 0..8 (tiny ring slots => several
-// workgroups per CU, its waves no longer phase-locked to MFMA-bound ones) and leaves z_0, z_1 as ready-made bf16 hi/lo
-// B-fragments in the first 8 KiB of the tile's `tokens` block; 2 streams chunks 9..48 and starts from those fragments.
-// PHASE 3 = PHASE 2 with the 128-input layers walked TWO output tiles per step (one DMA of both chunks into a 32 KiB slot, two
-// independent accumulator chains, half the workgroup barriers of the trunk): 26 steps instead of 40.
-// PHASE -1 (shape '8x1persist', experimental) = the fused kernel as PERSISTENT workgroups: one per CU, each walking tile groups
-// blockIdx.x, blockIdx.x + gridDim.x, ...; the bias tables stay in LDS and the weight ring never drains -- the last three steps
-// of a group already stream steps 0..2 of the next one into the slots they free (slot(s) = s % 3 holds for every group) -- so
-// a group pays neither the launch gap nor the exposed first-chunk latency of a fresh workgroup.
-template <int NTL, int PHASE> __host__ __device__ constexpr int n_steps() {
-    return PHASE == 1 ? 9 * NTL : PHASE == 2 ? N_CHUNKS - 9 : PHASE == 3 ? 26 : 9 * NTL + (N_CHUNKS - 9);
-}
-template <int NTL, int PHASE> __host__ __device__ constexpr int step_chunk(int s) {       // first chunk of a step
-    if (PHASE == 3)
-        return s < 4 ? 9 + s : s < 12 ? 13 + 2 * (s - 4) : s < 16 ? 29 + (s - 12) : s < 20 ? 33 + 2 * (s - 16) : s < 22 ? 41 + 2 * (s - 20)
-             : s == 22 ? 45 : s < 25 ? 46 + (s - 23) : 48;
-    return PHASE == 2 ? s + 9 : s < 9 * NTL ? s % 9 : s - 9 * (NTL - 1);
-}
-template <int PHASE> __host__ __device__ constexpr int step_count(int s) {                // chunks streamed in that step
-    return PHASE == 3 && ((s >= 4 && s < 12) || (s >= 16 && s < 22)) ? 2 : 1;
-}
+// SHERF_MLP_TRACE (profiling builds only, tools/mlp_trace.py): every wave stamps s_memtime at the end of its MFMA stream, after the
+// weight-DMA wait and after the workgroup barrier of every step into LDS; selected workgroups copy the stamps out at the end.
+#ifndef SHERF_MLP_TRACE
+#define SHERF_MLP_TRACE 0
+#endif
+#if SHERF_MLP_TRACE
+__device__ uint32_t* g_mlp_trace = nullptr;           // [slot][wave 0..7][64 steps][4] u32
+__device__ int g_mlp_trace_every = 0;
+#define SHERF_TRACE_STAMP(cx, step, k) do { if ((cx).lane == 0) (cx).trace[(step) * 4 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
+#endif
 
-template <int PREC, int NW, int NTL, int PHASE = 0> struct Ctx {
+// SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers
+#ifndef SHERF_MLP_ABLATE
+#define SHERF_MLP_ABLATE 0
+#endif
+
+template <int PREC> struct Ctx {
     const char* ws;          // packed weight stream (global)
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
-    char* lds;               // NSLOT ring slots
-    int lane, h, dbg, wave, pending;
+    const char* lds;         // NSLOT ring slots (generic pointer, + this lane's 16 bytes: what the ds_reads use)
+    uint32_t lds_addr;       // LDS byte address of the ring (what the DMA's M0 takes), wave-uniform
+    int lane, h, wave;
 #if SHERF_MLP_TRACE
     uint32_t* trace;         // this wave's [64][4] stamps in LDS
 #endif
-    bool more;               // PHASE -1: this workgroup has another tile group after the current one (uniform)
-    static constexpr int SLOT = (PHASE == 1 ? 3 : PHASE == 3 ? 16 : MAX_NKB) * 1024 * (PREC + 1);     // chunks 0..8: <= 3 K-blocks; pairs: 2 x 8
-    // <NW=4, NTL=1> (shape '4x1'): half-size workgroups, TWO co-resident per CU (one wave of each per SIMD) that are not coupled by
-    // each other's barriers; their rings must fit the 160 KiB LDS together -> two slots, one step of prefetch distance.
-    static constexpr int NSLOT = (NW == 4 && NTL == 1) ? 2 : 3;
-    __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT + lane * 16; }
+    static constexpr int UNIT = (PREC + 1) * 1024;                         // bytes per unit: hi [, lo]
+    static constexpr int SLOT = (PREC == 1 ? 20 : 12) * 1024;              // the largest step, padded
+    __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT; }
 };
 
-// Weight stream L2 -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPR round trip), three ring
-// slots, two steps of prefetch distance.  Completion: a wave waits (counted vmcnt) until only the pieces of the most
-// recently issued step are still in flight, then the workgroup barrier makes every wave's pieces visible.
+// Weight stream L2 -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPR round trip).  Every step is a whole
+// number of rounds of the four waves (the stream is padded), so the issue is branch free.  Completion: a wave waits (counted
+// vmcnt) until only the pieces of the most recently issued step are still in flight, then the workgroup barrier makes every
+// wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int PREC, int NW, int NTL, int PHASE>
-__device__ __forceinline__ int dma_issue(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
-    if (step >= n_steps<NTL, PHASE>() || (cx.dbg & 32)) return 0;
-    const int c = step_chunk<NTL, PHASE>(step);
-    const int pieces = chunk_nkb(c) * (PREC + 1) * step_count<PHASE>(step);       // a paired step streams two equal, adjacent chunks
-    const char* src = cx.ws + (size_t)chunk_off_kb(c) * 1024 + cx.lane * 16;
-    char* dst = cx.lds + (step % Ctx<PREC, NW, NTL, PHASE>::NSLOT) * Ctx<PREC, NW, NTL, PHASE>::SLOT;
-    int n = 0;
-    constexpr int kMaxPieces = (PHASE == 3 ? 16 : MAX_NKB) * (PREC + 1);
+template <int PREC>
+__device__ __forceinline__ void dma_issue(Ctx<PREC>& cx, int step) {
+    if (step >= N_STEPS || (SHERF_MLP_ABLATE & 32)) return;
+    const char* src = cx.ws + (size_t)step_off_kib<PREC>(step) * 1024;          // (+ this lane's 16 bytes: folded into cx.ws)
+    const uint32_t dst = cx.lds_addr + (step % NSLOT) * Ctx<PREC>::SLOT;
 #pragma unroll
-    for (int i = 0; i < (kMaxPieces + NW - 1) / NW; ++i) {
-        const int p = cx.wave + i * NW;                        // wave-uniform
-        if (p < pieces) {
-            // Inline asm on purpose: hipcc drains an LDS-DMA it knows about (vmcnt(0)) before every ds_read that might alias
-            // it, which would serialise the ring.  M0 = LDS byte address of the piece (saved/restored: compiler-reserved).
-            const char* g = src + p * 1024;
-            uint32_t l = (uint32_t)(size_t)(lptr_t)(dst + p * 1024);
-            if constexpr (PHASE != 0) l = __builtin_amdgcn_readfirstlane(l);   // wave-uniform by construction; the split kernels' control
-                                                                               // flow hides that from the compiler ("s" constraint)
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
-            ++n;
-        }
+    for (int i = 0; i < step_pieces<PREC>(step) / NW; ++i) {
+        // piece p = wave + 4 i (the wave's own 1 KiB offset is folded into cx.ws / cx.lds_addr).  Inline asm on purpose: hipcc
+        // drains an LDS-DMA it knows about (vmcnt(0)) before every ds_read that might alias it, which would serialise the ring.
+        // M0 = LDS byte address of the piece (saved/restored: compiler-reserved).
+        const char* g = src + i * NW * 1024;
+        const uint32_t l = dst + i * NW * 1024;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(l) : "memory");
     }
-    return n;
 }
 
 __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt(n) needs an immediate
@@ -190,32 +200,19 @@ __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// end of step s: step s+1 must have landed (everything but the newest issue), then step s's slot is recycled for s+3
-// SHERF_MLP_TRACE (profiling builds only, tools/mlp_trace.py): every wave stamps s_memtime at the end of its MFMA stream, after the
-// weight-DMA wait and after the workgroup barrier of every step into LDS; selected workgroups copy the stamps out at the end.
-#ifndef SHERF_MLP_TRACE
-#define SHERF_MLP_TRACE 0
-#endif
-#if SHERF_MLP_TRACE
-__device__ uint32_t* g_mlp_trace = nullptr;           // [slot][wave 0..7][64 steps][4] u32
-__device__ int g_mlp_trace_every = 0;
-#define SHERF_TRACE_STAMP(cx, step, k) do { if ((cx).lane == 0) (cx).trace[(step) * 4 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
-#endif
-
-template <int PREC, int NW, int NTL, int PHASE>
-__device__ __forceinline__ void advance(Ctx<PREC, NW, NTL, PHASE>& cx, int step) {
-    constexpr int NSLOT = Ctx<PREC, NW, NTL, PHASE>::NSLOT;
+// end of step s: step s+1 must have landed (everything but the newest issue, step s+2), then step s's slot is recycled for s+3
+template <int PREC>
+__device__ __forceinline__ void step_wait(Ctx<PREC>& cx, int step) {
     SHERF_TRACE_STAMP(cx, step, 0);
-    wait_vm(NSLOT == 2 ? 0 : cx.pending);    // two slots: the newest issue IS step s+1
+    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(step + 2) / NW);
     SHERF_TRACE_STAMP(cx, step, 1);
-    if (!(cx.dbg & 64)) wg_barrier();
+    if (!(SHERF_MLP_ABLATE & 64)) wg_barrier();
     SHERF_TRACE_STAMP(cx, step, 2);
-    if constexpr (PHASE == -1) {             // past the end of this group: the freed slot takes step (step + 3) % 3 of the next group
-        if (step + NSLOT >= n_steps<NTL, PHASE>()) { cx.pending = cx.more ? dma_issue(cx, (step + NSLOT) % NSLOT) : 0; return; }
-    }
-    cx.pending = dma_issue(cx, step + NSLOT);
+}
+template <int PREC>
+__device__ __forceinline__ void advance(Ctx<PREC>& cx, int step) {
+    step_wait(cx, step);
+    dma_issue(cx, step + NSLOT);
 }
 
 template <class C>
@@ -243,11 +240,10 @@ __device__ __forceinline__ float exp_(float x) { return expf(x); }
 __device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
 __device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 #endif
-// SHERF_MLP_FAST_ERF (off; to be measured and parity-checked on hardware): Abramowitz-Stegun 7.1.26 for the exact-GELU erf,
-// |error| <= 1.5e-7, ~14 VALU instead of libm's ~38 -- the 32 erf evaluations per lane are the largest VALU block left
-// in the prologue (~1.2 K of 5.3 K instructions per tile).  tests/test_mlp_pack.py checks the formula in float32.
+// SHERF_MLP_FAST_ERF: Abramowitz-Stegun 7.1.26 for the exact-GELU erf, |error| <= 1.5e-7 (fp32 evaluation: tests/test_mlp_pack.py),
+// ~14 straight-line VALU instead of libm's ~38 + branches -- the 32 erf evaluations per lane were the largest VALU block of the prologue.
 #ifndef SHERF_MLP_FAST_ERF
-#define SHERF_MLP_FAST_ERF 0
+#define SHERF_MLP_FAST_ERF 1
 #endif
 __device__ __forceinline__ float erf_(float x) {
 #if SHERF_MLP_FAST_ERF
@@ -259,68 +255,99 @@ __device__ __forceinline__ float erf_(float x) {
     return erff(x);
 #endif
 }
-#ifndef SHERF_MLP_P1_WAVES
-#define SHERF_MLP_P1_WAVES 2     // waves per SIMD the transformer-only launch is compiled for (VGPR cap 512 / this)
+// SHERF_MLP_DECODER_PRIO: issue priority of a wave once it enters the MFMA-bound decoder (over the co-resident workgroup's wave on
+// the same SIMD whenever that one is in its VALU-bound prologue; a new wave starts at priority 0)
+#ifndef SHERF_MLP_DECODER_PRIO
+#define SHERF_MLP_DECODER_PRIO 2
 #endif
-#ifndef SHERF_MLP_INTERLEAVE
-#define SHERF_MLP_INTERLEAVE 0
-#endif
-// SHERF_MLP_WAVE_PRIO (off; to be measured): the two waves a SIMD hosts leave every workgroup barrier together, interleave their
-// MFMA chains and then run their VALU epilogues at the same time with the MFMA pipe idle.  Giving the first half of the waves
-// (one per SIMD) issue priority lets that wave finish its chain first and do its epilogue under the other wave's MFMAs.
-#ifndef SHERF_MLP_WAVE_PRIO
-#define SHERF_MLP_WAVE_PRIO 0
-#endif
-// acc[col] += W_step[kb0 .. kb0+NK) . B[col]: one segment of a chunk's K range, NCOL column sets sharing the A fragments
-// SHERF_MLP_SPLITK (experiment): the 8-K-block segments accumulate even / odd K-blocks in two independent chains (summed at the
-// end), so that a wave's MFMA stream is not one 24-deep dependent chain.
-#ifndef SHERF_MLP_SPLITK
-#define SHERF_MLP_SPLITK 0
-#endif
-template <int PREC, int NK, int NCOL, int IL>
-__device__ __forceinline__ void mma_seg(const char* s, int kb0, int nkb_total, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
-#if SHERF_MLP_SPLITK
-    if constexpr (PREC == 1 && NK == 8 && NCOL == 1) {
-        f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < NK; kb += 2) {
-            const uint4 ah0 = *reinterpret_cast<const uint4*>(s + (kb0 + kb) * 1024);
-            const uint4 al0 = *reinterpret_cast<const uint4*>(s + (nkb_total + kb0 + kb) * 1024);
-            const uint4 ah1 = *reinterpret_cast<const uint4*>(s + (kb0 + kb + 1) * 1024);
-            const uint4 al1 = *reinterpret_cast<const uint4*>(s + (nkb_total + kb0 + kb + 1) * 1024);
-            acc[0] = mfma(al0, b[0][kb].hi, acc[0]);
-            acc2 = mfma(al1, b[0][kb + 1].hi, acc2);
-            acc[0] = mfma(ah0, b[0][kb].lo, acc[0]);
-            acc2 = mfma(ah1, b[0][kb + 1].lo, acc2);
-            acc[0] = mfma(ah0, b[0][kb].hi, acc[0]);
-            acc2 = mfma(ah1, b[0][kb + 1].hi, acc2);
-        }
-        acc[0] += acc2;
-        return;
-    }
-#endif
+
+// ---- MFMA segments.  `s` = the step's slot (+ this lane's 16 bytes); unit u of the step lives at s + u * UNIT: hi, then lo. ----
+// NCOL column sets (tokens) sharing the A fragments of ONE chunk: the transformer's independent chains
+template <int PREC, int NK, int NCOL>
+__device__ __forceinline__ void mma_cols(const char* s, int u0, const BFrag<PREC> (&b)[NCOL][NK], f32x16 (&acc)[NCOL]) {
+    constexpr int UNIT = Ctx<PREC>::UNIT;
 #pragma unroll
     for (int kb = 0; kb < NK; ++kb) {
-        const uint4 ah = *reinterpret_cast<const uint4*>(s + (kb0 + kb) * 1024);
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(s + (u0 + kb) * UNIT);
         if constexpr (PREC == 1) {
-            const uint4 al = *reinterpret_cast<const uint4*>(s + (nkb_total + kb0 + kb) * 1024);
+            const u32x4 al = *reinterpret_cast<const u32x4*>(s + (u0 + kb) * UNIT + 1024);
 #pragma unroll
-            for (int t = 0; t < NCOL; ++t) {
-                acc[t] = mfma(al, b[t][kb].hi, acc[t]);
-                acc[t] = mfma(ah, b[t][kb].lo, acc[t]);
-            }
+            for (int t = 0; t < NCOL; ++t) acc[t] = mfma<PREC>(al, b[t][kb].hi, acc[t]);
+#pragma unroll
+            for (int t = 0; t < NCOL; ++t) acc[t] = mfma<PREC>(ah, b[t][kb].lo, acc[t]);
         }
 #pragma unroll
-        for (int t = 0; t < NCOL; ++t) acc[t] = mfma(ah, b[t][kb].hi, acc[t]);
-        // Software pipeline across chunks: the previous chunk's epilogue (ReLU + bf16 hi/lo split, ~60 VALU) is independent
-        // of this chunk's MFMAs; left alone the compiler sinks all four epilogues of a layer in front of the next layer's
-        // first MFMA (240 VALU during which this wave's MFMA pipe idles).  Ask for a few of them after every K-block.
-        if constexpr (IL > 0 && PREC == 1 && NK >= 4) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NCOL, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, IL, 0);
-        }
+        for (int t = 0; t < NCOL; ++t) acc[t] = mfma<PREC>(ah, b[t][kb].hi, acc[t]);
     }
+}
+// Six (PREC 1) / two (PREC 0) MFMAs of one K-block on TWO accumulator chains, alternating, as ONE ordered asm block: hipcc's
+// scheduler otherwise mixes the chains at will and drops the next fragments' ds_reads and their waits between dependent MFMAs
+// (the "memory" clobber keeps the compiler's LDS reads on their side of the block: a fetch written before it stays before it).
+// Hazards hipcc cannot see inside an asm statement (cdna_hip_programming.md 5.7): the block opens with `s_nop 1` (a VALU-written B
+// fragment -> MFMA operand) and every READER of the accumulators other than the next block goes through mfma_settle() first.
+template <int PREC>
+__device__ __forceinline__ void mfma_block(f32x16& acc0, f32x16& acc1, const u32x4& ah0, const u32x4& al0, const u32x4& ah1, const u32x4& al1,
+                                           const u32x4& bh0, const u32x4& bl0, const u32x4& bh1, const u32x4& bl1) {
+    if constexpr (PREC == 1)
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %3, %6, %0\n\t"
+                     "v_mfma_f32_32x32x16_f16 %1, %5, %8, %1\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %2, %7, %0\n\t"
+                     "v_mfma_f32_32x32x16_f16 %1, %4, %9, %1\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %2, %6, %0\n\t"
+                     "v_mfma_f32_32x32x16_f16 %1, %4, %8, %1"
+                     : "+v"(acc0), "+v"(acc1) : "v"(ah0), "v"(al0), "v"(ah1), "v"(al1), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1) : "memory");
+    else
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %0, %2, %4, %0\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %1, %3, %5, %1"
+                     : "+v"(acc0), "+v"(acc1) : "v"(ah0), "v"(ah1), "v"(bh0), "v"(bh1) : "memory");
+}
+// an MFMA's result -> any reader other than the next MFMA taking it whole as C: 12 wait states for the 8-pass XDL ops
+__device__ __forceinline__ void mfma_settle(f32x16& acc0, f32x16& acc1) {
+    asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+}
+
+// the A fragments of two units (p, p + UNIT): a pair of chunks at one K-block, or one chunk at two consecutive K-blocks
+template <int PREC> struct AFrag { u32x4 h0, l0, h1, l1; };
+template <int PREC>
+__device__ __forceinline__ AFrag<PREC> load_units(const char* p) {
+    constexpr int UNIT = Ctx<PREC>::UNIT;
+    AFrag<PREC> f;
+    f.h0 = *reinterpret_cast<const u32x4*>(p); f.h1 = *reinterpret_cast<const u32x4*>(p + UNIT);
+    if constexpr (PREC == 1) { f.l0 = *reinterpret_cast<const u32x4*>(p + 1024); f.l1 = *reinterpret_cast<const u32x4*>(p + UNIT + 1024); }
+    else { f.l0 = f.h0; f.l1 = f.h1; }
+    return f;
+}
+// NB blocks over consecutive unit pairs (u0 + 2 i, u0 + 2 i + 1) of the step's slot.  `cur` holds the fragments of the first pair
+// (loaded by the caller: right after the step's barrier, so that their LDS latency hides under the DMA issue / the previous
+// pair's epilogue); every block's successor is fetched BEFORE the block is issued -- the asm's "memory" clobber pins that order
+// -- and MORE says that another segment of the same step follows at u0 + 2 NB (its first pair is then left in `cur`).
+//   PAIR = true : units = (chunk 0, chunk 1) at K-block i, both chains take b[i]             (a pair of output chunks)
+//   PAIR = false: units = (kb 2i, kb 2i+1) of ONE chunk, chain 0 takes b[2i], chain 1 b[2i+1] (split-K: the caller adds the chains)
+template <int PREC, int NB, bool PAIR, bool MORE>
+__device__ __forceinline__ void mma_chains(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
+    constexpr int UNIT = Ctx<PREC>::UNIT;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        AFrag<PREC> nxt;
+        const bool pre = i + 1 < NB || MORE;
+        if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
+        const BFrag<PREC>& b0 = b[PAIR ? i : 2 * i];
+        const BFrag<PREC>& b1 = b[PAIR ? i : 2 * i + 1];
+        if constexpr (PREC == 1) mfma_block<PREC>(acc0, acc1, cur.h0, cur.l0, cur.h1, cur.l1, b0.hi, b0.lo, b1.hi, b1.lo);
+        else mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
+        if (pre) cur = nxt;
+    }
+}
+template <int PREC, int NK, bool MORE = false>
+__device__ __forceinline__ void mma_pair(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
+    mma_chains<PREC, NK, true, MORE>(s, u0, b, acc0, acc1, cur);
+}
+template <int PREC, int NK>
+__device__ __forceinline__ void mma_splitk(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
+    static_assert(NK % 2 == 0, "even / odd K-block chains");
+    mma_chains<PREC, NK / 2, false, false>(s, u0, b, acc0, acc1, cur);
 }
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   // partner lane holds the other 16 features
@@ -374,110 +401,77 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
     }
 }
 
+// two finished accumulator tiles (a pair of chunks) -> four K-blocks of the next layer; pinned in place: left alone the compiler
+// sinks every epilogue of a layer in front of the next layer's first MFMA and keeps all the raw accumulators alive until then
+template <int PREC, bool RELU>
+__device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PREC>* out) {
+    mfma_settle(acc0, acc1);
+    if constexpr (RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = relu(acc0[r]); acc1[r] = relu(acc1[r]); }
+    }
+    split_tile<PREC>(acc0, out[0], out[1]);
+    split_tile<PREC>(acc1, out[2], out[3]);
+    __builtin_amdgcn_sched_barrier(0);
+}
 
-// VAR: scheduling variant of the same arithmetic (results bit-identical): low byte = SHERF_MLP_INTERLEAVE count, next byte =
-// SHERF_MLP_WAVE_PRIO level.  Runtime-selectable through `shape` 5-7 of sherf_nerf_mlp so that sherf_amd.tune can time them on
-// the hardware it runs on; the -D macros only move the default.
-template <int PREC, int NW, int NTL, int PHASE = 0, int VAR = (SHERF_MLP_INTERLEAVE | (SHERF_MLP_WAVE_PRIO << 8))>      // (bits 16+: PHASE_PRIO)
-__global__ void __launch_bounds__(NW * 64, PHASE == 1 ? SHERF_MLP_P1_WAVES : NTL == 1 ? 2 : 1)
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, 2)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int dbg) {
-    using CX = Ctx<PREC, NW, NTL, PHASE>;
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
-    constexpr int IL = VAR & 0xff, PRIO = (VAR >> 8) & 0xff, PHASE_PRIO = (VAR >> 16) & 0xff;
-    __shared__ __attribute__((aligned(16))) char lds[CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW * NTL >= n_tiles) return;           // whole workgroup beyond the data
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
     CX cx;
-    float* lbias = reinterpret_cast<float*>(lds + CX::NSLOT * CX::SLOT);
+    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
     for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
-    cx.ws = ws; cx.wbias = lbias; cx.lds = lds;
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.dbg = dbg;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
+    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
 #if SHERF_MLP_TRACE
-    cx.trace = reinterpret_cast<uint32_t*>(lds + CX::NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
+    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
     if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
 #endif
-    if constexpr (PRIO > 0) { if (cx.wave < NW / 2) __builtin_amdgcn_s_setprio(PRIO); }
-    int j = cx.lane & 31, h = cx.h;                                  // (not const: PHASE -1 launders them per group)
-    int64_t tile[NTL];
-    bool live[NTL];
-#pragma unroll
-    for (int u = 0; u < NTL; ++u) {
-        if constexpr (PHASE == -1) tile[u] = ((int64_t)blockIdx.x * NW + cx.wave) * NTL + u;      // scalar: lives across the group loop
-        else tile[u] = ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * NTL + u;
-        live[u] = tile[u] < n_tiles;
-        if (!live[u]) tile[u] = n_tiles - 1;                         // dead tiles still take part in every barrier
-    }
+    const int j = cx.lane & 31, h = cx.h;
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
 
     dma_issue(cx, 0);
-    const int n1 = dma_issue(cx, 1);
-    wait_vm(n1);                              // step 0 (this wave's pieces) landed
+    dma_issue(cx, 1);
+    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
     __syncthreads();
-    cx.pending = CX::NSLOT == 2 ? n1 : dma_issue(cx, 2);
+    dma_issue(cx, 2);
 
-    [[maybe_unused]] int64_t grp = blockIdx.x;                       // PHASE -1: tile group of this pass
-    bool again = false;
-    do {                                                             // one pass unless PHASE == -1 (persistent workgroups)
-    if constexpr (PHASE == -1) {
-        cx.more = grp + gridDim.x < (n_tiles + NW * NTL - 1) / (NW * NTL);
-        // keep the per-chunk source addresses from being hoisted out of the group loop (dozens of live 64-bit VGPR pairs)
-        asm volatile("" : "+s"(cx.ws));
-        asm volatile("" : "+v"(cx.lane));         // same for everything derived from the lane id: one live VGPR, re-derived per group
-        j = cx.lane & 31; h = cx.lane >> 5; cx.h = h;
-    }
-    BFrag<PREC> z0b[NTL][2], z1b[NTL][2];                            // fused tokens z_0, z_1 as K-blocks, per tile
-    float xc[NTL][3], vc[NTL][3];
+    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
+    float xc[3], vc[3];
     int step = 0;
 
-    // z_0 / z_1 hand-over between the two launches of the split shape: 8 uint4 per lane per tile, lane-major, written over the
-    // first 8 KiB of the tile's own `tokens` block (the wave has read its tokens into registers long before): fragment
-    // q = 4 * (0: z_0, 1: z_1) + 2 * kb + (0: hi, 1: lo).
-    uint4* const zfrag = reinterpret_cast<uint4*>(const_cast<float4*>(tokens));
-    if constexpr (PHASE >= 2) {
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) {
-            const float* ex = extras + tile[u] * 12 * 32 + j;
-            xc[u][0] = ex[0]; xc[u][1] = ex[32]; xc[u][2] = ex[64]; vc[u][0] = ex[96]; vc[u][1] = ex[128]; vc[u][2] = ex[160];
-            const uint4* zp = zfrag + tile[u] * 768 + cx.lane;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                z0b[u][kb].hi = zp[(2 * kb) * 64];
-                z1b[u][kb].hi = zp[(4 + 2 * kb) * 64];
-                if constexpr (PREC == 1) { z0b[u][kb].lo = zp[(2 * kb + 1) * 64]; z1b[u][kb].lo = zp[(4 + 2 * kb + 1) * 64]; }
-            }
-        }
-    }
-    // ================= transformer, one tile at a time (steps 9u .. 9u+8 replay chunks 0..8) =================
-#pragma unroll
-    for (int u = 0; u < (PHASE >= 2 ? 0 : NTL); ++u) {
+    // ================= transformer: step 0 = chunks 0..4, step 1 = chunks 5..8 =================
+    {
         // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
         f32x16 tok[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float4 v = tokens[((tile[u] * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+                float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
                 tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
             }
-        const float* ex = extras + tile[u] * 12 * 32 + j;
-        xc[u][0] = ex[0]; xc[u][1] = ex[32]; xc[u][2] = ex[64]; vc[u][0] = ex[96]; vc[u][1] = ex[128]; vc[u][2] = ex[160];
+        const float* ex = extras + tile * 12 * 32 + j;
+        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
 
+        const char* s = cx.slot(step);
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
         {
             BFrag<PREC> b[1][2];
             pe_frags<PREC, 5, 2>(h, ex[192], ex[224], ex[256], b[0]);
-            if constexpr (PHASE == -1) {
-                if (u == 0 && grp != (int64_t)blockIdx.x) {          // steps 0..2 were streamed by the previous group's last steps
-                    wait_vm(0);
-                    __syncthreads();
-                    cx.pending = 0;
-                }
-            }
             f32x16 acc[1] = {bias_tile(cx, 0)};
-            mma_seg<PREC, 2, 1, IL>(cx.slot(step), 0, 2, b, acc);
-            advance(cx, step); ++step;
+            mma_cols<PREC, 2, 1>(s, 0, b, acc);
             tok[2] += acc[0];
         }
         // ---- LN1 + to_qkv (chunks 1..5), attention, to_out (6) ----
@@ -488,15 +482,13 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         {
             BFrag<PREC> b2[2][2] = {{ln[0][0], ln[0][1]}, {ln[1][0], ln[1][1]}};
             f32x16 acc[2] = {bias_tile(cx, 1), bias_tile(cx, 1)};
-            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, b2, acc);          // [q head0 | q head1]
-            advance(cx, step); ++step;
+            mma_cols<PREC, 2, 2>(s, 2, b2, acc);                      // [q head0 | q head1]
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) qa[i][r] = acc[i][r];
             f32x16 acc2[2] = {bias_tile(cx, 2), bias_tile(cx, 2)};
-            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, b2, acc2);         // [q head2 | pad]
-            advance(cx, step); ++step;
+            mma_cols<PREC, 2, 2>(s, 4, b2, acc2);                     // [q head2 | pad]
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -507,8 +499,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         float v0[3][8];
         {
             f32x16 acc[3] = {bias_tile(cx, 3), bias_tile(cx, 3), bias_tile(cx, 3)};
-            mma_seg<PREC, 2, 3, IL>(cx.slot(step), 0, 2, ln, acc);          // [k head0 | k head1]
-            advance(cx, step); ++step;
+            mma_cols<PREC, 2, 3>(s, 6, ln, acc);                      // [k head0 | k head1]
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -521,7 +512,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         }
         {
             f32x16 acc[3] = {bias_tile(cx, 4), bias_tile(cx, 4), bias_tile(cx, 4)};
-            mma_seg<PREC, 2, 3, IL>(cx.slot(step), 0, 2, ln, acc);          // [k head2 | v head0]
+            mma_cols<PREC, 2, 3>(s, 8, ln, acc);                      // [k head2 | v head0]
             advance(cx, step); ++step;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -554,10 +545,10 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
+        s = cx.slot(step);
         {
             f32x16 acc[3] = {bias_tile(cx, 5), bias_tile(cx, 5), bias_tile(cx, 5)};
-            mma_seg<PREC, 2, 3, IL>(cx.slot(step), 0, 2, ln, acc);          // [v head1 | v head2]
-            advance(cx, step); ++step;
+            mma_cols<PREC, 2, 3>(s, 0, ln, acc);                      // [v head1 | v head2]
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -576,8 +567,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                     ob[i][hd] = make_frag<PREC>(o[i][hd][0], o[i][hd][1], o[i][hd][2], o[i][hd][3], o[i][hd][4], o[i][hd][5],
                                                 o[i][hd][6], o[i][hd][7]);
             f32x16 acc[2] = {bias_tile(cx, 6), bias_tile(cx, 6)};
-            mma_seg<PREC, 3, 2, IL>(cx.slot(step), 0, 3, ob, acc);          // to_out + bias
-            advance(cx, step); ++step;
+            mma_cols<PREC, 3, 2>(s, 2, ob, acc);                      // to_out + bias
             y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];             // residual (renderer.py:925)
         }
         // ---- FF: LN2 -> Linear -> GELU(erf) -> Linear, residual (chunks 7, 8) ----
@@ -586,8 +576,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             layer_norm<PREC>(cx, y[0], 1, l2[0][0], l2[0][1]);
             layer_norm<PREC>(cx, y[1], 1, l2[1][0], l2[1][1]);
             f32x16 acc[2] = {bias_tile(cx, 7), bias_tile(cx, 7)};
-            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, l2, acc);
-            advance(cx, step); ++step;
+            mma_cols<PREC, 2, 2>(s, 5, l2, acc);
             BFrag<PREC> gb[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -596,184 +585,119 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 split_tile<PREC>(acc[i], gb[i][0], gb[i][1]);
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
-            mma_seg<PREC, 2, 2, IL>(cx.slot(step), 0, 2, gb, acc2);
+            mma_cols<PREC, 2, 2>(s, 7, gb, acc2);
             advance(cx, step); ++step;
             f32x16 za = acc2[0] + y[0], zb = acc2[1] + y[1];
-            split_tile<PREC>(za, z0b[u][0], z0b[u][1]);
-            split_tile<PREC>(zb, z1b[u][0], z1b[u][1]);
+            split_tile<PREC>(za, z0b[0], z0b[1]);
+            split_tile<PREC>(zb, z1b[0], z1b[1]);
         }
     }
-    if constexpr (PHASE == 1) {                                      // hand z_0, z_1 to the decoder launch and stop
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) {
-            if (!live[u]) continue;
-            uint4* zp = zfrag + tile[u] * 768 + cx.lane;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                zp[(2 * kb) * 64] = z0b[u][kb].hi;
-                zp[(4 + 2 * kb) * 64] = z1b[u][kb].hi;
-                if constexpr (PREC == 1) { zp[(2 * kb + 1) * 64] = z0b[u][kb].lo; zp[(4 + 2 * kb + 1) * 64] = z1b[u][kb].lo; }
-            }
-        }
-        return;
-    }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ================= NeRF decoder: all NTL tiles of the wave share every weight fragment =================
-    // PHASE_PRIO (shape '4x1phase'): from here on the wave is MFMA-bound -- it gets issue priority over the co-resident workgroup's wave on
-    // this SIMD whenever that one is still in its VALU-bound transformer / encoding prologue (a new wave starts at priority 0)
-    if constexpr (PHASE_PRIO > 0) __builtin_amdgcn_s_setprio(PHASE_PRIO);
-    BFrag<PREC> ha[NTL][8], hb[NTL][8], pe[NTL][3];
-#pragma unroll
-    for (int u = 0; u < NTL; ++u) pe_frags<PREC, 6, 3>(h, xc[u][0], xc[u][1], xc[u][2], pe[u]);
-    // one output tile of a trunk layer: bias, MFMAs over the listed input segments, ReLU, split into the next layer's K-blocks
-#define SHERF_TRUNK_TILE(CHUNK, OUT, T, ...)                                                          \
-    {                                                                                                 \
-        f32x16 acc[NTL];                                                                              \
-        _Pragma("unroll") for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, CHUNK);                \
-        const char* s_ = cx.slot(step);                                                               \
-        __VA_ARGS__                                                                                   \
-        advance(cx, step); ++step;                                                                    \
-        _Pragma("unroll") for (int u = 0; u < NTL; ++u) {                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[u][r] = relu(acc[u][r]);               \
-            split_tile<PREC>(acc[u], OUT[u][2 * (T)], OUT[u][2 * (T) + 1]);                          \
-        }                                                                                             \
+    // ================= NeRF decoder =================
+    if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
+    BFrag<PREC> ha[8], hb[8];
+    AFrag<PREC> cur = load_units<PREC>(cx.slot(step));               // first fragments of the next step: fetched right behind its barrier
+    // (the fetch goes out BEFORE the DMA issue of the slot just freed: its LDS latency hides under those ~30 instructions)
+#define SHERF_NEXT_STEP() do { step_wait(cx, step); cur = load_units<PREC>(cx.slot(step + 1)); dma_issue(cx, step + NSLOT); ++step; } while (0)
+    // a 128 -> 128 layer: two pairs of output chunks x two K-halves = four steps; chunk C0 + T -> OUT[2T], OUT[2T+1]
+#define SHERF_LAYER128(C0, IN, OUT, RELU)                                                             \
+    _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                   \
+        f32x16 acc0 = bias_tile(cx, (C0) + 2 * P), acc1 = bias_tile(cx, (C0) + 2 * P + 1);            \
+        mma_pair<PREC, 4>(cx.slot(step), 0, IN, acc0, acc1, cur);                                     \
+        SHERF_NEXT_STEP();                                                                            \
+        mma_pair<PREC, 4>(cx.slot(step), 0, IN + 4, acc0, acc1, cur);                                 \
+        SHERF_NEXT_STEP();                                                                            \
+        finish_pair<PREC, RELU>(acc0, acc1, OUT + 4 * P);                                             \
     }
-    // two output tiles of a 128-input layer in ONE step (PHASE 3): the slot holds chunk CHUNK (hi, lo) then chunk CHUNK + 1
-#define SHERF_TRUNK_PAIR(CHUNK, OUT, T, IN, RELU)                                                     \
-    {                                                                                                 \
-        static_assert(PREC == 1, "paired steps rely on the hi+lo chunk layout being contiguous");     \
-        f32x16 acc0[NTL], acc1[NTL];                                                                  \
-        _Pragma("unroll") for (int u = 0; u < NTL; ++u) { acc0[u] = bias_tile(cx, CHUNK); acc1[u] = bias_tile(cx, (CHUNK) + 1); } \
-        const char* s_ = cx.slot(step);                                                               \
-        mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, IN, acc0);                                                    \
-        mma_seg<PREC, 8, NTL, IL>(s_ + 2 * 8 * 1024, 0, 8, IN, acc1);                                     \
-        advance(cx, step); ++step;                                                                    \
-        _Pragma("unroll") for (int u = 0; u < NTL; ++u) {                                             \
-            if (RELU) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { acc0[u][r] = relu(acc0[u][r]); acc1[u][r] = relu(acc1[u][r]); } } \
-            split_tile<PREC>(acc0[u], OUT[u][2 * (T)], OUT[u][2 * (T) + 1]);                          \
-            split_tile<PREC>(acc1[u], OUT[u][2 * (T) + 2], OUT[u][2 * (T) + 3]);                      \
-        }                                                                                             \
-    }
+    {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
+        BFrag<PREC> pe[3];
+        pe_frags<PREC, 6, 3>(h, xc[0], xc[1], xc[2], pe);
 #pragma unroll
-    for (int T = 0; T < 4; ++T)     // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
-        SHERF_TRUNK_TILE(9 + T, ha, T, mma_seg<PREC, 3, NTL, IL>(s_, 0, 5, pe, acc); mma_seg<PREC, 2, NTL, IL>(s_, 3, 5, z0b, acc);)
-#pragma unroll
-    for (int L = 0; L < 4; ++L) {   // pts_linears.1-4 (ping-pong ha -> hb -> ha ...)
-        if constexpr (PHASE == 3) {
-#pragma unroll
-            for (int T = 0; T < 4; T += 2) {
-                if (L & 1) SHERF_TRUNK_PAIR(13 + 4 * L + T, ha, T, hb, true)
-                else SHERF_TRUNK_PAIR(13 + 4 * L + T, hb, T, ha, true)
-            }
-        } else {
-#pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                if (L & 1) SHERF_TRUNK_TILE(13 + 4 * L + T, ha, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, hb, acc);)
-                else SHERF_TRUNK_TILE(13 + 4 * L + T, hb, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, ha, acc);)
-            }
+        for (int P = 0; P < 2; ++P) {
+            f32x16 acc0 = bias_tile(cx, 9 + 2 * P), acc1 = bias_tile(cx, 10 + 2 * P);
+            const char* s = cx.slot(step);
+            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur);
+            mma_pair<PREC, 2>(s, 6, z0b, acc0, acc1, cur);
+            SHERF_NEXT_STEP();
+            finish_pair<PREC, true>(acc0, acc1, ha + 4 * P);
         }
     }
+    SHERF_LAYER128(13, ha, hb, true)     // pts_linears.1-4 (ping-pong ha -> hb -> ha ...)
+    SHERF_LAYER128(17, hb, ha, true)
+    SHERF_LAYER128(21, ha, hb, true)
+    SHERF_LAYER128(25, hb, ha, true)
+    {   // pts_linears.5 : [PE6 | z_0 | h(128)]: the encoding is recomputed (24 registers not carried through four layers)
+        float x0 = xc[0], x1 = xc[1], x2 = xc[2];
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+        BFrag<PREC> pe[3];
+        pe_frags<PREC, 6, 3>(h, x0, x1, x2, pe);
 #pragma unroll
-    for (int T = 0; T < 4; ++T)     // pts_linears.5 : [PE6 | z_0 | h(128)] ; after 4 layers the activations are back in ha
-        SHERF_TRUNK_TILE(29 + T, hb, T, mma_seg<PREC, 3, NTL, IL>(s_, 0, 13, pe, acc); mma_seg<PREC, 2, NTL, IL>(s_, 3, 13, z0b, acc);
-                         mma_seg<PREC, 8, NTL, IL>(s_, 5, 13, ha, acc);)
-    if constexpr (PHASE == 3) {
-#pragma unroll
-        for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(33 + T, ha, T, hb, true)                              // pts_linears.6
-#pragma unroll
-        for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(37 + T, hb, T, ha, true)                              // pts_linears.7
-    } else {
-#pragma unroll
-        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(33 + T, ha, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, hb, acc);)   // pts_linears.6
-#pragma unroll
-        for (int T = 0; T < 4; ++T) SHERF_TRUNK_TILE(37 + T, hb, T, mma_seg<PREC, 8, NTL, IL>(s_, 0, 8, ha, acc);)   // pts_linears.7
-    }
-    // ---- heads: feature_linear (4 tiles, no activation) into ha, alpha_linear (tile 45, row 0), both from hb ----
-    float sigma[NTL];
-    if constexpr (PHASE == 3) {
-#pragma unroll
-        for (int T = 0; T < 4; T += 2) SHERF_TRUNK_PAIR(41 + T, ha, T, hb, false)
-    } else {
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            f32x16 acc[NTL];
-#pragma unroll
-            for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 41 + T);
-            mma_seg<PREC, 8, NTL, IL>(cx.slot(step), 0, 8, hb, acc);
-            advance(cx, step); ++step;
-#pragma unroll
-            for (int u = 0; u < NTL; ++u) split_tile<PREC>(acc[u], ha[u][2 * T], ha[u][2 * T + 1]);
+        for (int P = 0; P < 2; ++P) {
+            f32x16 acc0 = bias_tile(cx, 29 + 2 * P), acc1 = bias_tile(cx, 30 + 2 * P);
+            const char* s = cx.slot(step);
+            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur);
+            mma_pair<PREC, 2>(s, 6, z0b, acc0, acc1, cur);
+            SHERF_NEXT_STEP();
+            mma_pair<PREC, 4>(cx.slot(step), 0, ha, acc0, acc1, cur);
+            SHERF_NEXT_STEP();
+            mma_pair<PREC, 4>(cx.slot(step), 0, ha + 4, acc0, acc1, cur);
+            SHERF_NEXT_STEP();
+            finish_pair<PREC, true>(acc0, acc1, hb + 4 * P);
         }
     }
+    SHERF_LAYER128(33, hb, ha, true)     // pts_linears.6
+    SHERF_LAYER128(37, ha, hb, true)     // pts_linears.7
+    // ---- heads: feature_linear (no activation) into ha, alpha_linear (chunk 45, row 0), both from hb ----
+    SHERF_LAYER128(41, hb, ha, false)
+    float sigma;
     {
-        f32x16 acc[NTL];
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 45);
-        mma_seg<PREC, 8, NTL, IL>(cx.slot(step), 0, 8, hb, acc);
-        advance(cx, step); ++step;
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) sigma[u] = acc[u][0];             // row 0 lives in reg 0 of the h == 0 lanes
+        f32x16 acc0 = bias_tile(cx, 45), acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        mma_splitk<PREC, 8>(cx.slot(step), 0, hb, acc0, acc1, cur);
+        SHERF_NEXT_STEP();
+        mfma_settle(acc0, acc1);
+        sigma = acc0[0] + acc1[0];                                   // row 0 lives in reg 0 of the h == 0 lanes
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- views_linear : [feature (8 kb) | PE4(v_c) (2 kb) | z_1 (2 kb)] -> 64, ReLU ; rgb_linear -> sigmoid ----
-    BFrag<PREC> pv[NTL][2], gb[NTL][4];
-#pragma unroll
-    for (int u = 0; u < NTL; ++u) pe_frags<PREC, 4, 2>(h, vc[u][0], vc[u][1], vc[u][2], pv[u]);
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-        f32x16 acc[NTL];
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 46 + T);
-        const char* s_ = cx.slot(step);
-        mma_seg<PREC, 8, NTL, IL>(s_, 0, 12, ha, acc);
-        mma_seg<PREC, 2, NTL, IL>(s_, 8, 12, pv, acc);
-        mma_seg<PREC, 2, NTL, IL>(s_, 10, 12, z1b, acc);
-        advance(cx, step); ++step;
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][r] = relu(acc[u][r]);
-            split_tile<PREC>(acc[u], gb[u][2 * T], gb[u][2 * T + 1]);
-        }
+    BFrag<PREC> gb[4];
+    {
+        BFrag<PREC> pv[2];
+        pe_frags<PREC, 4, 2>(h, vc[0], vc[1], vc[2], pv);
+        f32x16 acc0 = bias_tile(cx, 46), acc1 = bias_tile(cx, 47);
+        mma_pair<PREC, 4>(cx.slot(step), 0, ha, acc0, acc1, cur);
+        SHERF_NEXT_STEP();
+        mma_pair<PREC, 4>(cx.slot(step), 0, ha + 4, acc0, acc1, cur);
+        SHERF_NEXT_STEP();
+        const char* s = cx.slot(step);
+        mma_pair<PREC, 2, true>(s, 0, pv, acc0, acc1, cur);
+        mma_pair<PREC, 2>(s, 4, z1b, acc0, acc1, cur);
+        SHERF_NEXT_STEP();
+        finish_pair<PREC, true>(acc0, acc1, gb);
     }
     {
-        f32x16 acc[NTL];
-#pragma unroll
-        for (int u = 0; u < NTL; ++u) acc[u] = bias_tile(cx, 48);
-        mma_seg<PREC, 4, NTL, IL>(cx.slot(step), 0, 4, gb, acc);
-        if constexpr (PHASE == -1) { if (cx.more) advance(cx, step); }       // frees slot (n_steps - 1) % 3 for the next group
-#pragma unroll
-        for (int u = 0; u < NTL; ++u)
-            if (live[u] && h == 0) {
-                const int64_t c = tile[u] * 32 + j;
-                if (c < nv) {
-                    float r = rcp_(1.0f + exp_(-acc[u][0])), g = rcp_(1.0f + exp_(-acc[u][1])), b = rcp_(1.0f + exp_(-acc[u][2]));
-                    out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma[u]);   // triplane.py:314
-                }
+        f32x16 acc0 = bias_tile(cx, 48), acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        mma_splitk<PREC, 4>(cx.slot(step), 0, gb, acc0, acc1, cur);
+        mfma_settle(acc0, acc1);
+        SHERF_TRACE_STAMP(cx, step, 0);
+        if (live && h == 0) {
+            const int64_t c = tile * 32 + j;
+            if (c < nv) {
+                float r = rcp_(1.0f + exp_(-(acc0[0] + acc1[0]))), g = rcp_(1.0f + exp_(-(acc0[1] + acc1[1]))), b = rcp_(1.0f + exp_(-(acc0[2] + acc1[2])));
+                out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma);   // triplane.py:314
             }
+        }
     }
+#undef SHERF_NEXT_STEP
+#undef SHERF_LAYER128
 #if SHERF_MLP_TRACE
-    if (g_mlp_trace && g_mlp_trace_every > 0 && blockIdx.x % g_mlp_trace_every == 0 && cx.lane < 64) {
+    if (g_mlp_trace && g_mlp_trace_every > 0 && blockIdx.x % g_mlp_trace_every == 0) {
         if (cx.lane == 0) cx.trace[63 * 4 + 2] = (uint32_t)__builtin_amdgcn_s_memtime();
         const size_t slot = blockIdx.x / g_mlp_trace_every;
         uint32_t* dst = g_mlp_trace + (slot * 8 + cx.wave) * 256;
         for (int i = cx.lane; i < 256; i += 64) dst[i] = cx.trace[i];
     }
 #endif
-    if constexpr (PHASE == -1) {
-        again = cx.more;
-        if (again) {
-            grp += gridDim.x;
-#pragma unroll
-            for (int u = 0; u < NTL; ++u) {
-                tile[u] = (grp * NW + cx.wave) * NTL + u;
-                live[u] = tile[u] < n_tiles;
-                if (!live[u]) tile[u] = n_tiles - 1;
-            }
-        }
-    }
-    } while (again);   // tile groups
-#undef SHERF_TRUNK_TILE
-#undef SHERF_TRUNK_PAIR
 }
 
 }  // namespace
@@ -786,92 +710,27 @@ extern "C" int sherf_mlp_set_trace(void* buf, int every) {
 }
 #endif
 
-extern "C" int sherf_mlp_stream_layout(int32_t* n_chunks, int32_t* nkb_host, int32_t max_chunks) {
-    SHERF_CHECK_ARG(n_chunks && nkb_host && max_chunks >= N_CHUNKS);
-    *n_chunks = N_CHUNKS;
-    for (int c = 0; c < N_CHUNKS; ++c) nkb_host[c] = chunk_nkb(c);
+extern "C" int sherf_mlp_stream_layout(int prec, int32_t* n_steps, int32_t* step_pieces_host, int32_t* units, int32_t max_steps) {
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && n_steps && step_pieces_host && units && max_steps >= N_STEPS);
+    *n_steps = N_STEPS;
+    for (int s = 0; s < N_STEPS; ++s) {
+        step_pieces_host[s] = prec ? step_pieces<1>(s) : step_pieces<0>(s);
+        for (int u = 0; u < 10; ++u) units[s * 10 + u] = u < step_units(s) ? step_unit(s, u) : -1;
+    }
     return SHERF_OK;
 }
 
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape >= 0 && shape <= 11 && capacity > 0);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape == 0 && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
-    const bool wide = shape == 1;                             // <NW=4, NTL=2>: one wave per SIMD, two tiles per wave
-#define SHERF_MLP(P, W, L)                                                                                                 \
-    hipLaunchKernelGGL((nerf_mlp_kernel<P, W, L>), dim3((unsigned)((tiles + (W) * (L) - 1) / ((W) * (L)))), dim3((W) * 64), 0,  \
-                       as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,                        \
-                       reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug)
-    if (shape == 10) {                        // 4x1 with the decoder phase at raised issue priority
-        SHERF_CHECK_ARG(prec == 1);
-        hipLaunchKernelGGL((nerf_mlp_kernel<1, 4, 1, 0, (2 << 16)>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-        SHERF_LAUNCH_CHECK();
-    }
-    if (shape == 8 || shape == 9) {           // 4 waves x 1 tile: two independent workgroups per CU (two-slot weight rings); 9 = + interleave 8
-        SHERF_CHECK_ARG(prec == 1);
-        if (shape == 8) SHERF_MLP(1, 4, 1);
-        else
-            hipLaunchKernelGGL((nerf_mlp_kernel<1, 4, 1, 0, 8>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, as_stream(stream), counters,
-                               reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                               reinterpret_cast<float4*>(out), g_sherf_debug);
-        SHERF_LAUNCH_CHECK();
-    }
-    if (shape >= 5) {                         // scheduling variants of the default kernel (same arithmetic, bit-identical results):
-        SHERF_CHECK_ARG(prec == 1);           // 5 = MFMA/VALU interleave 8, 6 = wave priority 2, 7 = both; chosen by sherf_amd.tune
-#define SHERF_MLP_VAR(V)                                                                                                     \
-    hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 0, V>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters, \
-                       reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,  \
-                       reinterpret_cast<float4*>(out), g_sherf_debug)
-        if (shape == 5) SHERF_MLP_VAR(8); else if (shape == 6) SHERF_MLP_VAR(2 << 8); else SHERF_MLP_VAR(8 | (2 << 8));
-#undef SHERF_MLP_VAR
-        SHERF_LAUNCH_CHECK();
-    }
-    if (shape == 4 || shape == 11) {          // experimental: persistent workgroups (PHASE -1): 4 = 8 waves, one per CU; 11 = 4 waves, two per CU
-        SHERF_CHECK_ARG(prec == 1);
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0, v = 0;
-            SHERF_HIP_CHECK(hipGetDevice(&dev));
-            SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-            n_cu = v > 0 ? v : 256;
-        }
-        if (shape == 11) {
-            const int64_t groups4 = (tiles + 3) / 4;
-            hipLaunchKernelGGL((nerf_mlp_kernel<1, 4, 1, -1>), dim3((unsigned)(groups4 < 2 * n_cu ? groups4 : 2 * n_cu)), dim3(256), 0,
-                               as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                               reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), g_sherf_debug);
-            SHERF_LAUNCH_CHECK();
-        }
-        const int64_t groups = (tiles + 7) / 8;
-        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, -1>), dim3((unsigned)(groups < n_cu ? groups : n_cu)), dim3(512), 0, as_stream(stream),
-                           counters, reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-        SHERF_LAUNCH_CHECK();
-    }
-    if (shape == 3) {                         // experimental: shape 2 with the decoder walking two output tiles per step (PHASE 3)
-        SHERF_CHECK_ARG(prec == 1);
-        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 1>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 3>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-        SHERF_LAUNCH_CHECK();
-    }
-    if (shape == 2) {                         // experimental: transformer prologue and decoder as two launches (see PHASE)
-        SHERF_CHECK_ARG(prec == 1);
-        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 1>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-        hipLaunchKernelGGL((nerf_mlp_kernel<1, 8, 1, 2>), dim3((unsigned)((tiles + 7) / 8)), dim3(512), 0, as_stream(stream), counters,
-                           reinterpret_cast<const float4*>(tokens), extras, reinterpret_cast<const char*>(wstream), wbias, capacity,
-                           reinterpret_cast<float4*>(out), g_sherf_debug);
-        SHERF_LAUNCH_CHECK();
-    }
-    if (prec == 0) { if (wide) SHERF_MLP(0, 4, 2); else SHERF_MLP(0, 8, 1); }
-    else { if (wide) SHERF_MLP(1, 4, 2); else SHERF_MLP(1, 8, 1); }
+    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
+    if (prec == 1)
+        hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     SHERF_LAUNCH_CHECK();
 }

@@ -224,11 +224,17 @@ __device__ __forceinline__ float depth_at(float near, float range, int k, int S)
     return __fadd_rn(near, __fmul_rn(step, range));
 }
 
-// One wave per ray.  Candidate samples (near-mask hit) are searched COOPERATIVELY: each candidate lane first fetches the
-// nine x-contiguous point segments of its 3x3x3 cell neighbourhood (18 independent loads, all candidates in parallel);
-// then, candidate by candidate, the segment table is broadcast (v_readlane) and the 64 lanes test 64 points at once;
-// the lexicographic minimum of (d^2, vertex id) is taken with one 64-bit LDS atomic min (d^2 >= 0, so the IEEE bit
-// pattern orders like the value).  Only points closer than the 5 cm threshold ever reach the atomic.
+// One wave per ray.  Candidate samples (near-mask hit: ~12 % of the samples, ~30 on a ray that crosses the body) are searched by
+// EIGHT-LANE GROUPS, eight candidates at a time: each candidate lane first fetches the nine x-contiguous point segments of its
+// 3x3x3 cell neighbourhood (18 independent loads, all candidates in parallel) and parks them with its position in an LDS record;
+// then group g of a round takes candidate 8 r + g, its 8 lanes walk the concatenated segments 8 points per step with every step's
+// loads in flight before the first distance is evaluated, and the lexicographic minimum of (d^2, vertex id) is taken with a 64-bit
+// LDS atomic min per group (d^2 >= 0, so the IEEE bit pattern orders like the value; only points inside the 5 cm threshold ever
+// reach the atomic).  Round 1 searched ONE candidate per step with all 64 lanes: one dependent L2 round trip per candidate,
+// ~30 per wave, was what the kernel's 450 us consisted of; a round of eight costs about the same trip.
+struct Cand { float x, y, z; int pad; int s[9]; int cum[9]; unsigned long long key; };     // 24 dwords
+constexpr int kMaxPtsUnroll = 4;                   // point loads in flight per lane and step group (8 lanes x 4 = 32 points)
+
 template <int NCH>
 __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                         const float* __restrict__ near, const float* __restrict__ far,
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid, int dbg) {
-    __shared__ unsigned long long s_key[4];
+    __shared__ Cand s_cand[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= R) return;
@@ -248,15 +254,15 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
     const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
     const float nr = near[ray], range = __fsub_rn(far[ray], nr);
     const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
+    Cand* const rec = s_cand[wave];
+    const int grp = lane >> 3, sub = lane & 7;
     int total = 0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int k = ch * 64 + lane;
         bool cand = false;
         float xs = 0.f, ys = 0.f, zs = 0.f;
-        int seg_s[9], seg_n[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { seg_s[i] = 0; seg_n[i] = 0; }
+        int cx = 0, cy = 0, cz = 0;
         if (k < S) {
             float t = depth_at(nr, range, k, S);
             float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
@@ -264,58 +270,65 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
             // quick reject: an unset near-mask bit proves that no vertex lies within 5 cm of this sample
             const float fs = g.inv_cell * (float)g.sub;
             const int sx = (int)floorf((xs - g.ox) * fs), sy = (int)floorf((ys - g.oy) * fs), sz = (int)floorf((zs - g.oz) * fs);
-            const int cx = g.sub == 2 ? sx >> 1 : sx, cy = g.sub == 2 ? sy >> 1 : sy, cz = g.sub == 2 ? sz >> 1 : sz;
+            cx = g.sub == 2 ? sx >> 1 : sx; cy = g.sub == 2 ? sy >> 1 : sy; cz = g.sub == 2 ? sz >> 1 : sz;
             if (sx >= 0 && cx < g.nx && sy >= 0 && cy < g.ny && sz >= 0 && cz < g.nz) {
                 const int q = (sz * (g.ny * g.sub) + sy) * (g.nx * g.sub) + sx;
                 cand = (((dbg & 2) || ((near_mask[q >> 5] >> (q & 31)) & 1u)) && !(dbg & 1));
-                if (cand) {
-                    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            }
+        }
+        const unsigned long long cmask = __ballot(cand);
+        const int ncand = __popcll(cmask);
+        const int rank = __popcll(cmask & ((1ull << lane) - 1ull));
+        if (cand) {                                  // this candidate's record: position, the 9 segments (start, cumulative count)
+            Cand& c = rec[rank];
+            c.x = xs; c.y = ys; c.z = zs; c.key = kInit;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            int st[9], en[9];
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) {
-                        const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
-                        if (qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny) {
-                            const int row = (qz * g.ny + qy) * g.nx;
-                            seg_s[i] = cell_start[row + x0];
-                            seg_n[i] = cell_start[row + x1 + 1] - seg_s[i];
-                        }
+            for (int i = 0; i < 9; ++i) {
+                const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
+                const bool ok = qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny;
+                const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
+                st[i] = cell_start[row + x0];
+                en[i] = ok ? cell_start[row + x1 + 1] : st[i];
+            }
+            int cum = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { c.s[i] = st[i]; cum += en[i] - st[i]; c.cum[i] = cum; }
+        }
+        __builtin_amdgcn_wave_barrier();             // (the wave runs in lockstep; the LDS records are ordered by s_waitcnt lgkmcnt)
+        for (int c0 = 0; c0 < ncand; c0 += 8) {
+            const int ci = c0 + grp;
+            if (ci < ncand) {
+                Cand& c = rec[ci];
+                const float qx = c.x, qy = c.y, qz = c.z;
+                int bs[9], cum[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { bs[i] = c.s[i]; cum[i] = c.cum[i]; }
+                const int npts = cum[8];
+                for (int base = 0; base < npts; base += 8 * kMaxPtsUnroll) {
+                    float4 v[kMaxPtsUnroll];
+#pragma unroll
+                    for (int u = 0; u < kMaxPtsUnroll; ++u) {
+                        const int t = base + u * 8 + sub;
+                        int p = bs[0] + t;
+#pragma unroll
+                        for (int i = 1; i < 9; ++i) p = (t >= cum[i - 1]) ? bs[i] + (t - cum[i - 1]) : p;
+                        v[u] = cell_pts[t < npts ? p : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kMaxPtsUnroll; ++u) {
+                        const int t = base + u * 8 + sub;
+                        const float dd = dist2_exact(qx, qy, qz, v[u].x, v[u].y, v[u].z);
+                        if (t < npts && dd < kThresh2)
+                            atomicMin(&c.key, ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u].w));
                     }
                 }
             }
         }
-        unsigned long long cmask = __ballot(cand);
-        unsigned long long my_key = kInit;
-        while (cmask) {
-            const int src = __ffsll((long long)cmask) - 1;
-            cmask &= cmask - 1;
-            const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xs), src));
-            const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ys), src));
-            const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, zs), src));
-            int bs[9], cum[10];
-            cum[0] = 0;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                bs[i] = __builtin_amdgcn_readlane(seg_s[i], src);
-                cum[i + 1] = cum[i] + __builtin_amdgcn_readlane(seg_n[i], src);
-            }
-            __builtin_amdgcn_wave_barrier();          // (no instruction: the wave runs in lockstep; marks the ordering the LDS slot relies on)
-            if (lane == 0) __hip_atomic_store(&s_key[wave], kInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __builtin_amdgcn_wave_barrier();
-            for (int base = 0; base < cum[9]; base += 64) {
-                const int t = base + lane;
-                if (t < cum[9]) {
-                    int p = bs[0] + t;
-#pragma unroll
-                    for (int i = 1; i < 9; ++i) p = (t >= cum[i]) ? bs[i] + (t - cum[i]) : p;
-                    const float4 v = cell_pts[p];
-                    const float dd = dist2_exact(qx, qy, qz, v.x, v.y, v.z);
-                    if (dd < kThresh2)
-                        atomicMin(&s_key[wave], ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v.w));
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const unsigned long long res = __hip_atomic_load(&s_key[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            if (lane == src) my_key = res;
-        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long my_key = cand ? __hip_atomic_load(&rec[rank].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : kInit;
+        __builtin_amdgcn_wave_barrier();             // every result is read before the next chunk's records overwrite them
         const bool valid = (unsigned)(my_key >> 32) < __float_as_uint(kThresh2);
         const uint64_t m = __ballot(valid);
         if (valid) dense_vid[(size_t)ray * S + k] = (int)(my_key & 0x7FFFFFFFull);

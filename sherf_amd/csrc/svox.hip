@@ -157,7 +157,9 @@ __global__ void __launch_bounds__(256) fix_to_float_kernel(const long long* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sparse 3x3x3 convolution on MFMA (v_mfma_f32_32x32x16_bf16, operands split hi/lo -> fp32-grade "bf16x3").
+// Sparse 3x3x3 convolution on MFMA (v_mfma_f32_32x32x16_f16, operands split hi + lo in fp16 -> fp32-grade "f16x3": 22 significant
+// bits per operand, three products; round 1 split in bf16 (16 bits) and its ~3e-5 error on the voxel rows was what the tokens --
+// and through the decoder's gain the per-sample sigma -- inherited.  Inputs are BatchNorm+ReLU outputs / O(1) features: far inside fp16's range).
 //   out[row][co] = sum_tap sum_ci act(in[nbr(row,tap)][ci]) * W[tap][ci][co]
 // A workgroup (4 waves) owns 32 output rows; the taps present in the tile are dealt round-robin to the waves, each
 // wave accumulates its taps into 32 x Cout fp32 tiles, and the four partial tiles are summed in a fixed order
@@ -166,15 +168,15 @@ __global__ void __launch_bounds__(256) fix_to_float_kernel(const long long* __re
 // on the fly; the B operand comes pre-packed in fragment order (sherf_amd/voxel.py: pack_conv_weights).
 // mode 0 submanifold, 1 stride-2 (k3 p1), 2 pointwise (1 tap, row -> same row: folds the 1x1 projections).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t pk2(float a, float b) {
-    bf16x2_t v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+    f16x2_t v; v[0] = (_Float16)a; v[1] = (_Float16)b;
     return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ float rt(float a) { return (float)((__bf16)a); }
+__device__ __forceinline__ float rt(float a) { return (float)((_Float16)a); }
 
 // BatchNorm of a conv's INPUT.  Training: the producer conv left fixed-point (2^-24) sums of its output and of its
 // squares in `acc` (integer atomics: order independent, bitwise reproducible; 8 interleaved sub-accumulators spread the
@@ -317,9 +319,9 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             for (int c = 0; c < NCOT; ++c) {
                 if (csel >= 0 && c != csel) continue;
                 const uint4 bhi = w[2 * c], blo = w[2 * c + 1];
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, alo), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, blo), acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ahi), __builtin_bit_cast(bf16x8_t, bhi), acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
             }
             if (kb + 1 < NKB) {
 #pragma unroll
@@ -446,6 +448,44 @@ extern "C" int sherf_svox_bn_finalize(const int64_t* acc, const int32_t* n_total
     SHERF_CHECK_ARG((!training || (acc && n_total_rows)) && gamma && beta && stats && bnparam && C > 0 && C <= 96);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, as_stream(stream), reinterpret_cast<const long long*>(acc),
                        n_total_rows, C, gamma, beta, stats, training, bnparam);
+    SHERF_LAUNCH_CHECK();
+}
+
+// nn.BatchNorm1d's train-mode side effect for every layer of the encoder in ONE launch (one workgroup per layer):
+//   running = (1 - momentum) running + momentum batch;  the variance unbiased (n / (n - 1));  num_batches_tracked += 1
+struct BnRunning {
+    int n_layers;
+    const float* stats[SHERF_SVOX_MAX_LAYERS];      // [2][C] batch mean / biased variance
+    float* rmean[SHERF_SVOX_MAX_LAYERS];
+    float* rvar[SHERF_SVOX_MAX_LAYERS];
+    long long* nbt[SHERF_SVOX_MAX_LAYERS];
+    const int32_t* n[SHERF_SVOX_MAX_LAYERS];        // rows the statistics were taken over
+    int C[SHERF_SVOX_MAX_LAYERS];
+    float momentum[SHERF_SVOX_MAX_LAYERS];
+};
+__global__ void __launch_bounds__(128) bn_running_kernel(BnRunning u) {
+    const int l = blockIdx.x;
+    const float m = u.momentum[l], n = (float)u.n[l][0];
+    for (int c = threadIdx.x; c < u.C[l]; c += 128) {
+        u.rmean[l][c] = u.rmean[l][c] * (1.0f - m) + m * u.stats[l][c];
+        u.rvar[l][c] = u.rvar[l][c] * (1.0f - m) + m * u.stats[l][u.C[l] + c] * n / (n - 1.0f);
+    }
+    if (threadIdx.x == 0 && u.nbt[l]) u.nbt[l][0] += 1;
+}
+
+extern "C" int sherf_svox_bn_running_update(int n_layers, const float* const* stats, float* const* running_mean, float* const* running_var,
+                                            int64_t* const* num_batches_tracked, const int32_t* const* n_rows, const int32_t* channels,
+                                            const float* momentum, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(n_layers > 0 && n_layers <= SHERF_SVOX_MAX_LAYERS && stats && running_mean && running_var && num_batches_tracked &&
+                    n_rows && channels && momentum);
+    BnRunning u;
+    u.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        SHERF_CHECK_ARG(stats[l] && running_mean[l] && running_var[l] && n_rows[l] && channels[l] > 0);
+        u.stats[l] = stats[l]; u.rmean[l] = running_mean[l]; u.rvar[l] = running_var[l];
+        u.nbt[l] = reinterpret_cast<long long*>(num_batches_tracked[l]); u.n[l] = n_rows[l]; u.C[l] = channels[l]; u.momentum[l] = momentum[l];
+    }
+    hipLaunchKernelGGL(bn_running_kernel, dim3(n_layers), dim3(128), 0, as_stream(stream), u);
     SHERF_LAUNCH_CHECK();
 }
 

@@ -56,14 +56,43 @@ def gather_rays(local, n_rays, tile=1024):
     return full
 
 
-def gather_views(local_frames, n_views):
-    """local_frames: {view index: [R, C]} rendered on this rank (view v lives on rank v % world) -> list of all frames."""
+def depth_range(near, far):
+    """[lo, hi] (float32 tensor [2] on near's device) of ALL sample depths t_k = near + k/(S-1) (far - near) of a frame: what
+    MipRayMarcher2 clamps the depth image with (ray_marcher.py:57: the min / max over the WHOLE tensor).  Evaluated exactly as the
+    sampler does (t_0 = near, t_{S-1} = near + (far - near)) on this rank's rays, then MIN / MAX-reduced over the ranks (one
+    8-byte all_reduce), so that a rank rendering a subset of the rays clamps with the frame's range, not its subset's:
+    pass it as rendering_options['depth_range']."""
+    n, f = near.detach().float().reshape(-1), far.detach().float().reshape(-1)
+    v = torch.stack([-n.min(), (n + (f - n)).max()])                  # one MAX reduction serves both ends
+    if world()[1] > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    return torch.stack([-v[0], v[1]])
+
+
+def render_ray_tiles(render, ray_origins, ray_directions, near, far, tile=1024):
+    """One frame sharded over the ranks by interleaved ray tiles.  render(ray_o, ray_d, near, far, extra_options) ->
+    (rgb [1,r,3], depth [1,r,1], acc [1,r,1]) renders a subset of rays (ImportanceRenderer.forward with the frame's other inputs
+    bound); -> the full [R, 5] (rgb, depth, acc) frame on every rank, identical to the single-process frame."""
+    R = ray_origins.shape[1]
+    idx = ray_tiles(R, tile=tile).to(ray_origins.device)
+    rng = depth_range(near, far)
+    rgb, depth, acc = render(ray_origins[:, idx], ray_directions[:, idx], near[:, idx], far[:, idx], dict(depth_range=rng))
+    return gather_rays(torch.cat([rgb[0], depth[0], acc[0]], 1), R, tile)
+
+
+def gather_views(local_frames, n_views, frame_shape=None, dtype=torch.float32, device=None):
+    """local_frames: {view index: [R, C]} rendered on this rank (view v lives on rank v % world) -> list of all frames.
+    A rank that owns no view (n_views < world) must pass frame_shape / device so that it still takes part in the collective."""
     rank, w = world()
     if w == 1:
         return [local_frames[v] for v in range(n_views)]
     per = (n_views + w - 1) // w
-    any_frame = next(iter(local_frames.values()))
-    buf = torch.zeros(per, *any_frame.shape, dtype=any_frame.dtype, device=any_frame.device)
+    if local_frames:
+        any_frame = next(iter(local_frames.values()))
+        frame_shape, dtype, device = tuple(any_frame.shape), any_frame.dtype, any_frame.device
+    elif frame_shape is None or device is None:
+        raise ValueError('gather_views: this rank renders no view -- pass frame_shape and device (the other ranks are waiting in the all_gather)')
+    buf = torch.zeros(per, *frame_shape, dtype=dtype, device=device)
     for i, v in enumerate(shard_views(n_views, rank, w)):
         buf[i] = local_frames[v]
     out = [torch.empty_like(buf) for _ in range(w)]

@@ -9,8 +9,13 @@ element e being W[rows[i], col(kb, h, e)].  `col` encodes where the kernel keeps
             k-slot (kb, h, e) holds feature  base + 16*kb + (e & 3) + 8*(e >> 2) + 4*h
   'nat'  -- the input was generated lane-locally (positional encodings): feature base + 16*kb + 8*h + e
 
-Every chunk stores a bf16 `hi` image followed by a `lo` image (W - hi, again rounded to bf16); prec 0 reads only
-`hi`, prec 1 ("bf16x3") both.  Reference parameter names: renderer.py:271-276, triplane.py:277-283.
+The stream is cut into STEPS (what the kernel's 3-slot LDS ring holds at a time): a step is a list of (chunk, K-block) UNITS in
+the order the kernel consumes them -- `step_unit` below restates csrc/mlp.hip's table (tests/test_boundary.py compares it with
+the library's own export, sherf_mlp_stream_layout) -- each unit being its 1 KiB `hi` fragment followed, for prec 1, by its `lo`
+fragment; every step is zero-padded to a multiple of 4 pieces (one DMA round of the workgroup's four waves).
+  prec 1 ("f16x3"): hi = fp16(W), lo = fp16(W - hi): 22 significant bits, three MFMAs per product in the kernel.
+  prec 0 ("bf16") : hi = bf16(W) only.
+Reference parameter names: renderer.py:271-276, triplane.py:277-283.
 """
 import numpy as np
 
@@ -109,17 +114,82 @@ def bias_table(vec, rows):
     return out
 
 
-def pack(sd, r='renderer.', d='decoder.'):
-    """-> (stream uint8 [bytes], wbias float32 [(49+4)*32], nkb list)."""
+N_STEPS = 43
+PRECISIONS = {'bf16': 0, 'f16x3': 1}
+
+
+def step_units(s):
+    """units in step s (csrc/mlp.hip: step_units)."""
+    return 10 if s < 4 else 8 if s < 20 else (10 if (s - 20) % 3 == 0 else 8) if s < 26 else 8 if s < 42 else 4
+
+
+def step_unit(s, u):
+    """unit u of step s -> (chunk, K-block) or None for padding (csrc/mlp.hip: step_unit)."""
+    if s == 0:
+        return (0, u) if u < 2 else (1 + (u - 2) // 2, (u - 2) % 2)
+    if s == 1:
+        return (5, u) if u < 2 else (6, u - 2) if u < 5 else (7, u - 5) if u < 7 else (8, u - 7) if u < 9 else None
+    if s < 4:
+        return (9 + 2 * (s - 2) + (u & 1), u // 2)
+    if s < 20:
+        q = s - 4
+        return (13 + 4 * (q // 4) + 2 * ((q % 4) // 2) + (u & 1), 4 * (q % 2) + u // 2)
+    if s < 26:
+        q = s - 20
+        return (29 + 2 * (q // 3) + (u & 1), (0, 5, 9)[q % 3] + u // 2)
+    if s < 34:
+        q = s - 26
+        return (33 + 4 * (q // 4) + 2 * ((q % 4) // 2) + (u & 1), 4 * (q % 2) + u // 2)
+    if s < 38:
+        q = s - 34
+        return (41 + 2 * (q // 2) + (u & 1), 4 * (q % 2) + u // 2)
+    if s == 38:
+        return (45, u)
+    if s < 42:
+        return (46 + (u & 1), 4 * (s - 39) + u // 2)
+    return (48, u)
+
+
+def step_pieces(s, prec):
+    return (step_units(s) * (prec + 1) + 3) // 4 * 4
+
+
+def _f16_bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+def pack(sd, r='renderer.', d='decoder.', prec=1):
+    """-> (stream uint8 [bytes], wbias float32 [(49+4)*32], nkb list) for the kernel's `prec` (1 = f16x3, 0 = bf16)."""
+    assert prec in (0, 1)
     specs = chunk_specs(sd, r, d)
-    parts, bias, nkbs = [], [], []
+    frag, bias, nkbs = [], [], []
     for sp in specs:
         img = chunk_image(sp)
-        hi = _bf16_bits(img)
-        lo = _bf16_bits(img - _bf16_val(img))
-        parts.append(hi.tobytes()); parts.append(lo.tobytes())
+        if prec == 1:
+            hi = _f16_bits(img)
+            lo = _f16_bits(img - hi.view(np.float16).astype(np.float32))
+        else:
+            hi, lo = _bf16_bits(img), None
+        frag.append((hi, lo))
         bias.append(bias_table(sp['bias'], sp['rows']))
         nkbs.append(img.shape[0])
+    parts, used = [], set()
+    for s_ in range(N_STEPS):
+        n = 0
+        for u in range(step_units(s_)):
+            cu = step_unit(s_, u)
+            if cu is None:
+                parts.append(bytes(1024 * (prec + 1)))
+            else:
+                c, kb = cu
+                assert kb < nkbs[c] and cu not in used, (s_, u, cu)
+                used.add(cu)
+                parts.append(frag[c][0][kb].tobytes())
+                if prec == 1:
+                    parts.append(frag[c][1][kb].tobytes())
+            n += prec + 1
+        parts.append(bytes(1024 * (step_pieces(s_, prec) - n)))
+    assert len(used) == sum(nkbs), 'every (chunk, K-block) unit must be streamed exactly once'
     t = r + 'transformer.layers.0.'
     for n in ('0.fn.norm.weight', '0.fn.norm.bias', '1.fn.norm.weight', '1.fn.norm.bias'):
         bias.append(bias_table(np.asarray(sd[t + n], np.float32), list(range(32))))

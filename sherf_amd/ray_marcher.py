@@ -16,6 +16,11 @@ class MipRayMarcher2(nn.Module):
             raise NotImplementedError("SHERF uses clamp_mode='relu' (train.py:332); softplus is not implemented in HIP")
         if not colors.is_cuda:
             raise RuntimeError('sherf_amd.MipRayMarcher2 runs on the GPU only (no CPU fallback)')
+        if colors.shape[-1] != 3:
+            raise RuntimeError(f'sherf_amd.MipRayMarcher2 composites 3 colour channels (SHERF: rgb), got {colors.shape[-1]}')
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (colors, densities, depths, rays_d)):
+            raise RuntimeError('sherf_amd.MipRayMarcher2 (dense) is forward only: gradients flow through ImportanceRenderer '
+                               '(enable_autograd, sherf_amd/backward.py); call it under torch.no_grad()')
         B, R, S = densities.shape[:3]
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         c, s, t, d = f32(colors).view(B * R, S, 3), f32(densities).view(B * R, S), f32(depths).view(B * R, S), f32(rays_d).view(B * R, 3)

@@ -19,9 +19,9 @@ from . import _lib, mlp_pack
 from .ray_marcher import MipRayMarcher2
 from .voxel import SparseConvNet, SparseConvTensor, pack_conv_weights  # noqa: F401
 
-# `shape` argument of sherf_nerf_mlp (include/sherf_hip.h).  '8x1il8' / '8x1prio' / '8x1prio_il8' differ from '8x1' in the
-# instruction schedule only (bit-identical results); sherf_amd.tune times them on the device and reports the fastest.
-MLP_SHAPES = {'8x1': 0, '4x2': 1, '8x1split': 2, '8x1split2': 3, '8x1persist': 4, '8x1il8': 5, '8x1prio': 6, '8x1prio_il8': 7, '4x1': 8, '4x1il8': 9, '4x1phase': 10, '4x1persist': 11}
+# `prec` argument of sherf_nerf_mlp (include/sherf_hip.h): 'f16x3' = split fp16 operands, three MFMAs per product (fp32-grade,
+# the default); 'bf16' = one bf16 product (north_star's nominal precision; misses the 1e-3 tolerance, kept for the comparison)
+MLP_PRECISIONS = mlp_pack.PRECISIONS
 
 V = 6890
 
@@ -49,7 +49,7 @@ def compute_normal(vertices, faces):
 class PositionalEncoding(nn.Module):
     """renderer.py:875-916 (buffers `_freqs`, `_phases` are part of the checkpoint contract)."""
 
-    def __init__(self, num_freqs=6, d_in=3, include_input=True):
+    def __init__(self, num_freqs=6, d_in=3, freq_factor=None, include_input=True):      # (freq_factor: unused there as well, :884)
         super().__init__()
         self.num_freqs, self.d_in, self.include_input = num_freqs, d_in, include_input
         self.freqs = 2.0 ** torch.linspace(0.0, num_freqs - 1, steps=num_freqs)
@@ -226,7 +226,7 @@ class _Workspace:
 
 class ImportanceRenderer(nn.Module):
     def __init__(self, use_1d_feature=True, use_2d_feature=True, use_3d_feature=True, use_trans=False, use_NeRF_decoder=False,
-                 smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='bf16x3'):
+                 smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='f16x3'):
         super().__init__()
         self.use_1d_feature, self.use_2d_feature, self.use_3d_feature = use_1d_feature, use_2d_feature, use_3d_feature
         self.use_trans, self.use_NeRF_decoder = use_trans, use_NeRF_decoder
@@ -242,7 +242,6 @@ class ImportanceRenderer(nn.Module):
         self.pos_enc = PositionalEncoding(num_freqs=6)
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
-        self.mlp_shape = os.environ.get('SHERF_MLP_SHAPE', '8x1')      # workgroup shape of sherf_nerf_mlp ('8x1' | '4x2' | experimental '8x1split', '8x1split2', '8x1persist')
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         # schedule variant of the voxel taps (sherf_hip.h): False = one branch per corner, True = unconditional loads (160 VGPRs),
         # '128' = unconditional loads compiled for 4 waves / SIMD
@@ -346,15 +345,16 @@ class ImportanceRenderer(nn.Module):
         return can
 
     # ---- weights -----------------------------------------------------------------------------
-    def _weights(self, decoder, device):
+    def _weights(self, decoder, device, precision=None):
+        prec = MLP_PRECISIONS[precision or self.mlp_precision]
         mods = [self.conv1d_projection, self.conv1d_reprojection, self.transformer, decoder]
-        key = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters()) + (str(device),)
+        key = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters()) + (str(device), prec)
         if self._wcache is not None and self._wcache['key'] == key:
             return self._wcache
         sd = {'renderer.' + k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()
               if not k.startswith('encoder_3d.')}
         sd.update({'decoder.' + k: v.detach().float().cpu().numpy() for k, v in decoder.state_dict().items()})
-        stream, wbias, _ = mlp_pack.pack(sd)
+        stream, wbias, _ = mlp_pack.pack(sd, prec=prec)
         Wr = self.conv1d_reprojection.weight.detach().float()[:, :, 0]          # [32, 96]
         Wp = self.conv1d_projection.weight.detach().float()[:, :, 0]            # [96, 192]
         bp = self.conv1d_projection.bias.detach().float()
@@ -398,6 +398,12 @@ class ImportanceRenderer(nn.Module):
         if ray_origins.shape[0] != 1:
             raise RuntimeError('per-GPU batch must be 1, as in the reference (renderer.py:320-321,567)')
         opts = rendering_options
+        if ray_origins.device.index is not None and ray_origins.device.index != torch.cuda.current_device():
+            # the native frame driver keeps per-device state under hipGetDevice() and the helpers use the current stream: render
+            # under the tensors' device
+            with torch.cuda.device(ray_origins.device):
+                return self.forward(planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
+                                    decoder, ray_origins, ray_directions, near, far, input_data, rendering_options)
         if opts.get('depth_resolution_importance', 0) != 0:
             raise NotImplementedError('importance sampling is unreachable/broken in the reference (renderer.py:376,383)')
         if opts.get('clamp_mode', 'relu') != 'relu' or opts.get('disparity_space_sampling', False):
@@ -408,7 +414,7 @@ class ImportanceRenderer(nn.Module):
         cap = int(opts.get('sample_capacity', R * S))
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         smpl = self._smpl(dev)
-        wc = self._weights(decoder, dev)
+        wc = self._weights(decoder, dev, opts.get('mlp_precision'))
         ws = self._ws.frame(R, S, cap, dev)
         prm, oprm, tprm = input_data['params'], input_data['obs_params'], input_data['t_params']
 
@@ -470,17 +476,25 @@ class ImportanceRenderer(nn.Module):
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
         # a13-a14: fused transformer + NeRF decoder
         fr.wstream, fr.wbias = A(wc['stream']), A(wc['wbias'])
-        fr.mlp_prec = {'bf16': 0, 'bf16x3': 1}[opts.get('mlp_precision', self.mlp_precision)]
-        fr.mlp_shape = MLP_SHAPES[opts.get('mlp_shape', self.mlp_shape)]   # split: experimental, overwrites ws['tokens']
+        fr.mlp_prec = MLP_PRECISIONS[opts.get('mlp_precision') or self.mlp_precision]
+        fr.mlp_shape = 0
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()
         s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
         s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if self.aux_stream else None
         noise = float(opts.get('density_noise', 0) or 0)
-        if noise > 0:                                                    # renderer.py:435-436 (training only)
+        rng = opts.get('depth_range')                                    # sherf_amd.dist: [lo, hi] of the WHOLE frame's depths
+        if noise > 0 or rng is not None:
             _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
-            ws['sample_out'][:, 3] += torch.randn(cap, device=dev) * noise
+            if noise > 0:                                                # renderer.py:435-436 (training only)
+                ws['sample_out'][:, 3] += torch.randn(cap, device=dev) * noise
+            if rng is not None:
+                # ray_marcher.py:57 clamps the depth image with the min / max over ALL depths of the frame; when this call renders
+                # only a subset of the frame's rays (ray-tile sharding) the caller supplies the frame-wide range, which replaces
+                # the subset's own in the counters the compositing kernel reads (order-preserving int encoding, csrc/common.h: f2ord)
+                bits = torch.as_tensor(rng, dtype=torch.float32, device=dev).reshape(2).contiguous().view(torch.int32)
+                ws['counters'][1:3] = torch.where(bits >= 0, bits, bits ^ 0x7FFFFFFF)
             _lib.call('sherf_render_frame', _ct.byref(fr), 2, levels, s_main, s_side, s_aux)
         else:
             _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side, s_aux)

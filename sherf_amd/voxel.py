@@ -58,13 +58,14 @@ def _stride_conv(cin, cout):
 
 
 def pack_conv_weights(wt):
-    """wt [ntaps, Cin, Cout] fp32 -> bf16 MFMA B-operand fragments [ntaps][Cin/16][Cout/32][hi,lo][64 lanes][8] (int16 bits).
+    """wt [ntaps, Cin, Cout] fp32 -> fp16 MFMA B-operand fragments [ntaps][Cin/16][Cout/32][hi,lo][64 lanes][8] (int16 bits):
+    hi = fp16(W), lo = fp16(W - hi) ("f16x3": 22 significant bits, three products in the kernel).
     Lane l = (column j = l & 31, half h = l >> 5) holds W[tap][16*kb + 8*h + e][32*cot + j], e = 0..7
-    (operand layout of v_mfma_f32_32x32x16_bf16; consumed by sconv3_kernel in csrc/svox.hip)."""
+    (operand layout of v_mfma_f32_32x32x16_f16; consumed by sconv3_kernel in csrc/svox.hip)."""
     T, Cin, Cout = wt.shape
     w = wt.float().reshape(T, Cin // 16, 2, 8, Cout // 32, 32).permute(0, 1, 4, 2, 5, 3).reshape(T, Cin // 16, Cout // 32, 64, 8)
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
     return torch.stack([hi, lo], 3).contiguous().view(torch.int16)
 
 
@@ -176,18 +177,21 @@ class SparseConvNet(nn.Module):
         return pl, feat, coord
 
     def finish(self, pl):
-        """nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance); call after the encoder was enqueued."""
-        if not (self.training and (torch.is_grad_enabled() or getattr(self, '_force_stats_update', False))):
+        """nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance); call after the encoder was enqueued.
+        Like nn.BatchNorm1d it depends on `self.training` only -- a train-mode forward under torch.no_grad() (the reference's
+        test loop renders with G in train mode, training_loop.py:193,311-330) advances the running statistics too."""
+        if not self.training:
             return
-        with torch.no_grad():
-            for m in pl['meta']:
-                bn = m['bn']
-                if not bn.track_running_stats:
-                    continue
-                n = (pl['L'][0]['n_total'] if m['lev'] == 0 else pl['L'][m['lev']]['n_rows']).float()
-                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * m['stats'][0])
-                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * m['stats'][1] * n / (n - 1))
-                bn.num_batches_tracked += 1
+        import ctypes
+        ms = [m for m in pl['meta'] if m['bn'].track_running_stats]
+        n = len(ms)
+        if not n:
+            return
+        VP, A = ctypes.c_void_p * n, _lib.addr
+        rows = [pl['L'][0]['n_total'] if m['lev'] == 0 else pl['L'][m['lev']]['n_rows'] for m in ms]
+        _lib.call('sherf_svox_bn_running_update', n, VP(*[A(m['stats']) for m in ms]), VP(*[A(m['bn'].running_mean) for m in ms]),
+                  VP(*[A(m['bn'].running_var) for m in ms]), VP(*[A(m['bn'].num_batches_tracked) for m in ms]), VP(*[A(r) for r in rows]),
+                  (ctypes.c_int32 * n)(*[m['cout'] for m in ms]), (ctypes.c_float * n)(*[float(m['bn'].momentum) for m in ms]), _lib.stream())
 
     def encode(self, sp, fold_mats, ws):
         """Runs the encoder on a SparseConvTensor (one native call, csrc/svox.hip: sherf_svox_encode); returns the three

@@ -15,6 +15,8 @@ CONFIGS = {
     'cfg1':  dict(H=128, W=128, S=32, plane_res=256, novel_pose=True, theta_tgt=0.4, theta_obs=-0.3),
     'cfg2':  dict(H=512, W=512, S=64, plane_res=256, novel_pose=False, theta_tgt=0.4, theta_obs=-0.3),
     'cfg3':  dict(H=512, W=512, S=64, plane_res=256, novel_pose=True, theta_tgt=0.4, theta_obs=-0.3),
+    # cfg2 framed tighter (the frame spans 1.55 m at the subject instead of 2.2 m): valid-sample fraction ~ SURVEY 8(d)'s probe value 0.076
+    'cfg2_dense': dict(H=512, W=512, S=64, plane_res=256, novel_pose=False, theta_tgt=0.4, theta_obs=-0.3, fill=1.55),
 }
 
 
@@ -62,7 +64,7 @@ def renderer_inputs(cfg_name, smpl=None):
     c = CONFIGS[cfg_name]
     smpl = smpl or synth.make_synth_smpl(0)
     d = synth.make_input_data(smpl, H=c['H'], W=c['W'], seed=1, theta_tgt=c['theta_tgt'],
-                              theta_obs=c['theta_obs'], novel_pose=c['novel_pose'])
+                              theta_obs=c['theta_obs'], novel_pose=c['novel_pose'], fill=c.get('fill', 2.2))
     r = _rs('inputs/' + cfg_name)
     P = c['plane_res']
     planes = r.standard_normal((1, 3, 32, P, P)).astype(np.float32)

@@ -254,7 +254,7 @@ def orbit_camera(theta, center, dist, H, W, fill=2.2):
     return K, R, T
 
 
-def make_input_data(smpl, H=32, W=32, seed=1, theta_tgt=0.4, theta_obs=-0.3, novel_pose=True, dist=3.0):
+def make_input_data(smpl, H=32, W=32, seed=1, theta_tgt=0.4, theta_obs=-0.3, novel_pose=True, dist=3.0, fill=2.2):
     """Collated (B=1) `input_data` dict as numpy arrays (keys of RenderPeople_dataset.py:362-391)."""
     rng = np.random.RandomState(seed)
     pose_t = rng.normal(0, 0.15, (1, 72)).astype(np.float32)
@@ -279,7 +279,7 @@ def make_input_data(smpl, H=32, W=32, seed=1, theta_tgt=0.4, theta_obs=-0.3, nov
     t_world_bounds = np.stack([mn, mx]).astype(np.float32)
 
     center = vertices.mean(0).astype(np.float64)
-    K, R, T = orbit_camera(theta_tgt, center, dist, H, W)
+    K, R, T = orbit_camera(theta_tgt, center, dist, H, W, fill=fill)
     ro, rd = get_rays(H, W, K, R, T)
     ray_o, ray_d, near, far, at_box = pack_near_far(wb, ro, rd)
     oK, oR, oT = orbit_camera(theta_obs, obs_vertices.mean(0).astype(np.float64), dist, H, W)

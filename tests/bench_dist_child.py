@@ -15,7 +15,7 @@ def main():
     import sherf_amd.renderer as AR
     import bench
     _lib.LIB_PATH, _lib._lib = os.environ['SHERF_HIPCPU_LIB'], None
-    _lib.ptr = lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr())
+    _lib.ptr = lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr())
     _lib.addr = lambda t, dtype=None: None if t is None else t.data_ptr()
     _lib.stream = lambda: ctypes.c_void_p(0)
     torch.cuda.current_stream = lambda dev=None: type('S', (), {'cuda_stream': 0})()
@@ -25,7 +25,7 @@ def main():
     AR.ImportanceRenderer.SMPL_NEUTRAL = property(lambda self: self._smpl(torch.device('cpu')))
     bench._device = lambda lrank: torch.device('cpu')
     sys.argv = ['bench.py', '--gpus', os.environ['WORLD_SIZE'], '--config', 'tiny', '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
-                '--no-torch-gpu-baseline', '--mlp-shape', '8x1']
+                '--no-torch-gpu-baseline']
     bench.main()
 
 

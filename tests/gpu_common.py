@@ -71,7 +71,7 @@ def to_cuda(x):
 
 
 @functools.lru_cache(None)
-def hip_modules(precision='bf16x3'):
+def hip_modules(precision='f16x3'):
     from sherf_amd.renderer import ImportanceRenderer
     from sherf_amd.triplane import NeRFDecoder
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl(), mlp_precision=precision)
@@ -83,7 +83,7 @@ def hip_modules(precision='bf16x3'):
     return dev_module(rend).train(), dev_module(dec).train()
 
 
-def hip_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, options=None):
+def hip_render(cfg, precision='f16x3', training=True, fx=None, sp_input=None, options=None):
     """Runs sherf_amd.ImportanceRenderer.forward on the fixture; the voxel coordinates come from the oracle's
     prepare_sp_input so this isolates the renderer (the TriPlaneGenerator glue has its own test)."""
     from sherf_amd.voxel import SparseConvTensor

@@ -17,15 +17,28 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'     # host compile of the sources that 
 
 
 def _cpu_mlp(src):
-    """mlp.hip for the host: the three inline-asm sites (LDS-DMA, vmcnt wait, barrier) become their functional equivalents."""
-    a = src.index('            uint32_t l = (uint32_t)(size_t)(lptr_t)(dst + p * 1024);')
-    b = src.index('            ++n;', a)
-    src = src[:a] + '            memcpy(dst + p * 1024 + cx.lane * 16, g, 16);              // what global_load_lds_dwordx4 does for this lane\n' + src[b:]
-    a = src.index('__device__ __forceinline__ void wait_vm(int n) {')
-    b = src.index('__device__ __forceinline__ void wg_barrier()', a)
-    src = src[:a] + '__device__ __forceinline__ void wait_vm(int) {}\n' + src[b:]
+    """mlp.hip for the host: the inline-asm sites (LDS-DMA, vmcnt wait, barrier, the ordered MFMA blocks and their settle nops)
+    become their functional equivalents."""
+    def cut(text, start, end, repl):
+        a = text.index(start)
+        b = text.index(end, a)
+        return text[:a] + repl + text[b:]
+    # LDS-DMA of one piece: what global_load_lds_dwordx4 does for this lane (the ring address is kept as an offset on the host)
+    src = cut(src, '        uint32_t keep;\n        asm volatile("s_mov_b32 %0, m0', '    }\n}', '        memcpy(const_cast<char*>(cx.lds) + l, g, 16);\n')
+    src = src.replace('cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;', 'cx.lds_addr = cx.wave * 1024;')
+    src = cut(src, '__device__ __forceinline__ void wait_vm(int n) {', '__device__ __forceinline__ void wg_barrier()',
+              '__device__ __forceinline__ void wait_vm(int) {}\n')
     src = re.sub(r'__device__ __forceinline__ void wg_barrier\(\) \{[^\n]*\}', '__device__ __forceinline__ void wg_barrier() { __syncthreads(); }', src)
+    # the six / two MFMAs of a block, in the asm's order
+    src = cut(src, '    if constexpr (PREC == 1)\n        asm volatile("s_nop 1', '}\n// an MFMA\'s result -> any reader',
+              '    if constexpr (PREC == 1) {\n'
+              '        acc0 = mfma<PREC>(al0, bh0, acc0); acc1 = mfma<PREC>(al1, bh1, acc1);\n'
+              '        acc0 = mfma<PREC>(ah0, bl0, acc0); acc1 = mfma<PREC>(ah1, bl1, acc1);\n'
+              '        acc0 = mfma<PREC>(ah0, bh0, acc0); acc1 = mfma<PREC>(ah1, bh1, acc1);\n'
+              '    } else { acc0 = mfma<PREC>(ah0, bh0, acc0); acc1 = mfma<PREC>(ah1, bh1, acc1); }\n')
+    src = src.replace('    asm volatile("s_nop 7\\n\\ts_nop 3" : "+v"(acc0), "+v"(acc1));', '    (void)acc0; (void)acc1;')
     src = re.sub(r'asm volatile\("" : "\+[sv]"\([^;]*;', ';', src)            # register-class launders (optimisation barriers only)
+    assert 'asm volatile' not in src, 'an inline-asm site of mlp.hip has no host equivalent'
     return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
 
 

@@ -161,6 +161,36 @@ inline hipcpu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipcpu_bf16x8 a, hi
     }
     return d;
 }
+// v_mfma_f32_32x32x16_f16: the same shape with fp16 operands
+typedef _Float16 hipcpu_f16x8 __attribute__((ext_vector_type(8)));
+inline hipcpu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipcpu_f16x8 a, hipcpu_f16x8 b, hipcpu_f32x16 c, int, int, int) {
+    struct Line { float a[8], b[8]; };
+    Line* sc = reinterpret_cast<Line*>(hipcpu_collective_buffer());
+    const int l = hipcpu_lane(), col = l & 31, h = l >> 5;
+    for (int e = 0; e < 8; ++e) { sc[l].a[e] = (float)a[e]; sc[l].b[e] = (float)b[e]; }
+    hipcpu_wave_sync();
+    hipcpu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = 0.f;
+        for (int hh = 0; hh < 2; ++hh)
+            for (int e = 0; e < 8; ++e) acc += sc[row + 32 * hh].a[e] * sc[col + 32 * hh].b[e];
+        d[r] += acc;
+    }
+    return d;
+}
+// v_cvt_pkrtz_f16_f32: two floats -> packed fp16, rounded TOWARD ZERO (finite overflow saturates to +-65504)
+typedef _Float16 hipcpu_f16x2 __attribute__((ext_vector_type(2)));
+inline _Float16 hipcpu_f32_to_f16_rtz(float x) {
+    _Float16 h = (_Float16)x;                                  // round to nearest even
+    const float back = (float)h;
+    if (std::isinf(back) && !std::isinf(x)) { unsigned short u = x > 0 ? 0x7bff : 0xfbff; memcpy(&h, &u, 2); return h; }
+    if (fabsf(back) > fabsf(x)) {                              // rounded away from zero: step one ulp toward zero
+        unsigned short u; memcpy(&u, &h, 2); u -= 1; memcpy(&h, &u, 2);
+    }
+    return h;
+}
+inline hipcpu_f16x2 __builtin_amdgcn_cvt_pkrtz(float a, float b) { hipcpu_f16x2 r; r[0] = hipcpu_f32_to_f16_rtz(a); r[1] = hipcpu_f32_to_f16_rtz(b); return r; }
 #endif
 inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {          // v_perm_b32: byte select from {hi:lo}
     const unsigned long long src = ((unsigned long long)hi << 32) | lo;

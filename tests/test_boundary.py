@@ -67,16 +67,22 @@ def test_renderer_is_picklable_like_reference_snapshots():
     assert set(r2.state_dict()) == set(rend.state_dict())
 
 
-def test_mlp_stream_layout_matches_packer(golden_dir):
+def test_mlp_stream_layout_matches_packer():
+    """The step table of the weight stream: the library's own export (csrc/mlp.hip, constexpr -- what the kernel walks) against its
+    restatement in the packer, for both precisions."""
     from sherf_amd import mlp_pack
-    from oracle import fixtures
-    n = ctypes.c_int32(0)
-    nkb = (ctypes.c_int32 * 64)()
-    assert _lib.lib().sherf_mlp_stream_layout(ctypes.byref(n), nkb, 64) == 0
-    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
-    sd = {k: fixtures.seeded_param(k, s) for k, s in shapes.items() if fixtures.seeded_param(k, s) is not None}
-    _, _, nkbs = mlp_pack.pack(sd)
-    assert n.value == len(nkbs) and list(nkb[:n.value]) == nkbs
+    for prec in (0, 1):
+        n = ctypes.c_int32(0)
+        pieces = (ctypes.c_int32 * 64)()
+        units = (ctypes.c_int32 * 640)()
+        assert _lib.lib().sherf_mlp_stream_layout(prec, ctypes.byref(n), pieces, units, 64) == 0
+        assert n.value == mlp_pack.N_STEPS
+        for s in range(n.value):
+            assert pieces[s] == mlp_pack.step_pieces(s, prec), s
+            for u in range(10):
+                want = mlp_pack.step_unit(s, u) if u < mlp_pack.step_units(s) else None
+                assert units[s * 10 + u] == (-1 if want is None else want[0] * 16 + want[1]), (s, u)
+    assert _lib.lib().sherf_mlp_stream_layout(2, ctypes.byref(n), pieces, units, 64) != 0
 
 
 def test_struct_layouts_match_header(tmp_path):

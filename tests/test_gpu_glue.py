@@ -1,0 +1,24 @@
+"""`-m gpu` (first run on an MI355X in round 2: green): the fused per-frame glue kernels (csrc/glue.hip) and the launch
+switches of the frame -- grids sized by the frame's own sample count, the gather's schedule variants -- must render the default frame's bits."""
+import pytest
+import torch
+
+from tests import gpu_common as G
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
+
+
+def test_fused_glue_kernels_on_device():
+    """csrc/glue.hip on hardware: the same comparison the CPU suite runs on the host build (tests/test_hipcpu_frame.py)."""
+    from tests.test_hipcpu_frame import check_fused_glue
+    print('fraction of vertices whose back-face bit differs from the tensor-op glue:', check_fused_glue())
+
+
+@pytest.mark.parametrize('cfg', ['tiny', 'cfg1'])
+def test_exact_grids_and_gather_variants_on_device(cfg):
+    """SHERF_FRAME_EXACT_GRIDS (launches sized by the frame's own sample count, one host wait) and the gather's schedule variants render
+    the same bits as the default frame on the device."""
+    a = G.hip_render(cfg)
+    for opts in (dict(exact_grids=True), dict(gather_branchless=True), dict(gather_branchless='128'), dict(exact_grids=True, gather_branchless=True)):
+        b = G.hip_render(cfg, options=opts)
+        assert torch.equal(b['rgb'], a['rgb']) and torch.equal(b['acc'], a['acc']) and torch.equal(b['depth'], a['depth']), opts

@@ -1,6 +1,6 @@
 """bias_act / upfirdn2d HIP kernels on the MI355X: the same checks as tests/test_hipcpu_ops.py (goldens of the unmodified reference's
 `_ref` implementations, both derivatives, channels_last, float16) with real device tensors and libsherf_hip_ops.so.
-NOT part of `-m gpu` yet: written after round 1's GPU budget was spent; run with `pytest -m gpu_experimental`."""
+Under `-m gpu` since round 2 (first hardware run: green after the channels_last pointer check was fixed)."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +8,7 @@ import torch
 from oracle import ops_cases as C
 from tests import test_hipcpu_ops as H
 
-pytestmark = [pytest.mark.gpu_experimental, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason='needs an MI355X')]
 
 
 @pytest.fixture(scope='module')

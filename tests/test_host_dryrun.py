@@ -151,42 +151,51 @@ def test_full_size_property_test_plumbing(monkeypatch):
     by the oracle, on a small configuration: checks the test's own plumbing (subset selection, shapes, comparisons)."""
     from tests import test_gpu_parity as T
 
-    def fake_render(cfg, precision='bf16x3', training=True, fx=None, sp_input=None, options=None):
+    def fake_render(cfg, precision='f16x3', training=True, fx=None, sp_input=None, options=None):
         f = dict(fx or G.fixture(cfg))
         opts = dict(f['options']); opts.update(options or {})
-        f['options'] = opts
+        f['options'] = dict(opts, margins=True)
         r = O.render_from_fixture(f, G.seeded_state(), training=training, keep=False)
-        ws = dict(counters=torch.tensor([r['valid'].numel(), 0, 0, 0]))
+        nv = r['valid'].numel()
+        ws = dict(counters=torch.tensor([nv, 0, 0, 0]), cs_idx=r['valid'].int(), cs_vid=r['vert_id'].int(), cs_tvid=r['t_vert_id'].int(),
+                  sample_out=torch.cat([r['sample_rgb'], r['sample_sigma'].view(-1, 1)], 1))
         return dict(rgb=r['rgb'], depth=r['depth'], acc=r['acc'], last=dict(ws=ws), rend=None)
     monkeypatch.setattr(T.G, 'hip_render', fake_render)
     T._full_size_properties('tiny', 7)
 
 
-# ---- bench.py: MLP launch-shape selection through a child process ---------------------------------------------------------------
-def test_bench_pick_mlp_shape_falls_back_and_parses(monkeypatch):
-    """No GPU here: the tune child fails -> the default shape with the error recorded; a well-formed child report -> its choice."""
+# ---- bench.py: roofline.traffic from rocprofv3 --pmc child passes ------------------------------------------------------------------
+def test_bench_pmc_traffic_parses_counter_csv_and_reports_failures(monkeypatch, tmp_path):
+    """No GPU / no profiler here: the two `rocprofv3 --pmc` child passes are faked -- their counter_collection.csv is parsed into HBM
+    bytes per nerf_mlp_kernel launch (FETCH_SIZE doubled, the gfx950 rule), and a failing pass yields {'error': ...}, never an exception."""
     import argparse
-    import json
     import subprocess
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    a = argparse.Namespace(config='cfg2', precision='bf16x3', bn_mode='train')
-    seen = {}
+    a = argparse.Namespace(config='cfg2', precision='f16x3', bn_mode='train')
+    seen = []
 
-    def fake_run(cmd, env=None, **kw):
-        seen['cmd'], seen['env'] = cmd, env
-        return subprocess.CompletedProcess(cmd, 1, stdout='', stderr='RuntimeError: no HIP device')
+    def fake_run(cmd, env=None, cwd=None, **kw):
+        seen.append((cmd, env))
+        counter, outdir = cmd[cmd.index('--pmc') + 1], cmd[cmd.index('-d') + 1]
+        os.makedirs(os.path.join(outdir, 'host', '123'), exist_ok=True)
+        with open(os.path.join(outdir, 'host', '123', '123_counter_collection.csv'), 'w') as f:
+            f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+            for i, v in enumerate((1000.0, 3000.0)):
+                f.write(f'{i},"void (anonymous namespace)::nerf_mlp_kernel<1>(int const*)","{counter}",{v if counter == "FETCH_SIZE" else v / 10}\n')
+            f.write(f'9,"gather_tokens_kernel","{counter}",777\n')
+        return subprocess.CompletedProcess(cmd, 0, stdout='', stderr='')
+    monkeypatch.setattr(bench.shutil if hasattr(bench, 'shutil') else __import__('shutil'), 'which', lambda n: '/bin/true')
     monkeypatch.setenv('RANK', '3'); monkeypatch.setenv('WORLD_SIZE', '8')
     monkeypatch.setattr(subprocess, 'run', fake_run)
-    shape, rep = bench.pick_mlp_shape(a, 3)
-    assert shape == '8x1' and 'no HIP device' in rep['error']
-    assert '--tune-child' in seen['cmd'] and seen['env']['LOCAL_RANK'] == '3' and 'RANK' not in seen['env'] and 'WORLD_SIZE' not in seen['env']
-    good = dict(best='8x1prio', shapes={'8x1': dict(ms=0.75, ok=True), '8x1prio': dict(ms=0.70, ok=True)})
-    monkeypatch.setattr(subprocess, 'run', lambda cmd, **kw: subprocess.CompletedProcess(cmd, 0, stdout='noise\nTUNE_JSON ' + json.dumps(good) + '\n', stderr=''))
-    assert bench.pick_mlp_shape(a, 0) == ('8x1prio', good)
+    r = bench.pmc_traffic(a, 3)
+    assert r['hbm_bytes_per_launch'] == int(2 * 2000.0 * 1024 + 200.0 * 1024) and r['dispatches'] == 2
+    assert all('--pmc-child' in c and e['LOCAL_RANK'] == '3' and 'RANK' not in e and e['TMPDIR'] == '/tmp' for c, e in seen)
+    assert [c[c.index('--pmc') + 1] for c, _ in seen] == ['FETCH_SIZE', 'WRITE_SIZE']                       # separate passes
+    assert not any(x in c for c, _ in seen for x in ('--sys-trace', '--kernel-trace', '--hip-trace', '--stats'))   # counters alone
 
     def boom(cmd, **kw):
         raise subprocess.TimeoutExpired(cmd, 1)
     monkeypatch.setattr(subprocess, 'run', boom)
-    assert bench.pick_mlp_shape(a, 0)[0] == '8x1'
+    assert 'error' in bench.pmc_traffic(a, 0)

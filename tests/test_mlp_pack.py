@@ -24,17 +24,24 @@ def _row_of(h, r):
 class Emu:
     """Emulates nerf_mlp_kernel for n samples; activations are [n, 32] tiles in natural row order."""
 
-    def __init__(self, stream, wbias, nkbs, use_lo=True):
+    def __init__(self, stream, wbias, nkbs, use_lo=True, prec=1):
+        """Reads the STEPPED stream back (mlp_pack.step_unit order: hi [, lo] piece per unit, steps padded to 4 pieces)."""
         self.bias = wbias.reshape(-1, 2, 16)
-        self.img = []
-        off = 0
-        for nkb in nkbs:
-            sz = nkb * 64 * 8
-            hi = np.frombuffer(stream[off * 2:(off + sz) * 2].tobytes(), np.uint16).astype(np.uint32) << 16
-            lo = np.frombuffer(stream[(off + sz) * 2:(off + 2 * sz) * 2].tobytes(), np.uint16).astype(np.uint32) << 16
-            w = hi.view(np.float32) + (lo.view(np.float32) if use_lo else 0)
-            self.img.append(w.reshape(nkb, 64, 8).astype(np.float64))
-            off += 2 * sz
+        self.img = [np.zeros((nkb, 64, 8)) for nkb in nkbs]
+        raw = np.frombuffer(stream.tobytes(), np.uint16).reshape(-1, 512)            # 1 KiB pieces of 64 lanes x 8 elements
+        dec = (lambda p: p.view(np.float16).astype(np.float64)) if prec == 1 else (lambda p: (p.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
+        piece = 0
+        for s_ in range(mlp_pack.N_STEPS):
+            for u in range(mlp_pack.step_units(s_)):
+                cu = mlp_pack.step_unit(s_, u)
+                if cu is not None:
+                    w = dec(raw[piece])
+                    if prec == 1 and use_lo:
+                        w = w + dec(raw[piece + 1])
+                    self.img[cu[0]][cu[1]] = w.reshape(64, 8)
+                piece += prec + 1
+            piece = sum(mlp_pack.step_pieces(i, prec) for i in range(s_ + 1))
+        assert piece * 1024 == stream.nbytes
 
     @staticmethod
     def tile_frags(tile):
@@ -136,7 +143,14 @@ def packed(golden_dir):
 def test_stream_layout(packed):
     sd, (stream, wbias, nkbs) = packed
     assert len(nkbs) == 49 and sum(nkbs) == 351
-    assert stream.nbytes == 2 * 351 * 1024
+    assert stream.nbytes == 704 * 1024 and sum(mlp_pack.step_pieces(s, 1) for s in range(mlp_pack.N_STEPS)) == 704
+    assert max(mlp_pack.step_pieces(s, 1) for s in range(mlp_pack.N_STEPS)) == 20          # the kernel's LDS ring slot: 20 KiB
+    assert all(mlp_pack.step_pieces(s, p) % 4 == 0 for s in range(mlp_pack.N_STEPS) for p in (0, 1))   # whole DMA rounds of 4 waves
+    units = [mlp_pack.step_unit(s, u) for s in range(mlp_pack.N_STEPS) for u in range(mlp_pack.step_units(s))]
+    real = [u for u in units if u is not None]
+    assert len(real) == 351 and len(set(real)) == 351 and units.count(None) == 1         # every (chunk, K-block) exactly once + one pad
+    s0, _, _ = mlp_pack.pack(sd, prec=0)
+    assert s0.nbytes == 1024 * sum(mlp_pack.step_pieces(s, 0) for s in range(mlp_pack.N_STEPS))
     assert wbias.size == (49 + 4) * 32
     assert nkbs[:9] == [2, 2, 2, 2, 2, 2, 3, 2, 2] and nkbs[9] == 5 and nkbs[29] == 13 and nkbs[46] == 12 and nkbs[48] == 4
 
@@ -152,11 +166,14 @@ def test_stream_reproduces_oracle_network(packed):
     emu = Emu(stream, wbias, nkbs, use_lo=True)
     rgb, sigma = emu.run(tok, r['tap_rgb'].numpy(), r['x_c'].numpy(), r['v_c'].numpy())
     ref_rgb, ref_sig = r['sample_rgb'].numpy(), r['sample_sigma'].numpy()
-    assert np.abs(sigma - ref_sig).max() / np.abs(ref_sig).max() < 2e-4
-    assert np.abs(rgb - ref_rgb).max() < 2e-4
-    # hi-only stream == plain bf16 weights: larger but bounded error
+    assert np.abs(sigma - ref_sig).max() / np.abs(ref_sig).max() < 2e-5          # hi + lo fp16 weights: 22 bits
+    assert np.abs(rgb - ref_rgb).max() < 2e-5
+    # hi-only streams == plain fp16 / bf16 weights: larger but bounded error
     rgb0, sigma0 = Emu(stream, wbias, nkbs, use_lo=False).run(tok, r['tap_rgb'].numpy(), r['x_c'].numpy(), r['v_c'].numpy())
-    assert np.abs(sigma0 - ref_sig).max() / np.abs(ref_sig).max() < 3e-2
+    assert 2e-5 < np.abs(sigma0 - ref_sig).max() / np.abs(ref_sig).max() < 5e-3
+    s0, wb0, _ = mlp_pack.pack(sd, prec=0)
+    rgb1, sigma1 = Emu(s0, wb0, nkbs, prec=0).run(tok, r['tap_rgb'].numpy(), r['x_c'].numpy(), r['v_c'].numpy())
+    assert np.abs(sigma1 - ref_sig).max() / np.abs(ref_sig).max() < 3e-2
 
 
 def test_fast_erf_formula_accuracy():

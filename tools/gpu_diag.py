@@ -18,7 +18,7 @@ def stage(name, fn):
         p(f'[{name}] EXCEPTION'); traceback.print_exc(); sys.stdout.flush()
 
 
-def main(cfg='tiny', prec='bf16x3'):
+def main(cfg='tiny', prec='f16x3'):
     p('device', torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).gcnArchName)
     t0 = time.time(); o = G.oracle_render(cfg); p(f'oracle {cfg} done in {time.time()-t0:.1f}s, nv={o["valid"].numel()}')
     h = G.hip_render(cfg, precision=prec)
@@ -57,7 +57,7 @@ def main(cfg='tiny', prec='bf16x3'):
     stage('tokens', s_tok)
 
     def s_mlp():
-        for pr in ('bf16x3', 'bf16'):
+        for pr in ('f16x3', 'bf16'):
             hh = h if pr == prec else G.hip_render(cfg, precision=pr)
             out = hh['last']['ws']['sample_out'][:n].cpu()
             sr = torch.relu(o['sample_sigma'][:n])
