@@ -98,7 +98,7 @@ def mlp_kernel_alone(w, precision, dev, iters=20, warmup=5):
     st = torch.cuda.current_stream(dev)
     stream = ct.c_void_p(st.cuda_stream)
     launch = lambda: _lib.call('sherf_nerf_mlp', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
-                               MLP_PRECISIONS[precision], 0, cap, A(out), stream)
+                               MLP_PRECISIONS[precision], A(ws['zfrag']), cap, A(out), stream)
     for _ in range(warmup):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

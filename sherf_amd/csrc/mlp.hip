@@ -230,12 +230,10 @@ __device__ __forceinline__ f32x16 bias_tile(const C& cx, int idx) {
 #define SHERF_MLP_FASTMATH 1
 #endif
 #if SHERF_MLP_FASTMATH
-__device__ __forceinline__ void sincos_(float x, float* s, float* c) { *s = __sinf(x); *c = __cosf(x); }
 __device__ __forceinline__ float exp_(float x) { return __expf(x); }
 __device__ __forceinline__ float rcp_(float x) { return __frcp_rn(x); }
 __device__ __forceinline__ float rsqrt_(float x) { return __frsqrt_rn(x); }
 #else
-__device__ __forceinline__ void sincos_(float x, float* s, float* c) { sincosf(x, s, c); }
 __device__ __forceinline__ float exp_(float x) { return expf(x); }
 __device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
 __device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
@@ -372,24 +370,41 @@ __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_
     split_tile<PREC>(y, k0, k1);
 }
 
+// sin / cos of an angle `a` [rad] with the range reduction done right: the phase in revolutions is a two-term product with
+// 1 / (2 pi) = kHi + kLo (the fma recovers the rounding error of a * kHi exactly), v_fract keeps its fraction, v_sin / v_cos take
+// revolutions.  Phase error < 1e-8 revolutions for |a| <= 2^8, against 6e-8 * |a| / (2 pi) of a plain a * (1 / 2 pi).
+__device__ __forceinline__ void sincos_exact_phase(float a, float* s, float* c) {
+#if SHERF_MLP_FASTMATH
+    const float kHi = 0.15915494f, kLo = 6.4206383e-09f;
+    const float p = a * kHi;
+    const float e = __builtin_fmaf(a, kHi, -p);
+    const float r = __builtin_amdgcn_fractf(p) + __builtin_fmaf(a, kLo, e);
+    *s = __builtin_amdgcn_sinf(r); *c = __builtin_amdgcn_cosf(r);
+#else
+    sincosf(a, s, c);
+#endif
+}
+
 // NeRF positional encoding in "natural" K-block order: feature f = 16*kb + 8*h + e of
-// [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]; entries >= 3 + 6*NF are zero.
+// [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]; entries >= 3 + 6*NF are zero.  Every octave is evaluated DIRECTLY from
+// 2^q x (exact in fp32), like the reference's sin(phase + x * f) (renderer.py:906): round 1 doubled the angle octave by octave
+// (s' = 2 s c, c' = 1 - 2 s^2), which doubles the error per octave as well -- 6e-6 on the top octave of PE6 from fp32 rounding alone,
+// 6e-5 with a 5e-7 error of the first sine -- and the decoder multiplies that by its gain (the tail of the per-sample sigma error).
 template <int PREC, int NF, int NKB>
 __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag<PREC> (&out)[NKB]) {
     float f[NKB * 16];
 #pragma unroll
     for (int i = 0; i < NKB * 16; ++i) f[i] = 0.f;
     f[0] = x; f[1] = y; f[2] = z;
-    float s[3], c[3];
-    sincos_(x, &s[0], &c[0]); sincos_(y, &s[1], &c[1]); sincos_(z, &s[2], &c[2]);
+    const float v3[3] = {x, y, z};
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (3 + 6 * q + a < NKB * 16) f[3 + 6 * q + a] = s[a];
-            if (6 + 6 * q + a < NKB * 16) f[6 + 6 * q + a] = c[a];
-            float s2 = 2.f * s[a] * c[a], c2 = 1.f - 2.f * s[a] * s[a];    // double the angle
-            s[a] = s2; c[a] = c2;
+            float s, c;
+            sincos_exact_phase(v3[a] * (float)(1 << q), &s, &c);
+            if (3 + 6 * q + a < NKB * 16) f[3 + 6 * q + a] = s;
+            if (6 + 6 * q + a < NKB * 16) f[6 + 6 * q + a] = c;
         }
     }
 #pragma unroll
@@ -415,43 +430,44 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// SHERF_MLP_TOKENS_WAVES: waves per SIMD nerf_tokens_kernel is compiled for (register cap 512 / this).  Its natural need is ~225
+// registers (two query and three key / value tokens of 32 features live at once; 194 after re-reading the residual tokens and walking keys / values token by token): 3 waves spill 21 registers.
+#ifndef SHERF_MLP_TOKENS_WAVES
+#define SHERF_MLP_TOKENS_WAVES 3
+#endif
+// ---- launch 1 of 2: the slot-fusion remainder + 3-token transformer.  VALU / latency bound (~2 K dependent VALU, LayerNorm and
+// softmax exchanges, 126 MFMAs per tile): measured inside the fused kernel it took 27 % of a wave's time while using 6 % of the
+// matrix pipe, and held the co-resident decoder wave to what one wave can issue.  As its own launch its 40 KiB of weights stay
+// resident in LDS (no ring, no per-step barrier) and every wave walks tiles on its own (persistent grid).  It leaves z_0 / z_1
+// as ready-made B-operand fragments: zfrag[tile][8][64 lanes] u32x4, fragment q = 4 * (0: z_0, 1: z_1) + 2 * kb + (0: hi, 1: lo)
+// (prec 0: only the hi slots are written / read).
 template <int PREC>
-__global__ void __launch_bounds__(NW * 64, 2)
-nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+__global__ void __launch_bounds__(NW * 64, SHERF_MLP_TOKENS_WAVES)
+nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                   const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, u32x4* __restrict__ zfrag) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
+    constexpr int WBYTES = (step_pieces<PREC>(0) + step_pieces<PREC>(1)) * 1024;
+    __shared__ __attribute__((aligned(16))) char lds[WBYTES + (N_CHUNKS + 4) * 32 * 4];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
-    CX cx;
-    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
-    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
-    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
-    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
-#if SHERF_MLP_TRACE
-    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
-    if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
-#endif
-    const int j = cx.lane & 31, h = cx.h;
-    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
-    const bool live = tile < n_tiles;
-    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
-
-    dma_issue(cx, 0);
-    dma_issue(cx, 1);
-    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;
+    float* lbias = reinterpret_cast<float*>(lds + WBYTES);
+    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];
+    for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
     __syncthreads();
-    dma_issue(cx, 2);
-
-    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
-    float xc[3], vc[3];
-    int step = 0;
-
-    // ================= transformer: step 0 = chunks 0..4, step 1 = chunks 5..8 =================
+    CX cx;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.wbias = lbias;
+    const int j = cx.lane & 31, h = cx.h;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
+    // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
+    // loop (hundreds of live registers, ~330 spills)
+    const char* wl = lds + cx.lane * 16;
+    asm volatile("" : "+v"(wl));
+    cx.wbias = lbias;
+    asm volatile("" : "+v"(cx.wbias));
+    BFrag<PREC> z0b[2], z1b[2];
+    // ================= transformer (chunks 0..8: the first two steps of the weight stream, resident in LDS) =================
     {
         // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
         f32x16 tok[3];
@@ -463,9 +479,8 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
             }
         const float* ex = extras + tile * 12 * 32 + j;
-        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
 
-        const char* s = cx.slot(step);
+        const char* s = wl;                                        // step 0: chunks 0..4
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
         {
             BFrag<PREC> b[1][2];
@@ -497,36 +512,34 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         float dot[2][3][3];                                     // [query token][head][key token]
         float o[2][3][8];                                       // attention output [query][head][8 of 16 dims]
         float v0[3][8];
-        {
-            f32x16 acc[3] = {bias_tile(cx, 3), bias_tile(cx, 3), bias_tile(cx, 3)};
-            mma_cols<PREC, 2, 3>(s, 6, ln, acc);                      // [k head0 | k head1]
+        // keys / values token by token (one 16-register accumulator instead of three: the kernel's register peak sits here)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 3; ++t) {
+            const BFrag<PREC> (&lt)[1][2] = reinterpret_cast<const BFrag<PREC> (&)[1][2]>(ln[t]);
+            f32x16 acc[1] = {bias_tile(cx, 3)};
+            mma_cols<PREC, 2, 1>(s, 6, lt, acc);                      // [k head0 | k head1]
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    float d0 = 0.f, d1 = 0.f;
+            for (int i = 0; i < 2; ++i) {
+                float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { d0 += qa[i][r] * acc[t][r]; d1 += qa[i][8 + r] * acc[t][8 + r]; }
-                    dot[i][0][t] = d0; dot[i][1][t] = d1;
-                }
+                for (int r = 0; r < 8; ++r) { d0 += qa[i][r] * acc[0][r]; d1 += qa[i][8 + r] * acc[0][8 + r]; }
+                dot[i][0][t] = d0; dot[i][1][t] = d1;
+            }
         }
-        {
-            f32x16 acc[3] = {bias_tile(cx, 4), bias_tile(cx, 4), bias_tile(cx, 4)};
-            mma_cols<PREC, 2, 3>(s, 8, ln, acc);                      // [k head2 | v head0]
-            advance(cx, step); ++step;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 3; ++t) {
+            const BFrag<PREC> (&lt)[1][2] = reinterpret_cast<const BFrag<PREC> (&)[1][2]>(ln[t]);
+            f32x16 acc[1] = {bias_tile(cx, 4)};
+            mma_cols<PREC, 2, 1>(s, 8, lt, acc);                      // [k head2 | v head0]
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    float d2 = 0.f;
+            for (int i = 0; i < 2; ++i) {
+                float d2 = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) d2 += qb[i][r] * acc[t][r];
-                    dot[i][2][t] = d2;
-                }
+                for (int r = 0; r < 8; ++r) d2 += qb[i][r] * acc[0][r];
+                dot[i][2][t] = d2;
+            }
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v0[t][r] = acc[t][8 + r];
+            for (int r = 0; r < 8; ++r) v0[t][r] = acc[0][8 + r];
         }
         // softmax over the 3 keys, scale 16^-0.5 (renderer.py:956,971-973)
 #pragma unroll
@@ -545,16 +558,22 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
-        s = cx.slot(step);
-        {
-            f32x16 acc[3] = {bias_tile(cx, 5), bias_tile(cx, 5), bias_tile(cx, 5)};
-            mma_cols<PREC, 2, 3>(s, 0, ln, acc);                      // [v head1 | v head2]
+        s = wl + step_pieces<PREC>(0) * 1024;                     // step 1: chunks 5..8
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { o[i][1][r] = 0.f; o[i][2][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const BFrag<PREC> (&lt)[1][2] = reinterpret_cast<const BFrag<PREC> (&)[1][2]>(ln[t]);
+            f32x16 acc[1] = {bias_tile(cx, 5)};
+            mma_cols<PREC, 2, 1>(s, 0, lt, acc);                      // [v head1 | v head2]
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    o[i][1][r] = dot[i][1][0] * acc[0][r] + dot[i][1][1] * acc[1][r] + dot[i][1][2] * acc[2][r];
-                    o[i][2][r] = dot[i][2][0] * acc[0][8 + r] + dot[i][2][1] * acc[1][8 + r] + dot[i][2][2] * acc[2][8 + r];
+                    o[i][1][r] += dot[i][1][t] * acc[0][r];
+                    o[i][2][r] += dot[i][2][t] * acc[0][8 + r];
                 }
         }
         f32x16 y[2];
@@ -568,7 +587,20 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                                                 o[i][hd][6], o[i][hd][7]);
             f32x16 acc[2] = {bias_tile(cx, 6), bias_tile(cx, 6)};
             mma_cols<PREC, 3, 2>(s, 2, ob, acc);                      // to_out + bias
-            y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];             // residual (renderer.py:925)
+            // residual (renderer.py:925).  tok[0], tok[1] are RE-READ (L2-hot, coalesced) instead of carried through the attention:
+            // 32 registers less at the kernel's pressure peak
+            const float4* tp = tokens;
+            asm volatile("" : "+v"(tp));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x16 tk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = tp[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+                    tk[4 * i] = v.x; tk[4 * i + 1] = v.y; tk[4 * i + 2] = v.z; tk[4 * i + 3] = v.w;
+                }
+                y[t] = acc[t] + tk;
+            }
         }
         // ---- FF: LN2 -> Linear -> GELU(erf) -> Linear, residual (chunks 7, 8) ----
         {
@@ -586,14 +618,70 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
             mma_cols<PREC, 2, 2>(s, 7, gb, acc2);
-            advance(cx, step); ++step;
             f32x16 za = acc2[0] + y[0], zb = acc2[1] + y[1];
             split_tile<PREC>(za, z0b[0], z0b[1]);
             split_tile<PREC>(zb, z1b[0], z1b[1]);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    u32x4* zp = zfrag + tile * 512 + cx.lane;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        zp[(2 * kb) * 64] = z0b[kb].hi;
+        zp[(4 + 2 * kb) * 64] = z1b[kb].hi;
+        if constexpr (PREC == 1) { zp[(2 * kb + 1) * 64] = z0b[kb].lo; zp[(4 + 2 * kb + 1) * 64] = z1b[kb].lo; }
+    }
+    }   // tiles
+}
 
+// ---- launch 2 of 2: the NeRF decoder, steps 2..42 of the weight stream through the 3-slot ring.  MFMA bound; two workgroups per
+// CU, so the two waves of a SIMD (one of each) are both in this phase all the time. ----
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, 2)
+nerf_decoder_kernel(const int32_t* __restrict__ counters, const u32x4* __restrict__ zfrag, const float* __restrict__ extras,
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    using CX = Ctx<PREC>;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
+    CX cx;
+    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
+    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
+    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
+#if SHERF_MLP_TRACE
+    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
+    if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
+#endif
+    const int j = cx.lane & 31, h = cx.h;
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
+
+    constexpr int STEP0 = 2;                                         // (steps 0, 1 belong to nerf_tokens_kernel)
+    dma_issue(cx, STEP0);
+    dma_issue(cx, STEP0 + 1);
+    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(STEP0 + 1) / NW);   // the first step (this wave's pieces) landed
+    __syncthreads();
+    dma_issue(cx, STEP0 + 2);
+
+    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks (nerf_tokens_kernel)
+    float xc[3], vc[3];
+    int step = STEP0;
+    {
+        const float* ex = extras + tile * 12 * 32 + j;
+        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
+        const u32x4* zp = zfrag + tile * 512 + cx.lane;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            z0b[kb].hi = zp[(2 * kb) * 64];
+            z1b[kb].hi = zp[(4 + 2 * kb) * 64];
+            if constexpr (PREC == 1) { z0b[kb].lo = zp[(2 * kb + 1) * 64]; z1b[kb].lo = zp[(4 + 2 * kb + 1) * 64]; }
+        }
+    }
     // ================= NeRF decoder =================
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
     BFrag<PREC> ha[8], hb[8];
@@ -721,16 +809,31 @@ extern "C" int sherf_mlp_stream_layout(int prec, int32_t* n_steps, int32_t* step
 }
 
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                              const float* wbias, int prec, int shape, int64_t capacity, float* out, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 1) && shape == 0 && capacity > 0);
+                              const float* wbias, int prec, void* zfrag, int64_t capacity, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && zfrag && out);
+    SHERF_CHECK_ARG((prec == 0 || prec == 1) && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
-    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
-    if (prec == 1)
-        hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
-    else
-        hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    const int64_t groups = (tiles + NW - 1) / NW;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        SHERF_HIP_CHECK(hipGetDevice(&dev));
+        SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+    }
+    const int64_t resident = (int64_t)SHERF_MLP_TOKENS_WAVES * n_cu;          // workgroups of 4 waves per CU = waves per SIMD
+    const dim3 grid_t((unsigned)(groups < resident ? groups : resident)), grid_d((unsigned)groups), block(NW * 64);
+    const float4* tok4 = reinterpret_cast<const float4*>(tokens);
+    const char* wsb = reinterpret_cast<const char*>(wstream);
+    u32x4* zf = reinterpret_cast<u32x4*>(zfrag);
+    if (prec == 1) {
+        hipLaunchKernelGGL((nerf_tokens_kernel<1>), grid_t, block, 0, as_stream(stream), counters, tok4, extras, wsb, wbias, capacity, zf);
+        hipLaunchKernelGGL((nerf_decoder_kernel<1>), grid_d, block, 0, as_stream(stream), counters, zf, extras, wsb, wbias, capacity,
+                           reinterpret_cast<float4*>(out));
+    } else {
+        hipLaunchKernelGGL((nerf_tokens_kernel<0>), grid_t, block, 0, as_stream(stream), counters, tok4, extras, wsb, wbias, capacity, zf);
+        hipLaunchKernelGGL((nerf_decoder_kernel<0>), grid_d, block, 0, as_stream(stream), counters, zf, extras, wsb, wbias, capacity,
+                           reinterpret_cast<float4*>(out));
+    }
     SHERF_LAUNCH_CHECK();
 }

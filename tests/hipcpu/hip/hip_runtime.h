@@ -202,6 +202,10 @@ template <class T> inline T __builtin_amdgcn_readfirstlane(T v) { return v; }   
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+// v_fract_f32 / v_sin_f32 / v_cos_f32 (the latter two take REVOLUTIONS)
+inline float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }
+inline float __builtin_amdgcn_sinf(float r) { return (float)sin(6.283185307179586476925 * (double)r); }
+inline float __builtin_amdgcn_cosf(float r) { return (float)cos(6.283185307179586476925 * (double)r); }
 inline float __expf(float x) { return expf(x); }
 inline float __sinf(float x) { return sinf(x); }
 inline float __cosf(float x) { return cosf(x); }

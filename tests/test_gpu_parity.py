@@ -154,10 +154,20 @@ def test_margin_protocol_whole_frame(cfg):
 
 
 def test_eval_mode_batchnorm_uses_running_stats():
+    """Eval mode normalises with the RUNNING statistics.  Every train-mode render before this test has advanced them (as
+    nn.BatchNorm1d does, also under no_grad: voxel.SparseConvNet.finish), so the seeded buffers the oracle uses are restored first --
+    and the test checks on the way that a train-mode render does move them."""
+    rend = G.hip_modules('f16x3')[0]
+    fixtures.load_seeded_state(rend, 'renderer.')
+    bn = rend.encoder_3d.conv0[1]
+    before, n0 = bn.running_mean.clone(), int(bn.num_batches_tracked)
+    G.hip_render('tiny', training=True)
+    assert int(bn.num_batches_tracked) == n0 + 1 and not torch.equal(bn.running_mean, before)
+    fixtures.load_seeded_state(rend, 'renderer.')
     o = G.oracle_render('tiny', training=False)
     h = G.hip_render('tiny', training=False)
     assert G.rel(h['rgb'], o['rgb']) < 1e-3
-    G.hip_modules()[0].train()
+    rend.train()
 
 
 def test_deterministic_and_ray_independent():

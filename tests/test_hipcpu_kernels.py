@@ -444,7 +444,8 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
     extras = ext.view(tiles, 32, 12).permute(0, 2, 1).reshape(-1).contiguous()
     counters = torch.tensor([n, 0, 0, 0], dtype=torch.int32)
     out = torch.zeros(tiles * 32, 4)
-    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, 0, n, _P(out), None) == 0
+    zfrag = torch.zeros(tiles * 2048)
+    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, _P(zfrag), n, _P(out), None) == 0
     sig_h, sig_ref = torch.relu(out[:n, 3]), torch.relu(r['sample_sigma'])
     e_sig = float((sig_h - sig_ref).abs().max() / sig_ref.max())
     e_rgb = float((out[:n, :3] - r['sample_rgb']).abs().max())
@@ -454,4 +455,4 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
     assert e_sig < tol_sig and e_rgb < tol_rgb, (e_sig, e_rgb)
     if prec == 1:
         assert r_sig < 1e-3 and r_rgb < 1e-3, (r_sig, r_rgb)
-    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, 1, n, _P(out), None) != 0   # shapes are gone
+    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, None, n, _P(out), None) != 0   # the scratch is mandatory

@@ -66,7 +66,7 @@ def test_training_frame_descriptor_is_complete(stubbed):
             assert getattr(fr, name), f'frame.{name} is NULL'
     assert (fr.R, fr.S, fr.capacity) == (1024, 16, 1024 * 16) and fr.vox_n == 6890 and fr.vox_training == 1
     assert (fr.P, fr.Hf, fr.Wf, fr.H, fr.W) == (32, 16, 16, 32, 32) and list(fr.vox_sh) == [int(v) for v in rend.last['bwd']['vox_sh']]
-    assert fr.mlp_prec == 1 and fr.mlp_shape == 0 and fr.main_after_layer == -1
+    assert fr.mlp_prec == 1 and fr.zfrag and fr.main_after_layer == -1
     assert {'plan', 'levels_struct', 'bwd', 'ws'} <= set(rend.last)
 
 
