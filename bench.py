@@ -98,7 +98,7 @@ def mlp_kernel_alone(w, precision, dev, iters=20, warmup=5):
     st = torch.cuda.current_stream(dev)
     stream = ct.c_void_p(st.cuda_stream)
     launch = lambda: _lib.call('sherf_nerf_mlp', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
-                               MLP_PRECISIONS[precision], A(ws['zfrag']), cap, A(out), stream)
+                               MLP_PRECISIONS[precision], cap, A(out), stream)
     for _ in range(warmup):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -135,10 +135,20 @@ def secondary_measurements(a, w, dev, nv, R):
             b = argparse.Namespace(**vars(a)); b.config = cfg
             w2 = make_workload(b, 0.4, dev)
             w2['rend'].exact_grids = w['rend'].exact_grids
-            ms = time_frames(w2, 10, 3, dev)
+            import ctypes as _ct
+            from sherf_amd import _lib as _abi
+            time_frames(w2, 1, 3, dev)
+            _abi.call('sherf_profile_frames', 1)
+            ms = time_frames(w2, 10, 0, dev)
+            buf = (_ct.c_float * (64 * 8))(); n_ms = _ct.c_int32(0)
+            _abi.call('sherf_profile_frames_read', buf, 64, _ct.byref(n_ms))
+            _abi.call('sherf_profile_frames', 0)
+            prof = np.array(buf[:n_ms.value * 8], dtype=np.float64).reshape(-1, 8)
             nv2 = int(w2['rend'].last['ws']['counters'][0])
             S = w2['opts']['depth_resolution']
-            out[cfg] = dict(ms_per_frame=ms, rays_per_s=R / (ms * 1e-3), valid_samples=nv2, valid_fraction=nv2 / (R * S))
+            names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done', 'mlp_kernel')
+            out[cfg] = dict(ms_per_frame=ms, rays_per_s=R / (ms * 1e-3), valid_samples=nv2, valid_fraction=nv2 / (R * S),
+                            frame_timeline_ms={k: round(float(v), 4) for k, v in zip(names, prof.mean(0))} if len(prof) else None)
             del w2
         except Exception as ex:
             out[cfg] = dict(error=f'{type(ex).__name__}: {str(ex)[:200]}')
@@ -222,6 +232,9 @@ def main():
         dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
     from sherf_amd import dist as sdist  # noqa: F401
 
+    if os.environ.get('SHERF_DEBUG'):
+        from sherf_amd import _lib as _dbg
+        _dbg.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (sampler: 1 = no candidates, 2 = every sample)
     w = make_workload(a, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend, opts = w['rend'], w['opts']
     rend.exact_grids = bool(a.exact_grids) or rend.exact_grids
@@ -414,7 +427,8 @@ def torch_gpu_baseline(cfg_name, dev, training, iters=3, save=None):
             g = lambda k: r[k].detach().cpu().numpy()
             np.savez(save, rgb=g('rgb'), acc=g('acc'), mask=g('mask'), valid=g('valid'), d2_all=g('d2_all'), vert_id=g('vert_id'),
                      t_vert_id=g('t_vert_id'), vert_gap=g('vert_gap'), t_vert_gap=g('t_vert_gap'), sample_rgb=g('sample_rgb'),
-                     sample_sigma=g('sample_sigma'))
+                     sample_sigma=g('sample_sigma'), cond_sigma=g('cond_sigma'), cond_rgb=g('cond_rgb'), cond_flip=g('cond_flip'),
+                     cond_eps=g('cond_eps'))
         return dict(value=R / dt, unit='rays/s', kind='port', seconds_per_frame=dt,
                     sample=f'whole {c["H"]}x{c["W"]}x{c["S"]} frame ({int(r["mask"].sum())} valid samples), oracle/sherf_oracle.py as stock '
                            f'PyTorch-ROCm fp32 ops on the GPU, best of {iters} after 1 warm-up')

@@ -157,18 +157,13 @@ int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int 
 int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t stream);
 
 /* a13+a14: rgb positional encoding -> slot-2 token, 3-token transformer (renderer.py:949-993), pos/view encodings (:875-916) and
- * NeRFDecoder (triplane.py:285-316) on MFMA (csrc/mlp.hip), as two launches on `stream`:
- *   nerf_tokens_kernel  -- the VALU / latency-bound transformer at three workgroups per CU with its weights resident in LDS; leaves
- *                          the fused tokens z_0, z_1 as ready-made MFMA operand fragments in `zfrag`;
- *   nerf_decoder_kernel -- the MFMA-bound decoder: 4-wave workgroups, two per CU, a 3-slot LDS ring of <= 20 KiB weight steps, two
- *                          independent accumulator chains per step.
- * Weights arrive as the pre-packed fragment stream built by sherf_amd/mlp_pack.py FOR THE SAME `prec`.  prec: 1 = f16x3 (operands
- * split hi + lo in fp16, three MFMAs per product, fp32 accumulate: fp32-grade, the default), 0 = bf16 (one product; north_star's
- * nominal precision, misses the 1e-3 tolerance).
- * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens); zfrag: caller-owned
- * scratch of 8 KiB per tile of `capacity` (overwritten); out[c] = (r,g,b,sigma). */
+ * NeRFDecoder (triplane.py:285-316) as ONE MFMA kernel (csrc/mlp.hip: 4-wave workgroups, two per CU, a 3-slot LDS ring of <= 20 KiB
+ * weight steps, two independent accumulator chains per step); weights arrive as the pre-packed fragment stream built by
+ * sherf_amd/mlp_pack.py FOR THE SAME `prec`.  prec: 1 = f16x3 (operands split hi + lo in fp16, three MFMAs per product, fp32
+ * accumulate: fp32-grade, the default), 0 = bf16 (one product; north_star's nominal precision, misses the 1e-3 tolerance).
+ * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                   const float* wbias, int prec, void* zfrag, int64_t capacity, float* out, sherf_stream_t stream);
+                   const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
 /* layout of the weight stream the kernel expects for `prec`: *n_steps steps; step_pieces_host[s] = its size in 1 KiB pieces (hi [, lo]
  * fragments, zero-padded to a multiple of 4); units[s * 10 + u] = chunk * 16 + K-block of the u-th (chunk, K-block) unit the kernel
  * consumes in step s (-1 = none / padding).  sherf_amd/mlp_pack.py restates it; tests/test_boundary.py compares the two. */
@@ -317,7 +312,7 @@ typedef struct {
     /* voxel encoder (a11) */
     const sherf_svox_plan* vox_plan; const int32_t* vox_coord; const float* vox_feat; int32_t vox_n, vox_training;
     /* MLP + compositing (a13-a16) */
-    const void* wstream; const float* wbias; int32_t mlp_prec, mlp_pad_; void* zfrag; float* sample_out;
+    const void* wstream; const float* wbias; int32_t mlp_prec, mlp_pad_; float* sample_out;
     int32_t white_back;
     int32_t main_after_layer;   /* scheduling: -1 = both streams start at once; k >= 0 = the ray side starts once encoder
                                  * layer k is done (the encoder's small launches are slowed 3-5x by a co-running sampler) */

@@ -526,6 +526,35 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
                        t_vert_gap=second_nearest_gap(x_c, input_data['t_vertices'].view(-1, 3), tvid))
             if not keep:
                 out.update(vert_id=vid, t_vert_id=tvid, sample_rgb=rgb_s, sample_sigma=sig_s)
+        if options.get('margins') and options.get('condition_probe', 4e-7) > 0:
+            # CONDITIONING of the reference's own function at fp32 input rounding.  Everything downstream of the canonical position x_c
+            # -- the nearest T-vertex, the projection into the observation view, 24 + 12 + 4 interpolation taps into tables that are
+            # white noise in the synthetic workload, positional encodings up to 2^5 x, a decoder whose density head has gain 20 -- is
+            # re-evaluated with x_c moved by eps along each axis in turn (eps = 4e-7: the size of the legitimate fp32 differences
+            # between two evaluation orders of the warp chain, cf. test_warp_matches_literal_lbs_chain).  The SUM over the three axes
+            # of the change of the reference's OWN sigma / rgb bounds (to first order) what any displacement of at most eps per
+            # coordinate does to them: what no fp32 re-implementation can be expected to undercut.
+            eps = float(options.get('condition_probe', 4e-7))
+            tv = input_data['t_vertices'].view(-1, 3)
+            c_sig = torch.zeros(nv); c_rgb = torch.zeros(nv); c_flip = torch.zeros(nv, dtype=torch.bool)
+            floor_s, floor_c = float(options.get('floor_sigma', 1.0)), float(options.get('floor_rgb', 0.1))
+            for axis in range(3):
+                xp = x_c.clone()
+                xp[:, axis] += eps
+                xw_p, tv_p = canonical_to_obs_world(st, OP, TP, tv, xp)
+                uv_p = project_uv(xw_p, input_data['obs_R_all'].view(3, 3), input_data['obs_T_all'].view(3, 1), input_data['obs_K_all'].view(3, 3))
+                f2d_p, _ = pixel_aligned_features(uv_p, obs_feat, obs_img)
+                g_p = voxel_grid_coords(xp, sp_input['bounds'], sp_input['out_sh'])
+                f3d_p = torch.cat([trilinear_sparse(k, f, s_, g_p) for (k, f, s_) in taps], -1) @ Wp.t() + state['renderer.conv1d_projection.bias']
+                for s0 in range(0, nv, CHUNK):
+                    sl = slice(s0, s0 + CHUNK)
+                    z = transformer(state, fuse_tokens(state, triplane_features(planes, xp[sl], bounds), f2d_p[sl], f3d_p[sl]))
+                    rgb_p, sig_p = nerf_decoder(state, positional_encoding(xp[sl], 6), z, positional_encoding(v_c[sl], 4))
+                    ds = (torch.relu(sig_p.view(-1)) - torch.relu(sig_s[sl].view(-1))).abs() / torch.relu(sig_s[sl].view(-1)).clamp(min=floor_s)
+                    dc = ((rgb_p - rgb_s[sl]).abs() / rgb_s[sl].abs().clamp(min=floor_c)).max(1)[0]
+                    c_sig[sl] += ds; c_rgb[sl] += dc
+                c_flip |= tv_p != tvid
+            out.update(cond_sigma=c_sig, cond_rgb=c_rgb, cond_flip=c_flip, cond_eps=torch.tensor(eps))
         if keep:
             out.update(vert_id=vid, vert_d2=d2[valid], x_s=xs, v_s=vs, x_c=x_c, v_c=v_c, x_w=x_w, t_vert_id=tvid, uv=uv,
                        f2d=f2d, tap_rgb=tap_rgb, grid=g, f3d_raw=f3d_raw, f3d=f3d, tokens_in=torch.cat(toks_in),

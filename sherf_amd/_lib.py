@@ -64,7 +64,7 @@ def _frame_fields():
     f.append(('vox_sh', _i32 * 3)); I('gather_split')
     P('tokens', 'extras', 'vox_plan', 'vox_coord', 'vox_feat'); I('vox_n', 'vox_training')
     P('wstream', 'wbias'); I('mlp_prec', 'mlp_pad_')
-    P('zfrag', 'sample_out'); I('white_back', 'main_after_layer')
+    P('sample_out'); I('white_back', 'main_after_layer')
     P('rgb', 'depth', 'acc')
     return f
 

@@ -51,13 +51,12 @@ def build(force=False, verbose=True):
 
 
 LIB_BWD = os.path.join(HERE, 'libsherf_hip_bwd.so')
-SOURCES_BWD = ['bwd_dense.hip', 'bwd_encoder.hip']
+SOURCES_BWD = ['bwd_dense.hip', 'bwd_gemm.hip', 'bwd_encoder.hip']
 
 
 def build_bwd(force=False, verbose=True):
-    """libsherf_hip_bwd.so: the (experimental) backward building blocks, include/sherf_hip_bwd.h.  Separate from the forward
-    library because it links rocBLAS (plain GEMMs of the dense layers); at run time the loader reuses the librocblas that
-    `import torch` already mapped."""
+    """libsherf_hip_bwd.so: the backward building blocks, include/sherf_hip_bwd.h (hand-written kernels only: the dense layers'
+    GEMMs are the MFMA kernels of csrc/bwd_gemm.hip; no vendor library is linked)."""
     deps = [os.path.join(CSRC, s) for s in SOURCES_BWD] + [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'sherf_hip_bwd.h')]
     if not force and os.path.exists(LIB_BWD) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_BWD) for d in deps):
         return LIB_BWD
@@ -70,7 +69,7 @@ def build_bwd(force=False, verbose=True):
         r = subprocess.run([hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {s}:\n{r.stdout.decode()}')
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-L/opt/rocm/lib', '-lrocblas', '-o', LIB_BWD],
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB_BWD],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout.decode())

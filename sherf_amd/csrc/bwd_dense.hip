@@ -1,10 +1,7 @@
-// Dense building blocks of the backward path (gfx950) -- see include/sherf_hip_bwd.h.  EXPERIMENTAL: compiles, mirrors
-// oracle/backward_explicit.py (CPU-verified), has not run on hardware yet.  fp32 VALU kernels + rocBLAS for the plain GEMMs.
+// Dense building blocks of the backward path (gfx950) -- see include/sherf_hip_bwd.h; mirrors oracle/backward_explicit.py.  fp32
+// element-wise / reduction kernels; the GEMMs are the MFMA kernels of csrc/bwd_gemm.hip.  First run on an MI355X in round 2
+// (tests/test_gpu_backward.py, green).
 #include "common.h"
-
-#include <mutex>
-
-#include <rocblas/rocblas.h>
 
 #include "../../include/sherf_hip_bwd.h"
 
@@ -13,8 +10,6 @@ int g_sherf_debug = 0;
 
 namespace {
 
-std::mutex g_mu;
-rocblas_handle g_handle[16] = {};
 
 #define SHERF_GRID(count) dim3((unsigned)((count + 255) / 256)), dim3(256)
 
@@ -303,34 +298,6 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ raw, const float*
 }
 
 }  // namespace
-
-extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                              float* C, int ldc, float beta, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
-    int dev = 0;
-    SHERF_HIP_CHECK(hipGetDevice(&dev));
-    SHERF_CHECK_ARG(dev >= 0 && dev < 16);
-    rocblas_handle h;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_handle[dev] && rocblas_create_handle(&g_handle[dev]) != rocblas_status_success) {
-            snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_bwd_gemm: rocblas_create_handle failed");
-            return SHERF_ELAUNCH;
-        }
-        h = g_handle[dev];
-    }
-    const float alpha = 1.f;
-    // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T: swap the operands and M <-> N
-    rocblas_status st = rocblas_set_stream(h, as_stream(stream));
-    if (st == rocblas_status_success)
-        st = rocblas_sgemm(h, transB ? rocblas_operation_transpose : rocblas_operation_none,
-                           transA ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
-    if (st != rocblas_status_success) {
-        snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_bwd_gemm: rocblas status %d", (int)st);
-        return SHERF_ELAUNCH;
-    }
-    return SHERF_OK;
-}
 
 extern "C" int sherf_bwd_untile(const float* tokens_tiled, const float* extras_tiled, int64_t n, float* tok, float* ext,
                                 sherf_stream_t stream) {

@@ -1,0 +1,237 @@
+// Dense GEMMs of the backward pass (BASELINE config 5) on MFMA: sherf_bwd_gemm, row-major
+//     C[M,N] = op(A)[M,K] . op(B)[K,N] + beta C.
+// Every call of the backward has one HUGE dimension (the valid samples, ~7e5) and two small ones (layer widths <= 199), in one
+// of three patterns (sherf_amd/backward_dense.py):
+//     forward recompute   y  = x  . W^T   (transA 0, transB 1)   M = samples
+//     data gradient       dx = dy . W     (transA 0, transB 0)   M = samples
+//     weight gradient     dW = dy^T . x   (transA 1, transB 0)   K = samples
+// Round 1 sent them to rocBLAS sgemm; these are hand-written gfx950 kernels on v_mfma_f32_32x32x16_f16 with the operands split
+// hi + lo in fp16 ("f16x3": three products, fp32 accumulate, ~2^-21 relative -- the forward's scheme, csrc/mlp.hip):
+//   tall_gemm  (transA 0): the small matrix is converted ONCE per workgroup into B-operand fragments in LDS (<= 104 KiB); persistent
+//              4-wave workgroups walk 32-row tiles of the tall operand, each wave its own tile, NT independent accumulator chains.
+//   wgrad_gemm (transA 1, transB 0): workgroups walk 16-sample steps of a slab of rows; both operand fragments are read straight
+//              from global memory (a lane's 8 K-values are 8 consecutive ROWS: 32 lanes read 32 consecutive floats of one row, coalesced);
+//              the waves split the output row tiles; partial sums are added to C with fp32 atomics (the reference does not require
+//              a deterministic reduction order, SURVEY section 7 hard part 6).
+// Any other shape / transposition goes to a plain fp32 kernel (correctness only: nothing on the path uses it).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+}
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1); split2(v[4], v[5], h2, l2); split2(v[6], v[7], h3, l3);
+    hi = u32x4{h0, h1, h2, h3}; lo = u32x4{l0, l1, l2, l3};
+}
+__device__ __forceinline__ f32x16 mfma3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+}
+// accumulator register r of lane (j = lane & 31, h = lane >> 5) <-> tile row (r & 3) + 8 (r >> 2) + 4 h, tile column j
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tall: C[M,N] = A[M,K] . S + beta C,   S[k][n] = transB ? B[n * ldb + k] : B[k * ldb + n]
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
+                                                        float* __restrict__ C, int ldc, int M, int N, int K, float beta) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, lo][64 lanes]
+    const int nkb = (K + 15) / 16;
+    for (int idx = threadIdx.x; idx < nkb * NT * 64; idx += 256) {
+        const int l = idx & 63, nt = (idx >> 6) % NT, kb = idx / (64 * NT);
+        const int n = 32 * nt + (l & 31), k0 = 16 * kb + 8 * (l >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            v[e] = (k < K && n < N) ? (transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
+        }
+        u32x4 hi, lo;
+        split8(v, hi, lo);
+        s_frag[((kb * NT + nt) * 2) * 64 + l] = hi;
+        s_frag[((kb * NT + nt) * 2 + 1) * 64 + l] = lo;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const bool vec = (lda % 4 == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
+    const int n_tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 32 + i;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = tile * 32 + acc_row(r, h), cc = 32 * nt + i;
+                acc[nt][r] = (beta != 0.f && rr < M && cc < N) ? beta * C[(size_t)rr * ldc + cc] : 0.f;
+            }
+        const float* arow = A + (size_t)(row < M ? row : M - 1) * lda;
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int k0 = 16 * kb + 8 * h;
+            float v[8];
+            if (vec && k0 + 8 <= K) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + k0), b = *reinterpret_cast<const float4*>(arow + k0 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = k0 + e < K ? arow[k0 + e] : 0.f;
+            }
+            if (row >= M) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            u32x4 ah, al;
+            split8(v, ah, al);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = mfma3(ah, al, s_frag[((kb * NT + nt) * 2) * 64 + lane], s_frag[((kb * NT + nt) * 2 + 1) * 64 + lane], acc[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = tile * 32 + acc_row(r, h), cc = 32 * nt + i;
+                if (rr < M && cc < N) C[(size_t)rr * ldc + cc] = acc[nt][r];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad: C[M,N] += A[Kbig,M]^T . B[Kbig,N]   (C pre-scaled by beta by the caller-side kernel below); M <= 256, N <= 32 NT
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSlab = 512;          // rows of the huge dimension per workgroup visit
+
+template <int NT, int MTW>          // MTW = row tiles of C per wave (the 4 waves take tiles w, w + 4)
+__global__ void __launch_bounds__(256) wgrad_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int N, int Kbig) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int MT = (M + 31) / 32;
+    f32x16 acc[MTW][NT];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][nt][r] = 0.f;
+    for (int slab = blockIdx.x; slab * kSlab < Kbig; slab += gridDim.x) {
+        const int r_end = min(Kbig, (slab + 1) * kSlab);
+        for (int r0 = slab * kSlab; r0 < r_end; r0 += 16) {
+            u32x4 bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = 32 * nt + i;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = r0 + 8 * h + e;
+                    v[e] = (r < r_end && n < N) ? B[(size_t)r * ldb + n] : 0.f;
+                }
+                split8(v, bh[nt], bl[nt]);
+            }
+#pragma unroll
+            for (int a = 0; a < MTW; ++a) {
+                const int mt = wave + 4 * a;
+                if (mt < MT) {                                  // wave-uniform
+                    const int m = 32 * mt + i;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = r0 + 8 * h + e;
+                        v[e] = (r < r_end && m < M) ? A[(size_t)r * lda + m] : 0.f;
+                    }
+                    u32x4 ah, al;
+                    split8(v, ah, al);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[a][nt] = mfma3(ah, al, bh[nt], bl[nt], acc[a][nt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MTW; ++a) {
+        const int mt = wave + 4 * a;
+        if (mt >= MT) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = 32 * mt + acc_row(r, h), cc = 32 * nt + i;
+                if (mm < M && cc < N && acc[a][nt][r] != 0.f) unsafeAtomicAdd(C + (size_t)mm * ldc + cc, acc[a][nt][r]);
+            }
+    }
+}
+
+__global__ void scale_kernel(float* __restrict__ C, int ldc, int M, int N, float beta) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * N) return;
+    float* p = C + (size_t)(idx / N) * ldc + idx % N;
+    *p = beta == 0.f ? 0.f : *p * beta;
+}
+
+// any shape: one thread per output element (fp32 FMAs)
+__global__ void plain_gemm_kernel(int transA, int transB, int M, int N, int K, const float* __restrict__ A, int lda,
+                                  const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, float beta) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * N) return;
+    const int m = (int)(idx / N), n = (int)(idx % N);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k)
+        s = fmaf(transA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k], transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n], s);
+    float* p = C + (size_t)m * ldc + n;
+    *p = beta == 0.f ? s : s + beta * *p;
+}
+
+int n_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                              float* C, int ldc, float beta, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
+    hipStream_t st = as_stream(stream);
+    const int NT = (N + 31) / 32, nkb = (K + 15) / 16;
+    if (!transA && NT <= 8 && (size_t)nkb * NT * 2048 <= 128 * 1024) {
+        const size_t smem = (size_t)nkb * NT * 2048;
+        const int tiles = (M + 31) / 32, grid = min((tiles + 3) / 4, n_cus());
+#define SHERF_TALL(n) case n: hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, B, ldb, transB, C, ldc, M, N, K, beta); break
+        switch (NT) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
+#undef SHERF_TALL
+        SHERF_LAUNCH_CHECK();
+    }
+    const int MT = (M + 31) / 32;
+    if (transA && !transB && NT <= 8 && MT <= 8 && ((MT + 3) / 4) * NT <= 8) {
+        if (beta != 1.f) hipLaunchKernelGGL(scale_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, C, ldc, M, N, beta);
+        const int slabs = (K + kSlab - 1) / kSlab, grid = min(slabs, 2 * n_cus());
+#define SHERF_WG(n, w) hipLaunchKernelGGL((wgrad_gemm_kernel<n, w>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K)
+#define SHERF_WGN(n) case n: if (MT <= 4) SHERF_WG(n, 1); else SHERF_WG(n, 2); break
+        switch (NT) {
+            SHERF_WGN(1); SHERF_WGN(2); SHERF_WGN(3); SHERF_WGN(4);
+            case 5: SHERF_WG(5, 1); break; case 6: SHERF_WG(6, 1); break; case 7: SHERF_WG(7, 1); break; case 8: SHERF_WG(8, 1); break;
+        }
+#undef SHERF_WGN
+#undef SHERF_WG
+        SHERF_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(plain_gemm_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta);
+    SHERF_LAUNCH_CHECK();
+}

@@ -207,7 +207,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                           f->extras, stream_main));
         }
         SHERF_PROF(4, main);
-        SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, f->zfrag, cap,
+        SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,
                                  f->sample_out, stream_main));
         SHERF_PROF(5, main);
     }

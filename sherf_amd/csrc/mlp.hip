@@ -430,44 +430,47 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// SHERF_MLP_TOKENS_WAVES: waves per SIMD nerf_tokens_kernel is compiled for (register cap 512 / this).  Its natural need is ~225
-// registers (two query and three key / value tokens of 32 features live at once; 194 after re-reading the residual tokens and walking keys / values token by token): 3 waves spill 21 registers.
-#ifndef SHERF_MLP_TOKENS_WAVES
-#define SHERF_MLP_TOKENS_WAVES 3
-#endif
-// ---- launch 1 of 2: the slot-fusion remainder + 3-token transformer.  VALU / latency bound (~2 K dependent VALU, LayerNorm and
-// softmax exchanges, 126 MFMAs per tile): measured inside the fused kernel it took 27 % of a wave's time while using 6 % of the
-// matrix pipe, and held the co-resident decoder wave to what one wave can issue.  As its own launch its 40 KiB of weights stay
-// resident in LDS (no ring, no per-step barrier) and every wave walks tiles on its own (persistent grid).  It leaves z_0 / z_1
-// as ready-made B-operand fragments: zfrag[tile][8][64 lanes] u32x4, fragment q = 4 * (0: z_0, 1: z_1) + 2 * kb + (0: hi, 1: lo)
-// (prec 0: only the hi slots are written / read).
+// One launch: transformer (steps 0-1) + decoder (steps 2-42).  Round 2 also measured the two as SEPARATE launches (the transformer
+// at 3 waves / SIMD with its weights resident in LDS, the decoder alone at two workgroups per CU): 0.23 + 0.62 ms against 0.69 ms
+// fused (profiles/r02_kernel_trace_v2_split.txt) -- the decoder alone is not faster than with the transformer of the co-resident
+// workgroup running under it, so the fused form stays.
 template <int PREC>
-__global__ void __launch_bounds__(NW * 64, SHERF_MLP_TOKENS_WAVES)
-nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                   const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, u32x4* __restrict__ zfrag) {
+__global__ void __launch_bounds__(NW * 64, 2)
+nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
-    constexpr int WBYTES = (step_pieces<PREC>(0) + step_pieces<PREC>(1)) * 1024;
-    __shared__ __attribute__((aligned(16))) char lds[WBYTES + (N_CHUNKS + 4) * 32 * 4];
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW >= n_tiles) return;
-    float* lbias = reinterpret_cast<float*>(lds + WBYTES);
-    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];
-    for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
-    __syncthreads();
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
     CX cx;
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.wbias = lbias;
+    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
+    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
+    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
+#if SHERF_MLP_TRACE
+    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
+    if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
+#endif
     const int j = cx.lane & 31, h = cx.h;
-    for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
-    // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
-    // loop (hundreds of live registers, ~330 spills)
-    const char* wl = lds + cx.lane * 16;
-    asm volatile("" : "+v"(wl));
-    cx.wbias = lbias;
-    asm volatile("" : "+v"(cx.wbias));
-    BFrag<PREC> z0b[2], z1b[2];
-    // ================= transformer (chunks 0..8: the first two steps of the weight stream, resident in LDS) =================
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
+
+    dma_issue(cx, 0);
+    dma_issue(cx, 1);
+    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
+    __syncthreads();
+    dma_issue(cx, 2);
+
+    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
+    float xc[3], vc[3];
+    int step = 0;
+
+    // ================= transformer: step 0 = chunks 0..4, step 1 = chunks 5..8 =================
     {
         // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
         f32x16 tok[3];
@@ -479,8 +482,9 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
                 tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
             }
         const float* ex = extras + tile * 12 * 32 + j;
+        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
 
-        const char* s = wl;                                        // step 0: chunks 0..4
+        const char* s = cx.slot(step);
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
         {
             BFrag<PREC> b[1][2];
@@ -541,6 +545,7 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
 #pragma unroll
             for (int r = 0; r < 8; ++r) v0[t][r] = acc[0][8 + r];
         }
+        advance(cx, step); ++step;
         // softmax over the 3 keys, scale 16^-0.5 (renderer.py:956,971-973)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -558,7 +563,7 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
-        s = wl + step_pieces<PREC>(0) * 1024;                     // step 1: chunks 5..8
+        s = cx.slot(step);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -618,70 +623,14 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
             mma_cols<PREC, 2, 2>(s, 7, gb, acc2);
+            advance(cx, step); ++step;
             f32x16 za = acc2[0] + y[0], zb = acc2[1] + y[1];
             split_tile<PREC>(za, z0b[0], z0b[1]);
             split_tile<PREC>(zb, z1b[0], z1b[1]);
         }
     }
-    u32x4* zp = zfrag + tile * 512 + cx.lane;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        zp[(2 * kb) * 64] = z0b[kb].hi;
-        zp[(4 + 2 * kb) * 64] = z1b[kb].hi;
-        if constexpr (PREC == 1) { zp[(2 * kb + 1) * 64] = z0b[kb].lo; zp[(4 + 2 * kb + 1) * 64] = z1b[kb].lo; }
-    }
-    }   // tiles
-}
+    __builtin_amdgcn_sched_barrier(0);
 
-// ---- launch 2 of 2: the NeRF decoder, steps 2..42 of the weight stream through the 3-slot ring.  MFMA bound; two workgroups per
-// CU, so the two waves of a SIMD (one of each) are both in this phase all the time. ----
-template <int PREC>
-__global__ void __launch_bounds__(NW * 64, 2)
-nerf_decoder_kernel(const int32_t* __restrict__ counters, const u32x4* __restrict__ zfrag, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
-    using CX = Ctx<PREC>;
-    constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
-    const int64_t nv = min((int64_t)counters[0], capacity);
-    const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
-    CX cx;
-    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
-    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
-    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
-    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
-#if SHERF_MLP_TRACE
-    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
-    if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
-#endif
-    const int j = cx.lane & 31, h = cx.h;
-    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
-    const bool live = tile < n_tiles;
-    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
-
-    constexpr int STEP0 = 2;                                         // (steps 0, 1 belong to nerf_tokens_kernel)
-    dma_issue(cx, STEP0);
-    dma_issue(cx, STEP0 + 1);
-    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(STEP0 + 1) / NW);   // the first step (this wave's pieces) landed
-    __syncthreads();
-    dma_issue(cx, STEP0 + 2);
-
-    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks (nerf_tokens_kernel)
-    float xc[3], vc[3];
-    int step = STEP0;
-    {
-        const float* ex = extras + tile * 12 * 32 + j;
-        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
-        const u32x4* zp = zfrag + tile * 512 + cx.lane;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            z0b[kb].hi = zp[(2 * kb) * 64];
-            z1b[kb].hi = zp[(4 + 2 * kb) * 64];
-            if constexpr (PREC == 1) { z0b[kb].lo = zp[(2 * kb + 1) * 64]; z1b[kb].lo = zp[(4 + 2 * kb + 1) * 64]; }
-        }
-    }
     // ================= NeRF decoder =================
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
     BFrag<PREC> ha[8], hb[8];
@@ -809,31 +758,16 @@ extern "C" int sherf_mlp_stream_layout(int prec, int32_t* n_steps, int32_t* step
 }
 
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                              const float* wbias, int prec, void* zfrag, int64_t capacity, float* out, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && zfrag && out);
+                              const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
     SHERF_CHECK_ARG((prec == 0 || prec == 1) && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
-    const int64_t groups = (tiles + NW - 1) / NW;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0, v = 0;
-        SHERF_HIP_CHECK(hipGetDevice(&dev));
-        SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = v > 0 ? v : 256;
-    }
-    const int64_t resident = (int64_t)SHERF_MLP_TOKENS_WAVES * n_cu;          // workgroups of 4 waves per CU = waves per SIMD
-    const dim3 grid_t((unsigned)(groups < resident ? groups : resident)), grid_d((unsigned)groups), block(NW * 64);
-    const float4* tok4 = reinterpret_cast<const float4*>(tokens);
-    const char* wsb = reinterpret_cast<const char*>(wstream);
-    u32x4* zf = reinterpret_cast<u32x4*>(zfrag);
-    if (prec == 1) {
-        hipLaunchKernelGGL((nerf_tokens_kernel<1>), grid_t, block, 0, as_stream(stream), counters, tok4, extras, wsb, wbias, capacity, zf);
-        hipLaunchKernelGGL((nerf_decoder_kernel<1>), grid_d, block, 0, as_stream(stream), counters, zf, extras, wsb, wbias, capacity,
-                           reinterpret_cast<float4*>(out));
-    } else {
-        hipLaunchKernelGGL((nerf_tokens_kernel<0>), grid_t, block, 0, as_stream(stream), counters, tok4, extras, wsb, wbias, capacity, zf);
-        hipLaunchKernelGGL((nerf_decoder_kernel<0>), grid_d, block, 0, as_stream(stream), counters, zf, extras, wsb, wbias, capacity,
-                           reinterpret_cast<float4*>(out));
-    }
+    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
+    if (prec == 1)
+        hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     SHERF_LAUNCH_CHECK();
 }

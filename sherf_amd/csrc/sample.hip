@@ -226,7 +226,8 @@ __device__ __forceinline__ float depth_at(float near, float range, int k, int S)
 
 // One wave per ray.  Candidate samples (near-mask hit: ~12 % of the samples, ~30 on a ray that crosses the body) are searched by
 // EIGHT-LANE GROUPS, eight candidates at a time: each candidate lane first fetches the nine x-contiguous point segments of its
-// 3x3x3 cell neighbourhood (18 independent loads, all candidates in parallel) and parks them with its position in an LDS record;
+// 3x3x3 cell neighbourhood, trimmed to the cells its 5 cm ball reaches (18 independent loads, all candidates in parallel), and parks
+// them with its position in an LDS record;
 // then group g of a round takes candidate 8 r + g, its 8 lanes walk the concatenated segments 8 points per step with every step's
 // loads in flight before the first distance is evaluated, and the lexicographic minimum of (d^2, vertex id) is taken with a 64-bit
 // LDS atomic min per group (d^2 >= 0, so the IEEE bit pattern orders like the value; only points inside the 5 cm threshold ever
@@ -282,15 +283,24 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
         if (cand) {                                  // this candidate's record: position, the 9 segments (start, cumulative count)
             Cand& c = rec[rank];
             c.x = xs; c.y = ys; c.z = zs; c.key = kInit;
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+            // only the cells the 5 cm ball can reach: a (y, z) row of cells farther than r in the yz plane is skipped, the others are
+            // trimmed in x to [x - sqrt(r^2 - d_yz^2), x + ...] (+ a safety margin) -- the 27-cell cube holds ~80 vertices of the body
+            // surface, the ball ~ a fifth of them; every vertex within r is still examined, so the minimum is unchanged
+            const float r = 0.05f + 1e-4f * g.cell;
             int st[9], en[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
-                const bool ok = qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny;
+                const float y0 = g.oy + qy * g.cell, z0 = g.oz + qz * g.cell;
+                const float ey = fmaxf(fmaxf(y0 - ys, ys - (y0 + g.cell)), 0.f), ez = fmaxf(fmaxf(z0 - zs, zs - (z0 + g.cell)), 0.f);
+                const float rem = r * r - (ey * ey + ez * ez);
+                const bool ok = qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny && rem > 0.f;
+                const float rx = sqrtf(fmaxf(rem, 0.f)) + 1e-4f * g.cell;
+                const int x0 = max(max((int)floorf((xs - rx - g.ox) * g.inv_cell), cx - 1), 0);
+                const int x1 = min(min((int)floorf((xs + rx - g.ox) * g.inv_cell), cx + 1), g.nx - 1);
                 const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
-                st[i] = cell_start[row + x0];
-                en[i] = ok ? cell_start[row + x1 + 1] : st[i];
+                st[i] = cell_start[row + (ok ? x0 : 0)];
+                en[i] = ok && x1 >= x0 ? cell_start[row + x1 + 1] : st[i];
             }
             int cum = 0;
 #pragma unroll

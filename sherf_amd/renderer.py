@@ -162,7 +162,6 @@ class _Workspace:
             ray_mask=torch.zeros(R * nch, dtype=torch.int64, device=dev), scan_ws=torch.zeros(R + R // 1024 + 2, **i32),
             geom=torch.zeros(cap, 8, **f32), tokens=torch.zeros(tiles * 3 * 8 * 32 * 4, **f32),
             extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(cap, 4, **f32),
-            zfrag=torch.zeros(tiles * 2048, **f32),                       # z_0 / z_1 operand fragments between the two MLP launches: 8 KiB per tile
             rgb=torch.zeros(R, 3, **f32), depth=torch.zeros(R, **f32), acc=torch.zeros(R, **f32),
             A=torch.zeros(3, 24, 12, **f32), posefeat=torch.zeros(3, 207, **f32), PO=torch.zeros(3, V, 3, **f32),
             SO=torch.zeros(3, V, 3, **f32), T2C=torch.zeros(V, 12, **f32), C2S=torch.zeros(V, 12, **f32),
@@ -442,7 +441,7 @@ class ImportanceRenderer(nn.Module):
         fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
         for k in ('A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
                   'counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws', 'geom',
-                  'cs_tvid', 'tokens', 'extras', 'zfrag', 'sample_out', 'rgb', 'depth', 'acc'):
+                  'cs_tvid', 'tokens', 'extras', 'sample_out', 'rgb', 'depth', 'acc'):
             setattr(fr, k, A(ws[k]))
         fr.obs_R, fr.obs_Th = a32(oprm['R'], 9), a32(oprm['Th'], 3)
         fr.cam_R, fr.cam_T, fr.cam_K = a32(input_data['obs_R_all'], 9), a32(input_data['obs_T_all'], 3), a32(input_data['obs_K_all'], 9)

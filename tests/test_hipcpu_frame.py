@@ -27,7 +27,7 @@ def cpu_product(tmp_path_factory):
     if not os.path.exists(build_cpu.CLANG):
         pytest.skip('needs the ROCm clang for the host build of the bf16 kernels')
     fwd = build_cpu.build('sherf_hipcpu_full', FWD_SOURCES, str(tmp_path_factory.mktemp('hipcpu_full')), compiler=build_cpu.CLANG)
-    bwd = build_cpu.build('sherf_hipcpu_bwd', ['bwd_dense.hip', 'bwd_encoder.hip'], str(tmp_path_factory.mktemp('hipcpu_bwd')))
+    bwd = build_cpu.build('sherf_hipcpu_bwd', ['bwd_dense.hip', 'bwd_gemm.hip', 'bwd_encoder.hip'], str(tmp_path_factory.mktemp('hipcpu_bwd')), compiler=build_cpu.CLANG)
     ops = build_cpu.build('sherf_hipcpu_ops', ['ops_lib.hip', 'ops_bias_act.hip', 'ops_upfirdn2d.hip'], str(tmp_path_factory.mktemp('hipcpu_ops')),
                           compiler=build_cpu.CLANG)
     from sherf_amd import backward_dense
@@ -262,12 +262,11 @@ def test_renderer_helpers_the_reference_generator_calls(cpu_product):
     assert torch.equal(G.plain(only_xy), G.plain(xy)) and 0.2 < float(G.plain(mask).float().mean()) < 0.8
 
 
-def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
+def check_whole_generator():
     """TriPlaneGenerator.forward(input_data, z, c) as the reference calls it (test_loop.py:189-190): ResNet-18 code -> mapping ->
-    StyleGAN2 tri-planes (bias_act / upfirdn2d kernels), ResNet-18 feature map, glue, renderer -- all three libraries built for the
-    host -- against the oracle renderer fed with the planes / feature map the same producers output."""
+    StyleGAN2 tri-planes (bias_act / upfirdn2d kernels), ResNet-18 feature map, glue, renderer -- against the oracle renderer fed with
+    the planes / feature map the same producers output.  Shared by the host-build test below and tests/test_gpu_producers.py."""
     from sherf_amd.triplane import TriPlaneGenerator
-    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))       # module parameters are "device" tensors too
     fx = dict(G.fixture('tiny'))
     rend, dec = G.hip_modules.__wrapped__()
     gen = TriPlaneGenerator(512, 0, 48, True, True, True, True, True, img_resolution=32, img_channels=3, mapping_kwargs=dict(num_layers=2),
@@ -281,11 +280,13 @@ def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
                 v = None if n.endswith('resample_filter') else fixtures.seeded_param(f'{name}.{n}', t.shape)
                 if v is not None:
                     t.copy_(torch.from_numpy(np.asarray(v, np.float32).reshape(tuple(t.shape))).to(t.dtype))
+    gen = G.dev_module(gen)
     gen.eval(); rend.train(); dec.train()
     d = G.to_cuda(fx['input_data'])
+    c0 = G.dev_tensor(torch.zeros(1, 25))
     with torch.no_grad():
-        out = gen(d, None, torch.zeros(1, 25), use_sr_module=False, test_flag=True, noise_mode='const')
-        ws = gen.mapping(None, torch.zeros(1, 25), input_img=d['obs_img_all'][:, 0])
+        out = gen(d, None, c0, use_sr_module=False, test_flag=True, noise_mode='const')
+        ws = gen.mapping(None, c0, input_img=d['obs_img_all'][:, 0])
         planes = gen.backbone.synthesis(ws, noise_mode='const')
         feat = gen.encoder_2d_feature(d['obs_img_all'][:, 0], extract_feature=True)
     assert out['image_raw'].shape == (1, 3, 32, 32) and planes.shape == (1, 96, 256, 256) and feat.shape == (1, 64, 16, 16)
@@ -301,6 +302,11 @@ def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
     img = G.plain(out['image_raw'])[0].permute(1, 2, 0).reshape(-1, 3)
     assert O.psnr(img, o['rgb']) > 55.0
     assert G.rel(G.plain(out['weights_image']).reshape(-1), o['acc']) < 2e-3
+
+
+def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))       # module parameters are "device" tensors too
+    check_whole_generator()
 
 
 def test_full_training_step_with_the_reconstruction_loss(cpu_product, monkeypatch):

@@ -19,7 +19,7 @@ from tests.hipcpu import build_cpu
 
 @pytest.fixture(scope='module')
 def cpu_lib(tmp_path_factory):
-    path = build_cpu.build('sherf_hipcpu_bwd', ['bwd_dense.hip', 'bwd_encoder.hip'], str(tmp_path_factory.mktemp('hipcpu')))
+    path = build_cpu.build('sherf_hipcpu_bwd', ['bwd_dense.hip', 'bwd_gemm.hip', 'bwd_encoder.hip'], str(tmp_path_factory.mktemp('hipcpu')), compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     for name, (ret, args) in _lib.parse_header(_lib.HEADER_BWD).items():
         fn = getattr(lib, name)
@@ -444,8 +444,7 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
     extras = ext.view(tiles, 32, 12).permute(0, 2, 1).reshape(-1).contiguous()
     counters = torch.tensor([n, 0, 0, 0], dtype=torch.int32)
     out = torch.zeros(tiles * 32, 4)
-    zfrag = torch.zeros(tiles * 2048)
-    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, _P(zfrag), n, _P(out), None) == 0
+    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out), None) == 0
     sig_h, sig_ref = torch.relu(out[:n, 3]), torch.relu(r['sample_sigma'])
     e_sig = float((sig_h - sig_ref).abs().max() / sig_ref.max())
     e_rgb = float((out[:n, :3] - r['sample_rgb']).abs().max())
@@ -455,4 +454,4 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
     assert e_sig < tol_sig and e_rgb < tol_rgb, (e_sig, e_rgb)
     if prec == 1:
         assert r_sig < 1e-3 and r_rgb < 1e-3, (r_sig, r_rgb)
-    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, None, n, _P(out), None) != 0   # the scratch is mandatory
+    assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), 2, n, _P(out), None) != 0        # unknown precision

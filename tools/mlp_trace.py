@@ -21,7 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-CLASSES = dict(first=(2, 4), trunk1_4=(4, 20), skip=(20, 26), trunk6_7=(26, 34), heads=(34, 39), views=(39, 42))      # decoder steps (0, 1 = nerf_tokens_kernel)
+CLASSES = dict(transformer=(0, 2), first=(2, 4), trunk1_4=(4, 20), skip=(20, 26), trunk6_7=(26, 34), heads=(34, 39), views=(39, 42))
 N_STEPS = 43
 
 
@@ -55,12 +55,12 @@ def main():
         lib = ct.CDLL(path)
         f = lib.sherf_nerf_mlp
         f.restype = ct.c_int
-        f.argtypes = [ct.c_void_p] * 5 + [ct.c_int, ct.c_void_p, ct.c_int64, ct.c_void_p, ct.c_void_p]
+        f.argtypes = [ct.c_void_p] * 5 + [ct.c_int, ct.c_int64, ct.c_void_p, ct.c_void_p]
         return lib, f
 
     def launch(f, prec=1):
         wc = wcs['f16x3' if prec else 'bf16']
-        return f(A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), prec, A(ws['zfrag']), capx, A(out), stream)
+        return f(A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), prec, capx, A(out), stream)
 
     def timed(f, prec=1, iters=20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -115,7 +115,6 @@ def main():
         t = (buf.cpu().numpy().astype(np.int64).reshape(nslot, 8, 64, 4)[:, :4]) & 0xffffffff
         st = t[:, :, :N_STEPS, :3].copy()                           # [workgroup, wave, step, (compute end, dma landed, barrier left)]
         start, end = t[:, :, 63, 0], t[:, :, 63, 2]
-        st[:, :, :2, :] = start[:, :, None, None]                   # the decoder kernel starts at step 2
         prev = np.concatenate([start[:, :, None], st[:, :, :-1, 2]], 2)
         comp = ((st[..., 0] - prev) & 0xffffffff)[:, :, :N_STEPS - 1]          # (the last step has no barrier: its stamp 0 only)
         vmw = ((st[..., 1] - st[..., 0]) & 0xffffffff)[:, :, :N_STEPS - 1]
