@@ -23,6 +23,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_VALID_SAMPLE = 429248       # 214,624 MAC per valid sample (fusion + transformer + decoder)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                # MI355X HBM3E (MI355X_MICROARCH.md)
+SECONDARY_ITERS = dict(mlp=20, mlp_warmup=5, frames=10, frames_warmup=3)      # (the host dry run of this script lowers them)
 
 
 def make_inputs(cfg_name, theta, dev):
@@ -83,12 +85,14 @@ def time_frames(w, steps, warmup, dev):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def mlp_kernel_alone(w, precision, dev, iters=20, warmup=5):
+def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None):
     """`sherf_nerf_mlp` alone on the tokens of the frame `w` rendered last, in `precision`: (ms per launch from HIP events on the
     launch stream, its [nv, 4] output)."""
     import ctypes as ct
     from sherf_amd import _lib
     from sherf_amd.renderer import MLP_PRECISIONS
+    iters = SECONDARY_ITERS['mlp'] if iters is None else iters
+    warmup = SECONDARY_ITERS['mlp_warmup'] if warmup is None else warmup
     rend = w['rend']
     ws, cap = rend.last['ws'], int(rend.last['cap'])
     wc = rend._weights(w['dec'], dev, precision)
@@ -137,9 +141,9 @@ def secondary_measurements(a, w, dev, nv, R):
             w2['rend'].exact_grids = w['rend'].exact_grids
             import ctypes as _ct
             from sherf_amd import _lib as _abi
-            time_frames(w2, 1, 3, dev)
+            time_frames(w2, 1, SECONDARY_ITERS['frames_warmup'], dev)
             _abi.call('sherf_profile_frames', 1)
-            ms = time_frames(w2, 10, 0, dev)
+            ms = time_frames(w2, SECONDARY_ITERS['frames'], 0, dev)
             buf = (_ct.c_float * (64 * 8))(); n_ms = _ct.c_int32(0)
             _abi.call('sherf_profile_frames_read', buf, 64, _ct.byref(n_ms))
             _abi.call('sherf_profile_frames', 0)

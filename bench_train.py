@@ -1,10 +1,13 @@
 """Training-step timing for BASELINE config 5 (forward render + backward through the HIP kernels + the reference's flat-grad
-all-reduce, training_loop.py:374-383 + Adam step) -- EXPERIMENTAL companion of bench.py, same launch contract:
+all-reduce, training_loop.py:374-383 + Adam step) -- companion of bench.py (whose metric is the forward render), same launch
+contract:
 
     python bench_train.py --gpus N --steps K --warmup W          (torchrun for N > 1, one rank per GPU)
 
-The backward pipeline (sherf_amd/backward.py) is verified on the CPU only so far; until its kernels have
-passed `pytest -m gpu_experimental` on an MI355X the number this prints is not a claim.  Rank 0 prints ONE JSON line.
+The backward pipeline (sherf_amd/backward.py) is checked against the unmodified reference's gradients by
+tests/test_gpu_backward.py (`pytest -m gpu`).  Rank 0 prints ONE JSON line; `roofline` is the step's dominant kernel
+(sherf_gather_tokens_bwd: the scatter of d_tokens into the tri-planes, the feature map and the voxel rows with fp32 atomics), timed
+with events on the launch stream inside the timed steps; `phases_ms` splits a step into forward / backward / all-reduce + Adam.
 """
 import argparse
 import json
@@ -69,8 +72,39 @@ def main():
         opt.step()
         return loss
 
+    # the dominant kernel of the step, timed live: events on the stream the call is launched on (torch's current stream)
+    from sherf_amd import _lib
+    scatter_ev, call0 = [], _lib.call
+
+    def timed_call(name, *args):
+        if name != 'sherf_gather_tokens_bwd':
+            return call0(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); call0(name, *args); e1.record()
+        scatter_ev.append((e0, e1))
+    _lib.call = timed_call
+    phase_ev = []
+    step0 = step
+
+    def step():                                             # the same step with three more events on the stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        sp = SparseConvTensor(vfeat, sp_input['coord'], sp_input['out_sh'], 1)
+        rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)
+        loss = ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
+        ev[1].record()
+        loss.backward()
+        ev[2].record()
+        sdist.allreduce_flat_grads(params)
+        opt.step()
+        ev[3].record()
+        phase_ev.append(ev)
+        return loss
+
     for _ in range(a.warmup):
         step()
+    scatter_ev.clear(); phase_ev.clear()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -85,11 +119,23 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+    scat_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in scatter_ev])) if scatter_ev else None
+    phases = {k: float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in phase_ev])) for i, k in enumerate(('forward', 'backward', 'allreduce_adam'))}
     if rank == 0:
+        n_valid = int(rend.last['ws']['counters'][0]) if rend.last else 0
+        # algorithmic bytes of the scatter per valid sample: d_tokens 384 B + geometry 32 B read; fp32 read-modify-write of the taps:
+        # tri-planes 3 slots x 4 taps x 128 B, feature map 2 slots x 4 taps x 128 B, voxel rows 3 levels x 8 taps x 3 slots x 128 B
+        bytes_per_sample = 384 + 32 + 2 * (3 * 4 * 128 + 2 * 4 * 128 + 3 * 8 * 3 * 128)
+        roofline = None
+        if scat_ms and n_valid:
+            ach = bytes_per_sample * n_valid / (scat_ms * 1e-3) / 1e9
+            roofline = dict(kernel='gather_tokens_bwd_kernel', bound='hbm', achieved=ach, peak=bench.PEAK_HBM_GBS, unit='GB/s', frac=ach / bench.PEAK_HBM_GBS,
+                            traffic=None, kernel_ms=scat_ms, bytes_per_sample=bytes_per_sample, valid_samples=n_valid,
+                            note='same-address fp32 atomics of neighbouring samples serialise in L2: atomic-bound, not bandwidth-bound')
         print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
                               unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
-                              scaling='weak', vs_baseline=None, dtype='fp32 backward (rocBLAS sgemm + fp32 kernels), f16x3 MFMA forward',
-                              data='synthetic', status='EXPERIMENTAL: backward kernels not yet verified on hardware', final_loss=float(loss),
+                              scaling='weak', vs_baseline=None, dtype='f32 (backward: fp32 kernels + MFMA GEMMs on a three-part bf16 split; forward: f16x3 MFMA)',
+                              data='synthetic', final_loss=float(loss), phases_ms=phases, roofline=roofline,
                               config=dict(workload=f'{a.config}: one view per GPU, stub loss MSE(rgb)+MSE(acc)', rays=R))))
     if world > 1:
         torch.distributed.barrier()

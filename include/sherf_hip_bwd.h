@@ -22,7 +22,7 @@ extern "C" {
 const char* sherf_bwd_last_error(void);
 
 /* C[M][N] = op(A)[M][K] . op(B)[K][N] + beta * C   (row-major; op = transpose when trans* != 0) on `stream`: hand-written MFMA
- * kernels (csrc/bwd_gemm.hip: fp16 hi + lo operand split, three products, fp32 accumulate -- fp32-grade) for the three patterns of the
+ * kernels (csrc/bwd_gemm.hip: three-part bf16 operand split, six products, fp32 accumulate -- fp32 grade) for the three patterns of the
  * backward, each with one huge dimension (the valid samples) and two layer-width ones: transA = 0 (M huge: forward recompute and data
  * gradients), transA = 1 / transB = 0 (K huge: weight gradients, partial sums added to C with fp32 atomics -- the summation order is
  * not deterministic); anything else runs on a plain fp32 kernel.  Replaces every `x @ W.t()` / `d.t() @ x` of

@@ -5,8 +5,15 @@
 //     forward recompute   y  = x  . W^T   (transA 0, transB 1)   M = samples
 //     data gradient       dx = dy . W     (transA 0, transB 0)   M = samples
 //     weight gradient     dW = dy^T . x   (transA 1, transB 0)   K = samples
-// Round 1 sent them to rocBLAS sgemm; these are hand-written gfx950 kernels on v_mfma_f32_32x32x16_f16 with the operands split
-// hi + lo in fp16 ("f16x3": three products, fp32 accumulate, ~2^-21 relative -- the forward's scheme, csrc/mlp.hip):
+// Round 1 sent them to rocBLAS sgemm; these are hand-written gfx950 kernels on v_mfma_f32_32x32x16_bf16 with each operand split
+// into THREE bf16 parts x = hi + mid + lo (the splits are exact in fp32) and the six products of weight >= 2^-16 kept
+// (lo.hi, mid.mid, hi.lo, mid.hi, hi.mid, hi.hi; small terms first; fp32 accumulate): ~2^-23 relative, fp32 grade.  Why not the
+// forward's cheaper schemes (measured on the MI355X in round 2):
+//   * fp16 hi + lo (the forward's f16x3): gradients are 1e-4 ... 1e-9 in magnitude, where fp16 (min normal 6e-5) has lost its precision
+//     or underflowed -- d_tokens_in came out 5e-3 off;
+//   * bf16 hi + lo (2^-16): range is fine, but the RECOMPUTED pre-activations carry 5e-5 of error, which flips ~5e-4 of the ReLU masks;
+//     a flipped mask changes a sample's gradient by O(1).
+// These GEMMs are < 1 % of the training step (section 8 of DESIGN.md), so the doubled MFMA count is free.
 //   tall_gemm  (transA 0): the small matrix is converted ONCE per workgroup into B-operand fragments in LDS (<= 104 KiB); persistent
 //              4-wave workgroups walk 32-row tiles of the tall operand, each wave its own tile, NT independent accumulator chains.
 //   wgrad_gemm (transA 1, transB 0): workgroups walk 16-sample steps of a slab of rows; both operand fragments are read straight
@@ -18,25 +25,36 @@
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+struct Frag { u32x4 hi, mid, lo; };        // 8 K-values of one lane, three bf16 parts each (two values per dword)
+
+// part = the top 16 bits of what is left (truncation: the remainder x - part is exact in fp32; one v_perm packs a pair)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
+    hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);          // [a.hi16 | b.hi16 << 16]
+    const float ra = a - __builtin_bit_cast(float, ua & 0xFFFF0000u), rb = b - __builtin_bit_cast(float, ub & 0xFFFF0000u);
+    const uint32_t va = __builtin_bit_cast(uint32_t, ra), vb = __builtin_bit_cast(uint32_t, rb);
+    mid = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, va & 0xFFFF0000u), sb = rb - __builtin_bit_cast(float, vb & 0xFFFF0000u);
+    lo = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
 }
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
-    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
-    split2(v[0], v[1], h0, l0); split2(v[2], v[3], h1, l1); split2(v[4], v[5], h2, l2); split2(v[6], v[7], h3, l3);
-    hi = u32x4{h0, h1, h2, h3}; lo = u32x4{l0, l1, l2, l3};
+__device__ __forceinline__ Frag split8(const float (&v)[8]) {
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) split2(v[2 * p], v[2 * p + 1], h[p], m[p], l[p]);
+    return Frag{u32x4{h[0], h[1], h[2], h[3]}, u32x4{m[0], m[1], m[2], m[3]}, u32x4{l[0], l[1], l[2], l[3]}};
 }
-__device__ __forceinline__ f32x16 mfma3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bl), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma1(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma6(const Frag& a, const Frag& b, f32x16 c) {
+    c = mfma1(a.lo, b.hi, c); c = mfma1(a.mid, b.mid, c); c = mfma1(a.hi, b.lo, c);
+    c = mfma1(a.mid, b.hi, c); c = mfma1(a.hi, b.mid, c);
+    return mfma1(a.hi, b.hi, c);
 }
 // accumulator register r of lane (j = lane & 31, h = lane >> 5) <-> tile row (r & 3) + 8 (r >> 2) + 4 h, tile column j
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -47,7 +65,7 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 template <int NT>
 __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
                                                         float* __restrict__ C, int ldc, int M, int N, int K, float beta) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, lo][64 lanes]
+    extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, mid, lo][64 lanes]
     const int nkb = (K + 15) / 16;
     for (int idx = threadIdx.x; idx < nkb * NT * 64; idx += 256) {
         const int l = idx & 63, nt = (idx >> 6) % NT, kb = idx / (64 * NT);
@@ -58,10 +76,10 @@ __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict_
             const int k = k0 + e;
             v[e] = (k < K && n < N) ? (transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
         }
-        u32x4 hi, lo;
-        split8(v, hi, lo);
-        s_frag[((kb * NT + nt) * 2) * 64 + l] = hi;
-        s_frag[((kb * NT + nt) * 2 + 1) * 64 + l] = lo;
+        const Frag f = split8(v);
+        s_frag[((kb * NT + nt) * 3) * 64 + l] = f.hi;
+        s_frag[((kb * NT + nt) * 3 + 1) * 64 + l] = f.mid;
+        s_frag[((kb * NT + nt) * 3 + 2) * 64 + l] = f.lo;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -92,11 +110,12 @@ __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
-            u32x4 ah, al;
-            split8(v, ah, al);
+            const Frag a = split8(v);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = mfma3(ah, al, s_frag[((kb * NT + nt) * 2) * 64 + lane], s_frag[((kb * NT + nt) * 2 + 1) * 64 + lane], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4* f = s_frag + ((kb * NT + nt) * 3) * 64 + lane;
+                acc[nt] = mfma6(a, Frag{f[0], f[64], f[128]}, acc[nt]);
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -128,7 +147,7 @@ __global__ void __launch_bounds__(256) wgrad_gemm_kernel(const float* __restrict
     for (int slab = blockIdx.x; slab * kSlab < Kbig; slab += gridDim.x) {
         const int r_end = min(Kbig, (slab + 1) * kSlab);
         for (int r0 = slab * kSlab; r0 < r_end; r0 += 16) {
-            u32x4 bh[NT], bl[NT];
+            Frag b[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = 32 * nt + i;
@@ -138,7 +157,7 @@ __global__ void __launch_bounds__(256) wgrad_gemm_kernel(const float* __restrict
                     const int r = r0 + 8 * h + e;
                     v[e] = (r < r_end && n < N) ? B[(size_t)r * ldb + n] : 0.f;
                 }
-                split8(v, bh[nt], bl[nt]);
+                b[nt] = split8(v);
             }
 #pragma unroll
             for (int a = 0; a < MTW; ++a) {
@@ -151,10 +170,9 @@ __global__ void __launch_bounds__(256) wgrad_gemm_kernel(const float* __restrict
                         const int r = r0 + 8 * h + e;
                         v[e] = (r < r_end && m < M) ? A[(size_t)r * lda + m] : 0.f;
                     }
-                    u32x4 ah, al;
-                    split8(v, ah, al);
+                    const Frag af = split8(v);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[a][nt] = mfma3(ah, al, bh[nt], bl[nt], acc[a][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc[a][nt] = mfma6(af, b[nt], acc[a][nt]);
                 }
             }
         }
@@ -193,16 +211,6 @@ __global__ void plain_gemm_kernel(int transA, int transB, int M, int N, int K, c
     *p = beta == 0.f ? s : s + beta * *p;
 }
 
-int n_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
-}
-
 }  // namespace
 
 extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -210,10 +218,12 @@ extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const
     SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
     hipStream_t st = as_stream(stream);
     const int NT = (N + 31) / 32, nkb = (K + 15) / 16;
-    if (!transA && NT <= 8 && (size_t)nkb * NT * 2048 <= 128 * 1024) {
-        const size_t smem = (size_t)nkb * NT * 2048;
+    if (!transA && NT <= 8 && (size_t)nkb * NT * 3072 <= 156 * 1024) {
+        const size_t smem = (size_t)nkb * NT * 3072;
         const int tiles = (M + 31) / 32, grid = min((tiles + 3) / 4, n_cus());
-#define SHERF_TALL(n) case n: hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, B, ldb, transB, C, ldc, M, N, K, beta); break
+#define SHERF_TALL(n) case n: \
+        if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, B, ldb, transB, C, ldc, M, N, K, beta); break
         switch (NT) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
 #undef SHERF_TALL
         SHERF_LAUNCH_CHECK();

@@ -40,6 +40,14 @@ extern int g_sherf_debug;   // ablation switches for profiling (sherf_set_debug)
 
 static inline hipStream_t as_stream(sherf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int n_cus() {             // compute units of the current device (256 on an MI355X); persistent kernels size their grids by it
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+}
 
 // grid header layout (12 x 32-bit): origin.xyz (f32), cell (f32), inv_cell (f32), nx, ny, nz (i32), sub (i32: the near
 // mask has sub x sub x sub bits per cell), 3 unused

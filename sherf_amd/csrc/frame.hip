@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 

@@ -89,11 +89,25 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
 // f16 hi/lo split of a pair: hi = the pair rounded toward zero (one v_cvt_pkrtz), lo = x - hi exactly in fp32 (hi keeps x's
 // leading 11 bits) and then rounded to fp16: hi + lo carries 22 significant bits.  |x| must stay below 65504 (fp16 range): the
 // activations of an 8 x 128 ReLU network fed with encodings in [-1, 1] and O(1) tokens sit 3-4 orders of magnitude below that.
+// SHERF_MLP_FMA_MIX: the residuals x - hi as ONE v_fma_mix_f32 each (f16 half of `hi` times -1.0 plus the f32 value) instead of
+// v_cvt_f32_f16 + v_sub_f32: 4 instead of 6 VALU per pair -- hipcc does not form it.  Verified on the MI355X: bit-identical output,
+// 0.665 vs 0.676 ms (profiles/r02_mlp_trace_v4.txt).  The host build of the test shim takes the plain-C form below.
+#ifndef SHERF_MLP_FMA_MIX
+#define SHERF_MLP_FMA_MIX 1
+#endif
 __device__ __forceinline__ void split2_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
+#if SHERF_MLP_FMA_MIX
+    float ra, rb;
+    asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+#else
     const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
     const float ra = __builtin_fmaf((float)h[0], -1.0f, a), rb = __builtin_fmaf((float)h[1], -1.0f, b);
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+#endif
 }
 
 template <int PREC>
@@ -141,6 +155,14 @@ __device__ int g_mlp_trace_every = 0;
 #define SHERF_TRACE_STAMP(cx, step, k) do { if ((cx).lane == 0) (cx).trace[(step) * 4 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
+#endif
+
+// SHERF_MLP_STAGGER (experiment; cycles, 0 = off): the two workgroups of a CU are dispatched together at launch and every tile costs the
+// same, so they march in PHASE -- both in the VALU-bound transformer, then both in the MFMA-bound decoder -- and the SIMD's two
+// pipes are never busy together.  With a stagger the first-generation workgroup in the odd wave slot idles for that many cycles once;
+// every later generation inherits the offset (a new workgroup starts when an old one ends).
+#ifndef SHERF_MLP_STAGGER
+#define SHERF_MLP_STAGGER 0
 #endif
 
 // SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers
@@ -231,7 +253,7 @@ __device__ __forceinline__ f32x16 bias_tile(const C& cx, int idx) {
 #endif
 #if SHERF_MLP_FASTMATH
 __device__ __forceinline__ float exp_(float x) { return __expf(x); }
-__device__ __forceinline__ float rcp_(float x) { return __frcp_rn(x); }
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32 (1 ulp); __frcp_rn is a full IEEE division: ~10 instructions
 __device__ __forceinline__ float rsqrt_(float x) { return __frsqrt_rn(x); }
 #else
 __device__ __forceinline__ float exp_(float x) { return expf(x); }
@@ -246,7 +268,7 @@ __device__ __forceinline__ float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 __device__ __forceinline__ float erf_(float x) {
 #if SHERF_MLP_FAST_ERF
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = rcp_(fmaf(0.3275911f, ax, 1.0f));
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     return copysignf(1.0f - poly * __expf(-ax * ax), x);
 #else
@@ -437,7 +459,8 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, 2)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out,
+                uint32_t stagger_first_gen) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
@@ -453,13 +476,26 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
 #if SHERF_MLP_TRACE
     cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
-    if (cx.lane == 0) { cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime(); cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }   // HW_ID
+    if (cx.lane == 0) {
+        cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime();
+        cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID: wave slot, SIMD, CU, SH, SE
+        cx.trace[63 * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // XCC_ID
+    }
 #endif
     const int j = cx.lane & 31, h = cx.h;
     int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
 
+#if SHERF_MLP_STAGGER
+    if (blockIdx.x < 2u * stagger_first_gen) {                        // first generation only: two workgroups per CU
+        const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        if (hw_id & 1u) {                                             // WAVE_ID bit 0: the second wave slot of this SIMD
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)SHERF_MLP_STAGGER) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+#endif
     dma_issue(cx, 0);
     dma_issue(cx, 1);
     wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
@@ -765,9 +801,9 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
     const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
     if (prec == 1)
         hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), (uint32_t)n_cus());
     else
         hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), (uint32_t)n_cus());
     SHERF_LAUNCH_CHECK();
 }

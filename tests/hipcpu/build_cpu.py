@@ -37,8 +37,9 @@ def _cpu_mlp(src):
               '        acc0 = mfma<PREC>(ah0, bh0, acc0); acc1 = mfma<PREC>(ah1, bh1, acc1);\n'
               '    } else { acc0 = mfma<PREC>(ah0, bh0, acc0); acc1 = mfma<PREC>(ah1, bh1, acc1); }\n')
     src = src.replace('    asm volatile("s_nop 7\\n\\ts_nop 3" : "+v"(acc0), "+v"(acc1));', '    (void)acc0; (void)acc1;')
+    src = src.replace('#define SHERF_MLP_FMA_MIX 1', '#define SHERF_MLP_FMA_MIX 0')       # v_fma_mix_f32 inline asm -> its plain-C equivalent
     src = re.sub(r'asm volatile\("" : "\+[sv]"\([^;]*;', ';', src)            # register-class launders (optimisation barriers only)
-    assert 'asm volatile' not in src, 'an inline-asm site of mlp.hip has no host equivalent'
+    assert 'asm volatile' not in src.replace('#if SHERF_MLP_FMA_MIX', '#if 0'), 'an inline-asm site of mlp.hip has no host equivalent'
     return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
 
 

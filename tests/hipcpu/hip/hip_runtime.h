@@ -115,6 +115,8 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 constexpr int hipMemcpyDeviceToHost = 2;
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 inline float unsafeAtomicAdd(float* p, float v) { return std::atomic_ref<float>(*p).fetch_add(v); }
@@ -204,6 +206,7 @@ inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
 // v_fract_f32 / v_sin_f32 / v_cos_f32 (the latter two take REVOLUTIONS)
 inline float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_sinf(float r) { return (float)sin(6.283185307179586476925 * (double)r); }
 inline float __builtin_amdgcn_cosf(float r) { return (float)cos(6.283185307179586476925 * (double)r); }
 inline float __expf(float x) { return expf(x); }

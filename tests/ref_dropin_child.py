@@ -29,7 +29,7 @@ def main():
     fwd = build_cpu.build('sherf_hipcpu_full', SOURCES, tmp, compiler=build_cpu.CLANG)
     # the product on host tensors (what the cpu_product fixture of tests/test_hipcpu_frame.py does)
     _lib.LIB_PATH, _lib._lib = fwd, None
-    _lib.ptr = lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr())
+    _lib.ptr = lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr())
     _lib.addr = lambda t, dtype=None: None if t is None else t.data_ptr()
     _lib.stream = lambda: ctypes.c_void_p(0)
     torch.cuda.current_stream = lambda dev=None: type('S', (), {'cuda_stream': 0})()

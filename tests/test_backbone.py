@@ -74,7 +74,7 @@ def test_small_generator_matches_reference_through_the_hip_kernels_on_cpu(tmp_pa
     path = build_cpu.build('sherf_hipcpu_ops', ['ops_lib.hip', 'ops_bias_act.hip', 'ops_upfirdn2d.hip'], str(tmp_path_factory.mktemp('hipcpu_ops_bb')),
                            compiler=build_cpu.CLANG)
     monkeypatch.setattr(_lib, 'LIB_OPS_PATH', path); monkeypatch.setattr(_lib, '_lib_ops', None)
-    monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr()))
     monkeypatch.setattr(_lib, 'stream', lambda: ctypes.c_void_p(0))
     monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))       # every host tensor is a "device" tensor of the shim
     g = _seed(S.Generator(**SMALL))

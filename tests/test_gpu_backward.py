@@ -69,6 +69,11 @@ def test_bwd_gemm_all_transpositions():
             e.gemm(tA, tB, a_c, b_c, c_c, 0.5); h.gemm(tA, tB, a_g, b_g, c_g, 0.5)
             torch.cuda.synchronize()
             _same(c_c, c_g, 1e-4)
+            # gradient-sized operands (1e-7): an fp16 operand split underflows here; the bf16 split must not
+            a_c.tensor().mul_(1e-7); a_g.tensor().mul_(1e-7)
+            e.gemm(tA, tB, a_c, b_c, c_c, 0.0); h.gemm(tA, tB, a_g, b_g, c_g, 0.0)
+            torch.cuda.synchronize()
+            _same(c_c, c_g, 1e-4)
 
 
 def test_bwd_elementwise_kernels():

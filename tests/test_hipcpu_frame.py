@@ -114,6 +114,7 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
     monkeypatch.setattr(bench, 'torch_gpu_baseline_child',
                         lambda a, lrank, timeout=300, save=None: bench.torch_gpu_baseline(a.config, torch.device('cpu'), a.bn_mode == 'train', iters=1, save=save))
     monkeypatch.setattr(bench, 'pmc_traffic', lambda a, lrank, timeout=150: dict(hbm_bytes_per_launch=12345, note='faked'))
+    monkeypatch.setattr(bench, 'SECONDARY_ITERS', dict(mlp=1, mlp_warmup=0, frames=1, frames_warmup=0))
     fixtures.CONFIGS['cfg3'], keep3 = dict(fixtures.CONFIGS['tiny']), fixtures.CONFIGS['cfg3']          # the secondary workloads, tiny-sized here
     fixtures.CONFIGS['cfg2_dense'], keepd = dict(fixtures.CONFIGS['tiny'], fill=1.55), fixtures.CONFIGS['cfg2_dense']
     try:

@@ -24,7 +24,7 @@ def ops(tmp_path_factory):
                            compiler=build_cpu.CLANG)
     mp = pytest.MonkeyPatch()
     mp.setattr(_lib, 'LIB_OPS_PATH', path); mp.setattr(_lib, '_lib_ops', None)
-    mp.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    mp.setattr(_lib, 'ptr', lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr()))
     mp.setattr(_lib, 'stream', lambda: ctypes.c_void_p(0))
     from sherf_amd import bias_act, upfirdn2d
     yield bias_act, upfirdn2d

@@ -22,7 +22,7 @@ def stubbed(monkeypatch):
     calls, frames = [], []
     monkeypatch.setattr(_lib, 'call', lambda name, *a: calls.append((name, a)))
     monkeypatch.setattr(_lib, 'addr', lambda t, dtype=None: None if t is None else t.data_ptr())
-    monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None: None if t is None else ctypes.c_void_p(t.data_ptr()))
+    monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr()))
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: type('S', (), {'cuda_stream': 0})())
     orig = _lib.Frame
 

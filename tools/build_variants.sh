@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds alternative libraries (same ABI) with kernel-variant macros / flags of csrc/mlp.hip for A/B runs with tools/mlp_trace.py:
+# Builds alternative libraries (same ABI) with kernel-variant macros / flags for A/B runs (tools/mlp_trace.py, SHERF_HIP_LIB=...):
 #   bash tools/build_variants.sh [tag ...]   -> sherf_amd/libsherf_hip_<tag>.so   (git-ignored, travel with gpurun)
 set -e
 cd "$(dirname "$0")/.."
@@ -12,8 +12,9 @@ build() { # tag, source file (without .hip), defines...
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "/$src.o\|variant_\|bwd_\|ops_") build/variant_$tag.o -o libsherf_hip_$tag.so
   echo "built libsherf_hip_$tag.so ($src: $*)"
 }
-declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0"
-                  [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" )
-TAGS=${@:-trace prio0 slowmath nodma nobar}
-for t in $TAGS; do build $t mlp ${DEFS[$t]} & done
+declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0" [nomix]="-DSHERF_MLP_FMA_MIX=0"
+                  [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [stag30]="-DSHERF_MLP_STAGGER=30000" [stag55]="-DSHERF_MLP_STAGGER=55000" [stag80]="-DSHERF_MLP_STAGGER=80000" [nn16]="-DSHERF_NN_WAVES=16" [nn12]="-DSHERF_NN_WAVES=12" )
+declare -A SRC=( [nn16]=sample [nn12]=sample )
+TAGS=${@:-trace nodma}
+for t in $TAGS; do build $t ${SRC[$t]:-mlp} ${DEFS[$t]} & done
 wait

@@ -74,7 +74,7 @@ def main():
     libs = {'product': os.path.join(ROOT, 'sherf_amd', 'libsherf_hip.so')}
     for path in sorted(glob.glob(os.path.join(ROOT, 'sherf_amd', 'libsherf_hip_*.so'))):
         tag = os.path.basename(path)[len('libsherf_hip_'):-3]
-        if tag not in ('bwd', 'ops'):
+        if tag not in ('bwd', 'ops') and not tag.startswith('nn'):        # (nn*: sampler variants, same MLP)
             libs[tag] = path
     bound = {t: bind(p) for t, p in libs.items()}
     launch(bound['product'][1]); torch.cuda.synchronize()
@@ -133,6 +133,29 @@ def main():
         for k, v in rep['classes'].items():
             print(f'        {k:12s} x{v["steps"]:2d}: compute {v["compute"]:7.0f}  vmcnt {v["vmcnt_wait"]:6.0f}  barrier {v["barrier_wait"]:6.0f}')
         print('        per-step compute:', ' '.join(f'{x:.0f}' for x in rep['per_step']['compute']), '| last', f'{rep["per_step"]["last_step_compute"]:.0f}')
+        # ---- are the two workgroups of a CU in phase?  every workgroup traced once: start / end stamps + its CU (HW_ID, XCC_ID) ----
+        buf2 = torch.zeros(groups * 8 * 256, dtype=torch.int32, device=dev)
+        assert lib.sherf_mlp_set_trace(buf2.data_ptr(), 1) == 0
+        launch(f); torch.cuda.synchronize()
+        t2 = (buf2.cpu().numpy().astype(np.int64).reshape(groups, 8, 64, 4)[:, 0]) & 0xffffffff          # wave 0 of every workgroup
+        s0, hw, e0, xcc = t2[:, 63, 0], t2[:, 63, 1], t2[:, 63, 2], t2[:, 63, 3] & 0xf
+        cu_key = (xcc << 16) | (hw & 0xff00)                                                              # XCC | SE, SH, CU
+        T = float(np.median((e0 - s0) & 0xffffffff))
+        phases, slots = [], []
+        for key in np.unique(cu_key):
+            idx = np.nonzero(cu_key == key)[0]
+            idx = idx[np.argsort(s0[idx])]
+            for a_, i in enumerate(idx):
+                for j in idx[:a_]:
+                    if ((s0[i] - s0[j]) & 0xffffffff) < ((e0[j] - s0[j]) & 0xffffffff):                   # j still running when i starts
+                        phases.append(((s0[i] - s0[j]) & 0xffffffff) / T)
+                        slots.append((int(hw[i] & 0xf), int(hw[j] & 0xf)))
+        ph = np.array(phases)
+        hist = np.histogram(ph, bins=10, range=(0, 1))[0]
+        rep['phase'] = dict(tile_cycles=T, cus=int(len(np.unique(cu_key))), pairs=int(len(ph)), hist_start_offset_over_T=[int(x) for x in hist],
+                            wave_slot_pairs_sample=slots[:8])
+        print(f'[phase] {len(np.unique(cu_key))} CUs, tile {T:.0f} cycles, co-resident start offsets / T histogram (0..1 in tenths): {hist.tolist()}')
+        print(f'        wave slots of co-resident pairs (new, old): {slots[:8]}')
         assert lib.sherf_mlp_set_trace(None, 0) == 0
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(report, open(a.out, 'w'), indent=1)
