@@ -97,30 +97,50 @@ __device__ __forceinline__ void nn_search(const CellGrid& g, const int32_t* __re
         }
 }
 
-// Radius <= cell special case: the ball lies inside the 3x3x3 neighbourhood of the query's own cell (cx,cy,cz), so the
-// nine x-contiguous segments are fetched with 18 INDEPENDENT loads up front (memory-level parallelism) before any
-// point is examined.
-__device__ __forceinline__ void nn_search27(const CellGrid& g, const int32_t* __restrict__ cell_start,
-                                            const float4* __restrict__ pts, float x, float y, float z, int cx, int cy, int cz,
-                                            float& best_d2, int& best_id) {
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    int s[9], e[9];
+// The same search with the memory accesses batched (one thread per query, nothing else to hide a load behind): when the ball
+// reaches at most 3 x 3 rows of cells (always, for a radius <= the cell size) the 18 row bounds are fetched together, then the points of
+// the concatenated segments four at a time.  Same candidate set and the same lexicographic minimum as nn_search -- the result does
+// not depend on the order of examination.  A wider ball takes the plain loops.
+__device__ __forceinline__ void nn_search_batched(const CellGrid& g, const int32_t* __restrict__ cell_start,
+                                                  const float4* __restrict__ pts, float x, float y, float z, float r,
+                                                  float& best_d2, int& best_id) {
+    const float rr = r + 1e-4f * g.cell;
+    int x0 = (int)floorf((x - rr - g.ox) * g.inv_cell), x1 = (int)floorf((x + rr - g.ox) * g.inv_cell);
+    int y0 = (int)floorf((y - rr - g.oy) * g.inv_cell), y1 = (int)floorf((y + rr - g.oy) * g.inv_cell);
+    int z0 = (int)floorf((z - rr - g.oz) * g.inv_cell), z1 = (int)floorf((z + rr - g.oz) * g.inv_cell);
+    x0 = max(x0, 0); y0 = max(y0, 0); z0 = max(z0, 0);
+    x1 = min(x1, g.nx - 1); y1 = min(y1, g.ny - 1); z1 = min(z1, g.nz - 1);
+    if (x0 > x1 || y0 > y1 || z0 > z1) return;
+    if (y1 - y0 > 2 || z1 - z0 > 2) { nn_search(g, cell_start, pts, x, y, z, r, best_d2, best_id); return; }
+    int s[9], cum[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
-        const bool ok = qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny;
-        const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
+        const int cz = z0 + i / 3, cy = y0 + i % 3;
+        const bool ok = cz <= z1 && cy <= y1;
+        const int row = ok ? (cz * g.ny + cy) * g.nx : 0;
         s[i] = cell_start[row + x0];
-        e[i] = ok ? cell_start[row + x1 + 1] : s[i];
+        cum[i] = ok ? cell_start[row + x1 + 1] : s[i];          // (end of the segment for now)
     }
+    int n = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
-        for (int p = s[i]; p < e[i]; ++p) {
-            const float4 q = pts[p];
-            const float d2 = dist2_exact(x, y, z, q.x, q.y, q.z);
-            const int id = __float_as_int(q.w);
-            if (d2 < best_d2 || (d2 == best_d2 && id < best_id)) { best_d2 = d2; best_id = id; }
+    for (int i = 0; i < 9; ++i) { n += cum[i] - s[i]; cum[i] = n; }
+    for (int base = 0; base < n; base += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = base + u;
+            int p = s[0] + t;
+#pragma unroll
+            for (int i = 1; i < 9; ++i) p = (t >= cum[i - 1]) ? s[i] + (t - cum[i - 1]) : p;
+            v[u] = pts[t < n ? p : 0];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d2 = dist2_exact(x, y, z, v[u].x, v[u].y, v[u].z);
+            const int id = __float_as_int(v[u].w);
+            if (base + u < n && (d2 < best_d2 || (d2 == best_d2 && id < best_id))) { best_d2 = d2; best_id = id; }
+        }
+    }
 }
 
 // order-preserving float <-> int map for atomicMin/atomicMax on floats of any sign

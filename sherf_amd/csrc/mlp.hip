@@ -157,14 +157,6 @@ __device__ int g_mlp_trace_every = 0;
 #define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
 #endif
 
-// SHERF_MLP_STAGGER (experiment; cycles, 0 = off): the two workgroups of a CU are dispatched together at launch and every tile costs the
-// same, so they march in PHASE -- both in the VALU-bound transformer, then both in the MFMA-bound decoder -- and the SIMD's two
-// pipes are never busy together.  With a stagger the first-generation workgroup in the odd wave slot idles for that many cycles once;
-// every later generation inherits the offset (a new workgroup starts when an old one ends).
-#ifndef SHERF_MLP_STAGGER
-#define SHERF_MLP_STAGGER 0
-#endif
-
 // SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers
 #ifndef SHERF_MLP_ABLATE
 #define SHERF_MLP_ABLATE 0
@@ -459,8 +451,7 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, 2)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out,
-                uint32_t stagger_first_gen) {
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
@@ -487,15 +478,6 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
 
-#if SHERF_MLP_STAGGER
-    if (blockIdx.x < 2u * stagger_first_gen) {                        // first generation only: two workgroups per CU
-        const uint32_t hw_id = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        if (hw_id & 1u) {                                             // WAVE_ID bit 0: the second wave slot of this SIMD
-            const uint64_t t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)SHERF_MLP_STAGGER) __builtin_amdgcn_s_sleep(64);
-        }
-    }
-#endif
     dma_issue(cx, 0);
     dma_issue(cx, 1);
     wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
@@ -801,9 +783,9 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
     const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
     if (prec == 1)
         hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), (uint32_t)n_cus());
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     else
         hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), (uint32_t)n_cus());
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     SHERF_LAUNCH_CHECK();
 }

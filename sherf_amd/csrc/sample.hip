@@ -224,31 +224,25 @@ __device__ __forceinline__ float depth_at(float near, float range, int k, int S)
     return __fadd_rn(near, __fmul_rn(step, range));
 }
 
-// One wave per ray at a time, PERSISTENT workgroups of 16 waves (one per CU) that keep the whole cell-sorted vertex table in LDS
-// (SMPL: 6890 points as x[], y[], z[] fp32 + u16 id = 94 KiB; loaded once per workgroup, 24 MB of L2 reads per launch).
-// Candidate samples (near-mask hit: ~12 % of the samples, ~30 on a ray that crosses the body) are searched by EIGHT-LANE GROUPS,
-// eight candidates at a time: each candidate lane first fetches the nine x-contiguous point segments of its 3x3x3 cell
-// neighbourhood, trimmed to the cells its 5 cm ball reaches (18 independent loads, all candidates in parallel), and parks them with
-// its position in an LDS record; then group g of a round takes candidate 8 r + g, its 8 lanes walk the concatenated segments 8 points
-// per step, and the lexicographic minimum of (d^2, vertex id) is taken with a 64-bit LDS atomic min per group (d^2 >= 0, so the IEEE
-// bit pattern orders like the value; only points inside the 5 cm threshold ever reach the atomic).
-// History (profiles/): round 1 searched ONE candidate per step with all 64 lanes -- one dependent L2 round trip per candidate,
-// ~30 per wave: 450 us.  Eight candidates per round with the points still read from L2: 339 us, of which 72 us is everything but the
-// search (profiles/r02_kernel_trace_v3_sampler_no_candidates.txt) -- what was left was the ~4 dependent L2 trips of the rounds.  With
-// the points in LDS a ray's dependent global accesses are two (near-mask word, segment bounds).
-struct Cand { float x, y, z; uint16_t s[9]; uint16_t cum[9]; unsigned long long key; };     // 14 dwords
+// One wave per ray.  Candidate samples (near-mask hit: ~12 % of the samples, ~30 on a ray that crosses the body) are searched by
+// EIGHT-LANE GROUPS, eight candidates at a time: each candidate lane first fetches the nine x-contiguous point segments of its
+// 3x3x3 cell neighbourhood, trimmed to the cells its 5 cm ball reaches (18 independent loads, all candidates in parallel), and parks
+// them with its position in an LDS record;
+// then group g of a round takes candidate 8 r + g, its 8 lanes walk the concatenated segments 8 points per step with every step's
+// loads in flight before the first distance is evaluated, and the lexicographic minimum of (d^2, vertex id) is taken with a 64-bit
+// LDS atomic min per group (d^2 >= 0, so the IEEE bit pattern orders like the value; only points inside the 5 cm threshold ever
+// reach the atomic).  Round 1 searched ONE candidate per step with all 64 lanes: one dependent L2 round trip per candidate,
+// ~30 per wave, was what the kernel's 450 us consisted of; a round of eight costs about the same trip.
+// The record is 14 dwords (segment starts and cumulative counts as u16: at most 65535 points, enforced where the cells are built):
+// four waves' records take 14 KiB of LDS, eight waves per SIMD are resident (24-dword records: six).  More resident rays is what
+// this latency-bound kernel wants -- round 2 also tried the opposite trade, persistent workgroups holding the whole vertex table
+// in LDS (no L2 trips in the rounds, but 8-16 waves per CU): 1.0-1.5 ms (profiles/r02_kernel_trace_v5_lds_sampler_rejected.txt).
+struct Cand { float x, y, z; uint16_t s[9]; uint16_t cum[9]; unsigned long long key; };
 static_assert(sizeof(Cand) == 56, "candidate record layout");
-#ifndef SHERF_NN_WAVES
-#define SHERF_NN_WAVES 8
-#endif
-constexpr int kNnWaves = SHERF_NN_WAVES;           // waves per workgroup (8: 122 KiB of LDS, leaves room for an encoder workgroup on the CU)
-constexpr int kMaxPtsUnroll = 4;                   // point fetches in flight per lane and step group (8 lanes x 4 = 32 points)
-constexpr int kNnPtsBytes = (SHERF_V * 14 + 15) / 16 * 16;
-constexpr int kNnLdsBytes = kNnPtsBytes + kNnWaves * 64 * (int)sizeof(Cand);
-static_assert(kNnLdsBytes <= 160 * 1024 && SHERF_V < 65536, "vertex table + candidate records must fit one CU's LDS; ids are u16");
+constexpr int kMaxPtsUnroll = 4;                   // point loads in flight per lane and step group (8 lanes x 4 = 32 points)
 
 template <int NCH>
-__global__ void __launch_bounds__(kNnWaves * 64) sample_nn_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+__global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                         const float* __restrict__ near, const float* __restrict__ far,
                                                         int R, int S, const float* __restrict__ Rg,
                                                         const float* __restrict__ Th, const float* __restrict__ hdr,
@@ -257,30 +251,17 @@ __global__ void __launch_bounds__(kNnWaves * 64) sample_nn_kernel(const float* _
                                                         const uint32_t* __restrict__ near_mask,
                                                         int32_t* __restrict__ ray_cnt, uint64_t* __restrict__ ray_mask,
                                                         int32_t* __restrict__ dense_vid, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) char s_nn[];
-    float* const s_px = reinterpret_cast<float*>(s_nn);
-    float* const s_py = s_px + SHERF_V;
-    float* const s_pz = s_py + SHERF_V;
-    uint16_t* const s_id = reinterpret_cast<uint16_t*>(s_pz + SHERF_V);
+    __shared__ Cand s_cand[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= R) return;
     const CellGrid g = load_grid(hdr);
-    // the table holds every point of the grid when there are at most SHERF_V of them (always, for SMPL); a larger point set is read
-    // from global memory instead (same arithmetic, uniform branch)
-    const int n_pts = cell_start[g.nx * g.ny * g.nz];
-    const bool in_lds = n_pts <= SHERF_V;
-    if (in_lds)
-        for (int i = threadIdx.x; i < n_pts; i += kNnWaves * 64) {
-            const float4 v = cell_pts[i];
-            s_px[i] = v.x; s_py[i] = v.y; s_pz[i] = v.z; s_id[i] = (uint16_t)__float_as_int(v.w);
-        }
-    __syncthreads();
-    const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
-    Cand* const rec = reinterpret_cast<Cand*>(s_nn + kNnPtsBytes) + wave * 64;
-    const int grp = lane >> 3, sub = lane & 7;
-    for (int ray = blockIdx.x * kNnWaves + wave; ray < R; ray += gridDim.x * kNnWaves) {
     const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
     const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
     const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+    const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
+    Cand* const rec = s_cand[wave];
+    const int grp = lane >> 3, sub = lane & 7;
     int total = 0;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -328,10 +309,7 @@ __global__ void __launch_bounds__(kNnWaves * 64) sample_nn_kernel(const float* _
             }
             int cum = 0;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                // u16 fields: starts < 65536 points (host check), a ball's point count saturates far below (a segment spans <= 3 cells)
-                c.s[i] = (uint16_t)st[i]; cum += en[i] - st[i]; c.cum[i] = (uint16_t)min(cum, 65535);
-            }
+            for (int i = 0; i < 9; ++i) { c.s[i] = (uint16_t)st[i]; cum += en[i] - st[i]; c.cum[i] = (uint16_t)cum; }
         }
         __builtin_amdgcn_wave_barrier();             // (the wave runs in lockstep; the LDS records are ordered by s_waitcnt lgkmcnt)
         for (int c0 = 0; c0 < ncand; c0 += 8) {
@@ -344,24 +322,21 @@ __global__ void __launch_bounds__(kNnWaves * 64) sample_nn_kernel(const float* _
                 for (int i = 0; i < 9; ++i) { bs[i] = c.s[i]; cum[i] = c.cum[i]; }
                 const int npts = cum[8];
                 for (int base = 0; base < npts; base += 8 * kMaxPtsUnroll) {
-                    float vx[kMaxPtsUnroll], vy[kMaxPtsUnroll], vz[kMaxPtsUnroll];
-                    int vid[kMaxPtsUnroll];
+                    float4 v[kMaxPtsUnroll];
 #pragma unroll
                     for (int u = 0; u < kMaxPtsUnroll; ++u) {
                         const int t = base + u * 8 + sub;
                         int p = bs[0] + t;
 #pragma unroll
                         for (int i = 1; i < 9; ++i) p = (t >= cum[i - 1]) ? bs[i] + (t - cum[i - 1]) : p;
-                        p = t < npts ? p : 0;
-                        if (in_lds) { vx[u] = s_px[p]; vy[u] = s_py[p]; vz[u] = s_pz[p]; vid[u] = s_id[p]; }
-                        else { const float4 v = cell_pts[p]; vx[u] = v.x; vy[u] = v.y; vz[u] = v.z; vid[u] = __float_as_int(v.w); }
+                        v[u] = cell_pts[t < npts ? p : 0];
                     }
 #pragma unroll
                     for (int u = 0; u < kMaxPtsUnroll; ++u) {
                         const int t = base + u * 8 + sub;
-                        const float dd = dist2_exact(qx, qy, qz, vx[u], vy[u], vz[u]);
+                        const float dd = dist2_exact(qx, qy, qz, v[u].x, v[u].y, v[u].z);
                         if (t < npts && dd < kThresh2)
-                            atomicMin(&c.key, ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)vid[u]);
+                            atomicMin(&c.key, ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u].w));
                     }
                 }
             }
@@ -376,7 +351,6 @@ __global__ void __launch_bounds__(kNnWaves * 64) sample_nn_kernel(const float* _
         total += __popcll(m);
     }
     if (lane == 0) ray_cnt[ray] = total;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -519,7 +493,7 @@ __global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restric
     float best = dist2_exact(xc, yc, zc, t_verts[vid * 3], t_verts[vid * 3 + 1], t_verts[vid * 3 + 2]);
     int bid = vid;
     float r = sqrtf(best) * 1.00001f + 1e-6f;
-    nn_search(g, tcell_start, tcell_pts, xc, yc, zc, r, best, bid);
+    nn_search_batched(g, tcell_start, tcell_pts, xc, yc, zc, r, best, bid);
     const float* L = C2S + (size_t)bid * 12;
     float hx = L[0] * xc + L[1] * yc + L[2] * zc + L[9];
     float hy = L[3] * xc + L[4] * yc + L[5] * zc + L[10];
@@ -537,7 +511,7 @@ extern "C" int sherf_build_cells(const float* verts, int n, const float* R, cons
                                  float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                                  uint32_t* near_mask, sherf_stream_t stream) {
     SHERF_CHECK_ARG(verts && grid_hdr && cell_start && cell_pts && scratch);
-    SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
+    SHERF_CHECK_ARG(n > 0 && n <= 65535 && cell_size > 0.f);        // (u16 point indices in the sampler's candidate records)
     SHERF_CHECK_ARG((R == nullptr) == (Th == nullptr));
     hipLaunchKernelGGL(build_cells_kernel, dim3(1), dim3(1024), 0, as_stream(stream), verts, n, R, Th, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
@@ -553,7 +527,7 @@ extern "C" int sherf_build_cells2(const float* verts_a, const float* R_a, const 
                                   float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                                   uint32_t* near_mask, sherf_stream_t stream) {
     SHERF_CHECK_ARG(verts_a && R_a && Th_a && verts_b && grid_hdr && cell_start && cell_pts && scratch && near_mask);
-    SHERF_CHECK_ARG(n > 0 && n <= 65536 && cell_size > 0.f);
+    SHERF_CHECK_ARG(n > 0 && n <= 65535 && cell_size > 0.f);        // (u16 point indices in the sampler's candidate records)
     hipLaunchKernelGGL(build_cells2_kernel, dim3(2), dim3(1024), 0, as_stream(stream), verts_a, R_a, Th_a, verts_b, n, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
     (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
@@ -579,16 +553,9 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     const float4* cp = reinterpret_cast<const float4*>(cell_pts);
     hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters);
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
-    // one persistent workgroup per CU (its LDS holds the vertex table)
-    static const int nn_env = getenv("SHERF_NN_GRID") ? atoi(getenv("SHERF_NN_GRID")) : 0;     // experiment: fewer workgroups than CUs
-    const int nn_grid = min(nn_env > 0 ? nn_env : n_cus(), cdiv(R, kNnWaves));
 #define SHERF_SAMPLE_LAUNCH(N)                                                                                        \
-    do {                                                                                                              \
-        SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_nn_kernel<N>),                      \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kNnLdsBytes));                \
-        hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(nn_grid), dim3(kNnWaves * 64), kNnLdsBytes, st, ray_o, ray_d, near, far, R, S, \
-                           Rg, Th, grid_hdr, cell_start, cp, near_mask, ray_cnt, ray_mask, dense_vid, g_sherf_debug);  \
-    } while (0)
+    hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
+                       grid_hdr, cell_start, cp, near_mask, ray_cnt, ray_mask, dense_vid, g_sherf_debug)
     if (nch == 1) SHERF_SAMPLE_LAUNCH(1); else if (nch == 2) SHERF_SAMPLE_LAUNCH(2);
     else if (nch == 3) SHERF_SAMPLE_LAUNCH(3); else SHERF_SAMPLE_LAUNCH(4);
     hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, ray_cnt, R, base_local, chunk_sum);

@@ -195,13 +195,30 @@ struct BnIn {
     float* bnparam;             // [3][Cin] scale, shift, relu(shift)
 };
 
+// SHERF_SCONV_TRACE (profiling builds only, tools/sconv_trace.py): wave 0 of every workgroup stamps s_memtime at its phase boundaries
+// into a global record [launch id, block, rows, NCOT << 8 | NKB, 12 stamps].
+#ifndef SHERF_SCONV_TRACE
+#define SHERF_SCONV_TRACE 0
+#endif
+#if SHERF_SCONV_TRACE
+__device__ uint32_t* g_sconv_trace = nullptr;
+__device__ unsigned g_sconv_trace_cap = 0, g_sconv_trace_n = 0;
+#define SCONV_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SCONV_STAMP(k) do { } while (0)
+#endif
+
 template <int NCOT, int NKB>   // Cout = 32 * NCOT, Cin = 16 * NKB
 __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, BnIn bin,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
-                                                     float* __restrict__ out_raw, long long* __restrict__ out_acc) {
+                                                     float* __restrict__ out_raw, long long* __restrict__ out_acc, int trace_id) {
     constexpr int COUT = 32 * NCOT, Cin = 16 * NKB;
+#if SHERF_SCONV_TRACE
+    uint32_t stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    SCONV_STAMP(0);
+#endif
     // the encoder is a short serial chain of small launches running next to the ray side's chip-filling kernels: its
     // waves take issue priority over co-resident waves (measured -20..30 us per frame; sherf_set_debug bit 7 turns it off)
     if (!(mode & 256)) __builtin_amdgcn_s_setprio(3);
@@ -215,27 +232,39 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     if (row0 >= n_rows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntaps = mode == 2 ? 1 : 27;
-    for (int i = tid; i < ntaps * 32; i += 256) {
-        const int tap = i >> 5, r = i & 31, row = row0 + r;
-        int nb = -1;
-        if (row < n_rows) {
-            if (mode == 2) nb = row;
-            else {
-                const int key = keys_out[row];
-                const int z = key / (Ho * Wo), y = (key / Wo) % Ho, x = key % Wo;
-                const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-                const int qz = mode ? 2 * z + kz - 1 : z + kz - 1, qy = mode ? 2 * y + ky - 1 : y + ky - 1,
-                          qx = mode ? 2 * x + kx - 1 : x + kx - 1;
-                if (qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi) {
-                    const int qk = (qz * Hi + qy) * Wi + qx;
-                    const uint2 rec = wp_in[qk >> 5];
-                    const uint32_t bit = 1u << (qk & 31);
-                    if (rec.x & bit) nb = (int)rec.y + __popc(rec.x & (bit - 1u));
-                }
-            }
+    {   // neighbour table: thread -> row tid & 31, taps (tid >> 5) + 8 j.  The row's key is read once and the (up to) four bitmap
+        // records are fetched together: two dependent L2 trips per workgroup instead of seven (profiles/r02_sconv_trace_v1.txt:
+        // this table was 6-8 K of a workgroup's 17-70 K cycles)
+        const int rr = tid & 31, row = row0 + rr;
+        const bool live = row < n_rows;
+        const int key = (live && mode != 2) ? keys_out[row] : 0;
+        const int z = key / (Ho * Wo), y = (key / Wo) % Ho, x = key % Wo;
+        int qk[4];
+        uint2 rec[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tap = (tid >> 5) + 8 * j;
+            const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+            const int qz = mode ? 2 * z + kz - 1 : z + kz - 1, qy = mode ? 2 * y + ky - 1 : y + ky - 1, qx = mode ? 2 * x + kx - 1 : x + kx - 1;
+            const bool ok = live && mode != 2 && tap < 27 && qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi;
+            qk[j] = ok ? (qz * Hi + qy) * Wi + qx : -1;
         }
-        s_nb[i] = nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rec[j] = qk[j] >= 0 ? wp_in[qk[j] >> 5] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tap = (tid >> 5) + 8 * j;
+            if (tap >= ntaps) continue;
+            int nb = -1;
+            if (mode == 2) nb = live ? row : -1;
+            else if (qk[j] >= 0) {
+                const uint32_t bit = 1u << (qk[j] & 31);
+                if (rec[j].x & bit) nb = (int)rec[j].y + __popc(rec[j].x & (bit - 1u));
+            }
+            s_nb[tap * 32 + rr] = nb;
+        }
     }
+    SCONV_STAMP(1);                                  // neighbour table done (this thread's share)
     const bool in_bn = bin.bnparam != nullptr;
     if (in_bn) {
         if (bin.acc) {
@@ -258,7 +287,9 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             for (int i = tid; i < 3 * Cin; i += 256) s_bn[i] = bin.bnparam[i];
         }
     }
+    SCONV_STAMP(2);                                  // BatchNorm prologue done
     __syncthreads();
+    SCONV_STAMP(3);
 
     f32x16_t acc[NCOT];
 #pragma unroll
@@ -275,32 +306,39 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     if (mode == 2) tapmask = wave < NCOT ? 1u : 0u;
     tapmask = __builtin_amdgcn_readfirstlane(tapmask);
 
-    // The tile is a chain of dependent gathers (neighbour row -> MFMA); with ~2 waves per SIMD nothing hides their latency
-    // unless the loads are issued ahead: a whole neighbour row (all k-blocks) is fetched one tap ahead, the weight
-    // fragments one k-block ahead.  Lanes without that neighbour read row 0 and are zeroed after the BatchNorm transform
-    // (no divergent control flow in the pipeline).
+    // The tile is a chain of dependent gathers (neighbour row, weight fragments -> MFMA) and a workgroup is alone or nearly alone on
+    // its CU (85-600 workgroups per launch), so nothing hides a load that is not issued well ahead.  Round 2's in-kernel timeline
+    // (profiles/r02_sconv_trace_v1.txt) showed one exposed L2 round trip PER K-BLOCK (weights fetched one K-block ahead: 3-8 K cycles
+    // per tap, 60-75 % of a workgroup's life).  Now every buffer is refilled IN PLACE right after its last use with the data of the
+    // tap PF taps ahead -- rows and weight fragments, K-block by K-block -- so every load has PF whole taps of work in front of it.
+    // PF is chosen by the register cost of a tap (rows 2 NKB + weights 2 NKB NCOT uint4): 3 / 2 / 1 taps.  Lanes without that
+    // neighbour read row 0 and are zeroed after the BatchNorm transform (no divergent control flow in the pipeline).  The order of
+    // the accumulation is unchanged (taps ascending per wave, K-blocks ascending): results are bit-identical to the simple loop.
+    constexpr int PF = NKB * NCOT <= 2 ? 3 : (NKB * NCOT <= 4 ? 2 : 1);   // (32 -> 32 at PF 4 costs 198 registers: 2 workgroups per CU, and level 1 launches 602)
     struct Row { float4 v[2 * NKB]; int nb; float mlt; };
-    auto load_row = [&](int tap, Row& R) {
-        const int nb = s_nb[tap * 32 + r];
-        R.nb = nb;
-        R.mlt = (in_mult && nb >= 0) ? (float)(in_mult[nb] - 1) : 0.f;
-        const float4* src = reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) { R.v[2 * kb] = src[4 * kb]; R.v[2 * kb + 1] = src[4 * kb + 1]; }
-    };
+    struct Wts { uint4 w[NKB][2 * NCOT]; };
+    auto row_src = [&](int nb) { return reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h; };
+    auto row_mult = [&](int nb) { return (in_mult && nb >= 0) ? (float)(in_mult[nb] - 1) : 0.f; };
     auto load_w = [&](int tap, int kb, uint4 (&w)[2 * NCOT]) {
         const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
 #pragma unroll
         for (int c = 0; c < 2 * NCOT; ++c)
             if (csel < 0 || (c >> 1) == csel) w[c] = wsrc[c * 64];
     };
-    auto compute = [&](int tap, const Row& R) {
-        uint4 w[2 * NCOT];
-        load_w(tap, 0, w);
+    auto load_all = [&](int tap, Row& R, Wts& W) {
+        const int nb = s_nb[tap * 32 + r];
+        R.nb = nb; R.mlt = row_mult(nb);
+        const float4* src = row_src(nb);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) { R.v[2 * kb] = src[4 * kb]; R.v[2 * kb + 1] = src[4 * kb + 1]; load_w(tap, kb, W.w[kb]); }
+    };
+    // one tap out of (R, W); each K-block's registers are refilled with tap `nxt`'s data (nxt < 0: nothing left to fetch) as soon as used
+    auto compute = [&](Row& R, Wts& W, int nxt) {
+        const int nb_next = nxt >= 0 ? s_nb[nxt * 32 + r] : -1;
+        const float mlt_next = nxt >= 0 ? row_mult(nb_next) : 0.f;
+        const float4* src_next = row_src(nb_next);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            uint4 wn[2 * NCOT];
-            if (kb + 1 < NKB) load_w(tap, kb + 1, wn);
             const float4 a = R.v[2 * kb], b = R.v[2 * kb + 1];
             float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             if (in_bn) {
@@ -318,41 +356,57 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
 #pragma unroll
             for (int c = 0; c < NCOT; ++c) {
                 if (csel >= 0 && c != csel) continue;
-                const uint4 bhi = w[2 * c], blo = w[2 * c + 1];
+                const uint4 bhi = W.w[kb][2 * c], blo = W.w[kb][2 * c + 1];
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
             }
-            if (kb + 1 < NKB) {
-#pragma unroll
-                for (int c = 0; c < 2 * NCOT; ++c) w[c] = wn[c];
+            if (nxt >= 0) {                          // uniform
+                R.v[2 * kb] = src_next[4 * kb]; R.v[2 * kb + 1] = src_next[4 * kb + 1];
+                load_w(nxt, kb, W.w[kb]);
             }
         }
+        R.nb = nb_next; R.mlt = mlt_next;
     };
     auto next_tap = [&](int tap) -> int {           // next set bit above `tap`, -1 if none (uniform)
         const uint32_t rest = tap >= 31 ? 0u : (tapmask & ~((2u << tap) - 1u));
         return rest ? __ffs(rest) - 1 : -1;
     };
-    int tap = tapmask ? __ffs(tapmask) - 1 : -1;
-    Row ra, rb;
-    if (tap >= 0) load_row(tap, ra);
-    while (tap >= 0) {                              // ping-pong between the two row buffers
-        int nt = next_tap(tap);
-        if (nt >= 0) load_row(nt, rb);
-        compute(tap, ra);
-        tap = nt;
-        if (tap < 0) break;
-        nt = next_tap(tap);
-        if (nt >= 0) load_row(nt, ra);
-        compute(tap, rb);
-        tap = nt;
+    Row rows[PF];
+    Wts wts[PF];
+    int taps[PF];
+    int t = tapmask ? __ffs(tapmask) - 1 : -1;      // the next tap nobody has fetched yet
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        taps[p] = t;
+        if (t >= 0) { load_all(t, rows[p], wts[p]); t = next_tap(t); }
     }
+    SCONV_STAMP(4);                                  // tap mask + the first PF taps issued
+#if SHERF_SCONV_TRACE
+    int n_done = 0;
+#endif
+    for (bool more = taps[0] >= 0; more;) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (taps[p] < 0) { more = false; break; }
+            compute(rows[p], wts[p], t);
+#if SHERF_SCONV_TRACE
+            if (n_done == 0) SCONV_STAMP(5);         // first tap of wave 0 done
+            ++n_done;
+#endif
+            taps[p] = t;
+            if (t >= 0) t = next_tap(t);
+        }
+    }
+    SCONV_STAMP(6);                                  // all taps of wave 0 done
     // D layout: lane = (col j = lane&31, half h), reg q <-> tile row (q&3) + 8*(q>>2) + 4*h
 #pragma unroll
     for (int c = 0; c < NCOT; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) s_red[((wave * 32) + (q & 3) + 8 * (q >> 2) + 4 * h) * COUT + c * 32 + r] = acc[c][q];
+    SCONV_STAMP(7);
     __syncthreads();
+    SCONV_STAMP(8);                                  // every wave's taps done
     constexpr int G = 256 / COUT;                       // row groups: 8 / 4 / 2
     const int g = tid / COUT, co = tid % COUT;
     float s1 = 0.f, s2 = 0.f;
@@ -374,7 +428,28 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
                       (unsigned long long)__double2ll_rn(t * kAccFix));
         }
     }
+#if SHERF_SCONV_TRACE
+    SCONV_STAMP(9);
+    if (threadIdx.x == 0 && g_sconv_trace) {
+        const unsigned slot = atomicAdd(&g_sconv_trace_n, 1u);
+        if (slot < g_sconv_trace_cap) {
+            uint32_t* d = g_sconv_trace + (size_t)slot * 16;
+            d[0] = (uint32_t)trace_id; d[1] = blockIdx.x; d[2] = (uint32_t)n_rows; d[3] = (NCOT << 8) | NKB | ((unsigned)mode << 16) | ((unsigned)n_done << 24);
+            for (int k = 0; k < 12; ++k) d[4 + k] = stamps[k];
+        }
+    }
+#endif
 }
+
+#if SHERF_SCONV_TRACE
+extern "C" int sherf_sconv_set_trace(void* buf, unsigned cap) {
+    const unsigned zero = 0;
+    SHERF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sconv_trace), &buf, sizeof(buf)));
+    SHERF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sconv_trace_cap), &cap, sizeof(cap)));
+    SHERF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sconv_trace_n), &zero, sizeof(zero)));
+    return SHERF_OK;
+}
+#endif
 
 // standalone form of the consumer prologue: acc (training) or running stats (eval) -> stats[2][C], bnparam[3][C]
 __global__ void __launch_bounds__(128) bn_finalize_kernel(const long long* __restrict__ acc, const int32_t* __restrict__ n_total_p, int C,
@@ -502,7 +577,9 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
 #define SHERF_CONV3(N, K)                                                                                                    \
     hipLaunchKernelGGL((sconv3_kernel<N, K>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,           \
                        reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                                 \
-                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, reinterpret_cast<long long*>(out_acc))
+                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id)
+    static int trace_launches = 0;                  // (profiling builds: launch ordinal -> the records' first word)
+    const int trace_id = SHERF_SCONV_TRACE ? trace_launches++ : 0;
     const int sel = (Cout / 32) * 10 + Cin / 16;
     switch (sel) {
         case 12: SHERF_CONV3(1, 2); break;     // 32 -> 32

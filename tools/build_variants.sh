@@ -13,8 +13,8 @@ build() { # tag, source file (without .hip), defines...
   echo "built libsherf_hip_$tag.so ($src: $*)"
 }
 declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0" [nomix]="-DSHERF_MLP_FMA_MIX=0"
-                  [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [stag30]="-DSHERF_MLP_STAGGER=30000" [stag55]="-DSHERF_MLP_STAGGER=55000" [stag80]="-DSHERF_MLP_STAGGER=80000" [nn16]="-DSHERF_NN_WAVES=16" [nn12]="-DSHERF_NN_WAVES=12" )
-declare -A SRC=( [nn16]=sample [nn12]=sample )
+                  [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [sconvtrace]="-DSHERF_SCONV_TRACE=1" )
+declare -A SRC=( [sconvtrace]=svox )
 TAGS=${@:-trace nodma}
 for t in $TAGS; do build $t ${SRC[$t]:-mlp} ${DEFS[$t]} & done
 wait

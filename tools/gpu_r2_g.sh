@@ -13,13 +13,11 @@ L=$GRAFT_REPO_ROOT/sherf_amd
 $B 2>/dev/null | grep '"metric"' | pr nn8_default
 SHERF_NN_GRID=192 $B 2>/dev/null | grep '"metric"' | pr nn8_grid192
 SHERF_NN_GRID=128 $B 2>/dev/null | grep '"metric"' | pr nn8_grid128
-SHERF_NN_GRID=512 $B 2>/dev/null | grep '"metric"' | pr nn8_grid512
 SHERF_HIP_LIB=$L/libsherf_hip_nn16.so $B 2>/dev/null | grep '"metric"' | pr nn16_default
 SHERF_HIP_LIB=$L/libsherf_hip_nn16.so SHERF_NN_GRID=192 $B 2>/dev/null | grep '"metric"' | pr nn16_grid192
 SHERF_HIP_LIB=$L/libsherf_hip_nn12.so $B 2>/dev/null | grep '"metric"' | pr nn12_default
-$B --exact-grids 2>/dev/null | grep '"metric"' | pr nn8_exact_grids
 SHERF_HIP_LIB=$L/libsherf_hip_stag55.so $B 2>/dev/null | grep '"metric"' | pr stag55_frame
-SHERF_HIP_LIB=$L/libsherf_hip_stag30.so $B 2>/dev/null | grep '"metric"' | pr stag30_frame
+
 cd /tmp
 prof() { # tag, env...
   local tag=$1; shift
@@ -34,5 +32,4 @@ prof() { # tag, env...
 }
 prof nn8 A=1
 prof nn16 SHERF_HIP_LIB=$L/libsherf_hip_nn16.so
-prof nn12 SHERF_HIP_LIB=$L/libsherf_hip_nn12.so
 timeout 300 python $GRAFT_REPO_ROOT/bench_train.py --steps 3 --warmup 1 > $OUT/train_g.log 2>&1; echo "[train rc=$?]"; grep '"metric"' $OUT/train_g.log | cut -c1-600
