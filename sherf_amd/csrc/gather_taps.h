@@ -40,6 +40,9 @@ __device__ __forceinline__ void gather_sample(const GatherArgs& ga, const float*
     for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - ga.bounds[a]) / (ga.bounds[3 + a] - ga.bounds[a]) - 1.f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
+#ifdef SHERF_GT_NO_PLANES
+        break;
+#endif
         const float g0 = p == 2 ? n[2] : n[0];                 // planes (x,y), (x,z), (z,y)
         const float g1 = p == 1 ? n[2] : n[1];
         float px = gt_clampf(((g0 + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
@@ -94,6 +97,7 @@ __device__ __forceinline__ void gather_sample(const GatherArgs& ga, const float*
             }
     }
     // ---- sparse voxel levels: renderer.py:544-556 + 762-782, align_corners=True ----
+#ifndef SHERF_GT_NO_VOXELS
     {
         float gz = ((xc[2] - ga.vox_min[2]) / 0.005f) / (float)ga.vox_d * 2.f - 1.f;   // out_sh = (D,H,W) = (z,y,x)
         float gy = ((xc[1] - ga.vox_min[1]) / 0.005f) / (float)ga.vox_h * 2.f - 1.f;
@@ -134,4 +138,5 @@ __device__ __forceinline__ void gather_sample(const GatherArgs& ga, const float*
             }
         }
     }
+#endif
 }
