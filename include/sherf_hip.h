@@ -164,16 +164,6 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
-/* a10-a14 in ONE launch: the taps of sherf_gather_tokens (mode 0, same arithmetic: the tokens are bit-identical) as the prologue of
- * the MLP kernel -- every wave gathers its own tile into registers while the co-resident workgroup's decoder keeps the MFMA pipe
- * busy.  tokens / extras are still WRITTEN (the backward starts from them) but never read back through HBM.  Arguments: those of
- * sherf_gather_tokens followed by those of sherf_nerf_mlp.  This is what sherf_render_frame launches unless
- * SHERF_FRAME_SPLIT_GATHER is set. */
-int sherf_gather_mlp(const int32_t* counters, const float* geom, const float* planes_f, int P, const float* feat_f, int Hf, int Wf,
-                     const float* img4, int H, int W, const sherf_vox_level* levels_host, const float* tok_bias,
-                     const float* bounds, const float* vox_min, const int32_t* vox_sh_host, const void* wstream,
-                     const float* wbias, int prec, int64_t capacity, float* tokens, float* extras, float* out,
-                     sherf_stream_t stream);
 /* layout of the weight stream the kernel expects for `prec`: *n_steps steps; step_pieces_host[s] = its size in 1 KiB pieces (hi [, lo]
  * fragments, zero-padded to a multiple of 4); units[s * 10 + u] = chunk * 16 + K-block of the u-th (chunk, K-block) unit the kernel
  * consumes in step s (-1 = none / padding).  sherf_amd/mlp_pack.py restates it; tests/test_boundary.py compares the two. */
@@ -297,7 +287,6 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
  * reference synchronises at the same point (boolean-mask indexing, renderer.py:320-321).  Results are identical.
  */
 #define SHERF_FRAME_EXACT_GRIDS 1
-#define SHERF_FRAME_SPLIT_GATHER 2   /* a10-a12 as their own launch (sherf_gather_tokens) in front of sherf_nerf_mlp instead of sherf_gather_mlp */
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */

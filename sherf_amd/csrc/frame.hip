@@ -191,15 +191,6 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                   f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, cap, f->geom,
                                   f->cs_tvid, stream_main));
         const int gv = ((f->gather_split & 2) ? 4 : 0) | ((f->gather_split & 4) ? 12 : 0);   // bit 1: branchless voxel-row loads (mode | 4); bit 2: in 128 VGPRs (mode | 12)
-        if (!(f->flags & SHERF_FRAME_SPLIT_GATHER)) {      // the product path: the taps are the MLP kernel's prologue
-            SHERF_PROF(3, main);
-            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
-            SHERF_PROF(4, main);
-            SHERF_RUN(sherf_gather_mlp(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W, levels,
-                                       f->tok_bias, f->bounds, f->vox_min, f->vox_sh, f->wstream, f->wbias, f->mlp_prec, cap, f->tokens,
-                                       f->extras, f->sample_out, stream_main));
-            SHERF_PROF(5, main);
-        } else {
         if (f->gather_split & 1) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1 | gv, cap, f->tokens,
@@ -220,7 +211,6 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,
                                  f->sample_out, stream_main));
         SHERF_PROF(5, main);
-        }
     }
     if (phase & 2) {
         // ---- a15-a16 ----

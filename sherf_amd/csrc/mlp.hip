@@ -27,7 +27,6 @@
 //   (lo*hi + hi*lo + hi*hi, fp32 accumulate): ~2^-21 relative, the mode that meets the 1e-3 per-sample tolerance.
 // prec 0 ("bf16"): one bf16 product (north_star's nominal precision; misses the tolerance by ~10x, reported for reference).
 #include "common.h"
-#include "gather_taps.h"
 
 namespace {
 
@@ -158,14 +157,10 @@ __device__ int g_mlp_trace_every = 0;
 #define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
 #endif
 
-#ifndef SHERF_MLP_FUSED_DIAG
-#define SHERF_MLP_FUSED_DIAG 0
-#endif
 // SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers
 #ifndef SHERF_MLP_ABLATE
 #define SHERF_MLP_ABLATE 0
 #endif
-
 
 template <int PREC> struct Ctx {
     const char* ws;          // packed weight stream (global)
@@ -206,7 +201,6 @@ __device__ __forceinline__ void dma_issue(Ctx<PREC>& cx, int step) {
 }
 
 __device__ __forceinline__ void wait_vm(int n) {              // s_waitcnt vmcnt(n) needs an immediate
-    if (SHERF_MLP_FUSED_DIAG & 8) n = 0;
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -450,20 +444,20 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// NOT fused with the taps of a10-a12 in front of it: round 2 built that (the gather as this kernel's prologue, every wave filling
+// its own tile's token registers while the co-resident workgroup's decoder keeps the MFMA pipe busy; commit 42beabf).  It is
+// bit-identical to the two launches on the CPU build and took the frame from 2.00 to 1.85 ms, but on the MI355X ~12 % of the tiles
+// came out wrong, a different set every launch -- with correct tokens in memory, with the taps ahead of any weight DMA, with every
+// counted wait replaced by vmcnt(0), even with the taps replaced by plain loads of the stored tokens (profiles/
+// r02_fused_gather_mlp_experiment_*.txt).  Unexplained, so not shipped; sherf_gather_tokens stays its own launch.
 // One launch: transformer (steps 0-1) + decoder (steps 2-42).  Round 2 also measured the two as SEPARATE launches (the transformer
 // at 3 waves / SIMD with its weights resident in LDS, the decoder alone at two workgroups per CU): 0.23 + 0.62 ms against 0.69 ms
 // fused (profiles/r02_kernel_trace_v2_split.txt) -- the decoder alone is not faster than with the transformer of the co-resident
 // workgroup running under it, so the fused form stays.
-//
-// FUSED: the taps of rows a10-a12 (csrc/gather_taps.h: the arithmetic of gather_tokens_kernel, bit for bit) are the kernel's
-// prologue: a wave gathers its own tile's tokens straight into the registers of the D layout, while the co-resident workgroup --
-// measured to run half a tile out of phase (profiles/r02_mlp_trace_v5_phase.txt) -- keeps the MFMA pipe busy.  The tokens and extras
-// are still written out (the attention's residual re-reads two of them, and the backward starts from them), but nothing reads
-// them back through HBM in between and the 0.39 ms gather launch that sat between the encoder and this kernel is gone.
-template <int PREC, bool FUSED>
+template <int PREC>
 __global__ void __launch_bounds__(NW * 64, 2)
-nerf_mlp_kernel(const int32_t* __restrict__ counters, float4* tokens, float* extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, GatherArgs ga) {
+nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
@@ -490,104 +484,35 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, float4* tokens, float* ext
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
 
-    if (!(FUSED && (SHERF_MLP_FUSED_DIAG & 4))) { dma_issue(cx, 0); dma_issue(cx, 1); }
-    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
-    float xc[3], vc[3], rgb[3];
-    f32x16 tok[3];                                                   // tokens in D layout (quad q = 2i+h -> regs 4i..4i+3)
-    if constexpr (FUSED) {
-        // the taps of this lane's sample for its four channel quads, under the weight DMA of steps 0 and 1 (their loads are older
-        // than every load here, so the compiler's own counted waits for the taps cover them; the counted wait below stays exact:
-        // loads return in order, and the stores issued here only make it wait longer, never shorter)
-        const int64_t c = tile * 32 + j;
-        float4 acc[3][4], rgb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int q[4] = {h, 2 + h, 4 + h, 6 + h};
-        xc[0] = xc[1] = xc[2] = vc[0] = vc[1] = vc[2] = 0.f;
-        if (live && c < nv) {
-            const float* gm = ga.geom + c * 8;
-#if SHERF_MLP_FUSED_DIAG & 64
-            {                                                        // diagnostic: the prologue's registers from memory instead of the taps
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[t][i] = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-                const float* ex = extras + tile * 12 * 32 + j;
-                rgb4 = make_float4(ex[192], ex[224], ex[256], 0.f);
-            }
-#else
-            gather_sample<4>(ga, gm, q, acc, rgb4);
-#endif
-            xc[0] = gm[0]; xc[1] = gm[1]; xc[2] = gm[2]; vc[0] = gm[3]; vc[1] = gm[4]; vc[2] = gm[5];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        rgb[0] = rgb4.x; rgb[1] = rgb4.y; rgb[2] = rgb4.z;
-        if (live && !(SHERF_MLP_FUSED_DIAG & 32)) {                  // tokens[tile][slot][quad][j], extras[tile][12][j]
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j] = acc[t][i];
-            float* ew = extras + tile * 12 * 32 + j;
-            if (h == 0) { ew[0] = xc[0]; ew[32] = xc[1]; ew[64] = xc[2]; ew[96] = vc[0]; ew[128] = vc[1]; ew[160] = vc[2]; }
-            else { ew[192] = rgb[0]; ew[224] = rgb[1]; ew[256] = rgb[2]; ew[288] = 0.f; ew[320] = 0.f; ew[352] = 0.f; }
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tok[t][4 * i] = acc[t][i].x; tok[t][4 * i + 1] = acc[t][i].y; tok[t][4 * i + 2] = acc[t][i].z; tok[t][4 * i + 3] = acc[t][i].w;
-            }
-    }
-    if (FUSED && (SHERF_MLP_FUSED_DIAG & 4)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dma_issue(cx, 0); dma_issue(cx, 1); }
-#if SHERF_MLP_FUSED_DIAG & 1
-    if constexpr (FUSED) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#endif
-#if SHERF_MLP_FUSED_DIAG & 2
-    if constexpr (FUSED) {                                           // registers reloaded from what was just stored
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        float4* tp0 = tokens; asm volatile("" : "+v"(tp0));
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 v = tp0[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-                tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
-            }
-        float* ep = extras; asm volatile("" : "+v"(ep));
-        const float* ex = ep + tile * 12 * 32 + j;
-        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
-        rgb[0] = ex[192]; rgb[1] = ex[224]; rgb[2] = ex[256];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#endif
+    dma_issue(cx, 0);
+    dma_issue(cx, 1);
     wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
     __syncthreads();
     dma_issue(cx, 2);
 
+    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
+    float xc[3], vc[3];
     int step = 0;
 
     // ================= transformer: step 0 = chunks 0..4, step 1 = chunks 5..8 =================
     {
-        if constexpr (!FUSED) {
+        // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
+        f32x16 tok[3];
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-                    tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
-                }
-            const float* ex = extras + tile * 12 * 32 + j;
-            xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
-            rgb[0] = ex[192]; rgb[1] = ex[224]; rgb[2] = ex[256];
-        }
+            for (int i = 0; i < 4; ++i) {
+                float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+                tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
+            }
+        const float* ex = extras + tile * 12 * 32 + j;
+        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
 
         const char* s = cx.slot(step);
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
         {
             BFrag<PREC> b[1][2];
-            pe_frags<PREC, 5, 2>(h, rgb[0], rgb[1], rgb[2], b[0]);
+            pe_frags<PREC, 5, 2>(h, ex[192], ex[224], ex[256], b[0]);
             f32x16 acc[1] = {bias_tile(cx, 0)};
             mma_cols<PREC, 2, 1>(s, 0, b, acc);
             tok[2] += acc[0];
@@ -693,21 +618,14 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, float4* tokens, float* ext
             mma_cols<PREC, 3, 2>(s, 2, ob, acc);                      // to_out + bias
             // residual (renderer.py:925).  tok[0], tok[1] are RE-READ (L2-hot, coalesced) instead of carried through the attention:
             // 32 registers less at the kernel's pressure peak
-            const float4* tp = tokens;                       // (FUSED: written by this lane in the prologue)
+            const float4* tp = tokens;
             asm volatile("" : "+v"(tp));
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x16 tk;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-#if SHERF_MLP_FUSED_DIAG & 16
-                    const float* fp = reinterpret_cast<const float*>(tp + ((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j);
-                    float4 v;                                      // L1-bypassing (system scope) loads
-                    v.x = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); v.y = __hip_atomic_load(fp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    v.z = __hip_atomic_load(fp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); v.w = __hip_atomic_load(fp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#else
                     const float4 v = tp[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-#endif
                     tk[4 * i] = v.x; tk[4 * i + 1] = v.y; tk[4 * i + 2] = v.z; tk[4 * i + 3] = v.w;
                 }
                 y[t] = acc[t] + tk;
@@ -863,42 +781,17 @@ extern "C" int sherf_mlp_stream_layout(int prec, int32_t* n_steps, int32_t* step
     return SHERF_OK;
 }
 
-static int launch_mlp(const int32_t* counters, float* tokens, float* extras, const void* wstream, const float* wbias, int prec,
-                      int64_t capacity, float* out, const GatherArgs* ga, sherf_stream_t stream) {
+extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                              const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
     SHERF_CHECK_ARG((prec == 0 || prec == 1) && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
-    const GatherArgs none = {};
-#define SHERF_MLP(P, F) hipLaunchKernelGGL((nerf_mlp_kernel<P, F>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<float4*>(tokens), \
-                                           extras, reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), F ? *ga : none)
-    if (ga) { if (prec == 1) SHERF_MLP(1, true); else SHERF_MLP(0, true); }
-    else { if (prec == 1) SHERF_MLP(1, false); else SHERF_MLP(0, false); }
-#undef SHERF_MLP
+    if (prec == 1)
+        hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     SHERF_LAUNCH_CHECK();
-}
-
-extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                              const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
-    return launch_mlp(counters, const_cast<float*>(tokens), const_cast<float*>(extras), wstream, wbias, prec, capacity, out, nullptr, stream);
-}
-
-extern "C" int sherf_gather_mlp(const int32_t* counters, const float* geom, const float* planes_f, int P, const float* feat_f, int Hf, int Wf,
-                                const float* img4, int H, int W, const sherf_vox_level* levels_host, const float* tok_bias,
-                                const float* bounds, const float* vox_min, const int32_t* vox_sh_host, const void* wstream,
-                                const float* wbias, int prec, int64_t capacity, float* tokens, float* extras, float* out,
-                                sherf_stream_t stream) {
-    SHERF_CHECK_ARG(geom && planes_f && feat_f && img4 && levels_host && tok_bias && bounds && vox_min && vox_sh_host);
-    SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0);
-    GatherArgs ga = {};
-    ga.geom = geom; ga.planes_f = reinterpret_cast<const float4*>(planes_f); ga.feat_f = reinterpret_cast<const float4*>(feat_f);
-    ga.img4 = reinterpret_cast<const float4*>(img4); ga.tok_bias = reinterpret_cast<const float4*>(tok_bias);
-    ga.bounds = bounds; ga.vox_min = vox_min;
-    for (int i = 0; i < 3; ++i) {
-        ga.lv[i] = levels_host[i];
-        SHERF_CHECK_ARG(ga.lv[i].wp && ga.lv[i].rows && ga.lv[i].D > 0 && ga.lv[i].H > 0 && ga.lv[i].W > 0);
-    }
-    ga.P = P; ga.Hf = Hf; ga.Wf = Wf; ga.H = H; ga.W = W;
-    ga.vox_d = vox_sh_host[0]; ga.vox_h = vox_sh_host[1]; ga.vox_w = vox_sh_host[2];
-    return launch_mlp(counters, tokens, extras, wstream, wbias, prec, capacity, out, &ga, stream);
 }

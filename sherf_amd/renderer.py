@@ -242,9 +242,6 @@ class ImportanceRenderer(nn.Module):
         self.pos_enc = PositionalEncoding(num_freqs=6)
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
-        # SHERF_FRAME_SPLIT_GATHER (sherf_hip.h): the taps as their own launch in front of the MLP kernel instead of as its prologue
-        # (sherf_gather_mlp, the default).  The options below only shape that separate launch.
-        self.split_gather = os.environ.get('SHERF_SPLIT_GATHER', '0') == '1'
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         # schedule variant of the voxel taps (sherf_hip.h): False = one branch per corner, True = unconditional loads (160 VGPRs),
         # '128' = unconditional loads compiled for 4 waves / SIMD
@@ -461,7 +458,7 @@ class ImportanceRenderer(nn.Module):
         feat_f = self._ws.table('feat_f', (Hf, Wf, 64), dev)
         img4 = self._ws.table('img4', (H, W, 4), dev)
         fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, -1), A(wc['Wa_t']), A(planes_f), Pres
-        fr.flags = (1 if opts.get('exact_grids', self.exact_grids) else 0) | (2 if opts.get('split_gather', self.split_gather) else 0)
+        fr.flags = 1 if opts.get('exact_grids', self.exact_grids) else 0
         fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, -1), A(wc['Wb_t']), A(feat_f), Hf, Wf
         fr.obs_img, fr.img4, fr.H, fr.W = a32(obs_input_img, -1), A(img4), H, W
         fr.tok_bias, fr.bounds = A(wc['tok_bias']), a32(input_data['t_world_bounds'], 6)

@@ -87,7 +87,6 @@ def _build(name, sources, out_dir, extra_src, compiler, defines):
             src = _cpu_mlp(src)
         src = src.replace('#include "common.h"', f'#include "{os.path.join(CSRC, "common.h")}"')
         src = src.replace('#include "ops_common.h"', f'#include "{os.path.join(CSRC, "ops_common.h")}"')
-        src = src.replace('#include "gather_taps.h"', f'#include "{os.path.join(CSRC, "gather_taps.h")}"')
         src = src.replace('#include "../../include/', f'#include "{os.path.join(ROOT, "include")}/')
         p = os.path.join(out_dir, s.replace('.hip', '.cpp'))
         open(p, 'w').write(src)

@@ -13,7 +13,7 @@ build() { # tag, source file (without .hip), defines...
   echo "built libsherf_hip_$tag.so ($src: $*)"
 }
 declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0" [nomix]="-DSHERF_MLP_FMA_MIX=0"
-                  [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [sconvtrace]="-DSHERF_SCONV_TRACE=1" [diag32]="-DSHERF_MLP_FUSED_DIAG=32" [diag64]="-DSHERF_MLP_FUSED_DIAG=64" [diag96]="-DSHERF_MLP_FUSED_DIAG=96" [novox]="-DSHERF_GT_NO_VOXELS" [noplanes]="-DSHERF_GT_NO_PLANES" [novoxplanes]="-DSHERF_GT_NO_VOXELS -DSHERF_GT_NO_PLANES" [diag4]="-DSHERF_MLP_FUSED_DIAG=4" [diag8]="-DSHERF_MLP_FUSED_DIAG=8" [diag12]="-DSHERF_MLP_FUSED_DIAG=12" )
+                  [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [sconvtrace]="-DSHERF_SCONV_TRACE=1" )
 declare -A SRC=( [sconvtrace]=svox )
 TAGS=${@:-trace nodma}
 for t in $TAGS; do build $t ${SRC[$t]:-mlp} ${DEFS[$t]} & done
