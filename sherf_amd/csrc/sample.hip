@@ -553,8 +553,13 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     const float4* cp = reinterpret_cast<const float4*>(cell_pts);
     hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters);
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
+    // 10 KiB of unused dynamic LDS per workgroup: caps the sampler at 6 workgroups per CU (6 of the 8 wave slots per SIMD).  The
+    // encoder's small dependent launches on the other stream are the frame's critical path until the gather; with every wave slot
+    // taken by the sampler their workgroups queue behind it (measured: frame 1.97 ms uncapped, 1.91 at 6, 1.92 at 5, 1.94 at 4;
+    // profiles/r02_sconv_sampler_balance.txt).
+    constexpr int nn_pad = 10 * 1024;
 #define SHERF_SAMPLE_LAUNCH(N)                                                                                        \
-    hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
+    hipLaunchKernelGGL(sample_nn_kernel<N>, dim3(cdiv(R, 4)), dim3(256), nn_pad, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
                        grid_hdr, cell_start, cp, near_mask, ray_cnt, ray_mask, dense_vid, g_sherf_debug)
     if (nch == 1) SHERF_SAMPLE_LAUNCH(1); else if (nch == 2) SHERF_SAMPLE_LAUNCH(2);
     else if (nch == 3) SHERF_SAMPLE_LAUNCH(3); else SHERF_SAMPLE_LAUNCH(4);

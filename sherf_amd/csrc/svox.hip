@@ -208,8 +208,12 @@ __device__ unsigned g_sconv_trace_cap = 0, g_sconv_trace_n = 0;
 #define SCONV_STAMP(k) do { } while (0)
 #endif
 
-template <int NCOT, int NKB>   // Cout = 32 * NCOT, Cin = 16 * NKB
-__global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
+// FOLD (mode 2, one tap: the waves split the output-channel tiles) and IN_BN (BatchNorm of the input) are compile-time: as run-time
+// switches they put a branch around every weight load and every MFMA group of the tap loop, and the compiler scheduled nothing
+// across them (round 2's ISA: one global load per basic block).
+template <int NCOT, int NKB, bool FOLD, int IN_BN>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
+__global__ void __launch_bounds__(256, (NCOT * NKB >= 12 ? 1 : 2))   // (level 2 launches 318 workgroups: two per CU must fit)
+sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, BnIn bin,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
@@ -231,13 +235,13 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     const int row0 = blockIdx.x * 32;
     if (row0 >= n_rows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntaps = mode == 2 ? 1 : 27;
+    const int ntaps = FOLD ? 1 : 27;
     {   // neighbour table: thread -> row tid & 31, taps (tid >> 5) + 8 j.  The row's key is read once and the (up to) four bitmap
         // records are fetched together: two dependent L2 trips per workgroup instead of seven (profiles/r02_sconv_trace_v1.txt:
         // this table was 6-8 K of a workgroup's 17-70 K cycles)
         const int rr = tid & 31, row = row0 + rr;
         const bool live = row < n_rows;
-        const int key = (live && mode != 2) ? keys_out[row] : 0;
+        const int key = (live && !FOLD) ? keys_out[row] : 0;
         const int z = key / (Ho * Wo), y = (key / Wo) % Ho, x = key % Wo;
         int qk[4];
         uint2 rec[4];
@@ -246,7 +250,7 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             const int tap = (tid >> 5) + 8 * j;
             const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
             const int qz = mode ? 2 * z + kz - 1 : z + kz - 1, qy = mode ? 2 * y + ky - 1 : y + ky - 1, qx = mode ? 2 * x + kx - 1 : x + kx - 1;
-            const bool ok = live && mode != 2 && tap < 27 && qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi;
+            const bool ok = live && !FOLD && tap < 27 && qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi;
             qk[j] = ok ? (qz * Hi + qy) * Wi + qx : -1;
         }
 #pragma unroll
@@ -256,7 +260,7 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
             const int tap = (tid >> 5) + 8 * j;
             if (tap >= ntaps) continue;
             int nb = -1;
-            if (mode == 2) nb = live ? row : -1;
+            if (FOLD) nb = live ? row : -1;
             else if (qk[j] >= 0) {
                 const uint32_t bit = 1u << (qk[j] & 31);
                 if (rec[j].x & bit) nb = (int)rec[j].y + __popc(rec[j].x & (bit - 1u));
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
         }
     }
     SCONV_STAMP(1);                                  // neighbour table done (this thread's share)
-    const bool in_bn = bin.bnparam != nullptr;
+    constexpr bool in_bn = IN_BN != 0, has_mult = IN_BN == 2;
     if (in_bn) {
         if (bin.acc) {
             if (tid < Cin) {
@@ -302,8 +306,8 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     for (int tap = wave; tap < ntaps; tap += 4)
         if (__ballot(s_nb[tap * 32 + r] >= 0) != 0ull) tapmask |= 1u << tap;
     // pointwise fold (one tap): the waves split the output-channel tiles instead of the taps
-    const int csel = mode == 2 ? wave : -1;
-    if (mode == 2) tapmask = wave < NCOT ? 1u : 0u;
+    const int csel = FOLD ? wave : -1;
+    if (FOLD) tapmask = wave < NCOT ? 1u : 0u;
     tapmask = __builtin_amdgcn_readfirstlane(tapmask);
 
     // The tile is a chain of dependent gathers (neighbour row, weight fragments -> MFMA) and a workgroup is alone or nearly alone on
@@ -318,12 +322,15 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     struct Row { float4 v[2 * NKB]; int nb; float mlt; };
     struct Wts { uint4 w[NKB][2 * NCOT]; };
     auto row_src = [&](int nb) { return reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h; };
-    auto row_mult = [&](int nb) { return (in_mult && nb >= 0) ? (float)(in_mult[nb] - 1) : 0.f; };
+    auto row_mult = [&](int nb) {                   // (the load is unconditional per lane: one uniform branch, no divergent one)
+        const float m = has_mult ? (float)(in_mult[nb >= 0 ? nb : 0] - 1) : 0.f;
+        return nb >= 0 ? m : 0.f;
+    };
     auto load_w = [&](int tap, int kb, uint4 (&w)[2 * NCOT]) {
         const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
 #pragma unroll
         for (int c = 0; c < 2 * NCOT; ++c)
-            if (csel < 0 || (c >> 1) == csel) w[c] = wsrc[c * 64];
+            if (!FOLD || (c >> 1) == csel) w[c] = wsrc[c * 64];
     };
     auto load_all = [&](int tap, Row& R, Wts& W) {
         const int nb = s_nb[tap * 32 + r];
@@ -334,8 +341,10 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
     };
     // one tap out of (R, W); each K-block's registers are refilled with tap `nxt`'s data (nxt < 0: nothing left to fetch) as soon as used
     auto compute = [&](Row& R, Wts& W, int nxt) {
-        const int nb_next = nxt >= 0 ? s_nb[nxt * 32 + r] : -1;
-        const float mlt_next = nxt >= 0 ? row_mult(nb_next) : 0.f;
+        const int nb_tab = s_nb[max(nxt, 0) * 32 + r];
+        const int nb_next = nxt >= 0 ? nb_tab : -1;
+        // (the multiplicity is fetched here and converted after the K-blocks: consumed at once it would drain every load in flight)
+        const int mult_raw = has_mult ? in_mult[nb_next >= 0 ? nb_next : 0] : 1;
         const float4* src_next = row_src(nb_next);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -355,18 +364,25 @@ __global__ void __launch_bounds__(256) sconv3_kernel(const int32_t* __restrict__
                                          pk2(v[4] - rt(v[4]), v[5] - rt(v[5])), pk2(v[6] - rt(v[6]), v[7] - rt(v[7])));
 #pragma unroll
             for (int c = 0; c < NCOT; ++c) {
-                if (csel >= 0 && c != csel) continue;
+                if (FOLD && c != csel) continue;
                 const uint4 bhi = W.w[kb][2 * c], blo = W.w[kb][2 * c + 1];
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
             }
-            if (nxt >= 0) {                          // uniform
+            if constexpr (PF == 1) {
+                // one buffer: the refill goes out HERE, right behind the K-block that freed its registers (left alone the compiler
+                // sinks all of a tap's refills behind its last MFMA and drains them at the top of the next tap); unconditional --
+                // past the last tap it fetches tap 0 / row 0 again, a few cached loads instead of a branch per K-block
+                R.v[2 * kb] = src_next[4 * kb]; R.v[2 * kb + 1] = src_next[4 * kb + 1];
+                load_w(max(nxt, 0), kb, W.w[kb]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (nxt >= 0) {                   // PF buffers: two or three taps of slack, placement does not matter (uniform branch)
                 R.v[2 * kb] = src_next[4 * kb]; R.v[2 * kb + 1] = src_next[4 * kb + 1];
                 load_w(nxt, kb, W.w[kb]);
             }
         }
-        R.nb = nb_next; R.mlt = mlt_next;
+        R.nb = nb_next; R.mlt = nb_next >= 0 ? (float)(mult_raw - 1) : 0.f;
     };
     auto next_tap = [&](int tap) -> int {           // next set bit above `tap`, -1 if none (uniform)
         const uint32_t rest = tap >= 31 ? 0u : (tapmask & ~((2u << tap) - 1u));
@@ -573,11 +589,17 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
     const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
     const dim3 grid(cdiv(max_rows, 32)), block(256);
-    if (g_sherf_debug & 128) mode |= 256;
-#define SHERF_CONV3(N, K)                                                                                                    \
-    hipLaunchKernelGGL((sconv3_kernel<N, K>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,           \
+    SHERF_CHECK_ARG(!in_mult || bin.bnparam);       // (the multiplicity only enters through the BatchNorm transform)
+    const bool fold = mode == 2;
+    const int bnm = bin.bnparam ? (in_mult ? 2 : 1) : 0;
+    const int kmode = mode | ((g_sherf_debug & 128) ? 256 : 0);
+#define SHERF_CONV3_(N, K, F, B)                                                                                             \
+    hipLaunchKernelGGL((sconv3_kernel<N, K, F, B>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,     \
                        reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                                 \
-                       reinterpret_cast<const uint4*>(w_packed), mode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id)
+                       reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id)
+#define SHERF_CONV3(N, K)                                                                                                    \
+    do { if (fold) { if (bnm == 2) SHERF_CONV3_(N, K, true, 2); else if (bnm) SHERF_CONV3_(N, K, true, 1); else SHERF_CONV3_(N, K, true, 0); } \
+         else { if (bnm == 2) SHERF_CONV3_(N, K, false, 2); else if (bnm) SHERF_CONV3_(N, K, false, 1); else SHERF_CONV3_(N, K, false, 0); } } while (0)
     static int trace_launches = 0;                  // (profiling builds: launch ordinal -> the records' first word)
     const int trace_id = SHERF_SCONV_TRACE ? trace_launches++ : 0;
     const int sel = (Cout / 32) * 10 + Cin / 16;
@@ -592,6 +614,8 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
             snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_svox_conv3: unsupported channel pair %d -> %d", Cin, Cout);
             return SHERF_EINVAL;
     }
+#undef SHERF_CONV3
+#undef SHERF_CONV3_
     SHERF_LAUNCH_CHECK();
 }
 
