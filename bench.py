@@ -129,7 +129,7 @@ def secondary_measurements(a, w, dev, nv, R):
             bf16_single_product=dict(kernel_ms=ms1, achieved_tflops=fl(ms1), frac=fl(ms1) / PEAK_BF16_TFLOPS,
                                      sigma_err_rel_to_max_vs_f16x3=float((got[:, 3].clamp(min=0) - sig).abs().max() / sig.max()),
                                      rgb_err_max_abs_vs_f16x3=float((got[:, :3] - ref[:, :3]).abs().max()),
-                                     note='north_star names bf16; it misses the 1e-3 tolerance (tests/test_gpu_parity.py), so it is not the product default'))
+                                     note='north_star names bf16; on the seeded weights it misses the 1e-3 tolerance (tests/test_gpu_parity.py), so it is not the product default'))
     except Exception as ex:
         out['mlp_kernel_alone'] = dict(error=f'{type(ex).__name__}: {str(ex)[:200]}')
     for cfg in ('cfg3', 'cfg2_dense'):

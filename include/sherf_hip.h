@@ -9,7 +9,8 @@
  *
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in `_host`;
- *   - the callee never allocates persistent memory, never synchronises, launches on `stream`;
+ *   - the callee never allocates persistent memory, never synchronises (two documented exceptions: sherf_render_frame with
+ *     SHERF_FRAME_EXACT_GRIDS waits once for the frame's sample count; sherf_profile_frames_read drains the ring), launches on `stream`;
  *   - returns 0 on success, a negative SHERF_E* code on bad arguments / launch failure
  *     (the Python wrapper raises RuntimeError, like TORCH_CHECK in bias_act.cpp:39-55);
  *   - fp32 unless stated; B == 1 (the reference forces a per-GPU batch of one, renderer.py:320-321).
@@ -160,7 +161,7 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * NeRFDecoder (triplane.py:285-316) as ONE MFMA kernel (csrc/mlp.hip: 4-wave workgroups, two per CU, a 3-slot LDS ring of <= 20 KiB
  * weight steps, two independent accumulator chains per step); weights arrive as the pre-packed fragment stream built by
  * sherf_amd/mlp_pack.py FOR THE SAME `prec`.  prec: 1 = f16x3 (operands split hi + lo in fp16, three MFMAs per product, fp32
- * accumulate: fp32-grade, the default), 0 = bf16 (one product; north_star's nominal precision, misses the 1e-3 tolerance).
+ * accumulate: fp32-grade, the default), 0 = bf16 (one product; north_star's nominal precision; on the seeded weights it misses the 1e-3 tolerance).
  * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
