@@ -24,9 +24,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_VALID_SAMPLE = 429248       # 214,624 MAC per valid sample (fusion + transformer + decoder)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                # MI355X HBM3E (MI355X_MICROARCH.md)
-# (the host dry run of this script lowers them).  The frame workloads get as much warm-up as the headline: timed 10 frames after 3, right
-# after the seconds of host work that build them, cfg3 read 3.1 ms per frame -- and 1.90 ms as the headline workload of its own run
-# (profiles/r02_cfg3_as_headline.txt): the first frames after an idle stretch run the encoder's launch chain at ramping clocks.
+# (the host dry run of this script lowers them)
 SECONDARY_ITERS = dict(mlp=20, mlp_warmup=5, frames=20, frames_warmup=10)
 
 

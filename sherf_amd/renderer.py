@@ -224,6 +224,9 @@ class _Workspace:
         return self._cached(kind, 0, shape, dev)
 
 
+_SIDE_STREAMS = {}           # device -> [side, aux]
+
+
 class ImportanceRenderer(nn.Module):
     def __init__(self, use_1d_feature=True, use_2d_feature=True, use_3d_feature=True, use_trans=False, use_NeRF_decoder=False,
                  smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='f16x3'):
@@ -259,11 +262,10 @@ class ImportanceRenderer(nn.Module):
         self._ws = _Workspace()
         self._wcache = None
         self.last = None
-        self._side_streams = None
 
     def __getstate__(self):
         s = self.__dict__.copy()
-        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_side_streams'):
+        for k in ('_smpl_dev', '_ws', '_wcache', 'last'):
             s[k] = None
         s['_ws'] = None
         return s
@@ -273,10 +275,14 @@ class ImportanceRenderer(nn.Module):
         self._ws = _Workspace()
 
     def _side(self, dev, idx=0):
-        cur = getattr(self, '_side_streams', None)
-        if cur is None or cur[0].device != dev:
+        # ONE pair of side streams per device for every renderer of the process: HIP multiplexes streams onto 4 hardware queues, and a
+        # second renderer with streams of its own (five in all) had two of its three streams share a queue -- its encoder chain and
+        # ray side ran one after the other (3.1 instead of 1.9 ms per frame, profiles/r02_cfg3_as_headline.txt).  Frames of different
+        # renderers are serialised by the native driver anyway.
+        cur = _SIDE_STREAMS.get(dev)
+        if cur is None:
             # the short serial chains get dispatch priority over the ray side's big kernels
-            self._side_streams = cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+            _SIDE_STREAMS[dev] = cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
         return cur[idx]
 
     # ---- SMPL --------------------------------------------------------------------------------
