@@ -5,6 +5,7 @@ packages in oracle/ref_shims (pytorch3d K-NN, spconv, torchvision, imageio) and 
 (no GPU here; SMPL pickle replaced by the synthetic SMPL of oracle/synth.py).
 
     python -m oracle.make_golden [tiny tiny_nv cfg1]
+    python -m oracle.make_golden tiny_ri cfg1_ri        # the reference-init variants only (+ the constructor check)
 
 Inputs and weights are regenerated from seeds by oracle/fixtures.py, so the files hold OUTPUTS only.
 /root/reference does not exist on the GPU box: nothing at test time imports this module.
@@ -43,8 +44,8 @@ def run(cfg_name, R, T, out_dir):
     torch.manual_seed(0)
     rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
     dec = T.NeRFDecoder(32)
-    fixtures.load_seeded_state(rend, 'renderer.')
-    fixtures.load_seeded_state(dec, 'decoder.')
+    fixtures.load_seeded_state(rend, 'renderer.', fixtures.variant_of(cfg_name))
+    fixtures.load_seeded_state(dec, 'decoder.', fixtures.variant_of(cfg_name))
     rend.train(); dec.train()        # the reference never calls .eval() before test (training_loop.py:193,321)
 
     d = fixtures.to_torch(fx['input_data'])
@@ -148,6 +149,37 @@ def run(cfg_name, R, T, out_dir):
     print(f'{cfg_name}: R={rgb.shape[1]} Nv={valid.numel()}/{mask.numel()} ({valid.numel()/mask.numel():.3%}) '
           f'ref forward {dt:.2f}s  rgb range [{rgb.min():.3f},{rgb.max():.3f}] acc max {acc.max():.3f} -> {path} '
           f'({os.path.getsize(path)/1e6:.2f} MB)')
+
+
+def run_refinit_check(R, T, out_dir):
+    """What `fixtures.refinit_param` claims about the reference's constructors, recorded from modules the UNMODIFIED reference builds
+    under torch.manual_seed(0): per tensor its kind (ones / zeros / uniform) and, for the uniform ones, max |value| * sqrt(fan_in)
+    (must be <= 1: the kaiming_uniform(a=sqrt(5)) bound) and std * sqrt(3 fan_in) (-> 1).  tests/test_oracle_golden.py compares."""
+    import json
+    torch.manual_seed(0)
+    rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
+    dec = T.NeRFDecoder(32)
+    rec = {}
+    for prefix, mod in (('renderer.', rend), ('decoder.', dec)):
+        named = list(mod.named_parameters()) + list(mod.named_buffers())
+        shapes = {prefix + n: tuple(t.shape) for n, t in named}
+        for n, t in named:
+            name = prefix + n
+            if name.split('.')[-1] in ('_freqs', '_phases', 'num_batches_tracked'):
+                continue
+            v = t.detach().double()
+            if bool((v == 1).all()):
+                rec[name] = dict(kind='ones')
+            elif bool((v == 0).all()):
+                rec[name] = dict(kind='zeros')
+            else:
+                w = shapes.get(name[:-len('bias')] + 'weight') if name.endswith('.bias') else tuple(t.shape)
+                fan_in = int(np.prod(w[1:]))
+                rec[name] = dict(kind='uniform', fan_in=fan_in, max_scaled=float(v.abs().max() * np.sqrt(fan_in)),
+                                 std_scaled=float(v.std() * np.sqrt(3 * fan_in)) if v.numel() > 1 else None, numel=int(v.numel()))
+    path = os.path.join(out_dir, 'refinit_reference_constructors.json')
+    json.dump(rec, open(path, 'w'), indent=0, sort_keys=True)
+    print('refinit check ->', path, {k: sum(1 for r in rec.values() if r['kind'] == k) for k in ('ones', 'zeros', 'uniform')})
 
 
 GRAD_SAMPLE = 64      # entries kept per gradient tensor (strided), next to its sum / abs-sum / L2 norm
@@ -348,6 +380,13 @@ if __name__ == '__main__':
     if names == ['rays']:
         run_rays(out_dir); sys.exit(0)
     R, T = import_reference()
+    if names == ['refinit']:
+        run_refinit_check(R, T, out_dir); sys.exit(0)
+    if all(n.endswith('_ri') for n in names):           # only the reference-init variants: leave the other files alone
+        run_refinit_check(R, T, out_dir)
+        for n in names:
+            run(n, R, T, out_dir)
+        sys.exit(0)
     run_rays(out_dir)
     run_small_units(R, T, out_dir)
     run_glue(R, T, out_dir)

@@ -1,30 +1,23 @@
 """TEST INFRASTRUCTURE (checker only: imported by tests/, bench.py's parity leg and __graft_entry__.smoke()).
 
-The margin protocol of SURVEY.md section 7, hard part 1.  The path contains three DISCONTINUOUS selectors --
-the 5 cm shell threshold d^2 < 0.0025 (renderer.py:315-319), the nearest posed vertex (:315, :564) and the nearest T-pose
-vertex (:627) -- so two correct fp32 implementations legitimately disagree on samples whose decision margin is within the
-rounding error of the quantities compared (|x| ~ 1 m -> 1e-7 on a coordinate -> ~1e-8 on d^2 at d = 5 cm).  Parity is therefore
-stated as:
+Parity protocol of SURVEY.md section 7, hard part 1.  The path contains three DISCONTINUOUS selectors -- the 5 cm shell threshold
+d^2 < 0.0025 (renderer.py:315-319), the nearest posed vertex (:315, :564) and the nearest T-pose vertex (:627) -- so two correct
+fp32 implementations legitimately disagree on samples whose decision margin is within the rounding error of the quantities
+compared (|x| ~ 1 m -> 1e-7 on a coordinate -> ~1e-8 on d^2 at d = 5 cm).  Parity is therefore stated in three parts:
 
-  * flips     every sample on which the two implementations take a different branch is listed with the ORACLE's margin;
-              all margins must be below `eps` (default 1e-6 on d^2, two orders above the rounding error) -- a flip with a
-              larger margin is a bug, not rounding;
-  * clean set samples valid in both, same vertex ids, all three oracle margins > eps: compared per sample with a TRUE relative
-              metric  |ours - ref| / max(|ref|, floor)   (floors: sigma+ 1.0 [1/m], rgb 0.1 of the [0,1] range);
+  * flips     every sample on which the two implementations take a different branch is listed with the ORACLE's margin; all
+              margins must be below `eps` (1e-6 on d^2, two orders above the rounding error): a flip with a larger margin is a bug;
+  * samples   on the samples both implementations put on the same branches, sigma+ and rgb are compared per sample with a TRUE
+              relative metric |a - b| / max(|b|, floor) (floors: sigma+ 1.0 [1/m], rgb 0.1 of the [0, 1] range), in one of two ways:
+              - `sample_protocol`: ours against the fp32 oracle, plain maximum <= tol.  This is the criterion on every
+                well-conditioned workload (all the small fixtures; the "_ri" variants at full size);
+              - `truth_protocol`: ours AND the fp32 oracle against the float64 evaluation of the same function on the same branches
+                (oracle/sherf_oracle.py: truth64_from_fixture).  On the adversarial seeded workload at full size (white-noise tables,
+                encodings up to 2^5 x, a density head of gain 20) the fp32 REFERENCE itself is further than 1e-3 from the truth on
+                the worst of ~10^6 samples, so "within 1e-3 of the reference" is not a property any fp32 implementation has there;
+                the criterion is instead that at every quantile (p50, p99, p99.9, max) our distance from the truth is at most the
+                reference's own plus tol -- no allowance derived from the implementation under test, no excluded fraction;
   * rays      a ray may exceed the image tolerance only if it contains a flipped / in-margin sample ("explained").
-
-Conditioning.  Off the margins the function is continuous but not benign: the synthetic workload's tables are white noise (a 1e-6 m
-move of the canonical point, projected at 700 px / m, is ~1e-3 of a texel of independent noise), the encodings reach 2^5 x and the
-density head has gain 20.  The oracle therefore also reports, per sample, how far ITS OWN sigma / rgb move when the canonical position
-is changed by +-4e-7 along each axis (the size of legitimate fp32 differences in the warp chain; oracle/sherf_oracle.py:
-condition_probe; per axis the larger of the two changes, summed over the axes: a first-order bound for any displacement of <= 4e-7
-per coordinate that also sees the kinks of the piecewise-linear tables on either side): measured on
-cfg1, the reference against itself under a random 4e-7 displacement has mean relative sigma change 4e-4 and p99.9 1.7e-2.  The
-per-sample criterion is
-      |ours - ref| / max(|ref|, floor)  <=  tol + cond_i      for all but <= 1e-4 of the clean samples (the bound is first order),
-      |ours - ref| / max(|ref|, floor)  <=  tol + 4 cond_i    for every clean sample,
-`cond_i` being that change (samples whose nearest T-vertex flips under the probe join the margin set).  Raw maxima / quantiles are
-reported beside it: nothing is hidden by the bound.
 """
 import numpy as np
 import torch
@@ -33,72 +26,112 @@ THRESH2 = 0.05 ** 2
 EPS = 1e-6
 FLOOR_SIGMA = 1.0
 FLOOR_RGB = 0.1
+QUANTILES = (0.5, 0.99, 0.999, 1.0)
+
+_t = lambda x: torch.as_tensor(x).detach().cpu()
 
 
-def sample_protocol(o, cs_idx, cs_vid, cs_tvid, sample_out, S, eps=EPS):
-    """o: oracle dict with mask [N], d2_all [N], valid [nv], vert_id, t_vert_id, vert_gap, t_vert_gap, sample_rgb, sample_sigma.
-    cs_idx / cs_vid / cs_tvid [n] int, sample_out [n,4] = (rgb, sigma raw): the implementation's compact samples (any order).
-    -> report dict (python scalars) + per-ray bool array `ray_touched` (ray contains a flipped or in-margin sample)."""
-    t = lambda x: torch.as_tensor(x).detach().cpu()
-    mask_o = t(o['mask']).bool()
+def _align(o, cs_idx, cs_vid, cs_tvid, eps):
+    """Common bookkeeping: flips with the oracle's margins, the samples valid in both, which of them sit on the same branches."""
+    mask_o = _t(o['mask']).bool()
     N = mask_o.numel()
-    d2 = t(o['d2_all']).double()
-    cs_idx = t(cs_idx).long(); cs_vid = t(cs_vid).long(); cs_tvid = t(cs_tvid).long(); sample_out = t(sample_out).double()
+    d2 = _t(o['d2_all']).double()
+    cs_idx = _t(cs_idx).long(); cs_vid = _t(cs_vid).long(); cs_tvid = _t(cs_tvid).long()
     mask_h = torch.zeros(N, dtype=torch.bool); mask_h[cs_idx] = True
     thr_margin = (d2 - THRESH2).abs()
     flip = mask_h != mask_o
     rep = dict(samples=int(N), valid_oracle=int(mask_o.sum()), valid_ours=int(mask_h.sum()), eps=eps,
                mask_flips=int(flip.sum()), mask_flip_max_margin=float(thr_margin[flip].max()) if flip.any() else 0.0)
-    # samples valid in both, aligned through the dense index
-    pos_o = torch.full((N,), -1, dtype=torch.long); pos_o[t(o['valid']).long()] = torch.arange(int(mask_o.sum()))
+    pos_o = torch.full((N,), -1, dtype=torch.long); pos_o[_t(o['valid']).long()] = torch.arange(int(mask_o.sum()))
     both = mask_o[cs_idx]
     io = pos_o[cs_idx[both]]                                   # oracle row of each of our common samples
-    vid_o, tvid_o = t(o['vert_id']).long()[io], t(o['t_vert_id']).long()[io]
-    gap_v, gap_t = t(o['vert_gap']).double()[io], t(o['t_vert_gap']).double()[io]
+    vid_o, tvid_o = _t(o['vert_id']).long()[io], _t(o['t_vert_id']).long()[io]
+    gap_v, gap_t = _t(o['vert_gap']).double()[io], _t(o['t_vert_gap']).double()[io]
     vflip = cs_vid[both] != vid_o
     tflip = (cs_tvid[both] != tvid_o) & ~vflip                 # (a different posed vertex moves x_c: its T-vertex may differ legitimately)
     rep.update(common=int(both.sum()), vertex_flips=int(vflip.sum()), vertex_flip_max_gap=float(gap_v[vflip].max()) if vflip.any() else 0.0,
                t_vertex_flips=int(tflip.sum()), t_vertex_flip_max_gap=float(gap_t[tflip].max()) if tflip.any() else 0.0)
-    clean = ~vflip & ~tflip & (gap_v > eps) & (gap_t > eps) & (thr_margin[cs_idx[both]] > eps)
-    has_cond = 'cond_sigma' in o
-    if has_cond:
-        clean = clean & ~t(o['cond_flip']).bool()[io]
-    so = sample_out[both]
-    sig_h, sig_o = so[:, 3].clamp(min=0), t(o['sample_sigma']).double().view(-1)[io].clamp(min=0)
-    rgb_h, rgb_o = so[:, :3], t(o['sample_rgb']).double()[io]
-    e_sig = (sig_h - sig_o).abs() / sig_o.clamp(min=FLOOR_SIGMA)
-    e_rgb = ((rgb_h - rgb_o).abs() / rgb_o.abs().clamp(min=FLOOR_RGB)).max(1)[0]
-    c = clean
-    if has_cond:
-        # excess over the reference's own fp32 conditioning (see the module docstring); the raw figures follow unchanged
-        x_sig = (e_sig - t(o['cond_sigma']).double()[io]).clamp(min=0)
-        x_rgb = (e_rgb - t(o['cond_rgb']).double()[io]).clamp(min=0)
-        q = lambda v, p: float(torch.quantile(v[c], p)) if c.any() else 0.0
-        # the bound is first order (finite differences at the displacement bound): among ~1e6 samples of a piecewise-linear white-noise
-        # function a few beat it.  So, beside the maximum: the FRACTION of clean samples over tol + cond_i (must stay <= 1e-4) and the
-        # excess over a 4x bound (a fence no sample may cross: four times what the reference's own output moves is an error, not rounding)
-        tol = 1e-3
-        c_s, c_r = t(o['cond_sigma']).double()[io], t(o['cond_rgb']).double()[io]
-        nclean = max(int(c.sum()), 1)
-        rep.update(sigma_excess_frac=float(((e_sig > tol + c_s) & c).sum()) / nclean, rgb_excess_frac=float(((e_rgb > tol + c_r) & c).sum()) / nclean,
-                   sigma_excess4_max=float((e_sig - 4 * c_s).clamp(min=0)[c].max()) if c.any() else 0.0,
-                   rgb_excess4_max=float((e_rgb - 4 * c_r).clamp(min=0)[c].max()) if c.any() else 0.0)
-        rep.update(sigma_excess_max=float(x_sig[c].max()) if c.any() else 0.0, rgb_excess_max=float(x_rgb[c].max()) if c.any() else 0.0,
-                   sigma_rel_p999=q(e_sig, 0.999), sigma_rel_p99=q(e_sig, 0.99), rgb_rel_p999=q(e_rgb, 0.999),
-                   cond_sigma_mean=float(t(o['cond_sigma']).double()[io][c].mean()) if c.any() else 0.0,
-                   cond_sigma_p999=q(t(o['cond_sigma']).double()[io], 0.999),
-                   ill_conditioned=int(((t(o['cond_sigma']).double()[io] > 1e-3) & c).sum()), cond_eps=float(o['cond_eps']))
-    rep.update(clean=int(c.sum()), in_margin=int((~c).sum()),
-               sigma_rel_max=float(e_sig[c].max()) if c.any() else 0.0, sigma_rel_mean=float(e_sig[c].mean()) if c.any() else 0.0,
-               rgb_rel_max=float(e_rgb[c].max()) if c.any() else 0.0, rgb_rel_mean=float(e_rgb[c].mean()) if c.any() else 0.0,
-               floors=dict(sigma=FLOOR_SIGMA, rgb=FLOOR_RGB),
-               sigma_rel_to_max=float((sig_h - sig_o).abs()[c].max() / sig_o.max()) if c.any() else 0.0,
-               rgb_abs_max=float((rgb_h - rgb_o).abs()[c].max()) if c.any() else 0.0)
-    R = N // S
+    same = ~vflip & ~tflip
+    in_margin = ~same | (gap_v <= eps) | (gap_t <= eps) | (thr_margin[cs_idx[both]] <= eps)
+    return rep, dict(flip=flip, both=both, io=io, same=same, in_margin=in_margin, cs_idx=cs_idx, N=N)
+
+
+def _rel_errors(sig_a, rgb_a, sig_b, rgb_b):
+    """per-sample true relative errors of (sigma+, rgb) a against b (b = the reference side)."""
+    sa, sb = sig_a.double().clamp(min=0), sig_b.double().clamp(min=0)
+    e_sig = (sa - sb).abs() / sb.clamp(min=FLOOR_SIGMA)
+    e_rgb = ((rgb_a.double() - rgb_b.double()).abs() / rgb_b.double().abs().clamp(min=FLOOR_RGB)).max(1)[0]
+    return e_sig, e_rgb
+
+
+def _touched(al, S, c):
+    R = al['N'] // S
     touched = torch.zeros(R, dtype=torch.bool)
-    touched[torch.nonzero(flip)[:, 0] // S] = True
-    touched[cs_idx[both][~c] // S] = True
-    return rep, touched.numpy()
+    touched[torch.nonzero(al['flip'])[:, 0] // S] = True
+    touched[al['cs_idx'][al['both']][~c] // S] = True
+    return touched.numpy()
+
+
+def sample_protocol(o, cs_idx, cs_vid, cs_tvid, sample_out, S, eps=EPS):
+    """Ours against the fp32 oracle.  o: oracle dict with mask [N], d2_all [N], valid [nv], vert_id, t_vert_id, vert_gap, t_vert_gap,
+    sample_rgb, sample_sigma.  cs_idx / cs_vid / cs_tvid [n] int, sample_out [n,4] = (rgb, sigma raw): the implementation's compact
+    samples (any order).  -> report dict (python scalars) + per-ray bool array `ray_touched` (ray contains a flipped or in-margin
+    sample).  The caller asserts `sigma_rel_max`, `rgb_rel_max` <= tol (clean = same branches, all three margins > eps)."""
+    rep, al = _align(o, cs_idx, cs_vid, cs_tvid, eps)
+    so = _t(sample_out).double()[al['both']]
+    io = al['io']
+    e_sig, e_rgb = _rel_errors(so[:, 3], so[:, :3], _t(o['sample_sigma']).view(-1)[io], _t(o['sample_rgb'])[io])
+    c = ~al['in_margin']
+    q = lambda v, p: float(torch.quantile(v[c], p)) if c.any() else 0.0
+    sig_o = _t(o['sample_sigma']).double().view(-1)[io].clamp(min=0)
+    rep.update(clean=int(c.sum()), in_margin=int((~c).sum()),
+               sigma_rel_max=q(e_sig, 1.0), sigma_rel_p999=q(e_sig, 0.999), sigma_rel_p99=q(e_sig, 0.99), sigma_rel_mean=float(e_sig[c].mean()) if c.any() else 0.0,
+               rgb_rel_max=q(e_rgb, 1.0), rgb_rel_p999=q(e_rgb, 0.999), rgb_rel_p99=q(e_rgb, 0.99), rgb_rel_mean=float(e_rgb[c].mean()) if c.any() else 0.0,
+               floors=dict(sigma=FLOOR_SIGMA, rgb=FLOOR_RGB),
+               sigma_rel_to_max=float((so[:, 3].clamp(min=0) - sig_o).abs()[c].max() / sig_o.max()) if c.any() else 0.0,
+               rgb_abs_max=float((so[:, :3] - _t(o['sample_rgb']).double()[io]).abs()[c].max()) if c.any() else 0.0)
+    return rep, _touched(al, S, c)
+
+
+def truth_protocol(o, truth, cs_idx, cs_vid, cs_tvid, sample_out, S, tol=1e-3, eps=EPS):
+    """Ours and the fp32 oracle `o` against the float64 truth on the oracle's branches (`truth`: sample_rgb [nv,3], sample_sigma [nv]
+    in the oracle's sample order).  Compared on EVERY common sample that sits on the same branches in both implementations (the
+    truth follows those branches, so nothing is excluded for being close to a margin).  -> (report, ray_touched); report['ok'] is
+    the verdict: Q_p(e_ours) <= Q_p(e_ref) + tol for p in QUANTILES, for sigma+ and for rgb."""
+    rep, al = _align(o, cs_idx, cs_vid, cs_tvid, eps)
+    so = _t(sample_out).double()[al['both']]
+    io = al['io']
+    sig_t, rgb_t = _t(truth['sample_sigma']).view(-1)[io], _t(truth['sample_rgb'])[io]
+    eo_sig, eo_rgb = _rel_errors(so[:, 3], so[:, :3], sig_t, rgb_t)                                           # ours vs truth
+    er_sig, er_rgb = _rel_errors(_t(o['sample_sigma']).view(-1)[io], _t(o['sample_rgb'])[io], sig_t, rgb_t)   # fp32 reference vs truth
+    ed_sig, ed_rgb = _rel_errors(so[:, 3], so[:, :3], _t(o['sample_sigma']).view(-1)[io], _t(o['sample_rgb'])[io])   # ours vs fp32 reference
+    c = al['same']
+    q = lambda v, p: float(torch.quantile(v[c], p)) if c.any() else 0.0
+    table, ok = {}, True
+    for name, eo, er, ed in (('sigma', eo_sig, er_sig, ed_sig), ('rgb', eo_rgb, er_rgb, ed_rgb)):
+        rows = {}
+        for p in QUANTILES:
+            a, b = q(eo, p), q(er, p)
+            rows['max' if p == 1.0 else f'p{100 * p:g}'] = dict(ours_vs_truth=a, ref32_vs_truth=b, ours_vs_ref32=q(ed, p), ok=bool(a <= b + tol))
+            ok = ok and a <= b + tol
+        rows['mean'] = dict(ours_vs_truth=float(eo[c].mean()) if c.any() else 0.0, ref32_vs_truth=float(er[c].mean()) if c.any() else 0.0,
+                            ours_vs_ref32=float(ed[c].mean()) if c.any() else 0.0)
+        table[name] = rows
+    rep.update(compared=int(c.sum()), table=table, tol=tol, ok=bool(ok), floors=dict(sigma=FLOOR_SIGMA, rgb=FLOOR_RGB),
+               criterion='quantile_p(|ours - fp64|) <= quantile_p(|fp32 reference - fp64|) + tol for p in (50, 99, 99.9, 100) %, sigma+ and rgb, '
+                         'true relative error with floors, over every common sample on the same branches')
+    return rep, _touched(al, S, ~al['in_margin'])
+
+
+def format_truth_table(rep):
+    """The table of truth_protocol as text (profiles/, test logs)."""
+    lines = [f"compared {rep['compared']} samples (common {rep['common']}; flips: mask {rep['mask_flips']}, vertex {rep['vertex_flips']}, "
+             f"t-vertex {rep['t_vertex_flips']}); tol {rep['tol']:g}; verdict {'PASS' if rep['ok'] else 'FAIL'}",
+             f"{'':10s}{'quantile':>9s}{'|ours-fp64|':>14s}{'|ref32-fp64|':>14s}{'|ours-ref32|':>14s}"]
+    for name in ('sigma', 'rgb'):
+        for k, r in rep['table'][name].items():
+            lines.append(f"{name:10s}{k:>9s}{r['ours_vs_truth']:14.3e}{r['ref32_vs_truth']:14.3e}{r['ours_vs_ref32']:14.3e}" + ('' if r.get('ok', True) else '   <-- FAIL'))
+    return '\n'.join(lines)
 
 
 def image_protocol(rgb, acc, o_rgb, o_acc, ray_touched, tol=1e-3, target_seed=5):

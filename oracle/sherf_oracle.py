@@ -55,13 +55,14 @@ def depths(near, far, S):
 # SMPL helpers
 # ----------------------------------------------------------------------------------------------
 def smpl_tensors(smpl):
-    """renderer.py:65-74."""
+    """renderer.py:65-74.  (Rounded to fp32 first, as the reference holds them, also in the float64 truth mode: the tables, like the
+    0.005 voxel size and the encodings' phase buffer below, are fp32 INPUTS of the function.)"""
     out = {}
-    out['v_template'] = torch.tensor(np.asarray(smpl['v_template'], dtype=float), dtype=F32)
-    out['shapedirs'] = torch.tensor(np.asarray(smpl['shapedirs'], dtype=float), dtype=F32)
-    out['posedirs'] = torch.tensor(np.asarray(smpl['posedirs'], dtype=float), dtype=F32)
-    out['weights'] = torch.tensor(np.asarray(smpl['weights'], dtype=float), dtype=F32)
-    out['J_regressor'] = torch.tensor(smpl['J_regressor'].toarray().astype(float), dtype=F32)
+    out['v_template'] = torch.tensor(np.asarray(smpl['v_template'], dtype=float), dtype=torch.float32).to(F32)
+    out['shapedirs'] = torch.tensor(np.asarray(smpl['shapedirs'], dtype=float), dtype=torch.float32).to(F32)
+    out['posedirs'] = torch.tensor(np.asarray(smpl['posedirs'], dtype=float), dtype=torch.float32).to(F32)
+    out['weights'] = torch.tensor(np.asarray(smpl['weights'], dtype=float), dtype=torch.float32).to(F32)
+    out['J_regressor'] = torch.tensor(smpl['J_regressor'].toarray().astype(float), dtype=torch.float32).to(F32)
     out['parents'] = torch.tensor(np.asarray(smpl['kintree_table']).astype(float), dtype=torch.long)[0]
     out['f'] = torch.tensor(np.asarray(smpl['f']).astype(float), dtype=torch.long)
     return out
@@ -161,9 +162,11 @@ def target_to_canonical(st, params, t_params, verts_smpl_unused, x_s, v_s, vid):
     return x_c, v_c
 
 
-def canonical_to_obs_world(st, obs_params, t_params, t_vertices, x_c):
-    """renderer.py:623-684 -> (world_src_pts [n,3], nearest T-vertex id [n])."""
-    _, k = nearest_vertex(x_c, t_vertices)
+def canonical_to_obs_world(st, obs_params, t_params, t_vertices, x_c, k=None):
+    """renderer.py:623-684 -> (world_src_pts [n,3], nearest T-vertex id [n]).  k: the nearest T-vertex ids, when they are GIVEN
+    (fp64 truth mode: the discrete decisions of the fp32 run are reused, see truth64_from_fixture)."""
+    if k is None:
+        _, k = nearest_vertex(x_c, t_vertices)
     bw = st['weights'][k]
     bw = bw + 0.2 * 0
     bw = bw / torch.sum(bw, -1, keepdim=True)
@@ -188,7 +191,7 @@ def positional_encoding(x, F):
     """renderer.py:875-916: [x, sin(f0 x), sin(f0 x + pi/2), sin(f1 x), ...] each a d_in-vector."""
     freqs = 2.0 ** torch.linspace(0.0, F - 1, F)
     fr = torch.repeat_interleave(freqs, 2).view(1, -1, 1)
-    ph = torch.zeros(2 * F); ph[1::2] = math.pi * 0.5
+    ph = torch.zeros(2 * F); ph[1::2] = float(np.float32(math.pi * 0.5))      # the fp32 `_phases` buffer (renderer.py:893)
     e = torch.sin(torch.addcmul(ph.view(1, -1, 1), x.unsqueeze(1).repeat(1, 2 * F, 1), fr)).view(x.shape[0], -1)
     return torch.cat([x, e], -1)
 
@@ -282,7 +285,7 @@ def prepare_sp_input(t_vertices, xyz):
     """triplane.py:174-217. t_vertices [6890,3] (canonical), xyz [6890,3] canonicalised obs verts."""
     mn = t_vertices.min(0)[0] - 0.05
     mx = t_vertices.max(0)[0] + 0.05
-    vs = torch.tensor([VOXEL] * 3, dtype=F32)
+    vs = torch.tensor([VOXEL] * 3, dtype=torch.float32).to(F32)
     dhw = xyz[:, [2, 1, 0]]
     coord = torch.round((dhw - mn[[2, 1, 0]][None]) / vs).to(torch.int32)
     out_sh = torch.ceil((mx[[2, 1, 0]] - mn[[2, 1, 0]]) / vs).to(torch.int32)
@@ -381,7 +384,7 @@ def sparse_encoder(state, feat, coord, out_sh, training=True, prefix='renderer.e
 def voxel_grid_coords(x_c, bounds, out_sh):
     """renderer.py:544-556 -> normalised (x,y,z) grid coords in [-1,1] of the level-0 volume."""
     dhw = x_c[:, [2, 1, 0]] - bounds[0][[2, 1, 0]][None]
-    dhw = dhw / torch.tensor([VOXEL] * 3, dtype=F32)
+    dhw = dhw / torch.tensor([VOXEL] * 3, dtype=torch.float32).to(F32)
     dhw = dhw / torch.tensor(out_sh, dtype=F32) * 2 - 1
     return dhw[:, [2, 1, 0]]
 
@@ -478,10 +481,12 @@ def composite(colors, sigma, t, rays_d, white_back=False):
 # the whole path
 # ----------------------------------------------------------------------------------------------
 def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, ray_d, near, far,
-           input_data, options, training=True, keep=True):
+           input_data, options, training=True, keep=True, decisions=None):
     """ImportanceRenderer.forward, renderer.py:286-398 (all feature branches on, NeRF decoder, transformer).
     planes [3,32,P,P]; obs_img [3,H,W]; obs_feat [64,H/2,W/2]; vertex_feat [6890,32]; ray_* [R,3]; near/far [R].
-    Returns dict with rgb [R,3], depth [R], acc [R] and (keep=True) every intermediate."""
+    Returns dict with rgb [R,3], depth [R], acc [R] and (keep=True) every intermediate.
+    decisions: dict(valid, vert_id, t_vert_id) = the three discrete selections of ANOTHER run (truth64_from_fixture); the K-NN
+    searches are then skipped and the continuous part of the path is evaluated on exactly those branches."""
     S = int(options['depth_resolution'])
     R_ = ray_o.shape[0]
     P = input_data['params']; OP = input_data['obs_params']; TP = input_data['t_params']
@@ -491,16 +496,24 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
     v = ray_d[:, None, :].expand(-1, S, -1).reshape(-1, 3)
     x_s = torch.matmul(x - Th, Rg); v_s = torch.matmul(v, Rg)                  # :309-310
     verts_s = torch.matmul(input_data['vertices'].view(-1, 3) - Th, Rg)        # :313-314
-    d2, vid_all = nearest_vertex(x_s, verts_s)                                 # :315
-    mask = d2 < THRESH2                                                        # :316-319
-    valid = torch.nonzero(mask)[:, 0]
+    if decisions is None:
+        d2, vid_all = nearest_vertex(x_s, verts_s)                             # :315
+        mask = d2 < THRESH2                                                    # :316-319
+        valid = torch.nonzero(mask)[:, 0]
+    else:
+        valid = decisions['valid'].long()
+        mask = torch.zeros(R_ * S, dtype=torch.bool); mask[valid] = True
+        vid_all = torch.zeros(R_ * S, dtype=torch.long); vid_all[valid] = decisions['vert_id'].long()
+        d2 = None
+        keep = False
     out = dict(t=t, mask=mask, valid=valid)
     nv = valid.numel()
     sig_full = torch.full((R_ * S,), -80.0); col_full = torch.zeros(R_ * S, 3)  # :364-368
     if nv > 0:
         xs, vs, vid = x_s[valid], v_s[valid], vid_all[valid]
         x_c, v_c = target_to_canonical(st, P, TP, verts_s, xs, vs, vid)        # :323
-        x_w, tvid = canonical_to_obs_world(st, OP, TP, input_data['t_vertices'].view(-1, 3), x_c)   # :328
+        x_w, tvid = canonical_to_obs_world(st, OP, TP, input_data['t_vertices'].view(-1, 3), x_c,
+                                           None if decisions is None else decisions['t_vert_id'].long())   # :328
         uv = project_uv(x_w, input_data['obs_R_all'].view(3, 3), input_data['obs_T_all'].view(3, 1), input_data['obs_K_all'].view(3, 3))
         f2d, tap_rgb = pixel_aligned_features(uv, obs_feat, obs_img)           # :330-340
         taps = sparse_encoder(state, vertex_feat, sp_input['coord'], sp_input['out_sh'], training)
@@ -519,48 +532,15 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
             rgbs.append(rgb); sigs.append(sig); toks_in.append(tok); toks_out.append(z)
         rgb_s, sig_s = torch.cat(rgbs), torch.cat(sigs)
         col_full[valid] = rgb_s; sig_full[valid] = sig_s
-        if keep or options.get('margins'):
+        if decisions is not None:
+            out.update(vert_id=vid, t_vert_id=tvid, sample_rgb=rgb_s, sample_sigma=sig_s, x_c=x_c)
+        elif keep or options.get('margins'):
             # decision margins of the three discontinuous selectors on the path (shell threshold, nearest posed vertex, nearest
             # T-pose vertex): what tests / bench use to tell an implementation's legitimate boundary flips from errors
             out.update(d2_all=d2, vert_gap=second_nearest_gap(xs, verts_s, vid),
                        t_vert_gap=second_nearest_gap(x_c, input_data['t_vertices'].view(-1, 3), tvid))
             if not keep:
                 out.update(vert_id=vid, t_vert_id=tvid, sample_rgb=rgb_s, sample_sigma=sig_s)
-        if options.get('margins') and options.get('condition_probe', 4e-7) > 0:
-            # CONDITIONING of the reference's own function at fp32 input rounding.  Everything downstream of the canonical position x_c
-            # -- the nearest T-vertex, the projection into the observation view, 24 + 12 + 4 interpolation taps into tables that are
-            # white noise in the synthetic workload, positional encodings up to 2^5 x, a decoder whose density head has gain 20 -- is
-            # re-evaluated with x_c moved by +eps and by -eps along each axis in turn (eps = 4e-7: the size of the legitimate fp32 differences
-            # between two evaluation orders of the warp chain, cf. test_warp_matches_literal_lbs_chain).  The SUM over the three axes
-            # of the change of the reference's OWN sigma / rgb bounds (to first order) what any displacement of at most eps per
-            # coordinate does to them: what no fp32 re-implementation can be expected to undercut.
-            eps = float(options.get('condition_probe', 4e-7))
-            tv = input_data['t_vertices'].view(-1, 3)
-            c_sig = torch.zeros(nv); c_rgb = torch.zeros(nv); c_flip = torch.zeros(nv, dtype=torch.bool)
-            floor_s, floor_c = float(options.get('floor_sigma', 1.0)), float(options.get('floor_rgb', 0.1))
-            for axis in range(3):
-              # both directions: the tables are piecewise linear, so a one-sided difference misses the kink (cell / texel boundary) that
-              # lies on the other side of the sample -- seen at full size, where the worst of 46 K pinned samples beat its one-sided
-              # bound by 1.7e-3; per axis the LARGER of the two changes enters the sum
-              a_sig = torch.zeros(nv); a_rgb = torch.zeros(nv)
-              for sign in (1.0, -1.0):
-                xp = x_c.clone()
-                xp[:, axis] += sign * eps
-                xw_p, tv_p = canonical_to_obs_world(st, OP, TP, tv, xp)
-                uv_p = project_uv(xw_p, input_data['obs_R_all'].view(3, 3), input_data['obs_T_all'].view(3, 1), input_data['obs_K_all'].view(3, 3))
-                f2d_p, _ = pixel_aligned_features(uv_p, obs_feat, obs_img)
-                g_p = voxel_grid_coords(xp, sp_input['bounds'], sp_input['out_sh'])
-                f3d_p = torch.cat([trilinear_sparse(k, f, s_, g_p) for (k, f, s_) in taps], -1) @ Wp.t() + state['renderer.conv1d_projection.bias']
-                for s0 in range(0, nv, CHUNK):
-                    sl = slice(s0, s0 + CHUNK)
-                    z = transformer(state, fuse_tokens(state, triplane_features(planes, xp[sl], bounds), f2d_p[sl], f3d_p[sl]))
-                    rgb_p, sig_p = nerf_decoder(state, positional_encoding(xp[sl], 6), z, positional_encoding(v_c[sl], 4))
-                    ds = (torch.relu(sig_p.view(-1)) - torch.relu(sig_s[sl].view(-1))).abs() / torch.relu(sig_s[sl].view(-1)).clamp(min=floor_s)
-                    dc = ((rgb_p - rgb_s[sl]).abs() / rgb_s[sl].abs().clamp(min=floor_c)).max(1)[0]
-                    a_sig[sl] = torch.maximum(a_sig[sl], ds); a_rgb[sl] = torch.maximum(a_rgb[sl], dc)
-                c_flip |= tv_p != tvid
-              c_sig += a_sig; c_rgb += a_rgb
-            out.update(cond_sigma=c_sig, cond_rgb=c_rgb, cond_flip=c_flip, cond_eps=torch.tensor(eps))
         if keep:
             out.update(vert_id=vid, vert_d2=d2[valid], x_s=xs, v_s=vs, x_c=x_c, v_c=v_c, x_w=x_w, t_vert_id=tvid, uv=uv,
                        f2d=f2d, tap_rgb=tap_rgb, grid=g, f3d_raw=f3d_raw, f3d=f3d, tokens_in=torch.cat(toks_in),
@@ -581,21 +561,70 @@ def render_from_fixture(fx, state, training=True, keep=True, device=None):
     return _render_from_fixture(fx, state, training, keep, None)
 
 
-def _render_from_fixture(fx, state, training, keep, device):
+class _working_dtype:
+    """Everything above takes its floating-point type from the module global `F32` and torch's default dtype; inside this context
+    both are float64."""
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __enter__(self):
+        global F32
+        self.prev = (F32, torch.get_default_dtype())
+        F32 = self.dt
+        torch.set_default_dtype(self.dt)
+
+    def __exit__(self, *a):
+        global F32
+        F32 = self.prev[0]
+        torch.set_default_dtype(self.prev[1])
+
+
+def truth64_from_fixture(fx, state, ref32, training=True, device=None):
+    """The fp64 TRUTH of the continuous part of the path: the same restatement evaluated in float64 from the same fp32 inputs and
+    weights (converted exactly), on the discrete branches of the fp32 run `ref32` (its valid set, nearest posed vertex and nearest
+    T-vertex per sample, its voxel coordinates: `render_from_fixture(...)` output, keep=False + options['margins'] or keep=True).
+    Both fp32 implementations -- this oracle run in fp32, pinned to the unmodified reference, and the HIP path -- are then measured
+    against it sample by sample (oracle/parity.py: truth_protocol): the independent arbiter VERDICT round 2 asked for in place of the
+    first-order conditioning probe.  -> dict(sample_rgb [nv,3], sample_sigma [nv], rgb, acc, depth, x_c), float64."""
+    dec = dict(valid=ref32['valid'], vert_id=ref32['vert_id'], t_vert_id=ref32['t_vert_id'])
+    spi = ref32['sp_input']
+    with _working_dtype(torch.float64):
+        def run(dev):
+            dd = lambda a: (a.double() if a.is_floating_point() else a) if torch.is_tensor(a) else a
+            st64 = {k: dd(v if dev is None else v.to(dev)) for k, v in state.items()}
+            sp64 = dict(coord=spi['coord'] if dev is None else spi['coord'].to(dev), out_sh=spi['out_sh'],
+                        bounds=dd(spi['bounds'] if dev is None else spi['bounds'].to(dev)))
+            if dev is not None:
+                dec_d = {k: v.to(dev) for k, v in dec.items()}
+            else:
+                dec_d = dec
+            return _render_from_fixture(fx, st64, training, False, dev, decisions=dec_d, sp_input=sp64, cast=torch.float64)
+        if device is not None:
+            with torch.device(device):
+                return run(torch.device(device))
+        return run(None)
+
+
+def _render_from_fixture(fx, state, training, keep, device, decisions=None, sp_input=None, cast=None):
     def to(a):
         if isinstance(a, np.ndarray):
             a = torch.from_numpy(np.ascontiguousarray(a))
+        if cast is not None and torch.is_tensor(a) and a.is_floating_point():
+            a = a.to(cast)
         return a.to(device) if device is not None and torch.is_tensor(a) else a
     d = {k: ({kk: to(vv) for kk, vv in v.items()} if isinstance(v, dict) else to(v)) for k, v in fx['input_data'].items()}
     st = smpl_tensors(fx['smpl'])
     OP = d['obs_params']
     obs_s = torch.matmul(d['obs_vertices'].view(-1, 3) - OP['Th'].view(1, 3), OP['R'].view(3, 3))
-    _, ovid = nearest_vertex(obs_s, obs_s)
-    obs_can, _ = target_to_canonical(st, OP, d['t_params'], obs_s, obs_s, None, ovid)       # triplane.py:129-132
-    sp_input = prepare_sp_input(d['t_vertices'].view(-1, 3), obs_can)
+    if sp_input is None:
+        _, ovid = nearest_vertex(obs_s, obs_s)
+        obs_can, _ = target_to_canonical(st, OP, d['t_params'], obs_s, obs_s, None, ovid)       # triplane.py:129-132
+        sp_input = prepare_sp_input(d['t_vertices'].view(-1, 3), obs_can)
+    else:
+        obs_can = None
     res = render(state, st, to(fx['planes'])[0], d['obs_img_all'][0, 0], to(fx['obs_feat'])[0], to(fx['vertex_feat']), sp_input,
                  d['ray_o_all'][0, 0], d['ray_d_all'][0, 0], d['near_all'][0, 0, :, 0], d['far_all'][0, 0, :, 0], d, fx['options'],
-                 training=training, keep=keep)
+                 training=training, keep=keep, decisions=decisions)
     res['sp_input'] = sp_input
     res['obs_vertex_canonical'] = obs_can
     return res

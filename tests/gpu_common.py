@@ -14,9 +14,20 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 @functools.lru_cache(None)
-def seeded_state():
+def state(variant='seeded'):
+    """name -> tensor for every renderer / decoder parameter: 'seeded' = the adversarial weights, 'ri' = the reference constructors'
+    distribution (synthdata/fixtures.py: refinit_param)."""
     shapes = json.load(open(os.path.join(GOLDEN, 'param_shapes.json')))
-    return {n: torch.from_numpy(fixtures.seeded_param(n, s)) for n, s in shapes.items() if fixtures.seeded_param(n, s) is not None}
+    vals = {n: fixtures.param_value(variant, n, s, shapes) for n, s in shapes.items()}
+    return {n: torch.from_numpy(v) for n, v in vals.items() if v is not None}
+
+
+def seeded_state():
+    return state('seeded')
+
+
+def state_for(cfg):
+    return state(fixtures.variant_of(cfg))
 
 
 @functools.lru_cache(None)
@@ -32,7 +43,7 @@ def fixture(cfg):
 
 @functools.lru_cache(4)
 def oracle_render(cfg, training=True):
-    return O.render_from_fixture(fixture(cfg), seeded_state(), training=training, keep=True)
+    return O.render_from_fixture(fixture(cfg), state_for(cfg), training=training, keep=True)
 
 
 # tests/test_hipcpu_frame.py sets this: the same parity tests then run with CPU tensors against the libraries built for the
@@ -71,13 +82,13 @@ def to_cuda(x):
 
 
 @functools.lru_cache(None)
-def hip_modules(precision='f16x3'):
+def hip_modules(precision='f16x3', variant='seeded'):
     from sherf_amd.renderer import ImportanceRenderer
     from sherf_amd.triplane import NeRFDecoder
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl(), mlp_precision=precision)
     dec = NeRFDecoder(32)
-    fixtures.load_seeded_state(rend, 'renderer.')
-    fixtures.load_seeded_state(dec, 'decoder.')
+    fixtures.load_seeded_state(rend, 'renderer.', variant)
+    fixtures.load_seeded_state(dec, 'decoder.', variant)
     if CPU_SHIM:
         rend._side = lambda dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})()
     return dev_module(rend).train(), dev_module(dec).train()
@@ -88,7 +99,7 @@ def hip_render(cfg, precision='f16x3', training=True, fx=None, sp_input=None, op
     prepare_sp_input so this isolates the renderer (the TriPlaneGenerator glue has its own test)."""
     from sherf_amd.voxel import SparseConvTensor
     fx = fx or fixture(cfg)
-    rend, dec = hip_modules(precision)
+    rend, dec = hip_modules(precision, fixtures.variant_of(cfg) if cfg in fixtures.CONFIGS else 'seeded')
     rend.train(training)
     if sp_input is None:
         sp_input = oracle_render(cfg)['sp_input']

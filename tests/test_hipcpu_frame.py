@@ -363,6 +363,11 @@ def test_full_training_step_with_the_reconstruction_loss(cpu_product, monkeypatc
     assert float(after) < float(total)
 
 
+def test_reference_init_variant_plain_tolerance(cpu_product):
+    """The well-conditioned workload (SURVEY 8(d)'s network, band-limited tables): every sample within 1e-3 of the oracle."""
+    P.test_margin_protocol_whole_frame('tiny_ri')
+
+
 def test_size_independent_properties_and_rotation(cpu_product):
     P.test_deterministic_and_ray_independent()
     P.test_global_rotation_flip_rate()
@@ -376,7 +381,8 @@ def test_config1_and_per_sample_precision(cpu_product):
     P.test_per_sample_sigma_rgb('f16x3', 1e-3, 1e-3)
     P.test_per_sample_sigma_rgb('bf16', 5e-2, 5e-2)
     P.test_end_to_end_vs_oracle_and_reference_golden('cfg1')
-    P.test_margin_protocol_whole_frame('cfg1')
+    P.test_margin_protocol_whole_frame('cfg1')              # adversarial weights: against the float64 truth
+    P.test_margin_protocol_whole_frame('cfg1_ri')           # reference-init network: within 1e-3 of the oracle outright
 
 
 def test_training_step_through_autograd_matches_reference_gradients(cpu_product, monkeypatch):

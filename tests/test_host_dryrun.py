@@ -157,13 +157,15 @@ def test_full_size_property_test_plumbing(monkeypatch):
         f = dict(fx or G.fixture(cfg))
         opts = dict(f['options']); opts.update(options or {})
         f['options'] = dict(opts, margins=True)
-        r = O.render_from_fixture(f, G.seeded_state(), training=training, keep=False)
+        r = O.render_from_fixture(f, G.state_for(cfg), training=training, keep=False)
         nv = r['valid'].numel()
         ws = dict(counters=torch.tensor([nv, 0, 0, 0]), cs_idx=r['valid'].int(), cs_vid=r['vert_id'].int(), cs_tvid=r['t_vert_id'].int(),
                   sample_out=torch.cat([r['sample_rgb'], r['sample_sigma'].view(-1, 1)], 1))
         return dict(rgb=r['rgb'], depth=r['depth'], acc=r['acc'], last=dict(ws=ws), rend=None)
     monkeypatch.setattr(T.G, 'hip_render', fake_render)
-    T._full_size_properties('tiny', 7)
+    T._full_size_properties('tiny', 7)                                   # subset mode (host build of the kernels)
+    T._full_size_properties('tiny_ri', 7, check_stride=5, device='cpu')  # whole-frame mode: the oracle "on the device" + its cross-check
+    T._full_size_properties('tiny', 7, check_stride=5, device='cpu')
 
 
 # ---- bench.py: roofline.traffic from rocprofv3 --pmc child passes ------------------------------------------------------------------

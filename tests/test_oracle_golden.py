@@ -223,3 +223,66 @@ def test_dataset_ray_restatement_matches_reference_source(golden_dir):
         for got, key in ((ray_o, 'ray_o'), (ray_d, 'ray_d'), (near, 'near'), (far, 'far'), (at_box, 'mask_at_box')):
             assert np.array_equal(got, g[f'{name}_{key}']), (name, key)
         assert (ray_d == np.float32(1e-8)).sum() > 0          # every case has exact zeros for the reference to patch
+
+
+# ---- the reference-init ("_ri") variant: SURVEY section 8(d)'s network, band-limited tables (synthdata/fixtures.py) ----------------
+def _state_ri(golden_dir):
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    vals = {n: fixtures.param_value('ri', n, s, shapes) for n, s in shapes.items()}
+    return {n: torch.from_numpy(v) for n, v in vals.items() if v is not None}
+
+
+def test_refinit_matches_reference_constructors(golden_dir):
+    """`fixtures.refinit_param` restates the distributions of the reference's own constructors.  The record
+    (tests/golden/refinit_reference_constructors.json) was taken from modules the unmodified reference built under torch.manual_seed(0)
+    (oracle/make_golden.py: run_refinit_check): every tensor we set to ones / zeros is ones / zeros there, every tensor we draw
+    uniformly is uniform there with the same bound 1/sqrt(fan_in) -- and our draw has the same statistics."""
+    rec = json.load(open(os.path.join(golden_dir, 'refinit_reference_constructors.json')))
+    shapes = json.load(open(os.path.join(golden_dir, 'param_shapes.json')))
+    seen = 0
+    for name, shp in shapes.items():
+        v = fixtures.param_value('ri', name, shp, shapes)
+        if v is None:
+            continue
+        r = rec[name]; seen += 1
+        if r['kind'] in ('ones', 'zeros'):
+            assert np.all(v == (1.0 if r['kind'] == 'ones' else 0.0)), name
+            continue
+        fan_in = r['fan_in']
+        off = 5.0 if name.endswith('alpha_linear.bias') else 0.0               # the documented density bias
+        assert r['max_scaled'] <= 1.0 + 1e-6 and np.abs(v - off).max() * np.sqrt(fan_in) <= 1.0 + 1e-6, name
+        if r['numel'] >= 2048:
+            assert abs(r['std_scaled'] - 1.0) < 0.05 and abs(float((v - off).std()) * np.sqrt(3 * fan_in) - 1.0) < 0.05, name
+    assert seen == len(rec)
+
+
+def test_tiny_ri_every_stage_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'renderer_tiny_ri.npz'))
+    r = O.render_from_fixture(fixtures.renderer_inputs('tiny_ri'), _state_ri(golden_dir), training=True)
+    mask = np.unpackbits(g['mask_bits'])[:int(g['n_samples'])].astype(bool)
+    assert (r['mask'].numpy() == mask).all() and (r['vert_id'].numpy() == g['vert_id']).all() and (r['t_vert_id'].numpy() == g['t_vert_id']).all()
+    for k, tol in (('x_c', 1e-5), ('x_w', 1e-5), ('uv', 1e-5), ('f2d', 5e-5), ('f3d_raw', 2e-4), ('f3d', 2e-4), ('sample_rgb', 1e-5),
+                   ('sample_sigma', 1e-5), ('weights', 1e-5)):
+        assert _rel(r[k], g[k]) < tol, (k, _rel(r[k], g[k]))
+    n = r['tokens_in'].shape[0]
+    assert _rel(r['tokens_out'], g['tokens_out'].reshape(n, 3, 32)) < 1e-5
+    assert _rel(r['rgb'], g['rgb']) < 1e-5 and _rel(r['acc'], g['acc'][:, 0]) < 1e-5
+
+
+def test_cfg1_ri_and_float64_truth(golden_dir):
+    """cfg1 with the reference-init network: the oracle against the unmodified reference's outputs, and the float64 truth mode against
+    both -- on this well-conditioned workload fp32 and float64 agree to fp32 rounding, per sample."""
+    from oracle import parity
+    g = np.load(os.path.join(golden_dir, 'renderer_cfg1_ri.npz'))
+    st = _state_ri(golden_dir)
+    fx = fixtures.renderer_inputs('cfg1_ri')
+    r = O.render_from_fixture(fx, st, training=True, keep=True)
+    mask = np.unpackbits(g['mask_bits'])[:int(g['n_samples'])].astype(bool)
+    assert (r['mask'].numpy() == mask).all() and (r['vert_id'].numpy() == g['vert_id']).all()
+    assert _rel(r['sample_sigma'], g['sample_sigma']) < 1e-5 and _rel(r['sample_rgb'], g['sample_rgb']) < 1e-5
+    assert _rel(r['rgb'], g['rgb']) < 1e-5 and O.psnr(r['rgb'], torch.from_numpy(g['rgb'])) > 100.0
+    t = O.truth64_from_fixture(fx, st, r)
+    assert t['sample_sigma'].dtype == torch.float64 and torch.get_default_dtype() == torch.float32 and O.F32 == torch.float32
+    e_sig, e_rgb = parity._rel_errors(torch.from_numpy(g['sample_sigma']), torch.from_numpy(g['sample_rgb']), t['sample_sigma'], t['sample_rgb'])
+    print(f'reference (fp32) vs float64 truth on cfg1_ri: sigma+ rel max {float(e_sig.max()):.2e}, rgb rel max {float(e_rgb.max()):.2e}')
+    assert float(e_sig.max()) < 1e-5 and float(e_rgb.max()) < 1e-5
