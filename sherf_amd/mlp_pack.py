@@ -115,7 +115,8 @@ def bias_table(vec, rows):
 
 
 N_STEPS = 43
-PRECISIONS = {'bf16': 0, 'f16x3': 1}
+PRECISIONS = {'bf16': 0, 'f16x3': 1, 'f16': 2}
+N_PIECE = {0: 1, 1: 2, 2: 1}          # 1 KiB fragments per unit: hi [, lo]
 
 
 def step_units(s):
@@ -151,16 +152,46 @@ def step_unit(s, u):
 
 
 def step_pieces(s, prec):
-    return (step_units(s) * (prec + 1) + 3) // 4 * 4
+    return (step_units(s) * N_PIECE[prec] + 3) // 4 * 4
 
 
 def _f16_bits(x):
     return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).view(np.uint16)
 
 
+F16_MAX = 65504.0
+
+
+def check_f16_range(sd, r='renderer.', d='decoder.', prec=1):
+    """The fp16 modes (prec 1, 2) hold weights AND activations as fp16 (hi [+ lo]): a value beyond 65504 would turn into inf - inf =
+    NaN silently.  Weights are checked here (non-finite or out of range -> ValueError; pack with prec 0 = bf16, which has fp32's
+    range, or rescale).  Activations: the kernel's inputs are encodings in [-1, 1] and O(1) tokens; a layer's output is bounded by
+    |x|_inf * max_row |W|_1 + |b|, so the product of those row norms bounds every activation -- it must stay below the fp16 range
+    too (a trained 8 x 128 ReLU decoder sits many orders below: ~1e1 per layer would be needed to reach it)."""
+    if prec == 0:
+        return
+    bound = 64.0                    # generous bound on |input|_inf: PE in [-1, 1], LayerNorm'd tokens, |x_c| of a few metres
+    for name, v in sd.items():
+        if not (name.startswith(d) or name.startswith(r + 'transformer') or name.startswith(r + 'conv1d_reprojection')):
+            continue
+        a = np.asarray(v, dtype=np.float32)
+        if not np.isfinite(a).all():
+            raise ValueError(f'{name}: non-finite values; the MLP weight stream cannot be packed')
+        if a.size and float(np.abs(a).max()) > F16_MAX:
+            raise ValueError(f'{name}: |w| up to {float(np.abs(a).max()):.3g} exceeds the fp16 range of mlp_precision f16x3 / f16; use bf16')
+    # a-priori bound of the activations: loose by orders of magnitude on real weights (it assumes every sign aligned), so it is only
+    # used to REJECT the absurd -- per-layer gains that let it reach 1e30 mean activations can really leave the fp16 range
+    for lname in [f'{d}pts_linears.{i}' for i in range(8)] + [d + 'feature_linear', d + 'views_linear']:
+        W = np.abs(np.asarray(sd[lname + '.weight'], np.float64)).sum(1).max()
+        bound = bound * W + np.abs(np.asarray(sd[lname + '.bias'], np.float64)).max()
+    if bound > 1e30:
+        raise ValueError(f'decoder weight norms allow activations up to ~{bound:.1e}: outside the fp16 range of mlp_precision f16x3 / f16; use bf16')
+
+
 def pack(sd, r='renderer.', d='decoder.', prec=1):
-    """-> (stream uint8 [bytes], wbias float32 [(49+4)*32], nkb list) for the kernel's `prec` (1 = f16x3, 0 = bf16)."""
-    assert prec in (0, 1)
+    """-> (stream uint8 [bytes], wbias float32 [(49+4)*32], nkb list) for the kernel's `prec` (1 = f16x3, 0 = bf16, 2 = f16)."""
+    assert prec in (0, 1, 2)
+    check_f16_range(sd, r, d, prec)
     specs = chunk_specs(sd, r, d)
     frag, bias, nkbs = [], [], []
     for sp in specs:
@@ -168,6 +199,8 @@ def pack(sd, r='renderer.', d='decoder.', prec=1):
         if prec == 1:
             hi = _f16_bits(img)
             lo = _f16_bits(img - hi.view(np.float16).astype(np.float32))
+        elif prec == 2:
+            hi, lo = _f16_bits(img), None
         else:
             hi, lo = _bf16_bits(img), None
         frag.append((hi, lo))
@@ -179,7 +212,7 @@ def pack(sd, r='renderer.', d='decoder.', prec=1):
         for u in range(step_units(s_)):
             cu = step_unit(s_, u)
             if cu is None:
-                parts.append(bytes(1024 * (prec + 1)))
+                parts.append(bytes(1024 * N_PIECE[prec]))
             else:
                 c, kb = cu
                 assert kb < nkbs[c] and cu not in used, (s_, u, cu)
@@ -187,7 +220,7 @@ def pack(sd, r='renderer.', d='decoder.', prec=1):
                 parts.append(frag[c][0][kb].tobytes())
                 if prec == 1:
                     parts.append(frag[c][1][kb].tobytes())
-            n += prec + 1
+            n += N_PIECE[prec]
         parts.append(bytes(1024 * (step_pieces(s_, prec) - n)))
     assert len(used) == sum(nkbs), 'every (chunk, K-block) unit must be streamed exactly once'
     t = r + 'transformer.layers.0.'

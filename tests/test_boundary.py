@@ -71,7 +71,7 @@ def test_mlp_stream_layout_matches_packer():
     """The step table of the weight stream: the library's own export (csrc/mlp.hip, constexpr -- what the kernel walks) against its
     restatement in the packer, for both precisions."""
     from sherf_amd import mlp_pack
-    for prec in (0, 1):
+    for prec in (0, 1, 2):
         n = ctypes.c_int32(0)
         pieces = (ctypes.c_int32 * 64)()
         units = (ctypes.c_int32 * 640)()
@@ -82,7 +82,7 @@ def test_mlp_stream_layout_matches_packer():
             for u in range(10):
                 want = mlp_pack.step_unit(s, u) if u < mlp_pack.step_units(s) else None
                 assert units[s * 10 + u] == (-1 if want is None else want[0] * 16 + want[1]), (s, u)
-    assert _lib.lib().sherf_mlp_stream_layout(2, ctypes.byref(n), pieces, units, 64) != 0
+    assert _lib.lib().sherf_mlp_stream_layout(3, ctypes.byref(n), pieces, units, 64) != 0
 
 
 def test_struct_layouts_match_header(tmp_path):

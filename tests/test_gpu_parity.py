@@ -183,6 +183,32 @@ def test_margin_protocol_whole_frame(cfg):
         _assert_plain(cfg, *_protocol(o, h, S))
 
 
+def test_auto_precision_is_calibrated_per_weights():
+    """mlp_precision='auto' (the product default): the first frame of a set of weights renders in f16x3 and measures the cheaper
+    modes on its own samples; the reference-init network then runs on single fp16 products and stays within 1e-3 of the oracle on
+    every sample, the adversarial seeded weights stay on f16x3."""
+    picks = {}
+    for cfg in ('tiny_ri', 'tiny'):
+        G.hip_modules.cache_clear()
+        first = G.hip_render(cfg, precision='auto')
+        rep = first['rend'].auto_report
+        picks[cfg] = rep['choice']
+        print(f"{cfg}: auto -> {rep['choice']} (errors vs f16x3 {rep['errors_vs_f16x3']}, {rep['samples']} samples)")
+        assert first['last']['mlp_precision'] == 'f16x3'                      # the calibration frame itself is fp32-grade
+        h = G.hip_render(cfg, precision='auto')
+        assert h['last']['mlp_precision'] == rep['choice'] and h['rend'].check_finite()
+        o = G.oracle_render(cfg)
+        fx = dict(G.fixture(cfg)); fx['options'] = dict(fx['options'], margins=True)
+        om = O.render_from_fixture(fx, G.state_for(cfg), training=True, keep=False)
+        _assert_plain(f'{cfg} auto={rep["choice"]}', *_protocol(om, h, fx['options']['depth_resolution']))
+        # new weights -> calibrated again
+        with torch.no_grad():
+            h['dec'].alpha_linear.bias.add_(0.0)
+        assert h['rend']._resolve_precision('auto', h['dec'], h['rgb'].device if False else next(h['dec'].parameters()).device)[1]
+    G.hip_modules.cache_clear()
+    assert picks == {'tiny_ri': 'f16', 'tiny': 'f16x3'}, picks
+
+
 def test_eval_mode_batchnorm_uses_running_stats():
     """Eval mode normalises with the RUNNING statistics.  Every train-mode render before this test has advanced them (as
     nn.BatchNorm1d does, also under no_grad: voxel.SparseConvNet.finish), so the seeded buffers the oracle uses are restored first --

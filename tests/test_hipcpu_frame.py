@@ -115,24 +115,46 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
                         lambda a, lrank, timeout=300, save=None: bench.torch_gpu_baseline(a.config, torch.device('cpu'), a.bn_mode == 'train', iters=1, save=save))
     monkeypatch.setattr(bench, 'pmc_traffic', lambda a, lrank, timeout=150: dict(hbm_bytes_per_launch=12345, note='faked'))
     monkeypatch.setattr(bench, 'SECONDARY_ITERS', dict(mlp=1, mlp_warmup=0, frames=1, frames_warmup=0))
-    fixtures.CONFIGS['cfg3'], keep3 = dict(fixtures.CONFIGS['tiny']), fixtures.CONFIGS['cfg3']          # the secondary workloads, tiny-sized here
-    fixtures.CONFIGS['cfg2_dense'], keepd = dict(fixtures.CONFIGS['tiny'], fill=1.55), fixtures.CONFIGS['cfg2_dense']
+    keep = {k: fixtures.CONFIGS[k] for k in ('cfg3', 'cfg2_dense', 'cfg3_ri', 'cfg2_dense_ri', 'cfg2')}
+    for sfx, var in (('', {}), ('_ri', dict(variant='ri'))):                       # the secondary workloads, tiny-sized here
+        fixtures.CONFIGS['cfg3' + sfx] = dict(fixtures.CONFIGS['tiny'], **var)
+        fixtures.CONFIGS['cfg2_dense' + sfx] = dict(fixtures.CONFIGS['tiny'], fill=1.55, **var)
+    fixtures.CONFIGS['cfg2'] = dict(fixtures.CONFIGS['tiny_nv'])
     try:
-        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--exact-grids'])
+        # the default workload: the reference-init network, precision 'auto' (-> one fp16 product), parity = truth protocol + plain 1e-3
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny_ri', '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--exact-grids'])
         bench.main()
+        res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
+        assert res['config']['mlp_precision'] == 'f16' and res['config']['mlp_precision_requested'] == 'auto' and res['dtype'].startswith('f16 MFMA')
+        assert res['config']['mlp_precision_auto']['choice'] == 'f16' and res['config']['exact_grids'] is True and res['config']['valid_samples'] > 0
+        assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and res['roofline']['traffic'] == 12345
+        assert 'frame_timeline_ms' in res and res['torch_gpu_baseline']['value'] > 0 and res['torch_gpu_baseline']['speedup_vs_it'] > 0
+        sec = res['secondary']
+        assert sec['mlp_kernel_alone']['f16x3']['kernel_ms'] > 0 and 1e-6 < sec['mlp_kernel_alone']['f16']['rgb_rel_err_max_vs_f16x3'] < 1e-3
+        assert sec['mlp_kernel_alone']['bf16']['rgb_rel_err_max_vs_f16x3'] > sec['mlp_kernel_alone']['f16']['rgb_rel_err_max_vs_f16x3']
+        assert sec['cfg3_ri']['rays_per_s'] > 0 and sec['cfg2_dense_ri']['valid_fraction'] > sec['cfg3_ri']['valid_fraction']
+        assert sec['cfg2']['mlp_precision'] == 'f16x3'                               # the adversarial weights stay fp32-grade under `auto`
+        assert res['value_dense'] == sec['cfg2_dense_ri']['rays_per_s'] and res['valid_fraction_dense'] == sec['cfg2_dense_ri']['valid_fraction']
+        par = res['parity']
+        assert res['parity_ok'] is True and par['ok'] and par['truth_ok'] and par['plain_ok'] and par['flips_ok'] and par['image_ok']
+        assert par['samples']['sigma_rel_max'] < 1e-3 and par['samples']['rgb_rel_max'] < 1e-3
+        assert par['truth']['table']['sigma']['max']['ours_vs_truth'] < 1e-3 and par['image']['psnr_vs_oracle_db'] > 60.0
+        # the adversarial workload under f16x3: the truth protocol alone
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'f16x3', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+                                          '--no-secondary'])
+        bench.main()
+        res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert res['config']['mlp_precision'] == 'f16x3' and res['parity_ok'] is True and 'plain_ok' not in res['parity']
+        # a precision that misses the tolerance: the JSON line says so and the process exits non-zero
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'bf16', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+                                          '--no-secondary', '--no-pmc'])
+        with pytest.raises(SystemExit) as ex:
+            bench.main()
+        res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert ex.value.code == 3 and res['parity_ok'] is False and res['parity']['truth_ok'] is False
     finally:
-        fixtures.CONFIGS['cfg3'], fixtures.CONFIGS['cfg2_dense'] = keep3, keepd
-    res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
-    assert res['config']['mlp_precision'] == 'f16x3' and res['config']['exact_grids'] is True and res['config']['valid_samples'] > 0
-    assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and res['roofline']['traffic'] == 12345
-    assert 'frame_timeline_ms' in res and res['torch_gpu_baseline']['value'] > 0 and res['torch_gpu_baseline']['speedup_vs_it'] > 0
-    sec = res['secondary']
-    assert sec['mlp_kernel_alone']['f16x3']['kernel_ms'] > 0 and sec['mlp_kernel_alone']['bf16_single_product']['sigma_err_rel_to_max_vs_f16x3'] > 1e-4
-    assert sec['cfg3']['rays_per_s'] > 0 and sec['cfg2_dense']['valid_fraction'] > sec['cfg3']['valid_fraction']
-    par = res['parity']
-    assert par['samples']['mask_flip_max_margin'] < 1e-6 and par['samples']['sigma_rel_max'] < 1e-3 and par['samples']['rgb_rel_max'] < 1e-3
-    assert par['image']['rays_over_tolerance_unexplained'] == 0 and par['image']['psnr_vs_oracle_db'] > 60.0
+        fixtures.CONFIGS.update(keep)
 
 
 def test_bench_two_ranks_dry_run(cpu_product):
@@ -366,6 +388,7 @@ def test_full_training_step_with_the_reconstruction_loss(cpu_product, monkeypatc
 def test_reference_init_variant_plain_tolerance(cpu_product):
     """The well-conditioned workload (SURVEY 8(d)'s network, band-limited tables): every sample within 1e-3 of the oracle."""
     P.test_margin_protocol_whole_frame('tiny_ri')
+    P.test_auto_precision_is_calibrated_per_weights()
 
 
 def test_size_independent_properties_and_rotation(cpu_product):
