@@ -51,11 +51,29 @@ def stub_missing_packages():
     except Exception:
         from . import voxel
         core = _stub('spconv.core', SparseConvTensor=voxel.SparseConvTensor)
-        pt = _stub('spconv.pytorch', core=core, SparseConvTensor=voxel.SparseConvTensor, SparseSequential=_missing, SubMConv3d=_missing,
-                   SparseConv3d=_missing, SparseInverseConv3d=_missing)
+        cont = _checkpoint_containers()
+        pt = _stub('spconv.pytorch', core=core, SparseConvTensor=voxel.SparseConvTensor, **cont)
+        # the module paths spconv 2.x's own classes live at (what a checkpoint pickled with the real package refers to)
+        pt.conv = _stub('spconv.pytorch.conv', **{k: v for k, v in cont.items() if 'Conv' in k})
+        pt.modules = _stub('spconv.pytorch.modules', SparseModule=cont['SparseModule'], SparseSequential=cont['SparseSequential'])
         sp = _stub('spconv', pytorch=pt, core=core)
         made.append('spconv')
     return made
+
+
+def _checkpoint_containers():
+    """Classes under spconv's names that can only be UNPICKLED: a network snapshot written where spconv was installed
+    (training_loop.py:563-579 pickles the whole generator; the sparse layers go in by import path) then loads on a machine without it --
+    `legacy.load_network_pkl` (legacy.py:24-62) needs the classes to exist, `misc.copy_params_and_buffers` (training_loop.py:207-208)
+    only reads their parameters.  Constructing or calling one raises."""
+    import torch.nn as nn
+
+    def make(name):
+        def __init__(self, *a, **k):
+            _missing()
+        return type(name, (nn.Module,), dict(__init__=__init__, forward=lambda self, *a, **k: _missing(), __module__='spconv.pytorch',
+                                             __doc__='parameter container standing in for spconv.pytorch.%s in unpickled checkpoints' % name))
+    return {n: make(n) for n in ('SparseModule', 'SparseSequential', 'SubMConv3d', 'SparseConv3d', 'SparseInverseConv3d', 'SubMConv2d', 'SparseConv2d')}
 
 
 def install(stub_missing=True):

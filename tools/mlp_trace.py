@@ -29,7 +29,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--every', type=int, default=61)
     ap.add_argument('--rounds', type=int, default=3)
-    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--config', default='cfg2_ri')
+    ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'], help='the precision the variants / the trace run in')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_trace.json'))
     a = ap.parse_args()
     import bench
@@ -37,6 +38,8 @@ def main():
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     ns = argparse.Namespace(config=a.config, precision='f16x3', bn_mode='train')
+    from sherf_amd.renderer import MLP_PRECISIONS
+    P = MLP_PRECISIONS[a.precision]
     w = bench.make_workload(ns, 0.4, dev)
     for _ in range(2):
         bench.render_frame(w)
@@ -48,7 +51,7 @@ def main():
     A = _lib.addr
     capx = (nv + 255) // 256 * 256
     stream = ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    wcs = {p: {k: v for k, v in rend._weights(dec, dev, p).items() if k in ('stream', 'wbias')} for p in ('f16x3', 'bf16')}
+    wcs = {p: {k: v for k, v in rend._weights(dec, dev, p).items() if k in ('stream', 'wbias')} for p in ('f16x3', 'bf16', 'f16')}
     out = torch.empty(tiles * 32, 4, device=dev)
 
     def bind(path):
@@ -58,11 +61,12 @@ def main():
         f.argtypes = [ct.c_void_p] * 5 + [ct.c_int, ct.c_int64, ct.c_void_p, ct.c_void_p]
         return lib, f
 
-    def launch(f, prec=1):
-        wc = wcs['f16x3' if prec else 'bf16']
+    def launch(f, prec=None):
+        prec = P if prec is None else prec
+        wc = wcs[{0: 'bf16', 1: 'f16x3', 2: 'f16'}[prec]]
         return f(A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), prec, capx, A(out), stream)
 
-    def timed(f, prec=1, iters=20):
+    def timed(f, prec=None, iters=20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
@@ -100,7 +104,7 @@ def main():
     report['bf16_single_product_ms'] = bt
     print(f'[bf16 x1] ms {" ".join(f"{x:.3f}" for x in bt)}')
     flop = nv * bench.FLOP_PER_VALID_SAMPLE
-    print(f'[roofline] f16x3 {flop / (min(times["product"]) * 1e-3) / 1e12 / bench.PEAK_BF16_TFLOPS:.3f}   bf16 x1 {flop / (min(bt) * 1e-3) / 1e12 / bench.PEAK_BF16_TFLOPS:.3f} of the bf16 peak')
+    print(f'[roofline] {a.precision} {flop / (min(times["product"]) * 1e-3) / 1e12 / bench.PEAK_BF16_TFLOPS:.3f}   bf16 x1 {flop / (min(bt) * 1e-3) / 1e12 / bench.PEAK_BF16_TFLOPS:.3f} of the bf16 peak')
 
     if 'trace' in bound:
         lib, f = bound['trace']
