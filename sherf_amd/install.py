@@ -83,6 +83,10 @@ def install(stub_missing=True):
     R = importlib.import_module('training.volumetric_rendering.renderer')
     T = importlib.import_module('training.triplane')
     R.ImportanceRenderer = T.ImportanceRenderer = renderer.ImportanceRenderer
+    # under torch.enable_grad() the hosted renderer records itself as ONE autograd node whose backward is the HIP backward pipeline
+    # (what the reference's loss.backward() at loss.py:173 then runs through); under no_grad -- every test / inference entry point of the
+    # reference -- nothing changes
+    renderer.ImportanceRenderer.enable_autograd = True
     T.NeRFDecoder = triplane.NeRFDecoder
     T.RaySampler = ray_sampler.RaySampler
     T.spconv = types.SimpleNamespace(core=types.SimpleNamespace(SparseConvTensor=voxel.SparseConvTensor))
