@@ -136,7 +136,7 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
 /* mode 0: all taps; 1: tri-plane + pixel taps only (levels_host may be NULL) -- can run before the voxel encoder has
  * finished; 2: voxel taps only, ADDED onto the tokens written by a mode-1 pass.  `mode | 4`: the voxel-row loads of the 8 corners are
  * issued unconditionally (absent corners read row 0 with weight 0) instead of under one branch per corner -- same sums, a schedule
- * variant timed per device by sherf_amd.tune; `mode | 12`: the same compiled for 4 waves / SIMD (128 VGPRs instead of 160). */
+ * variant (opt-in, rendering_options['gather_branchless']); `mode | 12`: the same compiled for 4 waves / SIMD (128 VGPRs instead of 160). */
 
 /* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
  * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):

@@ -213,19 +213,33 @@ __global__ void plain_gemm_kernel(int transA, int transB, int M, int N, int K, c
 
 }  // namespace
 
+static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA, 2 = weight-gradient MFMA, 0 = plain
+extern "C" int sherf_bwd_gemm_last_path() { return g_last_path; }
+
 extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, float beta, sherf_stream_t stream) {
     SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
     hipStream_t st = as_stream(stream);
     const int NT = (N + 31) / 32, nkb = (K + 15) / 16;
-    if (!transA && NT <= 8 && (size_t)nkb * NT * 3072 <= 156 * 1024) {
-        const size_t smem = (size_t)nkb * NT * 3072;
+    // tall product: the small matrix B lives in LDS as MFMA fragments (3072 bytes per (K-block, 32-column tile): hi + lo + ...).  When
+    // the whole of B does not fit (the skip layer's data gradient dx = dy[n,128] . W[128,199]: 8 K-blocks x 7 tiles = 168 KiB), the
+    // columns are cut into slices that do and the kernel is launched once per slice (offset B and C) -- every decoder shape of the
+    // backward stays on the MFMA path (tests/test_backward_dense.py: test_decoder_shapes_stay_on_mfma).
+    const int nt_fit = min(8, (int)((156 * 1024) / ((size_t)nkb * 3072)));
+    if (!transA && nt_fit >= 1 && NT <= 4 * nt_fit) {
         const int tiles = (M + 31) / 32, grid = min((tiles + 3) / 4, n_cus());
+        for (int n0 = 0; n0 < N; n0 += 32 * nt_fit) {
+            const int Ns = min(N - n0, 32 * nt_fit), NTs = (Ns + 31) / 32;
+            const size_t smem = (size_t)nkb * NTs * 3072;
+            const float* Bs = transB ? B + (size_t)n0 * ldb : B + n0;
+            float* Cs = C + n0;
 #define SHERF_TALL(n) case n: \
-        if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, B, ldb, transB, C, ldc, M, N, K, beta); break
-        switch (NT) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
+            if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+            hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta); break
+            switch (NTs) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
 #undef SHERF_TALL
+        }
+        g_last_path = 1;
         SHERF_LAUNCH_CHECK();
     }
     const int MT = (M + 31) / 32;
@@ -240,8 +254,10 @@ extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const
         }
 #undef SHERF_WGN
 #undef SHERF_WG
+        g_last_path = 2;
         SHERF_LAUNCH_CHECK();
     }
+    g_last_path = 0;
     hipLaunchKernelGGL(plain_gemm_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta);
     SHERF_LAUNCH_CHECK();
 }

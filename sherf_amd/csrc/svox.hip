@@ -557,6 +557,9 @@ struct BnRunning {
 __global__ void __launch_bounds__(128) bn_running_kernel(BnRunning u) {
     const int l = blockIdx.x;
     const float m = u.momentum[l], n = (float)u.n[l][0];
+    // a level with <= 1 row has no unbiased variance (n / (n - 1)): nn.BatchNorm1d raises there ("Expected more than 1 value per
+    // channel"); a device kernel cannot, so the running statistics of such a layer are left untouched instead of turning into inf / NaN
+    if (n < 2.0f) return;
     for (int c = threadIdx.x; c < u.C[l]; c += 128) {
         u.rmean[l][c] = u.rmean[l][c] * (1.0f - m) + m * u.stats[l][c];
         u.rvar[l][c] = u.rvar[l][c] * (1.0f - m) + m * u.stats[l][u.C[l] + c] * n / (n - 1.0f);

@@ -56,15 +56,19 @@ def gather_rays(local, n_rays, tile=1024):
     return full
 
 
-def depth_range(near, far):
+def depth_range(near, far, reduce=False):
     """[lo, hi] (float32 tensor [2] on near's device) of ALL sample depths t_k = near + k/(S-1) (far - near) of a frame: what
-    MipRayMarcher2 clamps the depth image with (ray_marcher.py:57: the min / max over the WHOLE tensor).  Evaluated exactly as the
-    sampler does (t_0 = near, t_{S-1} = near + (far - near)) on this rank's rays, then MIN / MAX-reduced over the ranks (one
-    8-byte all_reduce), so that a rank rendering a subset of the rays clamps with the frame's range, not its subset's:
-    pass it as rendering_options['depth_range']."""
+    MipRayMarcher2 clamps the depth image with (ray_marcher.py:57: the min / max over the WHOLE tensor).  t is linear in k, so the
+    extremes of a ray are its end points t_0 = near and t_{S-1} = near + (far - near) (evaluated exactly as the sampler does) -- in
+    EITHER order: a ray with far < near contributes t_{S-1} to the minimum, as in the reference's torch.min / max over all depths and
+    in the frame kernel's own depth_minmax.  Pass the FULL frame's near / far (every rank of a ray-tile sharded frame holds them: no
+    collective needed) and hand the result to the renderer as rendering_options['depth_range'], so that a rank rendering a subset
+    of the rays clamps with the frame's range, not its subset's.  reduce=True: for callers that only hold their own rays -- the
+    per-rank ranges are MIN / MAX-reduced over the ranks (one 8-byte all_reduce)."""
     n, f = near.detach().float().reshape(-1), far.detach().float().reshape(-1)
-    v = torch.stack([-n.min(), (n + (f - n)).max()])                  # one MAX reduction serves both ends
-    if world()[1] > 1:
+    e = n + (f - n)
+    v = torch.stack([-torch.minimum(n, e).min(), torch.maximum(n, e).max()])     # (one MAX reduction serves both ends)
+    if reduce and world()[1] > 1:
         dist.all_reduce(v, op=dist.ReduceOp.MAX)
     return torch.stack([-v[0], v[1]])
 

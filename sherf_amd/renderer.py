@@ -253,7 +253,7 @@ class ImportanceRenderer(nn.Module):
         # '128' = unconditional loads compiled for 4 waves / SIMD
         self.gather_branchless = {'0': False, '1': True, '128': '128'}[os.environ.get('SHERF_GATHER_BRANCHLESS', '0')]
         # SHERF_FRAME_EXACT_GRIDS (sherf_hip.h): launch warp / gather / MLP for the frame's actual valid-sample count (one host wait per
-        # frame, where the reference has its own) instead of the R*S capacity; same results, chosen per device by sherf_amd.tune
+        # frame, where the reference has its own) instead of the R*S capacity; same results
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream

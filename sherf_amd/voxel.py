@@ -189,8 +189,13 @@ class SparseConvNet(nn.Module):
             return
         VP, A = ctypes.c_void_p * n, _lib.addr
         rows = [pl['L'][0]['n_total'] if m['lev'] == 0 else pl['L'][m['lev']]['n_rows'] for m in ms]
-        _lib.call('sherf_svox_bn_running_update', n, VP(*[A(m['stats']) for m in ms]), VP(*[A(m['bn'].running_mean) for m in ms]),
-                  VP(*[A(m['bn'].running_var) for m in ms]), VP(*[A(m['bn'].num_batches_tracked) for m in ms]), VP(*[A(r) for r in rows]),
+        for m in ms:
+            if m['bn'].momentum is None:
+                raise NotImplementedError('BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the native running-'
+                                          'statistics update; the reference uses momentum=0.01 (renderer.py:807)')
+        f32, i32, i64 = torch.float32, torch.int32, torch.int64                    # the kernel reads raw pointers: check what they point at
+        _lib.call('sherf_svox_bn_running_update', n, VP(*[A(m['stats'], f32) for m in ms]), VP(*[A(m['bn'].running_mean, f32) for m in ms]),
+                  VP(*[A(m['bn'].running_var, f32) for m in ms]), VP(*[A(m['bn'].num_batches_tracked, i64) for m in ms]), VP(*[A(r, i32) for r in rows]),
                   (ctypes.c_int32 * n)(*[m['cout'] for m in ms]), (ctypes.c_float * n)(*[float(m['bn'].momentum) for m in ms]), _lib.stream())
 
     def encode(self, sp, fold_mats, ws):

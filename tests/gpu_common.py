@@ -81,8 +81,13 @@ def to_cuda(x):
     return x
 
 
-@functools.lru_cache(None)
 def hip_modules(precision='f16x3', variant='seeded'):
+    """(renderer, decoder) with the variant's weights, one pair per (precision, variant) for the whole session."""
+    return _hip_modules(precision, variant)
+
+
+@functools.lru_cache(None)
+def _hip_modules(precision, variant):
     from sherf_amd.renderer import ImportanceRenderer
     from sherf_amd.triplane import NeRFDecoder
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl(), mlp_precision=precision)
@@ -92,6 +97,10 @@ def hip_modules(precision='f16x3', variant='seeded'):
     if CPU_SHIM:
         rend._side = lambda dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})()
     return dev_module(rend).train(), dev_module(dec).train()
+
+
+hip_modules.cache_clear = _hip_modules.cache_clear
+hip_modules.__wrapped__ = lambda precision='f16x3', variant='seeded': _hip_modules.__wrapped__(precision, variant)      # a fresh, uncached pair
 
 
 def hip_render(cfg, precision='f16x3', training=True, fx=None, sp_input=None, options=None):
