@@ -29,6 +29,9 @@ const char* sherf_bwd_last_error(void);
  * oracle/backward_explicit.py (decoder_bwd.lin_bwd, transformer_bwd). */
 int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float beta, sherf_stream_t stream);
+/* which kernel the last sherf_bwd_gemm call of this process took: 1 = tall MFMA (column-sliced when B exceeds the LDS), 2 = weight-
+ * gradient MFMA, 0 = the plain fp32 kernel (tests assert that no layer shape of the path reaches it). */
+int sherf_bwd_gemm_last_path(void);
 
 /* tokens / extras of the forward (tile-major, sherf_gather_tokens) -> row-major tok[n][96], ext[n][12]; and the inverse
  * for d_tokens (rows beyond n are zero filled up to the tile boundary). */

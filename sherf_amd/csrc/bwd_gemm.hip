@@ -20,7 +20,8 @@
 //              from global memory (a lane's 8 K-values are 8 consecutive ROWS: 32 lanes read 32 consecutive floats of one row, coalesced);
 //              the waves split the output row tiles; partial sums are added to C with fp32 atomics (the reference does not require
 //              a deterministic reduction order, SURVEY section 7 hard part 6).
-// Any other shape / transposition goes to a plain fp32 kernel (correctness only: nothing on the path uses it).
+// Any other shape / transposition goes to a plain fp32 kernel (correctness only: no layer shape of the path reaches it,
+// tests/test_hipcpu_kernels.py; a tall product whose B fragments exceed the LDS is cut into column slices instead).
 #include "common.h"
 
 namespace {

@@ -70,6 +70,21 @@ def test_dense_entry_points_match_their_specification(cpu_lib, monkeypatch):
             for m in (a_c, a_g):
                 m.tensor().mul_(1e-7)
             e.gemm(tA, tB, a_c, b_c, c_c, 0.0); h.gemm(tA, tB, a_g, b_g, c_g, 0.0); _same(c_c, c_g)
+    # every GEMM shape of the decoder / transformer backward stays on the MFMA kernels -- also the skip layer's data gradient
+    # dx = dy[n,128] . W[128,199], whose fragment image (8 K-blocks x 7 column tiles) exceeds the LDS and is cut into column slices
+    # (it used to fall through to plain_gemm_kernel, 6.9 ms per call on the hardware)
+    cpu_lib.sherf_bwd_gemm_last_path.restype = ctypes.c_int
+    rows = 300
+    shapes = [(128, 71), (128, 128), (128, 199), (64, 187), (3, 64), (1, 128), (144, 32), (32, 48), (32, 32), (32, 96)]     # (out, in) of every Linear
+    for out_f, in_f in shapes:
+        for tA, tB, (M, N, K) in ((0, 0, (rows, in_f, out_f)),          # dx = dy . W
+                                  (0, 1, (rows, out_f, in_f)),          # forward recompute y = x . W^T
+                                  (1, 0, (out_f, in_f, rows))):         # dW = dy^T . x
+            a_c, a_g = _pair(*((K, M) if tA else (M, K)), seed=7)
+            b_c, b_g = _pair(*((N, K) if tB else (K, N)), seed=8)
+            c_c, c_g = _pair(M, N, ld=N + 3, seed=9)
+            e.gemm(tA, tB, a_c, b_c, c_c, 1.0); h.gemm(tA, tB, a_g, b_g, c_g, 1.0); _same(c_c, c_g)
+            assert cpu_lib.sherf_bwd_gemm_last_path() in (1, 2), (out_f, in_f, tA, tB)
     y_c, y_g = _pair(n, 40, 45, 4); b_c, b_g = _pair(1, 40, seed=5)
     for act in (0, 1):
         e.bias_act(y_c, b_c, act); h.bias_act(y_g, b_g, act); _same(y_c, y_g)
