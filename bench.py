@@ -262,8 +262,8 @@ def main():
     import ctypes as _ct
 
     def step():
-        rgb, depth, acc = render_frame(w)
-        tile = torch.cat([rgb[0], depth[0], acc[0]], 1)
+        render_frame(w)
+        tile = rend.last['out']          # the frame's output buffer as the kernel wrote it: planar [rgb (3R) | depth (R) | acc (R)], no repacking
         if world > 1:
             # the gather of this frame's tiles runs on RCCL's own stream (async_op) and is awaited one step later, so that it
             # overlaps the next frame's sampling instead of stalling the render stream for a latency-bound 5 MB exchange
@@ -337,7 +337,8 @@ def main():
                 res['valid_fraction_dense'] = dense['valid_fraction']
         ours = None
         if world == 1 and not a.no_torch_gpu_baseline:      # our own samples of the frame, for the margin protocol below
-            tile = step().detach().float().cpu().numpy()
+            flat = step().detach().float().cpu()
+            tile = torch.cat([flat[:3 * R].view(R, 3), flat[3 * R:4 * R].view(R, 1), flat[4 * R:].view(R, 1)], 1).numpy()   # [R,5] = (rgb, depth, acc)
             lw = rend.last['ws']
             ours = dict(tile=tile, cs_idx=lw['cs_idx'][:nv].cpu(), cs_vid=lw['cs_vid'][:nv].cpu(), cs_tvid=lw['cs_tvid'][:nv].cpu(),
                         sample_out=lw['sample_out'][:nv].cpu())

@@ -165,7 +165,6 @@ class _Workspace:
             ray_mask=torch.zeros(R * nch, dtype=torch.int64, device=dev), scan_ws=torch.zeros(R + R // 1024 + 2, **i32),
             geom=torch.zeros(cap, 8, **f32), tokens=torch.zeros(tiles * 3 * 8 * 32 * 4, **f32),
             extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(cap, 4, **f32),
-            rgb=torch.zeros(R, 3, **f32), depth=torch.zeros(R, **f32), acc=torch.zeros(R, **f32),
             A=torch.zeros(3, 24, 12, **f32), posefeat=torch.zeros(3, 207, **f32), PO=torch.zeros(3, V, 3, **f32),
             SO=torch.zeros(3, V, 3, **f32), T2C=torch.zeros(V, 12, **f32), C2S=torch.zeros(V, 12, **f32),
             grid_hdr=torch.zeros(2, 12, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
@@ -507,8 +506,14 @@ class ImportanceRenderer(nn.Module):
         fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
         for k in ('A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
                   'counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws', 'geom',
-                  'cs_tvid', 'tokens', 'extras', 'sample_out', 'rgb', 'depth', 'acc'):
+                  'cs_tvid', 'tokens', 'extras', 'sample_out'):
             setattr(fr, k, A(ws[k]))
+        # the frame's outputs: ONE fresh buffer per call, planar [rgb (3R) | depth (R) | acc (R)], written by the compositing kernel and
+        # returned as views -- no copies behind the frame (rounds 1-2 cloned three workspace tensors: three launches per frame), and
+        # a caller may keep as many frames as it likes
+        out = torch.empty(5 * R, dtype=torch.float32, device=dev)
+        fr.rgb, fr.depth, fr.acc = A(out), A(out) + 12 * R, A(out) + 16 * R
+        ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
         fr.obs_R, fr.obs_Th = a32(oprm['R'], 9), a32(oprm['Th'], 3)
         fr.cam_R, fr.cam_T, fr.cam_K = a32(input_data['obs_R_all'], 9), a32(input_data['obs_T_all'], 3), a32(input_data['obs_K_all'], 9)
         fr.verts, fr.tverts = a32(input_data['vertices'], V, 3), a32(input_data['t_vertices'], V, 3)
@@ -573,5 +578,6 @@ class ImportanceRenderer(nn.Module):
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min, vox_sh=[int(v) for v in obs_sp_input['out_sh']],
                                   coord=vcoord, H=H, W=W, white_back=bool(opts.get('white_back', False))))
-        return ws['rgb'].view(1, R, 3).clone(), ws['depth'].view(1, R, 1).clone(), ws['acc'].view(1, R, 1).clone()
+        self.last['out'] = out
+        return ws['rgb'].view(1, R, 3), ws['depth'].view(1, R, 1), ws['acc'].view(1, R, 1)
 
