@@ -136,7 +136,9 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
 /* mode 0: all taps; 1: tri-plane + pixel taps only (levels_host may be NULL) -- can run before the voxel encoder has
  * finished; 2: voxel taps only, ADDED onto the tokens written by a mode-1 pass.  `mode | 4`: the voxel-row loads of the 8 corners are
  * issued unconditionally (absent corners read row 0 with weight 0) instead of under one branch per corner -- same sums, a schedule
- * variant (opt-in, rendering_options['gather_branchless']); `mode | 12`: the same compiled for 4 waves / SIMD (128 VGPRs instead of 160). */
+ * variant (opt-in, rendering_options['gather_branchless']); `mode | 12`: the same compiled for 4 waves / SIMD (128 VGPRs instead of 160).
+ * `mode | 16`: planes_f, feat_f and the levels' rows hold fp16 (sherf_fold_tables(out_half), SHERF_FRAME_HALF_TABLES); img4, the
+ * arithmetic and the tokens stay fp32. */
 
 /* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
  * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):
@@ -153,7 +155,9 @@ int sherf_gather_tokens_bwd(const int32_t* counters, const float* geom, const fl
                             float* d_rows0, float* d_rows1, float* d_rows2, float* d_tok_bias, sherf_stream_t stream);
 
 int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int groups, int pix_stride,
-                      int64_t group_base, sherf_stream_t stream);
+                      int64_t group_base, int out_half, sherf_stream_t stream);
+/* out_half != 0: `out` is written as fp16 (same element offsets, 2 bytes each: the first half of the fp32-sized buffer) for
+ * sherf_gather_tokens(mode | 16). */
 /* obs image [3][HW] -> [HW][4] (rgb0) for the rgb tap of renderer.py:336 */
 int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t stream);
 
@@ -288,6 +292,10 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
  * reference synchronises at the same point (boolean-mask indexing, renderer.py:320-321).  Results are identical.
  */
 #define SHERF_FRAME_EXACT_GRIDS 1
+/* frame->flags & SHERF_FRAME_HALF_TABLES (opt-in; sherf_amd.ImportanceRenderer sets it with the single-product MLP precisions): the
+ * folded tri-plane / feature-map tables and the folded voxel rows are written and tapped as fp16 (round to nearest even; half the bytes
+ * through L2 in the gather, which is bound there).  Same buffers: their first half is used. */
+#define SHERF_FRAME_HALF_TABLES 2
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */

@@ -14,7 +14,7 @@
 
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                            sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
-                           sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels);   // svox.hip
+                           sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels, int fold_half);   // svox.hip
 
 namespace {
 
@@ -135,9 +135,10 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         };
         if (!stream_aux) SHERF_RUN(smpl_tables(stream_side));
         const int stagger = f->main_after_layer;
+        const int half_tables = (f->flags & SHERF_FRAME_HALF_TABLES) ? 1 : 0;      // folded tables + voxel rows in fp16 (the image stays fp32)
         auto fold_tables = [&](sherf_stream_t st) -> int {      // per-frame table re-layout (channel-last, projections folded in)
-            SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, st));
-            SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, st));
+            SHERF_RUN(sherf_fold_tables(f->planes, f->Wa_t, f->planes_f, f->P * f->P, 3, 32, (int64_t)f->P * f->P * 32, half_tables, st));
+            SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, half_tables, st));
             return sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, st);
         };
         if (stream_aux) {       // independent of rays and voxels: off the ray side's chain, ahead of the level builds
@@ -150,7 +151,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             const std::function<int()> smpl_on_aux = [&]() -> int { return smpl_tables(stream_aux); };
             SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
                                              stagger >= 0 ? d.ev_mid : nullptr, stagger, stream_aux, d.ev_lev,
-                                             stream_aux ? &smpl_on_aux : nullptr));
+                                             stream_aux ? &smpl_on_aux : nullptr, half_tables));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
             SHERF_PROF(2, side);
             return SHERF_OK;
@@ -190,7 +191,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
                                   f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, cap, f->geom,
                                   f->cs_tvid, stream_main));
-        const int gv = ((f->gather_split & 2) ? 4 : 0) | ((f->gather_split & 4) ? 12 : 0);   // bit 1: branchless voxel-row loads (mode | 4); bit 2: in 128 VGPRs (mode | 12)
+        const int gv = ((f->gather_split & 2) ? 4 : 0) | ((f->gather_split & 4) ? 12 : 0) |  // bit 1: branchless voxel-row loads (mode | 4); bit 2: in 128 VGPRs (mode | 12)
+                       (half_tables ? 16 : 0);                                                // mode | 16: fp16 tables
         if (f->gather_split & 1) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1 | gv, cap, f->tokens,

@@ -23,14 +23,28 @@ __device__ __forceinline__ void axpy4(float4& a, float w, const float4 v) {
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
+// one channel quad of a table: 16 bytes of fp32, or (HT) 8 bytes of fp16 widened in registers -- `idx` counts quads either way
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+template <bool HT>
+__device__ __forceinline__ float4 ldq(const void* __restrict__ base, size_t idx) {
+    if constexpr (HT) {
+        const h16x4 v = reinterpret_cast<const h16x4*>(base)[idx];
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    } else {
+        return reinterpret_cast<const float4*>(base)[idx];
+    }
+}
+
 // BL: voxel-row loads issued unconditionally (see phase 2 below); same taps, same sums -- a launch-time variant
 // (`mode | 4` of sherf_gather_tokens) so that it can be timed against the branching form on the device.
 // MINW: waves per SIMD the kernel is compiled for (register cap 512 / MINW): the unconditional form wants 160 VGPRs (3 waves / SIMD);
 // `mode | 12` asks for it squeezed into 128 (4 waves / SIMD) -- more loads per wave AND more waves, if the compiler finds the registers.
-template <bool BL, int MINW>
+// HT: fp16 tables (sherf_fold_tables(out_half) / the encoder's half fold rows): the kernel is bound by the bytes it pulls through L2
+// (74 % of its wave cycles wait, profiles/r03_pmc_mlp_gather_sampler.txt), so halving them is its speed-up; same taps, fp32 sums.
+template <bool BL, int MINW, bool HT>
 __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
-                                                            const float4* __restrict__ planes_f, int P,
-                                                            const float4* __restrict__ feat_f, int Hf, int Wf,
+                                                            const void* __restrict__ planes_f, int P,
+                                                            const void* __restrict__ feat_f, int Hf, int Wf,
                                                             const float4* __restrict__ img4, int H, int W, Levels lv,
                                                             const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
                                                             const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
@@ -72,7 +86,7 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
                         int xx = xi + dx, yy = yi + dy;
                         if (xx >= 0 && xx < P && yy >= 0 && yy < P) {
                             float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
-                            axpy4(acc[p], w, planes_f[((size_t)(p * P + yy) * P + xx) * 8 + l]);
+                            axpy4(acc[p], w, ldq<HT>(planes_f, ((size_t)(p * P + yy) * P + xx) * 8 + l));
                         }
                     }
             }
@@ -90,9 +104,9 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
                         int xx = xi + dx, yy = yi + dy;
                         if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
                             float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
-                            const float4* t = feat_f + ((size_t)yy * Wf + xx) * 16;
-                            axpy4(acc[0], w, t[l]);
-                            axpy4(acc[1], w, t[8 + l]);
+                            const size_t t = ((size_t)yy * Wf + xx) * 16;
+                            axpy4(acc[0], w, ldq<HT>(feat_f, t + l));
+                            axpy4(acc[1], w, ldq<HT>(feat_f, t + 8 + l));
                         }
                     }
                 px = clampf((gx + 1.f) * 0.5f * (W - 1), -2.f, (float)W + 1.f);
@@ -148,20 +162,20 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         const float w = rec[t].x ? ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz) : 0.f;
-                        const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)(rec[t].x ? rec[t].y : 0u) * 24;
-                        axpy4(acc[0], w, r[l]);
-                        axpy4(acc[1], w, r[8 + l]);
-                        axpy4(acc[2], w, r[16 + l]);
+                        const size_t r = (size_t)(rec[t].x ? rec[t].y : 0u) * 24;
+                        axpy4(acc[0], w, ldq<HT>(lev.rows, r + l));
+                        axpy4(acc[1], w, ldq<HT>(lev.rows, r + 8 + l));
+                        axpy4(acc[2], w, ldq<HT>(lev.rows, r + 16 + l));
                     }
                     } else {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         if (rec[t].x) {
                             const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
-                            const float4* r = reinterpret_cast<const float4*>(lev.rows) + (size_t)rec[t].y * 24;
-                            axpy4(acc[0], w, r[l]);
-                            axpy4(acc[1], w, r[8 + l]);
-                            axpy4(acc[2], w, r[16 + l]);
+                            const size_t r = (size_t)rec[t].y * 24;
+                            axpy4(acc[0], w, ldq<HT>(lev.rows, r + l));
+                            axpy4(acc[1], w, ldq<HT>(lev.rows, r + 8 + l));
+                            axpy4(acc[2], w, ldq<HT>(lev.rows, r + 16 + l));
                         }
                     }
                     }
@@ -322,6 +336,7 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && tok_bias && bounds && vox_min && vox_sh_host && tokens && extras);
     const bool branchless = (mode & 4) != 0 || SHERF_GATHER_BRANCHLESS;
     const bool squeezed = branchless && (mode & 8) != 0;
+    const bool half_tables = (mode & 16) != 0;
     mode &= 3;
     SHERF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 1 || levels_host));
     SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
@@ -332,12 +347,13 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     }
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
     const int64_t tiles = (capacity + 31) / 32;
-#define SHERF_GATHER(BL, MW)                                                                                                   \
-    hipLaunchKernelGGL((gather_tokens_kernel<BL, MW>), dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), \
-                       counters, geom, reinterpret_cast<const float4*>(planes_f), P, reinterpret_cast<const float4*>(feat_f), Hf, Wf, \
+#define SHERF_GATHER(BL, MW, HT)                                                                                               \
+    hipLaunchKernelGGL((gather_tokens_kernel<BL, MW, HT>), dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), \
+                       counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,         \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode)
-    if (squeezed) SHERF_GATHER(true, 4); else if (branchless) SHERF_GATHER(true, 1); else SHERF_GATHER(false, 1);
+    if (half_tables) { if (squeezed) SHERF_GATHER(true, 4, true); else if (branchless) SHERF_GATHER(true, 1, true); else SHERF_GATHER(false, 1, true); }
+    else { if (squeezed) SHERF_GATHER(true, 4, false); else if (branchless) SHERF_GATHER(true, 1, false); else SHERF_GATHER(false, 1, false); }
 #undef SHERF_GATHER
     SHERF_LAUNCH_CHECK();
 }

@@ -226,6 +226,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     // the encoder is a short serial chain of small launches running next to the ray side's chip-filling kernels: its
     // waves take issue priority over co-resident waves (measured -20..30 us per frame; sherf_set_debug bit 7 turns it off)
     if (!(mode & 256)) __builtin_amdgcn_s_setprio(3);
+    const bool out_half = FOLD && (mode & 512);          // folded rows as fp16 (the gather's half-table mode, csrc/fold.hip)
     mode &= 255;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
@@ -430,7 +431,11 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
         for (int rr = g; rr < 32; rr += G) {
             const float val = ((s_red[(0 * 32 + rr) * COUT + co] + s_red[(1 * 32 + rr) * COUT + co]) + s_red[(2 * 32 + rr) * COUT + co]) +
                               s_red[(3 * 32 + rr) * COUT + co];
-            if (row0 + rr < n_rows) { out_raw[(size_t)(row0 + rr) * COUT + co] = val; s1 += val; s2 += val * val; }
+            if (row0 + rr < n_rows) {
+                if (out_half) reinterpret_cast<_Float16*>(out_raw)[(size_t)(row0 + rr) * COUT + co] = (_Float16)val;
+                else out_raw[(size_t)(row0 + rr) * COUT + co] = val;
+                s1 += val; s2 += val * val;
+            }
         }
     if (out_acc) {
         __syncthreads();
@@ -587,6 +592,8 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
                         int Hi, int Wi, const float* in_raw, int Cin, BnIn bin, const int32_t* in_mult,
                         const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, int64_t* out_acc,
                         sherf_stream_t stream) {
+    const int out_half = (mode & 512) ? 512 : 0;
+    mode &= ~512;
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
     SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
@@ -595,7 +602,7 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     SHERF_CHECK_ARG(!in_mult || bin.bnparam);       // (the multiplicity only enters through the BatchNorm transform)
     const bool fold = mode == 2;
     const int bnm = bin.bnparam ? (in_mult ? 2 : 1) : 0;
-    const int kmode = mode | ((g_sherf_debug & 128) ? 256 : 0);
+    const int kmode = mode | ((g_sherf_debug & 128) ? 256 : 0) | (fold ? out_half : 0);
 #define SHERF_CONV3_(N, K, F, B)                                                                                             \
     hipLaunchKernelGGL((sconv3_kernel<N, K, F, B>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,     \
                        reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                                 \
@@ -653,7 +660,7 @@ static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {
 // must not wait behind them.
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                            sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
-                           sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels) {
+                           sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels, int fold_half) {
     SHERF_CHECK_ARG(p && coord && feat && n > 0 && levels_out_host && p->n_layers > 0 && p->n_layers <= SHERF_SVOX_MAX_LAYERS);
     SHERF_CHECK_ARG(p->zero_ptr && p->zero_bytes > 0 && p->acc_fix && p->g0 && p->mult && p->n_total);
     SHERF_CHECK_ARG(aux == nullptr || (lev_ev != nullptr && aux != stream));
@@ -717,7 +724,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
                 fst = aux;
             }
             SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, cur_bn, nullptr,
-                                   p->fold_mat[ntap], 96, 2, dst.cap, p->fold_rows[ntap], nullptr, fst));
+                                   p->fold_mat[ntap], 96, 2 | (fold_half ? 512 : 0), dst.cap, p->fold_rows[ntap], nullptr, fst));
             levels_out_host[ntap].wp = dst.wp;
             levels_out_host[ntap].rows = p->fold_rows[ntap];
             levels_out_host[ntap].D = dst.D; levels_out_host[ntap].H = dst.H; levels_out_host[ntap].W = dst.W;
@@ -734,5 +741,5 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
 
 extern "C" int sherf_svox_encode(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                                  sherf_vox_level* levels_out_host, sherf_stream_t stream) {
-    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1, nullptr, nullptr, nullptr);
+    return sherf_svox_encode_impl(p, coord, feat, n, training, levels_out_host, stream, nullptr, -1, nullptr, nullptr, nullptr, 0);
 }

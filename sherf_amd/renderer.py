@@ -231,7 +231,7 @@ _SIDE_STREAMS = {}           # device -> [side, aux]
 
 class ImportanceRenderer(nn.Module):
     def __init__(self, use_1d_feature=True, use_2d_feature=True, use_3d_feature=True, use_trans=False, use_NeRF_decoder=False,
-                 smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='auto'):
+                 smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='auto', table_precision='auto'):
         super().__init__()
         self.use_1d_feature, self.use_2d_feature, self.use_3d_feature = use_1d_feature, use_2d_feature, use_3d_feature
         self.use_trans, self.use_NeRF_decoder = use_trans, use_NeRF_decoder
@@ -247,6 +247,7 @@ class ImportanceRenderer(nn.Module):
         self.pos_enc = PositionalEncoding(num_freqs=6)
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
+        self.table_precision = table_precision            # 'auto' | 'f32' | 'f16' (see _half_tables)
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         # schedule variant of the voxel taps (sherf_hip.h): False = one branch per corner, True = unconditional loads (160 VGPRs),
         # '128' = unconditional loads compiled for 4 waves / SIMD
@@ -408,32 +409,54 @@ class ImportanceRenderer(nn.Module):
         choice = self._wcache['auto']
         return (choice, False) if choice is not None else ('f16x3', True)
 
-    def _calibrate(self, decoder, dev, ws, cap):
-        """mlp_precision='auto': run the MLP kernel of the frame just enqueued again in every candidate precision on the same tokens
-        and keep the cheapest one whose sigma+ / rgb stay within AUTO_TOL (true relative error with the parity floors) of the
-        f16x3 result on EVERY sample of the frame.  One extra launch per candidate and one host wait, once per set of weights."""
-        A = _lib.addr
-        st = _ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        ref = ws['sample_out']
-        nv = int(ws['counters'][0])
-        choice, report = 'f16x3', {}
-        if nv > 0:
-            sig_r = ref[:nv, 3].clamp(min=0)
-            for cand in self.AUTO_CANDIDATES:
-                wc = self._weights(decoder, dev, cand)
-                out = torch.empty_like(ref)
-                _lib.call('sherf_nerf_mlp', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
-                          MLP_PRECISIONS[cand], cap, A(out), st)
-                e_sig = ((out[:nv, 3].clamp(min=0) - sig_r).abs() / sig_r.clamp(min=1.0)).max()
-                e_rgb = ((out[:nv, :3] - ref[:nv, :3]).abs() / ref[:nv, :3].abs().clamp(min=0.1)).max()
-                e = float(torch.maximum(e_sig, e_rgb))
-                report[cand] = e
-                if e == e and e <= self.AUTO_TOL:
-                    choice = cand
-                    break
-        self._wcache['auto'] = choice
-        self.auto_report = dict(choice=choice, errors_vs_f16x3=report, samples=nv, tol=self.AUTO_TOL)
-        return choice
+    def _set_config(self, fr, decoder, dev, prec_name, half_tables, exact):
+        """The precision-dependent fields of the frame descriptor: the MLP fragment stream of `prec_name` and the table format."""
+        wc = self._weights(decoder, dev, prec_name)
+        fr.wstream, fr.wbias = _lib.addr(wc['stream']), _lib.addr(wc['wbias'])
+        fr.mlp_prec = MLP_PRECISIONS[prec_name]
+        fr.flags = (1 if exact else 0) | (2 if half_tables else 0)
+        return wc
+
+    def _calibrate(self, fr, decoder, dev, ws, levels, streams, exact):
+        """mlp_precision='auto': before the frame proper (f16x3, fp32 tables) the SAME frame is rendered in every candidate
+        configuration -- the cheaper MLP precision together with the fp16 tables it implies -- and its per-sample sigma+ / rgb are kept;
+        the cheapest candidate within AUTO_TOL (true relative error with the parity floors, every sample of the frame) of the f16x3
+        result is used from the next frame on.  One extra frame per candidate and one host wait, once per set of weights."""
+        cands = {}
+        for cand in self.AUTO_CANDIDATES:
+            self._set_config(fr, decoder, dev, cand, self._half_tables(cand, None), exact)
+            _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, *streams)
+            cands[cand] = ws['sample_out'].clone()
+        self._set_config(fr, decoder, dev, 'f16x3', False, exact)
+
+        def decide():
+            ref = ws['sample_out']
+            nv = int(ws['counters'][0])
+            choice, report = 'f16x3', {}
+            if nv > 0:
+                sig_r = ref[:nv, 3].clamp(min=0)
+                for cand, out in cands.items():
+                    e_sig = ((out[:nv, 3].clamp(min=0) - sig_r).abs() / sig_r.clamp(min=1.0)).max()
+                    e_rgb = ((out[:nv, :3] - ref[:nv, :3]).abs() / ref[:nv, :3].abs().clamp(min=0.1)).max()
+                    e = float(torch.maximum(e_sig, e_rgb))
+                    report[cand] = e
+                    if e == e and e <= self.AUTO_TOL:
+                        choice = cand
+                        break
+            self._wcache['auto'] = choice
+            self.auto_report = dict(choice=choice, errors_vs_f16x3=report, samples=nv, tol=self.AUTO_TOL,
+                                    tables={c: ('f16' if self._half_tables(c, None) else 'f32') for c in cands})
+            return choice
+        return decide
+
+    def _half_tables(self, prec_name, requested):
+        """Format of the folded tables the gather taps: 'f32' / 'f16' on request (rendering_options['table_precision'] or the
+        constructor's), otherwise fp16 exactly when the MLP runs on single products -- its first MFMA rounds the tokens to 11 (8)
+        bits anyway, and the calibration of `auto` measures the two together."""
+        req = requested or getattr(self, 'table_precision', 'auto')
+        if req in ('f32', 'f16'):
+            return req == 'f16'
+        return prec_name in ('f16', 'bf16')
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
@@ -529,7 +552,7 @@ class ImportanceRenderer(nn.Module):
         feat_f = self._ws.table('feat_f', (Hf, Wf, 64), dev)
         img4 = self._ws.table('img4', (H, W, 4), dev)
         fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, -1), A(wc['Wa_t']), A(planes_f), Pres
-        fr.flags = 1 if opts.get('exact_grids', self.exact_grids) else 0
+        exact = bool(opts.get('exact_grids', self.exact_grids))
         fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, -1), A(wc['Wb_t']), A(feat_f), Hf, Wf
         fr.obs_img, fr.img4, fr.H, fr.W = a32(obs_input_img, -1), A(img4), H, W
         fr.tok_bias, fr.bounds = A(wc['tok_bias']), a32(input_data['t_world_bounds'], 6)
@@ -546,14 +569,18 @@ class ImportanceRenderer(nn.Module):
         fr.vox_plan = _ct.addressof(pl['plan'])
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
         # a13-a14: fused transformer + NeRF decoder
-        fr.wstream, fr.wbias = A(wc['stream']), A(wc['wbias'])
-        fr.mlp_prec = MLP_PRECISIONS[prec_name]
+        half = self._half_tables(prec_name, opts.get('table_precision')) and not getattr(self, '_in_autograd', False)   # (the backward reads fp32 tables)
+        self._set_config(fr, decoder, dev, prec_name, half, exact)
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()
         s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
         s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if self.aux_stream else None
         noise = float(opts.get('density_noise', 0) or 0)
+        decide = None
+        if calibrate and noise == 0:
+            decide = self._calibrate(fr, decoder, dev, ws, levels, (s_main, s_side, s_aux), exact)
+            half = False
         rng = opts.get('depth_range')                                    # sherf_amd.dist: [lo, hi] of the WHOLE frame's depths
         if noise > 0 or rng is not None:
             _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
@@ -569,11 +596,11 @@ class ImportanceRenderer(nn.Module):
         else:
             _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side, s_aux)
         self.encoder_3d.finish(pl)
-        if calibrate and noise == 0:
-            self._calibrate(decoder, dev, ws, cap)
+        if decide is not None:
+            decide()
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=prec_name,
+        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=prec_name, table_precision='f16' if half else 'f32',
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min, vox_sh=[int(v) for v in obs_sp_input['out_sh']],

@@ -249,8 +249,10 @@ def test_batchnorm_backward_and_row_kernels_on_cpu(cpu_lib, monkeypatch):
 # ---- kernels of the FORWARD library that need no gfx950 intrinsic: compositing (fwd + bwd), gather (fwd + bwd), table folds ----
 @pytest.fixture(scope='module')
 def fwd_lib(tmp_path_factory):
+    if not os.path.exists(build_cpu.CLANG):
+        pytest.skip('needs the ROCm clang for the host build (_Float16 tables)')
     path = build_cpu.build('sherf_hipcpu_fwd', ['composite.hip', 'gather.hip', 'fold.hip'], str(tmp_path_factory.mktemp('hipcpu_fwd')),
-                           extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n')
+                           extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
     for name in ('sherf_composite_compact', 'sherf_composite_compact_bwd', 'sherf_gather_tokens', 'sherf_gather_tokens_bwd', 'sherf_fold_tables',
@@ -322,8 +324,8 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     Wp = state['renderer.conv1d_projection.weight'][:, :, 0]; bp = state['renderer.conv1d_projection.bias']
     Wa, Wb, Wc = Wr[:, 0:32], Wr[:, 32:64], Wr[:, 64:96]
     planes_f, feat_f, img4 = torch.zeros(3, P, P, 32), torch.zeros(Hf, Wf, 64), torch.zeros(H, W, 4)
-    assert fwd_lib.sherf_fold_tables(_P(planes), _P(Wa.t().contiguous()), _P(planes_f), P * P, 3, 32, P * P * 32, None) == 0
-    assert fwd_lib.sherf_fold_tables(_P(obs_feat), _P(Wb.t().contiguous()), _P(feat_f), Hf * Wf, 2, 64, 32, None) == 0
+    assert fwd_lib.sherf_fold_tables(_P(planes), _P(Wa.t().contiguous()), _P(planes_f), P * P, 3, 32, P * P * 32, 0, None) == 0
+    assert fwd_lib.sherf_fold_tables(_P(obs_feat), _P(Wb.t().contiguous()), _P(feat_f), Hf * Wf, 2, 64, 32, 0, None) == 0
     assert fwd_lib.sherf_img_to_hwc4(_P(obs_img), _P(img4), H * W, None) == 0
     assert torch.allclose(planes_f, torch.einsum('oi,pihw->phwo', Wa, planes), atol=1e-5)
     # voxel levels: (bits, prefix) records + folded rows  F_l = cat_s Wc Wp[32s:32s+32, cols_l]
@@ -353,6 +355,24 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     assert rel(tok, ref) < 1e-4
     ex = extras.view(tiles, 12, 32).permute(0, 2, 1).reshape(tiles * 32, 12)[:n]
     assert rel(ex[:, 0:3], r['x_c']) < 1e-6 and rel(ex[:, 6:9], r['tap_rgb']) < 1e-5
+    # ---- the fp16-table mode (mode | 16): tables folded to half by the same kernel, rows given as half; the taps, their weights and
+    #      the sums are unchanged, so the tokens differ from the fp32-table ones by the rounding of the table entries only (2^-11) ----
+    planes_h, feat_h = torch.zeros(3, P, P, 32), torch.zeros(Hf, Wf, 64)                      # fp32-sized buffers, first half used
+    assert fwd_lib.sherf_fold_tables(_P(planes), _P(Wa.t().contiguous()), _P(planes_h), P * P, 3, 32, P * P * 32, 1, None) == 0
+    assert fwd_lib.sherf_fold_tables(_P(obs_feat), _P(Wb.t().contiguous()), _P(feat_h), Hf * Wf, 2, 64, 32, 1, None) == 0
+    got_h = planes_h.view(-1).view(torch.float16)[:planes_f.numel()].view_as(planes_f)
+    assert torch.equal(got_h, planes_f.half())                                                  # round to nearest even of the fp32 fold
+    levels_h = (_lib.VoxLevel * 3)()
+    for i in range(3):
+        rows_h = keep[2 * i + 1].half().contiguous()
+        keep.append(rows_h)
+        levels_h[i].wp, levels_h[i].rows = levels[i].wp, rows_h.data_ptr()
+        levels_h[i].D, levels_h[i].H, levels_h[i].W = levels[i].D, levels[i].H, levels[i].W
+    tokens_h, extras_h = torch.zeros(tiles * 3072), torch.zeros(tiles * 384)
+    assert fwd_lib.sherf_gather_tokens(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels_h, _P(tok_bias), _P(bounds),
+                                       _P(vox_min), vox_sh, 16, n, _P(tokens_h), _P(extras_h), None) == 0
+    tok_h = tokens_h.view(tiles, 3, 8, 32, 4).permute(0, 3, 1, 2, 4).reshape(tiles * 32, 3, 32)[:n]
+    assert 1e-6 < rel(tok_h, tok) < 1e-3 and torch.equal(extras_h, extras)
     # ---- backward: scatter of d_tokens ----
     dt = g['stage.tokens_in']
     pad = torch.zeros(tiles * 32, 96); pad[:n] = dt.reshape(n, 96)
