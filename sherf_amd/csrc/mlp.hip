@@ -447,17 +447,36 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
     }
 }
 
+// SHERF_MLP_PK_RELU (prec 2): ReLU on the PACKED fp16 pairs after the conversion (v_pk_max_f16: one instruction per two values)
+// instead of one integer max per fp32 value before it -- relu(round(x)) == round(relu(x)), 272 VALU less per tile of a kernel that
+// issues ~2 900 of them beside 374 MFMAs (profiles/r03_mlp_isa_mix.txt).
+#ifndef SHERF_MLP_PK_RELU
+#define SHERF_MLP_PK_RELU 0
+#endif
+__device__ __forceinline__ uint32_t relu2_f16(uint32_t p) {
+    f16x2 v = __builtin_bit_cast(f16x2, p);
+    v = __builtin_elementwise_max(v, f16x2{(_Float16)0.0f, (_Float16)0.0f});
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 // two finished accumulator tiles (a pair of chunks) -> four K-blocks of the next layer; pinned in place: left alone the compiler
 // sinks every epilogue of a layer in front of the next layer's first MFMA and keeps all the raw accumulators alive until then
 template <int PREC, bool RELU>
 __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PREC>* out) {
     mfma_settle(acc0, acc1);
-    if constexpr (RELU) {
+    constexpr bool PK = RELU && PREC == 2 && SHERF_MLP_PK_RELU;
+    if constexpr (RELU && !PK) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = relu(acc0[r]); acc1[r] = relu(acc1[r]); }
     }
     split_tile<PREC>(acc0, out[0], out[1]);
     split_tile<PREC>(acc1, out[2], out[3]);
+    if constexpr (PK) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[f].hi[e] = relu2_f16(out[f].hi[e]);
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -471,8 +490,11 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
 // at 3 waves / SIMD with its weights resident in LDS, the decoder alone at two workgroups per CU): 0.23 + 0.62 ms against 0.69 ms
 // fused (profiles/r02_kernel_trace_v2_split.txt) -- the decoder alone is not faster than with the transformer of the co-resident
 // workgroup running under it, so the fused form stays.
+#ifndef SHERF_MLP_LB
+#define SHERF_MLP_LB 2            // minimum waves / SIMD the single-product instances are compiled for (register cap 512 / LB)
+#endif
 template <int PREC>
-__global__ void __launch_bounds__(NW * 64, 2)
+__global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_LB)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
     using CX = Ctx<PREC>;

@@ -415,7 +415,7 @@ def _subset(fx, sel):
     return out
 
 
-def _full_size_properties(cfg, stride, check_stride=97, device=None):
+def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='f16x3'):
     """BASELINE.json's full frame size.  The WHOLE frame goes through the protocol: the oracle's own code runs as stock ATen ops on
     the GPU for it (fp32, then float64 for the truth; seconds instead of the CPU's tens of minutes) -- and is itself checked against
     the oracle on the CPU on every `check_stride`-th ray, so the pin to the reference carries over.  Plus the size-independent
@@ -463,13 +463,14 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None):
         o = O.render_from_fixture(fx_sub, state, training=True, keep=False)
         truth = O.truth64_from_fixture(fx_sub, state, o)
     spi = o['sp_input']                                             # depends on the vertices, not on the rays
-    a = G.hip_render(cfg, sp_input=spi)
-    b = G.hip_render(cfg, sp_input=spi)
+    a = G.hip_render(cfg, sp_input=spi, precision=precision)
+    b = G.hip_render(cfg, sp_input=spi, precision=precision)
+    assert a['last']['mlp_precision'] == precision and a['last']['table_precision'] == ('f32' if precision == 'f16x3' else 'f16')
     assert a['rgb'].shape == (R, 3) and torch.isfinite(a['rgb']).all() and torch.isfinite(a['acc']).all()
     assert float(a['acc'].min()) >= 0.0 and float(a['acc'].max()) <= 1.0 + 1e-5 and float(a['rgb'].abs().max()) <= 1.01
     assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['depth'], b['depth']) and torch.equal(a['acc'], b['acc'])
     sel_i = np.arange(stride // 2, R, stride)
-    sub = G.hip_render(cfg, fx=_subset(fx, sel_i), sp_input=spi)
+    sub = G.hip_render(cfg, fx=_subset(fx, sel_i), sp_input=spi, precision=precision)
     assert torch.equal(sub['rgb'], a['rgb'][sel_i]) and torch.equal(sub['acc'], a['acc'][sel_i])
     h = a if on_gpu else sub
     tag = f'{cfg} ({sel.size} rays of {R})'
@@ -480,14 +481,14 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None):
         rep, img = _protocol(o, h, S, truth)
         _assert_truth(tag, rep, img)
     assert rep['valid_ours'] + rep['mask_flips'] >= rep['valid_oracle'] >= rep['valid_ours'] - rep['mask_flips']
-    w = G.hip_render(cfg, sp_input=spi, options=dict(white_back=True))
+    w = G.hip_render(cfg, sp_input=spi, options=dict(white_back=True), precision=precision)
     assert torch.allclose(w['rgb'], a['rgb'] + 2 * (1 - a['acc'])[:, None], atol=1e-5)
     print(f"{cfg}: {R} rays, {sel.size} of them vs oracle: rgb rel err {G.rel(h['rgb'], o['rgb']):.2e}, valid samples {o['valid'].numel()}")
 
 
-@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg2_ri', 'cfg3_ri'])
-def test_full_size_frame_properties(cfg):
+@pytest.mark.parametrize('cfg,precision', [('cfg2', 'f16x3'), ('cfg3', 'f16x3'), ('cfg2_ri', 'f16'), ('cfg3_ri', 'f16')])
+def test_full_size_frame_properties(cfg, precision):
     """BASELINE configs 2 and 3: 512 x 512 rays x 64 samples (novel view / novel pose), WHOLE frame through the protocol: the
-    adversarial seeded workload against the float64 truth, the reference-init workload ("_ri") within 1e-3 of the fp32 oracle
-    outright."""
-    _full_size_properties(cfg, 15)
+    adversarial seeded workload (fp32-grade f16x3, which `auto` keeps it on) against the float64 truth; the reference-init workload
+    ("_ri") in the configuration `auto` picks for it -- single fp16 products, fp16 tables -- within 1e-3 of the fp32 oracle outright."""
+    _full_size_properties(cfg, 15, precision=precision)
