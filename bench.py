@@ -15,6 +15,11 @@ import os
 import sys
 import time
 
+# Frames are issued round-robin on `--streams` caller streams (default 2), each with its own pair of side streams: more HIP streams than
+# the runtime's default of 4 hardware queues, onto which it would multiplex them (two chains sharing a queue run one after the other:
+# DESIGN section 7).  Must be set before the HIP runtime initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 
@@ -218,6 +223,11 @@ def main():
                          'initialisation, alpha bias + 5) and band-limited tables; cfg2 = the adversarial seeded weights of rounds 1-2')
     ap.add_argument('--precision', default='auto', choices=['auto', 'f16x3', 'f16', 'bf16'],
                     help='MLP operand precision; auto (the product default) = calibrated per set of weights on the first frame')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='caller streams the frames are issued on, round-robin (each frame is one ImportanceRenderer.forward on its '
+                         'stream; every stream has its own workspace): with 2, frame N+1\'s low-occupancy first phase (cell lists, '
+                         'sampling, the encoder\'s chain of small launches) runs under frame N\'s chip-filling gather and MLP; 1 = one '
+                         'frame at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-torch-gpu-baseline', action='store_true',
                     help='skip timing the oracle (the reference algorithm as stock ATen ops, brute-force K-NN) ON THE GPU over the whole '
@@ -261,7 +271,20 @@ def main():
     from sherf_amd import _lib as _abi
     import ctypes as _ct
 
+    n_streams = max(1, int(a.streams))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
+    torch.cuda.synchronize(dev)                  # the workload's setup (default stream) is complete before any frame stream starts
+    counter = [0]
+
     def step():
+        if n_streams == 1:
+            return frame_on_current_stream()
+        st = streams[counter[0] % n_streams]
+        counter[0] += 1
+        with torch.cuda.stream(st):
+            return frame_on_current_stream()
+
+    def frame_on_current_stream():
         render_frame(w)
         tile = rend.last['out']          # the frame's output buffer as the kernel wrote it: planar [rgb (3R) | depth (R) | acc (R)], no repacking
         if world > 1:
@@ -279,6 +302,8 @@ def main():
         while inflight:
             inflight.pop(0)[0].wait()
 
+    for _ in range(n_streams if n_streams > 1 else 0):     # every stream's workspace exists (and `auto` is calibrated) before the warm-up proper
+        step()
     for _ in range(a.warmup):
         step()
     drain()
@@ -318,7 +343,8 @@ def main():
                                         f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
                                parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=used, mlp_precision_requested=a.precision,
                                mlp_precision_auto=getattr(rend, 'auto_report', None), network=fixtures_variant_note(a.config),
-                               batchnorm=a.bn_mode, exact_grids=bool(rend.exact_grids)))
+                               batchnorm=a.bn_mode, exact_grids=bool(rend.exact_grids), caller_streams=n_streams,
+                               table_precision=rend.last.get('table_precision')))
         if mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
             res['roofline'] = dict(kernel='nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',

@@ -226,7 +226,7 @@ class _Workspace:
         return self._cached(kind, 0, shape, dev)
 
 
-_SIDE_STREAMS = {}           # device -> [side, aux]
+_SIDE_STREAMS = {}           # (device, caller stream) -> [side, aux]
 
 
 class ImportanceRenderer(nn.Module):
@@ -262,7 +262,7 @@ class ImportanceRenderer(nn.Module):
         # not parameters / buffers (the reference keeps the SMPL dict as a plain attribute too, renderer.py:284);
         # excluded from pickling so module snapshots stay loadable without the asset or the .so handle.
         self._smpl_dev = None
-        self._ws = _Workspace()
+        self._ws = {}                 # (device, caller stream) -> _Workspace
         self._wcache = None
         self.last = None
 
@@ -275,17 +275,31 @@ class ImportanceRenderer(nn.Module):
 
     def __setstate__(self, s):
         self.__dict__.update(s)
-        self._ws = _Workspace()
+        self._ws = {}
+
+    def _workspace(self, dev, main=None):
+        """The frame workspace of the CALLER'S STREAM: frames issued on one stream share it (they are ordered anyway); frames issued
+        round-robin on several streams -- the way to overlap frame N+1's low-occupancy first phase (cell lists, sampling, the encoder's
+        chain of small launches) with frame N's chip-filling gather and MLP -- get one each, so nothing of frame N is overwritten
+        while it is still in flight.  (A set costs ~0.5 KB per sample of capacity: 8 GB at 512x512x64 -- sized for 288 GB of HBM.)"""
+        sid = (main or torch.cuda.current_stream(dev)).cuda_stream
+        if self._ws is None or not isinstance(self._ws, dict):
+            self._ws = {}
+        w = self._ws.get((str(dev), sid))
+        if w is None:
+            w = self._ws[(str(dev), sid)] = _Workspace()
+        return w
 
     def _side(self, dev, idx=0):
         # ONE pair of side streams per device for every renderer of the process: HIP multiplexes streams onto 4 hardware queues, and a
         # second renderer with streams of its own (five in all) had two of its three streams share a queue -- its encoder chain and
         # ray side ran one after the other (3.1 instead of 1.9 ms per frame, profiles/r02_cfg3_as_headline.txt).  Frames of different
         # renderers are serialised by the native driver anyway.
-        cur = _SIDE_STREAMS.get(dev)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # one pair per caller stream (see _workspace)
+        cur = _SIDE_STREAMS.get(key)
         if cur is None:
             # the short serial chains get dispatch priority over the ray side's big kernels
-            _SIDE_STREAMS[dev] = cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+            _SIDE_STREAMS[key] = cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
         return cur[idx]
 
     # ---- SMPL --------------------------------------------------------------------------------
@@ -503,7 +517,8 @@ class ImportanceRenderer(nn.Module):
         smpl = self._smpl(dev)
         prec_name, calibrate = self._resolve_precision(opts.get('mlp_precision') or self.mlp_precision, decoder, dev)
         wc = self._weights(decoder, dev, prec_name)
-        ws = self._ws.frame(R, S, cap, dev)
+        wsp = self._workspace(dev)
+        ws = wsp.frame(R, S, cap, dev)
         prm, oprm, tprm = input_data['params'], input_data['obs_params'], input_data['t_params']
 
         # One native call enqueues the whole frame on two HIP streams (csrc/frame.hip): the sparse voxel encoder is a chain
@@ -548,9 +563,9 @@ class ImportanceRenderer(nn.Module):
         Pres = planes.shape[-1]
         Hf, Wf = obs_input_feature.shape[-2:]
         H, W = obs_input_img.shape[-2:]
-        planes_f = self._ws.table('planes_f', (3, Pres, Pres, 32), dev)
-        feat_f = self._ws.table('feat_f', (Hf, Wf, 64), dev)
-        img4 = self._ws.table('img4', (H, W, 4), dev)
+        planes_f = wsp.table('planes_f', (3, Pres, Pres, 32), dev)
+        feat_f = wsp.table('feat_f', (Hf, Wf, 64), dev)
+        img4 = wsp.table('img4', (H, W, 4), dev)
         fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, -1), A(wc['Wa_t']), A(planes_f), Pres
         exact = bool(opts.get('exact_grids', self.exact_grids))
         fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, -1), A(wc['Wb_t']), A(feat_f), Hf, Wf
@@ -564,7 +579,7 @@ class ImportanceRenderer(nn.Module):
         gb = opts.get('gather_branchless', self.gather_branchless)
         fr.gather_split = (1 if opts.get('gather_split', self.gather_split) else 0) | (4 if gb == '128' else 2 if gb else 0)
         # a11: sparse voxel encoder plan (persistent buffers) + this frame's voxels
-        pl, vfeat, vcoord = self.encoder_3d.prepare(canonical_sp_conv_volume, wc['fold'], self._ws)
+        pl, vfeat, vcoord = self.encoder_3d.prepare(canonical_sp_conv_volume, wc['fold'], wsp)
         keep += [vfeat, vcoord]
         fr.vox_plan = _ct.addressof(pl['plan'])
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0

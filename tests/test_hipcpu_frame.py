@@ -122,7 +122,7 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
     fixtures.CONFIGS['cfg2'] = dict(fixtures.CONFIGS['tiny_nv'])
     try:
         # the default workload: the reference-init network, precision 'auto' (-> one fp16 product), parity = truth protocol + plain 1e-3
-        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny_ri', '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--exact-grids'])
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny_ri', '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--streams', '1', '--exact-grids'])
         bench.main()
         res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
         assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
@@ -141,13 +141,13 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
         assert par['samples']['sigma_rel_max'] < 1e-3 and par['samples']['rgb_rel_max'] < 1e-3
         assert par['truth']['table']['sigma']['max']['ours_vs_truth'] < 1e-3 and par['image']['psnr_vs_oracle_db'] > 60.0
         # the adversarial workload under f16x3: the truth protocol alone
-        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'f16x3', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'f16x3', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--streams', '1',
                                           '--no-secondary'])
         bench.main()
         res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
         assert res['config']['mlp_precision'] == 'f16x3' and res['parity_ok'] is True and 'plain_ok' not in res['parity']
         # a precision that misses the tolerance: the JSON line says so and the process exits non-zero
-        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'bf16', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+        monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'bf16', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--streams', '1',
                                           '--no-secondary', '--no-pmc'])
         with pytest.raises(SystemExit) as ex:
             bench.main()
