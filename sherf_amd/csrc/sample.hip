@@ -354,6 +354,202 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 3: the same search as TWO passes over a dense candidate list.  sample_nn_kernel above gives every
+// ray one wave for the whole job, so a ray through the body (~30 candidates, four dependent search rounds) holds its wave ~10x
+// longer than a ray beside it (none): 250 of its 330 us were candidate search at a quarter of the chip's occupancy.  Here
+//   pass 1 (cand_mark): positions + near-mask reject for every sample, four rays in flight per wave; a workgroup's candidates
+//           (dense index ray * S + k) are staged in LDS and appended to a global list with ONE atomic reservation per workgroup
+//           (order is irrelevant: results land in per-ray bit masks);
+//   pass 2 (cand_search): the list is walked eight lanes per candidate, 32 candidates per workgroup step, every lane group busy --
+//           the same trimmed 3x3x3 cell walk and the same lexicographic (d^2, vertex id) minimum as above, bit for bit;
+// then ray counts come from the masks' popcounts inside the first scan kernel.  The list lives in cs_xs (written only by the
+// compaction afterwards): 4 * capacity entries, so the path is taken when that provably holds every sample (capacity >= R S / 4).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMarkRays = 4;          // rays in flight per wave of pass 1
+
+template <int NCH>
+__global__ void __launch_bounds__(256) cand_mark_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                        const float* __restrict__ near, const float* __restrict__ far, int R, int S,
+                                                        const float* __restrict__ Rg, const float* __restrict__ Th,
+                                                        const float* __restrict__ hdr, const uint32_t* __restrict__ near_mask,
+                                                        int32_t* __restrict__ cand_list, int64_t list_cap, int32_t* __restrict__ cand_count,
+                                                        uint64_t* __restrict__ ray_mask, int dbg) {
+    constexpr int RPW = 16 / NCH;                    // rays per wave: a workgroup stages at most 4 * RPW * 64 * NCH = 4096 candidates
+    __shared__ int s_list[4096];
+    __shared__ int s_n, s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const CellGrid g = load_grid(hdr);
+    const float fs = g.inv_cell * (float)g.sub;
+    const int ray0 = (blockIdx.x * 4 + wave) * RPW;
+    for (int rb = 0; rb < RPW; rb += kMarkRays) {
+        float o[kMarkRays][3], d[kMarkRays][3], nr[kMarkRays], rg[kMarkRays];
+#pragma unroll
+        for (int u = 0; u < kMarkRays; ++u) {
+            const int ray = min(ray0 + rb + u, R - 1);
+            o[u][0] = ray_o[ray * 3]; o[u][1] = ray_o[ray * 3 + 1]; o[u][2] = ray_o[ray * 3 + 2];
+            d[u][0] = ray_d[ray * 3]; d[u][1] = ray_d[ray * 3 + 1]; d[u][2] = ray_d[ray * 3 + 2];
+            nr[u] = near[ray]; rg[u] = __fsub_rn(far[ray], nr[u]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int k = ch * 64 + lane;
+            uint32_t word[kMarkRays];
+            int bit[kMarkRays];
+#pragma unroll
+            for (int u = 0; u < kMarkRays; ++u) {      // every ray's mask word is requested before the first one is looked at
+                bit[u] = -1; word[u] = 0u;
+                if (k < S && rb + u < RPW && ray0 + rb + u < R) {
+                    const float t = depth_at(nr[u], rg[u], k, S);
+                    const float x = __fadd_rn(o[u][0], __fmul_rn(t, d[u][0])), y = __fadd_rn(o[u][1], __fmul_rn(t, d[u][1])),
+                                z = __fadd_rn(o[u][2], __fmul_rn(t, d[u][2]));
+                    float xs, ys, zs;
+                    to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+                    const int sx = (int)floorf((xs - g.ox) * fs), sy = (int)floorf((ys - g.oy) * fs), sz = (int)floorf((zs - g.oz) * fs);
+                    const int cx = g.sub == 2 ? sx >> 1 : sx, cy = g.sub == 2 ? sy >> 1 : sy, cz = g.sub == 2 ? sz >> 1 : sz;
+                    if (sx >= 0 && cx < g.nx && sy >= 0 && cy < g.ny && sz >= 0 && cz < g.nz) {
+                        const int q = (sz * (g.ny * g.sub) + sy) * (g.nx * g.sub) + sx;
+                        bit[u] = q & 31;
+                        word[u] = near_mask[q >> 5];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kMarkRays; ++u) {
+                const int ray = ray0 + rb + u;
+                const bool cand = bit[u] >= 0 && (((dbg & 2) || ((word[u] >> bit[u]) & 1u)) && !(dbg & 1));
+                const unsigned long long cm = __ballot(cand);
+                if (rb + u < RPW && ray < R && lane == 0) ray_mask[(size_t)ray * NCH + ch] = 0ull;       // pass 2 ORs the valid bits in
+                if (cm) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n, __popcll(cm));
+                    base = __shfl(base, 0);
+                    if (cand) s_list[base + __popcll(cm & ((1ull << lane) - 1ull))] = ray * S + k;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (threadIdx.x == 0) s_base = n ? atomicAdd(cand_count, n) : 0;
+    __syncthreads();
+    const int64_t gb = s_base;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (gb + i < list_cap) cand_list[gb + i] = s_list[i];
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restrict__ cand_list, int64_t list_cap,
+                                                          const int32_t* __restrict__ cand_count, const float* __restrict__ ray_o,
+                                                          const float* __restrict__ ray_d, const float* __restrict__ near,
+                                                          const float* __restrict__ far, int S, const float* __restrict__ Rg,
+                                                          const float* __restrict__ Th, const float* __restrict__ hdr,
+                                                          const int32_t* __restrict__ cell_start, const float4* __restrict__ cell_pts,
+                                                          unsigned long long* __restrict__ ray_mask, int32_t* __restrict__ dense_vid) {
+    __shared__ int s_seg[32][20];                    // per candidate of the step: 9 segment starts, 9 counts
+    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const CellGrid g = load_grid(hdr);
+    const int64_t n = min((int64_t)*cand_count, list_cap);
+    const float r = 0.05f + 1e-4f * g.cell;
+    const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
+    for (int64_t c0 = (int64_t)blockIdx.x * 32; c0 < n; c0 += (int64_t)gridDim.x * 32) {
+        const int64_t ci = c0 + grp;
+        const bool live = ci < n;
+        const int idx = live ? cand_list[ci] : 0;
+        const int ray = idx / S, k = idx - ray * S;
+        const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+        const float t = depth_at(nr, range, k, S);
+        const float x = __fadd_rn(ray_o[ray * 3], __fmul_rn(t, ray_d[ray * 3])), y = __fadd_rn(ray_o[ray * 3 + 1], __fmul_rn(t, ray_d[ray * 3 + 1])),
+                    z = __fadd_rn(ray_o[ray * 3 + 2], __fmul_rn(t, ray_d[ray * 3 + 2]));
+        float xs, ys, zs;
+        to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+        const int cx = (int)floorf((xs - g.ox) * g.inv_cell), cy = (int)floorf((ys - g.oy) * g.inv_cell), cz = (int)floorf((zs - g.oz) * g.inv_cell);
+        // the nine x-contiguous point segments of the 3x3x3 neighbourhood, trimmed to what the 5 cm ball reaches (as in sample_nn_kernel):
+        // lane `sub` of the group prepares row `sub`, lane 0 also row 8
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int i = pass ? 8 : sub;
+            if (pass && sub != 0) break;
+            const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
+            const float y0 = g.oy + qy * g.cell, z0 = g.oz + qz * g.cell;
+            const float ey = fmaxf(fmaxf(y0 - ys, ys - (y0 + g.cell)), 0.f), ez = fmaxf(fmaxf(z0 - zs, zs - (z0 + g.cell)), 0.f);
+            const float rem = r * r - (ey * ey + ez * ez);
+            const bool ok = live && qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny && rem > 0.f;
+            const float rx = sqrtf(fmaxf(rem, 0.f)) + 1e-4f * g.cell;
+            const int x0 = max(max((int)floorf((xs - rx - g.ox) * g.inv_cell), cx - 1), 0);
+            const int x1 = min(min((int)floorf((xs + rx - g.ox) * g.inv_cell), cx + 1), g.nx - 1);
+            const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
+            const int st = cell_start[row + (ok ? x0 : 0)];
+            const int en = ok && x1 >= x0 ? cell_start[row + x1 + 1] : st;
+            s_seg[grp][i] = st; s_seg[grp][9 + i] = en - st;
+        }
+        __builtin_amdgcn_wave_barrier();             // (a group's eight lanes sit in one wave, which runs in lockstep; LDS ordered by lgkmcnt)
+        int bs[9], cum[9];
+        int run = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { bs[i] = s_seg[grp][i]; run += s_seg[grp][9 + i]; cum[i] = run; }
+        __builtin_amdgcn_wave_barrier();             // every lane has read the step's segments before the next step rewrites them
+        const int npts = cum[8];
+        unsigned long long key = kInit;
+        for (int base = 0; base < npts; base += 8 * kMaxPtsUnroll) {
+            float4 v[kMaxPtsUnroll];
+#pragma unroll
+            for (int u = 0; u < kMaxPtsUnroll; ++u) {
+                const int tt = base + u * 8 + sub;
+                int p = bs[0] + tt;
+#pragma unroll
+                for (int i = 1; i < 9; ++i) p = (tt >= cum[i - 1]) ? bs[i] + (tt - cum[i - 1]) : p;
+                v[u] = cell_pts[tt < npts ? p : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < kMaxPtsUnroll; ++u) {
+                const int tt = base + u * 8 + sub;
+                const float dd = dist2_exact(xs, ys, zs, v[u].x, v[u].y, v[u].z);
+                if (tt < npts && dd < kThresh2) {
+                    const unsigned long long cand = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u].w);
+                    key = cand < key ? cand : key;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {      // lexicographic (d^2, vertex id) minimum over the group's eight lanes
+            const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other < key ? other : key;
+        }
+        if (live && sub == 0 && (unsigned)(key >> 32) < __float_as_uint(kThresh2)) {
+            dense_vid[idx] = (int)(key & 0x7FFFFFFFull);
+            atomicOr(&ray_mask[(size_t)ray * NCH + (k >> 6)], 1ull << (k & 63));
+        }
+    }
+}
+
+// first scan kernel of the two-pass path: a ray's count is the popcount of its masks (also stored, the compositing reads ray_cnt)
+template <int NCH>
+__global__ void __launch_bounds__(1024) scan_chunk_mask_kernel(const uint64_t* __restrict__ ray_mask, int R, int32_t* __restrict__ cnt,
+                                                               int32_t* __restrict__ base, int32_t* __restrict__ chunk_sum) {
+    __shared__ int s[1024];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = 0;
+    if (i < R) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) v += __popcll(ray_mask[(size_t)i * NCH + ch]);
+        cnt[i] = v;
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int a = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (i < R) base[i] = s[threadIdx.x] - v;
+    if (threadIdx.x == 1023) chunk_sum[blockIdx.x] = s[1023];
+}
+
+// ---------------------------------------------------------------------------------------------
 // exclusive scan of ray_cnt -> ray_base (chunks of 1024 rays), total -> counters[0]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) scan_chunk_kernel(const int32_t* __restrict__ cnt, int R,
@@ -416,8 +612,9 @@ __global__ void __launch_bounds__(256) depth_minmax_kernel(const float* __restri
     }
 }
 
-__global__ void init_counters_kernel(int32_t* counters) {
+__global__ void init_counters_kernel(int32_t* counters, int32_t* cand_count) {
     counters[0] = 0; counters[1] = 0x7FFFFFFF; counters[2] = (int32_t)0x80000000; counters[3] = 0;
+    *cand_count = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -551,8 +748,25 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     int32_t* base_local = scan_ws;              // [R]
     int32_t* chunk_sum = scan_ws + R;           // [n_chunks]
     const float4* cp = reinterpret_cast<const float4*>(cell_pts);
-    hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters);
+    int32_t* cand_count = scan_ws + R + R / 1024 + 1;      // last word of scan_ws ([R] local bases, [<= R/1024 + 1] chunk sums, this)
+    hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters, cand_count);
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
+    // two passes over a dense candidate list (see cand_mark_kernel) whenever the list -- 4 * capacity entries in cs_xs, which the
+    // compaction below only writes afterwards -- provably holds every sample; sherf_set_debug bit 9 forces the one-wave-per-ray kernel
+    const bool two_pass = !(g_sherf_debug & 512) && 4 * capacity >= (int64_t)R * S;
+    if (two_pass) {
+        int32_t* cand_list = reinterpret_cast<int32_t*>(cs_xs);
+        const int64_t list_cap = 4 * capacity;
+        unsigned long long* rm = reinterpret_cast<unsigned long long*>(ray_mask);
+#define SHERF_TWO_PASS(N)                                                                                                          \
+        hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
+                           grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
+        hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, ray_o, ray_d,   \
+                           near, far, S, Rg, Th, grid_hdr, cell_start, cp, rm, dense_vid);                                         \
+        hipLaunchKernelGGL(scan_chunk_mask_kernel<N>, dim3(n_chunks), dim3(1024), 0, st, ray_mask, R, ray_cnt, base_local, chunk_sum)
+        if (nch == 1) { SHERF_TWO_PASS(1); } else if (nch == 2) { SHERF_TWO_PASS(2); } else if (nch == 3) { SHERF_TWO_PASS(3); } else { SHERF_TWO_PASS(4); }
+#undef SHERF_TWO_PASS
+    } else {
     // 10 KiB of unused dynamic LDS per workgroup: caps the sampler at 6 workgroups per CU (6 of the 8 wave slots per SIMD).  The
     // encoder's small dependent launches on the other stream are the frame's critical path until the gather; with every wave slot
     // taken by the sampler their workgroups queue behind it (measured: frame 1.97 ms uncapped, 1.91 at 6, 1.92 at 5, 1.94 at 4;
@@ -564,6 +778,7 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     if (nch == 1) SHERF_SAMPLE_LAUNCH(1); else if (nch == 2) SHERF_SAMPLE_LAUNCH(2);
     else if (nch == 3) SHERF_SAMPLE_LAUNCH(3); else SHERF_SAMPLE_LAUNCH(4);
     hipLaunchKernelGGL(scan_chunk_kernel, dim3(n_chunks), dim3(1024), 0, st, ray_cnt, R, base_local, chunk_sum);
+    }
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, st, chunk_sum, n_chunks, counters);
 #define SHERF_COMPACT_LAUNCH(N)                                                                                        \
     hipLaunchKernelGGL(compact_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,   \

@@ -59,6 +59,7 @@ template <class T> inline T hipcpu_exchange(T v, int src_lane) {
 }
 inline float __shfl_xor(float v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 inline int __shfl_xor(int v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
+inline unsigned __shfl_xor(unsigned v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 template <class T> inline T __shfl_down(T v, int d) { const int l = hipcpu_lane() + d; return hipcpu_exchange(v, l < 64 ? l : hipcpu_lane()); }
 template <class T> inline T __shfl(T v, int src) { return hipcpu_exchange(v, src & 63); }
 inline unsigned long long __ballot(int pred) {           // every lane of the wave must call it (no divergence), as the shim's other collectives
@@ -121,6 +122,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 inline float unsafeAtomicAdd(float* p, float v) { return std::atomic_ref<float>(*p).fetch_add(v); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_or(v); }
+inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { return std::atomic_ref<unsigned long long>(*p).fetch_or(v); }
 template <class T> inline T atomicMin(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v < o && !a.compare_exchange_weak(o, v)) {} return o; }
 template <class T> inline T atomicMax(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v > o && !a.compare_exchange_weak(o, v)) {} return o; }
 inline long long __double2ll_rn(double x) { return llrint(x); }

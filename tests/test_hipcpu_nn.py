@@ -61,39 +61,47 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     ids = cell_pts[0, :, 3].contiguous().view(torch.int32)
     assert sorted(ids.tolist()) == list(range(n)) and torch.equal(cell_pts[0, :, :3], verts[ids.long()])
     assert int(cell_start[0].max()) == n
-    # rays: through the shell, through the cluster, past everything
-    R, S = 96, 80
-    o = rs.uniform(-0.1, 0.1, size=(R, 3)).astype(np.float32); o[:, 2] -= 1.0
-    tgt = rs.uniform(-0.3, 0.3, size=(R, 3)).astype(np.float32)
-    tgt[:24] = np.array([0.25, 0.0, 0.0]) + rs.uniform(-0.015, 0.015, size=(24, 3))          # aimed at the cluster
-    tgt[24:32] += np.array([3.0, 3.0, 0.0])                                                   # misses
-    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
-    near, far = np.full(R, 0.55, np.float32), np.full(R, 1.45, np.float32)
-    ray_o, ray_d = torch.from_numpy(o), torch.from_numpy(d.astype(np.float32))
-    t_near, t_far = torch.from_numpy(near), torch.from_numpy(far)
-    cap = R * S
-    counters = torch.zeros(4, dtype=torch.int32); ray_base = torch.zeros(R, dtype=torch.int32); ray_cnt = torch.zeros(R, dtype=torch.int32)
-    cs_idx = torch.zeros(cap, dtype=torch.int32); cs_vid = torch.zeros(cap, dtype=torch.int32); cs_xs = torch.zeros(cap, 4)
-    dense_vid = torch.zeros(R * S, dtype=torch.int32); ray_mask = torch.zeros(R * 2, dtype=torch.int64); scan_ws = torch.zeros(R + R // 1024 + 2, dtype=torch.int32)
-    assert lib.sherf_sample_mask_nn(_P(ray_o), _P(ray_d), _P(t_near), _P(t_far), R, S, _P(Rg), _P(Th), _P(hdr), _P(cell_start), _P(cell_pts),
-                                    _P(near_mask), cap, _P(counters), _P(ray_base), _P(ray_cnt), _P(cs_idx), _P(cs_vid), _P(cs_xs),
-                                    _P(dense_vid), _P(ray_mask), _P(scan_ws), None) == 0
-    # brute force in the same arithmetic: depths of math_utils.py:101-118, positions o + t d with separate roundings
-    k = np.arange(S, dtype=np.float32)
-    step = (k / np.float32(S - 1)).astype(np.float32)
-    t = (near[:, None] + (step[None, :] * (far - near)[:, None]).astype(np.float32)).astype(np.float32)
-    x = (o[:, None, :] + (t[..., None] * d[:, None, :].astype(np.float32)).astype(np.float32)).astype(np.float32).reshape(-1, 3)
-    d2 = _d2(x, verts.numpy())
-    best = d2.min(1)
-    vid = np.array([np.flatnonzero(row == m)[0] for row, m in zip(d2, best)])
-    valid = np.flatnonzero(best < np.float32(0.05 * 0.05))
-    nv = int(counters[0])
-    assert nv == valid.size and nv > 300
-    assert np.array_equal(cs_idx[:nv].numpy(), valid) and np.array_equal(cs_vid[:nv].numpy(), vid[valid])
-    assert np.array_equal(cs_xs[:nv, :3].numpy(), x[valid])
-    assert np.array_equal(ray_cnt.numpy(), np.bincount(valid // S, minlength=R))
-    # some ball really holds more points than one 32-point step of a group
-    assert ((d2[valid] < np.float32(0.0025)).sum(1) > 32).any()
+    # rays: through the shell, through the cluster, past everything -- for both search paths (two passes over a dense candidate list /
+    # one wave per ray: sherf_set_debug bit 9) and one, two and three 64-sample chunks per ray
+    import ctypes as _ct
+    dbg = _ct.c_int.in_dll(lib, 'g_sherf_debug')
+    for S, flag in ((80, 0), (80, 512), (40, 0), (150, 0), (150, 512)):
+        dbg.value = flag
+        R = 96
+        o = rs.uniform(-0.1, 0.1, size=(R, 3)).astype(np.float32); o[:, 2] -= 1.0
+        tgt = rs.uniform(-0.3, 0.3, size=(R, 3)).astype(np.float32)
+        tgt[:24] = np.array([0.25, 0.0, 0.0]) + rs.uniform(-0.015, 0.015, size=(24, 3))          # aimed at the cluster
+        tgt[24:32] += np.array([3.0, 3.0, 0.0])                                                   # misses
+        d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        near, far = np.full(R, 0.55, np.float32), np.full(R, 1.45, np.float32)
+        ray_o, ray_d = torch.from_numpy(o), torch.from_numpy(d.astype(np.float32))
+        t_near, t_far = torch.from_numpy(near), torch.from_numpy(far)
+        cap = R * S
+        counters = torch.zeros(4, dtype=torch.int32); ray_base = torch.zeros(R, dtype=torch.int32); ray_cnt = torch.zeros(R, dtype=torch.int32)
+        cs_idx = torch.zeros(cap, dtype=torch.int32); cs_vid = torch.zeros(cap, dtype=torch.int32); cs_xs = torch.zeros(cap, 4)
+        dense_vid = torch.zeros(R * S, dtype=torch.int32); ray_mask = torch.zeros(R * ((S + 63) // 64), dtype=torch.int64); scan_ws = torch.zeros(R + R // 1024 + 2, dtype=torch.int32)
+        assert lib.sherf_sample_mask_nn(_P(ray_o), _P(ray_d), _P(t_near), _P(t_far), R, S, _P(Rg), _P(Th), _P(hdr), _P(cell_start), _P(cell_pts),
+                                        _P(near_mask), cap, _P(counters), _P(ray_base), _P(ray_cnt), _P(cs_idx), _P(cs_vid), _P(cs_xs),
+                                        _P(dense_vid), _P(ray_mask), _P(scan_ws), None) == 0
+        # brute force in the same arithmetic: depths of math_utils.py:101-118, positions o + t d with separate roundings
+        k = np.arange(S, dtype=np.float32)
+        step = (k / np.float32(S - 1)).astype(np.float32)
+        t = (near[:, None] + (step[None, :] * (far - near)[:, None]).astype(np.float32)).astype(np.float32)
+        x = (o[:, None, :] + (t[..., None] * d[:, None, :].astype(np.float32)).astype(np.float32)).astype(np.float32).reshape(-1, 3)
+        d2 = _d2(x, verts.numpy())
+        best = d2.min(1)
+        vid = np.array([np.flatnonzero(row == m)[0] for row, m in zip(d2, best)])
+        valid = np.flatnonzero(best < np.float32(0.05 * 0.05))
+        nv = int(counters[0])
+        assert nv == valid.size and nv > 150, (S, flag, nv, valid.size)
+        assert np.array_equal(cs_idx[:nv].numpy(), valid) and np.array_equal(cs_vid[:nv].numpy(), vid[valid])
+        assert np.array_equal(cs_xs[:nv, :3].numpy(), x[valid])
+        assert np.array_equal(ray_cnt.numpy(), np.bincount(valid // S, minlength=R))
+        # some ball really holds more points than one 32-point step of a group
+        assert ((d2[valid] < np.float32(0.0025)).sum(1) > 32).any()
+
+
+    dbg.value = 0
 
     # ---- the warp's T-vertex search on the same grid (grid 1 of the pair): near and far same-index vertices ----
     nq = 400
