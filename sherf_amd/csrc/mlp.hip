@@ -450,8 +450,10 @@ __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag
 // SHERF_MLP_PK_RELU (prec 2): ReLU on the PACKED fp16 pairs after the conversion (v_pk_max_f16: one instruction per two values)
 // instead of one integer max per fp32 value before it -- relu(round(x)) == round(relu(x)), 272 VALU less per tile of a kernel that
 // issues ~2 900 of them beside 374 MFMAs (profiles/r03_mlp_isa_mix.txt).
+// Measured on the MI355X (profiles/r03_mlp_variants.txt): 0.306 -> 0.292 ms, bit-identical; together with -fno-slp-vectorize
+// (packed fp32 VALU beside MFMAs costs more than the pair it replaces: MI355X_MICROARCH.md) 0.288 ms.
 #ifndef SHERF_MLP_PK_RELU
-#define SHERF_MLP_PK_RELU 0
+#define SHERF_MLP_PK_RELU 1
 #endif
 __device__ __forceinline__ uint32_t relu2_f16(uint32_t p) {
     f16x2 v = __builtin_bit_cast(f16x2, p);

@@ -8,12 +8,13 @@ cd sherf_amd
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wno-unused-value -mcode-object-version=5"
 build() { # tag, source file (without .hip), defines...
   local tag=$1 src=$2; shift; shift
-  /opt/rocm/bin/hipcc $FLAGS "$@" -c csrc/$src.hip -o build/variant_$tag.o
+  local extra=""; [ "$src" = mlp ] && extra="-fno-slp-vectorize"      # (sherf_amd/build.py: EXTRA_FLAGS)
+  /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c csrc/$src.hip -o build/variant_$tag.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "/$src.o\|variant_\|bwd_\|ops_") build/variant_$tag.o -o libsherf_hip_$tag.so
   echo "built libsherf_hip_$tag.so ($src: $*)"
 }
 declare -A DEFS=( [trace]="-DSHERF_MLP_TRACE=1" [prio0]="-DSHERF_MLP_DECODER_PRIO=0" [slowmath]="-DSHERF_MLP_FASTMATH=0 -DSHERF_MLP_FAST_ERF=0" [nomix]="-DSHERF_MLP_FMA_MIX=0"
-                  [pkrelu]="-DSHERF_MLP_PK_RELU=1" [noslp]="-fno-slp-vectorize" [pkrelu_noslp]="-DSHERF_MLP_PK_RELU=1 -fno-slp-vectorize" [lb4]="-DSHERF_MLP_LB=4" [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [sconvtrace]="-DSHERF_SCONV_TRACE=1" )
+                  [nopkrelu]="-DSHERF_MLP_PK_RELU=0" [lb4]="-DSHERF_MLP_LB=4" [nodma]="-DSHERF_MLP_ABLATE=32" [nobar]="-DSHERF_MLP_ABLATE=64" [sconvtrace]="-DSHERF_SCONV_TRACE=1" )
 declare -A SRC=( [sconvtrace]=svox )
 TAGS=${@:-trace nodma}
 for t in $TAGS; do build $t ${SRC[$t]:-mlp} ${DEFS[$t]} & done
