@@ -228,6 +228,10 @@ def main():
                          'stream; every stream has its own workspace): with 2, frame N+1\'s low-occupancy first phase (cell lists, '
                          'sampling, the encoder\'s chain of small launches) runs under frame N\'s chip-filling gather and MLP; 1 = one '
                          'frame at a time')
+    ap.add_argument('--partition', default='views', choices=['views', 'rays'],
+                    help='N > 1: views (default, BASELINE config 4: every rank renders its own target view, weak scaling) or rays (ONE frame '
+                         'cut into interleaved 1024-ray tiles over the ranks, sherf_amd.dist.ray_tiles: strong scaling, value = the frame\'s '
+                         'rays / time); either way one RCCL all_gather of the rendered tiles per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-torch-gpu-baseline', action='store_true',
                     help='skip timing the oracle (the reference algorithm as stock ATen ops, brute-force K-NN) ON THE GPU over the whole '
@@ -256,16 +260,31 @@ def main():
         time_frames(w, 3, 1, dev)
         return
     if world > 1:
+        import datetime
         import torch.distributed as dist
         backend = os.environ.get('SHERF_DIST_BACKEND', 'nccl')          # 'nccl' = RCCL; 'gloo' only for the CPU dry-run in tests/
-        dist.init_process_group(backend, **(dict(device_id=dev) if backend == 'nccl' else {}))
+        # a rank that dies must take the job down instead of leaving the others in the all_gather: bounded collective timeout here,
+        # and every exception below leaves through os._exit (the launcher then stops the remaining ranks)
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=int(os.environ.get('SHERF_DIST_TIMEOUT', '300'))),
+                                **(dict(device_id=dev) if backend == 'nccl' else {}))
     from sherf_amd import dist as sdist  # noqa: F401
 
     if os.environ.get('SHERF_DEBUG'):
         from sherf_amd import _lib as _dbg
         _dbg.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (sampler: 1 = no candidates, 2 = every sample)
-    w = make_workload(a, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
+    rays_mode = world > 1 and a.partition == 'rays'
+    w = make_workload(a, 0.4 if rays_mode else 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend, opts = w['rend'], w['opts']
+    R_frame = w['d']['ray_o_all'].shape[2]
+    if rays_mode:
+        # this rank's interleaved tiles of THE frame (sherf_amd.dist: balances the body's footprint); the depth image is clamped with
+        # the whole frame's depth range (ray_marcher.py:57), computed from the full near / far every rank holds -- no collective
+        tile_rays = 1024 if R_frame >= 16 * 1024 else 128              # (small test frames: still several tiles per rank)
+        idx = sdist.ray_tiles(R_frame, rank, world, tile=tile_rays).to(dev)
+        opts['depth_range'] = sdist.depth_range(w['d']['near_all'][:, 0], w['d']['far_all'][:, 0])
+        for k in ('ray_o_all', 'ray_d_all', 'near_all', 'far_all'):
+            w['d'][k] = w['d'][k][:, :, idx].contiguous()
+        n_pad = sdist.padded_shard_size(R_frame, world, tile_rays)
     rend.exact_grids = bool(a.exact_grids) or rend.exact_grids
     R = w['d']['ray_o_all'].shape[2]; S = opts['depth_resolution']
     from sherf_amd import _lib as _abi
@@ -287,6 +306,8 @@ def main():
     def frame_on_current_stream():
         render_frame(w)
         tile = rend.last['out']          # the frame's output buffer as the kernel wrote it: planar [rgb (3R) | depth (R) | acc (R)], no repacking
+        if rays_mode and tile.numel() != 5 * n_pad:           # ranks own 1024-ray tiles: equal shard sizes for the gather
+            tile = torch.nn.functional.pad(tile, (0, 5 * n_pad - tile.numel()))
         if world > 1:
             # the gather of this frame's tiles runs on RCCL's own stream (async_op) and is awaited one step later, so that it
             # overlaps the next frame's sampling instead of stalling the render stream for a latency-bound 5 MB exchange
@@ -336,12 +357,12 @@ def main():
         dtype = {'f16x3': 'f16x3 MFMA (fp32-grade: operands split hi + lo in fp16, three products, fp32 accumulate), fp32 elsewhere',
                  'f16': 'f16 MFMA (fp16 operands rounded to nearest, one product, fp32 accumulate), fp32 elsewhere',
                  'bf16': 'bf16 MFMA (one product, fp32 accumulate), fp32 elsewhere'}[used]
-        res = dict(metric='rendered rays/sec at 512x512x64 samples (ImportanceRenderer.forward)', value=world * R * a.steps / dt,
+        res = dict(metric='rendered rays/sec at 512x512x64 samples (ImportanceRenderer.forward)', value=(R_frame if rays_mode else world * R) * a.steps / dt,
                    unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype=dtype, data='synthetic',
+                   higher_is_better=True, scaling='strong' if rays_mode else 'weak', vs_baseline=None, dtype=dtype, data='synthetic',
                    config=dict(workload=f'{a.config}: 512x512 rays x 64 samples, synthetic SMPL subject, novel view, all feature branches, '
-                                        f'one view per GPU', rays=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
-                               parallelism=f'views x{world}' if world > 1 else 'single GPU', mlp_precision=used, mlp_precision_requested=a.precision,
+                                        f'one view per GPU', rays=R_frame if rays_mode else R, rays_per_rank=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
+                               parallelism=(f'ray tiles x{world} (one frame)' if rays_mode else f'views x{world}') if world > 1 else 'single GPU', mlp_precision=used, mlp_precision_requested=a.precision,
                                mlp_precision_auto=getattr(rend, 'auto_report', None), network=fixtures_variant_note(a.config),
                                batchnorm=a.bn_mode, exact_grids=bool(rend.exact_grids), caller_streams=n_streams,
                                table_precision=rend.last.get('table_precision')))
@@ -527,4 +548,14 @@ def torch_gpu_baseline(cfg_name, dev, training, iters=3, save=None):
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        if int(os.environ.get('WORLD_SIZE', 1)) > 1:        # do not linger in (or before) a collective the other ranks are waiting in
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)
+        raise

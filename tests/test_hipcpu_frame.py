@@ -157,9 +157,11 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
         fixtures.CONFIGS.update(keep)
 
 
-def test_bench_two_ranks_dry_run(cpu_product):
+@pytest.mark.parametrize('partition', ['views', 'rays'])
+def test_bench_two_ranks_dry_run(cpu_product, partition):
     """bench.py as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), two ranks over gloo
-    on the host build: every rank renders its own view, the step ends with the all_gather of the tiles, rank 0 prints the one line."""
+    on the host build: every rank renders its own view (weak scaling) or its interleaved ray tiles of ONE frame (--partition rays,
+    strong scaling), the step ends with the all_gather of the tiles, rank 0 prints the one line."""
     import json
     import socket
     import subprocess
@@ -170,7 +172,7 @@ def test_bench_two_ranks_dry_run(cpu_product):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   SHERF_DIST_BACKEND='gloo', SHERF_HIPCPU_LIB=_lib.LIB_PATH, OMP_NUM_THREADS='2')
+                   SHERF_DIST_BACKEND='gloo', SHERF_HIPCPU_LIB=_lib.LIB_PATH, OMP_NUM_THREADS='2', SHERF_BENCH_PARTITION=partition)
         procs.append(subprocess.Popen([sys.executable, os.path.join(G.ROOT, 'tests', 'bench_dist_child.py')], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -178,8 +180,13 @@ def test_bench_two_ranks_dry_run(cpu_product):
     lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
     assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]          # rank 0 prints ONE line
     res = json.loads(lines[0])
-    assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['parallelism'] == 'views x2'
-    assert res['value'] > 0 and abs(res['value'] - 2 * res['config']['rays'] * res['steps'] / (res['ms_per_step'] * 1e-3 * res['steps'])) < 1e-6 * res['value']
+    per_step = res['ms_per_step'] * 1e-3
+    if partition == 'views':
+        assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['parallelism'] == 'views x2'
+        assert res['value'] > 0 and abs(res['value'] - 2 * res['config']['rays'] * res['steps'] / (per_step * res['steps'])) < 1e-6 * res['value']
+    else:
+        assert res['n_gpus'] == 2 and res['scaling'] == 'strong' and res['config']['parallelism'] == 'ray tiles x2 (one frame)'
+        assert res['config']['rays'] == 1024 and abs(res['value'] - 1024 / per_step) < 1e-6 * res['value']      # the FRAME's rays per second
 
 
 def test_ray_tile_sharding_two_ranks(cpu_product):
