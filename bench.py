@@ -365,7 +365,7 @@ def main():
                                parallelism=(f'ray tiles x{world} (one frame)' if rays_mode else f'views x{world}') if world > 1 else 'single GPU', mlp_precision=used, mlp_precision_requested=a.precision,
                                mlp_precision_auto=getattr(rend, 'auto_report', None), network=fixtures_variant_note(a.config),
                                batchnorm=a.bn_mode, exact_grids=bool(rend.exact_grids), caller_streams=n_streams,
-                               table_precision=rend.last.get('table_precision')))
+                               table_precision=rend.last.get('table_precision'), encoder_precision=rend.last.get('encoder_precision')))
         if mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
             res['roofline'] = dict(kernel='nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',

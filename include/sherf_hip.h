@@ -296,6 +296,9 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
  * folded tri-plane / feature-map tables and the folded voxel rows are written and tapped as fp16 (round to nearest even; half the bytes
  * through L2 in the gather, which is bound there).  Same buffers: their first half is used. */
 #define SHERF_FRAME_HALF_TABLES 2
+/* frame->flags & SHERF_FRAME_ENCODER_SINGLE (opt-in, set together with HALF_TABLES by sherf_amd.ImportanceRenderer): the sparse
+ * convolutions multiply single fp16 products (operands rounded to nearest even) instead of the three of the f16x3 split. */
+#define SHERF_FRAME_ENCODER_SINGLE 4
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */

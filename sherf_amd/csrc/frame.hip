@@ -151,7 +151,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             const std::function<int()> smpl_on_aux = [&]() -> int { return smpl_tables(stream_aux); };
             SHERF_RUN(sherf_svox_encode_impl(f->vox_plan, f->vox_coord, f->vox_feat, f->vox_n, f->vox_training, levels, stream_side,
                                              stagger >= 0 ? d.ev_mid : nullptr, stagger, stream_aux, d.ev_lev,
-                                             stream_aux ? &smpl_on_aux : nullptr, half_tables));
+                                             stream_aux ? &smpl_on_aux : nullptr,
+                                             half_tables | ((f->flags & SHERF_FRAME_ENCODER_SINGLE) ? 2 : 0)));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_enc, side));
             SHERF_PROF(2, side);
             return SHERF_OK;

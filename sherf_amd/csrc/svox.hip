@@ -211,7 +211,10 @@ __device__ unsigned g_sconv_trace_cap = 0, g_sconv_trace_n = 0;
 // FOLD (mode 2, one tap: the waves split the output-channel tiles) and IN_BN (BatchNorm of the input) are compile-time: as run-time
 // switches they put a branch around every weight load and every MFMA group of the tap loop, and the compiler scheduled nothing
 // across them (round 2's ISA: one global load per basic block).
-template <int NCOT, int NKB, bool FOLD, int IN_BN>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
+// SP: single fp16 product per term (operands rounded to nearest even, the `hi` weight fragments only) instead of the three of the
+// f16x3 split: a third of the MFMA issue and half the weight loads of a tap.  Follows the frame's table precision (the encoder's output
+// is rounded to fp16 rows there anyway, and mlp_precision='auto' calibrates the whole configuration against f16x3 on the frame).
+template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
 __global__ void __launch_bounds__(256, (NCOT * NKB >= 12 ? 1 : 2))   // (level 2 launches 318 workgroups: two per CU must fit)
 sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
@@ -331,7 +334,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
         const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
 #pragma unroll
         for (int c = 0; c < 2 * NCOT; ++c)
-            if (!FOLD || (c >> 1) == csel) w[c] = wsrc[c * 64];
+            if ((!FOLD || (c >> 1) == csel) && !(SP && (c & 1))) w[c] = wsrc[c * 64];          // (SP: the `lo` fragments are never fetched)
     };
     auto load_all = [&](int tap, Row& R, Wts& W) {
         const int nb = s_nb[tap * 32 + r];
@@ -361,6 +364,13 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
             const uint4 ahi = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+            if constexpr (SP) {
+#pragma unroll
+                for (int c = 0; c < NCOT; ++c) {
+                    if (FOLD && c != csel) continue;
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, W.w[kb][2 * c]), acc[c], 0, 0, 0);
+                }
+            } else {
             const uint4 alo = make_uint4(pk2(v[0] - rt(v[0]), v[1] - rt(v[1])), pk2(v[2] - rt(v[2]), v[3] - rt(v[3])),
                                          pk2(v[4] - rt(v[4]), v[5] - rt(v[5])), pk2(v[6] - rt(v[6]), v[7] - rt(v[7])));
 #pragma unroll
@@ -370,6 +380,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
+            }
             }
             if constexpr (PF == 1) {
                 // one buffer: the refill goes out HERE, right behind the K-block that freed its registers (left alone the compiler
@@ -593,7 +604,8 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
                         const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, int64_t* out_acc,
                         sherf_stream_t stream) {
     const int out_half = (mode & 512) ? 512 : 0;
-    mode &= ~512;
+    const bool single = (mode & 1024) != 0;               // one fp16 product per term (see sconv3_kernel: SP)
+    mode &= ~(512 | 1024);
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
     SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
@@ -603,10 +615,11 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     const bool fold = mode == 2;
     const int bnm = bin.bnparam ? (in_mult ? 2 : 1) : 0;
     const int kmode = mode | ((g_sherf_debug & 128) ? 256 : 0) | (fold ? out_half : 0);
-#define SHERF_CONV3_(N, K, F, B)                                                                                             \
-    hipLaunchKernelGGL((sconv3_kernel<N, K, F, B>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,     \
+#define SHERF_CONV3__(N, K, F, B, S)                                                                                         \
+    hipLaunchKernelGGL((sconv3_kernel<N, K, F, B, S>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,  \
                        reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                                 \
                        reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id)
+#define SHERF_CONV3_(N, K, F, B) do { if (single) SHERF_CONV3__(N, K, F, B, true); else SHERF_CONV3__(N, K, F, B, false); } while (0)
 #define SHERF_CONV3(N, K)                                                                                                    \
     do { if (fold) { if (bnm == 2) SHERF_CONV3_(N, K, true, 2); else if (bnm) SHERF_CONV3_(N, K, true, 1); else SHERF_CONV3_(N, K, true, 0); } \
          else { if (bnm == 2) SHERF_CONV3_(N, K, false, 2); else if (bnm) SHERF_CONV3_(N, K, false, 1); else SHERF_CONV3_(N, K, false, 0); } } while (0)
@@ -626,6 +639,7 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     }
 #undef SHERF_CONV3
 #undef SHERF_CONV3_
+#undef SHERF_CONV3__
     SHERF_LAUNCH_CHECK();
 }
 
@@ -711,8 +725,8 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         // eval: bnparam comes from the running statistics and was prepared by the caller (sherf_svox_bn_finalize with
         // training = 0) when they last changed.
         SHERF_RUN(launch_conv3(dst.keys, dst.n_rows, dst.D, dst.H, dst.W, src.wp, src.D, src.H, src.W, cur, ly.cin, cur_bn,
-                               (lev == 0 && cur_bn.bnparam) ? p->mult : nullptr, ly.wt, ly.cout, ly.down ? 1 : 0, dst.cap, ly.out,
-                               training ? ly.acc : nullptr, stream));
+                               (lev == 0 && cur_bn.bnparam) ? p->mult : nullptr, ly.wt, ly.cout, (ly.down ? 1 : 0) | ((fold_half & 2) ? 1024 : 0),
+                               dst.cap, ly.out, training ? ly.acc : nullptr, stream));
         if (ev && li == ev_layer) SHERF_HIP_CHECK(hipEventRecord(ev, as_stream(stream)));
         lev = dlev; cur = ly.out; cur_bn = bn_of(ly, dlev);
         if (ly.tap) {
@@ -724,7 +738,8 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
                 fst = aux;
             }
             SHERF_RUN(launch_conv3(nullptr, dst.n_rows, 1, 1, 1, nullptr, 1, 1, 1, ly.out, ly.cout, cur_bn, nullptr,
-                                   p->fold_mat[ntap], 96, 2 | (fold_half ? 512 : 0), dst.cap, p->fold_rows[ntap], nullptr, fst));
+                                   p->fold_mat[ntap], 96, 2 | ((fold_half & 1) ? 512 : 0) | ((fold_half & 2) ? 1024 : 0), dst.cap,
+                                   p->fold_rows[ntap], nullptr, fst));
             levels_out_host[ntap].wp = dst.wp;
             levels_out_host[ntap].rows = p->fold_rows[ntap];
             levels_out_host[ntap].D = dst.D; levels_out_host[ntap].H = dst.H; levels_out_host[ntap].W = dst.W;

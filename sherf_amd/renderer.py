@@ -231,7 +231,7 @@ _SIDE_STREAMS = {}           # (device, caller stream) -> [side, aux]
 
 class ImportanceRenderer(nn.Module):
     def __init__(self, use_1d_feature=True, use_2d_feature=True, use_3d_feature=True, use_trans=False, use_NeRF_decoder=False,
-                 smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='auto', table_precision='auto'):
+                 smpl=None, smpl_path=os.path.join('assets', 'SMPL_NEUTRAL.pkl'), mlp_precision='auto', table_precision='auto', encoder_precision='auto'):
         super().__init__()
         self.use_1d_feature, self.use_2d_feature, self.use_3d_feature = use_1d_feature, use_2d_feature, use_3d_feature
         self.use_trans, self.use_NeRF_decoder = use_trans, use_NeRF_decoder
@@ -247,7 +247,8 @@ class ImportanceRenderer(nn.Module):
         self.pos_enc = PositionalEncoding(num_freqs=6)
         self.view_enc = PositionalEncoding(num_freqs=4)
         self.mlp_precision = mlp_precision
-        self.table_precision = table_precision            # 'auto' | 'f32' | 'f16' (see _half_tables)
+        self.table_precision = table_precision            # 'auto' | 'f32' | 'f16'      (see _resolve_config)
+        self.encoder_precision = encoder_precision        # 'auto' | 'f16x3' | 'f16'
         self.gather_split = os.environ.get('SHERF_GATHER_SPLIT', '0') == '1'   # tri-plane/pixel taps before the encoder join
         # schedule variant of the voxel taps (sherf_hip.h): False = one branch per corner, True = unconditional loads (160 VGPRs),
         # '128' = unconditional loads compiled for 4 waves / SIMD
@@ -408,69 +409,75 @@ class ImportanceRenderer(nn.Module):
         out['stream'], out['wbias'] = wc['streams'][prec]
         return out
 
-    # ---- mlp_precision='auto' ------------------------------------------------------------------
-    AUTO_CANDIDATES = ('f16',)          # cheaper modes tried against the fp32-grade 'f16x3', cheapest first
+    # ---- precision configuration ----------------------------------------------------------------
+    # A frame's configuration = (MLP operand precision, format of the folded tables the gather taps, operand precision of the sparse
+    # convolutions).  'f16x3' / fp32 tables / 'f16x3' is the fp32-grade reference configuration.  mlp_precision='auto' measures the
+    # cheaper ones, cheapest first, against it on a whole frame of the weights' own samples and keeps the first within AUTO_TOL.
+    REFERENCE_CONFIG = ('f16x3', 'f32', 'f16x3')
+    AUTO_CANDIDATES = (('f16', 'f16', 'f16'), ('f16', 'f16', 'f16x3'), ('f16', 'f32', 'f16x3'))
     AUTO_TOL = 2.5e-4                   # a quarter of north_star's 1e-3 per-sample budget (true relative error, floors 1.0 / 0.1)
 
-    def _resolve_precision(self, name, decoder, dev):
-        """'auto' -> the precision chosen for the CURRENT weights (None while they are uncalibrated: the frame then renders in
-        'f16x3' and `_calibrate` measures the candidates on that frame's own samples)."""
-        if name != 'auto':
-            return name, False
-        if torch.is_grad_enabled() and getattr(self, 'enable_autograd', False):
-            return 'f16x3', False                        # training: weights change every step, stay fp32-grade
-        wc = self._weights(decoder, dev, 'f16x3')
-        choice = self._wcache['auto']
-        return (choice, False) if choice is not None else ('f16x3', True)
+    def _resolve_config(self, opts, decoder, dev):
+        """-> ((mlp, tables, encoder), calibrate?).  Explicit settings win (rendering_options, then the constructor's); 'auto' tables
+        are fp16 exactly when the MLP runs on single products (its first MFMA rounds the tokens to 11 / 8 bits anyway), an 'auto'
+        encoder follows the tables (its output is rounded to fp16 rows there).  The autograd path stays fp32-grade throughout: weights
+        change every step and the backward reads fp32 tables."""
+        mlp = opts.get('mlp_precision') or self.mlp_precision
+        tab = opts.get('table_precision') or getattr(self, 'table_precision', 'auto')
+        enc = opts.get('encoder_precision') or getattr(self, 'encoder_precision', 'auto')
+        training = getattr(self, '_in_autograd', False) or (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False))
+        if training:
+            return (mlp if mlp != 'auto' else 'f16x3', 'f32', 'f16x3'), False
+        if mlp == 'auto':
+            self._weights(decoder, dev, 'f16x3')
+            choice = self._wcache['auto']
+            if choice is None:
+                return self.REFERENCE_CONFIG, True
+            mlp, t0, e0 = choice
+            return (mlp, t0 if tab == 'auto' else tab, e0 if enc == 'auto' else enc), False
+        tab = tab if tab != 'auto' else ('f16' if mlp in ('f16', 'bf16') else 'f32')
+        enc = enc if enc != 'auto' else ('f16' if tab == 'f16' else 'f16x3')
+        return (mlp, tab, enc), False
 
-    def _set_config(self, fr, decoder, dev, prec_name, half_tables, exact):
-        """The precision-dependent fields of the frame descriptor: the MLP fragment stream of `prec_name` and the table format."""
-        wc = self._weights(decoder, dev, prec_name)
+    def _set_config(self, fr, decoder, dev, cfg, exact):
+        """The precision-dependent fields of the frame descriptor: the MLP fragment stream and the table / encoder flags."""
+        wc = self._weights(decoder, dev, cfg[0])
         fr.wstream, fr.wbias = _lib.addr(wc['stream']), _lib.addr(wc['wbias'])
-        fr.mlp_prec = MLP_PRECISIONS[prec_name]
-        fr.flags = (1 if exact else 0) | (2 if half_tables else 0)
+        fr.mlp_prec = MLP_PRECISIONS[cfg[0]]
+        fr.flags = (1 if exact else 0) | (2 if cfg[1] == 'f16' else 0) | (4 if cfg[2] == 'f16' else 0)
         return wc
 
     def _calibrate(self, fr, decoder, dev, ws, levels, streams, exact):
-        """mlp_precision='auto': before the frame proper (f16x3, fp32 tables) the SAME frame is rendered in every candidate
-        configuration -- the cheaper MLP precision together with the fp16 tables it implies -- and its per-sample sigma+ / rgb are kept;
-        the cheapest candidate within AUTO_TOL (true relative error with the parity floors, every sample of the frame) of the f16x3
-        result is used from the next frame on.  One extra frame per candidate and one host wait, once per set of weights."""
-        cands = {}
-        for cand in self.AUTO_CANDIDATES:
-            self._set_config(fr, decoder, dev, cand, self._half_tables(cand, None), exact)
+        """mlp_precision='auto': before the frame proper (the reference configuration) the SAME frame is rendered in every candidate
+        configuration and its per-sample sigma+ / rgb are kept; the first (cheapest) candidate within AUTO_TOL -- true relative error
+        with the parity floors, EVERY sample of the frame -- of the reference result is used from the next frame on.  One extra frame
+        per candidate and one host wait, once per set of weights."""
+        cands = []
+        for cfg in self.AUTO_CANDIDATES:
+            self._set_config(fr, decoder, dev, cfg, exact)
             _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, *streams)
-            cands[cand] = ws['sample_out'].clone()
-        self._set_config(fr, decoder, dev, 'f16x3', False, exact)
+            cands.append((cfg, ws['sample_out'].clone()))
+        self._set_config(fr, decoder, dev, self.REFERENCE_CONFIG, exact)
 
         def decide():
             ref = ws['sample_out']
             nv = int(ws['counters'][0])
-            choice, report = 'f16x3', {}
+            choice, report = self.REFERENCE_CONFIG, {}
             if nv > 0:
                 sig_r = ref[:nv, 3].clamp(min=0)
-                for cand, out in cands.items():
+                for cfg, out in cands:
                     e_sig = ((out[:nv, 3].clamp(min=0) - sig_r).abs() / sig_r.clamp(min=1.0)).max()
                     e_rgb = ((out[:nv, :3] - ref[:nv, :3]).abs() / ref[:nv, :3].abs().clamp(min=0.1)).max()
                     e = float(torch.maximum(e_sig, e_rgb))
-                    report[cand] = e
+                    report['mlp %s / tables %s / encoder %s' % cfg] = e
                     if e == e and e <= self.AUTO_TOL:
-                        choice = cand
+                        choice = cfg
                         break
             self._wcache['auto'] = choice
-            self.auto_report = dict(choice=choice, errors_vs_f16x3=report, samples=nv, tol=self.AUTO_TOL,
-                                    tables={c: ('f16' if self._half_tables(c, None) else 'f32') for c in cands})
+            self.auto_report = dict(choice=choice[0], config=dict(mlp=choice[0], tables=choice[1], encoder=choice[2]),
+                                    errors_vs_reference_config=report, samples=nv, tol=self.AUTO_TOL)
             return choice
         return decide
-
-    def _half_tables(self, prec_name, requested):
-        """Format of the folded tables the gather taps: 'f32' / 'f16' on request (rendering_options['table_precision'] or the
-        constructor's), otherwise fp16 exactly when the MLP runs on single products -- its first MFMA rounds the tokens to 11 (8)
-        bits anyway, and the calibration of `auto` measures the two together."""
-        req = requested or getattr(self, 'table_precision', 'auto')
-        if req in ('f32', 'f16'):
-            return req == 'f16'
-        return prec_name in ('f16', 'bf16')
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
@@ -515,7 +522,8 @@ class ImportanceRenderer(nn.Module):
         cap = int(opts.get('sample_capacity', R * S))
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         smpl = self._smpl(dev)
-        prec_name, calibrate = self._resolve_precision(opts.get('mlp_precision') or self.mlp_precision, decoder, dev)
+        cfg, calibrate = self._resolve_config(opts, decoder, dev)
+        prec_name = cfg[0]
         wc = self._weights(decoder, dev, prec_name)
         wsp = self._workspace(dev)
         ws = wsp.frame(R, S, cap, dev)
@@ -584,8 +592,7 @@ class ImportanceRenderer(nn.Module):
         fr.vox_plan = _ct.addressof(pl['plan'])
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
         # a13-a14: fused transformer + NeRF decoder
-        half = self._half_tables(prec_name, opts.get('table_precision')) and not getattr(self, '_in_autograd', False)   # (the backward reads fp32 tables)
-        self._set_config(fr, decoder, dev, prec_name, half, exact)
+        self._set_config(fr, decoder, dev, cfg, exact)
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()
@@ -595,7 +602,6 @@ class ImportanceRenderer(nn.Module):
         decide = None
         if calibrate and noise == 0:
             decide = self._calibrate(fr, decoder, dev, ws, levels, (s_main, s_side, s_aux), exact)
-            half = False
         rng = opts.get('depth_range')                                    # sherf_amd.dist: [lo, hi] of the WHOLE frame's depths
         if noise > 0 or rng is not None:
             _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
@@ -615,7 +621,7 @@ class ImportanceRenderer(nn.Module):
             decide()
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=prec_name, table_precision='f16' if half else 'f32',
+        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2],
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min, vox_sh=[int(v) for v in obs_sp_input['out_sh']],

@@ -193,7 +193,7 @@ def test_auto_precision_is_calibrated_per_weights():
         first = G.hip_render(cfg, precision='auto')
         rep = first['rend'].auto_report
         picks[cfg] = rep['choice']
-        print(f"{cfg}: auto -> {rep['choice']} (errors vs f16x3 {rep['errors_vs_f16x3']}, {rep['samples']} samples)")
+        print(f"{cfg}: auto -> {rep['config']} (errors vs the reference configuration {rep['errors_vs_reference_config']}, {rep['samples']} samples)")
         assert first['last']['mlp_precision'] == 'f16x3'                      # the calibration frame itself is fp32-grade
         h = G.hip_render(cfg, precision='auto')
         assert h['last']['mlp_precision'] == rep['choice'] and h['rend'].check_finite()
@@ -204,7 +204,7 @@ def test_auto_precision_is_calibrated_per_weights():
         # new weights -> calibrated again
         with torch.no_grad():
             h['dec'].alpha_linear.bias.add_(0.0)
-        assert h['rend']._resolve_precision('auto', h['dec'], h['rgb'].device if False else next(h['dec'].parameters()).device)[1]
+        assert h['rend']._resolve_config(dict(mlp_precision='auto'), h['dec'], next(h['dec'].parameters()).device)[1]
     G.hip_modules.cache_clear()
     assert picks == {'tiny_ri': 'f16', 'tiny': 'f16x3'}, picks
 
@@ -466,6 +466,7 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
     a = G.hip_render(cfg, sp_input=spi, precision=precision)
     b = G.hip_render(cfg, sp_input=spi, precision=precision)
     assert a['last']['mlp_precision'] == precision and a['last']['table_precision'] == ('f32' if precision == 'f16x3' else 'f16')
+    assert a['last']['encoder_precision'] == ('f16x3' if precision == 'f16x3' else 'f16')
     assert a['rgb'].shape == (R, 3) and torch.isfinite(a['rgb']).all() and torch.isfinite(a['acc']).all()
     assert float(a['acc'].min()) >= 0.0 and float(a['acc'].max()) <= 1.0 + 1e-5 and float(a['rgb'].abs().max()) <= 1.01
     assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['depth'], b['depth']) and torch.equal(a['acc'], b['acc'])
