@@ -15,9 +15,9 @@ import os
 import sys
 import time
 
-# Frames are issued round-robin on `--streams` caller streams (default 2), each with its own pair of side streams: more HIP streams than
-# the runtime's default of 4 hardware queues, onto which it would multiplex them (two chains sharing a queue run one after the other:
-# DESIGN section 7).  Must be set before the HIP runtime initialises.
+# With `--streams N > 1` frames are issued round-robin on N caller streams, each with its own pair of side streams: more HIP streams
+# than the runtime's default of 4 hardware queues, onto which it would multiplex them (two chains sharing a queue run one after the
+# other: DESIGN section 7).  Must be set before the HIP runtime initialises; harmless with one stream.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np
@@ -75,6 +75,10 @@ def make_workload(a, theta, dev):
     sp_input, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
     sp = SparseConvTensor(to(fx['vertex_feat']), sp_input['coord'], sp_input['out_sh'], 1)
     opts = dict(fx['options']); opts['mlp_precision'] = a.precision
+    if getattr(a, 'table_precision', None):
+        opts['table_precision'] = a.table_precision
+    if getattr(a, 'encoder_precision', None):
+        opts['encoder_precision'] = a.encoder_precision
     return dict(rend=rend, dec=dec, d=d, sp=sp, sp_input=sp_input, planes=to(fx['planes']), obs_feat=to(fx['obs_feat']),
                 obs_img=d['obs_img_all'][:, 0], opts=opts)
 
@@ -223,11 +227,13 @@ def main():
                          'initialisation, alpha bias + 5) and band-limited tables; cfg2 = the adversarial seeded weights of rounds 1-2')
     ap.add_argument('--precision', default='auto', choices=['auto', 'f16x3', 'f16', 'bf16'],
                     help='MLP operand precision; auto (the product default) = calibrated per set of weights on the first frame')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--table-precision', default=None, choices=['f32', 'f16'], help='override the folded tables\' format (default: follows the MLP precision)')
+    ap.add_argument('--encoder-precision', default=None, choices=['f16x3', 'f16'], help='override the sparse convolutions\' operand precision (default: follows the tables)')
+    ap.add_argument('--streams', type=int, default=1,
                     help='caller streams the frames are issued on, round-robin (each frame is one ImportanceRenderer.forward on its '
-                         'stream; every stream has its own workspace): with 2, frame N+1\'s low-occupancy first phase (cell lists, '
-                         'sampling, the encoder\'s chain of small launches) runs under frame N\'s chip-filling gather and MLP; 1 = one '
-                         'frame at a time')
+                         'stream; every stream has its own workspace).  1 (default) = one frame at a time.  With 2, frame N+1\'s first phase '
+                         'runs under frame N\'s gather and MLP -- measured SLOWER on the MI355X (1.45 vs 1.35 ms per frame: the kernels of the '
+                         'two frames slow each other more than the overlap gains, profiles/r03_streams_overlap.txt), kept as an option')
     ap.add_argument('--partition', default='views', choices=['views', 'rays'],
                     help='N > 1: views (default, BASELINE config 4: every rank renders its own target view, weak scaling) or rays (ONE frame '
                          'cut into interleaved 1024-ray tiles over the ranks, sherf_amd.dist.ray_tiles: strong scaling, value = the frame\'s '
