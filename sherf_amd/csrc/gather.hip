@@ -53,7 +53,15 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
     const int64_t n_tiles = (nv + 31) / 32;
     const int l = threadIdx.x & 7;                 // channel quad within a slot
     const int j = threadIdx.x >> 3;                // sample within the tile (0..31)
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // XCD-banded tile order (dbg bit 10 turns it off): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each with its own 4 MiB L2,
+    // and the tables (28-60 MB) fit none of them.  The compact samples are ray-major, so a CONTIGUOUS range of tiles is a band of image
+    // rows = a slab of the body; giving XCD k the k-th eighth of the tiles (instead of every eighth tile) makes each L2 serve one slab
+    // of the feature map, of the voxel rows and of the (x, y) / (z, y) planes instead of all of them.
+    const bool banded = !(dbg & 1024) && gridDim.x % 8 == 0;
+    const int64_t per_xcd = (n_tiles + 7) / 8, slots = gridDim.x / 8;
+    for (int64_t it = banded ? blockIdx.x / 8 : blockIdx.x; it < (banded ? per_xcd : n_tiles); it += banded ? slots : gridDim.x) {
+        const int64_t tile = banded ? (int64_t)(blockIdx.x % 8) * per_xcd + it : it;
+        if (tile >= n_tiles) break;
         const int64_t c = tile * 32 + j;
         float4 acc[3];
         if (mode == 2) acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);     // voxel pass adds onto the stored tokens
@@ -348,7 +356,7 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
     const int64_t tiles = (capacity + 31) / 32;
 #define SHERF_GATHER(BL, MW, HT)                                                                                               \
-    hipLaunchKernelGGL((gather_tokens_kernel<BL, MW, HT>), dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), \
+    hipLaunchKernelGGL((gather_tokens_kernel<BL, MW, HT>), dim3((unsigned)(tiles < 16384 ? (tiles + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream), \
                        counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,         \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode)
