@@ -212,6 +212,168 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
     }
 }
 
+// fp16 tables, EIGHT channels per lane (round 3).  The counters of the kernel above (profiles/r03_pmc_gather_ta.txt) read: texture
+// addresser busy 85 % of the launch, 1.44e8 cache accesses -- the SAME with fp32 and with fp16 tables, same 370 us.  The addresser
+// takes a wave's load four lanes per cycle whether a lane asks for 8 or for 16 bytes: the kernel's time is its number of wave-level
+// load instructions x 16 cycles, not its bytes.  So with fp16 tables a lane takes 16 bytes = EIGHT channels, FOUR lanes own a
+// 32-channel slot and a wave covers 16 samples instead of 8: half the load instructions for the same taps.  Same stencils, same
+// weights, fp32 sums; the tokens / extras come out in the same tile-major layout (a lane stores two quads).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+struct f8 { float4 a, b; };
+__device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__ base, size_t idx8) {
+    const h16x8 v = reinterpret_cast<const h16x8*>(base)[idx8];
+    acc.a.x += w * (float)v[0]; acc.a.y += w * (float)v[1]; acc.a.z += w * (float)v[2]; acc.a.w += w * (float)v[3];
+    acc.b.x += w * (float)v[4]; acc.b.y += w * (float)v[5]; acc.b.z += w * (float)v[6]; acc.b.w += w * (float)v[7];
+}
+
+__global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
+                                                               const void* __restrict__ planes_f, int P, const void* __restrict__ feat_f,
+                                                               int Hf, int Wf, const float4* __restrict__ img4, int H, int W, Levels lv,
+                                                               const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
+                                                               const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
+                                                               float4* __restrict__ tokens, float* __restrict__ extras, int dbg, int mode) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32, n_pairs = (n_tiles + 1) / 2;       // a workgroup step = two tiles = 64 samples
+    const int l = threadIdx.x & 3;                 // channel octet within a slot (quads 2l, 2l + 1)
+    const int js = threadIdx.x >> 2;               // sample within the pair of tiles (0..63)
+    const bool banded = !(dbg & 1024) && gridDim.x % 8 == 0;                  // XCD-banded order, as in gather_tokens_kernel
+    const int64_t per_xcd = (n_pairs + 7) / 8, slots = gridDim.x / 8;
+    for (int64_t it = banded ? blockIdx.x / 8 : blockIdx.x; it < (banded ? per_xcd : n_pairs); it += banded ? slots : gridDim.x) {
+        const int64_t pair = banded ? (int64_t)(blockIdx.x % 8) * per_xcd + it : it;
+        if (pair >= n_pairs) break;
+        const int64_t tile = pair * 2 + (js >> 5);
+        const int j = js & 31;
+        if (tile >= n_tiles) continue;
+        const int64_t c = tile * 32 + j;
+        f8 acc[3];
+        if (mode == 2) { for (int s_ = 0; s_ < 3; ++s_) acc[s_].a = acc[s_].b = make_float4(0.f, 0.f, 0.f, 0.f); }
+        else { for (int s_ = 0; s_ < 3; ++s_) { acc[s_].a = tok_bias[8 * s_ + 2 * l]; acc[s_].b = tok_bias[8 * s_ + 2 * l + 1]; } }
+        float4 rgb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nv) {
+            const float* gm = geom + c * 8;
+            const float xc[3] = {gm[0], gm[1], gm[2]};
+            if (mode != 2) {                                                  // extras rows 0-5 = x_c, v_c: lanes 0-2 write two each
+                if (l < 3) { extras[(tile * 12 + 2 * l) * 32 + j] = gm[2 * l]; extras[(tile * 12 + 2 * l + 1) * 32 + j] = gm[2 * l + 1]; }
+            }
+            float n[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if ((dbg & 8) || mode == 2) break;
+                const float ga = p == 2 ? n[2] : n[0];
+                const float gb = p == 1 ? n[2] : n[1];
+                float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+                float py = clampf(((gb + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < P && yy >= 0 && yy < P)
+                            axpy8(acc[p], (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy), planes_f, ((size_t)(p * P + yy) * P + xx) * 4 + l);
+                    }
+            }
+            if (!(dbg & 16) && mode != 2) {
+                float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
+                float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
+                float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
+                            const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            const size_t t = ((size_t)yy * Wf + xx) * 8;
+                            axpy8(acc[0], w, feat_f, t + l);
+                            axpy8(acc[1], w, feat_f, t + 4 + l);
+                        }
+                    }
+                px = clampf((gx + 1.f) * 0.5f * (W - 1), -2.f, (float)W + 1.f);
+                py = clampf((gy + 1.f) * 0.5f * (H - 1), -2.f, (float)H + 1.f);
+                x0 = floorf(px); y0 = floorf(py); fx = px - x0; fy = py - y0;
+                xi = (int)x0; yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < W && yy >= 0 && yy < H) axpy4(rgb, (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy), img4[(size_t)yy * W + xx]);
+                    }
+            }
+            if (mode != 2) {                                                  // rows 6-8 = tapped rgb, 9-11 = 0
+                if (l == 3) { extras[(tile * 12 + 6) * 32 + j] = rgb.x; extras[(tile * 12 + 7) * 32 + j] = rgb.y; }
+                extras[(tile * 12 + 8 + l) * 32 + j] = (l == 0) ? rgb.z : 0.f;
+            }
+            if (!(dbg & 4) && mode != 1) {
+                float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;
+                float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
+                float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
+#pragma unroll 1
+                for (int L = 0; L < 3; ++L) {
+                    const sherf_vox_level& lev = lv.l[L];
+                    float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
+                    float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
+                    float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
+                    float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                    float fx = px - x0, fy = py - y0, fz = pz - z0;
+                    int xi = (int)x0, yi = (int)y0, zi = (int)z0;
+                    uint2 rec[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int xx = xi + (t & 1), yy = yi + ((t >> 1) & 1), zz = zi + (t >> 2);
+                        const bool inb = xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
+                        const int key = inb ? (zz * lev.H + yy) * lev.W + xx : 0;
+                        const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                        const uint32_t bit = 1u << (key & 31);
+                        rec[t] = make_uint2((inb && (rr.x & bit)) ? 1u : 0u, rr.y + __popc(rr.x & (bit - 1u)));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (rec[t].x) {
+                            const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
+                            const size_t r = (size_t)rec[t].y * 12;
+                            axpy8(acc[0], w, lev.rows, r + l);
+                            axpy8(acc[1], w, lev.rows, r + 4 + l);
+                            axpy8(acc[2], w, lev.rows, r + 8 + l);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int s_ = 0; s_ < 3; ++s_) acc[s_].a = acc[s_].b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mode != 2) {                               // padding columns of the last tile
+                if (l < 3) { extras[(tile * 12 + 2 * l) * 32 + j] = 0.f; extras[(tile * 12 + 2 * l + 1) * 32 + j] = 0.f; }
+                if (l == 3) { extras[(tile * 12 + 6) * 32 + j] = 0.f; extras[(tile * 12 + 7) * 32 + j] = 0.f; }
+                extras[(tile * 12 + 8 + l) * 32 + j] = 0.f;
+            }
+        }
+        // tokens[tile][slot][quad][j] (float4): this lane owns quads 2l and 2l + 1 of every slot
+        if (mode == 2) {
+            if (c < nv)
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    float4* ta = tokens + ((tile * 3 + s_) * 8 + 2 * l) * 32 + j;
+                    float4 t0 = ta[0], t1 = ta[32];
+                    t0.x += acc[s_].a.x; t0.y += acc[s_].a.y; t0.z += acc[s_].a.z; t0.w += acc[s_].a.w;
+                    t1.x += acc[s_].b.x; t1.y += acc[s_].b.y; t1.z += acc[s_].b.z; t1.w += acc[s_].b.w;
+                    ta[0] = t0; ta[32] = t1;
+                }
+            continue;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            tokens[((tile * 3 + s_) * 8 + 2 * l) * 32 + j] = acc[s_].a;
+            tokens[((tile * 3 + s_) * 8 + 2 * l + 1) * 32 + j] = acc[s_].b;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward of the gather (BASELINE config 5; oracle/backward_explicit.py: folded_taps_bwd, step (i)): every tap is linear
 // in its table, so d_tokens is scattered with the forward's tap weights into the gradients of the FOLDED tables
@@ -360,7 +522,13 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
                        counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,         \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode)
-    if (half_tables) { if (squeezed) SHERF_GATHER(true, 4, true); else if (branchless) SHERF_GATHER(true, 1, true); else SHERF_GATHER(false, 1, true); }
+    if (half_tables && !branchless && !(g_sherf_debug & 2048)) {      // eight channels per lane (debug bit 11: the four-per-lane kernel on fp16 tables)
+        const int64_t pairs = (tiles + 1) / 2;
+        hipLaunchKernelGGL(gather_tokens_h8_kernel, dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
+                           counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
+                           reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
+                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode);
+    } else if (half_tables) { if (squeezed) SHERF_GATHER(true, 4, true); else if (branchless) SHERF_GATHER(true, 1, true); else SHERF_GATHER(false, 1, true); }
     else { if (squeezed) SHERF_GATHER(true, 4, false); else if (branchless) SHERF_GATHER(true, 1, false); else SHERF_GATHER(false, 1, false); }
 #undef SHERF_GATHER
     SHERF_LAUNCH_CHECK();

@@ -755,18 +755,16 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     // compaction below only writes afterwards -- provably holds every sample; sherf_set_debug bit 9 forces the one-wave-per-ray kernel
     const bool two_pass = !(g_sherf_debug & 512) && 4 * capacity >= (int64_t)R * S;
     if (two_pass) {
-        // the search is a PERSISTENT grid (the candidate count is only known on the device): six workgroups per CU, pinned there by
-        // 22 KiB of unused dynamic LDS each, so that two of the eight wave slots per SIMD stay free for the encoder's small dependent
-        // launches on the other stream for the whole of its ~0.2 ms -- persistent workgroups in every slot would hold them off until
-        // the search is done (as for sample_nn_kernel below: profiles/r02_sconv_sampler_balance.txt)
-        constexpr int search_pad = 22 * 1024;
+        // the search is a PERSISTENT grid (the candidate count is only known on the device), eight workgroups per CU.  Capping it at six
+        // (22 KiB of LDS padding, as sample_nn_kernel below is) to keep wave slots free for the encoder's launches on the other stream
+        // was measured and LOST: 1.346 -> 1.381 ms per frame (profiles/r03_bench_d_*.txt) -- the search simply ran longer.
         int32_t* cand_list = reinterpret_cast<int32_t*>(cs_xs);
         const int64_t list_cap = 4 * capacity;
         unsigned long long* rm = reinterpret_cast<unsigned long long*>(ray_mask);
 #define SHERF_TWO_PASS(N)                                                                                                          \
         hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
                            grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
-        hipLaunchKernelGGL(cand_search_kernel<N>, dim3(6 * n_cus()), dim3(256), search_pad, st, cand_list, list_cap, cand_count, ray_o, ray_d,   \
+        hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, ray_o, ray_d,   \
                            near, far, S, Rg, Th, grid_hdr, cell_start, cp, rm, dense_vid);                                         \
         hipLaunchKernelGGL(scan_chunk_mask_kernel<N>, dim3(n_chunks), dim3(1024), 0, st, ray_mask, R, ray_cnt, base_local, chunk_sum)
         if (nch == 1) { SHERF_TWO_PASS(1); } else if (nch == 2) { SHERF_TWO_PASS(2); } else if (nch == 3) { SHERF_TWO_PASS(3); } else { SHERF_TWO_PASS(4); }

@@ -324,17 +324,20 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     // the accumulation is unchanged (taps ascending per wave, K-blocks ascending): results are bit-identical to the simple loop.
     constexpr int PF = NKB * NCOT <= 2 ? 3 : (NKB * NCOT <= 4 ? 2 : 1);   // (32 -> 32 at PF 4 costs 198 registers: 2 workgroups per CU, and level 1 launches 602)
     struct Row { float4 v[2 * NKB]; int nb; float mlt; };
-    struct Wts { uint4 w[NKB][2 * NCOT]; };
+    constexpr int WPC = SP ? 1 : 2;                   // weight fragments per (K-block, output tile): hi [, lo]
+    struct Wts { uint4 w[NKB][WPC * NCOT]; };
     auto row_src = [&](int nb) { return reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h; };
     auto row_mult = [&](int nb) {                   // (the load is unconditional per lane: one uniform branch, no divergent one)
         const float m = has_mult ? (float)(in_mult[nb >= 0 ? nb : 0] - 1) : 0.f;
         return nb >= 0 ? m : 0.f;
     };
-    auto load_w = [&](int tap, int kb, uint4 (&w)[2 * NCOT]) {
-        const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;
+    auto load_w = [&](int tap, int kb, uint4 (&w)[WPC * NCOT]) {
+        const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;     // memory: [cot][hi, lo][64 lanes]
 #pragma unroll
-        for (int c = 0; c < 2 * NCOT; ++c)
-            if ((!FOLD || (c >> 1) == csel) && !(SP && (c & 1))) w[c] = wsrc[c * 64];          // (SP: the `lo` fragments are never fetched)
+        for (int c = 0; c < NCOT; ++c)
+#pragma unroll
+            for (int q = 0; q < WPC; ++q)                                                  // (SP: the `lo` fragments are never fetched)
+                if (!FOLD || c == csel) w[WPC * c + q] = wsrc[(2 * c + q) * 64];
     };
     auto load_all = [&](int tap, Row& R, Wts& W) {
         const int nb = s_nb[tap * 32 + r];
@@ -368,7 +371,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
 #pragma unroll
                 for (int c = 0; c < NCOT; ++c) {
                     if (FOLD && c != csel) continue;
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, W.w[kb][2 * c]), acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, W.w[kb][WPC * c]), acc[c], 0, 0, 0);
                 }
             } else {
             const uint4 alo = make_uint4(pk2(v[0] - rt(v[0]), v[1] - rt(v[1])), pk2(v[2] - rt(v[2]), v[3] - rt(v[3])),
@@ -376,7 +379,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
 #pragma unroll
             for (int c = 0; c < NCOT; ++c) {
                 if (FOLD && c != csel) continue;
-                const uint4 bhi = W.w[kb][2 * c], blo = W.w[kb][2 * c + 1];
+                const uint4 bhi = W.w[kb][WPC * c], blo = W.w[kb][WPC * c + WPC - 1];
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);

@@ -419,8 +419,8 @@ class ImportanceRenderer(nn.Module):
 
     def _resolve_config(self, opts, decoder, dev):
         """-> ((mlp, tables, encoder), calibrate?).  Explicit settings win (rendering_options, then the constructor's); 'auto' tables
-        are fp16 exactly when the MLP runs on single products (its first MFMA rounds the tokens to 11 / 8 bits anyway), an 'auto'
-        encoder follows the tables (its output is rounded to fp16 rows there).  The autograd path stays fp32-grade throughout: weights
+        are fp16 exactly when the MLP runs on single products (its first MFMA rounds the tokens to 11 / 8 bits anyway); an 'auto'
+        encoder stays f16x3 unless mlp_precision='auto' measured the single-product convolutions acceptable on the frame.  The autograd path stays fp32-grade throughout: weights
         change every step and the backward reads fp32 tables."""
         mlp = opts.get('mlp_precision') or self.mlp_precision
         tab = opts.get('table_precision') or getattr(self, 'table_precision', 'auto')
@@ -436,7 +436,7 @@ class ImportanceRenderer(nn.Module):
             mlp, t0, e0 = choice
             return (mlp, t0 if tab == 'auto' else tab, e0 if enc == 'auto' else enc), False
         tab = tab if tab != 'auto' else ('f16' if mlp in ('f16', 'bf16') else 'f32')
-        enc = enc if enc != 'auto' else ('f16' if tab == 'f16' else 'f16x3')
+        enc = enc if enc != 'auto' else 'f16x3'      # (single-product convolutions only where `auto` has measured them: AUTO_CANDIDATES)
         return (mlp, tab, enc), False
 
     def _set_config(self, fr, decoder, dev, cfg, exact):

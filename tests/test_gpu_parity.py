@@ -466,7 +466,7 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
     a = G.hip_render(cfg, sp_input=spi, precision=precision)
     b = G.hip_render(cfg, sp_input=spi, precision=precision)
     assert a['last']['mlp_precision'] == precision and a['last']['table_precision'] == ('f32' if precision == 'f16x3' else 'f16')
-    assert a['last']['encoder_precision'] == ('f16x3' if precision == 'f16x3' else 'f16')
+    assert a['last']['encoder_precision'] == 'f16x3'
     assert a['rgb'].shape == (R, 3) and torch.isfinite(a['rgb']).all() and torch.isfinite(a['acc']).all()
     assert float(a['acc'].min()) >= 0.0 and float(a['acc'].max()) <= 1.0 + 1e-5 and float(a['rgb'].abs().max()) <= 1.01
     assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['depth'], b['depth']) and torch.equal(a['acc'], b['acc'])
