@@ -414,7 +414,9 @@ class ImportanceRenderer(nn.Module):
     # convolutions).  'f16x3' / fp32 tables / 'f16x3' is the fp32-grade reference configuration.  mlp_precision='auto' measures the
     # cheaper ones, cheapest first, against it on a whole frame of the weights' own samples and keeps the first within AUTO_TOL.
     REFERENCE_CONFIG = ('f16x3', 'f32', 'f16x3')
-    AUTO_CANDIDATES = (('f16', 'f16', 'f16'), ('f16', 'f16', 'f16x3'), ('f16', 'f32', 'f16x3'))
+    # (('f16', 'f16', 'f16') -- single-product sparse convolutions too -- is NOT a candidate: correct on the host build, wrong folded rows on
+    #  the MI355X, cause not found yet: DESIGN section 9, profiles/r03_bench_e_gather_h8.txt; the calibration rejected it, as it should)
+    AUTO_CANDIDATES = (('f16', 'f16', 'f16x3'), ('f16', 'f32', 'f16x3'))
     AUTO_TOL = 2.5e-4                   # a quarter of north_star's 1e-3 per-sample budget (true relative error, floors 1.0 / 0.1)
 
     def _resolve_config(self, opts, decoder, dev):
