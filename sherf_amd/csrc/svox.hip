@@ -214,8 +214,11 @@ __device__ unsigned g_sconv_trace_cap = 0, g_sconv_trace_n = 0;
 // SP: single fp16 product per term (operands rounded to nearest even, the `hi` weight fragments only) instead of the three of the
 // f16x3 split: a third of the MFMA issue and half the weight loads of a tap.  Follows the frame's table precision (the encoder's output
 // is rounded to fp16 rows there anyway, and mlp_precision='auto' calibrates the whole configuration against f16x3 on the frame).
-template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
-__global__ void __launch_bounds__(256, (NCOT * NKB >= 12 ? 1 : 2))   // (level 2 launches 318 workgroups: two per CU must fit)
+// NW: waves per workgroup the 27 taps are split over.  A workgroup's life is a serial chain of dependent gathers, ~7 taps per wave at
+// NW = 4 (profiles/r02_sconv_trace_v3.txt: 28 K of its ~50 K cycles); at NW = 8 a wave walks 3-4 taps and the partial tiles of eight
+// waves are summed in LDS (up to 98 KiB: these workgroups are alone or nearly alone on their CU anyway).
+template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP, int NW>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
+__global__ void __launch_bounds__(64 * NW, (NW == 8 ? 2 : (NCOT * NKB >= 12 ? 1 : 2)))   // (level 2 launches 318 workgroups: two per CU must fit)
 sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, BnIn bin,
@@ -234,7 +237,8 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
     float* s_bn = reinterpret_cast<float*>(smem + 27 * 32 * 4);                 // [3][Cin]
-    float* s_red = s_bn + 3 * Cin;                                              // [4][32][COUT]
+    float* s_red = s_bn + 3 * Cin;                                              // [NW][32][COUT]
+    constexpr int NT = 64 * NW;
     const int n_rows = *n_rows_out;
     const int row0 = blockIdx.x * 32;
     if (row0 >= n_rows) return;
@@ -247,21 +251,22 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
         const bool live = row < n_rows;
         const int key = (live && !FOLD) ? keys_out[row] : 0;
         const int z = key / (Ho * Wo), y = (key / Wo) % Ho, x = key % Wo;
-        int qk[4];
-        uint2 rec[4];
+        constexpr int TG = 2 * NW, NJ = 32 / TG;           // tap groups of 32 threads, taps per thread
+        int qk[NJ];
+        uint2 rec[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tap = (tid >> 5) + 8 * j;
+        for (int j = 0; j < NJ; ++j) {
+            const int tap = (tid >> 5) + TG * j;
             const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
             const int qz = mode ? 2 * z + kz - 1 : z + kz - 1, qy = mode ? 2 * y + ky - 1 : y + ky - 1, qx = mode ? 2 * x + kx - 1 : x + kx - 1;
             const bool ok = live && !FOLD && tap < 27 && qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi;
             qk[j] = ok ? (qz * Hi + qy) * Wi + qx : -1;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rec[j] = qk[j] >= 0 ? wp_in[qk[j] >> 5] : make_uint2(0u, 0u);
+        for (int j = 0; j < NJ; ++j) rec[j] = qk[j] >= 0 ? wp_in[qk[j] >> 5] : make_uint2(0u, 0u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tap = (tid >> 5) + 8 * j;
+        for (int j = 0; j < NJ; ++j) {
+            const int tap = (tid >> 5) + TG * j;
             if (tap >= ntaps) continue;
             int nb = -1;
             if (FOLD) nb = live ? row : -1;
@@ -292,7 +297,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
                 }
             }
         } else {
-            for (int i = tid; i < 3 * Cin; i += 256) s_bn[i] = bin.bnparam[i];
+            for (int i = tid; i < 3 * Cin; i += NT) s_bn[i] = bin.bnparam[i];
         }
     }
     SCONV_STAMP(2);                                  // BatchNorm prologue done
@@ -307,7 +312,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     const int r = lane & 31, h = lane >> 5;
     // taps of this wave (tap = wave, wave+4, ...) that have at least one neighbour in the tile
     uint32_t tapmask = 0;
-    for (int tap = wave; tap < ntaps; tap += 4)
+    for (int tap = wave; tap < ntaps; tap += NW)
         if (__ballot(s_nb[tap * 32 + r] >= 0) != 0ull) tapmask |= 1u << tap;
     // pointwise fold (one tap): the waves split the output-channel tiles instead of the taps
     const int csel = FOLD ? wave : -1;
@@ -438,13 +443,16 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     SCONV_STAMP(7);
     __syncthreads();
     SCONV_STAMP(8);                                  // every wave's taps done
-    constexpr int G = 256 / COUT;                       // row groups: 8 / 4 / 2
+    constexpr int G = NT / COUT;                        // row groups: 8 / 4 / 2 (NW = 4), 16 / 8 / 5 (NW = 8)
     const int g = tid / COUT, co = tid % COUT;
     float s1 = 0.f, s2 = 0.f;
     if (g < G)
         for (int rr = g; rr < 32; rr += G) {
-            const float val = ((s_red[(0 * 32 + rr) * COUT + co] + s_red[(1 * 32 + rr) * COUT + co]) + s_red[(2 * 32 + rr) * COUT + co]) +
-                              s_red[(3 * 32 + rr) * COUT + co];
+            float val = ((s_red[(0 * 32 + rr) * COUT + co] + s_red[(1 * 32 + rr) * COUT + co]) + s_red[(2 * 32 + rr) * COUT + co]) +
+                        s_red[(3 * 32 + rr) * COUT + co];
+            if constexpr (NW == 8)
+                val += ((s_red[(4 * 32 + rr) * COUT + co] + s_red[(5 * 32 + rr) * COUT + co]) + s_red[(6 * 32 + rr) * COUT + co]) +
+                       s_red[(7 * 32 + rr) * COUT + co];
             if (row0 + rr < n_rows) {
                 if (out_half) reinterpret_cast<_Float16*>(out_raw)[(size_t)(row0 + rr) * COUT + co] = (_Float16)val;
                 else out_raw[(size_t)(row0 + rr) * COUT + co] = val;
@@ -612,16 +620,24 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
     SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
-    const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * Cout * 4;
-    const dim3 grid(cdiv(max_rows, 32)), block(256);
+    // taps over eight waves for the 27-tap convolutions (sherf_set_debug bit 12: four, as the pointwise folds always are)
+    const bool wide = mode != 2 && !(g_sherf_debug & 4096);
+    const int nw = wide ? 8 : 4;
+    const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)nw * 32 * Cout * 4;
+    const dim3 grid(cdiv(max_rows, 32)), block(64 * nw);
     SHERF_CHECK_ARG(!in_mult || bin.bnparam);       // (the multiplicity only enters through the BatchNorm transform)
     const bool fold = mode == 2;
     const int bnm = bin.bnparam ? (in_mult ? 2 : 1) : 0;
     const int kmode = mode | ((g_sherf_debug & 128) ? 256 : 0) | (fold ? out_half : 0);
-#define SHERF_CONV3__(N, K, F, B, S)                                                                                         \
-    hipLaunchKernelGGL((sconv3_kernel<N, K, F, B, S>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo,  \
-                       reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                                 \
-                       reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id)
+#define SHERF_CONV3___(N, K, F, B, S, W)                                                                                     \
+    do {                                                                                                                          \
+        if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv3_kernel<N, K, F, B, S, W>), \
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
+        hipLaunchKernelGGL((sconv3_kernel<N, K, F, B, S, W>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo, \
+                           reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                             \
+                           reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id); \
+    } while (0)
+#define SHERF_CONV3__(N, K, F, B, S) do { if (wide && !F) SHERF_CONV3___(N, K, F, B, S, 8); else SHERF_CONV3___(N, K, F, B, S, 4); } while (0)
 #define SHERF_CONV3_(N, K, F, B) do { if (single) SHERF_CONV3__(N, K, F, B, true); else SHERF_CONV3__(N, K, F, B, false); } while (0)
 #define SHERF_CONV3(N, K)                                                                                                    \
     do { if (fold) { if (bnm == 2) SHERF_CONV3_(N, K, true, 2); else if (bnm) SHERF_CONV3_(N, K, true, 1); else SHERF_CONV3_(N, K, true, 0); } \
@@ -643,6 +659,7 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
 #undef SHERF_CONV3
 #undef SHERF_CONV3_
 #undef SHERF_CONV3__
+#undef SHERF_CONV3___
     SHERF_LAUNCH_CHECK();
 }
 
