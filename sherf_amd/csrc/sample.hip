@@ -439,6 +439,8 @@ __global__ void __launch_bounds__(256) cand_mark_kernel(const float* __restrict_
         if (gb + i < list_cap) cand_list[gb + i] = s_list[i];
 }
 
+constexpr int kSearchU = 2;           // candidates in flight per eight-lane group (the kernel is a chain of dependent L2 trips)
+
 template <int NCH>
 __global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restrict__ cand_list, int64_t list_cap,
                                                           const int32_t* __restrict__ cand_count, const float* __restrict__ ray_o,
@@ -447,80 +449,107 @@ __global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restr
                                                           const float* __restrict__ Th, const float* __restrict__ hdr,
                                                           const int32_t* __restrict__ cell_start, const float4* __restrict__ cell_pts,
                                                           unsigned long long* __restrict__ ray_mask, int32_t* __restrict__ dense_vid) {
-    __shared__ int s_seg[32][20];                    // per candidate of the step: 9 segment starts, 9 counts
+    constexpr int U = kSearchU;
+    __shared__ int s_seg[U][32][20];                 // per candidate of the step: 9 segment starts, 9 counts
     const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const CellGrid g = load_grid(hdr);
     const int64_t n = min((int64_t)*cand_count, list_cap);
     const float r = 0.05f + 1e-4f * g.cell;
     const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
-    for (int64_t c0 = (int64_t)blockIdx.x * 32; c0 < n; c0 += (int64_t)gridDim.x * 32) {
-        const int64_t ci = c0 + grp;
-        const bool live = ci < n;
-        const int idx = live ? cand_list[ci] : 0;
-        const int ray = idx / S, k = idx - ray * S;
-        const float nr = near[ray], range = __fsub_rn(far[ray], nr);
-        const float t = depth_at(nr, range, k, S);
-        const float x = __fadd_rn(ray_o[ray * 3], __fmul_rn(t, ray_d[ray * 3])), y = __fadd_rn(ray_o[ray * 3 + 1], __fmul_rn(t, ray_d[ray * 3 + 1])),
-                    z = __fadd_rn(ray_o[ray * 3 + 2], __fmul_rn(t, ray_d[ray * 3 + 2]));
-        float xs, ys, zs;
-        to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
-        const int cx = (int)floorf((xs - g.ox) * g.inv_cell), cy = (int)floorf((ys - g.oy) * g.inv_cell), cz = (int)floorf((zs - g.oz) * g.inv_cell);
+    for (int64_t c0 = (int64_t)blockIdx.x * 32 * U; c0 < n; c0 += (int64_t)gridDim.x * 32 * U) {
+        bool live[U];
+        int idx[U], ray[U], k[U];
+        float xs[U], ys[U], zs[U];
+        // every load of a stage is issued for all U candidates before any of them is consumed: U independent chains per lane group
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t ci = c0 + u * 32 + grp;
+            live[u] = ci < n;
+            idx[u] = live[u] ? cand_list[ci] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ray[u] = idx[u] / S; k[u] = idx[u] - ray[u] * S;
+            const float nr = near[ray[u]], range = __fsub_rn(far[ray[u]], nr);
+            const float t = depth_at(nr, range, k[u], S);
+            const float x = __fadd_rn(ray_o[ray[u] * 3], __fmul_rn(t, ray_d[ray[u] * 3])),
+                        y = __fadd_rn(ray_o[ray[u] * 3 + 1], __fmul_rn(t, ray_d[ray[u] * 3 + 1])),
+                        z = __fadd_rn(ray_o[ray[u] * 3 + 2], __fmul_rn(t, ray_d[ray[u] * 3 + 2]));
+            to_smpl_frame(x, y, z, Rg, Th, xs[u], ys[u], zs[u]);
+        }
         // the nine x-contiguous point segments of the 3x3x3 neighbourhood, trimmed to what the 5 cm ball reaches (as in sample_nn_kernel):
         // lane `sub` of the group prepares row `sub`, lane 0 also row 8
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int i = pass ? 8 : sub;
-            if (pass && sub != 0) break;
-            const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
-            const float y0 = g.oy + qy * g.cell, z0 = g.oz + qz * g.cell;
-            const float ey = fmaxf(fmaxf(y0 - ys, ys - (y0 + g.cell)), 0.f), ez = fmaxf(fmaxf(z0 - zs, zs - (z0 + g.cell)), 0.f);
-            const float rem = r * r - (ey * ey + ez * ez);
-            const bool ok = live && qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny && rem > 0.f;
-            const float rx = sqrtf(fmaxf(rem, 0.f)) + 1e-4f * g.cell;
-            const int x0 = max(max((int)floorf((xs - rx - g.ox) * g.inv_cell), cx - 1), 0);
-            const int x1 = min(min((int)floorf((xs + rx - g.ox) * g.inv_cell), cx + 1), g.nx - 1);
-            const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
-            const int st = cell_start[row + (ok ? x0 : 0)];
-            const int en = ok && x1 >= x0 ? cell_start[row + x1 + 1] : st;
-            s_seg[grp][i] = st; s_seg[grp][9 + i] = en - st;
+        for (int u = 0; u < U; ++u) {
+            const int cx = (int)floorf((xs[u] - g.ox) * g.inv_cell), cy = (int)floorf((ys[u] - g.oy) * g.inv_cell), cz = (int)floorf((zs[u] - g.oz) * g.inv_cell);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int i = pass ? 8 : sub;
+                if (pass && sub != 0) break;
+                const int qz = cz + i / 3 - 1, qy = cy + i % 3 - 1;
+                const float y0 = g.oy + qy * g.cell, z0 = g.oz + qz * g.cell;
+                const float ey = fmaxf(fmaxf(y0 - ys[u], ys[u] - (y0 + g.cell)), 0.f), ez = fmaxf(fmaxf(z0 - zs[u], zs[u] - (z0 + g.cell)), 0.f);
+                const float rem = r * r - (ey * ey + ez * ez);
+                const bool ok = live[u] && qz >= 0 && qz < g.nz && qy >= 0 && qy < g.ny && rem > 0.f;
+                const float rx = sqrtf(fmaxf(rem, 0.f)) + 1e-4f * g.cell;
+                const int x0 = max(max((int)floorf((xs[u] - rx - g.ox) * g.inv_cell), cx - 1), 0);
+                const int x1 = min(min((int)floorf((xs[u] + rx - g.ox) * g.inv_cell), cx + 1), g.nx - 1);
+                const int row = ok ? (qz * g.ny + qy) * g.nx : 0;
+                const int st = cell_start[row + (ok ? x0 : 0)];
+                const int en = ok && x1 >= x0 ? cell_start[row + x1 + 1] : st;
+                s_seg[u][grp][i] = st; s_seg[u][grp][9 + i] = en - st;
+            }
         }
         __builtin_amdgcn_wave_barrier();             // (a group's eight lanes sit in one wave, which runs in lockstep; LDS ordered by lgkmcnt)
-        int bs[9], cum[9];
-        int run = 0;
+        int bs[U][9], cum[U][9], npts[U];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { bs[i] = s_seg[grp][i]; run += s_seg[grp][9 + i]; cum[i] = run; }
+        for (int u = 0; u < U; ++u) {
+            int run = 0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { bs[u][i] = s_seg[u][grp][i]; run += s_seg[u][grp][9 + i]; cum[u][i] = run; }
+            npts[u] = run;
+        }
         __builtin_amdgcn_wave_barrier();             // every lane has read the step's segments before the next step rewrites them
-        const int npts = cum[8];
-        unsigned long long key = kInit;
-        for (int base = 0; base < npts; base += 8 * kMaxPtsUnroll) {
-            float4 v[kMaxPtsUnroll];
+        unsigned long long key[U];
+        int most = 0;
 #pragma unroll
-            for (int u = 0; u < kMaxPtsUnroll; ++u) {
-                const int tt = base + u * 8 + sub;
-                int p = bs[0] + tt;
+        for (int u = 0; u < U; ++u) { key[u] = kInit; most = max(most, npts[u]); }
+        for (int base = 0; base < most; base += 8 * kMaxPtsUnroll) {
+            float4 v[U][kMaxPtsUnroll];
 #pragma unroll
-                for (int i = 1; i < 9; ++i) p = (tt >= cum[i - 1]) ? bs[i] + (tt - cum[i - 1]) : p;
-                v[u] = cell_pts[tt < npts ? p : 0];
-            }
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int u = 0; u < kMaxPtsUnroll; ++u) {
-                const int tt = base + u * 8 + sub;
-                const float dd = dist2_exact(xs, ys, zs, v[u].x, v[u].y, v[u].z);
-                if (tt < npts && dd < kThresh2) {
-                    const unsigned long long cand = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u].w);
-                    key = cand < key ? cand : key;
+                for (int w = 0; w < kMaxPtsUnroll; ++w) {
+                    const int tt = base + w * 8 + sub;
+                    int p = bs[u][0] + tt;
+#pragma unroll
+                    for (int i = 1; i < 9; ++i) p = (tt >= cum[u][i - 1]) ? bs[u][i] + (tt - cum[u][i - 1]) : p;
+                    v[u][w] = cell_pts[tt < npts[u] ? p : 0];
                 }
-            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int w = 0; w < kMaxPtsUnroll; ++w) {
+                    const int tt = base + w * 8 + sub;
+                    const float dd = dist2_exact(xs[u], ys[u], zs[u], v[u][w].x, v[u][w].y, v[u][w].z);
+                    if (tt < npts[u] && dd < kThresh2) {
+                        const unsigned long long cand = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[u][w].w);
+                        key[u] = cand < key[u] ? cand : key[u];
+                    }
+                }
         }
 #pragma unroll
-        for (int off = 4; off > 0; off >>= 1) {      // lexicographic (d^2, vertex id) minimum over the group's eight lanes
-            const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
-            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            key = other < key ? other : key;
-        }
-        if (live && sub == 0 && (unsigned)(key >> 32) < __float_as_uint(kThresh2)) {
-            dense_vid[idx] = (int)(key & 0x7FFFFFFFull);
-            atomicOr(&ray_mask[(size_t)ray * NCH + (k >> 6)], 1ull << (k & 63));
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {  // lexicographic (d^2, vertex id) minimum over the group's eight lanes
+                const unsigned lo = __shfl_xor((unsigned)key[u], off), hi = __shfl_xor((unsigned)(key[u] >> 32), off);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key[u] = other < key[u] ? other : key[u];
+            }
+            if (live[u] && sub == 0 && (unsigned)(key[u] >> 32) < __float_as_uint(kThresh2)) {
+                dense_vid[idx[u]] = (int)(key[u] & 0x7FFFFFFFull);
+                atomicOr(&ray_mask[(size_t)ray[u] * NCH + (k[u] >> 6)], 1ull << (k[u] & 63));
+            }
         }
     }
 }
