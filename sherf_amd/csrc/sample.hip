@@ -439,7 +439,10 @@ __global__ void __launch_bounds__(256) cand_mark_kernel(const float* __restrict_
         if (gb + i < list_cap) cand_list[gb + i] = s_list[i];
 }
 
-constexpr int kSearchU = 2;           // candidates in flight per eight-lane group (the kernel is a chain of dependent L2 trips)
+// candidates in flight per eight-lane group.  Two (every stage's loads issued for both before either is consumed) was measured in round 3:
+// 232 us against 209 us with one (profiles/r03_bench_f_sconv8_search2.txt) -- the extra registers cost more occupancy than the second
+// chain hides.
+constexpr int kSearchU = 1;
 
 template <int NCH>
 __global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restrict__ cand_list, int64_t list_cap,

@@ -620,8 +620,11 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
     SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
     SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
-    // taps over eight waves for the 27-tap convolutions (sherf_set_debug bit 12: four, as the pointwise folds always are)
-    const bool wide = mode != 2 && !(g_sherf_debug & 4096);
+    // four waves per workgroup.  Eight (sherf_set_debug bit 12; a wave then walks 3-4 taps instead of ~7 and eight partial tiles are summed
+    // in LDS) was built and measured in round 3 and LOST: encoder_done 0.66 -> 0.755 ms, frame 1.29 -> 1.39 ms (profiles/
+    // r03_bench_f_sconv8_search2.txt) -- 512-thread workgroups fit one per CU where two 256-thread ones shared it, and the 96 -> 96
+    // instance spills at the 256-register cap.
+    const bool wide = mode != 2 && (g_sherf_debug & 4096) != 0;
     const int nw = wide ? 8 : 4;
     const size_t smem = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)nw * 32 * Cout * 4;
     const dim3 grid(cdiv(max_rows, 32)), block(64 * nw);
