@@ -86,25 +86,31 @@ def main():
     phase_ev = []
     step0 = step
 
+    host_t = []
+
     def step():                                             # the same step with three more events on the stream
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         opt.zero_grad(set_to_none=True)
+        h0 = time.perf_counter()
         ev[0].record()
         sp = SparseConvTensor(vfeat, sp_input['coord'], sp_input['out_sh'], 1)
         rgb, depth, acc = rend(planes, obs_img, obs_feat, sp, None, sp_input, dec, ro, rd, nr, fr, d, opts)
         loss = ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
         ev[1].record()
+        h1 = time.perf_counter()
         loss.backward()
         ev[2].record()
+        h2 = time.perf_counter()
         sdist.allreduce_flat_grads(params)
         opt.step()
         ev[3].record()
+        host_t.append((h1 - h0, h2 - h1, time.perf_counter() - h2))      # host time of each phase's enqueue (the backward's includes its one read-back)
         phase_ev.append(ev)
         return loss
 
     for _ in range(a.warmup):
         step()
-    scatter_ev.clear(); phase_ev.clear()
+    scatter_ev.clear(); phase_ev.clear(); host_t.clear()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -135,7 +141,8 @@ def main():
         print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
                               unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32 (backward: fp32 kernels + MFMA GEMMs on a three-part bf16 split; forward: f16x3 MFMA)',
-                              data='synthetic', final_loss=float(loss), phases_ms=phases, roofline=roofline,
+                              data='synthetic', final_loss=float(loss), phases_ms=phases,
+                              host_ms=dict(zip(('forward', 'backward', 'allreduce_adam'), (1e3 * np.mean(host_t, 0)).tolist())), roofline=roofline,
                               config=dict(workload=f'{a.config}: one view per GPU, stub loss MSE(rgb)+MSE(acc)', rays=R))))
     if world > 1:
         torch.distributed.barrier()

@@ -169,6 +169,13 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* The weight stream for `prec` built on the device (what sherf_amd/mlp_pack.py: pack() builds on the host, bit for bit): slot i (2 bytes) of
+ * stream_out = piece (src[i] & 1: 0 = hi, 1 = lo) of flat[src[i] >> 1], zero where src[i] < 0; bias_out[i] = flat[bias_src[i]] or 0.
+ * `flat` = the parameters of mlp_pack.packed_names() concatenated, (src, bias_src) = mlp_pack.stream_index() (device copies).
+ * *flag (device) is set to 0, then |= 1 if a packed value is not finite, |= 2 if one exceeds the fp16 range in an fp16 mode: the
+ * caller reads it back and raises (the reference has no such failure mode: its Linear layers run in fp32, triplane.py:285-316). */
+int sherf_mlp_pack_stream(const float* flat, const int32_t* src, int64_t n_slots, int prec, void* stream_out,
+                          const int32_t* bias_src, int n_bias, float* bias_out, int32_t* flag, sherf_stream_t stream);
 /* layout of the weight stream the kernel expects for `prec`: *n_steps steps; step_pieces_host[s] = its size in 1 KiB pieces (hi [, lo]
  * fragments, zero-padded to a multiple of 4); units[s * 10 + u] = chunk * 16 + K-block of the u-th (chunk, K-block) unit the kernel
  * consumes in step s (-1 = none / padding).  sherf_amd/mlp_pack.py restates it; tests/test_boundary.py compares the two. */
@@ -221,6 +228,15 @@ int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do,
                      const uint32_t* wp_in, int Di, int Hi, int Wi, const float* in_raw, int Cin,
                      const float* in_bn, const int32_t* in_mult, const void* w_packed, int Cout, int mode,
                      int max_rows, float* out_raw, int64_t* out_acc, sherf_stream_t stream);
+/* Input gradient of that convolution on the same kernel (BASELINE config 5): d_in[i][ci] = sum_k sum_co d_raw[o(i,k)][co] W[co][k][ci],
+ * o(i,k) = the row at offset 1 - k from i (down == 0) or the coarse voxel (i + 1 - k) / 2 where whole (down == 1; spconv's stride-2
+ * SparseConv3d backward, reference renderer.py:1071-1079 layers).  keys_i / n_rows_i / (Di,Hi,Wi): the level of the layer's INPUT
+ * rows (those that receive), wp_o / (Do,Ho,Wo): the level of d_raw's rows.  w_packed_t: pack_conv_weights of wt[k'][co][ci] =
+ * W[co][26 - k'][ci].  *d_raw_amax (device): bits of max |d_raw| (sherf_bwd_bn_relu writes it) -- gradients are O(1e-7), the fp16
+ * operand split needs O(1): the rows are scaled by a power of two into range and the result scaled back, both exact. */
+int sherf_svox_conv3_dgrad(const int32_t* keys_i, const int32_t* n_rows_i, int Di, int Hi, int Wi, const uint32_t* wp_o, int Do,
+                           int Ho, int Wo, const float* d_raw, int Cout, const uint32_t* d_raw_amax, const void* w_packed_t,
+                           int Cin, int down, int max_rows, float* d_in, sherf_stream_t stream);
 /* out_acc (optional): [8][2][Cout] int64, zeroed by the caller; the conv adds 2^24-scaled sums of its output rows and of
  * their squares (8 interleaved sub-accumulators) -- the batch statistics of the BatchNorm that follows it. */
 /* statistics over the reference's row set (n_total rows, the non-voxel rows being zeros) -> bnparam[3][C] =

@@ -89,11 +89,13 @@ int sherf_bwd_bn_relu_apply(const float* raw, const float* bnparam, const int32_
  * BatchNorm (batch statistics over the reference's row set) + ReLU backward of one layer: d_out = gradient w.r.t. the
  * per-voxel activation relu(bn(raw)) + (mult - 1) relu(shift); raw [cap][C] the conv output, bnparam [3][C] / stats [2][C]
  * as left by the forward, mult (level 0 only, else NULL), n_total = rows of the reference row set, n_rows = voxels.
- * -> d_raw [cap][C] (zero beyond n_rows), dgamma[C], dbeta[C]; sums[3][C] is scratch. */
+ * -> d_raw [cap][C] (zero beyond n_rows), dgamma[C], dbeta[C]; sums[3][C] is scratch.  amax (may be NULL): receives the bit pattern
+ * of max |d_raw| -- the input scale of the MFMA input-gradient convolution (include/sherf_hip.h: sherf_svox_conv3_dgrad). */
 int sherf_bwd_bn_relu(const float* d_out, const float* raw, const float* bnparam, const float* stats, const float* gamma,
                       const int32_t* mult, const int32_t* n_total, const int32_t* n_rows, int64_t cap, int C, float* sums,
-                      float* d_raw, float* dgamma, float* dbeta, sherf_stream_t stream);
-/* Sparse conv backward w.r.t. its input: for the rows (keys_i, dims Di..) of the INPUT level,
+                      float* d_raw, float* dgamma, float* dbeta, uint32_t* amax, sherf_stream_t stream);
+/* (fp32 VALU form, kept as the check of the MFMA one the step uses -- sherf_svox_conv3_dgrad, 16.5 ms -> see profiles/ per step.)
+ * Sparse conv backward w.r.t. its input: for the rows (keys_i, dims Di..) of the INPUT level,
  * d_in[i][ci] = sum_k sum_co d_raw[o(i,k)][co] W[co][k][ci], W = the reference weight [Cout][27][Cin]; the rows o live in the
  * level described by wp_o (dims Do..): mode 0 submanifold (same level), mode 1 stride-2 (o in the coarser level). */
 int sherf_bwd_conv_dgrad(const int32_t* keys_i, const int32_t* n_rows_i, int Di, int Hi, int Wi, const uint32_t* wp_o, int Do,

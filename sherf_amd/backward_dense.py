@@ -28,6 +28,12 @@ class Mat:
         return Mat(torch.zeros(int(rows) * int(cols), dtype=torch.float32, device=device), rows, cols)
 
     @staticmethod
+    def empty(rows, cols, device):
+        """Uninitialised: only for buffers the next kernel overwrites completely (a 3n x 144 activation is 1.2 GB at 512 x 512 x 64:
+        zero-filling every intermediate cost round 2's step 3.2 ms of fill kernels)."""
+        return Mat(torch.empty(int(rows) * int(cols), dtype=torch.float32, device=device), rows, cols)
+
+    @staticmethod
     def of(t):
         """A contiguous 2-D (or 1-D -> one row) parameter tensor as a Mat (no copy when already fp32 contiguous)."""
         t = t.detach().to(torch.float32).contiguous()
@@ -115,10 +121,12 @@ class HipOps:
 
     # ---- sparse encoder backward (levels are dicts: keys / wp / n_rows int32 tensors, dims (D,H,W), cap) ----
     def bn_relu_bwd(self, d_out, raw, bnparam, stats, gamma, mult, n_total, n_rows, d_raw, dgamma, dbeta):
-        sums = Mat.zeros(3, raw.cols, raw.buf.device)
+        sums = Mat.empty(1, 3 * raw.cols + 1, raw.buf.device)                  # [3][C] scratch + the amax word (both zeroed by the call)
+        amax = sums.colslice(3 * raw.cols, 3 * raw.cols + 1)
         _lib.call_bwd('sherf_bwd_bn_relu', self._p(d_out), self._p(raw), self._p(bnparam), self._p(stats), self._p(gamma),
                       None if mult is None else _lib.ptr(mult), _lib.ptr(n_total), _lib.ptr(n_rows), raw.rows, raw.cols, self._p(sums),
-                      self._p(d_raw), self._p(dgamma), self._p(dbeta), self.st)
+                      self._p(d_raw), self._p(dgamma), self._p(dbeta), self._p(amax), self.st)
+        d_raw.amax = amax                                                       # read by conv_dgrad (bits of max |d_raw|)
 
     def conv_wgrad(self, lev_out, lev_in, in_raw, Cin, in_bn, in_mult, d_raw, Cout, mode, dW):
         _lib.call_bwd('sherf_bwd_conv_wgrad', _lib.ptr(lev_out['keys']), _lib.ptr(lev_out['n_rows']), *lev_out['dims'], _lib.ptr(lev_in['wp']),
@@ -126,6 +134,18 @@ class HipOps:
                       None if in_mult is None else _lib.ptr(in_mult), self._p(d_raw), Cout, mode, lev_out['cap'], self._p(dW), self.st)
 
     def conv_dgrad(self, lev_in, lev_out, d_raw, Cout, W, Cin, mode, d_in):
+        """On the forward's MFMA sparse-convolution kernel (sherf_svox_conv3_dgrad): the taps mirrored, the channel roles exchanged, d_raw
+        scaled into the fp16 split's range by the maximum sherf_bwd_bn_relu left in d_raw.amax.  (The fp32 VALU kernel this replaces,
+        sherf_bwd_conv_dgrad, took 16.5 ms of round 2's step; it stays in the library as the check: conv_dgrad_valu.)"""
+        if getattr(d_raw, 'amax', None) is None:
+            raise RuntimeError('conv_dgrad: d_raw carries no amax (it must come from bn_relu_bwd)')
+        Wt = W.tensor().view(Cout, 27, Cin).flip(1).permute(1, 0, 2).contiguous()        # wt[k'][co][ci] = W[co][26 - k'][ci]
+        from .voxel import pack_conv_weights
+        wp = pack_conv_weights(Wt)
+        _lib.call('sherf_svox_conv3_dgrad', _lib.ptr(lev_in['keys']), _lib.ptr(lev_in['n_rows']), *lev_in['dims'], _lib.ptr(lev_out['wp']),
+                  *lev_out['dims'], self._p(d_raw), Cout, self._p(d_raw.amax), _lib.ptr(wp), Cin, mode, lev_in['cap'], self._p(d_in), self.st)
+
+    def conv_dgrad_valu(self, lev_in, lev_out, d_raw, Cout, W, Cin, mode, d_in):
         _lib.call_bwd('sherf_bwd_conv_dgrad', _lib.ptr(lev_in['keys']), _lib.ptr(lev_in['n_rows']), *lev_in['dims'], _lib.ptr(lev_out['wp']),
                       *lev_out['dims'], self._p(d_raw), Cout, self._p(W), Cin, mode, lev_in['cap'], self._p(d_in), self.st)
 
@@ -145,12 +165,13 @@ def dense_backward(ops, state, tok, ext, d_sample):
     rgb encoding to conv1d_reprojection.weight[:, 32:64] (the rest of that weight's gradient comes from the tap backward)."""
     n, dev = tok.rows, tok.buf.device
     Z = lambda r, c: Mat.zeros(r, c, dev)
+    E = lambda r, c: Mat.empty(r, c, dev)                           # (every E below is written in full before it is read)
     P = lambda name: Mat.of(state[name])
     grads = {}
 
     def lin_fwd(x, wname, act, out=None):
         W = P(wname + '.weight')                                   # [out, in]
-        y = out if out is not None else Z(x.rows, W.rows)
+        y = out if out is not None else E(x.rows, W.rows)
         ops.gemm(0, 1, x, W, y)
         ops.bias_act(y, P(wname + '.bias') if (wname + '.bias') in state else None, act)
         return y
@@ -158,51 +179,51 @@ def dense_backward(ops, state, tok, ext, d_sample):
     def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True):
         """grads of y = x W^T + b; returns d_x (accumulated into d_in with beta)."""
         W = P(wname + '.weight')
-        dW = Z(W.rows, W.cols)
+        dW = E(W.rows, W.cols)
         ops.gemm(1, 0, d_out, x, dW)
         grads[wname + '.weight'] = dW.tensor().view(state[wname + '.weight'].shape).clone()
         if bias and (wname + '.bias') in state:
             db = Z(1, W.rows)
             ops.colsum(d_out, db)
             grads[wname + '.bias'] = db.tensor().view(-1).clone()
-        dx = d_in if d_in is not None else Z(d_out.rows, W.cols)
+        dx = d_in if d_in is not None else E(d_out.rows, W.cols)
         ops.gemm(0, 0, d_out, W, dx, beta)
         return dx
 
     # ================= forward recompute =================
     Wr = state['renderer.conv1d_reprojection.weight'].detach().float()[:, :, 0]
     Wb = Mat.of(Wr[:, 32:64].contiguous())                          # [32 out, 32 in]
-    pe_rgb = Z(n, 33)
+    pe_rgb = E(n, 33)
     ops.pe(ext.colslice(6, 9), 5, pe_rgb)
-    tin = Z(n, 96)                                                  # tokens_in = tok (+ slot 2: PE(rgb)[:32] Wb^T)
+    tin = E(n, 96)                                                  # tokens_in = tok (+ slot 2: PE(rgb)[:32] Wb^T)
     ops.copy2d(tin, tok)
     ops.gemm(0, 1, pe_rgb.colslice(0, 32), Wb, tin.colslice(64, 96), 1.0)
     t = 'renderer.transformer.layers.0.'
     tin3 = tin.as_rows(3 * n, 32)
-    h0, xh0, inv0 = Z(3 * n, 32), Z(3 * n, 32), Z(3 * n, 1)
+    h0, xh0, inv0 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
     ops.ln_fwd(tin3, P(t + '0.fn.norm.weight'), P(t + '0.fn.norm.bias'), h0, xh0, inv0)
-    qkv = Z(3 * n, 144)
+    qkv = E(3 * n, 144)
     ops.gemm(0, 1, h0, P(t + '0.fn.fn.to_qkv.weight'), qkv)
-    att, o = Z(n, 27), Z(3 * n, 48)
+    att, o = E(n, 27), E(3 * n, 48)
     ops.attn_fwd(qkv.as_rows(n, 432), att, o.as_rows(n, 144))
     y = lin_fwd(o, t + '0.fn.fn.to_out.0', 0)
     ops.copy2d(y, tin3, add=True)                                   # residual
-    h1, xh1, inv1 = Z(3 * n, 32), Z(3 * n, 32), Z(3 * n, 1)
+    h1, xh1, inv1 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
     ops.ln_fwd(y, P(t + '1.fn.norm.weight'), P(t + '1.fn.norm.bias'), h1, xh1, inv1)
     u = lin_fwd(h1, t + '1.fn.fn.net.0', 0)
-    ge = Z(3 * n, 32)
+    ge = E(3 * n, 32)
     ops.gelu_fwd(u, ge)
     z = lin_fwd(ge, t + '1.fn.fn.net.3', 0)
     ops.copy2d(z, y, add=True)
     z96 = z.as_rows(n, 96)                                          # [n, slot 0 | slot 1 | slot 2]
     # ---- decoder ----
     d = 'decoder.'
-    x0 = Z(n, 71)
+    x0 = E(n, 71)
     ops.pe(ext.colslice(0, 3), 6, x0.colslice(0, 39))
     ops.copy2d(x0.colslice(39, 71), z96.colslice(0, 32))
     ins, hs = [], []
     h = x0
-    cat5 = Z(n, 199)
+    cat5 = E(n, 199)
     for i in range(8):
         ins.append(h)
         out = cat5.colslice(71, 199) if i == 4 else None            # layer 4 writes straight into cat([x0, h4])
@@ -213,7 +234,7 @@ def dense_backward(ops, state, tok, ext, d_sample):
             ops.copy2d(cat5.colslice(0, 71), x0)
             h = cat5
     h7 = hs[7]
-    vin = Z(n, 187)
+    vin = E(n, 187)
     lin_fwd(h7, d + 'feature_linear', 0, vin.colslice(0, 128))
     ops.pe(ext.colslice(3, 6), 4, vin.colslice(128, 155))
     ops.copy2d(vin.colslice(155, 187), z96.colslice(32, 64))
@@ -222,7 +243,7 @@ def dense_backward(ops, state, tok, ext, d_sample):
     ops.rgb_fwd(rgb)
 
     # ================= backward =================
-    d_lin = Z(n, 3)
+    d_lin = E(n, 3)
     ops.copy2d(d_lin, d_sample.colslice(0, 3))
     ops.rgb_bwd(d_lin, rgb)
     d_g = lin_bwd(d_lin, g, d + 'rgb_linear')
@@ -231,12 +252,12 @@ def dense_backward(ops, state, tok, ext, d_sample):
     d_sigma = d_sample.colslice(3, 4)
     d_h = lin_bwd(d_vin.colslice(0, 128), h7, d + 'feature_linear')
     lin_bwd(d_sigma, h7, d + 'alpha_linear', d_in=d_h, beta=1.0)
-    d_x0 = Z(n, 71)
+    d_x0 = E(n, 71)
     for i in range(7, -1, -1):
         ops.relu_mask(d_h, hs[i])
         d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}')
         if i == 5:
-            ops.copy2d(d_x0, d_in.colslice(0, 71), add=True)
+            ops.copy2d(d_x0, d_in.colslice(0, 71))                  # (first contribution: plain copy, d_x0 starts uninitialised)
             d_h = d_in.colslice(71, 199)
         elif i == 0:
             ops.copy2d(d_x0, d_in, add=True)
@@ -250,20 +271,20 @@ def dense_backward(ops, state, tok, ext, d_sample):
     d_ge = lin_bwd(d_out, ge, t + '1.fn.fn.net.3')
     ops.gelu_bwd(d_ge, u)
     d_h1 = lin_bwd(d_ge, h1, t + '1.fn.fn.net.0')
-    d_y, dw, db = Z(3 * n, 32), Z(1, 32), Z(1, 32)
+    d_y, dw, db = E(3 * n, 32), Z(1, 32), Z(1, 32)
     ops.ln_bwd(d_h1, P(t + '1.fn.norm.weight'), xh1, inv1, d_y, dw, db)
     grads[t + '1.fn.norm.weight'], grads[t + '1.fn.norm.bias'] = dw.tensor().view(-1).clone(), db.tensor().view(-1).clone()
     ops.copy2d(d_y, d_out, add=True)
     # ---- y = o Wo^T + bo + tokens_in ----
     d_o = lin_bwd(d_y, o, t + '0.fn.fn.to_out.0')
-    d_qkv = Z(3 * n, 144)
+    d_qkv = E(3 * n, 144)
     ops.attn_bwd(qkv.as_rows(n, 432), att, d_o.as_rows(n, 144), d_qkv.as_rows(n, 432))
     d_h0 = lin_bwd(d_qkv, h0, t + '0.fn.fn.to_qkv', bias=False)
-    d_tin, dw0, db0 = Z(3 * n, 32), Z(1, 32), Z(1, 32)
+    d_tin, dw0, db0 = E(3 * n, 32), Z(1, 32), Z(1, 32)
     ops.ln_bwd(d_h0, P(t + '0.fn.norm.weight'), xh0, inv0, d_tin, dw0, db0)
     grads[t + '0.fn.norm.weight'], grads[t + '0.fn.norm.bias'] = dw0.tensor().view(-1).clone(), db0.tensor().view(-1).clone()
     ops.copy2d(d_tin, d_y, add=True)
     d_tin96 = d_tin.as_rows(n, 96)
-    dWb_pe = Z(32, 32)
+    dWb_pe = E(32, 32)
     ops.gemm(1, 0, d_tin96.colslice(64, 96), pe_rgb.colslice(0, 32), dWb_pe)
     return d_tin96, grads, dWb_pe.tensor().clone()

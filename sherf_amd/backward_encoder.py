@@ -13,6 +13,7 @@ def encoder_backward(ops, state, ctx, d_levels):
     d_levels: the three Mats [cap_l, C_l] from taps_backward.  -> (d_vertex_feat Mat [N,32], grads {name: tensor})."""
     dev = ctx['g0'].buf.device
     Z = lambda r, c: Mat.zeros(r, c, dev)
+    E = lambda r, c: Mat.empty(r, c, dev)            # written in full (rows < n_rows; the rest is never read) before any read
     grads = {}
     layers, levels = ctx['layers'], ctx['levels']
     d_g, tap_i = None, 2
@@ -27,7 +28,7 @@ def encoder_backward(ops, state, ctx, d_levels):
                 ops.copy2d(d_g, d_levels[tap_i], add=True)
             tap_i -= 1
         at_l0 = ly['lev_out'] == 0
-        d_raw, dgam, dbet = Z(lo['cap'], C), Z(1, C), Z(1, C)
+        d_raw, dgam, dbet = E(lo['cap'], C), E(1, C), E(1, C)       # (sherf_bwd_bn_relu zeroes d_raw's rows >= n_rows itself)
         ops.bn_relu_bwd(d_g, ly['raw'], ly['bnparam'], ly['stats'], Mat.of(state[ly['bname'] + '.weight']),
                         ctx['mult'] if at_l0 else None, ctx['n_total'] if at_l0 else lo['n_rows'], lo['n_rows'], d_raw, dgam, dbet)
         grads[ly['bname'] + '.weight'], grads[ly['bname'] + '.bias'] = dgam.tensor().view(-1).clone(), dbet.tensor().view(-1).clone()

@@ -109,31 +109,53 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 }
 
 // d_x = inv * (d_xh - mean(d_xh) - xh * mean(d_xh * xh)),  d_xh = d_y * w;  dw += d_y * xh, db += d_y
-__global__ void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ xh,
-                              const float* __restrict__ inv, int64_t rows, float* __restrict__ dx, float* __restrict__ dw,
-                              float* __restrict__ db) {
-    __shared__ float s_w[32], s_b[32];
-    if (threadIdx.x < 32) { s_w[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
-    __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < rows) {
-        float g[32], h[32], m1 = 0.f, m2 = 0.f;
+// Eight lanes x float4 per 32-wide row (coalesced 128-byte rows; the two row means are three xor-shuffles), the parameter gradients
+// kept in registers over the workgroup's rows and reduced once at the end: lanes of equal channel quad by shuffles, the four waves
+// through LDS, one global atomic per channel per workgroup.  (Round 2's form -- one thread per row, 64 LDS atomics per thread on the
+// same 32 words -- took 2.35 ms per call on 2 M rows, 26x the time of its memory traffic: profiles/r02_train_step_final_rocprofv3_stats.txt.)
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ xh,
+                                                     const float* __restrict__ inv, int64_t rows, float* __restrict__ dx, float* __restrict__ dw,
+                                                     float* __restrict__ db) {
+    __shared__ float s_red[4][8][8];
+    const int l = threadIdx.x & 7, sub = threadIdx.x >> 3;
+    const float4 wv = reinterpret_cast<const float4*>(w)[l];
+    const float4* dy4 = reinterpret_cast<const float4*>(dy);
+    const float4* xh4 = reinterpret_cast<const float4*>(xh);
+    float4* dx4 = reinterpret_cast<float4*>(dx);
+    float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r0 = (int64_t)blockIdx.x * 32; r0 < rows; r0 += (int64_t)gridDim.x * 32) {      // (uniform trip count: shuffles inside)
+        const int64_t r = r0 + sub;
+        const bool live = r < rows;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 d = live ? dy4[r * 8 + l] : z, h = live ? xh4[r * 8 + l] : z;
+        aw[0] += d.x * h.x; aw[1] += d.y * h.y; aw[2] += d.z * h.z; aw[3] += d.w * h.w;
+        ab[0] += d.x; ab[1] += d.y; ab[2] += d.z; ab[3] += d.w;
+        const float4 g = make_float4(d.x * wv.x, d.y * wv.y, d.z * wv.z, d.w * wv.w);
+        float m1 = (g.x + g.y) + (g.z + g.w), m2 = (g.x * h.x + g.y * h.y) + (g.z * h.z + g.w * h.w);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const float d = dy[r * 32 + c];
-            h[c] = xh[r * 32 + c];
-            atomicAdd(&s_w[c], d * h[c]);
-            atomicAdd(&s_b[c], d);
-            g[c] = d * w[c];
-            m1 += g[c]; m2 += g[c] * h[c];
-        }
+        for (int o = 1; o < 8; o <<= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
         m1 *= (1.f / 32.f); m2 *= (1.f / 32.f);
-        const float iv = inv[r];
+        if (live) {
+            const float iv = inv[r];
+            dx4[r * 8 + l] = make_float4(iv * (g.x - m1 - h.x * m2), iv * (g.y - m1 - h.y * m2), iv * (g.z - m1 - h.z * m2), iv * (g.w - m1 - h.w * m2));
+        }
+    }
 #pragma unroll
-        for (int c = 0; c < 32; ++c) dx[r * 32 + c] = iv * (g[c] - m1 - h[c] * m2);
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { aw[q] += __shfl_xor(aw[q], o); ab[q] += __shfl_xor(ab[q], o); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s_red[wave][lane][q] = aw[q]; s_red[wave][lane][4 + q] = ab[q]; }
     }
     __syncthreads();
-    if (threadIdx.x < 32) { unsafeAtomicAdd(dw + threadIdx.x, s_w[threadIdx.x]); unsafeAtomicAdd(db + threadIdx.x, s_b[threadIdx.x]); }
+    if (threadIdx.x < 64) {                       // thread -> (which = t >> 5, channel c = t & 31)
+        const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+        const float t = (s_red[0][c >> 2][4 * which + (c & 3)] + s_red[1][c >> 2][4 * which + (c & 3)]) +
+                        (s_red[2][c >> 2][4 * which + (c & 3)] + s_red[3][c >> 2][4 * which + (c & 3)]);
+        unsafeAtomicAdd((which ? db : dw) + c, t);
+    }
 }
 
 // one thread per (sample, head): q_i = qkv[n][i][16h..], k_j = qkv[n][j][48 + 16h..], v_j = qkv[n][j][96 + 16h..]
@@ -354,7 +376,9 @@ extern "C" int sherf_bwd_ln_fwd(const float* x, const float* w, const float* b, 
 extern "C" int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh, const float* inv, int64_t rows, float* dx,
                                 float* dw, float* db, sherf_stream_t stream) {
     SHERF_CHECK_ARG(dy && w && xh && inv && dx && dw && db && rows > 0);
-    hipLaunchKernelGGL(ln_bwd_kernel, SHERF_GRID(rows), 0, as_stream(stream), dy, w, xh, inv, rows, dx, dw, db);
+    const int64_t groups = (rows + 31) / 32;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)(groups < 4096 ? groups : 4096)), dim3(256), 0, as_stream(stream), dy, w, xh, inv, rows, dx,
+                       dw, db);
     SHERF_LAUNCH_CHECK();
 }
 

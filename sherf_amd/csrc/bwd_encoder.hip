@@ -48,20 +48,33 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            const int32_t* __restrict__ n_total_p, const int32_t* __restrict__ n_rows_p,
                                                            int64_t cap, int C, float* __restrict__ d_raw, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, uint32_t* __restrict__ amax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= cap * C) return;
-    const int64_t r = i / C;
-    const int c = (int)(i % C);
-    const float scale = bnparam[c], shift = bnparam[C + c], mean = stats[c], inv = 1.f / sqrtf(stats[C + c] + 1e-3f);
-    const float dy0 = shift > 0.f ? sums[2 * C + c] : 0.f, xh0 = -mean * inv;
-    const float s1 = sums[c] + dy0, s2 = sums[C + c] + dy0 * xh0;
-    if (blockIdx.x == 0 && r == 0) { dgamma[c] = s2; dbeta[c] = s1; }
-    if (r >= *n_rows_p) { d_raw[i] = 0.f; return; }
-    const float N = (float)(*n_total_p);
-    const float x = raw[i];
-    const float dy = (x * scale + shift > 0.f) ? d_out[i] : 0.f;
-    d_raw[i] = (gamma[c] * inv / N) * (N * dy - s1 - (x - mean) * inv * s2);
+    float out = 0.f;
+    if (i < cap * C) {
+        const int64_t r = i / C;
+        const int c = (int)(i % C);
+        const float scale = bnparam[c], shift = bnparam[C + c], mean = stats[c], inv = 1.f / sqrtf(stats[C + c] + 1e-3f);
+        const float dy0 = shift > 0.f ? sums[2 * C + c] : 0.f, xh0 = -mean * inv;
+        const float s1 = sums[c] + dy0, s2 = sums[C + c] + dy0 * xh0;
+        if (blockIdx.x == 0 && r == 0) { dgamma[c] = s2; dbeta[c] = s1; }
+        if (r < *n_rows_p) {
+            const float N = (float)(*n_total_p);
+            const float x = raw[i];
+            const float dy = (x * scale + shift > 0.f) ? d_out[i] : 0.f;
+            out = (gamma[c] * inv / N) * (N * dy - s1 - (x - mean) * inv * s2);
+        }
+        d_raw[i] = out;
+    }
+    // max |d_raw| of the layer (bit pattern; non-negative floats order like unsigned integers): the scale of the MFMA input-gradient
+    // convolution that reads d_raw next (sherf_svox_conv3_dgrad).  One atomic per wave that holds a new candidate.
+    if (amax) {
+        float m = fabsf(out);
+        if (!(m <= 3.0e38f)) m = 0.f;                    // (a non-finite gradient must not pick the scale; it still propagates as itself)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+    }
 }
 
 // ---- sparse conv backward w.r.t. the INPUT: d_in[i][ci] = sum_k sum_co d_raw[o(i,k)][co] * W[co][k][ci] ------------------
@@ -207,13 +220,14 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const int32_t* __restr
 
 extern "C" int sherf_bwd_bn_relu(const float* d_out, const float* raw, const float* bnparam, const float* stats, const float* gamma,
                                  const int32_t* mult, const int32_t* n_total, const int32_t* n_rows, int64_t cap, int C, float* sums,
-                                 float* d_raw, float* dgamma, float* dbeta, sherf_stream_t stream) {
+                                 float* d_raw, float* dgamma, float* dbeta, uint32_t* amax, sherf_stream_t stream) {
     SHERF_CHECK_ARG(d_out && raw && bnparam && stats && gamma && n_total && n_rows && sums && d_raw && dgamma && dbeta && cap > 0 && C > 0 && C <= 256);
     SHERF_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)3 * C * sizeof(float), as_stream(stream)));
+    if (amax) SHERF_HIP_CHECK(hipMemsetAsync(amax, 0, sizeof(uint32_t), as_stream(stream)));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, as_stream(stream), d_out, raw, bnparam, stats,
                        mult, n_rows, C, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((cap * C + 255) / 256)), dim3(256), 0, as_stream(stream), d_out, raw, bnparam,
-                       stats, gamma, sums, n_total, n_rows, cap, C, d_raw, dgamma, dbeta);
+                       stats, gamma, sums, n_total, n_rows, cap, C, d_raw, dgamma, dbeta, amax);
     SHERF_LAUNCH_CHECK();
 }
 

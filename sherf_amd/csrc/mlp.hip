@@ -825,6 +825,53 @@ extern "C" int sherf_mlp_stream_layout(int prec, int32_t* n_steps, int32_t* step
     return SHERF_OK;
 }
 
+// ---- the weight stream packed on the device (sherf_amd/mlp_pack.py: stream_index) ----------------------------------------------------
+// slot i (2 bytes) of the stream = piece (src[i] & 1: 0 hi, 1 lo) of element flat[src[i] >> 1], zero where src[i] < 0; bias table likewise
+// in fp32.  flag |= 1: a packed value is not finite; |= 2: beyond the fp16 range in an fp16 mode (prec 1, 2) -- the caller raises.
+namespace {
+__global__ void __launch_bounds__(256) mlp_pack_stream_kernel(const float* __restrict__ flat, const int32_t* __restrict__ src, int64_t n16, int prec,
+                                                              uint16_t* __restrict__ out, const int32_t* __restrict__ bias_src, int n_bias,
+                                                              float* __restrict__ bias_out, int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int bad = 0;
+    if (i < n16) {
+        const int32_t sidx = src[i];
+        uint16_t bits = 0;
+        if (sidx >= 0) {
+            const float v = flat[sidx >> 1];
+            if (!(fabsf(v) <= 3.0e38f)) bad |= 1;
+            if (prec == 0) {
+                const uint32_t b = __float_as_uint(v);
+                bits = (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);               // round to nearest even (as torch / numpy)
+            } else {
+                if (fabsf(v) > 65504.0f) bad |= 2;
+                const _Float16 hi = (_Float16)v;
+                const _Float16 pc = (sidx & 1) ? (_Float16)(v - (float)hi) : hi;
+                bits = __builtin_bit_cast(uint16_t, pc);
+            }
+        }
+        out[i] = bits;
+    }
+    if (i < n_bias) {
+        const int32_t b = bias_src[i];
+        const float v = b >= 0 ? flat[b] : 0.f;
+        if (!(fabsf(v) <= 3.0e38f)) bad |= 1;
+        bias_out[i] = v;
+    }
+    if (bad) atomicOr(reinterpret_cast<unsigned*>(flag), (unsigned)bad);
+}
+}  // namespace
+
+extern "C" int sherf_mlp_pack_stream(const float* flat, const int32_t* src, int64_t n_slots, int prec, void* stream_out,
+                                     const int32_t* bias_src, int n_bias, float* bias_out, int32_t* flag, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(flat && src && stream_out && bias_src && bias_out && flag && n_slots > 0 && n_bias > 0 && n_bias <= n_slots);
+    SHERF_CHECK_ARG(prec >= 0 && prec <= 2);
+    SHERF_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int32_t), as_stream(stream)));
+    hipLaunchKernelGGL(mlp_pack_stream_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, as_stream(stream), flat, src, n_slots, prec,
+                       reinterpret_cast<uint16_t*>(stream_out), bias_src, n_bias, bias_out, flag);
+    SHERF_LAUNCH_CHECK();
+}
+
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);

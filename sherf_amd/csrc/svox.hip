@@ -223,7 +223,8 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, BnIn bin,
                                                      const int32_t* __restrict__ in_mult, const uint4* __restrict__ wpk, int mode,
-                                                     float* __restrict__ out_raw, long long* __restrict__ out_acc, int trace_id) {
+                                                     float* __restrict__ out_raw, long long* __restrict__ out_acc, int trace_id,
+                                                     const uint32_t* __restrict__ in_amax) {
     constexpr int COUT = 32 * NCOT, Cin = 16 * NKB;
 #if SHERF_SCONV_TRACE
     uint32_t stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -234,6 +235,14 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     if (!(mode & 256)) __builtin_amdgcn_s_setprio(3);
     const bool out_half = FOLD && (mode & 512);          // folded rows as fp16 (the gather's half-table mode, csrc/fold.hip)
     mode &= 255;
+    // in_amax (the input-gradient use, sherf_svox_conv3_dgrad): bits of max |in_raw|.  The fp16 operand split holds 22 bits of an O(1) value
+    // but gradients are O(1e-7): the rows are scaled by the power of two that brings their maximum into [0.5, 1) before the split (exact)
+    // and the result is scaled back (exact); elements below 6e-5 of the maximum keep an absolute error of 3e-8 of it -- fp32's own.
+    float in_scale = 1.f, out_scale = 1.f;
+    if (IN_BN == 0 && in_amax) {
+        const int be = (int)((*in_amax >> 23) & 0xffu);                 // biased exponent of the maximum
+        if (be >= 1 && be <= 252) { in_scale = __uint_as_float((uint32_t)(253 - be) << 23); out_scale = __uint_as_float((uint32_t)(be + 1) << 23); }
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_nb = reinterpret_cast<int*>(smem);                                   // [27][32]
     float* s_bn = reinterpret_cast<float*>(smem + 27 * 32 * 4);                 // [3][Cin]
@@ -258,8 +267,12 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
         for (int j = 0; j < NJ; ++j) {
             const int tap = (tid >> 5) + TG * j;
             const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
-            const int qz = mode ? 2 * z + kz - 1 : z + kz - 1, qy = mode ? 2 * y + ky - 1 : y + ky - 1, qx = mode ? 2 * x + kx - 1 : x + kx - 1;
-            const bool ok = live && !FOLD && tap < 27 && qz >= 0 && qz < Di && qy >= 0 && qy < Hi && qx >= 0 && qx < Wi;
+            // mode 0: same level, offset k - 1; mode 1: fine voxel 2 o + k - 1 under coarse output o; mode 3 (transpose of mode 1, the input
+            // gradient of a stride-2 layer): coarse voxel (q + k - 1) / 2 above fine output q where that is a whole, non-negative voxel
+            int qz = mode == 1 ? 2 * z + kz - 1 : z + kz - 1, qy = mode == 1 ? 2 * y + ky - 1 : y + ky - 1, qx = mode == 1 ? 2 * x + kx - 1 : x + kx - 1;
+            bool ok = live && !FOLD && tap < 27 && qz >= 0 && qy >= 0 && qx >= 0;
+            if (mode == 3) { ok = ok && !((qz | qy | qx) & 1); qz >>= 1; qy >>= 1; qx >>= 1; }
+            ok = ok && qz < Di && qy < Hi && qx < Wi;
             qk[j] = ok ? (qz * Hi + qy) * Wi + qx : -1;
         }
 #pragma unroll
@@ -367,6 +380,10 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sc[Cin + e], 0.f) + R.mlt * sc[2 * Cin + e];
             }
+            if constexpr (IN_BN == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= in_scale;
+            }
             if (R.nb < 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -453,6 +470,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
             if constexpr (NW == 8)
                 val += ((s_red[(4 * 32 + rr) * COUT + co] + s_red[(5 * 32 + rr) * COUT + co]) + s_red[(6 * 32 + rr) * COUT + co]) +
                        s_red[(7 * 32 + rr) * COUT + co];
+            val *= out_scale;
             if (row0 + rr < n_rows) {
                 if (out_half) reinterpret_cast<_Float16*>(out_raw)[(size_t)(row0 + rr) * COUT + co] = (_Float16)val;
                 else out_raw[(size_t)(row0 + rr) * COUT + co] = val;
@@ -613,12 +631,13 @@ extern "C" int sherf_svox_bn_running_update(int n_layers, const float* const* st
 static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int Do, int Ho, int Wo, const uint32_t* wp_in, int Di,
                         int Hi, int Wi, const float* in_raw, int Cin, BnIn bin, const int32_t* in_mult,
                         const void* w_packed, int Cout, int mode, int max_rows, float* out_raw, int64_t* out_acc,
-                        sherf_stream_t stream) {
+                        sherf_stream_t stream, const uint32_t* in_amax = nullptr) {
     const int out_half = (mode & 512) ? 512 : 0;
     const bool single = (mode & 1024) != 0;               // one fp16 product per term (see sconv3_kernel: SP)
     mode &= ~(512 | 1024);
     SHERF_CHECK_ARG(n_rows_out && in_raw && w_packed && out_raw && (mode == 2 || (keys_out && wp_in)));
-    SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 2);
+    SHERF_CHECK_ARG(Cin >= 16 && Cin <= 96 && Cin % 16 == 0 && (Cout == 32 || Cout == 64 || Cout == 96) && max_rows > 0 && mode >= 0 && mode <= 3);
+    SHERF_CHECK_ARG(!in_amax || !bin.bnparam);      // (the input scale applies to raw rows only)
     SHERF_CHECK_ARG(bin.acc == nullptr || (bin.n_total && bin.gamma && bin.beta && bin.stats && bin.bnparam));
     // four waves per workgroup.  Eight (sherf_set_debug bit 12; a wave then walks 3-4 taps instead of ~7 and eight partial tiles are summed
     // in LDS) was built and measured in round 3 and LOST: encoder_done 0.66 -> 0.755 ms, frame 1.29 -> 1.39 ms (profiles/
@@ -638,7 +657,8 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));       \
         hipLaunchKernelGGL((sconv3_kernel<N, K, F, B, S, W>), grid, block, smem, as_stream(stream), keys_out, n_rows_out, Do, Ho, Wo, \
                            reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                             \
-                           reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id); \
+                           reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id, \
+                           in_amax);                                                                                            \
     } while (0)
 #define SHERF_CONV3__(N, K, F, B, S) do { if (wide && !F) SHERF_CONV3___(N, K, F, B, S, 8); else SHERF_CONV3___(N, K, F, B, S, 4); } while (0)
 #define SHERF_CONV3_(N, K, F, B) do { if (single) SHERF_CONV3__(N, K, F, B, true); else SHERF_CONV3__(N, K, F, B, false); } while (0)
@@ -655,7 +675,12 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
         case 34: SHERF_CONV3(3, 4); break;     // 64 -> 96
         case 36: SHERF_CONV3(3, 6); break;     // 96 -> 96
         case 32: SHERF_CONV3(3, 2); break;     // 32 -> 96 (fold)
+        // the two transposed channel pairs only the input gradient of the stride-2 layers needs (sherf_svox_conv3_dgrad: raw rows, three
+        // products, four waves -- one instance each instead of the 24 of a forward pair)
+        case 14: if (fold || bnm || single) goto unsupported; SHERF_CONV3___(1, 4, false, 0, false, 4); break;     // 64 -> 32
+        case 26: if (fold || bnm || single) goto unsupported; SHERF_CONV3___(2, 6, false, 0, false, 4); break;     // 96 -> 64
         default:
+        unsupported:
             snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_svox_conv3: unsupported channel pair %d -> %d", Cin, Cout);
             return SHERF_EINVAL;
     }
@@ -673,6 +698,18 @@ extern "C" int sherf_svox_conv3(const int32_t* keys_out, const int32_t* n_rows_o
     BnIn bin{nullptr, nullptr, nullptr, nullptr, nullptr, const_cast<float*>(in_bn)};
     return launch_conv3(keys_out, n_rows_out, Do, Ho, Wo, wp_in, Di, Hi, Wi, in_raw, Cin, bin, in_mult, w_packed, Cout, mode,
                         max_rows, out_raw, out_acc, stream);
+}
+
+// Input gradient of a sparse convolution on the same MFMA kernel: d_in[i][ci] = sum_k sum_co d_raw[o(i, k)][co] W[co][k][ci] is a sparse
+// convolution of d_raw with the taps mirrored and the channel roles exchanged -- w_packed_t = pack_conv_weights of wt[k'][co][ci] =
+// W[co][26 - k'][ci] (sherf_amd/backward_dense.py) -- over the neighbour rule of the layer (mode 0) or its transpose (stride 2: mode 3).
+extern "C" int sherf_svox_conv3_dgrad(const int32_t* keys_i, const int32_t* n_rows_i, int Di, int Hi, int Wi, const uint32_t* wp_o, int Do,
+                                      int Ho, int Wo, const float* d_raw, int Cout, const uint32_t* d_raw_amax, const void* w_packed_t,
+                                      int Cin, int down, int max_rows, float* d_in, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d_raw_amax && (down == 0 || down == 1));
+    BnIn bin{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return launch_conv3(keys_i, n_rows_i, Di, Hi, Wi, wp_o, Do, Ho, Wo, d_raw, Cout, bin, nullptr, w_packed_t, Cin, down ? 3 : 0, max_rows,
+                        d_in, nullptr, stream, d_raw_amax);
 }
 
 static int scan_level(const sherf_svox_level_ws& l, sherf_stream_t stream) {

@@ -40,9 +40,10 @@ def nat_feature(kb, h, e):
     return 16 * kb + 8 * h + e
 
 
-def chunk_specs(sd, r='renderer.', d='decoder.'):
-    """sd: name -> numpy array (fp32).  Returns the 49 chunk specs, in kernel order."""
-    g = lambda n: np.asarray(sd[n], dtype=np.float32)
+def chunk_specs(sd, r='renderer.', d='decoder.', dtype=np.float32):
+    """sd: name -> numpy array.  Returns the 49 chunk specs, in kernel order (dtype int64: `sd` holds element INDICES, see
+    stream_index)."""
+    g = lambda n: np.asarray(sd[n], dtype=dtype)
     ident = list(range(32))
     specs = []
 
@@ -80,11 +81,11 @@ def chunk_nkb(spec):
     return sum(s[2] for s in spec['segs'])
 
 
-def chunk_image(spec):
-    """fp32 A-operand image [nkb][64 lanes][8]."""
+def chunk_image(spec, fill=0):
+    """A-operand image [nkb][64 lanes][8] in the dtype of the spec's matrix (fp32 values, or int64 indices with fill = -1)."""
     W = spec['W']
     nkb = chunk_nkb(spec)
-    img = np.zeros((nkb, 64, 8), np.float32)
+    img = np.full((nkb, 64, 8), fill, W.dtype)
     kb0 = 0
     for kind, base, n, real in spec['segs']:
         for kb in range(n):
@@ -101,9 +102,10 @@ def chunk_image(spec):
     return img
 
 
-def bias_table(vec, rows):
-    """[2][16] fp32 in accumulator (D) layout: reg r of half h <-> tile row (r&3) + 8*(r>>2) + 4*h."""
-    out = np.zeros((2, 16), np.float32)
+def bias_table(vec, rows, fill=0):
+    """[2][16] in accumulator (D) layout: reg r of half h <-> tile row (r&3) + 8*(r>>2) + 4*h (fp32 values, or int64 indices with
+    fill = -1)."""
+    out = np.full((2, 16), fill, np.float32 if vec is None else np.asarray(vec).dtype)
     if vec is None:
         return out
     for h in range(2):
@@ -188,6 +190,16 @@ def check_f16_range(sd, r='renderer.', d='decoder.', prec=1):
         raise ValueError(f'decoder weight norms allow activations up to ~{bound:.1e}: outside the fp16 range of mlp_precision f16x3 / f16; use bf16')
 
 
+def raise_for_flags(flag, bound, prec):
+    """The device pack's checks (sherf_mlp_pack_stream's flag word, the a-priori activation bound) -> check_f16_range's errors."""
+    if flag & 1:
+        raise ValueError('non-finite values in the transformer / decoder weights; the MLP weight stream cannot be packed')
+    if prec != 0 and (flag & 2):
+        raise ValueError('a transformer / decoder weight exceeds the fp16 range of mlp_precision f16x3 / f16; use bf16')
+    if prec != 0 and bound > 1e30:
+        raise ValueError(f'decoder weight norms allow activations up to ~{bound:.1e}: outside the fp16 range of mlp_precision f16x3 / f16; use bf16')
+
+
 def pack(sd, r='renderer.', d='decoder.', prec=1):
     """-> (stream uint8 [bytes], wbias float32 [(49+4)*32], nkb list) for the kernel's `prec` (1 = f16x3, 0 = bf16, 2 = f16)."""
     assert prec in (0, 1, 2)
@@ -228,3 +240,80 @@ def pack(sd, r='renderer.', d='decoder.', prec=1):
         bias.append(bias_table(np.asarray(sd[t + n], np.float32), list(range(32))))
     stream = np.frombuffer(b''.join(parts), dtype=np.uint8).copy()
     return stream, np.stack(bias).reshape(-1).astype(np.float32), nkbs
+
+
+# ---- the same stream, packed ON THE DEVICE -----------------------------------------------------------------------------------------
+# The stream is a pure gather of weight elements (plus rounding), so its layout can be computed once per architecture as an index map
+# and applied by a kernel (csrc/mlp.hip: sherf_mlp_pack_stream) every time the weights change: a training step repacks after every
+# optimiser update, and the Python loops of chunk_image above cost ~45 ms per call (round 2's training step: 48 ms of its 132 ms).
+_NORM_NAMES = ('0.fn.norm.weight', '0.fn.norm.bias', '1.fn.norm.weight', '1.fn.norm.bias')
+
+
+def packed_names(r='renderer.', d='decoder.'):
+    """Parameters the stream and the bias table read, in the order of the flat vector the device pack takes."""
+    t = r + 'transformer.layers.0.'
+    names = [r + 'conv1d_reprojection.weight', t + '0.fn.fn.to_qkv.weight', t + '0.fn.fn.to_out.0.weight', t + '0.fn.fn.to_out.0.bias',
+             t + '1.fn.fn.net.0.weight', t + '1.fn.fn.net.0.bias', t + '1.fn.fn.net.3.weight', t + '1.fn.fn.net.3.bias']
+    for L in range(8):
+        names += [f'{d}pts_linears.{L}.weight', f'{d}pts_linears.{L}.bias']
+    for n in ('feature_linear', 'alpha_linear', 'views_linear', 'rgb_linear'):
+        names += [d + n + '.weight', d + n + '.bias']
+    return names + [t + n for n in _NORM_NAMES]
+
+
+_index_cache = {}
+
+
+def stream_index(shapes, r='renderer.', d='decoder.', prec=1):
+    """shapes: name -> shape of every parameter of packed_names().  -> (src int32 [2-byte slots of the stream], bias_src int32
+    [(49+4)*32]): slot i of the stream holds piece (src[i] & 1) -- 0 = hi, 1 = lo -- of element src[i] >> 1 of the flat vector
+    (the parameters of packed_names() concatenated), or zero padding where src[i] < 0; bias_src likewise (fp32, no pieces).
+    Built by running the host packer above on element indices instead of values: one statement of the layout."""
+    names = packed_names(r, d)
+    key = (prec, r, d, tuple(tuple(shapes[n]) for n in names))
+    if key in _index_cache:
+        return _index_cache[key]
+    sd, off = {}, 0
+    for n in names:
+        k = int(np.prod(shapes[n]))
+        sd[n] = np.arange(off, off + k, dtype=np.int64).reshape(tuple(shapes[n]))
+        off += k
+    specs = chunk_specs(sd, r, d, dtype=np.int64)
+    imgs = [chunk_image(sp, fill=-1) for sp in specs]                 # [nkb][64][8] element indices
+    npc = N_PIECE[prec]
+    pad = np.full(512, -1, np.int64)
+    parts = []
+    for s_ in range(N_STEPS):
+        n = 0
+        for u in range(step_units(s_)):
+            cu = step_unit(s_, u)
+            for q in range(npc):
+                if cu is None:
+                    parts.append(pad)
+                else:
+                    e = imgs[cu[0]][cu[1]].reshape(-1)
+                    parts.append(np.where(e >= 0, 2 * e + q, -1))
+            n += npc
+        parts += [pad] * (step_pieces(s_, prec) - n)
+    src = np.concatenate(parts).astype(np.int32)
+    bias = [bias_table(sp['bias'], sp['rows'], fill=-1).astype(np.int64) if sp['bias'] is not None else np.full((2, 16), -1, np.int64)
+            for sp in specs]
+    t = r + 'transformer.layers.0.'
+    bias += [bias_table(sd[t + n], list(range(32)), fill=-1) for n in _NORM_NAMES]
+    out = (src, np.stack(bias).reshape(-1).astype(np.int32), off)
+    _index_cache[key] = out
+    return out
+
+
+def pack_from_index(flat, src, bias_src, prec):
+    """The index map applied on the host (numpy): what sherf_mlp_pack_stream computes on the device.  tests: == pack()."""
+    flat = np.asarray(flat, np.float32)
+    v = np.where(src >= 0, flat[np.maximum(src, 0) >> 1], np.float32(0)).astype(np.float32)
+    if prec == 0:
+        bits = _bf16_bits(v)
+    else:
+        hi = v.astype(np.float16)
+        bits = np.where((src & 1) == 1, (v - hi.astype(np.float32)).astype(np.float16).view(np.uint16), hi.view(np.uint16))
+        bits = np.where(src >= 0, bits, 0).astype(np.uint16)
+    wb = np.where(bias_src >= 0, flat[np.maximum(bias_src, 0)], np.float32(0)).astype(np.float32)
+    return bits.view(np.uint8), wb

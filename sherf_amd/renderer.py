@@ -396,18 +396,50 @@ class ImportanceRenderer(nn.Module):
                 fold.append(pack_conv_weights(F.t().contiguous()[None]).to(device))   # [C_l, 96] as a 1-tap conv
             tok_bias = torch.cat([br + Wc @ bp[32 * s:32 * s + 32] for s in range(3)]).contiguous().to(device)
             wc = self._wcache = dict(key=key, Wa_t=Wa.t().contiguous().to(device), Wb_t=Wb.t().contiguous().to(device), fold=fold,
-                                     tok_bias=tok_bias, streams={}, auto=None, sd=None)
+                                     tok_bias=tok_bias, streams={}, auto=None, flat=None)
         if prec not in wc['streams']:
-            if wc['sd'] is None:
-                sd = {'renderer.' + k: v.detach().float().cpu().numpy() for k, v in self.state_dict().items()
-                      if not k.startswith('encoder_3d.')}
-                sd.update({'decoder.' + k: v.detach().float().cpu().numpy() for k, v in decoder.state_dict().items()})
-                wc['sd'] = sd
-            stream, wbias, _ = mlp_pack.pack(wc['sd'], prec=prec)
-            wc['streams'][prec] = (torch.from_numpy(stream).to(device), torch.from_numpy(wbias).to(device))
+            wc['streams'][prec] = self._pack_stream(decoder, device, prec, wc)
         out = dict(wc)
         out['stream'], out['wbias'] = wc['streams'][prec]
         return out
+
+    def _pack_stream(self, decoder, device, prec, wc):
+        """The MLP's fragment stream + bias table for `prec`, packed ON THE DEVICE from the live parameters (sherf_mlp_pack_stream applying
+        mlp_pack.stream_index's element map: bit-identical to the host packer mlp_pack.pack, tests/test_mlp_pack.py, at ~0.1 ms
+        instead of ~45 ms -- a training step repacks after every optimiser update).  The fp16 range checks of the host packer
+        (mlp_pack.check_f16_range) are made on the device and read back once per repack: same ValueError."""
+        named = {'renderer.' + k: v for k, v in self.named_parameters() if not k.startswith('encoder_3d.')}
+        named.update({'decoder.' + k: v for k, v in decoder.named_parameters()})
+        names = mlp_pack.packed_names()
+        if wc.get('flat') is None:
+            wc['flat'] = torch.cat([named[n].detach().to(device=device, dtype=torch.float32).reshape(-1) for n in names])
+        flat = wc['flat']
+        ikey = (prec, str(device))
+        cache = self.__dict__.setdefault('_pack_index', {})          # (plain attribute: not a parameter / buffer / submodule)
+        idx = cache.get(ikey)
+        if idx is None:
+            src, bsrc, n_flat = mlp_pack.stream_index({n: tuple(named[n].shape) for n in names}, prec=prec)
+            idx = cache[ikey] = (torch.from_numpy(src).to(device), torch.from_numpy(bsrc).to(device), n_flat)
+        src, bsrc, n_flat = idx
+        if flat.numel() != n_flat:
+            raise RuntimeError('sherf_amd: parameter shapes changed under a cached stream index')
+        stream = torch.empty(2 * src.numel(), dtype=torch.uint8, device=device)
+        wbias = torch.empty(bsrc.numel(), dtype=torch.float32, device=device)
+        flag = torch.empty(1, dtype=torch.int32, device=device)
+        P = _lib.ptr
+        _lib.call('sherf_mlp_pack_stream', P(flat), P(src), src.numel(), prec, P(stream), P(bsrc), bsrc.numel(), P(wbias), P(flag), _lib.stream())
+        checks = [flag.to(torch.float32)]
+        if prec != 0 and not torch.is_grad_enabled():
+            # a-priori bound of the activations (mlp_pack.check_f16_range): product of the layers' row norms.  Skipped while training
+            # (weights move a little per step from a checked start; the kernel's own non-finite flag, check_finite(), stays armed)
+            bound = torch.full((), 64.0, dtype=torch.float64, device=device)
+            for lname in [f'decoder.pts_linears.{i}' for i in range(8)] + ['decoder.feature_linear', 'decoder.views_linear']:
+                W, b = named[lname + '.weight'].detach().double(), named[lname + '.bias'].detach().double()
+                bound = bound * W.abs().sum(1).max() + b.abs().max()
+            checks.append(bound.clamp(max=1e38).to(torch.float32).reshape(1))
+        vals = torch.cat(checks).tolist()
+        mlp_pack.raise_for_flags(int(vals[0]), vals[1] if len(vals) > 1 else 0.0, prec)
+        return stream, wbias
 
     # ---- precision configuration ----------------------------------------------------------------
     # A frame's configuration = (MLP operand precision, format of the folded tables the gather taps, operand precision of the sparse

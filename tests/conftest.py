@@ -16,3 +16,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _poison_uninitialised_backward_buffers(monkeypatch):
+    """The backward allocates the buffers a kernel overwrites completely with torch.empty (sherf_amd/backward_dense.py: Mat.empty).
+    Under test they are filled with NaN, so a kernel that leaves part of one unwritten shows up in every gradient check."""
+    import torch
+    from sherf_amd import backward_dense
+
+    def poisoned(rows, cols, device):
+        return backward_dense.Mat(torch.full((int(rows) * int(cols),), float('nan'), dtype=torch.float32, device=device), rows, cols)
+    monkeypatch.setattr(backward_dense.Mat, 'empty', staticmethod(poisoned))

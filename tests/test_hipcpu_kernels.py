@@ -202,8 +202,53 @@ def test_sparse_conv_gradient_kernels_on_cpu(cpu_lib, monkeypatch, mode):
         _same(dW_c, dW_g, 1e-4)
     di_c, di_g = Mat(torch.zeros(fine_e['cap'] * Cin), fine_e['cap'], Cin), Mat(torch.zeros(fine_e['cap'] * Cin), fine_e['cap'], Cin)
     e.conv_dgrad(fine_e, out_e, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_c)
-    h.conv_dgrad(fine_k, out_k, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_g)
+    h.conv_dgrad_valu(fine_k, out_k, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_g)
     _same(di_c, di_g, 1e-4)
+
+
+@pytest.fixture(scope='module')
+def svox_lib(tmp_path_factory):
+    if not os.path.exists(build_cpu.CLANG):
+        pytest.skip('needs the ROCm clang for the host build of the MFMA kernels')
+    path = build_cpu.build('sherf_hipcpu_svox', ['svox.hip'], str(tmp_path_factory.mktemp('hipcpu_svox')),
+                           extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
+    lib = ctypes.CDLL(path)
+    protos = _lib.parse_header()
+    for fn in ('sherf_svox_conv3_dgrad',):
+        getattr(lib, fn).restype, getattr(lib, fn).argtypes = protos[fn][0], [a[0] for a in protos[fn][1]]
+    return lib
+
+
+@pytest.mark.parametrize('mode,Cin,Cout', [(0, 32, 32), (1, 32, 32), (1, 32, 64), (0, 64, 64), (1, 64, 96), (0, 96, 96)])
+def test_mfma_input_gradient_convolution_on_cpu(cpu_lib, svox_lib, monkeypatch, mode, Cin, Cout):
+    """HipOps.conv_dgrad as the training step runs it -- the forward's MFMA sparse-convolution kernel with mirrored taps, exchanged channel
+    roles, and the rows scaled into the fp16 split's range by the maximum sherf_bwd_bn_relu left behind -- against the specification
+    (tests/bwd_emulator.py) for every layer shape of the encoder, on gradient-sized values (1e-7: unscaled, the split underflows)."""
+    from tests.bwd_emulator import make_level
+    e, h = EmuOps(), CpuKernelOps(cpu_lib, monkeypatch)
+
+    def call(name, *a):
+        rc = getattr(svox_lib, name)(*a)
+        assert rc == 0, name
+    monkeypatch.setattr(_lib, 'call', call)
+    g = torch.Generator().manual_seed(3 + Cin + Cout)
+    fine_e, fine_k = make_level(torch.unique(torch.randint(0, 8 * 10 * 12, (260,), generator=g)), (8, 10, 12))
+    out_e, out_k = (fine_e, fine_k) if mode == 0 else make_level(torch.unique(torch.randint(0, 4 * 5 * 6, (70,), generator=g)), (4, 5, 6))
+    d_raw = torch.randn(out_e['cap'] * Cout, generator=g) * 1e-7
+    d_raw[::7] *= 1e-4                                             # elements far below the maximum
+    W = torch.randn(Cout * 27 * Cin, generator=g) * 0.1
+    di_c, di_g = Mat(torch.zeros(fine_e['cap'] * Cin), fine_e['cap'], Cin), Mat(torch.full((fine_e['cap'] * Cin,), float('nan')), fine_e['cap'], Cin)
+    e.conv_dgrad(fine_e, out_e, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_c)
+    dm = Mat(d_raw.clone(), out_e['cap'], Cout)
+    n_o = int(out_e['n_rows'])
+    dm.amax = Mat(d_raw.view(-1, Cout)[:n_o].abs().max().reshape(1).clone(), 1, 1)             # (as sherf_bwd_bn_relu leaves it: bits of max |d_raw|)
+    h.conv_dgrad(fine_k, out_k, dm, Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_g)
+    n_i = int(fine_e['n_rows'])
+    a, b = di_c.tensor()[:n_i].double(), di_g.tensor()[:n_i].double()
+    assert torch.isfinite(b).all()
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    with pytest.raises(RuntimeError):
+        h.conv_dgrad(fine_k, out_k, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_g)   # no amax
 
 
 def test_batchnorm_backward_and_row_kernels_on_cpu(cpu_lib, monkeypatch):
@@ -231,6 +276,7 @@ def test_batchnorm_backward_and_row_kernels_on_cpu(cpu_lib, monkeypatch):
                       mult.to(torch.int32) if use_mult else None, torch.tensor([N], dtype=torch.int32), lev_k['n_rows'], *og)
         for a, b in zip(oc, og):
             _same(a, b, 1e-4)
+        assert float(og[0].amax.tensor().view(-1)[0]) == float(og[0].tensor()[:n].abs().max())      # the scale of the MFMA input gradient
     a_c, a_g = Mat(torch.zeros(cap * C), cap, C), Mat(torch.zeros(cap * C), cap, C)
     e.bn_relu_apply(Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), torch.tensor(n), a_c)
     h.bn_relu_apply(Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), lev_k['n_rows'], a_g)
@@ -457,8 +503,38 @@ def mlp_lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    lib.sherf_nerf_mlp.restype, lib.sherf_nerf_mlp.argtypes = protos['sherf_nerf_mlp'][0], [a[0] for a in protos['sherf_nerf_mlp'][1]]
+    for fn in ('sherf_nerf_mlp', 'sherf_mlp_pack_stream'):
+        getattr(lib, fn).restype, getattr(lib, fn).argtypes = protos[fn][0], [a[0] for a in protos[fn][1]]
     return lib
+
+
+@pytest.mark.parametrize('prec', [0, 1, 2])
+def test_device_pack_kernel_source_on_cpu(mlp_lib, frame, prec):
+    """sherf_mlp_pack_stream (the weight stream packed by a kernel from the live parameters: what a training step does after every
+    optimiser update) == the host packer mlp_pack.pack, bit for bit; its flag word reports non-finite / out-of-fp16-range weights."""
+    from sherf_amd import mlp_pack
+    fx, state, r, g = frame
+    sd = {k: v.numpy() for k, v in state.items() if not k.startswith('renderer.encoder_3d.')}
+    stream, wbias, _ = mlp_pack.pack(sd, prec=prec)
+    names = mlp_pack.packed_names()
+    src, bsrc, n_flat = mlp_pack.stream_index({n: sd[n].shape for n in names}, prec=prec)
+    flat = torch.cat([state[n].float().reshape(-1) for n in names]).contiguous()
+    src_t, bsrc_t = torch.from_numpy(src), torch.from_numpy(bsrc)
+
+    def run(flat):
+        out, wb, flag = torch.zeros(2 * src.size, dtype=torch.uint8), torch.zeros(bsrc.size), torch.full((1,), 7, dtype=torch.int32)
+        assert mlp_lib.sherf_mlp_pack_stream(_P(flat), _P(src_t), src.size, prec, _P(out), _P(bsrc_t), bsrc.size, _P(wb), _P(flag), None) == 0
+        return out.numpy(), wb.numpy(), int(flag)
+    out, wb, flag = run(flat)
+    assert flag == 0 and np.array_equal(out, stream) and np.array_equal(wb, wbias)
+    big = flat.clone(); big[int(src[src >= 0][0]) >> 1] = 1e5
+    assert run(big)[2] == (0 if prec == 0 else 2)
+    nan = flat.clone(); nan[int(src[src >= 0][5]) >> 1] = float('nan')
+    assert run(nan)[2] & 1
+    with pytest.raises(ValueError):
+        mlp_pack.raise_for_flags(2, 0.0, 1)
+    mlp_pack.raise_for_flags(2, 0.0, 0)
+    assert mlp_lib.sherf_mlp_pack_stream(_P(flat), _P(src_t), src.size, 3, _P(torch.zeros(4)), _P(bsrc_t), bsrc.size, _P(torch.zeros(4)), _P(torch.zeros(1, dtype=torch.int32)), None) != 0
 
 
 @pytest.mark.parametrize('prec,tol_sig,tol_rgb', [(1, 2e-5, 2e-5), (0, 5e-2, 5e-2), (2, 6e-3, 6e-3)])

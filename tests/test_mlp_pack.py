@@ -155,6 +155,21 @@ def test_stream_layout(packed):
     assert nkbs[:9] == [2, 2, 2, 2, 2, 2, 3, 2, 2] and nkbs[9] == 5 and nkbs[29] == 13 and nkbs[46] == 12 and nkbs[48] == 4
 
 
+@pytest.mark.parametrize('prec', [0, 1, 2])
+def test_index_map_reproduces_the_host_packer(packed, prec):
+    """mlp_pack.stream_index (the layout as an element-index map, applied by sherf_mlp_pack_stream on the device) == pack()."""
+    sd, _ = packed
+    stream, wbias, _ = mlp_pack.pack(sd, prec=prec)
+    names = mlp_pack.packed_names()
+    src, bsrc, n_flat = mlp_pack.stream_index({n: sd[n].shape for n in names}, prec=prec)
+    flat = np.concatenate([np.asarray(sd[n], np.float32).reshape(-1) for n in names])
+    assert flat.size == n_flat and src.size * 2 == stream.nbytes and bsrc.size == wbias.size
+    s2, wb2 = mlp_pack.pack_from_index(flat, src, bsrc, prec)
+    assert np.array_equal(s2, stream) and np.array_equal(wb2, wbias)
+    used = np.unique(src[src >= 0] >> 1)
+    assert used.size > 0.95 * (n_flat - 4 * 32 - sum(sd[n].size for n in names if n.endswith('.bias')))   # (weights: all but a few unused columns)
+
+
 def test_stream_reproduces_oracle_network(packed):
     sd, (stream, wbias, nkbs) = packed
     state = {k: torch.from_numpy(v) for k, v in sd.items()}
