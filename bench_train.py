@@ -77,7 +77,7 @@ def main():
     scatter_ev, call0 = [], _lib.call
 
     def timed_call(name, *args):
-        if name != 'sherf_gather_tokens_bwd':
+        if name != 'sherf_gather_tokens_bwd_binned':
             return call0(name, *args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); call0(name, *args); e1.record()

@@ -153,6 +153,16 @@ int sherf_gather_tokens_bwd(const int32_t* counters, const float* geom, const fl
                             int H, int W, const sherf_vox_level* levels_host, const float* bounds, const float* vox_min,
                             const int32_t* vox_sh_host, int64_t capacity, float* d_planes_f, float* d_feat_f,
                             float* d_rows0, float* d_rows1, float* d_rows2, float* d_tok_bias, sherf_stream_t stream);
+/* The same scatter with the samples binned by the coarsest tapped voxel cell they fall in and accumulated per bin in LDS windows (the
+ * three voxel levels and the tri-planes; the pixel-aligned taps stay direct): one device atomic per touched address per bin instead of
+ * one per sample and tap (csrc/gather.hip).  Same contract and outputs (sums differ in the last ulp, as between any two runs of the
+ * direct form); `scratch`: int32 words, at least what sherf_gather_bwd_scratch_words reports for (levels, capacity); not zeroed by the caller. */
+int sherf_gather_tokens_bwd_binned(const int32_t* counters, const float* geom, const float* d_tokens, int P, int Hf, int Wf,
+                                   int H, int W, const sherf_vox_level* levels_host, const float* bounds, const float* vox_min,
+                                   const int32_t* vox_sh_host, int64_t capacity, float* d_planes_f, float* d_feat_f,
+                                   float* d_rows0, float* d_rows1, float* d_rows2, float* d_tok_bias, int32_t* scratch,
+                                   int64_t scratch_words, sherf_stream_t stream);
+int sherf_gather_bwd_scratch_words(const sherf_vox_level* levels_host, int64_t capacity, int64_t* words_host);
 
 int sherf_fold_tables(const float* in, const float* Wt, float* out, int HW, int groups, int pix_stride,
                       int64_t group_base, int out_half, sherf_stream_t stream);

@@ -496,6 +496,287 @@ __global__ void __launch_bounds__(256) gather_tokens_bwd_kernel(const int32_t* _
     for (int i = threadIdx.x; i < 96; i += 256) unsafeAtomicAdd(d_tok_bias + i, (&s_bias[0][0])[i]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same scatter with the samples BINNED by the coarsest tapped voxel cell they fall in (4 cm), one workgroup per bin accumulating in
+// LDS and flushing once.  The direct form above issues ~2900 device-scope fp32 atomics per sample, 78 % of them into the voxel rows --
+// ~1.6 G atomics onto ~1 M addresses, chains of hundreds to thousands of same-address updates: 20.3 ms of round 2's 87 ms of kernels
+// per step (profiles/r02_train_step_final_rocprofv3_stats.txt).  All samples of a bin share their 8 corners at the coarsest level, touch
+// at most a 5^3 block of the middle level and (almost always) a 6^3 block of the finest, and a 6 x 6 texel window of each plane: those
+// windows (147 KiB of the CU's 160 KiB LDS) take the samples' updates as LDS atomics and reach memory as ONE atomic per touched
+// address per bin.  A corner outside a window (a bin whose samples straddle one more voxel than the window holds) takes the direct
+// path, as do the pixel-aligned taps (their window depends on the camera, not on the cell).  Sums are order dependent in the last
+// ulp exactly as before.  Four launches: count (+ list of non-empty bins), scan, fill, scatter.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBinNT = 512;                       // threads of the scatter workgroup
+constexpr int kW0 = 6, kW1 = 5, kWP = 6;          // window edge: finest / middle tapped level, plane texels
+constexpr int kR0 = kW0 * kW0 * kW0, kR1 = kW1 * kW1 * kW1, kR2 = 8, kRV = kR0 + kR1 + kR2, kRP = 3 * kWP * kWP;
+constexpr size_t kBinSmem = (size_t)(kRV * 96 + kRP * 32) * 4 + (size_t)(kRV + 16) * 4;
+
+struct VoxTap { int xi, yi, zi; float fx, fy, fz; };
+
+__device__ __forceinline__ void vox_grid_coords(const float* __restrict__ gm, const float* __restrict__ vox_min, int3 vox_sh, float& gx, float& gy, float& gz) {
+    gz = ((gm[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;
+    gy = ((gm[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
+    gx = ((gm[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
+}
+
+__device__ __forceinline__ VoxTap vox_tap(const sherf_vox_level& lev, float gx, float gy, float gz) {     // (the forward's stencil, align_corners=True)
+    const float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
+    const float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
+    const float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
+    const float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+    return VoxTap{(int)x0, (int)y0, (int)z0, px - x0, py - y0, pz - z0};
+}
+
+struct PlaneTap { int xi, yi; float fx, fy; };
+__device__ __forceinline__ PlaneTap plane_tap(int p, const float* n, int P) {                            // (align_corners=False)
+    const float ga = p == 2 ? n[2] : n[0], gb = p == 1 ? n[2] : n[1];
+    const float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+    const float py = clampf(((gb + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+    const float x0 = floorf(px), y0 = floorf(py);
+    return PlaneTap{(int)x0, (int)y0, px - x0, py - y0};
+}
+
+// bin of a sample: its base corner at the coarsest tapped level, each component in [-2, dim + 1] after the stencil's clamp
+__device__ __forceinline__ int bin_of(const sherf_vox_level& lev, const VoxTap& t) {
+    return ((t.zi + 2) * (lev.H + 4) + (t.yi + 2)) * (lev.W + 4) + (t.xi + 2);
+}
+
+// scratch words: [0] number of non-empty bins, [4 ..) counts[n_bins], cursor[n_bins], offsets[n_bins], nonempty[n_bins], bin[cap], sorted[cap]
+struct BinWs { int32_t *n_nonempty, *counts, *cursor, *offsets, *nonempty, *bin, *sorted; int n_bins; };
+__host__ __device__ inline BinWs bin_ws(int32_t* scratch, int n_bins, int64_t cap) {
+    BinWs w;
+    w.n_nonempty = scratch; w.counts = scratch + 4; w.cursor = w.counts + n_bins; w.offsets = w.cursor + n_bins; w.nonempty = w.offsets + n_bins;
+    w.bin = w.nonempty + n_bins; w.sorted = w.bin + cap; w.n_bins = n_bins;
+    return w;
+}
+
+__global__ void __launch_bounds__(256) bin_count_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom, sherf_vox_level lev2,
+                                                        const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity, BinWs w) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nv) return;
+    float gx, gy, gz;
+    vox_grid_coords(geom + c * 8, vox_min, vox_sh, gx, gy, gz);
+    const int b = bin_of(lev2, vox_tap(lev2, gx, gy, gz));
+    w.bin[c] = b;
+    if (atomicAdd(w.counts + b, 1) == 0) w.nonempty[atomicAdd(w.n_nonempty, 1)] = b;       // first sample of the bin lists it
+}
+
+// exclusive scan of counts -> offsets by ONE workgroup (tens of thousands of bins: a chunk per thread, the chunk totals scanned in LDS)
+__global__ void __launch_bounds__(1024) bin_scan_kernel(BinWs w) {
+    __shared__ int s_tot[1024];
+    const int per = (w.n_bins + 1023) / 1024;
+    const int b0 = min((int)threadIdx.x * per, w.n_bins), b1 = min(b0 + per, w.n_bins);
+    int t = 0;
+    for (int b = b0; b < b1; ++b) t += w.counts[b];
+    s_tot[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan of the chunk totals
+        const int v = threadIdx.x >= (unsigned)o ? s_tot[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_tot[threadIdx.x] - t;
+    for (int b = b0; b < b1; ++b) { w.offsets[b] = run; run += w.counts[b]; }
+}
+
+__global__ void __launch_bounds__(256) bin_fill_kernel(const int32_t* __restrict__ counters, int64_t capacity, BinWs w) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nv) return;
+    const int b = w.bin[c];
+    w.sorted[w.offsets[b] + atomicAdd(w.cursor + b, 1)] = (int32_t)c;
+}
+
+__device__ __forceinline__ void lds_add4(float* dst, float wgt, const float4 d) {
+    atomicAdd(dst + 0, wgt * d.x); atomicAdd(dst + 1, wgt * d.y); atomicAdd(dst + 2, wgt * d.z); atomicAdd(dst + 3, wgt * d.w);
+}
+
+__global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const float* __restrict__ geom, const float4* __restrict__ d_tokens, int P, int Hf,
+                                                                          int Wf, int H, int W, LevelsBwd lv, const float* __restrict__ bounds,
+                                                                          const float* __restrict__ vox_min, int3 vox_sh, BinWs w,
+                                                                          float4* __restrict__ d_planes_f, float4* __restrict__ d_feat_f,
+                                                                          float* __restrict__ d_tok_bias, int dbg) {
+    // (sherf_set_debug bit 13: windows of ONE voxel / texel below the coarsest level -- nearly every corner takes the spill path; tests)
+    const int lim0 = (dbg & 8192) ? 1 : kW0, lim1 = (dbg & 8192) ? 1 : kW1, limp = (dbg & 8192) ? 1 : kWP;
+    extern __shared__ __attribute__((aligned(16))) float bsm[];
+    float* acc_v = bsm;                                     // [kRV][96]: level 0 window, level 1 window, level 2 corners
+    float* acc_p = bsm + kRV * 96;                          // [3][kWP][kWP][32]
+    int* s_row = reinterpret_cast<int*>(acc_p + kRP * 32);  // [kRV] row of every window voxel (-1: none)
+    int* s_org = s_row + kRV;                               // [12]: origin (x, y, z) of the level 0 / level 1 windows, (x, y) of the three plane windows
+    __shared__ float s_bias[3][32];
+    const int tid = threadIdx.x, l = tid & 7, sub = tid >> 3;
+    const int n_list = *w.n_nonempty;
+    float4 bsum[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int bi = blockIdx.x; bi < n_list; bi += gridDim.x) {
+        const int b = w.nonempty[bi], cnt = w.counts[b], start = w.offsets[b];
+        const sherf_vox_level& L2 = lv.l[2];
+        const int c2x = b % (L2.W + 4) - 2, c2y = (b / (L2.W + 4)) % (L2.H + 4) - 2, c2z = b / ((L2.W + 4) * (L2.H + 4)) - 2;
+        for (int i = tid; i < kRV * 96 + kRP * 32; i += kBinNT) bsm[i] = 0.f;
+        if (tid < 12) s_org[tid] = 0x7fffffff;
+        __syncthreads();
+        // ---- pass A: window origins = the smallest base corner among the bin's samples ----
+        for (int i = tid; i < cnt; i += kBinNT) {
+            const float* gm = geom + (int64_t)w.sorted[start + i] * 8;
+            float gx, gy, gz;
+            vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
+#pragma unroll
+            for (int L = 0; L < 2; ++L) {
+                const VoxTap t = vox_tap(lv.l[L], gx, gy, gz);
+                atomicMin(s_org + 3 * L + 0, t.xi); atomicMin(s_org + 3 * L + 1, t.yi); atomicMin(s_org + 3 * L + 2, t.zi);
+            }
+            float n[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const PlaneTap t = plane_tap(p, n, P);
+                atomicMin(s_org + 6 + 2 * p, t.xi); atomicMin(s_org + 7 + 2 * p, t.yi);
+            }
+        }
+        __syncthreads();
+        // ---- pass B: eight lanes per sample (lane l: channel quad l of each slot), kBinNT / 8 samples at a time ----
+        for (int i0 = 0; i0 < cnt; i0 += kBinNT / 8) {
+            const int i = i0 + sub;
+            if (i >= cnt) continue;
+            const int64_t c = w.sorted[start + i];
+            const int64_t tile = c >> 5;
+            const int j = (int)(c & 31);
+            float4 d[3];
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                d[s_] = d_tokens[((tile * 3 + s_) * 8 + l) * 32 + j];
+                bsum[s_].x += d[s_].x; bsum[s_].y += d[s_].y; bsum[s_].z += d[s_].z; bsum[s_].w += d[s_].w;
+            }
+            const float* gm = geom + c * 8;
+            // tri-planes: slot p <- plane p
+            float n[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const PlaneTap t = plane_tap(p, n, P);
+                const int ox = s_org[6 + 2 * p], oy = s_org[7 + 2 * p];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int xx = t.xi + dx, yy = t.yi + dy;
+                        if (!(xx >= 0 && xx < P && yy >= 0 && yy < P)) continue;
+                        const float wgt = (dx ? t.fx : 1.f - t.fx) * (dy ? t.fy : 1.f - t.fy);
+                        const int lx = xx - ox, ly = yy - oy;
+                        if (lx < limp && ly < limp) lds_add4(acc_p + ((p * kWP + ly) * kWP + lx) * 32 + 4 * l, wgt, d[p]);
+                        else scatter4(d_planes_f + ((size_t)(p * P + yy) * P + xx) * 8 + l, wgt, d[p]);
+                    }
+            }
+            // pixel-aligned feature map: direct (slots 0, 1)
+            {
+                const float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
+                const float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
+                const float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
+                const float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                const int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
+                            const float wgt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            float4* t = d_feat_f + ((size_t)yy * Wf + xx) * 16;
+                            scatter4(t + l, wgt, d[0]);
+                            scatter4(t + 8 + l, wgt, d[1]);
+                        }
+                    }
+            }
+            // voxel levels: all three slots
+            float gx, gy, gz;
+            vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
+#pragma unroll 1
+            for (int L = 0; L < 3; ++L) {
+                const sherf_vox_level& lev = lv.l[L];
+                const VoxTap t = vox_tap(lev, gx, gy, gz);
+                const int ox = L == 2 ? c2x : s_org[3 * L], oy = L == 2 ? c2y : s_org[3 * L + 1], oz = L == 2 ? c2z : s_org[3 * L + 2];
+                const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), rb = L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1);
+                const int lim = L == 0 ? lim0 : (L == 1 ? lim1 : 2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int xx = t.xi + (k & 1), yy = t.yi + ((k >> 1) & 1), zz = t.zi + (k >> 2);
+                    if (!(xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D)) continue;
+                    const float wgt = ((k & 1) ? t.fx : 1.f - t.fx) * (((k >> 1) & 1) ? t.fy : 1.f - t.fy) * ((k >> 2) ? t.fz : 1.f - t.fz);
+                    const int lx = xx - ox, ly = yy - oy, lz = zz - oz;
+                    if (lx < lim && ly < lim && lz < lim) {
+                        float* a = acc_v + (size_t)(rb + (lz * wd + ly) * wd + lx) * 96 + 4 * l;
+                        lds_add4(a, wgt, d[0]); lds_add4(a + 32, wgt, d[1]); lds_add4(a + 64, wgt, d[2]);
+                    } else {                                 // beyond the window: the direct path
+                        const int key = (zz * lev.H + yy) * lev.W + xx;
+                        const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                        const uint32_t bit = 1u << (key & 31);
+                        if (!(rr.x & bit)) continue;
+                        float4* rp = reinterpret_cast<float4*>(lv.d_rows[L]) + (size_t)(rr.y + __popc(rr.x & (bit - 1u))) * 24;
+                        scatter4(rp + l, wgt, d[0]); scatter4(rp + 8 + l, wgt, d[1]); scatter4(rp + 16 + l, wgt, d[2]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- flush: the row of every window voxel, then one atomic per touched address ----
+        for (int v = tid; v < kRV; v += kBinNT) {
+            const int L = v < kR0 ? 0 : (v < kR0 + kR1 ? 1 : 2);
+            const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), q = v - (L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1));
+            const sherf_vox_level& lev = lv.l[L];
+            const int ox = L == 2 ? c2x : s_org[3 * L], oy = L == 2 ? c2y : s_org[3 * L + 1], oz = L == 2 ? c2z : s_org[3 * L + 2];
+            const int xx = ox + q % wd, yy = oy + (q / wd) % wd, zz = oz + q / (wd * wd);
+            int row = -1;
+            if (ox != 0x7fffffff && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
+                const int key = (zz * lev.H + yy) * lev.W + xx;
+                const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                const uint32_t bit = 1u << (key & 31);
+                if (rr.x & bit) row = (int)rr.y + __popc(rr.x & (bit - 1u));
+            }
+            s_row[v] = row;
+        }
+        __syncthreads();
+        for (int i = tid; i < kRV * 24; i += kBinNT) {
+            const int v = i / 24, q = i % 24, row = s_row[v];
+            if (row < 0) continue;
+            const int L = v < kR0 ? 0 : (v < kR0 + kR1 ? 1 : 2);
+            const float4 val = *reinterpret_cast<const float4*>(acc_v + (size_t)v * 96 + 4 * q);
+            float* dst = lv.d_rows[L] + (size_t)row * 96 + 4 * q;
+            if (val.x != 0.f) unsafeAtomicAdd(dst + 0, val.x);
+            if (val.y != 0.f) unsafeAtomicAdd(dst + 1, val.y);
+            if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
+            if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
+        }
+        for (int i = tid; i < kRP * 8; i += kBinNT) {
+            const int t = i / 8, q = i % 8, p = t / (kWP * kWP), ly = (t / kWP) % kWP, lx = t % kWP;
+            if (s_org[6 + 2 * p] == 0x7fffffff) continue;
+            const int xx = s_org[6 + 2 * p] + lx, yy = s_org[7 + 2 * p] + ly;
+            if (!(xx >= 0 && xx < P && yy >= 0 && yy < P)) continue;
+            const float4 val = *reinterpret_cast<const float4*>(acc_p + (size_t)t * 32 + 4 * q);
+            float* dst = reinterpret_cast<float*>(d_planes_f + ((size_t)(p * P + yy) * P + xx) * 8 + q);
+            if (val.x != 0.f) unsafeAtomicAdd(dst + 0, val.x);
+            if (val.y != 0.f) unsafeAtomicAdd(dst + 1, val.y);
+            if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
+            if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
+        }
+        __syncthreads();
+    }
+    // d_tok_bias
+    for (int i = tid; i < 96; i += kBinNT) (&s_bias[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+        atomicAdd(&s_bias[s_][4 * l + 0], bsum[s_].x); atomicAdd(&s_bias[s_][4 * l + 1], bsum[s_].y);
+        atomicAdd(&s_bias[s_][4 * l + 2], bsum[s_].z); atomicAdd(&s_bias[s_][4 * l + 3], bsum[s_].w);
+    }
+    __syncthreads();
+    for (int i = tid; i < 96; i += kBinNT) unsafeAtomicAdd(d_tok_bias + i, (&s_bias[0][0])[i]);
+}
+
 }  // namespace
 
 extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
@@ -552,5 +833,50 @@ extern "C" int sherf_gather_tokens_bwd(const int32_t* counters, const float* geo
     hipLaunchKernelGGL(gather_tokens_bwd_kernel, dim3((unsigned)(tiles < 16384 ? tiles : 16384)), dim3(256), 0, as_stream(stream), counters,
                        geom, reinterpret_cast<const float4*>(d_tokens), P, Hf, Wf, H, W, lv, bounds, vox_min, sh, capacity,
                        reinterpret_cast<float4*>(d_planes_f), reinterpret_cast<float4*>(d_feat_f), d_tok_bias);
+    SHERF_LAUNCH_CHECK();
+}
+
+static int bwd_bins(const sherf_vox_level& l2) { return (l2.D + 4) * (l2.H + 4) * (l2.W + 4); }
+
+static int64_t bwd_scratch_words(const sherf_vox_level* levels_host, int64_t capacity) {
+    return 4 + (int64_t)4 * bwd_bins(levels_host[2]) + 2 * capacity;
+}
+
+extern "C" int sherf_gather_bwd_scratch_words(const sherf_vox_level* levels_host, int64_t capacity, int64_t* words_host) {
+    SHERF_CHECK_ARG(levels_host && words_host && capacity > 0 && levels_host[2].D > 0 && levels_host[2].H > 0 && levels_host[2].W > 0);
+    *words_host = bwd_scratch_words(levels_host, capacity);
+    return SHERF_OK;
+}
+
+extern "C" int sherf_gather_tokens_bwd_binned(const int32_t* counters, const float* geom, const float* d_tokens, int P, int Hf, int Wf,
+                                              int H, int W, const sherf_vox_level* levels_host, const float* bounds, const float* vox_min,
+                                              const int32_t* vox_sh_host, int64_t capacity, float* d_planes_f, float* d_feat_f,
+                                              float* d_rows0, float* d_rows1, float* d_rows2, float* d_tok_bias, int32_t* scratch,
+                                              int64_t scratch_words, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && geom && d_tokens && levels_host && bounds && vox_min && vox_sh_host && d_planes_f && d_feat_f &&
+                    d_rows0 && d_rows1 && d_rows2 && d_tok_bias && scratch);
+    SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
+    LevelsBwd lv = {};
+    for (int i = 0; i < 3; ++i) {
+        lv.l[i] = levels_host[i];
+        SHERF_CHECK_ARG(lv.l[i].wp && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
+    }
+    SHERF_CHECK_ARG(scratch_words >= bwd_scratch_words(levels_host, capacity));
+    lv.d_rows[0] = d_rows0; lv.d_rows[1] = d_rows1; lv.d_rows[2] = d_rows2;
+    const int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
+    const int n_bins = bwd_bins(lv.l[2]);
+    const BinWs w = bin_ws(scratch, n_bins, capacity);
+    hipStream_t st = as_stream(stream);
+    SHERF_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)(4 + 2 * (int64_t)n_bins) * sizeof(int32_t), st));      // list length, counts, cursors
+    const unsigned sb = (unsigned)((capacity + 255) / 256);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(sb), dim3(256), 0, st, counters, geom, lv.l[2], vox_min, sh, capacity, w);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3(sb), dim3(256), 0, st, counters, capacity, w);
+    SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_tokens_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kBinSmem));
+    const int64_t max_list = capacity < n_bins ? capacity : n_bins;
+    hipLaunchKernelGGL(gather_tokens_bwd_binned_kernel, dim3((unsigned)(max_list < 2048 ? max_list : 2048)), dim3(kBinNT), kBinSmem, st, geom,
+                       reinterpret_cast<const float4*>(d_tokens), P, Hf, Wf, H, W, lv, bounds, vox_min, sh, w,
+                       reinterpret_cast<float4*>(d_planes_f), reinterpret_cast<float4*>(d_feat_f), d_tok_bias, g_sherf_debug);
     SHERF_LAUNCH_CHECK();
 }

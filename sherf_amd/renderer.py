@@ -429,7 +429,7 @@ class ImportanceRenderer(nn.Module):
         P = _lib.ptr
         _lib.call('sherf_mlp_pack_stream', P(flat), P(src), src.numel(), prec, P(stream), P(bsrc), bsrc.numel(), P(wbias), P(flag), _lib.stream())
         checks = [flag.to(torch.float32)]
-        if prec != 0 and not torch.is_grad_enabled():
+        if prec != 0 and not getattr(self, '_in_autograd', False):
             # a-priori bound of the activations (mlp_pack.check_f16_range): product of the layers' row norms.  Skipped while training
             # (weights move a little per step from a checked start; the kernel's own non-finite flag, check_finite(), stays armed)
             bound = torch.full((), 64.0, dtype=torch.float64, device=device)

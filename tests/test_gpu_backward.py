@@ -231,9 +231,36 @@ def test_sparse_conv_gradient_kernels(mode):
         assert G.rel(dW_g.tensor().cpu(), dW_c.tensor()) < 1e-4
     di_c, di_g = Mat(torch.zeros(fine_c['cap'] * Cin), fine_c['cap'], Cin), Mat(torch.zeros(fine_c['cap'] * Cin).cuda(), fine_c['cap'], Cin)
     e.conv_dgrad(fine_c, out_c, Mat(d_raw.clone(), out_c['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_c)
-    h.conv_dgrad(fine_g, out_g, Mat(d_raw.cuda(), out_c['cap'], Cout), Cout, Mat(W.cuda(), Cout, 27 * Cin), Cin, mode, di_g)
+    h.conv_dgrad_valu(fine_g, out_g, Mat(d_raw.cuda(), out_c['cap'], Cout), Cout, Mat(W.cuda(), Cout, 27 * Cin), Cin, mode, di_g)
     torch.cuda.synchronize()
     assert G.rel(di_g.tensor().cpu(), di_c.tensor()) < 1e-4
+
+
+@pytest.mark.parametrize('mode,Cin,Cout', [(0, 32, 32), (1, 32, 32), (1, 32, 64), (0, 64, 64), (1, 64, 96), (0, 96, 96)])
+def test_mfma_input_gradient_convolution(mode, Cin, Cout):
+    """HipOps.conv_dgrad as the training step runs it (sherf_svox_conv3_dgrad: the forward's MFMA sparse convolution with mirrored taps,
+    exchanged channel roles and the rows scaled into the fp16 split's range by the layer's max |d_raw|) against the specification, for
+    every layer shape of the encoder, on gradient-sized values (1e-7) with elements far below the maximum."""
+    from sherf_amd.backward_dense import HipOps, Mat
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    fine_c, fine_g = _random_level((12, 16, 20), 900, 1)
+    out_c, out_g = (fine_c, fine_g) if mode == 0 else _random_level((6, 8, 10), 300, 2)
+    gen = torch.Generator().manual_seed(3 + Cin + Cout)
+    d_raw = torch.randn(out_c['cap'] * Cout, generator=gen) * 1e-7
+    d_raw[::7] *= 1e-4
+    W = torch.randn(Cout * 27 * Cin, generator=gen) * 0.1
+    di_c = Mat(torch.zeros(fine_c['cap'] * Cin), fine_c['cap'], Cin)
+    di_g = Mat(torch.full((fine_c['cap'] * Cin,), float('nan')).cuda(), fine_c['cap'], Cin)
+    e.conv_dgrad(fine_c, out_c, Mat(d_raw.clone(), out_c['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_c)
+    dm = Mat(d_raw.cuda(), out_c['cap'], Cout)
+    n_o, n_i = int(out_c['n_rows']), int(fine_c['n_rows'])
+    dm.amax = Mat(d_raw.view(-1, Cout)[:n_o].abs().max().reshape(1).cuda(), 1, 1)
+    h.conv_dgrad(fine_g, out_g, dm, Cout, Mat(W.cuda(), Cout, 27 * Cin), Cin, mode, di_g)
+    torch.cuda.synchronize()
+    a, b = di_c.tensor()[:n_i].double(), di_g.tensor()[:n_i].cpu().double()
+    assert torch.isfinite(b).all()
+    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
 
 
 def test_batchnorm_backward_and_small_encoder_kernels():
@@ -262,6 +289,7 @@ def test_batchnorm_backward_and_small_encoder_kernels():
     torch.cuda.synchronize()
     for a, b in zip(outs_c, outs_g):
         assert G.rel(b.tensor().cpu(), a.tensor()) < 1e-4
+    assert float(outs_g[0].amax.tensor().view(-1)[0]) == float(outs_g[0].tensor()[:n].abs().max())      # the scale of the MFMA input gradient
     # bn_relu_apply, gather_rows, unfold32
     a_c, a_g = Mat(torch.zeros(cap * C), cap, C), Mat(torch.zeros(cap * C).cuda(), cap, C)
     e.bn_relu_apply(Mat(raw.clone(), cap, C), Mat(bn.clone(), 1, 3 * C), torch.tensor(n), a_c)
@@ -286,8 +314,10 @@ def test_batchnorm_backward_and_small_encoder_kernels():
     assert G.rel(di_g.tensor().cpu(), di_c.tensor()) < 1e-4 and G.rel(dw_g.tensor().cpu(), dw_c.tensor()) < 1e-4
 
 
-def test_gather_backward_kernel():
-    """sherf_gather_tokens_bwd against the oracle's tap stencils, in the kernel's folded channel-last layouts."""
+@pytest.mark.parametrize('binned', [True, False])
+def test_gather_backward_kernel(binned):
+    """sherf_gather_tokens_bwd_binned (the step's form: samples binned by coarse voxel cell, LDS windows) and sherf_gather_tokens_bwd (direct
+    atomics) against the oracle's tap stencils, in the kernel's folded channel-last layouts."""
     import ctypes
     from oracle import backward_explicit as BX
     from sherf_amd import _lib
@@ -311,9 +341,18 @@ def test_gather_backward_kernel():
     d_rows = [Mat.zeros(L[t[0]]['cap'], 96, 'cuda') for t in taps]
     f32 = lambda t: t.detach().float().contiguous()
     bounds, vox_min = f32(b['bounds']).view(6), f32(b['vox_min']).view(3)
-    _lib.call('sherf_gather_tokens_bwd', _lib.ptr(ws['counters']), _lib.ptr(ws['geom']), _lib.ptr(d_tiled), P, Hf, Wf, b['H'], b['W'],
-              last['levels_struct'], _lib.ptr(bounds), _lib.ptr(vox_min), (ctypes.c_int32 * 3)(*b['vox_sh']), last['cap'], ops._p(d_planes_f),
-              ops._p(d_feat_f), ops._p(d_rows[0]), ops._p(d_rows[1]), ops._p(d_rows[2]), ops._p(d_bias), _lib.stream())
+    args = (_lib.ptr(ws['counters']), _lib.ptr(ws['geom']), _lib.ptr(d_tiled), P, Hf, Wf, b['H'], b['W'],
+            last['levels_struct'], _lib.ptr(bounds), _lib.ptr(vox_min), (ctypes.c_int32 * 3)(*b['vox_sh']), last['cap'], ops._p(d_planes_f),
+            ops._p(d_feat_f), ops._p(d_rows[0]), ops._p(d_rows[1]), ops._p(d_rows[2]), ops._p(d_bias))
+    if binned:
+        words = ctypes.c_int64(0)
+        _lib.call('sherf_gather_bwd_scratch_words', last['levels_struct'], last['cap'], ctypes.byref(words))
+        scratch = torch.full((words.value,), -7, dtype=torch.int32, device='cuda')
+        _lib.call('sherf_gather_tokens_bwd_binned', *args, _lib.ptr(scratch), words.value, _lib.stream())
+        torch.cuda.synchronize()
+        assert int(scratch[4:4 + (words.value - 4 - 2 * last['cap']) // 4].sum()) == n
+    else:
+        _lib.call('sherf_gather_tokens_bwd', *args, _lib.stream())
     torch.cuda.synchronize()
     dt = g['stage.tokens_in']
     bnd = torch.from_numpy(fx['input_data']['t_world_bounds']).view(2, 3)

@@ -302,7 +302,7 @@ def fwd_lib(tmp_path_factory):
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
     for name in ('sherf_composite_compact', 'sherf_composite_compact_bwd', 'sherf_gather_tokens', 'sherf_gather_tokens_bwd', 'sherf_fold_tables',
-                 'sherf_img_to_hwc4'):
+                 'sherf_img_to_hwc4', 'sherf_gather_tokens_bwd_binned', 'sherf_gather_bwd_scratch_words'):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = protos[name][0], [a[0] for a in protos[name][1]]
     return lib
@@ -423,11 +423,32 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     dt = g['stage.tokens_in']
     pad = torch.zeros(tiles * 32, 96); pad[:n] = dt.reshape(n, 96)
     d_tiled = pad.view(tiles, 32, 3, 8, 4).permute(0, 2, 3, 1, 4).reshape(-1).contiguous()
-    d_planes_f, d_feat_f, d_bias = torch.zeros(3 * P * P, 32), torch.zeros(Hf * Wf, 64), torch.zeros(96)
-    d_rows = [torch.zeros(k['cap'], 96) for k in kers]
-    assert fwd_lib.sherf_gather_tokens_bwd(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
-                                           _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), None) == 0
     bnd = bounds.view(2, 3)
+    words = ctypes.c_int64(0)
+    assert fwd_lib.sherf_gather_bwd_scratch_words(levels, n, ctypes.byref(words)) == 0 and words.value > 2 * n
+    scratch = torch.full((words.value,), -7, dtype=torch.int32)                 # (not zeroed by the caller)
+    dbg = ctypes.c_int.in_dll(fwd_lib, 'g_sherf_debug')
+    for binned in (True, 8192, False):                 # the step's form (binned, LDS windows); the same with one-voxel windows (spill path); the direct one
+      dbg.value = binned if binned is not True and binned else 0
+      d_planes_f, d_feat_f, d_bias = torch.zeros(3 * P * P, 32), torch.zeros(Hf * Wf, 64), torch.zeros(96)
+      d_rows = [torch.zeros(k['cap'], 96) for k in kers]
+      if binned:
+        assert fwd_lib.sherf_gather_tokens_bwd_binned(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
+                                                      _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), _P(scratch),
+                                                      words.value, None) == 0
+        cnt = scratch[4:4 + (words.value - 4 - 2 * n) // 4]
+        assert int(cnt.sum()) == n and int(scratch[0]) == int((cnt > 0).sum())                  # every sample binned once; the list of non-empty bins
+        assert sorted(scratch[words.value - n:].tolist()) == list(range(n))                      # the sorted order is a permutation of the samples
+        assert fwd_lib.sherf_gather_tokens_bwd_binned(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
+                                                      _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), _P(scratch),
+                                                      words.value - 1, None) != 0               # scratch too small
+      else:
+        assert fwd_lib.sherf_gather_tokens_bwd(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
+                                               _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), None) == 0
+      _check_scatter(BX, r, dt, n, P, Hf, Wf, H, W, bnd, d_planes_f, d_feat_f, d_rows, d_bias, rel)
+
+
+def _check_scatter(BX, r, dt, n, P, Hf, Wf, H, W, bnd, d_planes_f, d_feat_f, d_rows, d_bias, rel):
     ref_pf = BX.triplane_bwd((3, 32, P, P), r['x_c'], bnd, dt.permute(1, 0, 2)).permute(0, 2, 3, 1).reshape(3 * P * P, 32)
     assert rel(d_planes_f, ref_pf) < 1e-4
     gg = 2.0 * r['uv'] / torch.tensor([W, H], dtype=torch.float32) - 1.0

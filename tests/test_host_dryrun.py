@@ -20,7 +20,12 @@ class _FakeCuda(torch.Tensor):
 @pytest.fixture()
 def stubbed(monkeypatch):
     calls, frames = [], []
-    monkeypatch.setattr(_lib, 'call', lambda name, *a: calls.append((name, a)))
+    def call(name, *a):
+        if name == 'sherf_mlp_pack_stream':            # (the weight stream packed on the device: its flag word must read "all finite")
+            ctypes.memset(a[8], 0, 4)
+            return
+        calls.append((name, a))
+    monkeypatch.setattr(_lib, 'call', call)
     monkeypatch.setattr(_lib, 'addr', lambda t, dtype=None: None if t is None else t.data_ptr())
     monkeypatch.setattr(_lib, 'ptr', lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr()))
     monkeypatch.setattr(torch.cuda, 'current_stream', lambda dev=None: type('S', (), {'cuda_stream': 0})())
@@ -38,7 +43,7 @@ def _run(training, options=None):
     from sherf_amd.triplane import NeRFDecoder
     from sherf_amd.voxel import SparseConvTensor
     fx = G.fixture('tiny')
-    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=G.smpl())
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=G.smpl(), mlp_precision='f16x3')   # (one frame per call: no calibration)
     dec = NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
     rend.train(training); dec.train(training)
@@ -109,7 +114,7 @@ def test_backward_glue_dry_run(stubbed, monkeypatch):
             assert out['params'][full].shape == p.shape, full
     assert out['planes'].shape == (1, 3, 32, 32, 32) and out['obs_feat'].shape == (1, 64, 16, 16) and out['vertex_feat'].shape == (6890, 32)
     assert bwd_calls.count('sherf_bwd_gemm') >= 50 and 'sherf_bwd_conv_wgrad' in bwd_calls and 'sherf_bwd_unfold32' in bwd_calls
-    assert [c[0] for c in calls].count('sherf_gather_tokens_bwd') == 1 and [c[0] for c in calls].count('sherf_composite_compact_bwd') == 1
+    assert [c[0] for c in calls].count('sherf_gather_tokens_bwd_binned') == 1 and [c[0] for c in calls].count('sherf_composite_compact_bwd') == 1
 
 
 def test_autograd_node_wiring(stubbed, monkeypatch):
