@@ -511,7 +511,8 @@ __global__ void __launch_bounds__(256) gather_tokens_bwd_kernel(const int32_t* _
 constexpr int kBinNT = 512;                       // threads of the scatter workgroup
 constexpr int kW0 = 6, kW1 = 5, kWP = 6;          // window edge: finest / middle tapped level, plane texels
 constexpr int kR0 = kW0 * kW0 * kW0, kR1 = kW1 * kW1 * kW1, kR2 = 8, kRV = kR0 + kR1 + kR2, kRP = 3 * kWP * kWP;
-constexpr size_t kBinSmem = (size_t)(kRV * 96 + kRP * 32) * 4 + (size_t)(kRV + 16) * 4;
+constexpr int kWF = 6, kRF = kWF * kWF;         // window of the pixel-aligned feature map (texels; 64 channels each)
+constexpr size_t kBinSmem = (size_t)(kRV * 96 + kRP * 32 + kRF * 64) * 4 + (size_t)(kRV + 16) * 4;
 
 struct VoxTap { int xi, yi, zi; float fx, fy, fz; };
 
@@ -536,6 +537,15 @@ __device__ __forceinline__ PlaneTap plane_tap(int p, const float* n, int P) {   
     const float py = clampf(((gb + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
     const float x0 = floorf(px), y0 = floorf(py);
     return PlaneTap{(int)x0, (int)y0, px - x0, py - y0};
+}
+
+struct PixTap { int xi, yi; float fx, fy; };
+__device__ __forceinline__ PixTap pix_tap(const float* __restrict__ gm, int W, int H, int Wf, int Hf) {   // (align_corners=True; gm[6..7] = pixel of the observed view)
+    const float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
+    const float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
+    const float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
+    const float x0 = floorf(px), y0 = floorf(py);
+    return PixTap{(int)x0, (int)y0, px - x0, py - y0};
 }
 
 // bin of a sample: its base corner at the coarsest tapped level, each component in [-2, dim + 1] after the stencil's clamp
@@ -601,22 +611,25 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
                                                                           float4* __restrict__ d_planes_f, float4* __restrict__ d_feat_f,
                                                                           float* __restrict__ d_tok_bias, int dbg) {
     // (sherf_set_debug bit 13: windows of ONE voxel / texel below the coarsest level -- nearly every corner takes the spill path; tests)
-    const int lim0 = (dbg & 8192) ? 1 : kW0, lim1 = (dbg & 8192) ? 1 : kW1, limp = (dbg & 8192) ? 1 : kWP;
+    const int lim0 = (dbg & 8192) ? 1 : kW0, lim1 = (dbg & 8192) ? 1 : kW1, limp = (dbg & 8192) ? 1 : kWP, limf = (dbg & 8192) ? 1 : kWF;
+    // (timing ablations, results incomplete: bit 14 no pixel-aligned taps, bit 15 no voxel taps, bit 16 no plane taps: tools/scatter_bench.py)
+    const bool do_pix = !(dbg & 16384), do_vox = !(dbg & 32768), do_pl = !(dbg & 65536);
     extern __shared__ __attribute__((aligned(16))) float bsm[];
     float* acc_v = bsm;                                     // [kRV][96]: level 0 window, level 1 window, level 2 corners
     float* acc_p = bsm + kRV * 96;                          // [3][kWP][kWP][32]
-    int* s_row = reinterpret_cast<int*>(acc_p + kRP * 32);  // [kRV] row of every window voxel (-1: none)
-    int* s_org = s_row + kRV;                               // [12]: origin (x, y, z) of the level 0 / level 1 windows, (x, y) of the three plane windows
+    float* acc_f = acc_p + kRP * 32;                        // [kWF][kWF][64]
+    int* s_row = reinterpret_cast<int*>(acc_f + kRF * 64);  // [kRV] row of every window voxel (-1: none)
+    int* s_org = s_row + kRV;                               // [14]: origin (x, y, z) of the level 0 / 1 windows, (x, y) of the three plane windows, of the feature-map window
     __shared__ float s_bias[3][32];
-    const int tid = threadIdx.x, l = tid & 7, sub = tid >> 3;
+    const int tid = threadIdx.x;
     const int n_list = *w.n_nonempty;
-    float4 bsum[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float bs0 = 0.f, bs1 = 0.f;                    // d_tok_bias: this lane's channel of slots 0-1, of slot 2 (lower half of the wave)
     for (int bi = blockIdx.x; bi < n_list; bi += gridDim.x) {
         const int b = w.nonempty[bi], cnt = w.counts[b], start = w.offsets[b];
         const sherf_vox_level& L2 = lv.l[2];
         const int c2x = b % (L2.W + 4) - 2, c2y = (b / (L2.W + 4)) % (L2.H + 4) - 2, c2z = b / ((L2.W + 4) * (L2.H + 4)) - 2;
-        for (int i = tid; i < kRV * 96 + kRP * 32; i += kBinNT) bsm[i] = 0.f;
-        if (tid < 12) s_org[tid] = 0x7fffffff;
+        for (int i = tid; i < kRV * 96 + kRP * 32 + kRF * 64; i += kBinNT) bsm[i] = 0.f;
+        if (tid < 14) s_org[tid] = 0x7fffffff;
         __syncthreads();
         // ---- pass A: window origins = the smallest base corner among the bin's samples ----
         for (int i = tid; i < cnt; i += kBinNT) {
@@ -636,88 +649,106 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
                 const PlaneTap t = plane_tap(p, n, P);
                 atomicMin(s_org + 6 + 2 * p, t.xi); atomicMin(s_org + 7 + 2 * p, t.yi);
             }
+            const PixTap tf = pix_tap(gm, W, H, Wf, Hf);
+            atomicMin(s_org + 12, tf.xi); atomicMin(s_org + 13, tf.yi);
         }
         __syncthreads();
-        // ---- pass B: eight lanes per sample (lane l: channel quad l of each slot), kBinNT / 8 samples at a time ----
-        for (int i0 = 0; i0 < cnt; i0 += kBinNT / 8) {
-            const int i = i0 + sub;
-            if (i >= cnt) continue;
-            const int64_t c = w.sorted[start + i];
-            const int64_t tile = c >> 5;
-            const int j = (int)(c & 31);
-            float4 d[3];
+        // ---- pass B: ONE sample per wave instruction, lane = channel.  A wave's 64 lanes add 64 consecutive floats of one window row:
+        // no two lanes of an instruction share an address or (beyond the two passes of 64 words over 32 banks) a bank.  (First form:
+        // eight samples x eight channel quads per instruction -- every instruction hit 8 banks 8 ways, and at the coarsest level all
+        // eight samples the same addresses: the voxel taps alone took 10 of the kernel's 14.4 ms, profiles/r03_scatter_ablation.txt.)
+        // d0 = channel `lane` of slots 0-1; d1 = channel 64 + (lane & 31) of slot 2 in BOTH halves of the wave, so that one
+        // instruction can serve two corners of slot 2 (lanes 0-31: corner k, lanes 32-63: corner k + 1).
+        {
+            const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, c31 = lane & 31;
+            const float* dt = reinterpret_cast<const float*>(d_tokens);
+            for (int i = wv; i < cnt; i += kBinNT / 64) {
+                const int64_t c = w.sorted[start + i];
+                const int64_t tile = c >> 5;
+                const int j = (int)(c & 31);
+                // d_tokens[tile][slot][quad][sample j] float4: channel ch of slot s = component ch & 3 of quad ch >> 2
+                const float d0 = dt[((((tile * 3 + half) * 8 + (c31 >> 2)) * 32 + j) << 2) + (c31 & 3)];
+                const float d1 = dt[((((tile * 3 + 2) * 8 + (c31 >> 2)) * 32 + j) << 2) + (c31 & 3)];
+                bs0 += d0; bs1 += half ? 0.f : d1;
+                const float* gm = geom + c * 8;
+                // tri-planes: plane p <- slot p (32 channels): two corners (dx = half) per instruction
+                if (do_pl) {
+                    float n[3];
 #pragma unroll
-            for (int s_ = 0; s_ < 3; ++s_) {
-                d[s_] = d_tokens[((tile * 3 + s_) * 8 + l) * 32 + j];
-                bsum[s_].x += d[s_].x; bsum[s_].y += d[s_].y; bsum[s_].z += d[s_].z; bsum[s_].w += d[s_].w;
-            }
-            const float* gm = geom + c * 8;
-            // tri-planes: slot p <- plane p
-            float n[3];
+                    for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+                    const float dp[3] = {__shfl(d0, c31), __shfl(d0, 32 + c31), d1};
 #pragma unroll
-            for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+                    for (int p = 0; p < 3; ++p) {
+                        const PlaneTap t = plane_tap(p, n, P);
+                        const int ox = s_org[6 + 2 * p], oy = s_org[7 + 2 * p];
+                        const int xx = t.xi + half;
+                        const float wx = half ? t.fx : 1.f - t.fx;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const PlaneTap t = plane_tap(p, n, P);
-                const int ox = s_org[6 + 2 * p], oy = s_org[7 + 2 * p];
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int xx = t.xi + dx, yy = t.yi + dy;
-                        if (!(xx >= 0 && xx < P && yy >= 0 && yy < P)) continue;
-                        const float wgt = (dx ? t.fx : 1.f - t.fx) * (dy ? t.fy : 1.f - t.fy);
-                        const int lx = xx - ox, ly = yy - oy;
-                        if (lx < limp && ly < limp) lds_add4(acc_p + ((p * kWP + ly) * kWP + lx) * 32 + 4 * l, wgt, d[p]);
-                        else scatter4(d_planes_f + ((size_t)(p * P + yy) * P + xx) * 8 + l, wgt, d[p]);
-                    }
-            }
-            // pixel-aligned feature map: direct (slots 0, 1)
-            {
-                const float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
-                const float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
-                const float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
-                const float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
-                const int xi = (int)x0, yi = (int)y0;
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int xx = xi + dx, yy = yi + dy;
-                        if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
-                            const float wgt = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
-                            float4* t = d_feat_f + ((size_t)yy * Wf + xx) * 16;
-                            scatter4(t + l, wgt, d[0]);
-                            scatter4(t + 8 + l, wgt, d[1]);
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const int yy = t.yi + dy;
+                            if (!(xx >= 0 && xx < P && yy >= 0 && yy < P)) continue;
+                            const float v = wx * (dy ? t.fy : 1.f - t.fy) * dp[p];
+                            const int lx = xx - ox, ly = yy - oy;
+                            if (lx < limp && ly < limp) atomicAdd(acc_p + ((p * kWP + ly) * kWP + lx) * 32 + c31, v);
+                            else unsafeAtomicAdd(reinterpret_cast<float*>(d_planes_f) + ((size_t)(p * P + yy) * P + xx) * 32 + c31, v);
                         }
                     }
-            }
-            // voxel levels: all three slots
-            float gx, gy, gz;
-            vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
-#pragma unroll 1
-            for (int L = 0; L < 3; ++L) {
-                const sherf_vox_level& lev = lv.l[L];
-                const VoxTap t = vox_tap(lev, gx, gy, gz);
-                const int ox = L == 2 ? c2x : s_org[3 * L], oy = L == 2 ? c2y : s_org[3 * L + 1], oz = L == 2 ? c2z : s_org[3 * L + 2];
-                const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), rb = L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1);
-                const int lim = L == 0 ? lim0 : (L == 1 ? lim1 : 2);
+                }
+                // pixel-aligned feature map: slots 0-1 = 64 channels = one corner per instruction
+                if (do_pix) {
+                    const PixTap t = pix_tap(gm, W, H, Wf, Hf);
+                    const int ox = s_org[12], oy = s_org[13];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int xx = t.xi + (k & 1), yy = t.yi + ((k >> 1) & 1), zz = t.zi + (k >> 2);
-                    if (!(xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D)) continue;
-                    const float wgt = ((k & 1) ? t.fx : 1.f - t.fx) * (((k >> 1) & 1) ? t.fy : 1.f - t.fy) * ((k >> 2) ? t.fz : 1.f - t.fz);
-                    const int lx = xx - ox, ly = yy - oy, lz = zz - oz;
-                    if (lx < lim && ly < lim && lz < lim) {
-                        float* a = acc_v + (size_t)(rb + (lz * wd + ly) * wd + lx) * 96 + 4 * l;
-                        lds_add4(a, wgt, d[0]); lds_add4(a + 32, wgt, d[1]); lds_add4(a + 64, wgt, d[2]);
-                    } else {                                 // beyond the window: the direct path
-                        const int key = (zz * lev.H + yy) * lev.W + xx;
-                        const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
-                        const uint32_t bit = 1u << (key & 31);
-                        if (!(rr.x & bit)) continue;
-                        float4* rp = reinterpret_cast<float4*>(lv.d_rows[L]) + (size_t)(rr.y + __popc(rr.x & (bit - 1u))) * 24;
-                        scatter4(rp + l, wgt, d[0]); scatter4(rp + 8 + l, wgt, d[1]); scatter4(rp + 16 + l, wgt, d[2]);
+                    for (int k = 0; k < 4; ++k) {
+                        const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
+                        if (!(xx >= 0 && xx < Wf && yy >= 0 && yy < Hf)) continue;
+                        const float v = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy) * d0;
+                        const int lx = xx - ox, ly = yy - oy;
+                        if (lx < limf && ly < limf) atomicAdd(acc_f + (ly * kWF + lx) * 64 + lane, v);
+                        else unsafeAtomicAdd(reinterpret_cast<float*>(d_feat_f) + ((size_t)yy * Wf + xx) * 64 + lane, v);
+                    }
+                }
+                // voxel levels: per corner one instruction for channels 0-63, per corner PAIR one for channels 64-95
+                if (do_vox) {
+                    float gx, gy, gz;
+                    vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
+#pragma unroll 1
+                    for (int L = 0; L < 3; ++L) {
+                        const sherf_vox_level& lev = lv.l[L];
+                        const VoxTap t = vox_tap(lev, gx, gy, gz);
+                        const int ox = L == 2 ? c2x : s_org[3 * L], oy = L == 2 ? c2y : s_org[3 * L + 1], oz = L == 2 ? c2z : s_org[3 * L + 2];
+                        const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), rb = L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1);
+                        const int lim = L == 0 ? lim0 : (L == 1 ? lim1 : 2);
+                        float* drow = lv.d_rows[L];
+                        // target of corner k: LDS word offset (>= 0), or -2 - row for the direct path, or -1 for none
+                        auto target = [&](int k, float& wgt) -> int64_t {
+                            const int xx = t.xi + (k & 1), yy = t.yi + ((k >> 1) & 1), zz = t.zi + (k >> 2);
+                            wgt = ((k & 1) ? t.fx : 1.f - t.fx) * (((k >> 1) & 1) ? t.fy : 1.f - t.fy) * ((k >> 2) ? t.fz : 1.f - t.fz);
+                            if (!(xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D)) return -1;
+                            const int lx = xx - ox, ly = yy - oy, lz = zz - oz;
+                            if (lx < lim && ly < lim && lz < lim) return (int64_t)(rb + (lz * wd + ly) * wd + lx) * 96;
+                            const int key = (zz * lev.H + yy) * lev.W + xx;
+                            const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                            const uint32_t bit = 1u << (key & 31);
+                            if (!(rr.x & bit)) return -1;
+                            return -2 - (int64_t)(rr.y + __popc(rr.x & (bit - 1u)));
+                        };
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {                       // channels 0-63 (uniform per wave)
+                            float wgt;
+                            const int64_t tg = target(k, wgt);
+                            if (tg >= 0) atomicAdd(acc_v + tg + lane, wgt * d0);
+                            else if (tg < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tg) * 96 + lane, wgt * d0);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) {                    // channels 64-95 of corners k (lower half) and k + 1 (upper half)
+                            float w0, w1;
+                            const int64_t t0 = target(k, w0), t1 = target(k + 1, w1);
+                            const int64_t tg = half ? t1 : t0;
+                            const float v = (half ? w1 : w0) * d1;
+                            if (tg >= 0) atomicAdd(acc_v + tg + 64 + c31, v);
+                            else if (tg < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tg) * 96 + 64 + c31, v);
+                        }
                     }
                 }
             }
@@ -763,16 +794,25 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
             if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
             if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
         }
+        for (int i = tid; i < kRF * 16; i += kBinNT) {
+            const int t = i / 16, q = i % 16, ly = t / kWF, lx = t % kWF;
+            if (s_org[12] == 0x7fffffff) continue;
+            const int xx = s_org[12] + lx, yy = s_org[13] + ly;
+            if (!(xx >= 0 && xx < Wf && yy >= 0 && yy < Hf)) continue;
+            const float4 val = *reinterpret_cast<const float4*>(acc_f + (size_t)t * 64 + 4 * q);
+            float* dst = reinterpret_cast<float*>(d_feat_f + ((size_t)yy * Wf + xx) * 16 + q);
+            if (val.x != 0.f) unsafeAtomicAdd(dst + 0, val.x);
+            if (val.y != 0.f) unsafeAtomicAdd(dst + 1, val.y);
+            if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
+            if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
+        }
         __syncthreads();
     }
     // d_tok_bias
     for (int i = tid; i < 96; i += kBinNT) (&s_bias[0][0])[i] = 0.f;
     __syncthreads();
-#pragma unroll
-    for (int s_ = 0; s_ < 3; ++s_) {
-        atomicAdd(&s_bias[s_][4 * l + 0], bsum[s_].x); atomicAdd(&s_bias[s_][4 * l + 1], bsum[s_].y);
-        atomicAdd(&s_bias[s_][4 * l + 2], bsum[s_].z); atomicAdd(&s_bias[s_][4 * l + 3], bsum[s_].w);
-    }
+    atomicAdd(&s_bias[0][0] + (tid & 63), bs0);
+    if ((tid & 63) < 32) atomicAdd(&s_bias[2][0] + (tid & 63), bs1);
     __syncthreads();
     for (int i = tid; i < 96; i += kBinNT) unsafeAtomicAdd(d_tok_bias + i, (&s_bias[0][0])[i]);
 }
