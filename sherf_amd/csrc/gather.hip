@@ -623,6 +623,8 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
     __shared__ float s_bias[3][32];
     const int tid = threadIdx.x;
     const int n_list = *w.n_nonempty;
+    const sherf_vox_level levs[3] = {lv.l[0], lv.l[1], lv.l[2]};
+    float* const drows[3] = {lv.d_rows[0], lv.d_rows[1], lv.d_rows[2]};
     float bs0 = 0.f, bs1 = 0.f;                    // d_tok_bias: this lane's channel of slots 0-1, of slot 2 (lower half of the wave)
     for (int bi = blockIdx.x; bi < n_list; bi += gridDim.x) {
         const int b = w.nonempty[bi], cnt = w.counts[b], start = w.offsets[b];
@@ -662,6 +664,9 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
         {
             const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, c31 = lane & 31;
             const float* dt = reinterpret_cast<const float*>(d_tokens);
+            int org[14];                                   // the window origins, read from LDS once per bin
+#pragma unroll
+            for (int k = 0; k < 14; ++k) org[k] = s_org[k];
             for (int i = wv; i < cnt; i += kBinNT / 64) {
                 const int64_t c = w.sorted[start + i];
                 const int64_t tile = c >> 5;
@@ -680,7 +685,7 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         const PlaneTap t = plane_tap(p, n, P);
-                        const int ox = s_org[6 + 2 * p], oy = s_org[7 + 2 * p];
+                        const int ox = org[6 + 2 * p], oy = org[7 + 2 * p];
                         const int xx = t.xi + half;
                         const float wx = half ? t.fx : 1.f - t.fx;
 #pragma unroll
@@ -697,7 +702,7 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
                 // pixel-aligned feature map: slots 0-1 = 64 channels = one corner per instruction
                 if (do_pix) {
                     const PixTap t = pix_tap(gm, W, H, Wf, Hf);
-                    const int ox = s_org[12], oy = s_org[13];
+                    const int ox = org[12], oy = org[13];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
@@ -712,14 +717,17 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
                 if (do_vox) {
                     float gx, gy, gz;
                     vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
-#pragma unroll 1
+                    // (the level loop is unrolled and the levels' descriptors live in registers: indexed at run time they were re-read from the
+                    //  kernel-argument segment at every corner, each read followed by s_waitcnt lgkmcnt(0) -- which also drains the LDS
+                    //  atomics in flight: ~300 cycles per atomic instruction, profiles/r03_scatter_ablation.txt)
+#pragma unroll
                     for (int L = 0; L < 3; ++L) {
-                        const sherf_vox_level& lev = lv.l[L];
+                        const sherf_vox_level lev = levs[L];
                         const VoxTap t = vox_tap(lev, gx, gy, gz);
-                        const int ox = L == 2 ? c2x : s_org[3 * L], oy = L == 2 ? c2y : s_org[3 * L + 1], oz = L == 2 ? c2z : s_org[3 * L + 2];
+                        const int ox = L == 2 ? c2x : org[3 * L], oy = L == 2 ? c2y : org[3 * L + 1], oz = L == 2 ? c2z : org[3 * L + 2];
                         const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), rb = L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1);
                         const int lim = L == 0 ? lim0 : (L == 1 ? lim1 : 2);
-                        float* drow = lv.d_rows[L];
+                        float* drow = drows[L];
                         // target of corner k: LDS word offset (>= 0), or -2 - row for the direct path, or -1 for none
                         auto target = [&](int k, float& wgt) -> int64_t {
                             const int xx = t.xi + (k & 1), yy = t.yi + ((k >> 1) & 1), zz = t.zi + (k >> 2);
