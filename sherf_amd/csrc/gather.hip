@@ -655,109 +655,143 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
             atomicMin(s_org + 12, tf.xi); atomicMin(s_org + 13, tf.yi);
         }
         __syncthreads();
-        // ---- pass B: ONE sample per wave instruction, lane = channel.  A wave's 64 lanes add 64 consecutive floats of one window row:
-        // no two lanes of an instruction share an address or (beyond the two passes of 64 words over 32 banks) a bank.  (First form:
-        // eight samples x eight channel quads per instruction -- every instruction hit 8 banks 8 ways, and at the coarsest level all
-        // eight samples the same addresses: the voxel taps alone took 10 of the kernel's 14.4 ms, profiles/r03_scatter_ablation.txt.)
-        // d0 = channel `lane` of slots 0-1; d1 = channel 64 + (lane & 31) of slot 2 in BOTH halves of the wave, so that one
-        // instruction can serve two corners of slot 2 (lanes 0-31: corner k, lanes 32-63: corner k + 1).
+        // ---- pass B.  Two roles per wave, per chunk of 64 of the bin's samples:
+        //  (1) lane = SAMPLE: every lane works out the stencils of its own sample once -- for each of its 24 voxel, 12 plane and 4
+        //      feature-map corners a target (word offset into the LDS window; -2 - index for the direct path; -1 none) and a weight,
+        //      kept in registers;
+        //  (2) lane = CHANNEL: the wave walks its samples one by one, broadcasts that sample's (target, weight) pairs with v_readlane
+        //      and adds weight x d[channel] -- 64 consecutive floats of one window row per instruction: no two lanes of an
+        //      instruction share an address, and the ~100 instructions of stencil arithmetic per corner are paid once per sample
+        //      instead of once per sample and wave instruction.  (Forms measured before this one, profiles/r03_scatter_ablation.txt:
+        //      eight samples x eight channel quads per instruction, 14.4 ms -- eight-way bank and same-address conflicts on every LDS
+        //      atomic; one sample per instruction with the stencils recomputed by all 64 lanes, 15-16 ms -- VALU-bound.)
         {
             const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, c31 = lane & 31;
             const float* dt = reinterpret_cast<const float*>(d_tokens);
             int org[14];                                   // the window origins, read from LDS once per bin
 #pragma unroll
             for (int k = 0; k < 14; ++k) org[k] = s_org[k];
-            for (int i = wv; i < cnt; i += kBinNT / 64) {
-                const int64_t c = w.sorted[start + i];
-                const int64_t tile = c >> 5;
-                const int j = (int)(c & 31);
-                // d_tokens[tile][slot][quad][sample j] float4: channel ch of slot s = component ch & 3 of quad ch >> 2
-                const float d0 = dt[((((tile * 3 + half) * 8 + (c31 >> 2)) * 32 + j) << 2) + (c31 & 3)];
-                const float d1 = dt[((((tile * 3 + 2) * 8 + (c31 >> 2)) * 32 + j) << 2) + (c31 & 3)];
-                bs0 += d0; bs1 += half ? 0.f : d1;
-                const float* gm = geom + c * 8;
-                // tri-planes: plane p <- slot p (32 channels): two corners (dx = half) per instruction
-                if (do_pl) {
+            for (int base = wv * 64; base < cnt; base += (kBinNT / 64) * 64) {
+                // ---- (1) lane = sample ----
+                const bool live = base + lane < cnt;
+                const int cs = live ? w.sorted[start + base + lane] : 0;
+                int tv[24], tp[12], tf[4];
+                float wvx[24], wpl[12], wfm[4];
+                {
+                    const float* gm = geom + (int64_t)cs * 8;
                     float n[3];
 #pragma unroll
                     for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
-                    const float dp[3] = {__shfl(d0, c31), __shfl(d0, 32 + c31), d1};
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
                         const PlaneTap t = plane_tap(p, n, P);
-                        const int ox = org[6 + 2 * p], oy = org[7 + 2 * p];
-                        const int xx = t.xi + half;
-                        const float wx = half ? t.fx : 1.f - t.fx;
 #pragma unroll
-                        for (int dy = 0; dy < 2; ++dy) {
-                            const int yy = t.yi + dy;
-                            if (!(xx >= 0 && xx < P && yy >= 0 && yy < P)) continue;
-                            const float v = wx * (dy ? t.fy : 1.f - t.fy) * dp[p];
-                            const int lx = xx - ox, ly = yy - oy;
-                            if (lx < limp && ly < limp) atomicAdd(acc_p + ((p * kWP + ly) * kWP + lx) * 32 + c31, v);
-                            else unsafeAtomicAdd(reinterpret_cast<float*>(d_planes_f) + ((size_t)(p * P + yy) * P + xx) * 32 + c31, v);
+                        for (int k = 0; k < 4; ++k) {
+                            const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
+                            const int lx = xx - org[6 + 2 * p], ly = yy - org[7 + 2 * p];
+                            int tg = -1;
+                            if (live && do_pl && xx >= 0 && xx < P && yy >= 0 && yy < P)
+                                tg = (lx < limp && ly < limp) ? ((p * kWP + ly) * kWP + lx) * 32 : -2 - ((p * P + yy) * P + xx);
+                            tp[4 * p + k] = tg;
+                            wpl[4 * p + k] = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy);
                         }
                     }
-                }
-                // pixel-aligned feature map: slots 0-1 = 64 channels = one corner per instruction
-                if (do_pix) {
                     const PixTap t = pix_tap(gm, W, H, Wf, Hf);
-                    const int ox = org[12], oy = org[13];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
-                        if (!(xx >= 0 && xx < Wf && yy >= 0 && yy < Hf)) continue;
-                        const float v = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy) * d0;
-                        const int lx = xx - ox, ly = yy - oy;
-                        if (lx < limf && ly < limf) atomicAdd(acc_f + (ly * kWF + lx) * 64 + lane, v);
-                        else unsafeAtomicAdd(reinterpret_cast<float*>(d_feat_f) + ((size_t)yy * Wf + xx) * 64 + lane, v);
+                        const int lx = xx - org[12], ly = yy - org[13];
+                        int tg = -1;
+                        if (live && do_pix && xx >= 0 && xx < Wf && yy >= 0 && yy < Hf)
+                            tg = (lx < limf && ly < limf) ? (ly * kWF + lx) * 64 : -2 - (yy * Wf + xx);
+                        tf[k] = tg;
+                        wfm[k] = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy);
                     }
-                }
-                // voxel levels: per corner one instruction for channels 0-63, per corner PAIR one for channels 64-95
-                if (do_vox) {
                     float gx, gy, gz;
                     vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
-                    // (the level loop is unrolled and the levels' descriptors live in registers: indexed at run time they were re-read from the
-                    //  kernel-argument segment at every corner, each read followed by s_waitcnt lgkmcnt(0) -- which also drains the LDS
-                    //  atomics in flight: ~300 cycles per atomic instruction, profiles/r03_scatter_ablation.txt)
 #pragma unroll
                     for (int L = 0; L < 3; ++L) {
                         const sherf_vox_level lev = levs[L];
-                        const VoxTap t = vox_tap(lev, gx, gy, gz);
+                        const VoxTap vt = vox_tap(lev, gx, gy, gz);
                         const int ox = L == 2 ? c2x : org[3 * L], oy = L == 2 ? c2y : org[3 * L + 1], oz = L == 2 ? c2z : org[3 * L + 2];
                         const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), rb = L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1);
                         const int lim = L == 0 ? lim0 : (L == 1 ? lim1 : 2);
-                        float* drow = drows[L];
-                        // target of corner k: LDS word offset (>= 0), or -2 - row for the direct path, or -1 for none
-                        auto target = [&](int k, float& wgt) -> int64_t {
-                            const int xx = t.xi + (k & 1), yy = t.yi + ((k >> 1) & 1), zz = t.zi + (k >> 2);
-                            wgt = ((k & 1) ? t.fx : 1.f - t.fx) * (((k >> 1) & 1) ? t.fy : 1.f - t.fy) * ((k >> 2) ? t.fz : 1.f - t.fz);
-                            if (!(xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D)) return -1;
-                            const int lx = xx - ox, ly = yy - oy, lz = zz - oz;
-                            if (lx < lim && ly < lim && lz < lim) return (int64_t)(rb + (lz * wd + ly) * wd + lx) * 96;
-                            const int key = (zz * lev.H + yy) * lev.W + xx;
-                            const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
-                            const uint32_t bit = 1u << (key & 31);
-                            if (!(rr.x & bit)) return -1;
-                            return -2 - (int64_t)(rr.y + __popc(rr.x & (bit - 1u)));
-                        };
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {                       // channels 0-63 (uniform per wave)
-                            float wgt;
-                            const int64_t tg = target(k, wgt);
-                            if (tg >= 0) atomicAdd(acc_v + tg + lane, wgt * d0);
-                            else if (tg < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tg) * 96 + lane, wgt * d0);
+                        for (int k = 0; k < 8; ++k) {
+                            const int xx = vt.xi + (k & 1), yy = vt.yi + ((k >> 1) & 1), zz = vt.zi + (k >> 2);
+                            wvx[8 * L + k] = ((k & 1) ? vt.fx : 1.f - vt.fx) * (((k >> 1) & 1) ? vt.fy : 1.f - vt.fy) * ((k >> 2) ? vt.fz : 1.f - vt.fz);
+                            int tg = -1;
+                            if (live && do_vox && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
+                                const int lx = xx - ox, ly = yy - oy, lz = zz - oz;
+                                if (lx < lim && ly < lim && lz < lim) tg = (rb + (lz * wd + ly) * wd + lx) * 96;
+                                else {                       // beyond the window: the row for the direct path
+                                    const int key = (zz * lev.H + yy) * lev.W + xx;
+                                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                                    const uint32_t bit = 1u << (key & 31);
+                                    if (rr.x & bit) tg = -2 - (int)(rr.y + __popc(rr.x & (bit - 1u)));
+                                }
+                            }
+                            tv[8 * L + k] = tg;
                         }
+                    }
+                }
+                // ---- (2) lane = channel ----
+                const int nact = min(64, cnt - base);
+                for (int sidx = 0; sidx < nact; ++sidx) {
+                    const int c = __builtin_amdgcn_readlane(cs, sidx);
+                    const int64_t tile = c >> 5;
+                    const int j = c & 31;
+                    // d_tokens[tile][slot][quad][sample j] float4: channel ch of slot s = component ch & 3 of quad ch >> 2
+                    const int64_t dbase = (((tile * 3) * 8 + (c31 >> 2)) * 32 + j) * 4 + (c31 & 3);
+                    const float dp0 = dt[dbase], dp1 = dt[dbase + 1024], d1 = dt[dbase + 2048];        // channel c31 of slots 0, 1, 2 (both halves)
+                    const float d0 = half ? dp1 : dp0;                                                   // channel `lane` of slots 0-1
+                    bs0 += d0; bs1 += half ? 0.f : d1;
+#define SHERF_RL(v) __builtin_amdgcn_readlane((v), sidx)
+#define SHERF_RLF(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), sidx))
+                    // tri-planes: plane p <- slot p (32 channels); the two corners dx = 0 / 1 share an instruction
 #pragma unroll
-                        for (int k = 0; k < 8; k += 2) {                    // channels 64-95 of corners k (lower half) and k + 1 (upper half)
-                            float w0, w1;
-                            const int64_t t0 = target(k, w0), t1 = target(k + 1, w1);
-                            const int64_t tg = half ? t1 : t0;
-                            const float v = (half ? w1 : w0) * d1;
+                    for (int p = 0; p < 3; ++p) {
+                        const float dpv = p == 0 ? dp0 : (p == 1 ? dp1 : d1);
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const int tA = SHERF_RL(tp[4 * p + 2 * dy]), tB = SHERF_RL(tp[4 * p + 2 * dy + 1]);
+                            const float wA = SHERF_RLF(wpl[4 * p + 2 * dy]), wB = SHERF_RLF(wpl[4 * p + 2 * dy + 1]);
+                            if (tA == -1 && tB == -1) continue;
+                            const int tg = half ? tB : tA;
+                            const float v = (half ? wB : wA) * dpv;
+                            if (tg >= 0) atomicAdd(acc_p + tg + c31, v);
+                            else if (tg < -1) unsafeAtomicAdd(reinterpret_cast<float*>(d_planes_f) + (size_t)(-2 - tg) * 32 + c31, v);
+                        }
+                    }
+                    // pixel-aligned feature map: slots 0-1 = 64 channels, one corner per instruction
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int tg = SHERF_RL(tf[k]);
+                        const float v = SHERF_RLF(wfm[k]) * d0;
+                        if (tg >= 0) atomicAdd(acc_f + tg + lane, v);
+                        else if (tg < -1) unsafeAtomicAdd(reinterpret_cast<float*>(d_feat_f) + (size_t)(-2 - tg) * 64 + lane, v);
+                    }
+                    // voxel levels: per corner one instruction for channels 0-63, per corner PAIR one for channels 64-95
+#pragma unroll
+                    for (int L = 0; L < 3; ++L) {
+                        float* drow = drows[L];
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) {
+                            const int tA = SHERF_RL(tv[8 * L + k]), tB = SHERF_RL(tv[8 * L + k + 1]);
+                            const float wA = SHERF_RLF(wvx[8 * L + k]), wB = SHERF_RLF(wvx[8 * L + k + 1]);
+                            if (tA >= 0) atomicAdd(acc_v + tA + lane, wA * d0);
+                            else if (tA < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tA) * 96 + lane, wA * d0);
+                            if (tB >= 0) atomicAdd(acc_v + tB + lane, wB * d0);
+                            else if (tB < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tB) * 96 + lane, wB * d0);
+                            if (tA == -1 && tB == -1) continue;
+                            const int tg = half ? tB : tA;
+                            const float v = (half ? wB : wA) * d1;
                             if (tg >= 0) atomicAdd(acc_v + tg + 64 + c31, v);
                             else if (tg < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tg) * 96 + 64 + c31, v);
                         }
                     }
+#undef SHERF_RL
+#undef SHERF_RLF
                 }
             }
         }
