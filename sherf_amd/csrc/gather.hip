@@ -498,21 +498,24 @@ __global__ void __launch_bounds__(256) gather_tokens_bwd_kernel(const int32_t* _
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same scatter with the samples BINNED by the coarsest tapped voxel cell they fall in (4 cm), one workgroup per bin accumulating in
-// LDS and flushing once.  The direct form above issues ~2900 device-scope fp32 atomics per sample, 78 % of them into the voxel rows --
-// ~1.6 G atomics onto ~1 M addresses, chains of hundreds to thousands of same-address updates: 20.3 ms of round 2's 87 ms of kernels
-// per step (profiles/r02_train_step_final_rocprofv3_stats.txt).  All samples of a bin share their 8 corners at the coarsest level, touch
-// at most a 5^3 block of the middle level and (almost always) a 6^3 block of the finest, and a 6 x 6 texel window of each plane: those
-// windows (147 KiB of the CU's 160 KiB LDS) take the samples' updates as LDS atomics and reach memory as ONE atomic per touched
-// address per bin.  A corner outside a window (a bin whose samples straddle one more voxel than the window holds) takes the direct
-// path, as do the pixel-aligned taps (their window depends on the camera, not on the cell).  Sums are order dependent in the last
-// ulp exactly as before.  Four launches: count (+ list of non-empty bins), scan, fill, scatter.
+// The same scatter with the samples BINNED by the coarsest tapped voxel cell they fall in (4 cm) and the lanes of a wave changing
+// roles.  The direct form above issues ~2900 device-scope fp32 atomics per sample in 16-byte pieces of eight different rows per
+// instruction, 78 % of them into the voxel rows, with chains of hundreds to thousands of same-address updates at the coarsest level:
+// 20.3 ms of round 2's 87 ms of kernels per step (profiles/r02_train_step_final_rocprofv3_stats.txt).  Here, per wave and chunk of 64 of
+// a bin's samples:
+//   (1) lane = SAMPLE: every lane works out the stencils of its own sample once -- a target row / texel and a weight for each of
+//       its 24 voxel, 12 plane and 4 feature-map corners, kept in registers;
+//   (2) lane = CHANNEL: the wave walks its samples one by one, broadcasts that sample's (target, weight) pairs with v_readlane and
+//       adds weight x d[channel]: 64 consecutive floats of one row per atomic instruction (whole cache lines, no two lanes on one
+//       address).  All samples of a bin share their 8 corners at the coarsest level -- the contended ones -- so those sums stay in
+//       REGISTERS (12 per lane) and reach memory once per wave and bin.
+// Measured on the way (profiles/r03_scatter_ablation.txt, 690 K samples): LDS windows for every level with 8 samples x 8 channel quads per
+// instruction 14.4 ms; the same with one sample per instruction and the stencils recomputed by all lanes 15-16 ms; with roles (1)/(2)
+// but LDS windows 14.9 ms, of which 12 ms were the LDS float atomics themselves (~150-300 cycles per ds_add_f32 instruction on this
+// part) -- the variant whose windows were shrunk to one voxel, i.e. whose adds went to memory instead, took 6.1 ms.  Hence: no LDS.
+// Sums are order dependent in the last ulp exactly as before.  Four launches: count (+ list of non-empty bins), scan, fill, scatter.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBinNT = 512;                       // threads of the scatter workgroup
-constexpr int kW0 = 6, kW1 = 5, kWP = 6;          // window edge: finest / middle tapped level, plane texels
-constexpr int kR0 = kW0 * kW0 * kW0, kR1 = kW1 * kW1 * kW1, kR2 = 8, kRV = kR0 + kR1 + kR2, kRP = 3 * kWP * kWP;
-constexpr int kWF = 6, kRF = kWF * kWF;         // window of the pixel-aligned feature map (texels; 64 channels each)
-constexpr size_t kBinSmem = (size_t)(kRV * 96 + kRP * 32 + kRF * 64) * 4 + (size_t)(kRV + 16) * 4;
+constexpr int kBinNT = 256;                       // threads of the scatter workgroup: four waves, each on its own chunks of the bin
 
 struct VoxTap { int xi, yi, zi; float fx, fy, fz; };
 
@@ -601,262 +604,175 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(const int32_t* __restrict
     w.sorted[w.offsets[b] + atomicAdd(w.cursor + b, 1)] = (int32_t)c;
 }
 
-__device__ __forceinline__ void lds_add4(float* dst, float wgt, const float4 d) {
-    atomicAdd(dst + 0, wgt * d.x); atomicAdd(dst + 1, wgt * d.y); atomicAdd(dst + 2, wgt * d.z); atomicAdd(dst + 3, wgt * d.w);
-}
-
 __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const float* __restrict__ geom, const float4* __restrict__ d_tokens, int P, int Hf,
                                                                           int Wf, int H, int W, LevelsBwd lv, const float* __restrict__ bounds,
                                                                           const float* __restrict__ vox_min, int3 vox_sh, BinWs w,
                                                                           float4* __restrict__ d_planes_f, float4* __restrict__ d_feat_f,
                                                                           float* __restrict__ d_tok_bias, int dbg) {
-    // (sherf_set_debug bit 13: windows of ONE voxel / texel below the coarsest level -- nearly every corner takes the spill path; tests)
-    const int lim0 = (dbg & 8192) ? 1 : kW0, lim1 = (dbg & 8192) ? 1 : kW1, limp = (dbg & 8192) ? 1 : kWP, limf = (dbg & 8192) ? 1 : kWF;
-    // (timing ablations, results incomplete: bit 14 no pixel-aligned taps, bit 15 no voxel taps, bit 16 no plane taps: tools/scatter_bench.py)
-    const bool do_pix = !(dbg & 16384), do_vox = !(dbg & 32768), do_pl = !(dbg & 65536);
-    extern __shared__ __attribute__((aligned(16))) float bsm[];
-    float* acc_v = bsm;                                     // [kRV][96]: level 0 window, level 1 window, level 2 corners
-    float* acc_p = bsm + kRV * 96;                          // [3][kWP][kWP][32]
-    float* acc_f = acc_p + kRP * 32;                        // [kWF][kWF][64]
-    int* s_row = reinterpret_cast<int*>(acc_f + kRF * 64);  // [kRV] row of every window voxel (-1: none)
-    int* s_org = s_row + kRV;                               // [14]: origin (x, y, z) of the level 0 / 1 windows, (x, y) of the three plane windows, of the feature-map window
-    __shared__ float s_bias[3][32];
-    const int tid = threadIdx.x;
+    // (timing ablations, results incomplete: sherf_set_debug bit 14 no pixel-aligned taps, bit 15 no voxel taps, bit 16 no plane taps;
+    //  bit 13: the coarsest level through memory like the others instead of registers -- same results: tools/scatter_bench.py, tests)
+    const bool do_pix = !(dbg & 16384), do_vox = !(dbg & 32768), do_pl = !(dbg & 65536), reg2 = !(dbg & 8192);
+    __shared__ float s_bias[96];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, c31 = lane & 31;
     const int n_list = *w.n_nonempty;
+    // (descriptors in registers: indexed at run time they are re-read from the kernel-argument segment at every use)
     const sherf_vox_level levs[3] = {lv.l[0], lv.l[1], lv.l[2]};
     float* const drows[3] = {lv.d_rows[0], lv.d_rows[1], lv.d_rows[2]};
+    const float* dt = reinterpret_cast<const float*>(d_tokens);
+    float* const dpl = reinterpret_cast<float*>(d_planes_f);
+    float* const dfm = reinterpret_cast<float*>(d_feat_f);
     float bs0 = 0.f, bs1 = 0.f;                    // d_tok_bias: this lane's channel of slots 0-1, of slot 2 (lower half of the wave)
     for (int bi = blockIdx.x; bi < n_list; bi += gridDim.x) {
         const int b = w.nonempty[bi], cnt = w.counts[b], start = w.offsets[b];
-        const sherf_vox_level& L2 = lv.l[2];
-        const int c2x = b % (L2.W + 4) - 2, c2y = (b / (L2.W + 4)) % (L2.H + 4) - 2, c2z = b / ((L2.W + 4) * (L2.H + 4)) - 2;
-        for (int i = tid; i < kRV * 96 + kRP * 32 + kRF * 64; i += kBinNT) bsm[i] = 0.f;
-        if (tid < 14) s_org[tid] = 0x7fffffff;
-        __syncthreads();
-        // ---- pass A: window origins = the smallest base corner among the bin's samples ----
-        for (int i = tid; i < cnt; i += kBinNT) {
-            const float* gm = geom + (int64_t)w.sorted[start + i] * 8;
-            float gx, gy, gz;
-            vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
+        float a2[8], b2[4];                        // coarsest level: corner k x channel `lane` (slots 0-1); corner pair x channel 64 + c31 (slot 2)
 #pragma unroll
-            for (int L = 0; L < 2; ++L) {
-                const VoxTap t = vox_tap(lv.l[L], gx, gy, gz);
-                atomicMin(s_org + 3 * L + 0, t.xi); atomicMin(s_org + 3 * L + 1, t.yi); atomicMin(s_org + 3 * L + 2, t.zi);
-            }
-            float n[3];
+        for (int k = 0; k < 8; ++k) a2[k] = 0.f;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+        for (int k = 0; k < 4; ++k) b2[k] = 0.f;
+        int row2 = -1;                             // lanes 0-7: the row of corner `lane` of the bin's cell (the same for all its samples)
+        for (int base = wv * 64; base < cnt; base += (kBinNT / 64) * 64) {
+            // ---- (1) lane = sample ----
+            const bool live = base + lane < cnt;
+            const int cs = live ? w.sorted[start + base + lane] : 0;
+            int tv[24], tp[12], tf[4];
+            float wvx[24], wpl[12], wfm[4];
+            {
+                const float* gm = geom + (int64_t)cs * 8;
+                float n[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const PlaneTap t = plane_tap(p, n, P);
-                atomicMin(s_org + 6 + 2 * p, t.xi); atomicMin(s_org + 7 + 2 * p, t.yi);
-            }
-            const PixTap tf = pix_tap(gm, W, H, Wf, Hf);
-            atomicMin(s_org + 12, tf.xi); atomicMin(s_org + 13, tf.yi);
-        }
-        __syncthreads();
-        // ---- pass B.  Two roles per wave, per chunk of 64 of the bin's samples:
-        //  (1) lane = SAMPLE: every lane works out the stencils of its own sample once -- for each of its 24 voxel, 12 plane and 4
-        //      feature-map corners a target (word offset into the LDS window; -2 - index for the direct path; -1 none) and a weight,
-        //      kept in registers;
-        //  (2) lane = CHANNEL: the wave walks its samples one by one, broadcasts that sample's (target, weight) pairs with v_readlane
-        //      and adds weight x d[channel] -- 64 consecutive floats of one window row per instruction: no two lanes of an
-        //      instruction share an address, and the ~100 instructions of stencil arithmetic per corner are paid once per sample
-        //      instead of once per sample and wave instruction.  (Forms measured before this one, profiles/r03_scatter_ablation.txt:
-        //      eight samples x eight channel quads per instruction, 14.4 ms -- eight-way bank and same-address conflicts on every LDS
-        //      atomic; one sample per instruction with the stencils recomputed by all 64 lanes, 15-16 ms -- VALU-bound.)
-        {
-            const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, c31 = lane & 31;
-            const float* dt = reinterpret_cast<const float*>(d_tokens);
-            int org[14];                                   // the window origins, read from LDS once per bin
+                for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
 #pragma unroll
-            for (int k = 0; k < 14; ++k) org[k] = s_org[k];
-            for (int base = wv * 64; base < cnt; base += (kBinNT / 64) * 64) {
-                // ---- (1) lane = sample ----
-                const bool live = base + lane < cnt;
-                const int cs = live ? w.sorted[start + base + lane] : 0;
-                int tv[24], tp[12], tf[4];
-                float wvx[24], wpl[12], wfm[4];
-                {
-                    const float* gm = geom + (int64_t)cs * 8;
-                    float n[3];
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const PlaneTap t = plane_tap(p, n, P);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
-                            const int lx = xx - org[6 + 2 * p], ly = yy - org[7 + 2 * p];
-                            int tg = -1;
-                            if (live && do_pl && xx >= 0 && xx < P && yy >= 0 && yy < P)
-                                tg = (lx < limp && ly < limp) ? ((p * kWP + ly) * kWP + lx) * 32 : -2 - ((p * P + yy) * P + xx);
-                            tp[4 * p + k] = tg;
-                            wpl[4 * p + k] = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy);
-                        }
-                    }
-                    const PixTap t = pix_tap(gm, W, H, Wf, Hf);
+                for (int p = 0; p < 3; ++p) {
+                    const PlaneTap t = plane_tap(p, n, P);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
-                        const int lx = xx - org[12], ly = yy - org[13];
-                        int tg = -1;
-                        if (live && do_pix && xx >= 0 && xx < Wf && yy >= 0 && yy < Hf)
-                            tg = (lx < limf && ly < limf) ? (ly * kWF + lx) * 64 : -2 - (yy * Wf + xx);
-                        tf[k] = tg;
-                        wfm[k] = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy);
-                    }
-                    float gx, gy, gz;
-                    vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
-#pragma unroll
-                    for (int L = 0; L < 3; ++L) {
-                        const sherf_vox_level lev = levs[L];
-                        const VoxTap vt = vox_tap(lev, gx, gy, gz);
-                        const int ox = L == 2 ? c2x : org[3 * L], oy = L == 2 ? c2y : org[3 * L + 1], oz = L == 2 ? c2z : org[3 * L + 2];
-                        const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), rb = L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1);
-                        const int lim = L == 0 ? lim0 : (L == 1 ? lim1 : 2);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int xx = vt.xi + (k & 1), yy = vt.yi + ((k >> 1) & 1), zz = vt.zi + (k >> 2);
-                            wvx[8 * L + k] = ((k & 1) ? vt.fx : 1.f - vt.fx) * (((k >> 1) & 1) ? vt.fy : 1.f - vt.fy) * ((k >> 2) ? vt.fz : 1.f - vt.fz);
-                            int tg = -1;
-                            if (live && do_vox && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
-                                const int lx = xx - ox, ly = yy - oy, lz = zz - oz;
-                                if (lx < lim && ly < lim && lz < lim) tg = (rb + (lz * wd + ly) * wd + lx) * 96;
-                                else {                       // beyond the window: the row for the direct path
-                                    const int key = (zz * lev.H + yy) * lev.W + xx;
-                                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
-                                    const uint32_t bit = 1u << (key & 31);
-                                    if (rr.x & bit) tg = -2 - (int)(rr.y + __popc(rr.x & (bit - 1u)));
-                                }
-                            }
-                            tv[8 * L + k] = tg;
-                        }
+                        tp[4 * p + k] = (live && do_pl && xx >= 0 && xx < P && yy >= 0 && yy < P) ? (p * P + yy) * P + xx : -1;
+                        wpl[4 * p + k] = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy);
                     }
                 }
-                // ---- (2) lane = channel ----
-                const int nact = min(64, cnt - base);
-                for (int sidx = 0; sidx < nact; ++sidx) {
-                    const int c = __builtin_amdgcn_readlane(cs, sidx);
-                    const int64_t tile = c >> 5;
-                    const int j = c & 31;
-                    // d_tokens[tile][slot][quad][sample j] float4: channel ch of slot s = component ch & 3 of quad ch >> 2
-                    const int64_t dbase = (((tile * 3) * 8 + (c31 >> 2)) * 32 + j) * 4 + (c31 & 3);
-                    const float dp0 = dt[dbase], dp1 = dt[dbase + 1024], d1 = dt[dbase + 2048];        // channel c31 of slots 0, 1, 2 (both halves)
-                    const float d0 = half ? dp1 : dp0;                                                   // channel `lane` of slots 0-1
-                    bs0 += d0; bs1 += half ? 0.f : d1;
+                const PixTap t = pix_tap(gm, W, H, Wf, Hf);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
+                    tf[k] = (live && do_pix && xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) ? yy * Wf + xx : -1;
+                    wfm[k] = ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy);
+                }
+                float gx, gy, gz;
+                vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
+#pragma unroll
+                for (int L = 0; L < 3; ++L) {
+                    const sherf_vox_level lev = levs[L];
+                    const VoxTap vt = vox_tap(lev, gx, gy, gz);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int xx = vt.xi + (k & 1), yy = vt.yi + ((k >> 1) & 1), zz = vt.zi + (k >> 2);
+                        // (a dead lane or a switched-off level weighs nothing: the register sums of the coarsest level take every sample)
+                        wvx[8 * L + k] = (live && do_vox) ? ((k & 1) ? vt.fx : 1.f - vt.fx) * (((k >> 1) & 1) ? vt.fy : 1.f - vt.fy) * ((k >> 2) ? vt.fz : 1.f - vt.fz) : 0.f;
+                        int tg = -1;
+                        if (live && do_vox && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
+                            const int key = (zz * lev.H + yy) * lev.W + xx;
+                            const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                            const uint32_t bit = 1u << (key & 31);
+                            if (rr.x & bit) tg = (int)(rr.y + __popc(rr.x & (bit - 1u)));
+                        }
+                        tv[8 * L + k] = tg;
+                    }
+                }
+            }
+            // the rows of the bin's eight coarsest-level corners: every sample of the bin has the same ones; lane k < 8 keeps corner k's
+            if (base == wv * 64) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = __builtin_amdgcn_readlane(tv[16 + k], 0);                      // (lane 0 is live whenever the wave has a chunk)
+                    if (lane == k) row2 = r;
+                }
+            }
+            // ---- (2) lane = channel ----
+            const int nact = min(64, cnt - base);
+            for (int sidx = 0; sidx < nact; ++sidx) {
+                const int c = __builtin_amdgcn_readlane(cs, sidx);
+                const int64_t tile = c >> 5;
+                const int j = c & 31;
+                // d_tokens[tile][slot][quad][sample j] float4: channel ch of slot s = component ch & 3 of quad ch >> 2
+                const int64_t dbase = (((tile * 3) * 8 + (c31 >> 2)) * 32 + j) * 4 + (c31 & 3);
+                const float dp0 = dt[dbase], dp1 = dt[dbase + 1024], d1 = dt[dbase + 2048];            // channel c31 of slots 0, 1, 2 (both halves)
+                const float d0 = half ? dp1 : dp0;                                                       // channel `lane` of slots 0-1
+                bs0 += d0; bs1 += half ? 0.f : d1;
 #define SHERF_RL(v) __builtin_amdgcn_readlane((v), sidx)
 #define SHERF_RLF(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), sidx))
-                    // tri-planes: plane p <- slot p (32 channels); the two corners dx = 0 / 1 share an instruction
+                // tri-planes: plane p <- slot p (32 channels); the two corners dx = 0 / 1 share an instruction
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const float dpv = p == 0 ? dp0 : (p == 1 ? dp1 : d1);
+                for (int p = 0; p < 3; ++p) {
+                    const float dpv = p == 0 ? dp0 : (p == 1 ? dp1 : d1);
 #pragma unroll
-                        for (int dy = 0; dy < 2; ++dy) {
-                            const int tA = SHERF_RL(tp[4 * p + 2 * dy]), tB = SHERF_RL(tp[4 * p + 2 * dy + 1]);
-                            const float wA = SHERF_RLF(wpl[4 * p + 2 * dy]), wB = SHERF_RLF(wpl[4 * p + 2 * dy + 1]);
-                            if (tA == -1 && tB == -1) continue;
-                            const int tg = half ? tB : tA;
-                            const float v = (half ? wB : wA) * dpv;
-                            if (tg >= 0) atomicAdd(acc_p + tg + c31, v);
-                            else if (tg < -1) unsafeAtomicAdd(reinterpret_cast<float*>(d_planes_f) + (size_t)(-2 - tg) * 32 + c31, v);
-                        }
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int tA = SHERF_RL(tp[4 * p + 2 * dy]), tB = SHERF_RL(tp[4 * p + 2 * dy + 1]);
+                        const float wA = SHERF_RLF(wpl[4 * p + 2 * dy]), wB = SHERF_RLF(wpl[4 * p + 2 * dy + 1]);
+                        if (tA < 0 && tB < 0) continue;
+                        const int tg = half ? tB : tA;
+                        if (tg >= 0) unsafeAtomicAdd(dpl + (size_t)tg * 32 + c31, (half ? wB : wA) * dpv);
                     }
-                    // pixel-aligned feature map: slots 0-1 = 64 channels, one corner per instruction
+                }
+                // pixel-aligned feature map: slots 0-1 = 64 channels, one corner per instruction
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int tg = SHERF_RL(tf[k]);
+                    if (tg >= 0) unsafeAtomicAdd(dfm + (size_t)tg * 64 + lane, SHERF_RLF(wfm[k]) * d0);
+                }
+                // voxel levels 0, 1: per corner one instruction for channels 0-63, per corner PAIR one for channels 64-95
+#pragma unroll
+                for (int L = 0; L < 3; ++L) {
+                    if (L == 2 && reg2) break;
+                    float* drow = drows[L];
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const int tA = SHERF_RL(tv[8 * L + k]), tB = SHERF_RL(tv[8 * L + k + 1]);
+                        const float wA = SHERF_RLF(wvx[8 * L + k]), wB = SHERF_RLF(wvx[8 * L + k + 1]);
+                        if (tA >= 0) unsafeAtomicAdd(drow + (size_t)tA * 96 + lane, wA * d0);
+                        if (tB >= 0) unsafeAtomicAdd(drow + (size_t)tB * 96 + lane, wB * d0);
+                        if (tA < 0 && tB < 0) continue;
+                        const int tg = half ? tB : tA;
+                        if (tg >= 0) unsafeAtomicAdd(drow + (size_t)tg * 96 + 64 + c31, (half ? wB : wA) * d1);
+                    }
+                }
+                // coarsest level: the bin's own eight corners, summed in registers
+                if (reg2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a2[k] += SHERF_RLF(wvx[16 + k]) * d0;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int tg = SHERF_RL(tf[k]);
-                        const float v = SHERF_RLF(wfm[k]) * d0;
-                        if (tg >= 0) atomicAdd(acc_f + tg + lane, v);
-                        else if (tg < -1) unsafeAtomicAdd(reinterpret_cast<float*>(d_feat_f) + (size_t)(-2 - tg) * 64 + lane, v);
+                        const float wA = SHERF_RLF(wvx[16 + 2 * k]), wB = SHERF_RLF(wvx[16 + 2 * k + 1]);
+                        b2[k] += (half ? wB : wA) * d1;
                     }
-                    // voxel levels: per corner one instruction for channels 0-63, per corner PAIR one for channels 64-95
-#pragma unroll
-                    for (int L = 0; L < 3; ++L) {
-                        float* drow = drows[L];
-#pragma unroll
-                        for (int k = 0; k < 8; k += 2) {
-                            const int tA = SHERF_RL(tv[8 * L + k]), tB = SHERF_RL(tv[8 * L + k + 1]);
-                            const float wA = SHERF_RLF(wvx[8 * L + k]), wB = SHERF_RLF(wvx[8 * L + k + 1]);
-                            if (tA >= 0) atomicAdd(acc_v + tA + lane, wA * d0);
-                            else if (tA < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tA) * 96 + lane, wA * d0);
-                            if (tB >= 0) atomicAdd(acc_v + tB + lane, wB * d0);
-                            else if (tB < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tB) * 96 + lane, wB * d0);
-                            if (tA == -1 && tB == -1) continue;
-                            const int tg = half ? tB : tA;
-                            const float v = (half ? wB : wA) * d1;
-                            if (tg >= 0) atomicAdd(acc_v + tg + 64 + c31, v);
-                            else if (tg < -1) unsafeAtomicAdd(drow + (size_t)(-2 - tg) * 96 + 64 + c31, v);
-                        }
-                    }
+                }
 #undef SHERF_RL
 #undef SHERF_RLF
-                }
             }
         }
-        __syncthreads();
-        // ---- flush: the row of every window voxel, then one atomic per touched address ----
-        for (int v = tid; v < kRV; v += kBinNT) {
-            const int L = v < kR0 ? 0 : (v < kR0 + kR1 ? 1 : 2);
-            const int wd = L == 0 ? kW0 : (L == 1 ? kW1 : 2), q = v - (L == 0 ? 0 : (L == 1 ? kR0 : kR0 + kR1));
-            const sherf_vox_level& lev = lv.l[L];
-            const int ox = L == 2 ? c2x : s_org[3 * L], oy = L == 2 ? c2y : s_org[3 * L + 1], oz = L == 2 ? c2z : s_org[3 * L + 2];
-            const int xx = ox + q % wd, yy = oy + (q / wd) % wd, zz = oz + q / (wd * wd);
-            int row = -1;
-            if (ox != 0x7fffffff && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D) {
-                const int key = (zz * lev.H + yy) * lev.W + xx;
-                const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
-                const uint32_t bit = 1u << (key & 31);
-                if (rr.x & bit) row = (int)rr.y + __popc(rr.x & (bit - 1u));
+        // the wave's sums of the coarsest level: one atomic per row and channel
+        if (reg2 && wv * 64 < cnt) {
+            float* drow = drows[2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = __builtin_amdgcn_readlane(row2, k);
+                if (r >= 0) unsafeAtomicAdd(drow + (size_t)r * 96 + lane, a2[k]);
             }
-            s_row[v] = row;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rA = __builtin_amdgcn_readlane(row2, 2 * k), rB = __builtin_amdgcn_readlane(row2, 2 * k + 1);
+                const int r = half ? rB : rA;
+                if (r >= 0) unsafeAtomicAdd(drow + (size_t)r * 96 + 64 + c31, b2[k]);
+            }
         }
-        __syncthreads();
-        for (int i = tid; i < kRV * 24; i += kBinNT) {
-            const int v = i / 24, q = i % 24, row = s_row[v];
-            if (row < 0) continue;
-            const int L = v < kR0 ? 0 : (v < kR0 + kR1 ? 1 : 2);
-            const float4 val = *reinterpret_cast<const float4*>(acc_v + (size_t)v * 96 + 4 * q);
-            float* dst = lv.d_rows[L] + (size_t)row * 96 + 4 * q;
-            if (val.x != 0.f) unsafeAtomicAdd(dst + 0, val.x);
-            if (val.y != 0.f) unsafeAtomicAdd(dst + 1, val.y);
-            if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
-            if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
-        }
-        for (int i = tid; i < kRP * 8; i += kBinNT) {
-            const int t = i / 8, q = i % 8, p = t / (kWP * kWP), ly = (t / kWP) % kWP, lx = t % kWP;
-            if (s_org[6 + 2 * p] == 0x7fffffff) continue;
-            const int xx = s_org[6 + 2 * p] + lx, yy = s_org[7 + 2 * p] + ly;
-            if (!(xx >= 0 && xx < P && yy >= 0 && yy < P)) continue;
-            const float4 val = *reinterpret_cast<const float4*>(acc_p + (size_t)t * 32 + 4 * q);
-            float* dst = reinterpret_cast<float*>(d_planes_f + ((size_t)(p * P + yy) * P + xx) * 8 + q);
-            if (val.x != 0.f) unsafeAtomicAdd(dst + 0, val.x);
-            if (val.y != 0.f) unsafeAtomicAdd(dst + 1, val.y);
-            if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
-            if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
-        }
-        for (int i = tid; i < kRF * 16; i += kBinNT) {
-            const int t = i / 16, q = i % 16, ly = t / kWF, lx = t % kWF;
-            if (s_org[12] == 0x7fffffff) continue;
-            const int xx = s_org[12] + lx, yy = s_org[13] + ly;
-            if (!(xx >= 0 && xx < Wf && yy >= 0 && yy < Hf)) continue;
-            const float4 val = *reinterpret_cast<const float4*>(acc_f + (size_t)t * 64 + 4 * q);
-            float* dst = reinterpret_cast<float*>(d_feat_f + ((size_t)yy * Wf + xx) * 16 + q);
-            if (val.x != 0.f) unsafeAtomicAdd(dst + 0, val.x);
-            if (val.y != 0.f) unsafeAtomicAdd(dst + 1, val.y);
-            if (val.z != 0.f) unsafeAtomicAdd(dst + 2, val.z);
-            if (val.w != 0.f) unsafeAtomicAdd(dst + 3, val.w);
-        }
-        __syncthreads();
     }
     // d_tok_bias
-    for (int i = tid; i < 96; i += kBinNT) (&s_bias[0][0])[i] = 0.f;
+    for (int i = tid; i < 96; i += kBinNT) s_bias[i] = 0.f;
     __syncthreads();
-    atomicAdd(&s_bias[0][0] + (tid & 63), bs0);
-    if ((tid & 63) < 32) atomicAdd(&s_bias[2][0] + (tid & 63), bs1);
+    atomicAdd(s_bias + lane, bs0);
+    if (lane < 32) atomicAdd(s_bias + 64 + lane, bs1);
     __syncthreads();
-    for (int i = tid; i < 96; i += kBinNT) unsafeAtomicAdd(d_tok_bias + i, (&s_bias[0][0])[i]);
+    for (int i = tid; i < 96; i += kBinNT) unsafeAtomicAdd(d_tok_bias + i, s_bias[i]);
 }
 
 }  // namespace
@@ -954,10 +870,8 @@ extern "C" int sherf_gather_tokens_bwd_binned(const int32_t* counters, const flo
     hipLaunchKernelGGL(bin_count_kernel, dim3(sb), dim3(256), 0, st, counters, geom, lv.l[2], vox_min, sh, capacity, w);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(bin_fill_kernel, dim3(sb), dim3(256), 0, st, counters, capacity, w);
-    SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_tokens_bwd_binned_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kBinSmem));
     const int64_t max_list = capacity < n_bins ? capacity : n_bins;
-    hipLaunchKernelGGL(gather_tokens_bwd_binned_kernel, dim3((unsigned)(max_list < 2048 ? max_list : 2048)), dim3(kBinNT), kBinSmem, st, geom,
+    hipLaunchKernelGGL(gather_tokens_bwd_binned_kernel, dim3((unsigned)(max_list < 2048 ? max_list : 2048)), dim3(kBinNT), 0, st, geom,
                        reinterpret_cast<const float4*>(d_tokens), P, Hf, Wf, H, W, lv, bounds, vox_min, sh, w,
                        reinterpret_cast<float4*>(d_planes_f), reinterpret_cast<float4*>(d_feat_f), d_tok_bias, g_sherf_debug);
     SHERF_LAUNCH_CHECK();
