@@ -29,6 +29,11 @@ const char* sherf_bwd_last_error(void);
  * oracle/backward_explicit.py (decoder_bwd.lin_bwd, transformer_bwd). */
 int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float beta, sherf_stream_t stream);
+/* The same product with the layer's epilogue fused: C = act(op(A) op(B) + beta C + bias[column]), act 0 identity / 1 ReLU (bias may be
+ * NULL).  Fused into the tall-product kernel's store (the forward recompute of the Linear layers: one pass over [n, C] less per
+ * layer); a second small pass on the other paths. */
+int sherf_bwd_gemm_bias_act(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                            float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream);
 /* which kernel the last sherf_bwd_gemm call of this process took: 1 = tall MFMA (column-sliced when B exceeds the LDS), 2 = weight-
  * gradient MFMA, 0 = the plain fp32 kernel (tests assert that no layer shape of the path reaches it). */
 int sherf_bwd_gemm_last_path(void);
@@ -43,6 +48,9 @@ int sherf_bwd_tile_tokens(const float* d_tok, int64_t n, float* d_tokens_tiled, 
 int sherf_bwd_bias_act(float* y, int ldy, const float* bias, int64_t n, int C, int act, sherf_stream_t stream);
 /* d[r][c] = h[r][c] > 0 ? d[r][c] : 0  (ReLU backward through the stored post-activation). */
 int sherf_bwd_relu_mask(float* d, int ldd, const float* h, int ldh, int64_t n, int C, sherf_stream_t stream);
+/* d *= [h > 0] and out[c] += sum_r d[r][c] in one pass (ReLU backward + the bias gradient of the layer that produced h); C divides 256;
+ * out accumulates (zeroed by the caller). */
+int sherf_bwd_relu_mask_colsum(float* d, int ldd, const float* h, int ldh, int64_t n, int C, float* out, sherf_stream_t stream);
 /* out[c] += sum_r d[r][c]   (bias gradients; out must be zeroed by the caller). */
 int sherf_bwd_colsum(const float* d, int ldd, int64_t n, int C, float* out, sherf_stream_t stream);
 /* dst[r][0..C) (+)= src[r][0..C): strided column-block copy (add != 0: accumulate). */

@@ -70,6 +70,16 @@ class HipOps:
         assert K == K2 and C.rows == M and C.cols == N, ('gemm shapes', tA, tB, A.rows, A.cols, B.rows, B.cols, C.rows, C.cols)
         _lib.call_bwd('sherf_bwd_gemm', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta), self.st)
 
+    def gemm_bias_act(self, tA, tB, A, B, C, bias, act, beta=0.0):
+        M, K = (A.cols, A.rows) if tA else (A.rows, A.cols)
+        K2, N = (B.cols, B.rows) if tB else (B.rows, B.cols)
+        assert K == K2 and C.rows == M and C.cols == N and (bias is None or bias.rows * bias.cols == N), ('gemm_bias_act shapes', M, N, K)
+        _lib.call_bwd('sherf_bwd_gemm_bias_act', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta),
+                      None if bias is None else self._p(bias), act, self.st)
+
+    def relu_mask_colsum(self, D, H, out):
+        _lib.call_bwd('sherf_bwd_relu_mask_colsum', self._p(D), D.ld, self._p(H), H.ld, D.rows, D.cols, self._p(out), self.st)
+
     def bias_act(self, Y, bias, act):
         _lib.call_bwd('sherf_bwd_bias_act', self._p(Y), Y.ld, None if bias is None else self._p(bias), Y.rows, Y.cols, act, self.st)
 
@@ -172,19 +182,20 @@ def dense_backward(ops, state, tok, ext, d_sample):
     def lin_fwd(x, wname, act, out=None):
         W = P(wname + '.weight')                                   # [out, in]
         y = out if out is not None else E(x.rows, W.rows)
-        ops.gemm(0, 1, x, W, y)
-        ops.bias_act(y, P(wname + '.bias') if (wname + '.bias') in state else None, act)
+        ops.gemm_bias_act(0, 1, x, W, y, P(wname + '.bias') if (wname + '.bias') in state else None, act)       # (bias + ReLU in the product's store)
         return y
 
-    def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True):
-        """grads of y = x W^T + b; returns d_x (accumulated into d_in with beta)."""
+    def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True, db=None):
+        """grads of y = x W^T + b; returns d_x (accumulated into d_in with beta).  db: the bias gradient when the caller already has it
+        (relu_mask_colsum sums the columns while it masks)."""
         W = P(wname + '.weight')
         dW = E(W.rows, W.cols)
         ops.gemm(1, 0, d_out, x, dW)
         grads[wname + '.weight'] = dW.tensor().view(state[wname + '.weight'].shape).clone()
         if bias and (wname + '.bias') in state:
-            db = Z(1, W.rows)
-            ops.colsum(d_out, db)
+            if db is None:
+                db = Z(1, W.rows)
+                ops.colsum(d_out, db)
             grads[wname + '.bias'] = db.tensor().view(-1).clone()
         dx = d_in if d_in is not None else E(d_out.rows, W.cols)
         ops.gemm(0, 0, d_out, W, dx, beta)
@@ -247,15 +258,17 @@ def dense_backward(ops, state, tok, ext, d_sample):
     ops.copy2d(d_lin, d_sample.colslice(0, 3))
     ops.rgb_bwd(d_lin, rgb)
     d_g = lin_bwd(d_lin, g, d + 'rgb_linear')
-    ops.relu_mask(d_g, g)
-    d_vin = lin_bwd(d_g, vin, d + 'views_linear')
+    db_v = Z(1, g.cols)
+    ops.relu_mask_colsum(d_g, g, db_v)
+    d_vin = lin_bwd(d_g, vin, d + 'views_linear', db=db_v)
     d_sigma = d_sample.colslice(3, 4)
     d_h = lin_bwd(d_vin.colslice(0, 128), h7, d + 'feature_linear')
     lin_bwd(d_sigma, h7, d + 'alpha_linear', d_in=d_h, beta=1.0)
     d_x0 = E(n, 71)
     for i in range(7, -1, -1):
-        ops.relu_mask(d_h, hs[i])
-        d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}')
+        db_i = Z(1, d_h.cols)
+        ops.relu_mask_colsum(d_h, hs[i], db_i)
+        d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}', db=db_i)
         if i == 5:
             ops.copy2d(d_x0, d_in.colslice(0, 71))                  # (first contribution: plain copy, d_x0 starts uninitialised)
             d_h = d_in.colslice(71, 199)

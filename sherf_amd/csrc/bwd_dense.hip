@@ -63,6 +63,27 @@ __global__ void colsum_kernel(const float* __restrict__ d, int ldd, int64_t n, i
     }
 }
 
+// d *= [h > 0] and out[c] += sum_r d[r][c] in one pass (the masked gradient is the next layer's d_out: its column sums are that
+// layer's bias gradient).  C divides 256: the 256 / C row groups of a workgroup walk its 512 rows interleaved.
+__global__ void __launch_bounds__(256) relu_mask_colsum_kernel(float* __restrict__ d, int ldd, const float* __restrict__ h, int ldh, int64_t n, int C,
+                                                               float* __restrict__ out) {
+    __shared__ float s_part[256];
+    const int G = 256 / C, g = threadIdx.x / C, c = threadIdx.x % C;
+    const int64_t r0 = (int64_t)blockIdx.x * 512, r1 = r0 + 512 < n ? r0 + 512 : n;
+    float a = 0.f;
+    for (int64_t r = r0 + g; r < r1; r += G) {
+        float v = d[r * ldd + c];
+        if (!(h[r * ldh + c] > 0.f)) { v = 0.f; d[r * ldd + c] = 0.f; }
+        a += v;
+    }
+    s_part[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0) {
+        for (int q = 1; q < G; ++q) a += s_part[q * C + c];
+        unsafeAtomicAdd(out + c, a);
+    }
+}
+
 __global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int64_t n, int C, int add) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * C) return;
@@ -345,6 +366,12 @@ extern "C" int sherf_bwd_bias_act(float* y, int ldy, const float* bias, int64_t 
 extern "C" int sherf_bwd_relu_mask(float* d, int ldd, const float* h, int ldh, int64_t n, int C, sherf_stream_t stream) {
     SHERF_CHECK_ARG(d && h && n > 0 && C > 0 && ldd >= C && ldh >= C);
     hipLaunchKernelGGL(relu_mask_kernel, SHERF_GRID(n * C), 0, as_stream(stream), d, ldd, h, ldh, n, C);
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_relu_mask_colsum(float* d, int ldd, const float* h, int ldh, int64_t n, int C, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(d && h && out && n > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldd >= C && ldh >= C);
+    hipLaunchKernelGGL(relu_mask_colsum_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, as_stream(stream), d, ldd, h, ldh, n, C, out);
     SHERF_LAUNCH_CHECK();
 }
 

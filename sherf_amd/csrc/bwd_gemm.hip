@@ -65,7 +65,8 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
-                                                        float* __restrict__ C, int ldc, int M, int N, int K, float beta) {
+                                                        float* __restrict__ C, int ldc, int M, int N, int K, float beta,
+                                                        const float* __restrict__ bias, int act) {
     extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, mid, lo][64 lanes]
     const int nkb = (K + 15) / 16;
     for (int idx = threadIdx.x; idx < nkb * NT * 64; idx += 256) {
@@ -123,7 +124,11 @@ __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = tile * 32 + acc_row(r, h), cc = 32 * nt + i;
-                if (rr < M && cc < N) C[(size_t)rr * ldc + cc] = acc[nt][r];
+                if (rr < M && cc < N) {              // epilogue of sherf_bwd_gemm_bias_act: + bias[column], ReLU (act 1)
+                    float v = acc[nt][r];
+                    if (bias) v += bias[cc];
+                    C[(size_t)rr * ldc + cc] = act == 1 ? fmaxf(v, 0.f) : v;
+                }
             }
     }
 }
@@ -212,13 +217,37 @@ __global__ void plain_gemm_kernel(int transA, int transB, int M, int N, int K, c
     *p = beta == 0.f ? s : s + beta * *p;
 }
 
+// y += bias[column], ReLU (act 1): the epilogue as its own pass, for the products that do not take the tall path
+__global__ void bias_act_tail_kernel(float* __restrict__ y, int ldy, const float* __restrict__ bias, int64_t n, int C, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    const float v = y[r * ldy + c] + (bias ? bias[c] : 0.f);
+    y[r * ldy + c] = act == 1 ? fmaxf(v, 0.f) : v;
+}
+
 }  // namespace
 
 static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA, 2 = weight-gradient MFMA, 0 = plain
 extern "C" int sherf_bwd_gemm_last_path() { return g_last_path; }
 
+static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream);
+
 extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, float beta, sherf_stream_t stream) {
+    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, nullptr, 0, stream);
+}
+
+extern "C" int sherf_bwd_gemm_bias_act(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                       float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(act == 0 || act == 1);
+    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, bias, act, stream);
+}
+
+static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream) {
     SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
     hipStream_t st = as_stream(stream);
     const int NT = (N + 31) / 32, nkb = (K + 15) / 16;
@@ -236,7 +265,7 @@ extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const
             float* Cs = C + n0;
 #define SHERF_TALL(n) case n: \
             if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-            hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta); break
+            hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta, bias ? bias + n0 : nullptr, act); break
             switch (NTs) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
 #undef SHERF_TALL
         }
@@ -256,9 +285,11 @@ extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const
 #undef SHERF_WGN
 #undef SHERF_WG
         g_last_path = 2;
+        if (bias || act) hipLaunchKernelGGL(bias_act_tail_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, C, ldc, bias, (int64_t)M, N, act);
         SHERF_LAUNCH_CHECK();
     }
     g_last_path = 0;
     hipLaunchKernelGGL(plain_gemm_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta);
+    if (bias || act) hipLaunchKernelGGL(bias_act_tail_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, C, ldc, bias, (int64_t)M, N, act);
     SHERF_LAUNCH_CHECK();
 }

@@ -12,7 +12,15 @@ class EmuOps:
         a = A.tensor().t() if tA else A.tensor()
         b = B.tensor().t() if tB else B.tensor()
         assert a.shape[1] == b.shape[0] and (C.rows, C.cols) == (a.shape[0], b.shape[1])
-        C.tensor().copy_(a @ b + beta * C.tensor())
+        C.tensor().copy_(a @ b + beta * C.tensor() if beta != 0.0 else a @ b)        # (beta == 0: C is not read, as in the kernels)
+
+    def gemm_bias_act(self, tA, tB, A, B, C, bias, act, beta=0.0):   # sherf_bwd_gemm_bias_act
+        self.gemm(tA, tB, A, B, C, beta)
+        self.bias_act(C, bias, act)
+
+    def relu_mask_colsum(self, D, H, out):                           # sherf_bwd_relu_mask_colsum (out accumulates)
+        self.relu_mask(D, H)
+        self.colsum(D, out)
 
     def bias_act(self, Y, bias, act):                                # sherf_bwd_bias_act
         y = Y.tensor() + (bias.tensor().view(-1) if bias is not None else 0.0)

@@ -93,6 +93,20 @@ def test_dense_entry_points_match_their_specification(cpu_lib, monkeypatch):
     s_c, s_g = Mat(torch.zeros(40), 1, 40), Mat(torch.zeros(40), 1, 40)
     e.colsum(d_c, s_c); h.colsum(d_g, s_g); _same(s_c, s_g)
     e.copy2d(y_c.colslice(3, 20), d_c.colslice(0, 17), add=True); h.copy2d(y_g.colslice(3, 20), d_g.colslice(0, 17), add=True); _same(y_c, y_g)
+    # the fused forms: ReLU mask + column sums in one pass (C divides 256), bias + ReLU in the product's store (tall path and the others)
+    for C in (64, 128):
+        m_c, m_g = _pair(1100, C, C + 5, 21); hh_c, hh_g = _pair(1100, C, C + 2, 22)
+        o_c, o_g = Mat(torch.zeros(C), 1, C), Mat(torch.zeros(C), 1, C)
+        e.relu_mask_colsum(m_c, hh_c, o_c); h.relu_mask_colsum(m_g, hh_g, o_g); _same(m_c, m_g); _same(o_c, o_g, 1e-4)
+    for tA, tB, (M, N, K) in ((0, 1, (700, 128, 71)), (0, 1, (700, 3, 64)), (1, 0, (40, 24, 300)), (1, 1, (9, 7, 5))):
+        for act, with_bias in ((1, True), (0, True), (1, False)):
+            a_c, a_g = _pair(*((K, M) if tA else (M, K)), seed=23)
+            bb_c, bb_g = _pair(*((N, K) if tB else (K, N)), seed=24)
+            c_c, c_g = _pair(M, N, ld=N + 3, seed=25)
+            bi_c, bi_g = _pair(1, N, seed=26)
+            e.gemm_bias_act(tA, tB, a_c, bb_c, c_c, bi_c if with_bias else None, act, 0.5)
+            h.gemm_bias_act(tA, tB, a_g, bb_g, c_g, bi_g if with_bias else None, act, 0.5)
+            _same(c_c, c_g, 1e-4)
     x_c, x_g = _pair(n, 3, 12, 7)
     for NF in (4, 5, 6):
         o_c, o_g = _pair(n, 3 + 6 * NF, 45, 8)
