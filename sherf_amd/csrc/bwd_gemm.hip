@@ -87,6 +87,12 @@ __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const bool vec = (lda % 4 == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
     const int n_tiles = (M + 31) / 32;
+    // bias of this lane's column of every tile, read once: in the store loop it
+    // was re-read per element behind the stores (the product got 30 % slower, profiles/r03_train_step_j_rocprofv3_stats.txt)
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && 32 * nt + i < N) ? bias[32 * nt + i] : 0.f;
+    const bool relu = act == 1;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int row = tile * 32 + i;
         f32x16 acc[NT];
@@ -124,11 +130,7 @@ __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = tile * 32 + acc_row(r, h), cc = 32 * nt + i;
-                if (rr < M && cc < N) {              // epilogue of sherf_bwd_gemm_bias_act: + bias[column], ReLU (act 1)
-                    float v = acc[nt][r];
-                    if (bias) v += bias[cc];
-                    C[(size_t)rr * ldc + cc] = act == 1 ? fmaxf(v, 0.f) : v;
-                }
+                if (rr < M && cc < N) { const float v = acc[nt][r] + bv[nt]; C[(size_t)rr * ldc + cc] = relu ? fmaxf(v, 0.f) : v; }   // epilogue of sherf_bwd_gemm_bias_act
             }
     }
 }
