@@ -63,13 +63,17 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // ---------------------------------------------------------------------------------------------------------------
 // tall: C[M,N] = A[M,K] . S + beta C,   S[k][n] = transB ? B[n * ldb + k] : B[k * ldb + n]
 // ---------------------------------------------------------------------------------------------------------------
+// Eight waves per workgroup (two per SIMD) share the B fragments: with four, a CU whose LDS holds one workgroup's fragments (96 KiB at
+// N = K = 128) ran ONE wave per SIMD -- nothing to overlap a tile's A loads and operand splits with another tile's MFMAs (35 % of the MFMA
+// rate its six products per term allow, profiles/r03_train_step_j_rocprofv3_stats.txt).
+constexpr int kTallWaves = 8;
 template <int NT>
-__global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
+__global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
                                                         float* __restrict__ C, int ldc, int M, int N, int K, float beta,
                                                         const float* __restrict__ bias, int act) {
     extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, mid, lo][64 lanes]
     const int nkb = (K + 15) / 16;
-    for (int idx = threadIdx.x; idx < nkb * NT * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < nkb * NT * 64; idx += 64 * kTallWaves) {
         const int l = idx & 63, nt = (idx >> 6) % NT, kb = idx / (64 * NT);
         const int n = 32 * nt + (l & 31), k0 = 16 * kb + 8 * (l >> 5);
         float v[8];
@@ -93,7 +97,7 @@ __global__ void __launch_bounds__(256) tall_gemm_kernel(const float* __restrict_
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && 32 * nt + i < N) ? bias[32 * nt + i] : 0.f;
     const bool relu = act == 1;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    for (int tile = blockIdx.x * kTallWaves + wave; tile < n_tiles; tile += gridDim.x * kTallWaves) {
         const int row = tile * 32 + i;
         f32x16 acc[NT];
 #pragma unroll
@@ -259,7 +263,7 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
     // backward stays on the MFMA path (tests/test_backward_dense.py: test_decoder_shapes_stay_on_mfma).
     const int nt_fit = min(8, (int)((156 * 1024) / ((size_t)nkb * 3072)));
     if (!transA && nt_fit >= 1 && NT <= 4 * nt_fit) {
-        const int tiles = (M + 31) / 32, grid = min((tiles + 3) / 4, n_cus());
+        const int tiles = (M + 31) / 32, grid = min((tiles + kTallWaves - 1) / kTallWaves, n_cus());
         for (int n0 = 0; n0 < N; n0 += 32 * nt_fit) {
             const int Ns = min(N - n0, 32 * nt_fit), NTs = (Ns + 31) / 32;
             const size_t smem = (size_t)nkb * NTs * 3072;
@@ -267,7 +271,7 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
             float* Cs = C + n0;
 #define SHERF_TALL(n) case n: \
             if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-            hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(256), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta, bias ? bias + n0 : nullptr, act); break
+            hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta, bias ? bias + n0 : nullptr, act); break
             switch (NTs) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
 #undef SHERF_TALL
         }

@@ -380,3 +380,34 @@ def test_gather_backward_kernel(binned):
         ref = BX.trilinear_sparse_bwd(keys, feats.shape[0], shape, r['grid'], dt.reshape(n, 96))
         assert G.rel(dr.tensor().cpu()[:feats.shape[0]], ref) < 1e-4
     assert G.rel(d_bias.tensor().cpu().view(3, 32), dt.sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('prec', [0, 1, 2])
+def test_device_weight_pack_is_the_host_packer_bit_for_bit(prec):
+    """sherf_mlp_pack_stream on the MI355X (the MLP's weight stream re-packed by a kernel after every optimiser update) == mlp_pack.pack on
+    the host, including the fp16 `lo` fragments that are denormal in fp16 (2^-11 of a small weight); its flag word reports out-of-range
+    and non-finite weights."""
+    import ctypes
+    import numpy as np
+    from sherf_amd import _lib, mlp_pack
+    state = G.seeded_state()
+    sd = {k: v.numpy() for k, v in state.items() if not k.startswith('renderer.encoder_3d.')}
+    stream, wbias, _ = mlp_pack.pack(sd, prec=prec)
+    names = mlp_pack.packed_names()
+    src, bsrc, n_flat = mlp_pack.stream_index({n: sd[n].shape for n in names}, prec=prec)
+    flat = torch.cat([state[n].float().reshape(-1) for n in names]).cuda()
+    src_t, bsrc_t = torch.from_numpy(src).cuda(), torch.from_numpy(bsrc).cuda()
+
+    def run(flat):
+        out = torch.zeros(2 * src.size, dtype=torch.uint8, device='cuda')
+        wb, flag = torch.zeros(bsrc.size, device='cuda'), torch.full((1,), 7, dtype=torch.int32, device='cuda')
+        _lib.call('sherf_mlp_pack_stream', _lib.ptr(flat), _lib.ptr(src_t), src.size, prec, _lib.ptr(out), _lib.ptr(bsrc_t), bsrc.size, _lib.ptr(wb),
+                  _lib.ptr(flag), _lib.stream())
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), wb.cpu().numpy(), int(flag)
+    out, wb, flag = run(flat)
+    assert flag == 0 and np.array_equal(out, stream) and np.array_equal(wb, wbias)
+    big = flat.clone(); big[int(src[src >= 0][0]) >> 1] = 1e5
+    assert run(big)[2] == (0 if prec == 0 else 2)
+    nan = flat.clone(); nan[int(src[src >= 0][5]) >> 1] = float('nan')
+    assert run(nan)[2] & 1
