@@ -102,7 +102,7 @@ def time_frames(w, steps, warmup, dev):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None):
+def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=False):
     """`sherf_nerf_mlp` alone on the tokens of the frame `w` rendered last, in `precision`: (ms per launch from HIP events on the
     launch stream, its [nv, 4] output)."""
     import ctypes as ct
@@ -114,6 +114,8 @@ def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None):
     ws, cap = rend.last['ws'], int(rend.last['cap'])
     wc = rend._weights(w['dec'], dev, precision)
     nv = int(ws['counters'][0])
+    if exact_grid:                                  # launch for the frame's own sample count instead of the buffers' capacity (R * S): no workgroup
+        cap = max((nv + 255) // 256 * 256, 256)     # that only reads the count and exits
     out = torch.empty(max((nv + 31) // 32 * 32, 32), 4, device=dev)
     A = _lib.addr
     st = torch.cuda.current_stream(dev)
@@ -143,6 +145,8 @@ def secondary_measurements(a, w, dev, nv, R):
         sig = ref[:, 3].clamp(min=0)
         fl = lambda ms: nv * FLOP_PER_VALID_SAMPLE / (ms * 1e-3) / 1e12
         rows = dict(f16x3=dict(kernel_ms=ms3, achieved_tflops=fl(ms3), frac=fl(ms3) / PEAK_BF16_TFLOPS, mfma_per_product=3))
+        rows['f16_exact_grid'] = dict(kernel_ms=mlp_kernel_alone(w, 'f16', dev, exact_grid=True)[0],
+                                      note='the f16 launch sized for the valid samples instead of the capacity R * S: what the empty workgroups of the in-frame launch cost')
         for name in ('f16', 'bf16'):
             ms1, got = mlp_kernel_alone(w, name, dev)
             rows[name] = dict(kernel_ms=ms1, achieved_tflops=fl(ms1), frac=fl(ms1) / PEAK_BF16_TFLOPS, mfma_per_product=1,
