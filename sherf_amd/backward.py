@@ -59,7 +59,7 @@ def render_backward(renderer, decoder, d_rgb, d_acc):
     if n == 0:
         raise RuntimeError('render_backward: no valid sample in the last frame')
     # ---- a13 + a14 ----
-    tok, ext = Mat.zeros(n, 96, dev), Mat.zeros(n, 12, dev)
+    tok, ext = Mat.empty(n, 96, dev), Mat.empty(n, 12, dev)                 # (sherf_bwd_untile writes both in full)
     ops.untile(ws['tokens'], ws['extras'], n, tok, ext)
     d_tin, grads, dWb_pe = dense_backward(ops, state, tok, ext, Mat(d_sample.view(-1), n, 4))
     # ---- a10-a13 ----

@@ -22,13 +22,14 @@ def taps_backward(ops, state, ctx, d_tin, dWb_pe):
     n, P, Hf, Wf = ctx['n'], ctx['P'], ctx['Hf'], ctx['Wf']
     dev = d_tin.buf.device
     Z = lambda r, c: Mat.zeros(r, c, dev)
+    E = lambda r, c: Mat.empty(r, c, dev)                           # written in full by the next kernel
     Wr = state['renderer.conv1d_reprojection.weight'].detach().float()[:, :, 0]
     Wp = state['renderer.conv1d_projection.weight'].detach().float()[:, :, 0]
     bp = state['renderer.conv1d_projection.bias'].detach().float()
     Wa, Wb, Wc = Wr[:, 0:32].contiguous(), Wr[:, 32:64].contiguous(), Wr[:, 64:96].contiguous()
     # ---- (i) scatter ----
     tiles = (n + 31) // 32
-    d_tiled = torch.zeros(tiles * 3 * 8 * 32 * 4, dtype=torch.float32, device=dev)
+    d_tiled = Mat.empty(1, tiles * 3 * 8 * 32 * 4, dev).buf            # (sherf_bwd_tile_tokens writes every padded tile)
     ops.tile_tokens(d_tin, n, d_tiled)
     d_planes_f, d_feat_f, d_bias = Z(3 * P * P, 32), Z(Hf * Wf, 64), Z(1, 96)
     d_rows = [Z(lv['cap'], 96) for lv in ctx['levels']]
@@ -45,9 +46,9 @@ def taps_backward(ops, state, ctx, d_tin, dWb_pe):
     for (c0, c1), lv, d_row in zip(cols, ctx['levels'], d_rows):
         C = lv['C']
         Fcat = torch.cat([Wc @ Wp[32 * s:32 * s + 32, c0:c1] for s in range(3)], 0).contiguous()      # [96, C]
-        act = Z(lv['cap'], C)
+        act = E(lv['cap'], C)
         ops.bn_relu_apply(lv['raw'], lv['bnparam'], lv['n_rows'], act)
-        d_act, G = Z(lv['cap'], C), Z(96, C)
+        d_act, G = E(lv['cap'], C), E(96, C)
         ops.gemm(0, 0, d_row, Mat.of(Fcat), d_act)
         ops.gemm(1, 0, d_row, act, G)
         d_levels.append(d_act)
