@@ -26,18 +26,27 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bnparam, const float* __restrict__ stats,
                                                             const int32_t* __restrict__ mult, const int32_t* __restrict__ n_rows_p, int C,
                                                             float* __restrict__ sums) {
+    // C <= 128: the 256 / C row groups of a workgroup walk its 256 rows interleaved (with one thread per channel, 32-channel layers kept
+    // 32 of 256 threads busy), their partial sums meet in LDS, three atomics per channel per workgroup
+    __shared__ float s_part[3][256];
     const int n_rows = *n_rows_p;
     const int r0 = blockIdx.x * 256, r1 = min(r0 + 256, n_rows);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    const int G = 256 / C, g = threadIdx.x / C, c = threadIdx.x % C;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (g < G) {
         const float scale = bnparam[c], shift = bnparam[C + c], mean = stats[c], inv = 1.f / sqrtf(stats[C + c] + 1e-3f);
-        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int r = r0; r < r1; ++r) {
+        for (int r = r0 + g; r < r1; r += G) {
             const float x = raw[(size_t)r * C + c], d = d_out[(size_t)r * C + c];
             const float dy = (x * scale + shift > 0.f) ? d : 0.f;
             s1 += dy; s2 += dy * (x - mean) * inv;
             if (mult) s3 += (float)(mult[r] - 1) * d;
         }
-        if (r1 > r0) { unsafeAtomicAdd(sums + c, s1); unsafeAtomicAdd(sums + C + c, s2); unsafeAtomicAdd(sums + 2 * C + c, s3); }
+    }
+    s_part[0][threadIdx.x] = s1; s_part[1][threadIdx.x] = s2; s_part[2][threadIdx.x] = s3;
+    __syncthreads();
+    if (g == 0 && r1 > r0) {
+        for (int q = 1; q < G; ++q) { s1 += s_part[0][q * C + c]; s2 += s_part[1][q * C + c]; s3 += s_part[2][q * C + c]; }
+        unsafeAtomicAdd(sums + c, s1); unsafeAtomicAdd(sums + C + c, s2); unsafeAtomicAdd(sums + 2 * C + c, s3);
     }
 }
 
@@ -73,7 +82,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         if (!(m <= 3.0e38f)) m = 0.f;                    // (a non-finite gradient must not pick the scale; it still propagates as itself)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+        // (the maximum only grows: a wave whose candidate is not above the value already there skips the same-address atomic -- all but a few do)
+        if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > *reinterpret_cast<volatile uint32_t*>(amax)) atomicMax(amax, __float_as_uint(m));
     }
 }
 
