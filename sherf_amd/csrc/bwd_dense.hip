@@ -103,15 +103,18 @@ __global__ void __launch_bounds__(256) relu_mask_colsum_kernel(float* __restrict
     }
 }
 
-// 64 column lanes x 4 row lanes per workgroup, 16 rows per thread: no per-element 64-bit division (the flat-index form spent more on
-// i / C than on the copy), 256-byte row segments per wave.  grid = (row groups of 64, column groups of 64).
-__global__ void __launch_bounds__(256) copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int64_t n, int C, int add) {
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+// 2^cl column lanes x (256 >> cl) row lanes per workgroup, 16 rows per thread: no per-element 64-bit division (the flat-index form spent
+// more on i / C than on the copy); cl is chosen by the launcher so that narrow matrices ([n, 3], [n, 32]) still fill their waves.
+// grid = (row groups of 16 * (256 >> cl), column groups of 2^cl).
+__global__ void __launch_bounds__(256) copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int64_t n, int C, int add,
+                                                     int cl) {
+    const int c = (blockIdx.y << cl) + (threadIdx.x & ((1 << cl) - 1));
     if (c >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6);
+    const int rl = 256 >> cl;
+    const int64_t r0 = (int64_t)blockIdx.x * 16 * rl + (threadIdx.x >> cl);
 #pragma unroll 4
     for (int q = 0; q < 16; ++q) {
-        const int64_t r = r0 + 4 * q;
+        const int64_t r = r0 + (int64_t)q * rl;
         if (r >= n) break;
         const float v = src[r * lds + c];
         if (add) dst[r * ldd + c] += v; else dst[r * ldd + c] = v;
@@ -408,7 +411,11 @@ extern "C" int sherf_bwd_colsum(const float* d, int ldd, int64_t n, int C, float
 
 extern "C" int sherf_bwd_copy2d(float* dst, int ldd, const float* src, int lds, int64_t n, int C, int add, sherf_stream_t stream) {
     SHERF_CHECK_ARG(dst && src && n > 0 && C > 0 && ldd >= C && lds >= C);
-    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, as_stream(stream), dst, ldd, src, lds, n, C, add);
+    int cl = 2;                                     // column lanes: the smallest power of two >= min(C, 64), at least 4
+    while ((1 << cl) < C && cl < 6) ++cl;
+    const int rows_per_wg = 16 * (256 >> cl);
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg), (unsigned)((C + (1 << cl) - 1) >> cl)), dim3(256), 0,
+                       as_stream(stream), dst, ldd, src, lds, n, C, add, cl);
     SHERF_LAUNCH_CHECK();
 }
 

@@ -58,31 +58,40 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const int32_t* __restrict__ n_total_p, const int32_t* __restrict__ n_rows_p,
                                                            int64_t cap, int C, float* __restrict__ d_raw, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, uint32_t* __restrict__ amax) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float out = 0.f;
-    if (i < cap * C) {
-        const int64_t r = i / C;
-        const int c = (int)(i % C);
-        const float scale = bnparam[c], shift = bnparam[C + c], mean = stats[c], inv = 1.f / sqrtf(stats[C + c] + 1e-3f);
-        const float dy0 = shift > 0.f ? sums[2 * C + c] : 0.f, xh0 = -mean * inv;
-        const float s1 = sums[c] + dy0, s2 = sums[C + c] + dy0 * xh0;
-        if (blockIdx.x == 0 && r == 0) { dgamma[c] = s2; dbeta[c] = s1; }
-        if (r < *n_rows_p) {
-            const float N = (float)(*n_total_p);
-            const float x = raw[i];
-            const float dy = (x * scale + shift > 0.f) ? d_out[i] : 0.f;
-            out = (gamma[c] * inv / N) * (N * dy - s1 - (x - mean) * inv * s2);
+    // 32 channel lanes x 8 row lanes, 8 rows per thread (C is a multiple of 32 here; other widths leave lanes idle): the channel's
+    // constants are formed once per thread instead of once per element, and no element needs a 64-bit division.
+    // grid = (row groups of 64, channel groups of 32).
+    const int c = blockIdx.y * 32 + (threadIdx.x & 31);
+    const bool on = c < C;
+    const int cc = on ? c : 0;
+    const float scale = bnparam[cc], shift = bnparam[C + cc], mean = stats[cc], inv = 1.f / sqrtf(stats[C + cc] + 1e-3f);
+    const float dy0 = shift > 0.f ? sums[2 * C + cc] : 0.f, xh0 = -mean * inv;
+    const float s1 = sums[cc] + dy0, s2 = sums[C + cc] + dy0 * xh0;
+    if (on && blockIdx.x == 0 && threadIdx.x < 32) { dgamma[c] = s2; dbeta[c] = s1; }
+    const int n_rows = *n_rows_p;
+    const float N = (float)(*n_total_p);
+    const float k = gamma[cc] * inv / N;
+    float m = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 5);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int64_t r = r0 + 8 * q;
+        if (!on || r >= cap) continue;
+        float out = 0.f;
+        if (r < n_rows) {
+            const float x = raw[r * C + c];
+            const float dy = (x * scale + shift > 0.f) ? d_out[r * C + c] : 0.f;
+            out = k * (N * dy - s1 - (x - mean) * inv * s2);
         }
-        d_raw[i] = out;
+        d_raw[r * C + c] = out;
+        const float a = fabsf(out);
+        if (a <= 3.0e38f) m = fmaxf(m, a);           // (a non-finite gradient must not pick the scale; it still propagates as itself)
     }
     // max |d_raw| of the layer (bit pattern; non-negative floats order like unsigned integers): the scale of the MFMA input-gradient
     // convolution that reads d_raw next (sherf_svox_conv3_dgrad).  One atomic per wave that holds a new candidate.
     if (amax) {
-        float m = fabsf(out);
-        if (!(m <= 3.0e38f)) m = 0.f;                    // (a non-finite gradient must not pick the scale; it still propagates as itself)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-        // (the maximum only grows: a wave whose candidate is not above the value already there skips the same-address atomic -- all but a few do)
         if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > *reinterpret_cast<volatile uint32_t*>(amax)) atomicMax(amax, __float_as_uint(m));
     }
 }
@@ -236,8 +245,8 @@ extern "C" int sherf_bwd_bn_relu(const float* d_out, const float* raw, const flo
     if (amax) SHERF_HIP_CHECK(hipMemsetAsync(amax, 0, sizeof(uint32_t), as_stream(stream)));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, as_stream(stream), d_out, raw, bnparam, stats,
                        mult, n_rows, C, sums);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((cap * C + 255) / 256)), dim3(256), 0, as_stream(stream), d_out, raw, bnparam,
-                       stats, gamma, sums, n_total, n_rows, cap, C, d_raw, dgamma, dbeta, amax);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((cap + 63) / 64), (unsigned)((C + 31) / 32)), dim3(256), 0, as_stream(stream), d_out, raw,
+                       bnparam, stats, gamma, sums, n_total, n_rows, cap, C, d_raw, dgamma, dbeta, amax);
     SHERF_LAUNCH_CHECK();
 }
 
