@@ -224,6 +224,69 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const int32_t* __restri
     }
 }
 
+// The same for the channel pairs whose Cin divides 256 (compile-time CIN, COUT): entry e = t + 256 j of thread t has the SAME input
+// channel c = t % CIN for every j (co = t / CIN + (256 / CIN) j), so a row's x is read from LDS once and reused for all NJ = CIN COUT / 256
+// entries of the thread -- one LDS read per product instead of two (the generic kernel, rows innermost, is LDS-bandwidth bound) -- and a
+// thread holds NJ accumulators instead of 36 (4 at 32 -> 32: more workgroups per CU).
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv_wgrad_fast_kernel(const int32_t* __restrict__ keys_o, const int32_t* __restrict__ n_rows_o, int Do, int Ho,
+                                                              int Wo, const uint2* __restrict__ wp_i, int Di, int Hi, int Wi,
+                                                              const float* __restrict__ in_raw, const float* __restrict__ in_bn,
+                                                              const int32_t* __restrict__ in_mult, const float* __restrict__ d_raw, int mode,
+                                                              float* __restrict__ dW) {
+    static_assert(256 % CIN == 0 && (CIN * COUT) % 256 == 0, "channel pair not covered by the fast kernel");
+    constexpr int NJ = CIN * COUT / 256, CSTEP = 256 / CIN;
+    __shared__ float s_x[32 * CIN], s_d[32 * COUT];
+    __shared__ int s_nb[32];
+    const int tap = blockIdx.x;
+    const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+    const int n_rows = *n_rows_o;
+    const int n_chunks = (n_rows + 31) / 32;
+    const int c = threadIdx.x % CIN, co0 = threadIdx.x / CIN;
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+    for (int chunk = blockIdx.y; chunk < n_chunks; chunk += gridDim.y) {
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int row = chunk * 32 + threadIdx.x;
+            int nb = -1;
+            if (row < n_rows) {
+                int z, y, x;
+                unkey(keys_o[row], Ho, Wo, z, y, x);
+                nb = mode ? lookup(wp_i, Di, Hi, Wi, 2 * z + kz - 1, 2 * y + ky - 1, 2 * x + kx - 1)
+                          : lookup(wp_i, Di, Hi, Wi, z + kz - 1, y + ky - 1, x + kx - 1);
+            }
+            s_nb[threadIdx.x] = nb;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * CIN; i += 256) {
+            const int r = i / CIN, ci = i % CIN;
+            const int nb = s_nb[r];
+            float v = 0.f;
+            if (nb >= 0) {
+                v = in_raw[(size_t)nb * CIN + ci];
+                if (in_bn) v = fmaxf(v * in_bn[ci] + in_bn[CIN + ci], 0.f) + (in_mult ? (float)(in_mult[nb] - 1) * in_bn[2 * CIN + ci] : 0.f);
+            }
+            s_x[i] = v;
+        }
+        for (int i = threadIdx.x; i < 32 * COUT; i += 256) {
+            const int r = i / COUT, row = chunk * 32 + r;
+            s_d[i] = (row < n_rows && s_nb[r] >= 0) ? d_raw[(size_t)row * COUT + i % COUT] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r) {
+            const float x = s_x[r * CIN + c];
+            const float* dr = s_d + r * COUT + co0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] += dr[CSTEP * j] * x;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) unsafeAtomicAdd(dW + ((size_t)(co0 + CSTEP * j) * 27 + tap) * CIN + c, acc[j]);
+}
+
 // level-0 aggregation backward: every input row gets the gradient of the voxel it was summed into
 __global__ void __launch_bounds__(256) gather_rows_kernel(const int32_t* __restrict__ coord, int n, int D, int H, int W,
                                                           const uint2* __restrict__ wp, const float* __restrict__ d_g, int C,
@@ -268,6 +331,14 @@ extern "C" int sherf_bwd_conv_wgrad(const int32_t* keys_o, const int32_t* n_rows
     SHERF_CHECK_ARG(Cin > 0 && Cout > 0 && Cin * Cout <= 36 * 256);
     const size_t smem = (size_t)32 * (Cin + Cout) * 4 + 32 * 4;
     const int splits = max_rows / 32 / 8 > 0 ? (max_rows / 32 / 8 < 64 ? max_rows / 32 / 8 : 64) : 1;
+#define SHERF_WGRAD_FAST(CI, CO)                                                                                                       \
+    if (Cin == CI && Cout == CO) {                                                                                                     \
+        hipLaunchKernelGGL((conv_wgrad_fast_kernel<CI, CO>), dim3(27, splits), dim3(256), 0, as_stream(stream), keys_o, n_rows_o, Do, Ho, Wo, \
+                           reinterpret_cast<const uint2*>(wp_i), Di, Hi, Wi, in_raw, in_bn, in_mult, d_raw, mode, dW);                   \
+        SHERF_LAUNCH_CHECK();                                                                                                          \
+    }
+    SHERF_WGRAD_FAST(32, 32) SHERF_WGRAD_FAST(32, 64) SHERF_WGRAD_FAST(64, 64) SHERF_WGRAD_FAST(64, 96)
+#undef SHERF_WGRAD_FAST
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(27, splits), dim3(256), smem, as_stream(stream), keys_o, n_rows_o, Do, Ho, Wo,
                        reinterpret_cast<const uint2*>(wp_i), Di, Hi, Wi, in_raw, Cin, in_bn, in_mult, d_raw, Cout, mode, dW);
     SHERF_LAUNCH_CHECK();
