@@ -30,7 +30,19 @@ def mm(a, w, scheme):
         ah, al = split(a, dt); r = (D(ah) + D(al)) @ D(q(wt, dt))
     elif kind == 'x3':
         ah, al = split(a, dt); wh, wl = split(wt, dt); r = D(ah) @ D(wh) + D(ah) @ D(wl) + D(al) @ D(wh)
+    elif kind[:3] == 'x3n':
+        # main term hi.hi on the fp16 MFMA, the two cross terms (2^-11 of it) on the narrow-format scaled MFMA
+        # (v_mfma_scale_f32_32x32x64_f8f6f4): BOTH operands of a cross product then carry m significant bits (fp8 e4m3 / fp6 e2m3: m = 4,
+        # fp6 e3m2 / fp4: fewer), the block scale carrying the 2^-11.  Emulated optimistically: every element keeps its own exponent.
+        m = int(kind[3:])
+        ah, al = split(a, dt); wh, wl = split(wt, dt)
+        r = D(ah) @ D(wh) + D(qbits(ah, m)) @ D(qbits(wl, m)) + D(qbits(al, m)) @ D(qbits(wh, m))
     return r.float()
+
+def qbits(x, m):
+    """x rounded to m significant bits (round to nearest even), exponent unbounded."""
+    mant, ex = torch.frexp(x.double())
+    return torch.ldexp(torch.round(mant * (1 << m)) / (1 << m), ex).float()
 
 def run(state, tok, x_c, v_c, sch):
     """sch: dict layer-name -> scheme; default key '*'."""
@@ -60,9 +72,9 @@ def run(state, tok, x_c, v_c, sch):
     return rgb, sigma
 
 if __name__ == '__main__':
-    state = G.seeded_state()
     bf, fp = torch.bfloat16, torch.float16
     for cfg in sys.argv[1:] or ['tiny']:
+        state = G.state_for(cfg)                   # (the "_ri" configurations: the reference-init network)
         o = G.oracle_render(cfg)
         tok, x_c, v_c = o['tokens_in'], o['x_c'], o['v_c']
         rgb0, sig0 = run(state, tok, x_c, v_c, {'*': 'fp32'})
@@ -74,6 +86,8 @@ if __name__ == '__main__':
         rep('bf16 x1', {'*': ('x1', bf)}); rep('bf16 x3', {'*': ('x3', bf)})
         rep('fp16 x1', {'*': ('x1', fp)}); rep('fp16 x2w', {'*': ('x2w', fp)}); rep('fp16 x2a', {'*': ('x2a', fp)}); rep('fp16 x3', {'*': ('x3', fp)})
         rep('bf16 x2a', {'*': ('x2a', bf)}); rep('bf16 x2w', {'*': ('x2w', bf)})
+        for m in (4, 3, 2):
+            rep(f'fp16 hi.hi + {m}-bit cross terms', {'*': (f'x3n{m}', fp)})
         names = ['qkv','out','ff0','ff1'] + [f'L{i}' for i in range(8)] + ['alpha','feat','views','rgb']
         print('  one layer fp16 x1, rest fp32:')
         for nm in names: rep('   ' + nm, {'*': 'fp32', nm: ('x1', fp)})
