@@ -193,8 +193,10 @@ def test_dense_backward_through_the_real_kernels(cpu_lib, monkeypatch, golden_di
         assert st[k].grad is not None and rel(v, st[k].grad) < 2e-3, (k, rel(v, st[k].grad))
 
 
-@pytest.mark.parametrize('mode', [0, 1])
-def test_sparse_conv_gradient_kernels_on_cpu(cpu_lib, monkeypatch, mode):
+@pytest.mark.parametrize('mode,Cin,Cout', [(0, 32, 64), (1, 32, 64), (0, 32, 32), (1, 64, 64), (0, 64, 96), (1, 96, 96)])
+def test_sparse_conv_gradient_kernels_on_cpu(cpu_lib, monkeypatch, mode, Cin, Cout):
+    """sherf_bwd_conv_wgrad (the compile-time channel pairs of the fast kernel and the generic one: 96 -> 96) and the fp32 form of the input
+    gradient against their specification."""
     from tests.bwd_emulator import make_level
     e, h = EmuOps(), CpuKernelOps(cpu_lib, monkeypatch)
     g = torch.Generator().manual_seed(1)
@@ -203,7 +205,6 @@ def test_sparse_conv_gradient_kernels_on_cpu(cpu_lib, monkeypatch, mode):
         out_e, out_k = fine_e, fine_k
     else:
         out_e, out_k = make_level(torch.unique(torch.randint(0, 4 * 5 * 6, (70,), generator=g)), (4, 5, 6))
-    Cin, Cout = 32, 64
     in_raw = torch.randn(fine_e['cap'] * Cin, generator=g); d_raw = torch.randn(out_e['cap'] * Cout, generator=g)
     bn = torch.randn(3 * Cin, generator=g); mult = torch.randint(1, 3, (fine_e['cap'],), generator=g)
     W = torch.randn(Cout * 27 * Cin, generator=g)
