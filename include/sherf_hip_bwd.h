@@ -1,13 +1,14 @@
 /* sherf_hip_bwd.h -- C ABI of libsherf_hip_bwd.so: building blocks of the BACKWARD of SHERF's rendering hot path
  * (BASELINE config 5: forward render + backward through HIP kernels).
  *
- * EXPERIMENTAL. Written after round 1's GPU budget was spent: every entry point compiles for gfx950 and mirrors, loop for
- * loop, a function of oracle/backward_explicit.py that is verified on the CPU against autograd and against the unmodified
- * reference's gradients -- but none of it has run on hardware yet.  Kept in its own library (it links rocBLAS for the
- * plain GEMMs of the dense layers) so the forward library libsherf_hip.so is untouched.
+ * Every entry point mirrors a function of oracle/backward_explicit.py that is verified on the CPU against autograd and against the
+ * unmodified reference's gradients; the kernels are checked from their source on the CPU (tests/hipcpu) and on the MI355X
+ * (tests/test_gpu_backward.py).  Kept in its own library so that the forward library libsherf_hip.so carries no training code; no vendor
+ * math library is linked (the GEMMs are the MFMA kernels of csrc/bwd_gemm.hip).
  *
  * Conventions: as sherf_hip.h (device pointers, caller-owned, launch on `stream`, 0 / negative error code).  Matrices are
- * row-major fp32 with an explicit leading dimension (`ld*`, in elements).  Correctness first: fp32 everywhere.
+ * row-major fp32 with an explicit leading dimension (`ld*`, in elements).  fp32 storage everywhere; the products run on MFMA with
+ * the operands split into three bf16 parts (fp32 range, 24 bits).
  */
 #ifndef SHERF_HIP_BWD_H
 #define SHERF_HIP_BWD_H

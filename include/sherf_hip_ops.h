@@ -1,9 +1,9 @@
 /* sherf_hip_ops.h -- C ABI of libsherf_hip_ops.so: the reference's own two custom element-wise / FIR operators, used by the
  * per-frame PRODUCERS of the hot path's inputs (StyleGAN2 tri-plane backbone), as HIP kernels.
  *
- * EXPERIMENTAL: written after round 1's GPU budget was spent.  Both kernels are verified on the CPU from their unchanged source
- * (tests/hipcpu) against goldens produced by the unmodified reference's `_bias_act_ref` / `_upfirdn2d_ref`; they have not run on
- * hardware yet.  Kept in their own library so that libsherf_hip.so (the rendering hot path) is untouched.
+ * Both kernels are verified against goldens produced by the unmodified reference's `_bias_act_ref` / `_upfirdn2d_ref`: from their unchanged
+ * source on the CPU (tests/hipcpu) and on the MI355X (tests/test_gpu_ops.py).  Kept in their own library so that libsherf_hip.so (the
+ * rendering hot path) is untouched.
  *
  * Conventions as sherf_hip.h: device pointers, caller-owned dense buffers, launch on `stream`, 0 or a negative error code,
  * sherf_ops_last_error() for the text.  dtype: 0 = float32, 1 = float16 (arithmetic always in float32, as bias_act.cu:22-24).

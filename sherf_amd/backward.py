@@ -1,13 +1,13 @@
-"""Backward of the rendering hot path (BASELINE config 5: forward render + backward through HIP kernels) -- EXPERIMENTAL.
+"""Backward of the rendering hot path (BASELINE config 5: forward render + backward through HIP kernels).
 
-Status: every stage exists as HIP kernels + orchestration and is verified AS FAR AS A MACHINE WITHOUT A GPU ALLOWS:
+How it is verified:
   * the mathematics: oracle/backward_explicit.py (hand-derived backward) == autograd through the oracle == the unmodified
     reference's gradients (tests/test_backward_math.py, tests/golden/grad_*.npz);
   * the orchestration (shapes, strides, transposition flags, accumulation, order): the functions below run on the CPU against
     a torch emulation of every C entry point and reproduce those gradients (tests/test_backward_dense.py);
-  * the kernels themselves (csrc/bwd_dense.hip, csrc/bwd_encoder.hip, and the two *_bwd kernels of the forward library) compile
-    for gfx950 but have NOT run on hardware: their tests are staged under the `gpu_experimental` marker
-    (tests/test_gpu_backward.py), outside `-m gpu`.
+  * the kernels (csrc/bwd_dense.hip, csrc/bwd_gemm.hip, csrc/bwd_encoder.hip, and the backward entry points of the forward library):
+    from their unchanged source on the CPU (tests/test_hipcpu_kernels.py, tests/test_hipcpu_frame.py) and on the MI355X against the
+    reference's gradient fingerprints (tests/test_gpu_backward.py, part of `-m gpu`).
 
 Stages (backward order):  composite  ->  dense (decoder + transformer)  ->  taps / slot fusion  ->  sparse encoder.
 """
@@ -102,7 +102,7 @@ def render_backward(renderer, decoder, d_rgb, d_acc):
 
 class RenderFunction(torch.autograd.Function):
     """autograd node around ImportanceRenderer.forward: (planes, obs_input_feature, sparse-voxel features, *parameters) ->
-    (rgb, depth, acc).  Opt-in (`renderer.enable_autograd = True`) while the backward kernels are unverified on hardware.
+    (rgb, depth, acc).  Opt-in per renderer (`renderer.enable_autograd = True`; `sherf_amd.install()` sets it for the class).
     The depth output carries no gradient (as in the reference's losses, loss.py:103-176)."""
 
     @staticmethod

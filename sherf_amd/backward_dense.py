@@ -1,13 +1,13 @@
-"""Backward of the per-sample dense stage (a13 + a14: slot-2 rgb encoding, transformer, NeRF decoder) -- EXPERIMENTAL.
+"""Backward of the per-sample dense stage (a13 + a14: slot-2 rgb encoding, transformer, NeRF decoder).
 
-Correctness-first formulation: the forward of the valid samples is recomputed in fp32, row-major [n, C], as a sequence of
-plain GEMMs (rocBLAS through `sherf_bwd_gemm`) and small element-wise HIP kernels, every activation kept in HBM (~6 KB per
-valid sample; 288 GB of HBM make that a non-issue), then back-propagated layer by layer.  It mirrors
-oracle/backward_explicit.py (decoder_bwd, transformer_bwd) line for line; the orchestration below is itself checked on the
-CPU by running it against a torch emulation of the C entry points (tests/bwd_emulator.py, tests/test_backward_dense.py),
-so what remains unverified until the next GPU session are the ~15 small kernels of csrc/bwd_dense.hip.
+The forward of the valid samples is recomputed in fp32, row-major [n, C], as a sequence of MFMA GEMMs (`sherf_bwd_gemm[_bias_act]`,
+csrc/bwd_gemm.hip: hand-written, three-part bf16 operand split, no vendor library) and small element-wise HIP kernels, every
+activation kept in HBM (~6 KB per valid sample; 288 GB of HBM make that a non-issue), then back-propagated layer by layer.  It
+mirrors oracle/backward_explicit.py (decoder_bwd, transformer_bwd) line for line; the orchestration below is checked on the CPU
+against a torch emulation of the C entry points (tests/bwd_emulator.py, tests/test_backward_dense.py), the kernels from their source
+on the CPU and on the MI355X (tests/test_hipcpu_kernels.py, tests/test_gpu_backward.py).
 
-The fused MFMA forward kernel stays the forward of record; a fused backward replaces this once it is correct.
+The fused MFMA forward kernel stays the forward of record; a fused backward of the decoder would replace the recompute.
 """
 import ctypes
 

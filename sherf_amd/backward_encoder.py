@@ -1,4 +1,4 @@
-"""Backward of the sparse voxel encoder (a11) -- EXPERIMENTAL; mirrors oracle/backward_explicit.py: encoder_bwd.
+"""Backward of the sparse voxel encoder (a11); mirrors oracle/backward_explicit.py: encoder_bwd.
 
 Per conv layer, last to first:  BatchNorm+ReLU backward over the reference's row set (sherf_bwd_bn_relu), weight gradient
 over the forward's neighbour pairs (sherf_bwd_conv_wgrad), input gradient (sherf_bwd_conv_dgrad); the three tapped levels

@@ -1,4 +1,4 @@
-"""Backward of the feature taps and of the slot fusion (a10-a13) in the FOLDED formulation of the forward -- EXPERIMENTAL.
+"""Backward of the feature taps and of the slot fusion (a10-a13) in the FOLDED formulation of the forward.
 
 forward  tokens[n][s] = tok_bias_s + taps(planes_f[s]) + taps(feat_f[:, 32s:32s+32]) (s < 2) + taps(rows_fold_l[:, 32s:32s+32])
 backward (i)  one scatter of d_tokens with the forward's tap weights (sherf_gather_tokens_bwd, csrc/gather.hip)

@@ -1,6 +1,7 @@
-// Backward of the sparse voxel encoder (a11) -- EXPERIMENTAL, correctness first (fp32 VALU, no MFMA): mirrors
-// oracle/backward_explicit.py (_bn_relu_bwd, encoder_bwd), which is verified on the CPU against autograd and against the
-// unmodified reference's gradients.  Has not run on hardware yet.  Part of libsherf_hip_bwd.so (include/sherf_hip_bwd.h).
+// Backward of the sparse voxel encoder (a11): BatchNorm + ReLU backward, the weight gradient and the row scatter of the aggregation (fp32
+// VALU); the input gradient runs on the forward's MFMA convolution (csrc/svox.hip: sherf_svox_conv3_dgrad), its fp32 form here is kept
+// as the check.  Mirrors oracle/backward_explicit.py (_bn_relu_bwd, encoder_bwd), which is verified on the CPU against autograd and
+// against the unmodified reference's gradients.  Part of libsherf_hip_bwd.so (include/sherf_hip_bwd.h).
 #include "common.h"
 
 #include "../../include/sherf_hip_bwd.h"

@@ -2,7 +2,8 @@
 as a drop-in for `training.networks_stylegan2.Generator` (networks_stylegan2.py:538-561): same constructor arguments, the same
 parameter / buffer names and shapes (checkpoint contract: `copy_params_and_buffers(require_all=True)`, training_loop.py:207-208)
 and the same arithmetic, on PyTorch-ROCm's library convolutions plus the two HIP operators of libsherf_hip_ops.so
-(`sherf_amd.bias_act`, `sherf_amd.upfirdn2d`).  SURVEY.md section 8(f) rank 2; EXPERIMENTAL until it has run on hardware.
+(`sherf_amd.bias_act`, `sherf_amd.upfirdn2d`).  SURVEY.md section 8(f) rank 2; verified against the unmodified reference on the CPU and on the MI355X
+(tests/test_gpu_producers.py).
 
 Structure (reference lines in the docstrings): a resolution pyramid 4 -> img_resolution of SynthesisBlocks, each two modulated 3x3
 convolutions (the first one x2 up-sampling: transposed convolution, then the [1,3,3,1] FIR with gain 4) and a 1x1 ToRGB whose

@@ -9,8 +9,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_experimental: GPU tests of kernels not yet exercised on hardware (backward path); "
-                                       "NOT part of -m gpu, run with -m gpu_experimental")
 
 
 @pytest.fixture(scope="session")
