@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3, call P: last sanity at HEAD -- smoke() and a short bench line
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-torch-gpu-baseline --no-secondary --no-pmc 2>/dev/null | cut -c1-400
