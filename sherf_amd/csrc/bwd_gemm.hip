@@ -13,10 +13,7 @@
 //     or underflowed -- d_tokens_in came out 5e-3 off;
 //   * bf16 hi + lo (2^-16): range is fine, but the RECOMPUTED pre-activations carry 5e-5 of error, which flips ~5e-4 of the ReLU masks;
 //     a flipped mask changes a sample's gradient by O(1).
-// The forward RECOMPUTE (sherf_bwd_gemm_bias_act) is the exception since round 3: its operands are the forward's own activations and weights,
-// O(1) in magnitude, and the forward kernel itself computed them on the fp16 hi + lo split (22 bits) -- so does the recompute now (three
-// products instead of six, two LDS parts instead of three); 2^-22 on the pre-activations flips ~2e-6 of the masks, the forward's own
-// level.  The gradient products keep the three bf16 parts.
+// These GEMMs are < 1 % of the training step (section 8 of DESIGN.md), so the doubled MFMA count is free.
 //   tall_gemm  (transA 0): the small matrix is converted ONCE per workgroup into B-operand fragments in LDS (<= 104 KiB); persistent
 //              4-wave workgroups walk 32-row tiles of the tall operand, each wave its own tile, NT independent accumulator chains.
 //   wgrad_gemm (transA 1, transB 0): workgroups walk 16-sample steps of a slab of rows; both operand fragments are read straight
@@ -60,29 +57,6 @@ __device__ __forceinline__ f32x16 mfma6(const Frag& a, const Frag& b, f32x16 c) 
     c = mfma1(a.mid, b.hi, c); c = mfma1(a.hi, b.mid, c);
     return mfma1(a.hi, b.hi, c);
 }
-// fp16 hi + lo split (22 bits, THREE products per term) for operands of O(1): the forward RECOMPUTE of the Linear layers, whose inputs are
-// the forward's own activations and weights -- the forward kernel computed them in exactly this precision class (mlp.hip, f16x3).  Not for
-// gradients (see the header: fp16 has lost its precision at 1e-7).
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-struct Frag2 { u32x4 hi, lo; };
-__device__ __forceinline__ Frag2 split8_f16(const float (&v)[8]) {
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const _Float16 a = (_Float16)v[2 * p], b = (_Float16)v[2 * p + 1];
-        h[p] = __builtin_bit_cast(uint32_t, f16x2v{a, b});
-        l[p] = __builtin_bit_cast(uint32_t, f16x2v{(_Float16)(v[2 * p] - (float)a), (_Float16)(v[2 * p + 1] - (float)b)});
-    }
-    return Frag2{u32x4{h[0], h[1], h[2], h[3]}, u32x4{l[0], l[1], l[2], l[3]}};
-}
-__device__ __forceinline__ f32x16 mfma1h(const u32x4& a, const u32x4& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma3h(const Frag2& a, const Frag2& b, f32x16 c) {
-    c = mfma1h(a.lo, b.hi, c); c = mfma1h(a.hi, b.lo, c);
-    return mfma1h(a.hi, b.hi, c);
-}
 // accumulator register r of lane (j = lane & 31, h = lane >> 5) <-> tile row (r & 3) + 8 (r >> 2) + 4 h, tile column j
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -93,12 +67,11 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // N = K = 128) ran ONE wave per SIMD -- nothing to overlap a tile's A loads and operand splits with another tile's MFMAs (35 % of the MFMA
 // rate its six products per term allow, profiles/r03_train_step_j_rocprofv3_stats.txt).
 constexpr int kTallWaves = 8;
-template <int NT, bool F16>           // F16: fp16 hi + lo operands, three products (the forward recompute); else three bf16 parts, six products
+template <int NT>
 __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
                                                         float* __restrict__ C, int ldc, int M, int N, int K, float beta,
                                                         const float* __restrict__ bias, int act) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, mid, lo][64 lanes]  (F16: [hi, lo])
-    constexpr int P = F16 ? 2 : 3;
+    extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [nkb][NT][hi, mid, lo][64 lanes]
     const int nkb = (K + 15) / 16;
     for (int idx = threadIdx.x; idx < nkb * NT * 64; idx += 64 * kTallWaves) {
         const int l = idx & 63, nt = (idx >> 6) % NT, kb = idx / (64 * NT);
@@ -109,16 +82,10 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float*
             const int k = k0 + e;
             v[e] = (k < K && n < N) ? (transB ? B[(size_t)n * ldb + k] : B[(size_t)k * ldb + n]) : 0.f;
         }
-        if constexpr (F16) {
-            const Frag2 f = split8_f16(v);
-            s_frag[((kb * NT + nt) * P) * 64 + l] = f.hi;
-            s_frag[((kb * NT + nt) * P + 1) * 64 + l] = f.lo;
-        } else {
-            const Frag f = split8(v);
-            s_frag[((kb * NT + nt) * P) * 64 + l] = f.hi;
-            s_frag[((kb * NT + nt) * P + 1) * 64 + l] = f.mid;
-            s_frag[((kb * NT + nt) * P + 2) * 64 + l] = f.lo;
-        }
+        const Frag f = split8(v);
+        s_frag[((kb * NT + nt) * 3) * 64 + l] = f.hi;
+        s_frag[((kb * NT + nt) * 3 + 1) * 64 + l] = f.mid;
+        s_frag[((kb * NT + nt) * 3 + 2) * 64 + l] = f.lo;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -155,20 +122,11 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float*
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
             }
-            if constexpr (F16) {
-                const Frag2 a = split8_f16(v);
+            const Frag a = split8(v);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const u32x4* f = s_frag + ((kb * NT + nt) * P) * 64 + lane;
-                    acc[nt] = mfma3h(a, Frag2{f[0], f[64]}, acc[nt]);
-                }
-            } else {
-                const Frag a = split8(v);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const u32x4* f = s_frag + ((kb * NT + nt) * P) * 64 + lane;
-                    acc[nt] = mfma6(a, Frag{f[0], f[64], f[128]}, acc[nt]);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4* f = s_frag + ((kb * NT + nt) * 3) * 64 + lane;
+                acc[nt] = mfma6(a, Frag{f[0], f[64], f[128]}, acc[nt]);
             }
         }
 #pragma unroll
@@ -281,22 +239,21 @@ static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm ca
 extern "C" int sherf_bwd_gemm_last_path() { return g_last_path; }
 
 static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                     float* C, int ldc, float beta, const float* bias, int act, bool f16, sherf_stream_t stream);
+                     float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream);
 
 extern "C" int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, float beta, sherf_stream_t stream) {
-    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, nullptr, 0, false, stream);
+    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, nullptr, 0, stream);
 }
 
 extern "C" int sherf_bwd_gemm_bias_act(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                                        float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream) {
     SHERF_CHECK_ARG(act == 0 || act == 1);
-    // the layer-forward entry point: operands of O(1) (activations, weights) -> the fp16 hi + lo split, three products per term
-    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, bias, act, true, stream);
+    return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, bias, act, stream);
 }
 
 static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                     float* C, int ldc, float beta, const float* bias, int act, bool f16, sherf_stream_t stream) {
+                     float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream) {
     SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
     hipStream_t st = as_stream(stream);
     const int NT = (N + 31) / 32, nkb = (K + 15) / 16;
@@ -304,22 +261,19 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
     // the whole of B does not fit (the skip layer's data gradient dx = dy[n,128] . W[128,199]: 8 K-blocks x 7 tiles = 168 KiB), the
     // columns are cut into slices that do and the kernel is launched once per slice (offset B and C) -- every decoder shape of the
     // backward stays on the MFMA path (tests/test_backward_dense.py: test_decoder_shapes_stay_on_mfma).
-    const size_t frag_bytes = f16 ? 2048 : 3072;        // per (K-block, 32-column tile): two or three 1 KiB parts
-    const int nt_fit = min(8, (int)((156 * 1024) / ((size_t)nkb * frag_bytes)));
+    const int nt_fit = min(8, (int)((156 * 1024) / ((size_t)nkb * 3072)));
     if (!transA && nt_fit >= 1 && NT <= 4 * nt_fit) {
         const int tiles = (M + 31) / 32, grid = min((tiles + kTallWaves - 1) / kTallWaves, n_cus());
         for (int n0 = 0; n0 < N; n0 += 32 * nt_fit) {
             const int Ns = min(N - n0, 32 * nt_fit), NTs = (Ns + 31) / 32;
-            const size_t smem = (size_t)nkb * NTs * frag_bytes;
+            const size_t smem = (size_t)nkb * NTs * 3072;
             const float* Bs = transB ? B + (size_t)n0 * ldb : B + n0;
             float* Cs = C + n0;
-#define SHERF_TALL_(n, h) do { \
-            if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n, h>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-            hipLaunchKernelGGL((tall_gemm_kernel<n, h>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta, bias ? bias + n0 : nullptr, act); } while (0)
-#define SHERF_TALL(n) case n: if (f16) SHERF_TALL_(n, true); else SHERF_TALL_(n, false); break
+#define SHERF_TALL(n) case n: \
+            if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+            hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta, bias ? bias + n0 : nullptr, act); break
             switch (NTs) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
 #undef SHERF_TALL
-#undef SHERF_TALL_
         }
         g_last_path = 1;
         SHERF_LAUNCH_CHECK();
