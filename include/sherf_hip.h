@@ -180,6 +180,15 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* The same network as TWO launches (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel), results bit-identical to sherf_nerf_mlp:
+ * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS,
+ * tiles handed out by a ticket counter; launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  The form
+ * the single-product precisions (prec 0, 2) run in: there the transformer's chain of dependent waits held a wave slot for 28 % of a
+ * tile's time inside the one-launch kernel.  zfrag: scratch, ((capacity + 31) / 32) tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1).
+ * counters[3] must hold 0 or 1 on entry (bit 0 = the non-finite flag of sherf_nerf_mlp; bits 1.. are used as the tile tickets and are
+ * cleared again by launch 2; sherf_sample_mask_nn zeroes the word every frame). */
+int sherf_nerf_mlp_split(int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                         const float* wbias, int prec, int64_t capacity, void* zfrag, float* out, sherf_stream_t stream);
 /* The weight stream for `prec` built on the device (what sherf_amd/mlp_pack.py: pack() builds on the host, bit for bit): slot i (2 bytes) of
  * stream_out = piece (src[i] & 1: 0 = hi, 1 = lo) of flat[src[i] >> 1], zero where src[i] < 0; bias_out[i] = flat[bias_src[i]] or 0.
  * `flat` = the parameters of mlp_pack.packed_names() concatenated, (src, bias_src) = mlp_pack.stream_index() (device copies).
@@ -326,6 +335,9 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
 /* frame->flags & SHERF_FRAME_ENCODER_SINGLE (opt-in, set together with HALF_TABLES by sherf_amd.ImportanceRenderer): the sparse
  * convolutions multiply single fp16 products (operands rounded to nearest even) instead of the three of the f16x3 split. */
 #define SHERF_FRAME_ENCODER_SINGLE 4
+/* frame->flags & SHERF_FRAME_MLP_SPLIT: the per-sample network runs as sherf_nerf_mlp_split (two launches; needs frame->zfrag) instead of
+ * sherf_nerf_mlp.  Same results bit for bit; sherf_amd.ImportanceRenderer sets it with the single-product MLP precisions. */
+#define SHERF_FRAME_MLP_SPLIT 8
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */
@@ -356,6 +368,7 @@ typedef struct {
     int32_t main_after_layer;   /* scheduling: -1 = both streams start at once; k >= 0 = the ray side starts once encoder
                                  * layer k is done (the encoder's small launches are slowed 3-5x by a co-running sampler) */
     float* rgb; float* depth; float* acc;
+    void* zfrag;                /* scratch of sherf_nerf_mlp_split (SHERF_FRAME_MLP_SPLIT), else NULL */
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);

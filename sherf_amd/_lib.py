@@ -65,7 +65,7 @@ def _frame_fields():
     P('tokens', 'extras', 'vox_plan', 'vox_coord', 'vox_feat'); I('vox_n', 'vox_training')
     P('wstream', 'wbias'); I('mlp_prec', 'mlp_pad_')
     P('sample_out'); I('white_back', 'main_after_layer')
-    P('rgb', 'depth', 'acc')
+    P('rgb', 'depth', 'acc', 'zfrag')
     return f
 
 

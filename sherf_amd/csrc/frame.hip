@@ -211,8 +211,14 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                           f->extras, stream_main));
         }
         SHERF_PROF(4, main);
-        SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,
-                                 f->sample_out, stream_main));
+        // debug bit 13 flips the form for A/B runs in one process (a frame without zfrag always takes the one-launch kernel)
+        const bool split = f->zfrag && (((f->flags & SHERF_FRAME_MLP_SPLIT) != 0) != ((g_sherf_debug & 8192) != 0));
+        if (split)
+            SHERF_RUN(sherf_nerf_mlp_split(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->zfrag,
+                                           f->sample_out, stream_main));
+        else
+            SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,
+                                     f->sample_out, stream_main));
         SHERF_PROF(5, main);
     }
     if (phase & 2) {

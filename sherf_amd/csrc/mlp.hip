@@ -31,6 +31,8 @@
 //   order of magnitude outside it on the adversarial seeded weights -- sherf_amd/renderer.py: mlp_precision='auto' measures which.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -108,7 +110,9 @@ __device__ __forceinline__ uint32_t pack2_f16(float a, float b) {      // round 
 __device__ __forceinline__ void split2_f16(float a, float b, uint32_t& hi, uint32_t& lo) {
 #if SHERF_MLP_FMA_MIX
     float ra, rb;
-    asm("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    // (the conversion itself is the builtin, NOT asm: an asm-written register feeding a compiler-visible MFMA gets no VALU -> MFMA
+    //  wait states from hipcc's hazard recognizer -- tools/mfma_hazard_check.py found three such sites, one wait state short, in round 3's build)
+    hi = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
     lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
@@ -379,7 +383,22 @@ __device__ __forceinline__ void mma_splitk(const char* s, int u0, const BFrag<PR
     mma_chains<PREC, NK / 2, false, false>(s, u0, b, acc0, acc1, cur);
 }
 
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   // partner lane holds the other 16 features
+// v + (the partner lane's v): the partner lane (lane ^ 32) holds the other 16 features of the sample.  SHERF_MLP_PERMLANE (round 4):
+// one v_permlane32_swap_b32 (VALU, no LDS round trip) instead of ds_bpermute_b32 + s_waitcnt lgkmcnt(0) -- the transformer did 36 of
+// those exchanges per tile, each a ~100-cycle stall of a wave that has nothing else to issue (tools/mlp_isa_segments.py).  The swap
+// leaves (lo, lo) in one register and (hi, hi) in the other; their sum is lo + hi in every lane: the same two addends as before.
+#ifndef SHERF_MLP_PERMLANE
+#define SHERF_MLP_PERMLANE 1
+#endif
+__device__ __forceinline__ float xhalf_sum(float v) {
+#if SHERF_MLP_PERMLANE
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+#else
+    return v + __shfl_xor(v, 32);
+#endif
+}
 
 // LayerNorm over the 32 features of a token (16 here, 16 in lane^32), eps 1e-5 (renderer.py:931)
 template <int PREC, class C>
@@ -387,12 +406,12 @@ __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += x[r];
-    s += xhalf(s);
+    s = xhalf_sum(s);
     const float mean = s * (1.0f / 32.0f);
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { float d = x[r] - mean; q += d * d; }
-    q += xhalf(q);
+    q = xhalf_sum(q);
     const float inv = rsqrt_(q * (1.0f / 32.0f) + 1e-5f);
     const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
     f32x16 y;
@@ -488,54 +507,23 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
 // came out wrong, a different set every launch -- with correct tokens in memory, with the taps ahead of any weight DMA, with every
 // counted wait replaced by vmcnt(0), even with the taps replaced by plain loads of the stored tokens (profiles/
 // r02_fused_gather_mlp_experiment_*.txt).  Unexplained, so not shipped; sherf_gather_tokens stays its own launch.
-// One launch: transformer (steps 0-1) + decoder (steps 2-42).  Round 2 also measured the two as SEPARATE launches (the transformer
-// at 3 waves / SIMD with its weights resident in LDS, the decoder alone at two workgroups per CU): 0.23 + 0.62 ms against 0.69 ms
-// fused (profiles/r02_kernel_trace_v2_split.txt) -- the decoder alone is not faster than with the transformer of the co-resident
-// workgroup running under it, so the fused form stays.
-#ifndef SHERF_MLP_LB
-#define SHERF_MLP_LB 2            // minimum waves / SIMD the single-product instances are compiled for (register cap 512 / LB)
-#endif
-template <int PREC>
-__global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_LB)
-nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
-    using CX = Ctx<PREC>;
-    constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
-    const int64_t nv = min((int64_t)counters[0], capacity);
-    const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
-    CX cx;
-    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
-    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
-    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
-    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
-#if SHERF_MLP_TRACE
-    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
-    if (cx.lane == 0) {
-        cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime();
-        cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID: wave slot, SIMD, CU, SH, SE
-        cx.trace[63 * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // XCC_ID
-    }
-#endif
+// One launch (nerf_mlp_kernel): transformer (steps 0-1) + decoder (steps 2-42).  Round 2 measured the two as SEPARATE launches on the
+// three-product precision (the transformer at 3 waves / SIMD with its weights resident in LDS, the decoder alone at two workgroups per
+// CU): 0.23 + 0.62 ms against 0.69 ms fused (profiles/r02_kernel_trace_v2_split.txt), so the fused form stayed.  Round 4: on the
+// SINGLE-product precisions the balance is different -- the decoder's MFMA work is a third, so the transformer (1 600 VALU, 39 MFMAs,
+// a chain of dependent waits: 17.7 K of a tile's 62 K cycles, profiles/r03_mlp_trace_f16_v1.txt) holds a wave slot for 28 % of the
+// time while using 3 % of the matrix pipe, and with three waves per SIMD the pipe idles whenever fewer than three are in the decoder.
+// The two-launch form (sherf_nerf_mlp_split) gives each half the occupancy it wants: nerf_tokens_kernel is barrier-free with resident
+// weights and pulls tiles from a ticket counter; nerf_decoder_kernel has every wave in the MFMA-bound phase all the time.
+// ---- the two halves of the network as device functions: one launch runs both (nerf_mlp_kernel), the two-launch form runs them as
+//      nerf_tokens_kernel + nerf_decoder_kernel (below) ----
+// Transformer (chunks 0..8 = steps 0-1 of the weight stream) of one 32-sample tile -> the fused tokens z_0, z_1 as K-blocks.
+//   RING = true : the weights walk the 3-slot ring (step 0 / 1 in slots 0 / 1; the two advance() calls recycle them)
+//   RING = false: the weights are resident at cx.lds (steps 0-1 back to back), no barrier, no DMA: waves run independently
+template <int PREC, bool RING>
+__device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __restrict__ tokens, const float* __restrict__ extras, int64_t tile,
+                                                 BFrag<PREC> (&z0b)[2], BFrag<PREC> (&z1b)[2]) {
     const int j = cx.lane & 31, h = cx.h;
-    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
-    const bool live = tile < n_tiles;
-    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
-
-    dma_issue(cx, 0);
-    dma_issue(cx, 1);
-    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(1) / NW);   // step 0 (this wave's pieces) landed
-    __syncthreads();
-    dma_issue(cx, 2);
-
-    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
-    float xc[3], vc[3];
-    int step = 0;
-
-    // ================= transformer: step 0 = chunks 0..4, step 1 = chunks 5..8 =================
     {
         // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
         f32x16 tok[3];
@@ -547,9 +535,8 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
                 tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
             }
         const float* ex = extras + tile * 12 * 32 + j;
-        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
 
-        const char* s = cx.slot(step);
+        const char* s = RING ? cx.slot(0) : cx.lds;               // step 0: chunks 0..4
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
         {
             BFrag<PREC> b[1][2];
@@ -610,7 +597,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 #pragma unroll
             for (int r = 0; r < 8; ++r) v0[t][r] = acc[0][8 + r];
         }
-        advance(cx, step); ++step;
+        if constexpr (RING) advance(cx, 0);
         // softmax over the 3 keys, scale 16^-0.5 (renderer.py:956,971-973)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -618,7 +605,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             for (int hd = 0; hd < 3; ++hd) {
                 float d[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) d[t] = (dot[i][hd][t] + xhalf(dot[i][hd][t])) * 0.25f;
+                for (int t = 0; t < 3; ++t) d[t] = xhalf_sum(dot[i][hd][t]) * 0.25f;
                 float m = fmaxf(d[0], fmaxf(d[1], d[2]));
                 float e0 = exp_(d[0] - m), e1 = exp_(d[1] - m), e2 = exp_(d[2] - m);
                 float inv = rcp_(e0 + e1 + e2);
@@ -628,7 +615,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[i][0][r] = dot[i][0][0] * v0[0][r] + dot[i][0][1] * v0[1][r] + dot[i][0][2] * v0[2][r];
-        s = cx.slot(step);
+        s = RING ? cx.slot(1) : cx.lds + step_pieces<PREC>(0) * 1024;     // step 1: chunks 5..8
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -688,16 +675,24 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
             mma_cols<PREC, 2, 2>(s, 7, gb, acc2);
-            advance(cx, step); ++step;
+            if constexpr (RING) advance(cx, 1);
             f32x16 za = acc2[0] + y[0], zb = acc2[1] + y[1];
             split_tile<PREC>(za, z0b[0], z0b[1]);
             split_tile<PREC>(zb, z1b[0], z1b[1]);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
 
+// NeRF decoder (steps 2..42 of the weight stream through the ring) of one tile; on entry steps 2-4 have been issued and step 2 has landed
+// (the caller's prologue, or the transformer's second advance()).
+template <int PREC>
+__device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __restrict__ counters, const BFrag<PREC> (&z0b)[2], const BFrag<PREC> (&z1b)[2],
+                                             const float (&xc)[3], const float (&vc)[3], int64_t tile, bool live, int64_t nv, float4* __restrict__ out) {
+    const int j = cx.lane & 31, h = cx.h;
     // ================= NeRF decoder =================
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
+    int step = 2;
     BFrag<PREC> ha[8], hb[8];
     AFrag<PREC> cur = load_units<PREC>(cx.slot(step));               // first fragments of the next step: fetched right behind its barrier
     // (the fetch goes out BEFORE the DMA issue of the slot just freed: its LDS latency hides under those ~30 instructions)
@@ -795,14 +790,167 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     }
 #undef SHERF_NEXT_STEP
 #undef SHERF_LAYER128
+}
+
+#ifndef SHERF_MLP_LB
+#define SHERF_MLP_LB 2            // minimum waves / SIMD the single-product instances are compiled for (register cap 512 / LB)
+#endif
+// ring prologue shared by the fused kernel (S0 = 0) and the decoder kernel (S0 = 2): steps S0, S0+1 issued, S0 landed, S0+2 issued
+template <int PREC, int S0>
+__device__ __forceinline__ void ring_prologue(Ctx<PREC>& cx) {
+    dma_issue(cx, S0);
+    dma_issue(cx, S0 + 1);
+    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(S0 + 1) / NW);   // step S0 (this wave's pieces) landed
+    __syncthreads();
+    dma_issue(cx, S0 + 2);
+}
+template <int PREC>
+__device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* ws, const float* wbias) {
+    using CX = Ctx<PREC>;
+    constexpr int NT = NW * 64;
+    float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
+    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
+    cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
 #if SHERF_MLP_TRACE
-    if (g_mlp_trace && g_mlp_trace_every > 0 && blockIdx.x % g_mlp_trace_every == 0) {
-        if (cx.lane == 0) cx.trace[63 * 4 + 2] = (uint32_t)__builtin_amdgcn_s_memtime();
-        const size_t slot = blockIdx.x / g_mlp_trace_every;
-        uint32_t* dst = g_mlp_trace + (slot * 8 + cx.wave) * 256;
-        for (int i = cx.lane; i < 256; i += 64) dst[i] = cx.trace[i];
+    cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
+    if (cx.lane == 0) {
+        cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime();
+        cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID: wave slot, SIMD, CU, SH, SE
+        cx.trace[63 * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // XCC_ID
     }
 #endif
+}
+#if SHERF_MLP_TRACE
+#define SHERF_TRACE_FLUSH(cx) do {                                                                           \
+    if (g_mlp_trace && g_mlp_trace_every > 0 && blockIdx.x % g_mlp_trace_every == 0) {                       \
+        if ((cx).lane == 0) (cx).trace[63 * 4 + 2] = (uint32_t)__builtin_amdgcn_s_memtime();                 \
+        const size_t slot = blockIdx.x / g_mlp_trace_every;                                                  \
+        uint32_t* dst = g_mlp_trace + (slot * 8 + (cx).wave) * 256;                                          \
+        for (int i = (cx).lane; i < 256; i += 64) dst[i] = (cx).trace[i];                                    \
+    } } while (0)
+#else
+#define SHERF_TRACE_FLUSH(cx) do { } while (0)
+#endif
+
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_LB)
+nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    using CX = Ctx<PREC>;
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
+    CX cx;
+    ring_ctx<PREC>(cx, lds, ws, wbias);
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
+    ring_prologue<PREC, 0>(cx);
+
+    BFrag<PREC> z0b[2], z1b[2];                                      // fused tokens z_0, z_1 as K-blocks
+    float xc[3], vc[3];
+    const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
+    xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
+    transformer_tile<PREC, true>(cx, tokens, extras, tile, z0b, z1b);
+    decoder_tile<PREC>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out);
+    SHERF_TRACE_FLUSH(cx);
+}
+
+// ---- the two-launch form -------------------------------------------------------------------------------------------------------
+// zfrag[tile][q][64 lanes] u32x4: the fused tokens as ready-made B-operand fragments, q = 2 * (0: z_0, 1: z_1) + kb for the single-product
+// precisions (4 KiB per tile), q = 4 * (z) + 2 * kb + (0: hi, 1: lo) for prec 1 (8 KiB per tile).
+template <int PREC> constexpr int ZFRAGS = PREC == 1 ? 8 : 4;
+
+// Launch 1 of 2: the slot-fusion remainder + the 3-token transformer.  VALU / latency bound; its 20-40 KiB of weights stay resident in
+// LDS (no ring, no per-step barrier) and every wave pulls tiles on its own from a ticket counter: bits 1.. of counters[3] (bit 0 is the
+// non-finite flag; the sampler zeroes the word every frame and nerf_decoder_kernel clears the ticket bits again at its end), so the
+// waves stay busy until the tiles run out -- a static split leaves the SIMDs with 5 or 6 of the ~5.3 tiles per wave slot.
+#ifndef SHERF_MLP_TOKENS_WAVES
+#define SHERF_MLP_TOKENS_WAVES 4
+#endif
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_TOKENS_WAVES)
+nerf_tokens_kernel(int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                   const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, u32x4* __restrict__ zfrag) {
+    using CX = Ctx<PREC>;
+    constexpr int NT = NW * 64;
+    constexpr int WBYTES = (step_pieces<PREC>(0) + step_pieces<PREC>(1)) * 1024;
+    __shared__ __attribute__((aligned(16))) char lds[WBYTES + (N_CHUNKS + 4) * 32 * 4];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    float* lbias = reinterpret_cast<float*>(lds + WBYTES);
+    for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];
+    for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
+    __syncthreads();
+    CX cx;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0;
+    unsigned* ticket = reinterpret_cast<unsigned*>(counters) + 3;
+    for (;;) {
+        unsigned t = 0;
+        if (cx.lane == 0) t = atomicAdd(ticket, 2u) >> 1;
+        const int64_t tile = (int64_t)__builtin_amdgcn_readfirstlane(__shfl(t, 0));      // (the shuffle is what broadcasts on the host build of the tests)
+        if (tile >= n_tiles) break;
+        // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
+        // loop (hundreds of live registers).  The OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and
+        // every weight read becomes a flat load.
+        uint32_t woff = cx.lane * 16, boff = 0;
+        asm volatile("" : "+v"(woff), "+v"(boff));
+        cx.lds = lds + woff;
+        cx.wbias = lbias + boff;
+        BFrag<PREC> z0b[2], z1b[2];
+        transformer_tile<PREC, false>(cx, tokens, extras, tile, z0b, z1b);
+        u32x4* zp = zfrag + tile * (ZFRAGS<PREC> * 64) + cx.lane;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (PREC == 1) {
+                zp[(2 * kb) * 64] = z0b[kb].hi; zp[(2 * kb + 1) * 64] = z0b[kb].lo;
+                zp[(4 + 2 * kb) * 64] = z1b[kb].hi; zp[(4 + 2 * kb + 1) * 64] = z1b[kb].lo;
+            } else {
+                zp[kb * 64] = z0b[kb].hi; zp[(2 + kb) * 64] = z1b[kb].hi;
+            }
+        }
+    }
+}
+
+// Launch 2 of 2: the NeRF decoder, steps 2..42 of the weight stream through the 3-slot ring: every wave of the chip in the MFMA-bound phase.
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : 3)
+nerf_decoder_kernel(int32_t* __restrict__ counters, const u32x4* __restrict__ zfrag, const float* __restrict__ extras,
+                    const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    using CX = Ctx<PREC>;
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    // the tokens kernel has finished (same stream): its ticket bits are cleared for the next launch; bit 0 (non-finite flag) stays
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAnd(reinterpret_cast<unsigned*>(counters) + 3, 1u);
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
+    CX cx;
+    ring_ctx<PREC>(cx, lds, ws, wbias);
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
+    ring_prologue<PREC, 2>(cx);
+
+    BFrag<PREC> z0b[2], z1b[2];
+    const u32x4* zp = zfrag + tile * (ZFRAGS<PREC> * 64) + cx.lane;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if constexpr (PREC == 1) {
+            z0b[kb].hi = zp[(2 * kb) * 64]; z0b[kb].lo = zp[(2 * kb + 1) * 64];
+            z1b[kb].hi = zp[(4 + 2 * kb) * 64]; z1b[kb].lo = zp[(4 + 2 * kb + 1) * 64];
+        } else {
+            z0b[kb].hi = zp[kb * 64]; z1b[kb].hi = zp[(2 + kb) * 64];
+        }
+    }
+    float xc[3], vc[3];
+    const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
+    xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
+    decoder_tile<PREC>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out);
+    SHERF_TRACE_FLUSH(cx);
 }
 
 }  // namespace
@@ -887,5 +1035,35 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
     else
         hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
                            reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    SHERF_LAUNCH_CHECK();
+}
+
+// The two-launch form (see nerf_tokens_kernel / nerf_decoder_kernel): same inputs, same outputs bit for bit; zfrag = scratch for the fused
+// tokens, (capacity + 31) / 32 tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1).  counters[3] must hold 0 or 1 on entry (its upper bits are the
+// tokens kernel's tile tickets: the sampler zeroes the word every frame, the decoder kernel clears the ticket bits at its end).
+extern "C" int sherf_nerf_mlp_split(int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                                    const float* wbias, int prec, int64_t capacity, void* zfrag, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out && zfrag);
+    SHERF_CHECK_ARG(prec >= 0 && prec <= 2 && capacity > 0);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0, v = 0;
+        SHERF_HIP_CHECK(hipGetDevice(&dev));
+        SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = v > 0 ? v : 256;
+    }
+    const int64_t tiles = (capacity + 31) / 32;
+    const int wgs_per_cu = prec == 1 ? 2 : SHERF_MLP_TOKENS_WAVES;           // (a 4-wave workgroup = one wave per SIMD)
+    const dim3 tgrid((unsigned)std::min<int64_t>((tiles + NW - 1) / NW, (int64_t)n_cu * wgs_per_cu)), block(NW * 64);
+    const dim3 dgrid((unsigned)((tiles + NW - 1) / NW));
+#define SHERF_SPLIT(P)                                                                                                                  \
+    do {                                                                                                                                 \
+        hipLaunchKernelGGL((nerf_tokens_kernel<P>), tgrid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), \
+                           extras, reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<u32x4*>(zfrag));            \
+        hipLaunchKernelGGL((nerf_decoder_kernel<P>), dgrid, block, 0, as_stream(stream), counters, reinterpret_cast<const u32x4*>(zfrag), \
+                           extras, reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));             \
+    } while (0)
+    if (prec == 1) SHERF_SPLIT(1); else if (prec == 2) SHERF_SPLIT(2); else SHERF_SPLIT(0);
+#undef SHERF_SPLIT
     SHERF_LAUNCH_CHECK();
 }

@@ -174,6 +174,14 @@ class _Workspace:
         self.key, self.t = key, t
         return t
 
+    def zfrag(self, cap, prec_name, dev):
+        """Scratch of sherf_nerf_mlp_split: the fused tokens as B-operand fragments, 4 KiB (8 KiB: f16x3) per 32-sample tile."""
+        words = ((cap + 31) // 32 + 8) * (2048 if prec_name == 'f16x3' else 1024)
+        z = self.t.get('zfrag')
+        if z is None or z.numel() < words or z.device != torch.device(dev):
+            z = self.t['zfrag'] = torch.empty(words, dtype=torch.int32, device=dev)
+        return z
+
     def voxel_levels(self, shapes, N, dev):
         key = (tuple(shapes), N, str(dev))
         if self.vox is not None and self.vox[0] == key:
@@ -256,6 +264,8 @@ class ImportanceRenderer(nn.Module):
         # SHERF_FRAME_EXACT_GRIDS (sherf_hip.h): launch warp / gather / MLP for the frame's actual valid-sample count (one host wait per
         # frame, where the reference has its own) instead of the R*S capacity; same results
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
+        # the per-sample network as two launches (sherf_nerf_mlp_split): None = where it is faster (the single-product precisions)
+        self.mlp_split = {'': None, '0': False, '1': True}[os.environ.get('SHERF_MLP_SPLIT', '')]
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
         self._smpl_src = smpl
@@ -479,6 +489,16 @@ class ImportanceRenderer(nn.Module):
         fr.wstream, fr.wbias = _lib.addr(wc['stream']), _lib.addr(wc['wbias'])
         fr.mlp_prec = MLP_PRECISIONS[cfg[0]]
         fr.flags = (1 if exact else 0) | (2 if cfg[1] == 'f16' else 0) | (4 if cfg[2] == 'f16' else 0)
+        # the two-launch form of the per-sample network (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel, bit-identical results)
+        # where it is the faster one: the single-product precisions (mlp_split=None), or as told
+        split = getattr(self, '_opt_mlp_split', None)
+        if split is None:
+            split = self.mlp_split if getattr(self, 'mlp_split', None) is not None else cfg[0] in ('f16', 'bf16')
+        fr.zfrag = None
+        if split:
+            ws = self._workspace(dev)
+            fr.zfrag = _lib.addr(ws.zfrag(int(fr.capacity), cfg[0], dev))
+            fr.flags |= 8
         return wc
 
     def _calibrate(self, fr, decoder, dev, ws, levels, streams, exact):
@@ -557,6 +577,7 @@ class ImportanceRenderer(nn.Module):
         f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
         smpl = self._smpl(dev)
         cfg, calibrate = self._resolve_config(opts, decoder, dev)
+        self._opt_mlp_split = opts.get('mlp_split')
         prec_name = cfg[0]
         wc = self._weights(decoder, dev, prec_name)
         wsp = self._workspace(dev)

@@ -72,6 +72,19 @@ inline unsigned long long __ballot(int pred) {           // every lane of the wa
     return m;
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipcpu_exchange(v, lane); }
+#ifdef __clang__
+// v_permlane32_swap_b32 vdst, src: lanes 32..63 of vdst <-> lanes 0..31 of src; -> {new vdst, new src}
+typedef unsigned hipcpu_u32x2 __attribute__((ext_vector_type(2)));
+inline hipcpu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
+    const int l = hipcpu_lane();
+    const unsigned from_src = hipcpu_exchange(src, l >= 32 ? l - 32 : l);       // what the upper half of vdst receives
+    const unsigned from_dst = hipcpu_exchange(vdst, l < 32 ? l + 32 : l);       // what the lower half of src receives
+    hipcpu_u32x2 r;
+    r[0] = l < 32 ? vdst : from_src;
+    r[1] = l < 32 ? from_dst : src;
+    return r;
+}
+#endif
 inline void __builtin_amdgcn_wave_barrier() { hipcpu_wave_sync(); }       // lockstep ordering points the kernels mark explicitly
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
@@ -122,6 +135,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 inline float unsafeAtomicAdd(float* p, float v) { return std::atomic_ref<float>(*p).fetch_add(v); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_or(v); }
+inline unsigned atomicAnd(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_and(v); }
 inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { return std::atomic_ref<unsigned long long>(*p).fetch_or(v); }
 template <class T> inline T atomicMin(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v < o && !a.compare_exchange_weak(o, v)) {} return o; }
 template <class T> inline T atomicMax(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v > o && !a.compare_exchange_weak(o, v)) {} return o; }
