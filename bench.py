@@ -4,10 +4,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the hot path over one 512x512 frame x 64 samples/ray of synthetic input already resident
-in HBM (BASELINE.json config 2: single subject novel view).  With N > 1 every rank renders its own target view
+in HBM (BASELINE.json config 2: single subject novel view, framed so that 7.6 % of the samples are valid -- the fraction SURVEY.md
+section 8(d) sized the path on).  With N > 1 every rank renders its own target view
 of the same subject (BASELINE config 4: views sharded across GPUs, weak scaling) and the step ends with the RCCL
 all_gather of the rendered [rays, 5] tiles (asynchronous, awaited one step later; the last one inside the timed region).
 Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its N ranks ITSELF (re-executes under
+torch.distributed.run on 127.0.0.1, one rank per GPU, as the reference spawns its own: sherf/train.py:98-103); launched by a
+torchrun-style launcher it checks --gpus against WORLD_SIZE and refuses a mismatch.
 """
 import argparse
 import json
@@ -31,6 +36,47 @@ PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.
 PEAK_HBM_GBS = 8000.0                # MI355X HBM3E (MI355X_MICROARCH.md)
 # (the host dry run of this script lowers them)
 SECONDARY_ITERS = dict(mlp=20, mlp_warmup=5, frames=20, frames_warmup=10)
+
+
+def _use_host_build():
+    """TEST INFRASTRUCTURE (tests/test_hipcpu_frame.py, tests/test_dist_cpu.py): SHERF_HIPCPU_LIB names a HOST build of the kernel library
+    (tests/hipcpu) -- the script then runs its whole plumbing (ranks, process group, gathers, the JSON line) on CPU tensors over gloo.
+    The numbers mean nothing there.  Never set on a GPU box."""
+    import ctypes
+    from sherf_amd import _lib
+    import sherf_amd.renderer as AR
+    _lib.LIB_PATH, _lib._lib = os.environ['SHERF_HIPCPU_LIB'], None
+    _lib.ptr = lambda t, dtype=None, channels_last_ok=False: None if t is None else ctypes.c_void_p(t.data_ptr())
+    _lib.addr = lambda t, dtype=None: None if t is None else t.data_ptr()
+    _lib.stream = lambda: ctypes.c_void_p(0)
+    torch.cuda.current_stream = lambda dev=None: type('S', (), {'cuda_stream': 0})()
+    torch.cuda.synchronize = lambda dev=None: None
+    torch.Tensor.is_cuda = property(lambda self: True)
+    AR.ImportanceRenderer._side = lambda self, dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})()
+    AR.ImportanceRenderer.SMPL_NEUTRAL = property(lambda self: self._smpl(torch.device('cpu')))
+    globals()['_device'] = lambda lrank: torch.device('cpu')
+    os.environ.setdefault('SHERF_DIST_BACKEND', 'gloo')
+
+
+def launch_ranks(n, script=None, argv=None):
+    """`--gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 (the reference
+    spawns its ranks itself too: sherf/train.py:98-103).  The ranks' output passes through; -> the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(script or __file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def check_world(gpus, world, what='bench.py'):
+    if gpus != world:
+        print(f'{what}: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line for the wrong N', file=sys.stderr)
+        sys.exit(2)
 
 
 def make_inputs(cfg_name, theta, dev):
@@ -102,9 +148,9 @@ def time_frames(w, steps, warmup, dev):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=False):
-    """`sherf_nerf_mlp` alone on the tokens of the frame `w` rendered last, in `precision`: (ms per launch from HIP events on the
-    launch stream, its [nv, 4] output)."""
+def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=False, split=False):
+    """`sherf_nerf_mlp` (split: `sherf_nerf_mlp_split`, the two-launch form) alone on the tokens of the frame `w` rendered last, in
+    `precision`: (ms per call from HIP events on the launch stream, its [nv, 4] output)."""
     import ctypes as ct
     from sherf_amd import _lib
     from sherf_amd.renderer import MLP_PRECISIONS
@@ -120,8 +166,13 @@ def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=Fals
     A = _lib.addr
     st = torch.cuda.current_stream(dev)
     stream = ct.c_void_p(st.cuda_stream)
-    launch = lambda: _lib.call('sherf_nerf_mlp', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
-                               MLP_PRECISIONS[precision], cap, A(out), stream)
+    if split:
+        zfrag = rend._workspace(dev).zfrag(cap, precision, dev)
+        launch = lambda: _lib.call('sherf_nerf_mlp_split', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
+                                   MLP_PRECISIONS[precision], cap, A(zfrag), A(out), stream)
+    else:
+        launch = lambda: _lib.call('sherf_nerf_mlp', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
+                                   MLP_PRECISIONS[precision], cap, A(out), stream)
     for _ in range(warmup):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,15 +200,21 @@ def secondary_measurements(a, w, dev, nv, R):
                                       note='the f16 launch sized for the valid samples instead of the capacity R * S: what the empty workgroups of the in-frame launch cost')
         for name in ('f16', 'bf16'):
             ms1, got = mlp_kernel_alone(w, name, dev)
-            rows[name] = dict(kernel_ms=ms1, achieved_tflops=fl(ms1), frac=fl(ms1) / PEAK_BF16_TFLOPS, mfma_per_product=1,
+            rows[name] = dict(kernel_ms=ms1, achieved_tflops=fl(ms1), frac=fl(ms1) / PEAK_BF16_TFLOPS, mfma_per_product=1, form='one launch (nerf_mlp_kernel)',
                               sigma_rel_err_max_vs_f16x3=float(((got[:, 3].clamp(min=0) - sig).abs() / sig.clamp(min=1.0)).max()),
                               rgb_rel_err_max_vs_f16x3=float(((got[:, :3] - ref[:, :3]).abs() / ref[:, :3].abs().clamp(min=0.1)).max()))
+            ms2, got2 = mlp_kernel_alone(w, name, dev, split=True)
+            rows[name + '_two_launches'] = dict(kernel_ms=ms2, achieved_tflops=fl(ms2), frac=fl(ms2) / PEAK_BF16_TFLOPS, mfma_per_product=1,
+                                                form='nerf_tokens_kernel + nerf_decoder_kernel (sherf_nerf_mlp_split)',
+                                                bit_identical_to_one_launch=bool(torch.equal(got, got2)))
+        ms3b, got3 = mlp_kernel_alone(w, 'f16x3', dev, split=True)
+        rows['f16x3_two_launches'] = dict(kernel_ms=ms3b, frac=fl(ms3b) / PEAK_BF16_TFLOPS, mfma_per_product=3, bit_identical_to_one_launch=bool(torch.equal(ref, got3)))
         out['mlp_kernel_alone'] = rows
     except Exception as ex:
         out['mlp_kernel_alone'] = dict(error=f'{type(ex).__name__}: {str(ex)[:200]}')
     ri = '_ri' if a.config.endswith('_ri') else ''
-    for cfg in ('cfg3' + ri, 'cfg2_dense' + ri, 'cfg2'):
-        if cfg == a.config:
+    for cfg in ('cfg2' + ri, 'cfg3' + ri, 'cfg2_dense' + ri, 'cfg2'):
+        if cfg == a.config or cfg in out:
             continue
         try:
             b = argparse.Namespace(**vars(a)); b.config = cfg
@@ -208,17 +265,23 @@ def pmc_traffic(a, lrank, timeout=150):
             rows = []
             for f in glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True):
                 rows += list(csv.DictReader(open(f)))
-            v = [float(x['Counter_Value']) for x in rows if 'nerf_mlp_kernel' in x.get('Kernel_Name', '') and x.get('Counter_Name') == counter]
-            if not v:
-                return dict(error=f'{counter}: no nerf_mlp_kernel rows (rc={r.returncode}): {r.stderr.strip()[-200:]}')
-            vals[counter] = (sum(v) / len(v), len(v))
+            per = {}                                  # the network's kernels (one launch, or the two of sherf_nerf_mlp_split): mean per dispatch, summed
+            for x in rows:
+                kn = x.get('Kernel_Name', '')
+                for key in ('nerf_mlp_kernel', 'nerf_tokens_kernel', 'nerf_decoder_kernel'):
+                    if key in kn and x.get('Counter_Name') == counter:
+                        per.setdefault(key, []).append(float(x['Counter_Value']))
+            if not per:
+                return dict(error=f'{counter}: no nerf_*_kernel rows (rc={r.returncode}): {r.stderr.strip()[-200:]}')
+            vals[counter] = (sum(sum(v) / len(v) for v in per.values()), max(len(v) for v in per.values()), {k: sum(v) / len(v) for k, v in per.items()})
         except Exception as ex:
             return dict(error=f'{counter}: {type(ex).__name__}: {str(ex)[:200]}')
         finally:
             shutil.rmtree(outdir, ignore_errors=True)
     fetch_kb, write_kb = vals['FETCH_SIZE'][0], vals['WRITE_SIZE'][0]
     return dict(hbm_bytes_per_launch=int(2 * fetch_kb * 1024 + write_kb * 1024), fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb,
-                dispatches=vals['FETCH_SIZE'][1], note='FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE as reported')
+                dispatches=vals['FETCH_SIZE'][1], fetch_kb_by_kernel=vals['FETCH_SIZE'][2], write_kb_by_kernel=vals['WRITE_SIZE'][2],
+                note='FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE as reported; the network\'s kernels summed per frame')
 
 
 def main():
@@ -226,9 +289,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', default='cfg2_ri',
-                    help='cfg2_ri (default) = BASELINE config 2 with the network SURVEY 8(d) specifies (the reference constructors\' '
-                         'initialisation, alpha bias + 5) and band-limited tables; cfg2 = the adversarial seeded weights of rounds 1-2')
+    ap.add_argument('--config', default='cfg2_dense_ri',
+                    help='cfg2_dense_ri (default) = BASELINE config 2 framed at the valid-sample fraction SURVEY 8(d) sized the path on (7.6 %%), with '
+                         'the network SURVEY 8(d) specifies (the reference constructors\' initialisation, alpha bias + 5) and band-limited tables; '
+                         'cfg2_ri = the same subject framed wider (4.1 %% valid: round 3\'s headline, now in `secondary`); cfg2 = the adversarial '
+                         'seeded weights of rounds 1-2')
     ap.add_argument('--precision', default='auto', choices=['auto', 'f16x3', 'f16', 'bf16'],
                     help='MLP operand precision; auto (the product default) = calibrated per set of weights on the first frame')
     ap.add_argument('--table-precision', default=None, choices=['f32', 'f16'], help='override the folded tables\' format (default: follows the MLP precision)')
@@ -260,7 +325,13 @@ def main():
                          'training_loop.py:193,311-330); eval = running statistics (G_ema.eval(), training_loop.py:196)')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ and not (a.torch_gpu_child or a.pmc_child):
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
+    if not (a.torch_gpu_child or a.pmc_child):
+        check_world(a.gpus, world)
+    if os.environ.get('SHERF_HIPCPU_LIB'):
+        _use_host_build()
     if a.torch_gpu_child:
         print('TORCH_GPU_JSON ' + json.dumps(torch_gpu_baseline(a.config, _device(lrank), a.bn_mode == 'train', save=a.save_oracle)), flush=True)
         return
@@ -356,6 +427,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     nv = int(rend.last['ws']['counters'][0])
+    rank_devices = [str(dev)]
+    if world > 1:
+        rank_devices = [None] * world
+        torch.distributed.all_gather_object(rank_devices, f'rank {rank}: {dev}' + (f' ({torch.cuda.get_device_name(dev)})' if dev.type == 'cuda' else ''))
     parity_failed = False
     ms = (_ct.c_float * (64 * 8))(); n_ms = _ct.c_int32(0)
     _abi.call('sherf_profile_frames_read', ms, 64, _ct.byref(n_ms))
@@ -368,7 +443,8 @@ def main():
                  'f16': 'f16 MFMA (fp16 operands rounded to nearest, one product, fp32 accumulate), fp32 elsewhere',
                  'bf16': 'bf16 MFMA (one product, fp32 accumulate), fp32 elsewhere'}[used]
         res = dict(metric='rendered rays/sec at 512x512x64 samples (ImportanceRenderer.forward)', value=(R_frame if rays_mode else world * R) * a.steps / dt,
-                   unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps,
+                   unit='rays/s', n_gpus=world, rccl_ranks=torch.distributed.get_world_size() if world > 1 else 1, rank_devices=rank_devices,
+                   steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps,
                    higher_is_better=True, scaling='strong' if rays_mode else 'weak', vs_baseline=None, dtype=dtype, data='synthetic',
                    config=dict(workload=f'{a.config}: 512x512 rays x 64 samples, synthetic SMPL subject, novel view, all feature branches, '
                                         f'one view per GPU', rays=R_frame if rays_mode else R, rays_per_rank=R, samples_per_ray=S, valid_samples=nv, valid_fraction=nv / (R * S),
@@ -378,10 +454,17 @@ def main():
                                table_precision=rend.last.get('table_precision'), encoder_precision=rend.last.get('encoder_precision')))
         if mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
-            res['roofline'] = dict(kernel='nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+            two = bool(rend.last.get('mlp_split'))
+            tiles = (nv + 31) // 32
+            res['roofline'] = dict(kernel='nerf_tokens_kernel + nerf_decoder_kernel (sherf_nerf_mlp_split: the network as two launches, timed together)' if two
+                                   else 'nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
                                    frac=ach / PEAK_BF16_TFLOPS, traffic=None, kernel_ms=mlp_ms,
                                    algorithmic_flop_per_launch=nv * FLOP_PER_VALID_SAMPLE,
-                                   timing='HIP events recorded by the native frame driver around sherf_nerf_mlp on its launch stream, mean over the timed frames')
+                                   # what the matrix pipe EXECUTES: 374 v_mfma_f32_32x32x16 per 32-sample tile and product (the two 1x1 projections of
+                                   # SURVEY 8(d)'s count are folded into the tables by other kernels, the transformer skips the token nobody reads)
+                                   executed_mfma_flop=tiles * 374 * 32768 * (3 if used == 'f16x3' else 1),
+                                   frac_executed=tiles * 374 * 32768 / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                                   timing='HIP events recorded by the native frame driver around the network\'s launch(es) on their launch stream, mean over the timed frames')
         if len(prof):
             names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done')
             res['frame_timeline_ms'] = {k: round(float(v), 4) for k, v in zip(names, prof[:, :7].mean(0))}
@@ -389,6 +472,11 @@ def main():
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary_measurements(a, w, dev, nv, R)
             dense = res['secondary'].get('cfg2_dense' + ('_ri' if a.config.endswith('_ri') else ''), {})
+            if a.config.startswith('cfg2_dense'):        # the headline IS the framing SURVEY 8(d) sized the path on (valid fraction 0.076)
+                dense = dict(rays_per_s=res['value'], ms_per_frame=res['ms_per_step'], valid_fraction=nv / (R * S))
+                wide = res['secondary'].get('cfg2' + ('_ri' if a.config.endswith('_ri') else ''), {})
+                if wide.get('rays_per_s'):               # round 3's headline framing (valid fraction 0.041), for comparison across rounds
+                    res['value_cfg2_wide_framing'] = wide['rays_per_s']; res['ms_per_step_cfg2_wide_framing'] = wide['ms_per_frame']
             if dense.get('rays_per_s'):                  # the valid-sample fraction SURVEY 8(d) sized the path on (0.076): first class
                 res['value_dense'] = dense['rays_per_s']; res['ms_per_step_dense'] = dense['ms_per_frame']
                 res['valid_fraction_dense'] = dense['valid_fraction']
@@ -445,18 +533,17 @@ def _oracle_state(cfg_name, dev=None):
     return {n: (torch.from_numpy(v) if dev is None else torch.from_numpy(v).to(dev)) for n, v in vals.items() if v is not None}
 
 
-def cpu_baseline(cfg_name):
-    """The oracle (CPU port of the reference algorithm, brute-force K-NN included) timed on the host cores, on a bounded sample of
-    the same workload: the centred 64x64-ray crop of the 512x512x64 frame.  (The crop sits on the body: ~1/3 of its samples are valid
-    against 4 % over the frame, so per ray it is the EXPENSIVE part of the frame -- stated in `sample`.)"""
+def cpu_baseline(cfg_name, stride=61):
+    """The oracle (CPU port of the reference algorithm, pinned to the unmodified reference by the golden vectors; brute-force K-NN
+    included) timed on the host cores, on a bounded UNBIASED sample of the same workload: every `stride`-th ray of the whole frame
+    (61 is coprime to the image width, so the subset covers every column and row band: the valid-sample fraction of the sample is
+    the frame's, unlike round 3's centred crop which sat on the body)."""
     from oracle import fixtures, sherf_oracle as O
-    import json as _json
     state = _oracle_state(cfg_name)
     fx = fixtures.renderer_inputs(cfg_name)
     c = fx['cfg']
-    H, W, n = c['H'], c['W'], 64
-    ys, xs = np.meshgrid(np.arange(H // 2 - n // 2, H // 2 + n // 2), np.arange(W // 2 - n // 2, W // 2 + n // 2), indexing='ij')
-    sel = (ys * W + xs).reshape(-1)
+    H, W = c['H'], c['W']
+    sel = np.arange(0, H * W, stride if H * W >= 64 * stride else 1)
     d = {k: (dict(v) if isinstance(v, dict) else v) for k, v in fx['input_data'].items()}
     for k in ('ray_o_all', 'ray_d_all', 'near_all', 'far_all'):
         d[k] = np.ascontiguousarray(d[k][:, :, sel])
@@ -467,8 +554,9 @@ def cpu_baseline(cfg_name):
         r = O.render_from_fixture(fx, state, training=True, keep=False)
     dt = time.perf_counter() - t0
     return dict(value=len(sel) / dt, unit='rays/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'centred {n}x{n}-ray crop of the {H}x{W}x{c["S"]} frame ({len(sel)} rays, {int(r["mask"].sum())} valid samples = '
-                       f'{int(r["mask"].sum()) / (len(sel) * c["S"]):.0%} of the crop), oracle/sherf_oracle.py fp32 torch-CPU, {dt:.1f} s')
+                kind_note='oracle/sherf_oracle.py: the CPU restatement of the reference, pinned to the unmodified reference by tests/golden (tests/test_oracle_golden.py)',
+                sample=f'every {stride}th ray of the whole {H}x{W}x{c["S"]} frame ({len(sel)} rays, {int(r["mask"].sum())} valid samples = '
+                       f'{int(r["mask"].sum()) / (len(sel) * c["S"]):.1%} of the sample: the frame\'s own fraction), fp32 torch-CPU, {dt:.1f} s')
 
 
 def frame_parity(ours, ref, S, plain=False):

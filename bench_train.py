@@ -2,7 +2,7 @@
 all-reduce, training_loop.py:374-383 + Adam step) -- companion of bench.py (whose metric is the forward render), same launch
 contract:
 
-    python bench_train.py --gpus N --steps K --warmup W          (torchrun for N > 1, one rank per GPU)
+    python bench_train.py --gpus N --steps K --warmup W          (N > 1: launches its N ranks itself, or runs under torchrun; one rank per GPU)
 
 The backward pipeline (sherf_amd/backward.py) is checked against the unmodified reference's gradients by
 tests/test_gpu_backward.py (`pytest -m gpu`).  Rank 0 prints ONE JSON line; `roofline` is the step's dominant kernel
@@ -29,12 +29,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg2')
     a = ap.parse_args()
+    import bench
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:        # no launcher in front: start the N ranks here (as bench.py does; sherf/train.py:98-103)
+        sys.exit(bench.launch_ranks(a.gpus, script=__file__))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
+    bench.check_world(a.gpus, world, 'bench_train.py')
     torch.cuda.set_device(lrank)
     dev = torch.device('cuda', lrank)
     if world > 1:
         torch.distributed.init_process_group('nccl', device_id=dev)
-    import bench
     from synthdata import fixtures, synth                    # seeded synthetic inputs (not the oracle)
     from sherf_amd import dist as sdist
     from sherf_amd.renderer import ImportanceRenderer
@@ -141,7 +144,7 @@ def main():
                             note='largest single kernel of the step; fp32 read-modify-write atomics of whole rows (lane = channel), the coarsest voxel level summed in registers per bin: '
                                  'atomic-rate bound, not bandwidth bound (round 2 direct form: 20.3 ms; profiles/r03_scatter_final.txt)')
         print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
-                              unit='rays/s', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
+                              unit='rays/s', n_gpus=world, rccl_ranks=torch.distributed.get_world_size() if world > 1 else 1, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32 (backward: fp32 kernels, MFMA GEMMs on a three-part bf16 split, MFMA sparse-conv input gradient on a range-scaled fp16 split; forward: f16x3 MFMA)',
                               data='synthetic', final_loss=float(loss), phases_ms=phases,
                               host_ms=dict(zip(('forward', 'backward', 'allreduce_adam'), (1e3 * np.mean(host_t, 0)).tolist())), roofline=roofline,

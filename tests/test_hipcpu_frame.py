@@ -124,11 +124,12 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
                         lambda a, lrank, timeout=300, save=None: bench.torch_gpu_baseline(a.config, torch.device('cpu'), a.bn_mode == 'train', iters=1, save=save))
     monkeypatch.setattr(bench, 'pmc_traffic', lambda a, lrank, timeout=150: dict(hbm_bytes_per_launch=12345, note='faked'))
     monkeypatch.setattr(bench, 'SECONDARY_ITERS', dict(mlp=1, mlp_warmup=0, frames=1, frames_warmup=0))
-    keep = {k: fixtures.CONFIGS[k] for k in ('cfg3', 'cfg2_dense', 'cfg3_ri', 'cfg2_dense_ri', 'cfg2')}
+    keep = {k: fixtures.CONFIGS[k] for k in ('cfg3', 'cfg2_dense', 'cfg3_ri', 'cfg2_dense_ri', 'cfg2', 'cfg2_ri')}
     for sfx, var in (('', {}), ('_ri', dict(variant='ri'))):                       # the secondary workloads, tiny-sized here
         fixtures.CONFIGS['cfg3' + sfx] = dict(fixtures.CONFIGS['tiny'], **var)
         fixtures.CONFIGS['cfg2_dense' + sfx] = dict(fixtures.CONFIGS['tiny'], fill=1.55, **var)
     fixtures.CONFIGS['cfg2'] = dict(fixtures.CONFIGS['tiny_nv'])
+    fixtures.CONFIGS['cfg2_ri'] = dict(fixtures.CONFIGS['tiny_nv'], variant='ri')
     try:
         # the default workload: the reference-init network, precision 'auto' (-> one fp16 product), parity = truth protocol + plain 1e-3
         monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny_ri', '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--streams', '1', '--exact-grids'])
@@ -137,11 +138,14 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
         assert res['n_gpus'] == 1 and res['steps'] == 1 and res['unit'] == 'rays/s' and res['value'] > 0
         assert res['config']['mlp_precision'] == 'f16' and res['config']['mlp_precision_requested'] == 'auto' and res['dtype'].startswith('f16 MFMA')
         assert res['config']['mlp_precision_auto']['choice'] == 'f16' and res['config']['exact_grids'] is True and res['config']['valid_samples'] > 0
-        assert res['roofline']['kernel'] == 'nerf_mlp_kernel' and res['roofline']['frac'] > 0 and res['roofline']['traffic'] == 12345
+        # (auto -> one fp16 product -> the network runs as two launches)
+        assert res['roofline']['kernel'].startswith('nerf_tokens_kernel + nerf_decoder_kernel') and res['roofline']['frac'] > 0 and res['roofline']['traffic'] == 12345
+        assert res['roofline']['executed_mfma_flop'] < res['roofline']['algorithmic_flop_per_launch'] * 1.2 and res['rccl_ranks'] == 1
         assert 'frame_timeline_ms' in res and res['torch_gpu_baseline']['value'] > 0 and res['torch_gpu_baseline']['speedup_vs_it'] > 0
         sec = res['secondary']
         assert sec['mlp_kernel_alone']['f16x3']['kernel_ms'] > 0 and 1e-6 < sec['mlp_kernel_alone']['f16']['rgb_rel_err_max_vs_f16x3'] < 1e-3
         assert sec['mlp_kernel_alone']['bf16']['rgb_rel_err_max_vs_f16x3'] > sec['mlp_kernel_alone']['f16']['rgb_rel_err_max_vs_f16x3']
+        assert all(sec['mlp_kernel_alone'][k + '_two_launches']['bit_identical_to_one_launch'] for k in ('f16', 'bf16', 'f16x3'))
         assert sec['cfg3_ri']['rays_per_s'] > 0 and sec['cfg2_dense_ri']['valid_fraction'] > sec['cfg3_ri']['valid_fraction']
         assert sec['cfg2']['mlp_precision'] == 'f16x3'                               # the adversarial weights stay fp32-grade under `auto`
         assert res['value_dense'] == sec['cfg2_dense_ri']['rays_per_s'] and res['valid_fraction_dense'] == sec['cfg2_dense_ri']['valid_fraction']
@@ -155,6 +159,7 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
         bench.main()
         res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
         assert res['config']['mlp_precision'] == 'f16x3' and res['parity_ok'] is True and 'plain_ok' not in res['parity']
+        assert res['roofline']['kernel'] == 'nerf_mlp_kernel'
         # a precision that misses the tolerance: the JSON line says so and the process exits non-zero
         monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'tiny', '--precision', 'bf16', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--streams', '1',
                                           '--no-secondary', '--no-pmc'])
@@ -196,6 +201,30 @@ def test_bench_two_ranks_dry_run(cpu_product, partition):
     else:
         assert res['n_gpus'] == 2 and res['scaling'] == 'strong' and res['config']['parallelism'] == 'ray tiles x2 (one frame)'
         assert res['config']['rays'] == 1024 and abs(res['value'] - 1024 / per_step) < 1e-6 * res['value']      # the FRAME's rays per second
+
+
+def test_bench_launches_its_own_ranks(cpu_product):
+    """`python bench.py --gpus 2 --config tiny` with NO launcher in front (the form bench.py's docstring advertises and the driver uses for
+    N = 1): the script re-executes itself under torch.distributed.run, two ranks over gloo on the host build, and rank 0's line says
+    n_gpus == 2 with both ranks' devices; started by a launcher with a different world size it refuses."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SHERF_HIPCPU_LIB=_lib.LIB_PATH, SHERF_DIST_BACKEND='gloo', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(G.ROOT, 'bench.py'), '--gpus', '2', '--config', 'tiny', '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
+            '--no-torch-gpu-baseline']
+    for extra, par in (([], 'views x2'), (['--partition', 'rays'], 'ray tiles x2 (one frame)')):
+        r = subprocess.run(base + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-800:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        res = json.loads(lines[0])
+        assert res['n_gpus'] == 2 and res['rccl_ranks'] == 2 and len(res['rank_devices']) == 2 and res['config']['parallelism'] == par
+    # a launcher that started ONE rank for --gpus 2: refused, no line
+    r = subprocess.run(base, env=dict(env, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 2 and 'refusing' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
 
 
 def test_ray_tile_sharding_two_ranks(cpu_product):
