@@ -469,6 +469,11 @@ class ImportanceRenderer(nn.Module):
         mlp = opts.get('mlp_precision') or self.mlp_precision
         tab = opts.get('table_precision') or getattr(self, 'table_precision', 'auto')
         enc = opts.get('encoder_precision') or getattr(self, 'encoder_precision', 'auto')
+        if enc == 'f16' and os.environ.get('SHERF_ALLOW_BROKEN_ENCODER_F16') != '1':
+            # single-fp16-product sparse convolutions: right on the host build of the kernels, WRONG images on the MI355X (DESIGN section 9,
+            # tools/enc_sp_diag.py) -- a diagnostic mode until that is explained, never something a caller gets silently
+            raise RuntimeError("encoder_precision='f16' renders wrong images on the MI355X (cause under investigation: DESIGN.md section 9); "
+                               "use 'f16x3' / 'auto', or set SHERF_ALLOW_BROKEN_ENCODER_F16=1 for diagnostics")
         training = getattr(self, '_in_autograd', False) or (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False))
         if training:
             return (mlp if mlp != 'auto' else 'f16x3', 'f32', 'f16x3'), False
