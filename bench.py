@@ -581,10 +581,13 @@ def frame_parity(ours, ref, S, plain=False):
                table=parity.format_truth_table(rep),
                oracle='oracle/sherf_oracle.py (pinned to the unmodified reference) as stock ATen ops on the GPU, whole frame: fp32 + float64 truth')
     ok = flips_ok and img_ok and rep['ok']
+    # the plain numbers against the fp32 reference are ALWAYS in the report (ours vs the reference, maximum over every sample off the
+    # margins); they decide the verdict on the reference-init workloads, where 1e-3 is required outright
+    srep, _ = parity.sample_protocol(o, ours['cs_idx'], ours['cs_vid'], ours['cs_tvid'], ours['sample_out'], S)
+    out['samples'] = srep
+    out['plain_within_1e-3_of_fp32_reference'] = bool(srep['sigma_rel_max'] <= 1e-3 and srep['rgb_rel_max'] <= 1e-3)
     if plain:
-        srep, _ = parity.sample_protocol(o, ours['cs_idx'], ours['cs_vid'], ours['cs_tvid'], ours['sample_out'], S)
-        out['samples'] = srep
-        out['plain_ok'] = bool(srep['sigma_rel_max'] <= 1e-3 and srep['rgb_rel_max'] <= 1e-3)
+        out['plain_ok'] = out['plain_within_1e-3_of_fp32_reference']
         ok = ok and out['plain_ok']
     out['ok'] = bool(ok)
     return out

@@ -111,11 +111,19 @@ class RenderFunction(torch.autograd.Function):
             rgb, depth, acc = call()
         ctx.renderer, ctx.decoder = renderer, decoder
         ctx.names = [n for n, _ in _named_params(renderer, decoder)]
+        # the backward reads the frame's compact samples, taps and encoder activations from the renderer's WORKSPACE (renderer.last), which
+        # the next forward of the same renderer on the same stream overwrites: the node remembers WHICH frame it recorded
+        ctx.frame = renderer.last
         ctx.mark_non_differentiable(depth)
         return rgb, depth, acc
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_acc):
+        if ctx.renderer.last is not ctx.frame:
+            raise RuntimeError('sherf_amd: backward of a frame whose workspace has been overwritten -- the same ImportanceRenderer rendered another '
+                               'frame between this forward and its backward (gradient accumulation over several forwards, a second generator pass, '
+                               'a grad-enabled forward in between).  Run every backward before the next forward of the same renderer, as the '
+                               'reference loop does (training_loop.py:354-386), or use one renderer per frame in flight.')
         out = render_backward(ctx.renderer, ctx.decoder, d_rgb, d_acc)
         grads = []
         for name, p in _named_params(ctx.renderer, ctx.decoder):

@@ -279,7 +279,7 @@ class ImportanceRenderer(nn.Module):
 
     def __getstate__(self):
         s = self.__dict__.copy()
-        for k in ('_smpl_dev', '_ws', '_wcache', 'last'):
+        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_flags'):
             s[k] = None
         s['_ws'] = None
         return s
@@ -381,7 +381,47 @@ class ImportanceRenderer(nn.Module):
     def check_finite(self):
         """True unless the MLP kernel of the LAST frame produced a non-finite sigma / rgb (its fp16 operand modes overflow beyond
         65504: csrc/mlp.hip sets counters[3]).  Synchronises with the frame; call it when validating a checkpoint, not per frame."""
-        return self.last is None or int(self.last['ws']['counters'][3]) == 0
+        return self.last is None or (int(self.last['ws']['counters'][3]) & 1) == 0      # (bits 1..: tile tickets of sherf_nerf_mlp_split)
+
+    # ---- `auto` stays honest after its calibration (VERDICT round 3, item 7a) --------------------------------------------------
+    AUTO_RECHECK_EVERY = int(os.environ.get('SHERF_AUTO_RECHECK', '256'))     # frames between re-calibrations of a kept choice (3 extra frames each)
+
+    def _auto_state_key(self):
+        """What the calibrated choice depends on besides the MLP's own parameters (those key the weight cache): the sparse encoder's
+        parameters AND buffers (BatchNorm running statistics): they set the magnitude of the fp16 tables' error."""
+        ts = list(self.encoder_3d.parameters())
+        if not self.encoder_3d.training:                   # (train-mode BatchNorm normalises with batch statistics and MOVES the running ones every frame)
+            ts += list(self.encoder_3d.buffers())
+        return (self.encoder_3d.training,) + tuple((t.data_ptr(), t._version) for t in ts)
+
+    def _flag_watch(self, ws, dev):
+        """The MLP kernel's non-finite flag (counters[3] bit 0: an fp16 operand beyond 65504) of EVERY frame, without a host wait: the word
+        is copied to pinned memory behind the frame and read a few frames later, once its event has passed.  A trip drops the
+        calibrated choice (the next frame re-calibrates, i.e. renders in the fp32-grade configuration) and is reported once."""
+        st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
+        if dev.type != 'cuda' or getattr(ws['counters'], 'device', dev).type != 'cuda':      # host build of the tests: read directly
+            if int(ws['counters'][3]) & 1:
+                st['tripped'] += 1
+            return st
+        ring = st['ring']
+        if len(ring) < 4:
+            ring.append(dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
+            st['next'] = len(ring) - 1
+        slot = ring[st.get('next', 0) % len(ring)]
+        st['next'] = (st.get('next', 0) + 1) % 4
+        if slot['busy']:
+            slot['ev'].synchronize()                       # (four frames old: long done)
+            if int(slot['host'][0]) & 1:
+                st['tripped'] += 1
+        slot['host'].copy_(ws['counters'][3:4], non_blocking=True)
+        slot['ev'].record(torch.cuda.current_stream(dev))
+        slot['busy'] = True
+        for other in ring:                                 # anything already finished is read now
+            if other is not slot and other['busy'] and other['ev'].query():
+                other['busy'] = False
+                if int(other['host'][0]) & 1:
+                    st['tripped'] += 1
+        return st
 
     # ---- weights -----------------------------------------------------------------------------
     def _weights(self, decoder, device, precision=None):
@@ -479,9 +519,21 @@ class ImportanceRenderer(nn.Module):
             return (mlp if mlp != 'auto' else 'f16x3', 'f32', 'f16x3'), False
         if mlp == 'auto':
             self._weights(decoder, dev, 'f16x3')
-            choice = self._wcache['auto']
+            wc = self._wcache
+            choice = wc['auto']
+            if choice is not None and choice != self.REFERENCE_CONFIG:
+                # a kept cheaper configuration is re-measured when anything it was measured under may have moved: the encoder's weights /
+                # statistics, AUTO_RECHECK_EVERY frames (other poses, cameras, subjects under the same weights), a tripped non-finite flag
+                st = self.__dict__.get('_flags') or {}
+                why = ('encoder state changed' if wc.get('auto_key') != self._auto_state_key() else
+                       'non-finite flag' if st.get('tripped', 0) > wc.get('auto_tripped', 0) else
+                       'periodic' if wc.get('auto_frames', 0) >= self.AUTO_RECHECK_EVERY else None)
+                if why:
+                    wc['auto_recalibrations'] = wc.get('auto_recalibrations', []) + [why]
+                    choice = wc['auto'] = None
             if choice is None:
                 return self.REFERENCE_CONFIG, True
+            wc['auto_frames'] = wc.get('auto_frames', 0) + 1
             mlp, t0, e0 = choice
             return (mlp, t0 if tab == 'auto' else tab, e0 if enc == 'auto' else enc), False
         tab = tab if tab != 'auto' else ('f16' if mlp in ('f16', 'bf16') else 'f32')
@@ -532,9 +584,12 @@ class ImportanceRenderer(nn.Module):
                     if e == e and e <= self.AUTO_TOL:
                         choice = cfg
                         break
-            self._wcache['auto'] = choice
+            wc = self._wcache
+            wc['auto'] = choice
+            wc['auto_key'], wc['auto_frames'], wc['auto_tripped'] = self._auto_state_key(), 0, (self.__dict__.get('_flags') or {}).get('tripped', 0)
             self.auto_report = dict(choice=choice[0], config=dict(mlp=choice[0], tables=choice[1], encoder=choice[2]),
-                                    errors_vs_reference_config=report, samples=nv, tol=self.AUTO_TOL)
+                                    errors_vs_reference_config=report, samples=nv, tol=self.AUTO_TOL,
+                                    recheck_every_frames=self.AUTO_RECHECK_EVERY, recalibrations=list(wc.get('auto_recalibrations', [])))
             return choice
         return decide
 
@@ -679,6 +734,8 @@ class ImportanceRenderer(nn.Module):
         self.encoder_3d.finish(pl)
         if decide is not None:
             decide()
+        if cfg[0] != 'f16x3' and not (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False)):
+            self._flag_watch(ws, dev)                      # single-product operands: watch the frame's non-finite flag (no host wait)
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
         self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8),

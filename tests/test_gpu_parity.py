@@ -201,6 +201,24 @@ def test_auto_precision_is_calibrated_per_weights():
         fx = dict(G.fixture(cfg)); fx['options'] = dict(fx['options'], margins=True)
         om = O.render_from_fixture(fx, G.state_for(cfg), training=True, keep=False)
         _assert_plain(f'{cfg} auto={rep["choice"]}', *_protocol(om, h, fx['options']['depth_resolution']))
+        if cfg == 'tiny_ri':
+            # the kept choice is not trusted for ever: ANOTHER pose / camera under the same weights renders on
+            # it and stays within the plain tolerance; it is re-measured periodically and when the kernel's non-finite flag trips
+            rend = h['rend']
+            other = G.hip_render('tiny_nv_ri', precision='auto')
+            assert other['rend'] is rend and other['last']['mlp_precision'] == 'f16'
+            fx2 = dict(G.fixture('tiny_nv_ri')); fx2['options'] = dict(fx2['options'], margins=True)
+            om2 = O.render_from_fixture(fx2, G.state_for('tiny_nv_ri'), training=True, keep=False)
+            _assert_plain('tiny_nv_ri on the choice calibrated on tiny_ri', *_protocol(om2, other, fx2['options']['depth_resolution']))
+            rend.AUTO_RECHECK_EVERY = rend._wcache['auto_frames'] + 1
+            assert G.hip_render(cfg, precision='auto')['last']['mlp_precision'] == 'f16'
+            again = G.hip_render(cfg, precision='auto')                          # the periodic re-calibration frame: fp32-grade
+            assert again['last']['mlp_precision'] == 'f16x3' and rend.auto_report['recalibrations'][-1] == 'periodic' and rend.auto_report['choice'] == 'f16'
+            rend.AUTO_RECHECK_EVERY = 1 << 30
+            assert G.hip_render(cfg, precision='auto')['last']['mlp_precision'] == 'f16'
+            rend._flags['tripped'] += 1                                          # what a non-finite output of a frame does, a few frames later
+            assert G.hip_render(cfg, precision='auto')['last']['mlp_precision'] == 'f16x3' and rend.auto_report['recalibrations'][-1] == 'non-finite flag'
+            del rend.AUTO_RECHECK_EVERY
         # new weights -> calibrated again
         with torch.no_grad():
             h['dec'].alpha_linear.bias.add_(0.0)

@@ -505,3 +505,14 @@ def test_training_step_through_autograd_matches_reference_gradients(cpu_product,
     assert G.rel(vfeat.grad, d_feat_e.tensor()) < 1e-4
     for k, v in g_e.items():
         assert G.rel(grads[k].reshape(-1), v.reshape(-1)) < 1e-4, k
+    # a backward whose frame has been overwritten by a later forward of the same renderer must refuse, not return the other frame's
+    # gradients: two forwards, then the FIRST one's backward
+    for p in list(rend.parameters()) + list(dec.parameters()):
+        p.grad = None
+    call = lambda: rend(planes, d['obs_img_all'][:, 0], obs_feat, SparseConvTensor(vfeat, spi['coord'], spi['out_sh'], 1), None, spd, dec,
+                        G.dev_tensor(d['ray_o_all'][:, 0]), d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, dict(fx['options']))
+    rgb1, _, acc1 = call()
+    rgb2, _, acc2 = call()
+    with pytest.raises(RuntimeError, match='workspace has been overwritten'):
+        O.stub_loss(rgb1[0], acc1[0, :, 0]).backward()
+    O.stub_loss(rgb2[0], acc2[0, :, 0]).backward()                              # the latest frame's backward is fine
