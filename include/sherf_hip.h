@@ -183,13 +183,10 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
 /* The same network as TWO launches (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel), results bit-identical to sherf_nerf_mlp:
- * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS,
- * tiles handed out by a ticket counter; launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  The form
- * the single-product precisions (prec 0, 2) run in: there the transformer's chain of dependent waits held a wave slot for 28 % of a
- * tile's time inside the one-launch kernel.  zfrag: scratch, ((capacity + 31) / 32) tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1).
- * counters[3] must hold 0 or 1 on entry (bit 0 = the non-finite flag of sherf_nerf_mlp; bits 1.. are used as the tile tickets and are
- * cleared again by launch 2; sherf_sample_mask_nn zeroes the word every frame). */
-int sherf_nerf_mlp_split(int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+ * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS;
+ * launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  zfrag: scratch for the fused tokens,
+ * ((capacity + 31) / 32) tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1). */
+int sherf_nerf_mlp_split(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                          const float* wbias, int prec, int64_t capacity, void* zfrag, float* out, sherf_stream_t stream);
 /* The weight stream for `prec` built on the device (what sherf_amd/mlp_pack.py: pack() builds on the host, bit for bit): slot i (2 bytes) of
  * stream_out = piece (src[i] & 1: 0 = hi, 1 = lo) of flat[src[i] >> 1], zero where src[i] < 0; bias_out[i] = flat[bias_src[i]] or 0.

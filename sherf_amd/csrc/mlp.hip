@@ -173,7 +173,8 @@ __device__ int g_mlp_trace_every = 0;
 #define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
 #endif
 
-// SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers
+// SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers, 128 = the decoder's A fragments
+// are read from LDS once (window builds) instead of every step
 #ifndef SHERF_MLP_ABLATE
 #define SHERF_MLP_ABLATE 0
 #endif
@@ -352,35 +353,65 @@ __device__ __forceinline__ AFrag<PREC> load_units(const char* p) {
     else { f.l0 = f.h0; f.l1 = f.h1; }
     return f;
 }
-// NB blocks over consecutive unit pairs (u0 + 2 i, u0 + 2 i + 1) of the step's slot.  `cur` holds the fragments of the first pair
-// (loaded by the caller: right after the step's barrier, so that their LDS latency hides under the DMA issue / the previous
-// pair's epilogue); every block's successor is fetched BEFORE the block is issued -- the asm's "memory" clobber pins that order
-// -- and MORE says that another segment of the same step follows at u0 + 2 NB (its first pair is then left in `cur`).
+// SHERF_MLP_AWIN (round 4): how many unit PAIRS of A fragments a wave fetches ahead inside a step.
+//   0 (rounds 2-3): one -- every block's successor is fetched right before the block is issued, i.e. one block (two MFMAs = 64 cycles of
+//     matrix pipe) ahead of its use.  The LDS answers a ds_read_b128 in >= 64 cycles when idle and in a multiple of that with twelve waves
+//     reading fragments and three workgroups' weight DMA landing, so EVERY block of a step began with an exposed s_waitcnt lgkmcnt:
+//     four dependent LDS round trips per step and wave (ISA: ds_read x2, s_waitcnt lgkmcnt(2), s_nop 1, v_mfma x2, repeated).
+//   W > 0: a window of W pairs.  Right behind the step's barrier the wave fetches the first W pairs of the step at once (they overlap
+//     the weight-DMA issue and the previous layer's epilogue), the blocks then run off the window and a pair beyond it (the five-pair
+//     steps of pts_linears.0 / .5) is fetched into the slot its block has just freed.  4 pairs = 32 registers for the single-product
+//     precisions (16 more than before); prec 1 keeps W = 0 (its fragments are twice the size and its blocks three times as long).
+#ifndef SHERF_MLP_AWIN
+#define SHERF_MLP_AWIN 4
+#endif
+template <int PREC> constexpr int AWIN = PREC == 1 ? 0 : SHERF_MLP_AWIN;
+template <int PREC> struct AWindow { AFrag<PREC> f[AWIN<PREC> > 0 ? AWIN<PREC> : 1]; };
+// (re)fill behind a barrier: the first min(n_pairs, W) pairs of the step whose slot is `s`
+template <int PREC>
+__device__ __forceinline__ void win_fill(AWindow<PREC>& w, const char* s, int n_pairs) {
+    constexpr int UNIT = Ctx<PREC>::UNIT, W = AWIN<PREC> > 0 ? AWIN<PREC> : 1;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+        if (i < n_pairs) w.f[i] = load_units<PREC>(s + 2 * i * UNIT);
+}
+// NB blocks over consecutive unit pairs (u0 + 2 i, u0 + 2 i + 1) of the step's slot `s`; the window holds the step's pairs as described
+// above (W = 0: w.f[0] = the pair of the next block).  Every fetch sits in front of an asm block whose "memory" clobber pins it there.
 //   PAIR = true : units = (chunk 0, chunk 1) at K-block i, both chains take b[i]             (a pair of output chunks)
 //   PAIR = false: units = (kb 2i, kb 2i+1) of ONE chunk, chain 0 takes b[2i], chain 1 b[2i+1] (split-K: the caller adds the chains)
+//   MORE: another segment of the same step follows at u0 + 2 NB;  tot_pairs: pairs of the whole step (default: this segment ends it)
 template <int PREC, int NB, bool PAIR, bool MORE>
-__device__ __forceinline__ void mma_chains(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
-    constexpr int UNIT = Ctx<PREC>::UNIT;
+__device__ __forceinline__ void mma_chains(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AWindow<PREC>& w, int tot_pairs = -1) {
+    constexpr int UNIT = Ctx<PREC>::UNIT, W = AWIN<PREC>;
+    const int p0 = u0 / 2, tot = tot_pairs >= 0 ? tot_pairs : p0 + NB;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        AFrag<PREC> nxt;
-        const bool pre = i + 1 < NB || MORE;
-        if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
         const BFrag<PREC>& b0 = b[PAIR ? i : 2 * i];
         const BFrag<PREC>& b1 = b[PAIR ? i : 2 * i + 1];
-        if constexpr (PREC == 1) mfma_block<PREC>(acc0, acc1, cur.h0, cur.l0, cur.h1, cur.l1, b0.hi, b0.lo, b1.hi, b1.lo);
-        else mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
-        if (pre) cur = nxt;
+        if constexpr (W == 0) {
+            AFrag<PREC> nxt;
+            const bool pre = i + 1 < NB || MORE;
+            if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
+            AFrag<PREC>& cur = w.f[0];
+            if constexpr (PREC == 1) mfma_block<PREC>(acc0, acc1, cur.h0, cur.l0, cur.h1, cur.l1, b0.hi, b0.lo, b1.hi, b1.lo);
+            else mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
+            if (pre) cur = nxt;
+        } else {
+            const int p = p0 + i;
+            AFrag<PREC>& cur = w.f[p % (W > 0 ? W : 1)];
+            mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
+            if (p + W < tot && !(SHERF_MLP_ABLATE & 128)) cur = load_units<PREC>(s + 2 * (p + W) * UNIT);       // the slot this block has just freed
+        }
     }
 }
 template <int PREC, int NK, bool MORE = false>
-__device__ __forceinline__ void mma_pair(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
-    mma_chains<PREC, NK, true, MORE>(s, u0, b, acc0, acc1, cur);
+__device__ __forceinline__ void mma_pair(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AWindow<PREC>& w, int tot_pairs = -1) {
+    mma_chains<PREC, NK, true, MORE>(s, u0, b, acc0, acc1, w, tot_pairs);
 }
 template <int PREC, int NK>
-__device__ __forceinline__ void mma_splitk(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
+__device__ __forceinline__ void mma_splitk(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AWindow<PREC>& w) {
     static_assert(NK % 2 == 0, "even / odd K-block chains");
-    mma_chains<PREC, NK / 2, false, false>(s, u0, b, acc0, acc1, cur);
+    mma_chains<PREC, NK / 2, false, false>(s, u0, b, acc0, acc1, w);
 }
 
 // v + (the partner lane's v): the partner lane (lane ^ 32) holds the other 16 features of the sample.  SHERF_MLP_PERMLANE (round 4):
@@ -694,9 +725,11 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
     int step = 2;
     BFrag<PREC> ha[8], hb[8];
-    AFrag<PREC> cur = load_units<PREC>(cx.slot(step));               // first fragments of the next step: fetched right behind its barrier
+    AWindow<PREC> cur;                                               // A fragments of the coming step: fetched right behind its barrier
+    win_fill<PREC>(cur, cx.slot(step), step_units(step) / 2);
     // (the fetch goes out BEFORE the DMA issue of the slot just freed: its LDS latency hides under those ~30 instructions)
-#define SHERF_NEXT_STEP() do { step_wait(cx, step); cur = load_units<PREC>(cx.slot(step + 1)); dma_issue(cx, step + NSLOT); ++step; } while (0)
+#define SHERF_NEXT_STEP() do { step_wait(cx, step); if (step + 1 < N_STEPS && !(SHERF_MLP_ABLATE & 128)) win_fill<PREC>(cur, cx.slot(step + 1), step_units(step + 1) / 2); \
+                               dma_issue(cx, step + NSLOT); ++step; } while (0)
     // a 128 -> 128 layer: two pairs of output chunks x two K-halves = four steps; chunk C0 + T -> OUT[2T], OUT[2T+1]
 #define SHERF_LAYER128(C0, IN, OUT, RELU)                                                             \
     _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                   \
@@ -714,7 +747,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
         for (int P = 0; P < 2; ++P) {
             f32x16 acc0 = bias_tile(cx, 9 + 2 * P), acc1 = bias_tile(cx, 10 + 2 * P);
             const char* s = cx.slot(step);
-            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur);
+            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur, 5);
             mma_pair<PREC, 2>(s, 6, z0b, acc0, acc1, cur);
             SHERF_NEXT_STEP();
             finish_pair<PREC, true>(acc0, acc1, ha + 4 * P);
@@ -733,7 +766,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
         for (int P = 0; P < 2; ++P) {
             f32x16 acc0 = bias_tile(cx, 29 + 2 * P), acc1 = bias_tile(cx, 30 + 2 * P);
             const char* s = cx.slot(step);
-            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur);
+            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur, 5);
             mma_pair<PREC, 2>(s, 6, z0b, acc0, acc1, cur);
             SHERF_NEXT_STEP();
             mma_pair<PREC, 4>(cx.slot(step), 0, ha, acc0, acc1, cur);
@@ -767,7 +800,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
         mma_pair<PREC, 4>(cx.slot(step), 0, ha + 4, acc0, acc1, cur);
         SHERF_NEXT_STEP();
         const char* s = cx.slot(step);
-        mma_pair<PREC, 2, true>(s, 0, pv, acc0, acc1, cur);
+        mma_pair<PREC, 2, true>(s, 0, pv, acc0, acc1, cur, 4);
         mma_pair<PREC, 2>(s, 4, z1b, acc0, acc1, cur);
         SHERF_NEXT_STEP();
         finish_pair<PREC, true>(acc0, acc1, gb);
@@ -865,16 +898,16 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 // precisions (4 KiB per tile), q = 4 * (z) + 2 * kb + (0: hi, 1: lo) for prec 1 (8 KiB per tile).
 template <int PREC> constexpr int ZFRAGS = PREC == 1 ? 8 : 4;
 
-// Launch 1 of 2: the slot-fusion remainder + the 3-token transformer.  VALU / latency bound; its 20-40 KiB of weights stay resident in
-// LDS (no ring, no per-step barrier) and every wave pulls tiles on its own from a ticket counter: bits 1.. of counters[3] (bit 0 is the
-// non-finite flag; the sampler zeroes the word every frame and nerf_decoder_kernel clears the ticket bits again at its end), so the
-// waves stay busy until the tiles run out -- a static split leaves the SIMDs with 5 or 6 of the ~5.3 tiles per wave slot.
+// Launch 1 of 2: the slot-fusion remainder + the 3-token transformer.  VALU / latency bound; its 24-48 KiB of weights stay resident in
+// LDS (no ring, no per-step barrier) and every wave walks its own tiles (wave w of the grid: tiles w, w + W, ...).  (Round 4's first
+// form pulled tiles from ONE atomic ticket word: 40 K tickets at the ~88 dequeues / us a single word sustains = 0.45 ms, measured
+// 0.54 ms -- profiles/r04_call_a.txt.  The static split leaves at most one tile per wave of imbalance.)
 #ifndef SHERF_MLP_TOKENS_WAVES
 #define SHERF_MLP_TOKENS_WAVES 4
 #endif
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_TOKENS_WAVES)
-nerf_tokens_kernel(int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                    const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, u32x4* __restrict__ zfrag) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
@@ -888,12 +921,7 @@ nerf_tokens_kernel(int32_t* __restrict__ counters, const float4* __restrict__ to
     __syncthreads();
     CX cx;
     cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0;
-    unsigned* ticket = reinterpret_cast<unsigned*>(counters) + 3;
-    for (;;) {
-        unsigned t = 0;
-        if (cx.lane == 0) t = atomicAdd(ticket, 2u) >> 1;
-        const int64_t tile = (int64_t)__builtin_amdgcn_readfirstlane(__shfl(t, 0));      // (the shuffle is what broadcasts on the host build of the tests)
-        if (tile >= n_tiles) break;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
         // loop (hundreds of live registers).  The OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and
         // every weight read becomes a flat load.
@@ -919,14 +947,12 @@ nerf_tokens_kernel(int32_t* __restrict__ counters, const float4* __restrict__ to
 // Launch 2 of 2: the NeRF decoder, steps 2..42 of the weight stream through the 3-slot ring: every wave of the chip in the MFMA-bound phase.
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : 3)
-nerf_decoder_kernel(int32_t* __restrict__ counters, const u32x4* __restrict__ zfrag, const float* __restrict__ extras,
+nerf_decoder_kernel(const int32_t* __restrict__ counters, const u32x4* __restrict__ zfrag, const float* __restrict__ extras,
                     const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
     using CX = Ctx<PREC>;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
     const int64_t n_tiles = (nv + 31) / 32;
-    // the tokens kernel has finished (same stream): its ticket bits are cleared for the next launch; bit 0 (non-finite flag) stays
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAnd(reinterpret_cast<unsigned*>(counters) + 3, 1u);
     if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
     CX cx;
     ring_ctx<PREC>(cx, lds, ws, wbias);
@@ -1039,9 +1065,8 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
 }
 
 // The two-launch form (see nerf_tokens_kernel / nerf_decoder_kernel): same inputs, same outputs bit for bit; zfrag = scratch for the fused
-// tokens, (capacity + 31) / 32 tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1).  counters[3] must hold 0 or 1 on entry (its upper bits are the
-// tokens kernel's tile tickets: the sampler zeroes the word every frame, the decoder kernel clears the ticket bits at its end).
-extern "C" int sherf_nerf_mlp_split(int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+// tokens, (capacity + 31) / 32 tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1).
+extern "C" int sherf_nerf_mlp_split(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                                     const float* wbias, int prec, int64_t capacity, void* zfrag, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out && zfrag);
     SHERF_CHECK_ARG(prec >= 0 && prec <= 2 && capacity > 0);

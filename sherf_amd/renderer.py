@@ -381,7 +381,7 @@ class ImportanceRenderer(nn.Module):
     def check_finite(self):
         """True unless the MLP kernel of the LAST frame produced a non-finite sigma / rgb (its fp16 operand modes overflow beyond
         65504: csrc/mlp.hip sets counters[3]).  Synchronises with the frame; call it when validating a checkpoint, not per frame."""
-        return self.last is None or (int(self.last['ws']['counters'][3]) & 1) == 0      # (bits 1..: tile tickets of sherf_nerf_mlp_split)
+        return self.last is None or (int(self.last['ws']['counters'][3]) & 1) == 0
 
     # ---- `auto` stays honest after its calibration (VERDICT round 3, item 7a) --------------------------------------------------
     AUTO_RECHECK_EVERY = int(os.environ.get('SHERF_AUTO_RECHECK', '256'))     # frames between re-calibrations of a kept choice (3 extra frames each)

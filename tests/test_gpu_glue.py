@@ -26,13 +26,12 @@ def test_exact_grids_and_gather_variants_on_device(cfg):
 
 @pytest.mark.parametrize('cfg', ['tiny', 'cfg1_ri'])
 def test_two_launch_mlp_renders_the_one_launch_bits_on_device(cfg):
-    """sherf_nerf_mlp_split (round 4: the transformer as a barrier-free, ticketed launch with resident weights + the decoder as its own
+    """sherf_nerf_mlp_split (round 4: the transformer as a barrier-free launch with resident weights + the decoder as its own
     MFMA-bound launch) against sherf_nerf_mlp, every precision, on the hardware: same bits.  The default form is the two-launch one exactly for
-    the single-product precisions; the ticket bits of counters[3] are cleared by the decoder launch."""
+    the single-product precisions; """
     for prec in ('f16x3', 'f16', 'bf16'):
         one = G.hip_render(cfg, precision=prec, options=dict(mlp_split=False))
         two = G.hip_render(cfg, precision=prec, options=dict(mlp_split=True))
         dflt = G.hip_render(cfg, precision=prec)
         for k in ('rgb', 'acc', 'depth'):
             assert torch.equal(one[k], two[k]) and torch.equal(one[k], dflt[k]), (prec, k)
-        assert int(two['last']['ws']['counters'][3]) == 0

@@ -87,7 +87,7 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
     # the single-product bf16 mode (north_star's nominal precision) runs through the same frame, at its own (looser) accuracy
     b = G.hip_render('tiny_nv', precision='bf16')
     assert 1e-4 < G.rel(b['rgb'], h['rgb']) < 0.2
-    # the per-sample network as two launches (sherf_nerf_mlp_split: ticketed tokens kernel + decoder kernel) == the one-launch kernel, in
+    # the per-sample network as two launches (sherf_nerf_mlp_split: tokens kernel + decoder kernel) == the one-launch kernel, in
     # every precision; the default picks the two-launch form exactly for the single-product precisions
     for prec in ('f16x3', 'f16', 'bf16'):
         one = G.hip_render('tiny_nv', precision=prec, options=dict(mlp_split=False))
@@ -95,7 +95,6 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
         dflt = G.hip_render('tiny_nv', precision=prec)
         for k in ('rgb', 'acc', 'depth'):
             assert torch.equal(one[k], two[k]) and torch.equal(one[k], dflt[k]), (prec, k)
-        assert int(two['last']['ws']['counters'][3]) == 0
 
 
 def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):

@@ -606,8 +606,7 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
     if prec == 1:
         assert r_sig < 1e-3 and r_rgb < 1e-3, (r_sig, r_rgb)
     assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), 3, n, _P(out), None) != 0        # unknown precision
-    # the two-launch form (tokens kernel with resident weights and ticketed tiles + decoder kernel): the same bits, twice in a row on the
-    # same counters (the decoder launch clears the ticket bits), the non-finite flag bit left alone
+    # the two-launch form (tokens kernel with resident weights + decoder kernel): the same bits; the non-finite flag word is left alone
     zfrag = torch.zeros(tiles * (2048 if prec == 1 else 1024), dtype=torch.int32)
     for flag in (0, 1):
         counters[3] = flag
