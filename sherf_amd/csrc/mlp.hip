@@ -174,7 +174,8 @@ __device__ int g_mlp_trace_every = 0;
 #endif
 
 // SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers, 128 = the decoder's A fragments
-// are read from LDS once (window builds) instead of every step
+// are read from LDS once (window builds) instead of every step, 256 = no transformer arithmetic (z = the raw tokens), 512 = no positional
+// encodings (zero fragments), 1024 = layer epilogues without conversion / ReLU (16 moves instead of 32 VALU)
 #ifndef SHERF_MLP_ABLATE
 #define SHERF_MLP_ABLATE 0
 #endif
@@ -473,6 +474,11 @@ __device__ __forceinline__ void sincos_exact_phase(float a, float* s, float* c) 
 // 6e-5 with a 5e-7 error of the first sine -- and the decoder multiplies that by its gain (the tail of the per-sample sigma error).
 template <int PREC, int NF, int NKB>
 __device__ __forceinline__ void pe_frags(int h, float x, float y, float z, BFrag<PREC> (&out)[NKB]) {
+    if constexpr ((SHERF_MLP_ABLATE & 512) != 0) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) out[kb] = make_frag<PREC>(x, y, z, 0.f, 0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     float f[NKB * 16];
 #pragma unroll
     for (int i = 0; i < NKB * 16; ++i) f[i] = 0.f;
@@ -516,6 +522,14 @@ __device__ __forceinline__ uint32_t relu2_f16(uint32_t p) {
 template <int PREC, bool RELU>
 __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PREC>* out) {
     mfma_settle(acc0, acc1);
+    if constexpr ((SHERF_MLP_ABLATE & 1024) != 0) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[f].hi[e] = __builtin_bit_cast(uint32_t, f < 2 ? acc0[4 * f + e] : acc1[4 * (f - 2) + e]);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     constexpr bool PK = RELU && PREC == 2 && SHERF_MLP_PK_RELU;
     if constexpr (RELU && !PK) {
 #pragma unroll
@@ -566,6 +580,12 @@ __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __
                 tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
             }
         const float* ex = extras + tile * 12 * 32 + j;
+        if constexpr ((SHERF_MLP_ABLATE & 256) != 0) {
+            split_tile<PREC>(tok[0] + tok[2], z0b[0], z0b[1]);
+            split_tile<PREC>(tok[1] + tok[2], z1b[0], z1b[1]);
+            if constexpr (RING) { advance(cx, 0); advance(cx, 1); }
+            return;
+        }
 
         const char* s = RING ? cx.slot(0) : cx.lds;               // step 0: chunks 0..4
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
