@@ -335,7 +335,7 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
  * convolutions multiply single fp16 products (operands rounded to nearest even) instead of the three of the f16x3 split. */
 #define SHERF_FRAME_ENCODER_SINGLE 4
 /* frame->flags & SHERF_FRAME_MLP_SPLIT: the per-sample network runs as sherf_nerf_mlp_split (two launches; needs frame->zfrag) instead of
- * sherf_nerf_mlp.  Same results bit for bit; sherf_amd.ImportanceRenderer sets it with the single-product MLP precisions. */
+ * sherf_nerf_mlp.  Same results bit for bit; opt-in (measured slower than the one launch on the MI355X: profiles/r04_call_b_mlp_ablations.txt). */
 #define SHERF_FRAME_MLP_SPLIT 8
 typedef struct {
     /* SMPL (a7-a9) */

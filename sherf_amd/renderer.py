@@ -264,7 +264,7 @@ class ImportanceRenderer(nn.Module):
         # SHERF_FRAME_EXACT_GRIDS (sherf_hip.h): launch warp / gather / MLP for the frame's actual valid-sample count (one host wait per
         # frame, where the reference has its own) instead of the R*S capacity; same results
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
-        # the per-sample network as two launches (sherf_nerf_mlp_split): None = where it is faster (the single-product precisions)
+        # the per-sample network as two launches (sherf_nerf_mlp_split): opt-in, measured slower than the one-launch kernel (see _set_config)
         self.mlp_split = {'': None, '0': False, '1': True}[os.environ.get('SHERF_MLP_SPLIT', '')]
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
@@ -546,11 +546,12 @@ class ImportanceRenderer(nn.Module):
         fr.wstream, fr.wbias = _lib.addr(wc['stream']), _lib.addr(wc['wbias'])
         fr.mlp_prec = MLP_PRECISIONS[cfg[0]]
         fr.flags = (1 if exact else 0) | (2 if cfg[1] == 'f16' else 0) | (4 if cfg[2] == 'f16' else 0)
-        # the two-launch form of the per-sample network (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel, bit-identical results)
-        # where it is the faster one: the single-product precisions (mlp_split=None), or as told
+        # the two-launch form of the per-sample network (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel, bit-identical results):
+        # opt-in.  Measured SLOWER than the one-launch kernel on the MI355X in every precision (f16, 512x512x64: 0.35 vs 0.285 ms at 4 %
+        # valid samples, 0.62 vs 0.51 ms at 7.6 %; profiles/r04_call_b_mlp_ablations.txt) -- see csrc/mlp.hip for why
         split = getattr(self, '_opt_mlp_split', None)
         if split is None:
-            split = self.mlp_split if getattr(self, 'mlp_split', None) is not None else cfg[0] in ('f16', 'bf16')
+            split = bool(getattr(self, 'mlp_split', None))
         fr.zfrag = None
         if split:
             ws = self._workspace(dev)

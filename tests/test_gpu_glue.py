@@ -27,8 +27,7 @@ def test_exact_grids_and_gather_variants_on_device(cfg):
 @pytest.mark.parametrize('cfg', ['tiny', 'cfg1_ri'])
 def test_two_launch_mlp_renders_the_one_launch_bits_on_device(cfg):
     """sherf_nerf_mlp_split (round 4: the transformer as a barrier-free launch with resident weights + the decoder as its own
-    MFMA-bound launch) against sherf_nerf_mlp, every precision, on the hardware: same bits.  The default form is the two-launch one exactly for
-    the single-product precisions; """
+    MFMA-bound launch) against sherf_nerf_mlp, every precision, on the hardware: same bits.  The default is the one-launch kernel (measured faster). """
     for prec in ('f16x3', 'f16', 'bf16'):
         one = G.hip_render(cfg, precision=prec, options=dict(mlp_split=False))
         two = G.hip_render(cfg, precision=prec, options=dict(mlp_split=True))
