@@ -185,6 +185,8 @@ template <int PREC> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     const char* lds;         // NSLOT ring slots (generic pointer, + this lane's 16 bytes: what the ds_reads use)
     uint32_t lds_addr;       // LDS byte address of the ring (what the DMA's M0 takes), wave-uniform
+    const char* ws_base;     // the stream without the wave / lane offsets, and the ring's LDS byte address (SHERF_MLP_DMA_SADDR)
+    uint32_t lds_base;
     int lane, h, wave;
 #if SHERF_MLP_TRACE
     uint32_t* trace;         // this wave's [64][4] stamps in LDS
@@ -200,9 +202,40 @@ template <int PREC> struct Ctx {
 // wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// SHERF_MLP_DMA_SADDR (round 4 experiment): a wave owns the K CONSECUTIVE pieces w K .. w K + K - 1 of a step and issues them from one
+// statement -- M0 written once, the source as SGPR base + this lane's 16 bytes, the piece index in the instruction's immediate offset
+// (which moves the LDS destination along with the source) -- instead of a VALU address add and an M0 save / set / restore per piece:
+// per tile 86 VALU and ~350 SALU less.  Same LDS image (the pieces only change owners).
+#ifndef SHERF_MLP_DMA_SADDR
+#define SHERF_MLP_DMA_SADDR 0
+#endif
+#if SHERF_MLP_DMA_SADDR
+template <int PREC>
+__device__ __forceinline__ void dma_issue_saddr(Ctx<PREC>& cx, int step) {
+    const int K = step_pieces<PREC>(step) / NW;
+    const char* sbase = cx.ws_base + (size_t)step_off_kib<PREC>(step) * 1024 + (size_t)(cx.wave * K) * 1024;
+    const uint32_t m = cx.lds_base + (step % NSLOT) * Ctx<PREC>::SLOT + (uint32_t)(cx.wave * K) * 1024;
+    const uint32_t voff = cx.lane * 16;
+    uint32_t keep;
+    if (K == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
+    else if (K == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
+}
+#endif
+
 template <int PREC>
 __device__ __forceinline__ void dma_issue(Ctx<PREC>& cx, int step) {
     if (step >= N_STEPS || (SHERF_MLP_ABLATE & 32)) return;
+#if SHERF_MLP_DMA_SADDR
+    if constexpr (PREC != 1) { dma_issue_saddr(cx, step); return; }
+#endif
     const char* src = cx.ws + (size_t)step_off_kib<PREC>(step) * 1024;          // (+ this lane's 16 bytes: folded into cx.ws)
     const uint32_t dst = cx.lds_addr + (step % NSLOT) * Ctx<PREC>::SLOT;
 #pragma unroll
@@ -284,6 +317,26 @@ __device__ __forceinline__ float erf_(float x) {
 #else
     return erff(x);
 #endif
+}
+// exact GELU 0.5 a (1 + erf(a / sqrt 2)) (renderer.py:940: nn.GELU()).
+//   FAST = false: through erf_ above (|error| <= 1.5e-7): the fp32-grade form prec 1 keeps.
+//   FAST = true (single-product precisions, round 4): gelu = relu(a) - |a| / 2 * y,  y = (a1 t + a2 t^2 + a3 t^3) exp(-a^2 / 2),
+//     t = 1 / (1 + p |a| / sqrt 2)  (Abramowitz-Stegun 7.1.25, |erf error| <= 2.5e-5 -> |gelu error| <= 1.3e-5 |a|: a twentieth of the
+//     fp16 rounding its consumer applies to it); written so that the sign of `a` never needs restoring: 11 VALU + 2 transcendentals
+//     instead of 16 + 2 -- the 32 evaluations per lane are the largest single VALU block of the transformer.
+template <bool FAST>
+__device__ __forceinline__ float gelu_(float a) {
+    if constexpr (!FAST) return 0.5f * a * (1.0f + erf_(a * 0.70710678118654752f));
+    const float aa = fabsf(a);
+    const float t = rcp_(fmaf(0.47047f * 0.70710678118654752f, aa, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+#if SHERF_MLP_FASTMATH
+    const float e = __builtin_amdgcn_exp2f(a * a * -0.72134752044448170f);           // exp(-a^2 / 2) = 2^(-a^2 log2(e) / 2)
+#else
+    const float e = expf(-0.5f * a * a);
+#endif
+    const float hy = 0.5f * poly * e;
+    return fmaf(-aa, hy, fmaxf(a, 0.0f));
 }
 // SHERF_MLP_DECODER_PRIO: issue priority of a wave once it enters the MFMA-bound decoder (over the co-resident workgroup's wave on
 // the same SIMD whenever that one is in its VALU-bound prologue; a new wave starts at priority 0)
@@ -432,23 +485,38 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 #endif
 }
 
-// LayerNorm over the 32 features of a token (16 here, 16 in lane^32), eps 1e-5 (renderer.py:931)
+// LayerNorm over the 32 features of a token (16 here, 16 in lane^32), eps 1e-5 (renderer.py:931).
+// prec 1 (fp32-grade): the two-pass form of round 1-3 (mean, then the sum of squared deviations).  Single-product precisions (round 4):
+// one pass -- sum and sum of squares together, var = E[x^2] - mean^2 (32 O(1) values in fp32: the cancellation costs ~1e-7) -- and the
+// normalisation as two fmas per feature ((x * inv - mean * inv) * g + b): 64 instead of 96 VALU per token, five tokens per tile.
 template <int PREC, class C>
 __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1) {
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += x[r];
-    s = xhalf_sum(s);
-    const float mean = s * (1.0f / 32.0f);
-    float q = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { float d = x[r] - mean; q += d * d; }
-    q = xhalf_sum(q);
-    const float inv = rsqrt_(q * (1.0f / 32.0f) + 1e-5f);
     const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
     f32x16 y;
+    if constexpr (PREC == 1) {
+        float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = (x[r] - mean) * inv * g[r] + bt[r];
+        for (int r = 0; r < 16; ++r) s += x[r];
+        s = xhalf_sum(s);
+        const float mean = s * (1.0f / 32.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { float d = x[r] - mean; q += d * d; }
+        q = xhalf_sum(q);
+        const float inv = rsqrt_(q * (1.0f / 32.0f) + 1e-5f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = (x[r] - mean) * inv * g[r] + bt[r];
+    } else {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s += x[r]; q = __builtin_fmaf(x[r], x[r], q); }
+        s = xhalf_sum(s); q = xhalf_sum(q);
+        const float mean = s * (1.0f / 32.0f);
+        const float var = fmaxf(__builtin_fmaf(-mean, mean, q * (1.0f / 32.0f)), 0.0f);
+        const float inv = rsqrt_(var + 1e-5f), off = -mean * inv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = __builtin_fmaf(__builtin_fmaf(x[r], inv, off), g[r], bt[r]);
+    }
     split_tile<PREC>(y, k0, k1);
 }
 
@@ -721,7 +789,7 @@ __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { float a = acc[i][r]; acc[i][r] = 0.5f * a * (1.0f + erf_(a * 0.70710678118654752f)); }
+                for (int r = 0; r < 16; ++r) acc[i][r] = gelu_<PREC != 1>(acc[i][r]);
                 split_tile<PREC>(acc[i], gb[i][0], gb[i][1]);
             }
             f32x16 acc2[2] = {bias_tile(cx, 8), bias_tile(cx, 8)};
@@ -867,6 +935,7 @@ __device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* w
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
     cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
+    cx.ws_base = ws; cx.lds_base = cx.lds_addr - cx.wave * 1024;
 #if SHERF_MLP_TRACE
     cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
     if (cx.lane == 0) {
@@ -940,7 +1009,7 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
     for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
     __syncthreads();
     CX cx;
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0; cx.ws_base = ws; cx.lds_base = 0;
     for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
         // loop (hundreds of live registers).  The OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and

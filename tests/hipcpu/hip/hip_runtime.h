@@ -226,6 +226,7 @@ inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_sinf(float r) { return (float)sin(6.283185307179586476925 * (double)r); }
 inline float __builtin_amdgcn_cosf(float r) { return (float)cos(6.283185307179586476925 * (double)r); }
 inline float __expf(float x) { return expf(x); }
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 inline float __sinf(float x) { return sinf(x); }
 inline float __cosf(float x) { return cosf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
