@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--config', default='cfg2_ri')
     ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'])
     ap.add_argument('--stress', type=int, default=0)
+    ap.add_argument('--forms', default='one,pipe', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), pipe (sherf_nerf_mlp_pipe)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_ab.json'))
     a = ap.parse_args()
     import bench
@@ -61,11 +62,14 @@ def main():
         two = getattr(lib, 'sherf_nerf_mlp_split', None)
         if two is not None:
             two.restype, two.argtypes = ct.c_int, [ct.c_void_p] * 5 + [ct.c_int, ct.c_int64, ct.c_void_p, ct.c_void_p, ct.c_void_p]
-        return one, two
+        pipe = getattr(lib, 'sherf_nerf_mlp_pipe', None)
+        if pipe is not None:
+            pipe.restype, pipe.argtypes = one.restype, one.argtypes
+        return one, two, pipe
 
     def launch(fn, form):
-        if form == 'one':
-            return fn[0](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
+        if form in ('one', 'pipe'):
+            return fn[0 if form == 'one' else 2](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
         return fn[1](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(zfrag), A(out), stream)
 
     def timed(fn, form, iters=20):
@@ -85,7 +89,9 @@ def main():
     bound = {t: bind(p) for t, p in libs.items()}
     launch(bound['product'], 'one'); torch.cuda.synchronize()
     ref = out[:nv].clone()
-    arms = [(t, form) for t, fn in bound.items() for form in ('one', 'two') if form == 'one' or fn[1] is not None]
+    forms = [f for f in a.forms.split(',') if f]
+    arms = [(t, form) for t, fn in bound.items() for form in forms
+            if form == 'one' or (form == 'two' and fn[1] is not None) or (form == 'pipe' and fn[2] is not None and a.precision != 'f16x3')]
     for _ in range(40):                                         # clock warm-up
         launch(bound['product'], 'one')
     torch.cuda.synchronize()
@@ -112,8 +118,8 @@ def main():
         big = torch.randn(64 << 20, device=dev)
         idxs = [torch.randint(0, big.numel(), (n,), device=dev) for n in (1 << 18, 1 << 21, 1 << 23, 3 << 20)]
         bad = {}
-        for form in ('one', 'two'):
-            if bound['product'][1] is None and form == 'two':
+        for form in forms:
+            if form == 'pipe' and a.precision == 'f16x3':
                 continue
             n_bad_launches, n_bad_words = 0, 0
             for it in range(a.stress):
