@@ -1346,8 +1346,11 @@ __device__ __forceinline__ void pipe_steps(Ctx<PREC>& cx, DState<PREC>& D, TStat
     }
 }
 
+#ifndef SHERF_MLP_PIPE_WAVES
+#define SHERF_MLP_PIPE_WAVES 2        // workgroups per CU = waves per SIMD the pipelined kernel is compiled and launched for
+#endif
 template <int PREC>
-__global__ void __launch_bounds__(NW * 64, 2)
+__global__ void __launch_bounds__(NW * 64, SHERF_MLP_PIPE_WAVES)
 nerf_mlp_pipe_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
                      const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
     using CX = Ctx<PREC>;
@@ -1623,7 +1626,7 @@ extern "C" int sherf_nerf_mlp_pipe(const int32_t* counters, const float* tokens,
         n_cu = v > 0 ? v : 256;
     }
     const int64_t groups = ((capacity + 31) / 32 + NW - 1) / NW;
-    const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)n_cu * 2)), block(NW * 64);       // persistent: two workgroups per CU
+    const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)n_cu * SHERF_MLP_PIPE_WAVES)), block(NW * 64);       // persistent
     if (prec == 2)
         hipLaunchKernelGGL((nerf_mlp_pipe_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
                            reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
