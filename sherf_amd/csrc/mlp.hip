@@ -185,8 +185,9 @@ template <int PREC> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     const char* lds;         // NSLOT ring slots (generic pointer, + this lane's 16 bytes: what the ds_reads use)
     uint32_t lds_addr;       // LDS byte address of the ring (what the DMA's M0 takes), wave-uniform
-    const char* ws_base;     // the stream without the wave / lane offsets, and the ring's LDS byte address (SHERF_MLP_DMA_SADDR)
+    const char* ws_base;     // the stream without the wave / lane offsets, and the ring's LDS byte address: the SADDR issue (saddr = true)
     uint32_t lds_base;
+    bool saddr;
     int lane, h, wave;
 #if SHERF_MLP_TRACE
     uint32_t* trace;         // this wave's [64][4] stamps in LDS
@@ -202,20 +203,15 @@ template <int PREC> struct Ctx {
 // wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// SHERF_MLP_DMA_SADDR (round 4 experiment): a wave owns the K CONSECUTIVE pieces w K .. w K + K - 1 of a step and issues them from one
-// statement -- M0 written once, the source as SGPR base + this lane's 16 bytes, the piece index in the instruction's immediate offset
-// (which moves the LDS destination along with the source) -- instead of a VALU address add and an M0 save / set / restore per piece:
-// per tile 86 VALU and ~350 SALU less.  Same LDS image (the pieces only change owners).
-#ifndef SHERF_MLP_DMA_SADDR
-#define SHERF_MLP_DMA_SADDR 0
-#endif
-#if SHERF_MLP_DMA_SADDR
-template <int PREC>
-__device__ __forceinline__ void dma_issue_saddr(Ctx<PREC>& cx, int step) {
-    const int K = step_pieces<PREC>(step) / NW;
-    const char* sbase = cx.ws_base + (size_t)step_off_kib<PREC>(step) * 1024 + (size_t)(cx.wave * K) * 1024;
-    const uint32_t m = cx.lds_base + (step % NSLOT) * Ctx<PREC>::SLOT + (uint32_t)(cx.wave * K) * 1024;
-    const uint32_t voff = cx.lane * 16;
+// The SADDR form of the issue (round 4; cx.saddr): a wave owns the K CONSECUTIVE pieces w K .. w K + K - 1 of a step and issues them from
+// one statement -- M0 written once, the source as an SGPR base + this lane's 16 bytes, the piece index in the instruction's immediate
+// offset (which moves the LDS destination along with the source) -- instead of a 64-bit VGPR address add and an M0 save / set /
+// restore per piece.  Same LDS image (the pieces only change owners).  Measured on the MI355X (profiles/r04_call_e_pipelined_mlp.txt):
+// in nerf_mlp_kernel it is SLOWER (0.545 vs 0.507 ms: the pieces leave back to back), so that kernel keeps the per-piece form; in the
+// pipelined kernel it is what makes the register budget work (the VGPR address pairs were what spilled, and a spill reload's
+// s_waitcnt vmcnt(0) drains the weight DMA in flight: 0.91 -> 0.55 ms).
+// glds_saddr: K (1..3) LDS-DMA loads of 1 KiB each from sbase + voff + 1024 i to LDS byte address m + 1024 i (+ lane * 16)
+__device__ __forceinline__ void glds_saddr(uint32_t voff, const char* sbase, uint32_t m, int K) {
     uint32_t keep;
     if (K == 2)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
@@ -228,14 +224,18 @@ __device__ __forceinline__ void dma_issue_saddr(Ctx<PREC>& cx, int step) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
 }
-#endif
+template <int PREC>
+__device__ __forceinline__ void dma_issue_saddr(Ctx<PREC>& cx, int step) {
+    const int K = step_pieces<PREC>(step) / NW;
+    const char* sbase = cx.ws_base + (size_t)step_off_kib<PREC>(step) * 1024 + (size_t)(cx.wave * K) * 1024;
+    const uint32_t m = cx.lds_base + (step % NSLOT) * Ctx<PREC>::SLOT + (uint32_t)(cx.wave * K) * 1024;
+    glds_saddr(cx.lane * 16, sbase, m, K);
+}
 
 template <int PREC>
 __device__ __forceinline__ void dma_issue(Ctx<PREC>& cx, int step) {
     if (step >= N_STEPS || (SHERF_MLP_ABLATE & 32)) return;
-#if SHERF_MLP_DMA_SADDR
-    if constexpr (PREC != 1) { dma_issue_saddr(cx, step); return; }
-#endif
+    if (cx.saddr) { dma_issue_saddr(cx, step); return; }
     const char* src = cx.ws + (size_t)step_off_kib<PREC>(step) * 1024;          // (+ this lane's 16 bytes: folded into cx.ws)
     const uint32_t dst = cx.lds_addr + (step % NSLOT) * Ctx<PREC>::SLOT;
 #pragma unroll
@@ -938,7 +938,7 @@ __device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* w
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
     cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
-    cx.ws_base = ws; cx.lds_base = cx.lds_addr - cx.wave * 1024;
+    cx.ws_base = ws; cx.lds_base = cx.lds_addr - cx.wave * 1024; cx.saddr = false;
 #if SHERF_MLP_TRACE
     cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
     if (cx.lane == 0) {
@@ -998,6 +998,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 // step out as 8 x {1 MFMA, up to 8 VALU}.  Persistent workgroups (2 per CU, 256 registers per lane), the transformer's 24 KiB of
 // weights resident in LDS, the decoder's 41 steps + one empty step (42 = 0 mod 3: the ring's slots stay compile-time constants across
 // groups) streaming through the same 3-slot ring without a gap between groups.  Same arithmetic, same bits as nerf_mlp_kernel.
+template <int PREC> struct LnPart { float s, q, inv, off; f32x16 y; };     // a LayerNorm between its parts (layer_norm_part)
 template <int PREC> struct TState {
     f32x16 tok[3];
     BFrag<PREC> b5[1][2];                    // PE5(rgb) fragments
@@ -1010,8 +1011,37 @@ template <int PREC> struct TState {
     BFrag<PREC> l2[2][2], gb[2][2];
     BFrag<PREC> z0b[2], z1b[2];
     float rgb[3], xc[3], vc[3];
+    LnPart<PREC> lnp;
 };
 constexpr int N_TSLICES = 31;
+// The slices that are pure VALU (LayerNorm, softmax, GELU) in FOUR parts each: a decoder step places part p behind its p-th MFMA block
+// (between fences), so that the arithmetic sits in the MFMAs' shadow whatever the scheduler would have preferred.  Same operations in
+// the same order as the whole slice (layer_norm / the loops of tslice).
+__host__ __device__ constexpr bool slice_in_parts(int Q) { return (Q >= 3 && Q <= 5) || Q == 14 || Q == 15 || Q == 22 || Q == 23 || (Q >= 25 && Q <= 28); }
+template <int PREC>
+__device__ __forceinline__ void layer_norm_part(const Ctx<PREC>& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1, LnPart<PREC>& L, int part) {
+    static_assert(PREC != 1, "the one-pass form");
+    if (part == 0) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s += x[r]; q = __builtin_fmaf(x[r], x[r], q); }
+        L.s = s; L.q = q;
+    } else if (part == 1) {
+        const float s = xhalf_sum(L.s), q = xhalf_sum(L.q);
+        const float mean = s * (1.0f / 32.0f);
+        const float var = fmaxf(__builtin_fmaf(-mean, mean, q * (1.0f / 32.0f)), 0.0f);
+        L.inv = rsqrt_(var + 1e-5f); L.off = -mean * L.inv;
+        const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) L.y[r] = __builtin_fmaf(__builtin_fmaf(x[r], L.inv, L.off), g[r], bt[r]);
+    } else if (part == 2) {
+        const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
+#pragma unroll
+        for (int r = 8; r < 16; ++r) L.y[r] = __builtin_fmaf(__builtin_fmaf(x[r], L.inv, L.off), g[r], bt[r]);
+    } else if (part == 3) {
+        split_tile<PREC>(L.y, k0, k1);
+    }
+}
 // slice Q of the transformer of `tile` (weights resident at wl: steps 0-1 back to back, + this lane's 16 bytes)
 template <int PREC, int Q>
 __device__ __forceinline__ void tslice(const Ctx<PREC>& cx, TState<PREC>& T, const char* wl, const float4* __restrict__ tokens,
@@ -1038,6 +1068,8 @@ __device__ __forceinline__ void tslice(const Ctx<PREC>& cx, TState<PREC>& T, con
         mma_cols<PREC, 2, 1>(s0, 0, T.b5, acc);
         T.tok[2] += acc[0];
         load_tok(0, T.tok[0]);
+    } else if constexpr (Q == 103) {                                 // (the token fetch of slice 3 alone: the parts form does the LayerNorm)
+        load_tok(1, T.tok[1]);
     } else if constexpr (Q == 3) {
         layer_norm<PREC>(cx, T.tok[2], 0, T.ln[2][0], T.ln[2][1]);
         load_tok(1, T.tok[1]);
@@ -1162,6 +1194,32 @@ __device__ __forceinline__ void tslice(const Ctx<PREC>& cx, TState<PREC>& T, con
     }
 }
 
+template <int PREC, int Q>
+__device__ __forceinline__ void tslice_part(const Ctx<PREC>& cx, TState<PREC>& T, int part) {
+    if constexpr (Q == 3) layer_norm_part<PREC>(cx, T.tok[2], 0, T.ln[2][0], T.ln[2][1], T.lnp, part);
+    else if constexpr (Q == 4 || Q == 5) layer_norm_part<PREC>(cx, T.tok[Q - 4], 0, T.ln[Q - 4][0], T.ln[Q - 4][1], T.lnp, part);
+    else if constexpr (Q == 22 || Q == 23) layer_norm_part<PREC>(cx, T.y[Q - 22], 1, T.l2[Q - 22][0], T.l2[Q - 22][1], T.lnp, part);
+    else if constexpr (Q == 14 || Q == 15) {                         // one head per part
+        constexpr int i = Q - 14;
+#pragma unroll
+        for (int hd = 0; hd < 3; ++hd) {
+            if (hd != part) continue;
+            float d[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) d[t] = xhalf_sum(T.dot[i][hd][t]) * 0.25f;
+            float m = fmaxf(d[0], fmaxf(d[1], d[2]));
+            float e0 = exp_(d[0] - m), e1 = exp_(d[1] - m), e2 = exp_(d[2] - m);
+            float inv = rcp_(e0 + e1 + e2);
+            T.dot[i][hd][0] = e0 * inv; T.dot[i][hd][1] = e1 * inv; T.dot[i][hd][2] = e2 * inv;
+        }
+    } else if constexpr (Q >= 25 && Q <= 28) {                       // two of the slice's eight values per part
+        constexpr int i = (Q - 25) / 2, r0 = 8 * ((Q - 25) % 2);
+#pragma unroll
+        for (int r = r0; r < r0 + 8; ++r)
+            if ((r - r0) / 2 == part) T.acc[i][r] = gelu_<true>(T.acc[i][r]);
+    }
+}
+
 // decoder state of the group in flight
 template <int PREC> struct PWindow { AFrag<PREC> f[SHERF_MLP_PIPE_AWIN]; };
 template <int PREC>
@@ -1216,8 +1274,9 @@ __host__ __device__ constexpr StepDesc step_desc(int S) {
 }
 // blocks on the compiler-visible MFMA builtin off the fragment window (mma_chains' window path without the asm blocks: hipcc places the
 // hazard wait states itself and is free to put other work between the MFMAs)
-template <int PREC, int NB, bool PAIR>
-__device__ __forceinline__ void mma_win(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, PWindow<PREC>& w, int tot_pairs = -1) {
+// `between(p)` runs after block p (p = the pair's index in the step): where a step places the parts of the other group's transformer slice
+template <int PREC, int NB, bool PAIR, class F>
+__device__ __forceinline__ void mma_win(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, PWindow<PREC>& w, int tot_pairs, F&& between) {
     constexpr int UNIT = Ctx<PREC>::UNIT, W = SHERF_MLP_PIPE_AWIN;
     static_assert(PREC != 1, "single-product precisions");
     const int p0 = u0 / 2, tot = tot_pairs >= 0 ? tot_pairs : p0 + NB;
@@ -1230,6 +1289,7 @@ __device__ __forceinline__ void mma_win(const char* s, int u0, const BFrag<PREC>
         acc0 = mfma<PREC>(cur.h0, b0.hi, acc0);
         acc1 = mfma<PREC>(cur.h1, b1.hi, acc1);
         if (p + W < tot) cur = load_units<PREC>(s + 2 * (p + W) * UNIT);
+        between(p);
     }
 }
 template <int PREC, bool RELU>
@@ -1247,9 +1307,9 @@ __device__ __forceinline__ void finish_free(const f32x16& acc0, const f32x16& ac
 template <int PREC>
 __device__ __forceinline__ BFrag<PREC>* dbuf(DState<PREC>& D, int which) { return which == B_HA ? D.ha : which == B_HB ? D.hb : D.gb; }
 
-template <int PREC, int S>
+template <int PREC, int S, class F>
 __device__ __forceinline__ void dstep(Ctx<PREC>& cx, DState<PREC>& D, const int32_t* __restrict__ counters, int64_t tile, bool live, int64_t nv,
-                                      float4* __restrict__ out) {
+                                      float4* __restrict__ out, F&& between) {
     constexpr StepDesc d = step_desc(S);
     const int j = cx.lane & 31, h = cx.h;
     if constexpr (d.fin >= 0) {
@@ -1272,12 +1332,12 @@ __device__ __forceinline__ void dstep(Ctx<PREC>& cx, DState<PREC>& D, const int3
         else D.acc1 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     }
     const char* sl = cx.slot(S);
-    if constexpr (d.kind == K_PAIR) mma_win<PREC, 4, true>(sl, 0, dbuf(D, d.in) + d.in_off, D.acc0, D.acc1, D.win);
-    else if constexpr (d.kind == K_PEZ0) { mma_win<PREC, 3, true>(sl, 0, D.pe, D.acc0, D.acc1, D.win, 5); mma_win<PREC, 2, true>(sl, 6, D.z0b, D.acc0, D.acc1, D.win); }
-    else if constexpr (d.kind == K_ALPHA) mma_win<PREC, 4, false>(sl, 0, D.hb, D.acc0, D.acc1, D.win);
-    else if constexpr (d.kind == K_PVZ1) { mma_win<PREC, 2, true>(sl, 0, D.pv, D.acc0, D.acc1, D.win, 4); mma_win<PREC, 2, true>(sl, 4, D.z1b, D.acc0, D.acc1, D.win); }
+    if constexpr (d.kind == K_PAIR) mma_win<PREC, 4, true>(sl, 0, dbuf(D, d.in) + d.in_off, D.acc0, D.acc1, D.win, -1, between);
+    else if constexpr (d.kind == K_PEZ0) { mma_win<PREC, 3, true>(sl, 0, D.pe, D.acc0, D.acc1, D.win, 5, between); mma_win<PREC, 2, true>(sl, 6, D.z0b, D.acc0, D.acc1, D.win, -1, between); }
+    else if constexpr (d.kind == K_ALPHA) mma_win<PREC, 4, false>(sl, 0, D.hb, D.acc0, D.acc1, D.win, -1, between);
+    else if constexpr (d.kind == K_PVZ1) { mma_win<PREC, 2, true>(sl, 0, D.pv, D.acc0, D.acc1, D.win, 4, between); mma_win<PREC, 2, true>(sl, 4, D.z1b, D.acc0, D.acc1, D.win, -1, between); }
     else {
-        mma_win<PREC, 2, false>(sl, 0, D.gb, D.acc0, D.acc1, D.win);
+        mma_win<PREC, 2, false>(sl, 0, D.gb, D.acc0, D.acc1, D.win, -1, between);
         if (live && h == 0) {
             const int64_t c = tile * 32 + j;
             if (c < nv) {
@@ -1308,6 +1368,9 @@ __device__ __forceinline__ void pipe_step_end(Ctx<PREC>& cx, DState<PREC>& D, bo
 #ifndef SHERF_MLP_PIPE_ORDER
 #define SHERF_MLP_PIPE_ORDER 1     // 1: a slice of pure VALU follows the decoder step in program order, a slice that opens with MFMAs leads it
 #endif
+#ifndef SHERF_MLP_PIPE_PARTS
+#define SHERF_MLP_PIPE_PARTS 1     // the pure-VALU slices in four fenced parts between the step's MFMA blocks (0: left to the scheduler)
+#endif
 #ifndef SHERF_MLP_PIPE_GROUPS
 #define SHERF_MLP_PIPE_GROUPS 12
 #endif
@@ -1324,13 +1387,24 @@ __device__ __forceinline__ void pipe_steps(Ctx<PREC>& cx, DState<PREC>& D, TStat
         //  that the VALU depending on them can sit between the decoder's)
         constexpr int Q = S - 2;
         constexpr bool lead = (Q >= 6 && Q <= 13) || (Q >= 17 && Q <= 20) || Q == 24 || Q == 29 || Q == 2;      // slices that open with MFMAs
-        if constexpr (Q < N_TSLICES && (lead || SHERF_MLP_PIPE_ORDER == 0)) tslice<PREC, Q>(cx, T, wl, tokens, extras, next_tile);
-        if constexpr (Q == N_TSLICES) {                                      // the next group's sample position / view direction
-            const float* ex = extras + next_tile * 12 * 32 + (cx.lane & 31);
-            T.xc[0] = ex[0]; T.xc[1] = ex[32]; T.xc[2] = ex[64]; T.vc[0] = ex[96]; T.vc[1] = ex[128]; T.vc[2] = ex[160];
+        constexpr bool parts = SHERF_MLP_PIPE_PARTS && Q < N_TSLICES && slice_in_parts(Q);
+        if constexpr (parts) {
+            // pure VALU (LayerNorm, softmax, GELU): part p right behind the step's p-th MFMA block, fenced in place (a Q == 3 slice also
+            // fetches the next token: with part 0)
+            if constexpr (Q == 3) tslice<PREC, 103>(cx, T, wl, tokens, extras, next_tile);
+            dstep<PREC, S>(cx, D, counters, tile, live, nv, out, [&](int p) {
+                if (p < 4) tslice_part<PREC, Q>(cx, T, p);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            if constexpr (Q < N_TSLICES && (lead || SHERF_MLP_PIPE_ORDER == 0)) tslice<PREC, Q>(cx, T, wl, tokens, extras, next_tile);
+            if constexpr (Q == N_TSLICES) {                                  // the next group's sample position / view direction
+                const float* ex = extras + next_tile * 12 * 32 + (cx.lane & 31);
+                T.xc[0] = ex[0]; T.xc[1] = ex[32]; T.xc[2] = ex[64]; T.vc[0] = ex[96]; T.vc[1] = ex[128]; T.vc[2] = ex[160];
+            }
+            dstep<PREC, S>(cx, D, counters, tile, live, nv, out, [](int) {});
+            if constexpr (Q < N_TSLICES && !(lead || SHERF_MLP_PIPE_ORDER == 0)) tslice<PREC, Q>(cx, T, wl, tokens, extras, next_tile);
         }
-        dstep<PREC, S>(cx, D, counters, tile, live, nv, out);
-        if constexpr (Q < N_TSLICES && !(lead || SHERF_MLP_PIPE_ORDER == 0)) tslice<PREC, Q>(cx, T, wl, tokens, extras, next_tile);
         // the step as hipcc should lay it out: an MFMA, then up to eight VALU of whatever is ready (the other group's transformer slice, this
         // group's epilogue / encodings), twelve times over (8-10 decoder MFMAs + the slice's own)
 #pragma unroll
@@ -1364,6 +1438,7 @@ nerf_mlp_pipe_kernel(const int32_t* __restrict__ counters, const float4* __restr
     if ((int64_t)blockIdx.x >= n_groups) return;
     CX cx;
     ring_ctx<PREC>(cx, lds, ws, wbias);
+    cx.saddr = true;
     char* wt = lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4;
     for (int i = threadIdx.x; i < WT / 16; i += NT) reinterpret_cast<u32x4*>(wt)[i] = reinterpret_cast<const u32x4*>(ws)[i];
     const char* wl = wt + cx.lane * 16;
@@ -1437,7 +1512,7 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
     for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
     __syncthreads();
     CX cx;
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0; cx.ws_base = ws; cx.lds_base = 0;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0; cx.ws_base = ws; cx.lds_base = 0; cx.saddr = false;
     for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
         // loop (hundreds of live registers).  The OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and
