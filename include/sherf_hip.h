@@ -186,11 +186,6 @@ int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* ex
  * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS;
  * launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  zfrag: scratch for the fused tokens,
  * ((capacity + 31) / 32) tiles x 4 KiB (prec 0, 2) or 8 KiB (prec 1). */
-/* The same network as ONE persistent, software-pipelined launch (csrc/mlp.hip: nerf_mlp_pipe_kernel; prec 0, 2 only): a wave runs tile-group
- * g's decoder and tile-group g+1's transformer in the same instruction stream (the transformer's VALU sits in the shadow of the decoder's
- * MFMAs), the weight ring streams across groups without a gap.  Results bit-identical to sherf_nerf_mlp. */
-int sherf_nerf_mlp_pipe(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                        const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
 int sherf_nerf_mlp_split(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                          const float* wbias, int prec, int64_t capacity, void* zfrag, float* out, sherf_stream_t stream);
 /* The weight stream for `prec` built on the device (what sherf_amd/mlp_pack.py: pack() builds on the host, bit for bit): slot i (2 bytes) of

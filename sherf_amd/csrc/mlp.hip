@@ -173,8 +173,7 @@ __device__ int g_mlp_trace_every = 0;
 #define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
 #endif
 
-// SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers, 128 = the decoder's A fragments
-// are read from LDS once (window builds) instead of every step, 256 = no transformer arithmetic (z = the raw tokens), 512 = no positional
+// SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers, 256 = no transformer arithmetic (z = the raw tokens), 512 = no positional
 // encodings (zero fragments), 1024 = layer epilogues without conversion / ReLU (16 moves instead of 32 VALU)
 #ifndef SHERF_MLP_ABLATE
 #define SHERF_MLP_ABLATE 0
@@ -185,9 +184,6 @@ template <int PREC> struct Ctx {
     const float* wbias;      // [N_CHUNKS + 4][2][16] D-layout bias / LayerNorm tables (LDS copy)
     const char* lds;         // NSLOT ring slots (generic pointer, + this lane's 16 bytes: what the ds_reads use)
     uint32_t lds_addr;       // LDS byte address of the ring (what the DMA's M0 takes), wave-uniform
-    const char* ws_base;     // the stream without the wave / lane offsets, and the ring's LDS byte address: the SADDR issue (saddr = true)
-    uint32_t lds_base;
-    bool saddr;
     int lane, h, wave;
 #if SHERF_MLP_TRACE
     uint32_t* trace;         // this wave's [64][4] stamps in LDS
@@ -203,39 +199,9 @@ template <int PREC> struct Ctx {
 // wave's pieces visible.
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// The SADDR form of the issue (round 4; cx.saddr): a wave owns the K CONSECUTIVE pieces w K .. w K + K - 1 of a step and issues them from
-// one statement -- M0 written once, the source as an SGPR base + this lane's 16 bytes, the piece index in the instruction's immediate
-// offset (which moves the LDS destination along with the source) -- instead of a 64-bit VGPR address add and an M0 save / set /
-// restore per piece.  Same LDS image (the pieces only change owners).  Measured on the MI355X (profiles/r04_call_e_pipelined_mlp.txt):
-// in nerf_mlp_kernel it is SLOWER (0.545 vs 0.507 ms: the pieces leave back to back), so that kernel keeps the per-piece form; in the
-// pipelined kernel it is what makes the register budget work (the VGPR address pairs were what spilled, and a spill reload's
-// s_waitcnt vmcnt(0) drains the weight DMA in flight: 0.91 -> 0.55 ms).
-// glds_saddr: K (1..3) LDS-DMA loads of 1 KiB each from sbase + voff + 1024 i to LDS byte address m + 1024 i (+ lane * 16)
-__device__ __forceinline__ void glds_saddr(uint32_t voff, const char* sbase, uint32_t m, int K) {
-    uint32_t keep;
-    if (K == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
-    else if (K == 3)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m) : "memory");
-}
-template <int PREC>
-__device__ __forceinline__ void dma_issue_saddr(Ctx<PREC>& cx, int step) {
-    const int K = step_pieces<PREC>(step) / NW;
-    const char* sbase = cx.ws_base + (size_t)step_off_kib<PREC>(step) * 1024 + (size_t)(cx.wave * K) * 1024;
-    const uint32_t m = cx.lds_base + (step % NSLOT) * Ctx<PREC>::SLOT + (uint32_t)(cx.wave * K) * 1024;
-    glds_saddr(cx.lane * 16, sbase, m, K);
-}
-
 template <int PREC>
 __device__ __forceinline__ void dma_issue(Ctx<PREC>& cx, int step) {
     if (step >= N_STEPS || (SHERF_MLP_ABLATE & 32)) return;
-    if (cx.saddr) { dma_issue_saddr(cx, step); return; }
     const char* src = cx.ws + (size_t)step_off_kib<PREC>(step) * 1024;          // (+ this lane's 16 bytes: folded into cx.ws)
     const uint32_t dst = cx.lds_addr + (step % NSLOT) * Ctx<PREC>::SLOT;
 #pragma unroll
@@ -407,74 +373,41 @@ __device__ __forceinline__ AFrag<PREC> load_units(const char* p) {
     else { f.l0 = f.h0; f.l1 = f.h1; }
     return f;
 }
-// SHERF_MLP_AWIN (round 4): how many unit PAIRS of A fragments a wave fetches ahead inside a step.
-//   0 (rounds 2-3): one -- every block's successor is fetched right before the block is issued, i.e. one block (two MFMAs = 64 cycles of
-//     matrix pipe) ahead of its use.  The LDS answers a ds_read_b128 in >= 64 cycles when idle and in a multiple of that with twelve waves
-//     reading fragments and three workgroups' weight DMA landing, so EVERY block of a step began with an exposed s_waitcnt lgkmcnt:
-//     four dependent LDS round trips per step and wave (ISA: ds_read x2, s_waitcnt lgkmcnt(2), s_nop 1, v_mfma x2, repeated).
-//   W > 0: a window of W pairs.  Right behind the step's barrier the wave fetches the first W pairs of the step at once (they overlap
-//     the weight-DMA issue and the previous layer's epilogue), the blocks then run off the window and a pair beyond it (the five-pair
-//     steps of pts_linears.0 / .5) is fetched into the slot its block has just freed.  4 pairs = 32 registers for the single-product
-//     precisions (16 more than before); prec 1 keeps W = 0 (its fragments are twice the size and its blocks three times as long).
-#ifndef SHERF_MLP_AWIN
-#define SHERF_MLP_AWIN 4
-#endif
-template <int PREC> constexpr int AWIN = PREC == 1 ? 0 : SHERF_MLP_AWIN;
-#ifndef SHERF_MLP_PIPE_AWIN
-#define SHERF_MLP_PIPE_AWIN 2          // (the pipelined kernel: registers are what it is short of)
-#endif
-template <int PREC> struct AWindow { AFrag<PREC> f[AWIN<PREC> > 0 ? AWIN<PREC> : 1]; };
-// (re)fill behind a barrier: the first min(n_pairs, W) pairs of the step whose slot is `s`
-template <int PREC>
-__device__ __forceinline__ void win_fill(AWindow<PREC>& w, const char* s, int n_pairs) {
-    constexpr int UNIT = Ctx<PREC>::UNIT, W = AWIN<PREC> > 0 ? AWIN<PREC> : 1;
-#pragma unroll
-    for (int i = 0; i < W; ++i)
-        if (i < n_pairs) w.f[i] = load_units<PREC>(s + 2 * i * UNIT);
-}
-// NB blocks over consecutive unit pairs (u0 + 2 i, u0 + 2 i + 1) of the step's slot `s`; the window holds the step's pairs as described
-// above (W = 0: w.f[0] = the pair of the next block).  Every fetch sits in front of an asm block whose "memory" clobber pins it there.
+// NB blocks over consecutive unit pairs (u0 + 2 i, u0 + 2 i + 1) of the step's slot.  `cur` holds the fragments of the first pair
+// (loaded by the caller: right after the step's barrier, so that their LDS latency hides under the DMA issue / the previous
+// pair's epilogue); every block's successor is fetched BEFORE the block is issued -- the asm's "memory" clobber pins that order
+// -- and MORE says that another segment of the same step follows at u0 + 2 NB (its first pair is then left in `cur`).
 //   PAIR = true : units = (chunk 0, chunk 1) at K-block i, both chains take b[i]             (a pair of output chunks)
 //   PAIR = false: units = (kb 2i, kb 2i+1) of ONE chunk, chain 0 takes b[2i], chain 1 b[2i+1] (split-K: the caller adds the chains)
-//   MORE: another segment of the same step follows at u0 + 2 NB;  tot_pairs: pairs of the whole step (default: this segment ends it)
 template <int PREC, int NB, bool PAIR, bool MORE>
-__device__ __forceinline__ void mma_chains(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AWindow<PREC>& w, int tot_pairs = -1) {
-    constexpr int UNIT = Ctx<PREC>::UNIT, W = AWIN<PREC>;
-    const int p0 = u0 / 2, tot = tot_pairs >= 0 ? tot_pairs : p0 + NB;
+__device__ __forceinline__ void mma_chains(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
+    constexpr int UNIT = Ctx<PREC>::UNIT;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
+        AFrag<PREC> nxt;
+        const bool pre = i + 1 < NB || MORE;
+        if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
         const BFrag<PREC>& b0 = b[PAIR ? i : 2 * i];
         const BFrag<PREC>& b1 = b[PAIR ? i : 2 * i + 1];
-        if constexpr (W == 0) {
-            AFrag<PREC> nxt;
-            const bool pre = i + 1 < NB || MORE;
-            if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
-            AFrag<PREC>& cur = w.f[0];
-            if constexpr (PREC == 1) mfma_block<PREC>(acc0, acc1, cur.h0, cur.l0, cur.h1, cur.l1, b0.hi, b0.lo, b1.hi, b1.lo);
-            else mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
-            if (pre) cur = nxt;
-        } else {
-            const int p = p0 + i;
-            AFrag<PREC>& cur = w.f[p % (W > 0 ? W : 1)];
-            mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
-            if (p + W < tot && !(SHERF_MLP_ABLATE & 128)) cur = load_units<PREC>(s + 2 * (p + W) * UNIT);       // the slot this block has just freed
-        }
+        if constexpr (PREC == 1) mfma_block<PREC>(acc0, acc1, cur.h0, cur.l0, cur.h1, cur.l1, b0.hi, b0.lo, b1.hi, b1.lo);
+        else mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
+        if (pre) cur = nxt;
     }
 }
 template <int PREC, int NK, bool MORE = false>
-__device__ __forceinline__ void mma_pair(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AWindow<PREC>& w, int tot_pairs = -1) {
-    mma_chains<PREC, NK, true, MORE>(s, u0, b, acc0, acc1, w, tot_pairs);
+__device__ __forceinline__ void mma_pair(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
+    mma_chains<PREC, NK, true, MORE>(s, u0, b, acc0, acc1, cur);
 }
 template <int PREC, int NK>
-__device__ __forceinline__ void mma_splitk(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AWindow<PREC>& w) {
+__device__ __forceinline__ void mma_splitk(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur) {
     static_assert(NK % 2 == 0, "even / odd K-block chains");
-    mma_chains<PREC, NK / 2, false, false>(s, u0, b, acc0, acc1, w);
+    mma_chains<PREC, NK / 2, false, false>(s, u0, b, acc0, acc1, cur);
 }
 
 // v + (the partner lane's v): the partner lane (lane ^ 32) holds the other 16 features of the sample.  SHERF_MLP_PERMLANE (round 4):
-// one v_permlane32_swap_b32 (VALU, no LDS round trip) instead of ds_bpermute_b32 + s_waitcnt lgkmcnt(0) -- the transformer did 36 of
-// those exchanges per tile, each a ~100-cycle stall of a wave that has nothing else to issue (tools/mlp_isa_segments.py).  The swap
+// one v_permlane32_swap_b32 (VALU, no LDS round trip) instead of ds_bpermute_b32 + s_waitcnt lgkmcnt(0) (36 exchanges per tile).  The swap
 // leaves (lo, lo) in one register and (hi, hi) in the other; their sum is lo + hi in every lane: the same two addends as before.
+// Measured: no difference in kernel time (profiles/r04_call_a_*.txt, build variant `noperm`); kept for the 36 LDS operations it removes.
 #ifndef SHERF_MLP_PERMLANE
 #define SHERF_MLP_PERMLANE 1
 #endif
@@ -624,13 +557,18 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
 // counted wait replaced by vmcnt(0), even with the taps replaced by plain loads of the stored tokens (profiles/
 // r02_fused_gather_mlp_experiment_*.txt).  Unexplained, so not shipped; sherf_gather_tokens stays its own launch.
 // One launch (nerf_mlp_kernel): transformer (steps 0-1) + decoder (steps 2-42).  Round 2 measured the two as SEPARATE launches on the
-// three-product precision (the transformer at 3 waves / SIMD with its weights resident in LDS, the decoder alone at two workgroups per
-// CU): 0.23 + 0.62 ms against 0.69 ms fused (profiles/r02_kernel_trace_v2_split.txt), so the fused form stayed.  Round 4: on the
-// SINGLE-product precisions the balance is different -- the decoder's MFMA work is a third, so the transformer (1 600 VALU, 39 MFMAs,
-// a chain of dependent waits: 17.7 K of a tile's 62 K cycles, profiles/r03_mlp_trace_f16_v1.txt) holds a wave slot for 28 % of the
-// time while using 3 % of the matrix pipe, and with three waves per SIMD the pipe idles whenever fewer than three are in the decoder.
-// The two-launch form (sherf_nerf_mlp_split) gives each half the occupancy it wants: nerf_tokens_kernel is barrier-free with resident
-// weights and pulls tiles from a ticket counter; nerf_decoder_kernel has every wave in the MFMA-bound phase all the time.
+// three-product precision: 0.23 + 0.62 ms against 0.69 ms fused (profiles/r02_kernel_trace_v2_split.txt).  Round 4 measured the
+// single-product precision every way round (profiles/r04_call_[a-e]_*.txt, cfg2_dense_ri, 1.27 M samples):
+//   one launch 0.51 ms; two launches (sherf_nerf_mlp_split below) 0.62 ms = transformer 0.20 + decoder 0.40 (the decoder ALONE keeps the
+//   matrix pipe 51 % busy: it is not the transformer that holds it back); with the weight DMA, the barriers and the per-step fragment
+//   reads all ablated 0.46 ms; without the transformer's arithmetic 0.42 ms; SQ counters: MFMA busy 46 % + VALU issue 57 % of the
+//   cycles -- the two add up, a tile's 2 900 VALU and 374 MFMAs barely overlap.  A microbenchmark (tools/ubench) shows they overlap
+//   perfectly inside ONE wave's stream (8 MFMAs + 64 VALU per iteration run at the 8 MFMAs' speed), so a persistent kernel that runs
+//   tile-group g's decoder and group g+1's transformer in the same stream was built (commits 0b79420..23ea087: builtin MFMAs,
+//   sched_group_barrier pipelines, fenced parts; two waves per SIMD at 255 registers without a spill once the weight DMA took its
+//   address from SGPRs): 0.55-0.56 ms in every variant -- no gain, and not bit-identical on the hardware (fma contraction order), so
+//   it is not in the tree.  What stays from round 4: the cheaper single-product LayerNorm / GELU (-250 VALU per tile), the lane^32
+//   exchange as v_permlane32_swap, the static hazard audit (tools/mfma_hazard_check.py), the two-launch form as a tested option.
 // ---- the two halves of the network as device functions: one launch runs both (nerf_mlp_kernel), the two-launch form runs them as
 //      nerf_tokens_kernel + nerf_decoder_kernel (below) ----
 // Transformer (chunks 0..8 = steps 0-1 of the weight stream) of one 32-sample tile -> the fused tokens z_0, z_1 as K-blocks.
@@ -816,11 +754,9 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
     int step = 2;
     BFrag<PREC> ha[8], hb[8];
-    AWindow<PREC> cur;                                               // A fragments of the coming step: fetched right behind its barrier
-    win_fill<PREC>(cur, cx.slot(step), step_units(step) / 2);
+    AFrag<PREC> cur = load_units<PREC>(cx.slot(step));               // first fragments of the next step: fetched right behind its barrier
     // (the fetch goes out BEFORE the DMA issue of the slot just freed: its LDS latency hides under those ~30 instructions)
-#define SHERF_NEXT_STEP() do { step_wait(cx, step); if (step + 1 < N_STEPS && !(SHERF_MLP_ABLATE & 128)) win_fill<PREC>(cur, cx.slot(step + 1), step_units(step + 1) / 2); \
-                               dma_issue(cx, step + NSLOT); ++step; } while (0)
+#define SHERF_NEXT_STEP() do { step_wait(cx, step); cur = load_units<PREC>(cx.slot(step + 1)); dma_issue(cx, step + NSLOT); ++step; } while (0)
     // a 128 -> 128 layer: two pairs of output chunks x two K-halves = four steps; chunk C0 + T -> OUT[2T], OUT[2T+1]
 #define SHERF_LAYER128(C0, IN, OUT, RELU)                                                             \
     _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                   \
@@ -838,7 +774,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
         for (int P = 0; P < 2; ++P) {
             f32x16 acc0 = bias_tile(cx, 9 + 2 * P), acc1 = bias_tile(cx, 10 + 2 * P);
             const char* s = cx.slot(step);
-            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur, 5);
+            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur);
             mma_pair<PREC, 2>(s, 6, z0b, acc0, acc1, cur);
             SHERF_NEXT_STEP();
             finish_pair<PREC, true>(acc0, acc1, ha + 4 * P);
@@ -857,7 +793,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
         for (int P = 0; P < 2; ++P) {
             f32x16 acc0 = bias_tile(cx, 29 + 2 * P), acc1 = bias_tile(cx, 30 + 2 * P);
             const char* s = cx.slot(step);
-            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur, 5);
+            mma_pair<PREC, 3, true>(s, 0, pe, acc0, acc1, cur);
             mma_pair<PREC, 2>(s, 6, z0b, acc0, acc1, cur);
             SHERF_NEXT_STEP();
             mma_pair<PREC, 4>(cx.slot(step), 0, ha, acc0, acc1, cur);
@@ -891,7 +827,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
         mma_pair<PREC, 4>(cx.slot(step), 0, ha + 4, acc0, acc1, cur);
         SHERF_NEXT_STEP();
         const char* s = cx.slot(step);
-        mma_pair<PREC, 2, true>(s, 0, pv, acc0, acc1, cur, 4);
+        mma_pair<PREC, 2, true>(s, 0, pv, acc0, acc1, cur);
         mma_pair<PREC, 2>(s, 4, z1b, acc0, acc1, cur);
         SHERF_NEXT_STEP();
         finish_pair<PREC, true>(acc0, acc1, gb);
@@ -938,7 +874,6 @@ __device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* w
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
     cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
-    cx.ws_base = ws; cx.lds_base = cx.lds_addr - cx.wave * 1024; cx.saddr = false;
 #if SHERF_MLP_TRACE
     cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
     if (cx.lane == 0) {
@@ -985,506 +920,6 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     SHERF_TRACE_FLUSH(cx);
 }
 
-// ---- the software-pipelined form (round 4; single-product precisions) ------------------------------------------------------------
-// What the measurements of round 4 say about nerf_mlp_kernel at one fp16 product per term (profiles/r04_call_b_*, r04_call_c_*,
-// r04_ubench_*): with the weight DMA, the barriers and the per-step fragment reads all ablated it still takes 0.46 of its 0.51 ms;
-// SQ counters: the SIMDs spend 46 % of their cycles in MFMAs and 57 % issuing VALU (4.5 cycles per instruction), and the two ADD UP:
-// the 2 900 VALU of a tile (1 600 of them the transformer, a phase with 39 MFMAs) and its 374 MFMAs are issued by DIFFERENT phases of a
-// wave's life, so they only overlap across waves -- and a wave in the VALU phase is a chain of dependent waits, not a smooth stream.
-// A microbenchmark shows what the hardware does when the two are in the SAME wave's stream: 8 MFMAs + 64 independent VALU per
-// iteration run at the speed of the 8 MFMAs alone.  So here a wave processes tile-group g's DECODER and tile-group g+1's TRANSFORMER
-// at the same time: the transformer is cut into 31 slices of 30-110 VALU (tslice<Q>), one per decoder step, its state carried in
-// registers; the decoder's MFMAs are builtins (not asm blocks), and a sched_group_barrier pipeline per step tells hipcc to lay the
-// step out as 8 x {1 MFMA, up to 8 VALU}.  Persistent workgroups (2 per CU, 256 registers per lane), the transformer's 24 KiB of
-// weights resident in LDS, the decoder's 41 steps + one empty step (42 = 0 mod 3: the ring's slots stay compile-time constants across
-// groups) streaming through the same 3-slot ring without a gap between groups.  Same arithmetic, same bits as nerf_mlp_kernel.
-template <int PREC> struct LnPart { float s, q, inv, off; f32x16 y; };     // a LayerNorm between its parts (layer_norm_part)
-template <int PREC> struct TState {
-    f32x16 tok[3];
-    BFrag<PREC> b5[1][2];                    // PE5(rgb) fragments
-    BFrag<PREC> ln[3][2];
-    float qa[2][16], qb[2][8];
-    float dot[2][3][3];
-    float o[2][3][8];
-    f32x16 acc[2];                           // to_out / FF accumulators between slices
-    f32x16 y[2];
-    BFrag<PREC> l2[2][2], gb[2][2];
-    BFrag<PREC> z0b[2], z1b[2];
-    float rgb[3], xc[3], vc[3];
-    LnPart<PREC> lnp;
-};
-constexpr int N_TSLICES = 31;
-// The slices that are pure VALU (LayerNorm, softmax, GELU) in FOUR parts each: a decoder step places part p behind its p-th MFMA block
-// (between fences), so that the arithmetic sits in the MFMAs' shadow whatever the scheduler would have preferred.  Same operations in
-// the same order as the whole slice (layer_norm / the loops of tslice).
-__host__ __device__ constexpr bool slice_in_parts(int Q) { return (Q >= 3 && Q <= 5) || Q == 14 || Q == 15 || Q == 22 || Q == 23 || (Q >= 25 && Q <= 28); }
-template <int PREC>
-__device__ __forceinline__ void layer_norm_part(const Ctx<PREC>& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1, LnPart<PREC>& L, int part) {
-    static_assert(PREC != 1, "the one-pass form");
-    if (part == 0) {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s += x[r]; q = __builtin_fmaf(x[r], x[r], q); }
-        L.s = s; L.q = q;
-    } else if (part == 1) {
-        const float s = xhalf_sum(L.s), q = xhalf_sum(L.q);
-        const float mean = s * (1.0f / 32.0f);
-        const float var = fmaxf(__builtin_fmaf(-mean, mean, q * (1.0f / 32.0f)), 0.0f);
-        L.inv = rsqrt_(var + 1e-5f); L.off = -mean * L.inv;
-        const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) L.y[r] = __builtin_fmaf(__builtin_fmaf(x[r], L.inv, L.off), g[r], bt[r]);
-    } else if (part == 2) {
-        const f32x16 g = bias_tile(cx, BIAS_LN + 2 * ln_idx), bt = bias_tile(cx, BIAS_LN + 2 * ln_idx + 1);
-#pragma unroll
-        for (int r = 8; r < 16; ++r) L.y[r] = __builtin_fmaf(__builtin_fmaf(x[r], L.inv, L.off), g[r], bt[r]);
-    } else if (part == 3) {
-        split_tile<PREC>(L.y, k0, k1);
-    }
-}
-// slice Q of the transformer of `tile` (weights resident at wl: steps 0-1 back to back, + this lane's 16 bytes)
-template <int PREC, int Q>
-__device__ __forceinline__ void tslice(const Ctx<PREC>& cx, TState<PREC>& T, const char* wl, const float4* __restrict__ tokens,
-                                       const float* __restrict__ extras, int64_t tile) {
-    const int j = cx.lane & 31, h = cx.h;
-    const char* s0 = wl;
-    const char* s1 = wl + step_pieces<PREC>(0) * 1024;
-    auto load_tok = [&](int t, f32x16& dst) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
-        }
-    };
-    // (a token is fetched one slice ahead of its LayerNorm and dropped right after it: 16-32 live registers instead of 48)
-    if constexpr (Q == 0) {
-        const float* ex = extras + tile * 12 * 32 + j;
-        T.rgb[0] = ex[192]; T.rgb[1] = ex[224]; T.rgb[2] = ex[256];
-        load_tok(2, T.tok[2]);
-    } else if constexpr (Q == 1) {
-        pe_frags<PREC, 5, 2>(h, T.rgb[0], T.rgb[1], T.rgb[2], T.b5[0]);
-    } else if constexpr (Q == 2) {
-        f32x16 acc[1] = {bias_tile(cx, 0)};
-        mma_cols<PREC, 2, 1>(s0, 0, T.b5, acc);
-        T.tok[2] += acc[0];
-        load_tok(0, T.tok[0]);
-    } else if constexpr (Q == 103) {                                 // (the token fetch of slice 3 alone: the parts form does the LayerNorm)
-        load_tok(1, T.tok[1]);
-    } else if constexpr (Q == 3) {
-        layer_norm<PREC>(cx, T.tok[2], 0, T.ln[2][0], T.ln[2][1]);
-        load_tok(1, T.tok[1]);
-    } else if constexpr (Q == 4 || Q == 5) {
-        layer_norm<PREC>(cx, T.tok[Q - 4], 0, T.ln[Q - 4][0], T.ln[Q - 4][1]);
-    } else if constexpr (Q == 6) {
-        BFrag<PREC> b2[2][2] = {{T.ln[0][0], T.ln[0][1]}, {T.ln[1][0], T.ln[1][1]}};
-        f32x16 acc[2] = {bias_tile(cx, 1), bias_tile(cx, 1)};
-        mma_cols<PREC, 2, 2>(s0, 2, b2, acc);                        // [q head0 | q head1]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T.qa[i][r] = acc[i][r];
-    } else if constexpr (Q == 7) {
-        BFrag<PREC> b2[2][2] = {{T.ln[0][0], T.ln[0][1]}, {T.ln[1][0], T.ln[1][1]}};
-        f32x16 acc2[2] = {bias_tile(cx, 2), bias_tile(cx, 2)};
-        mma_cols<PREC, 2, 2>(s0, 4, b2, acc2);                       // [q head2 | pad]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) T.qb[i][r] = acc2[i][r];
-    } else if constexpr (Q >= 8 && Q <= 10) {
-        constexpr int t = Q - 8;
-        const BFrag<PREC> (&lt)[1][2] = reinterpret_cast<const BFrag<PREC> (&)[1][2]>(T.ln[t]);
-        f32x16 acc[1] = {bias_tile(cx, 3)};
-        mma_cols<PREC, 2, 1>(s0, 6, lt, acc);                        // [k head0 | k head1]
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { d0 += T.qa[i][r] * acc[0][r]; d1 += T.qa[i][8 + r] * acc[0][8 + r]; }
-            T.dot[i][0][t] = d0; T.dot[i][1][t] = d1;
-        }
-    } else if constexpr (Q >= 11 && Q <= 13) {
-        constexpr int t = Q - 11;
-        const BFrag<PREC> (&lt)[1][2] = reinterpret_cast<const BFrag<PREC> (&)[1][2]>(T.ln[t]);
-        f32x16 acc[1] = {bias_tile(cx, 4)};
-        mma_cols<PREC, 2, 1>(s0, 8, lt, acc);                        // [k head2 | v head0]  (v head0: taken when this chunk is redone below)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float d2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) d2 += T.qb[i][r] * acc[0][r];
-            T.dot[i][2][t] = d2;
-        }
-    } else if constexpr (Q == 14 || Q == 15) {                       // softmax over the 3 keys, scale 16^-0.5 (renderer.py:956,971-973)
-        constexpr int i = Q - 14;
-#pragma unroll
-        for (int hd = 0; hd < 3; ++hd) {
-            float d[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) d[t] = xhalf_sum(T.dot[i][hd][t]) * 0.25f;
-            float m = fmaxf(d[0], fmaxf(d[1], d[2]));
-            float e0 = exp_(d[0] - m), e1 = exp_(d[1] - m), e2 = exp_(d[2] - m);
-            float inv = rcp_(e0 + e1 + e2);
-            T.dot[i][hd][0] = e0 * inv; T.dot[i][hd][1] = e1 * inv; T.dot[i][hd][2] = e2 * inv;
-        }
-    } else if constexpr (Q == 16) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int hd = 0; hd < 3; ++hd)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) T.o[i][hd][r] = 0.f;
-    } else if constexpr (Q >= 17 && Q <= 19) {
-        // the value heads, token by token.  v head 0 shares its chunk with k head 2: that chunk is multiplied AGAIN here (two MFMAs per
-        // token) instead of carrying 24 registers of v across the softmax; o[.][0] accumulates in the order t = 0, 1, 2 -- the same
-        // products and the same fma chain as the one-expression form of nerf_mlp_kernel
-        constexpr int t = Q - 17;
-        const BFrag<PREC> (&lt)[1][2] = reinterpret_cast<const BFrag<PREC> (&)[1][2]>(T.ln[t]);
-        f32x16 accv[1] = {bias_tile(cx, 4)};
-        mma_cols<PREC, 2, 1>(s0, 8, lt, accv);                       // [k head2 | v head0]
-        f32x16 acc[1] = {bias_tile(cx, 5)};
-        mma_cols<PREC, 2, 1>(s1, 0, lt, acc);                        // [v head1 | v head2]
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                T.o[i][0][r] = t == 0 ? T.dot[i][0][t] * accv[0][8 + r] : T.o[i][0][r] + T.dot[i][0][t] * accv[0][8 + r];
-                T.o[i][1][r] += T.dot[i][1][t] * acc[0][r];
-                T.o[i][2][r] += T.dot[i][2][t] * acc[0][8 + r];
-            }
-    } else if constexpr (Q == 20) {
-        BFrag<PREC> ob[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int hd = 0; hd < 3; ++hd)
-                ob[i][hd] = make_frag<PREC>(T.o[i][hd][0], T.o[i][hd][1], T.o[i][hd][2], T.o[i][hd][3], T.o[i][hd][4], T.o[i][hd][5],
-                                            T.o[i][hd][6], T.o[i][hd][7]);
-        T.acc[0] = bias_tile(cx, 6); T.acc[1] = bias_tile(cx, 6);
-        mma_cols<PREC, 3, 2>(s1, 2, ob, T.acc);                      // to_out + bias
-    } else if constexpr (Q == 21) {                                  // residual (renderer.py:925): tokens 0, 1 re-read (L2-hot)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x16 tk;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-                tk[4 * i] = v.x; tk[4 * i + 1] = v.y; tk[4 * i + 2] = v.z; tk[4 * i + 3] = v.w;
-            }
-            T.y[t] = T.acc[t] + tk;
-        }
-    } else if constexpr (Q == 22 || Q == 23) {
-        layer_norm<PREC>(cx, T.y[Q - 22], 1, T.l2[Q - 22][0], T.l2[Q - 22][1]);
-    } else if constexpr (Q == 24) {
-        T.acc[0] = bias_tile(cx, 7); T.acc[1] = bias_tile(cx, 7);
-        mma_cols<PREC, 2, 2>(s1, 5, T.l2, T.acc);
-    } else if constexpr (Q >= 25 && Q <= 28) {                       // GELU, a quarter of the 32 values per slice
-        constexpr int i = (Q - 25) / 2, r0 = 8 * ((Q - 25) % 2);
-#pragma unroll
-        for (int r = r0; r < r0 + 8; ++r) T.acc[i][r] = gelu_<PREC != 1>(T.acc[i][r]);
-    } else if constexpr (Q == 29) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) split_tile<PREC>(T.acc[i], T.gb[i][0], T.gb[i][1]);
-        T.acc[0] = bias_tile(cx, 8); T.acc[1] = bias_tile(cx, 8);
-        mma_cols<PREC, 2, 2>(s1, 7, T.gb, T.acc);
-    } else if constexpr (Q == 30) {
-        f32x16 za = T.acc[0] + T.y[0], zb = T.acc[1] + T.y[1];
-        split_tile<PREC>(za, T.z0b[0], T.z0b[1]);
-        split_tile<PREC>(zb, T.z1b[0], T.z1b[1]);
-    }
-}
-
-template <int PREC, int Q>
-__device__ __forceinline__ void tslice_part(const Ctx<PREC>& cx, TState<PREC>& T, int part) {
-    if constexpr (Q == 3) layer_norm_part<PREC>(cx, T.tok[2], 0, T.ln[2][0], T.ln[2][1], T.lnp, part);
-    else if constexpr (Q == 4 || Q == 5) layer_norm_part<PREC>(cx, T.tok[Q - 4], 0, T.ln[Q - 4][0], T.ln[Q - 4][1], T.lnp, part);
-    else if constexpr (Q == 22 || Q == 23) layer_norm_part<PREC>(cx, T.y[Q - 22], 1, T.l2[Q - 22][0], T.l2[Q - 22][1], T.lnp, part);
-    else if constexpr (Q == 14 || Q == 15) {                         // one head per part
-        constexpr int i = Q - 14;
-#pragma unroll
-        for (int hd = 0; hd < 3; ++hd) {
-            if (hd != part) continue;
-            float d[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) d[t] = xhalf_sum(T.dot[i][hd][t]) * 0.25f;
-            float m = fmaxf(d[0], fmaxf(d[1], d[2]));
-            float e0 = exp_(d[0] - m), e1 = exp_(d[1] - m), e2 = exp_(d[2] - m);
-            float inv = rcp_(e0 + e1 + e2);
-            T.dot[i][hd][0] = e0 * inv; T.dot[i][hd][1] = e1 * inv; T.dot[i][hd][2] = e2 * inv;
-        }
-    } else if constexpr (Q >= 25 && Q <= 28) {                       // two of the slice's eight values per part
-        constexpr int i = (Q - 25) / 2, r0 = 8 * ((Q - 25) % 2);
-#pragma unroll
-        for (int r = r0; r < r0 + 8; ++r)
-            if ((r - r0) / 2 == part) T.acc[i][r] = gelu_<true>(T.acc[i][r]);
-    }
-}
-
-// decoder state of the group in flight
-template <int PREC> struct PWindow { AFrag<PREC> f[SHERF_MLP_PIPE_AWIN]; };
-template <int PREC>
-__device__ __forceinline__ void pwin_fill(PWindow<PREC>& w, const char* s, int n_pairs) {
-    constexpr int UNIT = Ctx<PREC>::UNIT;
-#pragma unroll
-    for (int i = 0; i < SHERF_MLP_PIPE_AWIN; ++i)
-        if (i < n_pairs) w.f[i] = load_units<PREC>(s + 2 * i * UNIT);
-}
-template <int PREC> struct DState {
-    BFrag<PREC> ha[8], hb[8], gb[4], pe[3], pv[2], z0b[2], z1b[2];
-    f32x16 acc0, acc1;
-    PWindow<PREC> win;
-    float xc[3], vc[3], sigma;
-};
-// the decoder's 41 steps (2..42) as data: what is finished before the step's MFMAs (the previous pair of output chunks -> K-blocks of
-// the next layer), which accumulators are opened, what the step multiplies.  (csrc/mlp.hip: decoder_tile is the same sequence as code.)
-enum { K_PAIR = 0, K_PEZ0 = 1, K_ALPHA = 2, K_PVZ1 = 3, K_RGB = 4 };
-enum { B_HA = 0, B_HB = 1, B_GB = 2 };
-struct StepDesc { int fin, fin_off, relu, bias0, bias1, kind, in, in_off; };
-__host__ __device__ constexpr StepDesc step_desc(int S) {
-    StepDesc d{-1, 0, 1, -1, -1, K_PAIR, B_HA, 0};
-    if (S == 2 || S == 3) { d.kind = K_PEZ0; d.bias0 = 9 + 2 * (S - 2); d.bias1 = d.bias0 + 1; if (S == 3) { d.fin = B_HA; d.fin_off = 0; } return d; }
-    if (S >= 4 && S <= 19) {                       // pts_linears.1-4: layer L reads (L even ? ha : hb), writes the other
-        const int q = S - 4, L = q / 4, r = q % 4;
-        d.in = (L % 2 == 0) ? B_HA : B_HB; d.in_off = (r % 2) * 4;
-        if (r % 2 == 0) { d.bias0 = 13 + 4 * L + r; d.bias1 = d.bias0 + 1; }
-        if (r == 2) { d.fin = (L % 2 == 0) ? B_HB : B_HA; d.fin_off = 0; }
-        if (r == 0) { d.fin = (L == 0) ? B_HA : ((L % 2 == 0) ? B_HA : B_HB); d.fin_off = 4; }     // the previous layer's second pair
-        return d;
-    }
-    if (S >= 20 && S <= 25) {                      // pts_linears.5: [PE6 | z_0] then ha (128), -> hb
-        const int q = S - 20, P = q / 3, r = q % 3;
-        if (r == 0) { d.kind = K_PEZ0; d.bias0 = 29 + 2 * P; d.bias1 = d.bias0 + 1; d.fin = P == 0 ? B_HA : B_HB; d.fin_off = P == 0 ? 4 : 0; }
-        else { d.in = B_HA; d.in_off = (r - 1) * 4; }
-        return d;
-    }
-    if (S >= 26 && S <= 37) {                      // pts_linears.6 (hb -> ha), .7 (ha -> hb), feature_linear (hb -> ha, no ReLU)
-        const int q = S - 26, L = q / 4, r = q % 4;
-        d.in = (L % 2 == 0) ? B_HB : B_HA; d.in_off = (r % 2) * 4;
-        if (r % 2 == 0) { d.bias0 = 33 + 4 * L + r; d.bias1 = d.bias0 + 1; }
-        if (r == 2) { d.fin = (L % 2 == 0) ? B_HA : B_HB; d.fin_off = 0; d.relu = L < 2; }
-        if (r == 0) { d.fin = (L % 2 == 0) ? B_HB : B_HA; d.fin_off = 4; d.relu = 1; }              // the previous layer's second pair (ReLU layers)
-        return d;
-    }
-    if (S == 38) { d.kind = K_ALPHA; d.bias0 = 45; d.bias1 = -2; d.fin = B_HA; d.fin_off = 4; d.relu = 0; d.in = B_HB; return d; }
-    if (S == 39) { d.bias0 = 46; d.bias1 = 47; d.in = B_HA; d.in_off = 0; return d; }
-    if (S == 40) { d.in = B_HA; d.in_off = 4; return d; }
-    if (S == 41) { d.kind = K_PVZ1; return d; }
-    d.kind = K_RGB; d.bias0 = 48; d.bias1 = -2; d.fin = B_GB; d.fin_off = 0; d.relu = 1; d.in = B_GB;                // S == 42
-    return d;
-}
-// blocks on the compiler-visible MFMA builtin off the fragment window (mma_chains' window path without the asm blocks: hipcc places the
-// hazard wait states itself and is free to put other work between the MFMAs)
-// `between(p)` runs after block p (p = the pair's index in the step): where a step places the parts of the other group's transformer slice
-template <int PREC, int NB, bool PAIR, class F>
-__device__ __forceinline__ void mma_win(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, PWindow<PREC>& w, int tot_pairs, F&& between) {
-    constexpr int UNIT = Ctx<PREC>::UNIT, W = SHERF_MLP_PIPE_AWIN;
-    static_assert(PREC != 1, "single-product precisions");
-    const int p0 = u0 / 2, tot = tot_pairs >= 0 ? tot_pairs : p0 + NB;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const BFrag<PREC>& b0 = b[PAIR ? i : 2 * i];
-        const BFrag<PREC>& b1 = b[PAIR ? i : 2 * i + 1];
-        const int p = p0 + i;
-        AFrag<PREC>& cur = w.f[p % W];
-        acc0 = mfma<PREC>(cur.h0, b0.hi, acc0);
-        acc1 = mfma<PREC>(cur.h1, b1.hi, acc1);
-        if (p + W < tot) cur = load_units<PREC>(s + 2 * (p + W) * UNIT);
-        between(p);
-    }
-}
-template <int PREC, bool RELU>
-__device__ __forceinline__ void finish_free(const f32x16& acc0, const f32x16& acc1, BFrag<PREC>* out) {
-    split_tile<PREC>(acc0, out[0], out[1]);
-    split_tile<PREC>(acc1, out[2], out[3]);
-    if constexpr (RELU) {
-        static_assert(PREC == 2 ? SHERF_MLP_PK_RELU : true, "the pipelined kernel's fp16 ReLU is the packed one");
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[f].hi[e] = PREC == 2 ? relu2_f16(out[f].hi[e]) : out[f].hi[e];
-    }
-}
-template <int PREC>
-__device__ __forceinline__ BFrag<PREC>* dbuf(DState<PREC>& D, int which) { return which == B_HA ? D.ha : which == B_HB ? D.hb : D.gb; }
-
-template <int PREC, int S, class F>
-__device__ __forceinline__ void dstep(Ctx<PREC>& cx, DState<PREC>& D, const int32_t* __restrict__ counters, int64_t tile, bool live, int64_t nv,
-                                      float4* __restrict__ out, F&& between) {
-    constexpr StepDesc d = step_desc(S);
-    const int j = cx.lane & 31, h = cx.h;
-    if constexpr (d.fin >= 0) {
-        if constexpr (PREC == 2) finish_free<PREC, d.relu != 0>(D.acc0, D.acc1, dbuf(D, d.fin) + d.fin_off);
-        else {                                         // bf16: ReLU on the fp32 values (as finish_pair does for prec 0)
-            f32x16 a0 = D.acc0, a1 = D.acc1;
-            if constexpr (d.relu != 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { a0[r] = relu(a0[r]); a1[r] = relu(a1[r]); }
-            }
-            finish_free<PREC, false>(a0, a1, dbuf(D, d.fin) + d.fin_off);
-        }
-    }
-    if constexpr (S == 39) D.sigma = D.acc0[0] + D.acc1[0];          // alpha_linear: row 0 lives in reg 0 of the h == 0 lanes
-    if constexpr (S == 2 || S == 20) pe_frags<PREC, 6, 3>(h, D.xc[0], D.xc[1], D.xc[2], D.pe);
-    if constexpr (S == 39) pe_frags<PREC, 4, 2>(h, D.vc[0], D.vc[1], D.vc[2], D.pv);
-    if constexpr (d.bias0 >= 0) {
-        D.acc0 = bias_tile(cx, d.bias0);
-        if constexpr (d.bias1 >= 0) D.acc1 = bias_tile(cx, d.bias1);
-        else D.acc1 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    }
-    const char* sl = cx.slot(S);
-    if constexpr (d.kind == K_PAIR) mma_win<PREC, 4, true>(sl, 0, dbuf(D, d.in) + d.in_off, D.acc0, D.acc1, D.win, -1, between);
-    else if constexpr (d.kind == K_PEZ0) { mma_win<PREC, 3, true>(sl, 0, D.pe, D.acc0, D.acc1, D.win, 5, between); mma_win<PREC, 2, true>(sl, 6, D.z0b, D.acc0, D.acc1, D.win, -1, between); }
-    else if constexpr (d.kind == K_ALPHA) mma_win<PREC, 4, false>(sl, 0, D.hb, D.acc0, D.acc1, D.win, -1, between);
-    else if constexpr (d.kind == K_PVZ1) { mma_win<PREC, 2, true>(sl, 0, D.pv, D.acc0, D.acc1, D.win, 4, between); mma_win<PREC, 2, true>(sl, 4, D.z1b, D.acc0, D.acc1, D.win, -1, between); }
-    else {
-        mma_win<PREC, 2, false>(sl, 0, D.gb, D.acc0, D.acc1, D.win, -1, between);
-        if (live && h == 0) {
-            const int64_t c = tile * 32 + j;
-            if (c < nv) {
-                float r = rcp_(1.0f + exp_(-(D.acc0[0] + D.acc1[0]))), g = rcp_(1.0f + exp_(-(D.acc0[1] + D.acc1[1]))), b = rcp_(1.0f + exp_(-(D.acc0[2] + D.acc1[2])));
-                out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, D.sigma);   // triplane.py:314
-                if (!(fabsf(D.sigma) <= 3.0e38f) || !(r + g + b <= 4.0f)) atomicOr(reinterpret_cast<unsigned*>(const_cast<int32_t*>(counters)) + 3, 1u);
-            }
-        }
-    }
-}
-
-// the ring as one endless sequence: steps 2..42 of a group, an empty step 43, then step 2 of the next group (43 - 2 + 1 = 42 = 0 mod 3)
-__host__ __device__ constexpr int seq_step(int s, int k) { return s + k <= 43 ? s + k : s + k - 42; }
-template <int PREC, int S>
-__device__ __forceinline__ void pipe_step_end(Ctx<PREC>& cx, DState<PREC>& D, bool more) {
-    constexpr int s1 = seq_step(S, 1), s2 = seq_step(S, 2), s3 = seq_step(S, 3);
-    SHERF_TRACE_STAMP(cx, S, 0);
-    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(s2) / NW);        // everything but the newest issue (s2) has landed: s1 is in LDS
-    if (!(SHERF_MLP_ABLATE & 64)) wg_barrier();
-    if constexpr (s1 != 43) {
-        if (s1 > S || more) pwin_fill<PREC>(D.win, cx.slot(s1), step_units(s1) / 2);     // (past the last group: nothing was fetched)
-    }
-    if constexpr (s3 != 43) {
-        if (s3 > S || more) dma_issue(cx, s3);                               // (a wrapped step belongs to the next group: only if there is one)
-    }
-}
-
-#ifndef SHERF_MLP_PIPE_ORDER
-#define SHERF_MLP_PIPE_ORDER 1     // 1: a slice of pure VALU follows the decoder step in program order, a slice that opens with MFMAs leads it
-#endif
-#ifndef SHERF_MLP_PIPE_PARTS
-#define SHERF_MLP_PIPE_PARTS 1     // the pure-VALU slices in four fenced parts between the step's MFMA blocks (0: left to the scheduler)
-#endif
-#ifndef SHERF_MLP_PIPE_GROUPS
-#define SHERF_MLP_PIPE_GROUPS 12
-#endif
-#ifndef SHERF_MLP_PIPE_VALU
-#define SHERF_MLP_PIPE_VALU 8
-#endif
-template <int PREC, int S>
-__device__ __forceinline__ void pipe_steps(Ctx<PREC>& cx, DState<PREC>& D, TState<PREC>& T, const char* wl, const int32_t* __restrict__ counters,
-                                           const float4* __restrict__ tokens, const float* __restrict__ extras, int64_t tile, bool live,
-                                           int64_t next_tile, bool more, int64_t nv, float4* __restrict__ out) {
-    if constexpr (S <= 42) {
-        __builtin_amdgcn_sched_barrier(0);                                   // one scheduling region per step
-        // (the slice FIRST in program order: the pipeline below hands out MFMAs in that order, and a slice's own MFMAs should lead so
-        //  that the VALU depending on them can sit between the decoder's)
-        constexpr int Q = S - 2;
-        constexpr bool lead = (Q >= 6 && Q <= 13) || (Q >= 17 && Q <= 20) || Q == 24 || Q == 29 || Q == 2;      // slices that open with MFMAs
-        constexpr bool parts = SHERF_MLP_PIPE_PARTS && Q < N_TSLICES && slice_in_parts(Q);
-        if constexpr (parts) {
-            // pure VALU (LayerNorm, softmax, GELU): part p right behind the step's p-th MFMA block, fenced in place (a Q == 3 slice also
-            // fetches the next token: with part 0)
-            if constexpr (Q == 3) tslice<PREC, 103>(cx, T, wl, tokens, extras, next_tile);
-            dstep<PREC, S>(cx, D, counters, tile, live, nv, out, [&](int p) {
-                if (p < 4) tslice_part<PREC, Q>(cx, T, p);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        } else {
-            if constexpr (Q < N_TSLICES && (lead || SHERF_MLP_PIPE_ORDER == 0)) tslice<PREC, Q>(cx, T, wl, tokens, extras, next_tile);
-            if constexpr (Q == N_TSLICES) {                                  // the next group's sample position / view direction
-                const float* ex = extras + next_tile * 12 * 32 + (cx.lane & 31);
-                T.xc[0] = ex[0]; T.xc[1] = ex[32]; T.xc[2] = ex[64]; T.vc[0] = ex[96]; T.vc[1] = ex[128]; T.vc[2] = ex[160];
-            }
-            dstep<PREC, S>(cx, D, counters, tile, live, nv, out, [](int) {});
-            if constexpr (Q < N_TSLICES && !(lead || SHERF_MLP_PIPE_ORDER == 0)) tslice<PREC, Q>(cx, T, wl, tokens, extras, next_tile);
-        }
-        // the step as hipcc should lay it out: an MFMA, then up to eight VALU of whatever is ready (the other group's transformer slice, this
-        // group's epilogue / encodings), twelve times over (8-10 decoder MFMAs + the slice's own)
-#pragma unroll
-        for (int i = 0; i < SHERF_MLP_PIPE_GROUPS; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x402, SHERF_MLP_PIPE_VALU, 0);          // VALU | transcendentals
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pipe_step_end<PREC, S>(cx, D, more);
-        pipe_steps<PREC, S + 1>(cx, D, T, wl, counters, tokens, extras, tile, live, next_tile, more, nv, out);
-    } else {
-        pipe_step_end<PREC, 43>(cx, D, more);                                // the empty step
-    }
-}
-
-#ifndef SHERF_MLP_PIPE_WAVES
-#define SHERF_MLP_PIPE_WAVES 2        // workgroups per CU = waves per SIMD the pipelined kernel is compiled and launched for
-#endif
-template <int PREC>
-__global__ void __launch_bounds__(NW * 64, SHERF_MLP_PIPE_WAVES)
-nerf_mlp_pipe_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                     const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
-    using CX = Ctx<PREC>;
-    constexpr int NT = NW * 64;
-    constexpr int WT = (step_pieces<PREC>(0) + step_pieces<PREC>(1)) * 1024;          // the transformer's weights: resident
-    // [ring: 3 slots][bias / LayerNorm tables][transformer weights]  (ring_ctx expects the first two in this order)
-    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + WT];
-    const int64_t nv = min((int64_t)counters[0], capacity);
-    const int64_t n_tiles = (nv + 31) / 32;
-    const int64_t n_groups = (n_tiles + NW - 1) / NW;
-    if ((int64_t)blockIdx.x >= n_groups) return;
-    CX cx;
-    ring_ctx<PREC>(cx, lds, ws, wbias);
-    cx.saddr = true;
-    char* wt = lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4;
-    for (int i = threadIdx.x; i < WT / 16; i += NT) reinterpret_cast<u32x4*>(wt)[i] = reinterpret_cast<const u32x4*>(ws)[i];
-    const char* wl = wt + cx.lane * 16;
-    ring_prologue<PREC, 2>(cx);                                              // (its barrier also publishes the tables and the resident weights)
-
-    DState<PREC> D;
-    TState<PREC> T;
-    int64_t g = blockIdx.x;
-    int64_t tile = min(g * NW + cx.wave, n_tiles - 1);
-    {   // the first group's transformer, on its own
-        tslice<PREC, 0>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 1>(cx, T, wl, tokens, extras, tile); tslice<PREC, 2>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 3>(cx, T, wl, tokens, extras, tile); tslice<PREC, 4>(cx, T, wl, tokens, extras, tile); tslice<PREC, 5>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 6>(cx, T, wl, tokens, extras, tile); tslice<PREC, 7>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 8>(cx, T, wl, tokens, extras, tile); tslice<PREC, 9>(cx, T, wl, tokens, extras, tile); tslice<PREC, 10>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 11>(cx, T, wl, tokens, extras, tile); tslice<PREC, 12>(cx, T, wl, tokens, extras, tile); tslice<PREC, 13>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 14>(cx, T, wl, tokens, extras, tile); tslice<PREC, 15>(cx, T, wl, tokens, extras, tile); tslice<PREC, 16>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 17>(cx, T, wl, tokens, extras, tile); tslice<PREC, 18>(cx, T, wl, tokens, extras, tile); tslice<PREC, 19>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 20>(cx, T, wl, tokens, extras, tile); tslice<PREC, 21>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 22>(cx, T, wl, tokens, extras, tile); tslice<PREC, 23>(cx, T, wl, tokens, extras, tile); tslice<PREC, 24>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 25>(cx, T, wl, tokens, extras, tile); tslice<PREC, 26>(cx, T, wl, tokens, extras, tile); tslice<PREC, 27>(cx, T, wl, tokens, extras, tile);
-        tslice<PREC, 28>(cx, T, wl, tokens, extras, tile); tslice<PREC, 29>(cx, T, wl, tokens, extras, tile); tslice<PREC, 30>(cx, T, wl, tokens, extras, tile);
-        const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
-        T.xc[0] = ex[0]; T.xc[1] = ex[32]; T.xc[2] = ex[64]; T.vc[0] = ex[96]; T.vc[1] = ex[128]; T.vc[2] = ex[160];
-    }
-    if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
-    pwin_fill<PREC>(D.win, cx.slot(2), step_units(2) / 2);
-    for (;;) {
-        // the transformer's results become this group's decoder inputs
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { D.z0b[k] = T.z0b[k]; D.z1b[k] = T.z1b[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { D.xc[k] = T.xc[k]; D.vc[k] = T.vc[k]; }
-        const bool live = g * NW + cx.wave < n_tiles;
-        tile = min(g * NW + cx.wave, n_tiles - 1);
-        const int64_t gn = g + gridDim.x;
-        const bool more = gn < n_groups;
-        // (past the last group the slices run once more on this group's own tile: their VALU hides under the MFMAs like any other, nothing is stored)
-        const int64_t next_tile = more ? min(gn * NW + cx.wave, n_tiles - 1) : tile;
-        pipe_steps<PREC, 2>(cx, D, T, wl, counters, tokens, extras, tile, live, next_tile, more, nv, out);
-        if (!more) break;
-        g = gn;
-    }
-    SHERF_TRACE_FLUSH(cx);
-}
-
 // ---- the two-launch form -------------------------------------------------------------------------------------------------------
 // zfrag[tile][q][64 lanes] u32x4: the fused tokens as ready-made B-operand fragments, q = 2 * (0: z_0, 1: z_1) + kb for the single-product
 // precisions (4 KiB per tile), q = 4 * (z) + 2 * kb + (0: hi, 1: lo) for prec 1 (8 KiB per tile).
@@ -1512,7 +947,7 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
     for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
     __syncthreads();
     CX cx;
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0; cx.ws_base = ws; cx.lds_base = 0; cx.saddr = false;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0;
     for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
         // loop (hundreds of live registers).  The OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and
@@ -1573,7 +1008,6 @@ nerf_decoder_kernel(const int32_t* __restrict__ counters, const u32x4* __restric
 
 }  // namespace
 
-#ifndef SHERF_MLP_ONLY_PIPE      // (tools: a translation unit with only the pipelined kernel compiles in a fraction of the time)
 #if SHERF_MLP_TRACE
 extern "C" int sherf_mlp_set_trace(void* buf, int every) {
     SHERF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_trace), &buf, sizeof(buf)));
@@ -1686,29 +1120,3 @@ extern "C" int sherf_nerf_mlp_split(const int32_t* counters, const float* tokens
     SHERF_LAUNCH_CHECK();
 }
 
-#endif  // SHERF_MLP_ONLY_PIPE
-
-// The software-pipelined form (nerf_mlp_pipe_kernel): same inputs, same outputs bit for bit; single-product precisions only (prec 0, 2).
-extern "C" int sherf_nerf_mlp_pipe(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
-                                   const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0, v = 0;
-        SHERF_HIP_CHECK(hipGetDevice(&dev));
-        SHERF_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = v > 0 ? v : 256;
-    }
-    const int64_t groups = ((capacity + 31) / 32 + NW - 1) / NW;
-    const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)n_cu * SHERF_MLP_PIPE_WAVES)), block(NW * 64);       // persistent
-    if (prec == 2)
-        hipLaunchKernelGGL((nerf_mlp_pipe_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
-#ifndef SHERF_MLP_ONLY_PIPE
-    else
-        hipLaunchKernelGGL((nerf_mlp_pipe_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
-#endif
-    SHERF_LAUNCH_CHECK();
-}

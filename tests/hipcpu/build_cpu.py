@@ -39,11 +39,6 @@ def _cpu_mlp(src):
     src = src.replace('    asm volatile("s_nop 7\\n\\ts_nop 3" : "+v"(acc0), "+v"(acc1));', '    (void)acc0; (void)acc1;')
     src = src.replace('#define SHERF_MLP_FMA_MIX 1', '#define SHERF_MLP_FMA_MIX 0')       # v_fma_mix_f32 inline asm -> its plain-C equivalent
     src = re.sub(r'asm volatile\("" : "\+[sv]"\([^;]*;', ';', src)            # register-class launders (optimisation barriers only)
-    # the SADDR issue: K pieces of 1 KiB, source base + lane offset, LDS byte address m (an offset on the host)
-    src = cut(src, '    uint32_t keep;\n    if (K == 2)\n        asm volatile("s_mov_b32 %0, m0', '}\ntemplate <int PREC>\n__device__ __forceinline__ void dma_issue_saddr',
-              '    for (int i = 0; i < K; ++i) memcpy(g_hipcpu_lds_base + m + 1024 * i + voff, sbase + 1024 * i + voff, 16);\n')
-    src = src.replace('__device__ __forceinline__ void glds_saddr(', 'static thread_local char* g_hipcpu_lds_base = nullptr;\n__device__ __forceinline__ void glds_saddr(')
-    src = src.replace("cx.lds_base = cx.lds_addr - cx.wave * 1024;", "cx.lds_base = 0; g_hipcpu_lds_base = lds;")
     assert 'asm volatile' not in src.replace('#if SHERF_MLP_FMA_MIX', '#if 0'), 'an inline-asm site of mlp.hip has no host equivalent'
     return src.replace('typedef __attribute__((address_space(3))) void* lptr_t;', 'typedef void* lptr_t;')
 

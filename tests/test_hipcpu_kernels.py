@@ -539,7 +539,7 @@ def mlp_lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp_split', 'sherf_nerf_mlp_pipe', 'sherf_mlp_pack_stream'):
+    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
         getattr(lib, fn).restype, getattr(lib, fn).argtypes = protos[fn][0], [a[0] for a in protos[fn][1]]
     return lib
 
@@ -607,13 +607,6 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
         assert r_sig < 1e-3 and r_rgb < 1e-3, (r_sig, r_rgb)
     assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), 3, n, _P(out), None) != 0        # unknown precision
     # the two-launch form (tokens kernel with resident weights + decoder kernel): the same bits; the non-finite flag word is left alone
-    # the software-pipelined persistent form (decoder of tile-group g + transformer of group g + 1 in one instruction stream): the same bits
-    if prec != 1:
-        out3 = torch.full((tiles * 32, 4), float('nan'))
-        assert mlp_lib.sherf_nerf_mlp_pipe(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out3), None) == 0
-        assert torch.equal(out3[:n], out[:n])
-    else:
-        assert mlp_lib.sherf_nerf_mlp_pipe(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out), None) != 0
     zfrag = torch.zeros(tiles * (2048 if prec == 1 else 1024), dtype=torch.int32)
     for flag in (0, 1):
         counters[3] = flag

@@ -29,7 +29,7 @@ def main():
     ap.add_argument('--config', default='cfg2_ri')
     ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'])
     ap.add_argument('--stress', type=int, default=0)
-    ap.add_argument('--forms', default='one,pipe', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), pipe (sherf_nerf_mlp_pipe)')
+    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split); pipe = the round-4 pipelined experiment, if the library has it')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_ab.json'))
     a = ap.parse_args()
     import bench
