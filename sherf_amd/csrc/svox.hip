@@ -251,7 +251,13 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     const int n_rows = *n_rows_out;
     const int row0 = blockIdx.x * 32;
     if (row0 >= n_rows) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // `wave` must be PROVABLY wave-uniform: the FOLD instances choose their output tile by it (c == csel), and with a merely divergent-looking
+    // condition hipcc predicates that block by EXEC and -- when the block is one MFMA, as in the single-product instances -- drops the
+    // s_cbranch_execz around it (short-skip removal).  MFMAs ignore EXEC on gfx950: the waves that do NOT own the tile then multiply with
+    // whatever sits in the weight registers.  That was round 3's "single-product convolutions: right on the host build, wrong on the
+    // MI355X" (tools/sconv_fold_diag.py: tile 2 of every fold garbage; the three-product instances kept their branches only because their
+    // blocks are longer).  readfirstlane makes the condition scalar: real branches.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntaps = FOLD ? 1 : 27;
     {   // neighbour table: thread -> row tid & 31, taps (tid >> 5) + 8 j.  The row's key is read once and the (up to) four bitmap
         // records are fetched together: two dependent L2 trips per workgroup instead of seven (profiles/r02_sconv_trace_v1.txt:

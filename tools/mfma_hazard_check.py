@@ -6,14 +6,19 @@ between such a block and the hand-placed settle is NOT covered by anything.  Thi
 
   R1  MFMA writes v[..]  ->  any non-MFMA instruction touching one of those registers      needs >= 12 wait states
   R2  MFMA writes v[..]  ->  MFMA reading one of them as SrcA / SrcB                       needs >= 12
-  R3  MFMA writes v[..]  ->  MFMA whose SrcC / vDst overlaps them but is not the SAME tuple  needs >= 12   (the same tuple as SrcC:
+  R3  MFMA writes v[..]  ->  MFMA whose SrcC overlaps them but is not the SAME tuple          needs >= 12   (the same tuple as SrcC:
       the back-to-back accumulate the hardware forwards, 0)
   R4  VALU writes vN     ->  MFMA reading vN (any source)                                  needs >= 2
+  R5  an MFMA inside an EXEC-predicated region that has NO skip branch: `s_and_saveexec` ... `v_mfma` with no `s_cbranch_execz/execnz` in
+      between.  MFMAs ignore EXEC on gfx950, so with EXEC = 0 the instruction still runs on whatever its operand registers hold; hipcc drops
+      the skip branch of SHORT predicated blocks (one MFMA) -- round 3's single-product sparse convolutions failed on the hardware this way
+      (csrc/svox.hip: `wave` had to be made provably uniform).  Reported per kernel; not a wait-state rule.
 
 The constants are the compiler's own for v_mfma_f32_32x32x16_{f16,bf16} on gfx950 (8 passes): `s_nop 11` between such an MFMA and a
 VALU / VMEM reader of its result, `s_nop 1` between a VALU write and the MFMA reading it (probe: tools/mfma_hazard_probe.hip, compiled
 with the same hipcc).  A wait state = one issued instruction; `s_nop N` = N + 1.  The scan is linear over the kernel's text (branch
-targets do not reset the window: conservative for the straight-line MLP kernel).
+targets do not reset the window: conservative for the straight-line MLP kernel; for kernels with control flow R1-R4 over-report across
+branches -- the sparse convolutions' MFMAs are builtins anyway, hipcc places their wait states -- while R5 is exact for them).
 
     python tools/mfma_hazard_check.py <file.s> [kernel-name-substring ...]      exit code 1 if any kernel has a violation
 """
@@ -50,6 +55,7 @@ def kernels(lines):
 
 
 def check(lines, start, end, verbose=True):
+    masked = None       # line of the last s_and_saveexec with no skip branch / restore behind it yet
     pending = []        # [regset, age in wait states, line no, text] per MFMA still inside the window
     valu = {}           # reg -> age of the last VALU write
     bad = []
@@ -63,6 +69,12 @@ def check(lines, start, end, verbose=True):
         args = t[len(op):]
         ops = regs(args)
         is_mfma = op.startswith('v_mfma') or op.startswith('v_smfma')
+        if op.startswith('s_and_saveexec') or op.startswith('s_andn2_saveexec') or op.startswith('s_or_saveexec'):
+            masked = ln + 1
+        elif op.startswith('s_cbranch_exec') or (op.startswith(('s_or_b64', 's_mov_b64', 's_xor_b64', 's_andn2_b64')) and args.strip().startswith('exec')):
+            masked = None
+        if is_mfma and masked is not None:
+            bad.append((ln + 1, 'R5', 0, masked, t))
         if is_mfma:
             n_mfma += 1
             parts = [p.strip() for p in args.split(',')]
@@ -75,9 +87,8 @@ def check(lines, start, end, verbose=True):
                     continue
                 if (srca | srcb) & p[0]:
                     bad.append((ln + 1, 'R2', p[1], p[2], t))
-                for tup in (srcc, dst):
-                    if tup & p[0] and tup != p[0]:
-                        bad.append((ln + 1, 'R3', p[1], p[2], t))
+                if srcc & p[0] and srcc != p[0]:             # (an overlapping DESTINATION is fine: the matrix pipe retires in order)
+                    bad.append((ln + 1, 'R3', p[1], p[2], t))
             for r in srca | srcb | srcc:
                 if r in valu and valu[r] < VALU_TO_MFMA:
                     bad.append((ln + 1, 'R4', valu[r], None, t))
@@ -121,6 +132,9 @@ def main():
             continue
         print(f'{name}: {n} MFMAs, {len(bad)} hazard violations')
         for ln, rule, age, src_ln, text in bad[:40]:
+            if rule == 'R5':
+                print(f'   line {ln}: R5 MFMA predicated by the s_*_saveexec at line {src_ln} without a skip branch: {text}')
+                continue
             print(f'   line {ln}: {rule} after {age} wait states' + (f' (MFMA at line {src_ln})' if src_ln else '') + f': {text}')
         if bad:
             rc = 1
