@@ -496,9 +496,10 @@ class ImportanceRenderer(nn.Module):
     # convolutions).  'f16x3' / fp32 tables / 'f16x3' is the fp32-grade reference configuration.  mlp_precision='auto' measures the
     # cheaper ones, cheapest first, against it on a whole frame of the weights' own samples and keeps the first within AUTO_TOL.
     REFERENCE_CONFIG = ('f16x3', 'f32', 'f16x3')
-    # (('f16', 'f16', 'f16') -- single-product sparse convolutions too -- is NOT a candidate: correct on the host build, wrong folded rows on
-    #  the MI355X, cause not found yet: DESIGN section 9, profiles/r03_bench_e_gather_h8.txt; the calibration rejected it, as it should)
-    AUTO_CANDIDATES = (('f16', 'f16', 'f16x3'), ('f16', 'f32', 'f16x3'))
+    # cheapest first.  ('f16', 'f16', 'f16') -- single-product sparse convolutions too -- is a candidate again in round 4: round 3's "wrong
+    # folded rows on the MI355X" was an MFMA that hipcc had predicated by EXEC without a skip branch (csrc/svox.hip: `wave`), fixed and
+    # guarded by tests/test_isa_hazards.py; the calibration measures it on the frame like every other candidate
+    AUTO_CANDIDATES = (('f16', 'f16', 'f16'), ('f16', 'f16', 'f16x3'), ('f16', 'f32', 'f16x3'))
     AUTO_TOL = 2.5e-4                   # a quarter of north_star's 1e-3 per-sample budget (true relative error, floors 1.0 / 0.1)
 
     def _resolve_config(self, opts, decoder, dev):
@@ -509,11 +510,6 @@ class ImportanceRenderer(nn.Module):
         mlp = opts.get('mlp_precision') or self.mlp_precision
         tab = opts.get('table_precision') or getattr(self, 'table_precision', 'auto')
         enc = opts.get('encoder_precision') or getattr(self, 'encoder_precision', 'auto')
-        if enc == 'f16' and os.environ.get('SHERF_ALLOW_BROKEN_ENCODER_F16') != '1':
-            # single-fp16-product sparse convolutions: right on the host build of the kernels, WRONG images on the MI355X (DESIGN section 9,
-            # tools/enc_sp_diag.py) -- a diagnostic mode until that is explained, never something a caller gets silently
-            raise RuntimeError("encoder_precision='f16' renders wrong images on the MI355X (cause under investigation: DESIGN.md section 9); "
-                               "use 'f16x3' / 'auto', or set SHERF_ALLOW_BROKEN_ENCODER_F16=1 for diagnostics")
         training = getattr(self, '_in_autograd', False) or (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False))
         if training:
             return (mlp if mlp != 'auto' else 'f16x3', 'f32', 'f16x3'), False

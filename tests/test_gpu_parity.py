@@ -481,15 +481,18 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
         o = O.render_from_fixture(fx_sub, state, training=True, keep=False)
         truth = O.truth64_from_fixture(fx_sub, state, o)
     spi = o['sp_input']                                             # depends on the vertices, not on the rays
-    a = G.hip_render(cfg, sp_input=spi, precision=precision)
-    b = G.hip_render(cfg, sp_input=spi, precision=precision)
+    enc = 'f16' if precision.endswith('+enc16') else 'f16x3'
+    precision = precision.split('+')[0]
+    ropts = dict(encoder_precision=enc)
+    a = G.hip_render(cfg, sp_input=spi, precision=precision, options=ropts)
+    b = G.hip_render(cfg, sp_input=spi, precision=precision, options=ropts)
     assert a['last']['mlp_precision'] == precision and a['last']['table_precision'] == ('f32' if precision == 'f16x3' else 'f16')
-    assert a['last']['encoder_precision'] == 'f16x3'
+    assert a['last']['encoder_precision'] == enc
     assert a['rgb'].shape == (R, 3) and torch.isfinite(a['rgb']).all() and torch.isfinite(a['acc']).all()
     assert float(a['acc'].min()) >= 0.0 and float(a['acc'].max()) <= 1.0 + 1e-5 and float(a['rgb'].abs().max()) <= 1.01
     assert torch.equal(a['rgb'], b['rgb']) and torch.equal(a['depth'], b['depth']) and torch.equal(a['acc'], b['acc'])
     sel_i = np.arange(stride // 2, R, stride)
-    sub = G.hip_render(cfg, fx=_subset(fx, sel_i), sp_input=spi, precision=precision)
+    sub = G.hip_render(cfg, fx=_subset(fx, sel_i), sp_input=spi, precision=precision, options=ropts)
     assert torch.equal(sub['rgb'], a['rgb'][sel_i]) and torch.equal(sub['acc'], a['acc'][sel_i])
     h = a if on_gpu else sub
     tag = f'{cfg} ({sel.size} rays of {R})'
@@ -505,9 +508,10 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
     print(f"{cfg}: {R} rays, {sel.size} of them vs oracle: rgb rel err {G.rel(h['rgb'], o['rgb']):.2e}, valid samples {o['valid'].numel()}")
 
 
-@pytest.mark.parametrize('cfg,precision', [('cfg2', 'f16x3'), ('cfg3', 'f16x3'), ('cfg2_ri', 'f16'), ('cfg3_ri', 'f16')])
+@pytest.mark.parametrize('cfg,precision', [('cfg2', 'f16x3'), ('cfg3', 'f16x3'), ('cfg2_ri', 'f16'), ('cfg3_ri', 'f16+enc16'), ('cfg2_dense_ri', 'f16+enc16')])
 def test_full_size_frame_properties(cfg, precision):
     """BASELINE configs 2 and 3: 512 x 512 rays x 64 samples (novel view / novel pose), WHOLE frame through the protocol: the
     adversarial seeded workload (fp32-grade f16x3, which `auto` keeps it on) against the float64 truth; the reference-init workload
-    ("_ri") in the configuration `auto` picks for it -- single fp16 products, fp16 tables -- within 1e-3 of the fp32 oracle outright."""
+    ("_ri") in the configurations `auto` picks from -- single fp16 products, fp16 tables, and ("+enc16": round 4, the headline configuration
+    of bench.py) single-product sparse convolutions as well -- within 1e-3 of the fp32 oracle outright."""
     _full_size_properties(cfg, 15, precision=precision)

@@ -166,7 +166,7 @@ def test_full_size_property_test_plumbing(monkeypatch):
         nv = r['valid'].numel()
         ws = dict(counters=torch.tensor([nv, 0, 0, 0]), cs_idx=r['valid'].int(), cs_vid=r['vert_id'].int(), cs_tvid=r['t_vert_id'].int(),
                   sample_out=torch.cat([r['sample_rgb'], r['sample_sigma'].view(-1, 1)], 1))
-        return dict(rgb=r['rgb'], depth=r['depth'], acc=r['acc'], last=dict(ws=ws, mlp_precision=precision, table_precision='f32' if precision == 'f16x3' else 'f16', encoder_precision='f16x3'), rend=None)
+        return dict(rgb=r['rgb'], depth=r['depth'], acc=r['acc'], last=dict(ws=ws, mlp_precision=precision, table_precision='f32' if precision == 'f16x3' else 'f16', encoder_precision=(options or {}).get('encoder_precision', 'f16x3')), rend=None)
     monkeypatch.setattr(T.G, 'hip_render', fake_render)
     T._full_size_properties('tiny', 7)                                   # subset mode (host build of the kernels)
     T._full_size_properties('tiny_ri', 7, check_stride=5, device='cpu')  # whole-frame mode: the oracle "on the device" + its cross-check

@@ -3,8 +3,6 @@
 import os
 import sys
 
-os.environ['SHERF_ALLOW_BROKEN_ENCODER_F16'] = '1'       # this IS the diagnostic of that mode
-
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
