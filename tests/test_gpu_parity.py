@@ -503,7 +503,7 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
         rep, img = _protocol(o, h, S, truth)
         _assert_truth(tag, rep, img)
     assert rep['valid_ours'] + rep['mask_flips'] >= rep['valid_oracle'] >= rep['valid_ours'] - rep['mask_flips']
-    w = G.hip_render(cfg, sp_input=spi, options=dict(white_back=True), precision=precision)
+    w = G.hip_render(cfg, sp_input=spi, options=dict(white_back=True, **ropts), precision=precision)
     assert torch.allclose(w['rgb'], a['rgb'] + 2 * (1 - a['acc'])[:, None], atol=1e-5)
     print(f"{cfg}: {R} rays, {sel.size} of them vs oracle: rgb rel err {G.rel(h['rgb'], o['rgb']):.2e}, valid samples {o['valid'].numel()}")
 
