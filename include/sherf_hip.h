@@ -99,7 +99,7 @@ int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a
  *        == the order of the reference's boolean-mask indexing (renderer.py:320), found by a two-pass
  *        count / scan / write so it is deterministic and needs no global atomics.
  *   workspace: dense_vid[R*S] int32, ray_mask[R*ceil(S/64)] u64, scan_ws[R + R/1024 + 2] int32 (the last word is the two-pass sampler's
- *   candidate count).  cs_xs doubles as the sampler's candidate list (4 * capacity entries of 4 bytes) before the compaction writes it:
+ *   candidate count).  cs_xs doubles as the sampler's candidate list (capacity records of 16 bytes: x_s + dense index; taken when capacity >= R * S) before the compaction writes it:
  *   its contents on entry are lost.  S <= 256. */
 int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
                          int R, int S, const float* Rg, const float* Th, const float* grid_hdr,

@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(256) sample_nn_kernel(const float* __restrict_
 //   pass 2 (cand_search): the list is walked eight lanes per candidate, 32 candidates per workgroup step, every lane group busy --
 //           the same trimmed 3x3x3 cell walk and the same lexicographic (d^2, vertex id) minimum as above, bit for bit;
 // then ray counts come from the masks' popcounts inside the first scan kernel.  The list lives in cs_xs (written only by the
-// compaction afterwards): 4 * capacity entries, so the path is taken when that provably holds every sample (capacity >= R S / 4).
+// compaction afterwards): `capacity` 16-byte records (x_s, dense index), so the path is taken when that provably holds every sample
+// (capacity >= R S, the default workspace).
 // ---------------------------------------------------------------------------------------------
 constexpr int kMarkRays = 4;          // rays in flight per wave of pass 1
 
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(256) cand_mark_kernel(const float* __restrict_
                                                         const float* __restrict__ near, const float* __restrict__ far, int R, int S,
                                                         const float* __restrict__ Rg, const float* __restrict__ Th,
                                                         const float* __restrict__ hdr, const uint32_t* __restrict__ near_mask,
-                                                        int32_t* __restrict__ cand_list, int64_t list_cap, int32_t* __restrict__ cand_count,
+                                                        float4* __restrict__ cand_list, int64_t list_cap, int32_t* __restrict__ cand_count,
                                                         uint64_t* __restrict__ ray_mask, int dbg) {
     constexpr int RPW = 16 / NCH;                    // rays per wave: a workgroup stages at most 4 * RPW * 64 * NCH = 4096 candidates
     __shared__ int s_list[4096];
@@ -434,9 +435,20 @@ __global__ void __launch_bounds__(256) cand_mark_kernel(const float* __restrict_
     const int n = s_n;
     if (threadIdx.x == 0) s_base = n ? atomicAdd(cand_count, n) : 0;
     __syncthreads();
+    // a candidate's record = (x_s, its dense index): the position is evaluated HERE, one thread per candidate, with the same operations the
+    // search used to repeat in all eight lanes of a group behind two more dependent loads (its list entry, then its ray) -- round 4
     const int64_t gb = s_base;
     for (int i = threadIdx.x; i < n; i += 256)
-        if (gb + i < list_cap) cand_list[gb + i] = s_list[i];
+        if (gb + i < list_cap) {
+            const int idx = s_list[i];
+            const int ray = idx / S, k = idx - ray * S;
+            const float nr1 = near[ray], t = depth_at(nr1, __fsub_rn(far[ray], nr1), k, S);
+            const float x = __fadd_rn(ray_o[ray * 3], __fmul_rn(t, ray_d[ray * 3])), y = __fadd_rn(ray_o[ray * 3 + 1], __fmul_rn(t, ray_d[ray * 3 + 1])),
+                        z = __fadd_rn(ray_o[ray * 3 + 2], __fmul_rn(t, ray_d[ray * 3 + 2]));
+            float xs, ys, zs;
+            to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+            cand_list[gb + i] = make_float4(xs, ys, zs, __int_as_float(idx));
+        }
 }
 
 // candidates in flight per eight-lane group.  Two (every stage's loads issued for both before either is consumed) was measured in round 3:
@@ -445,11 +457,8 @@ __global__ void __launch_bounds__(256) cand_mark_kernel(const float* __restrict_
 constexpr int kSearchU = 1;
 
 template <int NCH>
-__global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restrict__ cand_list, int64_t list_cap,
-                                                          const int32_t* __restrict__ cand_count, const float* __restrict__ ray_o,
-                                                          const float* __restrict__ ray_d, const float* __restrict__ near,
-                                                          const float* __restrict__ far, int S, const float* __restrict__ Rg,
-                                                          const float* __restrict__ Th, const float* __restrict__ hdr,
+__global__ void __launch_bounds__(256) cand_search_kernel(const float4* __restrict__ cand_list, int64_t list_cap,
+                                                          const int32_t* __restrict__ cand_count, int S, const float* __restrict__ hdr,
                                                           const int32_t* __restrict__ cell_start, const float4* __restrict__ cell_pts,
                                                           unsigned long long* __restrict__ ray_mask, int32_t* __restrict__ dense_vid) {
     constexpr int U = kSearchU;
@@ -459,6 +468,13 @@ __global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restr
     const int64_t n = min((int64_t)*cand_count, list_cap);
     const float r = 0.05f + 1e-4f * g.cell;
     const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
+    // the NEXT step's records are requested before this step's dependent chain (cell rows -> points) starts: one round trip off the chain
+    float4 rec_next[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t ci = (int64_t)blockIdx.x * 32 * U + u * 32 + grp;
+        rec_next[u] = cand_list[ci < n ? ci : 0];
+    }
     for (int64_t c0 = (int64_t)blockIdx.x * 32 * U; c0 < n; c0 += (int64_t)gridDim.x * 32 * U) {
         bool live[U];
         int idx[U], ray[U], k[U];
@@ -468,17 +484,12 @@ __global__ void __launch_bounds__(256) cand_search_kernel(const int32_t* __restr
         for (int u = 0; u < U; ++u) {
             const int64_t ci = c0 + u * 32 + grp;
             live[u] = ci < n;
-            idx[u] = live[u] ? cand_list[ci] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+            const float4 rec = rec_next[u];                            // (x_s, dense index): written by cand_mark
+            const int64_t cn = ci + (int64_t)gridDim.x * 32 * U;
+            rec_next[u] = cand_list[cn < n ? cn : 0];
+            xs[u] = rec.x; ys[u] = rec.y; zs[u] = rec.z;
+            idx[u] = live[u] ? __float_as_int(rec.w) : 0;
             ray[u] = idx[u] / S; k[u] = idx[u] - ray[u] * S;
-            const float nr = near[ray[u]], range = __fsub_rn(far[ray[u]], nr);
-            const float t = depth_at(nr, range, k[u], S);
-            const float x = __fadd_rn(ray_o[ray[u] * 3], __fmul_rn(t, ray_d[ray[u] * 3])),
-                        y = __fadd_rn(ray_o[ray[u] * 3 + 1], __fmul_rn(t, ray_d[ray[u] * 3 + 1])),
-                        z = __fadd_rn(ray_o[ray[u] * 3 + 2], __fmul_rn(t, ray_d[ray[u] * 3 + 2]));
-            to_smpl_frame(x, y, z, Rg, Th, xs[u], ys[u], zs[u]);
         }
         // the nine x-contiguous point segments of the 3x3x3 neighbourhood, trimmed to what the 5 cm ball reaches (as in sample_nn_kernel):
         // lane `sub` of the group prepares row `sub`, lane 0 also row 8
@@ -667,6 +678,10 @@ __global__ void __launch_bounds__(256) compact_kernel(const float* __restrict__ 
     if (ray >= R) return;
     int base = ray_base_local[ray] + chunk_off[ray >> 10];
     if (lane == 0) ray_base[ray] = base;
+    uint64_t any = 0;                                  // most rays miss the body: they leave before the eight ray loads
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) any |= ray_mask[(size_t)ray * NCH + ch];
+    if (any == 0) return;
     const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
     const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
     const float nr = near[ray], range = __fsub_rn(far[ray], nr);
@@ -711,7 +726,11 @@ __global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restric
     const float4 xs = cs_xs[c];
     float vx, vy, vz;
     rot_only(ray_d[ray * 3], ray_d[ray * 3 + 1], ray_d[ray * 3 + 2], Rg, vx, vy, vz);   // renderer.py:310
-    const float* P = T2C + (size_t)vid * 12;
+    // (the 3 x 4 affine as three 16-byte loads: rows of 48 bytes are 16-byte aligned; twelve scalar loads were a third of this kernel's
+    //  load instructions, and it is bound by those like the gather -- DESIGN section 5.2)
+    const float4* P4 = reinterpret_cast<const float4*>(T2C) + (size_t)vid * 3;
+    const float4 pa = P4[0], pb = P4[1], pc = P4[2];
+    const float P[12] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w, pc.x, pc.y, pc.z, pc.w};
     float xc = P[0] * xs.x + P[1] * xs.y + P[2] * xs.z + P[9];
     float yc = P[3] * xs.x + P[4] * xs.y + P[5] * xs.z + P[10];
     float zc = P[6] * xs.x + P[7] * xs.y + P[8] * xs.z + P[11];
@@ -723,13 +742,15 @@ __global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restric
     int bid = vid;
     float r = sqrtf(best) * 1.00001f + 1e-6f;
     nn_search_batched(g, tcell_start, tcell_pts, xc, yc, zc, r, best, bid);
-    const float* L = C2S + (size_t)bid * 12;
+    const float4* L4 = reinterpret_cast<const float4*>(C2S) + (size_t)bid * 3;
+    const float4 la = L4[0], lb = L4[1], lc = L4[2];
+    const float L[12] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w};
     float hx = L[0] * xc + L[1] * yc + L[2] * zc + L[9];
     float hy = L[3] * xc + L[4] * yc + L[5] * zc + L[10];
     float hz = L[6] * xc + L[7] * yc + L[8] * zc + L[11];
     float iz = hz + 1e-5f;                                 // renderer.py:699
-    float* o = geom + c * 8;
-    o[0] = xc; o[1] = yc; o[2] = zc; o[3] = ux; o[4] = uy; o[5] = uz; o[6] = hx / iz; o[7] = hy / iz;
+    float4* o = reinterpret_cast<float4*>(geom + c * 8);
+    o[0] = make_float4(xc, yc, zc, ux); o[1] = make_float4(uy, uz, hx / iz, hy / iz);
     cs_tvid[c] = bid;
     }
 }
@@ -783,21 +804,21 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     int32_t* cand_count = scan_ws + R + R / 1024 + 1;      // last word of scan_ws ([R] local bases, [<= R/1024 + 1] chunk sums, this)
     hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters, cand_count);
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
-    // two passes over a dense candidate list (see cand_mark_kernel) whenever the list -- 4 * capacity entries in cs_xs, which the
+    // two passes over a dense candidate list (see cand_mark_kernel) whenever the list -- `capacity` records in cs_xs, which the
     // compaction below only writes afterwards -- provably holds every sample; sherf_set_debug bit 9 forces the one-wave-per-ray kernel
-    const bool two_pass = !(g_sherf_debug & 512) && 4 * capacity >= (int64_t)R * S;
+    const bool two_pass = !(g_sherf_debug & 512) && capacity >= (int64_t)R * S;
     if (two_pass) {
         // the search is a PERSISTENT grid (the candidate count is only known on the device), eight workgroups per CU.  Capping it at six
         // (22 KiB of LDS padding, as sample_nn_kernel below is) to keep wave slots free for the encoder's launches on the other stream
         // was measured and LOST: 1.346 -> 1.381 ms per frame (profiles/r03_bench_d_*.txt) -- the search simply ran longer.
-        int32_t* cand_list = reinterpret_cast<int32_t*>(cs_xs);
-        const int64_t list_cap = 4 * capacity;
+        float4* cand_list = reinterpret_cast<float4*>(cs_xs);            // one 16-byte record per candidate: the list holds `capacity` of them
+        const int64_t list_cap = capacity;
         unsigned long long* rm = reinterpret_cast<unsigned long long*>(ray_mask);
 #define SHERF_TWO_PASS(N)                                                                                                          \
         hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
                            grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
-        hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, ray_o, ray_d,   \
-                           near, far, S, Rg, Th, grid_hdr, cell_start, cp, rm, dense_vid);                                         \
+        hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S,              \
+                           grid_hdr, cell_start, cp, rm, dense_vid);                                                               \
         hipLaunchKernelGGL(scan_chunk_mask_kernel<N>, dim3(n_chunks), dim3(1024), 0, st, ray_mask, R, ray_cnt, base_local, chunk_sum)
         if (nch == 1) { SHERF_TWO_PASS(1); } else if (nch == 2) { SHERF_TWO_PASS(2); } else if (nch == 3) { SHERF_TWO_PASS(3); } else { SHERF_TWO_PASS(4); }
 #undef SHERF_TWO_PASS
