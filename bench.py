@@ -313,6 +313,8 @@ def main():
                          'frame: the "reference single-GPU render()" denominator SURVEY.md section 8(d) asks for beside the CPU one, and '
                          'the source of the `parity` entry (N = 1 only; runs in a child process after the measurement)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the bf16 kernel line and the cfg3 / cfg2_dense frame timings (N = 1 only)')
+    ap.add_argument('--no-train', action='store_true', help='skip the `train` entry: bench_train.py (BASELINE config 5: forward + backward through the HIP '
+                                                            'kernels + flat-gradient exchange + Adam) run for a few steps in a child process (N = 1 only)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1 only)')
     ap.add_argument('--exact-grids', action='store_true',
                     help='size the launches behind the compaction by the frame\'s own sample count (one host wait per frame: sherf_hip.h)')
@@ -487,6 +489,8 @@ def main():
             lw = rend.last['ws']
             ours = dict(tile=tile, cs_idx=lw['cs_idx'][:nv].cpu(), cs_vid=lw['cs_vid'][:nv].cpu(), cs_tvid=lw['cs_tvid'][:nv].cpu(),
                         sample_out=lw['sample_out'][:nv].cpu())
+        if world == 1 and not a.no_train and not a.no_secondary and not os.environ.get('SHERF_HIPCPU_LIB'):
+            res['train'] = train_step_child(lrank)
         if not a.no_cpu_baseline and world == 1:            # reported at N = 1 only (rank 0's host cores)
             res['cpu_baseline'] = cpu_baseline(a.config)
         if world == 1 and not a.no_pmc and 'roofline' in res:
@@ -591,6 +595,25 @@ def frame_parity(ours, ref, S, plain=False):
         ok = ok and out['plain_ok']
     out['ok'] = bool(ok)
     return out
+
+
+def train_step_child(lrank, timeout=240):
+    """BASELINE config 5 beside the render metric: bench_train.py (one view, forward + backward through the HIP kernels + the reference's
+    flat-gradient exchange + Adam, training_loop.py:354-386) for a few steps in a child process -> its JSON line (ms per step, phases,
+    the roofline of its dominant kernel), so that the driver's bench run times the training step too."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['LOCAL_RANK'] = str(lrank)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_train.py'), '--steps', '4', '--warmup', '2'], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=timeout, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if not line:
+            return dict(error=f'child rc={r.returncode}: {r.stderr.strip()[-300:]}')
+        d = json.loads(line[-1])
+        return {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'phases_ms', 'host_ms', 'roofline', 'dtype', 'config', 'final_loss')}
+    except Exception as ex:
+        return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
 
 
 def torch_gpu_baseline_child(a, lrank, timeout=300, save=None):
