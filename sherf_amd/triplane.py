@@ -76,7 +76,9 @@ class TriPlaneGenerator(nn.Module):
         self._last_planes = None
         # vertex features + voxelisation as two HIP launches (csrc/glue.hip) instead of ~40 tensor ops, when no
         # gradient is being recorded (training keeps the tensor-op glue so that autograd reaches the image encoders)
-        self.fused_glue = os.environ.get('SHERF_FUSED_GLUE', '0') == '1'
+        # the per-frame glue (triplane.py:105-137, 174-217) as two HIP launches whenever no gradient is recorded (csrc/glue.hip; checked on the
+        # MI355X against the unmodified reference's glue outputs, tests/test_gpu_glue.py): the default since round 4
+        self.fused_glue = os.environ.get('SHERF_FUSED_GLUE', '1') == '1'
 
     def mapping(self, z, c, input_img=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         z = self.encoder_2d(input_img)

@@ -261,8 +261,9 @@ def test_generator_glue(cpu_product):
 
 
 def check_fused_glue():
-    """csrc/glue.hip (sherf_vertex_features, sherf_voxelize: SURVEY 8f rank 1) against the tensor-op glue it replaces at inference time and,
-    through it, the oracle: same culled vertices, features to 1e-5, identical voxel coordinates / shape / bounds, identical image."""
+    """csrc/glue.hip (sherf_vertex_features, sherf_voxelize: SURVEY 8f rank 1) against the unmodified reference's glue outputs (golden),
+    the oracle's voxelisation, and the tensor-op glue it replaces at inference time: same culled vertices, features to 1e-5, identical
+    voxel coordinates / shape / bounds, identical image."""
     fx = dict(G.fixture('tiny'))
     gen = P._generator(fx)
     d = G.to_cuda(fx['input_data'])
@@ -274,6 +275,14 @@ def check_fused_glue():
         s_ref, _ = gen.prepare_sp_input(d['t_vertices'].float(), can)
         s_hip, _ = gen.fused_prepare_sp_input(d['t_vertices'].float(), can)
     m_ref, m_hip = G.plain(m_ref), G.plain(m_hip)
+    # directly against the UNMODIFIED reference's own glue (tests/golden/glue_tiny.npz, oracle/make_golden.py: triplane.py:105-126) and the
+    # oracle's voxelisation (pinned to the reference by renderer_tiny.npz) -- not only against our tensor-op glue
+    gold = np.load(os.path.join(G.GOLDEN, 'glue_tiny.npz'))
+    g_same = torch.from_numpy(gold['front_mask']) == m_hip[0]
+    assert float((~g_same).float().mean()) < 2e-3                               # grazing vertices: the sign of a ~0 dot product
+    assert G.rel(G.plain(f_hip)[0][g_same], torch.from_numpy(gold['vertex_feat'])[g_same]) < 1e-4
+    o_sp = G.oracle_render('tiny')['sp_input']
+    assert s_hip['out_sh'] == o_sp['out_sh'] and float((G.plain(s_hip['coord']) != o_sp['coord']).any(1).float().mean()) < 2e-3
     same = m_ref == m_hip
     assert tuple(m_hip.shape) == (1, 6890) and m_hip.dtype == torch.bool and float((~same).float().mean()) < 5e-4      # (dot products ~ 0)
     assert float((G.plain(f_hip) - G.plain(f_ref))[same].abs().max()) < 1e-5 * max(1.0, float(G.plain(f_ref).abs().max()))
