@@ -646,15 +646,24 @@ def stub_loss(rgb, acc):
     """BASELINE config 5's stub training loss: MSE(rgb, T_rgb) + MSE(acc, T_acc) with seeded targets
     (RandomState(11): rgb target first, then acc, as in make_golden.loss_targets).  rgb [R,3], acc [R]."""
     rs = np.random.RandomState(11)
-    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1,) + tuple(rgb.shape)).astype(np.float32))[0]
-    t_acc = torch.from_numpy(rs.uniform(0, 1, (1,) + tuple(acc.shape) + (1,)).astype(np.float32))[0, :, 0]
+    t_rgb = torch.from_numpy(rs.uniform(-1, 1, (1,) + tuple(rgb.shape)).astype(np.float32))[0].to(rgb.device)
+    t_acc = torch.from_numpy(rs.uniform(0, 1, (1,) + tuple(acc.shape) + (1,)).astype(np.float32))[0, :, 0].to(acc.device)
     return ((rgb - t_rgb) ** 2).mean() + ((acc - t_acc) ** 2).mean()
 
 
 STAGE_KEYS = ('sample_rgb', 'sample_sigma', 'tokens_out', 'tokens_in', 'f2d', 'f3d', 'f3d_raw')
 
 
-def gradients_from_fixture(fx, state, stages=False):
+def gradients_from_fixture(fx, state, stages=False, device=None, info=None):
+    """info: an optional dict that receives 'sp_input' (the voxelisation the graph used).  device: None = CPU (the oracle proper); a GPU device runs the SAME autograd graph through stock PyTorch-ROCm ops there (the
+    full-size gradient check of tests/test_gpu_backward.py: 512 x 512 x 64 takes seconds instead of the CPU's hours)."""
+    if device is not None:
+        with torch.device(device):
+            return _gradients_from_fixture(fx, {k: v.to(device) for k, v in state.items()}, stages, torch.device(device), info)
+    return _gradients_from_fixture(fx, state, stages, None, info)
+
+
+def _gradients_from_fixture(fx, state, stages, device, info=None):
     """Backward of the path by autograd through this restatement (training-mode BatchNorm): returns (loss, {name: grad})
     for every renderer / decoder parameter that receives one and for the three feature inputs
     ('input.planes', 'input.obs_feat', 'input.vertex_feat').  The oracle for the HIP backward kernels (BASELINE config 5).
@@ -666,9 +675,10 @@ def gradients_from_fixture(fx, state, stages=False):
     st = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
     fx = dict(fx)
     leaves = {}
+    mv = lambda t: t if device is None else t.to(device)
     for key, name in (('planes', 'input.planes'), ('obs_feat', 'input.obs_feat'), ('vertex_feat', 'input.vertex_feat')):
-        leaves[name] = torch.from_numpy(np.ascontiguousarray(fx[key])).requires_grad_(True)
-    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        leaves[name] = mv(torch.from_numpy(np.ascontiguousarray(fx[key]))).requires_grad_(True)
+    to = lambda a: mv(torch.from_numpy(np.ascontiguousarray(a))) if isinstance(a, np.ndarray) else (mv(a) if torch.is_tensor(a) else a)
     d = {k: ({kk: to(vv) for kk, vv in v.items()} if isinstance(v, dict) else to(v)) for k, v in fx['input_data'].items()}
     smpl = smpl_tensors(fx['smpl'])
     OP = d['obs_params']
@@ -677,6 +687,8 @@ def gradients_from_fixture(fx, state, stages=False):
         _, ovid = nearest_vertex(obs_s, obs_s)
         obs_can, _ = target_to_canonical(smpl, OP, d['t_params'], obs_s, obs_s, None, ovid)
     sp_input = prepare_sp_input(d['t_vertices'].view(-1, 3), obs_can)
+    if info is not None:
+        info['sp_input'] = sp_input
     res = render(st, smpl, leaves['input.planes'][0], d['obs_img_all'][0, 0], leaves['input.obs_feat'][0], leaves['input.vertex_feat'],
                  sp_input, d['ray_o_all'][0, 0], d['ray_d_all'][0, 0], d['near_all'][0, 0, :, 0], d['far_all'][0, 0, :, 0], d,
                  fx['options'], training=True, keep=stages)

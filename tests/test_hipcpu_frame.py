@@ -460,6 +460,15 @@ def test_config1_and_per_sample_precision(cpu_product):
     P.test_margin_protocol_whole_frame('cfg1_ri')           # reference-init network: within 1e-3 of the oracle outright
 
 
+def test_full_size_backward_check_plumbing(cpu_product, monkeypatch):
+    """tests/test_gpu_backward.py::test_full_size_backward_against_oracle_autograd's own procedure (oracle autograd on a device, two
+    HIP backward runs on fresh modules, per-gradient relative error + run-to-run spread) on the host build at the tiny size."""
+    from tests import test_gpu_backward as GB
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    worst, spread = GB._full_size_backward('tiny_ri', 'cpu')
+    assert max(spread.values()) < 1e-4 and len(worst) >= 81  # (the host build's threads reorder the float atomics too: ~3e-6)
+
+
 def test_training_step_through_autograd_matches_reference_gradients(cpu_product, monkeypatch):
     """BASELINE config 5 on the CPU: forward recorded as ONE autograd node (renderer.enable_autograd), stub loss,
     loss.backward() through the native backward pipeline; gradients against the fingerprints of the UNMODIFIED reference's
