@@ -60,6 +60,15 @@ def test_whole_generator_with_its_own_producers_on_device():
     check_whole_generator()
 
 
+def test_snapshot_and_training_step_against_reference_golden_on_device(monkeypatch):
+    """SURVEY 8(f) ranks 3 + 4 on the MI355X against the UNMODIFIED reference's own snapshot / `accumulate_gradients` outputs
+    (tests/golden/trainstep_tiny_nv.npz; oracle/make_golden_trainstep.py): names / shapes / values of the snapshot contract, the frame the
+    reference renders from its snapshot, our pickled snapshot resuming to the same bits, the six loss terms and all 240 gradient
+    fingerprints of one generator step."""
+    from tests.test_hipcpu_frame import check_snapshot_and_training_step_against_reference_golden
+    check_snapshot_and_training_step_against_reference_golden(monkeypatch)
+
+
 def test_reconstruction_loss_and_weight_update_on_device():
     """loss.py:103-176 + training_loop.py:365-383 on the GPU: the same terms and the same SGD step as the CPU run of the identical
     stub generator (tests/test_loss.py)."""

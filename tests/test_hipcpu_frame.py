@@ -379,6 +379,136 @@ def check_whole_generator():
     assert G.rel(G.plain(out['weights_image']).reshape(-1), o['acc']) < 2e-3
 
 
+def check_snapshot_and_training_step_against_reference_golden(monkeypatch):
+    """SURVEY 8(f) ranks 3 + 4 against the UNMODIFIED reference's own outputs (tests/golden/trainstep_tiny_nv.npz, written by
+    oracle/make_golden_trainstep.py from `training.triplane.TriPlaneGenerator`, its persistence and `StyleGAN2Loss.accumulate_gradients`):
+
+      f4  sherf_amd's generator exposes the reference snapshot's names / shapes (all but the unused super-resolution head) (`copy_params_and_buffers(require_all=True)`),
+          takes the same values by name, renders the frame the reference rendered from its snapshot, and a pickled snapshot of it resumes
+          into a differently initialised generator to the same bits;
+      f3  one generator step (sherf_amd.loss: loss.py:103-176 + training_loop.py:365-383) returns the reference's loss terms and, for every
+          one of its 240 parameter gradients, the reference's fingerprint.
+
+    Shared by the host-build test below and tests/test_gpu_producers.py (the MI355X)."""
+    import copy
+    import io
+    import pickle
+    import sys
+    from oracle import make_golden_trainstep as MG
+    from sherf_amd import loss as L
+    from sherf_amd import triplane as TP
+    ref = np.load(os.path.join(G.GOLDEN, f'trainstep_{MG.CFG}.npz'))
+    fx = dict(G.fixture(MG.CFG))
+    normals = G.dev_tensor(torch.from_numpy(ref['normals']))
+    monkeypatch.setattr(TP, 'compute_normal', lambda vertices, faces: normals)     # the reference's ill-defined normals, as it computed them
+
+    def build(seed):
+        torch.manual_seed(seed)
+        kw = MG.gen_kwargs(fx['options'])
+        gen = TP.TriPlaneGenerator(kw.pop('z_dim'), kw.pop('c_dim'), kw.pop('w_dim'), True, True, True, True, True, smpl=G.smpl(),
+                                   **{k: v for k, v in kw.items() if not k.startswith('use_')})
+        gen.fused_glue = False                                                      # (the fused glue derives its own normals: tests/test_gpu_glue.py)
+        return gen
+
+    gen = build(0)
+    MG.load_whole_generator_state(gen)
+    named = list(gen.named_parameters()) + list(gen.named_buffers())
+    ours = {n: 'x'.join(str(int(x)) for x in t.shape) for n, t in named}
+    # (the 2x super-resolution head is the one module this package does not carry: every SHERF script runs --use_sr_module False, its
+    #  entries of a reference snapshot are simply not consumed; everything else must be there under the same name and shape)
+    keep = [i for i, n in enumerate(ref['names'].tolist()) if not n.startswith('superresolution.')]
+    theirs = {ref['names'][i].item(): ref['shapes'][i].item() for i in keep}
+    assert ours == theirs, sorted(set(ours.items()) ^ set(theirs.items()))[:6]
+    assert sorted(n for n, _ in gen.named_parameters()) == sorted(ref['names'][i].item() for i in keep if ref['is_param'][i])   # (parameter vs buffer)
+    l2 = {ref['names'][i].item(): float(ref['state_l2'][i]) for i in keep}
+    for n, t in named:
+        assert abs(float(t.detach().double().norm()) - l2[n]) <= 1e-6 * max(1.0, l2[n]), n
+    gen = G.dev_module(gen)
+    d = G.to_cuda(MG.batch(fx))
+    d['mask_at_box_all'] = G.plain(d['mask_at_box_all']).bool() if G.CPU_SHIM else d['mask_at_box_all'].bool()
+    z, c0 = G.dev_tensor(torch.zeros(1, 512)), G.dev_tensor(torch.zeros(1, 0))
+
+    def render(g):
+        g.eval(); g.renderer.train(); g.decoder.train()
+        g.renderer.enable_autograd = False
+        with torch.no_grad():
+            out = g(d, z, c0, use_sr_module=False, noise_mode='const')
+        return {k: G.plain(v) for k, v in out.items() if torch.is_tensor(v)}
+
+    snap = copy.deepcopy(gen)                                                       # before the render moves the running statistics
+    a = render(gen)
+    img_ref = torch.from_numpy(ref['image_raw'])
+    assert O.psnr(a['image_raw'], img_ref) > 50.0, O.psnr(a['image_raw'], img_ref)
+    assert G.rel(a['image_raw'], img_ref) < 2e-3 and G.rel(a['weights_image'], torch.from_numpy(ref['weights_image'])) < 2e-3
+    # our snapshot, written as training_loop.py:563-579 writes it, resumes to the same bits
+    buf = io.BytesIO()
+    pickle.dump(dict(G=copy.deepcopy(snap).eval().requires_grad_(False).cpu(), G_ema=None), buf)
+    buf.seek(0)
+    data = pickle.load(buf)
+    gen2 = build(1)
+    with torch.no_grad():                                                           # misc.copy_params_and_buffers(require_all=True)
+        src = dict(list(data['G'].named_parameters()) + list(data['G'].named_buffers()))
+        for n, t in list(gen2.named_parameters()) + list(gen2.named_buffers()):
+            t.copy_(src[n].detach())
+    gen2 = G.dev_module(gen2)
+    b = render(gen2)
+    assert torch.equal(a['image_raw'], b['image_raw']) and torch.equal(a['weights_image'], b['weights_image'])
+
+    # ---- f3 ----
+    sys.path.insert(0, os.path.join(G.ROOT, 'oracle', 'ref_shims'))
+    try:
+        import lpips as lpips_stand_in                                              # the SAME stand-in the golden run drove the reference's loss with
+    finally:
+        sys.path.pop(0)
+    gen3 = build(2)
+    with torch.no_grad():
+        for n, t in list(gen3.named_parameters()) + list(gen3.named_buffers()):
+            t.copy_(src[n].detach())
+    gen3 = G.dev_module(gen3)
+    gen3.eval(); gen3.renderer.train(); gen3.decoder.train()
+    gen3.renderer.enable_autograd = True
+    H, W = d['obs_img_all'].shape[-2:]
+    lp = lpips_stand_in.LPIPS()
+    loss = L.ReconstructionLoss(torch.device('cpu') if G.CPU_SHIM else torch.device('cuda'), gen3, lpips_fn=lambda x, y: lp(x, y).reshape(-1),
+                                neural_rendering_resolution_initial=max(H, W))
+    opt = torch.optim.Adam([p for p in gen3.parameters()], lr=2e-4, betas=(0.0, 0.99), eps=1e-8)
+    grads = {}
+    orig_update = L.update_weights
+
+    def update(module, opt_, num_gpus=None, scheduler=None):                        # the gradients as the optimiser sees them (after sanitising)
+        sdist_params = [p for p in module.parameters() if p.numel() > 0]
+        L.sdist.allreduce_flat_grads(sdist_params, world_size=num_gpus)
+        grads.update({n: G.plain(p.grad.detach()).clone() for n, p in module.named_parameters() if p.grad is not None})
+        opt_.step()
+    monkeypatch.setattr(L, 'update_weights', update)
+    out = L.training_step(gen3, opt, loss, d, z, G.dev_tensor(torch.zeros(1, 25)), gain=1, num_gpus=1, use_sr_module=False)
+    monkeypatch.setattr(L, 'update_weights', orig_update)
+    terms = [float(G.plain(t.detach()).reshape(-1)[0]) for t in out]
+    for x, y in zip(terms, ref['loss_terms']):
+        assert abs(x - y) <= 2e-4 * max(1.0, abs(y)), (terms, ref['loss_terms'].tolist())
+    assert sorted(grads) == ref['grad_names'].tolist(), sorted(set(grads) ^ set(ref['grad_names'].tolist()))[:6]
+    worst = {}
+    for n in grads:
+        f, r = O.grad_fingerprint(grads[n].float()), ref['grad.' + n]
+        worst[n] = (abs(f[2] - r[2]) / (r[2] + 1e-30), float(np.linalg.norm(f[3:] - r[3:]) / (np.linalg.norm(r[3:]) + 1e-30)), r[2])
+    top = sorted(((v[0], v[1], n) for n, v in worst.items() if v[2] > 1e-9), reverse=True)[:5]
+    print(f'training step vs the reference: loss terms {terms} vs {ref["loss_terms"].tolist()}; {len(grads)} gradients, worst (norm, samples) {top}')
+    enc = lambda k: 'encoder_3d' in k
+    for n, (en, es, nr) in worst.items():
+        if nr <= 1e-9:
+            continue
+        # (sparse-encoder entries: ill-conditioned on this fixture -- an activation at the ReLU kink, see tests/test_gpu_backward.py)
+        assert en < (0.15 if enc(n) else 1e-2) and es < (0.15 if enc(n) else 2e-2), (n, en, es)
+    return terms, worst
+
+
+def test_snapshot_and_training_step_against_reference_golden(cpu_product, monkeypatch):
+    from sherf_amd.renderer import ImportanceRenderer
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    monkeypatch.setattr(ImportanceRenderer, '_side', lambda self, dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})())
+    check_snapshot_and_training_step_against_reference_golden(monkeypatch)
+
+
 def test_whole_generator_with_its_own_producers(cpu_product, monkeypatch):
     monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))       # module parameters are "device" tensors too
     check_whole_generator()
