@@ -472,7 +472,9 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
             # (two fp32 evaluation orders of the same function: 1e-4 on the well-conditioned variant; the adversarial one amplifies
             #  them to the level the truth protocol below measures)
             xtol = 1e-4 if fixtures.variant_of(cfg) == 'ri' else 3e-3
-            assert G.rel(o['sample_rgb'][rows], oc['sample_rgb']) < xtol and G.rel(torch.relu(o['sample_sigma'][rows]), torch.relu(oc['sample_sigma'])) < xtol
+            same = o['t_vert_id'][rows] == oc['t_vert_id']      # (a T-vertex tie the two runs break differently warps that ONE sample elsewhere)
+            assert G.rel(o['sample_rgb'][rows][same], oc['sample_rgb'][same]) < xtol
+            assert G.rel(torch.relu(o['sample_sigma'][rows][same]), torch.relu(oc['sample_sigma'][same])) < xtol
         assert G.rel(o['rgb'][sel_c], oc['rgb']) < 1e-4 if fixtures.variant_of(cfg) == 'ri' else 1e-3
         sel, fx_sub = np.arange(R), fx
     else:                                                           # host build of the kernels: a strided subset only
