@@ -465,6 +465,7 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
         oc = O.render_from_fixture(_subset(fx_m, sel_c), state, training=True, keep=False)
         m_dev = o['mask'].view(R, S)[sel_c].reshape(-1)
         assert int((m_dev != oc['mask']).sum()) <= 2
+        xtol = 1e-4 if fixtures.variant_of(cfg) == 'ri' else 3e-3
         if torch.equal(m_dev, oc['mask']):
             dense = (torch.as_tensor(sel_c)[:, None] * S + torch.arange(S)[None]).reshape(-1)[oc['mask']]
             rows = (torch.cumsum(o['mask'].long(), 0) - 1)[dense]                # the same samples in the whole-frame run
@@ -475,7 +476,10 @@ def _full_size_properties(cfg, stride, check_stride=97, device=None, precision='
             same = o['t_vert_id'][rows] == oc['t_vert_id']      # (a T-vertex tie the two runs break differently warps that ONE sample elsewhere)
             assert G.rel(o['sample_rgb'][rows][same], oc['sample_rgb'][same]) < xtol
             assert G.rel(torch.relu(o['sample_sigma'][rows][same]), torch.relu(oc['sample_sigma'][same])) < xtol
-        assert G.rel(o['rgb'][sel_c], oc['rgb']) < 1e-4 if fixtures.variant_of(cfg) == 'ri' else 1e-3
+        ok_ray = torch.ones(len(sel_c), dtype=torch.bool)
+        if torch.equal(m_dev, oc['mask']):
+            ok_ray[(dense[~same] // S - sel_c[0]) // check_stride] = False      # the ray of such a sample
+        assert G.rel(o['rgb'][sel_c][ok_ray], oc['rgb'][ok_ray]) < xtol
         sel, fx_sub = np.arange(R), fx
     else:                                                           # host build of the kernels: a strided subset only
         sel = np.arange(stride // 2, R, stride)
