@@ -140,7 +140,8 @@ int sherf_gather_tokens(const int32_t* counters, const float* geom, const float*
  * issued unconditionally (absent corners read row 0 with weight 0) instead of under one branch per corner -- same sums, a schedule
  * variant (opt-in, rendering_options['gather_branchless']); `mode | 12`: the same compiled for 4 waves / SIMD (128 VGPRs instead of 160).
  * `mode | 16`: planes_f, feat_f and the levels' rows hold fp16 (sherf_fold_tables(out_half), SHERF_FRAME_HALF_TABLES); img4, the
- * arithmetic and the tokens stay fp32. */
+ * arithmetic and the tokens stay fp32.  `mode | part << 8 | nparts << 16` (nparts 2..255): only part `part` of the tile list cut into
+ * `nparts` contiguous parts (see sherf_nerf_mlp_part). */
 
 /* Per-frame re-layout NCHW -> channel-last with a 32x32 projection per texel (the linear part of
  * conv1d_reprojection, renderer.py:423-424, commuted with the interpolation):
@@ -182,6 +183,11 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* sherf_nerf_mlp on ONE contiguous part of the tile list: the compact tiles are cut into `nparts` parts at multiples of 8 tiles (256
+ * samples; the cut is computed on the device from counters[0]) and this launch runs part `part` -- so that part k's network can run on
+ * one stream beside part k + 1's sherf_gather_tokens (`mode | part << 8 | nparts << 16`: the same cut) on another.  nparts <= 1: everything. */
+int sherf_nerf_mlp_part(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                        const float* wbias, int prec, int64_t capacity, float* out, int part, int nparts, sherf_stream_t stream);
 /* The same network as TWO launches (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel), results bit-identical to sherf_nerf_mlp:
  * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS;
  * launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  zfrag: scratch for the fused tokens,
@@ -362,7 +368,7 @@ typedef struct {
     /* voxel encoder (a11) */
     const sherf_svox_plan* vox_plan; const int32_t* vox_coord; const float* vox_feat; int32_t vox_n, vox_training;
     /* MLP + compositing (a13-a16) */
-    const void* wstream; const float* wbias; int32_t mlp_prec, mlp_pad_; float* sample_out;
+    const void* wstream; const float* wbias; int32_t mlp_prec, mlp_parts; float* sample_out;   /* mlp_parts 2..8: gather + network in that many parts on two streams (sherf_nerf_mlp_part); 0, 1: whole */
     int32_t white_back;
     int32_t main_after_layer;   /* scheduling: -1 = both streams start at once; k >= 0 = the ray side starts once encoder
                                  * layer k is done (the encoder's small launches are slowed 3-5x by a co-running sampler) */

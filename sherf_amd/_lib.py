@@ -63,7 +63,7 @@ def _frame_fields():
     P('geom', 'cs_tvid', 'tok_bias', 'bounds', 'vox_min')
     f.append(('vox_sh', _i32 * 3)); I('gather_split')
     P('tokens', 'extras', 'vox_plan', 'vox_coord', 'vox_feat'); I('vox_n', 'vox_training')
-    P('wstream', 'wbias'); I('mlp_prec', 'mlp_pad_')
+    P('wstream', 'wbias'); I('mlp_prec', 'mlp_parts')
     P('sample_out'); I('white_back', 'main_after_layer')
     P('rgb', 'depth', 'acc', 'zfrag')
     return f

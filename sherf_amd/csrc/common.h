@@ -146,3 +146,15 @@ __device__ __forceinline__ void nn_search_batched(const CellGrid& g, const int32
 // order-preserving float <-> int map for atomicMin/atomicMax on floats of any sign
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// A frame's compact tiles cut into `nparts` contiguous parts (whole groups of 8 tiles = 256 samples: an MLP workgroup's four tiles and the
+// gather's tile pairs never straddle a boundary), so that the gather of part k + 1 and the MLP of part k can be in flight together on
+// two streams (csrc/frame.hip).  nparts <= 1: the whole range.
+__device__ __forceinline__ void sherf_part_range(int64_t n_tiles, int part, int nparts, int64_t& lo, int64_t& hi) {
+    if (nparts <= 1) { lo = 0; hi = n_tiles; return; }
+    const int64_t units = (n_tiles + 7) / 8;
+    lo = units * part / nparts * 8;
+    hi = units * (part + 1) / nparts * 8;
+    if (hi > n_tiles) hi = n_tiles;
+    if (lo > hi) lo = hi;
+}

@@ -7,6 +7,7 @@
 // compositing (main).
 #include "common.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <functional>
@@ -20,10 +21,11 @@ namespace {
 
 constexpr int kMaxDev = 16;
 constexpr int kRing = 64;
+constexpr int kMaxParts = 8;
 
 struct DevState {
     bool init = false;
-    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8], ev_cnt;
+    hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8], ev_cnt, ev_part[kMaxParts], ev_mlp;
     int32_t* host_nv = nullptr;      // pinned: the frame's valid-sample count for SHERF_FRAME_EXACT_GRIDS
 };
 DevState g_dev[kMaxDev];
@@ -104,6 +106,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_fold, hipEventDisableTiming));
                 for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_cnt, hipEventDisableTiming));
+                for (int k = 0; k < kMaxParts; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_part[k], hipEventDisableTiming));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mlp, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d.host_nv), 64, 0));
                 d.init = true;
             }
@@ -194,6 +198,27 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                   f->cs_tvid, stream_main));
         const int gv = ((f->gather_split & 2) ? 4 : 0) | ((f->gather_split & 4) ? 12 : 0) |  // bit 1: branchless voxel-row loads (mode | 4); bit 2: in 128 VGPRs (mode | 12)
                        (half_tables ? 16 : 0);                                                // mode | 16: fp16 tables
+        // Gather and MLP in `nparts` contiguous parts of the tile list, part k's MLP (matrix pipe) on the side stream beside part k + 1's
+        // gather (texture addresser) on the main one: the two kernels are bound by different units of the CU (frame->mlp_parts).
+        const int nparts = std::min(((g_sherf_debug >> 16) & 15) ? ((g_sherf_debug >> 16) & 15) : f->mlp_parts, kMaxParts);   // (debug bits 16-19 override: A/B runs)
+        const bool split_form = f->zfrag && (((f->flags & SHERF_FRAME_MLP_SPLIT) != 0) != ((g_sherf_debug & 8192) != 0));
+        if (nparts > 1 && !(f->gather_split & 1) && !split_form) {
+            SHERF_PROF(3, main);
+            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
+            for (int k = 0; k < nparts; ++k) {
+                SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
+                                              levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv | (k << 8) | (nparts << 16), cap,
+                                              f->tokens, f->extras, stream_main));
+                SHERF_HIP_CHECK(hipEventRecord(d.ev_part[k], main));
+                SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_part[k], 0));
+                SHERF_RUN(sherf_nerf_mlp_part(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, k, nparts,
+                                              stream_side));
+            }
+            SHERF_PROF(4, main);
+            SHERF_HIP_CHECK(hipEventRecord(d.ev_mlp, side));
+            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_mlp, 0));
+            SHERF_PROF(5, main);
+        } else {
         if (f->gather_split & 1) {      // tri-plane + pixel taps do not need the encoder: run them while it is still busy
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           nullptr, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 1 | gv, cap, f->tokens,
@@ -220,6 +245,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,
                                      f->sample_out, stream_main));
         SHERF_PROF(5, main);
+        }
     }
     if (phase & 2) {
         // ---- a15-a16 ----

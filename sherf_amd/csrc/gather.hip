@@ -50,7 +50,10 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
                                                             const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
                                                             float4* __restrict__ tokens, float* __restrict__ extras, int dbg, int mode) {
     const int64_t nv = min((int64_t)counters[0], capacity);
-    const int64_t n_tiles = (nv + 31) / 32;
+    int64_t t_lo, n_tiles;                          // this launch's part of the tiles (mode bits 8-15: part, 16-23: number of parts)
+    sherf_part_range((nv + 31) / 32, (mode >> 8) & 255, (mode >> 16) & 255, t_lo, n_tiles);
+    n_tiles -= t_lo;
+    mode &= 255;
     const int l = threadIdx.x & 7;                 // channel quad within a slot
     const int j = threadIdx.x >> 3;                // sample within the tile (0..31)
     // XCD-banded tile order (dbg bit 10 turns it off): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each with its own 4 MiB L2,
@@ -60,8 +63,9 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
     const bool banded = !(dbg & 1024) && gridDim.x % 8 == 0;
     const int64_t per_xcd = (n_tiles + 7) / 8, slots = gridDim.x / 8;
     for (int64_t it = banded ? blockIdx.x / 8 : blockIdx.x; it < (banded ? per_xcd : n_tiles); it += banded ? slots : gridDim.x) {
-        const int64_t tile = banded ? (int64_t)(blockIdx.x % 8) * per_xcd + it : it;
+        int64_t tile = banded ? (int64_t)(blockIdx.x % 8) * per_xcd + it : it;
         if (tile >= n_tiles) break;
+        tile += t_lo;
         const int64_t c = tile * 32 + j;
         float4 acc[3];
         if (mode == 2) acc[0] = acc[1] = acc[2] = make_float4(0.f, 0.f, 0.f, 0.f);     // voxel pass adds onto the stored tokens
@@ -233,7 +237,10 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
                                                                const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
                                                                float4* __restrict__ tokens, float* __restrict__ extras, int dbg, int mode) {
     const int64_t nv = min((int64_t)counters[0], capacity);
-    const int64_t n_tiles = (nv + 31) / 32, n_pairs = (n_tiles + 1) / 2;       // a workgroup step = two tiles = 64 samples
+    int64_t t_lo, t_hi;                             // this launch's part of the tiles (mode bits 8-15: part, 16-23: number of parts)
+    sherf_part_range((nv + 31) / 32, (mode >> 8) & 255, (mode >> 16) & 255, t_lo, t_hi);
+    mode &= 255;
+    const int64_t n_tiles = t_hi - t_lo, n_pairs = (n_tiles + 1) / 2;          // a workgroup step = two tiles = 64 samples (t_lo is even)
     const int l = threadIdx.x & 3;                 // channel octet within a slot (quads 2l, 2l + 1)
     const int js = threadIdx.x >> 2;               // sample within the pair of tiles (0..63)
     const bool banded = !(dbg & 1024) && gridDim.x % 8 == 0;                  // XCD-banded order, as in gather_tokens_kernel
@@ -241,9 +248,10 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
     for (int64_t it = banded ? blockIdx.x / 8 : blockIdx.x; it < (banded ? per_xcd : n_pairs); it += banded ? slots : gridDim.x) {
         const int64_t pair = banded ? (int64_t)(blockIdx.x % 8) * per_xcd + it : it;
         if (pair >= n_pairs) break;
-        const int64_t tile = pair * 2 + (js >> 5);
+        int64_t tile = pair * 2 + (js >> 5);
         const int j = js & 31;
         if (tile >= n_tiles) continue;
+        tile += t_lo;
         const int64_t c = tile * 32 + j;
         f8 acc[3];
         if (mode == 2) { for (int s_ = 0; s_ < 3; ++s_) acc[s_].a = acc[s_].b = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -786,6 +794,8 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
     const bool branchless = (mode & 4) != 0 || SHERF_GATHER_BRANCHLESS;
     const bool squeezed = branchless && (mode & 8) != 0;
     const bool half_tables = (mode & 16) != 0;
+    const int part = (mode >> 8) & 255, nparts = (mode >> 16) & 255;       // a contiguous part of the tiles (common.h: sherf_part_range)
+    SHERF_CHECK_ARG(nparts == 0 || part < nparts);
     mode &= 3;
     SHERF_CHECK_ARG(mode >= 0 && mode <= 2 && (mode == 1 || levels_host));
     SHERF_CHECK_ARG(P > 0 && Hf > 0 && Wf > 0 && H > 0 && W > 0 && capacity > 0);
@@ -795,18 +805,19 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
         SHERF_CHECK_ARG(lv.l[i].wp && lv.l[i].rows && lv.l[i].D > 0 && lv.l[i].H > 0 && lv.l[i].W > 0);
     }
     int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
-    const int64_t tiles = (capacity + 31) / 32;
+    const int64_t tiles = nparts > 1 ? ((capacity + 255) / 256 + nparts - 1) / nparts * 8 + 8 : (capacity + 31) / 32;    // most a part can hold
+    const int kmode = mode | (part << 8) | (nparts << 16);
 #define SHERF_GATHER(BL, MW, HT)                                                                                               \
     hipLaunchKernelGGL((gather_tokens_kernel<BL, MW, HT>), dim3((unsigned)(tiles < 16384 ? (tiles + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream), \
                        counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,         \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
-                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode)
+                       vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode)
     if (half_tables && !branchless && !(g_sherf_debug & 2048)) {      // eight channels per lane (debug bit 11: the four-per-lane kernel on fp16 tables)
         const int64_t pairs = (tiles + 1) / 2;
         hipLaunchKernelGGL(gather_tokens_h8_kernel, dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
                            counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                            reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
-                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, mode);
+                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode);
     } else if (half_tables) { if (squeezed) SHERF_GATHER(true, 4, true); else if (branchless) SHERF_GATHER(true, 1, true); else SHERF_GATHER(false, 1, true); }
     else { if (squeezed) SHERF_GATHER(true, 4, false); else if (branchless) SHERF_GATHER(true, 1, false); else SHERF_GATHER(false, 1, false); }
 #undef SHERF_GATHER

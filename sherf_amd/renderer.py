@@ -266,6 +266,9 @@ class ImportanceRenderer(nn.Module):
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
         # the per-sample network as two launches (sherf_nerf_mlp_split): opt-in, measured slower than the one-launch kernel (see _set_config)
         self.mlp_split = {'': None, '0': False, '1': True}[os.environ.get('SHERF_MLP_SPLIT', '')]
+        # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
+        # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
+        self.mlp_parts = int(os.environ.get('SHERF_MLP_PARTS', '0'))
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
         self._smpl_src = smpl
@@ -705,6 +708,7 @@ class ImportanceRenderer(nn.Module):
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
         # a13-a14: fused transformer + NeRF decoder
         self._set_config(fr, decoder, dev, cfg, exact)
+        fr.mlp_parts = int(opts.get('mlp_parts', getattr(self, 'mlp_parts', 0)))
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
         levels = (_lib.VoxLevel * 3)()
@@ -735,7 +739,7 @@ class ImportanceRenderer(nn.Module):
             self._flag_watch(ws, dev)                      # single-product operands: watch the frame's non-finite flag (no host wait)
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8),
+        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_parts=int(fr.mlp_parts),
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min, vox_sh=[int(v) for v in obs_sp_input['out_sh']],

@@ -95,6 +95,11 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
         dflt = G.hip_render('tiny_nv', precision=prec)
         for k in ('rgb', 'acc', 'depth'):
             assert torch.equal(one[k], two[k]) and torch.equal(one[k], dflt[k]), (prec, k)
+    # gather + network cut into parts on two streams (sherf_nerf_mlp_part): a schedule, not an arithmetic, variant
+    for parts in (2, 3, 8):
+        b = G.hip_render('tiny_nv', options=dict(mlp_parts=parts))
+        assert b['last']['mlp_parts'] == parts
+        assert torch.equal(b['rgb'], h['rgb']) and torch.equal(b['acc'], h['acc']) and torch.equal(b['depth'], h['depth']), parts
 
 
 def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):

@@ -1,0 +1,68 @@
+"""A/B timings of whole frames under `sherf_set_debug` settings, interleaved in ONE process on one box (GPU box only):
+
+    python tools/frame_ab.py --config cfg2_dense_ri --arms 0,0x20000,0x30000,0x40000 [--names whole,2parts,...]
+
+Every arm renders the bench frame with the given debug word; rounds are interleaved after a clock warm-up, the first arm's output is the
+reference every other arm's rgb / depth / acc is compared with bit for bit."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='cfg2_dense_ri')
+    ap.add_argument('--arms', default='0')
+    ap.add_argument('--names', default='')
+    ap.add_argument('--rounds', type=int, default=4)
+    ap.add_argument('--iters', type=int, default=20)
+    a = ap.parse_args()
+    import bench
+    from sherf_amd import _lib
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    w = bench.make_workload(argparse.Namespace(config=a.config, precision='auto', bn_mode='train'), 0.4, dev)
+    arms = [int(x, 0) for x in a.arms.split(',')]
+    names = a.names.split(',') if a.names else [hex(x) for x in arms]
+    lib = _lib.lib()
+    for _ in range(3):
+        bench.render_frame(w)                                   # calibration of `auto` + warm-up
+    torch.cuda.synchronize()
+    print('configuration:', {k: w['rend'].last.get(k) for k in ('mlp_precision', 'table_precision', 'encoder_precision')})
+    ref = None
+    outs = {}
+    for x, n in zip(arms, names):
+        lib.sherf_set_debug(x)
+        r = bench.render_frame(w)
+        torch.cuda.synchronize()
+        outs[n] = [t.clone() for t in r]
+        if ref is None:
+            ref = outs[n]
+        print(f'[bits] {n}: identical to {names[0]}: {all(torch.equal(p, q) for p, q in zip(outs[n], ref))}')
+    for _ in range(30):
+        bench.render_frame(w)
+    times = {n: [] for n in names}
+    for _ in range(a.rounds):
+        for x, n in zip(arms, names):
+            lib.sherf_set_debug(x)
+            for _ in range(3):
+                bench.render_frame(w)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                bench.render_frame(w)
+            e1.record(); torch.cuda.synchronize()
+            times[n].append(e0.elapsed_time(e1) / a.iters)
+    lib.sherf_set_debug(0)
+    for n in names:
+        print(f'[arm] {n:12s} ms/frame {" ".join(f"{t:.4f}" for t in times[n])}   min {min(times[n]):.4f}')
+
+
+if __name__ == '__main__':
+    main()
