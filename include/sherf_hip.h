@@ -86,6 +86,15 @@ int sherf_build_cells(const float* verts, int n, const float* R, const float* Th
 int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a, const float* verts_b, int n,
                        float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                        uint32_t* near_mask, sherf_stream_t stream);
+/* Near lists of a cell list built by sherf_build_cells / sherf_build_cells2 (set 0): for every sub-cell of the near mask the exact
+ * set of vertices that can lie within `radius` of a point of the sub-cell (the near mask's criterion: box distance < radius + margin),
+ * as u16 indices into cell_pts.  near_hdr: int32[2 * SHERF_NEAR_SUBCELLS + 2] = (start, count) per sub-cell + the allocation cursor
+ * (zeroed here); near_list: u16[list_cap], list_cap >= 125 n + 3 * SHERF_NEAR_SUBCELLS (every list padded to four entries); the order
+ * of a list's entries is unspecified.  Replaces the per-candidate cell walk of pytorch3d's role (renderer.py:313-318) in
+ * sherf_sample_mask_nn: 40 instead of 75 distance tests per candidate on a body, no segment bookkeeping. */
+#define SHERF_NEAR_SUBCELLS 524288
+int sherf_build_near_lists(const float* grid_hdr, const float* cell_pts, int n, float radius, int32_t* near_hdr,
+                           uint16_t* near_list, int64_t list_cap, sherf_stream_t stream);
 /* near_mask (nullable): uint32[32768]; one bit per sub-cell (edge cell/sub, sub in grid_hdr[8]): set iff the sub-cell's box
  * comes within cell_size of some vertex -- an unset bit proves "no vertex within the query radius". */
 
@@ -101,12 +110,14 @@ int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a
  *   workspace: dense_vid[R*S] int32, ray_mask[R*ceil(S/64)] u64, scan_ws[R + R/1024 + 2] int32 (the last word is the two-pass sampler's
  *   candidate count).  cs_xs doubles as the sampler's candidate list (capacity records of 16 bytes: x_s + dense index; taken when capacity >= R * S) before the compaction writes it:
  *   its contents on entry are lost.  S <= 256. */
+/* near_hdr / near_list (both NULL or both set): the near lists of sherf_build_near_lists for the SAME cell list; the two-pass sampler's
+ * search then tests one exact list per candidate instead of walking its cell neighbourhood (same results: the comparisons are the same). */
 int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
                          int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
                          const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask,
                          int64_t capacity, int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
                          int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
-                         int32_t* scan_ws, sherf_stream_t stream);
+                         int32_t* scan_ws, const int32_t* near_hdr, const uint16_t* near_list, sherf_stream_t stream);
 
 /* a8+a9+a10 (geometry part): per compact sample: x_c, v_c via T2C[vid]; nearest T-pose vertex (exact, cell
  * list of t_vertices, renderer.py:627); uv via C2S.  geom[c][8] = (x_c.xyz, v_c.xyz, u, v); cs_tvid[c]. */
@@ -374,6 +385,7 @@ typedef struct {
                                  * layer k is done (the encoder's small launches are slowed 3-5x by a co-running sampler) */
     float* rgb; float* depth; float* acc;
     void* zfrag;                /* scratch of sherf_nerf_mlp_split (SHERF_FRAME_MLP_SPLIT), else NULL */
+    int32_t* near_hdr; uint16_t* near_list; int64_t near_list_cap;   /* sherf_build_near_lists buffers (NULL: the cell-walk search) */
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);

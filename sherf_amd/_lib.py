@@ -65,7 +65,8 @@ def _frame_fields():
     P('tokens', 'extras', 'vox_plan', 'vox_coord', 'vox_feat'); I('vox_n', 'vox_training')
     P('wstream', 'wbias'); I('mlp_prec', 'mlp_parts')
     P('sample_out'); I('white_back', 'main_after_layer')
-    P('rgb', 'depth', 'acc', 'zfrag')
+    P('rgb', 'depth', 'acc', 'zfrag', 'near_hdr', 'near_list')
+    f.append(('near_list_cap', _i64))
     return f
 
 

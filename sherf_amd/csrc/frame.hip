@@ -168,9 +168,11 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
                                      f->cell_scratch, f->near_mask, stream_main));
         if (stagger >= 0) SHERF_HIP_CHECK(hipStreamWaitEvent(main, stagger < f->vox_plan->n_layers ? d.ev_mid : d.ev_enc, 0));
+        if (f->near_hdr && f->near_list)
+            SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, stream_main));
         SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
-                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, stream_main));
+                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main));
         // SHERF_FRAME_EXACT_GRIDS: the kernels after the compaction are launched for the frame's ACTUAL number of valid samples instead
         // of the buffers' capacity (R*S, of which a body fills a few percent: the MLP's grid is then ~96 % workgroups that allocate
         // 8 waves x 250 VGPRs + 85 KiB LDS only to read the count and exit, one at a time per CU, behind the real ones).  The count is

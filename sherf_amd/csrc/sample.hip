@@ -216,6 +216,72 @@ __global__ void __launch_bounds__(256) near_mask_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Near lists (round 4): for every sub-cell of the near mask, the EXACT set of vertices that can be within the query radius of a point of
+// that sub-cell (box distance < radius + margin: the near mask's own criterion, so "bit set" == "list not empty").  A candidate sample
+// then tests ONE contiguous list (40 vertices on average on a body) instead of walking the nine trimmed x-rows of its 3 x 3 x 3 cell
+// neighbourhood (75 on average), and finding point t of the walk no longer takes a nine-way select per point: the candidate search was
+// bound by exactly those VALU instructions (142 per four points; profiles/r04_*near_lists*).  Entries are u16 indices into cell_pts
+// (n <= 65535), every list starts on a multiple of four entries (one 8-byte load = four entries); the order inside a list is whatever
+// the atomics made it -- the search takes the lexicographic minimum of (d^2, vertex id), which no order changes.
+//   near_hdr[q] = (start, count) per sub-cell q (zeroed by the caller), near_list[list_cap] u16, cursor = one word (zeroed).
+// Three launches: count (vertex-centric, like near_mask_kernel), allocate (+ the near mask from the counts), fill.
+// ---------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ void __launch_bounds__(256) near_lists_pairs_kernel(const float4* __restrict__ pts, int n, const float* __restrict__ hdr,
+                                                               float radius, int2* __restrict__ near_hdr,
+                                                               uint16_t* __restrict__ near_list, int64_t list_cap) {
+    const CellGrid g = load_grid(hdr);
+    const int sub = g.sub, snx = g.nx * sub, sny = g.ny * sub, snz = g.nz * sub;
+    // one vertex per 8 lanes x ... : a vertex's (2 sub + 1)^3 <= 125 sub-cells are spread over the 32 threads of its group
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 5, t = threadIdx.x & 31;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const float cs = g.cell / (float)sub, rad = radius + 1e-3f * cs, rad2 = rad * rad, fs = g.inv_cell * (float)sub;
+    const int sx = (int)floorf((p.x - g.ox) * fs), sy = (int)floorf((p.y - g.oy) * fs), sz = (int)floorf((p.z - g.oz) * fs);
+    const int w = 2 * sub + 1, w3 = w * w * w;
+    for (int e = t; e < w3; e += 32) {
+        const int dz = e / (w * w) - sub, dy = (e / w) % w - sub, dx = e % w - sub;
+        const int qx = sx + dx, qy = sy + dy, qz = sz + dz;
+        if (qx < 0 || qx >= snx || qy < 0 || qy >= sny || qz < 0 || qz >= snz) continue;
+        const float bx = g.ox + qx * cs, by = g.oy + qy * cs, bz = g.oz + qz * cs;
+        const float ex = fmaxf(fmaxf(bx - p.x, p.x - (bx + cs)), 0.f), ey = fmaxf(fmaxf(by - p.y, p.y - (by + cs)), 0.f),
+                    ez = fmaxf(fmaxf(bz - p.z, p.z - (bz + cs)), 0.f);
+        if (ex * ex + ey * ey + ez * ez < rad2) {
+            const int q = (qz * sny + qy) * snx + qx;
+            if (!FILL) atomicAdd(&near_hdr[q].y, 1);
+            else {
+                const int slot = atomicAdd(&near_hdr[q].y, 1);
+                const int64_t at = (int64_t)near_hdr[q].x + slot;
+                if (at < list_cap) near_list[at] = (uint16_t)i;
+            }
+        }
+    }
+}
+
+// thread per sub-cell: its list's start from ONE atomic per wave (lists padded to whole quads), the count reset for the fill pass to
+// count up again, and the near mask's word straight from the ballot
+__global__ void __launch_bounds__(256) near_lists_alloc_kernel(const float* __restrict__ hdr, int2* __restrict__ near_hdr, int32_t* __restrict__ cursor,
+                                                               int64_t list_cap, uint32_t* __restrict__ near_mask) {
+    const CellGrid g = load_grid(hdr);
+    const int nsub = g.nx * g.ny * g.nz * g.sub * g.sub * g.sub;
+    const int q = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int c = q < nsub ? near_hdr[q].y : 0;
+    const int pc = (c + 3) & ~3;
+    int incl = pc;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    const int total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 0 && total) base = atomicAdd(cursor, total);
+    base = __shfl(base, 0);
+    const unsigned long long any = __ballot(c > 0);
+    if (near_mask && (lane & 31) == 0) near_mask[q >> 5] = (uint32_t)(any >> (lane & 32));
+    if (q < nsub) {
+        const int64_t start = (int64_t)base + (incl - pc);
+        near_hdr[q] = start + pc <= list_cap ? make_int2((int)start, 0) : make_int2(0, 0);      // (cannot happen with the documented list_cap)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pass 1: one wave per ray: depths, positions, exact NN within 5 cm, validity mask
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float depth_at(float near, float range, int k, int S) {
@@ -569,6 +635,75 @@ __global__ void __launch_bounds__(256) cand_search_kernel(const float4* __restri
 }
 
 // first scan kernel of the two-pass path: a ray's count is the popcount of its masks (also stored, the compositing reads ray_cnt)
+// The candidate search over the near lists (see near_lists_pairs_kernel): eight lanes per candidate as in cand_search_kernel, a lane
+// takes four list entries per step (one 8-byte load) and their four points; the next step's record and list header are in flight while
+// this step's points are compared.  Same comparisons on the same points' bits, fewer of them: results identical.
+template <int NCH>
+__global__ void __launch_bounds__(256) cand_search_lists_kernel(const float4* __restrict__ cand_list, int64_t list_cap,
+                                                                const int32_t* __restrict__ cand_count, int S, const float* __restrict__ hdr,
+                                                                const int2* __restrict__ near_hdr, const uint16_t* __restrict__ near_list,
+                                                                const float4* __restrict__ cell_pts,
+                                                                unsigned long long* __restrict__ ray_mask, int32_t* __restrict__ dense_vid) {
+    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const CellGrid g = load_grid(hdr);
+    const int snx = g.nx * g.sub, sny = g.ny * g.sub, snz = g.nz * g.sub;
+    const float fs = g.inv_cell * (float)g.sub;
+    const int64_t n = min((int64_t)*cand_count, list_cap);
+    const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
+    const int64_t stride = (int64_t)gridDim.x * 32;
+    auto sub_cell = [&](const float4& rec) -> int {                   // cand_mark's own arithmetic on the same floats -> the same sub-cell
+        const int sx = (int)floorf((rec.x - g.ox) * fs), sy = (int)floorf((rec.y - g.oy) * fs), sz = (int)floorf((rec.z - g.oz) * fs);
+        const bool in = sx >= 0 && sx < snx && sy >= 0 && sy < sny && sz >= 0 && sz < snz;
+        return in ? (sz * sny + sy) * snx + sx : -1;
+    };
+    int64_t ci = (int64_t)blockIdx.x * 32 + grp;
+    float4 rec = cand_list[ci < n ? ci : 0];
+    float4 rec_next = cand_list[ci + stride < n ? ci + stride : 0];
+    int q0 = sub_cell(rec);
+    int2 h = near_hdr[ci < n && q0 >= 0 ? q0 : 0];
+    for (; ci - grp < n; ci += stride) {                              // (the whole workgroup leaves together: c0 = ci - grp is uniform)
+        const bool live = ci < n && sub_cell(rec) >= 0;
+        const float xs = rec.x, ys = rec.y, zs = rec.z;
+        const int idx = live ? __float_as_int(rec.w) : 0;
+        const int st = h.x, cn = live ? h.y : 0;
+        // next step: its header can be requested now (its record arrived a step ago), and the record after it
+        const int64_t cn1 = ci + stride, cn2 = ci + 2 * stride;
+        rec = rec_next;
+        const int qn = sub_cell(rec);
+        h = near_hdr[cn1 < n && qn >= 0 ? qn : 0];
+        rec_next = cand_list[cn2 < n ? cn2 : 0];
+        unsigned long long key = kInit;
+        for (int base = 0; base < cn; base += 32) {
+            const int e = base + sub * 4;
+            uint2 w = make_uint2(0u, 0u);
+            if (e < cn) w = *reinterpret_cast<const uint2*>(near_list + st + e);
+            const int id[4] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = cell_pts[e + j < cn ? id[j] : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dd = dist2_exact(xs, ys, zs, v[j].x, v[j].y, v[j].z);
+                if (e + j < cn && dd < kThresh2) {
+                    const unsigned long long cand = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[j].w);
+                    key = cand < key ? cand : key;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {      // lexicographic (d^2, vertex id) minimum over the group's eight lanes
+            const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other < key ? other : key;
+        }
+        if (live && sub == 0 && (unsigned)(key >> 32) < __float_as_uint(kThresh2)) {
+            const int ray = idx / S, k = idx - ray * S;
+            dense_vid[idx] = (int)(key & 0x7FFFFFFFull);
+            atomicOr(&ray_mask[(size_t)ray * NCH + (k >> 6)], 1ull << (k & 63));
+        }
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(1024) scan_chunk_mask_kernel(const uint64_t* __restrict__ ray_mask, int R, int32_t* __restrict__ cnt,
                                                                int32_t* __restrict__ base, int32_t* __restrict__ chunk_sum) {
@@ -786,15 +921,31 @@ extern "C" int sherf_build_cells2(const float* verts_a, const float* R_a, const 
     SHERF_LAUNCH_CHECK();
 }
 
+extern "C" int sherf_build_near_lists(const float* grid_hdr, const float* cell_pts, int n, float radius, int32_t* near_hdr,
+                                      uint16_t* near_list, int64_t list_cap, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(grid_hdr && cell_pts && near_hdr && near_list);
+    SHERF_CHECK_ARG(n > 0 && n <= 65535 && radius > 0.f && list_cap >= (int64_t)125 * n + 3 * SHERF_NEAR_SUBCELLS);
+    hipStream_t st = as_stream(stream);
+    int2* nh = reinterpret_cast<int2*>(near_hdr);
+    int32_t* cursor = near_hdr + 2 * SHERF_NEAR_SUBCELLS;                 // the word behind the last header
+    (void)hipMemsetAsync(near_hdr, 0, (2 * (size_t)SHERF_NEAR_SUBCELLS + 2) * sizeof(int32_t), st);
+    const float4* pts = reinterpret_cast<const float4*>(cell_pts);
+    hipLaunchKernelGGL(near_lists_pairs_kernel<false>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap);
+    hipLaunchKernelGGL(near_lists_alloc_kernel, dim3(SHERF_NEAR_SUBCELLS / 256), dim3(256), 0, st, grid_hdr, nh, cursor, list_cap,
+                       static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(near_lists_pairs_kernel<true>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap);
+    SHERF_LAUNCH_CHECK();
+}
+
 extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, const float* near, const float* far,
                                        int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
                                        const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask, int64_t capacity,
                                     int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
                                        int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
-                                       int32_t* scan_ws, sherf_stream_t stream) {
+                                       int32_t* scan_ws, const int32_t* near_hdr, const uint16_t* near_list, sherf_stream_t stream) {
     SHERF_CHECK_ARG(ray_o && ray_d && near && far && Rg && Th && grid_hdr && cell_start && cell_pts && near_mask);
     SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && cs_vid && cs_xs && dense_vid && ray_mask && scan_ws);
-    SHERF_CHECK_ARG(R > 0 && S >= 2 && S <= 256 && (int64_t)R * S < 2147483647LL && capacity > 0);
+    SHERF_CHECK_ARG(R > 0 && S >= 2 && S <= 256 && (int64_t)R * S < 2147483647LL && capacity > 0 && (near_hdr == nullptr) == (near_list == nullptr));
     hipStream_t st = as_stream(stream);
     const int nch = (S + 63) / 64;
     const int n_chunks = cdiv(R, 1024);
@@ -814,11 +965,16 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
         float4* cand_list = reinterpret_cast<float4*>(cs_xs);            // one 16-byte record per candidate: the list holds `capacity` of them
         const int64_t list_cap = capacity;
         unsigned long long* rm = reinterpret_cast<unsigned long long*>(ray_mask);
+        const bool lists = near_hdr && near_list && !(g_sherf_debug & 16384);      // debug bit 14: the cell walk, for A/B runs
 #define SHERF_TWO_PASS(N)                                                                                                          \
         hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
                            grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
-        hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S,              \
-                           grid_hdr, cell_start, cp, rm, dense_vid);                                                               \
+        if (lists)                                                                                                                 \
+            hipLaunchKernelGGL(cand_search_lists_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S,    \
+                               grid_hdr, reinterpret_cast<const int2*>(near_hdr), near_list, cp, rm, dense_vid);                   \
+        else                                                                                                                       \
+            hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S,          \
+                               grid_hdr, cell_start, cp, rm, dense_vid);                                                           \
         hipLaunchKernelGGL(scan_chunk_mask_kernel<N>, dim3(n_chunks), dim3(1024), 0, st, ray_mask, R, ray_cnt, base_local, chunk_sum)
         if (nch == 1) { SHERF_TWO_PASS(1); } else if (nch == 2) { SHERF_TWO_PASS(2); } else if (nch == 3) { SHERF_TWO_PASS(3); } else { SHERF_TWO_PASS(4); }
 #undef SHERF_TWO_PASS

@@ -27,6 +27,7 @@ from .voxel import SparseConvNet, SparseConvTensor, pack_conv_weights  # noqa: F
 MLP_PRECISIONS = mlp_pack.PRECISIONS
 
 V = 6890
+NEAR_SUBCELLS = 524288        # SHERF_NEAR_SUBCELLS (include/sherf_hip.h)
 
 
 def compute_normal(vertices, faces):
@@ -170,6 +171,9 @@ class _Workspace:
             grid_hdr=torch.zeros(2, 12, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
             cell_pts=torch.zeros(2, V, 4, **f32), cell_scratch=torch.zeros(2 * 5 * V, **i32),
             near_mask=torch.zeros(32768, **i32),
+            # sherf_build_near_lists: (start, count) per sub-cell of the near mask + the cursor; u16 vertex lists (worst case, never grown)
+            near_hdr=torch.zeros(2 * NEAR_SUBCELLS + 2, **i32),
+            near_list=torch.zeros(125 * V + 3 * NEAR_SUBCELLS, dtype=torch.int16, device=dev),
         )
         self.key, self.t = key, t
         return t
@@ -672,6 +676,8 @@ class ImportanceRenderer(nn.Module):
         # the frame's outputs: ONE fresh buffer per call, planar [rgb (3R) | depth (R) | acc (R)], written by the compositing kernel and
         # returned as views -- no copies behind the frame (rounds 1-2 cloned three workspace tensors: three launches per frame), and
         # a caller may keep as many frames as it likes
+        if opts.get('near_lists', getattr(self, 'near_lists', True)):           # exact vertex list per near-mask sub-cell (False: the cell walk)
+            fr.near_hdr, fr.near_list, fr.near_list_cap = A(ws['near_hdr']), A(ws['near_list']), ws['near_list'].numel()
         out = torch.empty(5 * R, dtype=torch.float32, device=dev)
         fr.rgb, fr.depth, fr.acc = A(out), A(out) + 12 * R, A(out) + 16 * R
         ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]

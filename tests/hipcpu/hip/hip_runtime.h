@@ -61,6 +61,7 @@ inline float __shfl_xor(float v, int m) { return hipcpu_exchange(v, hipcpu_lane(
 inline int __shfl_xor(int v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 inline unsigned __shfl_xor(unsigned v, int m) { return hipcpu_exchange(v, hipcpu_lane() ^ m); }
 template <class T> inline T __shfl_down(T v, int d) { const int l = hipcpu_lane() + d; return hipcpu_exchange(v, l < 64 ? l : hipcpu_lane()); }
+template <class T> inline T __shfl_up(T v, int d) { const int l = hipcpu_lane() - d; return hipcpu_exchange(v, l >= 0 ? l : hipcpu_lane()); }
 template <class T> inline T __shfl(T v, int src) { return hipcpu_exchange(v, src & 63); }
 inline unsigned long long __ballot(int pred) {           // every lane of the wave must call it (no divergence), as the shim's other collectives
     unsigned char* sc = hipcpu_collective_buffer();
@@ -99,6 +100,8 @@ struct float4 { float x, y, z, w; };
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 struct int3 { int x, y, z; };
+struct int2 { int x, y; };
+inline int2 make_int2(int a, int b) { return {a, b}; }
 inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 inline uint2 make_uint2(uint32_t a, uint32_t b) { return {a, b}; }
 inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return {a, b, c, d}; }

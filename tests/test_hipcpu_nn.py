@@ -24,7 +24,7 @@ def lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n')
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for name in ('sherf_build_cells', 'sherf_build_cells2', 'sherf_sample_mask_nn', 'sherf_warp_geom'):
+    for name in ('sherf_build_cells', 'sherf_build_cells2', 'sherf_build_near_lists', 'sherf_sample_mask_nn', 'sherf_warp_geom'):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = protos[name][0], [a[0] for a in protos[name][1]]
     return lib
@@ -63,9 +63,38 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     assert int(cell_start[0].max()) == n
     # rays: through the shell, through the cluster, past everything -- for both search paths (two passes over a dense candidate list /
     # one wave per ray: sherf_set_debug bit 9) and one, two and three 64-sample chunks per ray
+    # the near lists (round 4): per sub-cell of the near mask exactly the vertices whose distance to the sub-cell's box is below the
+    # radius (+ the mask's margin) -- checked against brute force; bit set <=> list not empty
+    NSUB = 524288
+    near_hdr = torch.zeros(2 * NSUB + 2, dtype=torch.int32); near_list = torch.zeros(125 * n + 3 * NSUB, dtype=torch.int16)
+    assert lib.sherf_build_near_lists(_P(hdr), _P(cell_pts), n, 0.05, _P(near_hdr), _P(near_list), near_list.numel(), None) == 0
+    g = hdr[0]
+    o, cell = g[:3].numpy().astype(np.float64), float(g[3])
+    nx, ny, nz, sub = [int(v) for v in g[5:9].view(torch.int32)]
+    cs = cell / sub
+    hq = near_hdr[:2 * NSUB].view(NSUB, 2).numpy()
+    nsub = nx * ny * nz * sub ** 3
+    assert not hq[nsub:].any() and (hq[:nsub, 0] % 4 == 0).all()
+    bits = np.unpackbits(near_mask.numpy().view(np.uint8), bitorder='little')[:nsub].astype(bool)
+    assert np.array_equal(bits, hq[:nsub, 1] > 0)
+    pts = cell_pts[0, :, :3].numpy().astype(np.float64)
+    total = 0
+    for q in rs.choice(np.flatnonzero(bits), 300, replace=False).tolist() + rs.randint(0, nsub, 100).tolist():
+        qx, qy, qz = q % (nx * sub), (q // (nx * sub)) % (ny * sub), q // (nx * sub * ny * sub)
+        b0 = o + np.array([qx, qy, qz]) * cs
+        e = np.maximum(np.maximum(b0 - pts, pts - (b0 + cs)), 0.0)
+        dist = np.sqrt((e ** 2).sum(1))
+        lst = near_list[hq[q, 0]: hq[q, 0] + hq[q, 1]].numpy().astype(np.int64) & 0xFFFF
+        assert len(set(lst.tolist())) == len(lst)
+        must, may = set(np.flatnonzero(dist < 0.05).tolist()), set(np.flatnonzero(dist < 0.05 + 2e-3 * cs).tolist())
+        assert must <= set(lst.tolist()) <= may, q
+        total += len(lst)
+    assert total > 2000
+    # lists never overlap: the allocation cursor == the sum of the padded counts
+    assert int(near_hdr[2 * NSUB]) == int(((hq[:nsub, 1] + 3) // 4 * 4).sum())
     import ctypes as _ct
     dbg = _ct.c_int.in_dll(lib, 'g_sherf_debug')
-    for S, flag in ((80, 0), (80, 512), (40, 0), (150, 0), (150, 512)):
+    for S, flag, lists in ((80, 0, True), (80, 0, False), (80, 512, False), (40, 0, True), (150, 0, True), (150, 0, False), (150, 512, False)):
         dbg.value = flag
         R = 96
         o = rs.uniform(-0.1, 0.1, size=(R, 3)).astype(np.float32); o[:, 2] -= 1.0
@@ -82,7 +111,8 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
         dense_vid = torch.zeros(R * S, dtype=torch.int32); ray_mask = torch.zeros(R * ((S + 63) // 64), dtype=torch.int64); scan_ws = torch.zeros(R + R // 1024 + 2, dtype=torch.int32)
         assert lib.sherf_sample_mask_nn(_P(ray_o), _P(ray_d), _P(t_near), _P(t_far), R, S, _P(Rg), _P(Th), _P(hdr), _P(cell_start), _P(cell_pts),
                                         _P(near_mask), cap, _P(counters), _P(ray_base), _P(ray_cnt), _P(cs_idx), _P(cs_vid), _P(cs_xs),
-                                        _P(dense_vid), _P(ray_mask), _P(scan_ws), None) == 0
+                                        _P(dense_vid), _P(ray_mask), _P(scan_ws), _P(near_hdr) if lists else None,
+                                        _P(near_list) if lists else None, None) == 0
         # brute force in the same arithmetic: depths of math_utils.py:101-118, positions o + t d with separate roundings
         k = np.arange(S, dtype=np.float32)
         step = (k / np.float32(S - 1)).astype(np.float32)
@@ -93,7 +123,7 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
         vid = np.array([np.flatnonzero(row == m)[0] for row, m in zip(d2, best)])
         valid = np.flatnonzero(best < np.float32(0.05 * 0.05))
         nv = int(counters[0])
-        assert nv == valid.size and nv > 150, (S, flag, nv, valid.size)
+        assert nv == valid.size and nv > 150, (S, flag, lists, nv, valid.size)
         assert np.array_equal(cs_idx[:nv].numpy(), valid) and np.array_equal(cs_vid[:nv].numpy(), vid[valid])
         assert np.array_equal(cs_xs[:nv, :3].numpy(), x[valid])
         assert np.array_equal(ray_cnt.numpy(), np.bincount(valid // S, minlength=R))
