@@ -81,7 +81,7 @@ int sherf_smpl_c2s_table(const float* weights, const float* A_big, const float* 
 int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
                       float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                       uint32_t* near_mask, sherf_stream_t stream);
-/* Both per-frame lists in one launch: set 0 = verts_a in the SMPL frame (with near_mask), set 1 = verts_b untransformed.
+/* Both per-frame lists in one launch: set 0 = verts_a in the SMPL frame (with near_mask; nullable, see sherf_build_near_lists), set 1 = verts_b untransformed.
  * grid_hdr[2][12], cell_start[2][SHERF_MAX_CELLS+1], cell_pts[2][n][4], scratch[2][5n]. */
 int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a, const float* verts_b, int n,
                        float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
@@ -94,7 +94,9 @@ int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a
  * sherf_sample_mask_nn: 40 instead of 75 distance tests per candidate on a body, no segment bookkeeping. */
 #define SHERF_NEAR_SUBCELLS 524288
 int sherf_build_near_lists(const float* grid_hdr, const float* cell_pts, int n, float radius, int32_t* near_hdr,
-                           uint16_t* near_list, int64_t list_cap, sherf_stream_t stream);
+                           uint16_t* near_list, int64_t list_cap, uint32_t* near_mask, sherf_stream_t stream);
+/* near_mask (nullable) here: the near mask's words written from the lists' counts (bit == "list not empty": the same bits
+ * sherf_build_cells2 computes) -- then sherf_build_cells2 can be given near_mask = NULL and skips its own mask pass. */
 /* near_mask (nullable): uint32[32768]; one bit per sub-cell (edge cell/sub, sub in grid_hdr[8]): set iff the sub-cell's box
  * comes within cell_size of some vertex -- an unset bit proves "no vertex within the query radius". */
 

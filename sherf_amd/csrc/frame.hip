@@ -165,11 +165,12 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         // layer `stagger`; concurrent -> the ray side's big kernels first, the encoder's ~50 small ones behind them.
         if (stagger >= 0) SHERF_RUN(enqueue_encoder());
         // ---- main: cell lists, a4-a6 sampling / mask / nearest vertex / compaction, table re-layout ----
+        const bool lists = f->near_hdr && f->near_list;             // exact vertex list per near-mask sub-cell: its counts also give the mask
         SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
-                                     f->cell_scratch, f->near_mask, stream_main));
+                                     f->cell_scratch, lists ? nullptr : f->near_mask, stream_main));
         if (stagger >= 0) SHERF_HIP_CHECK(hipStreamWaitEvent(main, stagger < f->vox_plan->n_layers ? d.ev_mid : d.ev_enc, 0));
-        if (f->near_hdr && f->near_list)
-            SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, stream_main));
+        if (lists)
+            SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, f->near_mask, stream_main));
         SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
                                        f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main));

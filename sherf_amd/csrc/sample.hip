@@ -250,8 +250,8 @@ __global__ void __launch_bounds__(256) near_lists_pairs_kernel(const float4* __r
             const int q = (qz * sny + qy) * snx + qx;
             if (!FILL) atomicAdd(&near_hdr[q].y, 1);
             else {
-                const int slot = atomicAdd(&near_hdr[q].y, 1);
-                const int64_t at = (int64_t)near_hdr[q].x + slot;
+                const int start = near_hdr[q].x;                      // (requested before the atomic's round trip, not behind it)
+                const int64_t at = (int64_t)start + atomicAdd(&near_hdr[q].y, 1);
                 if (at < list_cap) near_list[at] = (uint16_t)i;
             }
         }
@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(256) near_lists_alloc_kernel(const float* __re
                                                                int64_t list_cap, uint32_t* __restrict__ near_mask) {
     const CellGrid g = load_grid(hdr);
     const int nsub = g.nx * g.ny * g.nz * g.sub * g.sub * g.sub;
+    if ((int)blockIdx.x * 256 >= ((nsub + 63) & ~63)) return;         // (whole workgroups beyond the grid; the launch covers SHERF_NEAR_SUBCELLS)
     const int q = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     const int c = q < nsub ? near_hdr[q].y : 0;
     const int pc = (c + 3) & ~3;
@@ -911,18 +912,20 @@ extern "C" int sherf_build_cells(const float* verts, int n, const float* R, cons
 extern "C" int sherf_build_cells2(const float* verts_a, const float* R_a, const float* Th_a, const float* verts_b, int n,
                                   float cell_size, float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                                   uint32_t* near_mask, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(verts_a && R_a && Th_a && verts_b && grid_hdr && cell_start && cell_pts && scratch && near_mask);
+    SHERF_CHECK_ARG(verts_a && R_a && Th_a && verts_b && grid_hdr && cell_start && cell_pts && scratch);
     SHERF_CHECK_ARG(n > 0 && n <= 65535 && cell_size > 0.f);        // (u16 point indices in the sampler's candidate records)
     hipLaunchKernelGGL(build_cells2_kernel, dim3(2), dim3(1024), 0, as_stream(stream), verts_a, R_a, Th_a, verts_b, n, cell_size,
                        grid_hdr, cell_start, reinterpret_cast<float4*>(cell_pts), scratch, near_mask);
-    (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
-    hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 16384 * sizeof(uint32_t), as_stream(stream),
-                       reinterpret_cast<const float*>(scratch), n, grid_hdr, cell_size, near_mask);
+    if (near_mask) {                                                 // (NULL: sherf_build_near_lists writes the mask from its counts)
+        (void)hipMemsetAsync(near_mask, 0, 32768 * sizeof(uint32_t), as_stream(stream));
+        hipLaunchKernelGGL(near_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 16384 * sizeof(uint32_t), as_stream(stream),
+                           reinterpret_cast<const float*>(scratch), n, grid_hdr, cell_size, near_mask);
+    }
     SHERF_LAUNCH_CHECK();
 }
 
 extern "C" int sherf_build_near_lists(const float* grid_hdr, const float* cell_pts, int n, float radius, int32_t* near_hdr,
-                                      uint16_t* near_list, int64_t list_cap, sherf_stream_t stream) {
+                                      uint16_t* near_list, int64_t list_cap, uint32_t* near_mask, sherf_stream_t stream) {
     SHERF_CHECK_ARG(grid_hdr && cell_pts && near_hdr && near_list);
     SHERF_CHECK_ARG(n > 0 && n <= 65535 && radius > 0.f && list_cap >= (int64_t)125 * n + 3 * SHERF_NEAR_SUBCELLS);
     hipStream_t st = as_stream(stream);
@@ -931,8 +934,7 @@ extern "C" int sherf_build_near_lists(const float* grid_hdr, const float* cell_p
     (void)hipMemsetAsync(near_hdr, 0, (2 * (size_t)SHERF_NEAR_SUBCELLS + 2) * sizeof(int32_t), st);
     const float4* pts = reinterpret_cast<const float4*>(cell_pts);
     hipLaunchKernelGGL(near_lists_pairs_kernel<false>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap);
-    hipLaunchKernelGGL(near_lists_alloc_kernel, dim3(SHERF_NEAR_SUBCELLS / 256), dim3(256), 0, st, grid_hdr, nh, cursor, list_cap,
-                       static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(near_lists_alloc_kernel, dim3(SHERF_NEAR_SUBCELLS / 256), dim3(256), 0, st, grid_hdr, nh, cursor, list_cap, near_mask);
     hipLaunchKernelGGL(near_lists_pairs_kernel<true>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap);
     SHERF_LAUNCH_CHECK();
 }

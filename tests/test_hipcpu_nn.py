@@ -67,7 +67,8 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     # radius (+ the mask's margin) -- checked against brute force; bit set <=> list not empty
     NSUB = 524288
     near_hdr = torch.zeros(2 * NSUB + 2, dtype=torch.int32); near_list = torch.zeros(125 * n + 3 * NSUB, dtype=torch.int16)
-    assert lib.sherf_build_near_lists(_P(hdr), _P(cell_pts), n, 0.05, _P(near_hdr), _P(near_list), near_list.numel(), None) == 0
+    mask2 = torch.full((32768,), -1, dtype=torch.int32)                # the mask as the list builder writes it == sherf_build_cells2's
+    assert lib.sherf_build_near_lists(_P(hdr), _P(cell_pts), n, 0.05, _P(near_hdr), _P(near_list), near_list.numel(), _P(mask2), None) == 0
     g = hdr[0]
     o, cell = g[:3].numpy().astype(np.float64), float(g[3])
     nx, ny, nz, sub = [int(v) for v in g[5:9].view(torch.int32)]
@@ -77,6 +78,7 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     assert not hq[nsub:].any() and (hq[:nsub, 0] % 4 == 0).all()
     bits = np.unpackbits(near_mask.numpy().view(np.uint8), bitorder='little')[:nsub].astype(bool)
     assert np.array_equal(bits, hq[:nsub, 1] > 0)
+    assert torch.equal(mask2[:(nsub + 31) // 32], near_mask[:(nsub + 31) // 32])
     pts = cell_pts[0, :, :3].numpy().astype(np.float64)
     total = 0
     for q in rs.choice(np.flatnonzero(bits), 300, replace=False).tolist() + rs.randint(0, nsub, 100).tolist():
