@@ -968,11 +968,14 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
         const int64_t list_cap = capacity;
         unsigned long long* rm = reinterpret_cast<unsigned long long*>(ray_mask);
         const bool lists = near_hdr && near_list && !(g_sherf_debug & 16384);      // debug bit 14: the cell walk, for A/B runs
+        // persistent workgroups per CU of the list search (8 = every wave slot; debug bits 20-23 override: A/B runs of how much of the
+        // chip the search should leave to the encoder's small launches on the other stream)
+        const int search_wgs = ((g_sherf_debug >> 20) & 15) ? ((g_sherf_debug >> 20) & 15) : 8;
 #define SHERF_TWO_PASS(N)                                                                                                          \
         hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
                            grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
         if (lists)                                                                                                                 \
-            hipLaunchKernelGGL(cand_search_lists_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S,    \
+            hipLaunchKernelGGL(cand_search_lists_kernel<N>, dim3(search_wgs * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S, \
                                grid_hdr, reinterpret_cast<const int2*>(near_hdr), near_list, cp, rm, dense_vid);                   \
         else                                                                                                                       \
             hipLaunchKernelGGL(cand_search_kernel<N>, dim3(8 * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S,          \

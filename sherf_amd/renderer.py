@@ -142,6 +142,31 @@ def SMPL_to_tensor(params, device):
 
 
 # ---------------------------------------------------------------------------------------------------
+# host-side bookkeeping of a frame: the caches below are keyed on the parameters' (data_ptr, version), looked
+# at EVERY frame -- through plain walks of the modules' own dicts (nn.Module.parameters() builds names, prefixes and a de-duplication set
+# on the way: ~10x the cost), once per frame (`state_key` is memoised for the duration of a forward)
+# ---------------------------------------------------------------------------------------------------
+def fast_params(module, out=None, buffers=False):
+    """Every parameter (buffers=True: and buffer) tensor below `module`, in registration order; shared tensors may repeat."""
+    out = [] if out is None else out
+    for p in module._parameters.values():
+        if p is not None:
+            out.append(p)
+    if buffers:
+        for b in module._buffers.values():
+            if b is not None:
+                out.append(b)
+    for c in module._modules.values():
+        if c is not None:
+            fast_params(c, out, buffers)
+    return out
+
+
+def state_key(tensors):
+    return tuple([(t.data_ptr(), t._version) for t in tensors])
+
+
+# ---------------------------------------------------------------------------------------------------
 # per-device workspace (sized for 288 GB of HBM: worst-case capacity, never reallocated per frame)
 # ---------------------------------------------------------------------------------------------------
 class _Workspace:
@@ -150,6 +175,8 @@ class _Workspace:
         self.t = {}
         self.vox = None
         self.bn = {}
+        self.desc = None
+        self.stacked = None
 
     def frame(self, R, S, cap, dev):
         key = (R, S, cap, str(dev))
@@ -176,7 +203,27 @@ class _Workspace:
             near_list=torch.zeros(125 * V + 3 * NEAR_SUBCELLS, dtype=torch.int16, device=dev),
         )
         self.key, self.t = key, t
+        self.desc = None
         return t
+
+    STATIC_FIELDS = ('A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
+                     'counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws', 'geom',
+                     'cs_tvid', 'tokens', 'extras', 'sample_out')
+
+    def descriptor(self, smpl):
+        """The `sherf_frame` of this workspace with every field that does not change from frame to frame filled in ONCE (workspace and
+        SMPL-asset pointers, sizes); forward() only writes the per-frame inputs into it.  (The native call reads it synchronously.)"""
+        d = self.desc
+        if d is not None and d[0] is self.t and d[1] is smpl:
+            return d[2]
+        A = _lib.addr
+        fr = _lib.Frame()
+        for k in self.STATIC_FIELDS:
+            setattr(fr, k, A(self.t[k]))
+        fr.J_template, fr.J_shapedirs, fr.parents = A(smpl['J_template']), A(smpl['J_shapedirs']), A(smpl['parents_i32'])
+        fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
+        self.desc = (self.t, smpl, fr, dict(near_hdr=A(self.t['near_hdr']), near_list=A(self.t['near_list']), near_cap=self.t['near_list'].numel()))
+        return fr
 
     def zfrag(self, cap, prec_name, dev):
         """Scratch of sherf_nerf_mlp_split: the fused tokens as B-operand fragments, 4 KiB (8 KiB: f16x3) per 32-sample tile."""
@@ -286,7 +333,7 @@ class ImportanceRenderer(nn.Module):
 
     def __getstate__(self):
         s = self.__dict__.copy()
-        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_flags'):
+        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_flags', '_frame_memo'):
             s[k] = None
         s['_ws'] = None
         return s
@@ -396,10 +443,12 @@ class ImportanceRenderer(nn.Module):
     def _auto_state_key(self):
         """What the calibrated choice depends on besides the MLP's own parameters (those key the weight cache): the sparse encoder's
         parameters AND buffers (BatchNorm running statistics): they set the magnitude of the fp16 tables' error."""
-        ts = list(self.encoder_3d.parameters())
-        if not self.encoder_3d.training:                   # (train-mode BatchNorm normalises with batch statistics and MOVES the running ones every frame)
-            ts += list(self.encoder_3d.buffers())
-        return (self.encoder_3d.training,) + tuple((t.data_ptr(), t._version) for t in ts)
+        # (train-mode BatchNorm normalises with batch statistics and MOVES the running ones every frame: parameters only there)
+        enc = self.encoder_3d
+        pk = enc.__dict__.get('_key_memo') or state_key(fast_params(enc))
+        if enc.training:
+            return (True,) + pk
+        return (False,) + pk + state_key([b for m in enc.modules() for b in m._buffers.values() if b is not None])
 
     def _flag_watch(self, ws, dev):
         """The MLP kernel's non-finite flag (counters[3] bit 0: an fp16 operand beyond 65504) of EVERY frame, without a host wait: the word
@@ -437,8 +486,16 @@ class ImportanceRenderer(nn.Module):
         only adds its stream."""
         precision = precision or self.mlp_precision
         prec = MLP_PRECISIONS[precision]
-        mods = [self.conv1d_projection, self.conv1d_reprojection, self.transformer, decoder]
-        key = tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters()) + (str(device),)
+        memo = self.__dict__.get('_frame_memo')                # (set for the duration of a forward: one walk per frame, not one per caller)
+        if memo is not None and memo[0] is decoder and memo[1] == device:
+            key = memo[2]
+        else:
+            ps = []
+            for m in (self.conv1d_projection, self.conv1d_reprojection, self.transformer, decoder):
+                fast_params(m, ps)
+            key = state_key(ps) + (str(device),)
+            if memo is not None:
+                self.__dict__['_frame_memo'] = (decoder, device, key)
         wc = self._wcache
         if wc is None or wc['key'] != key:
             Wr = self.conv1d_reprojection.weight.detach().float()[:, :, 0]          # [32, 96]
@@ -634,14 +691,31 @@ class ImportanceRenderer(nn.Module):
             raise NotImplementedError('importance sampling is unreachable/broken in the reference (renderer.py:376,383)')
         if opts.get('clamp_mode', 'relu') != 'relu' or opts.get('disparity_space_sampling', False):
             raise NotImplementedError('only clamp_mode=relu, disparity_space_sampling=False (train.py:330-332)')
+        # the state keys of the weights are computed once in this call (see _weights, _auto_state_key, SparseConvNet._pack); plain
+        # __dict__ stores: nn.Module.__setattr__ costs more than the walks it would guard
+        d, enc = self.__dict__, self.encoder_3d.__dict__
+        d['_frame_memo'] = (None, None, None)
+        enc['_key_memo'] = state_key(fast_params(self.encoder_3d))
+        try:
+            return self._forward(planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_sp_input, decoder, ray_origins,
+                                 ray_directions, near, far, input_data, opts)
+        finally:
+            d['_frame_memo'] = None
+            enc['_key_memo'] = None
+
+    def _forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_sp_input, decoder, ray_origins,
+                 ray_directions, near, far, input_data, opts):
         dev = ray_origins.device
         S = int(opts['depth_resolution'])
         R = ray_origins.shape[1]
         cap = int(opts.get('sample_capacity', R * S))
-        f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+        F32 = torch.float32
+
+        def f32(t):                                    # (already fp32 and contiguous -- the usual case: no dispatcher round trips)
+            return t if (t.dtype is F32 and t.is_contiguous() and not t.requires_grad) else t.detach().to(dtype=F32).contiguous()
         smpl = self._smpl(dev)
         cfg, calibrate = self._resolve_config(opts, decoder, dev)
-        self._opt_mlp_split = opts.get('mlp_split')
+        self.__dict__['_opt_mlp_split'] = opts.get('mlp_split')
         prec_name = cfg[0]
         wc = self._weights(decoder, dev, prec_name)
         wsp = self._workspace(dev)
@@ -655,37 +729,40 @@ class ImportanceRenderer(nn.Module):
         main = torch.cuda.current_stream(dev)
         side = self._side(dev)
         A = _lib.addr
-        fr = _lib.Frame()
+        fr = wsp.descriptor(smpl)                                        # workspace / asset pointers: filled in once per workspace
         keep = []                                                        # conversions that must outlive the enqueue
 
-        def a32(t, *shape):
-            t = f32(t).view(*shape)
+        def a32(t, n):                                                   # address of `t` as n contiguous fp32 values
+            t = f32(t)
+            if t.numel() != n:
+                raise RuntimeError(f'sherf_amd: expected {n} values, got a tensor of shape {tuple(t.shape)}')
             keep.append(t)
             return A(t)
 
-        poses = torch.stack([f32(prm['poses']).view(72), f32(tprm['poses']).view(72), f32(oprm['poses']).view(72)])
-        shapes = torch.stack([f32(prm['shapes']).view(10), f32(tprm['shapes']).view(10), f32(oprm['shapes']).view(10)])
-        keep += [poses, shapes]
+        # the three SMPL parameter sets side by side (target, big pose, observation): two small concatenations per frame -- reused while
+        # the six source tensors are the same objects at the same versions (a static subject / camera sweep)
+        srcs = (prm['poses'], tprm['poses'], oprm['poses'], prm['shapes'], tprm['shapes'], oprm['shapes'])
+        skey = tuple([(id(t), t._version, t.data_ptr()) for t in srcs])
+        if wsp.stacked is None or wsp.stacked[0] != skey:
+            wsp.stacked = (skey, torch.stack([f32(t).reshape(72) for t in srcs[:3]]), torch.stack([f32(t).reshape(10) for t in srcs[3:]]), srcs)
+        poses, shapes = wsp.stacked[1], wsp.stacked[2]
         fr.poses, fr.shapes = A(poses), A(shapes)
-        fr.J_template, fr.J_shapedirs, fr.parents = A(smpl['J_template']), A(smpl['J_shapedirs']), A(smpl['parents_i32'])
-        fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
-        for k in ('A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
-                  'counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws', 'geom',
-                  'cs_tvid', 'tokens', 'extras', 'sample_out'):
-            setattr(fr, k, A(ws[k]))
+        nl = wsp.desc[3]
+        if opts.get('near_lists', getattr(self, 'near_lists', True)):           # exact vertex list per near-mask sub-cell (False: the cell walk)
+            fr.near_hdr, fr.near_list, fr.near_list_cap = nl['near_hdr'], nl['near_list'], nl['near_cap']
+        else:
+            fr.near_hdr, fr.near_list, fr.near_list_cap = None, None, 0
         # the frame's outputs: ONE fresh buffer per call, planar [rgb (3R) | depth (R) | acc (R)], written by the compositing kernel and
         # returned as views -- no copies behind the frame (rounds 1-2 cloned three workspace tensors: three launches per frame), and
         # a caller may keep as many frames as it likes
-        if opts.get('near_lists', getattr(self, 'near_lists', True)):           # exact vertex list per near-mask sub-cell (False: the cell walk)
-            fr.near_hdr, fr.near_list, fr.near_list_cap = A(ws['near_hdr']), A(ws['near_list']), ws['near_list'].numel()
         out = torch.empty(5 * R, dtype=torch.float32, device=dev)
         fr.rgb, fr.depth, fr.acc = A(out), A(out) + 12 * R, A(out) + 16 * R
         ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
         fr.obs_R, fr.obs_Th = a32(oprm['R'], 9), a32(oprm['Th'], 3)
         fr.cam_R, fr.cam_T, fr.cam_K = a32(input_data['obs_R_all'], 9), a32(input_data['obs_T_all'], 3), a32(input_data['obs_K_all'], 9)
-        fr.verts, fr.tverts = a32(input_data['vertices'], V, 3), a32(input_data['t_vertices'], V, 3)
+        fr.verts, fr.tverts = a32(input_data['vertices'], V * 3), a32(input_data['t_vertices'], V * 3)
         fr.Rg, fr.Th = a32(prm['R'], 9), a32(prm['Th'], 3)
-        fr.ray_o, fr.ray_d = a32(ray_origins, R, 3), a32(ray_directions, R, 3)
+        fr.ray_o, fr.ray_d = a32(ray_origins, R * 3), a32(ray_directions, R * 3)
         fr.near, fr.far = a32(near, R), a32(far, R)
         fr.R, fr.S, fr.capacity = R, S, cap
         # per-frame table re-layout (channel-last) with the slot projections folded in
@@ -695,12 +772,14 @@ class ImportanceRenderer(nn.Module):
         planes_f = wsp.table('planes_f', (3, Pres, Pres, 32), dev)
         feat_f = wsp.table('feat_f', (Hf, Wf, 64), dev)
         img4 = wsp.table('img4', (H, W, 4), dev)
-        fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, -1), A(wc['Wa_t']), A(planes_f), Pres
+        fr.planes, fr.Wa_t, fr.planes_f, fr.P = a32(planes, planes.numel()), A(wc['Wa_t']), A(planes_f), Pres
         exact = bool(opts.get('exact_grids', self.exact_grids))
-        fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, -1), A(wc['Wb_t']), A(feat_f), Hf, Wf
-        fr.obs_img, fr.img4, fr.H, fr.W = a32(obs_input_img, -1), A(img4), H, W
+        fr.obs_feat, fr.Wb_t, fr.feat_f, fr.Hf, fr.Wf = a32(obs_input_feature, obs_input_feature.numel()), A(wc['Wb_t']), A(feat_f), Hf, Wf
+        fr.obs_img, fr.img4, fr.H, fr.W = a32(obs_input_img, obs_input_img.numel()), A(img4), H, W
         fr.tok_bias, fr.bounds = A(wc['tok_bias']), a32(input_data['t_world_bounds'], 6)
-        vox_min = f32(obs_sp_input['bounds']).view(2, 3)[0].contiguous()
+        vox_min = f32(obs_sp_input['bounds'])                            # [.., 2, 3]: its first row = the voxel grid's origin
+        if vox_min.numel() != 6:
+            raise RuntimeError('sherf_amd: obs_sp_input["bounds"] must hold 2 x 3 values')
         keep.append(vox_min)
         fr.vox_min = A(vox_min)
         for i, v in enumerate(obs_sp_input['out_sh']):
@@ -745,10 +824,10 @@ class ImportanceRenderer(nn.Module):
             self._flag_watch(ws, dev)                      # single-product operands: watch the frame's non-finite flag (no host wait)
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.last = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_parts=int(fr.mlp_parts),
+        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_parts=int(fr.mlp_parts),
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
-                                  bounds=input_data['t_world_bounds'], vox_min=vox_min, vox_sh=[int(v) for v in obs_sp_input['out_sh']],
+                                  bounds=input_data['t_world_bounds'], vox_min=vox_min.reshape(-1)[:3], vox_sh=[int(v) for v in obs_sp_input['out_sh']],
                                   coord=vcoord, H=H, W=W, white_back=bool(opts.get('white_back', False))))
         self.last['out'] = out
         return ws['rgb'].view(1, R, 3), ws['depth'].view(1, R, 1), ws['acc'].view(1, R, 1)

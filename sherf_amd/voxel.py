@@ -87,7 +87,8 @@ class SparseConvNet(nn.Module):
 
     # ---- host-side caches -------------------------------------------------------------------
     def _pack(self, device):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        from .renderer import fast_params, state_key          # (plain dict walks: this runs every frame)
+        key = (self.__dict__.get('_key_memo') or state_key(fast_params(self))) + (str(device),)
         if self._packed is not None and self._packed['key'] == key:
             return self._packed
         layers = []
@@ -157,8 +158,11 @@ class SparseConvNet(nn.Module):
     def prepare(self, sp, fold_mats, ws):
         """Host-side part of a frame: plan lookup + (eval mode) running statistics into the plan's stats buffer.
         Returns (plan dict, features fp32, coordinates int32)."""
-        feat = sp.features.detach().float().contiguous()
-        coord = sp.indices.to(torch.int32).contiguous()
+        feat, coord = sp.features, sp.indices
+        if feat.dtype is not torch.float32 or feat.requires_grad or not feat.is_contiguous():
+            feat = feat.detach().float().contiguous()
+        if coord.dtype is not torch.int32 or not coord.is_contiguous():
+            coord = coord.to(torch.int32).contiguous()
         pl = self.plan(sp.spatial_shape, feat.shape[0], fold_mats, ws, feat.device)
         if not self.training:
             # eval (the reference's inference path: G_ema.eval(), training_loop.py:196): BatchNorm uses the running
@@ -187,16 +191,23 @@ class SparseConvNet(nn.Module):
         n = len(ms)
         if not n:
             return
-        VP, A = ctypes.c_void_p * n, _lib.addr
-        rows = [pl['L'][0]['n_total'] if m['lev'] == 0 else pl['L'][m['lev']]['n_rows'] for m in ms]
-        for m in ms:
-            if m['bn'].momentum is None:
-                raise NotImplementedError('BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the native running-'
-                                          'statistics update; the reference uses momentum=0.01 (renderer.py:807)')
-        f32, i32, i64 = torch.float32, torch.int32, torch.int64                    # the kernel reads raw pointers: check what they point at
-        _lib.call('sherf_svox_bn_running_update', n, VP(*[A(m['stats'], f32) for m in ms]), VP(*[A(m['bn'].running_mean, f32) for m in ms]),
-                  VP(*[A(m['bn'].running_var, f32) for m in ms]), VP(*[A(m['bn'].num_batches_tracked, i64) for m in ms]), VP(*[A(r, i32) for r in rows]),
-                  (ctypes.c_int32 * n)(*[m['cout'] for m in ms]), (ctypes.c_float * n)(*[float(m['bn'].momentum) for m in ms]), _lib.stream())
+        # the argument arrays are rebuilt only when a buffer has moved (same storage frame after frame: load_state_dict copies in place)
+        key = tuple([(m['bn'].running_mean.data_ptr(), m['bn'].running_var.data_ptr(), m['bn'].num_batches_tracked.data_ptr(), m['bn'].momentum)
+                     for m in ms])
+        args = pl.get('running_args')
+        if args is None or args[0] != key:
+            VP, A = ctypes.c_void_p * n, _lib.addr
+            rows = [pl['L'][0]['n_total'] if m['lev'] == 0 else pl['L'][m['lev']]['n_rows'] for m in ms]
+            for m in ms:
+                if m['bn'].momentum is None:
+                    raise NotImplementedError('BatchNorm1d(momentum=None) (cumulative moving average) is not implemented by the native running-'
+                                              'statistics update; the reference uses momentum=0.01 (renderer.py:807)')
+            f32, i32, i64 = torch.float32, torch.int32, torch.int64                # the kernel reads raw pointers: check what they point at
+            args = pl['running_args'] = (key, (n, VP(*[A(m['stats'], f32) for m in ms]), VP(*[A(m['bn'].running_mean, f32) for m in ms]),
+                                               VP(*[A(m['bn'].running_var, f32) for m in ms]), VP(*[A(m['bn'].num_batches_tracked, i64) for m in ms]),
+                                               VP(*[A(r, i32) for r in rows]), (ctypes.c_int32 * n)(*[m['cout'] for m in ms]),
+                                               (ctypes.c_float * n)(*[float(m['bn'].momentum) for m in ms])))
+        _lib.call('sherf_svox_bn_running_update', *args[1], _lib.stream())
 
     def encode(self, sp, fold_mats, ws):
         """Runs the encoder on a SparseConvTensor (one native call, csrc/svox.hip: sherf_svox_encode); returns the three
