@@ -968,9 +968,10 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
         const int64_t list_cap = capacity;
         unsigned long long* rm = reinterpret_cast<unsigned long long*>(ray_mask);
         const bool lists = near_hdr && near_list && !(g_sherf_debug & 16384);      // debug bit 14: the cell walk, for A/B runs
-        // persistent workgroups per CU of the list search (8 = every wave slot; debug bits 20-23 override: A/B runs of how much of the
-        // chip the search should leave to the encoder's small launches on the other stream)
-        const int search_wgs = ((g_sherf_debug >> 20) & 15) ? ((g_sherf_debug >> 20) & 15) : 8;
+        // persistent workgroups per CU of the list search: SIX of the eight that fit -- the other two wave slots per SIMD go to the
+        // encoder's small dependent launches on the other stream, which the frame waits for just as long (MI355X, dense framing: 8 ->
+        // 1.751 ms, 6 -> 1.726, 4 -> 1.774, 3 -> 1.826 per frame; profiles/r04_call_m_*).  Debug bits 20-23 override for A/B runs.
+        const int search_wgs = ((g_sherf_debug >> 20) & 15) ? ((g_sherf_debug >> 20) & 15) : 6;
 #define SHERF_TWO_PASS(N)                                                                                                          \
         hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
                            grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
