@@ -461,7 +461,10 @@ def main():
                                parallelism=(f'ray tiles x{world} (one frame)' if rays_mode else f'views x{world}') if world > 1 else 'single GPU', mlp_precision=used, mlp_precision_requested=a.precision,
                                mlp_precision_auto=getattr(rend, 'auto_report', None), network=fixtures_variant_note(a.config),
                                batchnorm=a.bn_mode, exact_grids=bool(rend.exact_grids), caller_streams=n_streams,
-                               table_precision=rend.last.get('table_precision'), encoder_precision=rend.last.get('encoder_precision')))
+                               table_precision=rend.last.get('table_precision'), encoder_precision=rend.last.get('encoder_precision'),
+                               # per caller stream: sampler side at R * S, token side (480 B / sample) at 1.5 x the frame's valid samples
+                               workspace_bytes=rend._workspace(dev).nbytes(), token_capacity=int(rend.last.get('cap', 0)),
+                               sampler_capacity=int(rend.last.get('sampler_cap', 0))))
         if mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
             two = bool(rend.last.get('mlp_split'))

@@ -225,6 +225,12 @@ int sherf_composite_compact(const int32_t* counters, const int32_t* ray_base, co
                             const int32_t* cs_idx, const float* sample_out, const float* ray_d,
                             const float* near, const float* far, int R, int S, int white_back, float* rgb,
                             float* depth, float* acc, sherf_stream_t stream);
+/* The same with a bound on the compact samples that sample_out holds (sherf_frame.tok_capacity): a ray whose samples reach beyond
+ * tok_cap is written as NaN and counters[3] |= 2 instead of being composited from memory nobody wrote. */
+int sherf_composite_compact_cap(int32_t* counters, const int32_t* ray_base, const int32_t* ray_cnt,
+                                const int32_t* cs_idx, const float* sample_out, const float* ray_d,
+                                const float* near, const float* far, int R, int S, int white_back, int64_t tok_cap,
+                                float* rgb, float* depth, float* acc, sherf_stream_t stream);
 
 /* MipRayMarcher2.forward on dense inputs (ray_marcher.py:67-70): colors[R][S][3], sigma[R][S], depths[R][S],
  * rays_d[R][3] -> rgb[R][3], depth[R], weights[R][S].  dminmax[2] (device) = global min/max of depths
@@ -388,9 +394,14 @@ typedef struct {
     float* rgb; float* depth; float* acc;
     void* zfrag;                /* scratch of sherf_nerf_mlp_split (SHERF_FRAME_MLP_SPLIT), else NULL */
     int32_t* near_hdr; uint16_t* near_list; int64_t near_list_cap;   /* sherf_build_near_lists buffers (NULL: the cell-walk search) */
+    int64_t tok_capacity;       /* samples that geom / tokens / extras / sample_out hold (0: `capacity`).  The sampler's own buffers stay at
+                                 * `capacity` (= R * S for the two-pass sampler); a frame with more valid samples than tok_capacity renders the
+                                 * rays it cannot hold as NaN and sets counters[3] bit 1 -- the caller sizes from counters[0] (phase 4) */
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);
+/* phase: 1 = everything up to the per-sample network, 2 = compositing, 3 = both; 4 (alone) = the sampler only (cell lists, shell mask,
+ * nearest vertex, compaction: counters[0] = the frame's number of valid samples) -- what a caller runs once to size tok_capacity. */
 /* stream_aux (may be NULL): a third stream on which the occupancy structure of voxel levels 1-3 is built while the
  * level-0 convolutions run on stream_side. */
 /* sizeof of {sherf_vox_level, sherf_svox_level_ws, sherf_svox_layer, sherf_svox_plan, sherf_frame} for binding checks */

@@ -23,10 +23,19 @@ __global__ void __launch_bounds__(256) composite_compact_kernel(const int32_t* _
                                                                 const float4* __restrict__ sample_out,
                                                                 const float* __restrict__ ray_d, const float* __restrict__ near,
                                                                 const float* __restrict__ far, int R, int S, int white_back,
+                                                                int64_t tok_cap, int32_t* __restrict__ flags,
                                                                 float* __restrict__ rgb, float* __restrict__ depth,
                                                                 float* __restrict__ acc) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= R) return;
+    if ((int64_t)ray_base[r] + ray_cnt[r] > tok_cap) {
+        // the frame holds more valid samples than the token-side buffers (sherf_frame.tok_capacity): this ray's samples were not
+        // evaluated.  Loud, not wrong: NaN pixels + counters[3] bit 1; the caller re-sizes from counters[0] and renders again.
+        const float qnan = __int_as_float(0x7fc00000);
+        rgb[r * 3] = rgb[r * 3 + 1] = rgb[r * 3 + 2] = qnan; depth[r] = qnan; acc[r] = qnan;
+        if (flags) atomicOr(flags, 2);
+        return;
+    }
     const float dmin = ord2f(counters[1]), dmax = ord2f(counters[2]);
     const float d0 = ray_d[r * 3], d1 = ray_d[r * 3 + 1], d2 = ray_d[r * 3 + 2];
     const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
@@ -135,6 +144,18 @@ __global__ void __launch_bounds__(256) composite_compact_bwd_kernel(const int32_
 
 }  // namespace
 
+extern "C" int sherf_composite_compact_cap(int32_t* counters, const int32_t* ray_base, const int32_t* ray_cnt,
+                                           const int32_t* cs_idx, const float* sample_out, const float* ray_d,
+                                           const float* near, const float* far, int R, int S, int white_back, int64_t tok_cap,
+                                           float* rgb, float* depth, float* acc, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && sample_out && ray_d && near && far && rgb && depth && acc);
+    SHERF_CHECK_ARG(R > 0 && S >= 2 && tok_cap > 0);
+    hipLaunchKernelGGL(composite_compact_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
+                       ray_cnt, cs_idx, reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back, tok_cap,
+                       counters + 3, rgb, depth, acc);
+    SHERF_LAUNCH_CHECK();
+}
+
 extern "C" int sherf_composite_compact(const int32_t* counters, const int32_t* ray_base, const int32_t* ray_cnt,
                                        const int32_t* cs_idx, const float* sample_out, const float* ray_d,
                                        const float* near, const float* far, int R, int S, int white_back, float* rgb,
@@ -142,8 +163,8 @@ extern "C" int sherf_composite_compact(const int32_t* counters, const int32_t* r
     SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && sample_out && ray_d && near && far && rgb && depth && acc);
     SHERF_CHECK_ARG(R > 0 && S >= 2);
     hipLaunchKernelGGL(composite_compact_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
-                       ray_cnt, cs_idx, reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back, rgb,
-                       depth, acc);
+                       ray_cnt, cs_idx, reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back,
+                       (int64_t)R * S, static_cast<int32_t*>(nullptr), rgb, depth, acc);
     SHERF_LAUNCH_CHECK();
 }
 

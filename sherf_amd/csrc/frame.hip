@@ -85,9 +85,23 @@ extern "C" int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t*
 
 extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
                                   sherf_stream_t stream_side, sherf_stream_t stream_aux) {
-    SHERF_CHECK_ARG(f && levels && (phase & 3) && stream_side != stream_main && (!stream_aux || (stream_aux != stream_main && stream_aux != stream_side)));
+    SHERF_CHECK_ARG(f && levels && ((phase & 3) || phase == 4) && stream_side != stream_main && (!stream_aux || (stream_aux != stream_main && stream_aux != stream_side)));
     hipStream_t main = as_stream(stream_main), side = as_stream(stream_side);
     std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    if (phase == 4) {                                                // the sampler alone: counters[0] = the frame's valid samples
+        SHERF_CHECK_ARG(f->R > 0 && f->S > 0 && f->capacity > 0);
+        const bool lists = f->near_hdr && f->near_list;
+        SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, SHERF_V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
+                                     f->cell_scratch, lists ? nullptr : f->near_mask, stream_main));
+        if (lists)
+            SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, SHERF_V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, f->near_mask, stream_main));
+        SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
+                                       f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
+                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main));
+        return SHERF_OK;
+    }
+    // token-side capacity: what geom / tokens / extras / sample_out hold
+    const int64_t tok_cap = (f->tok_capacity > 0 && f->tok_capacity < f->capacity) ? f->tok_capacity : f->capacity;
     const auto host_t0 = std::chrono::steady_clock::now();
     static int cur_slot = -1;          // guarded by g_frame_mu; phase 2 of a split call reuses phase 1's slot
 #define SHERF_PROF(j, strm) do { if (cur_slot >= 0) SHERF_HIP_CHECK(hipEventRecord(g_prof_ev[cur_slot][j], strm)); } while (0)
@@ -190,7 +204,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
         SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
         if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
-        int64_t cap = f->capacity;
+        int64_t cap = tok_cap;
         if (exact) {
             SHERF_HIP_CHECK(hipEventSynchronize(d.ev_cnt));
             int64_t c = *d.host_nv > 0 ? ((int64_t)*d.host_nv + 255) / 256 * 256 : 256;      // whole MLP tile groups
@@ -252,8 +266,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
     }
     if (phase & 2) {
         // ---- a15-a16 ----
-        SHERF_RUN(sherf_composite_compact(f->counters, f->ray_base, f->ray_cnt, f->cs_idx, f->sample_out, f->ray_d, f->near, f->far,
-                                          f->R, f->S, f->white_back, f->rgb, f->depth, f->acc, stream_main));
+        SHERF_RUN(sherf_composite_compact_cap(f->counters, f->ray_base, f->ray_cnt, f->cs_idx, f->sample_out, f->ray_d, f->near, f->far,
+                                              f->R, f->S, f->white_back, tok_cap, f->rgb, f->depth, f->acc, stream_main));
         SHERF_PROF(6, main);
         if (cur_slot >= 0) {
             std::lock_guard<std::mutex> lk(g_mu);

@@ -177,6 +177,7 @@ class _Workspace:
         self.bn = {}
         self.desc = None
         self.stacked = None
+        self.tok_cap = 0
 
     def frame(self, R, S, cap, dev):
         key = (R, S, cap, str(dev))
@@ -185,14 +186,11 @@ class _Workspace:
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         nch = (S + 63) // 64
-        tiles = (cap + 31) // 32 + 8
         t = dict(
             counters=torch.zeros(4, **i32), ray_base=torch.zeros(R, **i32), ray_cnt=torch.zeros(R, **i32),
             cs_idx=torch.zeros(cap, **i32), cs_vid=torch.zeros(cap, **i32), cs_tvid=torch.zeros(cap, **i32),
             cs_xs=torch.zeros(cap, 4, **f32), dense_vid=torch.zeros(R * S, **i32),
             ray_mask=torch.zeros(R * nch, dtype=torch.int64, device=dev), scan_ws=torch.zeros(R + R // 1024 + 2, **i32),
-            geom=torch.zeros(cap, 8, **f32), tokens=torch.zeros(tiles * 3 * 8 * 32 * 4, **f32),
-            extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(cap, 4, **f32),
             A=torch.zeros(3, 24, 12, **f32), posefeat=torch.zeros(3, 207, **f32), PO=torch.zeros(3, V, 3, **f32),
             SO=torch.zeros(3, V, 3, **f32), T2C=torch.zeros(V, 12, **f32), C2S=torch.zeros(V, 12, **f32),
             grid_hdr=torch.zeros(2, 12, **f32), cell_start=torch.zeros(2, 64 * 64 * 64 + 1, **i32),
@@ -204,7 +202,34 @@ class _Workspace:
         )
         self.key, self.t = key, t
         self.desc = None
+        self.tok_cap = 0
+        self.tokens(min(cap, 256), dev)                   # (placeholders until the frame's own count is known: renderer._token_capacity)
         return t
+
+    def tokens(self, tok_cap, dev):
+        """The token-side buffers -- geom (32 B), tokens + extras (432 B), sample_out (16 B per sample) -- for `tok_cap` compact samples:
+        480 of the workspace's ~510 bytes per sample, sized from the frame's OWN number of valid samples (a body fills 4-8 % of
+        R * S) instead of the worst case."""
+        if tok_cap == self.tok_cap:
+            return
+        f32 = dict(dtype=torch.float32, device=dev)
+        tiles = (tok_cap + 31) // 32 + 8
+        for k in ('geom', 'tokens', 'extras', 'sample_out', 'zfrag'):
+            self.t.pop(k, None)                           # (free first: the new set may not fit beside the old one)
+        self.t.update(geom=torch.zeros(tok_cap, 8, **f32), tokens=torch.zeros(tiles * 3 * 8 * 32 * 4, **f32),
+                      extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(tok_cap, 4, **f32))
+        self.tok_cap = tok_cap
+        if self.desc is not None:                         # the cached descriptor follows (its other fields stay as they are)
+            fr = self.desc[2]
+            for k in ('geom', 'tokens', 'extras', 'sample_out'):
+                setattr(fr, k, _lib.addr(self.t[k]))
+
+    def nbytes(self):
+        seen, n = set(), 0
+        for v in list(self.t.values()) + list(self.bn.values()):
+            if torch.is_tensor(v) and v.untyped_storage().data_ptr() not in seen:
+                seen.add(v.untyped_storage().data_ptr()); n += v.untyped_storage().nbytes()
+        return n
 
     STATIC_FIELDS = ('A', 'posefeat', 'PO', 'SO', 'T2C', 'C2S', 'grid_hdr', 'cell_start', 'cell_pts', 'cell_scratch', 'near_mask',
                      'counters', 'ray_base', 'ray_cnt', 'cs_idx', 'cs_vid', 'cs_xs', 'dense_vid', 'ray_mask', 'scan_ws', 'geom',
@@ -320,6 +345,10 @@ class ImportanceRenderer(nn.Module):
         # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
         # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
         self.mlp_parts = int(os.environ.get('SHERF_MLP_PARTS', '0'))
+        # token-side workspace (geom / tokens / extras / sample_out: 480 B per compact sample): 'auto' = sized from the frame's own number
+        # of valid samples (first frame: the sampler alone + one host wait; later frames: the counts of finished frames, read without a
+        # wait, grow it ahead of need), 'worst' = R * S as in rounds 1-3 (8 GB at 512 x 512 x 64), or a number of samples
+        self.token_capacity = os.environ.get('SHERF_TOKEN_CAPACITY', 'auto')
         self.main_after_layer = int(os.environ.get('SHERF_MAIN_AFTER_LAYER', '-1'))   # stream scheduling, see sherf_frame
         self.aux_stream = os.environ.get('SHERF_AUX_STREAM', '1') == '1'           # voxel level structure on a third stream
         self._smpl_src = smpl
@@ -435,7 +464,7 @@ class ImportanceRenderer(nn.Module):
     def check_finite(self):
         """True unless the MLP kernel of the LAST frame produced a non-finite sigma / rgb (its fp16 operand modes overflow beyond
         65504: csrc/mlp.hip sets counters[3]).  Synchronises with the frame; call it when validating a checkpoint, not per frame."""
-        return self.last is None or (int(self.last['ws']['counters'][3]) & 1) == 0
+        return self.last is None or (int(self.last['ws']['counters'][3]) & 3) == 0      # (bit 1: the token-side workspace overflowed)
 
     # ---- `auto` stays honest after its calibration (VERDICT round 3, item 7a) --------------------------------------------------
     AUTO_RECHECK_EVERY = int(os.environ.get('SHERF_AUTO_RECHECK', '256'))     # frames between re-calibrations of a kept choice (3 extra frames each)
@@ -455,29 +484,64 @@ class ImportanceRenderer(nn.Module):
         is copied to pinned memory behind the frame and read a few frames later, once its event has passed.  A trip drops the
         calibrated choice (the next frame re-calibrates, i.e. renders in the fp32-grade configuration) and is reported once."""
         st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
-        if dev.type != 'cuda' or getattr(ws['counters'], 'device', dev).type != 'cuda':      # host build of the tests: read directly
-            if int(ws['counters'][3]) & 1:
+
+        def note(c):                                       # c = (valid samples, ., ., flags) of a finished frame
+            if c[3] & 1:
                 st['tripped'] += 1
+            if c[3] & 2:                                   # more valid samples than the token-side workspace held: NaN rays in that frame
+                st['overflowed'] = st.get('overflowed', 0) + 1
+            st['nv_seen'] = max(st.get('nv_seen', 0), c[0])
+        if dev.type != 'cuda' or getattr(ws['counters'], 'device', dev).type != 'cuda':      # host build of the tests: read directly
+            note(ws['counters'].tolist())
             return st
         ring = st['ring']
         if len(ring) < 4:
-            ring.append(dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
+            ring.append(dict(host=torch.zeros(4, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
             st['next'] = len(ring) - 1
         slot = ring[st.get('next', 0) % len(ring)]
         st['next'] = (st.get('next', 0) + 1) % 4
         if slot['busy']:
             slot['ev'].synchronize()                       # (four frames old: long done)
-            if int(slot['host'][0]) & 1:
-                st['tripped'] += 1
-        slot['host'].copy_(ws['counters'][3:4], non_blocking=True)
+            note(slot['host'].tolist())
+        slot['host'].copy_(ws['counters'], non_blocking=True)
         slot['ev'].record(torch.cuda.current_stream(dev))
         slot['busy'] = True
         for other in ring:                                 # anything already finished is read now
             if other is not slot and other['busy'] and other['ev'].query():
                 other['busy'] = False
-                if int(other['host'][0]) & 1:
-                    st['tripped'] += 1
+                note(other['host'].tolist())
         return st
+
+    TOKEN_HEADROOM = 1.5         # token-side capacity = this x the largest count seen, re-sized when a frame passes TOKEN_GROW_AT of it
+    TOKEN_GROW_AT = 0.8
+
+    TOKEN_GRANULE = 8192
+
+    def _round_tokens(self, n, cap):
+        g = self.TOKEN_GRANULE
+        return int(min(cap, max(g, (int(n) + g - 1) // g * g)))
+
+    def _token_capacity(self, opts, wsp, cap, dev, probe):
+        """Samples the token-side buffers of `wsp` should hold for this frame (see `token_capacity` in __init__).  `probe()` runs the
+        sampler alone and returns the frame's valid-sample count (one host wait): used when the workspace has never seen a frame."""
+        want = opts.get('token_capacity', getattr(self, 'token_capacity', 'auto'))
+        if want in ('worst', None) or (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False)) or getattr(self, '_in_autograd', False):
+            return cap                                     # (training: the backward sizes its own matrices from the count it reads anyway)
+        if want != 'auto':
+            return self._round_tokens(int(want), cap)
+        st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
+        seen = wsp.__dict__.setdefault('nv_sized_for', None)
+        if seen is None:                                   # first frame on this workspace
+            nv = probe()
+            wsp.nv_sized_for = nv
+            st['nv_seen'] = 0
+            return self._round_tokens(self.TOKEN_HEADROOM * nv, cap)
+        nv = st.get('nv_seen', 0)
+        if nv > self.TOKEN_GROW_AT * wsp.tok_cap and wsp.tok_cap < cap:
+            wsp.nv_sized_for = nv
+            st['token_regrowths'] = st.get('token_regrowths', 0) + 1
+            return self._round_tokens(self.TOKEN_HEADROOM * nv, cap)
+        return wsp.tok_cap
 
     # ---- weights -----------------------------------------------------------------------------
     def _weights(self, decoder, device, precision=None):
@@ -615,7 +679,7 @@ class ImportanceRenderer(nn.Module):
         fr.zfrag = None
         if split:
             ws = self._workspace(dev)
-            fr.zfrag = _lib.addr(ws.zfrag(int(fr.capacity), cfg[0], dev))
+            fr.zfrag = _lib.addr(ws.zfrag(int(fr.tok_capacity or fr.capacity), cfg[0], dev))
             fr.flags |= 8
         return wc
 
@@ -791,14 +855,25 @@ class ImportanceRenderer(nn.Module):
         keep += [vfeat, vcoord]
         fr.vox_plan = _ct.addressof(pl['plan'])
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
+        levels = (_lib.VoxLevel * 3)()
+        s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
+        s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if self.aux_stream else None
+
+        # token-side workspace: sized from the frame's own count (see _token_capacity)
+        def probe():
+            _lib.call('sherf_render_frame', _ct.byref(fr), 4, levels, s_main, s_side, s_aux)
+            return int(ws['counters'][0])                                # (one host wait, once per workspace)
+        tok = self._token_capacity(opts, wsp, cap, dev, probe)
+        if tok != wsp.tok_cap:
+            if dev.type == 'cuda' and not isinstance(ws['counters'], type(None)) and ws['counters'].device.type == 'cuda':
+                torch.cuda.synchronize(dev)                              # frames in flight still read the old buffers
+            wsp.tokens(tok, dev)
+        fr.tok_capacity = wsp.tok_cap
         # a13-a14: fused transformer + NeRF decoder
         self._set_config(fr, decoder, dev, cfg, exact)
         fr.mlp_parts = int(opts.get('mlp_parts', getattr(self, 'mlp_parts', 0)))
         fr.white_back = 1 if opts.get('white_back', False) else 0
         fr.main_after_layer = int(opts.get('main_after_layer', self.main_after_layer))
-        levels = (_lib.VoxLevel * 3)()
-        s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
-        s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if self.aux_stream else None
         noise = float(opts.get('density_noise', 0) or 0)
         decide = None
         if calibrate and noise == 0:
@@ -807,7 +882,7 @@ class ImportanceRenderer(nn.Module):
         if noise > 0 or rng is not None:
             _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
             if noise > 0:                                                # renderer.py:435-436 (training only)
-                ws['sample_out'][:, 3] += torch.randn(cap, device=dev) * noise
+                ws['sample_out'][:, 3] += torch.randn(wsp.tok_cap, device=dev) * noise
             if rng is not None:
                 # ray_marcher.py:57 clamps the depth image with the min / max over ALL depths of the frame; when this call renders
                 # only a subset of the frame's rays (ray-tile sharding) the caller supplies the frame-wide range, which replaces
@@ -820,11 +895,11 @@ class ImportanceRenderer(nn.Module):
         self.encoder_3d.finish(pl)
         if decide is not None:
             decide()
-        if cfg[0] != 'f16x3' and not (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False)):
-            self._flag_watch(ws, dev)                      # single-product operands: watch the frame's non-finite flag (no host wait)
+        if not (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False)) and not getattr(self, '_in_autograd', False):
+            self._flag_watch(ws, dev)                      # the frame's count and flags (non-finite fp16 operand, token overflow): no host wait
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_parts=int(fr.mlp_parts),
+        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=wsp.tok_cap, sampler_cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_parts=int(fr.mlp_parts),
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min.reshape(-1)[:3], vox_sh=[int(v) for v in obs_sp_input['out_sh']],

@@ -138,6 +138,7 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 template <class T> inline T atomicAdd(T* p, T v) { return std::atomic_ref<T>(*p).fetch_add(v); }
 inline float unsafeAtomicAdd(float* p, float v) { return std::atomic_ref<float>(*p).fetch_add(v); }
 inline unsigned atomicOr(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_or(v); }
+inline int atomicOr(int* p, int v) { return std::atomic_ref<int>(*p).fetch_or(v); }
 inline unsigned atomicAnd(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_and(v); }
 inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { return std::atomic_ref<unsigned long long>(*p).fetch_or(v); }
 template <class T> inline T atomicMin(T* p, T v) { std::atomic_ref<T> a(*p); T o = a.load(); while (v < o && !a.compare_exchange_weak(o, v)) {} return o; }
