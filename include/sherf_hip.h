@@ -362,6 +362,10 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
 /* frame->flags & SHERF_FRAME_MLP_SPLIT: the per-sample network runs as sherf_nerf_mlp_split (two launches; needs frame->zfrag) instead of
  * sherf_nerf_mlp.  Same results bit for bit; opt-in (measured slower than the one launch on the MI355X: profiles/r04_call_b_mlp_ablations.txt). */
 #define SHERF_FRAME_MLP_SPLIT 8
+/* frame->flags & SHERF_FRAME_REPORT_COUNT: counters[0] (the frame's valid samples) is copied to pinned memory right behind the sampler
+ * and sherf_frame_count() returns it after waiting for THAT point of the frame only -- the warp, gather, network and compositing are
+ * still in flight.  What a caller uses to check tok_capacity on a frame with new inputs without draining the GPU. */
+#define SHERF_FRAME_REPORT_COUNT 16
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */
@@ -400,6 +404,9 @@ typedef struct {
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);
+/* The valid-sample count of the last frame this process enqueued on the current device with SHERF_FRAME_REPORT_COUNT (waits for the
+ * sampler of that frame, not for the frame). */
+int sherf_frame_count(int32_t* nv_host);
 /* phase: 1 = everything up to the per-sample network, 2 = compositing, 3 = both; 4 (alone) = the sampler only (cell lists, shell mask,
  * nearest vertex, compaction: counters[0] = the frame's number of valid samples) -- what a caller runs once to size tok_capacity. */
 /* stream_aux (may be NULL): a third stream on which the occupancy structure of voxel levels 1-3 is built while the

@@ -27,6 +27,8 @@ struct DevState {
     bool init = false;
     hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8], ev_cnt, ev_part[kMaxParts], ev_mlp;
     int32_t* host_nv = nullptr;      // pinned: the frame's valid-sample count for SHERF_FRAME_EXACT_GRIDS
+    hipEvent_t ev_rep[8];            // SHERF_FRAME_REPORT_COUNT: a ring of (pinned word, event) pairs; host_nv[8 + slot]
+    int rep_next = 0, rep_last = -1;
 };
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
@@ -83,6 +85,19 @@ extern "C" int sherf_profile_frames_read(float* ms_host, int32_t max_n, int32_t*
     return SHERF_OK;
 }
 
+extern "C" int sherf_frame_count(int32_t* nv_host) {
+    SHERF_CHECK_ARG(nv_host);
+    int dev = 0;
+    SHERF_HIP_CHECK(hipGetDevice(&dev));
+    SHERF_CHECK_ARG(dev >= 0 && dev < kMaxDev);
+    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    DevState& d = g_dev[dev];
+    SHERF_CHECK_ARG(d.init && d.rep_last >= 0);
+    SHERF_HIP_CHECK(hipEventSynchronize(d.ev_rep[d.rep_last]));
+    *nv_host = d.host_nv[8 + d.rep_last];
+    return SHERF_OK;
+}
+
 extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
                                   sherf_stream_t stream_side, sherf_stream_t stream_aux) {
     SHERF_CHECK_ARG(f && levels && ((phase & 3) || phase == 4) && stream_side != stream_main && (!stream_aux || (stream_aux != stream_main && stream_aux != stream_side)));
@@ -123,6 +138,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                 for (int k = 0; k < kMaxParts; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_part[k], hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mlp, hipEventDisableTiming));
                 SHERF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d.host_nv), 64, 0));
+                for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_rep[k], hipEventDisableTiming));
                 d.init = true;
             }
         }
@@ -194,6 +210,13 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         // copied to pinned memory here and awaited just before the warp is enqueued -- the one host synchronisation of this mode (the
         // reference synchronises at the same point: its boolean-mask indexing, renderer.py:320-321); the encoder chain and the table
         // folds are enqueued in between and keep the GPU busy meanwhile.  Same results: every kernel clamps to min(count, capacity).
+        if (f->flags & SHERF_FRAME_REPORT_COUNT) {
+            const int slot = d.rep_next;
+            d.rep_next = (d.rep_next + 1) % 8;
+            SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv + 8 + slot, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));
+            SHERF_HIP_CHECK(hipEventRecord(d.ev_rep[slot], main));
+            d.rep_last = slot;
+        }
         const bool exact = (f->flags & SHERF_FRAME_EXACT_GRIDS) != 0;
         if (exact) {
             SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));

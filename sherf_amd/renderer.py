@@ -669,7 +669,7 @@ class ImportanceRenderer(nn.Module):
         wc = self._weights(decoder, dev, cfg[0])
         fr.wstream, fr.wbias = _lib.addr(wc['stream']), _lib.addr(wc['wbias'])
         fr.mlp_prec = MLP_PRECISIONS[cfg[0]]
-        fr.flags = (1 if exact else 0) | (2 if cfg[1] == 'f16' else 0) | (4 if cfg[2] == 'f16' else 0)
+        fr.flags = (1 if exact else 0) | (2 if cfg[1] == 'f16' else 0) | (4 if cfg[2] == 'f16' else 0) | (16 if self.__dict__.get('_opt_report_count') else 0)
         # the two-launch form of the per-sample network (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel, bit-identical results):
         # opt-in.  Measured SLOWER than the one-launch kernel on the MI355X in every precision (f16, 512x512x64: 0.35 vs 0.285 ms at 4 %
         # valid samples, 0.62 vs 0.51 ms at 7.6 %; profiles/r04_call_b_mlp_ablations.txt) -- see csrc/mlp.hip for why
@@ -863,7 +863,17 @@ class ImportanceRenderer(nn.Module):
         def probe():
             _lib.call('sherf_render_frame', _ct.byref(fr), 4, levels, s_main, s_side, s_aux)
             return int(ws['counters'][0])                                # (one host wait, once per workspace)
+        first = wsp.__dict__.get('nv_sized_for') is None
         tok = self._token_capacity(opts, wsp, cap, dev, probe)
+        # a frame whose rays / vertices are not the previous frame's tensors may hold any number of valid samples: its count is read back
+        # right behind the sampler (the rest of the frame stays in flight) and the frame is rendered again if it did not fit.  Frames on the
+        # same inputs (a benchmark loop) and slowly changing sequences on explicit / worst-case capacities never wait.
+        scene = (input_data['vertices'].data_ptr(), input_data['vertices']._version, ray_origins.data_ptr(), ray_origins._version,
+                 near.data_ptr(), near._version, far.data_ptr(), far._version)
+        verify = (not first and wsp.__dict__.get('scene') != scene and wsp.tok_cap < cap
+                  and opts.get('token_capacity', getattr(self, 'token_capacity', 'auto')) == 'auto' and tok < cap)
+        wsp.scene = scene
+        self.__dict__['_opt_report_count'] = verify
         if tok != wsp.tok_cap:
             if dev.type == 'cuda' and not isinstance(ws['counters'], type(None)) and ws['counters'].device.type == 'cuda':
                 torch.cuda.synchronize(dev)                              # frames in flight still read the old buffers
@@ -879,19 +889,36 @@ class ImportanceRenderer(nn.Module):
         if calibrate and noise == 0:
             decide = self._calibrate(fr, decoder, dev, ws, levels, (s_main, s_side, s_aux), exact)
         rng = opts.get('depth_range')                                    # sherf_amd.dist: [lo, hi] of the WHOLE frame's depths
-        if noise > 0 or rng is not None:
-            _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
-            if noise > 0:                                                # renderer.py:435-436 (training only)
-                ws['sample_out'][:, 3] += torch.randn(wsp.tok_cap, device=dev) * noise
-            if rng is not None:
-                # ray_marcher.py:57 clamps the depth image with the min / max over ALL depths of the frame; when this call renders
-                # only a subset of the frame's rays (ray-tile sharding) the caller supplies the frame-wide range, which replaces
-                # the subset's own in the counters the compositing kernel reads (order-preserving int encoding, csrc/common.h: f2ord)
-                bits = torch.as_tensor(rng, dtype=torch.float32, device=dev).reshape(2).contiguous().view(torch.int32)
-                ws['counters'][1:3] = torch.where(bits >= 0, bits, bits ^ 0x7FFFFFFF)
-            _lib.call('sherf_render_frame', _ct.byref(fr), 2, levels, s_main, s_side, s_aux)
-        else:
-            _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side, s_aux)
+
+        def enqueue():
+            if noise > 0 or rng is not None:
+                _lib.call('sherf_render_frame', _ct.byref(fr), 1, levels, s_main, s_side, s_aux)
+                if noise > 0:                                            # renderer.py:435-436 (training only)
+                    ws['sample_out'][:, 3] += torch.randn(wsp.tok_cap, device=dev) * noise
+                if rng is not None:
+                    # ray_marcher.py:57 clamps the depth image with the min / max over ALL depths of the frame; when this call renders
+                    # only a subset of the frame's rays (ray-tile sharding) the caller supplies the frame-wide range, which replaces
+                    # the subset's own in the counters the compositing kernel reads (order-preserving int encoding, csrc/common.h: f2ord)
+                    bits = torch.as_tensor(rng, dtype=torch.float32, device=dev).reshape(2).contiguous().view(torch.int32)
+                    ws['counters'][1:3] = torch.where(bits >= 0, bits, bits ^ 0x7FFFFFFF)
+                _lib.call('sherf_render_frame', _ct.byref(fr), 2, levels, s_main, s_side, s_aux)
+            else:
+                _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, s_main, s_side, s_aux)
+        enqueue()
+        if verify:
+            nv_now = _ct.c_int32(0)
+            _lib.call('sherf_frame_count', _ct.byref(nv_now))            # waits for this frame's sampler only
+            if nv_now.value > wsp.tok_cap:
+                if dev.type == 'cuda' and ws['counters'].device.type == 'cuda':
+                    torch.cuda.synchronize(dev)
+                wsp.tokens(self._round_tokens(self.TOKEN_HEADROOM * nv_now.value, cap), dev)
+                wsp.nv_sized_for = nv_now.value
+                fr.tok_capacity = wsp.tok_cap
+                if fr.zfrag:
+                    fr.zfrag = _lib.addr(wsp.zfrag(int(fr.tok_capacity), cfg[0], dev))
+                st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
+                st['token_rerenders'] = st.get('token_rerenders', 0) + 1
+                enqueue()
         self.encoder_3d.finish(pl)
         if decide is not None:
             decide()

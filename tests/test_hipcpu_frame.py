@@ -141,6 +141,22 @@ def test_token_workspace_is_sized_from_the_frame(cpu_product):
         for k in ('rgb', 'depth', 'acc'):
             assert torch.equal(again[k], worst[k]), k
         assert rend.check_finite()
+        # other inputs under the same workspace (new ray / vertex tensors): the frame's count is read right behind its sampler and the frame
+        # rendered again if it did not fit -- first a frame with few valid samples (rays cut short), then the full one, 3 x its size
+        import copy
+        fx_short = copy.deepcopy(dict(G.fixture('tiny_nv')))
+        d = fx_short['input_data']
+        d['far_all'] = (d['near_all'] + 0.3 * (d['far_all'] - d['near_all'])).astype(d['far_all'].dtype)
+        wsp.nv_sized_for = None
+        short = G.hip_render('tiny_nv', fx=fx_short)
+        nv_short = int(short['last']['ws']['counters'][0])
+        assert 0 < nv_short < nv / 1.6 and short['last']['cap'] < nv
+        before = rend._flags.get('token_rerenders', 0)
+        full = G.hip_render('tiny_nv')
+        assert rend._flags.get('token_rerenders', 0) == before + 1 and full['last']['cap'] >= nv
+        for k in ('rgb', 'depth', 'acc'):
+            assert torch.equal(full[k], worst[k]), k
+        assert rend.check_finite()
     finally:
         del rend.TOKEN_GRANULE
         G.hip_modules.cache_clear()
