@@ -257,9 +257,12 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
         if (mode == 2) { for (int s_ = 0; s_ < 3; ++s_) acc[s_].a = acc[s_].b = make_float4(0.f, 0.f, 0.f, 0.f); }
         else { for (int s_ = 0; s_ < 3; ++s_) { acc[s_].a = tok_bias[8 * s_ + 2 * l]; acc[s_].b = tok_bias[8 * s_ + 2 * l + 1]; } }
         float4 rgb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < nv) {
+        const bool valid = c < nv;
+        float xv[3] = {0.f, 0.f, 0.f};                 // x_c for the voxel taps below (outside the divergent branch)
+        if (valid) {
             const float* gm = geom + c * 8;
             const float xc[3] = {gm[0], gm[1], gm[2]};
+            xv[0] = xc[0]; xv[1] = xc[1]; xv[2] = xc[2];
             if (mode != 2) {                                                  // extras rows 0-5 = x_c, v_c: lanes 0-2 write two each
                 if (l < 3) { extras[(tile * 12 + 2 * l) * 32 + j] = gm[2 * l]; extras[(tile * 12 + 2 * l + 1) * 32 + j] = gm[2 * l + 1]; }
             }
@@ -318,47 +321,53 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
                 if (l == 3) { extras[(tile * 12 + 6) * 32 + j] = rgb.x; extras[(tile * 12 + 7) * 32 + j] = rgb.y; }
                 extras[(tile * 12 + 8 + l) * 32 + j] = (l == 0) ? rgb.z : 0.f;
             }
-            if (!(dbg & 4) && mode != 1) {
-                float gz = ((xc[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;
-                float gy = ((xc[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
-                float gx = ((xc[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
-#pragma unroll 1
-                for (int L = 0; L < 3; ++L) {
-                    const sherf_vox_level& lev = lv.l[L];
-                    float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
-                    float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
-                    float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
-                    float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
-                    float fx = px - x0, fy = py - y0, fz = pz - z0;
-                    int xi = (int)x0, yi = (int)y0, zi = (int)z0;
-                    uint2 rec[8];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const int xx = xi + (t & 1), yy = yi + ((t >> 1) & 1), zz = zi + (t >> 2);
-                        const bool inb = xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
-                        const int key = inb ? (zz * lev.H + yy) * lev.W + xx : 0;
-                        const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
-                        const uint32_t bit = 1u << (key & 31);
-                        rec[t] = make_uint2((inb && (rr.x & bit)) ? 1u : 0u, rr.y + __popc(rr.x & (bit - 1u)));
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        if (rec[t].x) {
-                            const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
-                            const size_t r = (size_t)rec[t].y * 12;
-                            axpy8(acc[0], w, lev.rows, r + l);
-                            axpy8(acc[1], w, lev.rows, r + 4 + l);
-                            axpy8(acc[2], w, lev.rows, r + 8 + l);
-                        }
-                    }
-                }
-            }
         } else {
             for (int s_ = 0; s_ < 3; ++s_) acc[s_].a = acc[s_].b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (mode != 2) {                               // padding columns of the last tile
                 if (l < 3) { extras[(tile * 12 + 2 * l) * 32 + j] = 0.f; extras[(tile * 12 + 2 * l + 1) * 32 + j] = 0.f; }
                 if (l == 3) { extras[(tile * 12 + 6) * 32 + j] = 0.f; extras[(tile * 12 + 7) * 32 + j] = 0.f; }
                 extras[(tile * 12 + 8 + l) * 32 + j] = 0.f;
+            }
+        }
+        // voxel taps (a11's three tapped levels).  A sample's four lanes need the same eight corner look-ups per level ((word, prefix) of
+        // the level's bitmap -> present?, row): lane l makes TWO of them (corners 2l, 2l + 1) and the quad exchanges the results -- a
+        // third of this kernel's load instructions were those look-ups repeated four times over (round 4).  Outside the `valid` branch:
+        // the exchange is a wave-level operation (invalid lanes look nothing up and add nothing).
+        if (!(dbg & 4) && mode != 1) {
+            const float gz = ((xv[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;
+            const float gy = ((xv[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
+            const float gx = ((xv[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
+            const int quad0 = (threadIdx.x & 63) & ~3;
+#pragma unroll 1
+            for (int L = 0; L < 3; ++L) {
+                const sherf_vox_level& lev = lv.l[L];
+                float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
+                float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
+                float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                float fx = px - x0, fy = py - y0, fz = pz - z0;
+                int xi = (int)x0, yi = (int)y0, zi = (int)z0;
+                int mine[2];                               // corner 2l + u: row index, or -1 if the voxel is absent
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int xx = xi + u, yy = yi + (l & 1), zz = zi + (l >> 1);
+                    const bool inb = valid && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
+                    const int key = inb ? (zz * lev.H + yy) * lev.W + xx : 0;
+                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                    const uint32_t bit = 1u << (key & 31);
+                    mine[u] = (inb && (rr.x & bit)) ? (int)(rr.y + __popc(rr.x & (bit - 1u))) : -1;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = __shfl(mine[t & 1], quad0 | (t >> 1));
+                    if (row >= 0) {
+                        const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
+                        const size_t r = (size_t)row * 12;
+                        axpy8(acc[0], w, lev.rows, r + l);
+                        axpy8(acc[1], w, lev.rows, r + 4 + l);
+                        axpy8(acc[2], w, lev.rows, r + 8 + l);
+                    }
+                }
             }
         }
         // tokens[tile][slot][quad][j] (float4): this lane owns quads 2l and 2l + 1 of every slot
