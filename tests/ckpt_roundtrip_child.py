@@ -68,6 +68,7 @@ def write(out_dir):
     # the back-face test of the per-vertex features uses the reference's ill-defined vertex normals (renderer.py:50-63: index assignment
     # with duplicate indices); computed ONCE here and handed to the reader, so both sides cull the same vertices
     normals = R.compute_normal(d['obs_vertices'].reshape(1, -1, 3), G.renderer.SMPL_NEUTRAL['f'])
+    R.compute_normal = lambda vertices, faces: normals       # (two evaluations of the ill-defined function need not agree: this render uses the SAME one)
     a = render(G, d)
     snapshot(G, os.path.join(out_dir, 'network-snapshot-000000.pkl'))
     torch.save(dict(image=a['image'], image_raw=a['image_raw'], weights=a['weights_image'], normals=normals,
