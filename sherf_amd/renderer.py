@@ -512,6 +512,22 @@ class ImportanceRenderer(nn.Module):
                 note(other['host'].tolist())
         return st
 
+    def poll_flags(self, wait=False):
+        """The watch's state (`tripped`, `overflowed`, `nv_seen`, ...) after reading every finished frame's counters; wait=True waits for
+        the frames still in flight first."""
+        st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
+        for slot in st['ring']:
+            if slot['busy'] and (wait or slot['ev'].query()):
+                slot['ev'].synchronize()
+                slot['busy'] = False
+                c = slot['host'].tolist()
+                if c[3] & 1:
+                    st['tripped'] += 1
+                if c[3] & 2:
+                    st['overflowed'] = st.get('overflowed', 0) + 1
+                st['nv_seen'] = max(st.get('nv_seen', 0), c[0])
+        return st
+
     TOKEN_HEADROOM = 1.5         # token-side capacity = this x the largest count seen, re-sized when a frame passes TOKEN_GROW_AT of it
     TOKEN_GROW_AT = 0.8
 

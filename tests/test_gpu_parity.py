@@ -521,3 +521,12 @@ def test_full_size_frame_properties(cfg, precision):
     ("_ri") in the configurations `auto` picks from -- single fp16 products, fp16 tables, and ("+enc16": round 4, the headline configuration
     of bench.py) single-product sparse convolutions as well -- within 1e-3 of the fp32 oracle outright."""
     _full_size_properties(cfg, 15, precision=precision)
+
+
+def test_token_workspace_is_sized_from_the_frame_on_device():
+    """The token-side workspace policy with the real HIP runtime underneath (pinned read-back of the count behind the sampler, events,
+    re-allocation while frames are in flight): first-frame probe, overflow -> NaN rays + flag, growth from finished frames' counts, a frame
+    on new inputs rendered again when it did not fit -- all bit-identical to the worst-case workspace."""
+    from tests.test_hipcpu_frame import check_token_workspace
+    check_token_workspace()
+

@@ -103,9 +103,14 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
 
 
 def test_token_workspace_is_sized_from_the_frame(cpu_product):
+    check_token_workspace()
+
+
+def check_token_workspace():
     """geom / tokens / extras / sample_out (480 of the workspace's ~510 bytes per sample) are sized from the frame's
     own number of valid samples, not R * S: the first frame runs the sampler alone to learn it, later frames grow it from the counts of
-    finished frames; a frame that does not fit renders its rays as NaN and raises the flag instead of compositing memory nobody wrote."""
+    finished frames; a frame that does not fit renders its rays as NaN and raises the flag instead of compositing memory nobody wrote.
+    Shared by the host-build test above and tests/test_gpu_parity.py (pinned count read-back, events: the real HIP runtime)."""
     G.hip_modules.cache_clear()
     rend, dec = G.hip_modules()
     rend.TOKEN_GRANULE = 16
@@ -114,7 +119,7 @@ def test_token_workspace_is_sized_from_the_frame(cpu_product):
         nv = int(worst['last']['ws']['counters'][0])
         R, S = worst['last']['R'], worst['last']['S']
         assert worst['last']['cap'] == R * S and worst['last']['sampler_cap'] == R * S and nv > 100
-        wsp = rend._workspace(torch.device('cpu'))
+        wsp = rend._workspace(torch.device('cpu') if G.CPU_SHIM else torch.device('cuda', torch.cuda.current_device()))
         tok_bytes = lambda: sum(wsp.t[k].numel() * 4 for k in ('geom', 'tokens', 'extras', 'sample_out'))
         big, big_tok = wsp.nbytes(), tok_bytes()
         assert big_tok > 480 * R * S
@@ -124,7 +129,7 @@ def test_token_workspace_is_sized_from_the_frame(cpu_product):
         assert tok_bytes() < 0.06 * big_tok and big - wsp.nbytes() > 0.9 * big_tok          # (the rest of the workspace does not scale with R * S * 480 B)
         for k in ('rgb', 'depth', 'acc'):
             assert torch.equal(auto[k], worst[k]), k
-        assert rend.check_finite() and not rend._flags.get('overflowed')
+        assert rend.check_finite() and not rend.poll_flags(wait=True).get('overflowed')
         # too small on purpose: the rays whose samples lie beyond the capacity are NaN, the others are the same bits, the flag is up
         small = G.hip_render('tiny_nv', options=dict(token_capacity=nv // 2))
         cap = small['last']['cap']
@@ -134,7 +139,7 @@ def test_token_workspace_is_sized_from_the_frame(cpu_product):
         assert 0 < int(lost.sum()) < R
         assert torch.isnan(small['rgb'][lost]).all() and torch.isnan(small['acc'][lost]).all() and torch.isnan(small['depth'][lost]).all()
         assert torch.equal(small['rgb'][~lost], worst['rgb'][~lost]) and torch.equal(small['acc'][~lost], worst['acc'][~lost])
-        assert not rend.check_finite() and rend._flags['overflowed'] >= 1
+        assert not rend.check_finite() and rend.poll_flags(wait=True)['overflowed'] >= 1
         # back on 'auto': the count the watch has seen (nv) exceeds 80 % of the capacity -> the next frame re-sizes before rendering
         again = G.hip_render('tiny_nv')
         assert again['last']['cap'] == (int(1.5 * nv) + 15) // 16 * 16 and rend._flags.get('token_regrowths', 0) >= 1

@@ -64,7 +64,10 @@ def test_training_frame_descriptor_is_complete(stubbed):
     calls, frames = stubbed
     rend, (rgb, depth, acc) = _run(True)
     # one native call enqueues the frame; a train-mode forward then advances the BatchNorm running statistics (one more launch)
-    assert [c[0] for c in calls] == ['sherf_render_frame', 'sherf_svox_bn_running_update']
+    # the first frame on a workspace runs the sampler alone (phase 4) to size the token-side buffers from the frame's own count, then
+    # one native call enqueues the frame
+    assert [c[0] for c in calls] == ['sherf_render_frame', 'sherf_render_frame', 'sherf_svox_bn_running_update']
+    assert [c[1][1] for c in calls[:2]] == [4, 3]
     assert rgb.shape == (1, 1024, 3) and depth.shape == (1, 1024, 1) and acc.shape == (1, 1024, 1)
     fr = frames[-1]
     for name, ctype in fr._fields_:
@@ -89,7 +92,7 @@ def test_density_noise_splits_the_frame_in_two_phases(stubbed, monkeypatch):
     monkeypatch.setattr(torch, 'randn', lambda n, device=None: torch.zeros(n))
     _run(True, dict(density_noise=0.5))
     phases = [c[1][1] for c in calls if c[0] == 'sherf_render_frame']
-    assert phases == [1, 2]
+    assert phases == [4, 1, 2]                 # (4: the first frame's sampler-only probe)
 
 
 def test_backward_glue_dry_run(stubbed, monkeypatch):
