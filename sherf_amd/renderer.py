@@ -188,7 +188,7 @@ class _Workspace:
         nch = (S + 63) // 64
         t = dict(
             counters=torch.zeros(4, **i32), ray_base=torch.zeros(R, **i32), ray_cnt=torch.zeros(R, **i32),
-            cs_idx=torch.zeros(cap, **i32), cs_vid=torch.zeros(cap, **i32), cs_tvid=torch.zeros(cap, **i32),
+            cs_idx=torch.zeros(cap, **i32), cs_vid=torch.zeros(cap, **i32),
             cs_xs=torch.zeros(cap, 4, **f32), dense_vid=torch.zeros(R * S, **i32),
             ray_mask=torch.zeros(R * nch, dtype=torch.int64, device=dev), scan_ws=torch.zeros(R + R // 1024 + 2, **i32),
             A=torch.zeros(3, 24, 12, **f32), posefeat=torch.zeros(3, 207, **f32), PO=torch.zeros(3, V, 3, **f32),
@@ -207,21 +207,22 @@ class _Workspace:
         return t
 
     def tokens(self, tok_cap, dev):
-        """The token-side buffers -- geom (32 B), tokens + extras (432 B), sample_out (16 B per sample) -- for `tok_cap` compact samples:
-        480 of the workspace's ~510 bytes per sample, sized from the frame's OWN number of valid samples (a body fills 4-8 % of
+        """The token-side buffers -- geom (32 B), tokens + extras (432 B), sample_out (16 B), cs_tvid (4 B per sample) -- for `tok_cap` compact
+        samples: 484 of the workspace's ~510 bytes per sample, sized from the frame's OWN number of valid samples (a body fills 4-8 % of
         R * S) instead of the worst case."""
         if tok_cap == self.tok_cap:
             return
         f32 = dict(dtype=torch.float32, device=dev)
         tiles = (tok_cap + 31) // 32 + 8
-        for k in ('geom', 'tokens', 'extras', 'sample_out', 'zfrag'):
+        for k in ('geom', 'tokens', 'extras', 'sample_out', 'cs_tvid', 'zfrag'):
             self.t.pop(k, None)                           # (free first: the new set may not fit beside the old one)
         self.t.update(geom=torch.zeros(tok_cap, 8, **f32), tokens=torch.zeros(tiles * 3 * 8 * 32 * 4, **f32),
-                      extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(tok_cap, 4, **f32))
+                      extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(tok_cap, 4, **f32),
+                      cs_tvid=torch.zeros(tok_cap, dtype=torch.int32, device=dev))
         self.tok_cap = tok_cap
         if self.desc is not None:                         # the cached descriptor follows (its other fields stay as they are)
             fr = self.desc[2]
-            for k in ('geom', 'tokens', 'extras', 'sample_out'):
+            for k in ('geom', 'tokens', 'extras', 'sample_out', 'cs_tvid'):
                 setattr(fr, k, _lib.addr(self.t[k]))
 
     def nbytes(self):

@@ -135,7 +135,7 @@ def check_token_workspace():
         cap = small['last']['cap']
         assert cap < nv
         base, cnt = small['last']['ws']['ray_base'], small['last']['ws']['ray_cnt']
-        lost = (base.long() + cnt.long()) > cap
+        lost = G.plain((base.long() + cnt.long()) > cap)
         assert 0 < int(lost.sum()) < R
         assert torch.isnan(small['rgb'][lost]).all() and torch.isnan(small['acc'][lost]).all() and torch.isnan(small['depth'][lost]).all()
         assert torch.equal(small['rgb'][~lost], worst['rgb'][~lost]) and torch.equal(small['acc'][~lost], worst['acc'][~lost])
