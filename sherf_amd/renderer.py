@@ -551,6 +551,7 @@ class ImportanceRenderer(nn.Module):
         if seen is None:                                   # first frame on this workspace
             nv = probe()
             wsp.nv_sized_for = nv
+            self.poll_flags(wait=True)                     # (the probe waited for the device anyway: counts still in the ring belong to the past)
             st['nv_seen'] = 0
             return self._round_tokens(self.TOKEN_HEADROOM * nv, cap)
         nv = st.get('nv_seen', 0)
