@@ -380,10 +380,21 @@ class ImportanceRenderer(nn.Module):
         sid = (main or torch.cuda.current_stream(dev)).cuda_stream
         if self._ws is None or not isinstance(self._ws, dict):
             self._ws = {}
-        w = self._ws.get((str(dev), sid))
+        key = (str(dev), sid)
+        w = self._ws.pop(key, None)
         if w is None:
-            w = self._ws[(str(dev), sid)] = _Workspace()
+            w = _Workspace()
+            # streams come and go, workspaces are gigabytes: at most MAX_WORKSPACES stay (least recently used goes; its frames are
+            # waited for first -- a caller that creates a fresh stream per frame pays that wait instead of leaking a workspace per stream)
+            while len(self._ws) >= self.MAX_WORKSPACES:
+                old_key = next(iter(self._ws))
+                if dev.type == 'cuda' and torch.cuda.is_available():
+                    torch.cuda.synchronize(dev)
+                del self._ws[old_key]
+        self._ws[key] = w                                    # (re-inserted: dict order = recency)
         return w
+
+    MAX_WORKSPACES = 4
 
     def _side(self, dev, idx=0):
         # ONE pair of side streams per device for every renderer of the process: HIP multiplexes streams onto 4 hardware queues, and a
@@ -391,10 +402,15 @@ class ImportanceRenderer(nn.Module):
         # ray side ran one after the other (3.1 instead of 1.9 ms per frame, profiles/r02_cfg3_as_headline.txt).  Frames of different
         # renderers are serialised by the native driver anyway.
         key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # one pair per caller stream (see _workspace)
-        cur = _SIDE_STREAMS.get(key)
+        cur = _SIDE_STREAMS.pop(key, None)
         if cur is None:
             # the short serial chains get dispatch priority over the ray side's big kernels
-            _SIDE_STREAMS[key] = cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+            cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+            while len(_SIDE_STREAMS) >= 4 * self.MAX_WORKSPACES:     # bounded like the workspaces (streams of callers long gone)
+                old = _SIDE_STREAMS.pop(next(iter(_SIDE_STREAMS)))
+                for st in old:
+                    st.synchronize()
+        _SIDE_STREAMS[key] = cur
         return cur[idx]
 
     # ---- SMPL --------------------------------------------------------------------------------

@@ -211,3 +211,20 @@ def test_bench_pmc_traffic_parses_counter_csv_and_reports_failures(monkeypatch, 
         raise subprocess.TimeoutExpired(cmd, 1)
     monkeypatch.setattr(subprocess, 'run', boom)
     assert 'error' in bench.pmc_traffic(a, 0)
+
+
+def test_workspaces_are_bounded_per_renderer():
+    """a caller that creates fresh streams must not leak one multi-gigabyte workspace per stream: the least recently used
+    goes once MAX_WORKSPACES exist; a stream that keeps rendering keeps its own."""
+    from sherf_amd.renderer import ImportanceRenderer
+    rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=G.smpl())
+    dev = torch.device('cpu')
+    S = lambda sid: type('X', (), {'cuda_stream': sid})()
+    first = rend._workspace(dev, main=S(100))
+    for sid in range(101, 101 + rend.MAX_WORKSPACES - 1):
+        rend._workspace(dev, main=S(sid))
+    assert rend._workspace(dev, main=S(100)) is first and len(rend._ws) == rend.MAX_WORKSPACES      # touched: most recent again
+    rend._workspace(dev, main=S(999))                                                                # evicts stream 101's, not 100's
+    assert len(rend._ws) == rend.MAX_WORKSPACES and rend._workspace(dev, main=S(100)) is first
+    assert (str(dev), 101) not in rend._ws
+
