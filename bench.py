@@ -136,14 +136,20 @@ def render_frame(w):
                          d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, w['opts'])
 
 
-def time_frames(w, steps, warmup, dev):
-    """ms per frame of `steps` back-to-back frames after `warmup` (device synchronised on both sides)."""
-    for _ in range(warmup):
-        render_frame(w)
+def time_frames(w, steps, warmup, dev, streams=None):
+    """ms per frame of `steps` back-to-back frames after `warmup` (device synchronised on both sides); `streams`: a list of caller streams
+    the frames are issued on round-robin (None: the current stream, one frame in flight)."""
+    def frame(i):
+        if not streams:
+            return render_frame(w)
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return render_frame(w)
+    for i in range(warmup):
+        frame(i)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        render_frame(w)
+    for i in range(steps):
+        frame(i)
     torch.cuda.synchronize(dev)
     return 1e3 * (time.perf_counter() - t0) / steps
 
@@ -233,8 +239,13 @@ def secondary_measurements(a, w, dev, nv, R):
             S = w2['opts']['depth_resolution']
             names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done', 'mlp_kernel')
             out[cfg] = dict(ms_per_frame=ms, rays_per_s=R / (ms * 1e-3), valid_samples=nv2, valid_fraction=nv2 / (R * S),
-                            mlp_precision=w2['rend'].last.get('mlp_precision'),
+                            mlp_precision=w2['rend'].last.get('mlp_precision'), frames_in_flight=1,
                             frame_timeline_ms={k: round(float(v), 4) for k, v in zip(names, prof.mean(0))} if len(prof) else None)
+            if int(getattr(a, 'streams', 1)) > 1 and dev.type == 'cuda':      # the same workload issued as the headline is: round-robin on N caller streams
+                sts = [torch.cuda.Stream(device=dev) for _ in range(int(a.streams))]
+                n = int(a.streams)
+                msn = time_frames(w2, max(SECONDARY_ITERS['frames'], 4 * n), 3 * n, dev, streams=sts)
+                out[cfg].update({f'ms_per_frame_{n}_streams': msn, f'rays_per_s_{n}_streams': R / (msn * 1e-3)})
             del w2
         except Exception as ex:
             out[cfg] = dict(error=f'{type(ex).__name__}: {str(ex)[:200]}')
@@ -298,11 +309,14 @@ def main():
                     help='MLP operand precision; auto (the product default) = calibrated per set of weights on the first frame')
     ap.add_argument('--table-precision', default=None, choices=['f32', 'f16'], help='override the folded tables\' format (default: follows the MLP precision)')
     ap.add_argument('--encoder-precision', default=None, choices=['f16x3', 'f16'], help='override the sparse convolutions\' operand precision (default: follows the tables)')
-    ap.add_argument('--streams', type=int, default=1,
+    ap.add_argument('--streams', type=int, default=4,
                     help='caller streams the frames are issued on, round-robin (each frame is one ImportanceRenderer.forward on its '
-                         'stream; every stream has its own workspace).  1 (default) = one frame at a time.  With 2, frame N+1\'s first phase '
-                         'runs under frame N\'s gather and MLP -- measured SLOWER on the MI355X (1.45 vs 1.35 ms per frame: the kernels of the '
-                         'two frames slow each other more than the overlap gains, profiles/r03_streams_overlap.txt), kept as an option')
+                         'stream; every stream has its own workspace).  4 (default since round 4): the low-occupancy first phase of three frames (cell '
+                         'lists, sampling, the encoder\'s chain of small launches) runs under the chip-filling gather / network of a fourth -- the '
+                         'job is then bound by the sum of the chip-filling kernels (dense framing 1.70 -> 1.49 ms per frame, cfg2_ri 1.17 -> 1.05; '
+                         '2 and 3 streams are SLOWER than 1: profiles/r04_call_s_t_caller_streams.txt).  1 = one frame in flight; the roofline and '
+                         'the frame timeline are always measured that way (a second, untimed pass) -- with frames overlapping a launch\'s wall time is '
+                         'not its cost')
     ap.add_argument('--partition', default='views', choices=['views', 'rays'],
                     help='N > 1: views (default, BASELINE config 4: every rank renders its own target view, weak scaling) or rays (ONE frame '
                          'cut into interleaved 1024-ray tiles over the ranks, sherf_amd.dist.ray_tiles: strong scaling, value = the frame\'s '
@@ -373,7 +387,7 @@ def main():
     from sherf_amd import _lib as _abi
     import ctypes as _ct
 
-    n_streams = max(1, int(a.streams))
+    n_streams = max(1, int(a.streams)) if dev.type == 'cuda' else 1       # (the host build of the tests has no streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
     torch.cuda.synchronize(dev)                  # the workload's setup (default stream) is complete before any frame stream starts
     counter = [0]
@@ -446,6 +460,26 @@ def main():
     drain()
     torch.cuda.synchronize()
     prof = np.array(ms[:n_ms.value * 8], dtype=np.float64).reshape(-1, 8)
+    prof_overlap, one_frame = None, None
+    if n_streams > 1:
+        # ONE frame in flight, same process, same workload: the kernels' own durations (what the roofline is about) and the frame's
+        # timeline.  In the timed region above frames of several streams share the chip: a launch's wall time there includes the time it
+        # ceded to other frames' kernels (reported beside it as `..._with_frames_overlapping`).
+        prof_overlap = prof
+        k1 = max(8, min(a.steps, 24))
+        for _ in range(4):
+            frame_on_current_stream()
+        drain(); torch.cuda.synchronize()
+        _abi.call('sherf_profile_frames', 1)
+        t2 = time.perf_counter()
+        for _ in range(k1):
+            frame_on_current_stream()
+        drain(); torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t2
+        _abi.call('sherf_profile_frames_read', ms, 64, _ct.byref(n_ms))
+        _abi.call('sherf_profile_frames', 0)
+        prof = np.array(ms[:n_ms.value * 8], dtype=np.float64).reshape(-1, 8)
+        one_frame = dict(ms_per_step=1e3 * dt1 / k1, rays_per_s=R * k1 / dt1, steps=k1)
     mlp_ms = float(prof[:, 7].mean()) if len(prof) else None
     if rank == 0:
         used = rend.last.get('mlp_precision', a.precision)                  # what `auto` resolved to for these weights
@@ -477,12 +511,22 @@ def main():
                                    # SURVEY 8(d)'s count are folded into the tables by other kernels, the transformer skips the token nobody reads)
                                    executed_mfma_flop=tiles * 374 * 32768 * (3 if used == 'f16x3' else 1),
                                    frac_executed=tiles * 374 * 32768 / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                                   timing='HIP events recorded by the native frame driver around the network\'s launch(es) on their launch stream, mean over the timed frames')
+                                   timing='HIP events recorded by the native frame driver around the network\'s launch(es) on their launch stream, mean over '
+                                          + ('the timed frames' if prof_overlap is None else
+                                             f'{len(prof)} frames rendered ONE AT A TIME right after the timed region (same process, same workload): the kernel\'s own duration; '
+                                             'in the timed region frames of several streams share the chip and a launch\'s wall time includes what it cedes to other frames'))
+            if prof_overlap is not None and len(prof_overlap):
+                res['roofline']['kernel_ms_with_frames_overlapping'] = float(prof_overlap[:, 7].mean())
         if len(prof):
             names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done')
             res['frame_timeline_ms'] = {k: round(float(v), 4) for k, v in zip(names, prof[:, :7].mean(0))}
             res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_alone, 4)          # Python + native enqueue, empty queue
             res['frame_timeline_ms']['host_wall_per_step_in_timed_loop'] = round(1e3 * host_dt / a.steps, 4)   # (includes queue back-pressure)
+            if prof_overlap is not None and len(prof_overlap):
+                res['frame_timeline_ms']['note'] = 'one frame in flight (the pass after the timed region)'
+                res['latency_ms_per_frame_with_frames_overlapping'] = round(float(prof_overlap[:, 6].mean()), 4)
+        if one_frame is not None and world == 1:
+            res['value_one_frame_in_flight'] = one_frame['rays_per_s']; res['ms_per_step_one_frame_in_flight'] = one_frame['ms_per_step']
         if world == 1 and not a.no_secondary:
             res['secondary'] = secondary_measurements(a, w, dev, nv, R)
             dense = res['secondary'].get('cfg2_dense' + ('_ri' if a.config.endswith('_ri') else ''), {})
@@ -490,7 +534,9 @@ def main():
                 dense = dict(rays_per_s=res['value'], ms_per_frame=res['ms_per_step'], valid_fraction=nv / (R * S))
                 wide = res['secondary'].get('cfg2' + ('_ri' if a.config.endswith('_ri') else ''), {})
                 if wide.get('rays_per_s'):               # round 3's headline framing (valid fraction 0.041), for comparison across rounds
-                    res['value_cfg2_wide_framing'] = wide['rays_per_s']; res['ms_per_step_cfg2_wide_framing'] = wide['ms_per_frame']
+                    k = f'rays_per_s_{n_streams}_streams' if n_streams > 1 and f'rays_per_s_{n_streams}_streams' in wide else 'rays_per_s'
+                    res['value_cfg2_wide_framing'] = wide[k]; res['ms_per_step_cfg2_wide_framing'] = R / wide[k] * 1e3
+                    res['value_cfg2_wide_framing_one_frame_in_flight'] = wide['rays_per_s']
             if dense.get('rays_per_s'):                  # the valid-sample fraction SURVEY 8(d) sized the path on (0.076): first class
                 res['value_dense'] = dense['rays_per_s']; res['ms_per_step_dense'] = dense['ms_per_frame']
                 res['valid_fraction_dense'] = dense['valid_fraction']

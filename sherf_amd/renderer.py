@@ -394,7 +394,7 @@ class ImportanceRenderer(nn.Module):
         self._ws[key] = w                                    # (re-inserted: dict order = recency)
         return w
 
-    MAX_WORKSPACES = 4
+    MAX_WORKSPACES = 8
 
     def _side(self, dev, idx=0):
         # ONE pair of side streams per device for every renderer of the process: HIP multiplexes streams onto 4 hardware queues, and a
