@@ -241,11 +241,7 @@ def secondary_measurements(a, w, dev, nv, R):
             out[cfg] = dict(ms_per_frame=ms, rays_per_s=R / (ms * 1e-3), valid_samples=nv2, valid_fraction=nv2 / (R * S),
                             mlp_precision=w2['rend'].last.get('mlp_precision'), frames_in_flight=1,
                             frame_timeline_ms={k: round(float(v), 4) for k, v in zip(names, prof.mean(0))} if len(prof) else None)
-            if int(getattr(a, 'streams', 1)) > 1 and dev.type == 'cuda':      # the same workload issued as the headline is: round-robin on N caller streams
-                sts = [torch.cuda.Stream(device=dev) for _ in range(int(a.streams))]
-                n = int(a.streams)
-                msn = time_frames(w2, max(SECONDARY_ITERS['frames'], 4 * n), 3 * n, dev, streams=sts)
-                out[cfg].update({f'ms_per_frame_{n}_streams': msn, f'rays_per_s_{n}_streams': R / (msn * 1e-3)})
+
             del w2
         except Exception as ex:
             out[cfg] = dict(error=f'{type(ex).__name__}: {str(ex)[:200]}')
@@ -460,26 +456,16 @@ def main():
     drain()
     torch.cuda.synchronize()
     prof = np.array(ms[:n_ms.value * 8], dtype=np.float64).reshape(-1, 8)
+    # With frames of several caller streams in flight the HIP events around a launch measure its WALL time, which includes what it cedes to
+    # the other frames' kernels -- not the kernel's own cost, and the per-frame timeline is a latency, not a schedule.  The roofline, the
+    # timeline and the secondary lines therefore come from a CHILD process that renders one frame at a time (`--streams 1`: this file, same
+    # workload, same box, right after the timed region); in this process they would also be distorted by HIP's mapping of a dozen streams
+    # onto four hardware queues (measured: 2.9 instead of 1.7 ms per frame for one frame in flight after a four-stream run).
     prof_overlap, one_frame = None, None
-    if n_streams > 1:
-        # ONE frame in flight, same process, same workload: the kernels' own durations (what the roofline is about) and the frame's
-        # timeline.  In the timed region above frames of several streams share the chip: a launch's wall time there includes the time it
-        # ceded to other frames' kernels (reported beside it as `..._with_frames_overlapping`).
+    if n_streams > 1 and world == 1 and rank == 0:
         prof_overlap = prof
-        k1 = max(8, min(a.steps, 24))
-        for _ in range(4):
-            frame_on_current_stream()
-        drain(); torch.cuda.synchronize()
-        _abi.call('sherf_profile_frames', 1)
-        t2 = time.perf_counter()
-        for _ in range(k1):
-            frame_on_current_stream()
-        drain(); torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t2
-        _abi.call('sherf_profile_frames_read', ms, 64, _ct.byref(n_ms))
-        _abi.call('sherf_profile_frames', 0)
-        prof = np.array(ms[:n_ms.value * 8], dtype=np.float64).reshape(-1, 8)
-        one_frame = dict(ms_per_step=1e3 * dt1 / k1, rays_per_s=R * k1 / dt1, steps=k1)
+        one_frame = bench_child(a, lrank, ['--streams', '1', '--steps', str(max(8, min(a.steps, 24))), '--warmup', '6']
+                                + (['--no-secondary'] if a.no_secondary else []))
     mlp_ms = float(prof[:, 7].mean()) if len(prof) else None
     if rank == 0:
         used = rend.last.get('mlp_precision', a.precision)                  # what `auto` resolved to for these weights
@@ -499,7 +485,14 @@ def main():
                                # per caller stream: sampler side at R * S, token side (480 B / sample) at 1.5 x the frame's valid samples
                                workspace_bytes=rend._workspace(dev).nbytes(), token_capacity=int(rend.last.get('cap', 0)),
                                sampler_capacity=int(rend.last.get('sampler_cap', 0))))
-        if mlp_ms:
+        if one_frame is not None and isinstance(one_frame.get('roofline'), dict):
+            res['roofline'] = dict(one_frame['roofline'])
+            res['roofline']['timing'] = ('HIP events recorded by the native frame driver around the network\'s launch on its launch stream, mean over the frames of a child run '
+                                         'of this file with ONE frame in flight (--streams 1; same workload, same box, right after the timed region): the kernel\'s own '
+                                         'duration.  In the timed region frames of several streams share the chip: `kernel_ms_with_frames_overlapping` is a launch\'s wall time there')
+            if len(prof_overlap):
+                res['roofline']['kernel_ms_with_frames_overlapping'] = float(prof_overlap[:, 7].mean())
+        elif mlp_ms:
             ach = nv * FLOP_PER_VALID_SAMPLE / (mlp_ms * 1e-3) / 1e12
             two = bool(rend.last.get('mlp_split'))
             tiles = (nv + 31) // 32
@@ -511,24 +504,32 @@ def main():
                                    # SURVEY 8(d)'s count are folded into the tables by other kernels, the transformer skips the token nobody reads)
                                    executed_mfma_flop=tiles * 374 * 32768 * (3 if used == 'f16x3' else 1),
                                    frac_executed=tiles * 374 * 32768 / (mlp_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                                   timing='HIP events recorded by the native frame driver around the network\'s launch(es) on their launch stream, mean over '
-                                          + ('the timed frames' if prof_overlap is None else
-                                             f'{len(prof)} frames rendered ONE AT A TIME right after the timed region (same process, same workload): the kernel\'s own duration; '
-                                             'in the timed region frames of several streams share the chip and a launch\'s wall time includes what it cedes to other frames'))
-            if prof_overlap is not None and len(prof_overlap):
-                res['roofline']['kernel_ms_with_frames_overlapping'] = float(prof_overlap[:, 7].mean())
-        if len(prof):
+                                   timing='HIP events recorded by the native frame driver around the network\'s launch(es) on their launch stream, mean over the timed frames'
+                                          + (' (frames of several caller streams overlap: a launch\'s wall time, not the kernel\'s own duration)' if n_streams > 1 else ''))
+        if one_frame is not None and isinstance(one_frame.get('frame_timeline_ms'), dict):
+            res['frame_timeline_ms'] = dict(one_frame['frame_timeline_ms'], note='one frame in flight (child run with --streams 1)')
+            res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_alone, 4)
+            res['frame_timeline_ms']['host_wall_per_step_in_timed_loop'] = round(1e3 * host_dt / a.steps, 4)
+            if len(prof_overlap):
+                res['latency_ms_per_frame_with_frames_overlapping'] = round(float(prof_overlap[:, 6].mean()), 4)
+            res['value_one_frame_in_flight'] = one_frame.get('value'); res['ms_per_step_one_frame_in_flight'] = one_frame.get('ms_per_step')
+        elif len(prof):
             names = ('host_enqueue', 'smpl_tables_done', 'encoder_done', 'rays_at_encoder_join', 'gather_done', 'mlp_done', 'frame_done')
             res['frame_timeline_ms'] = {k: round(float(v), 4) for k, v in zip(names, prof[:, :7].mean(0))}
             res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_alone, 4)          # Python + native enqueue, empty queue
             res['frame_timeline_ms']['host_wall_per_step_in_timed_loop'] = round(1e3 * host_dt / a.steps, 4)   # (includes queue back-pressure)
-            if prof_overlap is not None and len(prof_overlap):
-                res['frame_timeline_ms']['note'] = 'one frame in flight (the pass after the timed region)'
-                res['latency_ms_per_frame_with_frames_overlapping'] = round(float(prof_overlap[:, 6].mean()), 4)
-        if one_frame is not None and world == 1:
-            res['value_one_frame_in_flight'] = one_frame['rays_per_s']; res['ms_per_step_one_frame_in_flight'] = one_frame['ms_per_step']
+        if one_frame is not None and one_frame.get('error'):
+            res['one_frame_in_flight_child'] = one_frame
         if world == 1 and not a.no_secondary:
-            res['secondary'] = secondary_measurements(a, w, dev, nv, R)
+            if one_frame is not None:                  # (one frame in flight: measured by the child; see above)
+                res['secondary'] = one_frame.get('secondary') or dict(error='no secondary in the child line')
+                ri_ = '_ri' if a.config.endswith('_ri') else ''
+                if a.config.startswith('cfg2_dense'):  # round 3's headline framing issued the way the headline is: N caller streams, its own child
+                    wide_n = bench_child(a, lrank, ['--streams', str(n_streams), '--config', 'cfg2' + ri_, '--steps', str(a.steps), '--warmup', str(max(a.warmup, 3 * n_streams)), '--no-secondary'])
+                    if isinstance(res['secondary'].get('cfg2' + ri_), dict) and wide_n.get('value'):
+                        res['secondary']['cfg2' + ri_].update({f'rays_per_s_{n_streams}_streams': wide_n['value'], f'ms_per_frame_{n_streams}_streams': wide_n['ms_per_step']})
+            else:
+                res['secondary'] = secondary_measurements(a, w, dev, nv, R)
             dense = res['secondary'].get('cfg2_dense' + ('_ri' if a.config.endswith('_ri') else ''), {})
             if a.config.startswith('cfg2_dense'):        # the headline IS the framing SURVEY 8(d) sized the path on (valid fraction 0.076)
                 dense = dict(rays_per_s=res['value'], ms_per_frame=res['ms_per_step'], valid_fraction=nv / (R * S))
@@ -653,6 +654,38 @@ def frame_parity(ours, ref, S, plain=False):
         ok = ok and out['plain_ok']
     out['ok'] = bool(ok)
     return out
+
+
+def bench_child(a, lrank, extra, timeout=400):
+    """This file again in a child process with other flags (same box, same environment) -> its JSON line.  No baselines, no PMC passes, no
+    training step in the child."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['LOCAL_RANK'] = str(lrank)
+    base = ['--config', a.config, '--precision', a.precision, '--bn-mode', a.bn_mode, '--no-cpu-baseline', '--no-torch-gpu-baseline', '--no-pmc', '--no-train']
+    for flag, val in (('--table-precision', a.table_precision), ('--encoder-precision', a.encoder_precision)):
+        if val:
+            base += [flag, val]
+    args, seen = [], set()
+    for tok in extra:                                   # flags in `extra` override the ones inherited from this run
+        args.append(tok)
+        if tok.startswith('--'):
+            seen.add(tok)
+    i, inherited = 0, []
+    while i < len(base):
+        takes_value = i + 1 < len(base) and not base[i + 1].startswith('--')
+        if base[i] not in seen:
+            inherited += base[i:i + (2 if takes_value else 1)]
+        i += 2 if takes_value else 1
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + inherited + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=timeout, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if not line:
+            return dict(error=f'child rc={r.returncode}: {r.stderr.strip()[-300:]}')
+        return json.loads(line[-1])
+    except Exception as ex:
+        return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
 
 
 def train_step_child(lrank, timeout=240):
