@@ -364,7 +364,7 @@ def main():
 
     if os.environ.get('SHERF_DEBUG'):
         from sherf_amd import _lib as _dbg
-        _dbg.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG']))     # ablation runs only (sampler: 1 = no candidates, 2 = every sample)
+        _dbg.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG'], 0))     # ablation runs only (sampler: 1 = no candidates, 2 = every sample)
     rays_mode = world > 1 and a.partition == 'rays'
     w = make_workload(a, 0.4 if rays_mode else 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend, opts = w['rend'], w['opts']
