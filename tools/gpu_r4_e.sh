@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call E: the software-pipelined MLP kernel (sherf_nerf_mlp_pipe) against the one-launch kernel: bit identity, timing, stress
+# round 4, call E (historical: the kernel was removed afterwards, commits 0b79420..23ea087 hold it): the software-pipelined MLP kernel (sherf_nerf_mlp_pipe) against the one-launch kernel: bit identity, timing, stress
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
