@@ -228,3 +228,27 @@ def test_workspaces_are_bounded_per_renderer():
     assert len(rend._ws) == rend.MAX_WORKSPACES and rend._workspace(dev, main=S(100)) is first
     assert (str(dev), 101) not in rend._ws
 
+
+
+def test_bench_child_command_line(monkeypatch):
+    """bench.py's child runs (one frame in flight for the roofline / timeline / secondary lines; the wide framing on N streams): flags given
+    to the child override the ones inherited from the parent's run, everything that must not run twice is switched off."""
+    import argparse
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen['cmd'] = cmd
+        return type('R', (), dict(stdout='noise\n{"value": 1.5, "ms_per_step": 2.0}\n', stderr='', returncode=0))()
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    a = argparse.Namespace(config='cfg2_dense_ri', precision='auto', bn_mode='train', table_precision=None, encoder_precision='f16')
+    out = bench.bench_child(a, 0, ['--streams', '1', '--steps', '12', '--config', 'cfg2_ri', '--no-secondary'])
+    assert out == dict(value=1.5, ms_per_step=2.0)
+    cmd = seen['cmd'][2:]
+    assert cmd.count('--config') == 1 and cmd[cmd.index('--config') + 1] == 'cfg2_ri'            # the child's own value wins
+    assert cmd[cmd.index('--streams') + 1] == '1' and cmd[cmd.index('--encoder-precision') + 1] == 'f16' and '--table-precision' not in cmd
+    for flag in ('--no-cpu-baseline', '--no-torch-gpu-baseline', '--no-pmc', '--no-train', '--no-secondary'):
+        assert flag in cmd
+    monkeypatch.setattr(subprocess, 'run', lambda cmd, **kw: type('R', (), dict(stdout='', stderr='boom', returncode=3))())
+    assert 'error' in bench.bench_child(a, 0, ['--streams', '1'])
