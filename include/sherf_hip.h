@@ -128,15 +128,6 @@ int sherf_warp_geom(const int32_t* counters, const int32_t* cs_idx, const int32_
                     const float* t_verts, const float* tgrid_hdr, const int32_t* tcell_start,
                     const float* tcell_pts, int64_t capacity, float* geom, int32_t* cs_tvid,
                     sherf_stream_t stream);
-/* The same in two launches with the nearest-T-vertex search over near lists of the T-pose grid (sherf_build_near_lists on set 1 of
- * sherf_build_cells2: grid_hdr + 12, cell_pts + 4 n): eight lanes per sample, one exact list per sample whenever its ball (radius = distance
- * to the same-index vertex) is at most 5 cm wide, the plain cell walk on one lane otherwise.  Same geom / cs_tvid bit for bit.  Opt-in
- * (sherf_frame.tnear_hdr / tnear_list). */
-int sherf_warp_geom_lists(const int32_t* counters, const int32_t* cs_idx, const int32_t* cs_vid, const float* cs_xs,
-                          const float* ray_d, int S, const float* Rg, const float* T2C, const float* C2S,
-                          const float* t_verts, const float* tgrid_hdr, const int32_t* tcell_start,
-                          const float* tcell_pts, const int32_t* tnear_hdr, const uint16_t* tnear_list, int64_t capacity,
-                          float* geom, int32_t* cs_tvid, sherf_stream_t stream);
 
 /* Sparse voxel level descriptor used by the gather (a11). All pointers device. */
 typedef struct {
@@ -407,7 +398,6 @@ typedef struct {
     float* rgb; float* depth; float* acc;
     void* zfrag;                /* scratch of sherf_nerf_mlp_split (SHERF_FRAME_MLP_SPLIT), else NULL */
     int32_t* near_hdr; uint16_t* near_list; int64_t near_list_cap;   /* sherf_build_near_lists buffers (NULL: the cell-walk search) */
-    int32_t* tnear_hdr; uint16_t* tnear_list;   /* near lists of the T-pose grid for sherf_warp_geom_lists (NULL: sherf_warp_geom); near_list_cap entries */
     int64_t tok_capacity;       /* samples that geom / tokens / extras / sample_out hold (0: `capacity`).  The sampler's own buffers stay at
                                  * `capacity` (= R * S for the two-pass sampler); a frame with more valid samples than tok_capacity renders the
                                  * rays it cannot hold as NaN and sets counters[3] bit 1 -- the caller sizes from counters[0] (phase 4) */

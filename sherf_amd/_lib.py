@@ -67,7 +67,6 @@ def _frame_fields():
     P('sample_out'); I('white_back', 'main_after_layer')
     P('rgb', 'depth', 'acc', 'zfrag', 'near_hdr', 'near_list')
     f.append(('near_list_cap', _i64))
-    P('tnear_hdr', 'tnear_list')
     f.append(('tok_capacity', _i64))
     return f
 

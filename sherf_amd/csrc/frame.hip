@@ -233,13 +233,6 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             int64_t c = *d.host_nv > 0 ? ((int64_t)*d.host_nv + 255) / 256 * 256 : 256;      // whole MLP tile groups
             if (c < cap) cap = c;
         }
-        if (f->tnear_hdr && f->tnear_list) {            // opt-in: the T-vertex search over near lists of the T-pose grid, eight lanes per sample
-            SHERF_RUN(sherf_build_near_lists(f->grid_hdr + kGridHdr, f->cell_pts + (size_t)V * 4, V, 0.05f, f->tnear_hdr, f->tnear_list,
-                                             f->near_list_cap, nullptr, stream_main));
-            SHERF_RUN(sherf_warp_geom_lists(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
-                                            f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, f->tnear_hdr,
-                                            f->tnear_list, cap, f->geom, f->cs_tvid, stream_main));
-        } else
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
                                   f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, cap, f->geom,
                                   f->cs_tvid, stream_main));

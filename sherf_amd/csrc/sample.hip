@@ -891,107 +891,6 @@ __global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restric
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// The warp in two launches, its nearest-T-vertex search over near lists (round 4, opt-in: sherf_warp_geom with tnear_hdr / tnear_list).
-// warp_geom_kernel searches per THREAD: a wave runs as long as its longest ball, and finding point t of the concatenated cell rows costs
-// the same nine-way select the candidate search was bound by.  Here launch A does the per-sample arithmetic up to the search radius,
-// launch B searches with EIGHT lanes per sample over the exact list of the sample's sub-cell in the T-pose grid (built like the posed
-// grid's lists: every vertex within 5 cm of the sub-cell's box), valid whenever the radius -- the distance to the same-index vertex --
-// is at most 5 cm; a wider ball (rare: strongly non-rigid blends) takes nn_search_batched on one lane.  The same lexicographic
-// (d^2, id) minimum over a superset of the ball: identical ids.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) warp_pre_kernel(const int32_t* __restrict__ counters, const int32_t* __restrict__ cs_idx,
-                                                       const int32_t* __restrict__ cs_vid, const float4* __restrict__ cs_xs,
-                                                       const float* __restrict__ ray_d, int S, const float* __restrict__ Rg,
-                                                       const float* __restrict__ T2C, const float* __restrict__ t_verts, int64_t capacity,
-                                                       float* __restrict__ geom) {
-    const int64_t nv = min((int64_t)counters[0], capacity);
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nv; c += (int64_t)gridDim.x * 256) {
-        const int ray = cs_idx[c] / S;
-        const int vid = cs_vid[c];
-        const float4 xs = cs_xs[c];
-        float vx, vy, vz;
-        rot_only(ray_d[ray * 3], ray_d[ray * 3 + 1], ray_d[ray * 3 + 2], Rg, vx, vy, vz);   // renderer.py:310
-        const float4* P4 = reinterpret_cast<const float4*>(T2C) + (size_t)vid * 3;
-        const float4 pa = P4[0], pb = P4[1], pc = P4[2];
-        const float P[12] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w, pc.x, pc.y, pc.z, pc.w};
-        float xc = P[0] * xs.x + P[1] * xs.y + P[2] * xs.z + P[9];
-        float yc = P[3] * xs.x + P[4] * xs.y + P[5] * xs.z + P[10];
-        float zc = P[6] * xs.x + P[7] * xs.y + P[8] * xs.z + P[11];
-        float ux = P[0] * vx + P[1] * vy + P[2] * vz;
-        float uy = P[3] * vx + P[4] * vy + P[5] * vz;
-        float uz = P[6] * vx + P[7] * vy + P[8] * vz;
-        const float best = dist2_exact(xc, yc, zc, t_verts[vid * 3], t_verts[vid * 3 + 1], t_verts[vid * 3 + 2]);
-        float4* o = reinterpret_cast<float4*>(geom + c * 8);
-        o[0] = make_float4(xc, yc, zc, ux); o[1] = make_float4(uy, uz, best, 0.f);       // (slots 6, 7: the pixel, written by launch B)
-    }
-}
-
-__global__ void __launch_bounds__(256) warp_tnn_lists_kernel(const int32_t* __restrict__ counters, const int32_t* __restrict__ cs_vid,
-                                                             const float* __restrict__ C2S, const float* __restrict__ thdr,
-                                                             const int32_t* __restrict__ tcell_start, const float4* __restrict__ tcell_pts,
-                                                             const int2* __restrict__ near_hdr, const uint16_t* __restrict__ near_list,
-                                                             int64_t capacity, float* __restrict__ geom, int32_t* __restrict__ cs_tvid) {
-    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    const CellGrid g = load_grid(thdr);
-    const int snx = g.nx * g.sub, sny = g.ny * g.sub, snz = g.nz * g.sub;
-    const float fs = g.inv_cell * (float)g.sub;
-    const int64_t nv = min((int64_t)counters[0], capacity);
-    for (int64_t c0 = (int64_t)blockIdx.x * 32; c0 < nv; c0 += (int64_t)gridDim.x * 32) {
-        const int64_t c = c0 + grp;
-        const bool live = c < nv;
-        const float4* gp = reinterpret_cast<const float4*>(geom + (live ? c : 0) * 8);
-        const float4 a = gp[0], b = gp[1];
-        const int vid = cs_vid[live ? c : 0];
-        const float xc = a.x, yc = a.y, zc = a.z, best0 = b.z;
-        const float r = sqrtf(best0) * 1.00001f + 1e-6f;                       // (as warp_geom_kernel: the same-index vertex bounds the ball)
-        const int sx = (int)floorf((xc - g.ox) * fs), sy = (int)floorf((yc - g.oy) * fs), sz = (int)floorf((zc - g.oz) * fs);
-        const bool in = sx >= 0 && sx < snx && sy >= 0 && sy < sny && sz >= 0 && sz < snz;
-        const bool use_list = live && in && r <= 0.05f;
-        const int2 h = near_hdr[use_list ? (sz * sny + sy) * snx + sx : 0];
-        const int st = h.x, cn = use_list ? h.y : 0;
-        unsigned long long key = ((unsigned long long)__float_as_uint(best0) << 32) | (unsigned)vid;
-        for (int base = 0; base < cn; base += 32) {
-            const int e = base + sub * 4;
-            uint2 w = make_uint2(0u, 0u);
-            if (e < cn) w = *reinterpret_cast<const uint2*>(near_list + st + e);
-            const int id[4] = {(int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16)};
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = tcell_pts[e + j < cn ? id[j] : 0];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dd = dist2_exact(xc, yc, zc, v[j].x, v[j].y, v[j].z);
-                const unsigned long long cand = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[j].w);
-                if (e + j < cn && cand < key) key = cand;
-            }
-        }
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) {
-            const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
-            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-            key = other < key ? other : key;
-        }
-        if (live && sub == 0) {
-            int bid = (int)(key & 0x7FFFFFFFull);
-            if (!use_list) {                                                    // a ball wider than the lists cover (or outside the grid)
-                float bd = best0;
-                bid = vid;
-                nn_search_batched(g, tcell_start, tcell_pts, xc, yc, zc, r, bd, bid);
-            }
-            const float4* L4 = reinterpret_cast<const float4*>(C2S) + (size_t)bid * 3;
-            const float4 la = L4[0], lb = L4[1], lc = L4[2];
-            const float L[12] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w};
-            float hx = L[0] * xc + L[1] * yc + L[2] * zc + L[9];
-            float hy = L[3] * xc + L[4] * yc + L[5] * zc + L[10];
-            float hz = L[6] * xc + L[7] * yc + L[8] * zc + L[11];
-            float iz = hz + 1e-5f;                                 // renderer.py:699
-            *reinterpret_cast<float2*>(geom + c * 8 + 6) = make_float2(hx / iz, hy / iz);
-            cs_tvid[c] = bid;
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
@@ -1105,22 +1004,6 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
                        reinterpret_cast<float4*>(cs_xs), cp)
     if (nch == 1) SHERF_COMPACT_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_LAUNCH(2);
     else if (nch == 3) SHERF_COMPACT_LAUNCH(3); else SHERF_COMPACT_LAUNCH(4);
-    SHERF_LAUNCH_CHECK();
-}
-
-extern "C" int sherf_warp_geom_lists(const int32_t* counters, const int32_t* cs_idx, const int32_t* cs_vid,
-                                     const float* cs_xs, const float* ray_d, int S, const float* Rg, const float* T2C,
-                                     const float* C2S, const float* t_verts, const float* tgrid_hdr,
-                                     const int32_t* tcell_start, const float* tcell_pts, const int32_t* tnear_hdr,
-                                     const uint16_t* tnear_list, int64_t capacity, float* geom, int32_t* cs_tvid, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(counters && cs_idx && cs_vid && cs_xs && ray_d && Rg && T2C && C2S && t_verts && tgrid_hdr &&
-                    tcell_start && tcell_pts && tnear_hdr && tnear_list && geom && cs_tvid);
-    SHERF_CHECK_ARG(S >= 2 && capacity > 0);
-    hipLaunchKernelGGL(warp_pre_kernel, dim3(min(8192, cdiv(capacity, 256))), dim3(256), 0, as_stream(stream), counters, cs_idx, cs_vid,
-                       reinterpret_cast<const float4*>(cs_xs), ray_d, S, Rg, T2C, t_verts, capacity, geom);
-    hipLaunchKernelGGL(warp_tnn_lists_kernel, dim3(min(8 * n_cus(), cdiv(capacity, 32))), dim3(256), 0, as_stream(stream), counters, cs_vid, C2S,
-                       tgrid_hdr, tcell_start, reinterpret_cast<const float4*>(tcell_pts), reinterpret_cast<const int2*>(tnear_hdr), tnear_list,
-                       capacity, geom, cs_tvid);
     SHERF_LAUNCH_CHECK();
 }
 

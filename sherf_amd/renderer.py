@@ -178,7 +178,6 @@ class _Workspace:
         self.desc = None
         self.stacked = None
         self.tok_cap = 0
-        self.tnear = None
 
     def frame(self, R, S, cap, dev):
         key = (R, S, cap, str(dev))
@@ -201,7 +200,6 @@ class _Workspace:
             near_hdr=torch.zeros(2 * NEAR_SUBCELLS + 2, **i32),
             near_list=torch.zeros(125 * V + 3 * NEAR_SUBCELLS, dtype=torch.int16, device=dev),
         )
-        self.tnear = None                                 # near lists of the T-pose grid: allocated when `warp_lists` is first used
         self.key, self.t = key, t
         self.desc = None
         self.tok_cap = 0
@@ -251,7 +249,6 @@ class _Workspace:
         fr.J_template, fr.J_shapedirs, fr.parents = A(smpl['J_template']), A(smpl['J_shapedirs']), A(smpl['parents_i32'])
         fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
         self.desc = (self.t, smpl, fr, dict(near_hdr=A(self.t['near_hdr']), near_list=A(self.t['near_list']), near_cap=self.t['near_list'].numel()))
-        self.tnear = None
         return fr
 
     def zfrag(self, cap, prec_name, dev):
@@ -349,7 +346,6 @@ class ImportanceRenderer(nn.Module):
         # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
         # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
         self.mlp_parts = int(os.environ.get('SHERF_MLP_PARTS', '0'))
-        self.warp_lists = os.environ.get('SHERF_WARP_LISTS', '0') == '1'         # see _forward (opt-in experiment)
         # token-side workspace (geom / tokens / extras / sample_out: 480 B per compact sample): 'auto' = sized from the frame's own number
         # of valid samples (first frame: the sampler alone + one host wait; later frames: the counts of finished frames, read without a
         # wait, grow it ahead of need), 'worst' = R * S as in rounds 1-3 (8 GB at 512 x 512 x 64), or a number of samples
@@ -854,13 +850,6 @@ class ImportanceRenderer(nn.Module):
             fr.near_hdr, fr.near_list, fr.near_list_cap = nl['near_hdr'], nl['near_list'], nl['near_cap']
         else:
             fr.near_hdr, fr.near_list, fr.near_list_cap = None, None, 0
-        # opt-in experiment (round 4, not yet measured on the MI355X): the warp's nearest-T-vertex search over near lists of the T-pose grid
-        if opts.get('warp_lists', getattr(self, 'warp_lists', False)):
-            if wsp.tnear is None:
-                wsp.tnear = (torch.zeros_like(ws['near_hdr']), torch.zeros_like(ws['near_list']))
-            fr.tnear_hdr, fr.tnear_list, fr.near_list_cap = A(wsp.tnear[0]), A(wsp.tnear[1]), nl['near_cap']
-        else:
-            fr.tnear_hdr, fr.tnear_list = None, None
         # the frame's outputs: ONE fresh buffer per call, planar [rgb (3R) | depth (R) | acc (R)], written by the compositing kernel and
         # returned as views -- no copies behind the frame (rounds 1-2 cloned three workspace tensors: three launches per frame), and
         # a caller may keep as many frames as it likes

@@ -97,8 +97,6 @@ inline void __builtin_amdgcn_wave_barrier() { hipcpu_wave_sync(); }       // loc
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 
 struct float4 { float x, y, z, w; };
-struct float2 { float x, y; };
-inline float2 make_float2(float a, float b) { return {a, b}; }
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 struct int3 { int x, y, z; };

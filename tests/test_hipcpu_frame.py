@@ -81,7 +81,7 @@ def test_stage_by_stage_parity(run):
 def test_frame_launch_switches_render_the_same_bits(cpu_product):
     """Grids sized by the frame's own sample count (SHERF_FRAME_EXACT_GRIDS) and the gather's schedule variants: same arithmetic."""
     h = G.hip_render('tiny_nv')
-    for opts in (dict(exact_grids=True), dict(gather_branchless=True), dict(gather_branchless='128'), dict(near_lists=False), dict(warp_lists=True)):
+    for opts in (dict(exact_grids=True), dict(gather_branchless=True), dict(gather_branchless='128'), dict(near_lists=False)):
         b = G.hip_render('tiny_nv', options=opts)
         assert torch.equal(b['rgb'], h['rgb']) and torch.equal(b['acc'], h['acc']) and torch.equal(b['depth'], h['depth']), opts
     # the single-product bf16 mode (north_star's nominal precision) runs through the same frame, at its own (looser) accuracy

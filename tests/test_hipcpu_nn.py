@@ -24,7 +24,7 @@ def lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n')
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for name in ('sherf_build_cells', 'sherf_build_cells2', 'sherf_build_near_lists', 'sherf_sample_mask_nn', 'sherf_warp_geom', 'sherf_warp_geom_lists'):
+    for name in ('sherf_build_cells', 'sherf_build_cells2', 'sherf_build_near_lists', 'sherf_sample_mask_nn', 'sherf_warp_geom'):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = protos[name][0], [a[0] for a in protos[name][1]]
     return lib
@@ -155,12 +155,3 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     # both paths were taken: balls within 3 x 3 rows of 5 cm cells, and balls far wider than that
     rad = np.sqrt(dq[np.arange(nq), same])
     assert (rad < 0.04).sum() > 100 and (rad > 0.2).sum() > 50
-    # the same through the two-launch form with near lists of this (T-pose) grid: eight lanes per sample over one exact list when the ball is
-    # at most 5 cm wide, the cell walk on one lane otherwise -- identical ids and geometry
-    tn_hdr = torch.zeros(2 * NSUB + 2, dtype=torch.int32); tn_list = torch.zeros(125 * n + 3 * NSUB, dtype=torch.int16)
-    assert lib.sherf_build_near_lists(_P(hdr[1]), _P(cell_pts[1]), n, 0.05, _P(tn_hdr), _P(tn_list), tn_list.numel(), None, None) == 0
-    geom2 = torch.full((nq, 8), float('nan')); tvid2 = torch.full((nq,), -7, dtype=torch.int32)
-    assert lib.sherf_warp_geom_lists(_P(counters_w), _P(w_idx), _P(w_vid), _P(w_xs), _P(w_rd), 2, _P(Rg), _P(ident), _P(ident), _P(verts),
-                                     _P(hdr[1]), _P(cell_start[1]), _P(cell_pts[1]), _P(tn_hdr), _P(tn_list), nq, _P(geom2), _P(tvid2), None) == 0
-    assert torch.equal(tvid2, tvid) and torch.equal(geom2, geom)
-    assert ((rad * 1.00001 + 1e-6) <= 0.05).sum() > 100 and ((rad * 1.00001 + 1e-6) > 0.05).sum() > 50          # both of ITS paths too
