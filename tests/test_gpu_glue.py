@@ -34,3 +34,15 @@ def test_two_launch_mlp_renders_the_one_launch_bits_on_device(cfg):
         dflt = G.hip_render(cfg, precision=prec)
         for k in ('rgb', 'acc', 'depth'):
             assert torch.equal(one[k], two[k]) and torch.equal(one[k], dflt[k]), (prec, k)
+
+
+@pytest.mark.parametrize('cfg,prec', [('tiny', 'f16x3'), ('cfg1_ri', 'f16')])
+def test_schedule_switches_render_the_same_bits_on_device(cfg, prec):
+    """Round 4's launch / data-structure switches on the hardware, each against the default frame bit for bit: the candidate search over
+    the cell walk instead of the near lists, gather + network in parts on two streams, grids sized by the frame's own count, the
+    worst-case token workspace."""
+    ref = G.hip_render(cfg, precision=prec)
+    for opts in (dict(near_lists=False), dict(mlp_parts=2), dict(mlp_parts=5), dict(exact_grids=True), dict(token_capacity='worst')):
+        b = G.hip_render(cfg, precision=prec, options=opts)
+        for k in ('rgb', 'acc', 'depth'):
+            assert torch.equal(ref[k], b[k]), (opts, k)
