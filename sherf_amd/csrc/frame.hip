@@ -281,6 +281,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         if (split)
             SHERF_RUN(sherf_nerf_mlp_split(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->zfrag,
                                            f->sample_out, stream_main));
+        else if (f->mlp_prec != 1 && (((f->flags & SHERF_FRAME_MLP_TWO_TILES) != 0) != ((g_sherf_debug & (1 << 24)) != 0)))   // (debug bit 24 flips the form: A/B runs)
+            SHERF_RUN(sherf_nerf_mlp2(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, stream_main));
         else
             SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,
                                      f->sample_out, stream_main));

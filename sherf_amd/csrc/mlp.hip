@@ -852,6 +852,206 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
 #undef SHERF_LAYER128
 }
 
+// =====================================================================================================================================
+// Round 5: TWO 32-sample tiles per wave (single-product precisions).  Why: round 4's counters and timeline say the one-tile kernel sits
+// at the SUM of its issue streams -- per tile a wave issues 374 MFMAs beside ~4 800 other instructions, of which ~1 950 are per-STEP
+// overhead of the weight ring (the A-fragment ds_reads and their waits, the DMA issue, the barrier, the block-opening s_nops) paid once
+// per 8 MFMAs.  With two tiles in a wave every A fragment read from LDS feeds TWO MFMAs, a step carries 16 MFMAs in FOUR independent
+// accumulator chains (consecutive MFMAs of a chain are three MFMAs = 96 pipe cycles apart: nothing the compiler drops between blocks
+// sits between dependent MFMAs any more), and ring traffic, barriers and waits per tile halve.  Registers: two tiles' activations
+// (2 x 64) + four accumulators (64) + fragments need the 256-register budget = two waves per SIMD (two 4-wave workgroups per CU), each
+// holding two tiles: four tiles in flight per SIMD instead of three.  The transformer runs tile after tile with its weights (steps 0-1)
+// resident in ring slots 0-1 -- no barrier, no DMA wait while it runs -- and parks the fused tokens z_0 / z_1 as B fragments in LDS.
+// Same MFMA order per accumulator as the one-tile kernel: bit-identical outputs.
+template <int PREC>
+__device__ __forceinline__ void mfma_block4(f32x16& t0c0, f32x16& t0c1, f32x16& t1c0, f32x16& t1c1, const u32x4& a0, const u32x4& a1,
+                                            const u32x4& b00, const u32x4& b01, const u32x4& b10, const u32x4& b11) {
+    // chain (tile t, unit u) <- A fragment a_u x B fragment b_tu; issue order t0u0, t1u0, t0u1, t1u1
+    static_assert(PREC != 1, "two tiles per wave: single-product precisions only");
+    if constexpr (PREC == 2)
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f32_32x32x16_f16 %0, %4, %6, %0\n\t"
+                     "v_mfma_f32_32x32x16_f16 %2, %4, %8, %2\n\t"
+                     "v_mfma_f32_32x32x16_f16 %1, %5, %7, %1\n\t"
+                     "v_mfma_f32_32x32x16_f16 %3, %5, %9, %3"
+                     : "+v"(t0c0), "+v"(t0c1), "+v"(t1c0), "+v"(t1c1) : "v"(a0), "v"(a1), "v"(b00), "v"(b01), "v"(b10), "v"(b11) : "memory");
+    else
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %2, %4, %8, %2\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %1, %5, %7, %1\n\t"
+                     "v_mfma_f32_32x32x16_bf16 %3, %5, %9, %3"
+                     : "+v"(t0c0), "+v"(t0c1), "+v"(t1c0), "+v"(t1c1) : "v"(a0), "v"(a1), "v"(b00), "v"(b01), "v"(b10), "v"(b11) : "memory");
+}
+__device__ __forceinline__ void mfma_settle4(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
+    asm volatile("s_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// as mma_chains, both tiles at once: acc[t][u]; PAIR: chain (t, u) takes b_t[i]; split-K: chain (t, u) takes b_t[2 i + u]
+template <int PREC, int NB, bool PAIR, bool MORE>
+__device__ __forceinline__ void mma_chains2(const char* s, int u0, const BFrag<PREC>* b0, const BFrag<PREC>* b1, f32x16 (&acc)[2][2], AFrag<PREC>& cur) {
+    constexpr int UNIT = Ctx<PREC>::UNIT;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        AFrag<PREC> nxt;
+        const bool pre = i + 1 < NB || MORE;
+        if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
+        const int k0 = PAIR ? i : 2 * i, k1 = PAIR ? i : 2 * i + 1;
+        mfma_block4<PREC>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur.h0, cur.h1, b0[k0].hi, b0[k1].hi, b1[k0].hi, b1[k1].hi);
+        if (pre) cur = nxt;
+    }
+}
+// four finished accumulator tiles (a pair of chunks x two tiles) -> four K-blocks of the next layer per tile
+template <int PREC, bool RELU>
+__device__ __forceinline__ void finish_quad(f32x16 (&acc)[2][2], BFrag<PREC>* out0, BFrag<PREC>* out1) {
+    mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    constexpr bool PK = RELU && PREC == 2 && SHERF_MLP_PK_RELU;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        BFrag<PREC>* out = t ? out1 : out0;
+        if constexpr (RELU && !PK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[t][0][r] = relu(acc[t][0][r]); acc[t][1][r] = relu(acc[t][1][r]); }
+        }
+        split_tile<PREC>(acc[t][0], out[0], out[1]);
+        split_tile<PREC>(acc[t][1], out[2], out[3]);
+        if constexpr (PK) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[f].hi[e] = relu2_f16(out[f].hi[e]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// NeRF decoder of TWO tiles (steps 2..42 through the ring); zst = this wave's LDS park of the fused tokens (+ this lane's 16 bytes):
+// fragment q of tile t at zst + (4 t + q) KiB, q = 0, 1: z_0's K-blocks, 2, 3: z_1's.  Entry state as decoder_tile.
+template <int PREC>
+__device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __restrict__ counters, const char* zst, const float (&xc)[2][3],
+                                              const float (&vc)[2][3], const int64_t (&tile)[2], const bool (&live)[2], int64_t nv, float4* __restrict__ out) {
+    const int j = cx.lane & 31, h = cx.h;
+    if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
+    int step = 2;
+    BFrag<PREC> ha[2][8], hb[2][8];
+    AFrag<PREC> cur = load_units<PREC>(cx.slot(step));
+    auto zfrag = [&](int t, int q) { BFrag<PREC> f; f.hi = *reinterpret_cast<const u32x4*>(zst + (4 * t + q) * 1024); return f; };
+#define SHERF_NEXT_STEP() do { step_wait(cx, step); cur = load_units<PREC>(cx.slot(step + 1)); dma_issue(cx, step + NSLOT); ++step; } while (0)
+#define SHERF_BIAS4(ACC, C0) do { ACC[0][0] = bias_tile(cx, (C0)); ACC[0][1] = bias_tile(cx, (C0) + 1); ACC[1][0] = ACC[0][0]; ACC[1][1] = ACC[0][1]; } while (0)
+#define SHERF_LAYER128_2(C0, IN, OUT, RELU)                                                           \
+    _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                   \
+        f32x16 acc[2][2];                                                                             \
+        SHERF_BIAS4(acc, (C0) + 2 * P);                                                               \
+        mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, IN[0], IN[1], acc, cur);                  \
+        SHERF_NEXT_STEP();                                                                            \
+        mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, IN[0] + 4, IN[1] + 4, acc, cur);          \
+        SHERF_NEXT_STEP();                                                                            \
+        finish_quad<PREC, RELU>(acc, OUT[0] + 4 * P, OUT[1] + 4 * P);                                 \
+    }
+    {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
+        BFrag<PREC> pe[2][3];
+        pe_frags<PREC, 6, 3>(h, xc[0][0], xc[0][1], xc[0][2], pe[0]);
+        pe_frags<PREC, 6, 3>(h, xc[1][0], xc[1][1], xc[1][2], pe[1]);
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            f32x16 acc[2][2];
+            SHERF_BIAS4(acc, 9 + 2 * P);
+            const char* s = cx.slot(step);
+            mma_chains2<PREC, 3, true, true>(s, 0, pe[0], pe[1], acc, cur);
+            const BFrag<PREC> z0[2][2] = {{zfrag(0, 0), zfrag(0, 1)}, {zfrag(1, 0), zfrag(1, 1)}};
+            mma_chains2<PREC, 2, true, false>(s, 6, z0[0], z0[1], acc, cur);
+            SHERF_NEXT_STEP();
+            finish_quad<PREC, true>(acc, ha[0] + 4 * P, ha[1] + 4 * P);
+        }
+    }
+    SHERF_LAYER128_2(13, ha, hb, true)     // pts_linears.1-4
+    SHERF_LAYER128_2(17, hb, ha, true)
+    SHERF_LAYER128_2(21, ha, hb, true)
+    SHERF_LAYER128_2(25, hb, ha, true)
+    {   // pts_linears.5 : [PE6 | z_0 | h(128)]
+        float x0[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            x0[t][0] = xc[t][0]; x0[t][1] = xc[t][1]; x0[t][2] = xc[t][2];
+            asm volatile("" : "+v"(x0[t][0]), "+v"(x0[t][1]), "+v"(x0[t][2]));
+        }
+        BFrag<PREC> pe[2][3];
+        pe_frags<PREC, 6, 3>(h, x0[0][0], x0[0][1], x0[0][2], pe[0]);
+        pe_frags<PREC, 6, 3>(h, x0[1][0], x0[1][1], x0[1][2], pe[1]);
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            f32x16 acc[2][2];
+            SHERF_BIAS4(acc, 29 + 2 * P);
+            const char* s = cx.slot(step);
+            mma_chains2<PREC, 3, true, true>(s, 0, pe[0], pe[1], acc, cur);
+            {
+                const BFrag<PREC> z0[2][2] = {{zfrag(0, 0), zfrag(0, 1)}, {zfrag(1, 0), zfrag(1, 1)}};
+                mma_chains2<PREC, 2, true, false>(s, 6, z0[0], z0[1], acc, cur);
+            }
+            SHERF_NEXT_STEP();
+            mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, ha[0], ha[1], acc, cur);
+            SHERF_NEXT_STEP();
+            mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, ha[0] + 4, ha[1] + 4, acc, cur);
+            SHERF_NEXT_STEP();
+            finish_quad<PREC, true>(acc, hb[0] + 4 * P, hb[1] + 4 * P);
+        }
+    }
+    SHERF_LAYER128_2(33, hb, ha, true)     // pts_linears.6
+    SHERF_LAYER128_2(37, ha, hb, true)     // pts_linears.7
+    SHERF_LAYER128_2(41, hb, ha, false)    // feature_linear -> ha
+    float sigma[2];
+    {   // alpha_linear (chunk 45, split-K over hb)
+        f32x16 acc[2][2];
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[0][0] = bias_tile(cx, 45); acc[1][0] = acc[0][0]; acc[0][1] = zero; acc[1][1] = zero;
+        mma_chains2<PREC, 4, false, false>(cx.slot(step), 0, hb[0], hb[1], acc, cur);
+        SHERF_NEXT_STEP();
+        mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+        sigma[0] = acc[0][0][0] + acc[0][1][0];
+        sigma[1] = acc[1][0][0] + acc[1][1][0];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    BFrag<PREC> gb[2][4];
+    {   // views_linear : [feature (8 kb) | PE4(v_c) (2 kb) | z_1 (2 kb)] -> 64, ReLU
+        BFrag<PREC> pv[2][2];
+        pe_frags<PREC, 4, 2>(h, vc[0][0], vc[0][1], vc[0][2], pv[0]);
+        pe_frags<PREC, 4, 2>(h, vc[1][0], vc[1][1], vc[1][2], pv[1]);
+        f32x16 acc[2][2];
+        SHERF_BIAS4(acc, 46);
+        mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, ha[0], ha[1], acc, cur);
+        SHERF_NEXT_STEP();
+        mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, ha[0] + 4, ha[1] + 4, acc, cur);
+        SHERF_NEXT_STEP();
+        const char* s = cx.slot(step);
+        mma_chains2<PREC, 2, true, true>(s, 0, pv[0], pv[1], acc, cur);
+        const BFrag<PREC> z1[2][2] = {{zfrag(0, 2), zfrag(0, 3)}, {zfrag(1, 2), zfrag(1, 3)}};
+        mma_chains2<PREC, 2, true, false>(s, 4, z1[0], z1[1], acc, cur);
+        SHERF_NEXT_STEP();
+        finish_quad<PREC, true>(acc, gb[0], gb[1]);
+    }
+    {   // rgb_linear (chunk 48, split-K over gb) -> sigmoid
+        f32x16 acc[2][2];
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[0][0] = bias_tile(cx, 48); acc[1][0] = acc[0][0]; acc[0][1] = zero; acc[1][1] = zero;
+        mma_chains2<PREC, 2, false, false>(cx.slot(step), 0, gb[0], gb[1], acc, cur);
+        mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (live[t] && h == 0) {
+                const int64_t c = tile[t] * 32 + j;
+                if (c < nv) {
+                    float r = rcp_(1.0f + exp_(-(acc[t][0][0] + acc[t][1][0]))), g = rcp_(1.0f + exp_(-(acc[t][0][1] + acc[t][1][1]))),
+                          b = rcp_(1.0f + exp_(-(acc[t][0][2] + acc[t][1][2])));
+                    out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma[t]);   // triplane.py:314
+                    if (!(fabsf(sigma[t]) <= 3.0e38f) || !(r + g + b <= 4.0f)) atomicOr(reinterpret_cast<unsigned*>(const_cast<int32_t*>(counters)) + 3, 1u);
+                }
+            }
+        }
+    }
+#undef SHERF_NEXT_STEP
+#undef SHERF_BIAS4
+#undef SHERF_LAYER128_2
+}
+
 #ifndef SHERF_MLP_LB
 #define SHERF_MLP_LB 2            // minimum waves / SIMD the single-product instances are compiled for (register cap 512 / LB)
 #endif
@@ -919,6 +1119,69 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     transformer_tile<PREC, true>(cx, tokens, extras, tile, z0b, z1b);
     decoder_tile<PREC>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out);
     SHERF_TRACE_FLUSH(cx);
+}
+
+// One launch, two tiles per wave (round 5; single-product precisions).  A 4-wave workgroup owns EIGHT tiles; LDS = the 3-slot ring + the bias
+// tables + 8 KiB per wave for the parked tokens (74.8 KiB: two workgroups per CU).  Schedule: ring prologue (steps 0, 1, 2 in slots 0, 1,
+// 2) -> the transformer of tile 0, then of tile 1, reading its weights from slots 0 / 1 with no barrier and no DMA wait in between ->
+// one barrier, slots 0 / 1 recycled for steps 3 / 4 -> decoder_tile2.
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, 2)
+nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    using CX = Ctx<PREC>;
+    static_assert(PREC != 1 && step_pieces<PREC>(0) * 1024 == CX::SLOT, "the transformer reads steps 0 / 1 from ring slots 0 / 1 back to back");
+    constexpr int RING = NSLOT * CX::SLOT, TABLES = (N_CHUNKS + 4) * 32 * 4, PARK = 2 * 4 * 1024;
+    __shared__ __attribute__((aligned(16))) char lds[RING + TABLES + NW * PARK];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    if ((int64_t)blockIdx.x * (2 * NW) >= n_tiles) return;           // whole workgroup beyond the data
+    CX cx;
+    ring_ctx<PREC>(cx, lds, ws, wbias);
+    int64_t tile[2];
+    bool live[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        tile[t] = (int64_t)blockIdx.x * (2 * NW) + 2 * cx.wave + t;
+        live[t] = tile[t] < n_tiles;
+        if (!live[t]) tile[t] = n_tiles - 1;                         // dead tiles still take part in every barrier
+    }
+    ring_prologue<PREC, 0>(cx);                                      // steps 0, 1 issued, step 0 landed, step 2 issued
+    wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(2) / NW);   // step 1 (this wave's pieces) landed too
+    wg_barrier();
+    char* park = lds + RING + TABLES + cx.wave * PARK + cx.lane * 16;
+    float xc[2][3], vc[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* ex = extras + tile[t] * 12 * 32 + (cx.lane & 31);
+        xc[t][0] = ex[0]; xc[t][1] = ex[32]; xc[t][2] = ex[64]; vc[t][0] = ex[96]; vc[t][1] = ex[128]; vc[t][2] = ex[160];
+    }
+    {
+        const char* ring_lane = cx.lds;
+        const float* tables = cx.wbias;
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {
+            // (the weights and tables in LDS do not change between the tiles: launder the offsets, as nerf_tokens_kernel does, or the
+            //  compiler hoists their reads out of the loop)
+            uint32_t woff = 0, boff = 0;
+            asm volatile("" : "+v"(woff), "+v"(boff));
+            cx.lds = ring_lane + woff;
+            cx.wbias = tables + boff;
+            BFrag<PREC> z0b[2], z1b[2];
+            transformer_tile<PREC, false>(cx, tokens, extras, t ? tile[1] : tile[0], z0b, z1b);
+            char* pk = park + t * 4096;
+            *reinterpret_cast<u32x4*>(pk) = z0b[0].hi; *reinterpret_cast<u32x4*>(pk + 1024) = z0b[1].hi;
+            *reinterpret_cast<u32x4*>(pk + 2048) = z1b[0].hi; *reinterpret_cast<u32x4*>(pk + 3072) = z1b[1].hi;
+        }
+        cx.lds = ring_lane;
+        cx.wbias = tables;
+    }
+    // every wave is done with the transformer's weights: slots 0 / 1 take steps 3 / 4 (step 2 landed long ago)
+    wait_vm(0);
+    wg_barrier();
+    dma_issue(cx, 3);
+    dma_issue(cx, 4);
+    decoder_tile2<PREC>(cx, counters, park, xc, vc, tile, live, nv, out);
 }
 
 // ---- the two-launch form -------------------------------------------------------------------------------------------------------
@@ -1095,6 +1358,22 @@ extern "C" int sherf_nerf_mlp_part(const int32_t* counters, const float* tokens,
 extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                               const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
     return sherf_nerf_mlp_part(counters, tokens, extras, wstream, wbias, prec, capacity, out, 0, 1, stream);
+}
+
+// Two tiles per wave (nerf_mlp2_kernel): the single-product precisions (prec 0, 2); same inputs, same outputs bit for bit as sherf_nerf_mlp.
+extern "C" int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                               const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0);
+    const int64_t tiles = (capacity + 31) / 32;
+    const dim3 grid((unsigned)((tiles + 2 * NW - 1) / (2 * NW))), block(NW * 64);
+    if (prec == 2)
+        hipLaunchKernelGGL((nerf_mlp2_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL((nerf_mlp2_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    SHERF_LAUNCH_CHECK();
 }
 
 // The two-launch form (see nerf_tokens_kernel / nerf_decoder_kernel): same inputs, same outputs bit for bit; zfrag = scratch for the fused

@@ -37,6 +37,11 @@ def _cpu_mlp(src):
               '        acc0 = mfma<PREC>(ah0, bh0, acc0); acc1 = mfma<PREC>(ah1, bh1, acc1);\n'
               '    } else { acc0 = mfma<PREC>(ah0, bh0, acc0); acc1 = mfma<PREC>(ah1, bh1, acc1); }\n')
     src = src.replace('    asm volatile("s_nop 7\\n\\ts_nop 3" : "+v"(acc0), "+v"(acc1));', '    (void)acc0; (void)acc1;')
+    # the two-tile kernel's block of four MFMAs (chain (t, u) <- a_u x b_tu, in the asm's order) and its settle
+    src = cut(src, '    static_assert(PREC != 1, "two tiles per wave: single-product precisions only");', '}\n__device__ __forceinline__ void mfma_settle4',
+              '    t0c0 = mfma<PREC>(a0, b00, t0c0); t1c0 = mfma<PREC>(a0, b10, t1c0);\n'
+              '    t0c1 = mfma<PREC>(a1, b01, t0c1); t1c1 = mfma<PREC>(a1, b11, t1c1);\n')
+    src = src.replace('    asm volatile("s_nop 7\\n\\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));', '    (void)a; (void)b; (void)c; (void)d;')
     src = src.replace('#define SHERF_MLP_FMA_MIX 1', '#define SHERF_MLP_FMA_MIX 0')       # v_fma_mix_f32 inline asm -> its plain-C equivalent
     src = re.sub(r'asm volatile\("" : "\+[sv]"\([^;]*;', ';', src)            # register-class launders (optimisation barriers only)
     assert 'asm volatile' not in src.replace('#if SHERF_MLP_FMA_MIX', '#if 0'), 'an inline-asm site of mlp.hip has no host equivalent'

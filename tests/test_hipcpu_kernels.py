@@ -539,7 +539,7 @@ def mlp_lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
+    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp2', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
         getattr(lib, fn).restype, getattr(lib, fn).argtypes = protos[fn][0], [a[0] for a in protos[fn][1]]
     return lib
 
@@ -613,3 +613,17 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
         out2 = torch.full((tiles * 32, 4), float('nan'))
         assert mlp_lib.sherf_nerf_mlp_split(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(zfrag), _P(out2), None) == 0
         assert torch.equal(out2[:n], out[:n]) and int(counters[3]) == flag
+    # two tiles per wave (round 5, single-product precisions): the same bits for every sample count modulo the 8-tile workgroup (dead tiles
+    # and half-empty waves take part in every barrier), and the f16x3 precision is refused
+    if prec == 1:
+        assert mlp_lib.sherf_nerf_mlp2(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out), None) != 0
+    else:
+        for m in sorted({n, n - 32, n - 40, 33, 1}):
+            if m < 1:
+                continue
+            counters[0], counters[3] = m, 0
+            ref = torch.full((tiles * 32, 4), float('nan'))
+            assert mlp_lib.sherf_nerf_mlp(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(ref), None) == 0
+            out3 = torch.full((tiles * 32, 4), float('nan'))
+            assert mlp_lib.sherf_nerf_mlp2(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out3), None) == 0
+            assert torch.equal(out3[:m], ref[:m]) and torch.isnan(out3[m:]).all() and int(counters[3]) == 0, m

@@ -109,7 +109,13 @@ def check(lines, start, end, verbose=True):
             if valu[r] > 8:
                 del valu[r]
         if is_mfma:
-            pending.append([dst, 0, ln + 1, t])
+            # the matrix pipe retires in order: a later MFMA's destination supersedes the overlapping part of an older one's (a reader of
+            # those registers depends on the LATER writer -- hipcc's own recognizer looks at the last writer too; round 5: the two-tile
+            # kernel's compiler-scheduled transformer re-uses half of a finished accumulator tuple as part of the next one)
+            for p in pending:
+                p[0] = p[0] - dst
+            pending = [p for p in pending if p[0]]
+            pending.append([set(dst), 0, ln + 1, t])
         elif op.startswith('v_') and ops and not op.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane')):
             for r in ops[0]:
                 valu[r] = 0
