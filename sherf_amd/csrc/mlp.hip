@@ -168,7 +168,9 @@ __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32
 #if SHERF_MLP_TRACE
 __device__ uint32_t* g_mlp_trace = nullptr;           // [slot][wave 0..7][64 steps][4] u32
 __device__ int g_mlp_trace_every = 0;
-#define SHERF_TRACE_STAMP(cx, step, k) do { if ((cx).lane == 0) (cx).trace[(step) * 4 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+// (two-tile kernel: its LDS is full -- stamps go into lanes of three VGPRs, index 8 + 3 (step - 2) + k)
+#define SHERF_TRACE_STAMP(cx, step, k) do { if ((cx).treg) trace_reg((cx), 8 + 3 * ((step) - 2) + (k)); \
+                                            else if ((cx).lane == 0) (cx).trace[(step) * 4 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SHERF_TRACE_STAMP(cx, step, k) do { } while (0)
 #endif
@@ -187,11 +189,29 @@ template <int PREC> struct Ctx {
     int lane, h, wave;
 #if SHERF_MLP_TRACE
     uint32_t* trace;         // this wave's [64][4] stamps in LDS
+    bool treg;               // stamps in registers instead (two-tile kernel)
+    uint32_t tv[3];
 #endif
     static constexpr int UNIT = NPIECE<PREC> * 1024;                       // bytes per unit: hi [, lo]
     static constexpr int SLOT = (PREC == 1 ? 20 : 12) * 1024;              // the largest step, padded
     __device__ __forceinline__ const char* slot(int step) const { return lds + (step % NSLOT) * SLOT; }
 };
+
+#if SHERF_MLP_TRACE
+template <class C>
+__device__ __forceinline__ void trace_put(C& cx, int idx, uint32_t v) {      // lane (idx % 64) of register idx / 64 (a compare + a select)
+    if (idx < 64) cx.tv[0] = cx.lane == idx ? v : cx.tv[0];
+    else if (idx < 128) cx.tv[1] = cx.lane == idx - 64 ? v : cx.tv[1];
+    else cx.tv[2] = cx.lane == idx - 128 ? v : cx.tv[2];
+}
+template <class C>
+__device__ __forceinline__ void trace_reg(C& cx, int idx) {
+    trace_put(cx, idx, (uint32_t)__builtin_amdgcn_s_memtime());
+}
+#define SHERF_TRACE_REG(cx, idx) trace_reg((cx), (idx))
+#else
+#define SHERF_TRACE_REG(cx, idx) do { } while (0)
+#endif
 
 // Weight stream L2 -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPR round trip).  Every step is a whole
 // number of rounds of the four waves (the stream is padded), so the issue is branch free.  Completion: a wave waits (counted
@@ -574,20 +594,26 @@ __device__ __forceinline__ void finish_pair(f32x16& acc0, f32x16& acc1, BFrag<PR
 // Transformer (chunks 0..8 = steps 0-1 of the weight stream) of one 32-sample tile -> the fused tokens z_0, z_1 as K-blocks.
 //   RING = true : the weights walk the 3-slot ring (step 0 / 1 in slots 0 / 1; the two advance() calls recycle them)
 //   RING = false: the weights are resident at cx.lds (steps 0-1 back to back), no barrier, no DMA: waves run independently
-template <int PREC, bool RING>
+// a tile's three tokens in D layout (quad q = 2i+h -> regs 4i..4i+3)
+__device__ __forceinline__ void load_tokens(const float4* __restrict__ tokens, int64_t tile, int j, int h, f32x16 (&tok)[3]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+            tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
+        }
+}
+//   PRE = false: the tile's tokens are read here, and tokens 0 / 1 RE-read for the residual (the one-tile kernels: 32 registers less at
+//                their pressure peak);  PRE = true: `tok` arrives loaded (the two-tile kernel prefetches the next tile's tokens under
+//                this tile's arithmetic and keeps tokens 0 / 1 for the residual: it has the 256-register budget)
+template <int PREC, bool RING, bool PRE = false>
 __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __restrict__ tokens, const float* __restrict__ extras, int64_t tile,
-                                                 BFrag<PREC> (&z0b)[2], BFrag<PREC> (&z1b)[2]) {
+                                                 BFrag<PREC> (&z0b)[2], BFrag<PREC> (&z1b)[2], f32x16 (&tok)[3]) {
     const int j = cx.lane & 31, h = cx.h;
     {
-        // ---- inputs: tokens in D layout (quad q = 2i+h -> regs 4i..4i+3), extras ----
-        f32x16 tok[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float4 v = tokens[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-                tok[t][4 * i] = v.x; tok[t][4 * i + 1] = v.y; tok[t][4 * i + 2] = v.z; tok[t][4 * i + 3] = v.w;
-            }
+        // ---- inputs: tokens in D layout, extras ----
+        if constexpr (!PRE) load_tokens(tokens, tile, j, h, tok);
         const float* ex = extras + tile * 12 * 32 + j;
         if constexpr ((SHERF_MLP_ABLATE & 256) != 0) {
             split_tile<PREC>(tok[0] + tok[2], z0b[0], z0b[1]);
@@ -706,17 +732,21 @@ __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __
             mma_cols<PREC, 3, 2>(s, 2, ob, acc);                      // to_out + bias
             // residual (renderer.py:925).  tok[0], tok[1] are RE-READ (L2-hot, coalesced) instead of carried through the attention:
             // 32 registers less at the kernel's pressure peak
-            const float4* tp = tokens;
-            asm volatile("" : "+v"(tp));
+            if constexpr (PRE) {
+                y[0] = acc[0] + tok[0]; y[1] = acc[1] + tok[1];
+            } else {
+                const float4* tp = tokens;
+                asm volatile("" : "+v"(tp));
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x16 tk;
+                for (int t = 0; t < 2; ++t) {
+                    f32x16 tk;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 v = tp[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
-                    tk[4 * i] = v.x; tk[4 * i + 1] = v.y; tk[4 * i + 2] = v.z; tk[4 * i + 3] = v.w;
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 v = tp[((tile * 3 + t) * 8 + (2 * i + h)) * 32 + j];
+                        tk[4 * i] = v.x; tk[4 * i + 1] = v.y; tk[4 * i + 2] = v.z; tk[4 * i + 3] = v.w;
+                    }
+                    y[t] = acc[t] + tk;
                 }
-                y[t] = acc[t] + tk;
             }
         }
         // ---- FF: LN2 -> Linear -> GELU(erf) -> Linear, residual (chunks 7, 8) ----
@@ -901,9 +931,12 @@ __device__ __forceinline__ void mma_chains2(const char* s, int u0, const BFrag<P
     }
 }
 // four finished accumulator tiles (a pair of chunks x two tiles) -> four K-blocks of the next layer per tile
-template <int PREC, bool RELU>
+//   SETTLE = false: the caller vouches for >= 12 issued instructions between the last MFMA and this point (a SHERF_NEXT_STEP: waits, barrier,
+//   fragment reads, DMA issue) -- tools/mfma_hazard_check.py (tests/test_isa_hazards.py) checks exactly that on the final ISA
+template <int PREC, bool RELU, bool SETTLE = true>
 __device__ __forceinline__ void finish_quad(f32x16 (&acc)[2][2], BFrag<PREC>* out0, BFrag<PREC>* out1) {
-    mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    if constexpr (SETTLE) mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+    else __builtin_amdgcn_sched_barrier(0);
     constexpr bool PK = RELU && PREC == 2 && SHERF_MLP_PK_RELU;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -936,7 +969,10 @@ __device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __re
     AFrag<PREC> cur = load_units<PREC>(cx.slot(step));
     auto zfrag = [&](int t, int q) { BFrag<PREC> f; f.hi = *reinterpret_cast<const u32x4*>(zst + (4 * t + q) * 1024); return f; };
 #define SHERF_NEXT_STEP() do { step_wait(cx, step); cur = load_units<PREC>(cx.slot(step + 1)); dma_issue(cx, step + NSLOT); ++step; } while (0)
-#define SHERF_BIAS4(ACC, C0) do { ACC[0][0] = bias_tile(cx, (C0)); ACC[0][1] = bias_tile(cx, (C0) + 1); ACC[1][0] = ACC[0][0]; ACC[1][1] = ACC[0][1]; } while (0)
+    // (tile 1's copy of the bias tables through a laundered offset: otherwise the compiler reads each table once and COPIES 16 registers)
+    Ctx<PREC> cx1 = cx;
+    { uint32_t boff = 0; asm volatile("" : "+v"(boff)); cx1.wbias = cx.wbias + boff; }
+#define SHERF_BIAS4(ACC, C0) do { ACC[0][0] = bias_tile(cx, (C0)); ACC[0][1] = bias_tile(cx, (C0) + 1); ACC[1][0] = bias_tile(cx1, (C0)); ACC[1][1] = bias_tile(cx1, (C0) + 1); } while (0)
 #define SHERF_LAYER128_2(C0, IN, OUT, RELU)                                                           \
     _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                   \
         f32x16 acc[2][2];                                                                             \
@@ -945,7 +981,7 @@ __device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __re
         SHERF_NEXT_STEP();                                                                            \
         mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, IN[0] + 4, IN[1] + 4, acc, cur);          \
         SHERF_NEXT_STEP();                                                                            \
-        finish_quad<PREC, RELU>(acc, OUT[0] + 4 * P, OUT[1] + 4 * P);                                 \
+        finish_quad<PREC, RELU, false>(acc, OUT[0] + 4 * P, OUT[1] + 4 * P);                          \
     }
     {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)]
         BFrag<PREC> pe[2][3];
@@ -960,7 +996,7 @@ __device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __re
             const BFrag<PREC> z0[2][2] = {{zfrag(0, 0), zfrag(0, 1)}, {zfrag(1, 0), zfrag(1, 1)}};
             mma_chains2<PREC, 2, true, false>(s, 6, z0[0], z0[1], acc, cur);
             SHERF_NEXT_STEP();
-            finish_quad<PREC, true>(acc, ha[0] + 4 * P, ha[1] + 4 * P);
+            finish_quad<PREC, true, false>(acc, ha[0] + 4 * P, ha[1] + 4 * P);
         }
     }
     SHERF_LAYER128_2(13, ha, hb, true)     // pts_linears.1-4
@@ -992,7 +1028,7 @@ __device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __re
             SHERF_NEXT_STEP();
             mma_chains2<PREC, 4, true, false>(cx.slot(step), 0, ha[0] + 4, ha[1] + 4, acc, cur);
             SHERF_NEXT_STEP();
-            finish_quad<PREC, true>(acc, hb[0] + 4 * P, hb[1] + 4 * P);
+            finish_quad<PREC, true, false>(acc, hb[0] + 4 * P, hb[1] + 4 * P);
         }
     }
     SHERF_LAYER128_2(33, hb, ha, true)     // pts_linears.6
@@ -1002,7 +1038,7 @@ __device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __re
     {   // alpha_linear (chunk 45, split-K over hb)
         f32x16 acc[2][2];
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[0][0] = bias_tile(cx, 45); acc[1][0] = acc[0][0]; acc[0][1] = zero; acc[1][1] = zero;
+        acc[0][0] = bias_tile(cx, 45); acc[1][0] = bias_tile(cx1, 45); acc[0][1] = zero; acc[1][1] = zero;
         mma_chains2<PREC, 4, false, false>(cx.slot(step), 0, hb[0], hb[1], acc, cur);
         SHERF_NEXT_STEP();
         mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
@@ -1026,14 +1062,15 @@ __device__ __forceinline__ void decoder_tile2(Ctx<PREC>& cx, const int32_t* __re
         const BFrag<PREC> z1[2][2] = {{zfrag(0, 2), zfrag(0, 3)}, {zfrag(1, 2), zfrag(1, 3)}};
         mma_chains2<PREC, 2, true, false>(s, 4, z1[0], z1[1], acc, cur);
         SHERF_NEXT_STEP();
-        finish_quad<PREC, true>(acc, gb[0], gb[1]);
+        finish_quad<PREC, true>(acc, gb[0], gb[1]);          // (no DMA issue behind the last steps: the settle stays)
     }
     {   // rgb_linear (chunk 48, split-K over gb) -> sigmoid
         f32x16 acc[2][2];
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[0][0] = bias_tile(cx, 48); acc[1][0] = acc[0][0]; acc[0][1] = zero; acc[1][1] = zero;
+        acc[0][0] = bias_tile(cx, 48); acc[1][0] = bias_tile(cx1, 48); acc[0][1] = zero; acc[1][1] = zero;
         mma_chains2<PREC, 2, false, false>(cx.slot(step), 0, gb[0], gb[1], acc, cur);
         mfma_settle4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+        SHERF_TRACE_STAMP(cx, step, 0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (live[t] && h == 0) {
@@ -1065,7 +1102,7 @@ __device__ __forceinline__ void ring_prologue(Ctx<PREC>& cx) {
     dma_issue(cx, S0 + 2);
 }
 template <int PREC>
-__device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* ws, const float* wbias) {
+__device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* ws, const float* wbias, bool lds_trace = true) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
     float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
@@ -1076,7 +1113,8 @@ __device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* w
     cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
 #if SHERF_MLP_TRACE
     cx.trace = reinterpret_cast<uint32_t*>(lds + NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4) + cx.wave * 256;
-    if (cx.lane == 0) {
+    cx.treg = !lds_trace; cx.tv[0] = cx.tv[1] = cx.tv[2] = 0;
+    if (lds_trace && cx.lane == 0) {
         cx.trace[63 * 4] = (uint32_t)__builtin_amdgcn_s_memtime();
         cx.trace[63 * 4 + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_ID: wave slot, SIMD, CU, SH, SE
         cx.trace[63 * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // XCC_ID
@@ -1116,7 +1154,10 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     float xc[3], vc[3];
     const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
     xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
-    transformer_tile<PREC, true>(cx, tokens, extras, tile, z0b, z1b);
+    {
+        f32x16 tok[3];
+        transformer_tile<PREC, true>(cx, tokens, extras, tile, z0b, z1b, tok);
+    }
     decoder_tile<PREC>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out);
     SHERF_TRACE_FLUSH(cx);
 }
@@ -1137,7 +1178,8 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     const int64_t n_tiles = (nv + 31) / 32;
     if ((int64_t)blockIdx.x * (2 * NW) >= n_tiles) return;           // whole workgroup beyond the data
     CX cx;
-    ring_ctx<PREC>(cx, lds, ws, wbias);
+    ring_ctx<PREC>(cx, lds, ws, wbias, false);
+    SHERF_TRACE_REG(cx, 0);
     int64_t tile[2];
     bool live[2];
 #pragma unroll
@@ -1149,6 +1191,7 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     ring_prologue<PREC, 0>(cx);                                      // steps 0, 1 issued, step 0 landed, step 2 issued
     wait_vm((SHERF_MLP_ABLATE & 32) ? 0 : step_pieces<PREC>(2) / NW);   // step 1 (this wave's pieces) landed too
     wg_barrier();
+    SHERF_TRACE_REG(cx, 1);
     char* park = lds + RING + TABLES + cx.wave * PARK + cx.lane * 16;
     float xc[2][3], vc[2][3];
 #pragma unroll
@@ -1159,8 +1202,12 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     {
         const char* ring_lane = cx.lds;
         const float* tables = cx.wbias;
+        f32x16 tnext[3];
+        load_tokens(tokens, tile[0], cx.lane & 31, cx.h, tnext);
 #pragma unroll 1
         for (int t = 0; t < 2; ++t) {
+            f32x16 tok[3] = {tnext[0], tnext[1], tnext[2]};
+            if (t == 0) load_tokens(tokens, tile[1], cx.lane & 31, cx.h, tnext);      // tile 1's tokens arrive under tile 0's arithmetic
             // (the weights and tables in LDS do not change between the tiles: launder the offsets, as nerf_tokens_kernel does, or the
             //  compiler hoists their reads out of the loop)
             uint32_t woff = 0, boff = 0;
@@ -1168,10 +1215,11 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
             cx.lds = ring_lane + woff;
             cx.wbias = tables + boff;
             BFrag<PREC> z0b[2], z1b[2];
-            transformer_tile<PREC, false>(cx, tokens, extras, t ? tile[1] : tile[0], z0b, z1b);
+            transformer_tile<PREC, false, true>(cx, tokens, extras, t ? tile[1] : tile[0], z0b, z1b, tok);
             char* pk = park + t * 4096;
             *reinterpret_cast<u32x4*>(pk) = z0b[0].hi; *reinterpret_cast<u32x4*>(pk + 1024) = z0b[1].hi;
             *reinterpret_cast<u32x4*>(pk + 2048) = z1b[0].hi; *reinterpret_cast<u32x4*>(pk + 3072) = z1b[1].hi;
+            SHERF_TRACE_REG(cx, 2 + t);
         }
         cx.lds = ring_lane;
         cx.wbias = tables;
@@ -1181,7 +1229,17 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     wg_barrier();
     dma_issue(cx, 3);
     dma_issue(cx, 4);
+    SHERF_TRACE_REG(cx, 4);
     decoder_tile2<PREC>(cx, counters, park, xc, vc, tile, live, nv, out);
+#if SHERF_MLP_TRACE
+    if (g_mlp_trace && g_mlp_trace_every > 0 && blockIdx.x % g_mlp_trace_every == 0) {      // [slot][wave 0..3][192]: stamps; 189 XCC_ID, 190 HW_ID, 191 end
+        SHERF_TRACE_REG(cx, 191);
+        trace_put(cx, 190, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+        trace_put(cx, 189, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)));
+        uint32_t* dst = g_mlp_trace + ((size_t)(blockIdx.x / g_mlp_trace_every) * 4 + cx.wave) * 192 + cx.lane;
+        dst[0] = cx.tv[0]; dst[64] = cx.tv[1]; dst[128] = cx.tv[2];
+    }
+#endif
 }
 
 // ---- the two-launch form -------------------------------------------------------------------------------------------------------
@@ -1221,7 +1279,10 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
         cx.lds = lds + woff;
         cx.wbias = lbias + boff;
         BFrag<PREC> z0b[2], z1b[2];
-        transformer_tile<PREC, false>(cx, tokens, extras, tile, z0b, z1b);
+        {
+            f32x16 tok[3];
+            transformer_tile<PREC, false>(cx, tokens, extras, tile, z0b, z1b, tok);
+        }
         u32x4* zp = zfrag + tile * (ZFRAGS<PREC> * 64) + cx.lane;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {

@@ -343,6 +343,9 @@ class ImportanceRenderer(nn.Module):
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
         # the per-sample network as two launches (sherf_nerf_mlp_split): opt-in, measured slower than the one-launch kernel (see _set_config)
         self.mlp_split = {'': None, '0': False, '1': True}[os.environ.get('SHERF_MLP_SPLIT', '')]
+        # two 32-sample tiles per wave in the per-sample network of the single-product precisions (sherf_nerf_mlp2, round 5; the same bits
+        # as the one-tile kernel): rendering option `mlp_two_tiles`, default from SHERF_MLP_TWO_TILES (on)
+        self.mlp_two_tiles = os.environ.get('SHERF_MLP_TWO_TILES', '1') == '1'
         # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
         # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
         self.mlp_parts = int(os.environ.get('SHERF_MLP_PARTS', '0'))
@@ -710,6 +713,9 @@ class ImportanceRenderer(nn.Module):
         split = getattr(self, '_opt_mlp_split', None)
         if split is None:
             split = bool(getattr(self, 'mlp_split', None))
+        two = getattr(self, '_opt_mlp_two_tiles', None)
+        if (bool(getattr(self, 'mlp_two_tiles', True)) if two is None else bool(two)) and cfg[0] != 'f16x3' and not split:
+            fr.flags |= 32                                                   # SHERF_FRAME_MLP_TWO_TILES
         fr.zfrag = None
         if split:
             ws = self._workspace(dev)
@@ -814,6 +820,7 @@ class ImportanceRenderer(nn.Module):
         smpl = self._smpl(dev)
         cfg, calibrate = self._resolve_config(opts, decoder, dev)
         self.__dict__['_opt_mlp_split'] = opts.get('mlp_split')
+        self.__dict__['_opt_mlp_two_tiles'] = opts.get('mlp_two_tiles')
         prec_name = cfg[0]
         wc = self._weights(decoder, dev, prec_name)
         wsp = self._workspace(dev)
@@ -960,7 +967,7 @@ class ImportanceRenderer(nn.Module):
             self._flag_watch(ws, dev)                      # the frame's count and flags (non-finite fp16 operand, token overflow): no host wait
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=wsp.tok_cap, sampler_cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_parts=int(fr.mlp_parts),
+        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=wsp.tok_cap, sampler_cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_two_tiles=bool(fr.flags & 32), mlp_parts=int(fr.mlp_parts),
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min.reshape(-1)[:3], vox_sh=[int(v) for v in obs_sp_input['out_sh']],

@@ -29,7 +29,7 @@ def main():
     ap.add_argument('--config', default='cfg2_ri')
     ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'])
     ap.add_argument('--stress', type=int, default=0)
-    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split); pipe = the round-4 pipelined experiment, if the library has it')
+    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), tt (sherf_nerf_mlp2: two tiles per wave); pipe = the round-4 pipelined experiment, if the library has it')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_ab.json'))
     a = ap.parse_args()
     import bench
@@ -65,11 +65,14 @@ def main():
         pipe = getattr(lib, 'sherf_nerf_mlp_pipe', None)
         if pipe is not None:
             pipe.restype, pipe.argtypes = one.restype, one.argtypes
-        return one, two, pipe
+        tt = getattr(lib, 'sherf_nerf_mlp2', None)
+        if tt is not None:
+            tt.restype, tt.argtypes = one.restype, one.argtypes
+        return one, two, pipe, tt
 
     def launch(fn, form):
-        if form in ('one', 'pipe'):
-            return fn[0 if form == 'one' else 2](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
+        if form in ('one', 'pipe', 'tt'):
+            return fn[{'one': 0, 'pipe': 2, 'tt': 3}[form]](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
         return fn[1](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(zfrag), A(out), stream)
 
     def timed(fn, form, iters=20):
@@ -91,7 +94,8 @@ def main():
     ref = out[:nv].clone()
     forms = [f for f in a.forms.split(',') if f]
     arms = [(t, form) for t, fn in bound.items() for form in forms
-            if form == 'one' or (form == 'two' and fn[1] is not None) or (form == 'pipe' and fn[2] is not None and a.precision != 'f16x3')]
+            if form == 'one' or (form == 'two' and fn[1] is not None) or (form == 'pipe' and fn[2] is not None and a.precision != 'f16x3')
+            or (form == 'tt' and fn[3] is not None and a.precision != 'f16x3')]
     for _ in range(40):                                         # clock warm-up
         launch(bound['product'], 'one')
     torch.cuda.synchronize()
@@ -119,7 +123,7 @@ def main():
         idxs = [torch.randint(0, big.numel(), (n,), device=dev) for n in (1 << 18, 1 << 21, 1 << 23, 3 << 20)]
         bad = {}
         for form in forms:
-            if form == 'pipe' and a.precision == 'f16x3':
+            if form in ('pipe', 'tt') and a.precision == 'f16x3':
                 continue
             n_bad_launches, n_bad_words = 0, 0
             for it in range(a.stress):
