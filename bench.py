@@ -133,8 +133,20 @@ def make_workload(a, theta, dev):
                 obs_img=d['obs_img_all'][:, 0], opts=opts)
 
 
+def fresh_copy(d):
+    """The frame's inputs with the tensors the valid-sample count depends on CLONED (rays, depth range, posed vertices, the SMPL frame's global
+    rotation / translation): what a caller rendering a sequence hands over -- new tensors every frame."""
+    d2 = dict(d)
+    for k in ('ray_o_all', 'ray_d_all', 'near_all', 'far_all', 'vertices'):
+        d2[k] = d[k].clone()
+    d2['params'] = dict(d['params'])
+    for k in ('R', 'Th'):
+        d2['params'][k] = d['params'][k].clone()
+    return d2
+
+
 def render_frame(w):
-    d = w['d']
+    d = fresh_copy(w['d']) if w.get('fresh') else w['d']
     with torch.no_grad():
         return w['rend'](w['planes'], w['obs_img'], w['obs_feat'], w['sp'], None, w['sp_input'], w['dec'], d['ray_o_all'][:, 0],
                          d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0], d, w['opts'])
@@ -158,7 +170,11 @@ def time_frames(w, steps, warmup, dev, streams=None):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=False, split=False):
+MLP_FORM_ENTRY = dict(one='sherf_nerf_mlp', pipelined='sherf_nerf_mlp3', two_tiles='sherf_nerf_mlp2')
+MLP_FORM_KERNEL = dict(one='nerf_mlp_kernel', pipelined='nerf_mlp3_kernel', two_tiles='nerf_mlp2_kernel')
+
+
+def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=False, split=False, form='one'):
     """`sherf_nerf_mlp` (split: `sherf_nerf_mlp_split`, the two-launch form) alone on the tokens of the frame `w` rendered last, in
     `precision`: (ms per call from HIP events on the launch stream, its [nv, 4] output)."""
     import ctypes as ct
@@ -181,7 +197,7 @@ def mlp_kernel_alone(w, precision, dev, iters=None, warmup=None, exact_grid=Fals
         launch = lambda: _lib.call('sherf_nerf_mlp_split', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
                                    MLP_PRECISIONS[precision], cap, A(zfrag), A(out), stream)
     else:
-        launch = lambda: _lib.call('sherf_nerf_mlp', A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
+        launch = lambda: _lib.call(MLP_FORM_ENTRY[form], A(ws['counters']), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']),
                                    MLP_PRECISIONS[precision], cap, A(out), stream)
     for _ in range(warmup):
         launch()
@@ -214,6 +230,10 @@ def secondary_measurements(a, w, dev, nv, R):
                               sigma_rel_err_max_vs_f16x3=float(((got[:, 3].clamp(min=0) - sig).abs() / sig.clamp(min=1.0)).max()),
                               rgb_rel_err_max_vs_f16x3=float(((got[:, :3] - ref[:, :3]).abs() / ref[:, :3].abs().clamp(min=0.1)).max()))
             ms2, got2 = mlp_kernel_alone(w, name, dev, split=True)
+            for form in ('pipelined', 'two_tiles'):                  # round 5's launch forms of the single-product network (the product default: pipelined)
+                msf, gotf = mlp_kernel_alone(w, name, dev, form=form)
+                rows[f'{name}_{form}'] = dict(kernel_ms=msf, achieved_tflops=fl(msf), frac=fl(msf) / PEAK_BF16_TFLOPS, mfma_per_product=1,
+                                              form=f'one launch ({MLP_FORM_KERNEL[form]})', bit_identical_to_one_tile_kernel=bool(torch.equal(got, gotf)))
             rows[name + '_two_launches'] = dict(kernel_ms=ms2, achieved_tflops=fl(ms2), frac=fl(ms2) / PEAK_BF16_TFLOPS, mfma_per_product=1,
                                                 form='nerf_tokens_kernel + nerf_decoder_kernel (sherf_nerf_mlp_split)',
                                                 bit_identical_to_one_launch=bool(torch.equal(got, got2)))
@@ -279,7 +299,7 @@ def pmc_traffic(a, lrank, timeout=150):
             per = {}                                  # the network's kernels (one launch, or the two of sherf_nerf_mlp_split): mean per dispatch, summed
             for x in rows:
                 kn = x.get('Kernel_Name', '')
-                for key in ('nerf_mlp_kernel', 'nerf_tokens_kernel', 'nerf_decoder_kernel'):
+                for key in ('nerf_mlp_kernel', 'nerf_mlp2_kernel', 'nerf_mlp3_kernel', 'nerf_tokens_kernel', 'nerf_decoder_kernel'):
                     if key in kn and x.get('Counter_Name') == counter:
                         per.setdefault(key, []).append(float(x['Counter_Value']))
             if not per:
@@ -298,8 +318,8 @@ def pmc_traffic(a, lrank, timeout=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='cfg2_dense_ri',
                     help='cfg2_dense_ri (default) = BASELINE config 2 framed at the valid-sample fraction SURVEY 8(d) sized the path on (7.6 %%), with '
                          'the network SURVEY 8(d) specifies (the reference constructors\' initialisation, alpha bias + 5) and band-limited tables; '
@@ -309,14 +329,19 @@ def main():
                     help='MLP operand precision; auto (the product default) = calibrated per set of weights on the first frame')
     ap.add_argument('--table-precision', default=None, choices=['f32', 'f16'], help='override the folded tables\' format (default: follows the MLP precision)')
     ap.add_argument('--encoder-precision', default=None, choices=['f16x3', 'f16'], help='override the sparse convolutions\' operand precision (default: follows the tables)')
-    ap.add_argument('--streams', type=int, default=4,
-                    help='caller streams the frames are issued on, round-robin (each frame is one ImportanceRenderer.forward on its '
-                         'stream; every stream has its own workspace).  4 (default since round 4): the low-occupancy first phase of three frames (cell '
-                         'lists, sampling, the encoder\'s chain of small launches) runs under the chip-filling gather / network of a fourth -- the '
-                         'job is then bound by the sum of the chip-filling kernels (dense framing 1.70 -> 1.49 ms per frame, cfg2_ri 1.17 -> 1.05; '
-                         '2 and 3 streams are SLOWER than 1: profiles/r04_call_s_t_caller_streams.txt).  1 = one frame in flight; the roofline and '
-                         'the frame timeline are always measured that way (a second, untimed pass) -- with frames overlapping a launch\'s wall time is '
-                         'not its cost')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='caller streams the frames are issued on, round-robin (each frame is one ImportanceRenderer.forward on its stream; every '
+                         'stream has its own workspace).  1 (default since round 5) = ONE frame in flight: the metric SURVEY 8(d) defines (R / wall '
+                         'time of one ImportanceRenderer.forward) and what the reference\'s strictly sequential evaluation loop does -- `value`, the '
+                         'roofline and the frame timeline all come from this one process.  The throughput with four frames in flight (round 4\'s '
+                         'headline: the low-occupancy first phase of three frames under the chip-filling kernels of a fourth, 1.70 -> 1.49 ms per '
+                         'frame at 3.4 x the latency) is measured by a child run and reported beside it as `value_frames_overlapped`')
+    ap.add_argument('--overlap-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--fresh-inputs', action='store_true',
+                    help='every frame gets FRESH input tensors (rays, depth range, vertices, SMPL parameters cloned per frame): the identity caches of '
+                         'the renderer miss as they do on a real sequence, so the token-capacity check behind the sampler runs (one host wait per '
+                         'frame).  Default off: the same tensors every frame, like a renderer turned around a fixed subject with unchanged rays; '
+                         'the N = 1 line reports both (`secondary.fresh_inputs`)')
     ap.add_argument('--partition', default='views', choices=['views', 'rays'],
                     help='N > 1: views (default, BASELINE config 4: every rank renders its own target view, weak scaling) or rays (ONE frame '
                          'cut into interleaved 1024-ray tiles over the ranks, sherf_amd.dist.ray_tiles: strong scaling, value = the frame\'s '
@@ -371,6 +396,7 @@ def main():
         _dbg.lib().sherf_set_debug(int(os.environ['SHERF_DEBUG'], 0))     # ablation runs only (sampler: 1 = no candidates, 2 = every sample)
     rays_mode = world > 1 and a.partition == 'rays'
     w = make_workload(a, 0.4 if rays_mode else 0.4 + rank * 2 * np.pi / max(world, 1), dev)
+    w['fresh'] = bool(a.fresh_inputs)
     rend, opts = w['rend'], w['opts']
     R_frame = w['d']['ray_o_all'].shape[2]
     if rays_mode:
@@ -466,7 +492,7 @@ def main():
     # workload, same box, right after the timed region); in this process they would also be distorted by HIP's mapping of a dozen streams
     # onto four hardware queues (measured: 2.9 instead of 1.7 ms per frame for one frame in flight after a four-stream run).
     prof_overlap, one_frame = None, None
-    if n_streams > 1 and world == 1 and rank == 0:
+    if n_streams > 1 and world == 1 and rank == 0 and not a.overlap_child:
         prof_overlap = prof
         one_frame = bench_child(a, lrank, ['--streams', '1', '--steps', str(max(8, min(a.steps, 24))), '--warmup', '6']
                                 + (['--no-secondary'] if a.no_secondary else []))
@@ -501,7 +527,7 @@ def main():
             two = bool(rend.last.get('mlp_split'))
             tiles = (nv + 31) // 32
             res['roofline'] = dict(kernel='nerf_tokens_kernel + nerf_decoder_kernel (sherf_nerf_mlp_split: the network as two launches, timed together)' if two
-                                   else 'nerf_mlp_kernel', bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                                   else MLP_FORM_KERNEL.get(rend.last.get('mlp_form', 'one'), 'nerf_mlp_kernel'), bound='mfma', achieved=ach, peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
                                    frac=ach / PEAK_BF16_TFLOPS, traffic=None, kernel_ms=mlp_ms,
                                    algorithmic_flop_per_launch=nv * FLOP_PER_VALID_SAMPLE,
                                    # what the matrix pipe EXECUTES: 374 v_mfma_f32_32x32x16 per 32-sample tile and product (the two 1x1 projections of
@@ -522,6 +548,21 @@ def main():
             res['frame_timeline_ms'] = {k: round(float(v), 4) for k, v in zip(names, prof[:, :7].mean(0))}
             res['frame_timeline_ms']['host_per_step_python'] = round(1e3 * host_alone, 4)          # Python + native enqueue, empty queue
             res['frame_timeline_ms']['host_wall_per_step_in_timed_loop'] = round(1e3 * host_dt / a.steps, 4)   # (includes queue back-pressure)
+        if a.overlap_child and len(prof):                   # (child of a one-stream run: throughput + latency with frames overlapping, nothing else)
+            res['latency_ms_per_frame'] = round(float(prof[:, 6].mean()), 4)
+            res['kernel_ms_with_frames_overlapping'] = float(prof[:, 7].mean())
+        if n_streams == 1 and world == 1 and not a.overlap_child and len(prof):
+            res['latency_ms_per_frame'] = round(float(prof[:, 6].mean()), 4)          # one frame in flight: the frame's own duration on the GPU
+        if n_streams == 1 and world == 1 and not a.overlap_child and not a.no_secondary and dev.type == 'cuda':
+            # round 4's headline beside the metric proper: the same frames issued round-robin on FOUR caller streams (own workspaces and side
+            # streams each) -- whole-job throughput with the first phase of three frames hidden under the chip-filling kernels of a fourth
+            ov = bench_child(a, lrank, ['--streams', '4', '--overlap-child', '--steps', str(max(a.steps, 100)), '--warmup', '16', '--no-secondary'])
+            res['value_frames_overlapped'] = ov.get('value'); res['ms_per_step_frames_overlapped'] = ov.get('ms_per_step')
+            res['latency_ms_per_frame_with_frames_overlapping'] = ov.get('latency_ms_per_frame')
+            res['frames_overlapped'] = dict(caller_streams=4, steps=ov.get('steps'), kernel_ms_with_frames_overlapping=ov.get('kernel_ms_with_frames_overlapping'),
+                                            workspaces=(ov.get('config') or {}).get('workspaces'), error=ov.get('error'),
+                                            note='child run of this file with --streams 4: every frame does all of its work (no cross-frame caching), four frames are in '
+                                                 'flight, each on its own 1.6 GB workspace; a frame then takes `latency_ms_per_frame_with_frames_overlapping`')
         if one_frame is not None and one_frame.get('error'):
             res['one_frame_in_flight_child'] = one_frame
         if world == 1 and not a.no_secondary:
@@ -545,6 +586,23 @@ def main():
             if dense.get('rays_per_s'):                  # the valid-sample fraction SURVEY 8(d) sized the path on (0.076): first class
                 res['value_dense'] = dense['rays_per_s']; res['ms_per_step_dense'] = dense['ms_per_frame']
                 res['valid_fraction_dense'] = dense['valid_fraction']
+        res['config']['inputs'] = ('FRESH tensors every frame (--fresh-inputs)' if a.fresh_inputs else
+                                   'the same input tensors every frame (the renderer\'s identity caches hit: no host wait per frame); `secondary.fresh_inputs` = new tensors per frame')
+        if world == 1 and not a.no_secondary and not a.overlap_child and n_streams == 1 and not a.fresh_inputs and isinstance(res.get('secondary'), dict):
+            try:                                            # the sequence case -- rays / vertices / pose in new tensors every frame
+                w['fresh'] = True
+                st0 = dict((rend.__dict__.get('_flags') or {}))
+                ms_f = time_frames(w, max(20, min(a.steps, 100)), 5, dev)
+                st1 = rend.__dict__.get('_flags') or {}
+                res['secondary']['fresh_inputs'] = dict(ms_per_frame=ms_f, rays_per_s=R / (ms_f * 1e-3), frames_in_flight=1,
+                                                        token_rerenders=int(st1.get('token_rerenders', 0)) - int(st0.get('token_rerenders', 0)),
+                                                        note='rays, depth range, posed vertices and the SMPL frame cloned into NEW tensors every frame: the valid-sample count is '
+                                                             'read back right behind the sampler (one host wait per frame, the rest of the frame stays in flight) and checked '
+                                                             'against the token workspace; the clones themselves (8.5 MB) are inside the timed region')
+            except Exception as ex:
+                res['secondary']['fresh_inputs'] = dict(error=f'{type(ex).__name__}: {str(ex)[:200]}')
+            finally:
+                w['fresh'] = False
         ours = None
         if world == 1 and not a.no_torch_gpu_baseline:      # our own samples of the frame, for the margin protocol below
             flat = step().detach().float().cpu()
@@ -554,6 +612,13 @@ def main():
                         sample_out=lw['sample_out'][:nv].cpu())
         if world == 1 and not a.no_train and not a.no_secondary and not os.environ.get('SHERF_HIPCPU_LIB'):
             res['train'] = train_step_child(lrank)
+        if world == 1 and not a.no_secondary and not a.overlap_child and not os.environ.get('SHERF_HIPCPU_LIB') and isinstance(res.get('secondary'), dict):
+            # the drop-in's real entry point at real size: TriPlaneGenerator.forward with the full-size StyleGAN2 backbone and both
+            # ResNet-18 passes around this renderer, per-stage HIP-event breakdown (bench_generator.py, a child process)
+            gf = generator_forward_child(a, lrank)
+            if gf.get('value'):
+                gf['rays_per_s_vs_renderer_alone'] = gf['value'] / res['value']
+            res['secondary']['generator_forward'] = gf
         if not a.no_cpu_baseline and world == 1:            # reported at N = 1 only (rank 0's host cores)
             res['cpu_baseline'] = cpu_baseline(a.config)
         if world == 1 and not a.no_pmc and 'roofline' in res:
@@ -578,6 +643,10 @@ def main():
             else:
                 res['parity'] = dict(error='the oracle child wrote no frame: ' + str(res['torch_gpu_baseline'].get('error')), ok=False)
             res['parity_ok'] = bool(res['parity'].get('ok'))
+        # the keys a reader compares across rounds first (the driver's tail cuts long lines)
+        first = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'latency_ms_per_frame', 'value_frames_overlapped', 'ms_per_step_frames_overlapped',
+                 'latency_ms_per_frame_with_frames_overlapping', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'parity_ok', 'roofline', 'cpu_baseline')
+        res = {**{k: res[k] for k in first if k in res}, **{k: v for k, v in res.items() if k not in first}}
         print(json.dumps(res))
         if res.get('parity_ok') is False:
             sys.stdout.flush()
@@ -707,6 +776,22 @@ def train_step_child(lrank, timeout=240):
             return dict(error=f'child rc={r.returncode}: {r.stderr.strip()[-300:]}')
         d = json.loads(line[-1])
         return {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'phases_ms', 'host_ms', 'roofline', 'dtype', 'config', 'final_loss')}
+    except Exception as ex:
+        return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
+
+
+def generator_forward_child(a, lrank, timeout=300):
+    """bench_generator.py in a child process -> its JSON line (TriPlaneGenerator.forward at full size: rays/s, stage table, cached-backbone variant)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['LOCAL_RANK'] = str(lrank)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_generator.py'), '--config', a.config, '--precision', a.precision, '--steps', '20', '--warmup', '5'],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if not line:
+            return dict(error=f'child rc={r.returncode}: {r.stderr.strip()[-300:]}')
+        return json.loads(line[-1])
     except Exception as ex:
         return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
 

@@ -206,6 +206,11 @@ int sherf_nerf_mlp_part(const int32_t* counters, const float* tokens, const floa
  * chains, two 4-wave workgroups of eight tiles per CU.  Same inputs, same outputs bit for bit as sherf_nerf_mlp. */
 int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                     const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* sherf_nerf_mlp for the single-product precisions (prec 0, 2 only), one tile per wave, with every layer epilogue of the decoder (fp32 -> fp16
+ * repack, ReLU, the next bias tiles) issued INSIDE the following ring step's MFMA stream on a second pair of accumulators (csrc/mlp.hip:
+ * nerf_mlp3_kernel, round 5).  Same inputs, same outputs bit for bit as sherf_nerf_mlp. */
+int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
 /* The same network as TWO launches (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel), results bit-identical to sherf_nerf_mlp:
  * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS;
  * launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  zfrag: scratch for the fused tokens,
@@ -370,6 +375,10 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
 /* frame->flags & SHERF_FRAME_MLP_TWO_TILES: the per-sample network of a single-product precision (mlp_prec 0, 2) runs as sherf_nerf_mlp2 (two tiles
  * per wave) instead of sherf_nerf_mlp; ignored for mlp_prec 1, for SHERF_FRAME_MLP_SPLIT and for mlp_parts > 1.  Same results bit for bit. */
 #define SHERF_FRAME_MLP_TWO_TILES 32
+/* frame->flags & SHERF_FRAME_MLP_PIPELINED: the per-sample network of a single-product precision (mlp_prec 0, 2) runs as sherf_nerf_mlp3 (one tile
+ * per wave, the decoder's layer epilogues inside the next ring step's MFMA stream) instead of sherf_nerf_mlp; takes precedence over
+ * SHERF_FRAME_MLP_TWO_TILES; ignored for mlp_prec 1, for SHERF_FRAME_MLP_SPLIT and for mlp_parts > 1.  Same results bit for bit. */
+#define SHERF_FRAME_MLP_PIPELINED 64
 /* frame->flags & SHERF_FRAME_REPORT_COUNT: counters[0] (the frame's valid samples) is copied to pinned memory right behind the sampler
  * and sherf_frame_count() returns it after waiting for THAT point of the frame only -- the warp, gather, network and compositing are
  * still in flight.  What a caller uses to check tok_capacity on a frame with new inputs without draining the GPU. */

@@ -57,6 +57,21 @@ def main():
     np.savez_compressed(os.path.join(HERE, '..', 'tests', 'golden', 'backbone_small.npz'), **out)
     full = N.Generator(**FULL)
     table = {n: list(t.shape) for n, t in list(full.named_parameters()) + list(full.named_buffers())}
+    # round 5: the FULL-size generator SHERF instantiates (28.7 M parameters, planes [1, 96, 256, 256]) RUN once, eval mode (fused modulation),
+    # noise_mode const, with the same seeded parameters -> a strided subset + whole-tensor moments of ws and the planes (backbone_full.npz):
+    # what tests/test_gpu_producers.py holds the device run of sherf_amd.stylegan2 at full size against
+    seed_module(full, 'backbone.')
+    zf = torch.from_numpy(np.random.RandomState(5).standard_normal((1, FULL['z_dim'])).astype(np.float32))
+    fo = {}
+    with torch.no_grad():
+        full.eval()
+        wsf = full.mapping(zf, None)
+        fo['ws'] = wsf.numpy()
+        v = full.synthesis(wsf, noise_mode='const').numpy()
+    fo['img_eval_const.sub'] = v[:, ::5, ::9, ::9].copy()
+    fo['img_eval_const.moments'] = np.array([v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64), np.square(v, dtype=np.float64).sum()])
+    np.savez_compressed(os.path.join(HERE, '..', 'tests', 'golden', 'backbone_full.npz'), **fo)
+    print('wrote backbone_full.npz', {k: v.shape for k, v in fo.items()}, 'planes', v.shape, 'abs max', float(np.abs(v).max()))
     small = {n: list(t.shape) for n, t in list(g.named_parameters()) + list(g.named_buffers())}
     json.dump(dict(full=table, small=small, num_ws_full=full.num_ws, num_ws_small=g.num_ws), open(os.path.join(HERE, '..', 'tests', 'golden', 'backbone_shapes.json'), 'w'), indent=0)
     print('wrote backbone_small.npz', {k: v.shape for k, v in out.items()}, len(table), 'full entries')

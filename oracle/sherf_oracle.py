@@ -532,8 +532,9 @@ def render(state, st, planes, obs_img, obs_feat, vertex_feat, sp_input, ray_o, r
             rgbs.append(rgb); sigs.append(sig); toks_in.append(tok); toks_out.append(z)
         rgb_s, sig_s = torch.cat(rgbs), torch.cat(sigs)
         col_full[valid] = rgb_s; sig_full[valid] = sig_s
+        out.update(vert_id=vid, t_vert_id=tvid)               # the discrete selections: what a float64 run on THESE branches re-uses
         if decisions is not None:
-            out.update(vert_id=vid, t_vert_id=tvid, sample_rgb=rgb_s, sample_sigma=sig_s, x_c=x_c)
+            out.update(sample_rgb=rgb_s, sample_sigma=sig_s, x_c=x_c)
         elif keep or options.get('margins'):
             # decision margins of the three discontinuous selectors on the path (shell threshold, nearest posed vertex, nearest
             # T-pose vertex): what tests / bench use to tell an implementation's legitimate boundary flips from errors
@@ -692,6 +693,8 @@ def _gradients_from_fixture(fx, state, stages, device, info=None):
     res = render(st, smpl, leaves['input.planes'][0], d['obs_img_all'][0, 0], leaves['input.obs_feat'][0], leaves['input.vertex_feat'],
                  sp_input, d['ray_o_all'][0, 0], d['ray_d_all'][0, 0], d['near_all'][0, 0, :, 0], d['far_all'][0, 0, :, 0], d,
                  fx['options'], training=True, keep=stages)
+    if info is not None and 'vert_id' in res:
+        info['decisions'] = dict(valid=res['valid'].detach(), vert_id=res['vert_id'].detach(), t_vert_id=res['t_vert_id'].detach())
     watched = {}
     if stages:
         for k in STAGE_KEYS:
@@ -712,6 +715,39 @@ def _gradients_from_fixture(fx, state, stages, device, info=None):
     if stages:
         grads.update({n: torch.cat([t.grad for t in ts]) for n, ts in chunked.items() if ts})
     return float(loss.detach()), grads
+
+
+def gradients_truth64_from_fixture(fx, state, info, device=None):
+    """The float64 TRUTH of the gradients (round 5; the backward's counterpart of truth64_from_fixture): autograd through the same restatement
+    evaluated in float64 from the same fp32 inputs and weights, on the discrete branches (valid set, nearest posed vertex, nearest T-vertex,
+    voxel coordinates) of the fp32 run whose `info` dict (gradients_from_fixture(..., info=info)) is passed in.  Both fp32 gradient sets -- the
+    oracle's own fp32 autograd, pinned to the unmodified reference's backward, and the HIP backward -- are then measured against it per
+    parameter: where the fp32 REFERENCE itself sits far from the truth (gradients that are sums of cancelling terms behind a BatchNorm, ReLU
+    kinks) a looser agreement is conditioning, not a kernel error.  -> (loss, {name: float64 grad})."""
+    dec, spi = info['decisions'], info['sp_input']
+    with _working_dtype(torch.float64):
+        def run(dev):
+            mv = (lambda t: t) if dev is None else (lambda t: t.to(dev))
+            dd = lambda a: (a.double() if a.is_floating_point() else a) if torch.is_tensor(a) else a
+            st = {k: (dd(mv(v)).clone().requires_grad_(True) if v.is_floating_point() else mv(v)) for k, v in state.items()}
+            leaves = {name: dd(mv(torch.from_numpy(np.ascontiguousarray(fx[key])))).requires_grad_(True)
+                      for key, name in (('planes', 'input.planes'), ('obs_feat', 'input.obs_feat'), ('vertex_feat', 'input.vertex_feat'))}
+            to = lambda a: dd(mv(torch.from_numpy(np.ascontiguousarray(a)))) if isinstance(a, np.ndarray) else (dd(mv(a)) if torch.is_tensor(a) else a)
+            d = {k: ({kk: to(vv) for kk, vv in v.items()} if isinstance(v, dict) else to(v)) for k, v in fx['input_data'].items()}
+            smpl = smpl_tensors(fx['smpl'])
+            sp64 = dict(coord=mv(spi['coord']), out_sh=spi['out_sh'], bounds=dd(mv(spi['bounds'])))
+            res = render(st, smpl, leaves['input.planes'][0], d['obs_img_all'][0, 0], leaves['input.obs_feat'][0], leaves['input.vertex_feat'], sp64,
+                         d['ray_o_all'][0, 0], d['ray_d_all'][0, 0], d['near_all'][0, 0, :, 0], d['far_all'][0, 0, :, 0], d, fx['options'],
+                         training=True, keep=False, decisions={k: mv(v) for k, v in dec.items()})
+            loss = stub_loss(res['rgb'], res['acc'])
+            loss.backward()
+            grads = {n: t.grad for n, t in leaves.items()}
+            grads.update({n: t.grad for n, t in st.items() if t.is_floating_point() and t.grad is not None})
+            return float(loss.detach()), grads
+        if device is not None:
+            with torch.device(device):
+                return run(torch.device(device))
+        return run(None)
 
 
 def psnr(a, b):

@@ -28,8 +28,11 @@ struct DevState {
     hipEvent_t ev_start, ev_smpl, ev_enc, ev_mid, ev_fold, ev_lev[8], ev_cnt, ev_part[kMaxParts], ev_mlp;
     int32_t* host_nv = nullptr;      // pinned: the frame's valid-sample count for SHERF_FRAME_EXACT_GRIDS
     hipEvent_t ev_rep[8];            // SHERF_FRAME_REPORT_COUNT: a ring of (pinned word, event) pairs; host_nv[8 + slot]
-    int rep_next = 0, rep_last = -1;
+    int rep_next = 0;
 };
+// the REPORT_COUNT slot of the last frame THIS THREAD enqueued (per device): another thread's (renderer's) frames on the same device take
+// their own slots, and a reader never waits with the enqueue lock held
+thread_local int t_rep_last[kMaxDev] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
 std::mutex g_frame_mu;    // one enqueue at a time: the join events are shared per device
@@ -90,11 +93,16 @@ extern "C" int sherf_frame_count(int32_t* nv_host) {
     int dev = 0;
     SHERF_HIP_CHECK(hipGetDevice(&dev));
     SHERF_CHECK_ARG(dev >= 0 && dev < kMaxDev);
-    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
     DevState& d = g_dev[dev];
-    SHERF_CHECK_ARG(d.init && d.rep_last >= 0);
-    SHERF_HIP_CHECK(hipEventSynchronize(d.ev_rep[d.rep_last]));
-    *nv_host = d.host_nv[8 + d.rep_last];
+    const int slot = t_rep_last[dev];
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+        SHERF_CHECK_ARG(d.init && slot >= 0);
+        ev = d.ev_rep[slot];
+    }
+    SHERF_HIP_CHECK(hipEventSynchronize(ev));          // (no lock held: other threads keep enqueueing; the ring has 8 slots per device)
+    *nv_host = d.host_nv[8 + slot];
     return SHERF_OK;
 }
 
@@ -215,7 +223,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             d.rep_next = (d.rep_next + 1) % 8;
             SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv + 8 + slot, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_rep[slot], main));
-            d.rep_last = slot;
+            t_rep_last[dev] = slot;
         }
         const bool exact = (f->flags & SHERF_FRAME_EXACT_GRIDS) != 0;
         if (exact) {
@@ -281,6 +289,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         if (split)
             SHERF_RUN(sherf_nerf_mlp_split(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->zfrag,
                                            f->sample_out, stream_main));
+        else if (f->mlp_prec != 1 && (((f->flags & SHERF_FRAME_MLP_PIPELINED) != 0) != ((g_sherf_debug & (1 << 25)) != 0)))    // (debug bit 25 flips the form: A/B runs)
+            SHERF_RUN(sherf_nerf_mlp3(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, stream_main));
         else if (f->mlp_prec != 1 && (((f->flags & SHERF_FRAME_MLP_TWO_TILES) != 0) != ((g_sherf_debug & (1 << 24)) != 0)))   // (debug bit 24 flips the form: A/B runs)
             SHERF_RUN(sherf_nerf_mlp2(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, stream_main));
         else

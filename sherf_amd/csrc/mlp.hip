@@ -883,6 +883,164 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
 }
 
 // =====================================================================================================================================
+// Round 5: the decoder with its epilogues INSIDE the MFMA stream (single-product precisions, one tile per wave).
+// What the in-kernel timeline of this round says (profiles/r05_call_c_*): a decoder step that only issues MFMAs runs at ~70 % of the matrix
+// pipe, a step that also carries a pair's epilogue (fp32 -> fp16 repack + ReLU of 32 accumulator registers, the next pair's bias reads) takes
+// ~620 cycles more -- during which the pipe idles: the co-resident workgroup is in its VALU-bound transformer then (the start offsets of
+// co-resident workgroups sit at half a period) and has no MFMAs to offer.  The microbenchmark (tools/ubench/issue_model.hip) shows where such
+// VALU work is free: a handful of instructions between two MFMAs of the SAME wave (8 MFMAs + 24 / 40 VALU: 35 / 36 cycles per MFMA against
+// 33.5 bare).  So here a finished pair of accumulator tiles is NOT converted at once: the next ring step runs on a SECOND pair of accumulators
+// and carries the conversion as four 8-instruction pieces pinned behind its four MFMA blocks; the piece order never crosses a dependency
+// (a layer's K-blocks 0-3 come from the pair finished two steps earlier, 4-7 from the one finished one step earlier, and the weight stream
+// already walks [pair 0: K lo, K hi][pair 1: K lo, K hi]); the bias tiles of a pair are read one step ahead, into the accumulators the
+// previous conversion has just released.  Same MFMA order per accumulator, same conversions: bit-identical to decoder_tile.
+template <int PREC, bool RELU>
+__device__ __forceinline__ void epi_piece(const f32x16& a0, const f32x16& a1, BFrag<PREC>* out, int i) {
+    static_assert(PREC != 1, "single-product precisions");
+    const f32x16& a = i < 2 ? a0 : a1;
+    const int o = (i & 1) * 8;
+    constexpr bool PK = RELU && PREC == 2 && SHERF_MLP_PK_RELU;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (RELU && !PK) ? relu(a[o + r]) : a[o + r];
+    out[i] = make_frag<PREC>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    if constexpr (PK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[i].hi[e] = relu2_f16(out[i].hi[e]);
+    }
+}
+// mma_chains with a filler pinned behind every block: fill(f0 + i) runs between block i and block i + 1
+template <int PREC, int NB, bool PAIR, bool MORE, class F>
+__device__ __forceinline__ void mma_chains_f(const char* s, int u0, const BFrag<PREC>* b, f32x16& acc0, f32x16& acc1, AFrag<PREC>& cur, int f0, F&& fill) {
+    constexpr int UNIT = Ctx<PREC>::UNIT;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        AFrag<PREC> nxt;
+        const bool pre = i + 1 < NB || MORE;
+        if (pre) nxt = load_units<PREC>(s + (u0 + 2 * (i + 1)) * UNIT);
+        const BFrag<PREC>& b0 = b[PAIR ? i : 2 * i];
+        const BFrag<PREC>& b1 = b[PAIR ? i : 2 * i + 1];
+        mfma_block<PREC>(acc0, acc1, cur.h0, cur.h0, cur.h1, cur.h1, b0.hi, b0.hi, b1.hi, b1.hi);
+        __builtin_amdgcn_sched_barrier(0);
+        fill(f0 + i);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pre) cur = nxt;
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __restrict__ counters, const BFrag<PREC> (&z0b)[2], const BFrag<PREC> (&z1b)[2],
+                                               const float (&xc)[3], const float (&vc)[3], int64_t tile, bool live, int64_t nv, float4* __restrict__ out) {
+    const int j = cx.lane & 31, h = cx.h;
+    if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
+    int step = 2;
+    BFrag<PREC> ha[8], hb[8];
+    f32x16 X0, X1, Y0, Y1;                                           // the two accumulator pairs
+    AFrag<PREC> cur = load_units<PREC>(cx.slot(step));
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto none = [](int) {};
+#define SHERF_NEXT_STEP() do { step_wait(cx, step); cur = load_units<PREC>(cx.slot(step + 1)); dma_issue(cx, step + NSLOT); ++step; } while (0)
+    // a 128 -> 128 layer (chunks C0..C0+3, IN -> OUT): pair 0 on X, pair 1 on Y.  On entry X holds pair 0's bias tiles and Y the previous
+    // layer's finished pair 1, whose conversion (-> IN[4..7], PREV_RELU) rides on the first step; on exit Y holds this layer's finished
+    // pair 1 and X the bias tiles NX0, NX1 (-1: zeros) of whatever runs on X next.
+#define SHERF_LAYER128_P(C0, IN, OUT, RELU, PREV_RELU, NX0, NX1)                                                                              \
+    mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, IN, X0, X1, cur, 0, [&](int i) { epi_piece<PREC, PREV_RELU>(Y0, Y1, IN + 4, i); }); \
+    SHERF_NEXT_STEP();                                                                                                                         \
+    mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, IN + 4, X0, X1, cur, 0, [&](int i) { if (i == 0) { Y0 = bias_tile(cx, (C0) + 2); Y1 = bias_tile(cx, (C0) + 3); } }); \
+    SHERF_NEXT_STEP();                                                                                                                         \
+    mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, IN, Y0, Y1, cur, 0, [&](int i) { epi_piece<PREC, RELU>(X0, X1, OUT, i); });           \
+    SHERF_NEXT_STEP();                                                                                                                         \
+    mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, IN + 4, Y0, Y1, cur, 0, [&](int i) { if (i == 0) { X0 = bias_tile(cx, NX0); X1 = (NX1) < 0 ? zero : bias_tile(cx, (NX1) < 0 ? 0 : (NX1)); } }); \
+    SHERF_NEXT_STEP();
+    {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)], one step per pair
+        BFrag<PREC> pe[3];
+        pe_frags<PREC, 6, 3>(h, xc[0], xc[1], xc[2], pe);
+        X0 = bias_tile(cx, 9); X1 = bias_tile(cx, 10);
+        const char* s = cx.slot(step);
+        mma_chains_f<PREC, 3, true, true>(s, 0, pe, X0, X1, cur, 0, [&](int i) { if (i == 0) { Y0 = bias_tile(cx, 11); Y1 = bias_tile(cx, 12); } });
+        mma_chains_f<PREC, 2, true, false>(s, 6, z0b, X0, X1, cur, 3, none);
+        SHERF_NEXT_STEP();
+        s = cx.slot(step);
+        auto carry = [&](int i) { if (i < 4) epi_piece<PREC, true>(X0, X1, ha, i); else { X0 = bias_tile(cx, 13); X1 = bias_tile(cx, 14); } };
+        mma_chains_f<PREC, 3, true, true>(s, 0, pe, Y0, Y1, cur, 0, carry);
+        mma_chains_f<PREC, 2, true, false>(s, 6, z0b, Y0, Y1, cur, 3, carry);
+        SHERF_NEXT_STEP();
+    }
+    SHERF_LAYER128_P(13, ha, hb, true, true, 17, 18)      // pts_linears.1-4
+    SHERF_LAYER128_P(17, hb, ha, true, true, 21, 22)
+    SHERF_LAYER128_P(21, ha, hb, true, true, 25, 26)
+    SHERF_LAYER128_P(25, hb, ha, true, true, 29, 30)
+    {   // pts_linears.5 : [PE6 | z_0 | h(128)], three steps per pair; on entry Y = pts_linears.4's pair 1 (-> ha[4..7])
+        float x0 = xc[0], x1 = xc[1], x2 = xc[2];
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+        BFrag<PREC> pe[3];
+        pe_frags<PREC, 6, 3>(h, x0, x1, x2, pe);
+        const char* s = cx.slot(step);
+        auto carry0 = [&](int i) { if (i < 4) epi_piece<PREC, true>(Y0, Y1, ha + 4, i); };
+        mma_chains_f<PREC, 3, true, true>(s, 0, pe, X0, X1, cur, 0, carry0);
+        mma_chains_f<PREC, 2, true, false>(s, 6, z0b, X0, X1, cur, 3, carry0);
+        SHERF_NEXT_STEP();
+        mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha, X0, X1, cur, 0, [&](int i) { if (i == 0) { Y0 = bias_tile(cx, 31); Y1 = bias_tile(cx, 32); } });
+        SHERF_NEXT_STEP();
+        mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha + 4, X0, X1, cur, 0, none);
+        SHERF_NEXT_STEP();
+        s = cx.slot(step);
+        auto carry1 = [&](int i) { if (i < 4) epi_piece<PREC, true>(X0, X1, hb, i); };
+        mma_chains_f<PREC, 3, true, true>(s, 0, pe, Y0, Y1, cur, 0, carry1);
+        mma_chains_f<PREC, 2, true, false>(s, 6, z0b, Y0, Y1, cur, 3, carry1);
+        SHERF_NEXT_STEP();
+        mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha, Y0, Y1, cur, 0, [&](int i) { if (i == 0) { X0 = bias_tile(cx, 33); X1 = bias_tile(cx, 34); } });
+        SHERF_NEXT_STEP();
+        mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha + 4, Y0, Y1, cur, 0, none);
+        SHERF_NEXT_STEP();
+    }
+    SHERF_LAYER128_P(33, hb, ha, true, true, 37, 38)      // pts_linears.6
+    SHERF_LAYER128_P(37, ha, hb, true, true, 41, 42)      // pts_linears.7
+    SHERF_LAYER128_P(41, hb, ha, false, true, 45, -1)     // feature_linear (no activation) -> ha; X <- alpha_linear's bias / zeros
+    float sigma;
+    BFrag<PREC> gb[4];
+    {
+        // alpha_linear (chunk 45, split-K over hb) on X; carries feature_linear's pair 1 (Y -> ha[4..7]), then reads views_linear's bias tiles into Y
+        mma_chains_f<PREC, 4, false, false>(cx.slot(step), 0, hb, X0, X1, cur, 0, [&](int i) {
+            epi_piece<PREC, false>(Y0, Y1, ha + 4, i);
+            if (i == 3) { Y0 = bias_tile(cx, 46); Y1 = bias_tile(cx, 47); }
+        });
+        SHERF_NEXT_STEP();
+        // views_linear : [feature (8 kb) | PE4(v_c) (2 kb) | z_1 (2 kb)] -> 64, ReLU, on Y; sigma leaves X behind the first block
+        BFrag<PREC> pv[2];
+        pe_frags<PREC, 4, 2>(h, vc[0], vc[1], vc[2], pv);
+        mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha, Y0, Y1, cur, 0, [&](int i) {
+            // (the WHOLE tuples stay live up to here: only element 0 of each is read, and hipcc would hand the other fifteen registers of an
+            //  accumulator to the bias reads above while the MFMA writing them is still in flight -- tools/mfma_hazard_check.py, R1)
+            if (i == 0) { asm volatile("" : "+v"(X0), "+v"(X1)); sigma = X0[0] + X1[0]; }               // row 0: reg 0 of the h == 0 lanes
+        });
+        SHERF_NEXT_STEP();
+        mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha + 4, Y0, Y1, cur, 0, [&](int i) { if (i == 0) { X0 = bias_tile(cx, 48); X1 = zero; } });
+        SHERF_NEXT_STEP();
+        const char* s = cx.slot(step);
+        mma_chains_f<PREC, 2, true, true>(s, 0, pv, Y0, Y1, cur, 0, none);
+        mma_chains_f<PREC, 2, true, false>(s, 4, z1b, Y0, Y1, cur, 2, none);
+        SHERF_NEXT_STEP();
+        finish_pair<PREC, true>(Y0, Y1, gb);                         // rgb_linear needs all of it: nothing to ride on
+    }
+    {
+        mma_chains_f<PREC, 2, false, false>(cx.slot(step), 0, gb, X0, X1, cur, 0, none);
+        mfma_settle(X0, X1);
+        SHERF_TRACE_STAMP(cx, step, 0);
+        if (live && h == 0) {
+            const int64_t c = tile * 32 + j;
+            if (c < nv) {
+                float r = rcp_(1.0f + exp_(-(X0[0] + X1[0]))), g = rcp_(1.0f + exp_(-(X0[1] + X1[1]))), b = rcp_(1.0f + exp_(-(X0[2] + X1[2])));
+                out[c] = make_float4(r * 1.002f - 0.001f, g * 1.002f - 0.001f, b * 1.002f - 0.001f, sigma);   // triplane.py:314
+                if (!(fabsf(sigma) <= 3.0e38f) || !(r + g + b <= 4.0f)) atomicOr(reinterpret_cast<unsigned*>(const_cast<int32_t*>(counters)) + 3, 1u);
+            }
+        }
+    }
+#undef SHERF_NEXT_STEP
+#undef SHERF_LAYER128_P
+}
+
+// =====================================================================================================================================
 // Round 5: TWO 32-sample tiles per wave (single-product precisions).  Why: round 4's counters and timeline say the one-tile kernel sits
 // at the SUM of its issue streams -- per tile a wave issues 374 MFMAs beside ~4 800 other instructions, of which ~1 950 are per-STEP
 // overhead of the weight ring (the A-fragment ds_reads and their waits, the DMA issue, the barrier, the block-opening s_nops) paid once
@@ -1242,6 +1400,37 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
 #endif
 }
 
+// One launch, one tile per wave, the decoder's epilogues inside its MFMA stream (decoder_tile_p; single-product precisions)
+#ifndef SHERF_MLP3_LB
+#define SHERF_MLP3_LB 2
+#endif
+template <int PREC>
+__global__ void __launch_bounds__(NW * 64, SHERF_MLP3_LB)
+nerf_mlp3_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
+                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+    using CX = Ctx<PREC>;
+    __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32;
+    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
+    CX cx;
+    ring_ctx<PREC>(cx, lds, ws, wbias);
+    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    const bool live = tile < n_tiles;
+    if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
+    ring_prologue<PREC, 0>(cx);
+    BFrag<PREC> z0b[2], z1b[2];
+    float xc[3], vc[3];
+    const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
+    xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
+    {
+        f32x16 tok[3];
+        transformer_tile<PREC, true>(cx, tokens, extras, tile, z0b, z1b, tok);
+    }
+    decoder_tile_p<PREC>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out);
+    SHERF_TRACE_FLUSH(cx);
+}
+
 // ---- the two-launch form -------------------------------------------------------------------------------------------------------
 // zfrag[tile][q][64 lanes] u32x4: the fused tokens as ready-made B-operand fragments, q = 2 * (0: z_0, 1: z_1) + kb for the single-product
 // precisions (4 KiB per tile), q = 4 * (z) + 2 * kb + (0: hi, 1: lo) for prec 1 (8 KiB per tile).
@@ -1433,6 +1622,23 @@ extern "C" int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, con
                            reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     else
         hipLaunchKernelGGL((nerf_mlp2_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    SHERF_LAUNCH_CHECK();
+}
+
+// One tile per wave with the decoder's epilogues inside its MFMA stream (nerf_mlp3_kernel): the single-product precisions (prec 0, 2); same
+// inputs, same outputs bit for bit as sherf_nerf_mlp.
+extern "C" int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
+                               const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0);
+    const int64_t tiles = (capacity + 31) / 32;
+    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
+    if (prec == 2)
+        hipLaunchKernelGGL((nerf_mlp3_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL((nerf_mlp3_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
                            reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
     SHERF_LAUNCH_CHECK();
 }

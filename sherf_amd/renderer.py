@@ -343,9 +343,10 @@ class ImportanceRenderer(nn.Module):
         self.exact_grids = os.environ.get('SHERF_EXACT_GRIDS', '0') == '1'
         # the per-sample network as two launches (sherf_nerf_mlp_split): opt-in, measured slower than the one-launch kernel (see _set_config)
         self.mlp_split = {'': None, '0': False, '1': True}[os.environ.get('SHERF_MLP_SPLIT', '')]
-        # two 32-sample tiles per wave in the per-sample network of the single-product precisions (sherf_nerf_mlp2, round 5; the same bits
-        # as the one-tile kernel): rendering option `mlp_two_tiles`, default from SHERF_MLP_TWO_TILES (on)
-        self.mlp_two_tiles = os.environ.get('SHERF_MLP_TWO_TILES', '1') == '1'
+        # launch form of the per-sample network for the single-product precisions (round 5; all forms give the same bits): 'pipelined' =
+        # sherf_nerf_mlp3 (the decoder's layer epilogues inside the next ring step's MFMA stream; the default: 2-3 % faster on the MI355X),
+        # 'two_tiles' = sherf_nerf_mlp2 (two tiles per wave), 'one' = sherf_nerf_mlp.  Rendering option `mlp_form`, default from SHERF_MLP_FORM
+        self.mlp_form = os.environ.get('SHERF_MLP_FORM', 'pipelined')
         # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
         # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
         self.mlp_parts = int(os.environ.get('SHERF_MLP_PARTS', '0'))
@@ -713,9 +714,11 @@ class ImportanceRenderer(nn.Module):
         split = getattr(self, '_opt_mlp_split', None)
         if split is None:
             split = bool(getattr(self, 'mlp_split', None))
-        two = getattr(self, '_opt_mlp_two_tiles', None)
-        if (bool(getattr(self, 'mlp_two_tiles', True)) if two is None else bool(two)) and cfg[0] != 'f16x3' and not split:
-            fr.flags |= 32                                                   # SHERF_FRAME_MLP_TWO_TILES
+        form = getattr(self, '_opt_mlp_form', None) or getattr(self, 'mlp_form', 'pipelined')
+        if form not in ('pipelined', 'two_tiles', 'one'):
+            raise ValueError(f"mlp_form must be 'pipelined', 'two_tiles' or 'one', not {form!r}")
+        if cfg[0] != 'f16x3' and not split:
+            fr.flags |= {'pipelined': 64, 'two_tiles': 32, 'one': 0}[form]   # SHERF_FRAME_MLP_PIPELINED / SHERF_FRAME_MLP_TWO_TILES
         fr.zfrag = None
         if split:
             ws = self._workspace(dev)
@@ -820,7 +823,7 @@ class ImportanceRenderer(nn.Module):
         smpl = self._smpl(dev)
         cfg, calibrate = self._resolve_config(opts, decoder, dev)
         self.__dict__['_opt_mlp_split'] = opts.get('mlp_split')
-        self.__dict__['_opt_mlp_two_tiles'] = opts.get('mlp_two_tiles')
+        self.__dict__['_opt_mlp_form'] = opts.get('mlp_form')
         prec_name = cfg[0]
         wc = self._weights(decoder, dev, prec_name)
         wsp = self._workspace(dev)
@@ -909,11 +912,15 @@ class ImportanceRenderer(nn.Module):
         # a frame whose rays / vertices are not the previous frame's tensors may hold any number of valid samples: its count is read back
         # right behind the sampler (the rest of the frame stays in flight) and the frame is rendered again if it did not fit.  Frames on the
         # same inputs (a benchmark loop) and slowly changing sequences on explicit / worst-case capacities never wait.
-        scene = (input_data['vertices'].data_ptr(), input_data['vertices']._version, ray_origins.data_ptr(), ray_origins._version,
-                 near.data_ptr(), near._version, far.data_ptr(), far._version)
+        # (everything the count depends on: the posed vertices, the rays' origins AND directions, the depth range, the global rotation /
+        #  translation of the SMPL frame.  The keyed tensors are kept referenced so that a freed tensor's address cannot come back at
+        #  version 0 and compare equal -- ADVICE round 4)
+        keyed = (input_data['vertices'], ray_origins, ray_directions, near, far, prm['R'], prm['Th'])
+        scene = tuple(x for t in keyed for x in (t.data_ptr(), t._version))
         verify = (not first and wsp.__dict__.get('scene') != scene and wsp.tok_cap < cap
                   and opts.get('token_capacity', getattr(self, 'token_capacity', 'auto')) == 'auto' and tok < cap)
         wsp.scene = scene
+        wsp.scene_refs = keyed
         self.__dict__['_opt_report_count'] = verify
         if tok != wsp.tok_cap:
             if dev.type == 'cuda' and not isinstance(ws['counters'], type(None)) and ws['counters'].device.type == 'cuda':
@@ -959,6 +966,11 @@ class ImportanceRenderer(nn.Module):
                     fr.zfrag = _lib.addr(wsp.zfrag(int(fr.tok_capacity), cfg[0], dev))
                 st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
                 st['token_rerenders'] = st.get('token_rerenders', 0) + 1
+                if decide is not None:
+                    # a calibration frame that had to be rendered again on larger token buffers: the candidates' outputs were taken at the old
+                    # capacity (fewer rows than this frame holds) -- drop this calibration, the next frame calibrates afresh
+                    decide = None
+                    self._wcache['auto'] = None
                 enqueue()
         self.encoder_3d.finish(pl)
         if decide is not None:
@@ -967,7 +979,7 @@ class ImportanceRenderer(nn.Module):
             self._flag_watch(ws, dev)                      # the frame's count and flags (non-finite fp16 operand, token overflow): no host wait
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
-        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=wsp.tok_cap, sampler_cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_two_tiles=bool(fr.flags & 32), mlp_parts=int(fr.mlp_parts),
+        self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=wsp.tok_cap, sampler_cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_form=('pipelined' if fr.flags & 64 else 'two_tiles' if fr.flags & 32 else 'one'), mlp_parts=int(fr.mlp_parts),
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min.reshape(-1)[:3], vox_sh=[int(v) for v in obs_sp_input['out_sh']],

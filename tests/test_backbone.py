@@ -68,6 +68,30 @@ def test_small_generator_matches_reference_ref_ops(monkeypatch):
     _check(g, z)
 
 
+def check_full_size_generator(dev=lambda t: t, tol=2e-4):
+    """The generator SHERF instantiates (256 x 256 x 96 planes, channel_base 32768, channel_max 512, 28.7 M parameters) RUN at full size, eval mode,
+    against the unmodified reference's run of the same seeded generator (tests/golden/backbone_full.npz, oracle/make_golden_backbone.py)."""
+    gold = np.load(os.path.join(GOLDEN, 'backbone_full.npz'))
+    g = dev(_seed(S.Generator(**FULL))).eval()
+    z = torch.from_numpy(np.random.RandomState(5).standard_normal((1, FULL['z_dim'])).astype(np.float32))
+    with torch.no_grad():
+        ws = g.mapping(dev(z), None)
+        img = G.plain(g.synthesis(ws, noise_mode='const')).numpy()
+    assert np.abs(G.plain(ws).numpy() - gold['ws']).max() < 1e-5
+    assert img.shape == (1, 96, 256, 256)
+    ref = gold['img_eval_const.sub']
+    err = np.abs(img[:, ::5, ::9, ::9] - ref).max() / np.abs(ref).max()
+    m = gold['img_eval_const.moments']
+    got = np.array([img.sum(dtype=np.float64), np.abs(img).sum(dtype=np.float64), np.square(img, dtype=np.float64).sum()])
+    assert err <= tol and np.all(np.abs(got[1:] - m[1:]) <= 1e-3 * np.abs(m[1:])), (err, got, m)
+    return err
+
+
+def test_full_size_generator_matches_reference_ref_ops(monkeypatch):
+    monkeypatch.setattr(S, 'OPS_IMPL', 'ref')
+    check_full_size_generator()
+
+
 def test_small_generator_matches_reference_through_the_hip_kernels_on_cpu(tmp_path_factory, monkeypatch):
     if not os.path.exists(build_cpu.CLANG):
         pytest.skip('needs the ROCm clang for the host build')

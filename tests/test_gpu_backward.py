@@ -209,9 +209,15 @@ def _full_size_backward(cfg, device, n_expected=None):
     O.NN_CHUNK, chunk0 = (32768 if device != 'cpu' else O.NN_CHUNK), O.NN_CHUNK
     try:
         loss_o, g_o = O.gradients_from_fixture(fx, G.state_for(cfg), device=torch.device(device), info=info)
+        # round 5: the float64 truth of every gradient on the fp32 run's discrete branches (oracle: gradients_truth64_from_fixture)
+        if device != 'cpu':
+            torch.cuda.empty_cache()
+        _, g_t = O.gradients_truth64_from_fixture(fx, G.state_for(cfg), info, device=None if device == 'cpu' else torch.device(device))
     finally:
         O.NN_CHUNK = chunk0
     g_o = {k: v.detach().float().cpu() for k, v in g_o.items()}
+    g_t = {k: v.detach().double().cpu() for k, v in g_t.items()}
+    info.pop('decisions', None)
     spi = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in info['sp_input'].items()}
     if device != 'cpu':
         torch.cuda.empty_cache()
@@ -234,26 +240,35 @@ def _full_size_backward(cfg, device, n_expected=None):
     names = sorted(k for k in g_o if not k.startswith('stage.'))
     assert set(names) == set(runs[0]), set(names) ^ set(runs[0])
     assert n_expected is None or len(names) == n_expected, len(names)
-    enc = lambda k: 'encoder_3d' in k or k == 'input.vertex_feat'
-    worst, spread = {}, {}
+    assert set(g_t) == set(names), set(g_t) ^ set(names)
+    worst, spread, ours_t, ref_t = {}, {}, {}, {}
     for k in names:
         ref = g_o[k].reshape(-1).double()
+        tru = g_t[k].reshape(-1)
         a, b = runs[0][k].reshape(-1).double(), runs[1][k].reshape(-1).double()
-        nrm = float(ref.norm()) + 1e-30
-        worst[k] = float((a - ref).norm()) / nrm
+        nrm = float(tru.norm()) + 1e-30
+        worst[k] = float((a - ref).norm()) / nrm                # ours vs the fp32 oracle (what rounds 3-4 bounded by 1e-2 / 0.15)
+        ours_t[k] = float((a - tru).norm()) / nrm               # ours vs the float64 truth
+        ref_t[k] = float((ref - tru).norm()) / nrm              # the fp32 oracle (== the reference's backward) vs the float64 truth
         spread[k] = float((a - b).norm()) / nrm
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
-    print(f'{cfg}: {len(names)} gradients, loss {loss_h:.6f} vs {loss_o:.6f}; worst relative errors {[(k, round(v, 5)) for k, v in top]}; '
-          f'largest run-to-run spread {max(spread.values()):.2e} ({max(spread, key=spread.get)})')
+    top = sorted(ours_t.items(), key=lambda kv: -kv[1])[:8]
+    print(f'{cfg}: {len(names)} gradients, loss {loss_h:.6f} vs {loss_o:.6f}; largest run-to-run spread {max(spread.values()):.2e} ({max(spread, key=spread.get)})')
+    print('   norm-relative distance from the float64 truth        ours      fp32 reference   (ours vs fp32 reference)')
+    for k, v in top:
+        print(f'   {k:50s} {v:.3e}   {ref_t[k]:.3e}   ({worst[k]:.3e})')
+    nenc = [k for k in names if 'encoder_3d' not in k and k != 'input.vertex_feat']
+    print(f'   worst outside the encoder: ours {max(ours_t[k] for k in nenc):.3e}  fp32 reference {max(ref_t[k] for k in nenc):.3e}')
     for k in names:
-        # (encoder entries: BatchNorm with batch statistics and activations at ReLU kinks amplify the forward's 1e-5-level differences:
-        #  the same looser bound as at the small sizes; everything else to 1 % of the gradient's norm)
-        assert worst[k] < (0.15 if enc(k) else 1e-2), (k, worst[k])
+        # The forward protocol's rule for extreme values, applied to every gradient (oracle/parity.py): our distance from
+        # the float64 truth may not exceed TWICE the fp32 reference's own distance from it plus 1e-3 of the gradient's norm.  Gradients the fp32
+        # reference itself cannot hold to 1e-3 (biases in front of a BatchNorm: sums of cancelling terms) get exactly the slack the reference
+        # needs, everything else 1e-3.  (Rounds 3-4: flat 1e-2, 0.15 for the encoder.)
+        assert ours_t[k] <= 2.0 * ref_t[k] + 1e-3, (k, ours_t[k], ref_t[k])
         assert spread[k] < 1e-3, (k, spread[k])
-    return worst, spread
+    return ours_t, ref_t
 
 
-@pytest.mark.parametrize('cfg', ['cfg2_ri'])
+@pytest.mark.parametrize('cfg', ['cfg2_ri', 'cfg2_dense_ri'])
 def test_full_size_backward_against_oracle_autograd(cfg):
     """BASELINE config 5 at its OWN size: 512 x 512 rays x 64 samples, ~7 x 10^5 valid samples -- where the
     binned tap scatter (float atomics: order dependent) and the eight-wave tall GEMMs actually run.  Every gradient (78 parameters + the three

@@ -36,6 +36,21 @@ def test_two_launch_mlp_renders_the_one_launch_bits_on_device(cfg):
             assert torch.equal(one[k], two[k]) and torch.equal(one[k], dflt[k]), (prec, k)
 
 
+@pytest.mark.parametrize('cfg', ['tiny', 'cfg1_ri'])
+def test_mlp_launch_forms_render_the_same_bits_on_device(cfg):
+    """Round 5's forms of the per-sample network for the single-product precisions -- 'pipelined' (sherf_nerf_mlp3: the decoder's layer epilogues
+    inside the next ring step's MFMA stream on a second accumulator pair; the default) and 'two_tiles' (sherf_nerf_mlp2: two tiles per wave) --
+    against the one-tile kernel of rounds 2-4, on the hardware: same bits; f16x3 ignores the option."""
+    for prec in ('f16', 'bf16', 'f16x3'):
+        one = G.hip_render(cfg, precision=prec, options=dict(mlp_form='one'))
+        assert one['last']['mlp_form'] == 'one'
+        for form in ('pipelined', 'two_tiles', None):
+            b = G.hip_render(cfg, precision=prec, options=dict(mlp_form=form) if form else None)
+            assert b['last']['mlp_form'] == ('one' if prec == 'f16x3' else (form or 'pipelined'))
+            for k in ('rgb', 'acc', 'depth'):
+                assert torch.equal(one[k], b[k]), (prec, form, k)
+
+
 @pytest.mark.parametrize('cfg,prec', [('tiny', 'f16x3'), ('cfg1_ri', 'f16')])
 def test_schedule_switches_render_the_same_bits_on_device(cfg, prec):
     """Round 4's launch / data-structure switches on the hardware, each against the default frame bit for bit: the candidate search over

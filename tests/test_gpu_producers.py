@@ -22,6 +22,16 @@ def test_stylegan2_backbone_matches_reference_generator_on_device():
     TB._check(g, z, dev=lambda t: t.cuda())
 
 
+def test_full_size_stylegan2_backbone_matches_reference_generator_on_device():
+    """Round 5: the FULL-size generator of triplane.py:58 (channel_base 32768, channel_max 512, planes [1, 96, 256, 256])
+    on the MI355X through the HIP operators against the unmodified reference's run of it (tests/golden/backbone_full.npz)."""
+    from sherf_amd import stylegan2 as S
+    from tests import test_backbone as TB
+    assert S.OPS_IMPL != 'ref'
+    err = TB.check_full_size_generator(dev=lambda t: t.cuda())
+    print(f'full-size backbone on the device vs the reference generator: {err:.2e} of the planes\' range')
+
+
 def test_stylegan2_gradients_through_the_hip_operators_on_device():
     """training-mode backward through the bias_act / upfirdn2d autograd nodes (HIP kernels, both derivative orders are exercised by
     tests/test_gpu_ops.py) equals the backward through the stock-PyTorch `ref` path."""

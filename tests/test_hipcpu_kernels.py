@@ -539,7 +539,7 @@ def mlp_lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp2', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
+    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp2', 'sherf_nerf_mlp3', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
         getattr(lib, fn).restype, getattr(lib, fn).argtypes = protos[fn][0], [a[0] for a in protos[fn][1]]
     return lib
 
@@ -617,6 +617,7 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
     # and half-empty waves take part in every barrier), and the f16x3 precision is refused
     if prec == 1:
         assert mlp_lib.sherf_nerf_mlp2(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out), None) != 0
+        assert mlp_lib.sherf_nerf_mlp3(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out), None) != 0
     else:
         for m in sorted({n, n - 32, n - 40, 33, 1}):
             if m < 1:
@@ -627,3 +628,7 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
             out3 = torch.full((tiles * 32, 4), float('nan'))
             assert mlp_lib.sherf_nerf_mlp2(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out3), None) == 0
             assert torch.equal(out3[:m], ref[:m]) and torch.isnan(out3[m:]).all() and int(counters[3]) == 0, m
+            # the decoder with its epilogues inside the MFMA stream (sherf_nerf_mlp3)
+            out4 = torch.full((tiles * 32, 4), float('nan'))
+            assert mlp_lib.sherf_nerf_mlp3(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out4), None) == 0
+            assert torch.equal(out4[:m], ref[:m]) and torch.isnan(out4[m:]).all() and int(counters[3]) == 0, m

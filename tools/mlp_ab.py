@@ -29,7 +29,8 @@ def main():
     ap.add_argument('--config', default='cfg2_ri')
     ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'])
     ap.add_argument('--stress', type=int, default=0)
-    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), tt (sherf_nerf_mlp2: two tiles per wave); pipe = the round-4 pipelined experiment, if the library has it')
+    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), tt (sherf_nerf_mlp2: two tiles per wave), pp (sherf_nerf_mlp3: epilogues inside the MFMA stream); pipe = the round-4 pipelined experiment, if the library has it')
+    ap.add_argument('--zero', default='', help="power probe: 'tokens' = zero tokens / extras, 'all' = zero weights too (same instruction stream, less switching; outputs are not compared)")
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_ab.json'))
     a = ap.parse_args()
     import bench
@@ -68,11 +69,14 @@ def main():
         tt = getattr(lib, 'sherf_nerf_mlp2', None)
         if tt is not None:
             tt.restype, tt.argtypes = one.restype, one.argtypes
-        return one, two, pipe, tt
+        pp = getattr(lib, 'sherf_nerf_mlp3', None)
+        if pp is not None:
+            pp.restype, pp.argtypes = one.restype, one.argtypes
+        return one, two, pipe, tt, pp
 
     def launch(fn, form):
-        if form in ('one', 'pipe', 'tt'):
-            return fn[{'one': 0, 'pipe': 2, 'tt': 3}[form]](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
+        if form in ('one', 'pipe', 'tt', 'pp'):
+            return fn[{'one': 0, 'pipe': 2, 'tt': 3, 'pp': 4}[form]](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
         return fn[1](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(zfrag), A(out), stream)
 
     def timed(fn, form, iters=20):
@@ -84,6 +88,11 @@ def main():
         assert rc == 0
         return e0.elapsed_time(e1) / iters
 
+    if a.zero:
+        ws = dict(ws)
+        ws['tokens'] = torch.zeros_like(ws['tokens']); ws['extras'] = torch.zeros_like(ws['extras'])
+        if a.zero == 'all':
+            wc = {k: torch.zeros_like(v) for k, v in wc.items()}
     libs = {'product': os.path.join(ROOT, 'sherf_amd', 'libsherf_hip.so')}
     for path in sorted(glob.glob(os.path.join(ROOT, 'sherf_amd', 'libsherf_hip_*.so'))):
         tag = os.path.basename(path)[len('libsherf_hip_'):-3]
@@ -95,7 +104,7 @@ def main():
     forms = [f for f in a.forms.split(',') if f]
     arms = [(t, form) for t, fn in bound.items() for form in forms
             if form == 'one' or (form == 'two' and fn[1] is not None) or (form == 'pipe' and fn[2] is not None and a.precision != 'f16x3')
-            or (form == 'tt' and fn[3] is not None and a.precision != 'f16x3')]
+            or (form == 'tt' and fn[3] is not None and a.precision != 'f16x3') or (form == 'pp' and fn[4] is not None and a.precision != 'f16x3')]
     for _ in range(40):                                         # clock warm-up
         launch(bound['product'], 'one')
     torch.cuda.synchronize()
@@ -123,7 +132,7 @@ def main():
         idxs = [torch.randint(0, big.numel(), (n,), device=dev) for n in (1 << 18, 1 << 21, 1 << 23, 3 << 20)]
         bad = {}
         for form in forms:
-            if form in ('pipe', 'tt') and a.precision == 'f16x3':
+            if form in ('pipe', 'tt', 'pp') and a.precision == 'f16x3':
                 continue
             n_bad_launches, n_bad_words = 0, 0
             for it in range(a.stress):
