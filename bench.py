@@ -73,6 +73,11 @@ def launch_ranks(n, script=None, argv=None):
     return subprocess.run(cmd, env=env).returncode
 
 
+def contextlib_null():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def check_world(gpus, world, what='bench.py'):
     if gpus != world:
         print(f'{what}: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line for the wrong N', file=sys.stderr)
@@ -413,20 +418,27 @@ def main():
     from sherf_amd import _lib as _abi
     import ctypes as _ct
 
-    n_streams = max(1, int(a.streams)) if dev.type == 'cuda' else 1       # (the host build of the tests has no streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
+    n_streams = max(1, int(a.streams))
+    if dev.type == 'cuda':
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream(dev)]
+    else:
+        # the host build of the tests has no streams: `--streams N` there still walks the round-robin bookkeeping (one gather queue per
+        # caller stream, below) with every "stream" the host itself -- what tests/test_hipcpu_frame.py runs with two gloo ranks
+        import contextlib
+        streams = [None] * n_streams
+        torch.cuda.stream = lambda st: contextlib.nullcontext()
     torch.cuda.synchronize(dev)                  # the workload's setup (default stream) is complete before any frame stream starts
     counter = [0]
 
     def step():
         if n_streams == 1:
-            return frame_on_current_stream()
-        st = streams[counter[0] % n_streams]
+            return frame_on_current_stream(0)
+        k = counter[0] % n_streams
         counter[0] += 1
-        with torch.cuda.stream(st):
-            return frame_on_current_stream()
+        with torch.cuda.stream(streams[k]):
+            return frame_on_current_stream(k)
 
-    def frame_on_current_stream():
+    def frame_on_current_stream(k):
         render_frame(w)
         tile = rend.last['out']          # the frame's output buffer as the kernel wrote it: planar [rgb (3R) | depth (R) | acc (R)], no repacking
         if rays_mode and tile.numel() != 5 * n_pad:           # ranks own 1024-ray tiles: equal shard sizes for the gather
@@ -434,17 +446,26 @@ def main():
         if world > 1:
             # the gather of this frame's tiles runs on RCCL's own stream (async_op) and is awaited one step later, so that it
             # overlaps the next frame's sampling instead of stalling the render stream for a latency-bound 5 MB exchange
+            # One queue PER CALLER STREAM (round 5): a frame waits for the previous gather issued on ITS stream only -- with one shared
+            # queue (round 4) every frame's stream was made to wait for a gather that belongs to another stream's frame, which serialises
+            # the streams the overlap is built from.  RCCL orders the collectives themselves (same issue order on every rank: the
+            # round-robin is deterministic).
             out = [torch.empty_like(tile) for _ in range(world)]
-            inflight.append((torch.distributed.all_gather(out, tile, async_op=True), out, tile))
-            while len(inflight) > 1:
-                inflight.pop(0)[0].wait()
+            q = inflight[k]
+            q.append((torch.distributed.all_gather(out, tile, async_op=True), out, tile))
+            gather_log.append((k, counter[0]))
+            while len(q) > 1:
+                q.pop(0)[0].wait()
         return tile
 
-    inflight = []
+    inflight = [[] for _ in range(n_streams)]
+    gather_log = []
 
-    def drain():                      # every gather issued so far is complete (on the render stream's timeline) after this
-        while inflight:
-            inflight.pop(0)[0].wait()
+    def drain():                      # every gather issued so far is complete (on its render stream's timeline) after this
+        for k, q in enumerate(inflight):
+            with torch.cuda.stream(streams[k]) if n_streams > 1 else contextlib_null():
+                while q:
+                    q.pop(0)[0].wait()
 
     for _ in range(n_streams if n_streams > 1 else 0):     # every stream's workspace exists (and `auto` is calibrated) before the warm-up proper
         step()
@@ -586,6 +607,15 @@ def main():
             if dense.get('rays_per_s'):                  # the valid-sample fraction SURVEY 8(d) sized the path on (0.076): first class
                 res['value_dense'] = dense['rays_per_s']; res['ms_per_step_dense'] = dense['ms_per_frame']
                 res['valid_fraction_dense'] = dense['valid_fraction']
+        # what the multi-GPU steps exchange, so that the first real SCALE run can be held against a prediction (no curve has been measured by
+        # us: one-GPU boxes).  Views / ray tiles: ONE all_gather of the frame's planar [5 R] fp32 output per step, asynchronous, awaited one frame
+        # later on the same caller stream -> off the critical path unless it takes longer than a frame; bandwidth model: every rank receives
+        # (N - 1) x 5 R x 4 bytes over its 7 xGMI links (~153 GB/s each, MI355X_MICROARCH.md) + ~20 us of launch / latency.
+        gather_bytes = 5 * (n_pad if rays_mode else R) * 4
+        res['config']['exchange'] = dict(collective='all_gather (RCCL), one per step, async', bytes_per_rank=gather_bytes, bytes_received_per_rank_at_8_gpus=7 * gather_bytes,
+                                         predicted_us_at_8_gpus=round(20 + 7 * gather_bytes / (7 * 153e9) * 1e6, 1), on_critical_path=False,
+                                         gathers_issued=len(gather_log), training_step_all_reduce_bytes='<= 219 MB: the flat gradient of the generator (28.7 M + 23.4 M + 0.3 M parameters x 4 B), training_loop.py:374-383',
+                                         measured_scaling='none by us (one-GPU boxes): the driver\'s SCALE run is the measurement')
         res['config']['inputs'] = ('FRESH tensors every frame (--fresh-inputs)' if a.fresh_inputs else
                                    'the same input tensors every frame (the renderer\'s identity caches hit: no host wait per frame); `secondary.fresh_inputs` = new tensors per frame')
         if world == 1 and not a.no_secondary and not a.overlap_child and n_streams == 1 and not a.fresh_inputs and isinstance(res.get('secondary'), dict):

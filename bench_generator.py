@@ -27,12 +27,12 @@ STAGES = ('encoder_2d', 'mapping', 'backbone_synthesis', 'encoder_2d_feature', '
 
 
 def build_generator(w, dev, small=False):
-    """The generator of train.py:237-428 (z 512, c 25, w 512, map_depth 2, cbase 32768, cmax 512, fp32) around the bench workload's renderer and
+    """The generator of train.py:237-428 / training_loop.py:192 (z 512, c_dim 0, w 512, map_depth 2, cbase 32768, cmax 512, fp32) around the bench workload's renderer and
     decoder (reference-init network); its own producers, initialised by their constructors under a fixed seed."""
     from sherf_amd.triplane import TriPlaneGenerator
     from synthdata import synth
     torch.manual_seed(0)
-    gen = TriPlaneGenerator(512, 25, 512, True, True, True, True, True, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=2),
+    gen = TriPlaneGenerator(512, 0, 512, True, True, True, True, True, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=2),
                             rendering_kwargs=dict(w['opts']), smpl=synth.make_synth_smpl(0), channel_base=512 if small else 32768,
                             channel_max=16 if small else 512, num_fp16_res=0, conv_clamp=None, fused_modconv_default='inference_only')
     gen.renderer, gen.decoder = w['rend'], w['dec']
@@ -141,6 +141,8 @@ def main():
     ap.add_argument('--config', default='cfg2_dense_ri')
     ap.add_argument('--precision', default='auto')
     ap.add_argument('--small-backbone', action='store_true', help='TEST ONLY: channel_base 512 / channel_max 16 (the host-build dry run of this script)')
+    ap.add_argument('--miopen-benchmark', action='store_true', help='torch.backends.cudnn.benchmark = True: MIOpen searches its convolution algorithms on first use')
+    ap.add_argument('--channels-last', action='store_true', help='producers (backbone, encoders) in channels_last memory format')
     a = ap.parse_args()
     import bench
     lrank = int(os.environ.get('LOCAL_RANK', 0))
@@ -149,13 +151,18 @@ def main():
         _Mark.on_gpu = False
     dev = bench._device(lrank)
     w = bench.make_workload(argparse.Namespace(config=a.config, precision=a.precision, bn_mode='train', table_precision=None, encoder_precision=None), 0.4, dev)
+    if a.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
     gen = build_generator(w, dev, small=a.small_backbone)
+    if a.channels_last:
+        for m in (gen.backbone, gen.encoder_2d, gen.encoder_2d_feature):
+            m.to(memory_format=torch.channels_last)
     d = w['d']
     R = d['ray_o_all'].shape[2]
     n_params = {k: int(sum(p.numel() for p in m.parameters())) for k, m in (('backbone', gen.backbone), ('encoder_2d', gen.encoder_2d),
                                                                              ('encoder_2d_feature', gen.encoder_2d_feature))}
     res = dict(metric='rays/s of TriPlaneGenerator.forward at 512x512x64 (test_loop.py:189-190), full-size producers', unit='rays/s', steps=a.steps, warmup=a.warmup,
-               config=dict(workload=a.config, rays=R, image=list(d['obs_img_all'].shape[-2:]), backbone='StyleGAN2 Generator z512 w512 map_depth 2 channel_base 32768 channel_max 512 -> planes [1,96,256,256]',
+               config=dict(workload=a.config, miopen_benchmark=bool(a.miopen_benchmark), channels_last=bool(a.channels_last), rays=R, image=list(d['obs_img_all'].shape[-2:]), backbone='StyleGAN2 Generator z512 w512 map_depth 2 channel_base 32768 channel_max 512 -> planes [1,96,256,256]',
                            parameters=n_params, weights='constructor initialisation under torch.manual_seed(0) (no pretrained pickle offline)',
                            mlp_precision=None, mlp_form=None))
     for name, cached in (('recomputed_every_frame', False), ('use_cached_backbone', True)):

@@ -24,8 +24,8 @@ def main():
     AR.ImportanceRenderer._side = lambda self, dev, idx=0: type('HostStream', (), {'cuda_stream': 8 + 8 * idx})()
     AR.ImportanceRenderer.SMPL_NEUTRAL = property(lambda self: self._smpl(torch.device('cpu')))
     bench._device = lambda lrank: torch.device('cpu')
-    sys.argv = ['bench.py', '--gpus', os.environ['WORLD_SIZE'], '--config', 'tiny', '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--streams', '1',
-                '--no-torch-gpu-baseline'] + (['--partition', os.environ['SHERF_BENCH_PARTITION']] if os.environ.get('SHERF_BENCH_PARTITION') else [])
+    sys.argv = ['bench.py', '--gpus', os.environ['WORLD_SIZE'], '--config', 'tiny', '--steps', os.environ.get('SHERF_BENCH_STEPS', '1'), '--warmup', '1', '--no-cpu-baseline',
+                '--streams', os.environ.get('SHERF_BENCH_STREAMS', '1'), '--no-torch-gpu-baseline'] + (['--partition', os.environ['SHERF_BENCH_PARTITION']] if os.environ.get('SHERF_BENCH_PARTITION') else [])
     bench.main()
 
 

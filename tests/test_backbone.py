@@ -158,6 +158,66 @@ def test_resnet18_encoders_contract_and_paths():
     assert sum(p.numel() for p in enc.parameters()) == 11689512                    # ResNet-18
 
 
+def resnet18_functional(sd, x, extract_feature=False, prefix='backbone.'):
+    """ResNet-18 (He et al. 2016, table 1: 7x7/2 stem, four stages of two basic blocks at 64 / 128 / 256 / 512 channels, stride-2 1x1 projection
+    shortcuts) written as plain torch.nn.functional calls over a torchvision-layout state dict -- an INDEPENDENT formulation of what
+    sherf_amd.resnet.ResNet18Classifier computes (torchvision itself is not installed offline), with SHERF's two read-outs (triplane.py:320-343):
+    the pooled 512-d code, and layer1's map with the max-pool skipped."""
+    F = torch.nn.functional
+    g = lambda n: sd[prefix + n]
+
+    def bn(x, n):                                                  # inference-mode batch norm: (x - mean) / sqrt(var + eps) * gamma + beta
+        sh = (1, -1, 1, 1)
+        return (x - g(n + '.running_mean').view(sh)) / torch.sqrt(g(n + '.running_var').view(sh) + 1e-5) * g(n + '.weight').view(sh) + g(n + '.bias').view(sh)
+
+    def block(x, n, stride):
+        y = F.relu(bn(F.conv2d(x, g(n + '.conv1.weight'), None, stride, 1), n + '.bn1'))
+        y = bn(F.conv2d(y, g(n + '.conv2.weight'), None, 1, 1), n + '.bn2')
+        if (prefix + n + '.downsample.0.weight') in sd:
+            x = bn(F.conv2d(x, g(n + '.downsample.0.weight'), None, stride, 0), n + '.downsample.1')
+        return F.relu(y + x)
+    x = F.relu(bn(F.conv2d(x, g('conv1.weight'), None, 2, 3), 'bn1'))
+    if not extract_feature:
+        x = F.max_pool2d(x, 3, 2, 1)
+    x = block(block(x, 'layer1.0', 1), 'layer1.1', 1)
+    if extract_feature:
+        return x
+    for li in (2, 3, 4):
+        x = block(block(x, f'layer{li}.0', 2), f'layer{li}.1', 1)
+    return x.mean((2, 3))
+
+
+def seeded_resnet(seed=0):
+    """A ResNet18Classifier with non-trivial running statistics and affine parameters (a fresh module's are 0 / 1: they would not test the norm)."""
+    from sherf_amd.resnet import ResNet18Classifier
+    torch.manual_seed(seed)
+    enc = ResNet18Classifier().eval()
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, t in enc.state_dict().items():
+            if n.endswith('running_mean'):
+                t.copy_(0.1 * torch.randn(t.shape, generator=gen))
+            elif n.endswith('running_var'):
+                t.copy_(0.5 + torch.rand(t.shape, generator=gen))
+            elif n.endswith('bn1.weight') or n.endswith('bn2.weight') or n.endswith('downsample.1.weight'):
+                t.copy_(0.5 + torch.rand(t.shape, generator=gen))
+            elif n.endswith('.bias') and 'fc' not in n:
+                t.copy_(0.1 * torch.randn(t.shape, generator=gen))
+    return enc
+
+
+def test_resnet18_encoder_against_an_independent_formulation():
+    """the encoder was only ever compared with itself.  Here: against resnet18_functional above (the architecture's definition as
+    functional calls), both read-outs, non-trivial BatchNorm state."""
+    enc = seeded_resnet()
+    sd = {k: v.double() for k, v in enc.state_dict().items()}
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((2, 3, 96, 64)).astype(np.float32))
+    with torch.no_grad():
+        for ef in (False, True):
+            got, want = enc(x, extract_feature=ef), resnet18_functional(sd, x.double(), ef)
+            assert got.shape == want.shape and G.rel(got, want) < 1e-4, (ef, G.rel(got, want))
+
+
 def test_generator_builds_its_producers_by_default():
     """TriPlaneGenerator() without injected modules owns the reference's sub-module names (checkpoint contract of
     triplane.py:53-65, minus the super-resolution module no SHERF script uses)."""

@@ -52,15 +52,37 @@ def test_stylegan2_gradients_through_the_hip_operators_on_device():
         assert G.rel(grads['cuda'][n], grads['ref'][n]) < 2e-3, n
 
 
-def test_resnet18_encoder_on_device_matches_cpu():
-    from sherf_amd.resnet import ResNet18Classifier
-    torch.manual_seed(0)
-    enc = ResNet18Classifier().eval()
-    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 128, 128)).astype(np.float32))
+def test_resnet18_encoder_on_device_against_an_independent_formulation():
+    """The ResNet-18 encoders on the MI355X (MIOpen convolutions through PyTorch-ROCm) against the architecture written out as functional calls in
+    float64 on the CPU (tests/test_backbone.py: resnet18_functional; torchvision is absent offline) -- both read-outs of triplane.py:320-343, at the
+    512 x 512 observation size, non-trivial BatchNorm state.  (Rounds 2-4 compared the module with itself.)"""
+    from tests import test_backbone as TB
+    enc = TB.seeded_resnet()
+    sd = {k: v.double() for k, v in enc.state_dict().items()}
+    x = torch.from_numpy(np.random.RandomState(0).standard_normal((1, 3, 512, 512)).astype(np.float32))
+    enc = enc.cuda()
     with torch.no_grad():
-        want = enc(x, extract_feature=True)
-        got = enc.cuda()(x.cuda(), extract_feature=True).cpu()
-    assert got.shape == (1, 64, 64, 64) and G.rel(got, want) < 1e-3
+        code, feat = enc(x.cuda()).cpu(), enc(x.cuda(), extract_feature=True).cpu()
+        assert code.shape == (1, 512) and feat.shape == (1, 64, 256, 256)
+        assert G.rel(feat, TB.resnet18_functional(sd, x.double(), True)) < 1e-4
+        assert G.rel(code, TB.resnet18_functional(sd, x.double(), False)) < 1e-3
+
+
+def test_density_noise_statistics_on_device():
+    """renderer.py:435-436 (training only): sigma += randn * density_noise between the network and the compositing.  On the device: the per-sample
+    sigma of a noisy frame minus the clean frame's is N(0, noise^2) (mean / standard deviation over ~600 valid samples), rgb is untouched, the
+    image changes, and noise 0 reproduces the clean frame bit for bit."""
+    clean = G.hip_render('tiny')
+    nv = int(clean['last']['ws']['counters'][0])
+    s0 = clean['last']['ws']['sample_out'][:nv].clone()
+    noisy = G.hip_render('tiny', options=dict(density_noise=0.5))
+    s1 = noisy['last']['ws']['sample_out'][:nv].clone()
+    d = (s1[:, 3] - s0[:, 3]).double().cpu()
+    assert nv > 300 and torch.equal(s1[:, :3], s0[:, :3])
+    assert abs(float(d.mean())) < 4 * 0.5 / nv ** 0.5 and abs(float(d.std()) - 0.5) < 0.06, (float(d.mean()), float(d.std()))
+    assert not torch.equal(noisy['rgb'], clean['rgb'])
+    again = G.hip_render('tiny', options=dict(density_noise=0))
+    assert torch.equal(again['rgb'], clean['rgb']) and torch.equal(again['acc'], clean['acc'])
 
 
 def test_whole_generator_with_its_own_producers_on_device():

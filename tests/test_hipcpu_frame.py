@@ -273,7 +273,7 @@ def test_bench_generator_dry_run(cpu_product, monkeypatch, capsys):
     assert res['config']['mlp_form'] == 'pipelined' and res['config']['mlp_precision'] == 'f16'
 
 
-@pytest.mark.parametrize('partition', ['views', 'rays'])
+@pytest.mark.parametrize('partition', ['views', 'rays', 'views-4-streams'])
 def test_bench_two_ranks_dry_run(cpu_product, partition):
     """bench.py as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), two ranks over gloo
     on the host build: every rank renders its own view (weak scaling) or its interleaved ray tiles of ONE frame (--partition rays,
@@ -288,7 +288,9 @@ def test_bench_two_ranks_dry_run(cpu_product, partition):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   SHERF_DIST_BACKEND='gloo', SHERF_HIPCPU_LIB=_lib.LIB_PATH, OMP_NUM_THREADS='2', SHERF_BENCH_PARTITION=partition)
+                   SHERF_DIST_BACKEND='gloo', SHERF_HIPCPU_LIB=_lib.LIB_PATH, OMP_NUM_THREADS='2', SHERF_BENCH_PARTITION=partition.split('-')[0])
+        if partition == 'views-4-streams':        # round 5: four caller streams per rank, one gather queue per stream (6 steps: every queue used, two wrap)
+            env.update(SHERF_BENCH_STREAMS='4', SHERF_BENCH_STEPS='6')
         procs.append(subprocess.Popen([sys.executable, os.path.join(G.ROOT, 'tests', 'bench_dist_child.py')], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -297,7 +299,12 @@ def test_bench_two_ranks_dry_run(cpu_product, partition):
     assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]          # rank 0 prints ONE line
     res = json.loads(lines[0])
     per_step = res['ms_per_step'] * 1e-3
-    if partition == 'views':
+    ex = res['config']['exchange']
+    assert ex['bytes_per_rank'] > 0 and ex['predicted_us_at_8_gpus'] > 20 and 'none by us' in ex['measured_scaling']
+    if partition.startswith('views'):
+        if partition == 'views-4-streams':
+            # 4 frames to create the workspaces + 1 warm-up + 6 timed + 3 for the host's own cost = 14 gathers, every one awaited (drain)
+            assert res['config']['caller_streams'] == 4 and res['steps'] == 6 and ex['gathers_issued'] == 14
         assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['parallelism'] == 'views x2'
         assert res['value'] > 0 and abs(res['value'] - 2 * res['config']['rays'] * res['steps'] / (per_step * res['steps'])) < 1e-6 * res['value']
     else:
@@ -702,7 +709,9 @@ def test_full_size_backward_check_plumbing(cpu_product, monkeypatch):
     ours_t, ref_t = GB._full_size_backward('tiny_ri', 'cpu')          # (asserts the float64-truth rule and the run-to-run spread itself)
     assert len(ours_t) >= 81 and set(ours_t) == set(ref_t)
     nenc = [k for k in ours_t if 'encoder_3d' not in k and k != 'input.vertex_feat']
-    assert max(ref_t[k] for k in nenc) < 1e-4                           # well-conditioned gradients: the fp32 reference is at its rounding level
+    # (at this size the fp32 reference's decoder gradients are themselves 1.2e-3 from the float64 truth -- small sums of cancelling per-sample terms --
+    #  and ours sit at the same distance to three digits: outside the encoder the two fp32 backward passes agree far better than either holds the truth)
+    assert all(abs(ours_t[k] - ref_t[k]) <= 0.2 * ref_t[k] + 1e-4 for k in nenc)
 
 
 def test_training_step_through_autograd_matches_reference_gradients(cpu_product, monkeypatch):

@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'])
     ap.add_argument('--stress', type=int, default=0)
     ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), tt (sherf_nerf_mlp2: two tiles per wave), pp (sherf_nerf_mlp3: epilogues inside the MFMA stream); pipe = the round-4 pipelined experiment, if the library has it')
+    ap.add_argument('--sustain', type=float, default=0.0, help='after the timings: launch the LAST form back to back for this many seconds (power / clock telemetry: tools/power_probe.py)')
     ap.add_argument('--zero', default='', help="power probe: 'tokens' = zero tokens / extras, 'all' = zero weights too (same instruction stream, less switching; outputs are not compared)")
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_ab.json'))
     a = ap.parse_args()
@@ -125,6 +126,17 @@ def main():
         print(f'[arm] {arm[0]:10s} {arm[1]:3s} ms {" ".join(f"{x:.3f}" for x in times[arm])}  frac {flop / (ms * 1e-3) / 1e12 / bench.PEAK_BF16_TFLOPS:.3f}  '
               f'|diff| vs product/one {diff:.2e}  counters[3] {int(counters[3])}')
 
+    if a.sustain > 0:
+        import time
+        arm = arms[-1]
+        t0 = time.perf_counter(); n = 0
+        print(f'[sustain] start {time.time():.3f}', flush=True)
+        while time.perf_counter() - t0 < a.sustain:
+            for _ in range(200):
+                launch(bound[arm[0]], arm[1])
+            torch.cuda.synchronize(); n += 200
+        dt = time.perf_counter() - t0
+        print(f'[sustain] end {time.time():.3f}: {arm[0]}/{arm[1]} x {n} launches in {dt:.2f} s = {1e3 * dt / n:.4f} ms per launch (back to back, incl. launch gaps)', flush=True)
     if a.stress:
         torch.manual_seed(0)
         side = torch.cuda.Stream(dev)
