@@ -82,10 +82,24 @@ class StageClock:
 
     def __enter__(self):
         g = self.gen
-        self._wrap(g.encoder_2d, 'forward', 'encoder_2d')
+        # the three producers go through TriPlaneGenerator._producer (eager call or hipGraph replay): timed there, so that both modes are covered
+        names = {'encoder_2d': 'encoder_2d', 'backbone.synthesis': 'backbone_synthesis', 'encoder_2d_feature': 'encoder_2d_feature'}
+        orig = g._producer
+
+        def producer(name, module, fn):
+            inner = orig(name, module, fn)
+
+            def timed(*a, **k):
+                e0, e1 = _Mark(), _Mark()
+                e0.record()
+                out = inner(*a, **k)
+                e1.record()
+                self.ev[names[name]] = (e0, e1)
+                return out
+            return timed
+        self.saved.append((g, '_producer', g.__dict__.get('_producer')))
+        g._producer = producer
         self._wrap(g.backbone.mapping, 'forward', 'mapping')                 # (sub-modules: their `forward` is wrapped on the instance)
-        self._wrap(g.backbone.synthesis, 'forward', 'backbone_synthesis')
-        self._wrap(g.encoder_2d_feature, 'forward', 'encoder_2d_feature')
         self._wrap(g.renderer, 'forward', 'renderer')
         self.t0 = _Mark(); self.t1 = _Mark()
         self.t0.record()
@@ -142,6 +156,7 @@ def main():
     ap.add_argument('--precision', default='auto')
     ap.add_argument('--small-backbone', action='store_true', help='TEST ONLY: channel_base 512 / channel_max 16 (the host-build dry run of this script)')
     ap.add_argument('--miopen-benchmark', action='store_true', help='torch.backends.cudnn.benchmark = True: MIOpen searches its convolution algorithms on first use')
+    ap.add_argument('--graph-producers', action='store_true', help='TriPlaneGenerator.graph_producers = True: the producers replayed as hipGraphs')
     ap.add_argument('--channels-last', action='store_true', help='producers (backbone, encoders) in channels_last memory format')
     a = ap.parse_args()
     import bench
@@ -154,6 +169,7 @@ def main():
     if a.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
     gen = build_generator(w, dev, small=a.small_backbone)
+    gen.graph_producers = bool(a.graph_producers)
     if a.channels_last:
         for m in (gen.backbone, gen.encoder_2d, gen.encoder_2d_feature):
             m.to(memory_format=torch.channels_last)
@@ -162,7 +178,7 @@ def main():
     n_params = {k: int(sum(p.numel() for p in m.parameters())) for k, m in (('backbone', gen.backbone), ('encoder_2d', gen.encoder_2d),
                                                                              ('encoder_2d_feature', gen.encoder_2d_feature))}
     res = dict(metric='rays/s of TriPlaneGenerator.forward at 512x512x64 (test_loop.py:189-190), full-size producers', unit='rays/s', steps=a.steps, warmup=a.warmup,
-               config=dict(workload=a.config, miopen_benchmark=bool(a.miopen_benchmark), channels_last=bool(a.channels_last), rays=R, image=list(d['obs_img_all'].shape[-2:]), backbone='StyleGAN2 Generator z512 w512 map_depth 2 channel_base 32768 channel_max 512 -> planes [1,96,256,256]',
+               config=dict(workload=a.config, miopen_benchmark=bool(a.miopen_benchmark), channels_last=bool(a.channels_last), graph_producers=bool(a.graph_producers), rays=R, image=list(d['obs_img_all'].shape[-2:]), backbone='StyleGAN2 Generator z512 w512 map_depth 2 channel_base 32768 channel_max 512 -> planes [1,96,256,256]',
                            parameters=n_params, weights='constructor initialisation under torch.manual_seed(0) (no pretrained pickle offline)',
                            mlp_precision=None, mlp_form=None))
     for name, cached in (('recomputed_every_frame', False), ('use_cached_backbone', True)):
@@ -175,6 +191,8 @@ def main():
     res['output'] = dict(image_raw=list(img.shape), finite=bool(torch.isfinite(img).all()), mean=float(img.mean()), weights_mean=float(out['weights_image'].mean()))
     res['config']['mlp_precision'] = w['rend'].last.get('mlp_precision'); res['config']['mlp_form'] = w['rend'].last.get('mlp_form')
     res['renderer_ms_inside_forward'] = res['recomputed_every_frame']['stages_ms'].get('renderer')
+    if a.graph_producers:
+        res['graphed'] = {k: ('off: ' + getattr(v, 'error', '?')) if v.off else 'captured' for k, v in gen.__dict__.get('_graphed', {}).items()}
     print(json.dumps(res))
 
 

@@ -211,6 +211,11 @@ int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, const float* e
  * nerf_mlp3_kernel, round 5).  Same inputs, same outputs bit for bit as sherf_nerf_mlp. */
 int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                     const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* sherf_nerf_mlp3 on ONE contiguous part of the tile list (the cut of sherf_nerf_mlp_part / sherf_gather_tokens), with the launch's residency as
+ * an argument: wgs_per_cu = 3 (or 0) what the kernel allows, 2 = a third of every SIMD's registers stays free for another kernel's waves (the
+ * gather of the next part on a second stream).  Same results. */
+int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens, const float* extras, const void* wstream, const float* wbias, int prec,
+                         int64_t capacity, float* out, int part, int nparts, int wgs_per_cu, sherf_stream_t stream);
 /* The same network as TWO launches (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel), results bit-identical to sherf_nerf_mlp:
  * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS;
  * launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  zfrag: scratch for the fused tokens,
@@ -421,8 +426,11 @@ typedef struct {
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);
-/* The valid-sample count of the last frame this process enqueued on the current device with SHERF_FRAME_REPORT_COUNT (waits for the
- * sampler of that frame, not for the frame). */
+/* The valid-sample count of the last frame THE CALLING THREAD enqueued on the current device with SHERF_FRAME_REPORT_COUNT (waits for the
+ * sampler of that frame, not for the frame; other threads' frames on the device have their own slots -- a ring of eight per device -- and the
+ * wait holds no lock).  State the library keeps per process: the join / report events and two pinned words per device, the profiling ring, and
+ * this per-thread slot index; sherf_render_frame serialises ENQUEUES on a device with a mutex (the join events are shared), so it is thread-safe
+ * but not lock-free -- the "no global mutable state" of SURVEY section 8(b) holds for every other entry point, not for the frame driver. */
 int sherf_frame_count(int32_t* nv_host);
 /* phase: 1 = everything up to the per-sample network, 2 = compositing, 3 = both; 4 (alone) = the sampler only (cell lists, shell mask,
  * nearest vertex, compaction: counters[0] = the frame's number of valid samples) -- what a caller runs once to size tok_capacity. */

@@ -233,8 +233,10 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         if (stagger < 0) SHERF_RUN(enqueue_encoder());
         if (!stream_aux) SHERF_RUN(fold_tables(stream_main));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
-        SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
-        if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
+        if (!(g_sherf_debug & (1 << 28))) {          // (debug bit 28, TIMING EXPERIMENTS ONLY: no joins in front of the warp -- results may be wrong)
+            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
+            if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
+        }
         int64_t cap = tok_cap;
         if (exact) {
             SHERF_HIP_CHECK(hipEventSynchronize(d.ev_cnt));
@@ -259,8 +261,12 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                               f->tokens, f->extras, stream_main));
                 SHERF_HIP_CHECK(hipEventRecord(d.ev_part[k], main));
                 SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_part[k], 0));
-                SHERF_RUN(sherf_nerf_mlp_part(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, k, nparts,
-                                              stream_side));
+                if (f->mlp_prec != 1 && (f->flags & SHERF_FRAME_MLP_PIPELINED))       // two workgroups per CU: room for the next part's gather beside it
+                    SHERF_RUN(sherf_nerf_mlp3_part(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, k, nparts,
+                                                   (g_sherf_debug & (1 << 26)) ? 3 : (g_sherf_debug & (1 << 27)) ? 1 : 2, stream_side));   // (debug bits 26 / 27: residency 3 / 1, for A/B runs)
+                else
+                    SHERF_RUN(sherf_nerf_mlp_part(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, k, nparts,
+                                                  stream_side));
             }
             SHERF_PROF(4, main);
             SHERF_HIP_CHECK(hipEventRecord(d.ev_mlp, side));

@@ -1407,15 +1407,16 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, SHERF_MLP3_LB)
 nerf_mlp3_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts) {
     using CX = Ctx<PREC>;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
-    const int64_t n_tiles = (nv + 31) / 32;
-    if ((int64_t)blockIdx.x * NW >= n_tiles) return;                 // whole workgroup beyond the data
+    int64_t t_lo, n_tiles;                                           // this launch's part of the tiles (sherf_nerf_mlp3_part; whole: 0, n)
+    sherf_part_range((nv + 31) / 32, part, nparts, t_lo, n_tiles);
+    if (t_lo + (int64_t)blockIdx.x * NW >= n_tiles) return;          // whole workgroup beyond the data
     CX cx;
     ring_ctx<PREC>(cx, lds, ws, wbias);
-    int64_t tile = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+    int64_t tile = t_lo + (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
     ring_prologue<PREC, 0>(cx);
@@ -1628,19 +1629,30 @@ extern "C" int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, con
 
 // One tile per wave with the decoder's epilogues inside its MFMA stream (nerf_mlp3_kernel): the single-product precisions (prec 0, 2); same
 // inputs, same outputs bit for bit as sherf_nerf_mlp.
+// `wgs_per_cu` (2 or 3; 0 = 3): the launch's residency.  3 = what the kernel's registers and LDS allow (three waves per SIMD); 2 = the launch declares
+// 12 KiB of dynamic LDS it never touches, so that only two workgroups fit a CU and a third of every SIMD's registers (and 50 KiB of LDS) stay free for
+// ANOTHER kernel's waves -- the gather of the next part of the frame on a second stream (csrc/frame.hip: mlp_parts).  The kernel is power-bound (DESIGN
+// section 5.1): its own duration barely depends on the residency.
+extern "C" int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens, const float* extras, const void* wstream, const float* wbias, int prec,
+                                    int64_t capacity, float* out, int part, int nparts, int wgs_per_cu, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0 && nparts >= 0 && nparts < 256 && (nparts <= 1 || (part >= 0 && part < nparts)));
+    SHERF_CHECK_ARG(wgs_per_cu >= 0 && wgs_per_cu <= 3);
+    const int64_t tiles = nparts > 1 ? ((capacity + 255) / 256 + nparts - 1) / nparts * 8 + 8 : (capacity + 31) / 32;    // most a part can hold
+    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
+    const unsigned pad = wgs_per_cu == 2 ? 12 * 1024 : wgs_per_cu == 1 ? 44 * 1024 : 0;
+    if (prec == 2)
+        hipLaunchKernelGGL((nerf_mlp3_kernel<2>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+    else
+        hipLaunchKernelGGL((nerf_mlp3_kernel<0>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+    SHERF_LAUNCH_CHECK();
+}
+
 extern "C" int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                                const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
-    SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0);
-    const int64_t tiles = (capacity + 31) / 32;
-    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
-    if (prec == 2)
-        hipLaunchKernelGGL((nerf_mlp3_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
-    else
-        hipLaunchKernelGGL((nerf_mlp3_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
-    SHERF_LAUNCH_CHECK();
+    return sherf_nerf_mlp3_part(counters, tokens, extras, wstream, wbias, prec, capacity, out, 0, 1, 0, stream);
 }
 
 // The two-launch form (see nerf_tokens_kernel / nerf_decoder_kernel): same inputs, same outputs bit for bit; zfrag = scratch for the fused

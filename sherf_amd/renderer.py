@@ -901,7 +901,7 @@ class ImportanceRenderer(nn.Module):
         fr.vox_coord, fr.vox_feat, fr.vox_n, fr.vox_training = A(vcoord), A(vfeat), vfeat.shape[0], 1 if self.encoder_3d.training else 0
         levels = (_lib.VoxLevel * 3)()
         s_main, s_side = _ct.c_void_p(main.cuda_stream), _ct.c_void_p(side.cuda_stream)
-        s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if self.aux_stream else None
+        s_aux = _ct.c_void_p(self._side(dev, 1).cuda_stream) if opts.get('aux_stream', self.aux_stream) else None
 
         # token-side workspace: sized from the frame's own count (see _token_capacity)
         def probe():

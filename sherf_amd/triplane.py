@@ -41,6 +41,50 @@ class NeRFDecoder(nn.Module):
                            'pass it to ImportanceRenderer.forward as `decoder`')
 
 
+class _GraphedProducer:
+    """One per-frame PRODUCER call (tri-plane synthesis, an image encoder, the mapping network: ~150 small library launches each) captured once
+    as a hipGraph and replayed: the launches of a frame's producers then cost the host one call and run without inter-launch gaps.  Inference
+    only (no autograd), static shapes: the capture is keyed on the arguments' shapes / dtypes, the keyword arguments and the module's parameter
+    storage (in-place weight updates keep the graph valid: it reads the live parameters; a re-allocated parameter re-captures).  Any failure to
+    capture falls back to the eager call for good."""
+
+    def __init__(self, module, fn):
+        self.module, self.fn, self.key, self.graph, self.static_in, self.static_out, self.off = module, fn, None, None, None, None, False
+
+    def _key(self, args, kw):
+        p = next(self.module.parameters(), None)
+        return (tuple((tuple(a.shape), a.dtype, a.device) if torch.is_tensor(a) else a for a in args), tuple(sorted(kw.items())),
+                None if p is None else p.data_ptr(), self.module.training)
+
+    def __call__(self, *args, **kw):
+        if self.off or torch.is_grad_enabled() or not all((not torch.is_tensor(a)) or a.device.type == 'cuda' for a in args):
+            return self.fn(*args, **kw)
+        try:
+            key = self._key(args, kw)
+            if key != self.key:
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                self.static_in = [a.clone() if torch.is_tensor(a) else a for a in args]
+                with torch.cuda.stream(side):                        # warm-up outside the capture: library workspaces, algorithm searches
+                    for _ in range(2):
+                        self.fn(*self.static_in, **kw)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.static_out = self.fn(*self.static_in, **kw)
+                self.graph, self.key = g, key
+            for dst, src in zip(self.static_in, args):
+                if torch.is_tensor(dst):
+                    dst.copy_(src)
+            self.graph.replay()
+            out = self.static_out
+            return out.clone() if torch.is_tensor(out) else out      # (the graph's output buffer is rewritten by the next replay)
+        except Exception as ex:                                      # capture not possible here (an op that synchronises, an old runtime): eager from now on
+            self.off, self.error = True, f'{type(ex).__name__}: {str(ex)[:200]}'
+            return self.fn(*args, **kw)
+
+
 class TriPlaneGenerator(nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, use_1d_feature, use_2d_feature, use_3d_feature, use_trans, use_NeRF_decoder,
                  img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={}, rendering_kwargs={}, sr_kwargs={},
@@ -79,9 +123,30 @@ class TriPlaneGenerator(nn.Module):
         # the per-frame glue (triplane.py:105-137, 174-217) as two HIP launches whenever no gradient is recorded (csrc/glue.hip; checked on the
         # MI355X against the unmodified reference's glue outputs, tests/test_gpu_glue.py): the default since round 4
         self.fused_glue = os.environ.get('SHERF_FUSED_GLUE', '1') == '1'
+        # round 5: the producers of an inference frame replayed as hipGraphs (_GraphedProducer).  MI355X, full-size generator
+        # (profiles/r05_call_i_*): forward() 8.0 -> 5.9 ms -- tri-plane synthesis 4.8 -> 2.65 ms, ResNet-18 code 1.18 -> 0.70 ms -- same image.
+        # On by default (SHERF_GRAPH_PRODUCERS=0 or `graph_producers = False` turn it off; a capture that fails falls back to eager calls)
+        self.graph_producers = os.environ.get('SHERF_GRAPH_PRODUCERS', '1') == '1'
+        self.__dict__['_graphed'] = {}
+
+    def __getstate__(self):
+        # snapshots (training_loop.py:563-579 pickles the generator) and deep copies (G_ema) carry no captured graphs and no device memo
+        state = dict(self.__dict__)
+        state['_graphed'] = {}
+        state.pop('_out_sh_memo', None)
+        return state
+
+    def _producer(self, name, module, fn):
+        """`fn` (a bound call of `module`), through its hipGraph when graph_producers is on and no gradient is recorded."""
+        if not getattr(self, 'graph_producers', False) or torch.is_grad_enabled():
+            return fn
+        gp = self.__dict__.setdefault('_graphed', {})
+        if name not in gp or gp[name].module is not module:
+            gp[name] = _GraphedProducer(module, fn)
+        return gp[name]
 
     def mapping(self, z, c, input_img=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        z = self.encoder_2d(input_img)
+        z = self._producer('encoder_2d', self.encoder_2d, self.encoder_2d)(input_img)
         if self.rendering_kwargs.get('c_gen_conditioning_zero', True):
             c = torch.zeros_like(c)
         return self.backbone.mapping(z, c * self.rendering_kwargs.get('c_scale', 0), truncation_psi=truncation_psi,
@@ -135,7 +200,13 @@ class TriPlaneGenerator(nn.Module):
         out_sh = torch.empty(3, device=dev, dtype=torch.int32)
         P = _lib.ptr
         _lib.call('sherf_voxelize', P(tv), P(can), V, P(bounds), P(coord), P(out_sh), _lib.stream())
-        return {'coord': coord, 'out_sh': out_sh.tolist(), 'batch_size': 1, 'bounds': bounds.unsqueeze(0)}, None
+        # out_sh (three integers the encoder's plan needs on the HOST) depends on the T-pose vertices' bounding box only: read back once per
+        # T-pose tensor instead of every frame -- the read-back is a host wait behind everything queued so far (the producers' graphs included)
+        key = (vertex.data_ptr(), vertex._version, tuple(vertex.shape))
+        memo = self.__dict__.get('_out_sh_memo')
+        if memo is None or memo[0] != key:
+            memo = self.__dict__['_out_sh_memo'] = (key, out_sh.tolist(), vertex)          # (the tensor is kept: its address cannot be recycled)
+        return {'coord': coord, 'out_sh': list(memo[1]), 'batch_size': 1, 'bounds': bounds.unsqueeze(0)}, None
 
     def canonical_obs_vertices(self, input_data):
         """coarse_deform_target2c(obs_params, obs_vertices, t_params, smpl_obs_pts) (triplane.py:129-132) through the
@@ -177,11 +248,11 @@ class TriPlaneGenerator(nn.Module):
             if use_cached_backbone and self._last_planes is not None:
                 planes = self._last_planes
             else:
-                planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
+                planes = self._producer('backbone.synthesis', self.backbone.synthesis, self.backbone.synthesis)(ws, update_emas=update_emas, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
         obs_input_img = input_data['obs_img_all'][:, 0]
-        obs_input_feature = self.encoder_2d_feature(obs_input_img, extract_feature=True)
+        obs_input_feature = self._producer('encoder_2d_feature', self.encoder_2d_feature, self.encoder_2d_feature)(obs_input_img, extract_feature=True)
         fused = self.fused_glue and not torch.is_grad_enabled() and obs_input_img.shape[0] == 1
         f3d, mask = (self.fused_vertex_features if fused else self.vertex_features)(input_data, obs_input_img, obs_input_feature)
         can = self.canonical_obs_vertices(input_data)
