@@ -196,6 +196,9 @@ int sherf_img_to_hwc4(const float* img, float* out, int HW, sherf_stream_t strea
  * tokens [tile][3][8][32] float4 / extras [tile][12][32] float: 32 samples per tile (sherf_gather_tokens).  out[c] = (r,g,b,sigma). */
 int sherf_nerf_mlp(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                    const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
+/* `prec | SHERF_MLP_NO_TRANSFORMER` in any sherf_nerf_mlp* entry point (and in sherf_frame.mlp_prec): the renderer was built with use_trans = False
+ * (renderer.py:261, 427) -- the slot-2 completion and the 3-token transformer are skipped, the decoder reads the fused tokens 0 / 1 as they are. */
+#define SHERF_MLP_NO_TRANSFORMER 256
 /* sherf_nerf_mlp on ONE contiguous part of the tile list: the compact tiles are cut into `nparts` parts at multiples of 8 tiles (256
  * samples; the cut is computed on the device from counters[0]) and this launch runs part `part` -- so that part k's network can run on
  * one stream beside part k + 1's sherf_gather_tokens (`mode | part << 8 | nparts << 16`: the same cut) on another.  nparts <= 1: everything. */

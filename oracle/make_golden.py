@@ -37,12 +37,14 @@ def import_reference():
     return R, T
 
 
-def run(cfg_name, R, T, out_dir):
+def run(cfg_name, R, T, out_dir, use_trans=True):
+    """use_trans=False (round 5): the same frame through the unmodified reference built WITHOUT its transformer (renderer.py:261, 427) ->
+    renderer_<cfg>_notrans.npz (final image + per-sample rgb / sigma + the discrete selections; the reference-init variant only)."""
     from oracle import fixtures
     fx = fixtures.renderer_inputs(cfg_name)
     c = fx['cfg']
     torch.manual_seed(0)
-    rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
+    rend = R.ImportanceRenderer(True, True, True, use_trans=use_trans, use_NeRF_decoder=True)
     dec = T.NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.', fixtures.variant_of(cfg_name))
     fixtures.load_seeded_state(dec, 'decoder.', fixtures.variant_of(cfg_name))
@@ -97,13 +99,14 @@ def run(cfg_name, R, T, out_dir):
         cap['f3d_raw'] = out.clone()
         return out
     rend.encoder_3d.forward = enc_rec
-    tr_fwd = rend.transformer.forward
+    if use_trans:
+        tr_fwd = rend.transformer.forward
 
-    def tr_rec(x):
-        out = tr_fwd(x)
-        cap['tokens_in'] = x.clone(); cap['tokens_out'] = out.clone()
-        return out
-    rend.transformer.forward = tr_rec
+        def tr_rec(x):
+            out = tr_fwd(x)
+            cap['tokens_in'] = x.clone(); cap['tokens_out'] = out.clone()
+            return out
+        rend.transformer.forward = tr_rec
     rm = rend.ray_marcher.run_forward
 
     def rm_rec(*a):
@@ -133,7 +136,7 @@ def run(cfg_name, R, T, out_dir):
         ref_cpu_seconds=np.float64(dt),
         sp_coord=cap['sp_coord'], sp_out_sh=cap['sp_out_sh'], sp_bounds=cap['sp_bounds'],
     )
-    if c['H'] * c['W'] * c['S'] <= 64 * 64 * 32:   # full per-stage intermediates only for the tiny configs
+    if use_trans and c['H'] * c['W'] * c['S'] <= 64 * 64 * 32:   # full per-stage intermediates only for the tiny configs
         out.update(
             x_c=cap['t2c'][0][0][0].numpy(), v_c=cap['t2c'][0][1][0].numpy(),
             t_vert_id=knn_calls[2][1].view(-1).numpy().astype(np.int32),
@@ -144,7 +147,7 @@ def run(cfg_name, R, T, out_dir):
             weights=cap['weights'][0, :, :, 0].numpy(),
             obs_vertex_canonical=cap['obs_vertex_canonical'],
         )
-    path = os.path.join(out_dir, f'renderer_{cfg_name}.npz')
+    path = os.path.join(out_dir, f'renderer_{cfg_name}.npz' if use_trans else f'renderer_{cfg_name}_notrans.npz')
     np.savez_compressed(path, **out)
     print(f'{cfg_name}: R={rgb.shape[1]} Nv={valid.numel()}/{mask.numel()} ({valid.numel()/mask.numel():.3%}) '
           f'ref forward {dt:.2f}s  rgb range [{rgb.min():.3f},{rgb.max():.3f}] acc max {acc.max():.3f} -> {path} '
@@ -380,6 +383,8 @@ if __name__ == '__main__':
     if names == ['rays']:
         run_rays(out_dir); sys.exit(0)
     R, T = import_reference()
+    if names == ['notrans']:                            # round 5: the reference built with use_trans = False, the reference-init tiny frame
+        run('tiny_ri', R, T, out_dir, use_trans=False); sys.exit(0)
     if names == ['refinit']:
         run_refinit_check(R, T, out_dir); sys.exit(0)
     if all(n.endswith('_ri') for n in names):           # only the reference-init variants: leave the other files alone

@@ -426,8 +426,11 @@ def _layer_norm(x, w, b):
 
 
 def transformer(state, tok, prefix='renderer.transformer.layers.0.'):
-    """renderer.py:949-993: pre-norm attention (3 heads x 16, scale 16^-0.5) + pre-norm FF (GELU exact). tok [n,3,32]."""
+    """renderer.py:949-993: pre-norm attention (3 heads x 16, scale 16^-0.5) + pre-norm FF (GELU exact). tok [n,3,32].
+    A state without the transformer's parameters is a renderer built with use_trans = False: renderer.py:427 is skipped, the tokens pass through."""
     p = prefix
+    if p + '0.fn.fn.to_qkv.weight' not in state:
+        return tok
     h = _layer_norm(tok, state[p + '0.fn.norm.weight'], state[p + '0.fn.norm.bias'])
     qkv = h @ state[p + '0.fn.fn.to_qkv.weight'].t()                      # [n,3,144]
     n = tok.shape[0]

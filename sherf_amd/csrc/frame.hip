@@ -261,7 +261,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
                                               f->tokens, f->extras, stream_main));
                 SHERF_HIP_CHECK(hipEventRecord(d.ev_part[k], main));
                 SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_part[k], 0));
-                if (f->mlp_prec != 1 && (f->flags & SHERF_FRAME_MLP_PIPELINED))       // two workgroups per CU: room for the next part's gather beside it
+                if ((f->mlp_prec & 255) != 1 && (f->flags & SHERF_FRAME_MLP_PIPELINED))       // two workgroups per CU: room for the next part's gather beside it
                     SHERF_RUN(sherf_nerf_mlp3_part(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, k, nparts,
                                                    (g_sherf_debug & (1 << 26)) ? 3 : (g_sherf_debug & (1 << 27)) ? 1 : 2, stream_side));   // (debug bits 26 / 27: residency 3 / 1, for A/B runs)
                 else
@@ -295,9 +295,9 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         if (split)
             SHERF_RUN(sherf_nerf_mlp_split(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->zfrag,
                                            f->sample_out, stream_main));
-        else if (f->mlp_prec != 1 && (((f->flags & SHERF_FRAME_MLP_PIPELINED) != 0) != ((g_sherf_debug & (1 << 25)) != 0)))    // (debug bit 25 flips the form: A/B runs)
+        else if ((f->mlp_prec & 255) != 1 && (((f->flags & SHERF_FRAME_MLP_PIPELINED) != 0) != ((g_sherf_debug & (1 << 25)) != 0)))    // (debug bit 25 flips the form: A/B runs)
             SHERF_RUN(sherf_nerf_mlp3(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, stream_main));
-        else if (f->mlp_prec != 1 && (((f->flags & SHERF_FRAME_MLP_TWO_TILES) != 0) != ((g_sherf_debug & (1 << 24)) != 0)))   // (debug bit 24 flips the form: A/B runs)
+        else if ((f->mlp_prec & 255) != 1 && (((f->flags & SHERF_FRAME_MLP_TWO_TILES) != 0) != ((g_sherf_debug & (1 << 24)) != 0)))   // (debug bit 24 flips the form: A/B runs)
             SHERF_RUN(sherf_nerf_mlp2(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, stream_main));
         else
             SHERF_RUN(sherf_nerf_mlp(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap,

@@ -187,6 +187,7 @@ template <int PREC> struct Ctx {
     const char* lds;         // NSLOT ring slots (generic pointer, + this lane's 16 bytes: what the ds_reads use)
     uint32_t lds_addr;       // LDS byte address of the ring (what the DMA's M0 takes), wave-uniform
     int lane, h, wave;
+    int notrans;             // use_trans = False (renderer.py:261, 427): the decoder reads the fused tokens 0 / 1 as they are
 #if SHERF_MLP_TRACE
     uint32_t* trace;         // this wave's [64][4] stamps in LDS
     bool treg;               // stamps in registers instead (two-tile kernel)
@@ -611,6 +612,16 @@ template <int PREC, bool RING, bool PRE = false>
 __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __restrict__ tokens, const float* __restrict__ extras, int64_t tile,
                                                  BFrag<PREC> (&z0b)[2], BFrag<PREC> (&z1b)[2], f32x16 (&tok)[3]) {
     const int j = cx.lane & 31, h = cx.h;
+    if (cx.notrans) {
+        // use_trans = False: no slot-2 completion, no transformer -- `sampled_features` go to the decoder unchanged (renderer.py:427, 432); the
+        // weight stream's first two steps are walked past (wave-uniform branch: a kernel argument)
+        if constexpr (!PRE) load_tokens(tokens, tile, j, h, tok);
+        split_tile<PREC>(tok[0], z0b[0], z0b[1]);
+        split_tile<PREC>(tok[1], z1b[0], z1b[1]);
+        if constexpr (RING) { advance(cx, 0); advance(cx, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     {
         // ---- inputs: tokens in D layout, extras ----
         if constexpr (!PRE) load_tokens(tokens, tile, j, h, tok);
@@ -1265,7 +1276,7 @@ __device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* w
     constexpr int NT = NW * 64;
     float* lbias = reinterpret_cast<float*>(lds + NSLOT * CX::SLOT);
     for (int i = threadIdx.x; i < (N_CHUNKS + 4) * 32; i += NT) lbias[i] = wbias[i];   // visible after the prologue barrier
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.notrans = 0;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cx.ws = ws + cx.wave * 1024 + cx.lane * 16; cx.wbias = lbias; cx.lds = lds + cx.lane * 16;
     cx.lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lptr_t)lds) + cx.wave * 1024;
@@ -1294,7 +1305,7 @@ __device__ __forceinline__ void ring_ctx(Ctx<PREC>& cx, char* lds, const char* w
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_LB)
 nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts) {
+                const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts, int notrans) {
     using CX = Ctx<PREC>;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
@@ -1303,6 +1314,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
     if (t_lo + (int64_t)blockIdx.x * NW >= n_tiles) return;          // whole workgroup beyond the data
     CX cx;
     ring_ctx<PREC>(cx, lds, ws, wbias);
+    cx.notrans = notrans;
     int64_t tile = t_lo + (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
@@ -1327,7 +1339,7 @@ nerf_mlp_kernel(const int32_t* __restrict__ counters, const float4* __restrict__
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, 2)
 nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out) {
+                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int notrans) {
     using CX = Ctx<PREC>;
     static_assert(PREC != 1 && step_pieces<PREC>(0) * 1024 == CX::SLOT, "the transformer reads steps 0 / 1 from ring slots 0 / 1 back to back");
     constexpr int RING = NSLOT * CX::SLOT, TABLES = (N_CHUNKS + 4) * 32 * 4, PARK = 2 * 4 * 1024;
@@ -1337,6 +1349,7 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     if ((int64_t)blockIdx.x * (2 * NW) >= n_tiles) return;           // whole workgroup beyond the data
     CX cx;
     ring_ctx<PREC>(cx, lds, ws, wbias, false);
+    cx.notrans = notrans;
     SHERF_TRACE_REG(cx, 0);
     int64_t tile[2];
     bool live[2];
@@ -1407,7 +1420,7 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, SHERF_MLP3_LB)
 nerf_mlp3_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts) {
+                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts, int notrans) {
     using CX = Ctx<PREC>;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
@@ -1416,6 +1429,7 @@ nerf_mlp3_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     if (t_lo + (int64_t)blockIdx.x * NW >= n_tiles) return;          // whole workgroup beyond the data
     CX cx;
     ring_ctx<PREC>(cx, lds, ws, wbias);
+    cx.notrans = notrans;
     int64_t tile = t_lo + (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
     const bool live = tile < n_tiles;
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
@@ -1447,7 +1461,7 @@ template <int PREC> constexpr int ZFRAGS = PREC == 1 ? 8 : 4;
 template <int PREC>
 __global__ void __launch_bounds__(NW * 64, PREC == 1 ? 2 : SHERF_MLP_TOKENS_WAVES)
 nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                   const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, u32x4* __restrict__ zfrag) {
+                   const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, u32x4* __restrict__ zfrag, int notrans) {
     using CX = Ctx<PREC>;
     constexpr int NT = NW * 64;
     constexpr int WBYTES = (step_pieces<PREC>(0) + step_pieces<PREC>(1)) * 1024;
@@ -1459,7 +1473,7 @@ nerf_tokens_kernel(const int32_t* __restrict__ counters, const float4* __restric
     for (int i = threadIdx.x; i < WBYTES / 16; i += NT) reinterpret_cast<u32x4*>(lds)[i] = reinterpret_cast<const u32x4*>(ws)[i];
     __syncthreads();
     CX cx;
-    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0;
+    cx.lane = threadIdx.x & 63; cx.h = cx.lane >> 5; cx.wave = threadIdx.x >> 6; cx.ws = ws; cx.lds_addr = 0; cx.notrans = notrans;
     for (int64_t tile = (int64_t)blockIdx.x * NW + cx.wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         // the weights and tables in LDS do not change between tiles: without the launder the compiler hoists their reads out of the tile
         // loop (hundreds of live registers).  The OFFSETS are laundered, not the pointers: a laundered pointer loses its address space and
@@ -1591,18 +1605,20 @@ extern "C" int sherf_mlp_pack_stream(const float* flat, const int32_t* src, int6
 extern "C" int sherf_nerf_mlp_part(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                                    const float* wbias, int prec, int64_t capacity, float* out, int part, int nparts, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    const int notrans = (prec & SHERF_MLP_NO_TRANSFORMER) ? 1 : 0;       // use_trans = False (include/sherf_hip.h)
+    prec &= ~SHERF_MLP_NO_TRANSFORMER;
     SHERF_CHECK_ARG(prec >= 0 && prec <= 2 && capacity > 0 && nparts >= 0 && nparts < 256 && (nparts <= 1 || (part >= 0 && part < nparts)));
     const int64_t tiles = nparts > 1 ? ((capacity + 255) / 256 + nparts - 1) / nparts * 8 + 8 : (capacity + 31) / 32;    // most a part can hold
     const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
     if (prec == 1)
         hipLaunchKernelGGL((nerf_mlp_kernel<1>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
     else if (prec == 2)
         hipLaunchKernelGGL((nerf_mlp_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
     else
         hipLaunchKernelGGL((nerf_mlp_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
     SHERF_LAUNCH_CHECK();
 }
 
@@ -1615,15 +1631,17 @@ extern "C" int sherf_nerf_mlp(const int32_t* counters, const float* tokens, cons
 extern "C" int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                                const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    const int notrans = (prec & SHERF_MLP_NO_TRANSFORMER) ? 1 : 0;
+    prec &= ~SHERF_MLP_NO_TRANSFORMER;
     SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0);
     const int64_t tiles = (capacity + 31) / 32;
     const dim3 grid((unsigned)((tiles + 2 * NW - 1) / (2 * NW))), block(NW * 64);
     if (prec == 2)
         hipLaunchKernelGGL((nerf_mlp2_kernel<2>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), notrans);
     else
         hipLaunchKernelGGL((nerf_mlp2_kernel<0>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), notrans);
     SHERF_LAUNCH_CHECK();
 }
 
@@ -1636,6 +1654,8 @@ extern "C" int sherf_nerf_mlp2(const int32_t* counters, const float* tokens, con
 extern "C" int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens, const float* extras, const void* wstream, const float* wbias, int prec,
                                     int64_t capacity, float* out, int part, int nparts, int wgs_per_cu, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out);
+    const int notrans = (prec & SHERF_MLP_NO_TRANSFORMER) ? 1 : 0;
+    prec &= ~SHERF_MLP_NO_TRANSFORMER;
     SHERF_CHECK_ARG((prec == 0 || prec == 2) && capacity > 0 && nparts >= 0 && nparts < 256 && (nparts <= 1 || (part >= 0 && part < nparts)));
     SHERF_CHECK_ARG(wgs_per_cu >= 0 && wgs_per_cu <= 3);
     const int64_t tiles = nparts > 1 ? ((capacity + 255) / 256 + nparts - 1) / nparts * 8 + 8 : (capacity + 31) / 32;    // most a part can hold
@@ -1643,10 +1663,10 @@ extern "C" int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens
     const unsigned pad = wgs_per_cu == 2 ? 12 * 1024 : wgs_per_cu == 1 ? 44 * 1024 : 0;
     if (prec == 2)
         hipLaunchKernelGGL((nerf_mlp3_kernel<2>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
     else
         hipLaunchKernelGGL((nerf_mlp3_kernel<0>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
     SHERF_LAUNCH_CHECK();
 }
 
@@ -1660,6 +1680,8 @@ extern "C" int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, con
 extern "C" int sherf_nerf_mlp_split(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                                     const float* wbias, int prec, int64_t capacity, void* zfrag, float* out, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && tokens && extras && wstream && wbias && out && zfrag);
+    const int notrans = (prec & SHERF_MLP_NO_TRANSFORMER) ? 1 : 0;
+    prec &= ~SHERF_MLP_NO_TRANSFORMER;
     SHERF_CHECK_ARG(prec >= 0 && prec <= 2 && capacity > 0);
     static int n_cu = 0;
     if (!n_cu) {
@@ -1675,7 +1697,7 @@ extern "C" int sherf_nerf_mlp_split(const int32_t* counters, const float* tokens
 #define SHERF_SPLIT(P)                                                                                                                  \
     do {                                                                                                                                 \
         hipLaunchKernelGGL((nerf_tokens_kernel<P>), tgrid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), \
-                           extras, reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<u32x4*>(zfrag));            \
+                           extras, reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<u32x4*>(zfrag), notrans);   \
         hipLaunchKernelGGL((nerf_decoder_kernel<P>), dgrid, block, 0, as_stream(stream), counters, reinterpret_cast<const u32x4*>(zfrag), \
                            extras, reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out));             \
     } while (0)

@@ -594,7 +594,8 @@ class ImportanceRenderer(nn.Module):
         else:
             ps = []
             for m in (self.conv1d_projection, self.conv1d_reprojection, self.transformer, decoder):
-                fast_params(m, ps)
+                if m is not None:                       # (use_trans = False: no transformer)
+                    fast_params(m, ps)
             key = state_key(ps) + (str(device),)
             if memo is not None:
                 self.__dict__['_frame_memo'] = (decoder, device, key)
@@ -626,6 +627,14 @@ class ImportanceRenderer(nn.Module):
         (mlp_pack.check_f16_range) are made on the device and read back once per repack: same ValueError."""
         named = {'renderer.' + k: v for k, v in self.named_parameters() if not k.startswith('encoder_3d.')}
         named.update({'decoder.' + k: v for k, v in decoder.named_parameters()})
+        if self.transformer is None:
+            # use_trans = False (renderer.py:261, 427): the kernel walks past the transformer's chunks (SHERF_MLP_NO_TRANSFORMER); their slots of the
+            # stream are packed from zeros so that the layout -- and every other chunk's place in it -- stays the one the kernel knows
+            z = lambda *sh: torch.zeros(*sh, device=device)
+            t = 'renderer.transformer.layers.0.'
+            named.update({t + '0.fn.norm.weight': z(32), t + '0.fn.norm.bias': z(32), t + '0.fn.fn.to_qkv.weight': z(144, 32), t + '0.fn.fn.to_out.0.weight': z(32, 48),
+                          t + '0.fn.fn.to_out.0.bias': z(32), t + '1.fn.norm.weight': z(32), t + '1.fn.norm.bias': z(32), t + '1.fn.fn.net.0.weight': z(32, 32),
+                          t + '1.fn.fn.net.0.bias': z(32), t + '1.fn.fn.net.3.weight': z(32, 32), t + '1.fn.fn.net.3.bias': z(32)})
         names = mlp_pack.packed_names()
         if wc.get('flat') is None:
             wc['flat'] = torch.cat([named[n].detach().to(device=device, dtype=torch.float32).reshape(-1) for n in names])
@@ -706,7 +715,7 @@ class ImportanceRenderer(nn.Module):
         """The precision-dependent fields of the frame descriptor: the MLP fragment stream and the table / encoder flags."""
         wc = self._weights(decoder, dev, cfg[0])
         fr.wstream, fr.wbias = _lib.addr(wc['stream']), _lib.addr(wc['wbias'])
-        fr.mlp_prec = MLP_PRECISIONS[cfg[0]]
+        fr.mlp_prec = MLP_PRECISIONS[cfg[0]] | (0 if self.use_trans else 256)      # SHERF_MLP_NO_TRANSFORMER
         fr.flags = (1 if exact else 0) | (2 if cfg[1] == 'f16' else 0) | (4 if cfg[2] == 'f16' else 0) | (16 if self.__dict__.get('_opt_report_count') else 0)
         # the two-launch form of the per-sample network (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel, bit-identical results):
         # opt-in.  Measured SLOWER than the one-launch kernel on the MI355X in every precision (f16, 512x512x64: 0.35 vs 0.285 ms at 4 %
@@ -765,6 +774,8 @@ class ImportanceRenderer(nn.Module):
     def forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
                 decoder, ray_origins, ray_directions, near, far, input_data, rendering_options):
         if getattr(self, 'enable_autograd', False) and torch.is_grad_enabled() and not getattr(self, '_in_autograd', False):
+            if not self.use_trans:
+                raise NotImplementedError('the backward through the HIP kernels covers use_trans = True only (the shipped configuration)')
             # opt-in training path (BASELINE config 5): the same forward, recorded as one autograd node whose backward runs
             # the HIP backward pipeline (sherf_amd/backward.py; experimental until verified on hardware)
             from .backward import RenderFunction, _named_params
@@ -780,9 +791,9 @@ class ImportanceRenderer(nn.Module):
                     self.encoder_3d._force_stats_update = False
             return RenderFunction.apply(self, decoder, call, planes, obs_input_feature, canonical_sp_conv_volume.features,
                                         *[p for _, p in _named_params(self, decoder)])
-        if not (self.use_1d_feature and self.use_2d_feature and self.use_3d_feature and self.use_trans and self.use_NeRF_decoder):
-            raise NotImplementedError('sherf_amd implements the shipped SHERF configuration: use_1d/2d/3d_feature, use_trans '
-                                      'and use_NeRF_decoder all True (train_*.sh)')
+        if not (self.use_1d_feature and self.use_2d_feature and self.use_3d_feature and self.use_NeRF_decoder):
+            raise NotImplementedError('sherf_amd implements use_1d/2d/3d_feature and use_NeRF_decoder all True (every train_*.sh / eval_*.sh); '
+                                      'use_trans may be False (round 5)')
         if not ray_origins.is_cuda:
             raise RuntimeError('sherf_amd.ImportanceRenderer runs on the GPU only (no CPU fallback)')
         if ray_origins.shape[0] != 1:

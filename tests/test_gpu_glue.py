@@ -51,6 +51,13 @@ def test_mlp_launch_forms_render_the_same_bits_on_device(cfg):
                 assert torch.equal(one[k], b[k]), (prec, form, k)
 
 
+def test_renderer_without_transformer_on_device():
+    """use_trans = False on the hardware against the golden of the unmodified reference built without its transformer (the all-True
+    restriction opened for use_trans)."""
+    from tests.test_hipcpu_frame import check_without_transformer
+    check_without_transformer()
+
+
 @pytest.mark.parametrize('cfg,prec', [('tiny', 'f16x3'), ('cfg1_ri', 'f16')])
 def test_schedule_switches_render_the_same_bits_on_device(cfg, prec):
     """Round 4's launch / data-structure switches on the hardware, each against the default frame bit for bit: the candidate search over

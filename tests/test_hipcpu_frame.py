@@ -103,6 +103,8 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
             assert b['last']['mlp_form'] == form
             for k in ('rgb', 'acc', 'depth'):
                 assert torch.equal(one[k], b[k]), (prec, form, k)
+    # use_trans = False (round 5): every launch form of the network against the golden of the unmodified reference built without its transformer
+    check_without_transformer()
     # gather + network cut into parts on two streams (sherf_nerf_mlp_part): a schedule, not an arithmetic, variant
     for parts in (2, 3, 8):
         b = G.hip_render('tiny_nv', options=dict(mlp_parts=parts))
@@ -446,6 +448,26 @@ def test_renderer_helpers_the_reference_generator_calls(cpu_product):
     assert float((G.plain(xy)[0, 0] - ref_uv).abs().max()) < 1e-3                       # pixels
     only_xy = rend.projection(d['obs_vertices'].reshape(1, -1, 3), d['obs_R_all'], d['obs_T_all'], d['obs_K_all'])
     assert torch.equal(G.plain(only_xy), G.plain(xy)) and 0.2 < float(G.plain(mask).float().mean()) < 0.8
+
+
+def check_without_transformer():
+    """ImportanceRenderer(use_trans=False) (renderer.py:261, 427): the HIP frame against tests/golden/renderer_tiny_ri_notrans.npz (the unmodified
+    reference built the same way) -- fp32-grade f16x3 to 1e-4 per sample, the single-product launch forms bit-identical to each other and within
+    their class of it; the backward is refused.  Shared by the host-build test and tests/test_gpu_glue.py."""
+    g = np.load(os.path.join(G.GOLDEN, 'renderer_tiny_ri_notrans.npz'))
+    ref = G.hip_render('tiny_ri', precision='f16x3', use_trans=False)
+    nv = int(ref['last']['ws']['counters'][0])
+    assert nv == int(g['n_valid']) and ref['rend'].transformer is None
+    so = G.plain(ref['last']['ws']['sample_out'][:nv])
+    assert G.rel(so[:, :3], g['sample_rgb']) < 1e-4 and G.rel(torch.relu(so[:, 3]), np.maximum(g['sample_sigma'], 0)) < 1e-4
+    assert G.rel(ref['rgb'], g['rgb']) < 1e-4 and G.rel(ref['acc'], g['acc'][:, 0]) < 1e-4
+    one = G.hip_render('tiny_ri', precision='f16', use_trans=False, options=dict(mlp_form='one'))
+    assert G.rel(one['rgb'], g['rgb']) < 2e-3
+    for opts in (dict(mlp_form='pipelined'), dict(mlp_form='two_tiles'), dict(mlp_split=True)):
+        b = G.hip_render('tiny_ri', precision='f16', use_trans=False, options=opts)
+        assert torch.equal(b['rgb'], one['rgb']) and torch.equal(b['acc'], one['acc']), opts
+    with_t = G.hip_render('tiny_ri', precision='f16x3')
+    assert G.rel(with_t['rgb'], ref['rgb']) > 1e-3                       # the transformer does change the image
 
 
 def check_whole_generator():

@@ -269,6 +269,20 @@ def test_tiny_ri_every_stage_matches_reference(golden_dir):
     assert _rel(r['rgb'], g['rgb']) < 1e-5 and _rel(r['acc'], g['acc'][:, 0]) < 1e-5
 
 
+def test_tiny_ri_without_transformer_matches_reference(golden_dir):
+    """use_trans = False (renderer.py:261, 427; round 5): the oracle on a state WITHOUT the transformer's parameters against the unmodified
+    reference built the same way (tests/golden/renderer_tiny_ri_notrans.npz, `python -m oracle.make_golden notrans`)."""
+    g = np.load(os.path.join(golden_dir, 'renderer_tiny_ri_notrans.npz'))
+    st = {k: v for k, v in _state_ri(golden_dir).items() if '.transformer.' not in k}
+    r = O.render_from_fixture(fixtures.renderer_inputs('tiny_ri'), st, training=True)
+    mask = np.unpackbits(g['mask_bits'])[:int(g['n_samples'])].astype(bool)
+    assert (r['mask'].numpy() == mask).all() and (r['vert_id'].numpy() == g['vert_id']).all()
+    assert _rel(r['sample_rgb'], g['sample_rgb']) < 1e-5 and _rel(r['sample_sigma'], g['sample_sigma']) < 1e-5
+    assert _rel(r['rgb'], g['rgb']) < 1e-5 and _rel(r['acc'], g['acc'][:, 0]) < 1e-5
+    full = np.load(os.path.join(golden_dir, 'renderer_tiny_ri.npz'))
+    assert _rel(full['sample_rgb'], g['sample_rgb']) > 1e-3                 # (the transformer does change the result: the two goldens differ)
+
+
 def test_cfg1_ri_and_float64_truth(golden_dir):
     """cfg1 with the reference-init network: the oracle against the unmodified reference's outputs, and the float64 truth mode against
     both -- on this well-conditioned workload fp32 and float64 agree to fp32 rounding, per sample."""
