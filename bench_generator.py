@@ -156,7 +156,8 @@ def main():
     ap.add_argument('--precision', default='auto')
     ap.add_argument('--small-backbone', action='store_true', help='TEST ONLY: channel_base 512 / channel_max 16 (the host-build dry run of this script)')
     ap.add_argument('--miopen-benchmark', action='store_true', help='torch.backends.cudnn.benchmark = True: MIOpen searches its convolution algorithms on first use')
-    ap.add_argument('--graph-producers', action='store_true', help='TriPlaneGenerator.graph_producers = True: the producers replayed as hipGraphs')
+    ap.add_argument('--eager-producers', action='store_true', help='TriPlaneGenerator.graph_producers = False in every variant (default: the product default, '
+                                                                   'producers replayed as hipGraphs; the eager number is measured beside it either way)')
     ap.add_argument('--channels-last', action='store_true', help='producers (backbone, encoders) in channels_last memory format')
     a = ap.parse_args()
     import bench
@@ -169,7 +170,7 @@ def main():
     if a.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
     gen = build_generator(w, dev, small=a.small_backbone)
-    gen.graph_producers = bool(a.graph_producers)
+    graph_default = bool(gen.graph_producers) and not a.eager_producers and dev.type == 'cuda'
     if a.channels_last:
         for m in (gen.backbone, gen.encoder_2d, gen.encoder_2d_feature):
             m.to(memory_format=torch.channels_last)
@@ -178,10 +179,15 @@ def main():
     n_params = {k: int(sum(p.numel() for p in m.parameters())) for k, m in (('backbone', gen.backbone), ('encoder_2d', gen.encoder_2d),
                                                                              ('encoder_2d_feature', gen.encoder_2d_feature))}
     res = dict(metric='rays/s of TriPlaneGenerator.forward at 512x512x64 (test_loop.py:189-190), full-size producers', unit='rays/s', steps=a.steps, warmup=a.warmup,
-               config=dict(workload=a.config, miopen_benchmark=bool(a.miopen_benchmark), channels_last=bool(a.channels_last), graph_producers=bool(a.graph_producers), rays=R, image=list(d['obs_img_all'].shape[-2:]), backbone='StyleGAN2 Generator z512 w512 map_depth 2 channel_base 32768 channel_max 512 -> planes [1,96,256,256]',
+               config=dict(workload=a.config, miopen_benchmark=bool(a.miopen_benchmark), channels_last=bool(a.channels_last), graph_producers=None, rays=R, image=list(d['obs_img_all'].shape[-2:]), backbone='StyleGAN2 Generator z512 w512 map_depth 2 channel_base 32768 channel_max 512 -> planes [1,96,256,256]',
                            parameters=n_params, weights='constructor initialisation under torch.manual_seed(0) (no pretrained pickle offline)',
                            mlp_precision=None, mlp_form=None))
-    for name, cached in (('recomputed_every_frame', False), ('use_cached_backbone', True)):
+    res['config']['graph_producers'] = graph_default
+    for name, cached, graphed in (('recomputed_every_frame', False, graph_default), ('recomputed_every_frame_eager_producers', False, False),
+                                  ('use_cached_backbone', True, graph_default)):
+        if name.endswith('eager_producers') and not graph_default:
+            continue                                        # (identical to the default variant)
+        gen.graph_producers = graphed
         ms, stages, out = run(gen, d, dev, a.steps, a.warmup, cached)
         floor = max((k for k in STAGES if k in stages), key=lambda k: stages[k])
         res[name] = dict(ms_per_forward=ms, rays_per_s=R / (ms * 1e-3), stages_ms={k: round(v, 4) for k, v in stages.items()}, floor=floor,
@@ -191,7 +197,7 @@ def main():
     res['output'] = dict(image_raw=list(img.shape), finite=bool(torch.isfinite(img).all()), mean=float(img.mean()), weights_mean=float(out['weights_image'].mean()))
     res['config']['mlp_precision'] = w['rend'].last.get('mlp_precision'); res['config']['mlp_form'] = w['rend'].last.get('mlp_form')
     res['renderer_ms_inside_forward'] = res['recomputed_every_frame']['stages_ms'].get('renderer')
-    if a.graph_producers:
+    if graph_default:
         res['graphed'] = {k: ('off: ' + getattr(v, 'error', '?')) if v.off else 'captured' for k, v in gen.__dict__.get('_graphed', {}).items()}
     print(json.dumps(res))
 

@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for flags in "" "--graph-producers"; do
+for flags in "--eager-producers" ""; do   # (as run: "" and "--graph-producers" -- replay became the default afterwards, the flag now selects the eager producers)
   timeout 400 python bench_generator.py --steps 30 --warmup 8 $flags > $OUT/r5i_gen.json 2> $OUT/r5i_gen.err; echo "[bench_generator '$flags' rc=$?]"
   python - <<'PY'
 import json
