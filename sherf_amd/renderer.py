@@ -367,7 +367,7 @@ class ImportanceRenderer(nn.Module):
 
     def __getstate__(self):
         s = self.__dict__.copy()
-        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_flags', '_frame_memo'):
+        for k in ('_smpl_dev', '_ws', '_wcache', 'last', '_flags', '_frame_memo', '_pack_flag_pending'):
             s[k] = None
         s['_ws'] = None
         return s
@@ -653,6 +653,21 @@ class ImportanceRenderer(nn.Module):
         flag = torch.empty(1, dtype=torch.int32, device=device)
         P = _lib.ptr
         _lib.call('sherf_mlp_pack_stream', P(flat), P(src), src.numel(), prec, P(stream), P(bsrc), bsrc.numel(), P(wbias), P(flag), _lib.stream())
+        if getattr(self, '_in_autograd', False) and device.type == 'cuda' and flag.device.type == 'cuda':
+            # Training: a repack follows every optimiser update, and reading its flag word back HERE made the host wait for the previous step's
+            # kernels (19.5 ms of host time per step in bench_train.py, rounds 3-4).  The word goes to pinned memory behind the pack kernel
+            # instead and is looked at by the NEXT repack, a whole step later, when it has long landed: the same ValueError, one step late
+            # (weights move a little per step from a checked start; the kernel's own non-finite flag, check_finite(), stays armed meanwhile).
+            pend = self.__dict__.get('_pack_flag_pending')
+            if pend is not None:
+                pend[0].synchronize()
+                mlp_pack.raise_for_flags(int(pend[1][0]), 0.0, pend[2])
+            host = torch.empty(1, dtype=torch.int32).pin_memory()
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.__dict__['_pack_flag_pending'] = (ev, host, prec, flag)
+            return stream, wbias
         checks = [flag.to(torch.float32)]
         if prec != 0 and not getattr(self, '_in_autograd', False):
             # a-priori bound of the activations (mlp_pack.check_f16_range): product of the layers' row norms.  Skipped while training

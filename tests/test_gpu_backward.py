@@ -282,6 +282,36 @@ def test_full_size_backward_against_oracle_autograd(cfg):
     _full_size_backward(cfg, 'cuda')
 
 
+def test_training_repack_reports_bad_weights_one_step_late():
+    """Round 5: under autograd the weight stream's flag word (non-finite / out-of-fp16-range weights) is no longer read back at the repack that set it
+    (a host wait behind the previous step's kernels) but at the NEXT repack: a weight that goes bad raises the same ValueError one step later, and
+    good steps never wait."""
+    from sherf_amd.voxel import SparseConvTensor
+    fx = G.fixture('tiny_nv')
+    rend, dec = G.hip_modules.__wrapped__('f16x3', 'seeded')
+    rend.enable_autograd = True
+    spi = G.oracle_render('tiny_nv')['sp_input']
+    d = G.to_cuda(fx['input_data'])
+    opts = dict(fx['options']); opts['mlp_precision'] = 'f16x3'
+
+    def step():
+        planes = G.to_cuda(fx['planes']).requires_grad_(True)
+        sp = SparseConvTensor(G.to_cuda(fx['vertex_feat']), G.dev_tensor(spi['coord']), spi['out_sh'], 1)
+        si = dict(coord=G.dev_tensor(spi['coord']), out_sh=spi['out_sh'], batch_size=1, bounds=G.dev_tensor(spi['bounds'])[None])
+        rgb, depth, acc = rend(planes, d['obs_img_all'][:, 0], G.to_cuda(fx['obs_feat']), sp, None, si, dec, d['ray_o_all'][:, 0], d['ray_d_all'][:, 0],
+                               d['near_all'][:, 0], d['far_all'][:, 0], d, opts)
+        (rgb.square().mean() + acc.square().mean()).backward()
+    step()
+    assert rend.__dict__.get('_pack_flag_pending') is not None            # the first repack's word is in flight, nothing was waited for
+    with torch.no_grad():
+        dec.pts_linears[3].weight[5, 7] = 1e6                             # beyond the fp16 range: the next repack flags it ...
+    step()                                                                # ... and is itself not read yet
+    with torch.no_grad():
+        dec.pts_linears[3].weight[5, 7] = 0.5
+    with pytest.raises(ValueError, match='fp16 range'):
+        step()                                                            # ... but the repack after it reads the word of the bad one
+
+
 def _random_level(dims, n, seed):
     """A random sparse level: sorted unique keys + the (bits, prefix) records the kernels use, as CPU and GPU dicts."""
     D, H, W = dims
