@@ -223,6 +223,13 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
 // 32-channel slot and a wave covers 16 samples instead of 8: half the load instructions for the same taps.  Same stencils, same
 // weights, fp32 sums; the tokens / extras come out in the same tile-major layout (a lane stores two quads).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// the first pair of tiles workgroup `b` of `g` takes (the loop header of gather_tokens_h8_kernel): n_pairs or more = none
+__device__ __forceinline__ int64_t banded_first_pair(int b, int g, int64_t n_pairs, int dbg) {
+    const bool banded = !(dbg & 1024) && g % 8 == 0;
+    if (!banded) return b;
+    const int64_t per_xcd = (n_pairs + 7) / 8;
+    return (int64_t)(b / 8) < per_xcd ? (int64_t)(b % 8) * per_xcd + b / 8 : n_pairs;
+}
 struct f8 { float4 a, b; };
 __device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__ base, size_t idx8) {
     const h16x8 v = reinterpret_cast<const h16x8*>(base)[idx8];
@@ -230,6 +237,11 @@ __device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__
     acc.b.x += w * (float)v[4]; acc.b.y += w * (float)v[5]; acc.b.z += w * (float)v[6]; acc.b.w += w * (float)v[7];
 }
 
+// STAGE (round 5): the (word, prefix) occupancy records of the two COARSER tapped levels (2.3 K + 0.3 K words at the
+// bench subject's grid: 20 KiB) are copied to LDS once per workgroup, and a workgroup then walks several pairs of tiles -- 16 of a sample's 24 first-hop
+// look-ups become LDS reads.  The counters of the round (profiles/r05_call_g_pmc_*) say the kernel waits on dependent gathers (waves parked 65 % of their
+// cycles, addresser 62 % busy): this shortens two of its three look-up -> row chains.  Same arithmetic: bit-identical tokens.
+template <bool STAGE>
 __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                                const void* __restrict__ planes_f, int P, const void* __restrict__ feat_f,
                                                                int Hf, int Wf, const float4* __restrict__ img4, int H, int W, Levels lv,
@@ -241,6 +253,17 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
     sherf_part_range((nv + 31) / 32, (mode >> 8) & 255, (mode >> 16) & 255, t_lo, t_hi);
     mode &= 255;
     const int64_t n_tiles = t_hi - t_lo, n_pairs = (n_tiles + 1) / 2;          // a workgroup step = two tiles = 64 samples (t_lo is even)
+    extern __shared__ __attribute__((aligned(16))) uint2 s_wp[];              // STAGE: level 1's records, then level 2's
+    int s_n1 = 0;                                    // level 2's records start behind level 1's
+    if constexpr (STAGE) {
+        const int n1 = (lv.l[1].D * lv.l[1].H * lv.l[1].W + 31) / 32, n2 = (lv.l[2].D * lv.l[2].H * lv.l[2].W + 31) / 32;
+        s_n1 = n1;
+        if ((banded_first_pair(blockIdx.x, gridDim.x, n_pairs, dbg)) < n_pairs && mode != 1) {     // (a workgroup beyond the data stages nothing)
+            for (int i = threadIdx.x; i < n1; i += 256) s_wp[i] = reinterpret_cast<const uint2*>(lv.l[1].wp)[i];
+            for (int i = threadIdx.x; i < n2; i += 256) s_wp[n1 + i] = reinterpret_cast<const uint2*>(lv.l[2].wp)[i];
+        }
+        __syncthreads();
+    }
     const int l = threadIdx.x & 3;                 // channel octet within a slot (quads 2l, 2l + 1)
     const int js = threadIdx.x >> 2;               // sample within the pair of tiles (0..63)
     const bool banded = !(dbg & 1024) && gridDim.x % 8 == 0;                  // XCD-banded order, as in gather_tokens_kernel
@@ -353,7 +376,9 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
                     const int xx = xi + u, yy = yi + (l & 1), zz = zi + (l >> 1);
                     const bool inb = valid && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
                     const int key = inb ? (zz * lev.H + yy) * lev.W + xx : 0;
-                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                    uint2 rr;
+                    if (STAGE && L > 0) rr = s_wp[(L == 2 ? s_n1 : 0) + (key >> 5)];
+                    else rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
                     const uint32_t bit = 1u << (key & 31);
                     mine[u] = (inb && (rr.x & bit)) ? (int)(rr.y + __popc(rr.x & (bit - 1u))) : -1;
                 }
@@ -823,7 +848,18 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode)
     if (half_tables && !branchless && !(g_sherf_debug & 2048)) {      // eight channels per lane (debug bit 11: the four-per-lane kernel on fp16 tables)
         const int64_t pairs = (tiles + 1) / 2;
-        hipLaunchKernelGGL(gather_tokens_h8_kernel, dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
+        // debug bit 29: the records of the two coarser levels staged in LDS (gather_tokens_h8_kernel<true>), a workgroup walks ~`ppw` pairs (4; debug bit
+        // 30: 16); only when they fit 40 KiB (four workgroups per CU keep their LDS) and every level is tapped (mode 0 / 2)
+        const size_t stage_bytes = mode == 1 ? 0 : 8 * (((size_t)lv.l[1].D * lv.l[1].H * lv.l[1].W + 31) / 32 + ((size_t)lv.l[2].D * lv.l[2].H * lv.l[2].W + 31) / 32);
+        if ((g_sherf_debug & (1 << 29)) && mode != 1 && stage_bytes <= 40 * 1024) {
+            const int ppw = (g_sherf_debug & (1 << 30)) ? 16 : 4;
+            const int64_t wgs = std::max<int64_t>(8, std::min<int64_t>(16384, ((pairs + ppw - 1) / ppw + 7) / 8 * 8));
+            hipLaunchKernelGGL(gather_tokens_h8_kernel<true>, dim3((unsigned)wgs), dim3(256), stage_bytes, as_stream(stream),
+                               counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
+                               reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
+                               capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode);
+        } else
+        hipLaunchKernelGGL(gather_tokens_h8_kernel<false>, dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
                            counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                            reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
                            capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode);
