@@ -275,7 +275,7 @@ def test_bench_generator_dry_run(cpu_product, monkeypatch, capsys):
     assert res['config']['mlp_form'] == 'pipelined' and res['config']['mlp_precision'] == 'f16'
 
 
-@pytest.mark.parametrize('partition', ['views', 'rays', 'views-4-streams'])
+@pytest.mark.parametrize('partition', ['views', 'rays', 'views-3-streams'])
 def test_bench_two_ranks_dry_run(cpu_product, partition):
     """bench.py as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), two ranks over gloo
     on the host build: every rank renders its own view (weak scaling) or its interleaved ray tiles of ONE frame (--partition rays,
@@ -291,8 +291,8 @@ def test_bench_two_ranks_dry_run(cpu_product, partition):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    SHERF_DIST_BACKEND='gloo', SHERF_HIPCPU_LIB=_lib.LIB_PATH, OMP_NUM_THREADS='2', SHERF_BENCH_PARTITION=partition.split('-')[0])
-        if partition == 'views-4-streams':        # round 5: four caller streams per rank, one gather queue per stream (5 steps: every queue used, one wraps)
-            env.update(SHERF_BENCH_STREAMS='4', SHERF_BENCH_STEPS='5')
+        if partition == 'views-3-streams':        # round 5: several caller streams per rank, one gather queue per stream (4 steps on 3 streams: every queue used, one wraps)
+            env.update(SHERF_BENCH_STREAMS='3', SHERF_BENCH_STEPS='4')
         procs.append(subprocess.Popen([sys.executable, os.path.join(G.ROOT, 'tests', 'bench_dist_child.py')], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -304,9 +304,9 @@ def test_bench_two_ranks_dry_run(cpu_product, partition):
     ex = res['config']['exchange']
     assert ex['bytes_per_rank'] > 0 and ex['predicted_us_at_8_gpus'] > 20 and 'none by us' in ex['measured_scaling']
     if partition.startswith('views'):
-        if partition == 'views-4-streams':
-            # 4 frames to create the workspaces + 1 warm-up + 5 timed + 3 for the host's own cost = 13 gathers, every one awaited (drain)
-            assert res['config']['caller_streams'] == 4 and res['steps'] == 5 and ex['gathers_issued'] == 13
+        if partition == 'views-3-streams':
+            # 3 frames to create the workspaces + 1 warm-up + 4 timed + 3 for the host's own cost = 11 gathers, every one awaited (drain)
+            assert res['config']['caller_streams'] == 3 and res['steps'] == 4 and ex['gathers_issued'] == 11
         assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['config']['parallelism'] == 'views x2'
         assert res['value'] > 0 and abs(res['value'] - 2 * res['config']['rays'] * res['steps'] / (per_step * res['steps'])) < 1e-6 * res['value']
     else:
