@@ -7,6 +7,18 @@
 
 extern char g_sherf_err[256];
 extern int g_sherf_debug;   // ablation switches for profiling (sherf_set_debug); 0 in production
+// Scheduling experiments of tools/frame_ab.py --exps (environment SHERF_EXPERIMENT, read per frame; unset in production): launch ORDER / stream
+// placement only, never arithmetic.  bit 0: level-0 rows scattered before the level builds are queued; bit 1: level builds on the encoder's own
+// stream; bit 2: cross-stream events created with hipEventReleaseToDevice (read once, at the first frame); bit 3: encoder queued before the ray side.
+#include <stdlib.h>
+// bit 4: host clock (us, CLOCK_MONOTONIC) of the frame driver's enqueue points on stderr
+#include <time.h>
+static inline double sherf_host_us() { timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); return t_.tv_sec * 1e6 + t_.tv_nsec * 1e-3; }
+#define SHERF_HOST_STAMP(xp_, what_) do { if ((xp_) & 16) fprintf(stderr, "[host] %.1f %s\n", sherf_host_us(), what_); } while (0)
+// (same bit: a host function queued IN the stream prints the host clock when the GPU gets there)
+static void sherf_gpu_stamp_fn(void* what_) { fprintf(stderr, "[host] %.1f gpu: %s\n", sherf_host_us(), (const char*)what_); }
+#define SHERF_GPU_STAMP(xp_, strm_, what_) do { if ((xp_) & 16) (void)hipLaunchHostFunc(strm_, sherf_gpu_stamp_fn, (void*)what_); } while (0)
+static inline int sherf_experiment() { const char* s_ = getenv("SHERF_EXPERIMENT"); return s_ ? atoi(s_) : 0; }
 
 #define SHERF_CHECK_ARG(cond)                                                                     \
     do {                                                                                          \

@@ -136,15 +136,17 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         {
             std::lock_guard<std::mutex> lk(g_mu);
             if (!d.init) {
-                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_start, hipEventDisableTiming));
-                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_smpl, hipEventDisableTiming));
-                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, hipEventDisableTiming));
-                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, hipEventDisableTiming));
-                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_fold, hipEventDisableTiming));
-                for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], hipEventDisableTiming));
+                // (device-to-device events; the two the HOST waits on -- ev_cnt, ev_rep -- keep the default system-scope release)
+                const unsigned evf = hipEventDisableTiming | ((sherf_experiment() & 4) ? hipEventReleaseToDevice : 0u);
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_start, evf));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_smpl, evf));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_enc, evf));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mid, evf));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_fold, evf));
+                for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_lev[k], evf));
                 SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_cnt, hipEventDisableTiming));
-                for (int k = 0; k < kMaxParts; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_part[k], hipEventDisableTiming));
-                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mlp, hipEventDisableTiming));
+                for (int k = 0; k < kMaxParts; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_part[k], evf));
+                SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_mlp, evf));
                 SHERF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&d.host_nv), 64, 0));
                 for (int k = 0; k < 8; ++k) SHERF_HIP_CHECK(hipEventCreateWithFlags(&d.ev_rep[k], hipEventDisableTiming));
                 d.init = true;
@@ -156,8 +158,11 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             std::lock_guard<std::mutex> lk(g_mu);
             cur_slot = g_prof_on ? g_prof_n % kRing : -1;
         }
+        const int xp = sherf_experiment();
+        SHERF_HOST_STAMP(xp, "frame enter");
         // inputs were produced on the caller's stream
         SHERF_PROF(0, main);
+        SHERF_GPU_STAMP(xp, main, "frame start");
         SHERF_HIP_CHECK(hipEventRecord(d.ev_start, main));
         SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_start, 0));
         // ---- a7-a9 per-frame SMPL tables: first needed by the warp (after sampling), so with an aux stream they queue there
@@ -201,7 +206,8 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         };
         // Launch order == start order (a launch costs the host ~5 us): staggered -> encoder first, the ray side waits for
         // layer `stagger`; concurrent -> the ray side's big kernels first, the encoder's ~50 small ones behind them.
-        if (stagger >= 0) SHERF_RUN(enqueue_encoder());
+        const bool encoder_first = stagger >= 0 || (xp & 8);
+        if (encoder_first) SHERF_RUN(enqueue_encoder());
         // ---- main: cell lists, a4-a6 sampling / mask / nearest vertex / compaction, table re-layout ----
         const bool lists = f->near_hdr && f->near_list;             // exact vertex list per near-mask sub-cell: its counts also give the mask
         SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
@@ -230,7 +236,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
             SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_cnt, main));
         }
-        if (stagger < 0) SHERF_RUN(enqueue_encoder());
+        if (!encoder_first) SHERF_RUN(enqueue_encoder());
         if (!stream_aux) SHERF_RUN(fold_tables(stream_main));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
         if (!(g_sherf_debug & (1 << 28))) {          // (debug bit 28, TIMING EXPERIMENTS ONLY: no joins in front of the warp -- results may be wrong)
@@ -239,7 +245,9 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         }
         int64_t cap = tok_cap;
         if (exact) {
+            SHERF_HOST_STAMP(xp, "count wait begins");
             SHERF_HIP_CHECK(hipEventSynchronize(d.ev_cnt));
+            SHERF_HOST_STAMP(xp, "count wait ends");
             int64_t c = *d.host_nv > 0 ? ((int64_t)*d.host_nv + 255) / 256 * 256 : 256;      // whole MLP tile groups
             if (c < cap) cap = c;
         }
@@ -310,6 +318,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_RUN(sherf_composite_compact_cap(f->counters, f->ray_base, f->ray_cnt, f->cs_idx, f->sample_out, f->ray_d, f->near, f->far,
                                               f->R, f->S, f->white_back, tok_cap, f->rgb, f->depth, f->acc, stream_main));
         SHERF_PROF(6, main);
+        SHERF_HOST_STAMP(sherf_experiment(), "frame leave");
         if (cur_slot >= 0) {
             std::lock_guard<std::mutex> lk(g_mu);
             g_prof_host_ms[cur_slot] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();

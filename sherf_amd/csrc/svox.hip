@@ -748,17 +748,48 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         const sherf_svox_level_ws& l = p->lev[i];
         SHERF_CHECK_ARG(l.bitmap && l.prefix && l.n_rows && l.chunk_ws && l.wp && l.keys && l.n_words > 0 && l.cap > 0 && l.D > 0 && l.H > 0 && l.W > 0);
     }
+    SHERF_HOST_STAMP(sherf_experiment(), "encoder first launch");
+    // (SHERF_EXPERIMENT bit 5: timing events along the encoder's stream, printed at the next frame's entry -- tools/host_stamps.py --trail)
+    static hipEvent_t xe[32];
+    static const char* xw[32];
+    static int xn = 0, xmade = 0;
+    const bool trail = (sherf_experiment() & 32) != 0;
+    if (trail && xn > 0) {
+        SHERF_HIP_CHECK(hipEventSynchronize(xe[xn - 1]));
+        fprintf(stderr, "[trail]");
+        for (int i = 1; i < xn; ++i) {
+            float ms = 0.f;
+            SHERF_HIP_CHECK(hipEventElapsedTime(&ms, xe[0], xe[i]));
+            fprintf(stderr, " %s %.0f", xw[i], ms * 1e3f);
+        }
+        fprintf(stderr, "\n");
+    }
+    xn = 0;
+    auto mark = [&](const char* what) -> int {
+        if (!trail || xn >= 32) return SHERF_OK;
+        if (xn >= xmade) { SHERF_HIP_CHECK(hipEventCreate(&xe[xn])); xmade = xn + 1; }
+        xw[xn] = what;
+        SHERF_HIP_CHECK(hipEventRecord(xe[xn++], as_stream(stream)));
+        return SHERF_OK;
+    };
+    SHERF_RUN(mark("entry"));
     SHERF_HIP_CHECK(hipMemsetAsync(p->zero_ptr, 0, (size_t)p->zero_bytes, as_stream(stream)));
     const sherf_svox_level_ws& l0 = p->lev[0];
     hipLaunchKernelGGL(mark_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), coord, n, l0.D, l0.H, l0.W, l0.bitmap);
     SHERF_RUN(scan_level(l0, stream));
+    SHERF_RUN(mark("level0"));
     auto build_level = [&](int k, sherf_stream_t st) -> int {       // level k from level k-1 (SparseConv3d k3 s2 p1 output sites)
         const sherf_svox_level_ws& src = p->lev[k - 1];
         hipLaunchKernelGGL(mark_down_kernel, dim3(cdiv(src.cap, 256)), dim3(256), 0, as_stream(st), src.keys, src.n_rows, src.D,
                            src.H, src.W, p->lev[k].bitmap);
         return scan_level(p->lev[k], st);
     };
-    if (aux) {
+    const int xp = sherf_experiment();
+    const bool levels_inline = aux && (xp & 2);
+    if (xp & 1)
+        SHERF_RUN(sherf_svox_scatter_rows(coord, feat, n, 32, l0.D, l0.H, l0.W, l0.bitmap, l0.prefix, l0.n_rows, p->acc_fix, p->g0,
+                                          p->mult, stream));
+    if (aux && !levels_inline) {
         SHERF_HIP_CHECK(hipEventRecord(lev_ev[0], as_stream(stream)));
         SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(aux), lev_ev[0], 0));
         for (int k = 1; k < 4; ++k) {
@@ -766,9 +797,14 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
             SHERF_HIP_CHECK(hipEventRecord(lev_ev[k], as_stream(aux)));
         }
     }
+    SHERF_HOST_STAMP(xp, "levels queued");
     if (after_levels) SHERF_RUN((*after_levels)());
-    SHERF_RUN(sherf_svox_scatter_rows(coord, feat, n, 32, l0.D, l0.H, l0.W, l0.bitmap, l0.prefix, l0.n_rows, p->acc_fix, p->g0,
-                                      p->mult, stream));
+    SHERF_HOST_STAMP(xp, "scatter_rows next");
+    SHERF_GPU_STAMP(xp, as_stream(stream), "encoder stream reached scatter_rows");
+    if (!(xp & 1))
+        SHERF_RUN(sherf_svox_scatter_rows(coord, feat, n, 32, l0.D, l0.H, l0.W, l0.bitmap, l0.prefix, l0.n_rows, p->acc_fix, p->g0,
+                                          p->mult, stream));
+    SHERF_RUN(mark("rows"));
     int lev = 0, ntap = 0;
     const float* cur = p->g0;
     BnIn cur_bn{};                                      // BatchNorm of `cur` (none for the raw level-0 features)
@@ -784,7 +820,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         const sherf_svox_level_ws& src = p->lev[lev];
         const sherf_svox_level_ws& dst = p->lev[dlev];
         if (ly.down) {
-            if (aux) SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), lev_ev[dlev], 0));
+            if (aux && !levels_inline) SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), lev_ev[dlev], 0));
             else SHERF_RUN(build_level(dlev, stream));
         }
         // training: the conv leaves fixed-point sums of its output in ly.acc, resolved by its consumers' prologues.
@@ -794,6 +830,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
                                (lev == 0 && cur_bn.bnparam) ? p->mult : nullptr, ly.wt, ly.cout, (ly.down ? 1 : 0) | ((fold_half & 2) ? 1024 : 0),
                                dst.cap, ly.out, training ? ly.acc : nullptr, stream));
         if (ev && li == ev_layer) SHERF_HIP_CHECK(hipEventRecord(ev, as_stream(stream)));
+        SHERF_RUN(mark(ly.down ? "down" : "conv"));
         lev = dlev; cur = ly.out; cur_bn = bn_of(ly, dlev);
         if (ly.tap) {
             SHERF_CHECK_ARG(ntap < 3 && p->fold_mat[ntap] && p->fold_rows[ntap]);
@@ -812,6 +849,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
             ++ntap;
         }
     }
+    SHERF_HOST_STAMP(xp, "encoder queued");
     SHERF_CHECK_ARG(ntap == 3);
     if (aux) {                                          // the caller's "encoder done" event on `stream` covers aux too
         SHERF_HIP_CHECK(hipEventRecord(lev_ev[7], as_stream(aux)));

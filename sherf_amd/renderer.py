@@ -409,7 +409,10 @@ class ImportanceRenderer(nn.Module):
         cur = _SIDE_STREAMS.pop(key, None)
         if cur is None:
             # the short serial chains get dispatch priority over the ray side's big kernels
-            cur = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(2)]
+            xp = int(os.environ.get('SHERF_EXPERIMENT_STREAMS', '0'))     # (timing experiments of tools/frame_ab.py: 1 swap the pair, 2 default priority, 4 skip two queues)
+            cur = [torch.cuda.Stream(device=dev, priority=0 if xp & 2 else -1) for _ in range(4 if xp & 4 else 2)][-2:]
+            if xp & 1:
+                cur.reverse()
             while len(_SIDE_STREAMS) >= 4 * self.MAX_WORKSPACES:     # bounded like the workspaces (streams of callers long gone)
                 old = _SIDE_STREAMS.pop(next(iter(_SIDE_STREAMS)))
                 for st in old:

@@ -114,6 +114,7 @@ constexpr hipError_t hipSuccess = 0;
 // (the library's event sets live for the process: never freed here)
 typedef double* hipEvent_t;
 constexpr unsigned hipEventDisableTiming = 2;
+constexpr unsigned hipEventReleaseToDevice = 0x40000000;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0.0); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new double(0.0); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
@@ -121,6 +122,7 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
     return hipSuccess;
 }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipLaunchHostFunc(hipStream_t, void (*fn)(void*), void* arg) { fn(arg); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*b - *a); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

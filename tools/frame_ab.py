@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--arms', default='0')
     ap.add_argument('--names', default='')
     ap.add_argument('--opts', default='')
+    ap.add_argument('--exps', default='', help='one SHERF_EXPERIMENT word per arm (launch order / stream placement experiments: csrc/common.h)')
     ap.add_argument('--timeline', action='store_true', help='print the HIP-event timeline of every arm (bench.frame_timeline)')
     ap.add_argument('--rounds', type=int, default=4)
     ap.add_argument('--iters', type=int, default=20)
@@ -58,11 +59,14 @@ def main():
     groups += [''] * (len(arms) - len(groups))
     arm_opts = [{kv.split('=')[0]: ast.literal_eval(kv.split('=')[1]) for kv in g.split(',') if kv} for g in groups]
     base_opts = dict(w['opts'])
+    exps = [x for x in a.exps.split(',') if x] + ['0'] * len(arms)
 
     def select(i):
         lib.sherf_set_debug(arms[i])
+        os.environ['SHERF_EXPERIMENT'] = str(int(exps[i], 0) | (int(os.environ.get('SHERF_EXPERIMENT_BASE', '0'), 0)))
         w['opts'] = dict(base_opts, **arm_opts[i])
     lib = _lib.lib()
+    os.environ['SHERF_EXPERIMENT'] = str(int(os.environ.get('SHERF_EXPERIMENT_BASE', '0'), 0))     # (bit 2 is read at the first frame)
     for _ in range(3):
         bench.render_frame(w)                                   # calibration of `auto` + warm-up
     torch.cuda.synchronize()
