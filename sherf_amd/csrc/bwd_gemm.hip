@@ -139,6 +139,106 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float*
     }
 }
 
+// The same product for the shapes the decoder / transformer backward is made of (beta == 0, K a multiple of 16 known at compile time, rows of A
+// 16-byte aligned): a streaming kernel.  Round 5: the general kernel above loads a K-block of A right before it splits it -- 1 KiB in flight
+// per wave against the ~60 KiB per CU that HBM latency x bandwidth asks for -- and ran 314 us per [750 000, 128] x [128, 128] product where the
+// bytes (768 MB) take ~140 us and the six-product MFMA stream ~80 us.  Here a wave fetches the WHOLE next tile of A (NKB x 2 dwordx4 per lane, 16 KiB
+// per wave, 128 KiB per CU) before it starts the current tile's MFMAs; the tile loop has no per-element bounds checks (only the last tile's rows and
+// the last column tile's columns are guarded).  Same arithmetic, same order of the six products and of the K-blocks: bit-identical to the kernel above.
+template <int NT, int NKB>
+__global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
+                                                          float* __restrict__ C, int ldc, int M, int N, const float* __restrict__ bias, int act) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [NKB][NT][hi, mid, lo][64 lanes]
+    constexpr int K = 16 * NKB;
+    for (int idx = threadIdx.x; idx < NKB * NT * 64; idx += 64 * kTallWaves) {
+        const int l = idx & 63, nt = (idx >> 6) % NT, kb = idx / (64 * NT);
+        const int n = 32 * nt + (l & 31), k0 = 16 * kb + 8 * (l >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = n < N ? (transB ? B[(size_t)n * ldb + k0 + e] : B[(size_t)(k0 + e) * ldb + n]) : 0.f;
+        const Frag f = split8(v);
+        s_frag[((kb * NT + nt) * 3) * 64 + l] = f.hi;
+        s_frag[((kb * NT + nt) * 3 + 1) * 64 + l] = f.mid;
+        s_frag[((kb * NT + nt) * 3 + 2) * 64 + l] = f.lo;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int n_tiles = (M + 31) / 32, stride = gridDim.x * kTallWaves;
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && 32 * nt + i < N) ? bias[32 * nt + i] : 0.f;
+    const bool relu = act == 1;
+    // A in two halves of the K-blocks: while a half is multiplied the other half (of this tile, then of the next) is in flight -- 8 KiB per wave, 64 KiB per CU.
+    // (The whole next tile in registers -- 128 of them beside 64 accumulators -- spilled.)
+    constexpr int HA = (NKB + 1) / 2, HB = NKB - HA;
+    float4 b0[HA][2], b1[HB > 0 ? HB : 1][2];
+    auto rowp = [&](int t) {
+        const int row = min(t * 32 + i, M - 1);               // (rows past M repeat the last one: computed, never stored)
+        return reinterpret_cast<const float4*>(A + (size_t)row * lda + 8 * h);
+    };
+    int tile = blockIdx.x * kTallWaves + wave;
+    if (tile < n_tiles) {
+        const float4* p = rowp(tile);
+#pragma unroll
+        for (int kb = 0; kb < HA; ++kb) { b0[kb][0] = p[4 * kb]; b0[kb][1] = p[4 * kb + 1]; }
+    }
+    for (; tile < n_tiles; tile += stride) {
+        {
+            const float4* p = rowp(tile);
+#pragma unroll
+            for (int kb = 0; kb < HB; ++kb) { b1[kb][0] = p[4 * (HA + kb)]; b1[kb][1] = p[4 * (HA + kb) + 1]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        auto block = [&](const float4 (&q)[2], int kb) {
+            const float v[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+            const Frag a = split8(v);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4* f = s_frag + ((kb * NT + nt) * 3) * 64 + lane;
+                acc[nt] = mfma6(a, Frag{f[0], f[64], f[128]}, acc[nt]);
+            }
+        };
+#pragma unroll
+        for (int kb = 0; kb < HA; ++kb) block(b0[kb], kb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + stride < n_tiles) {
+            const float4* p = rowp(tile + stride);
+#pragma unroll
+            for (int kb = 0; kb < HA; ++kb) { b0[kb][0] = p[4 * kb]; b0[kb][1] = p[4 * kb + 1]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) block(b1[kb], HA + kb);
+        const bool full = tile * 32 + 32 <= M;                  // wave-uniform
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cc = 32 * nt + i;
+            if (cc < N) {
+                float* cp = C + (size_t)(tile * 32 + 4 * h) * ldc + cc;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[nt][r] + bv[nt];
+                        cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2);
+                        const float v = acc[nt][r] + bv[nt];
+                        if (tile * 32 + 4 * h + dr < M) cp[(size_t)dr * ldc] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // wgrad: C[M,N] += A[Kbig,M]^T . B[Kbig,N]   (C pre-scaled by beta by the caller-side kernel below); M <= 256, N <= 32 NT
 // ---------------------------------------------------------------------------------------------------------------
@@ -235,7 +335,7 @@ __global__ void bias_act_tail_kernel(float* __restrict__ y, int ldy, const float
 
 }  // namespace
 
-static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA, 2 = weight-gradient MFMA, 0 = plain
+static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA (general), 3 = tall MFMA (streaming), 2 = weight-gradient MFMA, 0 = plain
 extern "C" int sherf_bwd_gemm_last_path() { return g_last_path; }
 
 static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -264,18 +364,33 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
     const int nt_fit = min(8, (int)((156 * 1024) / ((size_t)nkb * 3072)));
     if (!transA && nt_fit >= 1 && NT <= 4 * nt_fit) {
         const int tiles = (M + 31) / 32, grid = min((tiles + kTallWaves - 1) / kTallWaves, n_cus());
+        bool streamed = false;
         for (int n0 = 0; n0 < N; n0 += 32 * nt_fit) {
             const int Ns = min(N - n0, 32 * nt_fit), NTs = (Ns + 31) / 32;
             const size_t smem = (size_t)nkb * NTs * 3072;
             const float* Bs = transB ? B + (size_t)n0 * ldb : B + n0;
             float* Cs = C + n0;
+            // the streaming kernel for the shapes of the path (every (column tiles, K-blocks) pair the decoder / transformer backward produces)
+            if (beta == 0.f && K % 16 == 0 && lda % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && !(sherf_experiment() & 64)) {      // (SHERF_EXPERIMENT bit 6: the general kernel, A/B runs)
+                bool hit = true;
+#define SHERF_STREAM(n, k) case (n) * 16 + (k): \
+                if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_stream_kernel<n, k>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+                hipLaunchKernelGGL((tall_stream_kernel<n, k>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, bias ? bias + n0 : nullptr, act); break
+                switch (NTs * 16 + nkb) {
+                    SHERF_STREAM(4, 8); SHERF_STREAM(3, 8); SHERF_STREAM(6, 8); SHERF_STREAM(1, 8); SHERF_STREAM(5, 2); SHERF_STREAM(1, 3);
+                    SHERF_STREAM(1, 2); SHERF_STREAM(2, 2); SHERF_STREAM(1, 9); SHERF_STREAM(6, 4); SHERF_STREAM(2, 8);
+                    default: hit = false;
+                }
+#undef SHERF_STREAM
+                if (hit) { streamed = true; continue; }
+            }
 #define SHERF_TALL(n) case n: \
             if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_gemm_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
             hipLaunchKernelGGL((tall_gemm_kernel<n>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, beta, bias ? bias + n0 : nullptr, act); break
             switch (NTs) { SHERF_TALL(1); SHERF_TALL(2); SHERF_TALL(3); SHERF_TALL(4); SHERF_TALL(5); SHERF_TALL(6); SHERF_TALL(7); SHERF_TALL(8); }
 #undef SHERF_TALL
         }
-        g_last_path = 1;
+        g_last_path = streamed ? 3 : 1;
         SHERF_LAUNCH_CHECK();
     }
     const int MT = (M + 31) / 32;

@@ -57,6 +57,43 @@ def _same(a, b, tol=1e-5):
     assert d <= tol * float(a.tensor().abs().max()) + 1e-12, d
 
 
+def test_streaming_tall_gemm_is_the_general_kernel_bit_for_bit(cpu_lib, monkeypatch):
+    """Round 5: every (column tiles, K-blocks) shape of the decoder / transformer backward with beta == 0 and 16-byte aligned rows takes
+    tall_stream_kernel (whole half-tiles of A prefetched, no per-element bounds checks): same six products in the same order -> the same bits
+    as the general kernel (SHERF_EXPERIMENT bit 6 selects it), ragged last tile, ragged last column tile, bias + ReLU epilogue, strided C."""
+    h = CpuKernelOps(cpu_lib, monkeypatch)
+    cpu_lib.sherf_bwd_gemm_last_path.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(5)
+
+    def mat(r, c, ld):
+        return Mat(torch.randn(r * ld, generator=g) * 1e-2, r, c, ld)
+    #          K    N   tB  rows
+    cases = [(128, 128, 1, 301), (128, 128, 0, 64), (128, 71, 0, 95), (128, 199, 0, 70), (128, 64, 1, 33), (64, 187, 0, 129), (32, 144, 1, 200), (48, 32, 1, 31),
+             (32, 32, 1, 97), (32, 48, 0, 66), (144, 32, 0, 130), (128, 3, 1, 40)]
+    for K, N, tB, rows in cases:
+        A = mat(rows, K, K + 4)
+        B = mat(N, K, K + 1) if tB else mat(K, N, N + 2)
+        bias = mat(1, N, N)
+        for act, with_bias in ((1, True), (0, False)):
+            outs = []
+            for general in (1, 0):
+                monkeypatch.setenv('SHERF_EXPERIMENT', '64' if general else '0')
+                C = Mat(torch.full((rows * (N + 5),), 7.0), rows, N, N + 5)
+                h.gemm_bias_act(0, tB, A, B, C, bias if with_bias else None, act)
+                assert cpu_lib.sherf_bwd_gemm_last_path() == (1 if general else 3), (K, N, tB, general)
+                outs.append(C.buf.clone())
+            assert torch.equal(outs[0], outs[1]), (K, N, tB, rows, act)
+            ref = A.tensor().double() @ (B.tensor().double().t() if tB else B.tensor().double())
+            if with_bias:
+                ref = ref + bias.tensor().double()
+            if act:
+                ref = ref.clamp(min=0)
+            got = torch.as_strided(outs[1], (rows, N), (N + 5, 1)).double()
+            assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-12
+            assert bool((torch.as_strided(outs[1], (rows, 5), (N + 5, 1), N) == 7.0).all())          # nothing written past the N columns
+    monkeypatch.setenv('SHERF_EXPERIMENT', '0')
+
+
 def test_dense_entry_points_match_their_specification(cpu_lib, monkeypatch):
     e, h = EmuOps(), CpuKernelOps(cpu_lib, monkeypatch)
     n = 70
