@@ -69,7 +69,8 @@ int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh, const flo
                      float* dw, float* db, sherf_stream_t stream);
 
 /* 3-token, 3-head x 16 attention core on qkv[n][3 tok][144] (q | k | v, each 3 heads x 16; renderer.py:949-977):
- * fwd: att[n][3 head][3][3] = softmax(q k^T / 4), o[n][3 tok][48]; bwd: d_o -> d_qkv. */
+ * fwd: att[n][3 head][3][3] = softmax(q k^T / 4), o[n][3 tok][48]; bwd: d_o -> d_qkv.  qkv, o, d_o, d_qkv: 16-byte aligned
+ * (a head's 16 floats travel as four dwordx4 accesses; SHERF_EINVAL otherwise). */
 int sherf_bwd_attn_fwd(const float* qkv, int64_t n, float* att, float* o, sherf_stream_t stream);
 int sherf_bwd_attn_bwd(const float* qkv, const float* att, const float* d_o, int64_t n, float* d_qkv, sherf_stream_t stream);
 

@@ -34,6 +34,12 @@ class Mat:
         return Mat(torch.empty(int(rows) * int(cols), dtype=torch.float32, device=device), rows, cols)
 
     @staticmethod
+    def empty_ld(rows, cols, ld, device):
+        """Uninitialised with padded rows (ld >= cols floats per row; the padding is never written nor read as data): a GEMM operand whose rows are
+        16-byte aligned and hold whole 16-float K-blocks takes the streaming kernel (csrc/bwd_gemm.hip)."""
+        return Mat(torch.empty(int(rows) * int(ld), dtype=torch.float32, device=device), rows, cols, ld)
+
+    @staticmethod
     def of(t):
         """A contiguous 2-D (or 1-D -> one row) parameter tensor as a Mat (no copy when already fp32 contiguous)."""
         t = t.detach().to(torch.float32).contiguous()
@@ -176,6 +182,7 @@ def dense_backward(ops, state, tok, ext, d_sample):
     n, dev = tok.rows, tok.buf.device
     Z = lambda r, c: Mat.zeros(r, c, dev)
     E = lambda r, c: Mat.empty(r, c, dev)                           # (every E below is written in full before it is read)
+    EP = lambda r, c: Mat.empty_ld(r, c, (c + 15) // 16 * 16, dev)   # rows padded to whole 16-float blocks (K = 71, 199, 187 operands)
     P = lambda name: Mat.of(state[name])
     grads = {}
 
@@ -229,12 +236,12 @@ def dense_backward(ops, state, tok, ext, d_sample):
     z96 = z.as_rows(n, 96)                                          # [n, slot 0 | slot 1 | slot 2]
     # ---- decoder ----
     d = 'decoder.'
-    x0 = E(n, 71)
+    x0 = EP(n, 71)
     ops.pe(ext.colslice(0, 3), 6, x0.colslice(0, 39))
     ops.copy2d(x0.colslice(39, 71), z96.colslice(0, 32))
     ins, hs = [], []
     h = x0
-    cat5 = E(n, 199)
+    cat5 = EP(n, 199)
     for i in range(8):
         ins.append(h)
         out = cat5.colslice(71, 199) if i == 4 else None            # layer 4 writes straight into cat([x0, h4])
@@ -245,7 +252,7 @@ def dense_backward(ops, state, tok, ext, d_sample):
             ops.copy2d(cat5.colslice(0, 71), x0)
             h = cat5
     h7 = hs[7]
-    vin = E(n, 187)
+    vin = EP(n, 187)
     lin_fwd(h7, d + 'feature_linear', 0, vin.colslice(0, 128))
     ops.pe(ext.colslice(3, 6), 4, vin.colslice(128, 155))
     ops.copy2d(vin.colslice(155, 187), z96.colslice(32, 64))
@@ -260,7 +267,7 @@ def dense_backward(ops, state, tok, ext, d_sample):
     d_g = lin_bwd(d_lin, g, d + 'rgb_linear')
     db_v = Z(1, g.cols)
     ops.relu_mask_colsum(d_g, g, db_v)
-    d_vin = lin_bwd(d_g, vin, d + 'views_linear', db=db_v)
+    d_vin = lin_bwd(d_g, vin, d + 'views_linear', db=db_v, d_in=EP(n, 187))       # (its first 128 columns are the next product's A: aligned rows)
     d_sigma = d_sample.colslice(3, 4)
     d_h = lin_bwd(d_vin.colslice(0, 128), h7, d + 'feature_linear')
     lin_bwd(d_sigma, h7, d + 'alpha_linear', d_in=d_h, beta=1.0)

@@ -207,6 +207,19 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// sixteen consecutive floats of a 64-byte aligned group (a head's slice of q / k / v / o: rows of 432 / 144 floats, offsets multiples of 16) as
+// four dwordx4 accesses: the scalar form cost 200 dword loads per thread, every one touching 64 different lines (round 5)
+__device__ __forceinline__ void ld16(const float* __restrict__ p, float (&d)[16]) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float4 v = q[j]; d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w; }
+}
+__device__ __forceinline__ void st16(float* __restrict__ p, const float (&d)[16]) {
+    float4* q = reinterpret_cast<float4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = make_float4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]);
+}
+
 // one thread per (sample, head): q_i = qkv[n][i][16h..], k_j = qkv[n][j][48 + 16h..], v_j = qkv[n][j][96 + 16h..]
 __global__ void attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float* __restrict__ att, float* __restrict__ o) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -216,9 +229,7 @@ __global__ void attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float*
     const float* base = qkv + s * 432 + 16 * h;
     float q[3][16], k[3][16], v[3][16];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int d = 0; d < 16; ++d) { q[t][d] = base[t * 144 + d]; k[t][d] = base[t * 144 + 48 + d]; v[t][d] = base[t * 144 + 96 + d]; }
+    for (int t = 0; t < 3; ++t) { ld16(base + t * 144, q[t]); ld16(base + t * 144 + 48, k[t]); ld16(base + t * 144 + 96, v[t]); }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float sc[3], m = -3.0e38f;
@@ -235,8 +246,10 @@ __global__ void attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float*
         e0 *= iv; e1 *= iv; e2 *= iv;
         float* ap = att + ((s * 3 + h) * 3 + a) * 3;
         ap[0] = e0; ap[1] = e1; ap[2] = e2;
+        float ov[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[(s * 3 + a) * 48 + 16 * h + e] = e0 * v[0][e] + e1 * v[1][e] + e2 * v[2][e];
+        for (int e = 0; e < 16; ++e) ov[e] = e0 * v[0][e] + e1 * v[1][e] + e2 * v[2][e];
+        st16(o + (s * 3 + a) * 48 + 16 * h, ov);
     }
 }
 
@@ -250,11 +263,8 @@ __global__ void attn_bwd_kernel(const float* __restrict__ qkv, const float* __re
     float q[3][16], k[3][16], v[3][16], go[3][16], A[3][3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            q[t][d] = base[t * 144 + d]; k[t][d] = base[t * 144 + 48 + d]; v[t][d] = base[t * 144 + 96 + d];
-            go[t][d] = d_o[(s * 3 + t) * 48 + 16 * h + d];
-        }
+        ld16(base + t * 144, q[t]); ld16(base + t * 144 + 48, k[t]); ld16(base + t * 144 + 96, v[t]);
+        ld16(d_o + (s * 3 + t) * 48 + 16 * h, go[t]);
 #pragma unroll
         for (int b = 0; b < 3; ++b) A[t][b] = att[((s * 3 + h) * 3 + t) * 3 + b];
     }
@@ -275,13 +285,16 @@ __global__ void attn_bwd_kernel(const float* __restrict__ qkv, const float* __re
     }
     float* ob = d_qkv + s * 432 + 16 * h;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t) {
+        float dq[16], dk[16], dv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            ob[t * 144 + e] = dS[t][0] * k[0][e] + dS[t][1] * k[1][e] + dS[t][2] * k[2][e];                    // d_q[t]
-            ob[t * 144 + 48 + e] = dS[0][t] * q[0][e] + dS[1][t] * q[1][e] + dS[2][t] * q[2][e];               // d_k[t]
-            ob[t * 144 + 96 + e] = A[0][t] * go[0][e] + A[1][t] * go[1][e] + A[2][t] * go[2][e];               // d_v[t]
+            dq[e] = dS[t][0] * k[0][e] + dS[t][1] * k[1][e] + dS[t][2] * k[2][e];                    // d_q[t]
+            dk[e] = dS[0][t] * q[0][e] + dS[1][t] * q[1][e] + dS[2][t] * q[2][e];                    // d_k[t]
+            dv[e] = A[0][t] * go[0][e] + A[1][t] * go[1][e] + A[2][t] * go[2][e];                    // d_v[t]
         }
+        st16(ob + t * 144, dq); st16(ob + t * 144 + 48, dk); st16(ob + t * 144 + 96, dv);
+    }
 }
 
 __global__ void gelu_fwd_kernel(const float* __restrict__ u, int64_t count, float* __restrict__ ge) {
@@ -442,13 +455,13 @@ extern "C" int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh
 }
 
 extern "C" int sherf_bwd_attn_fwd(const float* qkv, int64_t n, float* att, float* o, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(qkv && att && o && n > 0);
+    SHERF_CHECK_ARG(qkv && att && o && n > 0 && ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(o)) & 15) == 0);
     hipLaunchKernelGGL(attn_fwd_kernel, SHERF_GRID(n * 3), 0, as_stream(stream), qkv, n, att, o);
     SHERF_LAUNCH_CHECK();
 }
 
 extern "C" int sherf_bwd_attn_bwd(const float* qkv, const float* att, const float* d_o, int64_t n, float* d_qkv, sherf_stream_t stream) {
-    SHERF_CHECK_ARG(qkv && att && d_o && d_qkv && n > 0);
+    SHERF_CHECK_ARG(qkv && att && d_o && d_qkv && n > 0 && ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(d_o) | reinterpret_cast<size_t>(d_qkv)) & 15) == 0);
     hipLaunchKernelGGL(attn_bwd_kernel, SHERF_GRID(n * 3), 0, as_stream(stream), qkv, att, d_o, n, d_qkv);
     SHERF_LAUNCH_CHECK();
 }

@@ -139,23 +139,24 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float*
     }
 }
 
-// The same product for the shapes the decoder / transformer backward is made of (beta == 0, K a multiple of 16 known at compile time, rows of A
-// 16-byte aligned): a streaming kernel.  Round 5: the general kernel above loads a K-block of A right before it splits it -- 1 KiB in flight
+// The same product for the shapes the decoder / transformer backward is made of (beta == 0, the number of 16-wide K-blocks known at compile time,
+// rows of A 16-byte aligned and padded to whole K-blocks): a streaming kernel.  Round 5: the general kernel above loads a K-block of A right before it splits it -- 1 KiB in flight
 // per wave against the ~60 KiB per CU that HBM latency x bandwidth asks for -- and ran 314 us per [750 000, 128] x [128, 128] product where the
 // bytes (768 MB) take ~140 us and the six-product MFMA stream ~80 us.  Here a wave fetches the WHOLE next tile of A (NKB x 2 dwordx4 per lane, 16 KiB
 // per wave, 128 KiB per CU) before it starts the current tile's MFMAs; the tile loop has no per-element bounds checks (only the last tile's rows and
 // the last column tile's columns are guarded).  Same arithmetic, same order of the six products and of the K-blocks: bit-identical to the kernel above.
 template <int NT, int NKB>
 __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
-                                                          float* __restrict__ C, int ldc, int M, int N, const float* __restrict__ bias, int act) {
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, const float* __restrict__ bias, int act) {
+    // K in (16 (NKB - 1), 16 NKB]: a row of A is read in whole 16-float blocks (the launcher checks lda >= 16 NKB: the tail of the last block lies in
+    // the row's own padding) and the elements past K are zeroed in registers (the padding is never written: it may hold anything, NaN included)
     extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [NKB][NT][hi, mid, lo][64 lanes]
-    constexpr int K = 16 * NKB;
     for (int idx = threadIdx.x; idx < NKB * NT * 64; idx += 64 * kTallWaves) {
         const int l = idx & 63, nt = (idx >> 6) % NT, kb = idx / (64 * NT);
         const int n = 32 * nt + (l & 31), k0 = 16 * kb + 8 * (l >> 5);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = n < N ? (transB ? B[(size_t)n * ldb + k0 + e] : B[(size_t)(k0 + e) * ldb + n]) : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = (n < N && k0 + e < K) ? (transB ? B[(size_t)n * ldb + k0 + e] : B[(size_t)(k0 + e) * ldb + n]) : 0.f;
         const Frag f = split8(v);
         s_frag[((kb * NT + nt) * 3) * 64 + l] = f.hi;
         s_frag[((kb * NT + nt) * 3 + 1) * 64 + l] = f.mid;
@@ -195,7 +196,11 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         auto block = [&](const float4 (&q)[2], int kb) {
-            const float v[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+            float v[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+            if (kb == NKB - 1 && K < 16 * NKB) {                 // (compile-time position, wave-uniform condition)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 16 * kb + 8 * h + e < K ? v[e] : 0.f;
+            }
             const Frag a = split8(v);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -243,6 +248,9 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const floa
 // wgrad: C[M,N] += A[Kbig,M]^T . B[Kbig,N]   (C pre-scaled by beta by the caller-side kernel below); M <= 256, N <= 32 NT
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSlab = 512;          // rows of the huge dimension per workgroup visit
+// steps of raw operand rows a wave of the round-5 kernels keeps in flight: as many as fit under the 63 outstanding loads the wave's counter can tell apart
+// (four stages of 16 dword loads made the compiler wait for the oldest stage at every refill)
+constexpr int wg_ring(int loads_per_stage) { return 56 / loads_per_stage < 1 ? 1 : 56 / loads_per_stage > 4 ? 4 : 56 / loads_per_stage; }
 
 template <int NT, int MTW>          // MTW = row tiles of C per wave (the 4 waves take tiles w, w + 4)
 __global__ void __launch_bounds__(256) wgrad_gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
@@ -303,6 +311,177 @@ __global__ void __launch_bounds__(256) wgrad_gemm_kernel(const float* __restrict
     }
 }
 
+// Round 5: the kernel above has every one of its four waves split ALL of B's column tiles for the one row tile it owns -- at 128 x 128 that is
+// five operand splits (1 120 VALU cycles) per 24 MFMAs (768 cycles) per wave and 16-row step, four times the same B work per workgroup -- and leaves
+// waves idle when C has fewer than four row tiles.  Two kernels replace it on the shapes of the path (same six products per term, fp32 atomics into C):
+//   wgrad_shared_kernel<MT, NT> (two or more row tiles): wave w owns row tiles w, w + 4; each B column tile is split ONCE per workgroup (by wave
+//     nt % 4) into a double-buffered LDS image every wave reads (one barrier per step); a wave's raw operand rows of step s + 1 are in flight while
+//     step s is multiplied;
+//   wgrad_solo_kernel<NT> (one row tile: M <= 32): the four waves take different 16-row steps of the slab (no sharing, no barrier).
+// an operand element that is loaded unconditionally (clamped address) and zeroed by its bit mask when its row / column is not real: with
+// `ok ? load : 0` the compiler branched around every single load and waited for it before the next (706 us per 128 x 128)
+__device__ __forceinline__ float masked(float v, uint32_t m) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & m); }
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) wgrad_shared_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                           float* __restrict__ C, int ldc, int M, int N, int Kbig) {
+    constexpr int MTW = (MT + 3) / 4, BW = (NT + 3) / 4;             // row tiles / B column tiles (to split) per wave
+    constexpr int kWgRing = wg_ring(8 * (MTW + BW));
+    __shared__ __attribute__((aligned(16))) u32x4 s_b[2][NT][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    f32x16 acc[MTW][NT];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][nt][r] = 0.f;
+    // this lane's column of every operand tile it loads, clamped into the matrix (loads stay in bounds; the value is zeroed when the column is not real)
+    int am[MTW], bn[BW];
+    bool aok[MTW], bok[BW];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a) { const int m = 32 * (wave + 4 * a) + i; aok[a] = wave + 4 * a < MT && m < M; am[a] = aok[a] ? m : 0; }
+#pragma unroll
+    for (int b = 0; b < BW; ++b) { const int n = 32 * (wave + 4 * b) + i; bok[b] = wave + 4 * b < NT && n < N; bn[b] = bok[b] ? n : 0; }
+    uint32_t amask[MTW], bmask[BW];
+#pragma unroll
+    for (int a = 0; a < MTW; ++a) amask[a] = aok[a] ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int b = 0; b < BW; ++b) bmask[b] = bok[b] ? 0xFFFFFFFFu : 0u;
+    // raw operand rows of the next kWgRing steps: dword loads (a lane's 8 K-values are 8 different ROWS of memory) are latency-bound one step ahead
+    // (measured: 676 us per 128 x 128 against round 2's 325): several steps ahead (wg_ring)
+    float ra[kWgRing][MTW][8], rb[kWgRing][BW][8];
+    auto fetch = [&](float (&da)[MTW][8], float (&db)[BW][8], int r0, int r_end) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = r0 + 8 * h + e;
+            const bool in = r < r_end;
+            const size_t rr = in ? r : r_end - 1;
+#pragma unroll
+            for (int a = 0; a < MTW; ++a) da[a][e] = A[rr * lda + am[a]];          // raw: the masks are applied where the value is USED (applied here,
+#pragma unroll
+            for (int b = 0; b < BW; ++b) db[b][e] = B[rr * ldb + bn[b]];          // every load is waited for on the spot)
+        }
+    };
+    auto clean = [&](float (&v)[8], uint32_t cm, int rs, int r_end) {             // zero what is not a real row / column of the operand
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = masked(v[e], (rs + 8 * h + e < r_end ? 0xFFFFFFFFu : 0u) & cm);
+    };
+    int buf = 0;
+    for (int slab = blockIdx.x; slab * kSlab < Kbig; slab += gridDim.x) {
+        const int r_end = min(Kbig, (slab + 1) * kSlab);
+#pragma unroll
+        for (int d = 0; d < kWgRing; ++d)
+            if (slab * kSlab + 16 * d < r_end) fetch(ra[d], rb[d], slab * kSlab + 16 * d, r_end);
+        for (int r0 = slab * kSlab; r0 < r_end; r0 += 16 * kWgRing) {
+#pragma unroll
+            for (int d = 0; d < kWgRing; ++d) {
+                const int rs = r0 + 16 * d;
+                if (rs >= r_end) break;                              // (uniform over the workgroup: the barrier below stays convergent)
+                Frag af[MTW];
+#pragma unroll
+                for (int a = 0; a < MTW; ++a) { clean(ra[d][a], amask[a], rs, r_end); af[a] = split8(ra[d][a]); }
+#pragma unroll
+                for (int b = 0; b < BW; ++b)
+                    if (wave + 4 * b < NT) {                         // wave-uniform
+                        clean(rb[d][b], bmask[b], rs, r_end);
+                        const Frag f = split8(rb[d][b]);
+                        s_b[buf][wave + 4 * b][0][lane] = f.hi; s_b[buf][wave + 4 * b][1][lane] = f.mid; s_b[buf][wave + 4 * b][2][lane] = f.lo;
+                    }
+                if (rs + 16 * kWgRing < r_end) fetch(ra[d], rb[d], rs + 16 * kWgRing, r_end);      // refill this stage
+                __syncthreads();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const Frag bf{s_b[buf][nt][0][lane], s_b[buf][nt][1][lane], s_b[buf][nt][2][lane]};
+#pragma unroll
+                    for (int a = 0; a < MTW; ++a)
+                        if (wave + 4 * a < MT) acc[a][nt] = mfma6(af[a], bf, acc[a][nt]);
+                }
+                buf ^= 1;     // (the image of step s is rewritten at step s + 2, behind the barrier of step s + 1 every reader of step s has passed)
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MTW; ++a) {
+        const int mt = wave + 4 * a;
+        if (mt >= MT) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = 32 * mt + acc_row(r, h), cc = 32 * nt + i;
+                if (mm < M && cc < N && acc[a][nt][r] != 0.f) unsafeAtomicAdd(C + (size_t)mm * ldc + cc, acc[a][nt][r]);
+            }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) wgrad_solo_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int N, int Kbig) {
+    constexpr int kWgRing = wg_ring(8 * (1 + NT));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const bool aok = i < M;
+    const int am = aok ? i : 0;
+    int bn[NT];
+    bool bok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { const int n = 32 * nt + i; bok[nt] = n < N; bn[nt] = bok[nt] ? n : 0; }
+    const uint32_t amask = aok ? 0xFFFFFFFFu : 0u;
+    uint32_t bmask[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bmask[nt] = bok[nt] ? 0xFFFFFFFFu : 0u;
+    float ra[kWgRing][8], rb[kWgRing][NT][8];
+    auto fetch = [&](float (&da)[8], float (&db)[NT][8], int r0, int r_end) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = r0 + 8 * h + e;
+            const bool in = r < r_end;
+            const size_t rr = in ? r : r_end - 1;
+            da[e] = A[rr * lda + am];                                 // raw (masked where used, see wgrad_shared_kernel)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) db[nt][e] = B[rr * ldb + bn[nt]];
+        }
+    };
+    for (int slab = blockIdx.x; slab * kSlab < Kbig; slab += gridDim.x) {
+        const int r_end = min(Kbig, (slab + 1) * kSlab);
+        const int rw = slab * kSlab + 16 * wave;                     // this wave's steps: rw, rw + 64, ...
+#pragma unroll
+        for (int d = 0; d < kWgRing; ++d)
+            if (rw + 64 * d < r_end) fetch(ra[d], rb[d], rw + 64 * d, r_end);
+        for (int r0 = rw; r0 < r_end; r0 += 64 * kWgRing) {
+#pragma unroll
+            for (int d = 0; d < kWgRing; ++d) {
+                const int rs = r0 + 64 * d;
+                if (rs >= r_end) break;
+                auto clean = [&](float (&v)[8], uint32_t cm) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = masked(v[e], (rs + 8 * h + e < r_end ? 0xFFFFFFFFu : 0u) & cm);
+                };
+                clean(ra[d], amask);
+                const Frag af = split8(ra[d]);
+                Frag bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { clean(rb[d][nt], bmask[nt]); bf[nt] = split8(rb[d][nt]); }
+                if (rs + 64 * kWgRing < r_end) fetch(ra[d], rb[d], rs + 64 * kWgRing, r_end);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma6(af, bf[nt], acc[nt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = acc_row(r, h), cc = 32 * nt + i;
+            if (mm < M && cc < N && acc[nt][r] != 0.f) unsafeAtomicAdd(C + (size_t)mm * ldc + cc, acc[nt][r]);
+        }
+}
+
 __global__ void scale_kernel(float* __restrict__ C, int ldc, int M, int N, float beta) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= M * N) return;
@@ -335,7 +514,7 @@ __global__ void bias_act_tail_kernel(float* __restrict__ y, int ldy, const float
 
 }  // namespace
 
-static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA (general), 3 = tall MFMA (streaming), 2 = weight-gradient MFMA, 0 = plain
+static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA (general), 3 = tall MFMA (streaming), 2 = weight-gradient MFMA (round 2's kernel), 4 = weight-gradient MFMA (shared-B / solo kernels), 0 = plain
 extern "C" int sherf_bwd_gemm_last_path() { return g_last_path; }
 
 static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -371,14 +550,15 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
             const float* Bs = transB ? B + (size_t)n0 * ldb : B + n0;
             float* Cs = C + n0;
             // the streaming kernel for the shapes of the path (every (column tiles, K-blocks) pair the decoder / transformer backward produces)
-            if (beta == 0.f && K % 16 == 0 && lda % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && !(sherf_experiment() & 64)) {      // (SHERF_EXPERIMENT bit 6: the general kernel, A/B runs)
+            if (beta == 0.f && lda >= 16 * nkb && lda % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && !(sherf_experiment() & 64)) {      // (SHERF_EXPERIMENT bit 6: the general kernel, A/B runs)
                 bool hit = true;
 #define SHERF_STREAM(n, k) case (n) * 16 + (k): \
                 if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_stream_kernel<n, k>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-                hipLaunchKernelGGL((tall_stream_kernel<n, k>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, bias ? bias + n0 : nullptr, act); break
+                hipLaunchKernelGGL((tall_stream_kernel<n, k>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, bias ? bias + n0 : nullptr, act); break
                 switch (NTs * 16 + nkb) {
                     SHERF_STREAM(4, 8); SHERF_STREAM(3, 8); SHERF_STREAM(6, 8); SHERF_STREAM(1, 8); SHERF_STREAM(5, 2); SHERF_STREAM(1, 3);
                     SHERF_STREAM(1, 2); SHERF_STREAM(2, 2); SHERF_STREAM(1, 9); SHERF_STREAM(6, 4); SHERF_STREAM(2, 8);
+                    SHERF_STREAM(4, 5); SHERF_STREAM(4, 13); SHERF_STREAM(2, 12);          // K = 71, 199, 187 (rows padded to whole blocks by the caller)
                     default: hit = false;
                 }
 #undef SHERF_STREAM
@@ -397,6 +577,24 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
     if (transA && !transB && NT <= 8 && MT <= 8 && ((MT + 3) / 4) * NT <= 8) {
         if (beta != 1.f) hipLaunchKernelGGL(scale_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, C, ldc, M, N, beta);
         const int slabs = (K + kSlab - 1) / kSlab, grid = min(slabs, 2 * n_cus());
+        // round 5: B split once per workgroup / the waves on different steps, for the (row tiles, column tiles) pairs of the path (SHERF_EXPERIMENT bit 7: the old kernel)
+        if (!(sherf_experiment() & 128)) {
+            bool hit = true;
+#define SHERF_WS(m, n) case (m) * 16 + (n): hipLaunchKernelGGL((wgrad_shared_kernel<m, n>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K); break
+#define SHERF_WO(n) case 16 + (n): hipLaunchKernelGGL((wgrad_solo_kernel<n>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K); break
+            switch (MT * 16 + NT) {
+                SHERF_WS(4, 4); SHERF_WS(4, 3); SHERF_WS(4, 7); SHERF_WS(2, 6); SHERF_WS(5, 1);
+                SHERF_WO(1); SHERF_WO(2); SHERF_WO(4);
+                default: hit = false;
+            }
+#undef SHERF_WS
+#undef SHERF_WO
+            if (hit) {
+                g_last_path = 4;
+                if (bias || act) hipLaunchKernelGGL(bias_act_tail_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, st, C, ldc, bias, (int64_t)M, N, act);
+                SHERF_LAUNCH_CHECK();
+            }
+        }
 #define SHERF_WG(n, w) hipLaunchKernelGGL((wgrad_gemm_kernel<n, w>), dim3(grid), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K)
 #define SHERF_WGN(n) case n: if (MT <= 4) SHERF_WG(n, 1); else SHERF_WG(n, 2); break
         switch (NT) {

@@ -43,13 +43,13 @@ def test_composite_backward_kernel(cfg):
 
 
 # ---- every entry point of include/sherf_hip_bwd.h against its torch emulation (tests/bwd_emulator.py) on random data ----
-def _pair(rows, cols, ld=None, seed=0):
+def _pair(rows, cols, ld=None, seed=0, off=3):
     """The same random matrix as a CPU Mat and a GPU Mat (with padding columns when ld > cols)."""
     from sherf_amd.backward_dense import Mat
     ld = ld or cols
     g = torch.Generator().manual_seed(seed)
     buf = torch.randn(rows * ld + 7, generator=g)
-    return Mat(buf.clone(), rows, cols, ld, 3), Mat(buf.cuda(), rows, cols, ld, 3)
+    return Mat(buf.clone(), rows, cols, ld, off), Mat(buf.cuda(), rows, cols, ld, off)
 
 
 def _same(a, b, tol=1e-5):
@@ -124,11 +124,11 @@ def test_bwd_elementwise_kernels():
     for a, b in zip(res_c, res_g):
         _same(a, b, 1e-4)
     # attention core forward / backward
-    q_c, q_g = _pair(n, 432, seed=13)
+    q_c, q_g = _pair(n, 432, seed=13, off=4)           # (the attention kernels take 16-byte aligned operands)
     a_c, a_g = Mat(torch.zeros(n * 27), n, 27), Mat(torch.zeros(n * 27).cuda(), n, 27)
     o_c, o_g = Mat(torch.zeros(n * 144), n, 144), Mat(torch.zeros(n * 144).cuda(), n, 144)
     e.attn_fwd(q_c, a_c, o_c); h.attn_fwd(q_g, a_g, o_g); _same(a_c, a_g); _same(o_c, o_g)
-    go_c, go_g = _pair(n, 144, seed=14)
+    go_c, go_g = _pair(n, 144, seed=14, off=0)
     dq_c, dq_g = Mat(torch.zeros(n * 432), n, 432), Mat(torch.zeros(n * 432).cuda(), n, 432)
     e.attn_bwd(q_c, a_c, go_c, dq_c); h.attn_bwd(q_g, a_g, go_g, dq_g); _same(dq_c, dq_g, 1e-4)
     # GELU / rgb head

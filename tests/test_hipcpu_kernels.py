@@ -46,10 +46,10 @@ class CpuKernelOps(HipOps):
         return ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)
 
 
-def _pair(rows, cols, ld=None, seed=0):
+def _pair(rows, cols, ld=None, seed=0, off=3):
     ld = ld or cols
     buf = torch.randn(rows * ld + 7, generator=torch.Generator().manual_seed(seed))
-    return Mat(buf.clone(), rows, cols, ld, 3), Mat(buf.clone(), rows, cols, ld, 3)
+    return Mat(buf.clone(), rows, cols, ld, off), Mat(buf.clone(), rows, cols, ld, off)
 
 
 def _same(a, b, tol=1e-5):
@@ -69,9 +69,12 @@ def test_streaming_tall_gemm_is_the_general_kernel_bit_for_bit(cpu_lib, monkeypa
         return Mat(torch.randn(r * ld, generator=g) * 1e-2, r, c, ld)
     #          K    N   tB  rows
     cases = [(128, 128, 1, 301), (128, 128, 0, 64), (128, 71, 0, 95), (128, 199, 0, 70), (128, 64, 1, 33), (64, 187, 0, 129), (32, 144, 1, 200), (48, 32, 1, 31),
-             (32, 32, 1, 97), (32, 48, 0, 66), (144, 32, 0, 130), (128, 3, 1, 40)]
+             (32, 32, 1, 97), (32, 48, 0, 66), (144, 32, 0, 130), (128, 3, 1, 40),
+             (71, 128, 1, 77), (199, 128, 1, 45), (187, 64, 1, 100)]          # K not a multiple of 16: rows padded to whole blocks, NaN in the padding
     for K, N, tB, rows in cases:
-        A = mat(rows, K, K + 4)
+        A = mat(rows, K, K + 4 if K % 16 == 0 else (K + 15) // 16 * 16)
+        if K % 16:
+            torch.as_strided(A.buf, (rows, A.ld - K), (A.ld, 1), K).fill_(float('nan'))
         B = mat(N, K, K + 1) if tB else mat(K, N, N + 2)
         bias = mat(1, N, N)
         for act, with_bias in ((1, True), (0, False)):
@@ -91,6 +94,38 @@ def test_streaming_tall_gemm_is_the_general_kernel_bit_for_bit(cpu_lib, monkeypa
             got = torch.as_strided(outs[1], (rows, N), (N + 5, 1)).double()
             assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-12
             assert bool((torch.as_strided(outs[1], (rows, 5), (N + 5, 1), N) == 7.0).all())          # nothing written past the N columns
+    monkeypatch.setenv('SHERF_EXPERIMENT', '0')
+
+
+def test_weight_gradient_gemm_kernels_of_round_5(cpu_lib, monkeypatch):
+    """dW = dy^T . x on wgrad_shared_kernel (B split once per workgroup into LDS, row tiles owned by waves) and wgrad_solo_kernel (one row tile: the
+    waves on different steps) for every (row tiles, column tiles) pair of the path: against float64, several slabs, ragged last step, ragged last
+    row / column tile, strided operands, accumulation into C (beta 1) and overwrite (beta 0); SHERF_EXPERIMENT bit 7 = round 2's kernel, same result to
+    fp32 rounding."""
+    h = CpuKernelOps(cpu_lib, monkeypatch)
+    cpu_lib.sherf_bwd_gemm_last_path.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(11)
+
+    def mat(r, c, ld, scale=1.0):
+        return Mat(torch.randn(r * ld, generator=g) * scale, r, c, ld)
+    #          M    N   rows
+    cases = [(128, 128, 1500), (128, 71, 530), (128, 199, 700), (64, 187, 1030), (144, 32, 1111), (32, 32, 2049), (32, 48, 600), (3, 64, 515), (1, 128, 1000)]
+    for M, N, rows in cases:
+        dy, x = mat(rows, M, M + 3, 1e-3), mat(rows, N, N + 1)
+        ref = dy.tensor().double().t() @ x.tensor().double()
+        for beta in (0.0, 1.0):
+            outs = []
+            for old in (0, 1):
+                monkeypatch.setenv('SHERF_EXPERIMENT', '128' if old else '0')
+                C = Mat(torch.full((M * (N + 2),), 0.25), M, N, N + 2)
+                h.gemm(1, 0, dy, x, C, beta)
+                assert cpu_lib.sherf_bwd_gemm_last_path() == (2 if old else 4), (M, N, old)
+                outs.append(C.buf.clone())
+            want = ref + (0.25 if beta else 0.0)
+            for o in outs:
+                got = torch.as_strided(o, (M, N), (N + 2, 1)).double()
+                assert float((got - want).abs().max()) <= 3e-6 * float(ref.abs().max()) + 1e-9, (M, N, rows, beta)
+                assert bool((torch.as_strided(o, (M, 2), (N + 2, 1), N) == 0.25).all())          # nothing written past the N columns
     monkeypatch.setenv('SHERF_EXPERIMENT', '0')
 
 
@@ -121,7 +156,7 @@ def test_dense_entry_points_match_their_specification(cpu_lib, monkeypatch):
             b_c, b_g = _pair(*((N, K) if tB else (K, N)), seed=8)
             c_c, c_g = _pair(M, N, ld=N + 3, seed=9)
             e.gemm(tA, tB, a_c, b_c, c_c, 1.0); h.gemm(tA, tB, a_g, b_g, c_g, 1.0); _same(c_c, c_g)
-            assert cpu_lib.sherf_bwd_gemm_last_path() in (1, 2), (out_f, in_f, tA, tB)
+            assert cpu_lib.sherf_bwd_gemm_last_path() in (1, 2, 4), (out_f, in_f, tA, tB)
     y_c, y_g = _pair(n, 40, 45, 4); b_c, b_g = _pair(1, 40, seed=5)
     for act in (0, 1):
         e.bias_act(y_c, b_c, act); h.bias_act(y_g, b_g, act); _same(y_c, y_g)
@@ -161,11 +196,11 @@ def test_dense_entry_points_match_their_specification(cpu_lib, monkeypatch):
     e.ln_bwd(dy_c, w_c, oc[1], oc[2], *rc); h.ln_bwd(dy_g, w_g, og[1], og[2], *rg)
     for a, b in zip(rc, rg):
         _same(a, b, 1e-4)
-    q_c, q_g = _pair(n, 432, seed=13)
+    q_c, q_g = _pair(n, 432, seed=13, off=4)           # (the attention kernels take 16-byte aligned operands)
     a_c, a_g = Mat(torch.zeros(n * 27), n, 27), Mat(torch.zeros(n * 27), n, 27)
     o_c, o_g = Mat(torch.zeros(n * 144), n, 144), Mat(torch.zeros(n * 144), n, 144)
     e.attn_fwd(q_c, a_c, o_c); h.attn_fwd(q_g, a_g, o_g); _same(a_c, a_g); _same(o_c, o_g)
-    go_c, go_g = _pair(n, 144, seed=14)
+    go_c, go_g = _pair(n, 144, seed=14, off=0)
     dq_c, dq_g = Mat(torch.zeros(n * 432), n, 432), Mat(torch.zeros(n * 432), n, 432)
     e.attn_bwd(q_c, a_c, go_c, dq_c); h.attn_bwd(q_g, a_g, go_g, dq_g); _same(dq_c, dq_g, 1e-4)
     u_c, u_g = _pair(n, 32, seed=15)

@@ -36,6 +36,31 @@ def main():
               ('dgrad qkv 144->32 (3n)', 0, 3 * n, 144, 32, 144, 32, False), ('dgrad to_out 32->48 (3n)', 0, 3 * n, 32, 48, 32, 48, False)]
     def set_debug(v):
         os.environ['SHERF_EXPERIMENT'] = '64' if v else '0'
+    # weight gradients dW[M,N] = dy[rows,M]^T . x[rows,N]: the shared-B / solo kernels against round 2's (SHERF_EXPERIMENT bit 7)
+    wshapes = [('dW 128x128', n, 128, 128), ('dW 128x71', n, 128, 71), ('dW 128x199', n, 128, 199), ('dW 64x187 (views)', n, 64, 187), ('dW 144x32 (qkv, 3n)', 3 * n, 144, 32),
+               ('dW 32x32 (ff, 3n)', 3 * n, 32, 32), ('dW 32x48 (to_out, 3n)', 3 * n, 32, 48), ('dW 3x64 (rgb)', n, 3, 64), ('dW 1x128 (alpha)', n, 1, 128)]
+    for label, rows, M, N in wshapes:
+        dy, x = mat(rows, M, None, 1e-3), mat(rows, N)
+        outs, times = [], []
+        for old in (1, 0):
+            os.environ['SHERF_EXPERIMENT'] = '128' if old else '0'
+            C = Mat(torch.zeros(M * N, device=dev), M, N)
+            run = lambda: ops.gemm(1, 0, dy, x, C)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            times.append(1e3 * e0.elapsed_time(e1) / a.iters)
+            outs.append(C.tensor().double().cpu())
+        os.environ['SHERF_EXPERIMENT'] = '0'
+        ref = (dy.tensor()[:200000].double().t() @ x.tensor()[:200000].double()).cpu() if rows > 200000 else None
+        rel = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
+        hbm = rows * (M + N) * 4 / 8e12 * 1e6
+        print(f'[wgrad] {label:24s} rows {rows:8d}: round 2 {times[0]:7.1f} us  round 5 {times[1]:7.1f} us  ({times[0] / times[1]:.2f}x)  max rel difference {rel:.1e}   bound: bytes {hbm:6.1f} us', flush=True)
     for label, tB, M, K, N, lda, ldc, ba in shapes:
         A = mat(M, K, lda, 1e-3)
         B = mat(N, K) if tB else mat(K, N)
