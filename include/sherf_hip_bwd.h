@@ -38,6 +38,12 @@ int sherf_bwd_gemm_bias_act(int transA, int transB, int M, int N, int K, const f
 /* which kernel the last sherf_bwd_gemm call of this process took: 1 = tall MFMA (column-sliced when B exceeds the LDS), 2 = weight-
  * gradient MFMA, 0 = the plain fp32 kernel (tests assert that no layer shape of the path reaches it). */
 int sherf_bwd_gemm_last_path(void);
+/* The data gradient of a Linear whose input came out of a ReLU (decoder_bwd of oracle/backward_explicit.py: d_h = (d_out . W) * [h > 0], db = sum_rows d_h):
+ *   C[M,N] = A[M,K] . B[K,N]  (+ r1_s[row * r1_lds] * r1_w[column]: a second head's K = 1 product, e.g. alpha_linear beside feature_linear)
+ *   C = 0 where mask[row * ldm + column] <= 0;   colsum[column] += sum_rows C.
+ * r1_s / r1_w (both or neither), mask, colsum: optional.  One kernel for N, K in (96, 128], 16-byte aligned rows of A; otherwise the separate kernels. */
+int sherf_bwd_gemm_dgrad_fused(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                               const float* r1_s, int r1_lds, const float* r1_w, const float* mask, int ldm, float* colsum, sherf_stream_t stream);
 
 /* tokens / extras of the forward (tile-major, sherf_gather_tokens) -> row-major tok[n][96], ext[n][12]; and the inverse
  * for d_tokens (rows beyond n are zero filled up to the tile boundary). */

@@ -83,6 +83,15 @@ class HipOps:
         _lib.call_bwd('sherf_bwd_gemm_bias_act', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta),
                       None if bias is None else self._p(bias), act, self.st)
 
+    def gemm_dgrad_fused(self, A, B, C, r1_s=None, r1_w=None, mask=None, colsum=None):
+        """C = A . B (+ r1_s r1_w) masked by `mask` > 0, colsum += column sums of C (sherf_bwd_gemm_dgrad_fused)."""
+        assert B.rows == A.cols and (C.rows, C.cols) == (A.rows, B.cols) and (r1_s is None) == (r1_w is None), 'gemm_dgrad_fused shapes'
+        assert r1_s is None or (r1_s.rows == A.rows and r1_s.cols == 1 and r1_w.rows * r1_w.cols == B.cols)
+        assert mask is None or (mask.rows, mask.cols) == (C.rows, C.cols)
+        o = lambda m: None if m is None else self._p(m)
+        _lib.call_bwd('sherf_bwd_gemm_dgrad_fused', A.rows, B.cols, A.cols, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, o(r1_s),
+                      0 if r1_s is None else r1_s.ld, o(r1_w), o(mask), 0 if mask is None else mask.ld, o(colsum), self.st)
+
     def relu_mask_colsum(self, D, H, out):
         _lib.call_bwd('sherf_bwd_relu_mask_colsum', self._p(D), D.ld, self._p(H), H.ld, D.rows, D.cols, self._p(out), self.st)
 
@@ -192,9 +201,11 @@ def dense_backward(ops, state, tok, ext, d_sample):
         ops.gemm_bias_act(0, 1, x, W, y, P(wname + '.bias') if (wname + '.bias') in state else None, act)       # (bias + ReLU in the product's store)
         return y
 
-    def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True, db=None):
+    def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True, db=None, fuse=None, dgrad=True):
         """grads of y = x W^T + b; returns d_x (accumulated into d_in with beta).  db: the bias gradient when the caller already has it
-        (relu_mask_colsum sums the columns while it masks)."""
+        (relu_mask_colsum sums the columns while it masks).  fuse = dict(mask=, colsum=[, r1_s=, r1_w=]): x came out of a ReLU -- the data gradient
+        is masked by the layer below's activations and its column sums (that layer's bias gradient) are taken in the product's store
+        (ops.gemm_dgrad_fused).  dgrad=False: parameter gradients only."""
         W = P(wname + '.weight')
         dW = E(W.rows, W.cols)
         ops.gemm(1, 0, d_out, x, dW)
@@ -204,8 +215,14 @@ def dense_backward(ops, state, tok, ext, d_sample):
                 db = Z(1, W.rows)
                 ops.colsum(d_out, db)
             grads[wname + '.bias'] = db.tensor().view(-1).clone()
+        if not dgrad:
+            return None
         dx = d_in if d_in is not None else E(d_out.rows, W.cols)
-        ops.gemm(0, 0, d_out, W, dx, beta)
+        if fuse is not None:
+            assert beta == 0.0
+            ops.gemm_dgrad_fused(d_out, W, dx, fuse.get('r1_s'), fuse.get('r1_w'), fuse.get('mask'), fuse.get('colsum'))
+        else:
+            ops.gemm(0, 0, d_out, W, dx, beta)
         return dx
 
     # ================= forward recompute =================
@@ -269,13 +286,23 @@ def dense_backward(ops, state, tok, ext, d_sample):
     ops.relu_mask_colsum(d_g, g, db_v)
     d_vin = lin_bwd(d_g, vin, d + 'views_linear', db=db_v, d_in=EP(n, 187))       # (its first 128 columns are the next product's A: aligned rows)
     d_sigma = d_sample.colslice(3, 4)
-    d_h = lin_bwd(d_vin.colslice(0, 128), h7, d + 'feature_linear')
-    lin_bwd(d_sigma, h7, d + 'alpha_linear', d_in=d_h, beta=1.0)
+    # d_h7 = (d_feature . Wf + d_sigma Wa) * [h7 > 0] and its column sums (pts_linears.7's bias gradient) in one product: the sigma head's K = 1
+    # product, the ReLU mask and the column sums ride in the store of the feature head's data gradient (round 5; 0.6 ms of passes per step before)
+    db_i = Z(1, 128)
+    d_h = lin_bwd(d_vin.colslice(0, 128), h7, d + 'feature_linear',
+                  fuse=dict(r1_s=d_sigma, r1_w=P(d + 'alpha_linear.weight'), mask=hs[7], colsum=db_i))
+    lin_bwd(d_sigma, h7, d + 'alpha_linear', dgrad=False)
     d_x0 = E(n, 71)
+    premasked = True                                                # d_h already is masked by hs[i] and db_i holds its column sums
     for i in range(7, -1, -1):
-        db_i = Z(1, d_h.cols)
-        ops.relu_mask_colsum(d_h, hs[i], db_i)
-        d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}', db=db_i)
+        if not premasked:
+            db_i = Z(1, d_h.cols)
+            ops.relu_mask_colsum(d_h, hs[i], db_i)
+        # the layer below's mask + bias gradient in this layer's data-gradient store, where that layer's output IS this layer's input (not the skip
+        # layer 5, whose input is cat([x0, h4]), nor layer 0)
+        nxt = Z(1, 128) if i in (7, 6, 4, 3, 2, 1) else None
+        d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}', db=db_i, fuse=None if nxt is None else dict(mask=hs[i - 1], colsum=nxt))
+        premasked, db_i = nxt is not None, nxt
         if i == 5:
             ops.copy2d(d_x0, d_in.colslice(0, 71))                  # (first contribution: plain copy, d_x0 starts uninitialised)
             d_h = d_in.colslice(71, 199)

@@ -145,9 +145,15 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float*
 // bytes (768 MB) take ~140 us and the six-product MFMA stream ~80 us.  Here a wave fetches the WHOLE next tile of A (NKB x 2 dwordx4 per lane, 16 KiB
 // per wave, 128 KiB per CU) before it starts the current tile's MFMAs; the tile loop has no per-element bounds checks (only the last tile's rows and
 // the last column tile's columns are guarded).  Same arithmetic, same order of the six products and of the K-blocks: bit-identical to the kernel above.
-template <int NT, int NKB>
+// FUSE (the data gradient of a layer whose input came out of a ReLU; sherf_bwd_gemm_dgrad_fused): in the store, C += r1_s[row] r1_w[column] (the
+// rank-one product of the sigma head joining the feature head's gradient), C = 0 where mask <= 0 (the ReLU of the layer below), colsum[column] += the
+// column sums of what was stored (that layer's bias gradient) -- the pass sherf_bwd_relu_mask_colsum made over the result afterwards, and a K = 1 GEMM.
+struct DgradFuse { const float* r1_s; int r1_lds; const float* r1_w; const float* mask; int ldm; float* colsum; };
+
+template <int NT, int NKB, bool FUSE = false>
 __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
-                                                          float* __restrict__ C, int ldc, int M, int N, int K, const float* __restrict__ bias, int act) {
+                                                          float* __restrict__ C, int ldc, int M, int N, int K, const float* __restrict__ bias, int act,
+                                                          DgradFuse fz) {
     // K in (16 (NKB - 1), 16 NKB]: a row of A is read in whole 16-float blocks (the launcher checks lda >= 16 NKB: the tail of the last block lies in
     // the row's own padding) and the elements past K are zeroed in registers (the padding is never written: it may hold anything, NaN included)
     extern __shared__ __attribute__((aligned(16))) u32x4 s_frag[];        // [NKB][NT][hi, mid, lo][64 lanes]
@@ -168,6 +174,9 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const floa
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && 32 * nt + i < N) ? bias[32 * nt + i] : 0.f;
+    float w1[NT], csum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { w1[nt] = (FUSE && fz.r1_w && 32 * nt + i < N) ? fz.r1_w[32 * nt + i] : 0.f; csum[nt] = 0.f; }
     const bool relu = act == 1;
     // A in two halves of the K-blocks: while a half is multiplied the other half (of this tile, then of the next) is in flight -- 8 KiB per wave, 64 KiB per CU.
     // (The whole next tile in registers -- 128 of them beside 64 accumulators -- spilled.)
@@ -220,6 +229,50 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const floa
 #pragma unroll
         for (int kb = 0; kb < HB; ++kb) block(b1[kb], HA + kb);
         const bool full = tile * 32 + 32 <= M;                  // wave-uniform
+        if constexpr (FUSE) {
+            // (one branch around each GROUP of loads: `ptr ? load : constant` per element made the compiler branch around every single load and wait for it)
+            float s1[16];                                       // the rank-one term's row factors of this lane's 16 rows
+            if (fz.r1_s) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1[r] = fz.r1_s[(size_t)min(tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2), M - 1) * fz.r1_lds];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cc = 32 * nt + i;
+                if (cc < N) {
+                    const int row0 = tile * 32 + 4 * h;
+                    float mv[16];
+                    if (fz.mask) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mv[r] = fz.mask[(size_t)min(row0 + (r & 3) + 8 * (r >> 2), M - 1) * fz.ldm + cc];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mv[r] = 1.f;
+                    }
+                    float ov[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = fmaf(s1[r], w1[nt], acc[nt][r] + bv[nt]);
+                        ov[r] = mv[r] > 0.f ? v : 0.f;
+                    }
+                    float* cp = C + (size_t)row0 * ldc + cc;
+                    if (full) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { cp[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = ov[r]; csum[nt] += ov[r]; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dr = (r & 3) + 8 * (r >> 2);
+                            if (row0 + dr < M) { cp[(size_t)dr * ldc] = ov[r]; csum[nt] += ov[r]; }
+                        }
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int cc = 32 * nt + i;
@@ -240,6 +293,26 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const floa
                     }
                 }
             }
+        }
+    }
+    if constexpr (FUSE) {
+        if (fz.colsum) {                                        // (uniform over the grid)
+            __syncthreads();                                    // every wave is past its last read of the fragment image: reuse it
+            float* red = reinterpret_cast<float*>(s_frag);      // [kTallWaves][32 NT]
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float t = csum[nt];
+                t += __shfl_xor(t, 32);                         // the two row halves of the tile
+                if (h == 0) red[wave * 32 * NT + 32 * nt + i] = t;
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < 32 * NT; c += 64 * kTallWaves)
+                if (c < N) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < kTallWaves; ++w) t += red[w * 32 * NT + c];
+                    unsafeAtomicAdd(fz.colsum + c, t);
+                }
         }
     }
 }
@@ -512,9 +585,24 @@ __global__ void bias_act_tail_kernel(float* __restrict__ y, int ldy, const float
     y[r * ldy + c] = act == 1 ? fmaxf(v, 0.f) : v;
 }
 
+// fallback of sherf_bwd_gemm_dgrad_fused: y = 0 where mask <= 0; colsum += column sums (256 rows per workgroup, a thread per column round-robin)
+__global__ void __launch_bounds__(256) mask_colsum_tail_kernel(float* __restrict__ y, int ldy, const float* __restrict__ mask, int ldm, int64_t n, int C,
+                                                               float* __restrict__ colsum) {
+    const int64_t r0 = (int64_t)blockIdx.x * 256, r1 = r0 + 256 < n ? r0 + 256 : n;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            float v = y[r * ldy + c];
+            if (mask && !(mask[r * ldm + c] > 0.f)) { v = 0.f; y[r * ldy + c] = 0.f; }
+            a += v;
+        }
+        if (colsum) unsafeAtomicAdd(colsum + c, a);
+    }
+}
+
 }  // namespace
 
-static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA (general), 3 = tall MFMA (streaming), 2 = weight-gradient MFMA (round 2's kernel), 4 = weight-gradient MFMA (shared-B / solo kernels), 0 = plain
+static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA (general), 3 = tall MFMA (streaming), 2 = weight-gradient MFMA (round 2's kernel), 4 = weight-gradient MFMA (shared-B / solo kernels), 5 = streaming tall MFMA with the fused data-gradient store, 0 = plain
 extern "C" int sherf_bwd_gemm_last_path() { return g_last_path; }
 
 static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -529,6 +617,30 @@ extern "C" int sherf_bwd_gemm_bias_act(int transA, int transB, int M, int N, int
                                        float* C, int ldc, float beta, const float* bias, int act, sherf_stream_t stream) {
     SHERF_CHECK_ARG(act == 0 || act == 1);
     return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, beta, bias, act, stream);
+}
+
+// C[M,N] = A[M,K] . B[K,N] (+ r1_s[row] r1_w[column]) masked by `mask` (> 0 keeps), colsum[column] += the column sums of the result: the data gradient of a
+// layer behind a ReLU in ONE kernel when the shape takes the streaming kernel (N, K = 128: every hidden layer of the decoder); otherwise the same result
+// from the separate kernels (product, K = 1 product with beta 1, mask + column sums).  r1_s / r1_w, mask, colsum: each optional (null).
+extern "C" int sherf_bwd_gemm_dgrad_fused(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                          const float* r1_s, int r1_lds, const float* r1_w, const float* mask, int ldm, float* colsum,
+                                          sherf_stream_t stream) {
+    SHERF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && lda >= K && ldb >= N && ldc >= N && (!r1_s == !r1_w) && (!r1_s || r1_lds > 0) && (!mask || ldm >= N));
+    hipStream_t st = as_stream(stream);
+    const int nkb = (K + 15) / 16, NT = (N + 31) / 32;
+    if (NT == 4 && nkb == 8 && lda >= 128 && lda % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && !(sherf_experiment() & 64)) {
+        const int tiles = (M + 31) / 32, grid = min((tiles + kTallWaves - 1) / kTallWaves, n_cus());
+        const size_t smem = (size_t)nkb * NT * 3072;
+        SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_stream_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((tall_stream_kernel<4, 8, true>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, B, ldb, 0, C, ldc, M, N, K, nullptr, 0,
+                           DgradFuse{r1_s, r1_lds, r1_w, mask, ldm, colsum});
+        g_last_path = 5;
+        SHERF_LAUNCH_CHECK();
+    }
+    SHERF_RUN(gemm_impl(0, 0, M, N, K, A, lda, B, ldb, C, ldc, 0.f, nullptr, 0, stream));
+    if (r1_s) SHERF_RUN(gemm_impl(0, 0, M, N, 1, r1_s, r1_lds, r1_w, N, C, ldc, 1.f, nullptr, 0, stream));
+    if (mask || colsum) hipLaunchKernelGGL(mask_colsum_tail_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, C, ldc, mask, ldm, (int64_t)M, N, colsum);
+    SHERF_LAUNCH_CHECK();
 }
 
 static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -554,7 +666,7 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const float* A
                 bool hit = true;
 #define SHERF_STREAM(n, k) case (n) * 16 + (k): \
                 if (smem > 64 * 1024) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_stream_kernel<n, k>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-                hipLaunchKernelGGL((tall_stream_kernel<n, k>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, bias ? bias + n0 : nullptr, act); break
+                hipLaunchKernelGGL((tall_stream_kernel<n, k>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, Bs, ldb, transB, Cs, ldc, M, Ns, K, bias ? bias + n0 : nullptr, act, DgradFuse{}); break
                 switch (NTs * 16 + nkb) {
                     SHERF_STREAM(4, 8); SHERF_STREAM(3, 8); SHERF_STREAM(6, 8); SHERF_STREAM(1, 8); SHERF_STREAM(5, 2); SHERF_STREAM(1, 3);
                     SHERF_STREAM(1, 2); SHERF_STREAM(2, 2); SHERF_STREAM(1, 9); SHERF_STREAM(6, 4); SHERF_STREAM(2, 8);

@@ -18,6 +18,16 @@ class EmuOps:
         self.gemm(tA, tB, A, B, C, beta)
         self.bias_act(C, bias, act)
 
+    def gemm_dgrad_fused(self, A, B, C, r1_s=None, r1_w=None, mask=None, colsum=None):      # sherf_bwd_gemm_dgrad_fused (colsum accumulates)
+        y = A.tensor() @ B.tensor()
+        if r1_s is not None:
+            y = y + r1_s.tensor() * r1_w.tensor().reshape(1, -1)
+        if mask is not None:
+            y = y * (mask.tensor() > 0).float()
+        C.tensor().copy_(y)
+        if colsum is not None:
+            colsum.tensor().add_(y.sum(0, keepdim=True))
+
     def relu_mask_colsum(self, D, H, out):                           # sherf_bwd_relu_mask_colsum (out accumulates)
         self.relu_mask(D, H)
         self.colsum(D, out)

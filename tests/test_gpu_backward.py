@@ -76,6 +76,29 @@ def test_bwd_gemm_all_transpositions():
             _same(c_c, c_g, 1e-4)
 
 
+def test_fused_data_gradient_store_on_device():
+    """sherf_bwd_gemm_dgrad_fused on the MI355X: the one-kernel path (N, K = 128, aligned rows) and the composition of separate kernels against the
+    emulator, with and without the rank-one term / mask / column sums; 40 000 rows so that every workgroup's column-sum reduction takes part."""
+    from sherf_amd.backward_dense import HipOps, Mat
+    from sherf_amd import _lib
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    for rows, K, N, lda, fused in ((40001, 128, 128, 132, True), (3000, 128, 128, 131, False), (5000, 64, 128, 64, False)):
+        a_c, a_g = _pair(rows, K, ld=lda, seed=31, off=0)
+        b_c, b_g = _pair(K, N, ld=N + 3, seed=32)
+        s_c, s_g = _pair(rows, 1, ld=4, seed=33)
+        w_c, w_g = _pair(1, N, seed=34)
+        m_c, m_g = _pair(rows, N, ld=N + 8, seed=35)
+        for use_r1, use_mask, use_sum in ((1, 1, 1), (0, 1, 1), (0, 0, 0)):
+            c_c, c_g = _pair(rows, N, ld=N + 5, seed=36)
+            o_c, o_g = Mat(torch.full((N,), 0.5), 1, N), Mat(torch.full((N,), 0.5).cuda(), 1, N)
+            args = lambda s1, w1, m, o: (s1 if use_r1 else None, w1 if use_r1 else None, m if use_mask else None, o if use_sum else None)
+            e.gemm_dgrad_fused(a_c, b_c, c_c, *args(s_c, w_c, m_c, o_c)); h.gemm_dgrad_fused(a_g, b_g, c_g, *args(s_g, w_g, m_g, o_g))
+            torch.cuda.synchronize()
+            assert (_lib.lib_bwd().sherf_bwd_gemm_last_path() == 5) == fused
+            _same(c_c, c_g, 1e-5); _same(o_c, o_g, 1e-4)
+
+
 def test_bwd_elementwise_kernels():
     from sherf_amd.backward_dense import HipOps, Mat
     from tests.bwd_emulator import EmuOps

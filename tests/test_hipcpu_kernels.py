@@ -97,6 +97,40 @@ def test_streaming_tall_gemm_is_the_general_kernel_bit_for_bit(cpu_lib, monkeypa
     monkeypatch.setenv('SHERF_EXPERIMENT', '0')
 
 
+def test_fused_data_gradient_store(cpu_lib, monkeypatch):
+    """sherf_bwd_gemm_dgrad_fused: C = A . B (+ rank-one term) masked by the layer below's activations, column sums accumulated -- the one-kernel
+    path (N, K = 128, aligned rows: last_path 5) and the composition of separate kernels (anything else) against float64, every optional part on / off,
+    ragged last tile, strided operands, colsum accumulating into what it held."""
+    h = CpuKernelOps(cpu_lib, monkeypatch)
+    cpu_lib.sherf_bwd_gemm_last_path.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(21)
+
+    def mat(r, c, ld, scale=1.0):
+        return Mat(torch.randn(r * ld, generator=g) * scale, r, c, ld)
+    for (rows, K, N, lda, fused) in ((301, 128, 128, 132, True), (64, 128, 128, 128, True), (95, 120, 100, 128, True), (77, 128, 128, 131, False), (130, 64, 128, 64, False),
+                                     (50, 128, 199, 128, False)):
+        A, B = mat(rows, K, lda, 1e-2), mat(K, N, N + 3)
+        s1, w1 = mat(rows, 1, 4), mat(1, N, N)
+        H = mat(rows, N, N + 8)
+        for use_r1, use_mask, use_sum in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (0, 0, 0), (0, 1, 0)):
+            C = Mat(torch.full((rows * (N + 5),), 3.0), rows, N, N + 5)
+            cs = Mat(torch.full((N,), 0.5), 1, N)
+            h.gemm_dgrad_fused(A, B, C, s1 if use_r1 else None, w1 if use_r1 else None, H if use_mask else None, cs if use_sum else None)
+            assert (cpu_lib.sherf_bwd_gemm_last_path() == 5) == fused, (rows, K, N, lda)
+            ref = A.tensor().double() @ B.tensor().double()
+            if use_r1:
+                ref = ref + s1.tensor().double() * w1.tensor().double()
+            if use_mask:
+                ref = ref * (H.tensor() > 0).double()
+            scale = float(ref.abs().max())
+            assert float((C.tensor().double() - ref).abs().max()) <= 3e-6 * scale + 1e-12, (rows, K, N, use_r1, use_mask)
+            assert bool((torch.as_strided(C.buf, (rows, 5), (N + 5, 1), N) == 3.0).all())
+            if use_sum:
+                assert float((cs.tensor().double() - 0.5 - ref.sum(0, keepdim=True)).abs().max()) <= 1e-5 * scale * rows ** 0.5 + 1e-9
+            else:
+                assert bool((cs.tensor() == 0.5).all())
+
+
 def test_weight_gradient_gemm_kernels_of_round_5(cpu_lib, monkeypatch):
     """dW = dy^T . x on wgrad_shared_kernel (B split once per workgroup into LDS, row tiles owned by waves) and wgrad_solo_kernel (one row tile: the
     waves on different steps) for every (row tiles, column tiles) pair of the path: against float64, several slabs, ragged last step, ragged last

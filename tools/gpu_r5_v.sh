@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, call V: the fused data-gradient store (mask + bias gradient + sigma head's rank-one term in the dgrad GEMM): backward tests, training step + kernel totals
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_backward.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 python bench_train.py --steps 5 --warmup 2 > $OUT/r5v_train.json 2> $OUT/r5v_train.err; echo "[train rc=$?]"; python -c "
+import json; d=json.loads(open('$OUT/r5v_train.json').read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('ms_per_step','value','unit','host_ms')})"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/r5v_prof -o trace -- python $GRAFT_REPO_ROOT/bench_train.py --steps 4 --warmup 1 > $OUT/r5v_prof.log 2>&1; echo "[rocprof rc=$?]"
+DB=$(find $OUT/r5v_prof -name "*.db" | head -1)
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $DB 0 70 > $OUT/r5v_train_stats.txt; rm -rf $OUT/r5v_prof; head -40 $OUT/r5v_train_stats.txt | cut -c1-150
