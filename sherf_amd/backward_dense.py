@@ -209,12 +209,12 @@ def dense_backward(ops, state, tok, ext, d_sample):
         W = P(wname + '.weight')
         dW = E(W.rows, W.cols)
         ops.gemm(1, 0, d_out, x, dW)
-        grads[wname + '.weight'] = dW.tensor().view(state[wname + '.weight'].shape).clone()
+        grads[wname + '.weight'] = dW.tensor().view(state[wname + '.weight'].shape)          # (dW / db: buffers of their own, nothing else writes them: no copy)
         if bias and (wname + '.bias') in state:
             if db is None:
                 db = Z(1, W.rows)
                 ops.colsum(d_out, db)
-            grads[wname + '.bias'] = db.tensor().view(-1).clone()
+            grads[wname + '.bias'] = db.tensor().view(-1)
         if not dgrad:
             return None
         dx = d_in if d_in is not None else E(d_out.rows, W.cols)
@@ -298,15 +298,22 @@ def dense_backward(ops, state, tok, ext, d_sample):
         if not premasked:
             db_i = Z(1, d_h.cols)
             ops.relu_mask_colsum(d_h, hs[i], db_i)
-        # the layer below's mask + bias gradient in this layer's data-gradient store, where that layer's output IS this layer's input (not the skip
-        # layer 5, whose input is cat([x0, h4]), nor layer 0)
+        # the layer below's mask + bias gradient in this layer's data-gradient store, where that layer's output IS this layer's input (not layer 0)
+        if i == 5:
+            # the skip layer: its input is cat([x0, h4]) -- the data gradient as TWO products over the two column ranges of the weight, so that the x0 part
+            # lands in d_x0 (no copy) and the h4 part in an aligned matrix of its own, masked by h4 with layer 4's bias gradient taken in the store (a
+            # [n, 199] result sliced at column 71 made layer 4's product misaligned: the general kernel + a separate mask pass, 0.9 ms per step)
+            lin_bwd(d_h, ins[5], d + 'pts_linears.5', db=db_i, dgrad=False)
+            W5 = P(d + 'pts_linears.5.weight')
+            ops.gemm(0, 0, d_h, W5.colslice(0, 71), d_x0)
+            db_i, d_h4 = Z(1, 128), E(n, 128)
+            ops.gemm_dgrad_fused(d_h, W5.colslice(71, 199), d_h4, mask=hs[4], colsum=db_i)
+            d_h, premasked = d_h4, True
+            continue
         nxt = Z(1, 128) if i in (7, 6, 4, 3, 2, 1) else None
         d_in = lin_bwd(d_h, ins[i], d + f'pts_linears.{i}', db=db_i, fuse=None if nxt is None else dict(mask=hs[i - 1], colsum=nxt))
         premasked, db_i = nxt is not None, nxt
-        if i == 5:
-            ops.copy2d(d_x0, d_in.colslice(0, 71))                  # (first contribution: plain copy, d_x0 starts uninitialised)
-            d_h = d_in.colslice(71, 199)
-        elif i == 0:
+        if i == 0:
             ops.copy2d(d_x0, d_in, add=True)
         else:
             d_h = d_in
@@ -320,7 +327,7 @@ def dense_backward(ops, state, tok, ext, d_sample):
     d_h1 = lin_bwd(d_ge, h1, t + '1.fn.fn.net.0')
     d_y, dw, db = E(3 * n, 32), Z(1, 32), Z(1, 32)
     ops.ln_bwd(d_h1, P(t + '1.fn.norm.weight'), xh1, inv1, d_y, dw, db)
-    grads[t + '1.fn.norm.weight'], grads[t + '1.fn.norm.bias'] = dw.tensor().view(-1).clone(), db.tensor().view(-1).clone()
+    grads[t + '1.fn.norm.weight'], grads[t + '1.fn.norm.bias'] = dw.tensor().view(-1), db.tensor().view(-1)
     ops.copy2d(d_y, d_out, add=True)
     # ---- y = o Wo^T + bo + tokens_in ----
     d_o = lin_bwd(d_y, o, t + '0.fn.fn.to_out.0')
@@ -329,9 +336,9 @@ def dense_backward(ops, state, tok, ext, d_sample):
     d_h0 = lin_bwd(d_qkv, h0, t + '0.fn.fn.to_qkv', bias=False)
     d_tin, dw0, db0 = E(3 * n, 32), Z(1, 32), Z(1, 32)
     ops.ln_bwd(d_h0, P(t + '0.fn.norm.weight'), xh0, inv0, d_tin, dw0, db0)
-    grads[t + '0.fn.norm.weight'], grads[t + '0.fn.norm.bias'] = dw0.tensor().view(-1).clone(), db0.tensor().view(-1).clone()
+    grads[t + '0.fn.norm.weight'], grads[t + '0.fn.norm.bias'] = dw0.tensor().view(-1), db0.tensor().view(-1)
     ops.copy2d(d_tin, d_y, add=True)
     d_tin96 = d_tin.as_rows(n, 96)
     dWb_pe = E(32, 32)
     ops.gemm(1, 0, d_tin96.colslice(64, 96), pe_rgb.colslice(0, 32), dWb_pe)
-    return d_tin96, grads, dWb_pe.tensor().clone()
+    return d_tin96, grads, dWb_pe.tensor()
