@@ -42,6 +42,10 @@ int sherf_bwd_gemm_last_path(void);
  *   C[M,N] = A[M,K] . B[K,N]  (+ r1_s[row * r1_lds] * r1_w[column]: a second head's K = 1 product, e.g. alpha_linear beside feature_linear)
  *   C = 0 where mask[row * ldm + column] <= 0;   colsum[column] += sum_rows C.
  * r1_s / r1_w (both or neither), mask, colsum: optional.  One kernel for N, K in (96, 128], 16-byte aligned rows of A; otherwise the separate kernels. */
+/* C[M,N] = act(A[M,K] . op(B) + bias) + addend[M,N]  (op(B) = B^T [N,K] when transB): a Linear joining a residual stream (renderer.py:979-1005: the
+ * transformer's to_out and feed-forward), the residual added in the product's store.  addend != C. */
+int sherf_bwd_gemm_bias_act_add(int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                const float* bias, int act, const float* addend, int ld_add, sherf_stream_t stream);
 int sherf_bwd_gemm_dgrad_fused(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                const float* r1_s, int r1_lds, const float* r1_w, const float* mask, int ldm, float* colsum, sherf_stream_t stream);
 
@@ -73,6 +77,9 @@ int sherf_bwd_ln_fwd(const float* x, const float* w, const float* b, int64_t row
                      sherf_stream_t stream);
 int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh, const float* inv, int64_t rows, float* dx,
                      float* dw, float* db, sherf_stream_t stream);
+/* the same with a residual gradient joining: dx = (LayerNorm backward of dy) + addend[rows][32]  (addend != dx) */
+int sherf_bwd_ln_bwd_add(const float* dy, const float* w, const float* xh, const float* inv, int64_t rows, const float* addend, float* dx,
+                         float* dw, float* db, sherf_stream_t stream);
 
 /* 3-token, 3-head x 16 attention core on qkv[n][3 tok][144] (q | k | v, each 3 heads x 16; renderer.py:949-977):
  * fwd: att[n][3 head][3][3] = softmax(q k^T / 4), o[n][3 tok][48]; bwd: d_o -> d_qkv.  qkv, o, d_o, d_qkv: 16-byte aligned

@@ -83,6 +83,13 @@ class HipOps:
         _lib.call_bwd('sherf_bwd_gemm_bias_act', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta),
                       None if bias is None else self._p(bias), act, self.st)
 
+    def gemm_bias_act_add(self, tB, A, B, C, bias, act, addend):
+        """C = act(A . op(B) + bias) + addend (sherf_bwd_gemm_bias_act_add: a Linear joining a residual stream)."""
+        K2, N = (B.cols, B.rows) if tB else (B.rows, B.cols)
+        assert K2 == A.cols and (C.rows, C.cols) == (A.rows, N) == (addend.rows, addend.cols) and addend.buf is not C.buf, 'gemm_bias_act_add shapes'
+        _lib.call_bwd('sherf_bwd_gemm_bias_act_add', int(tB), A.rows, N, A.cols, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld,
+                      None if bias is None else self._p(bias), act, self._p(addend), addend.ld, self.st)
+
     def gemm_dgrad_fused(self, A, B, C, r1_s=None, r1_w=None, mask=None, colsum=None):
         """C = A . B (+ r1_s r1_w) masked by `mask` > 0, colsum += column sums of C (sherf_bwd_gemm_dgrad_fused)."""
         assert B.rows == A.cols and (C.rows, C.cols) == (A.rows, B.cols) and (r1_s is None) == (r1_w is None), 'gemm_dgrad_fused shapes'
@@ -113,8 +120,13 @@ class HipOps:
     def ln_fwd(self, x, w, b, y, xh, inv):
         _lib.call_bwd('sherf_bwd_ln_fwd', self._p(x), self._p(w), self._p(b), x.rows, self._p(y), self._p(xh), self._p(inv), self.st)
 
-    def ln_bwd(self, dy, w, xh, inv, dx, dw, db):
-        _lib.call_bwd('sherf_bwd_ln_bwd', self._p(dy), self._p(w), self._p(xh), self._p(inv), dy.rows, self._p(dx), self._p(dw), self._p(db), self.st)
+    def ln_bwd(self, dy, w, xh, inv, dx, dw, db, addend=None):
+        if addend is None:
+            _lib.call_bwd('sherf_bwd_ln_bwd', self._p(dy), self._p(w), self._p(xh), self._p(inv), dy.rows, self._p(dx), self._p(dw), self._p(db), self.st)
+        else:                                       # dx = LN backward + a residual gradient joining (one pass less)
+            assert addend.ld == addend.cols == 32 and addend.rows == dy.rows
+            _lib.call_bwd('sherf_bwd_ln_bwd_add', self._p(dy), self._p(w), self._p(xh), self._p(inv), dy.rows, self._p(addend), self._p(dx), self._p(dw),
+                          self._p(db), self.st)
 
     def attn_fwd(self, qkv, att, o):
         _lib.call_bwd('sherf_bwd_attn_fwd', self._p(qkv), qkv.rows, self._p(att), self._p(o), self.st)
@@ -195,10 +207,14 @@ def dense_backward(ops, state, tok, ext, d_sample):
     P = lambda name: Mat.of(state[name])
     grads = {}
 
-    def lin_fwd(x, wname, act, out=None):
+    def lin_fwd(x, wname, act, out=None, addend=None):
         W = P(wname + '.weight')                                   # [out, in]
         y = out if out is not None else E(x.rows, W.rows)
-        ops.gemm_bias_act(0, 1, x, W, y, P(wname + '.bias') if (wname + '.bias') in state else None, act)       # (bias + ReLU in the product's store)
+        b = P(wname + '.bias') if (wname + '.bias') in state else None
+        if addend is not None:
+            ops.gemm_bias_act_add(1, x, W, y, b, act, addend)     # (... and the residual stream the output joins)
+        else:
+            ops.gemm_bias_act(0, 1, x, W, y, b, act)               # (bias + ReLU in the product's store)
         return y
 
     def lin_bwd(d_out, x, wname, d_in=None, beta=0.0, bias=True, db=None, fuse=None, dgrad=True):
@@ -241,15 +257,13 @@ def dense_backward(ops, state, tok, ext, d_sample):
     ops.gemm(0, 1, h0, P(t + '0.fn.fn.to_qkv.weight'), qkv)
     att, o = E(n, 27), E(3 * n, 48)
     ops.attn_fwd(qkv.as_rows(n, 432), att, o.as_rows(n, 144))
-    y = lin_fwd(o, t + '0.fn.fn.to_out.0', 0)
-    ops.copy2d(y, tin3, add=True)                                   # residual
+    y = lin_fwd(o, t + '0.fn.fn.to_out.0', 0, addend=tin3)          # residual (added in the product's store)
     h1, xh1, inv1 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
     ops.ln_fwd(y, P(t + '1.fn.norm.weight'), P(t + '1.fn.norm.bias'), h1, xh1, inv1)
     u = lin_fwd(h1, t + '1.fn.fn.net.0', 0)
     ge = E(3 * n, 32)
     ops.gelu_fwd(u, ge)
-    z = lin_fwd(ge, t + '1.fn.fn.net.3', 0)
-    ops.copy2d(z, y, add=True)
+    z = lin_fwd(ge, t + '1.fn.fn.net.3', 0, addend=y)
     z96 = z.as_rows(n, 96)                                          # [n, slot 0 | slot 1 | slot 2]
     # ---- decoder ----
     d = 'decoder.'
@@ -317,7 +331,8 @@ def dense_backward(ops, state, tok, ext, d_sample):
             ops.copy2d(d_x0, d_in, add=True)
         else:
             d_h = d_in
-    d_z = Z(n, 96)                                                  # slot 2 of the transformer output is never read
+    d_z = E(n, 96)                                                  # slot 2 of the transformer output is never read: its gradient is zero
+    d_z.colslice(64, 96).tensor().zero_()                           # (the other two thirds are written in full below)
     ops.copy2d(d_z.colslice(0, 32), d_x0.colslice(39, 71))
     ops.copy2d(d_z.colslice(32, 64), d_vin.colslice(155, 187))
     d_out = d_z.as_rows(3 * n, 32)
@@ -326,18 +341,16 @@ def dense_backward(ops, state, tok, ext, d_sample):
     ops.gelu_bwd(d_ge, u)
     d_h1 = lin_bwd(d_ge, h1, t + '1.fn.fn.net.0')
     d_y, dw, db = E(3 * n, 32), Z(1, 32), Z(1, 32)
-    ops.ln_bwd(d_h1, P(t + '1.fn.norm.weight'), xh1, inv1, d_y, dw, db)
+    ops.ln_bwd(d_h1, P(t + '1.fn.norm.weight'), xh1, inv1, d_y, dw, db, addend=d_out)          # (+ the residual branch's gradient)
     grads[t + '1.fn.norm.weight'], grads[t + '1.fn.norm.bias'] = dw.tensor().view(-1), db.tensor().view(-1)
-    ops.copy2d(d_y, d_out, add=True)
     # ---- y = o Wo^T + bo + tokens_in ----
     d_o = lin_bwd(d_y, o, t + '0.fn.fn.to_out.0')
     d_qkv = E(3 * n, 144)
     ops.attn_bwd(qkv.as_rows(n, 432), att, d_o.as_rows(n, 144), d_qkv.as_rows(n, 432))
     d_h0 = lin_bwd(d_qkv, h0, t + '0.fn.fn.to_qkv', bias=False)
     d_tin, dw0, db0 = E(3 * n, 32), Z(1, 32), Z(1, 32)
-    ops.ln_bwd(d_h0, P(t + '0.fn.norm.weight'), xh0, inv0, d_tin, dw0, db0)
+    ops.ln_bwd(d_h0, P(t + '0.fn.norm.weight'), xh0, inv0, d_tin, dw0, db0, addend=d_y)
     grads[t + '0.fn.norm.weight'], grads[t + '0.fn.norm.bias'] = dw0.tensor().view(-1), db0.tensor().view(-1)
-    ops.copy2d(d_tin, d_y, add=True)
     d_tin96 = d_tin.as_rows(n, 96)
     dWb_pe = E(32, 32)
     ops.gemm(1, 0, d_tin96.colslice(64, 96), pe_rgb.colslice(0, 32), dWb_pe)

@@ -164,7 +164,7 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 // same 32 words -- took 2.35 ms per call on 2 M rows, 26x the time of its memory traffic: profiles/r02_train_step_final_rocprofv3_stats.txt.)
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ xh,
                                                      const float* __restrict__ inv, int64_t rows, float* __restrict__ dx, float* __restrict__ dw,
-                                                     float* __restrict__ db) {
+                                                     float* __restrict__ db, const float* __restrict__ addend) {
     __shared__ float s_red[4][8][8];
     const int l = threadIdx.x & 7, sub = threadIdx.x >> 3;
     const float4 wv = reinterpret_cast<const float4*>(w)[l];
@@ -186,7 +186,9 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* __restrict__ d
         m1 *= (1.f / 32.f); m2 *= (1.f / 32.f);
         if (live) {
             const float iv = inv[r];
-            dx4[r * 8 + l] = make_float4(iv * (g.x - m1 - h.x * m2), iv * (g.y - m1 - h.y * m2), iv * (g.z - m1 - h.z * m2), iv * (g.w - m1 - h.w * m2));
+            float4 o = make_float4(iv * (g.x - m1 - h.x * m2), iv * (g.y - m1 - h.y * m2), iv * (g.z - m1 - h.z * m2), iv * (g.w - m1 - h.w * m2));
+            if (addend) { const float4 a = reinterpret_cast<const float4*>(addend)[r * 8 + l]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }      // (uniform)
+            dx4[r * 8 + l] = o;
         }
     }
 #pragma unroll
@@ -221,7 +223,7 @@ __device__ __forceinline__ void st16(float* __restrict__ p, const float (&d)[16]
 }
 
 // one thread per (sample, head): q_i = qkv[n][i][16h..], k_j = qkv[n][j][48 + 16h..], v_j = qkv[n][j][96 + 16h..]
-__global__ void attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float* __restrict__ att, float* __restrict__ o) {
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float* __restrict__ att, float* __restrict__ o) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * 3) return;
     const int64_t s = i / 3;
@@ -253,7 +255,8 @@ __global__ void attn_fwd_kernel(const float* __restrict__ qkv, int64_t n, float*
     }
 }
 
-__global__ void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ att, const float* __restrict__ d_o, int64_t n,
+// (launch bounds: without them the compiler budgets for 1024-thread workgroups, 128 registers, and spilled q / k / v / d_o -- 192 floats per thread)
+__global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ att, const float* __restrict__ d_o, int64_t n,
                                 float* __restrict__ d_qkv) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * 3) return;
@@ -450,7 +453,16 @@ extern "C" int sherf_bwd_ln_bwd(const float* dy, const float* w, const float* xh
     SHERF_CHECK_ARG(dy && w && xh && inv && dx && dw && db && rows > 0);
     const int64_t groups = (rows + 31) / 32;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)(groups < 4096 ? groups : 4096)), dim3(256), 0, as_stream(stream), dy, w, xh, inv, rows, dx,
-                       dw, db);
+                       dw, db, static_cast<const float*>(nullptr));
+    SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_bwd_ln_bwd_add(const float* dy, const float* w, const float* xh, const float* inv, int64_t rows, const float* addend, float* dx,
+                                    float* dw, float* db, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(dy && w && xh && inv && addend && dx && dw && db && rows > 0 && addend != dx);
+    const int64_t groups = (rows + 31) / 32;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)(groups < 4096 ? groups : 4096)), dim3(256), 0, as_stream(stream), dy, w, xh, inv, rows, dx,
+                       dw, db, addend);
     SHERF_LAUNCH_CHECK();
 }
 

@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_gemm_kernel(const float*
 // FUSE (the data gradient of a layer whose input came out of a ReLU; sherf_bwd_gemm_dgrad_fused): in the store, C += r1_s[row] r1_w[column] (the
 // rank-one product of the sigma head joining the feature head's gradient), C = 0 where mask <= 0 (the ReLU of the layer below), colsum[column] += the
 // column sums of what was stored (that layer's bias gradient) -- the pass sherf_bwd_relu_mask_colsum made over the result afterwards, and a K = 1 GEMM.
-struct DgradFuse { const float* r1_s; int r1_lds; const float* r1_w; const float* mask; int ldm; float* colsum; };
+struct DgradFuse { const float* r1_s; int r1_lds; const float* r1_w; const float* mask; int ldm; float* colsum; const float* addend; int ld_add; };
+// (addend: a residual stream joining the product in the store -- sherf_bwd_gemm_bias_act_add: C = act(A . op(B) + bias) + addend)
 
 template <int NT, int NKB, bool FUSE = false>
 __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int transB,
@@ -252,10 +253,20 @@ __global__ void __launch_bounds__(64 * kTallWaves) tall_stream_kernel(const floa
 #pragma unroll
                         for (int r = 0; r < 16; ++r) mv[r] = 1.f;
                     }
+                    float av[16];
+                    if (fz.addend) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) av[r] = fz.addend[(size_t)min(row0 + (r & 3) + 8 * (r >> 2), M - 1) * fz.ld_add + cc];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) av[r] = 0.f;
+                    }
                     float ov[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float v = fmaf(s1[r], w1[nt], acc[nt][r] + bv[nt]);
+                        float v = acc[nt][r] + bv[nt];
+                        v = relu ? fmaxf(v, 0.f) : v;
+                        v = fmaf(s1[r], w1[nt], v) + av[r];
                         ov[r] = mv[r] > 0.f ? v : 0.f;
                     }
                     float* cp = C + (size_t)row0 * ldc + cc;
@@ -600,6 +611,15 @@ __global__ void __launch_bounds__(256) mask_colsum_tail_kernel(float* __restrict
     }
 }
 
+// fallback of sherf_bwd_gemm_bias_act_add: y += addend
+__global__ void add2d_tail_kernel(float* __restrict__ y, int ldy, const float* __restrict__ a, int lda, int64_t n, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    y[r * ldy + c] += a[r * lda + c];
+}
+
 }  // namespace
 
 static int g_last_path = -1;          // which kernel the last sherf_bwd_gemm call took: 1 = tall MFMA (general), 3 = tall MFMA (streaming), 2 = weight-gradient MFMA (round 2's kernel), 4 = weight-gradient MFMA (shared-B / solo kernels), 5 = streaming tall MFMA with the fused data-gradient store, 0 = plain
@@ -633,13 +653,34 @@ extern "C" int sherf_bwd_gemm_dgrad_fused(int M, int N, int K, const float* A, i
         const size_t smem = (size_t)nkb * NT * 3072;
         SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tall_stream_kernel<4, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((tall_stream_kernel<4, 8, true>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, B, ldb, 0, C, ldc, M, N, K, nullptr, 0,
-                           DgradFuse{r1_s, r1_lds, r1_w, mask, ldm, colsum});
+                           DgradFuse{r1_s, r1_lds, r1_w, mask, ldm, colsum, nullptr, 0});
         g_last_path = 5;
         SHERF_LAUNCH_CHECK();
     }
     SHERF_RUN(gemm_impl(0, 0, M, N, K, A, lda, B, ldb, C, ldc, 0.f, nullptr, 0, stream));
     if (r1_s) SHERF_RUN(gemm_impl(0, 0, M, N, 1, r1_s, r1_lds, r1_w, N, C, ldc, 1.f, nullptr, 0, stream));
     if (mask || colsum) hipLaunchKernelGGL(mask_colsum_tail_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, C, ldc, mask, ldm, (int64_t)M, N, colsum);
+    SHERF_LAUNCH_CHECK();
+}
+
+// C[M,N] = act(A[M,K] . op(B) + bias) + addend[M,N]: a Linear whose output joins a residual stream (the transformer's to_out and net.3), the residual
+// added in the product's store on the streaming kernel's shapes (N <= 32, K = 32 / 48); otherwise the product followed by an add pass.
+extern "C" int sherf_bwd_gemm_bias_act_add(int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                           const float* bias, int act, const float* addend, int ld_add, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(A && B && C && addend && M > 0 && N > 0 && K > 0 && lda >= K && ldc >= N && ld_add >= N && (act == 0 || act == 1) && addend != C);
+    hipStream_t st = as_stream(stream);
+    const int nkb = (K + 15) / 16, NT = (N + 31) / 32;
+    if (NT == 1 && (nkb == 2 || nkb == 3) && lda >= 16 * nkb && lda % 4 == 0 && (reinterpret_cast<size_t>(A) & 15) == 0 && !(sherf_experiment() & 64)) {
+        const int tiles = (M + 31) / 32, grid = min((tiles + kTallWaves - 1) / kTallWaves, n_cus());
+        const size_t smem = (size_t)nkb * NT * 3072 < 1024 ? 1024 : (size_t)nkb * NT * 3072;
+        const DgradFuse fz{nullptr, 0, nullptr, nullptr, 0, nullptr, addend, ld_add};
+        if (nkb == 2) hipLaunchKernelGGL((tall_stream_kernel<1, 2, true>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, B, ldb, transB, C, ldc, M, N, K, bias, act, fz);
+        else hipLaunchKernelGGL((tall_stream_kernel<1, 3, true>), dim3(grid), dim3(64 * kTallWaves), smem, st, A, lda, B, ldb, transB, C, ldc, M, N, K, bias, act, fz);
+        g_last_path = 5;
+        SHERF_LAUNCH_CHECK();
+    }
+    SHERF_RUN(gemm_impl(0, transB, M, N, K, A, lda, B, ldb, C, ldc, 0.f, bias, act, stream));
+    hipLaunchKernelGGL(add2d_tail_kernel, dim3((unsigned)(((int64_t)M * N + 255) / 256)), dim3(256), 0, st, C, ldc, addend, ld_add, (int64_t)M, N);
     SHERF_LAUNCH_CHECK();
 }
 

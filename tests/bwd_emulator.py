@@ -18,6 +18,11 @@ class EmuOps:
         self.gemm(tA, tB, A, B, C, beta)
         self.bias_act(C, bias, act)
 
+    def gemm_bias_act_add(self, tB, A, B, C, bias, act, addend):      # sherf_bwd_gemm_bias_act_add
+        add = addend.tensor().clone()
+        self.gemm_bias_act(0, tB, A, B, C, bias, act)
+        C.tensor().add_(add)
+
     def gemm_dgrad_fused(self, A, B, C, r1_s=None, r1_w=None, mask=None, colsum=None):      # sherf_bwd_gemm_dgrad_fused (colsum accumulates)
         y = A.tensor() @ B.tensor()
         if r1_s is not None:
@@ -62,10 +67,13 @@ class EmuOps:
         xh.tensor().copy_(xc * iv); inv.tensor().copy_(iv)
         y.tensor().copy_(xc * iv * w.tensor().view(-1) + b.tensor().view(-1))
 
-    def ln_bwd(self, dy, w, xh, inv, dx, dw, db):                    # sherf_bwd_ln_bwd (dw, db accumulate)
+    def ln_bwd(self, dy, w, xh, inv, dx, dw, db, addend=None):       # sherf_bwd_ln_bwd / sherf_bwd_ln_bwd_add (dw, db accumulate)
+        add = None if addend is None else addend.tensor().clone()
         DY, XH = dy.tensor(), xh.tensor()
         g = DY * w.tensor().view(-1)
         dx.tensor().copy_(inv.tensor() * (g - g.mean(-1, keepdim=True) - XH * (g * XH).mean(-1, keepdim=True)))
+        if add is not None:
+            dx.tensor().add_(add)
         dw.tensor().add_((DY * XH).sum(0, keepdim=True)); db.tensor().add_(DY.sum(0, keepdim=True))
 
     def attn_fwd(self, qkv, att, o):                                 # sherf_bwd_attn_fwd

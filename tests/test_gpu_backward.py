@@ -99,6 +99,42 @@ def test_fused_data_gradient_store_on_device():
             _same(c_c, c_g, 1e-5); _same(o_c, o_g, 1e-4)
 
 
+def test_residual_joins_in_the_store_on_device():
+    """sherf_bwd_gemm_bias_act_add (the transformer's to_out / net.3 with their residual) on the fused path (N = 32, K = 32 / 48, aligned rows) and the
+    fallback, and sherf_bwd_ln_bwd_add, against the emulator."""
+    from sherf_amd.backward_dense import HipOps, Mat
+    from sherf_amd import _lib
+    from tests.bwd_emulator import EmuOps
+    e, h = EmuOps(), HipOps()
+    for rows, K, N, lda, fused in ((30001, 48, 32, 48, True), (7001, 32, 32, 36, True), (900, 32, 32, 33, False), (700, 64, 32, 64, False)):
+        a_c, a_g = _pair(rows, K, ld=lda, seed=41, off=0)
+        b_c, b_g = _pair(N, K, ld=K + 1, seed=42)
+        bi_c, bi_g = _pair(1, N, seed=43)
+        r_c, r_g = _pair(rows, N, ld=N, seed=44, off=0)
+        for act in (0, 1):
+            c_c, c_g = _pair(rows, N, ld=N + 4, seed=45)
+            e.gemm_bias_act_add(1, a_c, b_c, c_c, bi_c, act, r_c); h.gemm_bias_act_add(1, a_g, b_g, c_g, bi_g, act, r_g)
+            torch.cuda.synchronize()
+            assert (_lib.lib_bwd().sherf_bwd_gemm_last_path() == 5) == fused
+            _same(c_c, c_g, 1e-5)
+    rows = 5003
+    dy_c, dy_g = _pair(rows, 32, seed=46, off=0)
+    x = torch.randn(rows, 32, generator=torch.Generator().manual_seed(47))
+    w_c, w_g = _pair(1, 32, seed=48, off=0)
+    xh = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    iv = 1.0 / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    ad_c, ad_g = _pair(rows, 32, seed=49, off=0)
+    mk = lambda t, dev: Mat(t.contiguous().view(-1).to(dev), t.shape[0], t.shape[1])
+    outs = []
+    for ops, dev, dy, w, ad in ((e, 'cpu', dy_c, w_c, ad_c), (h, 'cuda', dy_g, w_g, ad_g)):
+        dx, dw, db = Mat(torch.zeros(rows * 32, device=dev), rows, 32), Mat(torch.zeros(32, device=dev), 1, 32), Mat(torch.zeros(32, device=dev), 1, 32)
+        ops.ln_bwd(dy, w, mk(xh, dev), mk(iv, dev), dx, dw, db, addend=ad)
+        outs.append((dx, dw, db))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        _same(a, b, 1e-4)
+
+
 def test_bwd_elementwise_kernels():
     from sherf_amd.backward_dense import HipOps, Mat
     from tests.bwd_emulator import EmuOps

@@ -97,6 +97,36 @@ def test_streaming_tall_gemm_is_the_general_kernel_bit_for_bit(cpu_lib, monkeypa
     monkeypatch.setenv('SHERF_EXPERIMENT', '0')
 
 
+def test_residual_joins_in_the_store(cpu_lib, monkeypatch):
+    """sherf_bwd_gemm_bias_act_add: C = act(A . B^T + bias) + addend on the streaming kernel's fused store (N <= 32, K = 32 / 48, aligned rows: last_path 5) and
+    as product + add pass (anything else); sherf_bwd_ln_bwd_add = sherf_bwd_ln_bwd + addend.  Against float64 / the plain entry point."""
+    h = CpuKernelOps(cpu_lib, monkeypatch)
+    cpu_lib.sherf_bwd_gemm_last_path.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(31)
+
+    def mat(r, c, ld, scale=1.0):
+        return Mat(torch.randn(r * ld, generator=g) * scale, r, c, ld)
+    for rows, K, N, lda, fused in ((301, 48, 32, 48, True), (97, 32, 32, 36, True), (64, 32, 20, 32, True), (90, 32, 32, 33, False), (70, 64, 32, 64, False), (50, 48, 40, 48, False)):
+        A, B, bias, R = mat(rows, K, lda), mat(N, K, K + 1), mat(1, N, N), mat(rows, N, N + 2)
+        for act, with_bias in ((0, True), (1, True), (0, False)):
+            C = Mat(torch.full((rows * (N + 3),), 9.0), rows, N, N + 3)
+            h.gemm_bias_act_add(1, A, B, C, bias if with_bias else None, act, R)
+            assert (cpu_lib.sherf_bwd_gemm_last_path() == 5) == fused, (rows, K, N, lda)
+            ref = A.tensor().double() @ B.tensor().double().t() + (bias.tensor().double() if with_bias else 0.0)
+            ref = (ref.clamp(min=0) if act else ref) + R.tensor().double()
+            assert float((C.tensor().double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max()), (rows, K, N, act)
+            assert bool((torch.as_strided(C.buf, (rows, 3), (N + 3, 1), N) == 9.0).all())
+    rows = 777
+    dy, xh, w, inv, add = mat(rows, 32, 32), mat(rows, 32, 32), mat(1, 32, 32), mat(rows, 1, 1), mat(rows, 32, 32)
+    outs = []
+    for use_add in (0, 1):
+        dx, dw, db = Mat(torch.zeros(rows * 32), rows, 32), Mat(torch.zeros(32), 1, 32), Mat(torch.zeros(32), 1, 32)
+        h.ln_bwd(dy, w, xh, inv, dx, dw, db, addend=add if use_add else None)
+        outs.append((dx.buf.clone(), dw.buf.clone(), db.buf.clone()))
+    assert torch.equal(outs[1][0], outs[0][0] + add.buf)
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-5) and torch.allclose(outs[1][2], outs[0][2], rtol=1e-5, atol=1e-5)      # (atomics: order-dependent rounding)
+
+
 def test_fused_data_gradient_store(cpu_lib, monkeypatch):
     """sherf_bwd_gemm_dgrad_fused: C = A . B (+ rank-one term) masked by the layer below's activations, column sums accumulated -- the one-kernel
     path (N, K = 128, aligned rows: last_path 5) and the composition of separate kernels (anything else) against float64, every optional part on / off,
