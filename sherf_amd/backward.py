@@ -33,11 +33,13 @@ def composite_backward(renderer, d_rgb, d_acc, ray_directions, near, far, white_
     ws, R, S, cap = last['ws'], last['R'], last['S'], last['cap']
     f32 = lambda t, *shape: t.detach().to(dtype=torch.float32).contiguous().view(*shape)
     P = _lib.ptr
-    out = torch.zeros(cap, 4, device=ws['sample_out'].device)
+    nv = int(ws['counters'][0])                                   # (the forward is long done: the loss has been formed from its output)
+    # rows of the frame's valid samples only: the kernel touches rows < nv (every ray's base + count lies below it), and the buffer used to be
+    # capacity = R x S rows -- a 268 MB zero fill per step at 512 x 512 x 64 for 12 MB of gradient
+    out = torch.zeros(max(nv, 1), 4, device=ws['sample_out'].device)
     _lib.call('sherf_composite_compact_bwd', P(ws['ray_base']), P(ws['ray_cnt']), P(ws['cs_idx']), P(ws['sample_out']),
               P(f32(ray_directions, R, 3)), P(f32(near, R)), P(f32(far, R)), R, S, 1 if white_back else 0,
               P(f32(d_rgb, R, 3)), P(f32(d_acc, R)), P(out), _lib.stream())
-    nv = int(ws['counters'][0])
     return out[:nv]
 
 
