@@ -76,6 +76,53 @@ def test_bwd_gemm_all_transpositions():
             _same(c_c, c_g, 1e-4)
 
 
+def test_round5_gemm_kernels_on_device(monkeypatch):
+    """The backward's round-5 GEMM kernels on the MI355X at the decoder / transformer shapes: tall_stream_kernel = the general kernel BIT FOR BIT
+    (SHERF_EXPERIMENT bit 6 selects the general one), incl. the padded K = 71 / 199 operands with NaN in the padding; wgrad_shared_kernel /
+    wgrad_solo_kernel = round 2's kernel (bit 7) to fp32 rounding (atomics: order-dependent) and both against float64."""
+    from sherf_amd.backward_dense import HipOps, Mat
+    from sherf_amd import _lib
+    h = HipOps()
+    g = torch.Generator().manual_seed(51)
+
+    def mat(r, c, ld, scale=1.0):
+        return Mat((torch.randn(r * ld, generator=g) * scale).cuda(), r, c, ld)
+    last = _lib.lib_bwd().sherf_bwd_gemm_last_path
+    rows = 20011
+    for K, N, tB in ((128, 128, 1), (128, 128, 0), (128, 71, 0), (128, 199, 0), (64, 187, 0), (32, 144, 1), (48, 32, 1), (32, 32, 1), (144, 32, 0), (71, 128, 1), (199, 128, 1), (187, 64, 1)):
+        lda = K + 4 if K % 16 == 0 else (K + 15) // 16 * 16
+        A, B, bias = mat(rows, K, lda, 1e-2), (mat(N, K, K + 1) if tB else mat(K, N, N + 2)), mat(1, N, N)
+        if K % 16:
+            torch.as_strided(A.buf, (rows, lda - K), (lda, 1), K).fill_(float('nan'))
+        outs = []
+        for general in (1, 0):
+            monkeypatch.setenv('SHERF_EXPERIMENT', '64' if general else '0')
+            C = Mat(torch.full((rows * (N + 5),), 7.0).cuda(), rows, N, N + 5)
+            h.gemm_bias_act(0, tB, A, B, C, bias, 1)
+            torch.cuda.synchronize()
+            assert last() == (1 if general else 3), (K, N, tB)
+            outs.append(C.buf.clone())
+        assert torch.equal(outs[0], outs[1]), (K, N, tB)
+        a64 = torch.as_strided(A.buf, (rows, K), (lda, 1)).double()
+        ref = (a64 @ (B.tensor().double().t() if tB else B.tensor().double()) + bias.tensor().double()).clamp(min=0)
+        assert float((torch.as_strided(outs[1], (rows, N), (N + 5, 1)).double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    rows = 70001
+    for M, N in ((128, 128), (128, 71), (128, 199), (64, 187), (144, 32), (32, 32), (32, 48), (3, 64), (1, 128)):
+        dy, x = mat(rows, M, M + 3, 1e-3), mat(rows, N, N + 1)
+        ref = dy.tensor().double().t() @ x.tensor().double()
+        outs = []
+        for old in (1, 0):
+            monkeypatch.setenv('SHERF_EXPERIMENT', '128' if old else '0')
+            C = Mat(torch.zeros(M * N).cuda(), M, N)
+            h.gemm(1, 0, dy, x, C)
+            torch.cuda.synchronize()
+            assert last() == (2 if old else 4), (M, N)
+            outs.append(C.tensor().double())
+        for o in outs:
+            assert float((o - ref).abs().max()) <= 3e-6 * float(ref.abs().max()) + 1e-12, (M, N)
+    monkeypatch.setenv('SHERF_EXPERIMENT', '0')
+
+
 def test_fused_data_gradient_store_on_device():
     """sherf_bwd_gemm_dgrad_fused on the MI355X: the one-kernel path (N, K = 128, aligned rows) and the composition of separate kernels against the
     emulator, with and without the rank-one term / mask / column sums; 40 000 rows so that every workgroup's column-sum reduction takes part."""
