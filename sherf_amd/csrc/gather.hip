@@ -599,11 +599,11 @@ __device__ __forceinline__ int bin_of(const sherf_vox_level& lev, const VoxTap& 
 }
 
 // scratch words: [0] number of non-empty bins, [4 ..) counts[n_bins], cursor[n_bins], offsets[n_bins], nonempty[n_bins], bin[cap], sorted[cap]
-struct BinWs { int32_t *n_nonempty, *counts, *cursor, *offsets, *nonempty, *bin, *sorted; int n_bins; };
+struct BinWs { int32_t *n_nonempty, *counts, *cursor, *offsets, *nonempty, *bin, *sorted, *blocks; int n_bins; };
 __host__ __device__ inline BinWs bin_ws(int32_t* scratch, int n_bins, int64_t cap) {
     BinWs w;
     w.n_nonempty = scratch; w.counts = scratch + 4; w.cursor = w.counts + n_bins; w.offsets = w.cursor + n_bins; w.nonempty = w.offsets + n_bins;
-    w.bin = w.nonempty + n_bins; w.sorted = w.bin + cap; w.n_bins = n_bins;
+    w.bin = w.nonempty + n_bins; w.sorted = w.bin + cap; w.blocks = w.sorted + cap; w.n_bins = n_bins;          // blocks[ceil(n_bins / 1024)]: run order only
     return w;
 }
 
@@ -817,6 +817,272 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
     for (int i = tid; i < 96; i += kBinNT) unsafeAtomicAdd(d_tok_bias + i, s_bias[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same scatter over the samples SORTED by the finest tapped voxel cell they fall in (1 cm), every level's sums in registers.
+// The kernel above keeps the coarsest level's eight corner rows in registers because all samples of a 4 cm bin share them, and sends the two
+// finer levels' 16 corners of every sample to memory: 24 of a sample's 34 atomic instructions (256 B each; the scatter's 3.7 ms are ~8 GB of
+// read-modify-write traffic).  With the samples in the order of their finest cell (x fastest) the corner rows of EVERY level stay the same over runs of
+// consecutive samples -- ~20 samples per 1 cm cell at the bench subject, longer at the coarser levels -- so a wave walks a contiguous stretch of
+// the sorted list, adds into 36 registers per lane and sends a level's eight rows to memory when that level's cell changes (run-length): the
+// voxel atomics drop from 24 per sample to ~12 per run; the tri-plane and feature-map corners (10 per sample) the same way over the runs of their
+// own base texel.  Measured on the MI355X (tools/scatter_bench.py, 690 K samples): 4.1 -> 2.4-2.5 ms, of which sorting + the walk without any tap 0.96; a 1 cm cell
+// holds 4.9 samples on average, so a finest-level row still receives one flush per adjacent cell -- ~260 M atomically added ELEMENTS in all (round 3's kernel: 1.5 G),
+// and that count, not bytes or latency, is what the time follows (~175 G elements / s through the L2 atomic units).  The bins become the finest level's cells (~1.1 M at the bench subject, most of them empty):
+// their scan runs on every workgroup (local scans + block totals; the one-workgroup scan above would walk 1 100 bins per thread).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bin_scan_blocks_kernel(BinWs w) {          // offsets[b] = exclusive scan inside the block of 1024 bins; blocks[blk] = its total
+    __shared__ int s_v[1024];
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    const int v = b < w.n_bins ? w.counts[b] : 0;
+    s_v[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int a = threadIdx.x >= (unsigned)o ? s_v[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_v[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (b < w.n_bins) w.offsets[b] = s_v[threadIdx.x] - v;
+    if (threadIdx.x == 1023) w.blocks[blockIdx.x] = s_v[1023];
+}
+
+__global__ void __launch_bounds__(1024) bin_scan_top_kernel(BinWs w, int n_blocks) {        // blocks[] -> exclusive scan, by one workgroup
+    __shared__ int s_v[1024];
+    int carry = 0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < n_blocks ? w.blocks[i] : 0;
+        s_v[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int a = threadIdx.x >= (unsigned)o ? s_v[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_v[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < n_blocks) w.blocks[i] = carry + s_v[threadIdx.x] - v;
+        const int tot = s_v[1023];
+        __syncthreads();
+        carry += tot;
+    }
+}
+
+__global__ void __launch_bounds__(256) bin_fill_blocks_kernel(const int32_t* __restrict__ counters, int64_t capacity, BinWs w) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nv) return;
+    const int b = w.bin[c];
+    w.sorted[w.blocks[b >> 10] + w.offsets[b] + atomicAdd(w.cursor + b, 1)] = (int32_t)c;
+}
+
+__global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_runs_kernel(const int32_t* __restrict__ counters, int64_t capacity, const float* __restrict__ geom,
+                                                                        const float4* __restrict__ d_tokens, int P, int Hf, int Wf, int H, int W, LevelsBwd lv,
+                                                                        const float* __restrict__ bounds, const float* __restrict__ vox_min, int3 vox_sh,
+                                                                        const int32_t* __restrict__ sorted, float4* __restrict__ d_planes_f,
+                                                                        float4* __restrict__ d_feat_f, float* __restrict__ d_tok_bias, int dbg) {
+    const bool do_pix = !(dbg & 16384), do_vox = !(dbg & 32768), do_pl = !(dbg & 65536);          // (timing ablations as above)
+    __shared__ float s_bias[96];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, c31 = lane & 31;
+    const sherf_vox_level levs[3] = {lv.l[0], lv.l[1], lv.l[2]};
+    float* const drows[3] = {lv.d_rows[0], lv.d_rows[1], lv.d_rows[2]};
+    const float* dt = reinterpret_cast<const float*>(d_tokens);
+    float* const dpl = reinterpret_cast<float*>(d_planes_f);
+    float* const dfm = reinterpret_cast<float*>(d_feat_f);
+    float bs0 = 0.f, bs1 = 0.f;
+    // this wave's contiguous stretch of the sorted list, in chunks of 64 samples
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_chunks = (nv + 63) >> 6, n_waves = (int64_t)gridDim.x * (kBinNT / 64);
+    const int64_t per = (n_chunks + n_waves - 1) / n_waves, wid = (int64_t)blockIdx.x * (kBinNT / 64) + wv;
+    const int64_t ch0 = min(wid * per, n_chunks), ch1 = min(ch0 + per, n_chunks);
+    float acc[3][8], accb[3][4];                   // level L: corner k x channel `lane` (slots 0-1); corner pair x channel 64 + c31 (slot 2)
+    int cur[3] = {-1, -1, -1};                     // the cell of the running sums (wave-uniform); -1: none
+    int rows[3] = {-1, -1, -1};                    // lanes 0-7: the row of corner `lane` of that cell
+#pragma unroll
+    for (int L = 0; L < 3; ++L) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[L][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) accb[L][k] = 0.f;
+    }
+    // the same for the tri-planes (plane p: corner (dx = half, dy) x channel c31) and the pixel-aligned feature map (corner k x channel `lane`): samples of one
+    // 1 cm cell fall on a handful of texels
+    float accp[3][2], accf[4];
+    int curp[3] = {-1, -1, -1}, curf = -1, tgp[3] = {-1, -1, -1}, tgf = -1;       // tgp[p] / tgf: lanes 0-3 hold the texel of corner `lane`
+#pragma unroll
+    for (int p = 0; p < 3; ++p) accp[p][0] = accp[p][1] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) accf[k] = 0.f;
+    auto flush_plane = [&](int p) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int tA = __builtin_amdgcn_readlane(tgp[p], 2 * dy), tB = __builtin_amdgcn_readlane(tgp[p], 2 * dy + 1);
+            const int tg = half ? tB : tA;
+            if (tg >= 0) unsafeAtomicAdd(dpl + (size_t)tg * 32 + c31, accp[p][dy]);
+            accp[p][dy] = 0.f;
+        }
+    };
+    auto flush_feat = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tg = __builtin_amdgcn_readlane(tgf, k);
+            if (tg >= 0) unsafeAtomicAdd(dfm + (size_t)tg * 64 + lane, accf[k]);
+            accf[k] = 0.f;
+        }
+    };
+    auto flush = [&](int L) {                      // a level's running sums to memory: one atomic per row and channel
+        float* drow = drows[L];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = __builtin_amdgcn_readlane(rows[L], k);
+            if (r >= 0) unsafeAtomicAdd(drow + (size_t)r * 96 + lane, acc[L][k]);
+            acc[L][k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rA = __builtin_amdgcn_readlane(rows[L], 2 * k), rB = __builtin_amdgcn_readlane(rows[L], 2 * k + 1);
+            const int r = half ? rB : rA;
+            if (r >= 0) unsafeAtomicAdd(drow + (size_t)r * 96 + 64 + c31, accb[L][k]);
+            accb[L][k] = 0.f;
+        }
+    };
+    for (int64_t ch = ch0; ch < ch1; ++ch) {
+        // ---- (1) lane = sample ----
+        const int64_t base = ch << 6;
+        const bool live = base + lane < nv;
+        const int cs = live ? sorted[base + lane] : 0;
+        int tv[24], tp[12], tf[4], ck[3], kp[3], kf;
+        float wvx[24], wpl[12], wfm[4];
+        {
+            const float* gm = geom + (int64_t)cs * 8;
+            float n[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) n[a] = 2.f * (gm[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const PlaneTap t = plane_tap(p, n, P);
+                kp[p] = (t.yi + 2) * (P + 4) + (t.xi + 2);                 // the stencil's base texel (components in [-2, P + 1] after the clamp)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
+                    tp[4 * p + k] = (live && do_pl && xx >= 0 && xx < P && yy >= 0 && yy < P) ? (p * P + yy) * P + xx : -1;
+                    wpl[4 * p + k] = (live && do_pl) ? ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy) : 0.f;
+                }
+            }
+            const PixTap t = pix_tap(gm, W, H, Wf, Hf);
+            kf = (t.yi + 2) * (Wf + 4) + (t.xi + 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = t.xi + (k & 1), yy = t.yi + (k >> 1);
+                tf[k] = (live && do_pix && xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) ? yy * Wf + xx : -1;
+                wfm[k] = (live && do_pix) ? ((k & 1) ? t.fx : 1.f - t.fx) * ((k >> 1) ? t.fy : 1.f - t.fy) : 0.f;
+            }
+            float gx, gy, gz;
+            vox_grid_coords(gm, vox_min, vox_sh, gx, gy, gz);
+#pragma unroll
+            for (int L = 0; L < 3; ++L) {
+                const sherf_vox_level lev = levs[L];
+                const VoxTap vt = vox_tap(lev, gx, gy, gz);
+                ck[L] = bin_of(lev, vt);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int xx = vt.xi + (k & 1), yy = vt.yi + ((k >> 1) & 1), zz = vt.zi + (k >> 2);
+                    wvx[8 * L + k] = (live && do_vox) ? ((k & 1) ? vt.fx : 1.f - vt.fx) * (((k >> 1) & 1) ? vt.fy : 1.f - vt.fy) * ((k >> 2) ? vt.fz : 1.f - vt.fz) : 0.f;
+                    const bool in = live && do_vox && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
+                    // (the occupancy record is loaded unconditionally from a clamped key and the result selected: a load inside the branch is waited for on the spot)
+                    const int key = in ? (zz * lev.H + yy) * lev.W + xx : 0;
+                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                    const uint32_t bit = 1u << (key & 31);
+                    tv[8 * L + k] = (in && (rr.x & bit)) ? (int)(rr.y + __popc(rr.x & (bit - 1u))) : -1;
+                }
+            }
+        }
+        // ---- (2) lane = channel ----
+        const int nact = (int)min((int64_t)64, nv - base);
+        // (the gradient rows are loaded where they are used: four samples ahead, or staged through LDS 32 samples at a time, measured the same 2.2 ms --
+        //  the walk does not wait for them; what is left is the atomic units' element rate, see the header)
+        {
+          for (int sidx = 0; sidx < nact; ++sidx) {
+            const int c = __builtin_amdgcn_readlane(cs, sidx);
+            const int64_t dbase = ((((int64_t)(c >> 5) * 3) * 8 + (c31 >> 2)) * 32 + (c & 31)) * 4 + (c31 & 3);       // d_tokens[tile][slot][quad][sample j] float4
+            const float dp0 = dt[dbase], dp1 = dt[dbase + 1024], d1 = dt[dbase + 2048];            // channel c31 of slots 0, 1, 2 (both halves)
+            const float d0 = half ? dp1 : dp0;                                                       // channel `lane` of slots 0-1
+            bs0 += d0; bs1 += half ? 0.f : d1;
+#define SHERF_RL(v) __builtin_amdgcn_readlane((v), sidx)
+#define SHERF_RLF(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), sidx))
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float dpv = p == 0 ? dp0 : (p == 1 ? dp1 : d1);
+                const int key = SHERF_RL(kp[p]);
+                if (key != curp[p]) {
+                    if (curp[p] >= 0) flush_plane(p);
+                    curp[p] = key;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = SHERF_RL(tp[4 * p + k]);
+                        if (lane == k) tgp[p] = r;
+                    }
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const float wA = SHERF_RLF(wpl[4 * p + 2 * dy]), wB = SHERF_RLF(wpl[4 * p + 2 * dy + 1]);
+                    accp[p][dy] += (half ? wB : wA) * dpv;
+                }
+            }
+            {
+                const int key = SHERF_RL(kf);
+                if (key != curf) {
+                    if (curf >= 0) flush_feat();
+                    curf = key;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = SHERF_RL(tf[k]);
+                        if (lane == k) tgf = r;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) accf[k] += SHERF_RLF(wfm[k]) * d0;
+            }
+#pragma unroll
+            for (int L = 0; L < 3; ++L) {
+                const int cell = SHERF_RL(ck[L]);
+                if (cell != cur[L]) {                                      // (wave-uniform) the level's cell changes: its sums leave, its rows are re-read
+                    if (cur[L] >= 0) flush(L);
+                    cur[L] = cell;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = SHERF_RL(tv[8 * L + k]);
+                        if (lane == k) rows[L] = r;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[L][k] += SHERF_RLF(wvx[8 * L + k]) * d0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float wA = SHERF_RLF(wvx[8 * L + 2 * k]), wB = SHERF_RLF(wvx[8 * L + 2 * k + 1]);
+                    accb[L][k] += (half ? wB : wA) * d1;
+                }
+            }
+#undef SHERF_RL
+#undef SHERF_RLF
+          }
+        }
+    }
+#pragma unroll
+    for (int L = 0; L < 3; ++L)
+        if (cur[L] >= 0) flush(L);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        if (curp[p] >= 0) flush_plane(p);
+    if (curf >= 0) flush_feat();
+    // d_tok_bias
+    for (int i = tid; i < 96; i += kBinNT) s_bias[i] = 0.f;
+    __syncthreads();
+    atomicAdd(s_bias + lane, bs0);
+    if (lane < 32) atomicAdd(s_bias + 64 + lane, bs1);
+    __syncthreads();
+    for (int i = tid; i < 96; i += kBinNT) unsafeAtomicAdd(d_tok_bias + i, s_bias[i]);
+}
+
 }  // namespace
 
 extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
@@ -892,8 +1158,9 @@ extern "C" int sherf_gather_tokens_bwd(const int32_t* counters, const float* geo
 
 static int bwd_bins(const sherf_vox_level& l2) { return (l2.D + 4) * (l2.H + 4) * (l2.W + 4); }
 
-static int64_t bwd_scratch_words(const sherf_vox_level* levels_host, int64_t capacity) {
-    return 4 + (int64_t)4 * bwd_bins(levels_host[2]) + 2 * capacity;
+static int64_t bwd_scratch_words(const sherf_vox_level* levels_host, int64_t capacity) {      // (bins of the finest tapped level: round 5's run order; the coarsest level's need less)
+    const int64_t nb = bwd_bins(levels_host[0]) > bwd_bins(levels_host[2]) ? bwd_bins(levels_host[0]) : bwd_bins(levels_host[2]);
+    return 4 + 4 * nb + 2 * capacity + (nb + 1023) / 1024 + 4;
 }
 
 extern "C" int sherf_gather_bwd_scratch_words(const sherf_vox_level* levels_host, int64_t capacity, int64_t* words_host) {
@@ -918,9 +1185,26 @@ extern "C" int sherf_gather_tokens_bwd_binned(const int32_t* counters, const flo
     SHERF_CHECK_ARG(scratch_words >= bwd_scratch_words(levels_host, capacity));
     lv.d_rows[0] = d_rows0; lv.d_rows[1] = d_rows1; lv.d_rows[2] = d_rows2;
     const int3 sh = make_int3(vox_sh_host[0], vox_sh_host[1], vox_sh_host[2]);
+    hipStream_t st = as_stream(stream);
+    if (!(sherf_experiment() & 256)) {               // round 5: samples in the order of their finest cell, every level's sums in registers (SHERF_EXPERIMENT bit 8: round 3's kernel)
+        SHERF_CHECK_ARG((int64_t)(lv.l[0].D + 4) * (lv.l[0].H + 4) * (lv.l[0].W + 4) < (int64_t)1 << 30);
+        const int nb = bwd_bins(lv.l[0]), n_blocks = (nb + 1023) / 1024;
+        const BinWs w0 = bin_ws(scratch, nb, capacity);
+        SHERF_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)(4 + 2 * (int64_t)nb) * sizeof(int32_t), st));
+        const unsigned sb0 = (unsigned)((capacity + 255) / 256);
+        hipLaunchKernelGGL(bin_count_kernel, dim3(sb0), dim3(256), 0, st, counters, geom, lv.l[0], vox_min, sh, capacity, w0);
+        hipLaunchKernelGGL(bin_scan_blocks_kernel, dim3(n_blocks), dim3(1024), 0, st, w0);
+        hipLaunchKernelGGL(bin_scan_top_kernel, dim3(1), dim3(1024), 0, st, w0, n_blocks);
+        hipLaunchKernelGGL(bin_fill_blocks_kernel, dim3(sb0), dim3(256), 0, st, counters, capacity, w0);
+        const int64_t chunks = (capacity + 63) / 64;
+        const int grid = (int)(chunks / 4 + 1 < 4 * n_cus() ? chunks / 4 + 1 : 4 * n_cus());
+        hipLaunchKernelGGL(gather_tokens_bwd_runs_kernel, dim3(grid), dim3(kBinNT), 0, st, counters, capacity, geom, reinterpret_cast<const float4*>(d_tokens),
+                           P, Hf, Wf, H, W, lv, bounds, vox_min, sh, w0.sorted, reinterpret_cast<float4*>(d_planes_f), reinterpret_cast<float4*>(d_feat_f),
+                           d_tok_bias, g_sherf_debug);
+        SHERF_LAUNCH_CHECK();
+    }
     const int n_bins = bwd_bins(lv.l[2]);
     const BinWs w = bin_ws(scratch, n_bins, capacity);
-    hipStream_t st = as_stream(stream);
     SHERF_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)(4 + 2 * (int64_t)n_bins) * sizeof(int32_t), st));      // list length, counts, cursors
     const unsigned sb = (unsigned)((capacity + 255) / 256);
     hipLaunchKernelGGL(bin_count_kernel, dim3(sb), dim3(256), 0, st, counters, geom, lv.l[2], vox_min, sh, capacity, w);

@@ -547,10 +547,12 @@ def test_batchnorm_backward_and_small_encoder_kernels():
     assert G.rel(di_g.tensor().cpu(), di_c.tensor()) < 1e-4 and G.rel(dw_g.tensor().cpu(), dw_c.tensor()) < 1e-4
 
 
-@pytest.mark.parametrize('binned', [True, False])
-def test_gather_backward_kernel(binned):
-    """sherf_gather_tokens_bwd_binned (the step's form: samples binned by coarse voxel cell, LDS windows) and sherf_gather_tokens_bwd (direct
-    atomics) against the oracle's tap stencils, in the kernel's folded channel-last layouts."""
+@pytest.mark.parametrize('binned', ['runs', True, False])
+def test_gather_backward_kernel(binned, monkeypatch):
+    """sherf_gather_tokens_bwd_binned -- 'runs': the step's form since round 5 (samples sorted by their finest voxel cell, every level's sums in registers,
+    run-length flushes); True: round 3's form (binned by the coarsest cell; SHERF_EXPERIMENT bit 8) -- and sherf_gather_tokens_bwd (direct atomics)
+    against the oracle's tap stencils, in the kernel's folded channel-last layouts."""
+    monkeypatch.setenv('SHERF_EXPERIMENT', '256' if binned is True else '0')
     import ctypes
     from oracle import backward_explicit as BX
     from sherf_amd import _lib
@@ -583,7 +585,8 @@ def test_gather_backward_kernel(binned):
         scratch = torch.full((words.value,), -7, dtype=torch.int32, device='cuda')
         _lib.call('sherf_gather_tokens_bwd_binned', *args, _lib.ptr(scratch), words.value, _lib.stream())
         torch.cuda.synchronize()
-        assert int(scratch[4:4 + (words.value - 4 - 2 * last['cap']) // 4].sum()) == n
+        lv = last['levels_struct'][0 if binned == 'runs' else 2]
+        assert int(scratch[4:4 + (lv.D + 4) * (lv.H + 4) * (lv.W + 4)].sum()) == n
     else:
         _lib.call('sherf_gather_tokens_bwd', *args, _lib.stream())
     torch.cuda.synchronize()

@@ -579,17 +579,26 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     assert fwd_lib.sherf_gather_bwd_scratch_words(levels, n, ctypes.byref(words)) == 0 and words.value > 2 * n
     scratch = torch.full((words.value,), -7, dtype=torch.int32)                 # (not zeroed by the caller)
     dbg = ctypes.c_int.in_dll(fwd_lib, 'g_sherf_debug')
-    for binned in (True, 8192, False):                 # the step's form (binned, LDS windows); the same with one-voxel windows (spill path); the direct one
-      dbg.value = binned if binned is not True and binned else 0
+    nb0 = (levels[0].D + 4) * (levels[0].H + 4) * (levels[0].W + 4)          # round 5's run order bins by the finest tapped level's cells
+    assert words.value == 4 + 4 * nb0 + 2 * n + (nb0 + 1023) // 1024 + 4
+    for binned in ('runs', True, 8192, False):         # round 5's form (sorted by finest cell, every level's sums in registers); round 3's (binned by coarsest
+      # cell: SHERF_EXPERIMENT bit 8); the same with the coarsest level through memory; the direct one
+      os.environ['SHERF_EXPERIMENT'] = '0' if binned == 'runs' else '256'
+      dbg.value = binned if binned not in (True, 'runs') and binned else 0
       d_planes_f, d_feat_f, d_bias = torch.zeros(3 * P * P, 32), torch.zeros(Hf * Wf, 64), torch.zeros(96)
       d_rows = [torch.zeros(k['cap'], 96) for k in kers]
       if binned:
         assert fwd_lib.sherf_gather_tokens_bwd_binned(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
                                                       _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), _P(scratch),
                                                       words.value, None) == 0
-        cnt = scratch[4:4 + (words.value - 4 - 2 * n) // 4]
+        nb = nb0 if binned == 'runs' else (levels[2].D + 4) * (levels[2].H + 4) * (levels[2].W + 4)
+        cnt = scratch[4:4 + nb]
         assert int(cnt.sum()) == n and int(scratch[0]) == int((cnt > 0).sum())                  # every sample binned once; the list of non-empty bins
-        assert sorted(scratch[words.value - n:].tolist()) == list(range(n))                      # the sorted order is a permutation of the samples
+        order = scratch[4 + 4 * nb + n:4 + 4 * nb + 2 * n]
+        assert sorted(order.tolist()) == list(range(n))                                          # the sorted order is a permutation of the samples
+        if binned == 'runs':                                                                      # ... in ascending order of the samples' finest cell
+            keys = scratch[4 + 4 * nb:4 + 4 * nb + n][order.long()]
+            assert bool((keys[1:] >= keys[:-1]).all()) and len(set(keys.tolist())) > 10
         assert fwd_lib.sherf_gather_tokens_bwd_binned(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
                                                       _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), _P(scratch),
                                                       words.value - 1, None) != 0               # scratch too small
@@ -597,6 +606,7 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
         assert fwd_lib.sherf_gather_tokens_bwd(_P(counters), _P(geom), _P(d_tiled), P, Hf, Wf, H, W, levels, _P(bounds), _P(vox_min), vox_sh, n,
                                                _P(d_planes_f), _P(d_feat_f), _P(d_rows[0]), _P(d_rows[1]), _P(d_rows[2]), _P(d_bias), None) == 0
       _check_scatter(BX, r, dt, n, P, Hf, Wf, H, W, bnd, d_planes_f, d_feat_f, d_rows, d_bias, rel)
+    os.environ['SHERF_EXPERIMENT'] = '0'
 
 
 def _check_scatter(BX, r, dt, n, P, Hf, Wf, H, W, bnd, d_planes_f, d_feat_f, d_rows, d_bias, rel):

@@ -64,17 +64,21 @@ def main():
     cnt = None
     print(f'{cfg}: {n} valid samples, levels ' + ' '.join(f"{int(L[t[0]]['n_rows'])}" for t in taps) + f' rows, P {P}, feature map {Hf}x{Wf}')
     print(f'direct form                         {timed(lambda: _lib.call("sherf_gather_tokens_bwd", *args, _lib.stream())):8.3f} ms')
-    for name, bits in (('binned', 0), ('binned, no pixel taps', 16384), ('binned, no voxel taps', 32768), ('binned, no plane taps', 65536),
-                       ('binned, no taps at all (sort + zero + flush scan)', 16384 | 32768 | 65536), ('binned, one-voxel windows (spill path)', 8192)):
+    for name, bits in (('sorted by finest cell, run-length sums (round 5)', 0), ('... no pixel taps', 16384), ('... no voxel taps', 32768), ('... no plane taps', 65536),
+                       ('... no taps at all (sort + walk)', 16384 | 32768 | 65536)):
         lib.sherf_set_debug(bits)
         t = timed(lambda: _lib.call('sherf_gather_tokens_bwd_binned', *args, _lib.ptr(scratch), words.value, _lib.stream()))
         print(f'{name:52s} {t:8.3f} ms')
         if cnt is None:
-            nb = (words.value - 4 - 2 * last['cap']) // 4
+            l0 = last['levels_struct'][0]
+            nb = (l0.D + 4) * (l0.H + 4) * (l0.W + 4)                 # (round 5: the bins are the finest tapped level's cells)
             cnt = scratch[4:4 + nb].cpu().numpy()
             ne = cnt[cnt > 0]
             print(f'    bins {nb}, non-empty {ne.size}, samples per non-empty bin: mean {ne.mean():.1f} median {np.median(ne):.0f} p90 {np.percentile(ne, 90):.0f} max {ne.max()}')
     lib.sherf_set_debug(0)
+    os.environ['SHERF_EXPERIMENT'] = '256'
+    print(f"round 3's kernel (binned by the coarsest cell)      {timed(lambda: _lib.call('sherf_gather_tokens_bwd_binned', *args, _lib.ptr(scratch), words.value, _lib.stream())):8.3f} ms")
+    os.environ['SHERF_EXPERIMENT'] = '0'
 
 
 if __name__ == '__main__':
