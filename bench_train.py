@@ -138,11 +138,12 @@ def main():
         roofline = None
         if scat_ms and n_valid:
             ach = bytes_per_sample * n_valid / (scat_ms * 1e-3) / 1e9
-            roofline = dict(kernel='sherf_gather_tokens_bwd_binned (bin count + scan + fill + gather_tokens_bwd_binned_kernel)', bound='hbm', achieved=ach,
+            roofline = dict(kernel='sherf_gather_tokens_bwd_binned (bin count + scans + fill + gather_tokens_bwd_runs_kernel)', bound='hbm', achieved=ach,
                             peak=bench.PEAK_HBM_GBS, unit='GB/s', frac=ach / bench.PEAK_HBM_GBS,
                             traffic=None, kernel_ms=scat_ms, bytes_per_sample=bytes_per_sample, valid_samples=n_valid,
-                            note='largest single kernel of the step; fp32 read-modify-write atomics of whole rows (lane = channel), the coarsest voxel level summed in registers per bin: '
-                                 'atomic-rate bound, not bandwidth bound (round 2 direct form: 20.3 ms; profiles/r03_scatter_final.txt)')
+                            note='largest single kernel of the step; fp32 read-modify-write atomics of whole rows (lane = channel); since round 5 over the samples sorted by their '
+                                 'finest voxel cell with every level / plane / feature-map sum in registers, flushed when its cell changes (the bytes above are the unmerged algorithm\'s): '
+                                 'bound by the number of atomically added elements, not by bandwidth (round 2 direct form: 20.3 ms, round 3 binned: 4.1 ms; profiles/r05_call_x_*)')
         print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
                               unit='rays/s', n_gpus=world, rccl_ranks=torch.distributed.get_world_size() if world > 1 else 1, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32 (backward: fp32 kernels, MFMA GEMMs on a three-part bf16 split, MFMA sparse-conv input gradient on a range-scaled fp16 split; forward: f16x3 MFMA)',
