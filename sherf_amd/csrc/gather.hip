@@ -820,15 +820,15 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_binned_kernel(const 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 5: the same scatter over the samples SORTED by the finest tapped voxel cell they fall in (1 cm), every level's sums in registers.
 // The kernel above keeps the coarsest level's eight corner rows in registers because all samples of a 4 cm bin share them, and sends the two
-// finer levels' 16 corners of every sample to memory: 24 of a sample's 34 atomic instructions (256 B each; the scatter's 3.7 ms are ~8 GB of
-// read-modify-write traffic).  With the samples in the order of their finest cell (x fastest) the corner rows of EVERY level stay the same over runs of
-// consecutive samples -- ~20 samples per 1 cm cell at the bench subject, longer at the coarser levels -- so a wave walks a contiguous stretch of
-// the sorted list, adds into 36 registers per lane and sends a level's eight rows to memory when that level's cell changes (run-length): the
-// voxel atomics drop from 24 per sample to ~12 per run; the tri-plane and feature-map corners (10 per sample) the same way over the runs of their
-// own base texel.  Measured on the MI355X (tools/scatter_bench.py, 690 K samples): 4.1 -> 2.4-2.5 ms, of which sorting + the walk without any tap 0.96; a 1 cm cell
-// holds 4.9 samples on average, so a finest-level row still receives one flush per adjacent cell -- ~260 M atomically added ELEMENTS in all (round 3's kernel: 1.5 G),
-// and that count, not bytes or latency, is what the time follows (~175 G elements / s through the L2 atomic units).  The bins become the finest level's cells (~1.1 M at the bench subject, most of them empty):
-// their scan runs on every workgroup (local scans + block totals; the one-workgroup scan above would walk 1 100 bins per thread).
+// finer levels' 16 corners, the 12 plane and the 4 feature-map corners of every sample to memory: 34 atomic instructions of 64 elements per
+// sample.  With the samples in the order of their finest cell (x fastest) the corner rows of EVERY level -- and the base texels of the planes and of
+// the feature map -- stay the same over runs of consecutive samples, so a wave walks a contiguous stretch of the sorted list, adds into 46
+// registers per lane and sends a level's eight rows (a plane's / the feature map's four texels) to memory when that cell changes (run-length).
+// Measured on the MI355X (tools/scatter_bench.py, 690 K samples): 4.1 -> 2.4-2.5 ms, of which sorting + the walk without any tap 0.9; a 1 cm cell
+// holds 4.9 samples on average, so a finest-level row still receives one flush per adjacent cell -- ~260 M atomically added ELEMENTS in all (round 3's
+// kernel: 1.5 G), and that count, not bytes or latency, is what the time follows (~175 G elements / s through the L2 atomic units; the gradient rows
+// loaded four samples ahead, or staged through LDS, changed nothing).  The bins become the finest level's cells (1.67 M at the bench subject, 140 K
+// of them occupied): their scan runs on every workgroup (local scans + block totals; the one-workgroup scan above would walk 1 600 bins per thread).
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) bin_scan_blocks_kernel(BinWs w) {          // offsets[b] = exclusive scan inside the block of 1024 bins; blocks[blk] = its total
     __shared__ int s_v[1024];
