@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5, call Y: the forward gather with unconditional row loads (SHERF_EXPERIMENT bit 9) against the shipped kernel, both framings, bits + timeline
+# (as it was run; the variant lost and its code -- bit 9 -- was removed again: DESIGN 9.27, profiles/r05_call_y_*)
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
