@@ -110,6 +110,16 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
         b = G.hip_render('tiny_nv', options=dict(mlp_parts=parts))
         assert b['last']['mlp_parts'] == parts
         assert torch.equal(b['rgb'], h['rgb']) and torch.equal(b['acc'], h['acc']) and torch.equal(b['depth'], h['depth']), parts
+    # round 5's launch-order / stream-placement experiments of the first phase (SHERF_EXPERIMENT, csrc/common.h: level-0 rows scattered before the level
+    # builds are queued, level builds on the encoder's own stream, encoder queued before the ray side; bit 4 = host-clock stamps on stderr): order only
+    import os
+    try:
+        for word in (1, 2, 3, 8, 9, 16):
+            os.environ['SHERF_EXPERIMENT'] = str(word)
+            b = G.hip_render('tiny_nv')
+            assert torch.equal(b['rgb'], h['rgb']) and torch.equal(b['acc'], h['acc']) and torch.equal(b['depth'], h['depth']), word
+    finally:
+        os.environ.pop('SHERF_EXPERIMENT', None)
 
 
 def test_token_workspace_is_sized_from_the_frame(cpu_product):
