@@ -219,6 +219,18 @@ int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, const float* e
  * gather of the next part on a second stream).  Same results. */
 int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens, const float* extras, const void* wstream, const float* wbias, int prec,
                          int64_t capacity, float* out, int part, int nparts, int wgs_per_cu, sherf_stream_t stream);
+/* Round 6: the positional encodings outside the network kernel.  sherf_gather_tokens_pe = sherf_gather_tokens on fp16 tables (`mode | 16`, mode 0 or
+ * 1) that also writes PE6(x_c) (renderer.py:875-916, 39 features -> 3 K-blocks), PE4(v_c) (27 -> 2) and PE5(rgb)[:32] (renderer.py:423; 2) of every
+ * sample as fp16 MFMA B-operand fragments: pefrag[tile][q][lane] x 16 bytes (features 16 kb + 8 h .. + 7 of sample j, lane = 32 h + j; q = 0-2 PE6,
+ * 3-4 PE4, 5-6 PE5; zero padded), ((capacity + 31) / 32) tiles x 7 KiB.  sherf_nerf_mlp3_pe = sherf_nerf_mlp3 (prec 2 only) reading them: same sin /
+ * cos sequence and rounding as the kernel's own evaluation, so the outputs equal sherf_nerf_mlp3's on the same tokens / extras bit for bit. */
+int sherf_gather_tokens_pe(const int32_t* counters, const float* geom, const float* planes_f, int P,
+                           const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
+                           const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
+                           const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
+                           float* extras, void* pefrag, sherf_stream_t stream);
+int sherf_nerf_mlp3_pe(const int32_t* counters, const float* tokens, const float* extras, const void* pefrag, const void* wstream,
+                       const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream);
 /* The same network as TWO launches (csrc/mlp.hip: nerf_tokens_kernel + nerf_decoder_kernel), results bit-identical to sherf_nerf_mlp:
  * launch 1 = slot-fusion remainder + 3-token transformer (renderer.py:423-427, 949-993), barrier-free with its weights resident in LDS;
  * launch 2 = NeRFDecoder (triplane.py:285-316) with every wave in the MFMA-bound phase.  zfrag: scratch for the fused tokens,
@@ -391,6 +403,11 @@ int sherf_svox_encode(const sherf_svox_plan* plan, const int32_t* coord, const f
  * and sherf_frame_count() returns it after waiting for THAT point of the frame only -- the warp, gather, network and compositing are
  * still in flight.  What a caller uses to check tok_capacity on a frame with new inputs without draining the GPU. */
 #define SHERF_FRAME_REPORT_COUNT 16
+/* frame->flags & SHERF_FRAME_PE_FRAGS (round 6; needs frame->pefrag, SHERF_FRAME_HALF_TABLES, mlp_prec 2 and SHERF_FRAME_MLP_PIPELINED, else ignored):
+ * the positional encodings PE6(x_c), PE4(v_c), PE5(rgb) are written by the gather as fp16 MFMA operand fragments (sherf_gather_tokens_pe) and READ by the
+ * network kernel (sherf_nerf_mlp3_pe) instead of evaluated in it -- the network kernel runs at the board's power cap, the gather waits on memory.  Same
+ * operand bits: the frame is bit-identical. */
+#define SHERF_FRAME_PE_FRAGS 128
 typedef struct {
     /* SMPL (a7-a9) */
     const float* poses; const float* shapes;           /* [3][72], [3][10]: target, big-pose, observation */
@@ -426,6 +443,7 @@ typedef struct {
     int64_t tok_capacity;       /* samples that geom / tokens / extras / sample_out hold (0: `capacity`).  The sampler's own buffers stay at
                                  * `capacity` (= R * S for the two-pass sampler); a frame with more valid samples than tok_capacity renders the
                                  * rays it cannot hold as NaN and sets counters[3] bit 1 -- the caller sizes from counters[0] (phase 4) */
+    void* pefrag;               /* SHERF_FRAME_PE_FRAGS: ((tok_capacity + 31) / 32 + 8) tiles x 7 KiB for the encodings' fragments, else NULL */
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);

@@ -68,6 +68,7 @@ def _frame_fields():
     P('rgb', 'depth', 'acc', 'zfrag', 'near_hdr', 'near_list')
     f.append(('near_list_cap', _i64))
     f.append(('tok_capacity', _i64))
+    P('pefrag')
     return f
 
 

@@ -84,6 +84,26 @@ __device__ __forceinline__ float dist2_exact(float ax, float ay, float az, float
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// sin / cos of an angle `a` [rad] with the range reduction done right: the phase in revolutions is a two-term product with
+// 1 / (2 pi) = kHi + kLo (the fma recovers the rounding error of a * kHi exactly), v_fract keeps its fraction, v_sin / v_cos take
+// revolutions.  Phase error < 1e-8 revolutions for |a| <= 2^8, against 6e-8 * |a| / (2 pi) of a plain a * (1 / 2 pi).
+// Shared by the network kernel (csrc/mlp.hip: pe_frags) and the gather (csrc/gather.hip: the encodings as ready-made MFMA operand fragments,
+// round 6) -- ONE definition, so that the two produce the same bits.  SHERF_MLP_FASTMATH=0 (a profiling build of mlp.hip): libm's sincosf.
+#ifndef SHERF_MLP_FASTMATH
+#define SHERF_MLP_FASTMATH 1
+#endif
+__device__ __forceinline__ void sherf_sincos_exact_phase(float a, float* s, float* c) {
+#if SHERF_MLP_FASTMATH
+    const float kHi = 0.15915494f, kLo = 6.4206383e-09f;
+    const float p = a * kHi;
+    const float e = __builtin_fmaf(a, kHi, -p);
+    const float r = __builtin_amdgcn_fractf(p) + __builtin_fmaf(a, kLo, e);
+    *s = __builtin_amdgcn_sinf(r); *c = __builtin_amdgcn_cosf(r);
+#else
+    sincosf(a, s, c);
+#endif
+}
+
 // Examine every vertex whose cell overlaps the ball (x, r); keep the lexicographic minimum of (d2, id).
 // All vertices with distance <= r are guaranteed to be examined (cell range widened by a safety margin).
 __device__ __forceinline__ void nn_search(const CellGrid& g, const int32_t* __restrict__ cell_start,

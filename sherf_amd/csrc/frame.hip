@@ -260,6 +260,11 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         // gather (texture addresser) on the main one: the two kernels are bound by different units of the CU (frame->mlp_parts).
         const int nparts = std::min(((g_sherf_debug >> 16) & 15) ? ((g_sherf_debug >> 16) & 15) : f->mlp_parts, kMaxParts);   // (debug bits 16-19 override: A/B runs)
         const bool split_form = f->zfrag && (((f->flags & SHERF_FRAME_MLP_SPLIT) != 0) != ((g_sherf_debug & 8192) != 0));
+        // SHERF_FRAME_PE_FRAGS (round 6): the gather writes the positional encodings as fp16 operand fragments and the pipelined single-fp16-product
+        // network reads them (sherf_gather_tokens_pe -> sherf_nerf_mlp3_pe; bit-identical frames).  Only in the configuration it is built for: fp16
+        // tables in the eight-channel gather, one pass, one part, the pipelined form; anything else renders as before.  (debug bit 23 turns it off: A/B runs)
+        const bool pe_frags = (f->flags & SHERF_FRAME_PE_FRAGS) && f->pefrag && half_tables && (f->mlp_prec & 255) == 2 && (f->flags & SHERF_FRAME_MLP_PIPELINED) &&
+                              !(g_sherf_debug & (1 << 25)) && !split_form && nparts <= 1 && !(f->gather_split & 7) && !(g_sherf_debug & (2048 | (1 << 29) | (1 << 23)));
         if (nparts > 1 && !(f->gather_split & 1) && !split_form) {
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
@@ -293,6 +298,11 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         } else {
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));
+            if (pe_frags)
+                SHERF_RUN(sherf_gather_tokens_pe(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
+                                                 levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv, cap, f->tokens,
+                                                 f->extras, f->pefrag, stream_main));
+            else
             SHERF_RUN(sherf_gather_tokens(f->counters, f->geom, f->planes_f, f->P, f->feat_f, f->Hf, f->Wf, f->img4, f->H, f->W,
                                           levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv, cap, f->tokens,
                                           f->extras, stream_main));
@@ -300,7 +310,9 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         SHERF_PROF(4, main);
         // debug bit 13 flips the form for A/B runs in one process (a frame without zfrag always takes the one-launch kernel)
         const bool split = f->zfrag && (((f->flags & SHERF_FRAME_MLP_SPLIT) != 0) != ((g_sherf_debug & 8192) != 0));
-        if (split)
+        if (pe_frags)
+            SHERF_RUN(sherf_nerf_mlp3_pe(f->counters, f->tokens, f->extras, f->pefrag, f->wstream, f->wbias, f->mlp_prec, cap, f->sample_out, stream_main));
+        else if (split)
             SHERF_RUN(sherf_nerf_mlp_split(f->counters, f->tokens, f->extras, f->wstream, f->wbias, f->mlp_prec, cap, f->zfrag,
                                            f->sample_out, stream_main));
         else if ((f->mlp_prec & 255) != 1 && (((f->flags & SHERF_FRAME_MLP_PIPELINED) != 0) != ((g_sherf_debug & (1 << 25)) != 0)))    // (debug bit 25 flips the form: A/B runs)

@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256, MINW) gather_tokens_kernel(const int32_t*
 // 32-channel slot and a wave covers 16 samples instead of 8: half the load instructions for the same taps.  Same stencils, same
 // weights, fp32 sums; the tokens / extras come out in the same tile-major layout (a lane stores two quads).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr int kPeStride = 120;          // halfs per sample of the encodings' LDS exchange: 112 + 8 (240 B: 16-byte aligned, 16 samples on 16 bank groups)
 // the first pair of tiles workgroup `b` of `g` takes (the loop header of gather_tokens_h8_kernel): n_pairs or more = none
 __device__ __forceinline__ int64_t banded_first_pair(int b, int g, int64_t n_pairs, int dbg) {
     const bool banded = !(dbg & 1024) && g % 8 == 0;
@@ -241,13 +242,22 @@ __device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__
 // bench subject's grid: 20 KiB) are copied to LDS once per workgroup, and a workgroup then walks several pairs of tiles -- 16 of a sample's 24 first-hop
 // look-ups become LDS reads.  The counters of the round (profiles/r05_call_g_pmc_*) say the kernel waits on dependent gathers (waves parked 65 % of their
 // cycles, addresser 62 % busy): this shortens two of its three look-up -> row chains.  Same arithmetic: bit-identical tokens.
-template <bool STAGE>
+// PE (round 6): the network kernel is bound by the board's power cap, this one by the latency of dependent gathers (its
+// VALU sits idle 85 % of the time) -- so the positional encodings PE6(x_c), PE4(v_c), PE5(rgb) (renderer.py:875-916, 423) are evaluated HERE, from
+// the values this kernel holds anyway, and handed to sherf_nerf_mlp3_pe as ready-made fp16 MFMA B-operand fragments:
+//     pefrag[tile][q][lane] (16 bytes: features 16 kb + 8 h .. + 7 of column j, lane = 32 h + j),  q = 0-2 PE6 kb, 3-4 PE4 kb, 5-6 PE5 kb,
+// in the SAME natural feature order, from the SAME sin / cos sequence (common.h) and rounding (nearest even) the kernel's own pe_frags<2> uses:
+// bit-identical operands.  Lane l < 3 of a sample's quad evaluates axis l of the three vectors (15 sin / cos pairs instead of the 63 every lane
+// of the network kernel computes, twice for PE6), the quad transposes through 240 bytes of LDS per sample into 8-feature groups, lane l stores
+// groups l, l + 4, l + 8, l + 12.  224 bytes per sample more to write, ~180 VALU per 16 samples.
+template <bool STAGE, bool PE = false>
 __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                                const void* __restrict__ planes_f, int P, const void* __restrict__ feat_f,
                                                                int Hf, int Wf, const float4* __restrict__ img4, int H, int W, Levels lv,
                                                                const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
                                                                const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
-                                                               float4* __restrict__ tokens, float* __restrict__ extras, int dbg, int mode) {
+                                                               float4* __restrict__ tokens, float* __restrict__ extras, int dbg, int mode,
+                                                               uint4* __restrict__ pefrag) {
     const int64_t nv = min((int64_t)counters[0], capacity);
     int64_t t_lo, t_hi;                             // this launch's part of the tiles (mode bits 8-15: part, 16-23: number of parts)
     sherf_part_range((nv + 31) / 32, (mode >> 8) & 255, (mode >> 16) & 255, t_lo, t_hi);
@@ -412,6 +422,51 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
         for (int s_ = 0; s_ < 3; ++s_) {
             tokens[((tile * 3 + s_) * 8 + 2 * l) * 32 + j] = acc[s_].a;
             tokens[((tile * 3 + s_) * 8 + 2 * l + 1) * 32 + j] = acc[s_].b;
+        }
+        if constexpr (PE) {
+            // the encodings of this sample as B-operand fragments (see the kernel's header).  A wave = 16 whole quads of ONE tile: the `continue`s
+            // above are wave-uniform, the LDS exchange stays inside a quad, wave_barrier orders it (the wave runs in lockstep)
+            __shared__ __attribute__((aligned(16))) _Float16 s_pe[64 * kPeStride];
+            _Float16* sp = s_pe + js * kPeStride;              // [PE6: 48 | PE4: 32 | PE5: 32] features, natural order
+            float v3[3] = {0.f, 0.f, 0.f};
+            if (valid) { const float* gm = geom + c * 8; v3[0] = gm[3]; v3[1] = gm[4]; v3[2] = gm[5]; }
+            if (l < 3) {
+                const float u6 = l == 0 ? xv[0] : l == 1 ? xv[1] : xv[2];
+                const float u4 = l == 0 ? v3[0] : l == 1 ? v3[1] : v3[2];
+                const float u5 = l == 0 ? rgb.x : l == 1 ? rgb.y : rgb.z;
+                sp[l] = (_Float16)u6; sp[48 + l] = (_Float16)u4; sp[80 + l] = (_Float16)u5;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    float sn, cs;
+                    sherf_sincos_exact_phase(u6 * (float)(1 << q), &sn, &cs);
+                    sp[3 + 6 * q + l] = (_Float16)sn; sp[6 + 6 * q + l] = (_Float16)cs;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float sn, cs;
+                    sherf_sincos_exact_phase(u4 * (float)(1 << q), &sn, &cs);
+                    sp[48 + 3 + 6 * q + l] = (_Float16)sn; sp[48 + 6 + 6 * q + l] = (_Float16)cs;
+                }
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    float sn, cs;
+                    sherf_sincos_exact_phase(u5 * (float)(1 << q), &sn, &cs);
+                    sp[80 + 3 + 6 * q + l] = (_Float16)sn;
+                    if (q < 4 || l < 2) sp[80 + 6 + 6 * q + l] = (_Float16)cs;        // (feature 32 = the last cosine is not an input of conv1d_reprojection's [:32])
+                }
+            } else {                                                                   // the zero padding of the K-blocks: PE6 39..47, PE4 27..31
+                sp[39] = (_Float16)0.f;
+                *reinterpret_cast<uint4*>(sp + 40) = make_uint4(0u, 0u, 0u, 0u);
+                sp[48 + 27] = (_Float16)0.f;
+                *reinterpret_cast<uint2*>(sp + 48 + 28) = make_uint2(0u, 0u);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = l + 4 * i;                                               // group g = 2 q + h: features 8 g .. 8 g + 7
+                if (g < 14) pefrag[((tile * 7 + (g >> 1)) * 2 + (g & 1)) * 32 + j] = *reinterpret_cast<const uint4*>(sp + 8 * g);
+            }
+            __builtin_amdgcn_wave_barrier();                                           // every group is read before the next step rewrites the slots
         }
     }
 }
@@ -1085,11 +1140,11 @@ __global__ void __launch_bounds__(kBinNT) gather_tokens_bwd_runs_kernel(const in
 
 }  // namespace
 
-extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
-                                   const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
-                                   const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
-                                   const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
-                                   float* extras, sherf_stream_t stream) {
+static int gather_tokens_impl(const int32_t* counters, const float* geom, const float* planes_f, int P,
+                              const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
+                              const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
+                              const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
+                              float* extras, void* pefrag, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && geom && planes_f && feat_f && img4 && tok_bias && bounds && vox_min && vox_sh_host && tokens && extras);
     const bool branchless = (mode & 4) != 0 || SHERF_GATHER_BRANCHLESS;
     const bool squeezed = branchless && (mode & 8) != 0;
@@ -1112,6 +1167,15 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
                        counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,         \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode)
+    // the encodings as fragments (sherf_gather_tokens_pe): the eight-channel kernel's pass that visits every sample once (mode 0 or 1)
+    SHERF_CHECK_ARG(!pefrag || (half_tables && !branchless && mode != 2));
+    if (pefrag) {
+        const int64_t pairs = (tiles + 1) / 2;
+        hipLaunchKernelGGL((gather_tokens_h8_kernel<false, true>), dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
+                           counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
+                           reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
+                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, reinterpret_cast<uint4*>(pefrag));
+    } else
     if (half_tables && !branchless && !(g_sherf_debug & 2048)) {      // eight channels per lane (debug bit 11: the four-per-lane kernel on fp16 tables)
         const int64_t pairs = (tiles + 1) / 2;
         // debug bit 29: the records of the two coarser levels staged in LDS (gather_tokens_h8_kernel<true>), a workgroup walks ~`ppw` pairs (4; debug bit
@@ -1123,16 +1187,37 @@ extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, c
             hipLaunchKernelGGL(gather_tokens_h8_kernel<true>, dim3((unsigned)wgs), dim3(256), stage_bytes, as_stream(stream),
                                counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                                reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
-                               capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode);
+                               capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, static_cast<uint4*>(nullptr));
         } else
         hipLaunchKernelGGL(gather_tokens_h8_kernel<false>, dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
                            counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                            reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
-                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode);
+                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, static_cast<uint4*>(nullptr));
     } else if (half_tables) { if (squeezed) SHERF_GATHER(true, 4, true); else if (branchless) SHERF_GATHER(true, 1, true); else SHERF_GATHER(false, 1, true); }
     else { if (squeezed) SHERF_GATHER(true, 4, false); else if (branchless) SHERF_GATHER(true, 1, false); else SHERF_GATHER(false, 1, false); }
 #undef SHERF_GATHER
     SHERF_LAUNCH_CHECK();
+}
+
+extern "C" int sherf_gather_tokens(const int32_t* counters, const float* geom, const float* planes_f, int P,
+                                   const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
+                                   const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
+                                   const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
+                                   float* extras, sherf_stream_t stream) {
+    return gather_tokens_impl(counters, geom, planes_f, P, feat_f, Hf, Wf, img4, H, W, levels_host, tok_bias, bounds, vox_min, vox_sh_host, mode,
+                              capacity, tokens, extras, nullptr, stream);
+}
+
+// sherf_gather_tokens on fp16 tables (`mode | 16`, mode 0 or 1) that ALSO writes the positional encodings of every sample as fp16 MFMA operand
+// fragments for sherf_nerf_mlp3_pe (gather_tokens_h8_kernel<false, true>): pefrag = ((capacity + 31) / 32) tiles x 7 KiB.
+extern "C" int sherf_gather_tokens_pe(const int32_t* counters, const float* geom, const float* planes_f, int P,
+                                      const float* feat_f, int Hf, int Wf, const float* img4, int H, int W,
+                                      const sherf_vox_level* levels_host, const float* tok_bias, const float* bounds,
+                                      const float* vox_min, const int32_t* vox_sh_host, int mode, int64_t capacity, float* tokens,
+                                      float* extras, void* pefrag, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(pefrag);
+    return gather_tokens_impl(counters, geom, planes_f, P, feat_f, Hf, Wf, img4, H, W, levels_host, tok_bias, bounds, vox_min, vox_sh_host, mode,
+                              capacity, tokens, extras, pefrag, stream);
 }
 
 extern "C" int sherf_gather_tokens_bwd(const int32_t* counters, const float* geom, const float* d_tokens, int P, int Hf, int Wf,

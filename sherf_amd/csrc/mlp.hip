@@ -444,7 +444,8 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 
 // LayerNorm over the 32 features of a token (16 here, 16 in lane^32), eps 1e-5 (renderer.py:931).
 // prec 1 (fp32-grade): the two-pass form of round 1-3 (mean, then the sum of squared deviations).  Single-product precisions (round 4):
-// one pass -- sum and sum of squares together, var = E[x^2] - mean^2 (32 O(1) values in fp32: the cancellation costs ~1e-7) -- and the
+// one pass -- sum and sum of squares together, var = E[x^2] - mean^2 (32 O(1) values in fp32: the cancellation costs ~1e-7; tokens whose
+// mean dwarfs their spread fall back to the two-pass variance, see the guard below) -- and the
 // normalisation as two fmas per feature ((x * inv - mean * inv) * g + b): 64 instead of 96 VALU per token, five tokens per tile.
 template <int PREC, class C>
 __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_idx, BFrag<PREC>& k0, BFrag<PREC>& k1) {
@@ -468,8 +469,17 @@ __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s += x[r]; q = __builtin_fmaf(x[r], x[r], q); }
         s = xhalf_sum(s); q = xhalf_sum(q);
-        const float mean = s * (1.0f / 32.0f);
-        const float var = fmaxf(__builtin_fmaf(-mean, mean, q * (1.0f / 32.0f)), 0.0f);
+        const float mean = s * (1.0f / 32.0f), ex2 = q * (1.0f / 32.0f);
+        float var = fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.0f);
+        // Cancellation guard (round 6): E[x^2] - mean^2 loses log2(E[x^2] / var) bits.  When some sample of
+        // the wave has a mean above 16 standard deviations (more than eight of the 24 bits gone) the whole wave takes the two-pass variance --
+        // a wave-uniform branch that tokens of O(1) mean never enter (3 VALU + a ballot per token in the common case).
+        if (__ballot(ex2 > 257.0f * var) != 0) {
+            float q2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = x[r] - mean; q2 = __builtin_fmaf(d, d, q2); }
+            var = xhalf_sum(q2) * (1.0f / 32.0f);
+        }
         const float inv = rsqrt_(var + 1e-5f), off = -mean * inv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] = __builtin_fmaf(__builtin_fmaf(x[r], inv, off), g[r], bt[r]);
@@ -477,20 +487,8 @@ __device__ __forceinline__ void layer_norm(const C& cx, const f32x16& x, int ln_
     split_tile<PREC>(y, k0, k1);
 }
 
-// sin / cos of an angle `a` [rad] with the range reduction done right: the phase in revolutions is a two-term product with
-// 1 / (2 pi) = kHi + kLo (the fma recovers the rounding error of a * kHi exactly), v_fract keeps its fraction, v_sin / v_cos take
-// revolutions.  Phase error < 1e-8 revolutions for |a| <= 2^8, against 6e-8 * |a| / (2 pi) of a plain a * (1 / 2 pi).
-__device__ __forceinline__ void sincos_exact_phase(float a, float* s, float* c) {
-#if SHERF_MLP_FASTMATH
-    const float kHi = 0.15915494f, kLo = 6.4206383e-09f;
-    const float p = a * kHi;
-    const float e = __builtin_fmaf(a, kHi, -p);
-    const float r = __builtin_amdgcn_fractf(p) + __builtin_fmaf(a, kLo, e);
-    *s = __builtin_amdgcn_sinf(r); *c = __builtin_amdgcn_cosf(r);
-#else
-    sincosf(a, s, c);
-#endif
-}
+// sin / cos with the exact phase reduction: csrc/common.h (shared with the gather, which can hand the encodings over as fragments)
+__device__ __forceinline__ void sincos_exact_phase(float a, float* s, float* c) { sherf_sincos_exact_phase(a, s, c); }
 
 // NeRF positional encoding in "natural" K-block order: feature f = 16*kb + 8*h + e of
 // [x(3), sin(2^0 x)(3), cos(2^0 x)(3), sin(2^1 x)(3), ...]; entries >= 3 + 6*NF are zero.  Every octave is evaluated DIRECTLY from
@@ -608,9 +606,11 @@ __device__ __forceinline__ void load_tokens(const float4* __restrict__ tokens, i
 //   PRE = false: the tile's tokens are read here, and tokens 0 / 1 RE-read for the residual (the one-tile kernels: 32 registers less at
 //                their pressure peak);  PRE = true: `tok` arrives loaded (the two-tile kernel prefetches the next tile's tokens under
 //                this tile's arithmetic and keeps tokens 0 / 1 for the residual: it has the 256-register budget)
-template <int PREC, bool RING, bool PRE = false>
+//   PEM = true (round 6, prec 2 only): PE5(rgb) arrives as two ready-made fp16 fragments (`pef`: sherf_gather_tokens_pe's pefrag[tile][5..6][lane],
+//                the same bits pe_frags<2, 5, 2> would produce) instead of 15 sin / cos pairs + selects + conversions per lane
+template <int PREC, bool RING, bool PRE = false, bool PEM = false>
 __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __restrict__ tokens, const float* __restrict__ extras, int64_t tile,
-                                                 BFrag<PREC> (&z0b)[2], BFrag<PREC> (&z1b)[2], f32x16 (&tok)[3]) {
+                                                 BFrag<PREC> (&z0b)[2], BFrag<PREC> (&z1b)[2], f32x16 (&tok)[3], const u32x4* __restrict__ pef = nullptr) {
     const int j = cx.lane & 31, h = cx.h;
     if (cx.notrans) {
         // use_trans = False: no slot-2 completion, no transformer -- `sampled_features` go to the decoder unchanged (renderer.py:427, 432); the
@@ -637,7 +637,8 @@ __device__ __forceinline__ void transformer_tile(Ctx<PREC>& cx, const float4* __
         // ---- chunk 0: slot-2 token += W_b . PE5(rgb)[:32] ----
         {
             BFrag<PREC> b[1][2];
-            pe_frags<PREC, 5, 2>(h, ex[192], ex[224], ex[256], b[0]);
+            if constexpr (PEM) { b[0][0].hi = pef[(tile * 7 + 5) * 64 + cx.lane]; b[0][1].hi = pef[(tile * 7 + 6) * 64 + cx.lane]; }
+            else pe_frags<PREC, 5, 2>(h, ex[192], ex[224], ex[256], b[0]);
             f32x16 acc[1] = {bias_tile(cx, 0)};
             mma_cols<PREC, 2, 1>(s, 0, b, acc);
             tok[2] += acc[0];
@@ -939,9 +940,13 @@ __device__ __forceinline__ void mma_chains_f(const char* s, int u0, const BFrag<
     }
 }
 
-template <int PREC>
+// PEM = true (round 6, prec 2): PE6(x_c) / PE4(v_c) are LOADED as fp16 fragments (pef = pefrag + this lane: [tile][q = 0-2 | 3-4][lane]) where
+// pe_frags computed them -- ~420 VALU per tile less in a kernel whose time follows its instruction energy.  The loads are
+// compiler-visible: their s_waitcnt can only be STRONGER than needed beside the asm-issued weight DMA (vmcnt retires in order).
+template <int PREC, bool PEM = false>
 __device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __restrict__ counters, const BFrag<PREC> (&z0b)[2], const BFrag<PREC> (&z1b)[2],
-                                               const float (&xc)[3], const float (&vc)[3], int64_t tile, bool live, int64_t nv, float4* __restrict__ out) {
+                                               const float (&xc)[3], const float (&vc)[3], int64_t tile, bool live, int64_t nv, float4* __restrict__ out,
+                                               const u32x4* __restrict__ pef = nullptr) {
     const int j = cx.lane & 31, h = cx.h;
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
     int step = 2;
@@ -965,7 +970,10 @@ __device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __r
     SHERF_NEXT_STEP();
     {   // pts_linears.0 : [PE6(x_c) (3 kb) | z_0 (2 kb)], one step per pair
         BFrag<PREC> pe[3];
-        pe_frags<PREC, 6, 3>(h, xc[0], xc[1], xc[2], pe);
+        if constexpr (PEM) {
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) pe[kb].hi = pef[(tile * 7 + kb) * 64];
+        } else pe_frags<PREC, 6, 3>(h, xc[0], xc[1], xc[2], pe);
         X0 = bias_tile(cx, 9); X1 = bias_tile(cx, 10);
         const char* s = cx.slot(step);
         mma_chains_f<PREC, 3, true, true>(s, 0, pe, X0, X1, cur, 0, [&](int i) { if (i == 0) { Y0 = bias_tile(cx, 11); Y1 = bias_tile(cx, 12); } });
@@ -985,7 +993,12 @@ __device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __r
         float x0 = xc[0], x1 = xc[1], x2 = xc[2];
         asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
         BFrag<PREC> pe[3];
-        pe_frags<PREC, 6, 3>(h, x0, x1, x2, pe);
+        if constexpr (PEM) {                                         // re-read (L2): 12 registers not carried through four layers
+            const u32x4* pp = pef;
+            asm volatile("" : "+v"(pp));
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) pe[kb].hi = pp[(tile * 7 + kb) * 64];
+        } else pe_frags<PREC, 6, 3>(h, x0, x1, x2, pe);
         const char* s = cx.slot(step);
         auto carry0 = [&](int i) { if (i < 4) epi_piece<PREC, true>(Y0, Y1, ha + 4, i); };
         mma_chains_f<PREC, 3, true, true>(s, 0, pe, X0, X1, cur, 0, carry0);
@@ -1019,7 +1032,8 @@ __device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __r
         SHERF_NEXT_STEP();
         // views_linear : [feature (8 kb) | PE4(v_c) (2 kb) | z_1 (2 kb)] -> 64, ReLU, on Y; sigma leaves X behind the first block
         BFrag<PREC> pv[2];
-        pe_frags<PREC, 4, 2>(h, vc[0], vc[1], vc[2], pv);
+        if constexpr (PEM) { pv[0].hi = pef[(tile * 7 + 3) * 64]; pv[1].hi = pef[(tile * 7 + 4) * 64]; }
+        else pe_frags<PREC, 4, 2>(h, vc[0], vc[1], vc[2], pv);
         mma_chains_f<PREC, 4, true, false>(cx.slot(step), 0, ha, Y0, Y1, cur, 0, [&](int i) {
             // (the WHOLE tuples stay live up to here: only element 0 of each is read, and hipcc would hand the other fifteen registers of an
             //  accumulator to the bias reads above while the MFMA writing them is still in flight -- tools/mfma_hazard_check.py, R1)
@@ -1417,10 +1431,11 @@ nerf_mlp2_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
 #ifndef SHERF_MLP3_LB
 #define SHERF_MLP3_LB 2
 #endif
-template <int PREC>
+template <int PREC, bool PEM = false>
 __global__ void __launch_bounds__(NW * 64, SHERF_MLP3_LB)
 nerf_mlp3_kernel(const int32_t* __restrict__ counters, const float4* __restrict__ tokens, const float* __restrict__ extras,
-                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts, int notrans) {
+                 const char* __restrict__ ws, const float* __restrict__ wbias, int64_t capacity, float4* __restrict__ out, int part, int nparts, int notrans,
+                 const u32x4* __restrict__ pefrag) {
     using CX = Ctx<PREC>;
     __shared__ __attribute__((aligned(16))) char lds[NSLOT * CX::SLOT + (N_CHUNKS + 4) * 32 * 4 + (SHERF_MLP_TRACE ? NW * 64 * 16 : 0)];
     const int64_t nv = min((int64_t)counters[0], capacity);
@@ -1435,14 +1450,16 @@ nerf_mlp3_kernel(const int32_t* __restrict__ counters, const float4* __restrict_
     if (!live) tile = n_tiles - 1;                                   // dead tiles still take part in every barrier
     ring_prologue<PREC, 0>(cx);
     BFrag<PREC> z0b[2], z1b[2];
-    float xc[3], vc[3];
-    const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
-    xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
+    float xc[3] = {0.f, 0.f, 0.f}, vc[3] = {0.f, 0.f, 0.f};
+    if constexpr (!PEM) {
+        const float* ex = extras + tile * 12 * 32 + (cx.lane & 31);
+        xc[0] = ex[0]; xc[1] = ex[32]; xc[2] = ex[64]; vc[0] = ex[96]; vc[1] = ex[128]; vc[2] = ex[160];
+    }
     {
         f32x16 tok[3];
-        transformer_tile<PREC, true>(cx, tokens, extras, tile, z0b, z1b, tok);
+        transformer_tile<PREC, true, false, PEM>(cx, tokens, extras, tile, z0b, z1b, tok, pefrag);
     }
-    decoder_tile_p<PREC>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out);
+    decoder_tile_p<PREC, PEM>(cx, counters, z0b, z1b, xc, vc, tile, live, nv, out, pefrag + cx.lane);
     SHERF_TRACE_FLUSH(cx);
 }
 
@@ -1663,16 +1680,35 @@ extern "C" int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens
     const unsigned pad = wgs_per_cu == 2 ? 12 * 1024 : wgs_per_cu == 1 ? 44 * 1024 : 0;
     if (prec == 2)
         hipLaunchKernelGGL((nerf_mlp3_kernel<2>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans,
+                           static_cast<const u32x4*>(nullptr));
     else
         hipLaunchKernelGGL((nerf_mlp3_kernel<0>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
-                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans);
+                           reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans,
+                           static_cast<const u32x4*>(nullptr));
     SHERF_LAUNCH_CHECK();
 }
 
 extern "C" int sherf_nerf_mlp3(const int32_t* counters, const float* tokens, const float* extras, const void* wstream,
                                const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
     return sherf_nerf_mlp3_part(counters, tokens, extras, wstream, wbias, prec, capacity, out, 0, 1, 0, stream);
+}
+
+// sherf_nerf_mlp3 (prec 2 only) with the positional encodings READ as fp16 operand fragments written by sherf_gather_tokens_pe (pefrag:
+// [tile][7][64 lanes] x 16 bytes) instead of evaluated in the kernel: same operand bits -> the same outputs bit for bit as sherf_nerf_mlp3 on the
+// tokens / extras of the same gather; `extras` is still read by the use_trans = False path only (and may not be NULL).
+extern "C" int sherf_nerf_mlp3_pe(const int32_t* counters, const float* tokens, const float* extras, const void* pefrag, const void* wstream,
+                                  const float* wbias, int prec, int64_t capacity, float* out, sherf_stream_t stream) {
+    SHERF_CHECK_ARG(counters && tokens && extras && pefrag && wstream && wbias && out);
+    const int notrans = (prec & SHERF_MLP_NO_TRANSFORMER) ? 1 : 0;
+    prec &= ~SHERF_MLP_NO_TRANSFORMER;
+    SHERF_CHECK_ARG(prec == 2 && capacity > 0);
+    const int64_t tiles = (capacity + 31) / 32;
+    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
+    hipLaunchKernelGGL((nerf_mlp3_kernel<2, true>), grid, block, 0, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
+                       reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), 0, 1, notrans,
+                       reinterpret_cast<const u32x4*>(pefrag));
+    SHERF_LAUNCH_CHECK();
 }
 
 // The two-launch form (see nerf_tokens_kernel / nerf_decoder_kernel): same inputs, same outputs bit for bit; zfrag = scratch for the fused

@@ -214,7 +214,7 @@ class _Workspace:
             return
         f32 = dict(dtype=torch.float32, device=dev)
         tiles = (tok_cap + 31) // 32 + 8
-        for k in ('geom', 'tokens', 'extras', 'sample_out', 'cs_tvid', 'zfrag'):
+        for k in ('geom', 'tokens', 'extras', 'sample_out', 'cs_tvid', 'zfrag', 'pefrag'):
             self.t.pop(k, None)                           # (free first: the new set may not fit beside the old one)
         self.t.update(geom=torch.zeros(tok_cap, 8, **f32), tokens=torch.zeros(tiles * 3 * 8 * 32 * 4, **f32),
                       extras=torch.zeros(tiles * 12 * 32, **f32), sample_out=torch.zeros(tok_cap, 4, **f32),
@@ -224,6 +224,16 @@ class _Workspace:
             fr = self.desc[2]
             for k in ('geom', 'tokens', 'extras', 'sample_out', 'cs_tvid'):
                 setattr(fr, k, _lib.addr(self.t[k]))
+            fr.pefrag = None
+
+    def pefrag(self, dev):
+        """The positional encodings as fp16 MFMA operand fragments (SHERF_FRAME_PE_FRAGS: written by the gather, read by the network kernel):
+        7 KiB per 32-sample tile = 224 B per sample, allocated with the token-side buffers' capacity the first time a frame asks for it."""
+        z = self.t.get('pefrag')
+        words = ((self.tok_cap + 31) // 32 + 8) * 7 * 64 * 4
+        if z is None or z.numel() != words or z.device != torch.device(dev):
+            z = self.t['pefrag'] = torch.zeros(words, dtype=torch.int32, device=dev)
+        return z
 
     def nbytes(self):
         seen, n = set(), 0
@@ -751,6 +761,15 @@ class ImportanceRenderer(nn.Module):
             ws = self._workspace(dev)
             fr.zfrag = _lib.addr(ws.zfrag(int(fr.tok_capacity or fr.capacity), cfg[0], dev))
             fr.flags |= 8
+        # round 6: the positional encodings leave the power-bound network kernel for the latency-bound gather (SHERF_FRAME_PE_FRAGS; the frame
+        # driver ignores the flag outside the configuration it is built for: fp16 tables, single fp16 products, the pipelined form, one part)
+        pe = getattr(self, '_opt_pe_in_gather', None)
+        if pe is None:
+            pe = getattr(self, 'pe_in_gather', True)
+        fr.pefrag = None
+        if pe and cfg[0] == 'f16' and cfg[1] == 'f16' and form == 'pipelined' and not split:
+            fr.pefrag = _lib.addr(self._workspace(dev).pefrag(dev))
+            fr.flags |= 128
         return wc
 
     def _calibrate(self, fr, decoder, dev, ws, levels, streams, exact):
@@ -853,6 +872,7 @@ class ImportanceRenderer(nn.Module):
         cfg, calibrate = self._resolve_config(opts, decoder, dev)
         self.__dict__['_opt_mlp_split'] = opts.get('mlp_split')
         self.__dict__['_opt_mlp_form'] = opts.get('mlp_form')
+        self.__dict__['_opt_pe_in_gather'] = opts.get('pe_in_gather')
         prec_name = cfg[0]
         wc = self._weights(decoder, dev, prec_name)
         wsp = self._workspace(dev)
@@ -993,6 +1013,8 @@ class ImportanceRenderer(nn.Module):
                 fr.tok_capacity = wsp.tok_cap
                 if fr.zfrag:
                     fr.zfrag = _lib.addr(wsp.zfrag(int(fr.tok_capacity), cfg[0], dev))
+                if fr.flags & 128:
+                    fr.pefrag = _lib.addr(wsp.pefrag(dev))
                 st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
                 st['token_rerenders'] = st.get('token_rerenders', 0) + 1
                 if decide is not None:
@@ -1009,6 +1031,7 @@ class ImportanceRenderer(nn.Module):
         vdbg = dict(levels=pl['L'], taps=pl['taps'], shapes=pl['shapes'])
         keep = (pl['rows'], planes_f, feat_f, img4)
         self.__dict__['last'] = dict(ws=ws, vox=vdbg, keep=keep, R=R, S=S, cap=wsp.tok_cap, sampler_cap=cap, plan=pl, levels_struct=levels, mlp_precision=cfg[0], table_precision=cfg[1], encoder_precision=cfg[2], mlp_split=bool(fr.flags & 8), mlp_form=('pipelined' if fr.flags & 64 else 'two_tiles' if fr.flags & 32 else 'one'), mlp_parts=int(fr.mlp_parts),
+                                     pe_in_gather=bool(fr.flags & 128) and int(fr.mlp_parts) <= 1 and not (int(fr.gather_split) & 7),
                          # handles for the (experimental) backward, sherf_amd/backward.py: references, no copies
                          bwd=dict(planes=planes, obs_feat=obs_input_feature, ray_d=ray_directions, near=near, far=far,
                                   bounds=input_data['t_world_bounds'], vox_min=vox_min.reshape(-1)[:3], vox_sh=[int(v) for v in obs_sp_input['out_sh']],

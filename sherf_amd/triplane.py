@@ -44,44 +44,94 @@ class NeRFDecoder(nn.Module):
 class _GraphedProducer:
     """One per-frame PRODUCER call (tri-plane synthesis, an image encoder, the mapping network: ~150 small library launches each) captured once
     as a hipGraph and replayed: the launches of a frame's producers then cost the host one call and run without inter-launch gaps.  Inference
-    only (no autograd), static shapes: the capture is keyed on the arguments' shapes / dtypes, the keyword arguments and the module's parameter
-    storage (in-place weight updates keep the graph valid: it reads the live parameters; a re-allocated parameter re-captures).  Any failure to
-    capture falls back to the eager call for good."""
+    only (no autograd, no submodule in training mode -- a capture would advance BatchNorm's running statistics three times and replays never),
+    static shapes: the capture is keyed on the arguments' shapes / dtypes / device, the keyword arguments and the module's parameter storage
+    (in-place weight updates keep the graph valid: it reads the live parameters; a re-allocated parameter re-captures).
+
+    A capture is only trusted after it has been CHECKED (round 6): the first replay's output must reproduce an eager call on the same
+    arguments (to 1e-3 of the output's range) -- an empty or partial capture (work that ran on another stream or device, a forward that does not read its input)
+    replays as a no-op and would return the first frame's output for ever.  Any failure (capture error, mismatch) falls back to the eager call
+    for good and is reported once through `warnings`."""
 
     def __init__(self, module, fn):
         self.module, self.fn, self.key, self.graph, self.static_in, self.static_out, self.off = module, fn, None, None, None, None, False
+        self.error = None
 
     def _key(self, args, kw):
-        p = next(self.module.parameters(), None)
-        return (tuple((tuple(a.shape), a.dtype, a.device) if torch.is_tensor(a) else a for a in args), tuple(sorted(kw.items())),
-                None if p is None else p.data_ptr(), self.module.training)
+        ps = list(self.module.parameters())
+        ptrs = (len(ps), ps[0].data_ptr(), ps[-1].data_ptr()) if ps else None
+        return (tuple((tuple(a.shape), a.dtype, a.device) if torch.is_tensor(a) else a for a in args), tuple(sorted(kw.items())), ptrs)
+
+    @staticmethod
+    def _same(a, b):
+        if torch.is_tensor(a):
+            if not (torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype):
+                return False
+            if not a.is_floating_point():
+                return bool(torch.equal(a, b))
+            # (library convolutions may sum in a different order from call to call: a tolerance, not bits; a poisoned / stale buffer is far outside it)
+            scale = float(b.abs().max()) if b.numel() else 0.0
+            return bool(torch.isfinite(a).all()) and float((a - b).abs().max() if a.numel() else 0.0) <= 1e-3 * scale + 1e-6
+        if isinstance(a, (tuple, list)):
+            return isinstance(b, (tuple, list)) and len(a) == len(b) and all(_GraphedProducer._same(x, y) for x, y in zip(a, b))
+        return a == b
+
+    @staticmethod
+    def _clone(o):
+        if torch.is_tensor(o):
+            return o.clone()
+        if isinstance(o, (tuple, list)):
+            return type(o)(_GraphedProducer._clone(x) for x in o)
+        return o
+
+    def _capture(self, args, kw):
+        dev = next(a.device for a in args if torch.is_tensor(a))
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            self.static_in = [a.clone() if torch.is_tensor(a) else a for a in args]
+            with torch.cuda.stream(side):                        # warm-up outside the capture: library workspaces, algorithm searches
+                for _ in range(2):
+                    eager = self.fn(*self.static_in, **kw)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            import warnings
+            with warnings.catch_warnings():
+                warnings.filterwarnings('error', message='.*[Gg]raph is empty.*')     # an empty capture is a failed capture
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):          # (a DataLoader's pin-memory thread may touch the device meanwhile)
+                    self.static_out = self.fn(*self.static_in, **kw)
+            # the check: poison the output buffer, replay, compare with the eager result of the same arguments
+            eager = self._clone(eager)
+            for o in (self.static_out if isinstance(self.static_out, (tuple, list)) else [self.static_out]):
+                if torch.is_tensor(o) and o.is_floating_point():
+                    o.fill_(float('nan'))
+            g.replay()
+            if not self._same(self.static_out, eager):
+                raise RuntimeError('the captured graph does not reproduce the eager call (empty / partial capture?)')
+            self.graph = g
 
     def __call__(self, *args, **kw):
-        if self.off or torch.is_grad_enabled() or not all((not torch.is_tensor(a)) or a.device.type == 'cuda' for a in args):
+        if (self.off or torch.is_grad_enabled() or not any(torch.is_tensor(a) for a in args)
+                or not all((not torch.is_tensor(a)) or a.device.type == 'cuda' for a in args)
+                or any(m.training for m in self.module.modules())):
             return self.fn(*args, **kw)
         try:
             key = self._key(args, kw)
             if key != self.key:
-                cur = torch.cuda.current_stream()
-                side = torch.cuda.Stream()
-                side.wait_stream(cur)
-                self.static_in = [a.clone() if torch.is_tensor(a) else a for a in args]
-                with torch.cuda.stream(side):                        # warm-up outside the capture: library workspaces, algorithm searches
-                    for _ in range(2):
-                        self.fn(*self.static_in, **kw)
-                cur.wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.static_out = self.fn(*self.static_in, **kw)
-                self.graph, self.key = g, key
+                self.graph = None
+                self._capture(args, kw)
+                self.key = key
             for dst, src in zip(self.static_in, args):
                 if torch.is_tensor(dst):
                     dst.copy_(src)
             self.graph.replay()
-            out = self.static_out
-            return out.clone() if torch.is_tensor(out) else out      # (the graph's output buffer is rewritten by the next replay)
+            return self._clone(self.static_out)                      # (the graph's output buffer is rewritten by the next replay)
         except Exception as ex:                                      # capture not possible here (an op that synchronises, an old runtime): eager from now on
-            self.off, self.error = True, f'{type(ex).__name__}: {str(ex)[:200]}'
+            self.off, self.graph, self.key = True, None, None
+            self.error = f'{type(ex).__name__}: {str(ex)[:200]}'
+            import warnings
+            warnings.warn(f'sherf_amd: hipGraph replay of {type(self.module).__name__} disabled, eager calls from now on ({self.error})')
             return self.fn(*args, **kw)
 
 

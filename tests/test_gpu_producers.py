@@ -122,3 +122,52 @@ def test_reconstruction_loss_and_weight_update_on_device():
     for a, b in zip(res['cpu'][:-1], res['cuda'][:-1]):
         assert abs(a - b) < 1e-5 * max(1.0, abs(a))
     assert torch.allclose(res['cpu'][-1], res['cuda'][-1], atol=1e-6)
+
+
+def test_graphed_producer_is_checked_and_falls_back_on_device():
+    """Round 6: a producer's hipGraph is trusted only after its first replay reproduced an eager call; a module with a submodule
+    in training mode is never graphed (BatchNorm statistics advance once per call, as in eager mode); a capture that cannot reproduce the eager
+    call (here: the forward does its work on a stream the capture does not see) turns itself off with a warning and keeps returning eager results."""
+    import warnings
+    from sherf_amd.triplane import _GraphedProducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU()).cuda().eval()
+    gp = _GraphedProducer(net, net.__call__)
+    with torch.no_grad():
+        for k in range(3):
+            x = torch.randn(1, 3, 16, 16, device='cuda')
+            y = gp(x)
+            assert gp.graph is not None and not gp.off
+            assert torch.allclose(y, net(x), rtol=1e-4, atol=1e-6), k           # fresh inputs reach the replay
+        # training mode: eager, statistics advance exactly once per call
+        net.train()
+        n0 = int(net[1].num_batches_tracked)
+        gp(x)
+        assert int(net[1].num_batches_tracked) == n0 + 1
+        net.eval()
+        # a forward the capture cannot see: result on another stream, joined with a host wait -> the capture fails or comes out empty; either way: off + eager
+        other = torch.cuda.Stream()
+
+        class Elsewhere(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.Parameter(torch.ones(1))
+
+            def forward(self, x):
+                out = torch.empty_like(x)
+                other.wait_stream(torch.cuda.current_stream()) if not torch.cuda.is_current_stream_capturing() else None
+                with torch.cuda.stream(other):
+                    out.copy_(x * 2 * self.w)
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.current_stream().wait_stream(other)
+                return out
+
+        m = Elsewhere().cuda().eval()
+        gq = _GraphedProducer(m, m.__call__)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            outs = [gq(torch.full((4,), float(k), device='cuda')) for k in range(1, 4)]
+        torch.cuda.synchronize()
+        assert gq.off and gq.error and any('eager calls from now on' in str(r.message) for r in rec)
+        for k, o in enumerate(outs, 1):
+            assert torch.equal(o.cpu(), torch.full((4,), 2.0 * k)), (k, o)

@@ -103,6 +103,19 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
             assert b['last']['mlp_form'] == form
             for k in ('rgb', 'acc', 'depth'):
                 assert torch.equal(one[k], b[k]), (prec, form, k)
+    # round 6: the positional encodings evaluated by the gather and handed to the pipelined fp16 network as operand fragments (SHERF_FRAME_PE_FRAGS:
+    # the default in that configuration) == the network evaluating them itself; other configurations ignore the option
+    on = G.hip_render('tiny_nv', precision='f16', options=dict(pe_in_gather=True))
+    off = G.hip_render('tiny_nv', precision='f16', options=dict(pe_in_gather=False))
+    assert on['last']['pe_in_gather'] and not off['last']['pe_in_gather'] and G.hip_render('tiny_nv', precision='f16')['last']['pe_in_gather']
+    pf = on['last']['ws']['pefrag']
+    assert pf is not None and int((pf != 0).sum()) > 1000
+    for k in ('rgb', 'acc', 'depth'):
+        assert torch.equal(on[k], off[k]), k
+    assert torch.equal(on['last']['ws']['sample_out'], off['last']['ws']['sample_out'])
+    for opts in (dict(mlp_form='one'), dict(mlp_parts=2), dict(table_precision='f32'), dict(mlp_split=True), dict(gather_split=True)):
+        assert not G.hip_render('tiny_nv', precision='f16', options=dict(pe_in_gather=True, **opts))['last']['pe_in_gather'], opts
+    assert not G.hip_render('tiny_nv', precision='bf16', options=dict(pe_in_gather=True))['last']['pe_in_gather']
     # use_trans = False (round 5): every launch form of the network against the golden of the unmodified reference built without its transformer
     check_without_transformer()
     # gather + network cut into parts on two streams (sherf_nerf_mlp_part): a schedule, not an arithmetic, variant

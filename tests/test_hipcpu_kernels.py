@@ -452,7 +452,7 @@ def fwd_lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for name in ('sherf_composite_compact', 'sherf_composite_compact_bwd', 'sherf_gather_tokens', 'sherf_gather_tokens_bwd', 'sherf_fold_tables',
+    for name in ('sherf_composite_compact', 'sherf_composite_compact_bwd', 'sherf_gather_tokens', 'sherf_gather_tokens_pe', 'sherf_gather_tokens_bwd', 'sherf_fold_tables',
                  'sherf_img_to_hwc4', 'sherf_gather_tokens_bwd_binned', 'sherf_gather_bwd_scratch_words'):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = protos[name][0], [a[0] for a in protos[name][1]]
@@ -685,7 +685,7 @@ def mlp_lib(tmp_path_factory):
                            extra_src='char g_sherf_err[256] = ""; int g_sherf_debug = 0;\n', compiler=build_cpu.CLANG)
     lib = ctypes.CDLL(path)
     protos = _lib.parse_header()
-    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp2', 'sherf_nerf_mlp3', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
+    for fn in ('sherf_nerf_mlp', 'sherf_nerf_mlp2', 'sherf_nerf_mlp3', 'sherf_nerf_mlp3_pe', 'sherf_nerf_mlp_split', 'sherf_mlp_pack_stream'):
         getattr(lib, fn).restype, getattr(lib, fn).argtypes = protos[fn][0], [a[0] for a in protos[fn][1]]
     return lib
 
@@ -778,3 +778,83 @@ def test_mlp_kernel_source_on_cpu(mlp_lib, frame, prec, tol_sig, tol_rgb):
             out4 = torch.full((tiles * 32, 4), float('nan'))
             assert mlp_lib.sherf_nerf_mlp3(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), prec, n, _P(out4), None) == 0
             assert torch.equal(out4[:m], ref[:m]) and torch.isnan(out4[m:]).all() and int(counters[3]) == 0, m
+
+
+def test_encodings_from_the_gather_feed_the_network_the_same_bits(fwd_lib, mlp_lib, frame):
+    """Round 6: sherf_gather_tokens_pe writes PE6(x_c) / PE4(v_c) / PE5(rgb) as fp16 MFMA operand fragments and
+    sherf_nerf_mlp3_pe reads them instead of evaluating the encodings -- real sources on the host build: (a) tokens / extras equal the plain
+    fp16-table gather's bit for bit; (b) the fragments hold the oracle's encodings (renderer.py:875-916) in natural feature order, rounded to fp16,
+    zero padded; (c) the network's outputs equal sherf_nerf_mlp3's on the same tokens / extras BIT FOR BIT, for every sample count modulo the tile."""
+    from sherf_amd import mlp_pack
+    from tests.bwd_emulator import make_level
+    fx, state, r, g = frame
+    n = r['x_c'].shape[0]
+    planes = torch.from_numpy(fx['planes'])[0].contiguous(); obs_feat = torch.from_numpy(fx['obs_feat'])[0].contiguous()
+    obs_img = torch.from_numpy(fx['input_data']['obs_img_all'])[0, 0].contiguous()
+    P, (Hf, Wf), (H, W) = planes.shape[-1], obs_feat.shape[-2:], obs_img.shape[-2:]
+    Wr = state['renderer.conv1d_reprojection.weight'][:, :, 0]; br = state['renderer.conv1d_reprojection.bias']
+    Wp = state['renderer.conv1d_projection.weight'][:, :, 0]; bp = state['renderer.conv1d_projection.bias']
+    Wa, Wb, Wc = Wr[:, 0:32], Wr[:, 32:64], Wr[:, 64:96]
+    planes_h, feat_h, img4 = torch.zeros(3, P, P, 32), torch.zeros(Hf, Wf, 64), torch.zeros(H, W, 4)
+    assert fwd_lib.sherf_fold_tables(_P(planes), _P(Wa.t().contiguous()), _P(planes_h), P * P, 3, 32, P * P * 32, 1, None) == 0
+    assert fwd_lib.sherf_fold_tables(_P(obs_feat), _P(Wb.t().contiguous()), _P(feat_h), Hf * Wf, 2, 64, 32, 1, None) == 0
+    assert fwd_lib.sherf_img_to_hwc4(_P(obs_img), _P(img4), H * W, None) == 0
+    levels = (_lib.VoxLevel * 3)()
+    keep = []
+    for i, ((keys, act, shape), (c0, c1)) in enumerate(zip(r['taps'], ((0, 32), (32, 96), (96, 192)))):
+        emu, ker = make_level(keys, shape)
+        Fcat = torch.cat([Wc @ Wp[32 * s:32 * s + 32, c0:c1] for s in range(3)], 0)
+        rows = torch.zeros(ker['cap'], 96); rows[:act.shape[0]] = act @ Fcat.t()
+        rows_h = rows.half().contiguous()
+        keep += [ker['wp'], rows_h]
+        levels[i].wp, levels[i].rows = ker['wp'].data_ptr(), rows_h.data_ptr()
+        levels[i].D, levels[i].H, levels[i].W = shape
+    tok_bias = torch.cat([br + Wc @ bp[32 * s:32 * s + 32] for s in range(3)]).contiguous()
+    geom = torch.zeros(n, 8); geom[:, 0:3], geom[:, 3:6], geom[:, 6:8] = r['x_c'], r['v_c'], r['uv']
+    tiles = (n + 31) // 32
+    counters = torch.tensor([n, 0, 0, 0], dtype=torch.int32)
+    bounds = torch.from_numpy(fx['input_data']['t_world_bounds']).reshape(6).contiguous()
+    vox_min = r['sp_input']['bounds'][0].contiguous()
+    vox_sh = (ctypes.c_int32 * 3)(*[int(v) for v in r['sp_input']['out_sh']])
+    tokens, extras = torch.zeros(tiles * 3072), torch.zeros(tiles * 384)
+    assert fwd_lib.sherf_gather_tokens(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels, _P(tok_bias), _P(bounds),
+                                       _P(vox_min), vox_sh, 16, n, _P(tokens), _P(extras), None) == 0
+    tokens_p, extras_p = torch.zeros(tiles * 3072), torch.zeros(tiles * 384)
+    pefrag = torch.full((tiles * 7 * 64 * 8,), float('nan'), dtype=torch.float16)
+    assert fwd_lib.sherf_gather_tokens_pe(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels, _P(tok_bias), _P(bounds),
+                                          _P(vox_min), vox_sh, 16, n, _P(tokens_p), _P(extras_p), _P(pefrag), None) == 0
+    assert torch.equal(tokens_p, tokens) and torch.equal(extras_p, extras)                                  # (a)
+    # fp32 tables / the voxel-only pass / no buffer are refused
+    assert fwd_lib.sherf_gather_tokens_pe(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels, _P(tok_bias), _P(bounds),
+                                          _P(vox_min), vox_sh, 0, n, _P(tokens_p), _P(extras_p), _P(pefrag), None) != 0
+    assert fwd_lib.sherf_gather_tokens_pe(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels, _P(tok_bias), _P(bounds),
+                                          _P(vox_min), vox_sh, 18, n, _P(tokens_p), _P(extras_p), _P(pefrag), None) != 0
+    assert fwd_lib.sherf_gather_tokens_pe(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels, _P(tok_bias), _P(bounds),
+                                          _P(vox_min), vox_sh, 16, n, _P(tokens_p), _P(extras_p), None, None) != 0
+    # (b) pefrag[tile][q][h][j][8]: feature 16 kb + 8 h + e of the natural order [v, sin(2^0 v), cos(2^0 v), ...]
+    ex = extras.view(tiles, 12, 32).permute(0, 2, 1).reshape(tiles * 32, 12)
+    pf = pefrag.view(tiles, 7, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(tiles * 32, 7 * 16).float()          # [sample][q * 16 + 8 h + e]
+    assert torch.isfinite(pf).all()
+    for lo, hi, cols, L, width in ((0, 48, slice(0, 3), 6, 39), (48, 80, slice(3, 6), 4, 27), (80, 112, slice(6, 9), 5, 32)):
+        want = O.positional_encoding(ex[:n, cols], L)[:, :width]
+        got = pf[:n, lo:hi]
+        assert float((got[:, :width] - want).abs().max()) < 1.2e-3, (lo, float((got[:, :width] - want).abs().max()))   # fp16 rounding of values in [-1, 1] (x_c up to ~1.3)
+        assert bool((got[:, width:] == 0).all())
+    assert bool((pf[n:] [:, 3:48:3] >= 0).all())                                                           # (padding columns: PE(0): finite)
+    # (c) the network on the same tokens / extras
+    stream, wbias, _ = mlp_pack.pack({k: v.numpy() for k, v in state.items() if not k.startswith('renderer.encoder_3d.')}, prec=2)
+    stream_t, wbias_t = torch.from_numpy(stream), torch.from_numpy(wbias)
+    for m in sorted({n, n - 32, n - 40, 33, 1}):
+        if m < 1:
+            continue
+        for notrans in (0, 256):
+            counters[0], counters[3] = m, 0
+            ref = torch.full((tiles * 32, 4), float('nan'))
+            assert mlp_lib.sherf_nerf_mlp3(_P(counters), _P(tokens), _P(extras), _P(stream_t), _P(wbias_t), 2 | notrans, n, _P(ref), None) == 0
+            out = torch.full((tiles * 32, 4), float('nan'))
+            assert mlp_lib.sherf_nerf_mlp3_pe(_P(counters), _P(tokens), _P(extras), _P(pefrag), _P(stream_t), _P(wbias_t), 2 | notrans, n, _P(out), None) == 0
+            assert torch.equal(out[:m], ref[:m]) and torch.isnan(out[m:]).all() and int(counters[3]) == 0, (m, notrans)
+    counters[0] = n
+    for bad in (0, 1):                                                                                      # only the single-fp16-product stream has this form
+        assert mlp_lib.sherf_nerf_mlp3_pe(_P(counters), _P(tokens), _P(extras), _P(pefrag), _P(stream_t), _P(wbias_t), bad, n, _P(out), None) != 0
+    assert mlp_lib.sherf_nerf_mlp3_pe(_P(counters), _P(tokens), _P(extras), None, _P(stream_t), _P(wbias_t), 2, n, _P(out), None) != 0
