@@ -176,7 +176,9 @@ __device__ int g_mlp_trace_every = 0;
 #endif
 
 // SHERF_MLP_ABLATE (profiling builds only; results are garbage): 32 = no weight DMA, 64 = no workgroup barriers, 256 = no transformer arithmetic (z = the raw tokens), 512 = no positional
-// encodings (zero fragments), 1024 = layer epilogues without conversion / ReLU (16 moves instead of 32 VALU)
+// encodings (zero fragments), 1024 = layer epilogues without conversion / ReLU (16 moves instead of 32 VALU), 2048 (pipelined decoder; round 6) = NO layer
+// epilogue at all: every layer's B operands stay the fp16 fused tokens z_0 / z_1 (real data, real weights, the full MFMA / ring / barrier stream):
+// with 256 + 512 the "MFMA-only" instruction stream whose duration is what the power cap leaves the matrix pipe on realistic operands
 #ifndef SHERF_MLP_ABLATE
 #define SHERF_MLP_ABLATE 0
 #endif
@@ -909,6 +911,7 @@ __device__ __forceinline__ void decoder_tile(Ctx<PREC>& cx, const int32_t* __res
 template <int PREC, bool RELU>
 __device__ __forceinline__ void epi_piece(const f32x16& a0, const f32x16& a1, BFrag<PREC>* out, int i) {
     static_assert(PREC != 1, "single-product precisions");
+    if constexpr ((SHERF_MLP_ABLATE & 2048) != 0) return;
     const f32x16& a = i < 2 ? a0 : a1;
     const int o = (i & 1) * 8;
     constexpr bool PK = RELU && PREC == 2 && SHERF_MLP_PK_RELU;
@@ -951,6 +954,10 @@ __device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __r
     if constexpr (SHERF_MLP_DECODER_PRIO > 0) __builtin_amdgcn_s_setprio(SHERF_MLP_DECODER_PRIO);
     int step = 2;
     BFrag<PREC> ha[8], hb[8];
+    if constexpr ((SHERF_MLP_ABLATE & 2048) != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ha[i] = z0b[i & 1]; hb[i] = z1b[i & 1]; }
+    }
     f32x16 X0, X1, Y0, Y1;                                           // the two accumulator pairs
     AFrag<PREC> cur = load_units<PREC>(cx.slot(step));
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1046,6 +1053,8 @@ __device__ __forceinline__ void decoder_tile_p(Ctx<PREC>& cx, const int32_t* __r
         mma_chains_f<PREC, 2, true, true>(s, 0, pv, Y0, Y1, cur, 0, none);
         mma_chains_f<PREC, 2, true, false>(s, 4, z1b, Y0, Y1, cur, 2, none);
         SHERF_NEXT_STEP();
+        if constexpr ((SHERF_MLP_ABLATE & 2048) != 0) { mfma_settle(Y0, Y1); gb[0] = z0b[0]; gb[1] = z0b[1]; gb[2] = z1b[0]; gb[3] = z1b[1]; }
+        else
         finish_pair<PREC, true>(Y0, Y1, gb);                         // rgb_linear needs all of it: nothing to ride on
     }
     {

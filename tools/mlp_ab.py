@@ -29,9 +29,10 @@ def main():
     ap.add_argument('--config', default='cfg2_ri')
     ap.add_argument('--precision', default='f16', choices=['f16x3', 'f16', 'bf16'])
     ap.add_argument('--stress', type=int, default=0)
-    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), tt (sherf_nerf_mlp2: two tiles per wave), pp (sherf_nerf_mlp3: epilogues inside the MFMA stream); pipe = the round-4 pipelined experiment, if the library has it')
+    ap.add_argument('--forms', default='one,two', help='launch forms to time: one (sherf_nerf_mlp), two (sherf_nerf_mlp_split), tt (sherf_nerf_mlp2: two tiles per wave), pp (sherf_nerf_mlp3: epilogues inside the MFMA stream), pe (sherf_nerf_mlp3_pe: pp with the encodings read as fragments the gather wrote); pipe = the round-4 pipelined experiment, if the library has it')
     ap.add_argument('--sustain', type=float, default=0.0, help='after the timings: launch the LAST form back to back for this many seconds (power / clock telemetry: tools/power_probe.py)')
     ap.add_argument('--zero', default='', help="power probe: 'tokens' = zero tokens / extras, 'all' = zero weights too (same instruction stream, less switching; outputs are not compared)")
+    ap.add_argument('--only', default='', help='comma list of library tags to run (default: the product library and every libsherf_hip_<tag>.so beside it)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'mlp_ab.json'))
     a = ap.parse_args()
     import bench
@@ -40,7 +41,9 @@ def main():
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     P = MLP_PRECISIONS[a.precision]
-    w = bench.make_workload(argparse.Namespace(config=a.config, precision='f16x3', bn_mode='train'), 0.4, dev)
+    # form `pe` (round 6: sherf_nerf_mlp3_pe) needs the frame's encodings as fragments: the frame is then rendered in the configuration that writes them
+    want_pe = 'pe' in a.forms.split(',')
+    w = bench.make_workload(argparse.Namespace(config=a.config, precision='f16' if want_pe else 'f16x3', bn_mode='train'), 0.4, dev)
     for _ in range(2):
         bench.render_frame(w)
     torch.cuda.synchronize()
@@ -73,9 +76,14 @@ def main():
         pp = getattr(lib, 'sherf_nerf_mlp3', None)
         if pp is not None:
             pp.restype, pp.argtypes = one.restype, one.argtypes
-        return one, two, pipe, tt, pp
+        pe = getattr(lib, 'sherf_nerf_mlp3_pe', None)
+        if pe is not None:
+            pe.restype, pe.argtypes = ct.c_int, [ct.c_void_p] * 6 + [ct.c_int, ct.c_int64, ct.c_void_p, ct.c_void_p]
+        return one, two, pipe, tt, pp, pe
 
     def launch(fn, form):
+        if form == 'pe':
+            return fn[5](A(counters), A(ws['tokens']), A(ws['extras']), A(ws['pefrag']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
         if form in ('one', 'pipe', 'tt', 'pp'):
             return fn[{'one': 0, 'pipe': 2, 'tt': 3, 'pp': 4}[form]](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(out), stream)
         return fn[1](A(counters), A(ws['tokens']), A(ws['extras']), A(wc['stream']), A(wc['wbias']), P, capx, A(zfrag), A(out), stream)
@@ -92,12 +100,14 @@ def main():
     if a.zero:
         ws = dict(ws)
         ws['tokens'] = torch.zeros_like(ws['tokens']); ws['extras'] = torch.zeros_like(ws['extras'])
+        if ws.get('pefrag') is not None:
+            ws['pefrag'] = torch.zeros_like(ws['pefrag'])
         if a.zero == 'all':
             wc = {k: torch.zeros_like(v) for k, v in wc.items()}
     libs = {'product': os.path.join(ROOT, 'sherf_amd', 'libsherf_hip.so')}
     for path in sorted(glob.glob(os.path.join(ROOT, 'sherf_amd', 'libsherf_hip_*.so'))):
         tag = os.path.basename(path)[len('libsherf_hip_'):-3]
-        if tag not in ('bwd', 'ops', 'trace') and not tag.startswith('nn'):
+        if tag not in ('bwd', 'ops', 'trace') and not tag.startswith('nn') and (not a.only or tag in a.only.split(',')):
             libs[tag] = path
     bound = {t: bind(p) for t, p in libs.items()}
     launch(bound['product'], 'one'); torch.cuda.synchronize()
@@ -105,7 +115,8 @@ def main():
     forms = [f for f in a.forms.split(',') if f]
     arms = [(t, form) for t, fn in bound.items() for form in forms
             if form == 'one' or (form == 'two' and fn[1] is not None) or (form == 'pipe' and fn[2] is not None and a.precision != 'f16x3')
-            or (form == 'tt' and fn[3] is not None and a.precision != 'f16x3') or (form == 'pp' and fn[4] is not None and a.precision != 'f16x3')]
+            or (form == 'tt' and fn[3] is not None and a.precision != 'f16x3') or (form == 'pp' and fn[4] is not None and a.precision != 'f16x3')
+            or (form == 'pe' and fn[5] is not None and a.precision == 'f16' and ws.get('pefrag') is not None)]
     for _ in range(40):                                         # clock warm-up
         launch(bound['product'], 'one')
     torch.cuda.synchronize()
@@ -144,7 +155,7 @@ def main():
         idxs = [torch.randint(0, big.numel(), (n,), device=dev) for n in (1 << 18, 1 << 21, 1 << 23, 3 << 20)]
         bad = {}
         for form in forms:
-            if form in ('pipe', 'tt', 'pp') and a.precision == 'f16x3':
+            if form in ('pipe', 'tt', 'pp', 'pe') and a.precision == 'f16x3':
                 continue
             n_bad_launches, n_bad_words = 0, 0
             for it in range(a.stress):
