@@ -453,6 +453,13 @@ int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* lev
  * this per-thread slot index; sherf_render_frame serialises ENQUEUES on a device with a mutex (the join events are shared), so it is thread-safe
  * but not lock-free -- the "no global mutable state" of SURVEY section 8(b) holds for every other entry point, not for the frame driver. */
 int sherf_frame_count(int32_t* nv_host);
+/* hipGraph replay of frames (round 6): the second consecutive sherf_render_frame call (phase 1 or 3) with the same descriptor bytes, encoder plan,
+ * streams and debug words is captured from the caller's stream and replayed by one hipGraphLaunch from then on (a frame's launch sequence depends on
+ * nothing else: no data-dependent value reaches the host).  Frames with SHERF_FRAME_REPORT_COUNT / _EXACT_GRIDS, profiled frames and new
+ * descriptors are enqueued launch by launch as before.  On by default (environment SHERF_FRAME_GRAPH=0: off); sherf_frame_graphs(0) turns it off and
+ * drops every captured graph, (1) turns it on.  sherf_frame_graph_stats: {captures, replays, eagerly enqueued frames, failed captures} since load. */
+int sherf_frame_graphs(int enable);
+int sherf_frame_graph_stats(int64_t* stats_host, int32_t n);
 /* phase: 1 = everything up to the per-sample network, 2 = compositing, 3 = both; 4 (alone) = the sampler only (cell lists, shell mask,
  * nearest vertex, compaction: counters[0] = the frame's number of valid samples) -- what a caller runs once to size tok_capacity. */
 /* stream_aux (may be NULL): a third stream on which the occupancy structure of voxel levels 1-3 is built while the

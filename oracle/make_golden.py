@@ -37,14 +37,15 @@ def import_reference():
     return R, T
 
 
-def run(cfg_name, R, T, out_dir, use_trans=True):
+def run(cfg_name, R, T, out_dir, use_trans=True, branches=(True, True, True)):
     """use_trans=False (round 5): the same frame through the unmodified reference built WITHOUT its transformer (renderer.py:261, 427) ->
-    renderer_<cfg>_notrans.npz (final image + per-sample rgb / sigma + the discrete selections; the reference-init variant only)."""
+    renderer_<cfg>_notrans.npz (final image + per-sample rgb / sigma + the discrete selections; the reference-init variant only).
+    branches (round 6): the constructor's use_1d / use_2d / use_3d_feature switches (renderer.py:261-269, 405-425) -> renderer_<cfg>_f<abc>.npz."""
     from oracle import fixtures
     fx = fixtures.renderer_inputs(cfg_name)
     c = fx['cfg']
     torch.manual_seed(0)
-    rend = R.ImportanceRenderer(True, True, True, use_trans=use_trans, use_NeRF_decoder=True)
+    rend = R.ImportanceRenderer(*[bool(b) for b in branches], use_trans=use_trans, use_NeRF_decoder=True)
     dec = T.NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.', fixtures.variant_of(cfg_name))
     fixtures.load_seeded_state(dec, 'decoder.', fixtures.variant_of(cfg_name))
@@ -136,7 +137,8 @@ def run(cfg_name, R, T, out_dir, use_trans=True):
         ref_cpu_seconds=np.float64(dt),
         sp_coord=cap['sp_coord'], sp_out_sh=cap['sp_out_sh'], sp_bounds=cap['sp_bounds'],
     )
-    if use_trans and c['H'] * c['W'] * c['S'] <= 64 * 64 * 32:   # full per-stage intermediates only for the tiny configs
+    all_on = all(branches)
+    if use_trans and all_on and c['H'] * c['W'] * c['S'] <= 64 * 64 * 32:   # full per-stage intermediates only for the tiny configs
         out.update(
             x_c=cap['t2c'][0][0][0].numpy(), v_c=cap['t2c'][0][1][0].numpy(),
             t_vert_id=knn_calls[2][1].view(-1).numpy().astype(np.int32),
@@ -147,7 +149,8 @@ def run(cfg_name, R, T, out_dir, use_trans=True):
             weights=cap['weights'][0, :, :, 0].numpy(),
             obs_vertex_canonical=cap['obs_vertex_canonical'],
         )
-    path = os.path.join(out_dir, f'renderer_{cfg_name}.npz' if use_trans else f'renderer_{cfg_name}_notrans.npz')
+    tag = ('' if use_trans else '_notrans') + ('' if all_on else '_f' + ''.join('1' if b else '0' for b in branches))
+    path = os.path.join(out_dir, f'renderer_{cfg_name}{tag}.npz')
     np.savez_compressed(path, **out)
     print(f'{cfg_name}: R={rgb.shape[1]} Nv={valid.numel()}/{mask.numel()} ({valid.numel()/mask.numel():.3%}) '
           f'ref forward {dt:.2f}s  rgb range [{rgb.min():.3f},{rgb.max():.3f}] acc max {acc.max():.3f} -> {path} '
@@ -385,6 +388,10 @@ if __name__ == '__main__':
     R, T = import_reference()
     if names == ['notrans']:                            # round 5: the reference built with use_trans = False, the reference-init tiny frame
         run('tiny_ri', R, T, out_dir, use_trans=False); sys.exit(0)
+    if names and names[0] == 'branches':                # round 6: the feature-branch switches, the reference-init tiny frame (e.g. `branches 110 101 011 100`)
+        for b in names[1:] or ['110', '101', '011', '100']:
+            run('tiny_ri', R, T, out_dir, branches=tuple(ch == '1' for ch in b))
+        sys.exit(0)
     if names == ['refinit']:
         run_refinit_check(R, T, out_dir); sys.exit(0)
     if all(n.endswith('_ri') for n in names):           # only the reference-init variants: leave the other files alone

@@ -106,11 +106,11 @@ extern "C" int sherf_frame_count(int32_t* nv_host) {
     return SHERF_OK;
 }
 
-extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
-                                  sherf_stream_t stream_side, sherf_stream_t stream_aux) {
-    SHERF_CHECK_ARG(f && levels && ((phase & 3) || phase == 4) && stream_side != stream_main && (!stream_aux || (stream_aux != stream_main && stream_aux != stream_side)));
+// The frame's launches, enqueued one by one on the three streams (with g_frame_mu held).  sherf_render_frame below either calls this, or captures
+// what it enqueues into a hipGraph once and replays the graph from then on.
+static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
+                                sherf_stream_t stream_side, sherf_stream_t stream_aux) {
     hipStream_t main = as_stream(stream_main), side = as_stream(stream_side);
-    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
     if (phase == 4) {                                                // the sampler alone: counters[0] = the frame's valid samples
         SHERF_CHECK_ARG(f->R > 0 && f->S > 0 && f->capacity > 0);
         const bool lists = f->near_hdr && f->near_list;
@@ -339,5 +339,137 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         }
     }
 #undef SHERF_PROF
+    return SHERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// hipGraph replay of a frame (round 6).  A frame is ~65 launches, ~20 event operations and a memset on three streams:
+// 0.2-0.28 ms of host time per call, at the head of every frame's latency.  Its launch sequence is a pure function of the descriptor -- every
+// pointer, size, flag and the encoder plan it names -- the three stream handles, the debug / experiment words and the device: none of the
+// data-dependent quantities (the valid-sample count, the voxel levels' row counts) ever reaches the host.  So the SECOND consecutive call with
+// the same key is captured (hipStreamBeginCapture on the caller's stream; the side / aux streams join the capture through the library's own
+// fork / join events, exactly as they join the frame) and instantiated, and from then on a frame costs one hipGraphLaunch.  A frame with new
+// pointers (fresh input tensors, a re-sized workspace, other weights) has a new key: it is enqueued launch by launch as before and starts its own
+// count, so sequences lose nothing.  Not captured: frames that report their count (SHERF_FRAME_REPORT_COUNT / _EXACT_GRIDS: a per-call pinned
+// slot / a host wait), profiled frames (sherf_profile_frames: per-frame timing events), the host-stamp experiments, phase 2 / 4 alone.  A capture
+// that fails for any reason renders the frame eagerly and never tries that key again.  sherf_frame_graphs(0) turns the whole mechanism off
+// (environment SHERF_FRAME_GRAPH=0: from the start); sherf_frame_graph_stats reads what happened.
+namespace {
+
+struct GraphEntry {
+    uint64_t key = 0, stamp = 0;
+    int state = 0;                    // 0 free, 1 seen once (eager), 2 captured, 3 capture failed (eager for good)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    sherf_vox_level lv[3];            // what the encoder's enqueue wrote into `levels_out_host` (host-side output of the call)
+};
+constexpr int kGraphSlots = 8;
+GraphEntry g_graphs[kMaxDev][kGraphSlots];
+uint64_t g_graph_clock = 0;
+int g_graph_on = -1;                  // -1: read SHERF_FRAME_GRAPH at the first frame
+int64_t g_graph_stats[4] = {0, 0, 0, 0};   // captures, replays, eager frames, failed captures
+
+inline void fnv(uint64_t& h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+}
+
+void graph_drop(GraphEntry& e) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+    e = GraphEntry();
+}
+
+}  // namespace
+
+extern "C" int sherf_frame_graphs(int enable) {
+    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    g_graph_on = enable ? 1 : 0;
+    if (!enable)
+        for (auto& dev : g_graphs)
+            for (auto& e : dev) graph_drop(e);
+    return SHERF_OK;
+}
+
+extern "C" int sherf_frame_graph_stats(int64_t* stats_host, int32_t n) {
+    SHERF_CHECK_ARG(stats_host && n >= 4);
+    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    for (int i = 0; i < 4; ++i) stats_host[i] = g_graph_stats[i];
+    return SHERF_OK;
+}
+
+extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_level* levels, sherf_stream_t stream_main,
+                                  sherf_stream_t stream_side, sherf_stream_t stream_aux) {
+    SHERF_CHECK_ARG(f && levels && ((phase & 3) || phase == 4) && stream_side != stream_main && (!stream_aux || (stream_aux != stream_main && stream_aux != stream_side)));
+    std::lock_guard<std::mutex> frame_lock(g_frame_mu);
+    if (g_graph_on < 0) {
+        const char* e = getenv("SHERF_FRAME_GRAPH");
+        g_graph_on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    int dev = 0;
+    bool prof;
+    { std::lock_guard<std::mutex> lk(g_mu); prof = g_prof_on; }
+    const int xp = sherf_experiment();
+    const bool eligible = g_graph_on == 1 && (phase == 1 || phase == 3) && !prof && !(f->flags & (SHERF_FRAME_EXACT_GRIDS | SHERF_FRAME_REPORT_COUNT)) &&
+                          !(xp & (16 | 32)) && f->vox_plan && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev && g_dev[dev].init;
+    if (!eligible) {
+        ++g_graph_stats[2];
+        return render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
+    }
+    uint64_t key = 1469598103934665603ull;
+    fnv(key, f, sizeof(*f));
+    fnv(key, f->vox_plan, sizeof(*f->vox_plan));
+    const uint64_t words[7] = {(uint64_t)phase, (uint64_t)(size_t)stream_main, (uint64_t)(size_t)stream_side, (uint64_t)(size_t)stream_aux,
+                               (uint64_t)(unsigned)g_sherf_debug, (uint64_t)(unsigned)xp, (uint64_t)dev};
+    fnv(key, words, sizeof(words));
+    if (key == 0) key = 1;
+    GraphEntry* slot = nullptr;
+    GraphEntry* lru = &g_graphs[dev][0];
+    for (auto& e : g_graphs[dev]) {
+        if (e.state && e.key == key) { slot = &e; break; }
+        if (e.stamp < lru->stamp) lru = &e;
+    }
+    hipStream_t main = as_stream(stream_main);
+    if (slot && slot->state == 2) {                                   // replay
+        slot->stamp = ++g_graph_clock;
+        for (int i = 0; i < 3; ++i) levels[i] = slot->lv[i];
+        SHERF_HIP_CHECK(hipGraphLaunch(slot->exec, main));
+        ++g_graph_stats[1];
+        return SHERF_OK;
+    }
+    if (!slot) {                                                      // first sighting: eager, remember the key
+        graph_drop(*lru);
+        lru->key = key; lru->state = 1; lru->stamp = ++g_graph_clock;
+        ++g_graph_stats[2];
+        return render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
+    }
+    slot->stamp = ++g_graph_clock;
+    if (slot->state == 3) {
+        ++g_graph_stats[2];
+        return render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
+    }
+    // second sighting: capture, instantiate, launch
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int rc = SHERF_ELAUNCH;
+    bool ok = hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        rc = render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
+        const hipError_t e = hipStreamEndCapture(main, &graph);       // (always ends the capture, also after a failed enqueue)
+        ok = rc == SHERF_OK && e == hipSuccess && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec != nullptr;
+    if (ok) ok = hipGraphLaunch(exec, main) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        slot->state = 3;
+        ++g_graph_stats[3]; ++g_graph_stats[2];
+        return render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
+    }
+    slot->graph = graph; slot->exec = exec; slot->state = 2;
+    for (int i = 0; i < 3; ++i) slot->lv[i] = levels[i];
+    ++g_graph_stats[0];
     return SHERF_OK;
 }

@@ -606,7 +606,7 @@ class ImportanceRenderer(nn.Module):
             key = memo[2]
         else:
             ps = []
-            for m in (self.conv1d_projection, self.conv1d_reprojection, self.transformer, decoder):
+            for m in (self.conv1d_projection, getattr(self, 'conv1d_reprojection', None), self.transformer, decoder):
                 if m is not None:                       # (use_trans = False: no transformer)
                     fast_params(m, ps)
             key = state_key(ps) + (str(device),)
@@ -614,10 +614,9 @@ class ImportanceRenderer(nn.Module):
                 self.__dict__['_frame_memo'] = (decoder, device, key)
         wc = self._wcache
         if wc is None or wc['key'] != key:
-            Wr = self.conv1d_reprojection.weight.detach().float()[:, :, 0]          # [32, 96]
+            Wr, br = self._effective_reprojection()                                  # [32, 96], [32]
             Wp = self.conv1d_projection.weight.detach().float()[:, :, 0]            # [96, 192]
             bp = self.conv1d_projection.bias.detach().float()
-            br = self.conv1d_reprojection.bias.detach().float()
             Wa, Wb, Wc = Wr[:, 0:32], Wr[:, 32:64], Wr[:, 64:96]
             cols = ((0, 32), (32, 96), (96, 192))
             fold = []
@@ -633,6 +632,35 @@ class ImportanceRenderer(nn.Module):
         out['stream'], out['wbias'] = wc['streams'][prec]
         return out
 
+    def feature_branches(self):
+        """(1d, 2d, 3d): which feature branches reach the fused tokens -- the constructor's switches read the way run_model's if / elif chain reads
+        them (renderer.py:405-425): all three; any two; otherwise the tri-plane features alone, whatever the remaining switches say (the chain has no
+        branch for a single 2-D or 3-D source: `sampled_features` stays the plane samples)."""
+        a, b, c = bool(self.use_1d_feature), bool(self.use_2d_feature), bool(self.use_3d_feature)
+        return (a, b, c) if a + b + c >= 2 else (True, False, False)
+
+    def _effective_reprojection(self):
+        """conv1d_reprojection as the [32, 96] matrix over [tri-plane | pixel-aligned | voxel] features + bias that the folded tables, the gather and
+        the network's slot-2 completion are built on, for EVERY combination of use_1d/2d/3d_feature (round 6; renderer.py:266-269, 405-425): a
+        two-branch renderer owns a Conv1d(64, 32) whose two 32-column blocks act on the two branches it has, in the order 1d, 2d, 3d -- the missing
+        branch's block is zero (its taps then add exact zeros: same sums as not taking them); tri-plane features alone pass through unprojected
+        (identity, no bias; there is no conv1d_reprojection module then)."""
+        on = self.feature_branches()
+        if sum(on) == 3:
+            return self.conv1d_reprojection.weight.detach().float()[:, :, 0], self.conv1d_reprojection.bias.detach().float()
+        dev = self.conv1d_projection.weight.device
+        W = torch.zeros(32, 96, device=dev)
+        if sum(on) == 1:
+            W[:, 0:32] = torch.eye(32, device=dev)
+            return W, torch.zeros(32, device=dev)
+        Wr = self.conv1d_reprojection.weight.detach().float()[:, :, 0]
+        k = 0
+        for i in range(3):
+            if on[i]:
+                W[:, 32 * i:32 * i + 32] = Wr[:, 32 * k:32 * k + 32]
+                k += 1
+        return W, self.conv1d_reprojection.bias.detach().float()
+
     def _pack_stream(self, decoder, device, prec, wc):
         """The MLP's fragment stream + bias table for `prec`, packed ON THE DEVICE from the live parameters (sherf_mlp_pack_stream applying
         mlp_pack.stream_index's element map: bit-identical to the host packer mlp_pack.pack, tests/test_mlp_pack.py, at ~0.1 ms
@@ -640,6 +668,10 @@ class ImportanceRenderer(nn.Module):
         (mlp_pack.check_f16_range) are made on the device and read back once per repack: same ValueError."""
         named = {'renderer.' + k: v for k, v in self.named_parameters() if not k.startswith('encoder_3d.')}
         named.update({'decoder.' + k: v for k, v in decoder.named_parameters()})
+        if sum(self.feature_branches()) != 3:
+            # fewer than three feature branches (round 6): the stream's slot-2 completion W_b . PE5(rgb) takes the EFFECTIVE [32, 96] matrix
+            Wr, br = self._effective_reprojection()
+            named['renderer.conv1d_reprojection.weight'], named['renderer.conv1d_reprojection.bias'] = Wr[:, :, None].to(device), br.to(device)
         if self.transformer is None:
             # use_trans = False (renderer.py:261, 427): the kernel walks past the transformer's chunks (SHERF_MLP_NO_TRANSFORMER); their slots of the
             # stream are packed from zeros so that the layout -- and every other chunk's place in it -- stays the one the kernel knows
@@ -763,9 +795,12 @@ class ImportanceRenderer(nn.Module):
             fr.flags |= 8
         # round 6: the positional encodings leave the power-bound network kernel for the latency-bound gather (SHERF_FRAME_PE_FRAGS; the frame
         # driver ignores the flag outside the configuration it is built for: fp16 tables, single fp16 products, the pipelined form, one part)
+        # MEASURED (MI355X, profiles/r06_call_a_*): bit-identical frames; the network kernel 0.509 -> 0.496 ms (-2.4 %; alone on the frame's tokens:
+        # 0.526 -> 0.523), the gather 0.463 -> 0.602 ms: the frame LOSES 0.14 ms.  Opt-in (rendering option / attribute `pe_in_gather`,
+        # SHERF_PE_IN_GATHER=1), off by default.
         pe = getattr(self, '_opt_pe_in_gather', None)
         if pe is None:
-            pe = getattr(self, 'pe_in_gather', True)
+            pe = getattr(self, 'pe_in_gather', os.environ.get('SHERF_PE_IN_GATHER', '0') == '1')
         fr.pefrag = None
         if pe and cfg[0] == 'f16' and cfg[1] == 'f16' and form == 'pipelined' and not split:
             fr.pefrag = _lib.addr(self._workspace(dev).pefrag(dev))
@@ -811,8 +846,8 @@ class ImportanceRenderer(nn.Module):
     def forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
                 decoder, ray_origins, ray_directions, near, far, input_data, rendering_options):
         if getattr(self, 'enable_autograd', False) and torch.is_grad_enabled() and not getattr(self, '_in_autograd', False):
-            if not self.use_trans:
-                raise NotImplementedError('the backward through the HIP kernels covers use_trans = True only (the shipped configuration)')
+            if not self.use_trans or sum(self.feature_branches()) != 3:
+                raise NotImplementedError('the backward through the HIP kernels covers the shipped configuration only (all three feature branches, use_trans = True)')
             # opt-in training path (BASELINE config 5): the same forward, recorded as one autograd node whose backward runs
             # the HIP backward pipeline (sherf_amd/backward.py; experimental until verified on hardware)
             from .backward import RenderFunction, _named_params
@@ -828,9 +863,8 @@ class ImportanceRenderer(nn.Module):
                     self.encoder_3d._force_stats_update = False
             return RenderFunction.apply(self, decoder, call, planes, obs_input_feature, canonical_sp_conv_volume.features,
                                         *[p for _, p in _named_params(self, decoder)])
-        if not (self.use_1d_feature and self.use_2d_feature and self.use_3d_feature and self.use_NeRF_decoder):
-            raise NotImplementedError('sherf_amd implements use_1d/2d/3d_feature and use_NeRF_decoder all True (every train_*.sh / eval_*.sh); '
-                                      'use_trans may be False (round 5)')
+        if not self.use_NeRF_decoder:
+            raise NotImplementedError('sherf_amd implements use_NeRF_decoder = True (every train_*.sh / eval_*.sh); the OSGDecoder path (triplane.py:242-265) is not built')
         if not ray_origins.is_cuda:
             raise RuntimeError('sherf_amd.ImportanceRenderer runs on the GPU only (no CPU fallback)')
         if ray_origins.shape[0] != 1:
@@ -901,7 +935,13 @@ class ImportanceRenderer(nn.Module):
         srcs = (prm['poses'], tprm['poses'], oprm['poses'], prm['shapes'], tprm['shapes'], oprm['shapes'])
         skey = tuple([(id(t), t._version, t.data_ptr()) for t in srcs])
         if wsp.stacked is None or wsp.stacked[0] != skey:
-            wsp.stacked = (skey, torch.stack([f32(t).reshape(72) for t in srcs[:3]]), torch.stack([f32(t).reshape(10) for t in srcs[3:]]), srcs)
+            # (written into the SAME two tensors every time: their addresses are part of the frame graph's key, csrc/frame.hip)
+            old = wsp.stacked
+            po = old[1] if old is not None and old[1].device == dev else torch.empty(3, 72, dtype=F32, device=dev)
+            sh = old[2] if old is not None and old[2].device == dev else torch.empty(3, 10, dtype=F32, device=dev)
+            torch.stack([f32(t).reshape(72) for t in srcs[:3]], out=po)
+            torch.stack([f32(t).reshape(10) for t in srcs[3:]], out=sh)
+            wsp.stacked = (skey, po, sh, srcs)
         poses, shapes = wsp.stacked[1], wsp.stacked[2]
         fr.poses, fr.shapes = A(poses), A(shapes)
         nl = wsp.desc[3]
@@ -912,9 +952,17 @@ class ImportanceRenderer(nn.Module):
         # the frame's outputs: ONE fresh buffer per call, planar [rgb (3R) | depth (R) | acc (R)], written by the compositing kernel and
         # returned as views -- no copies behind the frame (rounds 1-2 cloned three workspace tensors: three launches per frame), and
         # a caller may keep as many frames as it likes
-        out = torch.empty(5 * R, dtype=torch.float32, device=dev)
+        # Round 6: frames replay as hipGraphs (csrc/frame.hip), keyed on every pointer of the descriptor -- so on the GPU the compositing kernel
+        # writes a buffer OWNED BY THE WORKSPACE (the same address frame after frame) and the caller's fresh buffer is one copy behind the frame
+        # (5 R floats: ~3 us); with graphs off (SHERF_FRAME_GRAPH=0) and on the host build the kernel writes the fresh buffer itself
+        static_out = dev.type == 'cuda' and os.environ.get('SHERF_FRAME_GRAPH', '1') != '0'
+        if static_out:
+            out = wsp.t.get('out_static')
+            if out is None or out.numel() != 5 * R or out.device != dev:
+                out = wsp.t['out_static'] = torch.empty(5 * R, dtype=torch.float32, device=dev)
+        else:
+            out = torch.empty(5 * R, dtype=torch.float32, device=dev)
         fr.rgb, fr.depth, fr.acc = A(out), A(out) + 12 * R, A(out) + 16 * R
-        ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
         fr.obs_R, fr.obs_Th = a32(oprm['R'], 9), a32(oprm['Th'], 3)
         fr.cam_R, fr.cam_T, fr.cam_K = a32(input_data['obs_R_all'], 9), a32(input_data['obs_T_all'], 3), a32(input_data['obs_K_all'], 9)
         fr.verts, fr.tverts = a32(input_data['vertices'], V * 3), a32(input_data['t_vertices'], V * 3)
@@ -1023,6 +1071,9 @@ class ImportanceRenderer(nn.Module):
                     decide = None
                     self._wcache['auto'] = None
                 enqueue()
+        if static_out:
+            out = out.clone()
+        ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
         self.encoder_3d.finish(pl)
         if decide is not None:
             decide()

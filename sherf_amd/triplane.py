@@ -130,6 +130,10 @@ class _GraphedProducer:
         except Exception as ex:                                      # capture not possible here (an op that synchronises, an old runtime): eager from now on
             self.off, self.graph, self.key = True, None, None
             self.error = f'{type(ex).__name__}: {str(ex)[:200]}'
+            try:
+                torch.cuda.synchronize()                             # (a failed capture leaves nothing in flight; surface anything it did leave here)
+            except Exception:
+                pass
             import warnings
             warnings.warn(f'sherf_amd: hipGraph replay of {type(self.module).__name__} disabled, eager calls from now on ({self.error})')
             return self.fn(*args, **kw)

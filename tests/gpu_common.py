@@ -81,16 +81,16 @@ def to_cuda(x):
     return x
 
 
-def hip_modules(precision='f16x3', variant='seeded', use_trans=True):
-    """(renderer, decoder) with the variant's weights, one pair per (precision, variant, use_trans) for the whole session."""
-    return _hip_modules(precision, variant, use_trans)
+def hip_modules(precision='f16x3', variant='seeded', use_trans=True, branches=(True, True, True)):
+    """(renderer, decoder) with the variant's weights, one pair per (precision, variant, use_trans, feature branches) for the whole session."""
+    return _hip_modules(precision, variant, use_trans, tuple(bool(b) for b in branches))
 
 
 @functools.lru_cache(None)
-def _hip_modules(precision, variant, use_trans=True):
+def _hip_modules(precision, variant, use_trans=True, branches=(True, True, True)):
     from sherf_amd.renderer import ImportanceRenderer
     from sherf_amd.triplane import NeRFDecoder
-    rend = ImportanceRenderer(True, True, True, use_trans=use_trans, use_NeRF_decoder=True, smpl=smpl(), mlp_precision=precision)
+    rend = ImportanceRenderer(*branches, use_trans=use_trans, use_NeRF_decoder=True, smpl=smpl(), mlp_precision=precision)
     dec = NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.', variant)
     fixtures.load_seeded_state(dec, 'decoder.', variant)
@@ -103,12 +103,12 @@ hip_modules.cache_clear = _hip_modules.cache_clear
 hip_modules.__wrapped__ = lambda precision='f16x3', variant='seeded', use_trans=True: _hip_modules.__wrapped__(precision, variant, use_trans)      # a fresh, uncached pair
 
 
-def hip_render(cfg, precision='f16x3', training=True, fx=None, sp_input=None, options=None, use_trans=True):
+def hip_render(cfg, precision='f16x3', training=True, fx=None, sp_input=None, options=None, use_trans=True, branches=(True, True, True)):
     """Runs sherf_amd.ImportanceRenderer.forward on the fixture; the voxel coordinates come from the oracle's
     prepare_sp_input so this isolates the renderer (the TriPlaneGenerator glue has its own test)."""
     from sherf_amd.voxel import SparseConvTensor
     fx = fx or fixture(cfg)
-    rend, dec = hip_modules(precision, fixtures.variant_of(cfg) if cfg in fixtures.CONFIGS else 'seeded', use_trans)
+    rend, dec = hip_modules(precision, fixtures.variant_of(cfg) if cfg in fixtures.CONFIGS else 'seeded', use_trans, branches)
     rend.train(training)
     if sp_input is None:
         sp_input = oracle_render(cfg)['sp_input']

@@ -123,6 +123,17 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
 }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipLaunchHostFunc(hipStream_t, void (*fn)(void*), void* arg) { fn(arg); return hipSuccess; }
+// hipGraph capture (csrc/frame.hip replays frames as graphs): every launch of the shim runs at once, so there is nothing to capture --
+// hipStreamBeginCapture reports "not supported" and the frame driver takes its launch-by-launch path, which is what the host build tests
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+constexpr int hipStreamCaptureModeThreadLocal = 1;
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 801; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 801; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 801; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*b - *a); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

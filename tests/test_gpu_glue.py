@@ -58,6 +58,25 @@ def test_renderer_without_transformer_on_device():
     check_without_transformer()
 
 
+def test_feature_branch_switches_on_device():
+    """use_1d / use_2d / use_3d_feature in every combination the reference's run_model distinguishes, on the hardware, against goldens of the unmodified
+    reference built with the same switches."""
+    from tests.test_hipcpu_frame import check_feature_branch_switches
+    check_feature_branch_switches()
+
+
+def test_encodings_in_the_gather_render_the_same_bits_on_device():
+    """Round 6: SHERF_FRAME_PE_FRAGS on the hardware -- the positional encodings written by the gather as fp16 operand fragments and read by the
+    pipelined network kernel -- the same frame bit for bit as the network evaluating them (opt-in: measured slower, profiles/r06_call_a_*)."""
+    for cfg in ('tiny_ri', 'cfg1_ri'):
+        off = G.hip_render(cfg, precision='f16', options=dict(pe_in_gather=False))
+        on = G.hip_render(cfg, precision='f16', options=dict(pe_in_gather=True))
+        assert on['last']['pe_in_gather'] and not off['last']['pe_in_gather']
+        for k in ('rgb', 'acc', 'depth'):
+            assert torch.equal(on[k], off[k]), (cfg, k)
+        assert torch.equal(on['last']['ws']['sample_out'], off['last']['ws']['sample_out'])
+
+
 @pytest.mark.parametrize('cfg,prec', [('tiny', 'f16x3'), ('cfg1_ri', 'f16')])
 def test_schedule_switches_render_the_same_bits_on_device(cfg, prec):
     """Round 4's launch / data-structure switches on the hardware, each against the default frame bit for bit: the candidate search over

@@ -530,3 +530,55 @@ def test_token_workspace_is_sized_from_the_frame_on_device():
     from tests.test_hipcpu_frame import check_token_workspace
     check_token_workspace()
 
+
+
+def test_frames_replay_as_hipgraphs_on_device():
+    """Round 6: the second consecutive frame on the same descriptor is captured into a hipGraph and replayed from then on
+    (csrc/frame.hip).  Replayed frames equal frames enqueued launch by launch BIT FOR BIT; an input changed IN PLACE reaches the replay (the graph
+    holds addresses, not values); a frame on freshly allocated input tensors has a new key: it is enqueued eagerly and renders the same image."""
+    import argparse
+    import ctypes as ct
+    import bench
+    from sherf_amd import _lib
+    dev = torch.device('cuda', 0)
+    w = bench.make_workload(argparse.Namespace(config='cfg1_ri', precision='f16', bn_mode='train'), 0.4, dev)
+
+    def frame():
+        r = bench.render_frame(w)
+        torch.cuda.synchronize()
+        return [t.clone() for t in r]
+
+    def stats():
+        s = (ct.c_int64 * 4)()
+        _lib.call('sherf_frame_graph_stats', s, 4)
+        return [int(v) for v in s]
+    try:
+        _lib.call('sherf_frame_graphs', 0)
+        for _ in range(3):                                   # token workspace sized, `last` settled
+            ref = frame()
+        s0 = stats()
+        _lib.call('sherf_frame_graphs', 1)
+        outs = [frame() for _ in range(6)]
+        s1 = stats()
+        assert s1[0] - s0[0] >= 1 and s1[1] - s0[1] >= 3 and s1[3] == s0[3], (s0, s1)        # captured once, replayed, no failed capture
+        for o in outs:
+            assert all(torch.equal(a, b) for a, b in zip(o, ref))
+        # an in-place change of an input reaches the replayed graph
+        w['planes'].mul_(1.25)
+        g = frame()
+        s2 = stats()
+        assert s2[1] > s1[1]                                  # (still a replay: same addresses)
+        _lib.call('sherf_frame_graphs', 0)
+        e = frame()
+        assert all(torch.equal(a, b) for a, b in zip(g, e)) and not torch.equal(g[0], ref[0])
+        # fresh input tensors every frame: new keys, eager enqueues, the same image
+        _lib.call('sherf_frame_graphs', 1)
+        w['fresh'] = True
+        s3 = stats()
+        for _ in range(3):
+            f = frame()
+            assert all(torch.equal(a, b) for a, b in zip(f, e))
+        s4 = stats()
+        assert s4[2] - s3[2] >= 3 and s4[0] == s3[0], (s3, s4)
+    finally:
+        _lib.call('sherf_frame_graphs', 1)

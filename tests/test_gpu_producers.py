@@ -145,29 +145,39 @@ def test_graphed_producer_is_checked_and_falls_back_on_device():
         gp(x)
         assert int(net[1].num_batches_tracked) == n0 + 1
         net.eval()
-        # a forward the capture cannot see: result on another stream, joined with a host wait -> the capture fails or comes out empty; either way: off + eager
-        other = torch.cuda.Stream()
+        # a capture that cannot reproduce the eager call (the forward bakes a host-side counter into its launch: every replay would return the
+        # capture's value) and a capture that fails (the forward refuses to run under capture): off + eager results + one warning each
+        class Counting(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.Parameter(torch.ones(1))
+                self.k = 0
 
-        class Elsewhere(torch.nn.Module):
+            def forward(self, x):
+                self.k += 1
+                return x * self.w * float(self.k)
+
+        class Refusing(torch.nn.Module):
             def __init__(self):
                 super().__init__()
                 self.w = torch.nn.Parameter(torch.ones(1))
 
             def forward(self, x):
-                out = torch.empty_like(x)
-                other.wait_stream(torch.cuda.current_stream()) if not torch.cuda.is_current_stream_capturing() else None
-                with torch.cuda.stream(other):
-                    out.copy_(x * 2 * self.w)
-                if not torch.cuda.is_current_stream_capturing():
-                    torch.cuda.current_stream().wait_stream(other)
-                return out
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('not under capture')
+                return x * 2 * self.w
 
-        m = Elsewhere().cuda().eval()
-        gq = _GraphedProducer(m, m.__call__)
-        with warnings.catch_warnings(record=True) as rec:
-            warnings.simplefilter('always')
-            outs = [gq(torch.full((4,), float(k), device='cuda')) for k in range(1, 4)]
-        torch.cuda.synchronize()
-        assert gq.off and gq.error and any('eager calls from now on' in str(r.message) for r in rec)
-        for k, o in enumerate(outs, 1):
-            assert torch.equal(o.cpu(), torch.full((4,), 2.0 * k)), (k, o)
+        for mod, want in ((Refusing(), lambda k, i: 2.0 * k), (Counting(), None)):
+            m = mod.cuda().eval()
+            gq = _GraphedProducer(m, m.__call__)
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter('always')
+                outs = [gq(torch.full((4,), float(k), device='cuda')) for k in range(1, 4)]
+            torch.cuda.synchronize()
+            assert gq.off and gq.error and sum('eager calls from now on' in str(r.message) for r in rec) == 1, (type(mod).__name__, gq.error)
+            if want is not None:
+                for k, o in enumerate(outs, 1):
+                    assert torch.equal(o.cpu(), torch.full((4,), want(k, 0))), (k, o)
+            else:                                       # every call after the failed check is an eager call: the counter keeps advancing
+                r = [float(o[0]) / k for k, o in enumerate(outs, 1)]
+                assert r[1] == r[0] + 1 and r[2] == r[1] + 1, r

@@ -104,10 +104,10 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
             for k in ('rgb', 'acc', 'depth'):
                 assert torch.equal(one[k], b[k]), (prec, form, k)
     # round 6: the positional encodings evaluated by the gather and handed to the pipelined fp16 network as operand fragments (SHERF_FRAME_PE_FRAGS:
-    # the default in that configuration) == the network evaluating them itself; other configurations ignore the option
+    # opt-in -- measured slower on the MI355X) == the network evaluating them itself; other configurations ignore the option
     on = G.hip_render('tiny_nv', precision='f16', options=dict(pe_in_gather=True))
     off = G.hip_render('tiny_nv', precision='f16', options=dict(pe_in_gather=False))
-    assert on['last']['pe_in_gather'] and not off['last']['pe_in_gather'] and G.hip_render('tiny_nv', precision='f16')['last']['pe_in_gather']
+    assert on['last']['pe_in_gather'] and not off['last']['pe_in_gather'] and not G.hip_render('tiny_nv', precision='f16')['last']['pe_in_gather']
     pf = on['last']['ws']['pefrag']
     assert pf is not None and int((pf != 0).sum()) > 1000
     for k in ('rgb', 'acc', 'depth'):
@@ -118,6 +118,8 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
     assert not G.hip_render('tiny_nv', precision='bf16', options=dict(pe_in_gather=True))['last']['pe_in_gather']
     # use_trans = False (round 5): every launch form of the network against the golden of the unmodified reference built without its transformer
     check_without_transformer()
+    # the feature-branch switches (round 6): goldens of the unmodified reference built with each combination
+    check_feature_branch_switches()
     # gather + network cut into parts on two streams (sherf_nerf_mlp_part): a schedule, not an arithmetic, variant
     for parts in (2, 3, 8):
         b = G.hip_render('tiny_nv', options=dict(mlp_parts=parts))
@@ -491,6 +493,36 @@ def check_without_transformer():
         assert torch.equal(b['rgb'], one['rgb']) and torch.equal(b['acc'], one['acc']), opts
     with_t = G.hip_render('tiny_ri', precision='f16x3')
     assert G.rel(with_t['rgb'], ref['rgb']) > 1e-3                       # the transformer does change the image
+
+
+def check_feature_branch_switches():
+    """ImportanceRenderer(use_1d_feature, use_2d_feature, use_3d_feature) in every combination run_model distinguishes (renderer.py:261-269, 405-425;
+    round 6): the HIP frame against goldens of the unmodified reference built with the same switches (tests/golden/renderer_tiny_ri_f<abc>.npz,
+    oracle/make_golden.py branches) -- fp32-grade f16x3 to 1e-4 per sample and on the image, the fp16 configuration within its class; a switch
+    combination with a single 2-D or 3-D source renders the tri-plane features alone, as the reference's if / elif chain does; the backward is refused."""
+    full = G.hip_render('tiny_ri', precision='f16x3')
+    for tag in ('110', '101', '011', '100'):
+        br = tuple(ch == '1' for ch in tag)
+        g = np.load(os.path.join(G.GOLDEN, f'renderer_tiny_ri_f{tag}.npz'))
+        h = G.hip_render('tiny_ri', precision='f16x3', branches=br)
+        nv = int(h['last']['ws']['counters'][0])
+        assert nv == int(g['n_valid']), tag
+        rend = h['rend']
+        assert rend.feature_branches() == br
+        assert (not hasattr(rend, 'conv1d_reprojection')) if tag == '100' else rend.conv1d_reprojection.weight.shape[1] == 64
+        so = G.plain(h['last']['ws']['sample_out'][:nv])
+        e_rgb, e_sig = G.rel(so[:, :3], g['sample_rgb']), G.rel(torch.relu(so[:, 3]), np.maximum(g['sample_sigma'], 0))
+        e_img = max(G.rel(h['rgb'], g['rgb']), G.rel(h['acc'], g['acc'][:, 0]))
+        print(f'branches {tag}: per-sample rgb {e_rgb:.2e} sigma+ {e_sig:.2e}, image {e_img:.2e}')
+        assert e_rgb < 1e-4 and e_sig < 1e-4 and e_img < 1e-4, (tag, e_rgb, e_sig, e_img)
+        assert G.rel(h['rgb'], full['rgb']) > 1e-3, tag                   # every switch changes the image
+        h16 = G.hip_render('tiny_ri', precision='f16', branches=br)
+        assert G.rel(h16['rgb'], g['rgb']) < 2e-3, tag
+    # a single 2-D / 3-D source: no branch of run_model's chain -> the tri-plane samples alone (== '100')
+    a = G.hip_render('tiny_ri', precision='f16x3', branches=(True, False, False))
+    for br in ((False, True, False), (False, False, True), (False, False, False)):
+        b = G.hip_render('tiny_ri', precision='f16x3', branches=br)
+        assert torch.equal(a['rgb'], b['rgb']), br
 
 
 def check_whole_generator():

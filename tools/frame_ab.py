@@ -58,11 +58,13 @@ def main():
     groups = a.opts.split(';') if a.opts else []
     groups += [''] * (len(arms) - len(groups))
     arm_opts = [{kv.split('=')[0]: ast.literal_eval(kv.split('=')[1]) for kv in g.split(',') if kv} for g in groups]
+    arm_graph = [o.pop('frame_graph', True) for o in arm_opts]
     base_opts = dict(w['opts'])
     exps = [x for x in a.exps.split(',') if x] + ['0'] * len(arms)
 
     def select(i):
         lib.sherf_set_debug(arms[i])
+        lib.sherf_frame_graphs(1 if arm_graph[i] else 0)              # (`frame_graph=False` in an arm's options: frames enqueued launch by launch)
         os.environ['SHERF_EXPERIMENT'] = str(int(exps[i], 0) | (int(os.environ.get('SHERF_EXPERIMENT_BASE', '0'), 0)))
         w['opts'] = dict(base_opts, **arm_opts[i])
     lib = _lib.lib()
@@ -101,6 +103,10 @@ def main():
             select(i)
             print(f'[timeline] {n}: {timeline(w)}')
     lib.sherf_set_debug(0)
+    import ctypes as ct
+    gs = (ct.c_int64 * 4)()
+    lib.sherf_frame_graph_stats(gs, 4)
+    print('[graphs] captured %d, replayed frames %d, enqueued frames %d, failed captures %d' % tuple(int(v) for v in gs))
     for n in names:
         print(f'[arm] {n:12s} ms/frame {" ".join(f"{t:.4f}" for t in times[n])}   min {min(times[n]):.4f}')
 
