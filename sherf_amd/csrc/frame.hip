@@ -29,6 +29,8 @@ struct DevState {
     int32_t* host_nv = nullptr;      // pinned: the frame's valid-sample count for SHERF_FRAME_EXACT_GRIDS
     hipEvent_t ev_rep[8];            // SHERF_FRAME_REPORT_COUNT: a ring of (pinned word, event) pairs; host_nv[8 + slot]
     int rep_next = 0;
+    hipStream_t cap_stream = nullptr;   // frame graphs are CAPTURED on this library-owned non-blocking stream (the caller's may be the legacy default
+                                        // stream, which cannot capture) and LAUNCHED on the caller's
 };
 // the REPORT_COUNT slot of the last frame THIS THREAD enqueued (per device): another thread's (renderer's) frames on the same device take
 // their own slots, and a reader never waits with the enqueue lock held
@@ -448,19 +450,29 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
         ++g_graph_stats[2];
         return render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
     }
-    // second sighting: capture, instantiate, launch
+    // second sighting: capture (on the library's own stream: the caller's may be the legacy default stream), instantiate, launch on the caller's
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int rc = SHERF_ELAUNCH;
-    bool ok = hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    const char* stage = "stream";
+    hipError_t e = hipSuccess;
+    DevState& d = g_dev[dev];
+    if (!d.cap_stream) e = hipStreamCreateWithFlags(&d.cap_stream, hipStreamNonBlocking);
+    bool ok = e == hipSuccess && d.cap_stream;
+    if (ok) { stage = "begin"; e = hipStreamBeginCapture(d.cap_stream, hipStreamCaptureModeThreadLocal); ok = e == hipSuccess; }
     if (ok) {
-        rc = render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);
-        const hipError_t e = hipStreamEndCapture(main, &graph);       // (always ends the capture, also after a failed enqueue)
+        stage = "enqueue";
+        rc = render_frame_enqueue(f, phase, levels, reinterpret_cast<sherf_stream_t>(d.cap_stream), stream_side, stream_aux);
+        e = hipStreamEndCapture(d.cap_stream, &graph);                // (always ends the capture, also after a failed enqueue)
+        if (rc == SHERF_OK) stage = "end";
         ok = rc == SHERF_OK && e == hipSuccess && graph != nullptr;
     }
-    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec != nullptr;
-    if (ok) ok = hipGraphLaunch(exec, main) == hipSuccess;
+    if (ok) { stage = "instantiate"; e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); ok = e == hipSuccess && exec != nullptr; }
+    if (ok) { stage = "launch"; e = hipGraphLaunch(exec, main); ok = e == hipSuccess; }
     if (!ok) {
+        if (getenv("SHERF_FRAME_GRAPH_DEBUG"))
+            fprintf(stderr, "[sherf] frame graph: capture failed at '%s' (rc %d, %s: %s); this descriptor renders launch by launch\n", stage, rc,
+                    hipGetErrorName(e), rc != SHERF_OK ? g_sherf_err : hipGetErrorString(e));
         (void)hipGetLastError();
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);

@@ -128,6 +128,8 @@ inline hipError_t hipLaunchHostFunc(hipStream_t, void (*fn)(void*), void* arg) {
 typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;
 constexpr int hipStreamCaptureModeThreadLocal = 1;
+constexpr unsigned hipStreamNonBlocking = 1;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 801; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 801; }
 inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 801; }
 inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 801; }
@@ -137,6 +139,7 @@ inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*b - *a); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorName(hipError_t) { return "hipError"; }
 inline const char* hipGetErrorString(hipError_t) { return "hipcpu"; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 constexpr int hipDeviceAttributeMultiprocessorCount = 63;

@@ -493,7 +493,9 @@ def test_mfma_input_gradient_convolution(mode, Cin, Cout):
     torch.cuda.synchronize()
     a, b = di_c.tensor()[:n_i].double(), di_g.tensor()[:n_i].cpu().double()
     assert torch.isfinite(b).all()
-    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    err = float((a - b).abs().max()) / float(a.abs().max())
+    print(f'input-gradient convolution mode {mode} {Cin} -> {Cout}: max error {err:.2e} of the maximum')
+    assert err <= 4e-7                       # round 6: both operands' lo halves carried at 2^11 (rounds 3-5: 2e-6)
 
 
 def test_batchnorm_backward_and_small_encoder_kernels():

@@ -397,7 +397,9 @@ def test_mfma_input_gradient_convolution_on_cpu(cpu_lib, svox_lib, monkeypatch, 
     n_i = int(fine_e['n_rows'])
     a, b = di_c.tensor()[:n_i].double(), di_g.tensor()[:n_i].double()
     assert torch.isfinite(b).all()
-    assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+    err = float((a - b).abs().max()) / float(a.abs().max())
+    print(f'input-gradient convolution mode {mode} {Cin} -> {Cout}: max error {err:.2e} of the maximum')
+    assert err <= 4e-7                       # round 6: both operands' lo halves carried at 2^11 (rounds 3-5: 2e-6)
     with pytest.raises(RuntimeError):
         h.conv_dgrad(fine_k, out_k, Mat(d_raw.clone(), out_e['cap'], Cout), Cout, Mat(W.clone(), Cout, 27 * Cin), Cin, mode, di_g)   # no amax
 
