@@ -277,7 +277,7 @@ def secondary_measurements(a, w, dev, nv, R):
     return out
 
 
-def pmc_traffic(a, lrank, timeout=150):
+def pmc_traffic(a, lrank, timeout=150, child=None, keys=None):
     """HBM bytes per launch of nerf_mlp_kernel from rocprofv3's counters, measured on THIS box right after the run: two `--pmc` passes
     (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md) of a 3-frame child, averaged over the kernel's dispatches;
     FETCH_SIZE doubled as that guide prescribes for gfx950 (128-byte requests tallied at 64).  -> dict or {'error': ...}."""
@@ -294,8 +294,9 @@ def pmc_traffic(a, lrank, timeout=150):
     vals = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         outdir = tempfile.mkdtemp(prefix='sherf_pmc_', dir='/tmp')
-        cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
-               '--config', a.config, '--precision', getattr(a, 'precision_used', a.precision), '--bn-mode', a.bn_mode]
+        # (`child` / `keys`: another command and other kernel names under the same two counter passes -- bench_train.py's tap scatter)
+        cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', outdir, '--'] + (list(child) if child else
+              [sys.executable, os.path.abspath(__file__), '--pmc-child', '--config', a.config, '--precision', getattr(a, 'precision_used', a.precision), '--bn-mode', a.bn_mode])
         try:
             r = subprocess.run(cmd, env=env, cwd='/tmp', stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
             rows = []
@@ -304,7 +305,7 @@ def pmc_traffic(a, lrank, timeout=150):
             per = {}                                  # the network's kernels (one launch, or the two of sherf_nerf_mlp_split): mean per dispatch, summed
             for x in rows:
                 kn = x.get('Kernel_Name', '')
-                for key in ('nerf_mlp_kernel', 'nerf_mlp2_kernel', 'nerf_mlp3_kernel', 'nerf_tokens_kernel', 'nerf_decoder_kernel'):
+                for key in (keys or ('nerf_mlp_kernel', 'nerf_mlp2_kernel', 'nerf_mlp3_kernel', 'nerf_tokens_kernel', 'nerf_decoder_kernel')):
                     if key in kn and x.get('Counter_Name') == counter:
                         per.setdefault(key, []).append(float(x['Counter_Value']))
             if not per:
@@ -658,6 +659,9 @@ def main():
                         sample_out=lw['sample_out'][:nv].cpu())
         if world == 1 and not a.no_train and not a.no_secondary and not os.environ.get('SHERF_HIPCPU_LIB'):
             res['train'] = train_step_child(lrank)
+            # the same step on the headline framing (1.27 M valid samples instead of cfg2's 0.69 M), the reference-init network
+            if a.config.startswith('cfg2_dense'):
+                res['train_dense'] = train_step_child(lrank, extra=['--config', a.config, '--no-pmc'])
         if world == 1 and not a.no_secondary and not a.overlap_child and not os.environ.get('SHERF_HIPCPU_LIB') and isinstance(res.get('secondary'), dict):
             # the drop-in's real entry point at real size: TriPlaneGenerator.forward with the full-size StyleGAN2 backbone and both
             # ResNet-18 passes around this renderer, per-stage HIP-event breakdown (bench_generator.py, a child process)
@@ -807,7 +811,7 @@ def bench_child(a, lrank, extra, timeout=400):
         return dict(error=f'{type(ex).__name__}: {str(ex)[:300]}')
 
 
-def train_step_child(lrank, timeout=240):
+def train_step_child(lrank, timeout=480, extra=()):
     """BASELINE config 5 beside the render metric: bench_train.py (one view, forward + backward through the HIP kernels + the reference's
     flat-gradient exchange + Adam, training_loop.py:354-386) for a few steps in a child process -> its JSON line (ms per step, phases,
     the roofline of its dominant kernel), so that the driver's bench run times the training step too."""
@@ -815,7 +819,7 @@ def train_step_child(lrank, timeout=240):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['LOCAL_RANK'] = str(lrank)
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_train.py'), '--steps', '4', '--warmup', '2'], env=env, stdout=subprocess.PIPE,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench_train.py'), '--steps', '4', '--warmup', '2'] + list(extra), env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, timeout=timeout, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if not line:

@@ -28,7 +28,11 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)       # two steps under rocprofv3 --pmc: nothing printed
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc passes that count the tap scatter\'s HBM bytes')
     a = ap.parse_args()
+    if a.pmc_child:
+        a.steps, a.warmup = 2, 1
     import bench
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:        # no launcher in front: start the N ranks here (as bench.py does; sherf/train.py:98-103)
         sys.exit(bench.launch_ranks(a.gpus, script=__file__))
@@ -47,7 +51,8 @@ def main():
     fx, d, to = bench.make_inputs(a.config, 0.4 + rank * 2 * np.pi / max(world, 1), dev)
     rend = ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True, smpl=smpl)
     dec = NeRFDecoder(32)
-    fixtures.load_seeded_state(rend, 'renderer.'); fixtures.load_seeded_state(dec, 'decoder.')
+    variant = fixtures.variant_of(a.config)                  # ('_ri' configurations: the reference-init network, as in bench.py)
+    fixtures.load_seeded_state(rend, 'renderer.', variant); fixtures.load_seeded_state(dec, 'decoder.', variant)
     rend.to(dev).train(); dec.to(dev).train()
     rend.enable_autograd = True
     gen = TriPlaneGenerator.__new__(TriPlaneGenerator)
@@ -130,20 +135,33 @@ def main():
         dt = float(t)
     scat_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in scatter_ev])) if scatter_ev else None
     phases = {k: float(np.mean([ev[i].elapsed_time(ev[i + 1]) for ev in phase_ev])) for i, k in enumerate(('forward', 'backward', 'allreduce_adam'))}
+    if a.pmc_child:
+        return
     if rank == 0:
         n_valid = int(rend.last['ws']['counters'][0]) if rend.last else 0
         # algorithmic bytes of the scatter per valid sample: d_tokens 384 B + geometry 32 B read; fp32 read-modify-write of the taps:
         # tri-planes 3 slots x 4 taps x 128 B, feature map 2 slots x 4 taps x 128 B, voxel rows 3 levels x 8 taps x 3 slots x 128 B
-        bytes_per_sample = 384 + 32 + 2 * (3 * 4 * 128 + 2 * 4 * 128 + 3 * 8 * 3 * 128)
+        # Round 6: rounds 2-5 priced this kernel with the UNMERGED algorithm's read-modify-write bytes (23 968 B per
+        # sample), which the run-length form no longer moves -- 6.8 TB/s "achieved" was above what the memory system can do.  Now: `achieved` =
+        # the bytes the kernel cannot avoid (d_tokens 384 B + geometry 32 B + its place in the sorted order 8 B per valid sample, read once)
+        # over its duration; `traffic` = what it actually moves (FETCH_SIZE x 2 + WRITE_SIZE of two rocprofv3 --pmc passes of this script,
+        # gfx950 rule of MI355X_MICROARCH.md), per launch.  The kernel is bound by atomic adds, not by bandwidth: the honest fraction is small.
+        bytes_per_sample = 384 + 32 + 8
         roofline = None
         if scat_ms and n_valid:
             ach = bytes_per_sample * n_valid / (scat_ms * 1e-3) / 1e9
-            roofline = dict(kernel='sherf_gather_tokens_bwd_binned (bin count + scans + fill + gather_tokens_bwd_runs_kernel)', bound='hbm', achieved=ach,
-                            peak=bench.PEAK_HBM_GBS, unit='GB/s', frac=ach / bench.PEAK_HBM_GBS,
-                            traffic=None, kernel_ms=scat_ms, bytes_per_sample=bytes_per_sample, valid_samples=n_valid,
-                            note='largest single kernel of the step; fp32 read-modify-write atomics of whole rows (lane = channel); since round 5 over the samples sorted by their '
-                                 'finest voxel cell with every level / plane / feature-map sum in registers, flushed when its cell changes (the bytes above are the unmerged algorithm\'s): '
-                                 'bound by the number of atomically added elements, not by bandwidth (round 2 direct form: 20.3 ms, round 3 binned: 4.1 ms; profiles/r05_call_x_*)')
+            traffic = None
+            if world == 1 and not a.no_pmc:
+                t = bench.pmc_traffic(a, lrank, timeout=240, child=[sys.executable, os.path.abspath(__file__), '--pmc-child', '--config', a.config],
+                                      keys=('gather_tokens_bwd_runs_kernel',))
+                traffic = t.get('hbm_bytes_per_launch') if isinstance(t, dict) and 'error' not in t else t
+            roofline = dict(kernel='gather_tokens_bwd_runs_kernel (the tap scatter of sherf_gather_tokens_bwd_binned; events also cover its bin count / scans / fill)', bound='hbm',
+                            achieved=ach, peak=bench.PEAK_HBM_GBS, unit='GB/s', frac=ach / bench.PEAK_HBM_GBS,
+                            traffic=traffic, kernel_ms=scat_ms, bytes_per_sample=bytes_per_sample, valid_samples=n_valid,
+                            traffic_gbs=(traffic / (scat_ms * 1e-3) / 1e9) if isinstance(traffic, (int, float)) else None,
+                            note='largest single kernel of the step; `achieved` counts only the bytes it must read once (d_tokens, geometry, sort order); fp32 atomic adds of '
+                                 'whole rows (lane = channel) over the samples sorted by their finest voxel cell, run-length sums in registers: bound by the number of atomically '
+                                 'added elements, not by bandwidth (round 2 direct form: 20.3 ms, round 3 binned: 4.1 ms, round 5: 2.4 ms; profiles/r05_call_x_*)')
         print(json.dumps(dict(metric='training rays/sec at 512x512x64 (forward + backward + flat-grad all-reduce + Adam)', value=world * R * a.steps / dt,
                               unit='rays/s', n_gpus=world, rccl_ranks=torch.distributed.get_world_size() if world > 1 else 1, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * dt / a.steps, higher_is_better=True,
                               scaling='weak', vs_baseline=None, dtype='f32 (backward: fp32 kernels, MFMA GEMMs on a three-part bf16 split, MFMA sparse-conv input gradient on a range-scaled fp16 split; forward: f16x3 MFMA)',

@@ -18,6 +18,9 @@ static inline double sherf_host_us() { timespec t_; clock_gettime(CLOCK_MONOTONI
 // (same bit: a host function queued IN the stream prints the host clock when the GPU gets there)
 static void sherf_gpu_stamp_fn(void* what_) { fprintf(stderr, "[host] %.1f gpu: %s\n", sherf_host_us(), (const char*)what_); }
 #define SHERF_GPU_STAMP(xp_, strm_, what_) do { if ((xp_) & 16) (void)hipLaunchHostFunc(strm_, sherf_gpu_stamp_fn, (void*)what_); } while (0)
+// SHERF_FRAME_GRAPH_DEBUG=1: while a frame is being captured into a hipGraph (csrc/frame.hip) the enqueue points are traced on stderr
+extern int g_sherf_cap_trace;
+#define SHERF_CAP_TRACE(what_) do { if (g_sherf_cap_trace) { fprintf(stderr, "[sherf] capture: %s\n", what_); fflush(stderr); } } while (0)
 static inline int sherf_experiment() { const char* s_ = getenv("SHERF_EXPERIMENT"); return s_ ? atoi(s_) : 0; }
 
 #define SHERF_CHECK_ARG(cond)                                                                     \

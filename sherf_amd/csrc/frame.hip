@@ -165,7 +165,9 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
         // inputs were produced on the caller's stream
         SHERF_PROF(0, main);
         SHERF_GPU_STAMP(xp, main, "frame start");
+        SHERF_CAP_TRACE("record ev_start");
         SHERF_HIP_CHECK(hipEventRecord(d.ev_start, main));
+        SHERF_CAP_TRACE("side waits ev_start");
         SHERF_HIP_CHECK(hipStreamWaitEvent(side, d.ev_start, 0));
         // ---- a7-a9 per-frame SMPL tables: first needed by the warp (after sampling), so with an aux stream they queue there
         // behind the table folds and level builds and the encoder chain starts at once on the side stream ----
@@ -190,6 +192,7 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
             SHERF_RUN(sherf_fold_tables(f->obs_feat, f->Wb_t, f->feat_f, f->Hf * f->Wf, 2, 64, 32, half_tables, st));
             return sherf_img_to_hwc4(f->obs_img, f->img4, f->H * f->W, st);
         };
+        SHERF_CAP_TRACE("fold tables on aux");
         if (stream_aux) {       // independent of rays and voxels: off the ray side's chain, ahead of the level builds
             SHERF_HIP_CHECK(hipStreamWaitEvent(as_stream(stream_aux), d.ev_start, 0));
             SHERF_RUN(fold_tables(stream_aux));
@@ -209,17 +212,21 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
         // Launch order == start order (a launch costs the host ~5 us): staggered -> encoder first, the ray side waits for
         // layer `stagger`; concurrent -> the ray side's big kernels first, the encoder's ~50 small ones behind them.
         const bool encoder_first = stagger >= 0 || (xp & 8);
+        SHERF_CAP_TRACE("cells");
         if (encoder_first) SHERF_RUN(enqueue_encoder());
         // ---- main: cell lists, a4-a6 sampling / mask / nearest vertex / compaction, table re-layout ----
         const bool lists = f->near_hdr && f->near_list;             // exact vertex list per near-mask sub-cell: its counts also give the mask
         SHERF_RUN(sherf_build_cells2(f->verts, f->Rg, f->Th, f->tverts, V, 0.05f, f->grid_hdr, f->cell_start, f->cell_pts,
                                      f->cell_scratch, lists ? nullptr : f->near_mask, stream_main));
         if (stagger >= 0) SHERF_HIP_CHECK(hipStreamWaitEvent(main, stagger < f->vox_plan->n_layers ? d.ev_mid : d.ev_enc, 0));
+        SHERF_CAP_TRACE("near lists");
         if (lists)
             SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, f->near_mask, stream_main));
+        SHERF_CAP_TRACE("sampler");
         SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
                                        f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main));
+        SHERF_CAP_TRACE("sampler queued");
         // SHERF_FRAME_EXACT_GRIDS: the kernels after the compaction are launched for the frame's ACTUAL number of valid samples instead
         // of the buffers' capacity (R*S, of which a body fills a few percent: the MLP's grid is then ~96 % workgroups that allocate
         // 8 waves x 250 VGPRs + 85 KiB LDS only to read the count and exit, one at a time per CU, behind the real ones).  The count is
@@ -238,7 +245,9 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
             SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_cnt, main));
         }
+        SHERF_CAP_TRACE("encoder");
         if (!encoder_first) SHERF_RUN(enqueue_encoder());
+        SHERF_CAP_TRACE("encoder queued");
         if (!stream_aux) SHERF_RUN(fold_tables(stream_main));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
         if (!(g_sherf_debug & (1 << 28))) {          // (debug bit 28, TIMING EXPERIMENTS ONLY: no joins in front of the warp -- results may be wrong)
@@ -253,6 +262,7 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
             int64_t c = *d.host_nv > 0 ? ((int64_t)*d.host_nv + 255) / 256 * 256 : 256;      // whole MLP tile groups
             if (c < cap) cap = c;
         }
+        SHERF_CAP_TRACE("warp");
         SHERF_RUN(sherf_warp_geom(f->counters, f->cs_idx, f->cs_vid, f->cs_xs, f->ray_d, f->S, f->Rg, f->T2C, f->C2S, f->tverts,
                                   f->grid_hdr + kGridHdr, f->cell_start + ncell1, f->cell_pts + (size_t)V * 4, cap, f->geom,
                                   f->cs_tvid, stream_main));
@@ -309,6 +319,7 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
                                           levels, f->tok_bias, f->bounds, f->vox_min, f->vox_sh, 0 | gv, cap, f->tokens,
                                           f->extras, stream_main));
         }
+        SHERF_CAP_TRACE("network");
         SHERF_PROF(4, main);
         // debug bit 13 flips the form for A/B runs in one process (a frame without zfrag always takes the one-launch kernel)
         const bool split = f->zfrag && (((f->flags & SHERF_FRAME_MLP_SPLIT) != 0) != ((g_sherf_debug & 8192) != 0));
@@ -329,6 +340,7 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
     }
     if (phase & 2) {
         // ---- a15-a16 ----
+        SHERF_CAP_TRACE("compositing");
         SHERF_RUN(sherf_composite_compact_cap(f->counters, f->ray_base, f->ray_cnt, f->cs_idx, f->sample_out, f->ray_d, f->near, f->far,
                                               f->R, f->S, f->white_back, tok_cap, f->rgb, f->depth, f->acc, stream_main));
         SHERF_PROF(6, main);
@@ -459,16 +471,22 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
     DevState& d = g_dev[dev];
     if (!d.cap_stream) e = hipStreamCreateWithFlags(&d.cap_stream, hipStreamNonBlocking);
     bool ok = e == hipSuccess && d.cap_stream;
+    g_sherf_cap_trace = getenv("SHERF_FRAME_GRAPH_DEBUG") ? 1 : 0;
+    SHERF_CAP_TRACE("begin");
     if (ok) { stage = "begin"; e = hipStreamBeginCapture(d.cap_stream, hipStreamCaptureModeThreadLocal); ok = e == hipSuccess; }
     if (ok) {
         stage = "enqueue";
         rc = render_frame_enqueue(f, phase, levels, reinterpret_cast<sherf_stream_t>(d.cap_stream), stream_side, stream_aux);
+        SHERF_CAP_TRACE("end capture");
         e = hipStreamEndCapture(d.cap_stream, &graph);                // (always ends the capture, also after a failed enqueue)
+        SHERF_CAP_TRACE("capture ended");
         if (rc == SHERF_OK) stage = "end";
         ok = rc == SHERF_OK && e == hipSuccess && graph != nullptr;
     }
-    if (ok) { stage = "instantiate"; e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); ok = e == hipSuccess && exec != nullptr; }
-    if (ok) { stage = "launch"; e = hipGraphLaunch(exec, main); ok = e == hipSuccess; }
+    if (ok) { stage = "instantiate"; SHERF_CAP_TRACE(stage); e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); ok = e == hipSuccess && exec != nullptr; }
+    if (ok) { stage = "launch"; SHERF_CAP_TRACE(stage); e = hipGraphLaunch(exec, main); ok = e == hipSuccess; }
+    SHERF_CAP_TRACE("done");
+    g_sherf_cap_trace = 0;
     if (!ok) {
         if (getenv("SHERF_FRAME_GRAPH_DEBUG"))
             fprintf(stderr, "[sherf] frame graph: capture failed at '%s' (rc %d, %s: %s); this descriptor renders launch by launch\n", stage, rc,

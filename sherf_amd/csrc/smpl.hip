@@ -10,6 +10,7 @@
 char g_sherf_err[256] = {0};
 
 int g_sherf_debug = 0;
+int g_sherf_cap_trace = 0;
 extern "C" int sherf_version(void) { return 100; }
 // profiling aid only (ablation switches used by tools/gpu_ablate.sh); 0 in production
 extern "C" int sherf_set_debug(int flags) { g_sherf_debug = flags; return SHERF_OK; }

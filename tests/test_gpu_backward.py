@@ -298,11 +298,19 @@ def test_full_backward_against_reference_gradients():
     # perturbation of the forward moves the reference's own encoder gradients by 5-6 %); the tight check of those kernels is
     # against the explicit backward at our forward point (tests/test_hipcpu_frame.py on the CPU, the kernel tests below here).
     enc = lambda k: 'encoder_3d' in k or k == 'input.vertex_feat'
+    worst_enc = [0.0, 0.0]
     for k in names:
         ours, r = O.grad_fingerprint(grads[k].float().cpu()), ref[k]
-        tn, tv = (0.15, 0.15) if enc(k) else (1e-2, 5e-2)
-        assert abs(ours[2] - r[2]) < tn * r[2] + 1e-30, (k, ours[2], r[2])
-        assert np.linalg.norm(ours[3:] - r[3:]) < tv * np.linalg.norm(r[3:]) + 1e-30, k
+        tn, tv = (ENC_TN, ENC_TV) if enc(k) else (1e-2, 5e-2)
+        en, evv = abs(ours[2] - r[2]) / (r[2] + 1e-30), np.linalg.norm(ours[3:] - r[3:]) / (np.linalg.norm(r[3:]) + 1e-30)
+        if enc(k):
+            worst_enc = [max(worst_enc[0], en), max(worst_enc[1], evv)]
+        assert en < tn, (k, ours[2], r[2])
+        assert evv < tv, (k, evv)
+    print(f'encoder gradients vs the reference golden: worst norm error {worst_enc[0]:.3e}, worst fingerprint error {worst_enc[1]:.3e}')
+
+
+ENC_TN, ENC_TV = 0.15, 0.15          # (tiny fixture, encoder entries: see test_full_backward_against_reference_gradients)
 
 
 def _full_size_backward(cfg, device, n_expected=None):
@@ -364,18 +372,17 @@ def _full_size_backward(cfg, device, n_expected=None):
         print(f'   {k:50s} {v:.3e}   {ref_t[k]:.3e}   ({worst[k]:.3e})')
     nenc = [k for k in names if 'encoder_3d' not in k and k != 'input.vertex_feat']
     print(f'   worst outside the encoder: ours {max(ours_t[k] for k in nenc):.3e}  fp32 reference {max(ref_t[k] for k in nenc):.3e}')
-    enc = lambda k: 'encoder_3d' in k or k == 'input.vertex_feat'
     for k in names:
         # Everything OUTSIDE the sparse encoder: the forward protocol's rule for extreme values (oracle/parity.py) -- our
         # distance from the float64 truth may not exceed TWICE the fp32 reference's own distance from it plus 1e-3 of the gradient's norm
         # (rounds 3-4: a flat 1e-2).  MI355X, 512 x 512 x 64 (profiles/r05_call_f_*): ours 4.5e-4, the fp32 reference 4.1e-4.
-        # The gradients BEHIND the sparse encoder (its parameters, the vertex features): the strict rule FAILS for them and is not claimed.
-        # Measured: ours 0.7-1.0e-2 of the norm from the truth at full size (2.5-3.4e-3 at the tiny size) where the fp32 reference sits at
-        # 1.0-1.7e-3 (0.5-1.5e-4).  Both are amplified rounding -- every BatchNorm backward subtracts the mean of a gradient whose common-mode
-        # part dominates, ~10^3-10^4 rounding units survive -- but our input-gradient convolutions multiply fp16 hi + lo operands (2e-6 of the
-        # specification per layer, DESIGN section 8, against fp32's 6e-8): the ratio of the two arithmetic precisions is the ratio seen here.
-        # Bound: 2e-2 of the gradient's norm (rounds 3-4: 0.15), the reference's own distance printed beside it.
-        assert ours_t[k] <= (2e-2 if enc(k) else 2.0 * ref_t[k] + 1e-3), (k, ours_t[k], ref_t[k])
+        # Round 6: the SAME rule for the gradients behind the sparse encoder (its parameters, the vertex features).  Rounds 3-5 bounded them by
+        # 0.15 / 2e-2 of the norm: the input-gradient convolutions multiplied fp16 hi + lo operands whose lo halves lost their low bits to
+        # fp16's 2^-24 floor (2e-6 of the specification per layer) and every BatchNorm backward behind them amplifies rounding 10^3-10^4
+        # times (it subtracts the mean of a gradient whose common-mode part dominates).  With both lo halves carried at 2^11 (csrc/svox.hip,
+        # IN_BN 3: 2-3e-7 of the maximum, fp32's own noise) ours sits where the fp32 reference sits: MI355X, cfg2_ri, worst entry
+        # (down0.1.bias) ours 1.017e-2 vs the reference's 1.015e-2 of the norm from the float64 truth (profiles/r06_call_c_*).
+        assert ours_t[k] <= 2.0 * ref_t[k] + 1e-3, (k, ours_t[k], ref_t[k])
         assert spread[k] < 1e-3, (k, spread[k])
     return ours_t, ref_t
 
