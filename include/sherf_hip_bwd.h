@@ -27,7 +27,13 @@ const char* sherf_bwd_last_error(void);
  * backward, each with one huge dimension (the valid samples) and two layer-width ones: transA = 0 (M huge: forward recompute and data
  * gradients), transA = 1 / transB = 0 (K huge: weight gradients, partial sums added to C with fp32 atomics -- the summation order is
  * not deterministic); anything else runs on a plain fp32 kernel.  Replaces every `x @ W.t()` / `d.t() @ x` of
- * oracle/backward_explicit.py (decoder_bwd.lin_bwd, transformer_bwd). */
+ * oracle/backward_explicit.py (decoder_bwd.lin_bwd, transformer_bwd).
+ * READABLE ROW PADDING (round 5's streaming kernel): with transA = 0, beta = 0, lda >= 16 * ceil(K / 16), lda % 4 == 0 and A
+ * 16-byte aligned, a row of A is read in whole 16-float blocks -- up to 15 floats beyond column K - 1 (masked in registers, never used).  Those
+ * floats must be READABLE: the natural case is a row padded to a multiple of 16 floats (lda >= 16 * ceil(K / 16) counted from the row's own
+ * first element).  An A that is a column slice of a wider matrix at a non-zero offset (offset % lda + 16 * ceil(K / 16) > lda) reads into the
+ * next row -- harmless -- except on the LAST row, where the caller must own 15 more floats behind the buffer, or pass such a slice with an lda
+ * that fails one of the conditions above (any lda % 4 != 0 view of it) to take the general kernel.  sherf_amd.backward_dense.Mat.empty_ld pads. */
 int sherf_bwd_gemm(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float beta, sherf_stream_t stream);
 /* The same product with the layer's epilogue fused: C = act(op(A) op(B) + beta C + bias[column]), act 0 identity / 1 ReLU (bias may be

@@ -178,7 +178,7 @@ class HipOps:
             raise RuntimeError('conv_dgrad: d_raw carries no amax (it must come from bn_relu_bwd)')
         Wt = W.tensor().view(Cout, 27, Cin).flip(1).permute(1, 0, 2).contiguous()        # wt[k'][co][ci] = W[co][26 - k'][ci]
         from .voxel import pack_conv_weights
-        wp = pack_conv_weights(Wt, lo_scale=2048.0)          # (the kernel's input-gradient instance carries both operands' lo halves at 2^11)
+        wp = pack_conv_weights(Wt)
         _lib.call('sherf_svox_conv3_dgrad', _lib.ptr(lev_in['keys']), _lib.ptr(lev_in['n_rows']), *lev_in['dims'], _lib.ptr(lev_out['wp']),
                   *lev_out['dims'], self._p(d_raw), Cout, self._p(d_raw.amax), _lib.ptr(wp), Cin, mode, lev_in['cap'], self._p(d_in), self.st)
 

@@ -381,6 +381,7 @@ constexpr int kGraphSlots = 8;
 GraphEntry g_graphs[kMaxDev][kGraphSlots];
 uint64_t g_graph_clock = 0;
 int g_graph_on = -1;                  // -1: read SHERF_FRAME_GRAPH at the first frame
+bool g_graph_aux_ok = false;          // SHERF_FRAME_GRAPH_AUX=1: capture three-stream frames too (crashes the runtime on this box: see sherf_render_frame)
 int64_t g_graph_stats[4] = {0, 0, 0, 0};   // captures, replays, eager frames, failed captures
 
 inline void fnv(uint64_t& h, const void* p, size_t n) {
@@ -419,13 +420,20 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
     if (g_graph_on < 0) {
         const char* e = getenv("SHERF_FRAME_GRAPH");
         g_graph_on = (e && atoi(e) == 0) ? 0 : 1;
+        const char* ea = getenv("SHERF_FRAME_GRAPH_AUX");
+        g_graph_aux_ok = ea && atoi(ea) != 0;
     }
     int dev = 0;
     bool prof;
     { std::lock_guard<std::mutex> lk(g_mu); prof = g_prof_on; }
     const int xp = sherf_experiment();
     const bool eligible = g_graph_on == 1 && (phase == 1 || phase == 3) && !prof && !(f->flags & (SHERF_FRAME_EXACT_GRIDS | SHERF_FRAME_REPORT_COUNT)) &&
-                          !(xp & (16 | 32)) && f->vox_plan && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev && g_dev[dev].init;
+                          !(xp & (16 | 32)) && f->vox_plan && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev && g_dev[dev].init &&
+                          // MEASURED (MI355X, ROCm 7.0 runtime of PyTorch 2.10; profiles/r06_call_d_f_*): hipStreamEndCapture CRASHES on the frame's
+                          // three-stream capture (main + side + aux with their cross dependencies) inside the product process, while the two-stream
+                          // capture works (and the same three-stream shape works in a stand-alone probe, tools/ubench/graph_probe.hip).  Until
+                          // that is understood only frames WITHOUT the third stream are captured (SHERF_FRAME_GRAPH_AUX=1 lifts the guard).
+                          (!stream_aux || g_graph_aux_ok);
     if (!eligible) {
         ++g_graph_stats[2];
         return render_frame_enqueue(f, phase, levels, stream_main, stream_side, stream_aux);

@@ -1687,6 +1687,10 @@ extern "C" int sherf_nerf_mlp3_part(const int32_t* counters, const float* tokens
     const int64_t tiles = nparts > 1 ? ((capacity + 255) / 256 + nparts - 1) / nparts * 8 + 8 : (capacity + 31) / 32;    // most a part can hold
     const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(NW * 64);
     const unsigned pad = wgs_per_cu == 2 ? 12 * 1024 : wgs_per_cu == 1 ? 44 * 1024 : 0;
+    if (wgs_per_cu == 1) {      // static 43.6 KiB + 44 KiB of padding is beyond the 64 KiB a launch may use without saying so
+        if (prec == 2) SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp3_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+        else SHERF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_mlp3_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+    }
     if (prec == 2)
         hipLaunchKernelGGL((nerf_mlp3_kernel<2>), grid, block, pad, as_stream(stream), counters, reinterpret_cast<const float4*>(tokens), extras,
                            reinterpret_cast<const char*>(wstream), wbias, capacity, reinterpret_cast<float4*>(out), part, nparts, notrans,

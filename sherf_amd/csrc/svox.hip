@@ -217,13 +217,14 @@ __device__ unsigned g_sconv_trace_cap = 0, g_sconv_trace_n = 0;
 // NW: waves per workgroup the 27 taps are split over.  A workgroup's life is a serial chain of dependent gathers, ~7 taps per wave at
 // NW = 4 (profiles/r02_sconv_trace_v3.txt: 28 K of its ~50 K cycles); at NW = 8 a wave walks 3-4 taps and the partial tiles of eight
 // waves are summed in LDS (up to 98 KiB: these workgroups are alone or nearly alone on their CU anyway).
-// IN_BN 3 (round 6): the INPUT-GRADIENT instance (sherf_svox_conv3_dgrad): raw rows like IN_BN 0, but the `lo` halves of
-// both operands are carried at 2^11 times their value and their two products go to a SECOND accumulator that joins the first with a factor 2^-11
-// at the end.  Why: lo = x - fp16(x) is at most 2^-11 |x|, and fp16 resolves nothing below 2^-24 -- for an element at 1e-3 of the layer's maximum
-// (where a gradient row's typical entries are) the unscaled lo keeps three bits, and the product carries 2e-5 instead of 2^-22; every BatchNorm
-// backward behind it amplifies that by 10^3-10^4: the encoder's gradients sat 5-8 x farther from the float64 truth than the
-// fp32 reference's.  Scaled, lo keeps its 11 bits down to elements 2^-13 of the maximum: 22 bits per operand, the same three MFMAs.
-template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP, int NW>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity, 3 raw input of the input-gradient convolution
+// Round 6: in the three-product instances (SP = false: the fp32-grade "f16x3" class -- the reference configuration of
+// `auto`, every training forward, and the input-gradient convolutions of the backward) the `lo` halves of BOTH operands are carried at 2^11 times
+// their value and their two products go to a SECOND accumulator that joins the first with a factor 2^-11 at the end.  Why: lo = x - fp16(x) is at
+// most 2^-11 |x|, and fp16 resolves nothing below 2^-24 -- for an operand at 1e-2 of the tile's largest (weights of 0.01, the typical entries of
+// a gradient row) the unscaled lo kept 6 bits instead of 11: 2e-6 of the specification per layer where fp32 has 6e-8, and every BatchNorm
+// backward behind such a layer amplifies rounding 10^3-10^4 times.  Scaled, lo keeps its 11 bits down to 2^-13 of fp16's
+// range: 22 bits per operand, the same three MFMAs, 16 more registers per output tile.
+template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP, int NW>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
 __global__ void __launch_bounds__(64 * NW, (NW == 8 ? 2 : (NCOT * NKB >= 12 ? 1 : 2)))   // (level 2 launches 318 workgroups: two per CU must fit)
 sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
@@ -245,7 +246,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     // but gradients are O(1e-7): the rows are scaled by the power of two that brings their maximum into [0.5, 1) before the split (exact)
     // and the result is scaled back (exact); elements below 6e-5 of the maximum keep an absolute error of 3e-8 of it -- fp32's own.
     float in_scale = 1.f, out_scale = 1.f;
-    if ((IN_BN == 0 || IN_BN == 3) && in_amax) {
+    if (IN_BN == 0 && in_amax) {
         const int be = (int)((*in_amax >> 23) & 0xffu);                 // biased exponent of the maximum
         if (be >= 1 && be <= 252) { in_scale = __uint_as_float((uint32_t)(253 - be) << 23); out_scale = __uint_as_float((uint32_t)(be + 1) << 23); }
     }
@@ -303,8 +304,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
         }
     }
     SCONV_STAMP(1);                                  // neighbour table done (this thread's share)
-    constexpr bool in_bn = IN_BN == 1 || IN_BN == 2, has_mult = IN_BN == 2, DG = IN_BN == 3;
-    static_assert(!DG || (!SP && !FOLD), "the input-gradient instance: three products, 27 taps");
+    constexpr bool in_bn = IN_BN != 0, has_mult = IN_BN == 2, SL = !SP;       // SL: scaled lo halves, second accumulator (see the kernel's header)
     if (in_bn) {
         if (bin.acc) {
             if (tid < Cin) {
@@ -331,11 +331,11 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     SCONV_STAMP(3);
 
     f32x16_t acc[NCOT];
-    f32x16_t acc2[DG ? NCOT : 1];                        // DG: the two lo products, at 2^11 times their value
+    f32x16_t acc2[SL ? NCOT : 1];                        // SL: the two lo products, at 2^11 times their value
 #pragma unroll
     for (int c = 0; c < NCOT; ++c)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { acc[c][q] = 0.f; if (DG) acc2[c][q] = 0.f; }
+        for (int q = 0; q < 16; ++q) { acc[c][q] = 0.f; if (SL) acc2[c][q] = 0.f; }
     const int r = lane & 31, h = lane >> 5;
     // taps of this wave (tap = wave, wave+4, ...) that have at least one neighbour in the tile
     uint32_t tapmask = 0;
@@ -394,7 +394,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sc[Cin + e], 0.f) + R.mlt * sc[2 * Cin + e];
             }
-            if constexpr (IN_BN == 0 || IN_BN == 3) {
+            if constexpr (IN_BN == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= in_scale;
             }
@@ -410,21 +410,16 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, W.w[kb][WPC * c]), acc[c], 0, 0, 0);
                 }
             } else {
-            constexpr float LS = DG ? 2048.0f : 1.0f;          // (x - rt(x)) * 2^11 is exact: |x - rt(x)| <= 2^-11 |x| < 2^-11
+            constexpr float LS = 2048.0f;                      // (x - rt(x)) * 2^11 is exact in fp32
             const uint4 alo = make_uint4(pk2((v[0] - rt(v[0])) * LS, (v[1] - rt(v[1])) * LS), pk2((v[2] - rt(v[2])) * LS, (v[3] - rt(v[3])) * LS),
                                          pk2((v[4] - rt(v[4])) * LS, (v[5] - rt(v[5])) * LS), pk2((v[6] - rt(v[6])) * LS, (v[7] - rt(v[7])) * LS));
 #pragma unroll
             for (int c = 0; c < NCOT; ++c) {
                 if (FOLD && c != csel) continue;
                 const uint4 bhi = W.w[kb][WPC * c], blo = W.w[kb][WPC * c + WPC - 1];
-                if constexpr (DG) {                            // blo = fp16((W - hi) * 2^11): sherf_amd/voxel.py pack_conv_weights(lo_scale=2048)
-                    acc2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc2[c], 0, 0, 0);
-                    acc2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc2[c], 0, 0, 0);
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
-                    continue;
-                }
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc[c], 0, 0, 0);
+                // blo = fp16((W - hi) * 2^11): sherf_amd/voxel.py pack_conv_weights
+                acc2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, alo), __builtin_bit_cast(f16x8_t, bhi), acc2[c], 0, 0, 0);
+                acc2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, blo), acc2[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, bhi), acc[c], 0, 0, 0);
             }
             }
@@ -473,7 +468,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
         }
     }
     SCONV_STAMP(6);                                  // all taps of wave 0 done
-    if constexpr (DG) {
+    if constexpr (SL) {
 #pragma unroll
         for (int c = 0; c < NCOT; ++c)
 #pragma unroll
@@ -695,20 +690,6 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     static int trace_launches = 0;                  // (profiling builds: launch ordinal -> the records' first word)
     const int trace_id = SHERF_SCONV_TRACE ? trace_launches++ : 0;
     const int sel = (Cout / 32) * 10 + Cin / 16;
-    if (in_amax) {                                       // the input-gradient convolutions: scaled lo halves (IN_BN 3; w_packed with lo * 2^11)
-        const int dsel = (fold || bnm || single) ? -1 : sel;
-        switch (dsel) {
-            case 12: SHERF_CONV3___(1, 2, false, 3, false, 4); break;     // 32 -> 32
-            case 14: SHERF_CONV3___(1, 4, false, 3, false, 4); break;     // 64 -> 32
-            case 24: SHERF_CONV3___(2, 4, false, 3, false, 4); break;     // 64 -> 64
-            case 26: SHERF_CONV3___(2, 6, false, 3, false, 4); break;     // 96 -> 64
-            case 36: SHERF_CONV3___(3, 6, false, 3, false, 4); break;     // 96 -> 96
-            default:
-                snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_svox_conv3_dgrad: unsupported channel pair %d -> %d", Cin, Cout);
-                return SHERF_EINVAL;
-        }
-        SHERF_LAUNCH_CHECK();
-    }
     switch (sel) {
         case 12: SHERF_CONV3(1, 2); break;     // 32 -> 32
         case 22: SHERF_CONV3(2, 2); break;     // 32 -> 64
@@ -716,7 +697,12 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
         case 34: SHERF_CONV3(3, 4); break;     // 64 -> 96
         case 36: SHERF_CONV3(3, 6); break;     // 96 -> 96
         case 32: SHERF_CONV3(3, 2); break;     // 32 -> 96 (fold)
+        // the two transposed channel pairs only the input gradient of the stride-2 layers needs (sherf_svox_conv3_dgrad: raw rows, three
+        // products, four waves -- one instance each instead of the 24 of a forward pair)
+        case 14: if (fold || bnm || single) goto unsupported; SHERF_CONV3___(1, 4, false, 0, false, 4); break;     // 64 -> 32
+        case 26: if (fold || bnm || single) goto unsupported; SHERF_CONV3___(2, 6, false, 0, false, 4); break;     // 96 -> 64
         default:
+        unsupported:
             snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_svox_conv3: unsupported channel pair %d -> %d", Cin, Cout);
             return SHERF_EINVAL;
     }

@@ -594,6 +594,19 @@ class ImportanceRenderer(nn.Module):
             return self._round_tokens(self.TOKEN_HEADROOM * nv, cap)
         return wsp.tok_cap
 
+    def drain_pack_flag(self):
+        """The weight-range flag word of the LAST training repack (read back one step late while training, _pack_stream): checked now.  Called when
+        training stops -- eval() / train(False) -- so that the final step's out-of-range or non-finite weights do not go unreported."""
+        pend = self.__dict__.pop('_pack_flag_pending', None)
+        if pend is not None:
+            pend[0].synchronize()
+            mlp_pack.raise_for_flags(int(pend[1][0]), 0.0, pend[2])
+
+    def train(self, mode=True):
+        if not mode:
+            self.drain_pack_flag()
+        return super().train(mode)
+
     # ---- weights -----------------------------------------------------------------------------
     def _weights(self, decoder, device, precision=None):
         """Packed weights for the frame: the fold tables (precision independent) + the MLP fragment stream in `precision`.  Cached on

@@ -57,10 +57,11 @@ def _stride_conv(cin, cout):
     return nn.Sequential(SparseConv3d(cin, cout), _bn(cout), nn.ReLU())
 
 
-def pack_conv_weights(wt, lo_scale=1.0):
+def pack_conv_weights(wt, lo_scale=2048.0):
     """wt [ntaps, Cin, Cout] fp32 -> fp16 MFMA B-operand fragments [ntaps][Cin/16][Cout/32][hi,lo][64 lanes][8] (int16 bits):
-    hi = fp16(W), lo = fp16((W - hi) * lo_scale) ("f16x3": 22 significant bits, three products in the kernel).  lo_scale = 2048 for the
-    input-gradient convolutions (csrc/svox.hip: IN_BN 3): W - hi is below 2^-11 |W| and would lose its low bits to fp16's 2^-24 floor.
+    hi = fp16(W), lo = fp16((W - hi) * 2^11) ("f16x3": 22 significant bits, three products in the kernel; the single-product instances read
+    `hi` only).  The scale (round 6; csrc/svox.hip: SL): W - hi is below 2^-11 |W| and lost its low bits to fp16's 2^-24 floor for weights
+    of 0.01 -- the kernel carries both operands' lo halves at 2^11 and folds the factor back into its second accumulator.
     Lane l = (column j = l & 31, half h = l >> 5) holds W[tap][16*kb + 8*h + e][32*cot + j], e = 0..7
     (operand layout of v_mfma_f32_32x32x16_f16; consumed by sconv3_kernel in csrc/svox.hip)."""
     T, Cin, Cout = wt.shape

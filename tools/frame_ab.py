@@ -68,6 +68,7 @@ def main():
         os.environ['SHERF_EXPERIMENT'] = str(int(exps[i], 0) | (int(os.environ.get('SHERF_EXPERIMENT_BASE', '0'), 0)))
         w['opts'] = dict(base_opts, **arm_opts[i])
     lib = _lib.lib()
+    lib.sherf_frame_graphs(0)                                     # (the warm-up renders launch by launch; every arm sets its own mode)
     os.environ['SHERF_EXPERIMENT'] = str(int(os.environ.get('SHERF_EXPERIMENT_BASE', '0'), 0))     # (bit 2 is read at the first frame)
     for _ in range(3):
         bench.render_frame(w)                                   # calibration of `auto` + warm-up
