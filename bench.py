@@ -473,11 +473,12 @@ def main():
     for _ in range(a.warmup):
         step()
     drain()
-    # Round 6: frames replay as hipGraphs (csrc/frame.hip: one hipGraphLaunch per frame instead of ~90 enqueue calls).  A replayed graph carries no
-    # per-frame timing events, so the timed region runs WITHOUT the driver's HIP events and a second pass of frames right behind it (same process,
-    # same workload, frames enqueued launch by launch with the events around every stage on its launch stream) measures the kernel's duration and
-    # the timeline.  SHERF_FRAME_GRAPH=0: graphs off, events inside the timed region as in rounds 2-5.
-    graphs_on = os.environ.get('SHERF_FRAME_GRAPH', '1') != '0' and dev.type == 'cuda'
+    # Round 6: frames CAN replay as hipGraphs (csrc/frame.hip; SHERF_FRAME_GRAPH=1 and rendering option aux_stream=False -- opt-in: measured on the
+    # MI355X, a replayed frame takes the GPU as long as an enqueued one).  A replayed graph carries no per-frame timing events, so with graphs on the
+    # timed region runs WITHOUT the driver's HIP events and a second pass of frames right behind it (same process, frames enqueued launch by launch
+    # with the events around every stage on its launch stream) measures the kernel's duration and the timeline.  Default: graphs off, events inside
+    # the timed region as in rounds 2-5.
+    graphs_on = os.environ.get('SHERF_FRAME_GRAPH', '0') == '1' and dev.type == 'cuda'
     _abi.call('sherf_profile_frames', 0 if graphs_on else 1)       # HIP events around sherf_nerf_mlp etc. on their launch streams (csrc/frame.hip)
     if world > 1:
         torch.distributed.barrier()

@@ -456,8 +456,11 @@ int sherf_frame_count(int32_t* nv_host);
 /* hipGraph replay of frames (round 6): the second consecutive sherf_render_frame call (phase 1 or 3) with the same descriptor bytes, encoder plan,
  * streams and debug words is captured from the caller's stream and replayed by one hipGraphLaunch from then on (a frame's launch sequence depends on
  * nothing else: no data-dependent value reaches the host).  Frames with SHERF_FRAME_REPORT_COUNT / _EXACT_GRIDS, profiled frames and new
- * descriptors are enqueued launch by launch as before.  On by default (environment SHERF_FRAME_GRAPH=0: off); sherf_frame_graphs(0) turns it off and
- * drops every captured graph, (1) turns it on.  sherf_frame_graph_stats: {captures, replays, eagerly enqueued frames, failed captures} since load. */
+ * descriptors are enqueued launch by launch as before.  OPT-IN (environment SHERF_FRAME_GRAPH=1, or sherf_frame_graphs(1); (0) turns it off and
+ * drops every captured graph) and only for frames WITHOUT a third stream (stream_aux == NULL): measured on the MI355X a replayed frame takes the GPU
+ * as long as an enqueued one (1.719 vs 1.722 ms; it saves ~0.25 ms of host time), the three-stream form is 25 us faster than either, and this
+ * runtime's hipStreamEndCapture crashes on the three-stream capture (csrc/frame.hip).  sherf_frame_graph_stats: {captures, replays, eagerly
+ * enqueued frames, failed captures} since load. */
 int sherf_frame_graphs(int enable);
 int sherf_frame_graph_stats(int64_t* stats_host, int32_t n);
 /* phase: 1 = everything up to the per-sample network, 2 = compositing, 3 = both; 4 (alone) = the sampler only (cell lists, shell mask,

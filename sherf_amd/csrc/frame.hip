@@ -366,8 +366,13 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
 // pointers (fresh input tensors, a re-sized workspace, other weights) has a new key: it is enqueued launch by launch as before and starts its own
 // count, so sequences lose nothing.  Not captured: frames that report their count (SHERF_FRAME_REPORT_COUNT / _EXACT_GRIDS: a per-call pinned
 // slot / a host wait), profiled frames (sherf_profile_frames: per-frame timing events), the host-stamp experiments, phase 2 / 4 alone.  A capture
-// that fails for any reason renders the frame eagerly and never tries that key again.  sherf_frame_graphs(0) turns the whole mechanism off
-// (environment SHERF_FRAME_GRAPH=0: from the start); sherf_frame_graph_stats reads what happened.
+// that fails for any reason renders the frame eagerly and never tries that key again.
+// MEASURED on the MI355X (profiles/r06_call_h_*, cfg2_dense_ri, arms interleaved, bit-identical frames): replayed frames 1.719 ms against 1.722 ms
+// enqueued launch by launch in the same two-stream form -- the GPU side gains NOTHING (the host runs ahead of a 1.7 ms frame either way; the
+// dependent chains are bound by their kernels, not by launch gaps) -- and the three-stream form this runtime cannot capture (hipStreamEndCapture
+// crashes, see `eligible` below) is 1.699 ms.  What a replay saves is the host's ~0.25 ms of enqueue work per frame.  So the mechanism is OPT-IN:
+// environment SHERF_FRAME_GRAPH=1 or sherf_frame_graphs(1) (and a caller that passes no third stream); off by default.  sherf_frame_graph_stats
+// reads what happened.
 namespace {
 
 struct GraphEntry {
@@ -419,7 +424,7 @@ extern "C" int sherf_render_frame(const sherf_frame* f, int phase, sherf_vox_lev
     std::lock_guard<std::mutex> frame_lock(g_frame_mu);
     if (g_graph_on < 0) {
         const char* e = getenv("SHERF_FRAME_GRAPH");
-        g_graph_on = (e && atoi(e) == 0) ? 0 : 1;
+        g_graph_on = (e && atoi(e) != 0) ? 1 : 0;                     // OFF unless asked for: see the note above sherf_render_frame
         const char* ea = getenv("SHERF_FRAME_GRAPH_AUX");
         g_graph_aux_ok = ea && atoi(ea) != 0;
     }

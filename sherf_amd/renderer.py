@@ -965,10 +965,10 @@ class ImportanceRenderer(nn.Module):
         # the frame's outputs: ONE fresh buffer per call, planar [rgb (3R) | depth (R) | acc (R)], written by the compositing kernel and
         # returned as views -- no copies behind the frame (rounds 1-2 cloned three workspace tensors: three launches per frame), and
         # a caller may keep as many frames as it likes
-        # Round 6: frames replay as hipGraphs (csrc/frame.hip), keyed on every pointer of the descriptor -- so on the GPU the compositing kernel
-        # writes a buffer OWNED BY THE WORKSPACE (the same address frame after frame) and the caller's fresh buffer is one copy behind the frame
-        # (5 R floats: ~3 us); with graphs off (SHERF_FRAME_GRAPH=0) and on the host build the kernel writes the fresh buffer itself
-        static_out = dev.type == 'cuda' and os.environ.get('SHERF_FRAME_GRAPH', '1') != '0'
+        # Round 6: frames can replay as hipGraphs (csrc/frame.hip; opt-in, SHERF_FRAME_GRAPH=1 -- measured: no GPU-side gain), keyed on every pointer
+        # of the descriptor -- then the compositing kernel writes a buffer OWNED BY THE WORKSPACE (the same address frame after frame) and the
+        # caller's fresh buffer is one copy behind the frame (5 R floats: ~3 us); otherwise the kernel writes the fresh buffer itself
+        static_out = dev.type == 'cuda' and os.environ.get('SHERF_FRAME_GRAPH', '0') == '1'
         if static_out:
             out = wsp.t.get('out_static')
             if out is None or out.numel() != 5 * R or out.device != dev:

@@ -294,9 +294,9 @@ def test_full_backward_against_reference_gradients():
     grads.update({'input.planes': out['planes'], 'input.obs_feat': out['obs_feat'], 'input.vertex_feat': out['vertex_feat']})
     names = [k for k in ref.files if k not in ('loss', 'ref_cpu_seconds')]
     assert set(names) == set(grads), set(names) ^ set(grads)
-    # encoder entries: loose bound only -- on this fixture they are ill-conditioned (an activation at the ReLU kink; a 3e-5
-    # perturbation of the forward moves the reference's own encoder gradients by 5-6 %); the tight check of those kernels is
-    # against the explicit backward at our forward point (tests/test_hipcpu_frame.py on the CPU, the kernel tests below here).
+    # encoder entries: rounds 2-5 bounded them by 0.15 ("ill-conditioned on this fixture": a 3e-5 perturbation of the forward moved the
+    # reference's own encoder gradients by 5-6 %) -- the perturbation was OUR forward's: three-product sparse convolutions whose lo halves lost
+    # their low bits (2e-6 per layer).  With the lo halves carried at 2^11 (round 6, csrc/svox.hip) they meet the bounds of every other gradient.
     enc = lambda k: 'encoder_3d' in k or k == 'input.vertex_feat'
     worst_enc = [0.0, 0.0]
     for k in names:
@@ -310,7 +310,7 @@ def test_full_backward_against_reference_gradients():
     print(f'encoder gradients vs the reference golden: worst norm error {worst_enc[0]:.3e}, worst fingerprint error {worst_enc[1]:.3e}')
 
 
-ENC_TN, ENC_TV = 0.15, 0.15          # (tiny fixture, encoder entries: see test_full_backward_against_reference_gradients)
+ENC_TN, ENC_TV = 1e-2, 5e-2          # round 6: the encoder's entries under the bounds of every other gradient (rounds 2-5: 0.15; measured 3.7e-4 / 8.5e-4)
 
 
 def _full_size_backward(cfg, device, n_expected=None):

@@ -532,16 +532,20 @@ def test_token_workspace_is_sized_from_the_frame_on_device():
 
 
 
-def test_frames_replay_as_hipgraphs_on_device():
-    """Round 6: the second consecutive frame on the same descriptor is captured into a hipGraph and replayed from then on
-    (csrc/frame.hip).  Replayed frames equal frames enqueued launch by launch BIT FOR BIT; an input changed IN PLACE reaches the replay (the graph
-    holds addresses, not values); a frame on freshly allocated input tensors has a new key: it is enqueued eagerly and renders the same image."""
+def test_frames_replay_as_hipgraphs_on_device(monkeypatch):
+    """Round 6: with SHERF_FRAME_GRAPH=1 / sherf_frame_graphs(1) the second consecutive frame on the same descriptor is
+    captured into a hipGraph and replayed from then on (csrc/frame.hip; opt-in, two-stream frames only -- measured: no GPU-side gain, and this
+    runtime cannot capture the three-stream form).  Replayed frames equal frames enqueued launch by launch BIT FOR BIT; an input changed IN PLACE
+    reaches the replay (the graph holds addresses, not values); a frame on freshly allocated input tensors has a new key: it is enqueued eagerly
+    and renders the same image; a three-stream frame is never captured."""
     import argparse
     import ctypes as ct
     import bench
     from sherf_amd import _lib
+    monkeypatch.setenv('SHERF_FRAME_GRAPH', '1')            # (the Python side then renders into the workspace's static output buffer)
     dev = torch.device('cuda', 0)
     w = bench.make_workload(argparse.Namespace(config='cfg1_ri', precision='f16', bn_mode='train'), 0.4, dev)
+    w['opts']['aux_stream'] = False
 
     def frame():
         r = bench.render_frame(w)
@@ -580,5 +584,13 @@ def test_frames_replay_as_hipgraphs_on_device():
             assert all(torch.equal(a, b) for a, b in zip(f, e))
         s4 = stats()
         assert s4[2] - s3[2] >= 3 and s4[0] == s3[0], (s3, s4)
+        # three streams: rendered launch by launch whatever the switch says, the same image
+        w['fresh'] = False
+        w['opts']['aux_stream'] = True
+        for _ in range(4):
+            f = frame()
+            assert all(torch.equal(a, b) for a, b in zip(f, e))
+        s5 = stats()
+        assert s5[0] == s4[0] and s5[1] == s4[1] and s5[3] == s4[3], (s4, s5)
     finally:
-        _lib.call('sherf_frame_graphs', 1)
+        _lib.call('sherf_frame_graphs', 0)

@@ -685,8 +685,8 @@ def check_snapshot_and_training_step_against_reference_golden(monkeypatch):
     for n, (en, es, nr) in worst.items():
         if nr <= 1e-9:
             continue
-        # (sparse-encoder entries: ill-conditioned on this fixture -- an activation at the ReLU kink, see tests/test_gpu_backward.py)
-        assert en < (0.15 if enc(n) else 1e-2) and es < (0.15 if enc(n) else 2e-2), (n, en, es)
+        # (sparse-encoder entries: rounds 2-5 allowed 0.15 -- our three-product convolutions lost the low bits of their lo halves; round 6: one bound)
+        assert en < 1e-2 and es < 2e-2, (n, en, es)
     return terms, worst
 
 
@@ -836,7 +836,7 @@ def test_training_step_through_autograd_matches_reference_gradients(cpu_product,
     enc = lambda k: 'encoder_3d' in k or k == 'input.vertex_feat'
     for k in names:
         ours, r = O.grad_fingerprint(grads[k].float()), ref[k]
-        tn, tv = (0.15, 0.15) if enc(k) else (1e-2, 5e-2)
+        tn, tv = (1e-2, 5e-2)                  # round 6: the encoder's entries too (rounds 2-5: 0.15 -- the "3e-5 perturbation" was our convolutions' lo halves)
         assert abs(ours[2] - r[2]) < tn * r[2] + 1e-30, (k, ours[2], r[2])
         assert np.linalg.norm(ours[3:] - r[3:]) < tv * np.linalg.norm(r[3:]) + 1e-30, k
     d_feat_e, g_e = orig(EmuOps(), seen['state'], seen['ctx'], seen['d_levels'])
