@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 STAGES = ('encoder_2d', 'mapping', 'backbone_synthesis', 'encoder_2d_feature', 'glue', 'renderer')
 
 
-def build_generator(w, dev, small=False):
+def build_generator(w, dev, small=False, num_fp16_res=0):
     """The generator of train.py:237-428 / training_loop.py:192 (z 512, c_dim 0, w 512, map_depth 2, cbase 32768, cmax 512, fp32) around the bench workload's renderer and
     decoder (reference-init network); its own producers, initialised by their constructors under a fixed seed."""
     from sherf_amd.triplane import TriPlaneGenerator
@@ -34,7 +34,8 @@ def build_generator(w, dev, small=False):
     torch.manual_seed(0)
     gen = TriPlaneGenerator(512, 0, 512, True, True, True, True, True, img_resolution=512, img_channels=3, mapping_kwargs=dict(num_layers=2),
                             rendering_kwargs=dict(w['opts']), smpl=synth.make_synth_smpl(0), channel_base=512 if small else 32768,
-                            channel_max=16 if small else 512, num_fp16_res=0, conv_clamp=None, fused_modconv_default='inference_only')
+                            channel_max=16 if small else 512, num_fp16_res=num_fp16_res, conv_clamp=256 if num_fp16_res > 0 else None,   # (train.py:427-428)
+                            fused_modconv_default='inference_only')
     gen.renderer, gen.decoder = w['rend'], w['dec']
     gen = gen.to(dev).eval()
     torch.manual_seed(0)
@@ -158,6 +159,7 @@ def main():
     ap.add_argument('--miopen-benchmark', action='store_true', help='torch.backends.cudnn.benchmark = True: MIOpen searches its convolution algorithms on first use')
     ap.add_argument('--eager-producers', action='store_true', help='TriPlaneGenerator.graph_producers = False in every variant (default: the product default, '
                                                                    'producers replayed as hipGraphs; the eager number is measured beside it either way)')
+    ap.add_argument('--fp16-res', type=int, default=4, help='also time the forward with this many fp16 resolutions in the tri-plane generator (the reference\'s --g_num_fp16_res; 0: skip)')
     ap.add_argument('--channels-last', action='store_true', help='producers (backbone, encoders) in channels_last memory format')
     a = ap.parse_args()
     import bench
@@ -193,7 +195,17 @@ def main():
         res[name] = dict(ms_per_forward=ms, rays_per_s=R / (ms * 1e-3), stages_ms={k: round(v, 4) for k, v in stages.items()}, floor=floor,
                          floor_share=stages[floor] / max(stages.get('total', ms), 1e-9))
     img = out['image_raw']
-    res['value'] = res['recomputed_every_frame']['rays_per_s']; res['ms_per_step'] = res['recomputed_every_frame']['ms_per_forward']
+    if a.fp16_res > 0 and dev.type == 'cuda':
+        # round 6: the same forward with the reference's OWN fp16 path in the tri-plane generator (train.py --g_num_fp16_res, networks_stylegan2.py:
+        # 423-431, 471-536: the last `num_fp16_res` resolutions in fp16, conv_clamp 256) -- an option of the reference, not its shipped default (0).  Same seed: same weights.
+        gen16 = build_generator(w, dev, small=a.small_backbone, num_fp16_res=a.fp16_res)
+        gen16.graph_producers = graph_default
+        ms16, stages16, out16 = run(gen16, d, dev, a.steps, a.warmup, False)
+        i16 = out16['image_raw']
+        res['recomputed_every_frame_backbone_fp16'] = dict(num_fp16_res=a.fp16_res, conv_clamp=256, ms_per_forward=ms16, rays_per_s=R / (ms16 * 1e-3),
+                                                           stages_ms={k: round(v, 4) for k, v in stages16.items()}, finite=bool(torch.isfinite(i16).all()),
+                                                           image_rel_diff_vs_fp32_backbone=float((i16 - img).abs().max() / (img.abs().max() + 1e-12)))
+        del gen16
     res['output'] = dict(image_raw=list(img.shape), finite=bool(torch.isfinite(img).all()), mean=float(img.mean()), weights_mean=float(out['weights_image'].mean()))
     res['config']['mlp_precision'] = w['rend'].last.get('mlp_precision'); res['config']['mlp_form'] = w['rend'].last.get('mlp_form')
     res['renderer_ms_inside_forward'] = res['recomputed_every_frame']['stages_ms'].get('renderer')

@@ -33,6 +33,40 @@ def seed_module(m, prefix):
             t.copy_(torch.from_numpy(np.asarray(fixtures.seeded_param(prefix + name, t.shape), np.float32).reshape(tuple(t.shape))).to(t.dtype))
 
 
+FULL_FP16 = dict(FULL, num_fp16_res=4, conv_clamp=256)          # train.py:427-428 with --g_num_fp16_res 4: the last four resolutions (32 .. 256) in fp16
+
+
+class _SaysCuda(torch.Tensor):
+    """A tensor that answers 'cuda' where networks_stylegan2.py:423 asks `ws.device.type` -- the reference forces fp32 off-GPU, and this container has no GPU.
+    A stand-in like oracle/ref_shims: the reference's SOURCE runs unmodified, in the dtype it would run in on a GPU (fp16 convolutions on the host)."""
+    @property
+    def device(self):
+        import types
+        return types.SimpleNamespace(type='cuda')
+
+
+def main_fp16():
+    """Round 6: the full-size generator with the reference's own fp16 path (num_fp16_res = 4, conv_clamp = 256; eval mode, noise const) ->
+    tests/golden/backbone_full_fp16.npz (a strided subset + whole-tensor moments of the planes)."""
+    sys.path.insert(0, REF)
+    from training import networks_stylegan2 as N
+    from torch_utils.ops import bias_act as BA, upfirdn2d as UP
+    BA._init = lambda: False; UP._init = lambda: False             # (no plugin build here: the `_ref` implementations, as for the fp32 goldens)
+    full = N.Generator(**FULL_FP16)
+    seed_module(full, 'backbone.')
+    zf = torch.from_numpy(np.random.RandomState(5).standard_normal((1, FULL['z_dim'])).astype(np.float32))
+    with torch.no_grad():
+        full.eval()
+        wsf = full.mapping(zf, None)
+        img = full.synthesis(wsf.as_subclass(_SaysCuda), noise_mode='const')
+    v = torch.Tensor(img.float()).numpy() if isinstance(img, torch.Tensor) else img
+    v = np.asarray(v, np.float32)
+    fo = {'ws': wsf.numpy(), 'img_eval_const.sub': v[:, ::5, ::9, ::9].copy(),
+          'img_eval_const.moments': np.array([v.sum(dtype=np.float64), np.abs(v).sum(dtype=np.float64), np.square(v, dtype=np.float64).sum()])}
+    np.savez_compressed(os.path.join(HERE, '..', 'tests', 'golden', 'backbone_full_fp16.npz'), **fo)
+    print('wrote backbone_full_fp16.npz', {k: x.shape for k, x in fo.items()}, 'planes', v.shape, 'dtype', img.dtype, 'abs max', float(np.abs(v).max()))
+
+
 def main():
     sys.path.insert(0, REF)
     from training import networks_stylegan2 as N                     # the reference's file, untouched
@@ -78,4 +112,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    main_fp16() if sys.argv[1:] == ['fp16'] else main()

@@ -68,6 +68,27 @@ def test_small_generator_matches_reference_ref_ops(monkeypatch):
     _check(g, z)
 
 
+def check_full_size_generator_fp16(dev, tol=2e-2):
+    """The full-size generator with the reference's own fp16 path (num_fp16_res = 4, conv_clamp = 256: train.py:427-428, networks_stylegan2.py:423-431) on the
+    device against the unmodified reference's source run in the same dtypes (tests/golden/backbone_full_fp16.npz; oracle/make_golden_backbone.py fp16: fp16
+    convolutions on the host behind a device-type stand-in -- the reference forces fp32 off-GPU).  Eight fp16 layers round differently on the two sides (the
+    library's fp16 convolutions accumulate in fp32 and round once per layer, as the host's do, but in another order): 2e-2 of the planes' range."""
+    gold = np.load(os.path.join(GOLDEN, 'backbone_full_fp16.npz'))
+    g = dev(_seed(S.Generator(**dict(FULL, num_fp16_res=4, conv_clamp=256)))).eval()
+    z = torch.from_numpy(np.random.RandomState(5).standard_normal((1, FULL['z_dim'])).astype(np.float32))
+    with torch.no_grad():
+        ws = g.mapping(dev(z), None)
+        img = g.synthesis(ws, noise_mode='const')
+    assert img.dtype == torch.float32 and any(b.use_fp16 for b in g.synthesis.children() if hasattr(b, 'use_fp16'))
+    img = G.plain(img).numpy()
+    ref = gold['img_eval_const.sub']
+    err = np.abs(img[:, ::5, ::9, ::9] - ref).max() / np.abs(ref).max()
+    m = gold['img_eval_const.moments']
+    got = np.array([img.sum(dtype=np.float64), np.abs(img).sum(dtype=np.float64), np.square(img, dtype=np.float64).sum()])
+    assert np.isfinite(img).all() and err <= tol and np.all(np.abs(got[1:] - m[1:]) <= 2e-2 * np.abs(m[1:])), (err, got, m)
+    return err
+
+
 def check_full_size_generator(dev=lambda t: t, tol=2e-4):
     """The generator SHERF instantiates (256 x 256 x 96 planes, channel_base 32768, channel_max 512, 28.7 M parameters) RUN at full size, eval mode,
     against the unmodified reference's run of the same seeded generator (tests/golden/backbone_full.npz, oracle/make_golden_backbone.py)."""

@@ -32,6 +32,16 @@ def test_full_size_stylegan2_backbone_matches_reference_generator_on_device():
     print(f'full-size backbone on the device vs the reference generator: {err:.2e} of the planes\' range')
 
 
+def test_full_size_stylegan2_backbone_fp16_path_on_device():
+    """Round 6: the reference's own fp16 path of the tri-plane generator (num_fp16_res = 4, conv_clamp = 256) at full size on the MI355X
+    against the unmodified reference's source run in the same dtypes (tests/golden/backbone_full_fp16.npz)."""
+    from sherf_amd import stylegan2 as S
+    from tests import test_backbone as TB
+    assert S.OPS_IMPL != 'ref'
+    err = TB.check_full_size_generator_fp16(dev=lambda t: t.cuda())
+    print(f'full-size backbone, fp16 path, on the device vs the reference generator: {err:.2e} of the planes\' range')
+
+
 def test_stylegan2_gradients_through_the_hip_operators_on_device():
     """training-mode backward through the bias_act / upfirdn2d autograd nodes (HIP kernels, both derivative orders are exercised by
     tests/test_gpu_ops.py) equals the backward through the stock-PyTorch `ref` path."""

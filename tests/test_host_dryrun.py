@@ -71,7 +71,7 @@ def test_training_frame_descriptor_is_complete(stubbed):
     assert rgb.shape == (1, 1024, 3) and depth.shape == (1, 1024, 1) and acc.shape == (1, 1024, 1)
     fr = frames[-1]
     for name, ctype in fr._fields_:
-        if ctype is ctypes.c_void_p and name != 'zfrag':            # (zfrag: scratch of the opt-in two-launch network only)
+        if ctype is ctypes.c_void_p and name not in ('zfrag', 'pefrag'):   # (scratch of the opt-in two-launch network / encodings-in-gather forms only)
             assert getattr(fr, name), f'frame.{name} is NULL'
     assert (fr.R, fr.S, fr.capacity) == (1024, 16, 1024 * 16) and fr.vox_n == 6890 and fr.vox_training == 1
     assert (fr.P, fr.Hf, fr.Wf, fr.H, fr.W) == (32, 16, 16, 32, 32) and list(fr.vox_sh) == [int(v) for v in rend.last['bwd']['vox_sh']]
