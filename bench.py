@@ -103,7 +103,7 @@ def fixtures_variant_note(cfg):
 
 def _device(lrank):
     # SHERF_LOCAL_DEVICE (testing only): every rank on that device -- a multi-rank dry run of the whole script on a one-GPU box
-    # (tools/gpu_r4_ab.sh: 2 ranks x 4 caller streams with SHERF_DIST_BACKEND=gloo); never set by the driver
+    # (tools/history/gpu_r4_ab.sh: 2 ranks x 4 caller streams with SHERF_DIST_BACKEND=gloo); never set by the driver
     if os.environ.get('SHERF_LOCAL_DEVICE'):
         lrank = int(os.environ['SHERF_LOCAL_DEVICE'])
     torch.cuda.set_device(lrank)
