@@ -16,7 +16,10 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
          '-mcode-object-version=5']   # v5 loads on every ROCm >= 5 runtime (torch bundles its own libamdhip64)
 # per-source flags.  mlp.hip: no SLP vectorisation -- hipcc packs adjacent fp32 adds / muls of the epilogues into v_pk_*_f32, which
 # beside MFMAs cost more than the scalar pair they replace (MI355X_MICROARCH.md: +22..26 cycles each); measured 0.292 -> 0.288 ms
-EXTRA_FLAGS = {'mlp.hip': ['-fno-slp-vectorize']}
+# gather.hip (round 6): hipcc's SLP pass turns the fp16 taps' `acc += w * (float)v[i]` into 8 v_cvt_f32_f16 + 4 v_pk_fma_f32 per eight channels where 8 v_fma_mix_f32
+# do (and 110 -> 96 VGPRs): gather_tokens_h8_kernel 0.461 -> 0.401 ms, the frame 1.665 -> 1.609 ms, bit-identical (profiles/r06_call_j_*).  sample.hip: no
+# difference; svox.hip: the encoder chain 0.63 -> 0.65 ms -- both keep the default.
+EXTRA_FLAGS = {'mlp.hip': ['-fno-slp-vectorize'], 'gather.hip': ['-fno-slp-vectorize']}
 
 
 def _stale():

@@ -232,8 +232,10 @@ __device__ __forceinline__ int64_t banded_first_pair(int b, int g, int64_t n_pai
     return (int64_t)(b / 8) < per_xcd ? (int64_t)(b % 8) * per_xcd + b / 8 : n_pairs;
 }
 struct f8 { float4 a, b; };
-__device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__ base, size_t idx8) {
-    const h16x8 v = reinterpret_cast<const h16x8*>(base)[idx8];
+// (idx8: a 32-bit index of 16-byte units -- the tables of this kernel are far below 4 GiB (sherf_gather_tokens checks), and a uniform base + a 32-bit lane
+//  offset is ONE address instruction where a 64-bit index is a multiply-add pair per load: round 6, this kernel turned out to be bound by its VALU count)
+__device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__ base, uint32_t idx8) {
+    const h16x8 v = *reinterpret_cast<const h16x8*>(static_cast<const char*>(base) + (size_t)(idx8 * 16u));
     acc.a.x += w * (float)v[0]; acc.a.y += w * (float)v[1]; acc.a.z += w * (float)v[2]; acc.a.w += w * (float)v[3];
     acc.b.x += w * (float)v[4]; acc.b.y += w * (float)v[5]; acc.b.z += w * (float)v[6]; acc.b.w += w * (float)v[7];
 }
@@ -250,7 +252,12 @@ __device__ __forceinline__ void axpy8(f8& acc, float w, const void* __restrict__
 // bit-identical operands.  Lane l < 3 of a sample's quad evaluates axis l of the three vectors (15 sin / cos pairs instead of the 63 every lane
 // of the network kernel computes, twice for PE6), the quad transposes through 240 bytes of LDS per sample into 8-feature groups, lane l stores
 // groups l, l + 4, l + 8, l + 12.  224 bytes per sample more to write, ~180 VALU per 16 samples.
-template <bool STAGE, bool PE = false>
+// PF (round 6): the voxel rows of corner t + 1 are requested BEFORE corner t's 24 multiply-adds instead of after them.  The kernel's time is its chain of dependent
+// load -> wait -> use rounds (~50 per 16 samples: 24 voxel corners, 12 plane and 8 pixel corners, the look-ups), each a full L1 / L2 round trip that only the other
+// waves of the SIMD cover.  Absent corners are read at row 0 with weight 0 (exact: rows are finite, the buffers start zeroed) so that the loads carry no branch -- a
+// load inside `if (present)` is waited for on the spot (round 5's trap) -- and a scheduling barrier per corner keeps the compiler from hoisting all 24 requests at once
+// (round 5's unconditional variant: 176 registers, two waves per SIMD, slower).  Same sums in the same order: bit-identical tokens.
+template <bool STAGE, bool PE = false, bool PF = false>
 __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
                                                                const void* __restrict__ planes_f, int P, const void* __restrict__ feat_f,
                                                                int Hf, int Wf, const float4* __restrict__ img4, int H, int W, Levels lv,
@@ -317,7 +324,7 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
                     for (int dx = 0; dx < 2; ++dx) {
                         int xx = xi + dx, yy = yi + dy;
                         if (xx >= 0 && xx < P && yy >= 0 && yy < P)
-                            axpy8(acc[p], (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy), planes_f, ((size_t)(p * P + yy) * P + xx) * 4 + l);
+                            axpy8(acc[p], (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy), planes_f, (uint32_t)(((p * P + yy) * P + xx) * 4 + l));
                     }
             }
             if (!(dbg & 16) && mode != 2) {
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
                         int xx = xi + dx, yy = yi + dy;
                         if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
                             const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
-                            const size_t t = ((size_t)yy * Wf + xx) * 8;
+                            const uint32_t t = (uint32_t)((yy * Wf + xx) * 8);
                             axpy8(acc[0], w, feat_f, t + l);
                             axpy8(acc[1], w, feat_f, t + 4 + l);
                         }
@@ -392,16 +399,44 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
                     const uint32_t bit = 1u << (key & 31);
                     mine[u] = (inb && (rr.x & bit)) ? (int)(rr.y + __popc(rr.x & (bit - 1u))) : -1;
                 }
+                if constexpr (PF) {
+                    int rows8[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) rows8[t] = __shfl(mine[t & 1], quad0 | (t >> 1));
+                    h16x8 buf[2][3];
+                    const char* rb = reinterpret_cast<const char*>(lev.rows);
+                    auto request = [&](int t, h16x8 (&b)[3]) {
+                        const uint32_t r = ((uint32_t)max(rows8[t], 0) * 12u + l) * 16u;
+                        b[0] = *reinterpret_cast<const h16x8*>(rb + (size_t)r);
+                        b[1] = *reinterpret_cast<const h16x8*>(rb + (size_t)(r + 64u));
+                        b[2] = *reinterpret_cast<const h16x8*>(rb + (size_t)(r + 128u));
+                    };
+                    request(0, buf[0]);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (t < 7) request(t + 1, buf[(t + 1) & 1]);
+                        const float w0 = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
+                        const float w = rows8[t] >= 0 ? w0 : 0.f;
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) {
+                            const h16x8 v = buf[t & 1][s_];
+                            acc[s_].a.x += w * (float)v[0]; acc[s_].a.y += w * (float)v[1]; acc[s_].a.z += w * (float)v[2]; acc[s_].a.w += w * (float)v[3];
+                            acc[s_].b.x += w * (float)v[4]; acc[s_].b.y += w * (float)v[5]; acc[s_].b.z += w * (float)v[6]; acc[s_].b.w += w * (float)v[7];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int row = __shfl(mine[t & 1], quad0 | (t >> 1));
                     if (row >= 0) {
                         const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
-                        const size_t r = (size_t)row * 12;
+                        const uint32_t r = (uint32_t)row * 12u;
                         axpy8(acc[0], w, lev.rows, r + l);
                         axpy8(acc[1], w, lev.rows, r + 4 + l);
                         axpy8(acc[2], w, lev.rows, r + 8 + l);
                     }
+                }
                 }
             }
         }
@@ -1167,6 +1202,8 @@ static int gather_tokens_impl(const int32_t* counters, const float* geom, const 
                        counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,         \
                        reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds,       \
                        vox_min, sh, capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode)
+    // the eight-channel kernel indexes its fp16 tables with 32-bit offsets of 16-byte units
+    SHERF_CHECK_ARG(!half_tables || ((int64_t)3 * P * P * 64 < ((int64_t)1 << 32) && (int64_t)Hf * Wf * 128 < ((int64_t)1 << 32)));
     // the encodings as fragments (sherf_gather_tokens_pe): the eight-channel kernel's pass that visits every sample once (mode 0 or 1)
     SHERF_CHECK_ARG(!pefrag || (half_tables && !branchless && mode != 2));
     if (pefrag) {
@@ -1189,6 +1226,12 @@ static int gather_tokens_impl(const int32_t* counters, const float* geom, const 
                                reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
                                capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, static_cast<uint4*>(nullptr));
         } else
+        if (g_sherf_debug & (1 << 21))          // (debug bit 21: the voxel rows of the next corner requested ahead -- gather_tokens_h8_kernel<.., PF = true>; A/B runs)
+        hipLaunchKernelGGL((gather_tokens_h8_kernel<false, false, true>), dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
+                           counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
+                           reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
+                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, static_cast<uint4*>(nullptr));
+        else
         hipLaunchKernelGGL(gather_tokens_h8_kernel<false>, dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
                            counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                            reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,

@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--opts', default='')
     ap.add_argument('--exps', default='', help='one SHERF_EXPERIMENT word per arm (launch order / stream placement experiments: csrc/common.h)')
     ap.add_argument('--timeline', action='store_true', help='print the HIP-event timeline of every arm (bench.frame_timeline)')
+    ap.add_argument('--dump', default='', help='save the first arm\'s rendered frame (rgb, depth, acc) to this file: frames of different LIBRARIES (SHERF_HIP_LIB, one process each) compared afterwards')
     ap.add_argument('--rounds', type=int, default=4)
     ap.add_argument('--iters', type=int, default=20)
     a = ap.parse_args()
@@ -84,6 +85,8 @@ def main():
         if ref is None:
             ref = outs[n]
         print(f'[bits] {n}: identical to {names[0]}: {all(torch.equal(p, q) for p, q in zip(outs[n], ref))}')
+    if a.dump:
+        torch.save([t.cpu() for t in ref], a.dump)
     for _ in range(30):
         bench.render_frame(w)
     times = {n: [] for n in names}

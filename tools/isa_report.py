@@ -38,7 +38,7 @@ def main():
         path = os.path.join(B.CSRC, src)
         if not os.path.exists(path):
             continue
-        r = subprocess.run([hipcc] + B.FLAGS + ['-I' + os.path.join(ROOT, 'include'), '-c', path, '-save-temps=obj', '-o', os.path.join(tmp, src + '.o')],
+        r = subprocess.run([hipcc] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ['-I' + os.path.join(ROOT, 'include'), '-c', path, '-save-temps=obj', '-o', os.path.join(tmp, src + '.o')],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmp)
         asm = os.path.join(tmp, src.replace('.hip', '') + '-hip-amdgcn-amd-amdhsa-gfx950.s')
         if r.returncode != 0 or not os.path.exists(asm):
