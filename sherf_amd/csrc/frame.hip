@@ -274,9 +274,9 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
         const bool split_form = f->zfrag && (((f->flags & SHERF_FRAME_MLP_SPLIT) != 0) != ((g_sherf_debug & 8192) != 0));
         // SHERF_FRAME_PE_FRAGS (round 6): the gather writes the positional encodings as fp16 operand fragments and the pipelined single-fp16-product
         // network reads them (sherf_gather_tokens_pe -> sherf_nerf_mlp3_pe; bit-identical frames).  Only in the configuration it is built for: fp16
-        // tables in the eight-channel gather, one pass, one part, the pipelined form; anything else renders as before.  (debug bit 23 turns it off: A/B runs)
+        // tables in the eight-channel gather, one pass, one part, the pipelined form; anything else renders as before.
         const bool pe_frags = (f->flags & SHERF_FRAME_PE_FRAGS) && f->pefrag && half_tables && (f->mlp_prec & 255) == 2 && (f->flags & SHERF_FRAME_MLP_PIPELINED) &&
-                              !(g_sherf_debug & (1 << 25)) && !split_form && nparts <= 1 && !(f->gather_split & 7) && !(g_sherf_debug & (2048 | (1 << 29) | (1 << 23)));
+                              !(g_sherf_debug & (1 << 25)) && !split_form && nparts <= 1 && !(f->gather_split & 7) && !(g_sherf_debug & (2048 | (1 << 29)));
         if (nparts > 1 && !(f->gather_split & 1) && !split_form) {
             SHERF_PROF(3, main);
             SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_enc, 0));

@@ -1226,7 +1226,7 @@ static int gather_tokens_impl(const int32_t* counters, const float* geom, const 
                                reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
                                capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, static_cast<uint4*>(nullptr));
         } else
-        if (g_sherf_debug & (1 << 21))          // (debug bit 21: the voxel rows of the next corner requested ahead -- gather_tokens_h8_kernel<.., PF = true>; A/B runs)
+        if (!(sherf_experiment() & 512))        // the voxel rows of the next corner requested ahead (PF; measured -2.8 % of this kernel, -1 % of the frame, bit-identical: profiles/r06_call_k_*).  SHERF_EXPERIMENT bit 9: round 5's one-corner-at-a-time loop (A/B runs)
         hipLaunchKernelGGL((gather_tokens_h8_kernel<false, false, true>), dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
                            counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                            reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
