@@ -506,6 +506,167 @@ __global__ void __launch_bounds__(256) gather_tokens_h8_kernel(const int32_t* __
     }
 }
 
+// SIXTEEN channels per lane (round 6): two lanes own a sample, a wave covers one whole 32-sample tile.  Why: once its taps ran on v_fma_mix (no SLP: sherf_amd/build.py)
+// the eight-channel kernel turned out to be bound by its VALU count as much as by its gathers -- ~1 750 instructions per 16 samples of which only 736 are the taps'
+// multiply-adds; the rest (a sample's normalised coordinates, three planes' and three levels' stencils: floors, fractions, 56 corner weights, occupancy look-ups,
+// eleven IEEE divisions) is the SAME for every lane of a sample and was computed by all four.  With two lanes per sample that arithmetic is done half as often per
+// sample; a lane takes 32 contiguous bytes of a row's slot (two 16-byte loads), the same number of load instructions per sample.  Same taps, same weights, same order
+// of accumulation per channel: bit-identical tokens / extras.  One pass over every tap (mode 0); the split / part / staged / encodings forms stay on the
+// eight-channel kernel.
+__global__ void __launch_bounds__(256, 4) gather_tokens_h16_kernel(const int32_t* __restrict__ counters, const float* __restrict__ geom,
+                                                                const void* __restrict__ planes_f, int P, const void* __restrict__ feat_f,
+                                                                int Hf, int Wf, const float4* __restrict__ img4, int H, int W, Levels lv,
+                                                                const float4* __restrict__ tok_bias, const float* __restrict__ bounds,
+                                                                const float* __restrict__ vox_min, int3 vox_sh, int64_t capacity,
+                                                                float4* __restrict__ tokens, float* __restrict__ extras, int dbg) {
+    const int64_t nv = min((int64_t)counters[0], capacity);
+    const int64_t n_tiles = (nv + 31) / 32, n_groups = (n_tiles + 3) / 4;       // a workgroup step = four tiles = 128 samples
+    const int l = threadIdx.x & 1;                  // half of a slot's 32 channels: octets 2l, 2l + 1 (quads 4l .. 4l + 3)
+    const int js = threadIdx.x >> 1;                // sample within the group of four tiles (0..127): a wave = one tile
+    const bool banded = !(dbg & 1024) && gridDim.x % 8 == 0;                    // XCD-banded order, as in gather_tokens_h8_kernel
+    const int64_t per_xcd = (n_groups + 7) / 8, slots = gridDim.x / 8;
+    for (int64_t it = banded ? blockIdx.x / 8 : blockIdx.x; it < (banded ? per_xcd : n_groups); it += banded ? slots : gridDim.x) {
+        const int64_t group = banded ? (int64_t)(blockIdx.x % 8) * per_xcd + it : it;
+        if (group >= n_groups) break;
+        const int64_t tile = group * 4 + (js >> 5);
+        const int j = js & 31;
+        if (tile >= n_tiles) continue;
+        const int64_t c = tile * 32 + j;
+        f8 acc[3][2];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) { acc[s_][o].a = tok_bias[8 * s_ + 2 * (2 * l + o)]; acc[s_][o].b = tok_bias[8 * s_ + 2 * (2 * l + o) + 1]; }
+        float4 rgb = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool valid = c < nv;
+        float xv[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            const float* gm = geom + c * 8;
+            const float xc[3] = {gm[0], gm[1], gm[2]};
+            xv[0] = xc[0]; xv[1] = xc[1]; xv[2] = xc[2];
+            if (l == 0) {                                                         // extras rows 0-5 = x_c, v_c
+#pragma unroll
+                for (int r = 0; r < 6; ++r) extras[(tile * 12 + r) * 32 + j] = gm[r];
+            }
+            float n[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) n[a] = 2.f * (xc[a] - bounds[a]) / (bounds[3 + a] - bounds[a]) - 1.f;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (dbg & 8) break;
+                const float ga = p == 2 ? n[2] : n[0];
+                const float gb = p == 1 ? n[2] : n[1];
+                float px = clampf(((ga + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+                float py = clampf(((gb + 1.f) * P - 1.f) * 0.5f, -2.f, (float)P + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < P && yy >= 0 && yy < P) {
+                            const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            const uint32_t t = (uint32_t)(((p * P + yy) * P + xx) * 4 + 2 * l);
+                            axpy8(acc[p][0], w, planes_f, t);
+                            axpy8(acc[p][1], w, planes_f, t + 1);
+                        }
+                    }
+            }
+            if (!(dbg & 16)) {
+                float gx = 2.0f * gm[6] / (float)W - 1.0f, gy = 2.0f * gm[7] / (float)H - 1.0f;
+                float px = clampf((gx + 1.f) * 0.5f * (Wf - 1), -2.f, (float)Wf + 1.f);
+                float py = clampf((gy + 1.f) * 0.5f * (Hf - 1), -2.f, (float)Hf + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), fx = px - x0, fy = py - y0;
+                int xi = (int)x0, yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < Wf && yy >= 0 && yy < Hf) {
+                            const float w = (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy);
+                            const uint32_t t = (uint32_t)((yy * Wf + xx) * 8 + 2 * l);
+                            axpy8(acc[0][0], w, feat_f, t);
+                            axpy8(acc[0][1], w, feat_f, t + 1);
+                            axpy8(acc[1][0], w, feat_f, t + 4);
+                            axpy8(acc[1][1], w, feat_f, t + 5);
+                        }
+                    }
+                px = clampf((gx + 1.f) * 0.5f * (W - 1), -2.f, (float)W + 1.f);
+                py = clampf((gy + 1.f) * 0.5f * (H - 1), -2.f, (float)H + 1.f);
+                x0 = floorf(px); y0 = floorf(py); fx = px - x0; fy = py - y0;
+                xi = (int)x0; yi = (int)y0;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        int xx = xi + dx, yy = yi + dy;
+                        if (xx >= 0 && xx < W && yy >= 0 && yy < H) axpy4(rgb, (dx ? fx : 1.f - fx) * (dy ? fy : 1.f - fy), img4[(size_t)yy * W + xx]);
+                    }
+            }
+            if (l == 1) {                                                         // rows 6-8 = tapped rgb, 9-11 = 0
+                extras[(tile * 12 + 6) * 32 + j] = rgb.x; extras[(tile * 12 + 7) * 32 + j] = rgb.y; extras[(tile * 12 + 8) * 32 + j] = rgb.z;
+#pragma unroll
+                for (int r = 9; r < 12; ++r) extras[(tile * 12 + r) * 32 + j] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) acc[s_][0].a = acc[s_][0].b = acc[s_][1].a = acc[s_][1].b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) extras[(tile * 12 + 6 * l + r) * 32 + j] = 0.f;     // padding columns of the last tile
+        }
+        // voxel taps: lane l makes FOUR of a level's eight corner look-ups (corners 4l .. 4l + 3 = the z-plane zi + l) and the pair exchanges the results
+        if (!(dbg & 4)) {
+            const float gz = ((xv[2] - vox_min[2]) / 0.005f) / (float)vox_sh.x * 2.f - 1.f;
+            const float gy = ((xv[1] - vox_min[1]) / 0.005f) / (float)vox_sh.y * 2.f - 1.f;
+            const float gx = ((xv[0] - vox_min[0]) / 0.005f) / (float)vox_sh.z * 2.f - 1.f;
+            const int pair0 = (threadIdx.x & 63) & ~1;
+#pragma unroll 1
+            for (int L = 0; L < 3; ++L) {
+                const sherf_vox_level& lev = lv.l[L];
+                float px = clampf((gx + 1.f) * 0.5f * (lev.W - 1), -2.f, (float)lev.W + 1.f);
+                float py = clampf((gy + 1.f) * 0.5f * (lev.H - 1), -2.f, (float)lev.H + 1.f);
+                float pz = clampf((gz + 1.f) * 0.5f * (lev.D - 1), -2.f, (float)lev.D + 1.f);
+                float x0 = floorf(px), y0 = floorf(py), z0 = floorf(pz);
+                float fx = px - x0, fy = py - y0, fz = pz - z0;
+                int xi = (int)x0, yi = (int)y0, zi = (int)z0;
+                int mine[4];                               // corner 4l + u: row index, or -1 if the voxel is absent
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int xx = xi + (u & 1), yy = yi + (u >> 1), zz = zi + l;
+                    const bool inb = valid && xx >= 0 && xx < lev.W && yy >= 0 && yy < lev.H && zz >= 0 && zz < lev.D;
+                    const int key = inb ? (zz * lev.H + yy) * lev.W + xx : 0;
+                    const uint2 rr = reinterpret_cast<const uint2*>(lev.wp)[key >> 5];
+                    const uint32_t bit = 1u << (key & 31);
+                    mine[u] = (inb && (rr.x & bit)) ? (int)(rr.y + __popc(rr.x & (bit - 1u))) : -1;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = __shfl(mine[t & 3], pair0 | (t >> 2));
+                    if (row >= 0) {
+                        const float w = ((t & 1) ? fx : 1.f - fx) * (((t >> 1) & 1) ? fy : 1.f - fy) * ((t >> 2) ? fz : 1.f - fz);
+                        const uint32_t r = (uint32_t)row * 12u + 2u * l;
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) {
+                            axpy8(acc[s_][0], w, lev.rows, r + 4 * s_);
+                            axpy8(acc[s_][1], w, lev.rows, r + 4 * s_ + 1);
+                        }
+                    }
+                }
+            }
+        }
+        // tokens[tile][slot][quad][j] (float4): this lane owns quads 4l .. 4l + 3 of every slot
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                tokens[((tile * 3 + s_) * 8 + 4 * l + 2 * o) * 32 + j] = acc[s_][o].a;
+                tokens[((tile * 3 + s_) * 8 + 4 * l + 2 * o + 1) * 32 + j] = acc[s_][o].b;
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Backward of the gather (BASELINE config 5; oracle/backward_explicit.py: folded_taps_bwd, step (i)): every tap is linear
 // in its table, so d_tokens is scattered with the forward's tap weights into the gradients of the FOLDED tables
@@ -1226,7 +1387,12 @@ static int gather_tokens_impl(const int32_t* counters, const float* geom, const 
                                reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
                                capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug, kmode, static_cast<uint4*>(nullptr));
         } else
-        if (!(sherf_experiment() & 512))        // the voxel rows of the next corner requested ahead (PF; measured -2.8 % of this kernel, -1 % of the frame, bit-identical: profiles/r06_call_k_*).  SHERF_EXPERIMENT bit 9: round 5's one-corner-at-a-time loop (A/B runs)
+        if (mode == 0 && nparts <= 1 && !(sherf_experiment() & 1024))      // two lanes per sample (round 6; SHERF_EXPERIMENT bit 10: the eight-channel kernel -- A/B runs)
+        hipLaunchKernelGGL(gather_tokens_h16_kernel, dim3((unsigned)((tiles + 3) / 4 < 16384 ? ((tiles + 3) / 4 + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
+                           counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
+                           reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,
+                           capacity, reinterpret_cast<float4*>(tokens), extras, g_sherf_debug);
+        else if (!(sherf_experiment() & 512))        // the voxel rows of the next corner requested ahead (PF; measured -2.8 % of this kernel, -1 % of the frame, bit-identical: profiles/r06_call_k_*).  SHERF_EXPERIMENT bit 9: round 5's one-corner-at-a-time loop (A/B runs)
         hipLaunchKernelGGL((gather_tokens_h8_kernel<false, false, true>), dim3((unsigned)(pairs < 16384 ? (pairs + 7) / 8 * 8 : 16384)), dim3(256), 0, as_stream(stream),
                            counters, geom, static_cast<const void*>(planes_f), P, static_cast<const void*>(feat_f), Hf, Wf,
                            reinterpret_cast<const float4*>(img4), H, W, lv, reinterpret_cast<const float4*>(tok_bias), bounds, vox_min, sh,

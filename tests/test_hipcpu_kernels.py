@@ -573,12 +573,15 @@ def test_gather_kernels_on_cpu(fwd_lib, frame):
     tok_h = tokens_h.view(tiles, 3, 8, 32, 4).permute(0, 3, 1, 2, 4).reshape(tiles * 32, 3, 32)[:n]
     assert 1e-6 < rel(tok_h, tok) < 1e-3 and torch.equal(extras_h, extras)
     # round 6: the voxel rows of the next corner requested ahead (the default; absent corners read row 0 with weight 0) and round 5's loop (SHERF_EXPERIMENT bit 9): the same bits
-    os.environ['SHERF_EXPERIMENT'] = '512'
-    tokens_pf, extras_pf = torch.zeros(tiles * 3072), torch.zeros(tiles * 384)
-    assert fwd_lib.sherf_gather_tokens(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels_h, _P(tok_bias), _P(bounds),
-                                       _P(vox_min), vox_sh, 16, n, _P(tokens_pf), _P(extras_pf), None) == 0
-    os.environ['SHERF_EXPERIMENT'] = '0'
-    assert torch.equal(tokens_pf, tokens_h) and torch.equal(extras_pf, extras_h)
+    # (the default on fp16 tables is round 6's sixteen-channel kernel -- two lanes per sample; SHERF_EXPERIMENT bit 10: the eight-channel kernel with the next
+    #  corner's rows requested ahead; bits 10 + 9: round 5's eight-channel loop)
+    for word in ('1024', '1536'):
+        os.environ['SHERF_EXPERIMENT'] = word
+        tokens_pf, extras_pf = torch.full((tiles * 3072,), float('nan')), torch.full((tiles * 384,), float('nan'))
+        assert fwd_lib.sherf_gather_tokens(_P(counters), _P(geom), _P(planes_h), P, _P(feat_h), Hf, Wf, _P(img4), H, W, levels_h, _P(tok_bias), _P(bounds),
+                                           _P(vox_min), vox_sh, 16, n, _P(tokens_pf), _P(extras_pf), None) == 0
+        os.environ['SHERF_EXPERIMENT'] = '0'
+        assert torch.equal(tokens_pf, tokens_h) and torch.equal(extras_pf, extras_h), word
     # ---- backward: scatter of d_tokens ----
     dt = g['stage.tokens_in']
     pad = torch.zeros(tiles * 32, 96); pad[:n] = dt.reshape(n, 96)
