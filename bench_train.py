@@ -151,7 +151,8 @@ def main():
         if scat_ms and n_valid:
             ach = bytes_per_sample * n_valid / (scat_ms * 1e-3) / 1e9
             traffic = None
-            if world == 1 and not a.no_pmc:
+            under_profiler = any(k.startswith(('ROCPROF', 'ROCP_TOOL')) for k in os.environ)      # (never a counter pass inside somebody else's rocprofv3 run)
+            if world == 1 and not a.no_pmc and not under_profiler:
                 t = bench.pmc_traffic(a, lrank, timeout=240, child=[sys.executable, os.path.abspath(__file__), '--pmc-child', '--config', a.config],
                                       keys=('gather_tokens_bwd_runs_kernel',))
                 traffic = t.get('hbm_bytes_per_launch') if isinstance(t, dict) and 'error' not in t else t

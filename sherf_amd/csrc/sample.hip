@@ -843,6 +843,62 @@ __global__ void __launch_bounds__(256) compact_kernel(const float* __restrict__ 
     }
 }
 
+// The same compaction with ONE LANE per ray for the part every ray takes (its base offset, its mask words) and a whole wave only for the rays that hold valid
+// samples (round 6).  compact_kernel above gives every ray a wave: 262 144 waves at 512 x 512 of which three quarters read eight bytes and leave -- the launch is bound
+// by creating them (77 us).  Here a wave takes 64 consecutive rays; the hit rays are walked one after the other by all 64 lanes (lane = sample of the chunk), their ray
+// data fetched through uniform addresses.  Same records at the same positions: bit-identical cs_idx / cs_vid / cs_xs / ray_base.
+template <int NCH>
+__global__ void __launch_bounds__(256) compact_rays_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                           const float* __restrict__ near, const float* __restrict__ far,
+                                                           int R, int S, const float* __restrict__ Rg, const float* __restrict__ Th,
+                                                           const int32_t* __restrict__ ray_base_local,
+                                                           const int32_t* __restrict__ chunk_off, const uint64_t* __restrict__ ray_mask,
+                                                           const int32_t* __restrict__ dense_vid, int64_t capacity,
+                                                           int32_t* __restrict__ ray_base, int32_t* __restrict__ cs_idx,
+                                                           int32_t* __restrict__ cs_vid, float4* __restrict__ cs_xs) {
+    const int lane = threadIdx.x & 63;
+    const int ray0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;              // this wave's 64 rays
+    if (ray0 >= R) return;
+    const int my = ray0 + lane;
+    int my_base = 0;
+    uint64_t my_any = 0;
+    if (my < R) {
+        my_base = ray_base_local[my] + chunk_off[my >> 10];
+        ray_base[my] = my_base;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) my_any |= ray_mask[(size_t)my * NCH + ch];
+    }
+    uint64_t hits = __ballot(my_any != 0);
+    while (hits) {
+        const int rl = __ffsll((unsigned long long)hits) - 1;
+        hits &= hits - 1;
+        const int ray = ray0 + rl;
+        int base = __shfl(my_base, rl);
+        const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
+        const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
+        const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const uint64_t m = ray_mask[(size_t)ray * NCH + ch];
+            const int k = ch * 64 + lane;
+            if ((m >> lane) & 1ull) {
+                const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                const int64_t c = (int64_t)base + rank;
+                if (c < capacity) {
+                    const float t = depth_at(nr, range, k, S);
+                    const float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
+                    float xs, ys, zs;
+                    to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+                    cs_idx[c] = ray * S + k;
+                    cs_vid[c] = dense_vid[(size_t)ray * S + k];
+                    cs_xs[c] = make_float4(xs, ys, zs, 0.f);
+                }
+            }
+            base += __popcll(m);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-sample warp: canonical point/direction, exact nearest T-pose vertex, pixel in the observation view
 // ---------------------------------------------------------------------------------------------
@@ -1002,8 +1058,17 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     hipLaunchKernelGGL(compact_kernel<N>, dim3(cdiv(R, 4)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,   \
                        base_local, chunk_sum, ray_mask, dense_vid, capacity, ray_base, cs_idx, cs_vid,                 \
                        reinterpret_cast<float4*>(cs_xs), cp)
+#define SHERF_COMPACT_RAYS_LAUNCH(N)                                                                                   \
+    hipLaunchKernelGGL(compact_rays_kernel<N>, dim3(cdiv(R, 256)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
+                       base_local, chunk_sum, ray_mask, dense_vid, capacity, ray_base, cs_idx, cs_vid,                 \
+                       reinterpret_cast<float4*>(cs_xs))
+    if (!(sherf_experiment() & 2048)) {         // one lane per ray, whole waves for the hit rays only (round 6).  SHERF_EXPERIMENT bit 11: one wave per ray (A/B runs)
+        if (nch == 1) SHERF_COMPACT_RAYS_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_RAYS_LAUNCH(2);
+        else if (nch == 3) SHERF_COMPACT_RAYS_LAUNCH(3); else SHERF_COMPACT_RAYS_LAUNCH(4);
+    } else {
     if (nch == 1) SHERF_COMPACT_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_LAUNCH(2);
     else if (nch == 3) SHERF_COMPACT_LAUNCH(3); else SHERF_COMPACT_LAUNCH(4);
+    }
     SHERF_LAUNCH_CHECK();
 }
 

@@ -96,8 +96,12 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     assert int(near_hdr[2 * NSUB]) == int(((hq[:nsub, 1] + 3) // 4 * 4).sum())
     import ctypes as _ct
     dbg = _ct.c_int.in_dll(lib, 'g_sherf_debug')
-    for S, flag, lists in ((80, 0, True), (80, 0, False), (80, 512, False), (40, 0, True), (150, 0, True), (150, 0, False), (150, 512, False)):
+    import os as _os
+    # (xp: SHERF_EXPERIMENT -- 2048 = the compaction with one wave per ray, rounds 3-5; default: one lane per ray + whole waves for the hit rays, round 6)
+    for S, flag, lists, xp in ((80, 0, True, '0'), (80, 0, True, '2048'), (80, 0, False, '0'), (80, 512, False, '0'), (40, 0, True, '0'), (40, 0, True, '2048'),
+                               (150, 0, True, '0'), (150, 0, True, '2048'), (150, 0, False, '0'), (150, 512, False, '0')):
         dbg.value = flag
+        _os.environ['SHERF_EXPERIMENT'] = xp
         R = 96
         o = rs.uniform(-0.1, 0.1, size=(R, 3)).astype(np.float32); o[:, 2] -= 1.0
         tgt = rs.uniform(-0.3, 0.3, size=(R, 3)).astype(np.float32)
@@ -129,11 +133,13 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
         assert np.array_equal(cs_idx[:nv].numpy(), valid) and np.array_equal(cs_vid[:nv].numpy(), vid[valid])
         assert np.array_equal(cs_xs[:nv, :3].numpy(), x[valid])
         assert np.array_equal(ray_cnt.numpy(), np.bincount(valid // S, minlength=R))
+        assert np.array_equal(ray_base.numpy(), np.concatenate([[0], np.cumsum(np.bincount(valid // S, minlength=R))[:-1]]))
         # some ball really holds more points than one 32-point step of a group
         assert ((d2[valid] < np.float32(0.0025)).sum(1) > 32).any()
 
 
     dbg.value = 0
+    _os.environ['SHERF_EXPERIMENT'] = '0'
 
     # ---- the warp's T-vertex search on the same grid (grid 1 of the pair): near and far same-index vertices ----
     nq = 400
