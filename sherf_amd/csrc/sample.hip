@@ -844,9 +844,10 @@ __global__ void __launch_bounds__(256) compact_kernel(const float* __restrict__ 
 }
 
 // The same compaction with ONE LANE per ray for the part every ray takes (its base offset, its mask words) and a whole wave only for the rays that hold valid
-// samples (round 6).  compact_kernel above gives every ray a wave: 262 144 waves at 512 x 512 of which three quarters read eight bytes and leave -- the launch is bound
-// by creating them (77 us).  Here a wave takes 64 consecutive rays; the hit rays are walked one after the other by all 64 lanes (lane = sample of the chunk), their ray
-// data fetched through uniform addresses.  Same records at the same positions: bit-identical cs_idx / cs_vid / cs_xs / ray_base.
+// samples (round 6 experiment, SHERF_EXPERIMENT bit 11).  The idea: compact_kernel above gives every ray a wave -- 262 144 waves at 512 x 512 of which three
+// quarters read eight bytes and leave.  Here a wave takes 64 consecutive rays and walks its hit rays one after the other with all 64 lanes.  Same records at the same
+// positions (bit-identical cs_idx / cs_vid / cs_xs / ray_base) -- and SLOWER on the MI355X (96 vs 77 us): the 262 144 short waves were never the cost, and ~16 hit rays
+// per wave in sequence put ~16 dependent round trips where the wave-per-ray kernel has one.  Kept as the measured counter-example.
 template <int NCH>
 __global__ void __launch_bounds__(256) compact_rays_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                            const float* __restrict__ near, const float* __restrict__ far,
@@ -1062,7 +1063,7 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     hipLaunchKernelGGL(compact_rays_kernel<N>, dim3(cdiv(R, 256)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
                        base_local, chunk_sum, ray_mask, dense_vid, capacity, ray_base, cs_idx, cs_vid,                 \
                        reinterpret_cast<float4*>(cs_xs))
-    if (!(sherf_experiment() & 2048)) {         // one lane per ray, whole waves for the hit rays only (round 6).  SHERF_EXPERIMENT bit 11: one wave per ray (A/B runs)
+    if (sherf_experiment() & 2048) {            // SHERF_EXPERIMENT bit 11: one lane per ray, whole waves for the hit rays only (round 6; MEASURED SLOWER: 96 vs 77 us, frame 1.615 vs 1.597 ms -- the hit rays of a wave are walked one after the other, each behind its own round trips; profiles/r06_call_m_*)
         if (nch == 1) SHERF_COMPACT_RAYS_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_RAYS_LAUNCH(2);
         else if (nch == 3) SHERF_COMPACT_RAYS_LAUNCH(3); else SHERF_COMPACT_RAYS_LAUNCH(4);
     } else {

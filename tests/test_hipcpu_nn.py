@@ -97,7 +97,7 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     import ctypes as _ct
     dbg = _ct.c_int.in_dll(lib, 'g_sherf_debug')
     import os as _os
-    # (xp: SHERF_EXPERIMENT -- 2048 = the compaction with one wave per ray, rounds 3-5; default: one lane per ray + whole waves for the hit rays, round 6)
+    # (xp: SHERF_EXPERIMENT -- 2048 = round 6's experimental compaction with one lane per ray + whole waves for the hit rays; default: one wave per ray)
     for S, flag, lists, xp in ((80, 0, True, '0'), (80, 0, True, '2048'), (80, 0, False, '0'), (80, 512, False, '0'), (40, 0, True, '0'), (40, 0, True, '2048'),
                                (150, 0, True, '0'), (150, 0, True, '2048'), (150, 0, False, '0'), (150, 512, False, '0')):
         dbg.value = flag
