@@ -56,6 +56,10 @@ def _use_host_build():
     AR.ImportanceRenderer.SMPL_NEUTRAL = property(lambda self: self._smpl(torch.device('cpu')))
     globals()['_device'] = lambda lrank: torch.device('cpu')
     os.environ.setdefault('SHERF_DIST_BACKEND', 'gloo')
+    if os.environ.get('SHERF_HIPCPU_LIB_BWD'):            # (bench_train.py on the host build: the backward library too)
+        from sherf_amd import backward_dense
+        _lib.LIB_BWD_PATH, _lib._lib_bwd = os.environ['SHERF_HIPCPU_LIB_BWD'], None
+        backward_dense.HipOps._p = staticmethod(lambda m: ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off))
 
 
 def launch_ranks(n, script=None, argv=None):

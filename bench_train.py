@@ -38,10 +38,28 @@ def main():
         sys.exit(bench.launch_ranks(a.gpus, script=__file__))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); lrank = int(os.environ.get('LOCAL_RANK', 0))
     bench.check_world(a.gpus, world, 'bench_train.py')
-    torch.cuda.set_device(lrank)
-    dev = torch.device('cuda', lrank)
+    host_build = bool(os.environ.get('SHERF_HIPCPU_LIB'))            # TEST INFRASTRUCTURE (tests/test_dist_cpu.py): the script's plumbing on CPU tensors over gloo
+    if host_build:
+        bench._use_host_build()
+        a.no_pmc = True
+    dev = bench._device(lrank)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('SHERF_DIST_BACKEND', 'nccl')        # 'nccl' = RCCL; 'gloo' only for the CPU dry run in tests/
+        torch.distributed.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+
+    class _Ev:                                                        # a point on the stream: a HIP event; wall clock on the host build (launches are synchronous there)
+        def __init__(self, enable_timing=True):
+            self.e = None if host_build else torch.cuda.Event(enable_timing=True)
+            self.t = 0.0
+
+        def record(self):
+            if self.e is not None:
+                self.e.record()
+            else:
+                self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return self.e.elapsed_time(other.e) if self.e is not None else 1e3 * (other.t - self.t)
     from synthdata import fixtures, synth                    # seeded synthetic inputs (not the oracle)
     from sherf_amd import dist as sdist
     from sherf_amd.renderer import ImportanceRenderer
@@ -65,6 +83,19 @@ def main():
     ro, rd, nr, fr = d['ray_o_all'][:, 0], d['ray_d_all'][:, 0], d['near_all'][:, 0], d['far_all'][:, 0]
     opts = dict(fx['options'])
     R = ro.shape[1]
+    # training_loop.py:231-236: rank 0's weights go to every rank before the first step.  (Ranks other than 0 are perturbed first, so that the broadcast is what
+    # makes them equal: `dist.params_equal_after_broadcast` in the JSON line -- every rank's checksum of its parameters and buffers, compared on rank 0.)
+    dist_info = None
+    if world > 1:
+        if rank != 0:
+            with torch.no_grad():
+                for p_ in list(rend.parameters()) + list(dec.parameters()):
+                    p_.mul_(1.0 + 1e-3 * rank)
+        n_sent = sdist.broadcast_params([rend, dec])
+        cs = torch.stack([t_.detach().double().sum() for t_ in list(rend.parameters()) + list(rend.buffers()) + list(dec.parameters())]).sum().reshape(1).to(dev)
+        allcs = [torch.empty_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(allcs, cs)
+        dist_info = dict(broadcast_tensors=n_sent, params_equal_after_broadcast=bool(all(float(c) == float(allcs[0]) for c in allcs)))
     params = [p for p in list(rend.parameters()) + list(dec.parameters())]
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.0, 0.99), eps=1e-8)          # train.py: G_opt_kwargs
     g = torch.Generator(device='cpu').manual_seed(11 + rank)
@@ -87,7 +118,7 @@ def main():
     def timed_call(name, *args):
         if name != 'sherf_gather_tokens_bwd_binned':
             return call0(name, *args)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _Ev(), _Ev()
         e0.record(); call0(name, *args); e1.record()
         scatter_ev.append((e0, e1))
     _lib.call = timed_call
@@ -97,7 +128,7 @@ def main():
     host_t = []
 
     def step():                                             # the same step with three more events on the stream
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev = [_Ev() for _ in range(4)]
         opt.zero_grad(set_to_none=True)
         h0 = time.perf_counter()
         ev[0].record()
@@ -168,7 +199,7 @@ def main():
                               scaling='weak', vs_baseline=None, dtype='f32 (backward: fp32 kernels, MFMA GEMMs on a three-part bf16 split, MFMA sparse-conv input gradient on a range-scaled fp16 split; forward: f16x3 MFMA)',
                               data='synthetic', final_loss=float(loss), phases_ms=phases,
                               host_ms=dict(zip(('forward', 'backward', 'allreduce_adam'), (1e3 * np.mean(host_t, 0)).tolist())), roofline=roofline,
-                              config=dict(workload=f'{a.config}: one view per GPU, stub loss MSE(rgb)+MSE(acc)', rays=R))))
+                              dist=dist_info, config=dict(workload=f'{a.config}: one view per GPU, stub loss MSE(rgb)+MSE(acc)', rays=R))))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

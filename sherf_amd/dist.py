@@ -104,6 +104,22 @@ def gather_views(local_frames, n_views, frame_shape=None, dtype=torch.float32, d
     return [out[v % w][v // w] for v in range(n_views)]
 
 
+def broadcast_params(modules, src=0, world_size=None):
+    """The reference's start-up distribution of the weights (training_loop.py:231-236): every parameter and buffer of every module, one
+    `broadcast(src=0)` each, so that all ranks start from rank 0's initialisation.  -> the number of tensors sent."""
+    _, w = world()
+    world_size = w if world_size is None else world_size
+    n = 0
+    for m in modules:
+        if m is None:
+            continue
+        for t in list(m.parameters()) + list(m.buffers()):
+            if t.numel() > 0 and world_size > 1:
+                dist.broadcast(t.data if t.requires_grad else t, src=src)
+                n += 1
+    return n
+
+
 def allreduce_flat_grads(params, world_size=None):
     """The reference's manual data-parallel gradient exchange (training_loop.py:374-383): flatten every existing
     grad, one all_reduce(SUM), divide by the number of GPUs, nan_to_num, scatter back."""

@@ -339,6 +339,34 @@ def test_bench_two_ranks_dry_run(cpu_product, partition):
         assert res['config']['rays'] == 1024 and abs(res['value'] - 1024 / per_step) < 1e-6 * res['value']      # the FRAME's rays per second
 
 
+@pytest.mark.slow
+def test_bench_train_two_ranks_dry_run(cpu_product):
+    """Round 6: bench_train.py ITSELF as the driver would launch BASELINE config 5 on two GPUs -- two ranks over gloo on the host
+    build: the reference's start-up broadcast of rank 0's weights (training_loop.py:231-236; rank 1 is perturbed first, so the broadcast is what makes the ranks
+    equal), one training step (forward, backward through the kernels' sources, the flat-gradient all-reduce of training_loop.py:374-383, Adam), ONE JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SHERF_DIST_BACKEND='gloo',
+                   SHERF_HIPCPU_LIB=_lib.LIB_PATH, SHERF_HIPCPU_LIB_BWD=_lib.LIB_BWD_PATH, OMP_NUM_THREADS='2', HIPCPU_THREADS='4')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(G.ROOT, 'bench_train.py'), '--gpus', '2', '--config', 'tiny', '--steps', '1', '--warmup', '0'],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]          # rank 0 prints ONE line
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['rccl_ranks'] == 2 and res['scaling'] == 'weak' and res['steps'] == 1
+    assert res['dist']['params_equal_after_broadcast'] is True and res['dist']['broadcast_tensors'] > 100
+    assert np.isfinite(res['final_loss']) and res['value'] > 0 and set(res['phases_ms']) == {'forward', 'backward', 'allreduce_adam'}
+
+
 def test_bench_launches_its_own_ranks(cpu_product):
     """`python bench.py --gpus 2 --config tiny` with NO launcher in front (the form bench.py's docstring advertises and the driver uses for
     N = 1): the script re-executes itself under torch.distributed.run, two ranks over gloo on the host build, and rank 0's line says
