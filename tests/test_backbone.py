@@ -68,11 +68,11 @@ def test_small_generator_matches_reference_ref_ops(monkeypatch):
     _check(g, z)
 
 
-def check_full_size_generator_fp16(dev, tol=2e-2):
+def check_full_size_generator_fp16(dev, tol=5e-3):
     """The full-size generator with the reference's own fp16 path (num_fp16_res = 4, conv_clamp = 256: train.py:427-428, networks_stylegan2.py:423-431) on the
     device against the unmodified reference's source run in the same dtypes (tests/golden/backbone_full_fp16.npz; oracle/make_golden_backbone.py fp16: fp16
     convolutions on the host behind a device-type stand-in -- the reference forces fp32 off-GPU).  Eight fp16 layers round differently on the two sides (the
-    library's fp16 convolutions accumulate in fp32 and round once per layer, as the host's do, but in another order): 2e-2 of the planes' range."""
+    library's fp16 convolutions accumulate in fp32 and round once per layer, as the host's do, but in another order): bound 5e-3 of the planes' range (measured on the MI355X: 6.9e-4)."""
     gold = np.load(os.path.join(GOLDEN, 'backbone_full_fp16.npz'))
     g = dev(_seed(S.Generator(**dict(FULL, num_fp16_res=4, conv_clamp=256)))).eval()
     z = torch.from_numpy(np.random.RandomState(5).standard_normal((1, FULL['z_dim'])).astype(np.float32))
