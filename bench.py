@@ -552,7 +552,7 @@ def main():
                                parallelism=(f'ray tiles x{world} (one frame)' if rays_mode else f'views x{world}') if world > 1 else 'single GPU', mlp_precision=used, mlp_precision_requested=a.precision,
                                mlp_precision_auto=getattr(rend, 'auto_report', None), network=fixtures_variant_note(a.config),
                                batchnorm=a.bn_mode, exact_grids=bool(rend.exact_grids), caller_streams=n_streams,
-                               table_precision=rend.last.get('table_precision'), encoder_precision=rend.last.get('encoder_precision'), pe_in_gather=bool(rend.last.get('pe_in_gather')),
+                               table_precision=rend.last.get('table_precision'), encoder_precision=rend.last.get('encoder_precision'), pe_in_gather=bool(rend.last.get('pe_in_gather')), mlp_form=rend.last.get('mlp_form'), mlp_form_auto=getattr(rend, 'form_report', None),
                                frame_graphs=dict(on=bool(graphs_on), captured=int(gstats[0]), replayed_frames=int(gstats[1]), enqueued_frames=int(gstats[2]), failed_captures=int(gstats[3])),
                                # workspace_bytes: ONE caller stream's (the largest); sampler side at R * S, token side (484 B / sample) at 1.5 x the frame's valid samples
                                workspace_bytes=max([w_.nbytes() for w_ in (rend._ws or {}).values()] or [0]), workspaces=len(rend._ws or {}), token_capacity=int(rend.last.get('cap', 0)),

@@ -356,7 +356,10 @@ class ImportanceRenderer(nn.Module):
         # launch form of the per-sample network for the single-product precisions (round 5; all forms give the same bits): 'pipelined' =
         # sherf_nerf_mlp3 (the decoder's layer epilogues inside the next ring step's MFMA stream; the default: 2-3 % faster on the MI355X),
         # 'two_tiles' = sherf_nerf_mlp2 (two tiles per wave), 'one' = sherf_nerf_mlp.  Rendering option `mlp_form`, default from SHERF_MLP_FORM
-        self.mlp_form = os.environ.get('SHERF_MLP_FORM', 'pipelined')
+        # 'auto' (round 6, the default): the three forms give the same bits and the kernel runs at the board's power cap, where their ranking turned out to be a
+        # property of the BOARD (evidence run 1: two tiles 0.506 ms, pipelined 0.532; other boxes: pipelined ahead by 1-3 %) -- so the first frame of a
+        # (device, precision) times each form on its own tokens once (a few milliseconds, one host wait) and the process keeps the fastest (_tune_mlp_form)
+        self.mlp_form = os.environ.get('SHERF_MLP_FORM', 'auto')
         # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
         # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
         self.mlp_parts = int(os.environ.get('SHERF_MLP_PARTS', '0'))
@@ -796,9 +799,12 @@ class ImportanceRenderer(nn.Module):
         split = getattr(self, '_opt_mlp_split', None)
         if split is None:
             split = bool(getattr(self, 'mlp_split', None))
-        form = getattr(self, '_opt_mlp_form', None) or getattr(self, 'mlp_form', 'pipelined')
-        if form not in ('pipelined', 'two_tiles', 'one'):
-            raise ValueError(f"mlp_form must be 'pipelined', 'two_tiles' or 'one', not {form!r}")
+        form = getattr(self, '_opt_mlp_form', None) or getattr(self, 'mlp_form', 'auto')
+        if form not in ('auto', 'pipelined', 'two_tiles', 'one'):
+            raise ValueError(f"mlp_form must be 'auto', 'pipelined', 'two_tiles' or 'one', not {form!r}")
+        self.__dict__['_form_auto'] = form == 'auto'
+        if form == 'auto':
+            form = self._FORM_CHOICE.get((str(dev), cfg[0]), 'pipelined')
         if cfg[0] != 'f16x3' and not split:
             fr.flags |= {'pipelined': 64, 'two_tiles': 32, 'one': 0}[form]   # SHERF_FRAME_MLP_PIPELINED / SHERF_FRAME_MLP_TWO_TILES
         fr.zfrag = None
@@ -819,6 +825,35 @@ class ImportanceRenderer(nn.Module):
             fr.pefrag = _lib.addr(self._workspace(dev).pefrag(dev))
             fr.flags |= 128
         return wc
+
+    _FORM_CHOICE = {}                   # (device, precision) -> the fastest of the bit-identical launch forms on THIS board (process-wide)
+    _FORM_ENTRY = dict(pipelined='sherf_nerf_mlp3', two_tiles='sherf_nerf_mlp2', one='sherf_nerf_mlp')
+
+    def _tune_mlp_form(self, fr, ws, dev, prec_name):
+        """mlp_form='auto': time the launch forms of the single-product network on the frame just rendered (its own tokens, counters and weight stream; every form
+        rewrites the same sample_out with the same bits) -- HIP events on the caller's stream, two warm-up + six timed launches each, one host wait -- and keep
+        the fastest for this (device, precision).  Once per process and board."""
+        key = (str(dev), prec_name)
+        if key in self._FORM_CHOICE or dev.type != 'cuda' or prec_name not in ('f16', 'bf16'):
+            return
+        st = torch.cuda.current_stream(dev)
+        stream = _ct.c_void_p(st.cuda_stream)
+        cap = int(fr.tok_capacity or fr.capacity)
+        times = {}
+        for form, entry in self._FORM_ENTRY.items():
+            launch = lambda: _lib.call(entry, fr.counters, fr.tokens, fr.extras, fr.wstream, fr.wbias, int(fr.mlp_prec), cap, fr.sample_out, stream)
+            for _ in range(2):
+                launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(6):
+                launch()
+            e1.record(st)
+            e1.synchronize()
+            times[form] = e0.elapsed_time(e1) / 6
+        best = min(times, key=times.get)
+        self._FORM_CHOICE[key] = best
+        self.__dict__['form_report'] = dict(choice=best, ms={k: round(v, 4) for k, v in times.items()}, device=str(dev), precision=prec_name)
 
     def _calibrate(self, fr, decoder, dev, ws, levels, streams, exact):
         """mlp_precision='auto': before the frame proper (the reference configuration) the SAME frame is rendered in every candidate
@@ -1086,6 +1121,9 @@ class ImportanceRenderer(nn.Module):
                 enqueue()
         if static_out:
             out = out.clone()
+        if self.__dict__.get('_form_auto') and not calibrate and noise == 0 and (str(dev), cfg[0]) not in self._FORM_CHOICE and cfg[0] != 'f16x3' \
+                and not (fr.flags & 8) and int(fr.mlp_parts) <= 1:
+            self._tune_mlp_form(fr, ws, dev, cfg[0])           # (the frame above is complete and correct; the forms are timed behind it)
         ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
         self.encoder_3d.finish(pl)
         if decide is not None:

@@ -46,7 +46,8 @@ def test_mlp_launch_forms_render_the_same_bits_on_device(cfg):
         assert one['last']['mlp_form'] == 'one'
         for form in ('pipelined', 'two_tiles', None):
             b = G.hip_render(cfg, precision=prec, options=dict(mlp_form=form) if form else None)
-            assert b['last']['mlp_form'] == ('one' if prec == 'f16x3' else (form or 'pipelined'))
+            # (no form asked for: `auto` -- round 6 -- keeps whichever of the bit-identical forms timed fastest on this board)
+            assert b['last']['mlp_form'] == ('one' if prec == 'f16x3' else form) if form else b['last']['mlp_form'] in ('one', 'pipelined', 'two_tiles')
             for k in ('rgb', 'acc', 'depth'):
                 assert torch.equal(one[k], b[k]), (prec, form, k)
 
