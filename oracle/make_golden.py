@@ -206,14 +206,14 @@ def loss_targets(shape_rgb, shape_acc):
             torch.from_numpy(rs.uniform(0, 1, tuple(shape_acc)).astype(np.float32)))
 
 
-def run_grad(cfg_name, R, T, out_dir):
+def run_grad(cfg_name, R, T, out_dir, use_trans=True):
     """Golden GRADIENTS: forward + backward of the unmodified reference (training mode, density_noise 0) under the stub
     loss, w.r.t. every renderer / decoder parameter and the three feature inputs (tri-planes, 2-D feature map, per-vertex
     voxel features).  Stored as fingerprints (grad_fingerprint) -- the full set would be 10 MB."""
     from oracle import fixtures
     fx = fixtures.renderer_inputs(cfg_name)
     torch.manual_seed(0)
-    rend = R.ImportanceRenderer(True, True, True, use_trans=True, use_NeRF_decoder=True)
+    rend = R.ImportanceRenderer(True, True, True, use_trans=use_trans, use_NeRF_decoder=True)      # (use_trans=False, round 6: grad_<cfg>_notrans.npz)
     dec = T.NeRFDecoder(32)
     fixtures.load_seeded_state(rend, 'renderer.')
     fixtures.load_seeded_state(dec, 'decoder.')
@@ -246,7 +246,7 @@ def run_grad(cfg_name, R, T, out_dir):
                 n_none += 1
                 continue
             out[prefix + name] = grad_fingerprint(p_.grad)
-    path = os.path.join(out_dir, f'grad_{cfg_name}.npz')
+    path = os.path.join(out_dir, f'grad_{cfg_name}.npz' if use_trans else f'grad_{cfg_name}_notrans.npz')
     np.savez_compressed(path, **out)
     print(f'grad {cfg_name}: loss {loss.item():.6f}, {len(out) - 2} gradient fingerprints ({n_none} parameters without grad), '
           f'ref fwd+bwd {dt:.2f}s -> {path} ({os.path.getsize(path)/1e3:.0f} KB)')
@@ -392,6 +392,8 @@ if __name__ == '__main__':
         for b in names[1:] or ['110', '101', '011', '100']:
             run('tiny_ri', R, T, out_dir, branches=tuple(ch == '1' for ch in b))
         sys.exit(0)
+    if names == ['grad_notrans']:                       # round 6: the reference's gradients WITHOUT its transformer (use_trans = False), the tiny novel-view frame
+        run_grad('tiny_nv', R, T, out_dir, use_trans=False); sys.exit(0)
     if names == ['refinit']:
         run_refinit_check(R, T, out_dir); sys.exit(0)
     if all(n.endswith('_ri') for n in names):           # only the reference-init variants: leave the other files alone

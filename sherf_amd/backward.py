@@ -63,7 +63,7 @@ def render_backward(renderer, decoder, d_rgb, d_acc):
     # ---- a13 + a14 ----
     tok, ext = Mat.empty(n, 96, dev), Mat.empty(n, 12, dev)                 # (sherf_bwd_untile writes both in full)
     ops.untile(ws['tokens'], ws['extras'], n, tok, ext)
-    d_tin, grads, dWb_pe = dense_backward(ops, state, tok, ext, Mat(d_sample.view(-1), n, 4))
+    d_tin, grads, dWb_pe = dense_backward(ops, state, tok, ext, Mat(d_sample.view(-1), n, 4), use_trans=getattr(renderer, 'transformer', None) is not None)
     # ---- a10-a13 ----
     planes, obs_feat = f32(b['planes']), f32(b['obs_feat'])
     P_, (Hf, Wf) = planes.shape[-1], obs_feat.shape[-2:]

@@ -193,7 +193,7 @@ class HipOps:
         _lib.call_bwd('sherf_bwd_bn_relu_apply', self._p(raw), self._p(bnparam), _lib.ptr(n_rows), raw.rows, raw.cols, self._p(act), self.st)
 
 
-def dense_backward(ops, state, tok, ext, d_sample):
+def dense_backward(ops, state, tok, ext, d_sample, use_trans=True):
     """tok [n,96] (gather output, row-major: slot tokens incl. bias, WITHOUT the slot-2 rgb encoding), ext [n,12]
     (x_c 0:3, v_c 3:6, tapped rgb 6:9), d_sample [n,4] = dL/d(rgb, sigma) per valid sample (compositing backward).
     `state`: {reference parameter name: tensor} of the renderer (prefix 'renderer.') and decoder ('decoder.').
@@ -242,29 +242,34 @@ def dense_backward(ops, state, tok, ext, d_sample):
         return dx
 
     # ================= forward recompute =================
-    Wr = state['renderer.conv1d_reprojection.weight'].detach().float()[:, :, 0]
-    Wb = Mat.of(Wr[:, 32:64].contiguous())                          # [32 out, 32 in]
-    pe_rgb = E(n, 33)
-    ops.pe(ext.colslice(6, 9), 5, pe_rgb)
-    tin = E(n, 96)                                                  # tokens_in = tok (+ slot 2: PE(rgb)[:32] Wb^T)
-    ops.copy2d(tin, tok)
-    ops.gemm(0, 1, pe_rgb.colslice(0, 32), Wb, tin.colslice(64, 96), 1.0)
     t = 'renderer.transformer.layers.0.'
-    tin3 = tin.as_rows(3 * n, 32)
-    h0, xh0, inv0 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
-    ops.ln_fwd(tin3, P(t + '0.fn.norm.weight'), P(t + '0.fn.norm.bias'), h0, xh0, inv0)
-    qkv = E(3 * n, 144)
-    ops.gemm(0, 1, h0, P(t + '0.fn.fn.to_qkv.weight'), qkv)
-    att, o = E(n, 27), E(3 * n, 48)
-    ops.attn_fwd(qkv.as_rows(n, 432), att, o.as_rows(n, 144))
-    y = lin_fwd(o, t + '0.fn.fn.to_out.0', 0, addend=tin3)          # residual (added in the product's store)
-    h1, xh1, inv1 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
-    ops.ln_fwd(y, P(t + '1.fn.norm.weight'), P(t + '1.fn.norm.bias'), h1, xh1, inv1)
-    u = lin_fwd(h1, t + '1.fn.fn.net.0', 0)
-    ge = E(3 * n, 32)
-    ops.gelu_fwd(u, ge)
-    z = lin_fwd(ge, t + '1.fn.fn.net.3', 0, addend=y)
-    z96 = z.as_rows(n, 96)                                          # [n, slot 0 | slot 1 | slot 2]
+    if use_trans:
+      Wr = state['renderer.conv1d_reprojection.weight'].detach().float()[:, :, 0]
+      Wb = Mat.of(Wr[:, 32:64].contiguous())                          # [32 out, 32 in]
+      pe_rgb = E(n, 33)
+      ops.pe(ext.colslice(6, 9), 5, pe_rgb)
+      tin = E(n, 96)                                                  # tokens_in = tok (+ slot 2: PE(rgb)[:32] Wb^T)
+      ops.copy2d(tin, tok)
+      ops.gemm(0, 1, pe_rgb.colslice(0, 32), Wb, tin.colslice(64, 96), 1.0)
+      tin3 = tin.as_rows(3 * n, 32)
+      h0, xh0, inv0 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
+      ops.ln_fwd(tin3, P(t + '0.fn.norm.weight'), P(t + '0.fn.norm.bias'), h0, xh0, inv0)
+      qkv = E(3 * n, 144)
+      ops.gemm(0, 1, h0, P(t + '0.fn.fn.to_qkv.weight'), qkv)
+      att, o = E(n, 27), E(3 * n, 48)
+      ops.attn_fwd(qkv.as_rows(n, 432), att, o.as_rows(n, 144))
+      y = lin_fwd(o, t + '0.fn.fn.to_out.0', 0, addend=tin3)          # residual (added in the product's store)
+      h1, xh1, inv1 = E(3 * n, 32), E(3 * n, 32), E(3 * n, 1)
+      ops.ln_fwd(y, P(t + '1.fn.norm.weight'), P(t + '1.fn.norm.bias'), h1, xh1, inv1)
+      u = lin_fwd(h1, t + '1.fn.fn.net.0', 0)
+      ge = E(3 * n, 32)
+      ops.gelu_fwd(u, ge)
+      z = lin_fwd(ge, t + '1.fn.fn.net.3', 0, addend=y)
+      z96 = z.as_rows(n, 96)                                          # [n, slot 0 | slot 1 | slot 2]
+    else:
+      # use_trans = False (renderer.py:261, 427; round 6): the fused tokens go to the decoder as they are -- slots 0 / 1 of the gather's output (slot 2, and with it
+      # the rgb encoding's W_b term, is never read)
+      z96 = tok
     # ---- decoder ----
     d = 'decoder.'
     x0 = EP(n, 71)
@@ -335,6 +340,9 @@ def dense_backward(ops, state, tok, ext, d_sample):
     d_z.colslice(64, 96).tensor().zero_()                           # (the other two thirds are written in full below)
     ops.copy2d(d_z.colslice(0, 32), d_x0.colslice(39, 71))
     ops.copy2d(d_z.colslice(32, 64), d_vin.colslice(155, 187))
+    if not use_trans:
+        dWb0 = Z(32, 32)
+        return d_z, grads, dWb0.tensor()
     d_out = d_z.as_rows(3 * n, 32)
     # ---- transformer: out = ge W2^T + b2 + y ----
     d_ge = lin_bwd(d_out, ge, t + '1.fn.fn.net.3')

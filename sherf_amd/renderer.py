@@ -894,8 +894,8 @@ class ImportanceRenderer(nn.Module):
     def forward(self, planes, obs_input_img, obs_input_feature, canonical_sp_conv_volume, obs_smpl_vertex_mask, obs_sp_input,
                 decoder, ray_origins, ray_directions, near, far, input_data, rendering_options):
         if getattr(self, 'enable_autograd', False) and torch.is_grad_enabled() and not getattr(self, '_in_autograd', False):
-            if not self.use_trans or sum(self.feature_branches()) != 3:
-                raise NotImplementedError('the backward through the HIP kernels covers the shipped configuration only (all three feature branches, use_trans = True)')
+            if sum(self.feature_branches()) != 3:
+                raise NotImplementedError('the backward through the HIP kernels covers all three feature branches (use_trans True or False); a renderer with a feature branch switched off is forward-only')
             # opt-in training path (BASELINE config 5): the same forward, recorded as one autograd node whose backward runs
             # the HIP backward pipeline (sherf_amd/backward.py; experimental until verified on hardware)
             from .backward import RenderFunction, _named_params

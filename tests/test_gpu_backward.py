@@ -272,15 +272,18 @@ def test_dense_backward_on_the_gpu():
         assert G.rel(v.cpu(), g[k]) < 5e-3, k
 
 
-def test_full_backward_against_reference_gradients():
+@pytest.mark.parametrize('use_trans', [True, False])
+def test_full_backward_against_reference_gradients(use_trans):
     """forward + backward through the HIP pipeline under the stub loss of BASELINE config 5, against the fingerprints of the
-    UNMODIFIED reference's gradients (tests/golden/grad_tiny_nv.npz) and the oracle's input gradients."""
+    UNMODIFIED reference's gradients (tests/golden/grad_tiny_nv.npz) and the oracle's input gradients.  use_trans = False (round 6): a
+    renderer built without its transformer against the reference built the same way (tests/golden/grad_tiny_nv_notrans.npz)."""
     import os
     from sherf_amd.backward import render_backward
     cfg = 'tiny_nv'
     fx = G.fixture(cfg)
-    ref = np.load(os.path.join(G.GOLDEN, f'grad_{cfg}.npz'))
-    h = G.hip_render(cfg)                                   # training-mode forward (batch statistics)
+    ref = np.load(os.path.join(G.GOLDEN, f'grad_{cfg}.npz' if use_trans else f'grad_{cfg}_notrans.npz'))
+    h = G.hip_render(cfg, use_trans=use_trans)              # training-mode forward (batch statistics)
+    assert (h['rend'].transformer is not None) == use_trans
     rend, dec = h['rend'], h['dec']                         # (G.hip_modules() with no argument is a DIFFERENT cache entry)
     R = h['rgb'].shape[0]
     rs = np.random.RandomState(11)

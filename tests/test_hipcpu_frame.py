@@ -819,17 +819,21 @@ def test_full_size_backward_check_plumbing(cpu_product, monkeypatch):
     assert all(abs(ours_t[k] - ref_t[k]) <= 0.2 * ref_t[k] + 1e-4 for k in nenc)
 
 
-def test_training_step_through_autograd_matches_reference_gradients(cpu_product, monkeypatch):
+@pytest.mark.parametrize('use_trans', [True, False])
+def test_training_step_through_autograd_matches_reference_gradients(cpu_product, monkeypatch, use_trans):
     """BASELINE config 5 on the CPU: forward recorded as ONE autograd node (renderer.enable_autograd), stub loss,
     loss.backward() through the native backward pipeline; gradients against the fingerprints of the UNMODIFIED reference's
-    gradients (tests/golden/grad_tiny_nv.npz) and against the explicit backward evaluated at our forward point."""
+    gradients (tests/golden/grad_tiny_nv.npz) and against the explicit backward evaluated at our forward point.
+    use_trans = False (round 6): the same through a renderer built without its transformer, against the reference built the same way
+    (tests/golden/grad_tiny_nv_notrans.npz, oracle/make_golden.py grad_notrans)."""
     from sherf_amd import backward as B
     from sherf_amd.voxel import SparseConvTensor
     from tests.bwd_emulator import EmuOps
     cfg = 'tiny_nv'
     fx = G.fixture(cfg)
-    ref = np.load(os.path.join(G.GOLDEN, f'grad_{cfg}.npz'))
-    rend, dec = G.hip_modules.__wrapped__()                # fresh modules: this test updates running statistics and .grad
+    ref = np.load(os.path.join(G.GOLDEN, f'grad_{cfg}.npz' if use_trans else f'grad_{cfg}_notrans.npz'))
+    rend, dec = G.hip_modules.__wrapped__() if use_trans else G._hip_modules.__wrapped__('f16x3', 'seeded', False)    # fresh modules: this test updates running statistics and .grad
+    assert (rend.transformer is not None) == use_trans
     rend.enable_autograd = True
     d = fixtures.to_torch(fx['input_data'])
     spi = G.oracle_render(cfg)['sp_input']
