@@ -389,6 +389,8 @@ def main():
     dev = _device(lrank)
     if a.pmc_child:                          # three frames under rocprofv3 --pmc (pmc_traffic): nothing else
         w = make_workload(a, 0.4, dev)
+        if os.environ.get('SHERF_BENCH_MLP_FORM'):         # the form `auto` chose in the parent: no timing launches of the other forms under the counters
+            w['opts']['mlp_form'] = os.environ['SHERF_BENCH_MLP_FORM']
         time_frames(w, 3, 1, dev)
         return
     if world > 1:
@@ -680,7 +682,10 @@ def main():
             a.precision_used = used
             del w
             torch.cuda.empty_cache()
-            pm = pmc_traffic(a, lrank)
+            form_used = res['config'].get('mlp_form')
+            if form_used in MLP_FORM_KERNEL and not res['config'].get('mlp_split'):
+                os.environ['SHERF_BENCH_MLP_FORM'] = form_used                   # (inherited by the counter passes' child)
+            pm = pmc_traffic(a, lrank, keys=(MLP_FORM_KERNEL[form_used] + '<',) if form_used in MLP_FORM_KERNEL and used != 'f16x3' else None)
             res['roofline']['traffic'] = pm.get('hbm_bytes_per_launch')
             res['roofline']['traffic_detail'] = pm
         if ours is not None:
