@@ -136,6 +136,11 @@ __device__ __forceinline__ void nn_search(const CellGrid& g, const int32_t* __re
 // reaches at most 3 x 3 rows of cells (always, for a radius <= the cell size) the 18 row bounds are fetched together, then the points of
 // the concatenated segments four at a time.  Same candidate set and the same lexicographic minimum as nn_search -- the result does
 // not depend on the order of examination.  A wider ball takes the plain loops.
+// SHERF_NN_ROWS_VARIANT (build-time, A/B libraries: tools/build_variants.sh nnrows): 2 = the row segments one after the other (round 6 experiment, slower)
+#ifndef SHERF_NN_ROWS_VARIANT
+#define SHERF_NN_ROWS_VARIANT 0
+#endif
+constexpr int sherf_nn_rows_variant = SHERF_NN_ROWS_VARIANT;
 __device__ __forceinline__ void nn_search_batched(const CellGrid& g, const int32_t* __restrict__ cell_start,
                                                   const float4* __restrict__ pts, float x, float y, float z, float r,
                                                   float& best_d2, int& best_id) {
@@ -155,6 +160,27 @@ __device__ __forceinline__ void nn_search_batched(const CellGrid& g, const int32
         const int row = ok ? (cz * g.ny + cy) * g.nx : 0;
         s[i] = cell_start[row + x0];
         cum[i] = ok ? cell_start[row + x1 + 1] : s[i];          // (end of the segment for now)
+    }
+    if (sherf_nn_rows_variant == 2) {
+        // Round 6 EXPERIMENT (build with -DSHERF_NN_ROWS_VARIANT=2; MEASURED SLOWER, profiles/r06_call_p_*): the (up to) nine row segments walked ONE AFTER THE
+        // OTHER, four points per step.  The loop below indexes the concatenation of the segments and finds point t's address with an eight-way select chain -- ~24 of
+        // its ~37 VALU per point -- and here a point costs its distance and its comparison; but a wave then runs the SUM over the nine rows of its lanes' longest
+        // segment instead of the longest concatenation: warp_geom 150 -> 176 us, the frame +30 us.  Same points, order-free minimum: identical results.
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            for (int p = s[i]; p < cum[i]; p += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = pts[p + u < cum[i] ? p + u : s[i]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d2 = dist2_exact(x, y, z, v[u].x, v[u].y, v[u].z);
+                    const int id = __float_as_int(v[u].w);
+                    if (p + u < cum[i] && (d2 < best_d2 || (d2 == best_d2 && id < best_id))) { best_d2 = d2; best_id = id; }
+                }
+            }
+        }
+        return;
     }
     int n = 0;
 #pragma unroll
