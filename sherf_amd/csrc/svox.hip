@@ -224,8 +224,13 @@ __device__ unsigned g_sconv_trace_cap = 0, g_sconv_trace_n = 0;
 // a gradient row) the unscaled lo kept 6 bits instead of 11: 2e-6 of the specification per layer where fp32 has 6e-8, and every BatchNorm
 // backward behind such a layer amplifies rounding 10^3-10^4 times.  Scaled, lo keeps its 11 bits down to 2^-13 of fp16's
 // range: 22 bits per operand, the same three MFMAs, 16 more registers per output tile.
-template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP, int NW>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
-__global__ void __launch_bounds__(64 * NW, (NW == 8 ? 2 : (NCOT * NKB >= 12 ? 1 : 2)))   // (level 2 launches 318 workgroups: two per CU must fit)
+// CS (round 6): COLUMN SPLIT -- a workgroup computes ONE of the layer's NCOT output tiles (blockIdx.y) instead of all of them.  The 64 / 96 -> 96 instances hold three
+// accumulator tiles and three tiles' weight fragments per K-block: 208-248 VGPRs a wave, and such a wave needs that many free registers on all four SIMDs of a CU at
+// once -- beside the ray side's kernels (51-59 registers, up to eight waves per SIMD) it waits: those two layers run 18 us alone and 90-150 us in the frame
+// (profiles/r06_kernel_trace_evidence_run_1_*).  One tile per workgroup: a third of the registers, three times the workgroups, the gathered rows read three times
+// (2.7 K / 10 K rows: nothing).  Same products in the same order per output element: bit-identical rows and statistics.
+template <int NCOT, int NKB, bool FOLD, int IN_BN, bool SP, int NW, bool CS = false>   // Cout = 32 * NCOT, Cin = 16 * NKB; IN_BN 0 raw input, 1 BatchNorm, 2 BatchNorm + row multiplicity
+__global__ void __launch_bounds__(64 * NW, (NW == 8 ? 2 : ((NCOT * NKB >= 12 && !CS) ? 1 : 2)))   // (level 2 launches 318 workgroups: two per CU must fit)
 sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ n_rows_out,
                                                      int Do, int Ho, int Wo, const uint2* __restrict__ wp_in, int Di, int Hi, int Wi,
                                                      const float* __restrict__ in_raw, BnIn bin,
@@ -233,6 +238,9 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
                                                      float* __restrict__ out_raw, long long* __restrict__ out_acc, int trace_id,
                                                      const uint32_t* __restrict__ in_amax) {
     constexpr int COUT = 32 * NCOT, Cin = 16 * NKB;
+    static_assert(!CS || !FOLD, "column split: the 27-tap instances");
+    constexpr int NC = CS ? 1 : NCOT, COUTL = 32 * NC;      // output tiles / columns THIS workgroup computes
+    const int c0 = CS ? (int)blockIdx.y : 0;                 // its first tile
 #if SHERF_SCONV_TRACE
     uint32_t stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     SCONV_STAMP(0);
@@ -330,10 +338,10 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     __syncthreads();
     SCONV_STAMP(3);
 
-    f32x16_t acc[NCOT];
-    f32x16_t acc2[SL ? NCOT : 1];                        // SL: the two lo products, at 2^11 times their value
+    f32x16_t acc[NC];
+    f32x16_t acc2[SL ? NC : 1];                        // SL: the two lo products, at 2^11 times their value
 #pragma unroll
-    for (int c = 0; c < NCOT; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) { acc[c][q] = 0.f; if (SL) acc2[c][q] = 0.f; }
     const int r = lane & 31, h = lane >> 5;
@@ -354,19 +362,19 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     // PF is chosen by the register cost of a tap (rows 2 NKB + weights 2 NKB NCOT uint4): 3 / 2 / 1 taps.  Lanes without that
     // neighbour read row 0 and are zeroed after the BatchNorm transform (no divergent control flow in the pipeline).  The order of
     // the accumulation is unchanged (taps ascending per wave, K-blocks ascending): results are bit-identical to the simple loop.
-    constexpr int PF = NKB * NCOT <= 2 ? 3 : (NKB * NCOT <= 4 ? 2 : 1);   // (32 -> 32 at PF 4 costs 198 registers: 2 workgroups per CU, and level 1 launches 602)
+    constexpr int PF = NKB * NC <= 2 ? 3 : (NKB * NC <= 4 ? 2 : 1);   // (32 -> 32 at PF 4 costs 198 registers: 2 workgroups per CU, and level 1 launches 602)
     struct Row { float4 v[2 * NKB]; int nb; float mlt; };
     constexpr int WPC = SP ? 1 : 2;                   // weight fragments per (K-block, output tile): hi [, lo]
-    struct Wts { uint4 w[NKB][WPC * NCOT]; };
+    struct Wts { uint4 w[NKB][WPC * NC]; };
     auto row_src = [&](int nb) { return reinterpret_cast<const float4*>(in_raw + (size_t)(nb >= 0 ? nb : 0) * Cin) + 2 * h; };
     auto row_mult = [&](int nb) {                   // (the load is unconditional per lane: one uniform branch, no divergent one)
         const float m = has_mult ? (float)(in_mult[nb >= 0 ? nb : 0] - 1) : 0.f;
         return nb >= 0 ? m : 0.f;
     };
-    auto load_w = [&](int tap, int kb, uint4 (&w)[WPC * NCOT]) {
-        const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT) * 2 * 64 + lane;     // memory: [cot][hi, lo][64 lanes]
+    auto load_w = [&](int tap, int kb, uint4 (&w)[WPC * NC]) {
+        const uint4* wsrc = wpk + ((size_t)(tap * NKB + kb) * NCOT + c0) * 2 * 64 + lane;     // memory: [cot][hi, lo][64 lanes]
 #pragma unroll
-        for (int c = 0; c < NCOT; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < WPC; ++q)                                                  // (SP: the `lo` fragments are never fetched)
                 if (!FOLD || c == csel) w[WPC * c + q] = wsrc[(2 * c + q) * 64];
@@ -405,7 +413,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
             const uint4 ahi = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
             if constexpr (SP) {
 #pragma unroll
-                for (int c = 0; c < NCOT; ++c) {
+                for (int c = 0; c < NC; ++c) {
                     if (FOLD && c != csel) continue;
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, ahi), __builtin_bit_cast(f16x8_t, W.w[kb][WPC * c]), acc[c], 0, 0, 0);
                 }
@@ -414,7 +422,7 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
             const uint4 alo = make_uint4(pk2((v[0] - rt(v[0])) * LS, (v[1] - rt(v[1])) * LS), pk2((v[2] - rt(v[2])) * LS, (v[3] - rt(v[3])) * LS),
                                          pk2((v[4] - rt(v[4])) * LS, (v[5] - rt(v[5])) * LS), pk2((v[6] - rt(v[6])) * LS, (v[7] - rt(v[7])) * LS));
 #pragma unroll
-            for (int c = 0; c < NCOT; ++c) {
+            for (int c = 0; c < NC; ++c) {
                 if (FOLD && c != csel) continue;
                 const uint4 bhi = W.w[kb][WPC * c], blo = W.w[kb][WPC * c + WPC - 1];
                 // blo = fp16((W - hi) * 2^11): sherf_amd/voxel.py pack_conv_weights
@@ -470,44 +478,44 @@ sconv3_kernel(const int32_t* __restrict__ keys_out, const int32_t* __restrict__ 
     SCONV_STAMP(6);                                  // all taps of wave 0 done
     if constexpr (SL) {
 #pragma unroll
-        for (int c = 0; c < NCOT; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[c][q] = __builtin_fmaf(acc2[c][q], 1.0f / 2048.0f, acc[c][q]);
     }
     // D layout: lane = (col j = lane&31, half h), reg q <-> tile row (q&3) + 8*(q>>2) + 4*h
 #pragma unroll
-    for (int c = 0; c < NCOT; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s_red[((wave * 32) + (q & 3) + 8 * (q >> 2) + 4 * h) * COUT + c * 32 + r] = acc[c][q];
+        for (int q = 0; q < 16; ++q) s_red[((wave * 32) + (q & 3) + 8 * (q >> 2) + 4 * h) * COUTL + c * 32 + r] = acc[c][q];
     SCONV_STAMP(7);
     __syncthreads();
     SCONV_STAMP(8);                                  // every wave's taps done
-    constexpr int G = NT / COUT;                        // row groups: 8 / 4 / 2 (NW = 4), 16 / 8 / 5 (NW = 8)
-    const int g = tid / COUT, co = tid % COUT;
+    constexpr int G = NT / COUT;                        // row groups: 8 / 4 / 2 (NW = 4), 16 / 8 / 5 (NW = 8).  (CS: the SAME grouping over this workgroup's 32 columns,
+    const int g = tid / COUTL, co = tid % COUTL;        //  so that the statistics' partial sums -- and their bits -- are those of the whole-row instance)
     float s1 = 0.f, s2 = 0.f;
     if (g < G)
         for (int rr = g; rr < 32; rr += G) {
-            float val = ((s_red[(0 * 32 + rr) * COUT + co] + s_red[(1 * 32 + rr) * COUT + co]) + s_red[(2 * 32 + rr) * COUT + co]) +
-                        s_red[(3 * 32 + rr) * COUT + co];
+            float val = ((s_red[(0 * 32 + rr) * COUTL + co] + s_red[(1 * 32 + rr) * COUTL + co]) + s_red[(2 * 32 + rr) * COUTL + co]) +
+                        s_red[(3 * 32 + rr) * COUTL + co];
             if constexpr (NW == 8)
-                val += ((s_red[(4 * 32 + rr) * COUT + co] + s_red[(5 * 32 + rr) * COUT + co]) + s_red[(6 * 32 + rr) * COUT + co]) +
-                       s_red[(7 * 32 + rr) * COUT + co];
+                val += ((s_red[(4 * 32 + rr) * COUTL + co] + s_red[(5 * 32 + rr) * COUTL + co]) + s_red[(6 * 32 + rr) * COUTL + co]) +
+                       s_red[(7 * 32 + rr) * COUTL + co];
             val *= out_scale;
             if (row0 + rr < n_rows) {
-                if (out_half) reinterpret_cast<_Float16*>(out_raw)[(size_t)(row0 + rr) * COUT + co] = (_Float16)val;
-                else out_raw[(size_t)(row0 + rr) * COUT + co] = val;
+                if (out_half) reinterpret_cast<_Float16*>(out_raw)[(size_t)(row0 + rr) * COUT + c0 * 32 + co] = (_Float16)val;
+                else out_raw[(size_t)(row0 + rr) * COUT + c0 * 32 + co] = val;
                 s1 += val; s2 += val * val;
             }
         }
     if (out_acc) {
         __syncthreads();
-        if (g < G) { s_red[g * COUT + co] = s1; s_red[(G + g) * COUT + co] = s2; }
+        if (g < G) { s_red[g * COUTL + co] = s1; s_red[(G + g) * COUTL + co] = s2; }
         __syncthreads();
-        if (tid < 2 * COUT) {
-            const int which = tid / COUT, c2 = tid % COUT;
+        if (tid < 2 * COUTL) {
+            const int which = tid / COUTL, c2 = tid % COUTL;
             double t = 0.0;
-            for (int q = 0; q < G; ++q) t += (double)s_red[(which * G + q) * COUT + c2];
-            atomicAdd(reinterpret_cast<unsigned long long*>(out_acc) + ((blockIdx.x % kAccSub) * 2 + which) * COUT + c2,
+            for (int q = 0; q < G; ++q) t += (double)s_red[(which * G + q) * COUTL + c2];
+            atomicAdd(reinterpret_cast<unsigned long long*>(out_acc) + ((blockIdx.x % kAccSub) * 2 + which) * COUT + c0 * 32 + c2,
                       (unsigned long long)__double2ll_rn(t * kAccFix));
         }
     }
@@ -690,6 +698,20 @@ static int launch_conv3(const int32_t* keys_out, const int32_t* n_rows_out, int 
     static int trace_launches = 0;                  // (profiling builds: launch ordinal -> the records' first word)
     const int trace_id = SHERF_SCONV_TRACE ? trace_launches++ : 0;
     const int sel = (Cout / 32) * 10 + Cin / 16;
+    // column split (SHERF_EXPERIMENT bit 12): the two 96-column single-product instances as three 32-column workgroups per row tile
+    // (grid.y = 3; see sconv3_kernel: CS) -- the same bits, a third of the accumulators and weight fragments per wave
+    if ((sel == 34 || sel == 36) && !fold && single && !wide && bnm && (sherf_experiment() & 4096)) {
+        const size_t smem_cs = (size_t)27 * 32 * 4 + (size_t)3 * Cin * 4 + (size_t)4 * 32 * 32 * 4;
+        const dim3 grid_cs(cdiv(max_rows, 32), 3);
+#define SHERF_CONV3_CS(K, B)                                                                                                     \
+        hipLaunchKernelGGL((sconv3_kernel<3, K, false, B, true, 4, true>), grid_cs, block, smem_cs, as_stream(stream), keys_out, n_rows_out, \
+                           Do, Ho, Wo, reinterpret_cast<const uint2*>(wp_in), Di, Hi, Wi, in_raw, bin, in_mult,                  \
+                           reinterpret_cast<const uint4*>(w_packed), kmode, out_raw, reinterpret_cast<long long*>(out_acc), trace_id, in_amax)
+        if (sel == 34) { if (bnm == 2) SHERF_CONV3_CS(4, 2); else SHERF_CONV3_CS(4, 1); }
+        else { if (bnm == 2) SHERF_CONV3_CS(6, 2); else SHERF_CONV3_CS(6, 1); }
+#undef SHERF_CONV3_CS
+        SHERF_LAUNCH_CHECK();
+    }
     switch (sel) {
         case 12: SHERF_CONV3(1, 2); break;     // 32 -> 32
         case 22: SHERF_CONV3(2, 2); break;     // 32 -> 64

@@ -133,6 +133,15 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
             os.environ['SHERF_EXPERIMENT'] = str(word)
             b = G.hip_render('tiny_nv')
             assert torch.equal(b['rgb'], h['rgb']) and torch.equal(b['acc'], h['acc']) and torch.equal(b['depth'], h['depth']), word
+        # round 6, bit 12: the two 96-column single-product sparse convolutions as three 32-column workgroups per row tile (svox.hip, sconv3_kernel: CS)
+        single = dict(encoder_precision='f16')
+        whole = G.hip_render('tiny_nv', precision='f16', options=single)
+        os.environ['SHERF_EXPERIMENT'] = '4096'
+        cs = G.hip_render('tiny_nv', precision='f16', options=single)
+        assert cs['last']['encoder_precision'] == 'f16'
+        for k in ('rgb', 'acc', 'depth'):
+            assert torch.equal(cs[k], whole[k]), k
+        assert torch.equal(cs['last']['ws']['sample_out'], whole['last']['ws']['sample_out'])
     finally:
         os.environ.pop('SHERF_EXPERIMENT', None)
 
