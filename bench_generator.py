@@ -195,6 +195,7 @@ def main():
         res[name] = dict(ms_per_forward=ms, rays_per_s=R / (ms * 1e-3), stages_ms={k: round(v, 4) for k, v in stages.items()}, floor=floor,
                          floor_share=stages[floor] / max(stages.get('total', ms), 1e-9))
     img = out['image_raw']
+    res['value'] = res['recomputed_every_frame']['rays_per_s']; res['ms_per_step'] = res['recomputed_every_frame']['ms_per_forward']
     if a.fp16_res > 0 and dev.type == 'cuda':
         # round 6: the same forward with the reference's OWN fp16 path in the tri-plane generator (train.py --g_num_fp16_res, networks_stylegan2.py:
         # 423-431, 471-536: the last `num_fp16_res` resolutions in fp16, conv_clamp 256) -- an option of the reference, not its shipped default (0).  Same seed: same weights.

@@ -235,7 +235,7 @@ def test_bench_main_dry_run(cpu_product, monkeypatch, capsys):
     # feed the `parity` entry -- BASELINE's "PSNR vs ref" for the very frame that was timed
     monkeypatch.setattr(bench, 'torch_gpu_baseline_child',
                         lambda a, lrank, timeout=300, save=None: bench.torch_gpu_baseline(a.config, torch.device('cpu'), a.bn_mode == 'train', iters=1, save=save))
-    monkeypatch.setattr(bench, 'pmc_traffic', lambda a, lrank, timeout=150: dict(hbm_bytes_per_launch=12345, note='faked'))
+    monkeypatch.setattr(bench, 'pmc_traffic', lambda a, lrank, timeout=150, child=None, keys=None: dict(hbm_bytes_per_launch=12345, note='faked'))
     monkeypatch.setattr(bench, 'SECONDARY_ITERS', dict(mlp=1, mlp_warmup=0, frames=1, frames_warmup=0))
     keep = {k: fixtures.CONFIGS[k] for k in ('cfg3', 'cfg2_dense', 'cfg3_ri', 'cfg2_dense_ri', 'cfg2', 'cfg2_ri')}
     for sfx, var in (('', {}), ('_ri', dict(variant='ri'))):                       # the secondary workloads, tiny-sized here
