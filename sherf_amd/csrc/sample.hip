@@ -705,6 +705,88 @@ __global__ void __launch_bounds__(256) cand_search_lists_kernel(const float4* __
     }
 }
 
+// The same search one pipeline stage deeper (SHERF_EXPERIMENT bit 14; round 6): cand_search_lists_kernel waits twice per candidate -- for its list entries, then for the points
+// they name.  Here the first 64 entries of the NEXT candidate's list are requested while this candidate's points are compared (its header arrived a step ago, the header after it
+// and the record after that are requested now), and a lane takes eight entries per step: one dependent wait per candidate for every list of up to 64 vertices (the average is 40).
+// Same comparisons on the same points' bits: identical results.
+template <int NCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) cand_search_lists2_kernel(const float4* __restrict__ cand_list, int64_t list_cap,
+                                                                 const int32_t* __restrict__ cand_count, int S, const float* __restrict__ hdr,
+                                                                 const int2* __restrict__ near_hdr, const uint16_t* __restrict__ near_list,
+                                                                 const float4* __restrict__ cell_pts,
+                                                                 unsigned long long* __restrict__ ray_mask, int32_t* __restrict__ dense_vid) {
+    const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const CellGrid g = load_grid(hdr);
+    const int snx = g.nx * g.sub, sny = g.ny * g.sub, snz = g.nz * g.sub;
+    const float fs = g.inv_cell * (float)g.sub;
+    const int64_t n = min((int64_t)*cand_count, list_cap);
+    const unsigned long long kInit = ((unsigned long long)__float_as_uint(kThresh2) << 32) | 0x7FFFFFFFull;
+    const int64_t stride = (int64_t)gridDim.x * 32;
+    auto sub_cell = [&](const float4& rec) -> int {                   // cand_mark's own arithmetic on the same floats -> the same sub-cell
+        const int sx = (int)floorf((rec.x - g.ox) * fs), sy = (int)floorf((rec.y - g.oy) * fs), sz = (int)floorf((rec.z - g.oz) * fs);
+        const bool in = sx >= 0 && sx < snx && sy >= 0 && sy < sny && sz >= 0 && sz < snz;
+        return in ? (sz * sny + sy) * snx + sx : -1;
+    };
+    auto entries = [&](int st, int cn, int e, uint2& a, uint2& b) {  // entries e .. e + 7 of a list (lists are padded to four entries)
+        a = make_uint2(0u, 0u); b = make_uint2(0u, 0u);
+        if (e < cn) a = *reinterpret_cast<const uint2*>(near_list + st + e);
+        if (e + 4 < cn) b = *reinterpret_cast<const uint2*>(near_list + st + e + 4);
+    };
+    int64_t ci = (int64_t)blockIdx.x * 32 + grp;
+    float4 r0 = cand_list[ci < n ? ci : 0];
+    float4 r1 = cand_list[ci + stride < n ? ci + stride : 0];
+    float4 r2 = cand_list[ci + 2 * stride < n ? ci + 2 * stride : 0];
+    const int q0 = sub_cell(r0), q1 = sub_cell(r1);
+    bool l0 = ci < n && q0 >= 0, l1 = ci + stride < n && q1 >= 0;
+    int2 h0 = near_hdr[l0 ? q0 : 0], h1 = near_hdr[l1 ? q1 : 0];
+    uint2 wa, wb;
+    entries(h0.x, l0 ? h0.y : 0, sub * 8, wa, wb);
+    for (; ci - grp < n; ci += stride) {                              // (the whole workgroup leaves together: ci - grp is uniform)
+        const bool live = l0;
+        const float xs = r0.x, ys = r0.y, zs = r0.z;
+        const int idx = live ? __float_as_int(r0.w) : 0;
+        const int st = h0.x, cn = live ? h0.y : 0;
+        uint2 ca = wa, cb = wb;
+        // the stages behind this candidate: entries of the next one, header of the one after it, record of the third
+        const int cn1 = l1 ? h1.y : 0;
+        entries(h1.x, cn1, sub * 8, wa, wb);
+        const int q2 = sub_cell(r2);
+        const bool l2 = ci + 2 * stride < n && q2 >= 0;
+        const int2 h2 = near_hdr[l2 ? q2 : 0];
+        const float4 r3 = cand_list[ci + 3 * stride < n ? ci + 3 * stride : 0];
+        unsigned long long key = kInit;
+        for (int base = 0; base < cn; base += 64) {
+            const int e = base + sub * 8;
+            if (base > 0) entries(st, cn, e, ca, cb);
+            const int id[8] = {(int)(ca.x & 0xFFFFu), (int)(ca.x >> 16), (int)(ca.y & 0xFFFFu), (int)(ca.y >> 16),
+                               (int)(cb.x & 0xFFFFu), (int)(cb.x >> 16), (int)(cb.y & 0xFFFFu), (int)(cb.y >> 16)};
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = cell_pts[e + j < cn ? id[j] : 0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dd = dist2_exact(xs, ys, zs, v[j].x, v[j].y, v[j].z);
+                if (e + j < cn && dd < kThresh2) {
+                    const unsigned long long cand = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)__float_as_int(v[j].w);
+                    key = cand < key ? cand : key;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {      // lexicographic (d^2, vertex id) minimum over the group's eight lanes
+            const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other < key ? other : key;
+        }
+        if (live && sub == 0 && (unsigned)(key >> 32) < __float_as_uint(kThresh2)) {
+            const int ray = idx / S, k = idx - ray * S;
+            dense_vid[idx] = (int)(key & 0x7FFFFFFFull);
+            atomicOr(&ray_mask[(size_t)ray * NCH + (k >> 6)], 1ull << (k & 63));
+        }
+        r0 = r1; r1 = r2; r2 = r3; l0 = l1; l1 = l2; h0 = h1; h1 = h2;
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(1024) scan_chunk_mask_kernel(const uint64_t* __restrict__ ray_mask, int R, int32_t* __restrict__ cnt,
                                                                int32_t* __restrict__ base, int32_t* __restrict__ chunk_sum) {
@@ -900,6 +982,59 @@ __global__ void __launch_bounds__(256) compact_rays_kernel(const float* __restri
     }
 }
 
+// The same compaction with SIXTEEN LANES per ray: a wave takes four consecutive rays, a lane the 4 NCH consecutive samples of its ray whose mask bits sit in one word
+// (NCH = 1, 2, 4: 64 is a multiple of 4 NCH).  A quarter of the waves of compact_kernel, the same three dependent round trips (offsets + masks, ray, vertex ids), and a lane's
+// vertex-id loads are issued together.  Same records at the same positions (SHERF_EXPERIMENT bit 13; round 6).
+template <int NCH>
+__global__ void __launch_bounds__(256) compact_quad_kernel(const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                           const float* __restrict__ near, const float* __restrict__ far,
+                                                           int R, int S, const float* __restrict__ Rg, const float* __restrict__ Th,
+                                                           const int32_t* __restrict__ ray_base_local,
+                                                           const int32_t* __restrict__ chunk_off, const uint64_t* __restrict__ ray_mask,
+                                                           const int32_t* __restrict__ dense_vid, int64_t capacity,
+                                                           int32_t* __restrict__ ray_base, int32_t* __restrict__ cs_idx,
+                                                           int32_t* __restrict__ cs_vid, float4* __restrict__ cs_xs) {
+    static_assert(NCH == 1 || NCH == 2 || NCH == 4, "a lane's samples must not straddle a mask word");
+    constexpr int SPL = 4 * NCH;                                               // samples per lane
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const int ray = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    if (ray >= R) return;
+    const int base = ray_base_local[ray] + chunk_off[ray >> 10];
+    if (sub == 0) ray_base[ray] = base;
+    const int k0 = sub * SPL, word = k0 >> 6, shift = k0 & 63;
+    int below = 0;                                                             // set bits of the ray below sample k0
+    uint64_t mine = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const uint64_t m = ray_mask[(size_t)ray * NCH + ch];
+        below += ch < word ? __popcll(m) : (ch == word ? __popcll(m & ((1ull << shift) - 1ull)) : 0);
+        mine = ch == word ? m : mine;
+    }
+    const unsigned bits = (unsigned)(mine >> shift) & ((1u << SPL) - 1u);
+    if (bits == 0) return;
+    const float o0 = ray_o[ray * 3], o1 = ray_o[ray * 3 + 1], o2 = ray_o[ray * 3 + 2];
+    const float d0 = ray_d[ray * 3], d1 = ray_d[ray * 3 + 1], d2 = ray_d[ray * 3 + 2];
+    const float nr = near[ray], range = __fsub_rn(far[ray], nr);
+    int vid[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) vid[j] = ((bits >> j) & 1u) ? dense_vid[(size_t)ray * S + k0 + j] : 0;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        if (!((bits >> j) & 1u)) continue;
+        const int k = k0 + j;
+        const int64_t c = (int64_t)base + below + __popc(bits & ((1u << j) - 1u));
+        if (c < capacity) {
+            const float t = depth_at(nr, range, k, S);
+            const float x = __fadd_rn(o0, __fmul_rn(t, d0)), y = __fadd_rn(o1, __fmul_rn(t, d1)), z = __fadd_rn(o2, __fmul_rn(t, d2));
+            float xs, ys, zs;
+            to_smpl_frame(x, y, z, Rg, Th, xs, ys, zs);
+            cs_idx[c] = ray * S + k;
+            cs_vid[c] = vid[j];
+            cs_xs[c] = make_float4(xs, ys, zs, 0.f);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-sample warp: canonical point/direction, exact nearest T-pose vertex, pixel in the observation view
 // ---------------------------------------------------------------------------------------------
@@ -1029,10 +1164,18 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
         // encoder's small dependent launches on the other stream, which the frame waits for just as long (MI355X, dense framing: 8 ->
         // 1.751 ms, 6 -> 1.726, 4 -> 1.774, 3 -> 1.826 per frame; profiles/r04_call_m_*).  Debug bits 20-23 override for A/B runs.
         const int search_wgs = ((g_sherf_debug >> 20) & 15) ? ((g_sherf_debug >> 20) & 15) : 6;
+        const bool tight = (sherf_experiment() & 32768) != 0;           // bit 15: ... held to 80 registers (six workgroups per CU; three spilled) instead of 87 (five)
+        const bool deep = (sherf_experiment() & 16384) != 0;            // SHERF_EXPERIMENT bit 14: the list search one pipeline stage deeper (round 6)
 #define SHERF_TWO_PASS(N)                                                                                                          \
         hipLaunchKernelGGL(cand_mark_kernel<N>, dim3(cdiv(R, 4 * (16 / N))), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th,    \
                            grid_hdr, near_mask, cand_list, list_cap, cand_count, ray_mask, g_sherf_debug);                         \
-        if (lists)                                                                                                                 \
+        if (lists && deep && tight)                                                                                                \
+            hipLaunchKernelGGL((cand_search_lists2_kernel<N, 6>), dim3(search_wgs * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S, \
+                               grid_hdr, reinterpret_cast<const int2*>(near_hdr), near_list, cp, rm, dense_vid);                   \
+        else if (lists && deep)                                                                                                    \
+            hipLaunchKernelGGL((cand_search_lists2_kernel<N, 5>), dim3(min(search_wgs, 5) * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S, \
+                               grid_hdr, reinterpret_cast<const int2*>(near_hdr), near_list, cp, rm, dense_vid);                   \
+        else if (lists)                                                                                                            \
             hipLaunchKernelGGL(cand_search_lists_kernel<N>, dim3(search_wgs * n_cus()), dim3(256), 0, st, cand_list, list_cap, cand_count, S, \
                                grid_hdr, reinterpret_cast<const int2*>(near_hdr), near_list, cp, rm, dense_vid);                   \
         else                                                                                                                       \
@@ -1063,6 +1206,13 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     hipLaunchKernelGGL(compact_rays_kernel<N>, dim3(cdiv(R, 256)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
                        base_local, chunk_sum, ray_mask, dense_vid, capacity, ray_base, cs_idx, cs_vid,                 \
                        reinterpret_cast<float4*>(cs_xs))
+#define SHERF_COMPACT_QUAD_LAUNCH(N)                                                                                   \
+    hipLaunchKernelGGL(compact_quad_kernel<N>, dim3(cdiv(R, 16)), dim3(256), 0, st, ray_o, ray_d, near, far, R, S, Rg, Th, \
+                       base_local, chunk_sum, ray_mask, dense_vid, capacity, ray_base, cs_idx, cs_vid,                 \
+                       reinterpret_cast<float4*>(cs_xs))
+    if ((sherf_experiment() & 8192) && nch != 3) {      // SHERF_EXPERIMENT bit 13: sixteen lanes per ray (round 6)
+        if (nch == 1) SHERF_COMPACT_QUAD_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_QUAD_LAUNCH(2); else SHERF_COMPACT_QUAD_LAUNCH(4);
+    } else
     if (sherf_experiment() & 2048) {            // SHERF_EXPERIMENT bit 11: one lane per ray, whole waves for the hit rays only (round 6; MEASURED SLOWER: 96 vs 77 us, frame 1.615 vs 1.597 ms -- the hit rays of a wave are walked one after the other, each behind its own round trips; profiles/r06_call_m_*)
         if (nch == 1) SHERF_COMPACT_RAYS_LAUNCH(1); else if (nch == 2) SHERF_COMPACT_RAYS_LAUNCH(2);
         else if (nch == 3) SHERF_COMPACT_RAYS_LAUNCH(3); else SHERF_COMPACT_RAYS_LAUNCH(4);

@@ -98,8 +98,11 @@ def test_shell_mask_and_vertex_ids_against_brute_force(lib):
     dbg = _ct.c_int.in_dll(lib, 'g_sherf_debug')
     import os as _os
     # (xp: SHERF_EXPERIMENT -- 2048 = round 6's experimental compaction with one lane per ray + whole waves for the hit rays; default: one wave per ray)
-    for S, flag, lists, xp in ((80, 0, True, '0'), (80, 0, True, '2048'), (80, 0, False, '0'), (80, 512, False, '0'), (40, 0, True, '0'), (40, 0, True, '2048'),
-                               (150, 0, True, '0'), (150, 0, True, '2048'), (150, 0, False, '0'), (150, 512, False, '0')):
+    # (8192 = sixteen lanes per ray, four rays per wave: one, two and four mask words per ray; three words fall back to the default kernel;
+    #  16384 = the list search one pipeline stage deeper, eight list entries per lane and step; 24576 = both; 49152 = the deeper search held to 80 registers)
+    for S, flag, lists, xp in ((80, 0, True, '0'), (80, 0, True, '2048'), (80, 0, True, '24576'), (80, 0, False, '0'), (80, 512, False, '0'), (40, 0, True, '0'),
+                               (40, 0, True, '2048'), (40, 0, True, '24576'), (150, 0, True, '0'), (150, 0, True, '2048'), (150, 0, True, '24576'), (150, 0, False, '0'),
+                               (150, 512, False, '0'), (200, 0, True, '0'), (200, 0, True, '24576'), (80, 0, True, '49152')):
         dbg.value = flag
         _os.environ['SHERF_EXPERIMENT'] = xp
         R = 96
