@@ -449,7 +449,8 @@ int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* lev
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);
 /* The valid-sample count of the last frame THE CALLING THREAD enqueued on the current device with SHERF_FRAME_REPORT_COUNT (waits for the
  * sampler of that frame, not for the frame; other threads' frames on the device have their own slots -- a ring of eight per device -- and the
- * wait holds no lock).  State the library keeps per process: the join / report events and two pinned words per device, the profiling ring, and
+ * wait holds no lock; a thread whose frame has been overtaken by eight later REPORT_COUNT frames on the device gets SHERF_EINVAL instead of
+ * another frame's count -- every slot carries the sequence number of the frame that holds it).  State the library keeps per process: the join / report events and two pinned words per device, the profiling ring, and
  * this per-thread slot index; sherf_render_frame serialises ENQUEUES on a device with a mutex (the join events are shared), so it is thread-safe
  * but not lock-free -- the "no global mutable state" of SURVEY section 8(b) holds for every other entry point, not for the frame driver. */
 int sherf_frame_count(int32_t* nv_host);

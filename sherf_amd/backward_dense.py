@@ -70,16 +70,26 @@ class HipOps:
             raise RuntimeError('sherf_amd: tensor is not on a GPU; the HIP path has no CPU fallback')
         return ctypes.c_void_p(m.buf.data_ptr() + 4 * m.off)
 
+    @staticmethod
+    def _rows_readable(A, K):
+        """include/sherf_hip_bwd.h (sherf_bwd_gemm): the streaming tall kernel reads a row of a non-transposed A in whole 16-float blocks (masked in registers),
+        so the last row's padding up to 16 ceil(K / 16) floats must lie inside the buffer."""
+        blocks = 16 * ((K + 15) // 16)
+        streaming = A.ld >= blocks and A.ld % 4 == 0                    # (sherf_bwd_gemm's own routing rule; otherwise the general kernel checks every element)
+        return not streaming or A.off + (A.rows - 1) * A.ld + blocks <= A.buf.numel()
+
     def gemm(self, tA, tB, A, B, C, beta=0.0):
         M, K = (A.cols, A.rows) if tA else (A.rows, A.cols)
         K2, N = (B.cols, B.rows) if tB else (B.rows, B.cols)
         assert K == K2 and C.rows == M and C.cols == N, ('gemm shapes', tA, tB, A.rows, A.cols, B.rows, B.cols, C.rows, C.cols)
+        assert tA or self._rows_readable(A, K), ('gemm: row padding of A not readable', A.off, A.rows, A.ld, K, A.buf.numel())
         _lib.call_bwd('sherf_bwd_gemm', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta), self.st)
 
     def gemm_bias_act(self, tA, tB, A, B, C, bias, act, beta=0.0):
         M, K = (A.cols, A.rows) if tA else (A.rows, A.cols)
         K2, N = (B.cols, B.rows) if tB else (B.rows, B.cols)
         assert K == K2 and C.rows == M and C.cols == N and (bias is None or bias.rows * bias.cols == N), ('gemm_bias_act shapes', M, N, K)
+        assert tA or self._rows_readable(A, K), ('gemm_bias_act: row padding of A not readable', A.off, A.rows, A.ld, K, A.buf.numel())
         _lib.call_bwd('sherf_bwd_gemm_bias_act', int(tA), int(tB), M, N, K, self._p(A), A.ld, self._p(B), B.ld, self._p(C), C.ld, float(beta),
                       None if bias is None else self._p(bias), act, self.st)
 

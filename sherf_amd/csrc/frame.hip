@@ -29,12 +29,14 @@ struct DevState {
     int32_t* host_nv = nullptr;      // pinned: the frame's valid-sample count for SHERF_FRAME_EXACT_GRIDS
     hipEvent_t ev_rep[8];            // SHERF_FRAME_REPORT_COUNT: a ring of (pinned word, event) pairs; host_nv[8 + slot]
     int rep_next = 0;
+    unsigned long long rep_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rep_counter = 0;   // which frame holds a slot: a reader whose frame has been overtaken by eight others is told so
     hipStream_t cap_stream = nullptr;   // frame graphs are CAPTURED on this library-owned non-blocking stream (the caller's may be the legacy default
                                         // stream, which cannot capture) and LAUNCHED on the caller's
 };
 // the REPORT_COUNT slot of the last frame THIS THREAD enqueued (per device): another thread's (renderer's) frames on the same device take
 // their own slots, and a reader never waits with the enqueue lock held
 thread_local int t_rep_last[kMaxDev] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+thread_local unsigned long long t_rep_seq[kMaxDev] = {0};
 DevState g_dev[kMaxDev];
 std::mutex g_mu;          // profiling ring + event creation
 std::mutex g_frame_mu;    // one enqueue at a time: the join events are shared per device
@@ -98,13 +100,23 @@ extern "C" int sherf_frame_count(int32_t* nv_host) {
     DevState& d = g_dev[dev];
     const int slot = t_rep_last[dev];
     hipEvent_t ev;
+    auto overtaken = [&]() -> int {
+        snprintf(g_sherf_err, sizeof(g_sherf_err), "sherf_frame_count: eight later frames on this device have reused the slot of this thread's last frame");
+        return SHERF_EINVAL;
+    };
     {
         std::lock_guard<std::mutex> frame_lock(g_frame_mu);
         SHERF_CHECK_ARG(d.init && slot >= 0);
+        if (d.rep_seq[slot] != t_rep_seq[dev]) return overtaken();
         ev = d.ev_rep[slot];
     }
     SHERF_HIP_CHECK(hipEventSynchronize(ev));          // (no lock held: other threads keep enqueueing; the ring has 8 slots per device)
-    *nv_host = d.host_nv[8 + slot];
+    const int32_t nv = d.host_nv[8 + slot];
+    {
+        std::lock_guard<std::mutex> frame_lock(g_frame_mu);     // the word is this frame's only if nobody took the slot while we waited
+        if (d.rep_seq[slot] != t_rep_seq[dev]) return overtaken();
+    }
+    *nv_host = nv;
     return SHERF_OK;
 }
 
@@ -239,6 +251,7 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
             SHERF_HIP_CHECK(hipMemcpyAsync(d.host_nv + 8 + slot, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, main));
             SHERF_HIP_CHECK(hipEventRecord(d.ev_rep[slot], main));
             t_rep_last[dev] = slot;
+            d.rep_seq[slot] = t_rep_seq[dev] = ++d.rep_counter;
         }
         const bool exact = (f->flags & SHERF_FRAME_EXACT_GRIDS) != 0;
         if (exact) {
@@ -250,10 +263,8 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
         SHERF_CAP_TRACE("encoder queued");
         if (!stream_aux) SHERF_RUN(fold_tables(stream_main));
         // ---- main: a8-a10 warp, a10-a12 gather, a13-a14 MLP ----
-        if (!(g_sherf_debug & (1 << 28))) {          // (debug bit 28, TIMING EXPERIMENTS ONLY: no joins in front of the warp -- results may be wrong)
-            SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
-            if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
-        }
+        SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_smpl, 0));
+        if (stream_aux) SHERF_HIP_CHECK(hipStreamWaitEvent(main, d.ev_fold, 0));
         int64_t cap = tok_cap;
         if (exact) {
             SHERF_HOST_STAMP(xp, "count wait begins");

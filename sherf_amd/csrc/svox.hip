@@ -8,6 +8,8 @@
 // multiplicity so BatchNorm statistics are taken over the reference's ROW set).
 #include "common.h"
 
+#include <mutex>
+
 #include <functional>
 
 namespace {
@@ -788,10 +790,14 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
     }
     SHERF_HOST_STAMP(sherf_experiment(), "encoder first launch");
     // (SHERF_EXPERIMENT bit 5: timing events along the encoder's stream, printed at the next frame's entry -- tools/host_stamps.py --trail)
+    // The trail's state is process-wide and only ever touched with the bit set, under its own lock (it used to be reset by every call of any thread).
     static hipEvent_t xe[32];
     static const char* xw[32];
     static int xn = 0, xmade = 0;
+    static std::mutex trail_mu;
     const bool trail = (sherf_experiment() & 32) != 0;
+    std::unique_lock<std::mutex> trail_lock(trail_mu, std::defer_lock);
+    if (trail) trail_lock.lock();
     if (trail && xn > 0) {
         SHERF_HIP_CHECK(hipEventSynchronize(xe[xn - 1]));
         fprintf(stderr, "[trail]");
@@ -802,7 +808,7 @@ int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const
         }
         fprintf(stderr, "\n");
     }
-    xn = 0;
+    if (trail) xn = 0;
     auto mark = [&](const char* what) -> int {
         if (!trail || xn >= 32) return SHERF_OK;
         if (xn >= xmade) { SHERF_HIP_CHECK(hipEventCreate(&xe[xn])); xmade = xn + 1; }

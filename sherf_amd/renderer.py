@@ -723,12 +723,14 @@ class ImportanceRenderer(nn.Module):
             if pend is not None:
                 pend[0].synchronize()
                 mlp_pack.raise_for_flags(int(pend[1][0]), 0.0, pend[2])
-            host = torch.empty(1, dtype=torch.int32).pin_memory()
+                ev, host = pend[0], pend[1]                        # (one pinned word and one event per renderer: the last pair has just been consumed)
+            else:
+                ev, host = torch.cuda.Event(), torch.empty(1, dtype=torch.int32).pin_memory()
             host.copy_(flag, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record()
             self.__dict__['_pack_flag_pending'] = (ev, host, prec, flag)
             return stream, wbias
+        self.drain_pack_flag()                                     # (a repack outside training: the last training step's word is due now)
         checks = [flag.to(torch.float32)]
         if prec != 0 and not getattr(self, '_in_autograd', False):
             # a-priori bound of the activations (mlp_pack.check_f16_range): product of the layers' row norms.  Skipped while training
