@@ -88,3 +88,22 @@ def test_schedule_switches_render_the_same_bits_on_device(cfg, prec):
         b = G.hip_render(cfg, precision=prec, options=opts)
         for k in ('rgb', 'acc', 'depth'):
             assert torch.equal(ref[k], b[k]), (opts, k)
+
+
+def test_round_6_experiment_kernels_render_the_same_bits_on_device(monkeypatch):
+    """The measured-and-rejected kernels of round 6 that stay in the library behind SHERF_EXPERIMENT bits, on the hardware, each against the product's frame bit
+    for bit: bit 12 the 96-column single-product sparse convolutions split by columns (MFMA kernels: the host build cannot see a predication fault, cf. round 3),
+    bit 13 the compaction with sixteen lanes per ray, bits 14 / 15 the list search one pipeline stage deeper, bit 11 the lane-per-ray compaction, bits 9 / 10
+    the eight-channel gathers."""
+    single = dict(encoder_precision='f16')
+    for cfg in ('tiny_ri', 'cfg1_ri'):
+        monkeypatch.setenv('SHERF_EXPERIMENT', '0')
+        ref = G.hip_render(cfg, precision='f16', options=single)
+        assert ref['last']['encoder_precision'] == 'f16'
+        for word in (4096, 8192, 16384, 16384 + 32768, 8192 + 16384, 2048, 1024, 1024 + 512):
+            monkeypatch.setenv('SHERF_EXPERIMENT', str(word))
+            b = G.hip_render(cfg, precision='f16', options=single)
+            for k in ('rgb', 'acc', 'depth'):
+                assert torch.equal(ref[k], b[k]), (cfg, word, k)
+            assert torch.equal(ref['last']['ws']['sample_out'], b['last']['ws']['sample_out']), (cfg, word)
+    monkeypatch.setenv('SHERF_EXPERIMENT', '0')
