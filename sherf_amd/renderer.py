@@ -1127,7 +1127,7 @@ class ImportanceRenderer(nn.Module):
                 and not (fr.flags & 8) and int(fr.mlp_parts) <= 1:
             self._tune_mlp_form(fr, ws, dev, cfg[0])           # (the frame above is complete and correct; the forms are timed behind it)
         ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
-        self.encoder_3d.finish(pl)
+        self.encoder_3d.finish(pl)                      # (on the encoder's own stream instead: measured, no gain -- DESIGN 9.38)
         if decide is not None:
             decide()
         if not (torch.is_grad_enabled() and getattr(self, 'enable_autograd', False)) and not getattr(self, '_in_autograd', False):

@@ -182,10 +182,11 @@ class SparseConvNet(nn.Module):
                 pl['eval_key'] = key
         return pl, feat, coord
 
-    def finish(self, pl):
+    def finish(self, pl, stream=None):
         """nn.BatchNorm1d side effect in train mode (momentum 0.01, unbiased variance); call after the encoder was enqueued.
         Like nn.BatchNorm1d it depends on `self.training` only -- a train-mode forward under torch.no_grad() (the reference's
-        test loop renders with G in train mode, training_loop.py:193,311-330) advances the running statistics too."""
+        test loop renders with G in train mode, training_loop.py:193,311-330) advances the running statistics too.
+        `stream`: a raw stream handle to launch on (the frame driver's encoder stream; default: the caller's current stream)."""
         if not self.training:
             return
         import ctypes
@@ -209,7 +210,7 @@ class SparseConvNet(nn.Module):
                                                VP(*[A(m['bn'].running_var, f32) for m in ms]), VP(*[A(m['bn'].num_batches_tracked, i64) for m in ms]),
                                                VP(*[A(r, i32) for r in rows]), (ctypes.c_int32 * n)(*[m['cout'] for m in ms]),
                                                (ctypes.c_float * n)(*[float(m['bn'].momentum) for m in ms])))
-        _lib.call('sherf_svox_bn_running_update', *args[1], _lib.stream())
+        _lib.call('sherf_svox_bn_running_update', *args[1], _lib.stream() if stream is None else stream)
 
     def encode(self, sp, fold_mats, ws):
         """Runs the encoder on a SparseConvTensor (one native call, csrc/svox.hip: sherf_svox_encode); returns the three
