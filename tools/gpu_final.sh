@@ -13,7 +13,7 @@ cd /tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-torch-gpu-baseline --no-secondary --no-pmc"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_final -o trace -- $B > $OUT/prof_final.log 2>&1; echo "[rocprof rc=$?]"
 DB=$(find $OUT/prof_final -name "*.db" | head -1)
-python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $DB 0 45 > $OUT/prof_final_stats.txt; python $GRAFT_REPO_ROOT/tools/rocpd_timeline.py $DB > $OUT/prof_final_timeline.txt 2>&1; head -14 $OUT/prof_final_stats.txt | cut -c1-140
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py $DB 0 45 20 > $OUT/prof_final_stats.txt; python $GRAFT_REPO_ROOT/tools/rocpd_timeline.py $DB > $OUT/prof_final_timeline.txt 2>&1; head -14 $OUT/prof_final_stats.txt | cut -c1-140
 find $OUT/prof_final -name "*.db" -size +20M -delete
 cd $GRAFT_REPO_ROOT; timeout 300 python bench_train.py --steps 4 --warmup 2 --no-pmc > $OUT/train_final.json 2> $OUT/train_final.err; echo "[train rc=$?]"; cut -c1-1500 $OUT/train_final.json; cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_final_train -o trace -- python $GRAFT_REPO_ROOT/bench_train.py --steps 3 --warmup 1 --no-pmc > $OUT/train_final.log 2>&1; echo "[train prof rc=$?]"

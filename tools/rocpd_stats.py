@@ -1,5 +1,7 @@
 """Summarise a rocprofv3 rocpd sqlite database (ROCm 7.2 default output): per-kernel totals, sorted by time.
-    python tools/rocpd_stats.py trace_results.db [n_steps] > profiles/<name>.txt"""
+    python tools/rocpd_stats.py trace_results.db [n_steps] [top] [tail_n] > profiles/<name>.txt
+tail_n: a second table over every kernel's LAST tail_n dispatches only -- the timed frames of a `bench.py --steps tail_n` run, without the calibration frames' and the
+form-tuning launches (back to back, i.e. at another operating point of the power cap) that the first table averages in."""
 import sqlite3
 import sys
 
@@ -16,3 +18,15 @@ if steps:
 print(f'{"total_ms":>10} {"calls":>7} {"avg_us":>10} {"min_us":>9} {"max_us":>9} {"pct":>6}  name')
 for n, c, t, a, mn, mx in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 60]:
     print(f'{t/1e6:10.3f} {c:7d} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f} {100*t/tot:6.2f}  {n[:120]}')
+
+tail_n = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if tail_n:
+    print(f'\n# the last {tail_n} dispatches of each kernel (the timed frames)')
+    print(f'{"total_ms":>10} {"calls":>7} {"avg_us":>10} {"min_us":>9} {"max_us":>9}  name')
+    out = []
+    for n, c, *_ in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 60]:
+        d = [r[0] for r in db.execute(f"select end-start from kernels where {name} = ? order by start desc limit ?", (n, tail_n))]
+        if len(d) == tail_n:                                   # (kernels that ran at least once per timed frame)
+            out.append((sum(d), len(d), sum(d) / len(d), min(d), max(d), n))
+    for t, c, a, mn, mx, n in sorted(out, reverse=True):
+        print(f'{t/1e6:10.3f} {c:7d} {a/1e3:10.1f} {mn/1e3:9.1f} {mx/1e3:9.1f}  {n[:120]}')
