@@ -1231,7 +1231,10 @@ extern "C" int sherf_warp_geom(const int32_t* counters, const int32_t* cs_idx, c
     SHERF_CHECK_ARG(counters && cs_idx && cs_vid && cs_xs && ray_d && Rg && T2C && C2S && t_verts && tgrid_hdr &&
                     tcell_start && tcell_pts && geom && cs_tvid);
     SHERF_CHECK_ARG(S >= 2 && capacity > 0);
-    hipLaunchKernelGGL(warp_geom_kernel, dim3(min(8192, cdiv(capacity, 256))), dim3(256), 0, as_stream(stream), counters, cs_idx,
+    // (SHERF_EXPERIMENT bits 16-19, round 6: w persistent workgroups per CU instead of one per 256 samples -- room for the encoder's big-register waves beside it)
+    const int warp_wgs = (sherf_experiment() >> 16) & 15;
+    const int warp_grid = warp_wgs ? min(warp_wgs * n_cus(), cdiv(capacity, 256)) : min(8192, cdiv(capacity, 256));
+    hipLaunchKernelGGL(warp_geom_kernel, dim3(warp_grid), dim3(256), 0, as_stream(stream), counters, cs_idx,
                        cs_vid, reinterpret_cast<const float4*>(cs_xs), ray_d, S, Rg, T2C, C2S, t_verts, tgrid_hdr,
                        tcell_start, reinterpret_cast<const float4*>(tcell_pts), capacity, geom, cs_tvid);
     SHERF_LAUNCH_CHECK();
