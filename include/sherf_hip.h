@@ -444,6 +444,9 @@ typedef struct {
                                  * `capacity` (= R * S for the two-pass sampler); a frame with more valid samples than tok_capacity renders the
                                  * rays it cannot hold as NaN and sets counters[3] bit 1 -- the caller sizes from counters[0] (phase 4) */
     void* pefrag;               /* SHERF_FRAME_PE_FRAGS: ((tok_capacity + 31) / 32 + 8) tiles x 7 KiB for the encodings' fragments, else NULL */
+    int32_t* sticky;            /* optional [3] (round 6): before a frame resets `counters` it folds what the previous frame left there into sticky[0] = max valid-sample
+                                 * count, sticky[1] = OR of the flag words (counters[3]), sticky[2] += 1 -- a caller may then read its frames' flags every few
+                                 * frames (one 32-byte copy + an event cost the caller's stream ~15 us per frame on the MI355X) instead of after every frame */
 } sherf_frame;
 int sherf_render_frame(const sherf_frame* frame, int phase, sherf_vox_level* levels_out_host, sherf_stream_t stream_main,
                        sherf_stream_t stream_side, sherf_stream_t stream_aux);

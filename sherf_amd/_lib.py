@@ -69,6 +69,7 @@ def _frame_fields():
     f.append(('near_list_cap', _i64))
     f.append(('tok_capacity', _i64))
     P('pefrag')
+    P('sticky')
     return f
 
 

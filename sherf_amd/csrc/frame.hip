@@ -16,6 +16,11 @@
 int sherf_svox_encode_impl(const sherf_svox_plan* p, const int32_t* coord, const float* feat, int n, int training,
                            sherf_vox_level* levels_out_host, sherf_stream_t stream, hipEvent_t ev, int ev_layer,
                            sherf_stream_t aux, hipEvent_t* lev_ev, const std::function<int()>* after_levels, int fold_half);   // svox.hip
+int sherf_sample_mask_nn_impl(const float* ray_o, const float* ray_d, const float* near, const float* far, int R, int S, const float* Rg, const float* Th,
+                              const float* grid_hdr, const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask, int64_t capacity,
+                              int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx, int32_t* cs_vid, float* cs_xs, int32_t* dense_vid,
+                              uint64_t* ray_mask, int32_t* scan_ws, const int32_t* near_hdr, const uint16_t* near_list, sherf_stream_t stream,
+                              int32_t* sticky);                                                                                 // sample.hip
 
 namespace {
 
@@ -132,9 +137,9 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
                                      f->cell_scratch, lists ? nullptr : f->near_mask, stream_main));
         if (lists)
             SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, SHERF_V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, f->near_mask, stream_main));
-        SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
+        SHERF_RUN(sherf_sample_mask_nn_impl(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
-                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main));
+                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main, f->sticky));
         return SHERF_OK;
     }
     // token-side capacity: what geom / tokens / extras / sample_out hold
@@ -235,9 +240,9 @@ static int render_frame_enqueue(const sherf_frame* f, int phase, sherf_vox_level
         if (lists)
             SHERF_RUN(sherf_build_near_lists(f->grid_hdr, f->cell_pts, V, 0.05f, f->near_hdr, f->near_list, f->near_list_cap, f->near_mask, stream_main));
         SHERF_CAP_TRACE("sampler");
-        SHERF_RUN(sherf_sample_mask_nn(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
+        SHERF_RUN(sherf_sample_mask_nn_impl(f->ray_o, f->ray_d, f->near, f->far, f->R, f->S, f->Rg, f->Th, f->grid_hdr, f->cell_start,
                                        f->cell_pts, f->near_mask, f->capacity, f->counters, f->ray_base, f->ray_cnt, f->cs_idx,
-                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main));
+                                       f->cs_vid, f->cs_xs, f->dense_vid, f->ray_mask, f->scan_ws, f->near_hdr, f->near_list, stream_main, f->sticky));
         SHERF_CAP_TRACE("sampler queued");
         // SHERF_FRAME_EXACT_GRIDS: the kernels after the compaction are launched for the frame's ACTUAL number of valid samples instead
         // of the buffers' capacity (R*S, of which a body fills a few percent: the MLP's grid is then ~96 % workgroups that allocate

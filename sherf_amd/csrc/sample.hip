@@ -873,7 +873,10 @@ __global__ void __launch_bounds__(256) depth_minmax_kernel(const float* __restri
     }
 }
 
-__global__ void init_counters_kernel(int32_t* counters, int32_t* cand_count) {
+// `sticky` (optional, the frame driver's): what the frame that used these counters before left in them is folded in before they are reset -- the largest valid-sample
+// count, the OR of the flag words, the number of frames folded -- so that a caller may look at its frames' flags every few frames instead of after every one.
+__global__ void init_counters_kernel(int32_t* counters, int32_t* cand_count, int32_t* sticky) {
+    if (sticky) { sticky[0] = max(sticky[0], counters[0]); sticky[1] |= counters[3]; sticky[2] += 1; }
     counters[0] = 0; counters[1] = 0x7FFFFFFF; counters[2] = (int32_t)0x80000000; counters[3] = 0;
     *cand_count = 0;
 }
@@ -1085,6 +1088,11 @@ __global__ void __launch_bounds__(256) warp_geom_kernel(const int32_t* __restric
 
 }  // namespace
 
+int sherf_sample_mask_nn_impl(const float* ray_o, const float* ray_d, const float* near, const float* far, int R, int S, const float* Rg, const float* Th,
+                              const float* grid_hdr, const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask, int64_t capacity,
+                              int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx, int32_t* cs_vid, float* cs_xs, int32_t* dense_vid,
+                              uint64_t* ray_mask, int32_t* scan_ws, const int32_t* near_hdr, const uint16_t* near_list, sherf_stream_t stream, int32_t* sticky);
+
 extern "C" int sherf_build_cells(const float* verts, int n, const float* R, const float* Th, float cell_size,
                                  float* grid_hdr, int32_t* cell_start, float* cell_pts, int32_t* scratch,
                                  uint32_t* near_mask, sherf_stream_t stream) {
@@ -1137,6 +1145,17 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
                                     int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
                                        int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
                                        int32_t* scan_ws, const int32_t* near_hdr, const uint16_t* near_list, sherf_stream_t stream) {
+    return sherf_sample_mask_nn_impl(ray_o, ray_d, near, far, R, S, Rg, Th, grid_hdr, cell_start, cell_pts, near_mask, capacity, counters, ray_base, ray_cnt,
+                                     cs_idx, cs_vid, cs_xs, dense_vid, ray_mask, scan_ws, near_hdr, near_list, stream, nullptr);
+}
+
+// (the frame driver's entry: `sticky`, see init_counters_kernel)
+int sherf_sample_mask_nn_impl(const float* ray_o, const float* ray_d, const float* near, const float* far,
+                              int R, int S, const float* Rg, const float* Th, const float* grid_hdr,
+                              const int32_t* cell_start, const float* cell_pts, const uint32_t* near_mask, int64_t capacity,
+                              int32_t* counters, int32_t* ray_base, int32_t* ray_cnt, int32_t* cs_idx,
+                              int32_t* cs_vid, float* cs_xs, int32_t* dense_vid, uint64_t* ray_mask,
+                              int32_t* scan_ws, const int32_t* near_hdr, const uint16_t* near_list, sherf_stream_t stream, int32_t* sticky) {
     SHERF_CHECK_ARG(ray_o && ray_d && near && far && Rg && Th && grid_hdr && cell_start && cell_pts && near_mask);
     SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && cs_vid && cs_xs && dense_vid && ray_mask && scan_ws);
     SHERF_CHECK_ARG(R > 0 && S >= 2 && S <= 256 && (int64_t)R * S < 2147483647LL && capacity > 0 && (near_hdr == nullptr) == (near_list == nullptr));
@@ -1147,7 +1166,7 @@ extern "C" int sherf_sample_mask_nn(const float* ray_o, const float* ray_d, cons
     int32_t* chunk_sum = scan_ws + R;           // [n_chunks]
     const float4* cp = reinterpret_cast<const float4*>(cell_pts);
     int32_t* cand_count = scan_ws + R + R / 1024 + 1;      // last word of scan_ws ([R] local bases, [<= R/1024 + 1] chunk sums, this)
-    hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters, cand_count);
+    hipLaunchKernelGGL(init_counters_kernel, dim3(1), dim3(1), 0, st, counters, cand_count, sticky);
     hipLaunchKernelGGL(depth_minmax_kernel, dim3(min(256, cdiv(R, 256))), dim3(256), 0, st, near, far, R, S, counters);
     // two passes over a dense candidate list (see cand_mark_kernel) whenever the list -- `capacity` records in cs_xs, which the
     // compaction below only writes afterwards -- provably holds every sample; sherf_set_debug bit 9 forces the one-wave-per-ray kernel

@@ -187,7 +187,8 @@ class _Workspace:
         f32 = dict(dtype=torch.float32, device=dev)
         nch = (S + 63) // 64
         t = dict(
-            counters=torch.zeros(4, **i32), ray_base=torch.zeros(R, **i32), ray_cnt=torch.zeros(R, **i32),
+            # counters: [0..3] the frame's (valid samples, depth min, depth max, flags); [4..6] `sticky` (sherf_frame.sticky: max count / OR of the flags / frames folded in)
+            counters=torch.zeros(8, **i32), ray_base=torch.zeros(R, **i32), ray_cnt=torch.zeros(R, **i32),
             cs_idx=torch.zeros(cap, **i32), cs_vid=torch.zeros(cap, **i32),
             cs_xs=torch.zeros(cap, 4, **f32), dense_vid=torch.zeros(R * S, **i32),
             ray_mask=torch.zeros(R * nch, dtype=torch.int64, device=dev), scan_ws=torch.zeros(R + R // 1024 + 2, **i32),
@@ -256,6 +257,7 @@ class _Workspace:
         fr = _lib.Frame()
         for k in self.STATIC_FIELDS:
             setattr(fr, k, A(self.t[k]))
+        fr.sticky = A(self.t['counters']) + 16
         fr.J_template, fr.J_shapedirs, fr.parents = A(smpl['J_template']), A(smpl['J_shapedirs']), A(smpl['parents_i32'])
         fr.posedirs, fr.shapedirs, fr.weights = A(smpl['posedirs_flat']), A(smpl['shapedirs']), A(smpl['weights'])
         self.desc = (self.t, smpl, fr, dict(near_hdr=A(self.t['near_hdr']), near_list=A(self.t['near_list']), near_cap=self.t['near_list'].numel()))
@@ -358,7 +360,8 @@ class ImportanceRenderer(nn.Module):
         # 'two_tiles' = sherf_nerf_mlp2 (two tiles per wave), 'one' = sherf_nerf_mlp.  Rendering option `mlp_form`, default from SHERF_MLP_FORM
         # 'auto' (round 6, the default): the three forms give the same bits and the kernel runs at the board's power cap, where their ranking turned out to be a
         # property of the BOARD (evidence run 1: two tiles 0.506 ms, pipelined 0.532; other boxes: pipelined ahead by 1-3 %) -- so the first frame of a
-        # (device, precision) times each form on its own tokens once (a few milliseconds, one host wait) and the process keeps the fastest (_tune_mlp_form)
+        # (device, precision) renders its frame again in each form (whole frames: behind the frame's low-power first phase the kernel runs ~15 % faster than back to back, and the
+        # forms rank differently there; 36 frames, once per process and board) and the process keeps the fastest (_tune_mlp_form)
         self.mlp_form = os.environ.get('SHERF_MLP_FORM', 'auto')
         # gather + per-sample network in N contiguous parts of the tile list, part k's network on the side stream beside part k + 1's
         # gather on the main one (sherf_hip.h: sherf_nerf_mlp_part; the same bits -- only the launch schedule differs); 0 / 1 = whole
@@ -516,53 +519,70 @@ class ImportanceRenderer(nn.Module):
             return (True,) + pk
         return (False,) + pk + state_key([b for m in enc.modules() for b in m._buffers.values() if b is not None])
 
-    def _flag_watch(self, ws, dev):
-        """The MLP kernel's non-finite flag (counters[3] bit 0: an fp16 operand beyond 65504) of EVERY frame, without a host wait: the word
-        is copied to pinned memory behind the frame and read a few frames later, once its event has passed.  A trip drops the
-        calibrated choice (the next frame re-calibrates, i.e. renders in the fp32-grade configuration) and is reported once."""
-        st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
+    WATCH_EVERY = 8              # frames between two read-backs of the counters (every frame's flags reach the sticky words on the device meanwhile)
 
-        def note(c):                                       # c = (valid samples, ., ., flags) of a finished frame
-            if c[3] & 1:
-                st['tripped'] += 1
-            if c[3] & 2:                                   # more valid samples than the token-side workspace held: NaN rays in that frame
-                st['overflowed'] = st.get('overflowed', 0) + 1
-            st['nv_seen'] = max(st.get('nv_seen', 0), c[0])
+    def _note_counters(self, st, c, ws=None):
+        """c = a workspace's eight counter words read back: [0..3] the last frame's (count, ., ., flags), [4..6] what the frames before it left (sticky)."""
+        flags, nv = c[3] | (c[5] if len(c) > 5 else 0), max(c[0], c[4] if len(c) > 4 else 0)
+        if flags & 1:
+            st['tripped'] += 1                             # an fp16 operand beyond 65504 in some frame since the last read-back
+        if flags & 2:                                      # more valid samples than the token-side workspace held: NaN rays in that frame
+            st['overflowed'] = st.get('overflowed', 0) + 1
+        st['nv_seen'] = max(st.get('nv_seen', 0), nv)
+        if ws is not None and len(c) > 5 and (c[5] or c[4]):
+            ws['counters'][4:7].zero_()                    # (sticky words are the host's to clear; rare for the flags, cheap for the count: behind a read-back only)
+
+    def _flag_watch(self, ws, dev):
+        """The MLP kernel's non-finite flag (counters[3] bit 0: an fp16 operand beyond 65504) and the token-overflow flag of EVERY frame, without a host wait and --
+        round 6 -- without a read-back behind every frame (the 32-byte copy + its event cost the caller's stream ~15 us per frame, tools/tail_probe.py): the frame
+        driver folds each frame's counters into sticky words on the device (sherf_frame.sticky) when the next frame resets them, and the words are copied to pinned
+        memory every WATCH_EVERY frames and read once their event has passed.  A trip drops the calibrated choice (the next frame re-calibrates, i.e. renders in the
+        fp32-grade configuration) and is reported once."""
+        st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
+        seen = st.setdefault('watched', {})                # (poll_flags(wait=True) reads the newest frames' words of every workspace directly)
+        seen[ws['counters'].data_ptr()] = ws['counters']
+        while len(seen) > 16:
+            seen.pop(next(iter(seen)))
         if dev.type != 'cuda' or getattr(ws['counters'], 'device', dev).type != 'cuda':      # host build of the tests: read directly
-            note(ws['counters'].tolist())
+            self._note_counters(st, ws['counters'].tolist(), ws)
             return st
         ring = st['ring']
+        for other in ring:                                 # anything already finished is read now
+            if other['busy'] and other['ev'].query():
+                other['busy'] = False
+                self._note_counters(st, other['host'].tolist())
+        st['since'] = st.get('since', self.WATCH_EVERY - 1) + 1          # (the first frame of a renderer is read back)
+        if st['since'] < self.WATCH_EVERY:
+            return st
+        st['since'] = 0
         if len(ring) < 4:
-            ring.append(dict(host=torch.zeros(4, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
+            ring.append(dict(host=torch.zeros(8, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
             st['next'] = len(ring) - 1
         slot = ring[st.get('next', 0) % len(ring)]
         st['next'] = (st.get('next', 0) + 1) % 4
         if slot['busy']:
-            slot['ev'].synchronize()                       # (four frames old: long done)
-            note(slot['host'].tolist())
+            slot['ev'].synchronize()                       # (4 x WATCH_EVERY frames old: long done)
+            self._note_counters(st, slot['host'].tolist())
         slot['host'].copy_(ws['counters'], non_blocking=True)
+        ws['counters'][4:7].zero_()                        # the sticky words start over behind the copy (same stream: ordered)
         slot['ev'].record(torch.cuda.current_stream(dev))
         slot['busy'] = True
-        for other in ring:                                 # anything already finished is read now
-            if other is not slot and other['busy'] and other['ev'].query():
-                other['busy'] = False
-                note(other['host'].tolist())
         return st
 
     def poll_flags(self, wait=False):
-        """The watch's state (`tripped`, `overflowed`, `nv_seen`, ...) after reading every finished frame's counters; wait=True waits for
-        the frames still in flight first."""
+        """The watch's state (`tripped`, `overflowed`, `nv_seen`, ...) after reading every finished read-back; wait=True also waits for the frames still in flight and
+        reads the newest frames' counters directly (one host wait)."""
         st = self.__dict__.setdefault('_flags', dict(ring=[], tripped=0))
         for slot in st['ring']:
             if slot['busy'] and (wait or slot['ev'].query()):
                 slot['ev'].synchronize()
                 slot['busy'] = False
-                c = slot['host'].tolist()
-                if c[3] & 1:
-                    st['tripped'] += 1
-                if c[3] & 2:
-                    st['overflowed'] = st.get('overflowed', 0) + 1
-                st['nv_seen'] = max(st.get('nv_seen', 0), c[0])
+                self._note_counters(st, slot['host'].tolist())
+        if wait:
+            for w in list((st.get('watched') or {}).values()):
+                if w.device.type == 'cuda':
+                    torch.cuda.synchronize(w.device)       # (frames of other caller streams included)
+                self._note_counters(st, w.tolist(), dict(counters=w))
         return st
 
     TOKEN_HEADROOM = 1.5         # token-side capacity = this x the largest count seen, re-sized when a frame passes TOKEN_GROW_AT of it
@@ -589,6 +609,7 @@ class ImportanceRenderer(nn.Module):
             wsp.nv_sized_for = nv
             self.poll_flags(wait=True)                     # (the probe waited for the device anyway: counts still in the ring belong to the past)
             st['nv_seen'] = 0
+            wsp.t['counters'][4:7].zero_()                 # (and so does what earlier frames left in the sticky words)
             return self._round_tokens(self.TOKEN_HEADROOM * nv, cap)
         nv = st.get('nv_seen', 0)
         if nv > self.TOKEN_GROW_AT * wsp.tok_cap and wsp.tok_cap < cap:
@@ -831,31 +852,41 @@ class ImportanceRenderer(nn.Module):
     _FORM_CHOICE = {}                   # (device, precision) -> the fastest of the bit-identical launch forms on THIS board (process-wide)
     _FORM_ENTRY = dict(pipelined='sherf_nerf_mlp3', two_tiles='sherf_nerf_mlp2', one='sherf_nerf_mlp')
 
-    def _tune_mlp_form(self, fr, ws, dev, prec_name):
-        """mlp_form='auto': time the launch forms of the single-product network on the frame just rendered (its own tokens, counters and weight stream; every form
-        rewrites the same sample_out with the same bits) -- HIP events on the caller's stream, two warm-up + six timed launches each, one host wait -- and keep
-        the fastest for this (device, precision).  Once per process and board."""
+    def _tune_mlp_form(self, fr, ws, dev, prec_name, levels, streams):
+        """mlp_form='auto': time WHOLE FRAMES in each of the three bit-identical launch forms of the single-product network -- the frame just rendered, again (same
+        descriptor but the form bits; every form rewrites the same outputs with the same bits; the encoder's running statistics are not advanced: that is finish()) --
+        and keep the fastest for this (device, precision).  Whole frames, not the kernel alone: under the board's power cap the kernel runs ~15 % faster behind the
+        frame's low-power first phase than back to back, and the forms' ranking differs between the two settings (profiles/r06_y_*: in the frame pipelined beats the
+        one-tile kernel, back to back it loses to it).  Interleaved rounds, HIP events on the caller's stream: 36 frames, once per process and board."""
         key = (str(dev), prec_name)
         if key in self._FORM_CHOICE or dev.type != 'cuda' or prec_name not in ('f16', 'bf16'):
             return
         st = torch.cuda.current_stream(dev)
-        stream = _ct.c_void_p(st.cuda_stream)
-        cap = int(fr.tok_capacity or fr.capacity)
-        times = {}
-        for form, entry in self._FORM_ENTRY.items():
-            launch = lambda: _lib.call(entry, fr.counters, fr.tokens, fr.extras, fr.wstream, fr.wbias, int(fr.mlp_prec), cap, fr.sample_out, stream)
-            for _ in range(2):
-                launch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(st)
-            for _ in range(6):
-                launch()
-            e1.record(st)
-            e1.synchronize()
-            times[form] = e0.elapsed_time(e1) / 6
-        best = min(times, key=times.get)
+        keep = int(fr.flags)
+        base = keep & ~(32 | 64 | 128 | 16)            # (the form bits, the encodings-in-gather form tied to one of them, the per-frame count report)
+        bits = dict(pipelined=64, two_tiles=32, one=0)
+        times = {f: [] for f in bits}
+        frame = lambda: _lib.call('sherf_render_frame', _ct.byref(fr), 3, levels, *streams)
+        try:
+            for rnd in range(3):                       # (round 0 warms up)
+                for form, b in bits.items():
+                    fr.flags = base | b
+                    frame()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    for _ in range(3):
+                        frame()
+                    e1.record(st)
+                    e1.synchronize()
+                    if rnd:
+                        times[form].append(e0.elapsed_time(e1) / 3)
+        finally:
+            fr.flags = keep
+        ms = {f: min(v) for f, v in times.items()}
+        best = min(ms, key=ms.get)
         self._FORM_CHOICE[key] = best
-        self.__dict__['form_report'] = dict(choice=best, ms={k: round(v, 4) for k, v in times.items()}, device=str(dev), precision=prec_name)
+        self.__dict__['form_report'] = dict(choice=best, ms={k: round(v, 4) for k, v in ms.items()}, basis='ms per whole frame, best of 2 interleaved rounds of 3 frames',
+                                            device=str(dev), precision=prec_name)
 
     def _calibrate(self, fr, decoder, dev, ws, levels, streams, exact):
         """mlp_precision='auto': before the frame proper (the reference configuration) the SAME frame is rendered in every candidate
@@ -1124,8 +1155,8 @@ class ImportanceRenderer(nn.Module):
         if static_out:
             out = out.clone()
         if self.__dict__.get('_form_auto') and not calibrate and noise == 0 and (str(dev), cfg[0]) not in self._FORM_CHOICE and cfg[0] != 'f16x3' \
-                and not (fr.flags & 8) and int(fr.mlp_parts) <= 1:
-            self._tune_mlp_form(fr, ws, dev, cfg[0])           # (the frame above is complete and correct; the forms are timed behind it)
+                and not (fr.flags & 8) and int(fr.mlp_parts) <= 1 and rng is None:
+            self._tune_mlp_form(fr, ws, dev, cfg[0], levels, (s_main, s_side, s_aux))    # (the frame above is complete and correct; the forms are timed behind it)
         ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
         self.encoder_3d.finish(pl)                      # (on the encoder's own stream instead: measured, no gain -- DESIGN 9.38)
         if decide is not None:

@@ -111,6 +111,8 @@ def main():
     gs = (ct.c_int64 * 4)()
     lib.sherf_frame_graph_stats(gs, 4)
     print('[graphs] captured %d, replayed frames %d, enqueued frames %d, failed captures %d' % tuple(int(v) for v in gs))
+    if w['rend'].__dict__.get('form_report'):
+        print('[mlp_form auto]', w['rend'].__dict__['form_report'])            # (the tuner's back-to-back launches, beside the in-frame `mlp_ms` of the timelines)
     for n in names:
         print(f'[arm] {n:12s} ms/frame {" ".join(f"{t:.4f}" for t in times[n])}   min {min(times[n]):.4f}')
 
