@@ -551,10 +551,13 @@ class ImportanceRenderer(nn.Module):
             if other['busy'] and other['ev'].query():
                 other['busy'] = False
                 self._note_counters(st, other['host'].tolist())
-        st['since'] = st.get('since', self.WATCH_EVERY - 1) + 1          # (the first frame of a renderer is read back)
-        if st['since'] < self.WATCH_EVERY:
+        since, key = st.setdefault('since', {}), ws['counters'].data_ptr()      # per workspace: frames issued round-robin on several streams each keep their own count
+        since[key] = since.get(key, self.WATCH_EVERY - 1) + 1              # (the first frame on a workspace is read back)
+        if since[key] < self.WATCH_EVERY:
             return st
-        st['since'] = 0
+        since[key] = 0
+        while len(since) > 16:
+            since.pop(next(iter(since)))
         if len(ring) < 4:
             ring.append(dict(host=torch.zeros(8, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
             st['next'] = len(ring) - 1
