@@ -9,7 +9,7 @@ extern char g_sherf_err[256];
 extern int g_sherf_debug;   // ablation switches for profiling (sherf_set_debug); 0 in production
 // Scheduling experiments of tools/frame_ab.py --exps (environment SHERF_EXPERIMENT, read per frame; unset in production): launch ORDER / stream
 // placement only, never arithmetic.  bit 0: level-0 rows scattered before the level builds are queued; bit 1: level builds on the encoder's own
-// stream; bit 2: cross-stream events created with hipEventReleaseToDevice (read once, at the first frame); bit 3: encoder queued before the ray side; bit 6: the backward's general tall GEMM kernel instead of the streaming one; bit 7: round 2's weight-gradient GEMM kernel; bit 8: round 3's tap scatter (binned by the coarsest cell); bit 9: the gather walks its voxel corners one at a time as in round 5 instead of requesting the next corner's rows ahead (gather_tokens_h8_kernel<.., PF>; same bits); bit 10: the eight-channel-per-lane gather instead of the sixteen-channel one (same bits); bit 11: the compaction with one lane per ray and whole waves for the hit rays only (same records; measured slower); bit 12: the two 96-column single-product sparse convolutions as three 32-column workgroups per row tile (sconv3_kernel: CS; same bits; measured slower); bit 13: the compaction with sixteen lanes per ray, four rays per wave (same records; no gain); bit 14: the list search one pipeline stage deeper (cand_search_lists2_kernel; same results; the frame measured slower), bit 15 with it: that kernel held to 80 registers.  Bits 16-19: the warp kernel as that many persistent workgroups per CU (0: one workgroup per 256 samples; measured slower).
+// stream; bit 2: cross-stream events created with hipEventReleaseToDevice (read once, at the first frame); bit 3: encoder queued before the ray side; bit 6: the backward's general tall GEMM kernel instead of the streaming one; bit 7: round 2's weight-gradient GEMM kernel; bit 8: round 3's tap scatter (binned by the coarsest cell); bit 9: the gather walks its voxel corners one at a time as in round 5 instead of requesting the next corner's rows ahead (gather_tokens_h8_kernel<.., PF>; same bits); bit 10: the eight-channel-per-lane gather instead of the sixteen-channel one (same bits); bit 11: the compaction with one lane per ray and whole waves for the hit rays only (same records; measured slower); bit 12: the two 96-column single-product sparse convolutions as three 32-column workgroups per row tile (sconv3_kernel: CS; same bits; measured slower); bit 13: the compaction with sixteen lanes per ray, four rays per wave (same records; no gain); bit 14: the list search one pipeline stage deeper (cand_search_lists2_kernel; same results; the frame measured slower), bit 15 with it: that kernel held to 80 registers.  Bits 16-19: the warp kernel as that many persistent workgroups per CU (0: one workgroup per 256 samples; measured slower).  Bit 20: the compositing walks a ray's samples one per trip as in rounds 1-5 instead of in batches of four (same arithmetic in the same order).
 #include <stdlib.h>
 // bit 4: host clock (us, CLOCK_MONOTONIC) of the frame driver's enqueue points on stderr
 #include <time.h>

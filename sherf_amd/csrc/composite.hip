@@ -16,6 +16,7 @@ __device__ __forceinline__ float depth_at(float near, float range, int k, int S)
     return __fadd_rn(near, __fmul_rn(step, range));
 }
 
+template <int BATCH>
 __global__ void __launch_bounds__(256) composite_compact_kernel(const int32_t* __restrict__ counters,
                                                                 const int32_t* __restrict__ ray_base,
                                                                 const int32_t* __restrict__ ray_cnt,
@@ -42,15 +43,29 @@ __global__ void __launch_bounds__(256) composite_compact_kernel(const int32_t* _
     const float nr = near[r], range = __fsub_rn(far[r], nr);
     const int base = ray_base[r], cnt = ray_cnt[r];
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, wsum = 0.f, dsum = 0.f;
-    for (int i = 0; i < cnt; ++i) {
-        const int k = cs_idx[base + i] - r * S;
-        const float4 o = sample_out[base + i];
-        const float t = depth_at(nr, range, k, S);
-        const float delta = (k == S - 1 ? 1e10f : depth_at(nr, range, k + 1, S) - t) * dn;
-        const float alpha = 1.f - expf(-(fmaxf(o.w, 0.f) * delta));
-        const float w = alpha * T;
-        T = T * (1.f - alpha + 1e-10f);
-        cr += w * o.x; cg += w * o.y; cb += w * o.z; wsum += w; dsum += w * t;
+    // A ray's samples in batches of BATCH = 4 (1: round 5's loop, SHERF_EXPERIMENT bit 20): the eight loads of a batch are requested together, then its samples enter the running products in order (the same arithmetic in the
+    // same order).  One sample per trip made a wave wait for memory once per sample of its longest ray -- up to 64 dependent round trips at the tail of every frame.
+    for (int i0 = 0; i0 < cnt; i0 += BATCH) {
+        int kk[BATCH];
+        float4 oo[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int i = min(i0 + j, cnt - 1);
+            kk[j] = cs_idx[base + i] - r * S;
+            oo[j] = sample_out[base + i];
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (i0 + j >= cnt) break;
+            const int k = kk[j];
+            const float4 o = oo[j];
+            const float t = depth_at(nr, range, k, S);
+            const float delta = (k == S - 1 ? 1e10f : depth_at(nr, range, k + 1, S) - t) * dn;
+            const float alpha = 1.f - expf(-(fmaxf(o.w, 0.f) * delta));
+            const float w = alpha * T;
+            T = T * (1.f - alpha + 1e-10f);
+            cr += w * o.x; cg += w * o.y; cb += w * o.z; wsum += w; dsum += w * t;
+        }
     }
     float dep = dsum / wsum;                                   // 0/0 -> NaN for empty rays
     if (dep != dep) dep = __int_as_float(0x7f800000);          // nan_to_num(.., inf)
@@ -150,7 +165,12 @@ extern "C" int sherf_composite_compact_cap(int32_t* counters, const int32_t* ray
                                            float* rgb, float* depth, float* acc, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && sample_out && ray_d && near && far && rgb && depth && acc);
     SHERF_CHECK_ARG(R > 0 && S >= 2 && tok_cap > 0);
-    hipLaunchKernelGGL(composite_compact_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
+    if (sherf_experiment() & (1 << 20))
+        hipLaunchKernelGGL(composite_compact_kernel<1>, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
+                           ray_cnt, cs_idx, reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back, tok_cap,
+                           counters + 3, rgb, depth, acc);
+    else
+    hipLaunchKernelGGL(composite_compact_kernel<4>, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
                        ray_cnt, cs_idx, reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back, tok_cap,
                        counters + 3, rgb, depth, acc);
     SHERF_LAUNCH_CHECK();
@@ -162,7 +182,7 @@ extern "C" int sherf_composite_compact(const int32_t* counters, const int32_t* r
                                        float* depth, float* acc, sherf_stream_t stream) {
     SHERF_CHECK_ARG(counters && ray_base && ray_cnt && cs_idx && sample_out && ray_d && near && far && rgb && depth && acc);
     SHERF_CHECK_ARG(R > 0 && S >= 2);
-    hipLaunchKernelGGL(composite_compact_kernel, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
+    hipLaunchKernelGGL(composite_compact_kernel<4>, dim3(cdiv(R, 256)), dim3(256), 0, as_stream(stream), counters, ray_base,
                        ray_cnt, cs_idx, reinterpret_cast<const float4*>(sample_out), ray_d, near, far, R, S, white_back,
                        (int64_t)R * S, static_cast<int32_t*>(nullptr), rgb, depth, acc);
     SHERF_LAUNCH_CHECK();

@@ -519,7 +519,7 @@ class ImportanceRenderer(nn.Module):
             return (True,) + pk
         return (False,) + pk + state_key([b for m in enc.modules() for b in m._buffers.values() if b is not None])
 
-    WATCH_EVERY = 8              # frames between two read-backs of the counters (every frame's flags reach the sticky words on the device meanwhile)
+    WATCH_EVERY = int(os.environ.get('SHERF_WATCH_EVERY', '8'))     # frames between two read-backs of the counters (every frame's flags reach the sticky words on the device meanwhile)
 
     def _note_counters(self, st, c, ws=None):
         """c = a workspace's eight counter words read back: [0..3] the last frame's (count, ., ., flags), [4..6] what the frames before it left (sticky)."""
@@ -552,8 +552,12 @@ class ImportanceRenderer(nn.Module):
                 other['busy'] = False
                 self._note_counters(st, other['host'].tolist())
         since, key = st.setdefault('since', {}), ws['counters'].data_ptr()      # per workspace: frames issued round-robin on several streams each keep their own count
-        since[key] = since.get(key, self.WATCH_EVERY - 1) + 1              # (the first frame on a workspace is read back)
-        if since[key] < self.WATCH_EVERY:
+        # Frames issued round-robin on SEVERAL caller streams are read back every frame, as in rounds 4-5: waiting for the ring's oldest slot is what keeps the host at most four
+        # frames ahead there, and without that throttle the streams' queues run deep and the frames overlap worse (four streams: 1.37 -> 1.54-1.64 ms per frame,
+        # profiles/r06_ad_*); the read-back's own cost hides behind the other streams' frames in that mode.
+        every = 1 if isinstance(self._ws, dict) and len(self._ws) > 1 else self.WATCH_EVERY
+        since[key] = since.get(key, every - 1) + 1                          # (the first frame on a workspace is read back)
+        if since[key] < every:
             return st
         since[key] = 0
         while len(since) > 16:

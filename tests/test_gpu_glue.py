@@ -100,7 +100,7 @@ def test_round_6_experiment_kernels_render_the_same_bits_on_device(monkeypatch):
         monkeypatch.setenv('SHERF_EXPERIMENT', '0')
         ref = G.hip_render(cfg, precision='f16', options=single)
         assert ref['last']['encoder_precision'] == 'f16'
-        for word in (4096, 8192, 16384, 16384 + 32768, 8192 + 16384, 2048, 1024, 1024 + 512):
+        for word in (4096, 8192, 16384, 16384 + 32768, 8192 + 16384, 2048, 1024, 1024 + 512, 1 << 20, 4 << 16):     # (bit 20: the one-sample-per-trip compositing loop; bits 16-19: warp residency)
             monkeypatch.setenv('SHERF_EXPERIMENT', str(word))
             b = G.hip_render(cfg, precision='f16', options=single)
             for k in ('rgb', 'acc', 'depth'):

@@ -129,7 +129,7 @@ def test_frame_launch_switches_render_the_same_bits(cpu_product):
     # builds are queued, level builds on the encoder's own stream, encoder queued before the ray side; bit 4 = host-clock stamps on stderr): order only
     import os
     try:
-        for word in (1, 2, 3, 8, 9, 16, 24576, 49152):     # (24576 / 49152, round 6: sixteen-lane compaction + the deeper list search)
+        for word in (1, 2, 3, 8, 9, 16, 24576, 49152, 1 << 20):     # (24576 / 49152, round 6: sixteen-lane compaction + the deeper list search)
             os.environ['SHERF_EXPERIMENT'] = str(word)
             b = G.hip_render('tiny_nv')
             assert torch.equal(b['rgb'], h['rgb']) and torch.equal(b['acc'], h['acc']) and torch.equal(b['depth'], h['depth']), word
