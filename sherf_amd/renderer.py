@@ -519,6 +519,7 @@ class ImportanceRenderer(nn.Module):
             return (True,) + pk
         return (False,) + pk + state_key([b for m in enc.modules() for b in m._buffers.values() if b is not None])
 
+    WATCH_RING = int(os.environ.get('SHERF_WATCH_RING', '4'))      # pinned slots of the read-back ring = frames the host may run ahead when every frame is read back
     WATCH_EVERY = int(os.environ.get('SHERF_WATCH_EVERY', '8'))     # frames between two read-backs of the counters (every frame's flags reach the sticky words on the device meanwhile)
 
     def _note_counters(self, st, c, ws=None):
@@ -562,11 +563,11 @@ class ImportanceRenderer(nn.Module):
         since[key] = 0
         while len(since) > 16:
             since.pop(next(iter(since)))
-        if len(ring) < 4:
+        if len(ring) < self.WATCH_RING:
             ring.append(dict(host=torch.zeros(8, dtype=torch.int32).pin_memory(), ev=torch.cuda.Event(), busy=False))
             st['next'] = len(ring) - 1
         slot = ring[st.get('next', 0) % len(ring)]
-        st['next'] = (st.get('next', 0) + 1) % 4
+        st['next'] = (st.get('next', 0) + 1) % self.WATCH_RING
         if slot['busy']:
             slot['ev'].synchronize()                       # (4 x WATCH_EVERY frames old: long done)
             self._note_counters(st, slot['host'].tolist())
