@@ -835,7 +835,7 @@ class ImportanceRenderer(nn.Module):
             raise ValueError(f"mlp_form must be 'auto', 'pipelined', 'two_tiles' or 'one', not {form!r}")
         self.__dict__['_form_auto'] = form == 'auto'
         if form == 'auto':
-            form = self._FORM_CHOICE.get((str(dev), cfg[0]), 'pipelined')
+            form = self._FORM_CHOICE.get(self._form_key(dev, cfg[0], fr), 'pipelined')
         if cfg[0] != 'f16x3' and not split:
             fr.flags |= {'pipelined': 64, 'two_tiles': 32, 'one': 0}[form]   # SHERF_FRAME_MLP_PIPELINED / SHERF_FRAME_MLP_TWO_TILES
         fr.zfrag = None
@@ -857,7 +857,15 @@ class ImportanceRenderer(nn.Module):
             fr.flags |= 128
         return wc
 
-    _FORM_CHOICE = {}                   # (device, precision) -> the fastest of the bit-identical launch forms on THIS board (process-wide)
+    _FORM_CHOICE = {}                   # (device, precision, size class) -> the fastest of the bit-identical launch forms on THIS board (process-wide)
+
+    @staticmethod
+    def _form_key(dev, prec_name, fr):
+        """The tuner's key: the board, the precision and the frame's size class (token capacity in factors of four) -- a process whose first frame is a thumbnail does
+        not decide for its full-size frames."""
+        cap = int(fr.tok_capacity or fr.capacity or 1)
+        return (str(dev), prec_name, max(cap, 1).bit_length() // 2)
+
     _FORM_ENTRY = dict(pipelined='sherf_nerf_mlp3', two_tiles='sherf_nerf_mlp2', one='sherf_nerf_mlp')
 
     def _tune_mlp_form(self, fr, ws, dev, prec_name, levels, streams):
@@ -866,7 +874,7 @@ class ImportanceRenderer(nn.Module):
         and keep the fastest for this (device, precision).  Whole frames, not the kernel alone: under the board's power cap the kernel runs ~15 % faster behind the
         frame's low-power first phase than back to back, and the forms' ranking differs between the two settings (profiles/r06_y_*: in the frame pipelined beats the
         one-tile kernel, back to back it loses to it).  Interleaved rounds, HIP events on the caller's stream: 36 frames, once per process and board."""
-        key = (str(dev), prec_name)
+        key = self._form_key(dev, prec_name, fr)
         if key in self._FORM_CHOICE or dev.type != 'cuda' or prec_name not in ('f16', 'bf16'):
             return
         st = torch.cuda.current_stream(dev)
@@ -1162,7 +1170,7 @@ class ImportanceRenderer(nn.Module):
                 enqueue()
         if static_out:
             out = out.clone()
-        if self.__dict__.get('_form_auto') and not calibrate and noise == 0 and (str(dev), cfg[0]) not in self._FORM_CHOICE and cfg[0] != 'f16x3' \
+        if self.__dict__.get('_form_auto') and not calibrate and noise == 0 and self._form_key(dev, cfg[0], fr) not in self._FORM_CHOICE and cfg[0] != 'f16x3' \
                 and not (fr.flags & 8) and int(fr.mlp_parts) <= 1 and rng is None:
             self._tune_mlp_form(fr, ws, dev, cfg[0], levels, (s_main, s_side, s_aux))    # (the frame above is complete and correct; the forms are timed behind it)
         ws['rgb'], ws['depth'], ws['acc'] = out[:3 * R].view(R, 3), out[3 * R:4 * R], out[4 * R:]
