@@ -229,9 +229,12 @@ __global__ void __launch_bounds__(256) near_mask_kernel(const float* __restrict_
 template <bool FILL>
 __global__ void __launch_bounds__(256) near_lists_pairs_kernel(const float4* __restrict__ pts, int n, const float* __restrict__ hdr,
                                                                float radius, int2* __restrict__ near_hdr,
-                                                               uint16_t* __restrict__ near_list, int64_t list_cap) {
+                                                               uint16_t* __restrict__ near_list, int64_t list_cap, int32_t* __restrict__ cursor) {
     const CellGrid g = load_grid(hdr);
     const int sub = g.sub, snx = g.nx * sub, sny = g.ny * sub, snz = g.nz * sub;
+    // (the counting pass also clears the allocation cursor behind the last header -- two words the caller's memset leaves out so that it is whole 16-byte
+    //  blocks: one fill kernel instead of two at the head of the ray side's chain; the cursor is first read by near_lists_alloc_kernel, a launch later)
+    if (!FILL && cursor && blockIdx.x == 0 && threadIdx.x == 0) { cursor[0] = 0; cursor[1] = 0; }
     // one vertex per 8 lanes x ... : a vertex's (2 sub + 1)^3 <= 125 sub-cells are spread over the 32 threads of its group
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 5, t = threadIdx.x & 31;
     if (i >= n) return;
@@ -1131,11 +1134,11 @@ extern "C" int sherf_build_near_lists(const float* grid_hdr, const float* cell_p
     hipStream_t st = as_stream(stream);
     int2* nh = reinterpret_cast<int2*>(near_hdr);
     int32_t* cursor = near_hdr + 2 * SHERF_NEAR_SUBCELLS;                 // the word behind the last header
-    (void)hipMemsetAsync(near_hdr, 0, (2 * (size_t)SHERF_NEAR_SUBCELLS + 2) * sizeof(int32_t), st);
+    (void)hipMemsetAsync(near_hdr, 0, 2 * (size_t)SHERF_NEAR_SUBCELLS * sizeof(int32_t), st);       // (the headers; the two cursor words: near_lists_pairs_kernel<false>)
     const float4* pts = reinterpret_cast<const float4*>(cell_pts);
-    hipLaunchKernelGGL(near_lists_pairs_kernel<false>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap);
+    hipLaunchKernelGGL(near_lists_pairs_kernel<false>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap, cursor);
     hipLaunchKernelGGL(near_lists_alloc_kernel, dim3(SHERF_NEAR_SUBCELLS / 256), dim3(256), 0, st, grid_hdr, nh, cursor, list_cap, near_mask);
-    hipLaunchKernelGGL(near_lists_pairs_kernel<true>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap);
+    hipLaunchKernelGGL(near_lists_pairs_kernel<true>, dim3(cdiv(n * 32, 256)), dim3(256), 0, st, pts, n, grid_hdr, radius, nh, near_list, list_cap, static_cast<int32_t*>(nullptr));
     SHERF_LAUNCH_CHECK();
 }
 

@@ -283,6 +283,7 @@ class _Workspace:
         # one contiguous region for everything that must be zero at the start of a frame -> a single memset
         n_acc = 16 * 8 * 2 * 96 * 2                                         # BatchNorm accumulators: 16 layers x [8][2][96] int64
         zsize = sum(d[1] for d in dims) + N + N * 32 * 2 + 2 + n_acc + 2
+        zsize = (zsize + 3) // 4 * 4                                        # (whole 16-byte blocks: the runtime clears them with ONE fill kernel, a ragged tail costs a second one)
         zero_region = torch.zeros(zsize, **i32)
         L, off = [], 0
         for li, (nvox, nwords, cap) in enumerate(dims):
